@@ -1,0 +1,138 @@
+/*
+ * ifa_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's (inferflow/inferflow) quantized
+ * transformer decode path.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product path
+ * (inferflow_amd/) never links or calls it.
+ *
+ * Parity pin: the block codecs are checked bit-for-bit against the reference's
+ * own header (src/common/quantization.h) compiled on the host into
+ * oracle/_ref/libifa_ref_quant.so (see oracle/Makefile, tests/golden/).
+ * The reference ships no golden vectors or tests of its own.
+ *
+ * Every function cites the reference file:line it restates (paths relative
+ * to the reference checkout).
+ */
+#ifndef IFA_ORACLE_H_
+#define IFA_ORACLE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Element types: numeric values follow the reference's ElementType enum
+ * (src/tensor/tensor_common.h:15-42) so that ids can cross the boundary. */
+enum {
+    ORC_F32 = 0, ORC_F16 = 1,
+    ORC_Q8_B32T1 = 7, ORC_Q8_B32T2 = 8, ORC_Q6_B64T1 = 9, ORC_Q5_B64T1 = 10,
+    ORC_Q5_B32T1 = 11, ORC_Q4_B16 = 12, ORC_Q4_B32T1A = 13, ORC_Q4_B32T1B = 14,
+    ORC_Q4_B64T1 = 17, ORC_Q3H_B64T1 = 18, ORC_Q3_B32T1A = 19, ORC_Q3_B32T1B = 20,
+    ORC_Q2_B32T1A = 21, ORC_Q2_B32T1B = 22
+};
+
+typedef uint16_t orc_f16;
+
+float    orc_h2f(orc_f16 h);
+orc_f16  orc_f2h(float f);
+void     orc_h2f_n(const orc_f16 *src, float *dst, size_t n);
+void     orc_f2h_n(const float *src, orc_f16 *dst, size_t n);
+
+int      orc_block_capacity(int dtype);  /* elements per block, 1 for F16/F32 */
+int      orc_block_bytes(int dtype);     /* bytes per block, 2/4 for F16/F32  */
+size_t   orc_row_bytes(int dtype, size_t cols);
+
+/* Weight / tensor quantizers (load time).  src is F16 [rows][cols]. */
+int orc_quantize_rows(int dtype, const orc_f16 *src, size_t rows, size_t cols, uint8_t *dst);
+/* Same, F32 source (the reference header is templated on SourceType). */
+int orc_quantize_rows_f32(int dtype, const float *src, size_t rows, size_t cols, uint8_t *dst);
+/* Block dequant to F16 (what Tensor_Dequantize*_Kernel writes) and to F32. */
+int orc_dequantize_rows(int dtype, const uint8_t *src, size_t rows, size_t cols, orc_f16 *dst);
+int orc_dequantize_rows_f32(int dtype, const uint8_t *src, size_t rows, size_t cols, float *dst);
+/* Integer codes in element order (what GetInt4 packs into dp4a lanes). */
+int orc_unpack_codes(int dtype, const uint8_t *src, size_t rows, size_t cols, int32_t *codes);
+
+/* Device activation quantizer (Tensor_QuantizeQ8_B32T2_Alg2_Kernel). */
+int orc_quantize_act_q8(const orc_f16 *src, size_t rows, size_t cols, uint8_t *dst);
+/* Host-style Q8_B32T2 row quantizer (Quantization::QuantizeRow_Q8_B32T2). */
+int orc_quantize_q8_b32t2_host(const orc_f16 *src, size_t rows, size_t cols, uint8_t *dst);
+
+/* GEMV y[rows] = W[rows][cols] . x */
+int orc_gemv_ax8(int dtype_w, const uint8_t *W, size_t rows, size_t cols,
+                 const uint8_t *xq8, orc_f16 *y, double *y_f64 /* nullable */);
+int orc_gemv_f16x(int dtype_w, const uint8_t *W, size_t rows, size_t cols,
+                  const orc_f16 *x, const orc_f16 *bias, orc_f16 *y, double *y_f64);
+
+/* Normalisation (eps = 1e-5 in the reference launchers). */
+void orc_rmsnorm(const orc_f16 *x, size_t rows, size_t cols, const orc_f16 *w,
+                 const orc_f16 *b, float multi_base, float eps, int nthreads_x, orc_f16 *y);
+void orc_stdnorm(const orc_f16 *x, size_t rows, size_t cols, const orc_f16 *w,
+                 const orc_f16 *b, float eps, int nthreads_x, orc_f16 *y);
+
+/* Position embedding on [tokens][heads][head_dim] F16, in place. */
+void orc_rope(orc_f16 *x, int head_dim, int heads, int tokens, int pos0,
+              float theta, int order, int rope_dims, int rope_cols);
+void orc_alibi(orc_f16 *scores, int ctx, int q_tokens, int heads, int base_head, int total_heads);
+
+void orc_softmax(orc_f16 *s, int cx, int cy, int cz, int prefix_len, float scale);
+void orc_act(const orc_f16 *x, size_t n_rows, size_t n_cols, int kind, int is_glu, orc_f16 *y);
+void orc_add(const orc_f16 *a, const orc_f16 *b, size_t n, size_t b_period, orc_f16 *c);
+void orc_mul(const orc_f16 *a, const orc_f16 *b, size_t n, orc_f16 *c);
+void orc_scale(const orc_f16 *a, float s, size_t n, orc_f16 *c);
+
+/* Attention for q_tokens new tokens over a cache of n rows (GQA, causal). */
+void orc_attention(const orc_f16 *q, const void *kcache, const void *vcache, int kv_dtype,
+                   int n_ctx, int q_tokens, int prefix_len, int heads, int kv_heads,
+                   int head_dim, float kq_scale, int use_alibi, int alibi_base_head,
+                   int alibi_total_heads, orc_f16 *out);
+
+/* MoE router top-k (HostTensorOpr::BuildRowsForMoE). */
+int orc_moe_topk(const float *probs, int experts, int top_k, int norm_topk,
+                 int *idx, float *w);
+
+/* ------------------------------------------------------------------ */
+/* Whole-model decoder (llama-style / falcon-style), quantized GPU-path */
+/* semantics.  Used as end-to-end oracle and as bench.py's cpu_baseline. */
+typedef struct {
+    int dim, layers, heads, kv_heads, head_dim, ffn, vocab, max_ctx;
+    int norm_kind;      /* 0 = rms, 1 = std */
+    int act_kind;       /* 0 = silu, 1 = gelu, 2 = relu */
+    int is_glu;         /* w3 present (gated) */
+    int rope_order;     /* 0 = none, 1 = std pairs, 2 = order-2 */
+    int use_alibi;
+    int parallel_attn;  /* falcon: ffn input = attn pre-norm output */
+    int share_input;    /* mlp_attn_share_input */
+    float rope_theta, partial_rotary, kq_scale, eps;
+    int kv_dtype;       /* ORC_F16 or ORC_Q8_B32T2 */
+    int full_quant_gemv;/* 1: activations quantised to Q8 before eligible GEMVs */
+    int experts, moe_top_k, moe_norm_topk;
+} orc_model_cfg;
+
+typedef struct orc_model orc_model;
+orc_model *orc_model_create(const orc_model_cfg *cfg);
+void       orc_model_destroy(orc_model *m);
+/* tensor ids */
+enum { ORC_T_EMBD = 0, ORC_T_OUT_NORM = 1, ORC_T_OUT_NORM_B = 2, ORC_T_LM_HEAD = 3,
+       ORC_T_ATTN_NORM = 10, ORC_T_ATTN_NORM_B = 11, ORC_T_WQ = 12, ORC_T_WK = 13,
+       ORC_T_WV = 14, ORC_T_WO = 15, ORC_T_FFN_NORM = 16, ORC_T_FFN_NORM_B = 17,
+       ORC_T_W1 = 18, ORC_T_W2 = 19, ORC_T_W3 = 20, ORC_T_MOE_GATE = 21,
+       ORC_T_WQ_B = 22, ORC_T_WK_B = 23, ORC_T_WV_B = 24, ORC_T_WO_B = 25,
+       ORC_T_W1_B = 26, ORC_T_W2_B = 27, ORC_T_W3_B = 28 };
+/* Attach (no copy) a tensor already in its final dtype.  expert = -1 for dense. */
+int orc_model_set_tensor(orc_model *m, int layer, int tensor_id, int expert, int dtype,
+                         const void *data, size_t rows, size_t cols);
+void orc_model_reset(orc_model *m);
+/* Process n_tokens new tokens at positions [prefix_len, prefix_len+n_tokens).
+ * logits_out: F16 [n_tokens][vocab] (may be NULL).  Returns greedy argmax of last row. */
+int orc_model_forward(orc_model *m, const int *tokens, int n_tokens, int prefix_len,
+                      orc_f16 *logits_out, int nthreads);
+/* debugging tap: copy of the last hidden state after final norm, F16[dim] */
+const orc_f16 *orc_model_last_hidden(const orc_model *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,313 @@
+/*
+ * ifa_oracle_model.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Whole-model decoder forward with the reference's GPU-path semantics
+ * (GpuInferenceWorker::Run, src/transformer/inference_worker.cc:234-340;
+ * per-layer op order: SURVEY.md appendix B).  Every intermediate tensor is
+ * F16, activations are re-quantised to Q8_B32T2 before each eligible GEMV
+ * (GetUseFullQuantGemv, inference_worker.cc:2707-2730), prefill rows go
+ * through "dequantise the weight to half, fp32-accumulate" (MatrixMultiplication,
+ * inference_worker.cc:2364-2432 + cublasGemmEx F16 in / F32 accumulate,
+ * src/tensor/cublas_engine.cu:420-436).
+ *
+ * Used (a) as the end-to-end parity oracle for the HIP engine and (b), with
+ * OpenMP, as bench.py's "port" cpu_baseline.
+ */
+#include "ifa_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_MAX_TENSOR_ID 32
+
+typedef struct {
+    int dtype;
+    const void *data;
+    size_t rows, cols;
+} orc_tensor;
+
+typedef struct {
+    orc_tensor t[ORC_MAX_TENSOR_ID];
+    orc_tensor *experts; /* [experts][3]: w1,w2,w3 */
+    void *kcache, *vcache;
+} orc_layer;
+
+struct orc_model {
+    orc_model_cfg cfg;
+    orc_tensor g[ORC_MAX_TENSOR_ID];
+    orc_layer *layers;
+    orc_f16 *last_hidden;
+};
+
+static int is_quant(int dtype) { return dtype != ORC_F16 && dtype != ORC_F32; }
+
+static int full_quant_eligible(int dtype)
+{
+    switch (dtype) {
+    case ORC_Q8_B32T2: case ORC_Q6_B64T1: case ORC_Q5_B64T1: case ORC_Q4_B32T1A:
+    case ORC_Q4_B32T1B: case ORC_Q4_B64T1: case ORC_Q3H_B64T1: return 1;
+    default: return 0;
+    }
+}
+
+orc_model *orc_model_create(const orc_model_cfg *cfg)
+{
+    orc_model *m = (orc_model *)calloc(1, sizeof(orc_model));
+    m->cfg = *cfg;
+    if (m->cfg.eps <= 0) m->cfg.eps = 1e-5f;
+    if (m->cfg.kq_scale <= 0) m->cfg.kq_scale = 1.0f;
+    if (m->cfg.partial_rotary <= 0) m->cfg.partial_rotary = 1.0f;
+    m->layers = (orc_layer *)calloc((size_t)cfg->layers, sizeof(orc_layer));
+    size_t kv_dim = (size_t)cfg->kv_heads * (size_t)cfg->head_dim;
+    size_t rowb = orc_row_bytes(cfg->kv_dtype == ORC_Q8_B32T2 ? ORC_Q8_B32T2 : ORC_F16, kv_dim);
+    for (int l = 0; l < cfg->layers; l++) {
+        m->layers[l].kcache = calloc((size_t)cfg->max_ctx, rowb);
+        m->layers[l].vcache = calloc((size_t)cfg->max_ctx, rowb);
+        if (cfg->experts > 0)
+            m->layers[l].experts = (orc_tensor *)calloc((size_t)cfg->experts * 3, sizeof(orc_tensor));
+    }
+    m->last_hidden = (orc_f16 *)calloc((size_t)cfg->dim, sizeof(orc_f16));
+    return m;
+}
+
+void orc_model_destroy(orc_model *m)
+{
+    if (!m) return;
+    for (int l = 0; l < m->cfg.layers; l++) {
+        free(m->layers[l].kcache); free(m->layers[l].vcache); free(m->layers[l].experts);
+    }
+    free(m->layers); free(m->last_hidden); free(m);
+}
+
+int orc_model_set_tensor(orc_model *m, int layer, int tensor_id, int expert, int dtype,
+                         const void *data, size_t rows, size_t cols)
+{
+    if (tensor_id < 0 || tensor_id >= ORC_MAX_TENSOR_ID) return -1;
+    orc_tensor t; t.dtype = dtype; t.data = data; t.rows = rows; t.cols = cols;
+    if (tensor_id < 10) { m->g[tensor_id] = t; return 0; }
+    if (layer < 0 || layer >= m->cfg.layers) return -1;
+    if (expert >= 0) {
+        if (expert >= m->cfg.experts) return -1;
+        int slot = tensor_id == ORC_T_W1 ? 0 : tensor_id == ORC_T_W2 ? 1 : tensor_id == ORC_T_W3 ? 2 : -1;
+        if (slot < 0) return -1;
+        m->layers[layer].experts[expert * 3 + slot] = t;
+        return 0;
+    }
+    m->layers[layer].t[tensor_id] = t;
+    return 0;
+}
+
+void orc_model_reset(orc_model *m)
+{
+    size_t kv_dim = (size_t)m->cfg.kv_heads * (size_t)m->cfg.head_dim;
+    size_t rowb = orc_row_bytes(m->cfg.kv_dtype == ORC_Q8_B32T2 ? ORC_Q8_B32T2 : ORC_F16, kv_dim);
+    for (int l = 0; l < m->cfg.layers; l++) {
+        memset(m->layers[l].kcache, 0, (size_t)m->cfg.max_ctx * rowb);
+        memset(m->layers[l].vcache, 0, (size_t)m->cfg.max_ctx * rowb);
+    }
+}
+
+const orc_f16 *orc_model_last_hidden(const orc_model *m) { return m->last_hidden; }
+
+/* C[T][rows(W)] = A[T][cols(W)] x W^T (+bias), reference dispatch rules. */
+static int matmul(const orc_model *m, const orc_f16 *A, int T, const orc_tensor *W,
+                  const orc_tensor *bias, orc_f16 *C)
+{
+    if (!W->data) return -1;
+    const orc_f16 *bptr = (bias && bias->data) ? (const orc_f16 *)bias->data : NULL;
+    size_t K = W->cols, N = W->rows;
+    int use_gemv = (T == 1) && (K % 32 == 0);
+    if (use_gemv && is_quant(W->dtype) && m->cfg.full_quant_gemv && full_quant_eligible(W->dtype)) {
+        uint8_t *xq = (uint8_t *)malloc(orc_row_bytes(ORC_Q8_B32T2, K));
+        orc_quantize_act_q8(A, 1, K, xq);
+        int rc = orc_gemv_ax8(W->dtype, (const uint8_t *)W->data, N, K, xq, C, NULL);
+        free(xq);
+        if (rc != 0) return rc;
+        if (bptr) orc_add(C, bptr, N, 0, C);
+        return 0;
+    }
+    for (int t = 0; t < T; t++) {
+        int rc = orc_gemv_f16x(W->dtype, (const uint8_t *)W->data, N, K, A + (size_t)t * K, bptr,
+                               C + (size_t)t * N, NULL);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+static void norm_rows(const orc_model *m, const orc_f16 *x, int T, const orc_tensor *w,
+                      const orc_tensor *b, orc_f16 *y)
+{
+    const orc_f16 *wp = w && w->data ? (const orc_f16 *)w->data : NULL;
+    const orc_f16 *bp = b && b->data ? (const orc_f16 *)b->data : NULL;
+    if (m->cfg.norm_kind == 0)
+        orc_rmsnorm(x, (size_t)T, (size_t)m->cfg.dim, wp, bp, 0.0f, m->cfg.eps, 128, y);
+    else
+        orc_stdnorm(x, (size_t)T, (size_t)m->cfg.dim, wp, bp, m->cfg.eps, 128, y);
+}
+
+static int ffn_dense(const orc_model *m, const orc_f16 *in, int T, const orc_tensor *w1,
+                     const orc_tensor *w1b, const orc_tensor *w3, const orc_tensor *w3b,
+                     const orc_tensor *w2, const orc_tensor *w2b, orc_f16 *out)
+{
+    size_t F = w1->rows, D = w2->rows;
+    orc_f16 *t1 = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * F);
+    orc_f16 *t2 = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * F);
+    int rc = matmul(m, in, T, w1, w1b, t1);
+    if (rc == 0) {
+        orc_act(t1, (size_t)T, F, m->cfg.act_kind, 0, t1);
+        if (w3 && w3->data) {
+            rc = matmul(m, in, T, w3, w3b, t2);
+            if (rc == 0) orc_mul(t1, t2, (size_t)T * F, t1);
+        }
+    }
+    if (rc == 0) rc = matmul(m, t1, T, w2, w2b, out);
+    (void)D;
+    free(t1); free(t2);
+    return rc;
+}
+
+int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
+                      orc_f16 *logits_out, int nthreads)
+{
+    const orc_model_cfg *c = &m->cfg;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    if (prefix_len + T > c->max_ctx || T <= 0) return -1;
+    const size_t D = (size_t)c->dim;
+    const size_t QD = (size_t)c->heads * (size_t)c->head_dim;
+    const size_t KVD = (size_t)c->kv_heads * (size_t)c->head_dim;
+    const int kvt = c->kv_dtype == ORC_Q8_B32T2 ? ORC_Q8_B32T2 : ORC_F16;
+    const size_t kv_rowb = orc_row_bytes(kvt, KVD);
+    orc_f16 *x = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
+    orc_f16 *xn = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
+    orc_f16 *hn = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
+    orc_f16 *q = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * QD);
+    orc_f16 *k = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * KVD);
+    orc_f16 *v = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * KVD);
+    orc_f16 *att = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * QD);
+    orc_f16 *a = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
+    orc_f16 *f = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
+    int rc = 0;
+
+    /* embedding rows (InferenceEngine::GetEmbdTensor, inference_engine.cc:1298-1353) */
+    {
+        const orc_tensor *e = &m->g[ORC_T_EMBD];
+        if (!e->data || e->dtype != ORC_F16) { rc = -2; goto done; }
+        for (int t = 0; t < T; t++) {
+            if (tokens[t] < 0 || (size_t)tokens[t] >= e->rows) { rc = -3; goto done; }
+            memcpy(x + (size_t)t * D, (const orc_f16 *)e->data + (size_t)tokens[t] * D, D * 2);
+        }
+    }
+    const int rope_dims = (int)((float)c->head_dim * c->partial_rotary + 0.5f);
+    const int rope_cols = rope_dims;
+    for (int l = 0; l < c->layers && rc == 0; l++) {
+        orc_layer *L = &m->layers[l];
+        /* attention pre-norm (inference_worker.cc:1038) */
+        const orc_f16 *attn_in = x;
+        if (L->t[ORC_T_ATTN_NORM].data) {
+            norm_rows(m, x, T, &L->t[ORC_T_ATTN_NORM], &L->t[ORC_T_ATTN_NORM_B], xn);
+            attn_in = xn;
+        }
+        rc = matmul(m, attn_in, T, &L->t[ORC_T_WQ], &L->t[ORC_T_WQ_B], q); if (rc) break;
+        rc = matmul(m, attn_in, T, &L->t[ORC_T_WK], &L->t[ORC_T_WK_B], k); if (rc) break;
+        rc = matmul(m, attn_in, T, &L->t[ORC_T_WV], &L->t[ORC_T_WV_B], v); if (rc) break;
+        if (c->rope_order != 0) {
+            orc_rope(q, c->head_dim, c->heads, T, prefix_len, c->rope_theta, c->rope_order, rope_dims, rope_cols);
+            orc_rope(k, c->head_dim, c->kv_heads, T, prefix_len, c->rope_theta, c->rope_order, rope_dims, rope_cols);
+        }
+        /* KV store at rows [prefix_len, prefix_len+T) (kv_cache.cc:159-249) */
+        if (kvt == ORC_Q8_B32T2) {
+            orc_quantize_act_q8(k, (size_t)T, KVD, (uint8_t *)L->kcache + (size_t)prefix_len * kv_rowb);
+            orc_quantize_act_q8(v, (size_t)T, KVD, (uint8_t *)L->vcache + (size_t)prefix_len * kv_rowb);
+        } else {
+            memcpy((uint8_t *)L->kcache + (size_t)prefix_len * kv_rowb, k, (size_t)T * kv_rowb);
+            memcpy((uint8_t *)L->vcache + (size_t)prefix_len * kv_rowb, v, (size_t)T * kv_rowb);
+        }
+        orc_attention(q, L->kcache, L->vcache, kvt, prefix_len + T, T, prefix_len, c->heads,
+                      c->kv_heads, c->head_dim, c->use_alibi ? 1.0f : c->kq_scale, c->use_alibi,
+                      0, c->heads, att);
+        rc = matmul(m, att, T, &L->t[ORC_T_WO], &L->t[ORC_T_WO_B], a); if (rc) break;
+        /* residual (inference_worker.cc:847-851) */
+        if (!c->parallel_attn && !c->share_input) orc_add(x, a, (size_t)T * D, 0, a);
+        const orc_f16 *ff_in = c->parallel_attn ? attn_in : (c->share_input ? x : a);
+        const orc_f16 *ff_n = ff_in;
+        if (L->t[ORC_T_FFN_NORM].data) {
+            norm_rows(m, ff_in, T, &L->t[ORC_T_FFN_NORM], &L->t[ORC_T_FFN_NORM_B], hn);
+            ff_n = hn;
+        }
+        if (c->experts > 0 && L->t[ORC_T_MOE_GATE].data) {
+            /* ProcessGpuLayer_Moe, inference_worker.cc:1924-2146 */
+            int E = c->experts;
+            orc_f16 *gate = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * (size_t)E);
+            rc = matmul(m, ff_n, T, &L->t[ORC_T_MOE_GATE], NULL, gate);
+            if (rc == 0) {
+                orc_softmax(gate, E, T, 1, -1, 1.0f);
+                orc_f16 *eo = (orc_f16 *)malloc(sizeof(orc_f16) * D);
+                memset(f, 0, sizeof(orc_f16) * (size_t)T * D);
+                for (int t = 0; t < T && rc == 0; t++) {
+                    float probs[64]; int idx[8]; float w[8];
+                    for (int e = 0; e < E; e++) probs[e] = orc_h2f(gate[(size_t)t * (size_t)E + (size_t)e]);
+                    int n = orc_moe_topk(probs, E, c->moe_top_k, c->moe_norm_topk, idx, w);
+                    /* experts visited in ascending id order (serial loop :2053-2121) */
+                    for (int e = 0; e < E && rc == 0; e++) {
+                        for (int j = 0; j < n; j++) {
+                            if (idx[j] != e) continue;
+                            const orc_tensor *ew = &L->experts[e * 3];
+                            rc = ffn_dense(m, ff_n + (size_t)t * D, 1, &ew[0], NULL, &ew[2], NULL, &ew[1], NULL, eo);
+                            /* AddByRowIdx_Kernel binary_tensor_opr.h:80-125: B = hfma(A, w, B) */
+                            orc_f16 wh = orc_f2h(w[j]);
+                            for (size_t d = 0; d < D; d++) {
+                                double p = (double)orc_h2f(eo[d]) * (double)orc_h2f(wh) + (double)orc_h2f(f[(size_t)t * D + d]);
+                                f[(size_t)t * D + d] = orc_f2h((float)p);
+                            }
+                        }
+                    }
+                }
+                free(eo);
+            }
+            free(gate);
+        } else {
+            rc = ffn_dense(m, ff_n, T, &L->t[ORC_T_W1], &L->t[ORC_T_W1_B], &L->t[ORC_T_W3],
+                           &L->t[ORC_T_W3_B], &L->t[ORC_T_W2], &L->t[ORC_T_W2_B], f);
+        }
+        if (rc) break;
+        /* layer_out = ff_out + residual (+ layer_input) (inference_worker.cc:936-947) */
+        orc_add(f, a, (size_t)T * D, 0, f);
+        if (c->parallel_attn || c->share_input) orc_add(f, x, (size_t)T * D, 0, f);
+        memcpy(x, f, sizeof(orc_f16) * (size_t)T * D);
+    }
+    if (rc == 0) {
+        /* ProcessPostLayer, inference_worker.cc:552-624 */
+        const orc_f16 *hfin = x;
+        if (m->g[ORC_T_OUT_NORM].data) {
+            norm_rows(m, x, T, &m->g[ORC_T_OUT_NORM], &m->g[ORC_T_OUT_NORM_B], xn);
+            hfin = xn;
+        }
+        memcpy(m->last_hidden, hfin + (size_t)(T - 1) * D, D * 2);
+        const orc_tensor *lm = &m->g[ORC_T_LM_HEAD];
+        size_t V = lm->rows;
+        orc_f16 *lg = logits_out ? logits_out : (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * V);
+        int t0 = logits_out ? 0 : T - 1;
+        if (logits_out) rc = matmul(m, hfin, T, lm, NULL, lg);
+        else rc = matmul(m, hfin + (size_t)t0 * D, 1, lm, NULL, lg + (size_t)t0 * V);
+        if (rc == 0) {
+            /* greedy = top-1 (sampling_strategy.cc:372-386); first max wins */
+            const orc_f16 *row = lg + (size_t)(T - 1) * V;
+            int best = 0; float bv = orc_h2f(row[0]);
+            for (size_t i = 1; i < V; i++) { float vv = orc_h2f(row[i]); if (vv > bv) { bv = vv; best = (int)i; } }
+            rc = best;
+        } else rc = -10;
+        if (!logits_out) free(lg);
+    } else {
+        rc = -11;
+    }
+done:
+    free(x); free(xn); free(hn); free(q); free(k); free(v); free(att); free(a); free(f);
+    return rc;
+}
