@@ -1,0 +1,93 @@
+"""ctypes binding of include/inferflow_amd.h.  Fails loudly when the HIP
+library is missing -- there is no CPU fallback on the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libinferflow_amd.so")
+_lib = None
+
+
+class IfaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("inferflow_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load libinferflow_amd.so (built by inferflow_amd/build.py / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                "inferflow_amd: %s is missing -- run `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IfaError(rc, lib().ifa_last_error().decode(errors="replace"))
+    return rc
+
+
+_vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+
+# name -> (restype, argtypes); mirrors include/inferflow_amd.h one to one
+SIGNATURES = {
+    "ifa_version": (C.c_char_p, []),
+    "ifa_last_error": (C.c_char_p, []),
+    "ifa_device_count": (_i, []),
+    "ifa_set_device": (_i, [_i]),
+    "ifa_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "ifa_free": (_i, [_vp]),
+    "ifa_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "ifa_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "ifa_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
+    "ifa_memset": (_i, [_vp, _i, _sz, _vp]),
+    "ifa_stream_create": (_i, [C.POINTER(_vp)]),
+    "ifa_stream_destroy": (_i, [_vp]),
+    "ifa_stream_sync": (_i, [_vp]),
+    "ifa_block_capacity": (_i, [_i]),
+    "ifa_block_bytes": (_i, [_i]),
+    "ifa_row_bytes": (_sz, [_i, _sz]),
+    "ifa_dtype_from_name": (_i, [C.c_char_p]),
+    "ifa_quantize": (_i, [_i, _vp, _sz, _sz, _vp, _vp]),
+    "ifa_quantize_f32": (_i, [_i, _vp, _sz, _sz, _vp, _vp]),
+    "ifa_dequantize": (_i, [_i, _vp, _sz, _sz, _vp, _vp]),
+    "ifa_quantize_act_q8": (_i, [_vp, _sz, _sz, _vp, _vp]),
+    "ifa_gemv": (_i, [_i, _vp, _sz, _sz, _i, _vp, _vp, _vp, _vp]),
+    "ifa_repack_weights": (_i, [_i, _vp, _sz, _sz, _vp, _vp]),
+    "ifa_gemv_tiled": (_i, [_i, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "ifa_layernorm": (_i, [_i, _vp, _sz, _sz, _vp, _vp, _f, _f, _vp, _vp]),
+    "ifa_rope": (_i, [_vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
+    "ifa_alibi": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "ifa_softmax": (_i, [_vp, _i, _i, _i, _i, _f, _vp]),
+    "ifa_activation": (_i, [_i, _i, _vp, _sz, _sz, _vp, _vp]),
+    "ifa_mul": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "ifa_add": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "ifa_scale": (_i, [_vp, _f, _sz, _vp, _vp]),
+    "ifa_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
+    "ifa_argmax": (_i, [_vp, _sz, _vp, _vp]),
+}
+
+
+def _declare(L):
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise ImportError("libinferflow_amd.so lacks symbols declared in include/inferflow_amd.h: %s" % missing)

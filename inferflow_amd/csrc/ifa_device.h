@@ -1,0 +1,101 @@
+// ifa_device.h -- device-side helpers shared by all gfx950 kernels.
+// wave64 only; no CUDA-compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ifa {
+
+typedef _Float16 half_t;
+
+// dtype ids == reference ElementType enum (src/tensor/tensor_common.h:15-42)
+enum DType : int {
+    F32 = 0, F16 = 1,
+    Q8_B32T1 = 7, Q8_B32T2 = 8, Q6_B64T1 = 9, Q5_B64T1 = 10, Q5_B32T1 = 11,
+    Q4_B16 = 12, Q4_B32T1A = 13, Q4_B32T1B = 14, Q4_B64T1 = 17, Q3H_B64T1 = 18,
+    Q3_B32T1A = 19, Q3_B32T1B = 20, Q2_B32T1A = 21, Q2_B32T1B = 22
+};
+
+__host__ __device__ constexpr int block_capacity(int dt)
+{
+    return (dt == F32 || dt == F16) ? 1
+        : (dt == Q4_B16) ? 16
+        : (dt == Q6_B64T1 || dt == Q5_B64T1 || dt == Q4_B64T1 || dt == Q3H_B64T1) ? 64
+        : (dt == Q8_B32T1 || dt == Q8_B32T2 || dt == Q5_B32T1 || dt == Q4_B32T1A || dt == Q4_B32T1B
+           || dt == Q3_B32T1A || dt == Q3_B32T1B || dt == Q2_B32T1A || dt == Q2_B32T1B) ? 32 : 0;
+}
+
+__host__ __device__ constexpr int block_bytes(int dt)
+{
+    return dt == F32 ? 4 : dt == F16 ? 2
+        : dt == Q8_B32T1 ? 36 : dt == Q8_B32T2 ? 34 : dt == Q6_B64T1 ? 52 : dt == Q5_B64T1 ? 44
+        : dt == Q5_B32T1 ? 24 : dt == Q4_B16 ? 10 : (dt == Q4_B32T1A || dt == Q4_B32T1B) ? 20
+        : dt == Q4_B64T1 ? 36 : dt == Q3H_B64T1 ? 32 : (dt == Q3_B32T1A || dt == Q3_B32T1B) ? 16
+        : (dt == Q2_B32T1A || dt == Q2_B32T1B) ? 12 : 0;
+}
+
+__host__ __device__ constexpr bool ax8_eligible(int dt)
+{   // GetUseFullQuantGemv, src/transformer/inference_worker.cc:2707-2730
+    return dt == Q8_B32T2 || dt == Q6_B64T1 || dt == Q5_B64T1 || dt == Q4_B32T1A || dt == Q4_B32T1B
+        || dt == Q4_B64T1 || dt == Q3H_B64T1;
+}
+
+// ---- fp16 helpers (RN conversions, like CUDA __float2half_rn) -------------
+__device__ __forceinline__ float h2f(half_t h) { return (float)h; }
+__device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }
+__device__ __forceinline__ float hbits2f(uint16_t b) { return (float)__builtin_bit_cast(half_t, b); }
+__device__ __forceinline__ uint16_t f2hbits(float f) { return __builtin_bit_cast(uint16_t, (half_t)f); }
+
+// ---- wave64 reductions -----------------------------------------------------
+// DPP within 16-lane rows, ds_bpermute across rows.  All lanes get the result.
+template <typename T>
+__device__ __forceinline__ T dpp_xor1(T v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); }
+template <typename T>
+__device__ __forceinline__ T dpp_xor2(T v) { return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); }
+template <typename T>
+__device__ __forceinline__ T dpp_half_mirror(T v) { return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false); }
+template <typename T>
+__device__ __forceinline__ T dpp_mirror(T v) { return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_half_mirror(v);
+    v += dpp_mirror(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = fmaxf(v, dpp_xor1(v));
+    v = fmaxf(v, dpp_xor2(v));
+    v = fmaxf(v, dpp_half_mirror(v));
+    v = fmaxf(v, dpp_mirror(v));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+// max over each aligned group of 32 lanes (a Q8_B32T2 block == 32 lanes)
+__device__ __forceinline__ float half_wave_max(float v)
+{
+    v = fmaxf(v, dpp_xor1(v));
+    v = fmaxf(v, dpp_xor2(v));
+    v = fmaxf(v, dpp_half_mirror(v));
+    v = fmaxf(v, dpp_mirror(v));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return v;
+}
+
+__device__ __forceinline__ int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+__device__ __forceinline__ uint32_t ld_u32_unaligned2(const uint8_t *p)
+{   // 2-byte aligned 32-bit read
+    const uint16_t *q = reinterpret_cast<const uint16_t *>(p);
+    return (uint32_t)q[0] | ((uint32_t)q[1] << 16);
+}
+
+} // namespace ifa

@@ -1,0 +1,289 @@
+// ifa_ops.hip -- op-level counterparts of TensorOpr::{LayerNormalization,
+// PositionEmbedding, SoftMax, Activation, Mul, Add, Scale} and the greedy
+// argmax, one launch per op, no hidden synchronisation.  These mirror the
+// reference op set for drop-in use and for op-by-op parity tests; the decode
+// engine (ifa_decode.hip) fuses the same device functions.
+#include "ifa_host.h"
+#include "ifa_device.h"
+#include "ifa_math.h"
+
+namespace ifa {
+
+// Tensor_RmsNorm_Kernel / Tensor_StdNorm_Kernel (src/kernels/unary_tensor_opr.h:216-289, :68-149),
+// launcher block (128,1), grid (1,rows) (src/tensor/tensor_opr.cu:511-520, :568-577).
+// Same partial-sum structure (128 partials, serial final sum) so the fp32 result
+// is bit-identical to the restated reference.
+template <int KIND>
+__global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x, int cols,
+                                                   const half_t *__restrict__ w, const half_t *__restrict__ b,
+                                                   float multi_base, float eps, half_t *__restrict__ y)
+{
+    __shared__ float part[128];
+    __shared__ float part2[128];
+    __shared__ float stat[2];
+    const int tid = threadIdx.x;
+    const half_t *src = x + (size_t)blockIdx.x * cols;
+    half_t *dst = y + (size_t)blockIdx.x * cols;
+    if constexpr (KIND == 0) {
+        part[tid] = rms_partial(src, cols, tid, 128);
+        __syncthreads();
+        if (tid == 0) stat[0] = rms_scale_from_partials(part, 128, cols, eps);
+        __syncthreads();
+        const float scale = stat[0];
+        const int x_len = (cols + 127) / 128;
+        const int xs0 = tid * x_len, xe = min((tid + 1) * x_len, cols);
+        for (int xi = xs0; xi < xe; xi++)
+            dst[xi] = f2h(rms_apply(h2f(src[xi]), scale, w ? w + xi : nullptr, b ? b + xi : nullptr, multi_base));
+    } else {
+        float sum = 0.0f, sum2 = 0.0f;
+        for (int xi = tid; xi < cols; xi += 128) {
+            double v = (double)h2f(src[xi]);
+            sum = (float)((double)sum + v);
+            sum2 = (float)((double)sum2 + v * v);
+        }
+        part[tid] = sum; part2[tid] = sum2;
+        __syncthreads();
+        if (tid == 0) {
+            float ts = 0.0f, ts2 = 0.0f;
+            for (int i = 0; i < 128; i++) { ts = ts + part[i]; ts2 = ts2 + part2[i]; }
+            float mean = ts / (float)cols;
+            float mm = mean * mean;
+            float var = ts2 / (float)cols - mm;
+            stat[0] = mean;
+            stat[1] = 1.0f / sqrtf(var + eps);
+        }
+        __syncthreads();
+        const float mean = stat[0], scale = stat[1];
+        for (int xi = tid; xi < cols; xi += 128) {
+            float v = (h2f(src[xi]) - mean) * scale;
+            if (w) v = v * h2f(w[xi]);
+            if (w && b) v = v + h2f(b[xi]);
+            dst[xi] = f2h(v);
+        }
+    }
+}
+
+// PosEmbedding_Rope_Order2_Kernel / _Std_Kernel (unary_tensor_opr.h:661-740)
+__global__ void __launch_bounds__(256) k_rope(half_t *__restrict__ x, int head_dim, int heads, int tokens, int pos0,
+                                              float theta, int order, int rope_dims, int rope_cols)
+{
+    const int half_dim = head_dim / 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)tokens * heads * half_dim;
+    if (idx >= total) return;
+    const int col = (int)(idx % half_dim);
+    const size_t rowi = idx / half_dim;
+    const int t = (int)(rowi / heads);
+    half_t *row = x + rowi * head_dim;
+    rope_rotate(row, col, pos0 + t, theta, order, rope_dims, rope_cols);
+}
+
+// PosEmbedding_Alibi_Std_Kernel (unary_tensor_opr.h:742-762)
+__global__ void __launch_bounds__(256) k_alibi(half_t *__restrict__ s, int ctx, int q_tokens, int heads,
+                                               int base_head, int total_heads)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)heads * q_tokens * ctx;
+    if (idx >= total) return;
+    const int col = (int)(idx % ctx);
+    const int h = (int)(idx / ((size_t)ctx * q_tokens));
+    const float mk = alibi_slope(h + base_head, total_heads);
+    float a = (float)col * mk;
+    s[idx] = f2h(a + h2f(s[idx]));
+}
+
+// Tensor_SoftMax_Alg2_Kernel (unary_tensor_opr.h:480-535): 32 lanes per row
+// (CUDA warp) with strided partial sums and an xor butterfly; reproduced on a
+// half-wave so the summation order matches the restated reference.
+__global__ void __launch_bounds__(64) k_softmax(half_t *__restrict__ s, int cx, int cy, size_t nrows, int prefix_len,
+                                               float scale)
+{
+    const int lane32 = threadIdx.x & 31;
+    const int sub = threadIdx.x >> 5;
+    const size_t rowi = (size_t)blockIdx.x * 2 + sub;
+    if (rowi >= nrows) return;
+    half_t *row = s + rowi * cx;
+    const int r = (int)(rowi % cy);
+    float mx = -INFINITY;
+    for (int xi = lane32; xi < cx; xi += 32) {
+        float v = scale * h2f(row[xi]);
+        if (prefix_len >= 0 && xi > prefix_len + r) v = -INFINITY;
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int m = 16; m > 0; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 32));
+    float sum = 0.0f;
+    for (int xi = lane32; xi < cx; xi += 32) {
+        float v = scale * h2f(row[xi]);
+        if (prefix_len >= 0 && xi > prefix_len + r) v = -INFINITY;
+        const float e = expf(v - mx);
+        sum = sum + e;
+        row[xi] = f2h(e);
+    }
+#pragma unroll
+    for (int m = 16; m > 0; m >>= 1) sum = sum + __shfl_xor(sum, m, 32);
+    const float inv = 1.0f / sum;
+    for (int xi = lane32; xi < cx; xi += 32) row[xi] = f2h(h2f(row[xi]) * inv);
+}
+
+__global__ void __launch_bounds__(256) k_activation(const half_t *__restrict__ x, size_t rows, size_t cols, int kind,
+                                                    int is_glu, half_t *__restrict__ y)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const size_t r = idx / cols, c = idx % cols;
+    const size_t in_off = is_glu ? (r * 2 * cols + c) : idx;
+    float fx = act_fn(h2f(x[in_off]), kind);
+    if (is_glu) fx = fx * h2f(x[in_off + cols]);
+    y[idx] = f2h(fx);
+}
+
+__global__ void __launch_bounds__(256) k_mul(const half_t *a, const half_t *b, size_t n, half_t *c)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i] = f2h(h2f(a[i]) * h2f(b[i]));
+}
+__global__ void __launch_bounds__(256) k_add(const half_t *a, const half_t *b, size_t n, size_t period, half_t *c)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i] = f2h(h2f(a[i]) + h2f(b[period ? i % period : i]));
+}
+__global__ void __launch_bounds__(256) k_scale(const half_t *a, float s, size_t n, half_t *c)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i] = f2h(h2f(a[i]) * s);
+}
+
+// greedy top-1: first maximum wins (GetSortedTopK, sampling_strategy.cc:372-386)
+__global__ void __launch_bounds__(1024) k_argmax(const half_t *__restrict__ v, size_t n, int *__restrict__ out)
+{
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY; int besti = 0x7FFFFFFF;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float f = h2f(v[i]);
+        if (f > best || (f == best && (int)i < besti)) { best = f; besti = (int)i; }
+    }
+    if (besti == 0x7FFFFFFF) { best = -INFINITY; }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        float ob = __shfl_xor(best, m); int oi = __shfl_xor(besti, m);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; w++)
+            if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        *out = besti == 0x7FFFFFFF ? 0 : besti;
+    }
+}
+
+} // namespace ifa
+
+using namespace ifa;
+
+extern "C" {
+
+int ifa_layernorm(int kind, const void *x, size_t rows, size_t cols, const void *w, const void *b,
+                  float multi_base, float eps, void *y, ifa_stream stream)
+{
+    IFA_REQUIRE(x && y, "ifa_layernorm: null pointer");
+    IFA_REQUIRE(kind == 0 || kind == 1, "ifa_layernorm: kind %d", kind);
+    IFA_REQUIRE(b == nullptr || w != nullptr, "ifa_layernorm: bias without weight");
+    if (rows == 0 || cols == 0) return IFA_OK;
+    if (kind == 0)
+        k_layernorm<0><<<dim3((unsigned)rows), dim3(128), 0, ifa_s(stream)>>>((const half_t *)x, (int)cols, (const half_t *)w, (const half_t *)b, multi_base, eps, (half_t *)y);
+    else
+        k_layernorm<1><<<dim3((unsigned)rows), dim3(128), 0, ifa_s(stream)>>>((const half_t *)x, (int)cols, (const half_t *)w, (const half_t *)b, multi_base, eps, (half_t *)y);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_rope(void *x, int head_dim, int heads, int tokens, int pos0, float theta, int order,
+             float partial_rotary_factor, ifa_stream stream)
+{
+    IFA_REQUIRE(x, "ifa_rope: null pointer");
+    IFA_REQUIRE(order == 1 || order == 2, "ifa_rope: order %d", order);
+    IFA_REQUIRE(head_dim > 0 && head_dim % 2 == 0, "ifa_rope: head_dim %d", head_dim);
+    if (tokens <= 0 || heads <= 0) return IFA_OK;
+    if (partial_rotary_factor <= 0) partial_rotary_factor = 1.0f;
+    // src/tensor/tensor_opr.cu:701-702 (F16 path passes rope_dims, appendix A12)
+    int rope_cols = (int)(head_dim * partial_rotary_factor + 0.5f);
+    int rope_dims = rope_cols;
+    size_t total = (size_t)tokens * heads * (head_dim / 2);
+    k_rope<<<dim3(ifa_cdiv(total, 256)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, pos0, theta, order, rope_dims, rope_cols);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_alibi(void *scores, int ctx, int q_tokens, int heads, int base_head, int total_heads, ifa_stream stream)
+{
+    IFA_REQUIRE(scores, "ifa_alibi: null pointer");
+    size_t total = (size_t)heads * q_tokens * ctx;
+    if (total == 0) return IFA_OK;
+    k_alibi<<<dim3(ifa_cdiv(total, 256)), dim3(256), 0, ifa_s(stream)>>>((half_t *)scores, ctx, q_tokens, heads, base_head, total_heads);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_softmax(void *s, int cx, int cy, int cz, int prefix_len, float scale, ifa_stream stream)
+{
+    IFA_REQUIRE(s, "ifa_softmax: null pointer");
+    size_t nrows = (size_t)cy * cz;
+    if (nrows == 0 || cx <= 0) return IFA_OK;
+    IFA_REQUIRE(nrows <= 0x7FFFFFFFu, "ifa_softmax: too many rows");
+    k_softmax<<<dim3(ifa_cdiv(nrows, 2)), dim3(64), 0, ifa_s(stream)>>>((half_t *)s, cx, cy, nrows, prefix_len, scale);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_activation(int kind, int is_glu, const void *x, size_t rows, size_t cols, void *y, ifa_stream stream)
+{
+    IFA_REQUIRE(x && y, "ifa_activation: null pointer");
+    IFA_REQUIRE(kind >= 0 && kind <= 2, "ifa_activation: kind %d", kind);
+    if (rows * cols == 0) return IFA_OK;
+    k_activation<<<dim3(ifa_cdiv(rows * cols, 256)), dim3(256), 0, ifa_s(stream)>>>((const half_t *)x, rows, cols, kind, is_glu, (half_t *)y);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_mul(const void *a, const void *b, size_t n, void *c, ifa_stream stream)
+{
+    IFA_REQUIRE(a && b && c, "ifa_mul: null pointer");
+    if (n == 0) return IFA_OK;
+    k_mul<<<dim3(ifa_cdiv(n, 256)), dim3(256), 0, ifa_s(stream)>>>((const half_t *)a, (const half_t *)b, n, (half_t *)c);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_add(const void *a, const void *b, size_t n, size_t b_period, void *c, ifa_stream stream)
+{
+    IFA_REQUIRE(a && b && c, "ifa_add: null pointer");
+    if (n == 0) return IFA_OK;
+    k_add<<<dim3(ifa_cdiv(n, 256)), dim3(256), 0, ifa_s(stream)>>>((const half_t *)a, (const half_t *)b, n, b_period, (half_t *)c);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_scale(const void *a, float s, size_t n, void *c, ifa_stream stream)
+{
+    IFA_REQUIRE(a && c, "ifa_scale: null pointer");
+    if (n == 0) return IFA_OK;
+    k_scale<<<dim3(ifa_cdiv(n, 256)), dim3(256), 0, ifa_s(stream)>>>((const half_t *)a, s, n, (half_t *)c);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_argmax(const void *logits, size_t n, int *out_index_dev, ifa_stream stream)
+{
+    IFA_REQUIRE(logits && out_index_dev, "ifa_argmax: null pointer");
+    IFA_REQUIRE(n > 0 && n < 0x7FFFFFFFu, "ifa_argmax: n %zu", n);
+    k_argmax<<<dim3(1), dim3(1024), 0, ifa_s(stream)>>>((const half_t *)logits, n, out_index_dev);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+} // extern "C"

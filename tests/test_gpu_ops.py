@@ -1,0 +1,281 @@
+"""-m gpu: op-level parity of the HIP kernels (through the C ABI) against the
+CPU oracle.  Integer / byte results must be bit-exact; fp results within the
+tolerance written next to each assert."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as o
+from inferflow_amd import dtypes as dt
+import inferflow_amd as ia
+from tests import gpu_util as g
+
+pytestmark = pytest.mark.gpu
+
+IDS = lambda ds: [dt.NAMES[d] for d in ds]  # noqa: E731
+
+
+def _rows(rng, rows, cols, scale=0.05):
+    x = rng.normal(0, scale, (rows, cols))
+    x[0, : min(cols, 64)] = 0.0              # all-zero blocks
+    if rows > 1:
+        x[1, :] = 0.125                      # constant row
+    if rows > 2:
+        x[2, 5] = 30.0                       # outlier
+    return x.astype(np.float16)
+
+
+# ----------------------------------------------------------------- codecs
+@pytest.mark.parametrize("d", dt.QUANT, ids=IDS(dt.QUANT))
+def test_quantize_bit_exact_vs_oracle(d):
+    rng = np.random.default_rng(d)
+    src = _rows(rng, 33, 512)
+    if d == dt.Q4_B16:
+        src = np.clip(src.astype(np.float32), -0.9, 1.4).astype(np.float16)
+    got = g.host(g.quantize(d, g.dev(src)))
+    assert np.array_equal(got, o.quantize(d, src))
+    s32 = (src.astype(np.float32) * np.float32(1.0001)).astype(np.float32)
+    got32 = g.host(g.quantize(d, g.dev(s32)))
+    assert np.array_equal(got32, o.quantize(d, s32))
+
+
+@pytest.mark.parametrize("d", dt.QUANT, ids=IDS(dt.QUANT))
+def test_quantize_and_dequantize_match_golden(golden, d):
+    name = dt.NAMES[d]
+    cols = int(golden["cols"])
+    src = golden["src_q4b16_f16" if d == dt.Q4_B16 else "src_f16"].view(np.float16)
+    if d != dt.Q8_B32T2:   # golden Q8_B32T2 is the host routine; device = alg 2 (appendix A3)
+        assert np.array_equal(g.host(g.quantize(d, g.dev(src))), golden["packed_" + name])
+    deq = g.host(g.dequantize(d, g.dev(golden["packed_" + name]), cols))
+    assert np.array_equal(deq.view(np.uint16), golden["deq16_" + name])
+
+
+def test_quantize_rejects_bad_shapes():
+    x = torch.zeros((2, 48), dtype=torch.float16, device="cuda")
+    out = g.empty_u8(2, 64)
+    rc = g.capi().ifa_quantize(dt.Q4_B64T1, g.p(x), 2, 48, g.p(out), None)
+    assert rc == -1 and b"multiple" in g.capi().ifa_last_error()
+    assert g.capi().ifa_quantize(dt.F16, g.p(x), 2, 48, g.p(out), None) == -1
+    assert g.capi().ifa_quantize(dt.Q4_B32T1A, g.p(x), 0, 64, g.p(out), None) == 0   # empty is fine
+
+
+@pytest.mark.parametrize("cols", [32, 96, 100, 4096, 11008])
+def test_act_quant_bit_exact(cols):
+    rng = np.random.default_rng(cols)
+    x = rng.normal(0, 1.0, (3, cols)).astype(np.float16)
+    x[1, :32] = 0
+    x[2, min(cols - 1, 40)] = 500.0
+    got = g.host(g.quantize_act(g.dev(x)))
+    exp = o.quantize_act_q8(x)
+    if cols % 32:   # ragged tail: bytes past the valid lanes of the last block are unspecified
+        nfull = cols // 32
+        assert np.array_equal(got[:, : nfull * 34], exp[:, : nfull * 34])
+        tail = slice(nfull * 34, nfull * 34 + 2 + cols % 32)
+        assert np.array_equal(got[:, tail], exp[:, tail])
+    else:
+        assert np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------- GEMV
+def _check_gemv(y_gpu, y_orc, y64, tag):
+    ulp = g.half_ulp_diff(y_gpu, y_orc)
+    # both sides are fp32 sums of the same exact terms in different orders:
+    # after rounding to half they may differ by at most 1 ulp, and rarely.
+    assert ulp.max() <= 1, "%s: max ulp %d" % (tag, ulp.max())
+    assert (ulp != 0).mean() <= 0.03, "%s: %.3f of rows differ" % (tag, (ulp != 0).mean())
+    err = np.abs(y_gpu.astype(np.float64) - y64)
+    tol = 2.0 ** -10 * np.abs(y64) + 2e-3 * np.abs(y64).mean() + 1e-6
+    assert (err <= tol).all(), "%s: |gpu - f64| exceeds half rounding + fp32 slack" % tag
+
+
+AX8_SHAPES = [(37, 256), (64, 4096), (9, 11008), (5, 64)]
+
+
+@pytest.mark.parametrize("d", dt.AX8, ids=IDS(dt.AX8))
+@pytest.mark.parametrize("rows,cols", AX8_SHAPES)
+def test_gemv_int8_path(d, rows, cols):
+    rng = np.random.default_rng(rows * 131 + cols + d)
+    w = rng.normal(0, 0.05, (rows, cols)).astype(np.float16)
+    x = rng.normal(0, 1.0, (1, cols)).astype(np.float16)
+    Wq = o.quantize(d, w)
+    xq = o.quantize_act_q8(x)
+    y_orc, y64 = o.gemv_ax8(d, Wq, rows, cols, xq, want_f64=True)
+    Wd, xd = g.dev(Wq), g.dev(xq)
+    y = g.host(g.gemv(d, Wd, rows, cols, xd, dt.Q8_B32T2))
+    _check_gemv(y, y_orc, y64, "aos")
+    yt = g.host(g.gemv_tiled(d, g.repack(d, Wd, rows, cols), rows, cols, xd))
+    assert np.array_equal(yt.view(np.uint16), y.view(np.uint16)), "tiled layout must give identical bits"
+    bias = rng.normal(0, 0.5, rows).astype(np.float16)
+    yb = g.host(g.gemv(d, Wd, rows, cols, xd, dt.Q8_B32T2, g.dev(bias)))
+    assert np.array_equal(yb.view(np.uint16), o.add(y, bias).view(np.uint16))
+
+
+def test_gemv_int8_rejects_ineligible_weight_type():
+    W = g.empty_u8(4, 128); x = g.empty_u8(1, 4 * 34); y = g.empty_f16(4)
+    rc = g.capi().ifa_gemv(dt.Q3_B32T1A, g.p(W), 4, 128, dt.Q8_B32T2, g.p(x), None, g.p(y), None)
+    assert rc == -1
+    rc = g.capi().ifa_gemv(dt.Q4_B64T1, g.p(W), 4, 96, dt.Q8_B32T2, g.p(x), None, g.p(y), None)
+    assert rc == -1    # cols % 64 (GemvCheckN, tensor_mul.cu:1123)
+
+
+F16X = dt.QUANT + [dt.F16]
+
+
+@pytest.mark.parametrize("d", F16X, ids=IDS(F16X))
+@pytest.mark.parametrize("rows,cols", [(19, 256), (32, 4096), (7, 1000)])
+def test_gemv_fp16_activation_path(d, rows, cols):
+    cap = dt.block_capacity(d)
+    if cols % cap:
+        pytest.skip("cols not a multiple of the block capacity")
+    rng = np.random.default_rng(rows + cols + d)
+    w = rng.normal(0, 0.05, (rows, cols)).astype(np.float16)
+    if d == dt.Q4_B16:
+        w = np.clip(w.astype(np.float32), -0.9, 1.4).astype(np.float16)
+    x = rng.normal(0, 1.0, cols).astype(np.float16)
+    bias = rng.normal(0, 0.5, rows).astype(np.float16)
+    Wq = w if d == dt.F16 else o.quantize(d, w)
+    y_orc, y64 = o.gemv_f16x(d, Wq, rows, cols, x, bias=bias, want_f64=True)
+    y = g.host(g.gemv(d, g.dev(Wq), rows, cols, g.dev(x), dt.F16, g.dev(bias)))
+    # fp32 accumulation in a different order, then half rounding twice (sum, +bias)
+    ulp = g.half_ulp_diff(y, y_orc)
+    assert ulp.max() <= 2 and (ulp != 0).mean() <= 0.1
+    assert np.allclose(y.astype(np.float64), y64, rtol=2e-3, atol=2e-3)
+
+
+# ------------------------------------------------- full-size property checks
+@pytest.mark.parametrize("rows,cols", [(4096, 4096), (11008, 4096), (4096, 11008)])
+def test_gemv_q4_full_size_against_dequantised_fp32(rows, cols):
+    """Llama-2-7B shapes (BASELINE configs[1]): the fused kernel must equal
+    dequant(W) @ dequant(x) computed in fp32 by torch on the same device."""
+    torch.manual_seed(rows + cols)
+    w = (torch.randn(rows, cols, device="cuda") * 0.02).half()
+    x = torch.randn(1, cols, device="cuda").half()
+    Wq = g.quantize(dt.Q4_B32T1A, w)
+    xq = g.quantize_act(x)
+    y = g.gemv(dt.Q4_B32T1A, Wq, rows, cols, xq, dt.Q8_B32T2).float()
+    yt = g.gemv_tiled(dt.Q4_B32T1A, g.repack(dt.Q4_B32T1A, Wq, rows, cols), rows, cols, xq).float()
+    assert torch.equal(y, yt)
+    Wd = g.dequantize(dt.Q4_B32T1A, Wq, cols)                       # half-rounded values
+    xs = xq.view(-1, 34)
+    xscale = xs[:, :2].contiguous().view(torch.float16).float()
+    xd = (xs[:, 2:].contiguous().view(torch.int8).float() * xscale).reshape(-1)
+    # exact value uses unrounded dequantised weights; Wd is rounded to half, so allow that
+    ref = (Wd.double() @ xd.double()).float()
+    err = (y - ref).abs()
+    bound = 2.0 ** -10 * ref.abs() + 4e-3 * ref.abs().mean()
+    assert bool((err <= bound).all()), float((err / bound).max())
+    # quantize -> dequantize round trip stays within half a step (+ fp16 rounding of base/scale)
+    blocks = w.float().view(rows, -1, 32)
+    step = (blocks.max(-1).values - blocks.min(-1).values) / 15
+    rt = (Wd.float().view(rows, -1, 32) - blocks).abs().max(-1).values
+    assert bool((rt <= 0.5 * step * 1.02 + 2e-4).all())
+
+
+# --------------------------------------------------------- norms / elementwise
+@pytest.mark.parametrize("cols", [288, 4096, 1000])
+def test_rmsnorm_bit_exact(cols):
+    rng = np.random.default_rng(cols)
+    x = rng.normal(0, 1.0, (3, cols)).astype(np.float16)
+    w = rng.normal(1, 0.1, cols).astype(np.float16)
+    b = rng.normal(0, 0.1, cols).astype(np.float16)
+    y = g.empty_f16(3, cols)
+    for (wv, bv, mb) in [(w, None, 0.0), (w, b, 0.0), (None, None, 0.0), (w, None, 1.0)]:
+        ia.check(g.capi().ifa_layernorm(0, g.p(g.dev(x)), 3, cols, g.p(g.dev(wv)) if wv is not None else None,
+                                        g.p(g.dev(bv)) if bv is not None else None, mb, 1e-5, g.p(y), g.stream()))
+        exp = o.rmsnorm(x, wv, bv, multi_base=mb)
+        assert np.array_equal(g.host(y).view(np.uint16), exp.view(np.uint16))
+
+
+@pytest.mark.parametrize("cols", [8192, 200])
+def test_stdnorm_bit_exact(cols):
+    rng = np.random.default_rng(cols)
+    x = rng.normal(0.3, 1.0, (2, cols)).astype(np.float16)
+    w = rng.normal(1, 0.1, cols).astype(np.float16)
+    b = rng.normal(0, 0.1, cols).astype(np.float16)
+    y = g.empty_f16(2, cols)
+    ia.check(g.capi().ifa_layernorm(1, g.p(g.dev(x)), 2, cols, g.p(g.dev(w)), g.p(g.dev(b)), 0.0, 1e-5, g.p(y), g.stream()))
+    assert np.array_equal(g.host(y).view(np.uint16), o.stdnorm(x, w, b).view(np.uint16))
+
+
+@pytest.mark.parametrize("order,partial", [(2, 1.0), (1, 1.0), (2, 0.5)])
+def test_rope(order, partial):
+    rng = np.random.default_rng(order)
+    x = rng.normal(0, 1.0, (3, 4, 128)).astype(np.float16)
+    xd = g.dev(x)
+    ia.check(g.capi().ifa_rope(g.p(xd), 128, 4, 3, 57, 10000.0, order, partial, g.stream()))
+    exp = o.rope(x, 57, 10000.0, order, partial)
+    # device powf/cosf/sinf vs libm: angles up to ~60 rad, |x| ~ 1 -> abs error well under 2 half ulps at 1.0
+    assert np.abs(g.host(xd).astype(np.float32) - exp.astype(np.float32)).max() <= 4e-3
+    if partial < 1.0:   # untouched tail
+        assert np.array_equal(g.host(xd)[..., 64:].view(np.uint16), x[..., 64:].view(np.uint16))
+
+
+def test_softmax_masked():
+    rng = np.random.default_rng(5)
+    s = rng.normal(0, 2.0, (2, 3, 77)).astype(np.float16)
+    sd = g.dev(s)
+    ia.check(g.capi().ifa_softmax(g.p(sd), 77, 3, 2, 40, 1.5, g.stream()))
+    exp = o.softmax(s, 40, 1.5)
+    got = g.host(sd)
+    assert np.abs(got.astype(np.float32) - exp.astype(np.float32)).max() <= 2e-3   # device expf vs libm
+    assert (got[:, 0, 41:] == 0).all() and (got[:, 2, 43:] == 0).all()
+    assert np.allclose(got.astype(np.float32).sum(-1), 1.0, atol=5e-3)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_activation(kind):
+    rng = np.random.default_rng(kind)
+    x = rng.normal(0, 2.0, (4, 256)).astype(np.float16)
+    y = g.empty_f16(4, 256)
+    ia.check(g.capi().ifa_activation(kind, 0, g.p(g.dev(x)), 4, 256, g.p(y), g.stream()))
+    exp = o.act(x, kind)
+    assert g.half_ulp_diff(g.host(y), exp).max() <= 1      # device expf/tanhf vs libm
+    y2 = g.empty_f16(4, 128)
+    ia.check(g.capi().ifa_activation(0, 1, g.p(g.dev(x)), 4, 128, g.p(y2), g.stream()))
+    assert g.half_ulp_diff(g.host(y2), o.act(x, 0, is_glu=True)).max() <= 1
+
+
+def test_add_mul_scale_bit_exact():
+    rng = np.random.default_rng(9)
+    a = rng.normal(0, 1.0, (4, 512)).astype(np.float16)
+    b = rng.normal(0, 1.0, (4, 512)).astype(np.float16)
+    c = g.empty_f16(4, 512)
+    ia.check(g.capi().ifa_add(g.p(g.dev(a)), g.p(g.dev(b)), a.size, 0, g.p(c), g.stream()))
+    assert np.array_equal(g.host(c).view(np.uint16), o.add(a, b).view(np.uint16))
+    ia.check(g.capi().ifa_add(g.p(g.dev(a)), g.p(g.dev(b[0])), a.size, 512, g.p(c), g.stream()))
+    assert np.array_equal(g.host(c).view(np.uint16), o.add(a, b[0], 512).view(np.uint16))
+    ia.check(g.capi().ifa_mul(g.p(g.dev(a)), g.p(g.dev(b)), a.size, g.p(c), g.stream()))
+    assert np.array_equal(g.host(c).view(np.uint16), o.mul(a, b).view(np.uint16))
+    ia.check(g.capi().ifa_scale(g.p(g.dev(a)), 0.37, a.size, g.p(c), g.stream()))
+    assert np.array_equal(g.host(c).view(np.uint16), o.scale(a, 0.37).view(np.uint16))
+
+
+def test_argmax_first_max_wins():
+    v = np.zeros(32000, np.float16)
+    v[[77, 31999, 500]] = [3.0, 3.0, 2.0]
+    out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ia.check(g.capi().ifa_argmax(g.p(g.dev(v)), v.size, g.p(out), g.stream()))
+    assert int(out.item()) == 77
+
+
+# ---------------------------------------------------------------- attention
+@pytest.mark.parametrize("kv_dtype", [dt.F16, dt.Q8_B32T2], ids=["kv_f16", "kv_q8"])
+@pytest.mark.parametrize("heads,kv_heads,hd,n_ctx,qt,alibi", [
+    (8, 8, 64, 37, 1, 0), (8, 2, 128, 200, 1, 0), (4, 4, 32, 16, 16, 0), (8, 4, 64, 50, 3, 1)])
+def test_attention(kv_dtype, heads, kv_heads, hd, n_ctx, qt, alibi):
+    rng = np.random.default_rng(heads * 7 + n_ctx)
+    prefix = n_ctx - qt
+    q = rng.normal(0, 1.0, (qt, heads, hd)).astype(np.float16)
+    k = rng.normal(0, 1.0, (n_ctx, kv_heads * hd)).astype(np.float16)
+    v = rng.normal(0, 1.0, (n_ctx, kv_heads * hd)).astype(np.float16)
+    if kv_dtype == dt.Q8_B32T2:
+        kc, vc = o.quantize_act_q8(k), o.quantize_act_q8(v)
+    else:
+        kc, vc = k, v
+    kq_scale = 1.0 if alibi else 2.0
+    exp = o.attention(q, kc, vc, kv_dtype, n_ctx, prefix, heads, kv_heads, hd, kq_scale, bool(alibi), 0, heads)
+    out = g.empty_f16(qt, heads * hd)
+    ia.check(g.capi().ifa_attention(g.p(g.dev(q)), g.p(g.dev(kc)), g.p(g.dev(vc)), kv_dtype, n_ctx, qt, prefix,
+                                    heads, kv_heads, hd, kq_scale, alibi, 0, heads, g.p(out), g.stream()))
+    # P differs by expf implementation and sum order (<= 1 half ulp per weight); O is a convex mix of |v| ~ 1
+    assert np.abs(g.host(out).astype(np.float32) - exp.astype(np.float32)).max() <= 6e-3
