@@ -82,7 +82,7 @@ def _check_gemv(y_gpu, y_orc, y64, tag):
     # both sides are fp32 sums of the same exact terms in different orders:
     # after rounding to half they may differ by at most 1 ulp, and rarely.
     assert ulp.max() <= 1, "%s: max ulp %d" % (tag, ulp.max())
-    assert (ulp != 0).mean() <= 0.03, "%s: %.3f of rows differ" % (tag, (ulp != 0).mean())
+    assert (ulp != 0).sum() <= max(1, 0.03 * ulp.size), "%s: %d of %d rows differ" % (tag, (ulp != 0).sum(), ulp.size)
     err = np.abs(y_gpu.astype(np.float64) - y64)
     tol = 2.0 ** -10 * np.abs(y64) + 2e-3 * np.abs(y64).mean() + 1e-6
     assert (err <= tol).all(), "%s: |gpu - f64| exceeds half rounding + fp32 slack" % tag
@@ -138,7 +138,7 @@ def test_gemv_fp16_activation_path(d, rows, cols):
     y = g.host(g.gemv(d, g.dev(Wq), rows, cols, g.dev(x), dt.F16, g.dev(bias)))
     # fp32 accumulation in a different order, then half rounding twice (sum, +bias)
     ulp = g.half_ulp_diff(y, y_orc)
-    assert ulp.max() <= 2 and (ulp != 0).mean() <= 0.1
+    assert ulp.max() <= 2 and (ulp != 0).sum() <= max(2, 0.1 * ulp.size)
     assert np.allclose(y.astype(np.float64), y64, rtol=2e-3, atol=2e-3)
 
 
