@@ -146,6 +146,72 @@ int ifa_attention(const void *q_f16, const void *kcache, const void *vcache, int
 /* ---- greedy argmax over F16 logits (SampleTokens top-1) ------------------ */
 int ifa_argmax(const void *logits_f16, size_t n, int *out_index_dev, ifa_stream stream);
 
+/* ======================================================================== */
+/* Per-device decode worker: counterpart of GpuInferenceWorker                */
+/* (src/transformer/inference_worker.h:23-62, inference_worker.cc:234-340)    */
+/* for the hyper-parameters of ModelSpec (src/transformer/model.h:72-151).    */
+/* ======================================================================== */
+typedef struct ifa_model ifa_model;
+
+typedef struct {
+    int dim, layers, heads, kv_heads, head_dim, ffn, vocab, max_ctx;
+    int norm_kind;       /* 0 rms, 1 std                      (normalization_function) */
+    int act_kind;        /* 0 silu, 1 gelu, 2 relu            (activation_function)    */
+    int is_glu;          /* informational: w3 present                                   */
+    int rope_order;      /* 0 none, 1 adjacent pairs, 2 half-split (qk_column_order)    */
+    int use_alibi;       /* position_embedding == alibi                                 */
+    int parallel_attn;   /* is_parallel_attn                                            */
+    int share_input;     /* mlp_attn_share_input                                        */
+    float rope_theta, partial_rotary, kq_scale, eps;
+    int kv_dtype;        /* IFA_F16 or IFA_Q8_B32T2 (device_kv_cache_data_type)         */
+    int full_quant_gemv; /* enable_full_quant_gemv (inference_engine.cc:57)             */
+    int experts, moe_top_k, moe_norm_topk;
+    int tp_rank, tp_size;/* tensor-parallel shard of this worker (heads/kv_heads/ffn are per-shard) */
+    int device;          /* HIP device ordinal */
+} ifa_model_config;
+
+/* tensor ids for ifa_model_set_tensor (StdDeviceNetwork, src/transformer/model.h:168-276) */
+enum {
+    IFA_T_EMBD = 0, IFA_T_OUT_NORM = 1, IFA_T_OUT_NORM_B = 2, IFA_T_LM_HEAD = 3,
+    IFA_T_ATTN_NORM = 10, IFA_T_ATTN_NORM_B = 11, IFA_T_WQ = 12, IFA_T_WK = 13, IFA_T_WV = 14, IFA_T_WO = 15,
+    IFA_T_FFN_NORM = 16, IFA_T_FFN_NORM_B = 17, IFA_T_W1 = 18, IFA_T_W2 = 19, IFA_T_W3 = 20, IFA_T_MOE_GATE = 21,
+    IFA_T_WQ_B = 22, IFA_T_WK_B = 23, IFA_T_WV_B = 24, IFA_T_WO_B = 25, IFA_T_W1_B = 26, IFA_T_W2_B = 27, IFA_T_W3_B = 28
+};
+
+int ifa_model_create(const ifa_model_config *cfg, ifa_model **out);
+int ifa_model_destroy(ifa_model *m);
+/* Copy a tensor that is already in its final dtype (reference block layout or F16)
+ * from device memory into the worker; eligible weight matrices are also re-tiled. */
+int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int dtype,
+                         const void *dev_src, size_t rows, size_t cols);
+/* F16 source quantised on the device to target_dtype first
+ * (DeviceTensorBuilder::Build_Quant, src/tensor/device_tensor_builder.cu:383-420). */
+int ifa_model_set_tensor_f16(ifa_model *m, int layer, int tensor_id, int expert, int target_dtype,
+                             const void *dev_src_f16, size_t rows, size_t cols);
+/* allocate KV caches (KVCache::Init, kv_cache.cc:278-319) and scratch */
+int ifa_model_finalize(ifa_model *m);
+int ifa_model_reset(ifa_model *m);
+/* options: "fused" (1), "graph" (1), "rpw_qkv|rpw_wo|rpw_ffn|rpw_w2|rpw_lm" (0 = auto) */
+int ifa_model_set_option(ifa_model *m, const char *name, int value);
+/* 1 if the fused batch-1 decode kernels cover this model, else 0 (+ reason) */
+int ifa_model_fused_supported(ifa_model *m, char *why, size_t why_len);
+/* One Infer() step for one query: n_tokens new tokens at positions
+ * [prefix_len, prefix_len+n_tokens); op-by-op; synchronous.  logits_out_dev (F16
+ * [n_tokens][vocab], nullable) mirrors return_output_tensors; *next_token_host is
+ * the greedy argmax of the last row. */
+int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int prefix_len,
+                      void *logits_out_dev, int *next_token_host);
+/* Greedy batch-1 decode of n_steps tokens starting from first_token at start_pos
+ * (its KV rows [0,start_pos) must already be cached).  Fused kernels, one graph
+ * replay per token, token fed back on the device.  out_tokens_host[n_steps]
+ * receives the generated ids; *elapsed_ms (nullable) the HIP-event time of the
+ * n_steps replays on the worker's stream. */
+int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps,
+                     int *out_tokens_host, float *elapsed_ms);
+/* debugging taps: "logits", "hidden", "kcache", "vcache" (device pointers) */
+int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr, size_t *bytes);
+void *ifa_model_stream(ifa_model *m);
+
 #ifdef __cplusplus
 }
 #endif

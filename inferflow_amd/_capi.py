@@ -76,7 +76,30 @@ SIGNATURES = {
     "ifa_scale": (_i, [_vp, _f, _sz, _vp, _vp]),
     "ifa_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "ifa_argmax": (_i, [_vp, _sz, _vp, _vp]),
+    "ifa_model_create": (_i, [_vp, C.POINTER(_vp)]),
+    "ifa_model_destroy": (_i, [_vp]),
+    "ifa_model_set_tensor": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _sz]),
+    "ifa_model_set_tensor_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _sz]),
+    "ifa_model_finalize": (_i, [_vp]),
+    "ifa_model_reset": (_i, [_vp]),
+    "ifa_model_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "ifa_model_fused_supported": (_i, [_vp, C.c_char_p, _sz]),
+    "ifa_model_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ifa_model_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ifa_model_get_buffer": (_i, [_vp, C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_sz)]),
+    "ifa_model_stream": (_vp, [_vp]),
 }
+
+
+class ModelConfig(C.Structure):
+    """ifa_model_config (include/inferflow_amd.h)"""
+    _fields_ = [(n, C.c_int) for n in (
+        "dim", "layers", "heads", "kv_heads", "head_dim", "ffn", "vocab", "max_ctx",
+        "norm_kind", "act_kind", "is_glu", "rope_order", "use_alibi", "parallel_attn",
+        "share_input")] + [(n, C.c_float) for n in (
+            "rope_theta", "partial_rotary", "kq_scale", "eps")] + [(n, C.c_int) for n in (
+                "kv_dtype", "full_quant_gemv", "experts", "moe_top_k", "moe_norm_topk",
+                "tp_rank", "tp_size", "device")]
 
 
 def _declare(L):

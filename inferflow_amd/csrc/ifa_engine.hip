@@ -1,0 +1,627 @@
+// ifa_engine.hip -- per-device decode worker: the MI355X counterpart of
+// GpuInferenceWorker (src/transformer/inference_worker.cc:234-340, :762-981,
+// :983-1405, :1726-1903, :552-624) for one query at a time.
+//
+//  * ifa_model_forward(): any number of new tokens, op-by-op through the same
+//    C-ABI ops the reference worker would call (TensorOpr / TensorMul
+//    counterparts), host-driven, synchronous on return.  Used for prefill and
+//    as the "unfused" cross-check of the decode kernels.
+//  * ifa_model_decode(): batch-1 greedy decode with the fused kernels of
+//    ifa_decode_kernels.h, one hipGraph replay per token, token fed back on the
+//    device (no host round trip inside a batch of steps).
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ifa_host.h"
+#include "ifa_decode_kernels.h"
+
+using namespace ifa;
+
+namespace {
+
+enum { T_EMBD = 0, T_OUT_NORM = 1, T_OUT_NORM_B = 2, T_LM_HEAD = 3,
+       T_ATTN_NORM = 10, T_ATTN_NORM_B = 11, T_WQ = 12, T_WK = 13, T_WV = 14, T_WO = 15,
+       T_FFN_NORM = 16, T_FFN_NORM_B = 17, T_W1 = 18, T_W2 = 19, T_W3 = 20, T_MOE_GATE = 21,
+       T_WQ_B = 22, T_WK_B = 23, T_WV_B = 24, T_WO_B = 25, T_W1_B = 26, T_W2_B = 27, T_W3_B = 28,
+       T_MAX = 32 };
+
+struct Tensor {
+    int dtype = -1;
+    void *data = nullptr;    // reference layout (AoS blocks / F16), engine-owned
+    void *tiled = nullptr;   // row-local plane layout for the fused kernels (or null)
+    size_t rows = 0, cols = 0;
+    bool present() const { return data != nullptr; }
+};
+
+struct Layer {
+    Tensor t[T_MAX];
+    void *kcache = nullptr, *vcache = nullptr;
+};
+
+} // namespace
+
+struct ifa_model {
+    ifa_model_config cfg;
+    std::vector<Layer> layers;
+    Tensor g[10];
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    // scratch
+    half_t *x = nullptr, *x2 = nullptr, *xn = nullptr, *hn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
+    half_t *att = nullptr, *a = nullptr, *f = nullptr, *t1 = nullptr, *t2 = nullptr, *logits = nullptr;
+    uint8_t *xq = nullptr;
+    int *state = nullptr;          // device: see k_dec_gather
+    int *tokens_dev = nullptr;
+    int *host_pinned = nullptr;    // pinned staging for state / tokens
+    int scratch_tokens = 0;
+    size_t kv_row_bytes = 0;
+    // decode graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    // options
+    int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
+    static constexpr int RING = 1024;
+};
+
+static void free_tensor(Tensor &t)
+{
+    if (t.data) (void)hipFree(t.data);
+    if (t.tiled) (void)hipFree(t.tiled);
+    t = Tensor();
+}
+
+static bool is_q4(int dt) { return dt == Q4_B32T1A || dt == Q4_B32T1B; }
+
+// ------------------------------------------------------------------ dispatch
+template <int EPI, int NORM>
+static int launch_dec_gemv_q4(const DecGemvParams &P, int nsets, int max_rows, int rpw_opt, hipStream_t s)
+{
+    const int nj = (P.nblk + 63) / 64;
+    if (nj < 1 || nj > 8) return ifa_fail(IFA_ERR_ARG, "fused GEMV supports up to 16384 columns (got %d)", P.cols);
+    const int R = nj <= 4 ? 2 : 1;
+    int rpw = rpw_opt > 0 ? rpw_opt : (max_rows + 3071) / 3072;
+    rpw = ((rpw + R - 1) / R) * R;
+    if (rpw < R) rpw = R;
+    DecGemvParams Q = P;
+    Q.rows_per_wave = rpw;
+    const unsigned waves = (unsigned)((max_rows + rpw - 1) / rpw);
+    dim3 grid((waves + (DEC_THREADS / 64) - 1) / (DEC_THREADS / 64), (unsigned)nsets);
+    const size_t smem = xlds_bytes(P.cols);
+#define IFA_DG(NJV, RV) \
+    case NJV: { \
+        auto kern = k_dec_gemv_q4<NJV, RV, EPI, NORM>; \
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        kern<<<grid, dim3(DEC_THREADS), smem, s>>>(Q); \
+    } break;
+    switch (nj) {
+        IFA_DG(1, 2) IFA_DG(2, 2) IFA_DG(3, 2) IFA_DG(4, 2) IFA_DG(5, 1) IFA_DG(6, 1) IFA_DG(7, 1) IFA_DG(8, 1)
+    }
+#undef IFA_DG
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+static int launch_lmhead(const DecLmHeadParams &P, int norm, int rpw_opt, hipStream_t s)
+{
+    const int chunks = P.cols / 8;
+    const int nj = (chunks + 63) / 64;
+    if (P.cols % 8 != 0 || nj < 1 || nj > 8) return ifa_fail(IFA_ERR_ARG, "fused lm_head supports cols %% 8 == 0 and <= 4096 (got %d)", P.cols);
+    DecLmHeadParams Q = P;
+    int rpw = rpw_opt > 0 ? rpw_opt : 4;
+    Q.rows_per_wave = rpw;
+    const unsigned waves = (unsigned)((P.rows + rpw - 1) / rpw);
+    dim3 grid((waves + 7) / 8);
+    const size_t smem = (((size_t)P.cols * 2 + 15) & ~(size_t)15) + 132 * 4 + 16;
+#define IFA_LM(NJV) \
+    case NJV: if (norm) k_dec_lmhead_f16<NJV, 2, 1><<<grid, dim3(DEC_THREADS), smem, s>>>(Q); \
+              else k_dec_lmhead_f16<NJV, 2, 0><<<grid, dim3(DEC_THREADS), smem, s>>>(Q); break;
+    switch (nj) { IFA_LM(1) IFA_LM(2) IFA_LM(3) IFA_LM(4) IFA_LM(5) IFA_LM(6) IFA_LM(7) IFA_LM(8) }
+#undef IFA_LM
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// Can the fused decode path run this model?  (otherwise decode falls back to forward())
+static bool fused_supported(const ifa_model *m, std::string *why)
+{
+    const ifa_model_config &c = m->cfg;
+    auto fail = [&](const char *s) { if (why) *why = s; return false; };
+    if (c.norm_kind != 0) return fail("std-norm models use the op-by-op path");
+    if (c.experts > 0) return fail("MoE uses the op-by-op path");
+    if (c.parallel_attn || c.share_input) return fail("parallel-attention models use the op-by-op path");
+    if (!c.full_quant_gemv) return fail("full_quant_gemv disabled");
+    if (c.head_dim > 256 || 256 % c.head_dim != 0) return fail("head_dim must divide 256");
+    if (c.kv_dtype == Q8_B32T2 && c.head_dim % 32 != 0) return fail("Q8 KV needs head_dim % 32 == 0");
+    if (c.dim % 32 != 0 || c.ffn % 32 != 0) return fail("dim/ffn must be multiples of 32");
+    for (const Layer &L : m->layers) {
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W2};
+        for (int id : ids) {
+            const Tensor &t = L.t[id];
+            if (!t.present() || !is_q4(t.dtype) || !t.tiled) return fail("fused path needs Q4_B32T1 weights (tiled)");
+            if (t.cols > 16384 || (t.cols / 32) % 4 != 0) return fail("fused path needs cols % 128 == 0 and <= 16384");
+        }
+        if (L.t[T_W3].present() && (!is_q4(L.t[T_W3].dtype) || !L.t[T_W3].tiled)) return fail("w3 must be Q4_B32T1");
+        if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present()) return fail("pre-norm weights required");
+        if (L.t[T_WQ].dtype != L.t[T_WK].dtype || L.t[T_WQ].dtype != L.t[T_WV].dtype) return fail("wq/wk/wv dtype mismatch");
+    }
+    const Tensor &lm = m->g[T_LM_HEAD];
+    if (!lm.present() || lm.dtype != F16 || lm.cols > 4096 || lm.cols % 8 != 0) return fail("fused lm_head needs F16 weights, cols <= 4096");
+    if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return fail("F16 embeddings required");
+    return true;
+}
+
+// --------------------------------------------------- fused step (enqueue only)
+static int enqueue_fused_step(ifa_model *m)
+{
+    const ifa_model_config &c = m->cfg;
+    hipStream_t s = m->stream;
+    const int D = c.dim, QD = c.heads * c.head_dim;
+    (void)QD;
+    k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, D, (int)m->g[T_EMBD].rows, m->x);
+    IFA_LAUNCH_CHECK();
+    half_t *x = m->x, *xnext = m->x2;
+    const int rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f);
+    for (int l = 0; l < c.layers; l++) {
+        Layer &L = m->layers[l];
+        // --- QKV
+        DecGemvParams P; memset(&P, 0, sizeof(P));
+        P.x = x; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
+        P.multi_base = 0.0f; P.eps = c.eps; P.cols = D; P.nblk = D / 32;
+        const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
+        half_t *outs[3] = {m->q, m->k, m->v};
+        int max_rows = 0;
+        for (int i = 0; i < 3; i++) {
+            P.set[i].W[0] = (const uint8_t *)L.t[ids[i]].tiled; P.set[i].bias[0] = (const half_t *)L.t[bids[i]].data;
+            P.set[i].y = outs[i]; P.set[i].rows = (int)L.t[ids[i]].rows;
+            max_rows = std::max(max_rows, P.set[i].rows);
+        }
+        int rc = launch_dec_gemv_q4<EPI_PLAIN, 1>(P, 3, max_rows, m->opt_rpw_qkv, s);
+        if (rc) return rc;
+        // --- attention
+        DecAttnParams A; memset(&A, 0, sizeof(A));
+        A.q = m->q; A.k_new = m->k; A.v_new = m->v; A.kcache = (uint8_t *)L.kcache; A.vcache = (uint8_t *)L.vcache;
+        A.state = m->state; A.heads = c.heads; A.kv_heads = c.kv_heads; A.head_dim = c.head_dim;
+        A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale; A.rope_theta = c.rope_theta;
+        A.rope_order = c.rope_order; A.rope_dims = rope_dims; A.rope_cols = rope_dims;
+        A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
+        A.out = m->att; A.max_ctx = c.max_ctx;
+        const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx);
+        if (A.kv_q8) k_dec_attn<true><<<dim3(c.heads), dim3(256), asmem, s>>>(A);
+        else k_dec_attn<false><<<dim3(c.heads), dim3(256), asmem, s>>>(A);
+        IFA_LAUNCH_CHECK();
+        // --- wo + residual
+        memset(&P, 0, sizeof(P));
+        P.x = m->att; P.cols = (int)L.t[T_WO].cols; P.nblk = P.cols / 32; P.eps = c.eps;
+        P.set[0].W[0] = (const uint8_t *)L.t[T_WO].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
+        P.set[0].y = m->a; P.set[0].rows = (int)L.t[T_WO].rows; P.residual = x;
+        rc = launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, 1, P.set[0].rows, m->opt_rpw_wo, s);
+        if (rc) return rc;
+        // --- ffn: w1 (+w3) with act
+        memset(&P, 0, sizeof(P));
+        P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
+        P.eps = c.eps; P.cols = D; P.nblk = D / 32; P.act_kind = c.act_kind;
+        P.set[0].W[0] = (const uint8_t *)L.t[T_W1].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W1_B].data;
+        P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows;
+        if (L.t[T_W3].present()) {
+            P.set[0].W[1] = (const uint8_t *)L.t[T_W3].tiled; P.set[0].bias[1] = (const half_t *)L.t[T_W3_B].data;
+            rc = launch_dec_gemv_q4<EPI_GLU, 1>(P, 1, P.set[0].rows, m->opt_rpw_ffn, s);
+        } else {
+            rc = launch_dec_gemv_q4<EPI_ACT, 1>(P, 1, P.set[0].rows, m->opt_rpw_ffn, s);
+        }
+        if (rc) return rc;
+        // --- w2 + residual
+        memset(&P, 0, sizeof(P));
+        P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = c.eps;
+        P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
+        P.set[0].y = xnext; P.set[0].rows = (int)L.t[T_W2].rows; P.residual = m->a;
+        rc = launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, 1, P.set[0].rows, m->opt_rpw_w2, s);
+        if (rc) return rc;
+        std::swap(x, xnext);
+    }
+    // the layer loop swaps an even/odd number of times; final hidden state is in `x`
+    DecLmHeadParams H; memset(&H, 0, sizeof(H));
+    H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
+    H.eps = c.eps; H.cols = D; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = m->logits;
+    H.rows = (int)m->g[T_LM_HEAD].rows; H.xn_out = m->xn;
+    int rc = launch_lmhead(H, m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, s);
+    if (rc) return rc;
+    k_dec_argmax_advance<<<dim3(1), dim3(1024), 0, s>>>(m->logits, H.rows, m->state, ifa_model::RING);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// ------------------------------------------------ op-by-op forward (any T)
+static int ensure_scratch(ifa_model *m, int T)
+{
+    if (T <= m->scratch_tokens) return IFA_OK;
+    const ifa_model_config &c = m->cfg;
+    auto re = [&](half_t *&p, size_t n) -> int {
+        if (p) IFA_HIP_CHECK(hipFree(p));
+        p = nullptr;
+        IFA_HIP_CHECK(hipMalloc((void **)&p, n * sizeof(half_t)));
+        return IFA_OK;
+    };
+    const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
+    size_t maxcols = std::max(std::max(D, QD), F);
+    int rc;
+    if ((rc = re(m->x, T * D)) || (rc = re(m->x2, T * D)) || (rc = re(m->xn, T * D)) || (rc = re(m->hn, T * D))
+        || (rc = re(m->q, T * QD)) || (rc = re(m->k, T * KVD)) || (rc = re(m->v, T * KVD)) || (rc = re(m->att, T * QD))
+        || (rc = re(m->a, T * D)) || (rc = re(m->f, T * D)) || (rc = re(m->t1, T * F)) || (rc = re(m->t2, T * F))
+        || (rc = re(m->logits, (size_t)T * c.vocab)))
+        return rc;
+    if (m->xq) IFA_HIP_CHECK(hipFree(m->xq));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->xq, (maxcols / 32 + 1) * 34));
+    if (m->tokens_dev) IFA_HIP_CHECK(hipFree(m->tokens_dev));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tokens_dev, sizeof(int) * (size_t)T));
+    m->scratch_tokens = T;
+    // buffers moved: any captured graph is stale
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+    return IFA_OK;
+}
+
+__global__ void __launch_bounds__(256) k_gather_rows(const half_t *__restrict__ embd, const int *__restrict__ tokens,
+                                                     int T, int dim, int vocab, half_t *__restrict__ x)
+{
+    const int t = blockIdx.y;
+    int tok = tokens[t];
+    tok = min(max(tok, 0), vocab - 1);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim; c += gridDim.x * blockDim.x)
+        x[(size_t)t * dim + c] = embd[(size_t)tok * dim + c];
+}
+
+// MatrixMultiplicationEx + MatrixMultiplication dispatch (inference_worker.cc:2337-2432)
+static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const Tensor &bias, half_t *C)
+{
+    if (!W.present()) return ifa_fail(IFA_ERR_STATE, "missing weight tensor");
+    const void *b = bias.present() ? bias.data : nullptr;
+    const size_t K = W.cols, N = W.rows;
+    ifa_stream s = m->stream;
+    const bool use_gemv = (T == 1) && (K % 32 == 0);
+    if (use_gemv && W.dtype != F16 && m->cfg.full_quant_gemv && ax8_eligible(W.dtype)) {
+        int rc = ifa_quantize_act_q8(A, 1, K, m->xq, s);
+        if (rc) return rc;
+        return ifa_gemv(W.dtype, W.data, N, K, Q8_B32T2, m->xq, b, C, s);
+    }
+    // T > 1 (or ineligible types): weights dequantised to half, fp32 accumulate per row
+    // (the reference dequantises the whole tensor and calls cublasGemmEx; same arithmetic)
+    for (int t = 0; t < T; t++) {
+        int rc = ifa_gemv(W.dtype, W.data, N, K, F16, A + (size_t)t * K, b, C + (size_t)t * N, s);
+        if (rc) return rc;
+    }
+    return IFA_OK;
+}
+
+static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y)
+{
+    return ifa_layernorm(m->cfg.norm_kind, x, (size_t)T, (size_t)m->cfg.dim, w.present() ? w.data : nullptr,
+                         b.present() ? b.data : nullptr, 0.0f, m->cfg.eps, y, m->stream);
+}
+
+static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token)
+{
+    const ifa_model_config &c = m->cfg;
+    if (T <= 0 || prefix_len < 0 || prefix_len + T > c.max_ctx)
+        return ifa_fail(IFA_ERR_ARG, "forward: %d tokens at prefix %d exceed max_ctx %d", T, prefix_len, c.max_ctx);
+    int rc = ensure_scratch(m, T);
+    if (rc) return rc;
+    ifa_stream s = m->stream;
+    const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim;
+    if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return ifa_fail(IFA_ERR_STATE, "F16 embeddings not set");
+    IFA_HIP_CHECK(hipMemcpyAsync(m->tokens_dev, tokens_host, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, m->stream));
+    k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->tokens_dev, T, (int)D,
+                                                                      (int)m->g[T_EMBD].rows, m->x);
+    IFA_LAUNCH_CHECK();
+    half_t *x = m->x;
+    const Tensor none;
+    for (int l = 0; l < c.layers; l++) {
+        Layer &L = m->layers[l];
+        const half_t *attn_in = x;
+        if (L.t[T_ATTN_NORM].present()) {
+            if ((rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn))) return rc;
+            attn_in = m->xn;
+        }
+        if ((rc = matmul(m, attn_in, T, L.t[T_WQ], L.t[T_WQ_B], m->q))) return rc;
+        if ((rc = matmul(m, attn_in, T, L.t[T_WK], L.t[T_WK_B], m->k))) return rc;
+        if ((rc = matmul(m, attn_in, T, L.t[T_WV], L.t[T_WV_B], m->v))) return rc;
+        if (c.rope_order != 0) {
+            if ((rc = ifa_rope(m->q, c.head_dim, c.heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
+            if ((rc = ifa_rope(m->k, c.head_dim, c.kv_heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
+        }
+        uint8_t *kdst = (uint8_t *)L.kcache + (size_t)prefix_len * m->kv_row_bytes;
+        uint8_t *vdst = (uint8_t *)L.vcache + (size_t)prefix_len * m->kv_row_bytes;
+        if (c.kv_dtype == Q8_B32T2) {
+            if ((rc = ifa_quantize_act_q8(m->k, T, KVD, kdst, s))) return rc;
+            if ((rc = ifa_quantize_act_q8(m->v, T, KVD, vdst, s))) return rc;
+        } else {
+            IFA_HIP_CHECK(hipMemcpyAsync(kdst, m->k, (size_t)T * m->kv_row_bytes, hipMemcpyDeviceToDevice, m->stream));
+            IFA_HIP_CHECK(hipMemcpyAsync(vdst, m->v, (size_t)T * m->kv_row_bytes, hipMemcpyDeviceToDevice, m->stream));
+        }
+        if ((rc = ifa_attention(m->q, L.kcache, L.vcache, c.kv_dtype, prefix_len + T, T, prefix_len, c.heads, c.kv_heads,
+                                c.head_dim, c.use_alibi ? 1.0f : c.kq_scale, c.use_alibi, c.tp_rank * c.heads,
+                                c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
+        if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
+        if (!c.parallel_attn && !c.share_input)
+            if ((rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
+        const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
+        const half_t *ff_n = ff_in;
+        if (L.t[T_FFN_NORM].present()) {
+            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn))) return rc;
+            ff_n = m->hn;
+        }
+        if ((rc = matmul(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], m->t1))) return rc;
+        if ((rc = ifa_activation(c.act_kind, 0, m->t1, (size_t)T, L.t[T_W1].rows, m->t1, s))) return rc;
+        if (L.t[T_W3].present()) {
+            if ((rc = matmul(m, ff_n, T, L.t[T_W3], L.t[T_W3_B], m->t2))) return rc;
+            if ((rc = ifa_mul(m->t1, m->t2, (size_t)T * L.t[T_W1].rows, m->t1, s))) return rc;
+        }
+        if ((rc = matmul(m, m->t1, T, L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
+        if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
+        if (c.parallel_attn || c.share_input)
+            if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
+        std::swap(m->x, m->f);
+        x = m->x;
+    }
+    const half_t *hfin = x;
+    if (m->g[T_OUT_NORM].present()) {
+        if ((rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn))) return rc;
+        hfin = m->xn;
+    } else {
+        IFA_HIP_CHECK(hipMemcpyAsync(m->xn, x, (size_t)T * D * 2, hipMemcpyDeviceToDevice, m->stream));
+    }
+    const Tensor &lm = m->g[T_LM_HEAD];
+    const size_t V = lm.rows;
+    int t0 = logits_out ? 0 : T - 1;
+    if (logits_out) { if ((rc = matmul(m, hfin, T, lm, none, m->logits))) return rc; }
+    else { if ((rc = matmul(m, hfin + (size_t)t0 * D, 1, lm, none, m->logits + (size_t)t0 * V))) return rc; }
+    if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
+    if ((rc = ifa_argmax(m->logits + (size_t)(T - 1) * V, V, m->state, s))) return rc;
+    IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (next_token) *next_token = m->host_pinned[0];
+    return IFA_OK;
+}
+
+extern "C" {
+
+int ifa_model_create(const ifa_model_config *cfg, ifa_model **out)
+{
+    IFA_REQUIRE(cfg && out, "ifa_model_create: null pointer");
+    IFA_REQUIRE(cfg->dim > 0 && cfg->layers > 0 && cfg->heads > 0 && cfg->kv_heads > 0 && cfg->head_dim > 0
+                && cfg->vocab > 0 && cfg->max_ctx > 0, "ifa_model_create: bad hyper-parameters");
+    IFA_REQUIRE(cfg->heads % cfg->kv_heads == 0, "ifa_model_create: heads %d not a multiple of kv_heads %d", cfg->heads, cfg->kv_heads);
+    IFA_REQUIRE(cfg->kv_dtype == F16 || cfg->kv_dtype == Q8_B32T2, "ifa_model_create: kv dtype %d", cfg->kv_dtype);
+    IFA_REQUIRE(cfg->norm_kind == 0 || cfg->norm_kind == 1, "ifa_model_create: norm_kind %d", cfg->norm_kind);
+    IFA_HIP_CHECK(hipSetDevice(cfg->device));
+    ifa_model *m = new ifa_model();
+    m->cfg = *cfg;
+    if (m->cfg.eps <= 0) m->cfg.eps = 1e-5f;
+    if (m->cfg.kq_scale <= 0) m->cfg.kq_scale = 1.0f;
+    if (m->cfg.partial_rotary <= 0) m->cfg.partial_rotary = 1.0f;
+    if (m->cfg.tp_size <= 0) m->cfg.tp_size = 1;
+    m->layers.resize((size_t)cfg->layers);
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete m; return ifa_fail(IFA_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = m;
+    return IFA_OK;
+}
+
+int ifa_model_destroy(ifa_model *m)
+{
+    if (!m) return IFA_OK;
+    (void)hipSetDevice(m->cfg.device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
+    for (Layer &L : m->layers) {
+        for (Tensor &t : L.t) free_tensor(t);
+        if (L.kcache) (void)hipFree(L.kcache);
+        if (L.vcache) (void)hipFree(L.vcache);
+    }
+    for (Tensor &t : m->g) free_tensor(t);
+    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits};
+    for (half_t **b : bufs) if (*b) (void)hipFree(*b);
+    if (m->xq) (void)hipFree(m->xq);
+    if (m->state) (void)hipFree(m->state);
+    if (m->tokens_dev) (void)hipFree(m->tokens_dev);
+    if (m->host_pinned) (void)hipHostFree(m->host_pinned);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return IFA_OK;
+}
+
+int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int dtype, const void *dev_src,
+                         size_t rows, size_t cols)
+{
+    IFA_REQUIRE(m && dev_src, "ifa_model_set_tensor: null pointer");
+    IFA_REQUIRE(tensor_id >= 0 && tensor_id < T_MAX, "ifa_model_set_tensor: tensor id %d", tensor_id);
+    IFA_REQUIRE(expert < 0, "ifa_model_set_tensor: MoE experts are not supported yet");
+    IFA_REQUIRE(block_capacity(dtype) > 0 && dtype != F32, "ifa_model_set_tensor: dtype %d", dtype);
+    IFA_REQUIRE(cols % (size_t)block_capacity(dtype) == 0, "ifa_model_set_tensor: cols %zu vs block capacity", cols);
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    Tensor *t;
+    if (tensor_id < 10) t = &m->g[tensor_id];
+    else {
+        IFA_REQUIRE(layer >= 0 && layer < m->cfg.layers, "ifa_model_set_tensor: layer %d", layer);
+        t = &m->layers[(size_t)layer].t[tensor_id];
+    }
+    free_tensor(*t);
+    const size_t bytes = rows * ifa_row_bytes(dtype, cols);
+    IFA_HIP_CHECK(hipMalloc(&t->data, bytes));
+    IFA_HIP_CHECK(hipMemcpyAsync(t->data, dev_src, bytes, hipMemcpyDeviceToDevice, m->stream));
+    t->dtype = dtype; t->rows = rows; t->cols = cols;
+    const bool is_matrix = tensor_id == T_WQ || tensor_id == T_WK || tensor_id == T_WV || tensor_id == T_WO
+        || tensor_id == T_W1 || tensor_id == T_W2 || tensor_id == T_W3;
+    if (is_matrix && ax8_eligible(dtype)) {
+        IFA_HIP_CHECK(hipMalloc(&t->tiled, bytes));
+        int rc = ifa_repack_weights(dtype, t->data, rows, cols, t->tiled, m->stream);
+        if (rc) return rc;
+    }
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    return IFA_OK;
+}
+
+int ifa_model_set_tensor_f16(ifa_model *m, int layer, int tensor_id, int expert, int target_dtype,
+                             const void *dev_src_f16, size_t rows, size_t cols)
+{
+    IFA_REQUIRE(m && dev_src_f16, "ifa_model_set_tensor_f16: null pointer");
+    if (target_dtype == F16) return ifa_model_set_tensor(m, layer, tensor_id, expert, F16, dev_src_f16, rows, cols);
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    void *tmp = nullptr;
+    const size_t bytes = rows * ifa_row_bytes(target_dtype, cols);
+    IFA_REQUIRE(bytes > 0, "ifa_model_set_tensor_f16: dtype %d", target_dtype);
+    IFA_HIP_CHECK(hipMalloc(&tmp, bytes));
+    int rc = ifa_quantize(target_dtype, dev_src_f16, rows, cols, tmp, m->stream);   // DeviceTensorBuilder::Build_Quant
+    if (rc == IFA_OK) rc = ifa_model_set_tensor(m, layer, tensor_id, expert, target_dtype, tmp, rows, cols);
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int ifa_model_finalize(ifa_model *m)
+{
+    IFA_REQUIRE(m, "ifa_model_finalize: null model");
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    const ifa_model_config &c = m->cfg;
+    const size_t KVD = (size_t)c.kv_heads * c.head_dim;
+    IFA_REQUIRE(c.kv_dtype != Q8_B32T2 || KVD % 32 == 0, "Q8 KV cache needs kv_dim %% 32 == 0");
+    m->kv_row_bytes = ifa_row_bytes(c.kv_dtype, KVD);
+    for (Layer &L : m->layers) {
+        if (!L.kcache) {   // KVCache::Init (kv_cache.cc:278-319): (kv_dim, max_ctx) per layer
+            IFA_HIP_CHECK(hipMalloc(&L.kcache, m->kv_row_bytes * (size_t)c.max_ctx));
+            IFA_HIP_CHECK(hipMalloc(&L.vcache, m->kv_row_bytes * (size_t)c.max_ctx));
+            IFA_HIP_CHECK(hipMemsetAsync(L.kcache, 0, m->kv_row_bytes * (size_t)c.max_ctx, m->stream));
+            IFA_HIP_CHECK(hipMemsetAsync(L.vcache, 0, m->kv_row_bytes * (size_t)c.max_ctx, m->stream));
+        }
+    }
+    if (!m->state) {
+        IFA_HIP_CHECK(hipMalloc((void **)&m->state, sizeof(int) * (8 + ifa_model::RING)));
+        IFA_HIP_CHECK(hipMemsetAsync(m->state, 0, sizeof(int) * (8 + ifa_model::RING), m->stream));
+        IFA_HIP_CHECK(hipHostMalloc((void **)&m->host_pinned, sizeof(int) * (8 + ifa_model::RING), hipHostMallocDefault));
+    }
+    int rc = ensure_scratch(m, 1);
+    if (rc) return rc;
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->finalized = true;
+    return IFA_OK;
+}
+
+int ifa_model_reset(ifa_model *m)
+{
+    IFA_REQUIRE(m && m->finalized, "ifa_model_reset: model not finalized");
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    for (Layer &L : m->layers) {
+        IFA_HIP_CHECK(hipMemsetAsync(L.kcache, 0, m->kv_row_bytes * (size_t)m->cfg.max_ctx, m->stream));
+        IFA_HIP_CHECK(hipMemsetAsync(L.vcache, 0, m->kv_row_bytes * (size_t)m->cfg.max_ctx, m->stream));
+    }
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return IFA_OK;
+}
+
+int ifa_model_set_option(ifa_model *m, const char *name, int value)
+{
+    IFA_REQUIRE(m && name, "ifa_model_set_option: null pointer");
+    struct { const char *n; int *p; } opts[] = {
+        {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
+        {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}};
+    for (auto &o : opts)
+        if (strcmp(o.n, name) == 0) {
+            *o.p = value;
+            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            return IFA_OK;
+        }
+    return ifa_fail(IFA_ERR_ARG, "ifa_model_set_option: unknown option '%s'", name);
+}
+
+int ifa_model_fused_supported(ifa_model *m, char *why, size_t why_len)
+{
+    IFA_REQUIRE(m, "ifa_model_fused_supported: null model");
+    std::string w;
+    bool ok = fused_supported(m, &w);
+    if (why && why_len) { strncpy(why, w.c_str(), why_len - 1); why[why_len - 1] = 0; }
+    return ok ? 1 : 0;
+}
+
+int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int prefix_len, void *logits_out_dev,
+                      int *next_token_host)
+{
+    IFA_REQUIRE(m && m->finalized, "ifa_model_forward: model not finalized");
+    IFA_REQUIRE(tokens_host, "ifa_model_forward: null tokens");
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    return forward_ops(m, tokens_host, n_tokens, prefix_len, logits_out_dev, next_token_host);
+}
+
+int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, int *out_tokens_host, float *elapsed_ms)
+{
+    IFA_REQUIRE(m && m->finalized, "ifa_model_decode: model not finalized");
+    IFA_REQUIRE(n_steps > 0 && n_steps <= ifa_model::RING, "ifa_model_decode: n_steps %d (max %d per call)", n_steps, ifa_model::RING);
+    IFA_REQUIRE(start_pos >= 0 && start_pos + n_steps <= m->cfg.max_ctx, "ifa_model_decode: positions [%d,%d) exceed max_ctx %d",
+                start_pos, start_pos + n_steps, m->cfg.max_ctx);
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    std::string why;
+    if (!m->opt_fused || !fused_supported(m, &why)) {
+        // op-by-op fallback: same semantics, host-driven
+        int tok = first_token;
+        for (int i = 0; i < n_steps; i++) {
+            int nt = 0;
+            int rc = forward_ops(m, &tok, 1, start_pos + i, nullptr, &nt);
+            if (rc) return rc;
+            if (out_tokens_host) out_tokens_host[i] = nt;
+            tok = nt;
+        }
+        if (elapsed_ms) *elapsed_ms = -1.0f;
+        return IFA_OK;
+    }
+    int rc = ensure_scratch(m, 1);
+    if (rc) return rc;
+    hipStream_t s = m->stream;
+    m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
+    IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
+    if (m->opt_graph && !m->graph_exec) {
+        IFA_HIP_CHECK(hipStreamSynchronize(s));
+        IFA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_fused_step(m);
+        hipGraph_t gph = nullptr;
+        hipError_t e = hipStreamEndCapture(s, &gph);
+        if (rc) { if (gph) (void)hipGraphDestroy(gph); return rc; }
+        if (e != hipSuccess) return ifa_fail(IFA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        if (m->graph) (void)hipGraphDestroy(m->graph);
+        m->graph = gph;
+        IFA_HIP_CHECK(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (elapsed_ms) { IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1)); IFA_HIP_CHECK(hipEventRecord(e0, s)); }
+    for (int i = 0; i < n_steps; i++) {
+        if (m->opt_graph) IFA_HIP_CHECK(hipGraphLaunch(m->graph_exec, s));
+        else if ((rc = enqueue_fused_step(m))) return rc;
+    }
+    if (elapsed_ms) IFA_HIP_CHECK(hipEventRecord(e1, s));
+    IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n_steps, hipMemcpyDeviceToHost, s));
+    IFA_HIP_CHECK(hipStreamSynchronize(s));
+    if (elapsed_ms) { IFA_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    if (out_tokens_host) memcpy(out_tokens_host, m->host_pinned + 8, sizeof(int) * (size_t)n_steps);
+    return IFA_OK;
+}
+
+int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr, size_t *bytes)
+{
+    IFA_REQUIRE(m && name && dptr, "ifa_model_get_buffer: null pointer");
+    const ifa_model_config &c = m->cfg;
+    size_t b = 0; void *p = nullptr;
+    if (!strcmp(name, "logits")) { p = m->logits; b = (size_t)c.vocab * 2; }
+    else if (!strcmp(name, "hidden")) { p = m->xn; b = (size_t)c.dim * 2; }
+    else if (!strcmp(name, "kcache") || !strcmp(name, "vcache")) {
+        IFA_REQUIRE(layer >= 0 && layer < c.layers && m->finalized, "ifa_model_get_buffer: layer %d", layer);
+        p = name[0] == 'k' ? m->layers[(size_t)layer].kcache : m->layers[(size_t)layer].vcache;
+        b = m->kv_row_bytes * (size_t)c.max_ctx;
+    } else return ifa_fail(IFA_ERR_ARG, "ifa_model_get_buffer: unknown buffer '%s'", name);
+    *dptr = p;
+    if (bytes) *bytes = b;
+    return IFA_OK;
+}
+
+void *ifa_model_stream(ifa_model *m) { return m ? (void *)m->stream : nullptr; }
+
+} // extern "C"

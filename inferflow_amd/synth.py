@@ -1,0 +1,82 @@
+"""Synthetic models for measurement and parity tests:
+fp16 source tensors N(0, 0.02) from seed = 1000 + layer*16 + tensor_id, norm
+weights = 1, quantised on the device with the reference rule; tensors below
+tensor_quant_threshold stay F16 (src/transformer/network_builder.cc:1557-1562),
+lm_head stays F16 (network_builder.cc:825-846)."""
+import torch
+
+from . import dtypes as dt
+from . import worker as W
+
+SHAPES = {
+    # data/models/llama2_7b_chat_hf/model_spec.json + config: d=4096 L=32 H=32 ffn=11008 vocab=32000
+    "llama2_7b": dict(dim=4096, layers=32, heads=32, kv_heads=32, head_dim=128, ffn=11008, vocab=32000),
+    # bin/llm_inference.tiny.ini shape (stories15M)
+    "tiny15m": dict(dim=288, layers=6, heads=6, kv_heads=6, head_dim=48, ffn=768, vocab=32000),
+    # small GQA shapes for parity tests
+    "test_gqa": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000),
+    "test_mha": dict(dim=256, layers=3, heads=8, kv_heads=8, head_dim=32, ffn=640, vocab=777),
+}
+
+MATRICES = [(W.T_WQ, "q"), (W.T_WK, "kv"), (W.T_WV, "kv"), (W.T_WO, "o"), (W.T_W1, "up"), (W.T_W3, "up"), (W.T_W2, "down")]
+TENSOR_QUANT_THRESHOLD = 4000000   # ModelSpec::tensor_quant_threshold (src/transformer/model.h:137)
+
+
+def _shape(kind, s):
+    qd, kvd = s["heads"] * s["head_dim"], s["kv_heads"] * s["head_dim"]
+    return {"q": (qd, s["dim"]), "kv": (kvd, s["dim"]), "o": (s["dim"], qd),
+            "up": (s["ffn"], s["dim"]), "down": (s["dim"], s["ffn"])}[kind]
+
+
+def gen_f16(shape, seed, std=0.02, device="cuda"):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    return (torch.randn(shape, generator=gen, device=device, dtype=torch.float32) * std).half()
+
+
+def build(shape_name, wdtype=dt.Q4_B32T1A, kv_dtype=dt.F16, max_ctx=1024, quant_threshold=TENSOR_QUANT_THRESHOLD,
+          std=0.02, keep_host=False, device=0, **overrides):
+    """Returns (worker, host_tensors or None).  host_tensors: {(layer, tid): (dtype, np array, rows, cols)}."""
+    s = dict(SHAPES[shape_name])
+    s.update({k: v for k, v in overrides.items() if k in s})
+    extra = {k: v for k, v in overrides.items() if k not in s}
+    wk = W.DecodeWorker(max_ctx=max_ctx, kv_dtype=kv_dtype, device=device, **s, **extra)
+    host = {} if keep_host else None
+    dev = "cuda:%d" % device
+
+    def put(layer, tid, target, t16):
+        rows, cols = (1, t16.numel()) if t16.dim() == 1 else t16.shape
+        wk.set_tensor_f16(layer, tid, target, t16, rows, cols)
+        if keep_host:
+            host[(layer, tid)] = (target, t16.cpu().view(torch.int16).numpy().view("float16").copy(), rows, cols)
+
+    put(-1, W.T_EMBD, dt.F16, gen_f16((s["vocab"], s["dim"]), 999, std, dev))
+    put(-1, W.T_OUT_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
+    put(-1, W.T_LM_HEAD, dt.F16, gen_f16((s["vocab"], s["dim"]), 998, std, dev))
+    for layer in range(s["layers"]):
+        put(layer, W.T_ATTN_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
+        put(layer, W.T_FFN_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
+        for tid, kind in MATRICES:
+            rows, cols = _shape(kind, s)
+            t16 = gen_f16((rows, cols), 1000 + layer * 16 + tid, std, dev)
+            target = wdtype if rows * cols >= quant_threshold else dt.F16
+            put(layer, tid, target, t16)
+    wk.finalize()
+    return wk, host, s
+
+
+def weight_bytes(shape_name, wdtype=dt.Q4_B32T1A, quant_threshold=TENSOR_QUANT_THRESHOLD):
+    """Algorithmic weight bytes per decoded token, excluding KV."""
+    s = SHAPES[shape_name]
+    per_layer = 0
+    for tid, kind in MATRICES:
+        rows, cols = _shape(kind, s)
+        d = wdtype if rows * cols >= quant_threshold else dt.F16
+        per_layer += rows * dt.row_bytes(d, cols)
+    lm_head = s["vocab"] * s["dim"] * 2
+    return per_layer * s["layers"] + lm_head
+
+
+def kv_bytes_per_ctx_row(shape_name, kv_dtype=dt.F16):
+    s = SHAPES[shape_name]
+    return s["layers"] * 2 * dt.row_bytes(kv_dtype, s["kv_heads"] * s["head_dim"])

@@ -1,0 +1,99 @@
+"""DecodeWorker -- Python handle on the per-device decode worker of the C ABI
+(ifa_model_*), the counterpart of the reference's GpuInferenceWorker
+(src/transformer/inference_worker.h:23-62).  torch is used only to hold device
+memory; all compute happens in libinferflow_amd.so."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi, dtypes as dt
+from ._capi import ModelConfig, check, lib
+
+# tensor ids (include/inferflow_amd.h)
+T_EMBD, T_OUT_NORM, T_OUT_NORM_B, T_LM_HEAD = 0, 1, 2, 3
+T_ATTN_NORM, T_ATTN_NORM_B, T_WQ, T_WK, T_WV, T_WO = 10, 11, 12, 13, 14, 15
+T_FFN_NORM, T_FFN_NORM_B, T_W1, T_W2, T_W3, T_MOE_GATE = 16, 17, 18, 19, 20, 21
+T_WQ_B, T_WK_B, T_WV_B, T_WO_B, T_W1_B, T_W2_B, T_W3_B = 22, 23, 24, 25, 26, 27, 28
+
+_DEFAULTS = dict(norm_kind=0, act_kind=0, is_glu=1, rope_order=2, use_alibi=0, parallel_attn=0, share_input=0,
+                 rope_theta=10000.0, partial_rotary=1.0, kq_scale=1.0, eps=1e-5, kv_dtype=dt.F16,
+                 full_quant_gemv=1, experts=0, moe_top_k=0, moe_norm_topk=1, tp_rank=0, tp_size=1, device=0)
+
+
+class DecodeWorker:
+    def __init__(self, **kw):
+        cfg = ModelConfig()
+        vals = dict(_DEFAULTS)
+        vals.update(kw)
+        for k, v in vals.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().ifa_model_create(C.byref(cfg), C.byref(self._h)))
+
+    # ---- weights -----------------------------------------------------------
+    def set_tensor(self, layer, tid, dtype, dev_tensor, rows, cols):
+        """dev_tensor: torch cuda tensor holding reference-layout blocks (uint8) or F16 values."""
+        check(lib().ifa_model_set_tensor(self._h, layer, tid, -1, dtype, C.c_void_p(dev_tensor.data_ptr()), rows, cols))
+
+    def set_tensor_f16(self, layer, tid, target_dtype, dev_f16, rows=None, cols=None):
+        if rows is None:
+            rows, cols = (1, dev_f16.numel()) if dev_f16.dim() == 1 else dev_f16.shape
+        check(lib().ifa_model_set_tensor_f16(self._h, layer, tid, -1, target_dtype,
+                                             C.c_void_p(dev_f16.data_ptr()), rows, cols))
+
+    def finalize(self):
+        check(lib().ifa_model_finalize(self._h))
+
+    def reset(self):
+        check(lib().ifa_model_reset(self._h))
+
+    def set_option(self, name, value):
+        check(lib().ifa_model_set_option(self._h, name.encode(), int(value)))
+
+    def fused_supported(self):
+        buf = C.create_string_buffer(256)
+        ok = lib().ifa_model_fused_supported(self._h, buf, 256)
+        return bool(ok), buf.value.decode()
+
+    # ---- inference -----------------------------------------------------------
+    def forward(self, tokens, prefix_len, logits_out=None):
+        """One Infer() step (op-by-op).  logits_out: optional torch cuda f16 [T][vocab]."""
+        toks = np.ascontiguousarray(tokens, np.int32)
+        nxt = C.c_int(0)
+        check(lib().ifa_model_forward(self._h, toks.ctypes.data_as(C.c_void_p), toks.size, prefix_len,
+                                      C.c_void_p(logits_out.data_ptr()) if logits_out is not None else None,
+                                      C.byref(nxt)))
+        return nxt.value
+
+    def decode(self, first_token, start_pos, n_steps, timed=True):
+        """Greedy batch-1 decode with the fused kernels; returns (tokens, gpu_ms)."""
+        out = np.zeros(n_steps, np.int32)
+        ms = C.c_float(-1.0)
+        check(lib().ifa_model_decode(self._h, int(first_token), int(start_pos), int(n_steps),
+                                     out.ctypes.data_as(C.c_void_p), C.byref(ms) if timed else None))
+        return out, ms.value
+
+    def buffer(self, name, layer=0):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib().ifa_model_get_buffer(self._h, name.encode(), layer, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_buffer(self, name, layer=0, nbytes=None):
+        p, n = self.buffer(name, layer)
+        n = n if nbytes is None else nbytes
+        out = np.empty(n, np.uint8)
+        check(lib().ifa_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(p), n, None))
+        check(lib().ifa_stream_sync(None))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().ifa_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

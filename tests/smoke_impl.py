@@ -1,23 +1,32 @@
-"""__graft_entry__.smoke(): one small invocation of the hot path on cuda:0,
-checked against the CPU oracle."""
+"""__graft_entry__.smoke(): one small decode of the hot path on cuda:0 (prefill
++ fused graph decode of a tiny Q4 model), checked against the CPU oracle."""
 import numpy as np
 import torch
 
 import oracle as o
-from inferflow_amd import dtypes as dt
+from inferflow_amd import dtypes as dt, synth
 from tests import gpu_util as g
+from tests.model_util import oracle_model_from_host
 
 
 def run():
     assert torch.cuda.is_available(), "smoke() needs a GPU"
-    rng = np.random.default_rng(0)
-    rows, cols = 256, 4096
-    w = rng.normal(0, 0.02, (rows, cols)).astype(np.float16)
-    x = rng.normal(0, 1.0, (1, cols)).astype(np.float16)
-    Wq_gpu = g.quantize(dt.Q4_B32T1A, g.dev(w))
-    assert np.array_equal(g.host(Wq_gpu), o.quantize(dt.Q4_B32T1A, w)), "weight quantizer mismatch"
-    xq_gpu = g.quantize_act(g.dev(x))
-    assert np.array_equal(g.host(xq_gpu), o.quantize_act_q8(x)), "activation quantizer mismatch"
-    y = g.host(g.gemv(dt.Q4_B32T1A, Wq_gpu, rows, cols, xq_gpu, dt.Q8_B32T2))
-    y_orc = o.gemv_ax8(dt.Q4_B32T1A, g.host(Wq_gpu), rows, cols, g.host(xq_gpu))
-    assert g.half_ulp_diff(y, y_orc).max() <= 1, "gemv mismatch"
+    wk, host, s = synth.build("test_gqa", dt.Q4_B32T1A, dt.F16, max_ctx=32, quant_threshold=0, std=0.06, keep_host=True)
+    ok, why = wk.fused_supported()
+    assert ok, why
+    om = oracle_model_from_host(host, s, 32, dt.F16)
+    prompt = np.array([5, 17, 400, 33, 2], np.int32)
+    lg = torch.empty((len(prompt), s["vocab"]), dtype=torch.float16, device="cuda")
+    tok = wk.forward(prompt, 0, lg)
+    tok_o, lg_o = om.forward(prompt, 0)
+    a, b = g.host(lg).astype(np.float32), lg_o.astype(np.float32)
+    cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+    assert cos > 0.9995, cos
+    toks, ms = wk.decode(tok, len(prompt), 4)
+    cur = tok
+    for i in range(4):
+        t_o, l_o = om.forward(np.array([cur], np.int32), len(prompt) + i)
+        top2 = np.sort(l_o[0].astype(np.float32))[-2:]
+        assert int(toks[i]) == t_o or top2[1] - top2[0] <= 0.05, "decode step %d mismatch" % i
+        cur = int(toks[i])
+    wk.close()
