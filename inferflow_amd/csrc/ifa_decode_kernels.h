@@ -386,11 +386,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_f16(const DecLmHeadP
         for (int rr = 0; rr < R; rr++) {
             float acc = 0.0f;
 #pragma unroll
-            for (int j = 0; j < NJ; j++)
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, cur[rr][j][k]),
-                                                 __builtin_bit_cast(half2_t, xr[j][k]), acc, false);
+            for (int j = 0; j < NJ; j++) acc = dot8_f16(cur[rr][j], xr[j], acc);
             acc = wave_sum(acc);
             if (lane == 0 && r + rr < row_end) P.logits[r + rr] = f2h(acc);
         }

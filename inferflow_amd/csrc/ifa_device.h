@@ -42,9 +42,12 @@ __host__ __device__ constexpr bool ax8_eligible(int dt)
 
 // ---- fp16 helpers (RN conversions, like CUDA __float2half_rn) -------------
 __device__ __forceinline__ float h2f(half_t h) { return (float)h; }
-__device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }
+// The empty asm keeps the fp32 value opaque so the compiler cannot fold the
+// producing fmul/fadd and the conversion into v_fma_mixlo_f16, which rounds
+// once from the exact result; the reference rounds to fp32 first, then to fp16.
+__device__ __forceinline__ half_t f2h(float f) { asm volatile("" : "+v"(f)); return (half_t)f; }
 __device__ __forceinline__ float hbits2f(uint16_t b) { return (float)__builtin_bit_cast(half_t, b); }
-__device__ __forceinline__ uint16_t f2hbits(float f) { return __builtin_bit_cast(uint16_t, (half_t)f); }
+__device__ __forceinline__ uint16_t f2hbits(float f) { return __builtin_bit_cast(uint16_t, f2h(f)); }
 
 // ---- wave64 reductions -----------------------------------------------------
 // DPP within 16-lane rows, ds_bpermute across rows.  All lanes get the result.
@@ -88,6 +91,18 @@ __device__ __forceinline__ float half_wave_max(float v)
     v = fmaxf(v, dpp_mirror(v));
     v = fmaxf(v, __shfl_xor(v, 16));
     return v;
+}
+
+// 8 half x 8 half products accumulated in fp32 (products of halfs are exact in fp32)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float dot8_f16(u32x4_t w, u32x4_t x, float acc)
+{
+    const half8v_t wh = __builtin_bit_cast(half8v_t, w);
+    const half8v_t xh = __builtin_bit_cast(half8v_t, x);
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc = __builtin_fmaf((float)wh[i], (float)xh[i], acc);
+    return acc;
 }
 
 __device__ __forceinline__ int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }

@@ -447,6 +447,8 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
         t = &m->layers[(size_t)layer].t[tensor_id];
     }
     free_tensor(*t);
+    // load time: the source may have been produced on another stream (e.g. the caller's default stream)
+    IFA_HIP_CHECK(hipDeviceSynchronize());
     const size_t bytes = rows * ifa_row_bytes(dtype, cols);
     IFA_HIP_CHECK(hipMalloc(&t->data, bytes));
     IFA_HIP_CHECK(hipMemcpyAsync(t->data, dev_src, bytes, hipMemcpyDeviceToDevice, m->stream));
@@ -473,6 +475,7 @@ int ifa_model_set_tensor_f16(ifa_model *m, int layer, int tensor_id, int expert,
     const size_t bytes = rows * ifa_row_bytes(target_dtype, cols);
     IFA_REQUIRE(bytes > 0, "ifa_model_set_tensor_f16: dtype %d", target_dtype);
     IFA_HIP_CHECK(hipMalloc(&tmp, bytes));
+    IFA_HIP_CHECK(hipDeviceSynchronize());   // source may come from another stream
     int rc = ifa_quantize(target_dtype, dev_src_f16, rows, cols, tmp, m->stream);   // DeviceTensorBuilder::Build_Quant
     if (rc == IFA_OK) rc = ifa_model_set_tensor(m, layer, tensor_id, expert, target_dtype, tmp, rows, cols);
     (void)hipStreamSynchronize(m->stream);

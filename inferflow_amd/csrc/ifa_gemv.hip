@@ -239,18 +239,11 @@ __global__ void __launch_bounds__(256) k_gemv_f16w(const half_t *__restrict__ W,
             if (c < chunks) { wreg[j] = wrow[c]; xreg[j] = xv[c]; }
         }
 #pragma unroll
-        for (int j = 0; j < NJ; j++)
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, wreg[j][k]),
-                                             __builtin_bit_cast(half2_t, xreg[j][k]), acc, false);
+        for (int j = 0; j < NJ; j++) acc = dot8_f16(wreg[j], xreg[j], acc);
     } else {
         for (int c = lane; c < chunks; c += 64) {
             u32x4 wv = wrow[c], xx = xv[c];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, wv[k]), __builtin_bit_cast(half2_t, xx[k]),
-                                             acc, false);
+            acc = dot8_f16(wv, xx, acc);
         }
     }
     // ragged tail (cols % 8)

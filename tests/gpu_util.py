@@ -35,8 +35,19 @@ def host(t):
     return t.numpy()
 
 
+_KEEP = []
+
+
 def p(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    """Device pointer of a tensor.  The tensor is kept alive for a while so that
+    `p(dev(x))` on a temporary cannot be recycled by torch's caching allocator
+    before the (asynchronous) kernel has read it."""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        del _KEEP[:128]
+    return C.c_void_p(t.data_ptr())
 
 
 def sync():
