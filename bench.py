@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: greedy batch-1 decode of a Llama-2-7B-shaped model with
+Q4_B32T1A weights (BASELINE.json configs[1]) on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one decoded token (one pass of the fused decode path over the whole
+model).  Weights are synthetic N(0,0.02) tensors quantised on the device with
+the reference rule (inferflow_amd/synth.py); the prompt is 16 random token ids.
+Rank 0 prints ONE JSON line.  Extra keys:
+  roofline      -- dominant kernel (fused W1/W3 GEMV): algorithmic bytes / HIP-event time
+  cpu_baseline  -- the oracle port of the same quantised decode path timed on the host
+                   cores (bounded sample; rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X spec (MI355X_MICROARCH.md)
+PROMPT_LEN = 16
+
+
+def cpu_baseline(wk_host_tensors, shape, n_tokens, threads):
+    """Oracle port (test infrastructure used as the measured CPU baseline, never as the product)."""
+    import numpy as np
+    import oracle as o
+    from inferflow_amd import dtypes as dt
+    max_ctx = PROMPT_LEN + n_tokens + 4
+    m = o.Model(dim=shape["dim"], layers=shape["layers"], heads=shape["heads"], kv_heads=shape["kv_heads"],
+                head_dim=shape["head_dim"], ffn=shape["ffn"], vocab=shape["vocab"], max_ctx=max_ctx, kv_dtype=dt.F16)
+    for (layer, tid), (dtype, arr, rows, cols) in wk_host_tensors.items():
+        m.set_tensor(max(layer, 0), tid, dtype, arr, rows, cols)
+    rng = np.random.default_rng(42)
+    prompt = rng.integers(3, shape["vocab"], 4).astype(np.int32)
+    tok = 0
+    for i, t in enumerate(prompt):       # decode-path prompt feed (T=1), untimed
+        tok, _ = m.forward(np.array([t], np.int32), i, want_logits=False, nthreads=threads)
+    t0 = time.perf_counter()
+    for i in range(n_tokens):
+        tok, _ = m.forward(np.array([tok], np.int32), len(prompt) + i, want_logits=False, nthreads=threads)
+    dt_s = time.perf_counter() - t0
+    return n_tokens / dt_s, dt_s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--shape", default="llama2_7b")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=0, help="CPU baseline sample size (0 = auto)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from inferflow_amd import dtypes as dt, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    else:
+        torch.cuda.set_device(0)
+
+    from inferflow_amd import parallel
+    steps, warmup = args.steps, args.warmup
+    max_ctx = PROMPT_LEN + warmup + steps + 8
+    t_build = time.perf_counter()
+    runner = parallel.build_runner(args.shape, dt.Q4_B32T1A, dt.F16, max_ctx, world, rank, local_rank)
+    t_build = time.perf_counter() - t_build
+
+    rng = np.random.default_rng(42)
+    prompt = rng.integers(3, runner.shape["vocab"], PROMPT_LEN).astype(np.int32)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # prefill (timed separately; op-by-op path)
+    barrier()
+    t0 = time.perf_counter()
+    tok = runner.prefill(prompt)
+    barrier()
+    prefill_s = time.perf_counter() - t0
+
+    toks_w, _ = runner.decode(tok, PROMPT_LEN, warmup) if warmup > 0 else ([tok], 0.0)
+    tok = int(toks_w[-1])
+    barrier()
+    t0 = time.perf_counter()
+    toks, gpu_ms = runner.decode(tok, PROMPT_LEN + warmup, steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    tok_s = steps / wall
+    n_avg = PROMPT_LEN + warmup + steps / 2.0
+    w_bytes = synth.weight_bytes(args.shape, dt.Q4_B32T1A)
+    kv_bytes = synth.kv_bytes_per_ctx_row(args.shape, dt.F16)
+    bytes_per_token = w_bytes + kv_bytes * n_avg
+    out = {
+        "metric": "decode tokens/sec, Llama-2-7B Q4 batch=1 greedy (whole job)",
+        "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": wall * 1e3 / steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "i8 (Q8 activations x Q4 weights, i32 dot, f32 scale, f16 I/O)",
+        "data": "synthetic",
+        "config": {"workload": "%s decode, Q4_B32T1A weights + F16 lm_head, F16 KV cache, batch 1 greedy, "
+                               "%d-token prompt, context %d..%d" % (args.shape, PROMPT_LEN, PROMPT_LEN + warmup,
+                                                                  PROMPT_LEN + warmup + steps),
+                   "parallelism": "tp%d" % world if world > 1 else "single", "weights_bytes": w_bytes,
+                   "bytes_per_token": bytes_per_token},
+        "gpu_event_ms_per_step": gpu_ms / steps if gpu_ms and gpu_ms > 0 else None,
+        "token_hbm_GBps": bytes_per_token * tok_s / 1e9,
+        "token_roofline_frac": bytes_per_token * tok_s / 1e9 / HBM_PEAK_GBPS,
+        "prefill_tok_s": PROMPT_LEN / prefill_s,
+        "build_s": t_build,
+        "last_tokens": [int(t) for t in toks[-4:]],
+    }
+    # ---- roofline of the dominant kernel, timed live with HIP events on the worker's stream
+    if world == 1 and runner.worker is not None:
+        s = runner.shape
+        ffn_rows, d = s["ffn"], s["dim"]
+        ffn13_bytes = 2 * ffn_rows * dt.row_bytes(dt.Q4_B32T1A, d)
+        us = runner.worker.time_kernel(3, 320)
+        per_kernel = {}
+        names = ["qkv", "attn", "wo", "ffn13", "w2", "lm_head"]
+        kb = [(s["heads"] + 2 * s["kv_heads"]) * s["head_dim"] * dt.row_bytes(dt.Q4_B32T1A, d), None,
+              d * dt.row_bytes(dt.Q4_B32T1A, s["heads"] * s["head_dim"]), ffn13_bytes,
+              d * dt.row_bytes(dt.Q4_B32T1A, ffn_rows), s["vocab"] * d * 2]
+        for i, nm in enumerate(names):
+            u = runner.worker.time_kernel(i, 160)
+            per_kernel[nm] = {"us": u, "GBps": (kb[i] / u / 1e3) if kb[i] else None}
+        out["roofline"] = {"bound": "hbm", "kernel": "k_dec_gemv_q4<EPI_GLU> (fused RMSNorm+Q8 quant+W1/W3 GEMV+SiLU*mul)",
+                           "achieved": ffn13_bytes / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": None,
+                           "bytes_per_launch": ffn13_bytes, "us_per_launch": us}
+        out["kernels"] = per_kernel
+    # ---- CPU baseline (oracle port) on a bounded sample
+    if world == 1 and not args.no_cpu_baseline and runner.worker is not None:
+        try:
+            threads = min(os.cpu_count() or 1, 128)
+            host = runner.export_host_tensors()
+            n_cpu = args.cpu_tokens or 8
+            v, secs = cpu_baseline(host, runner.shape, n_cpu, threads)
+            if secs < 5 and not args.cpu_tokens:      # fast host: take a longer sample (~10-30 s)
+                n_cpu = int(min(256, max(8, 15.0 / (secs / n_cpu))))
+                v, secs = cpu_baseline(host, runner.shape, n_cpu, threads)
+            out["cpu_baseline"] = {"value": v, "unit": "tokens/s", "cores": threads, "kind": "port",
+                                   "sample": "%s Q4 decode of %d tokens after a 4-token prompt, oracle C port "
+                                             "(OpenMP), %.1f s" % (args.shape, n_cpu, secs)}
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
+                                   "sample": "failed: %r" % (e,)}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -211,6 +211,12 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps,
 /* debugging taps: "logits", "hidden", "kcache", "vcache" (device pointers) */
 int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr, size_t *bytes);
 void *ifa_model_stream(ifa_model *m);
+/* reference-layout copy of a loaded tensor (device pointer); returns 1 if the tensor is not set */
+int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols);
+/* Average duration (HIP events on the worker's stream) of `iters` back-to-back
+ * launches of one fused decode kernel, rotating over the layers' weights:
+ * which = 0 qkv, 1 attention, 2 wo, 3 ffn w1/w3, 4 w2, 5 lm_head.  For bench.py's roofline. */
+int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,8 @@ SIGNATURES = {
     "ifa_model_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ifa_model_get_buffer": (_i, [_vp, C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "ifa_model_stream": (_vp, [_vp]),
+    "ifa_model_time_kernel": (_i, [_vp, _i, _i, _vp]),
+    "ifa_model_get_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
 }
 
 

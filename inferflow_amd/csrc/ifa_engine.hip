@@ -152,81 +152,107 @@ static bool fused_supported(const ifa_model *m, std::string *why)
 }
 
 // --------------------------------------------------- fused step (enqueue only)
+static int launch_qkv(ifa_model *m, int l, const half_t *x)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    DecGemvParams P; memset(&P, 0, sizeof(P));
+    P.x = x; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
+    P.multi_base = 0.0f; P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32;
+    const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
+    half_t *outs[3] = {m->q, m->k, m->v};
+    int max_rows = 0;
+    for (int i = 0; i < 3; i++) {
+        P.set[i].W[0] = (const uint8_t *)L.t[ids[i]].tiled; P.set[i].bias[0] = (const half_t *)L.t[bids[i]].data;
+        P.set[i].y = outs[i]; P.set[i].rows = (int)L.t[ids[i]].rows;
+        max_rows = std::max(max_rows, P.set[i].rows);
+    }
+    return launch_dec_gemv_q4<EPI_PLAIN, 1>(P, 3, max_rows, m->opt_rpw_qkv, m->stream);
+}
+
+static int launch_attn(ifa_model *m, int l)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    const int rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f);
+    DecAttnParams A; memset(&A, 0, sizeof(A));
+    A.q = m->q; A.k_new = m->k; A.v_new = m->v; A.kcache = (uint8_t *)L.kcache; A.vcache = (uint8_t *)L.vcache;
+    A.state = m->state; A.heads = c.heads; A.kv_heads = c.kv_heads; A.head_dim = c.head_dim;
+    A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale; A.rope_theta = c.rope_theta;
+    A.rope_order = c.rope_order; A.rope_dims = rope_dims; A.rope_cols = rope_dims;
+    A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
+    A.out = m->att; A.max_ctx = c.max_ctx;
+    const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx);
+    if (A.kv_q8) k_dec_attn<true><<<dim3(c.heads), dim3(256), asmem, m->stream>>>(A);
+    else k_dec_attn<false><<<dim3(c.heads), dim3(256), asmem, m->stream>>>(A);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+static int launch_wo(ifa_model *m, int l, const half_t *x)
+{
+    Layer &L = m->layers[(size_t)l];
+    DecGemvParams P; memset(&P, 0, sizeof(P));
+    P.x = m->att; P.cols = (int)L.t[T_WO].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
+    P.set[0].W[0] = (const uint8_t *)L.t[T_WO].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
+    P.set[0].y = m->a; P.set[0].rows = (int)L.t[T_WO].rows; P.residual = x;
+    return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, 1, P.set[0].rows, m->opt_rpw_wo, m->stream);
+}
+
+static int launch_ffn13(ifa_model *m, int l)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    DecGemvParams P; memset(&P, 0, sizeof(P));
+    P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
+    P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32; P.act_kind = c.act_kind;
+    P.set[0].W[0] = (const uint8_t *)L.t[T_W1].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W1_B].data;
+    P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows;
+    if (L.t[T_W3].present()) {
+        P.set[0].W[1] = (const uint8_t *)L.t[T_W3].tiled; P.set[0].bias[1] = (const half_t *)L.t[T_W3_B].data;
+        return launch_dec_gemv_q4<EPI_GLU, 1>(P, 1, P.set[0].rows, m->opt_rpw_ffn, m->stream);
+    }
+    return launch_dec_gemv_q4<EPI_ACT, 1>(P, 1, P.set[0].rows, m->opt_rpw_ffn, m->stream);
+}
+
+static int launch_w2(ifa_model *m, int l, half_t *xnext)
+{
+    Layer &L = m->layers[(size_t)l];
+    DecGemvParams P; memset(&P, 0, sizeof(P));
+    P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
+    P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
+    P.set[0].y = xnext; P.set[0].rows = (int)L.t[T_W2].rows; P.residual = m->a;
+    return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, 1, P.set[0].rows, m->opt_rpw_w2, m->stream);
+}
+
+static int launch_lm(ifa_model *m, const half_t *x)
+{
+    const ifa_model_config &c = m->cfg;
+    DecLmHeadParams H; memset(&H, 0, sizeof(H));
+    H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
+    H.eps = c.eps; H.cols = c.dim; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = m->logits;
+    H.rows = (int)m->g[T_LM_HEAD].rows; H.xn_out = m->xn;
+    return launch_lmhead(H, m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, m->stream);
+}
+
 static int enqueue_fused_step(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
     hipStream_t s = m->stream;
-    const int D = c.dim, QD = c.heads * c.head_dim;
-    (void)QD;
-    k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, D, (int)m->g[T_EMBD].rows, m->x);
+    k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows, m->x);
     IFA_LAUNCH_CHECK();
     half_t *x = m->x, *xnext = m->x2;
-    const int rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f);
+    int rc;
     for (int l = 0; l < c.layers; l++) {
-        Layer &L = m->layers[l];
-        // --- QKV
-        DecGemvParams P; memset(&P, 0, sizeof(P));
-        P.x = x; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
-        P.multi_base = 0.0f; P.eps = c.eps; P.cols = D; P.nblk = D / 32;
-        const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
-        half_t *outs[3] = {m->q, m->k, m->v};
-        int max_rows = 0;
-        for (int i = 0; i < 3; i++) {
-            P.set[i].W[0] = (const uint8_t *)L.t[ids[i]].tiled; P.set[i].bias[0] = (const half_t *)L.t[bids[i]].data;
-            P.set[i].y = outs[i]; P.set[i].rows = (int)L.t[ids[i]].rows;
-            max_rows = std::max(max_rows, P.set[i].rows);
-        }
-        int rc = launch_dec_gemv_q4<EPI_PLAIN, 1>(P, 3, max_rows, m->opt_rpw_qkv, s);
-        if (rc) return rc;
-        // --- attention
-        DecAttnParams A; memset(&A, 0, sizeof(A));
-        A.q = m->q; A.k_new = m->k; A.v_new = m->v; A.kcache = (uint8_t *)L.kcache; A.vcache = (uint8_t *)L.vcache;
-        A.state = m->state; A.heads = c.heads; A.kv_heads = c.kv_heads; A.head_dim = c.head_dim;
-        A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale; A.rope_theta = c.rope_theta;
-        A.rope_order = c.rope_order; A.rope_dims = rope_dims; A.rope_cols = rope_dims;
-        A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
-        A.out = m->att; A.max_ctx = c.max_ctx;
-        const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx);
-        if (A.kv_q8) k_dec_attn<true><<<dim3(c.heads), dim3(256), asmem, s>>>(A);
-        else k_dec_attn<false><<<dim3(c.heads), dim3(256), asmem, s>>>(A);
-        IFA_LAUNCH_CHECK();
-        // --- wo + residual
-        memset(&P, 0, sizeof(P));
-        P.x = m->att; P.cols = (int)L.t[T_WO].cols; P.nblk = P.cols / 32; P.eps = c.eps;
-        P.set[0].W[0] = (const uint8_t *)L.t[T_WO].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
-        P.set[0].y = m->a; P.set[0].rows = (int)L.t[T_WO].rows; P.residual = x;
-        rc = launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, 1, P.set[0].rows, m->opt_rpw_wo, s);
-        if (rc) return rc;
-        // --- ffn: w1 (+w3) with act
-        memset(&P, 0, sizeof(P));
-        P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
-        P.eps = c.eps; P.cols = D; P.nblk = D / 32; P.act_kind = c.act_kind;
-        P.set[0].W[0] = (const uint8_t *)L.t[T_W1].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W1_B].data;
-        P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows;
-        if (L.t[T_W3].present()) {
-            P.set[0].W[1] = (const uint8_t *)L.t[T_W3].tiled; P.set[0].bias[1] = (const half_t *)L.t[T_W3_B].data;
-            rc = launch_dec_gemv_q4<EPI_GLU, 1>(P, 1, P.set[0].rows, m->opt_rpw_ffn, s);
-        } else {
-            rc = launch_dec_gemv_q4<EPI_ACT, 1>(P, 1, P.set[0].rows, m->opt_rpw_ffn, s);
-        }
-        if (rc) return rc;
-        // --- w2 + residual
-        memset(&P, 0, sizeof(P));
-        P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = c.eps;
-        P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
-        P.set[0].y = xnext; P.set[0].rows = (int)L.t[T_W2].rows; P.residual = m->a;
-        rc = launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, 1, P.set[0].rows, m->opt_rpw_w2, s);
-        if (rc) return rc;
+        if ((rc = launch_qkv(m, l, x))) return rc;
+        if ((rc = launch_attn(m, l))) return rc;
+        if ((rc = launch_wo(m, l, x))) return rc;
+        if ((rc = launch_ffn13(m, l))) return rc;
+        if ((rc = launch_w2(m, l, xnext))) return rc;
         std::swap(x, xnext);
     }
-    // the layer loop swaps an even/odd number of times; final hidden state is in `x`
-    DecLmHeadParams H; memset(&H, 0, sizeof(H));
-    H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
-    H.eps = c.eps; H.cols = D; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = m->logits;
-    H.rows = (int)m->g[T_LM_HEAD].rows; H.xn_out = m->xn;
-    int rc = launch_lmhead(H, m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, s);
-    if (rc) return rc;
-    k_dec_argmax_advance<<<dim3(1), dim3(1024), 0, s>>>(m->logits, H.rows, m->state, ifa_model::RING);
+    if ((rc = launch_lm(m, x))) return rc;
+    k_dec_argmax_advance<<<dim3(1), dim3(1024), 0, s>>>(m->logits, (int)m->g[T_LM_HEAD].rows, m->state, ifa_model::RING);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
@@ -626,5 +652,58 @@ int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr,
 }
 
 void *ifa_model_stream(ifa_model *m) { return m ? (void *)m->stream : nullptr; }
+
+int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols)
+{
+    IFA_REQUIRE(m && tensor_id >= 0 && tensor_id < T_MAX, "ifa_model_get_tensor: bad arguments");
+    const Tensor *t;
+    if (tensor_id < 10) t = &m->g[tensor_id];
+    else {
+        IFA_REQUIRE(layer >= 0 && layer < m->cfg.layers, "ifa_model_get_tensor: layer %d", layer);
+        t = &m->layers[(size_t)layer].t[tensor_id];
+    }
+    if (dtype) *dtype = t->dtype;
+    if (dptr) *dptr = t->data;
+    if (rows) *rows = t->rows;
+    if (cols) *cols = t->cols;
+    return t->present() ? IFA_OK : 1;   /* 1 = tensor not set (not an error) */
+}
+
+int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
+{
+    IFA_REQUIRE(m && m->finalized && avg_us, "ifa_model_time_kernel: bad arguments");
+    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 5, "ifa_model_time_kernel: which %d iters %d", which, iters);
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    std::string why;
+    if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
+    int rc = ensure_scratch(m, 1);
+    if (rc) return rc;
+    hipStream_t s = m->stream;
+    m->host_pinned[0] = 1; m->host_pinned[1] = std::min(m->cfg.max_ctx - 1, 64); m->host_pinned[2] = 0;
+    IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
+    auto one = [&](int i) -> int {
+        const int l = i % m->cfg.layers;     // rotate over layers: distinct weights every launch
+        switch (which) {
+        case 0: return launch_qkv(m, l, m->x);
+        case 1: return launch_attn(m, l);
+        case 2: return launch_wo(m, l, m->x);
+        case 3: return launch_ffn13(m, l);
+        case 4: return launch_w2(m, l, m->x2);
+        default: return launch_lm(m, m->x);
+        }
+    };
+    for (int i = 0; i < 3; i++) if ((rc = one(i))) return rc;
+    hipEvent_t e0, e1;
+    IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1));
+    IFA_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; i++) if ((rc = one(i))) return rc;
+    IFA_HIP_CHECK(hipEventRecord(e1, s));
+    IFA_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    IFA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = ms * 1000.0f / (float)iters;
+    return IFA_OK;
+}
 
 } // extern "C"

@@ -74,6 +74,27 @@ class DecodeWorker:
                                      out.ctypes.data_as(C.c_void_p), C.byref(ms) if timed else None))
         return out, ms.value
 
+    def time_kernel(self, which, iters=200):
+        """avg microseconds per launch of one fused kernel (0 qkv, 1 attn, 2 wo, 3 ffn13, 4 w2, 5 lm_head)"""
+        us = C.c_float(0)
+        check(lib().ifa_model_time_kernel(self._h, which, iters, C.byref(us)))
+        return us.value
+
+    def get_tensor_host(self, layer, tid):
+        """(dtype, uint8/uint16 numpy copy, rows, cols) of a loaded tensor in reference layout, or None."""
+        d, p, r, c = C.c_int(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+        rc = lib().ifa_model_get_tensor(self._h, layer, tid, C.byref(d), C.byref(p), C.byref(r), C.byref(c))
+        if rc == 1:
+            return None
+        check(rc)
+        nbytes = r.value * dt.row_bytes(d.value, c.value)
+        out = np.empty(nbytes, np.uint8)
+        check(lib().ifa_memcpy_d2h(out.ctypes.data_as(C.c_void_p), p, nbytes, None))
+        check(lib().ifa_stream_sync(None))
+        if d.value == dt.F16:
+            out = out.view(np.uint16)
+        return d.value, out, r.value, c.value
+
     def buffer(self, name, layer=0):
         p, n = C.c_void_p(), C.c_size_t()
         check(lib().ifa_model_get_buffer(self._h, name.encode(), layer, C.byref(p), C.byref(n)))
