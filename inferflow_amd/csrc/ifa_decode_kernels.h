@@ -7,8 +7,9 @@
 //   k_dec_gemv<WO>    : [Q8 act-quant] + Wo GEMV + bias + residual add
 //   k_dec_gemv<FFN13> : [RMSNorm -> quant] + W1,W3 GEMV + act(t1)*t2
 //   k_dec_gemv<W2>    : [quant] + W2 GEMV + bias + residual add(s)
-// plus embedding gather, final-norm + F16 lm_head GEMV and a device-side greedy
-// argmax that also advances the position, so a whole step is graph-replayable.
+// plus embedding gather (+ the step's RoPE table), final-norm + F16 lm_head GEMV
+// and a device-side greedy argmax that also advances the position, so a whole
+// step is graph-replayable.
 //
 // Rounding points are the reference's (every op boundary is an F16 tensor); the
 // prologue reproduces Tensor_RmsNorm_Kernel's partial-sum order exactly, so the
@@ -17,8 +18,11 @@
 // Weight rows are streamed from the row-local plane layout (ifa_tiled.h):
 // lane l owns blocks l+64j of every row, issues one aligned 16-byte load per
 // block plus a 4-byte (base,scale) load, and keeps its slice of the int8
-// activation in registers for all rows it processes.  The first batch of weight
-// loads is issued BEFORE the prologue so HBM latency overlaps the norm/quant.
+// activation in registers for all rows it processes.  Each kernel runs ONE
+// resident wave set (<= 2 workgroups per CU); a wave walks row batches
+// b = wave, wave+W, ... so the prologue is paid once, the first batch of weight
+// loads is issued BEFORE the prologue (HBM latency overlaps norm/quant) and the
+// next batch is always in flight while the current one is reduced.
 #pragma once
 #include "ifa_device.h"
 #include "ifa_math.h"
@@ -30,7 +34,23 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
+// q = roundf(v / qs) exactly as Tensor_QuantizeQ8_B32T2_Alg2_Kernel computes it, without
+// paying an IEEE division per element: t = v * (1/qs) is within a few ulp of v/qs, so
+// round-to-nearest of t equals roundf(v/qs) unless t sits within 2^-9 of a half-integer
+// (then the true division decides).  |v/qs| <= 127 so 2^-9 dwarfs the ~2^-16 error of t.
+__device__ __forceinline__ int q8_round_div(float v, float qs, float rqs)
+{
+    const float t = v * rqs;
+    const float k = __builtin_rintf(t);
+    if (__builtin_expect(fabsf(fabsf(t - k) - 0.5f) < 0.001953125f, 0)) return (int)roundf(v / qs);
+    return (int)k;
+}
+
+#ifndef IFA_NT_WEIGHTS
+#define IFA_NT_WEIGHTS 1            // stream weights with the non-temporal policy (read once per token)
+#endif
 constexpr int DEC_THREADS = 512;   // 8 waves per workgroup
+constexpr int DEC_WAVES = DEC_THREADS / 64;
 
 // ------------------------------------------------------------------ LDS image
 // of the (normalised and) quantised activation vector
@@ -39,12 +59,18 @@ struct XLds {
     float *scale;    // [cols/32]  fp32 value of the fp16-rounded block scale
     float *xsum;     // [cols/32]  sum of the 32 int8 codes (exact in fp32)
     float *part;     // [128] partial sums + [4] stats
+    half_t *xh;      // [cols] staged input
 };
 
 __host__ __device__ inline size_t xlds_bytes(int cols)
 {
     size_t nb = (size_t)cols / 32;
-    return ((size_t)cols + 15) / 16 * 16 + nb * 8 + 132 * 4 + 16;
+    size_t off = ((size_t)cols + 15) / 16 * 16 + nb * 8;
+    off = (off + 15) / 16 * 16;
+    off += 132 * 4;
+    off = (off + 15) / 16 * 16;
+    off += (size_t)cols * 2;
+    return off + 16;
 }
 
 __device__ __forceinline__ XLds xlds_carve(char *smem, int cols)
@@ -56,80 +82,119 @@ __device__ __forceinline__ XLds xlds_carve(char *smem, int cols)
     l.scale = reinterpret_cast<float *>(smem + off); off += nb * 4;
     l.xsum = reinterpret_cast<float *>(smem + off); off += nb * 4;
     off = (off + 15) / 16 * 16;
-    l.part = reinterpret_cast<float *>(smem + off);
+    l.part = reinterpret_cast<float *>(smem + off); off += 132 * 4;
+    off = (off + 15) / 16 * 16;
+    l.xh = reinterpret_cast<half_t *>(smem + off);
     return l;
 }
 
 // Prologue shared by every decode GEMV kernel.  NORM: 0 none, 1 RMS.
 //   xn = NORM ? half(rms(x)) : x ;  Q8_B32T2 quantisation of xn exactly as
 //   Tensor_QuantizeQ8_B32T2_Alg2_Kernel (src/kernels/tensor_quant.h:44-82).
-// Must be called by all DEC_THREADS threads.  cols % 32 == 0.
-template <int NORM>
-__device__ __forceinline__ void dec_prologue(const half_t *__restrict__ x, const half_t *__restrict__ nw,
-                                             const half_t *__restrict__ nb, float multi_base, float eps, int cols,
-                                             const XLds &L, half_t *__restrict__ xn_out)
-{
-    const int tid = threadIdx.x;
-    float scale = 1.0f;
-    if constexpr (NORM == 1) {
-        if (tid < 128) L.part[tid] = rms_partial(x, cols, tid, 128);
-        __syncthreads();
-        if (tid == 0) L.part[128] = rms_scale_from_partials(L.part, 128, cols, eps);
-        __syncthreads();
-        scale = L.part[128];
+// Split in two so that the activation loads are the FIRST memory operations of
+// the kernel (loads return in issue order per wave: issued after the weight
+// stream they would only arrive once that stream has drained).
+//   XPre pre; pre.issue(...);   ... issue weight loads ...;   pre.finish(...);
+// Must be executed by all DEC_THREADS threads.  cols % 32 == 0, cols <= 8*DEC_THREADS*MAXC.
+template <int NORM, int MAXC>
+struct XPre {
+    half8_t xv[MAXC];
+    half8_t wv[NORM ? MAXC : 1], bv[NORM ? MAXC : 1];
+
+    __device__ __forceinline__ void issue(const half_t *__restrict__ x, const half_t *__restrict__ nw,
+                                          const half_t *__restrict__ nb, int cols)
+    {
+        const int chunks = cols >> 3;
+#pragma unroll
+        for (int k = 0; k < MAXC; k++) {
+            const int c = threadIdx.x + k * DEC_THREADS;
+            if (c < chunks) {
+                xv[k] = *reinterpret_cast<const half8_t *>(x + (size_t)c * 8);
+                if constexpr (NORM == 1) {
+                    if (nw) wv[k] = *reinterpret_cast<const half8_t *>(nw + (size_t)c * 8);
+                    if (nb) bv[k] = *reinterpret_cast<const half8_t *>(nb + (size_t)c * 8);
+                }
+            }
+        }
     }
-    const int chunks = cols >> 3;
-    for (int c = tid; c < chunks; c += DEC_THREADS) {
-        const half8_t xv = *reinterpret_cast<const half8_t *>(x + (size_t)c * 8);
-        float v[8];
+
+    __device__ __forceinline__ void finish(const half_t *__restrict__ nw, const half_t *__restrict__ nb,
+                                           float multi_base, float eps, int cols, const XLds &L,
+                                           half_t *__restrict__ xn_out, long long *trc = nullptr)
+    {
+        const int tid = threadIdx.x;
+        const int chunks = cols >> 3;
+        float scale = 1.0f;
         if constexpr (NORM == 1) {
-            half8_t wv, bv;
-            if (nw) wv = *reinterpret_cast<const half8_t *>(nw + (size_t)c * 8);
-            if (nb) bv = *reinterpret_cast<const half8_t *>(nb + (size_t)c * 8);
-            half8_t outv;
+#pragma unroll
+            for (int k = 0; k < MAXC; k++) {
+                const int c = tid + k * DEC_THREADS;
+                if (c < chunks) *reinterpret_cast<half8_t *>(L.xh + (size_t)c * 8) = xv[k];
+            }
+            __syncthreads();
+            if (trc) trc[4] = wall_clock64();
+            if (tid < 128) L.part[tid] = rms_partial(L.xh, cols, tid, 128);
+            __syncthreads();
+            if (trc) trc[5] = wall_clock64();
+            if (tid == 0) L.part[128] = rms_scale_from_partials(L.part, 128, cols, eps);
+            __syncthreads();
+            if (trc) trc[6] = wall_clock64();
+            scale = L.part[128];
+        } else {
+            if (trc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; k++) {
+            const int c = tid + k * DEC_THREADS;
+            if (c >= chunks) continue;       // whole quads (4 lanes = one block) are in or out together
+            float v[8];
+            if constexpr (NORM == 1) {
+                half8_t outv;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float t = (float)xv[k][i] * scale;
+                    if (nw) {
+                        float m = multi_base + (float)wv[k][i];
+                        t = t * m;
+                        if (nb) t = t + (float)bv[k][i];
+                    }
+                    half_t th = f2h(t);
+                    outv[i] = th;
+                    v[i] = h2f(th);
+                }
+                if (xn_out && blockIdx.x == 0) *reinterpret_cast<half8_t *>(xn_out + (size_t)c * 8) = outv;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = (float)xv[k][i];
+            }
+            float mx = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v[i]));
+            mx = fmaxf(mx, dpp_xor1(mx));
+            mx = fmaxf(mx, dpp_xor2(mx));
+            const float qs = mx / 127;
+            const float rqs = 1.0f / qs;
+            int q[8]; int s = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                float t = (float)xv[i] * scale;
-                if (nw) {
-                    float m = multi_base + (float)wv[i];
-                    t = t * m;
-                    if (nb) t = t + (float)bv[i];
-                }
-                half_t th = f2h(t);
-                outv[i] = th;
-                v[i] = h2f(th);
+                int qq = qs <= 0.000001f ? 0 : q8_round_div(v[i], qs, rqs);
+                qq = min(max(qq, -128), 127);
+                q[i] = qq; s += qq;
             }
-            if (xn_out && blockIdx.x == 0 && blockIdx.y == 0) *reinterpret_cast<half8_t *>(xn_out + (size_t)c * 8) = outv;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = (float)xv[i];
+            s += dpp_xor1(s);
+            s += dpp_xor2(s);
+            u32x2 packed;
+            packed[0] = (uint32_t)(q[0] & 0xFF) | ((uint32_t)(q[1] & 0xFF) << 8) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[3] & 0xFF) << 24);
+            packed[1] = (uint32_t)(q[4] & 0xFF) | ((uint32_t)(q[5] & 0xFF) << 8) | ((uint32_t)(q[6] & 0xFF) << 16) | ((uint32_t)(q[7] & 0xFF) << 24);
+            *reinterpret_cast<u32x2 *>(L.codes + (size_t)c * 8) = packed;
+            if ((c & 3) == 0) {
+                L.scale[c >> 2] = h2f(f2h(qs));    // the fp16-rounded scale is what the GEMV multiplies by
+                L.xsum[c >> 2] = (float)s;
+            }
         }
-        float mx = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v[i]));
-        mx = fmaxf(mx, dpp_xor1(mx));     // 4 consecutive lanes == one 32-element block
-        mx = fmaxf(mx, dpp_xor2(mx));
-        const float qs = mx / 127;
-        int q[8]; int s = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int qq = qs <= 0.000001f ? 0 : (int)roundf(v[i] / qs);
-            qq = min(max(qq, -128), 127);
-            q[i] = qq; s += qq;
-        }
-        s += dpp_xor1(s);
-        s += dpp_xor2(s);
-        u32x2 packed;
-        packed[0] = (uint32_t)(q[0] & 0xFF) | ((uint32_t)(q[1] & 0xFF) << 8) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[3] & 0xFF) << 24);
-        packed[1] = (uint32_t)(q[4] & 0xFF) | ((uint32_t)(q[5] & 0xFF) << 8) | ((uint32_t)(q[6] & 0xFF) << 16) | ((uint32_t)(q[7] & 0xFF) << 24);
-        *reinterpret_cast<u32x2 *>(L.codes + (size_t)c * 8) = packed;
-        if ((c & 3) == 0) {
-            L.scale[c >> 2] = h2f(f2h(qs));    // the fp16-rounded scale is what the GEMV multiplies by
-            L.xsum[c >> 2] = (float)s;
-        }
+        __syncthreads();
     }
-    __syncthreads();
-}
+};
 
 // ------------------------------------------------------------------ Q4_B32T1
 // registers of one lane for NJ blocks of the activation / of one weight row
@@ -165,16 +230,23 @@ template <int NJ>
 struct WRowQ4 {
     u32x4 c[NJ];
     uint32_t sb[NJ];
-    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, bool row_ok)
+    // Unconditional loads (addresses clamped into the row): a load under an exec-masked
+    // branch makes the compiler's vmcnt bookkeeping conservative -- every later wait
+    // for OLDER data (e.g. the activation) turns into vmcnt(0), i.e. "wait for the whole
+    // weight stream".  Lanes past the row end re-read the last block; their activation
+    // registers are zero, so they contribute exactly 0.
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = lane + 64 * j;
-            c[j] = u32x4{0, 0, 0, 0}; sb[j] = 0;
-            if (row_ok && blk < nblk) {
-                c[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow + (size_t)blk * 16));
-                sb[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(wrow + (size_t)nblk * 16 + (size_t)blk * 4));
-            }
+            const int blk = min(lane + 64 * j, nblk - 1);
+#if IFA_NT_WEIGHTS
+            c[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow + (size_t)blk * 16));
+            sb[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(wrow + (size_t)nblk * 16 + (size_t)blk * 4));
+#else
+            c[j] = *reinterpret_cast<const u32x4 *>(wrow + (size_t)blk * 16);
+            sb[j] = *reinterpret_cast<const uint32_t *>(wrow + (size_t)nblk * 16 + (size_t)blk * 4);
+#endif
         }
     }
     // lane-partial of sum_blk xs*(dot*scale + xsum*base); same expression as ax8_term (ifa_gemv.hip)
@@ -216,12 +288,13 @@ struct DecGemvParams {
     const half_t *norm_w, *norm_b;
     float multi_base, eps;
     int cols, nblk;
-    DecMatSet set[3];          // grid.y selects
+    DecMatSet set[3];          // rows of the sets are concatenated into one virtual row space
+    int nsets, total_rows;
     const half_t *residual;    // EPI_RESIDUAL: y = half(residual + y)
     const half_t *residual2;   // optional second add (parallel-attn / shared-input models)
     int act_kind;
     half_t *xn_out;            // optional copy of the normalised activation
-    int rows_per_wave;
+    long long *trace;          // optional [gridDim.x][8] wall-clock stamps (100 MHz) for tuning
 };
 
 __device__ __forceinline__ half_t dec_bias(float acc, const half_t *bias, int row)
@@ -231,68 +304,131 @@ __device__ __forceinline__ half_t dec_bias(float acc, const half_t *bias, int ro
     return y;
 }
 
-template <int NJ, int R, int EPI, int NORM>
+// virtual row -> (set, row).  Everything is selected from kernel-argument scalars:
+// indexing P.set[] with a runtime index would make the compiler fetch the pointer
+// from the kernarg segment with a VECTOR load and wait vmcnt(0) for it -- i.e. for
+// every weight load issued before it -- which serialises the whole stream.
+struct DecRow {
+    int si, row;
+    const uint8_t *W0, *W1;
+    const half_t *b0, *b1;
+    half_t *y;
+};
+
+__device__ __forceinline__ DecRow dec_locate(const DecGemvParams &P, int v)
+{
+    const int r0 = P.set[0].rows, r1 = P.set[1].rows;
+    DecRow d;
+    const bool in1 = P.nsets > 1 && v >= r0;
+    const bool in2 = P.nsets > 2 && v >= r0 + r1;
+    d.si = in2 ? 2 : (in1 ? 1 : 0);
+    d.row = in2 ? v - r0 - r1 : (in1 ? v - r0 : v);
+    d.W0 = in2 ? P.set[2].W[0] : (in1 ? P.set[1].W[0] : P.set[0].W[0]);
+    d.W1 = in2 ? P.set[2].W[1] : (in1 ? P.set[1].W[1] : P.set[0].W[1]);
+    d.b0 = in2 ? P.set[2].bias[0] : (in1 ? P.set[1].bias[0] : P.set[0].bias[0]);
+    d.b1 = in2 ? P.set[2].bias[1] : (in1 ? P.set[1].bias[1] : P.set[0].bias[1]);
+    d.y = in2 ? P.set[2].y : (in1 ? P.set[1].y : P.set[0].y);
+    return d;
+}
+
+// RW = rows (EPI_GLU: row pairs) per wave and pass; rows are strided over the waves
+// (v = (pass*RW + i)*W + wave) so neighbouring waves stream neighbouring rows.
+// Order of memory traffic inside the kernel (measured, see DESIGN.md "Kernel timeline"):
+//   1. activation (+norm weight) loads by all threads, then a barrier: the CU's memory
+//      pipeline is FIFO across waves, so these must be queued before any weight request;
+//   2. D1 rows of weights per wave (~40 KiB per CU: accepted without blocking);
+//   3. cooperative norm + Q8 quantisation through LDS (VALU-bound, ~2 us);
+//   4. the remaining rows -- all of them at once, nothing waits on them until the dots;
+//   5. every wave reduces its RW rows as independent chains, then lane i finishes row i
+//      (bias / residual / activation) so the epilogue's loads overlap too.
+template <int NJ, int RW, int EPI, int NORM>
 __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_q4(const DecGemvParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const XLds L = xlds_carve(smem, P.cols);
-    const DecMatSet &S = P.set[blockIdx.y];
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * (DEC_THREADS / 64) + (threadIdx.x >> 6);
-    const int row0 = gw * P.rows_per_wave;
-    const int row_end = min(row0 + P.rows_per_wave, S.rows);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (SGPR)
+    const int gw = blockIdx.x * DEC_WAVES + wave;
+    const int W = gridDim.x * DEC_WAVES;
     const size_t row_bytes = (size_t)P.nblk * 20;
     constexpr int NM = (EPI == EPI_GLU) ? 2 : 1;
+    const int npass = (P.total_rows + RW * W - 1) / (RW * W);
 
-    // 1) first batch of weight loads, before anything that needs the activation
-    WRowQ4<NJ> cur[NM][R];
-#pragma unroll
-    for (int m = 0; m < NM; m++)
-#pragma unroll
-        for (int rr = 0; rr < R; rr++)
-            cur[m][rr].load(S.W[m] + (size_t)(row0 + rr) * row_bytes, P.nblk, lane, row0 + rr < row_end);
+    const bool tr = P.trace != nullptr && threadIdx.x == 64;
+    if (tr) P.trace[blockIdx.x * 8 + 0] = wall_clock64();
 
-    // 2) norm + quantise the activation into LDS (all threads), then this lane's slice into registers
-    dec_prologue<NORM>(P.x, P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out);
-    if (row0 >= S.rows) return;
+    WRowQ4<NJ> w[NM][RW];
+    auto load_rows = [&](int pass, int i0, int i1) {
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            if (i < i0 || i >= i1) continue;
+            const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);   // clamped: rows past the end re-read the last row
+            const DecRow d = dec_locate(P, v);
+            w[0][i].load(d.W0 + (size_t)d.row * row_bytes, P.nblk, lane);
+            if constexpr (NM == 2) w[1][i].load(d.W1 + (size_t)d.row * row_bytes, P.nblk, lane);
+        }
+    };
+    auto load_pass = [&](int pass) { load_rows(pass, 0, RW); };
+    // rows requested BEFORE the cooperative prologue: what the CU's memory pipeline accepts
+    // without blocking (~32-48 KiB per CU); a barrier behind blocked loads would only
+    // release once the slowest wave's requests have been accepted, i.e. late in the stream
+    constexpr int D1 = (NM * NJ >= 6) ? 1 : (NM * NJ >= 3 ? 1 : 2);
+
+    {
+        constexpr int MAXC = NORM ? 2 : 4;
+        XPre<NORM, MAXC> pre;
+        pre.issue(P.x, P.norm_w, P.norm_b, P.cols);
+        // the CU's memory queue is FIFO across waves: make sure every wave's activation
+        // request is queued before ANY wave floods it with weight requests
+        __syncthreads();
+        load_rows(0, 0, D1);
+        if (tr) P.trace[blockIdx.x * 8 + 1] = wall_clock64();
+        pre.finish(P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out,
+                   (P.trace != nullptr && threadIdx.x == 0) ? P.trace + blockIdx.x * 8 : nullptr);
+        load_rows(0, D1, RW);
+    }
+    if (tr) P.trace[blockIdx.x * 8 + 2] = wall_clock64();
+    if (gw >= P.total_rows) return;
     XRegsQ4<NJ> X;
     X.load(L, lane, P.nblk);
+    if (tr) P.trace[blockIdx.x * 8 + 3] = wall_clock64();
 
-    // 3) stream rows, next batch in flight while the current one is reduced
-    for (int r = row0; r < row_end; r += R) {
-        WRowQ4<NJ> nxt[NM][R];
-        const bool more = r + R < row_end;
+    for (int pass = 0; pass < npass; pass++) {
+        if (pass > 0) load_pass(pass);
+        float a[NM][RW];
 #pragma unroll
-        for (int m = 0; m < NM; m++)
+        for (int i = 0; i < RW; i++)
 #pragma unroll
-            for (int rr = 0; rr < R; rr++)
-                nxt[m][rr].load(S.W[m] + (size_t)(r + R + rr) * row_bytes, P.nblk, lane, more && (r + R + rr < row_end));
+            for (int m = 0; m < NM; m++) a[m][i] = w[m][i].dot(X);
 #pragma unroll
-        for (int rr = 0; rr < R; rr++) {
-            const int row = r + rr;
-            float a0 = wave_sum(cur[0][rr].dot(X));
-            float a1 = 0.0f;
-            if constexpr (NM == 2) a1 = wave_sum(cur[1][rr].dot(X));
-            if (lane == 0 && row < row_end) {
-                half_t y = dec_bias(a0, S.bias[0], row);
-                if constexpr (EPI == EPI_RESIDUAL) {
-                    y = f2h(h2f(P.residual[row]) + h2f(y));             // TensorOpr::Add (half add)
-                    if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
-                } else if constexpr (EPI == EPI_GLU) {
-                    half_t t2 = dec_bias(a1, S.bias[1], row);
-                    half_t act = f2h(act_fn(h2f(y), P.act_kind));       // TensorOpr::Activation -> F16
-                    y = f2h(h2f(act) * h2f(t2));                        // TensorOpr::Mul
-                } else if constexpr (EPI == EPI_ACT) {
-                    y = f2h(act_fn(h2f(y), P.act_kind));
-                }
-                S.y[row] = y;
-            }
+        for (int i = 0; i < RW; i++)
+#pragma unroll
+            for (int m = 0; m < NM; m++) a[m][i] = wave_sum(a[m][i]);
+        // lane i finishes row i
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            if (lane == i) { a0 = a[0][i]; if constexpr (NM == 2) a1 = a[1][i]; }
         }
-#pragma unroll
-        for (int m = 0; m < NM; m++)
-#pragma unroll
-            for (int rr = 0; rr < R; rr++) cur[m][rr] = nxt[m][rr];
+        const int v = (pass * RW + lane) * W + gw;
+        if (lane < RW && v < P.total_rows) {
+            const DecRow d = dec_locate(P, v);
+            const int row = d.row;
+            half_t y = dec_bias(a0, d.b0, row);
+            if constexpr (EPI == EPI_RESIDUAL) {
+                y = f2h(h2f(P.residual[row]) + h2f(y));             // TensorOpr::Add (half add)
+                if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
+            } else if constexpr (EPI == EPI_GLU) {
+                half_t t2 = dec_bias(a1, d.b1, row);
+                half_t act = f2h(act_fn(h2f(y), P.act_kind));       // TensorOpr::Activation -> F16
+                y = f2h(h2f(act) * h2f(t2));                        // TensorOpr::Mul
+            } else if constexpr (EPI == EPI_ACT) {
+                y = f2h(act_fn(h2f(y), P.act_kind));
+            }
+            d.y[row] = y;
+        }
     }
+    if (tr) P.trace[blockIdx.x * 8 + 7] = wall_clock64();
 }
 
 // ------------------------------------------------- final norm + F16 lm_head
@@ -305,7 +441,6 @@ struct DecLmHeadParams {
     half_t *logits;       // [rows]
     int rows;
     half_t *xn_out;
-    int rows_per_wave;
 };
 
 // x chunk (8 halfs) per lane per j, activation normalised in the prologue and
@@ -317,33 +452,37 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_f16(const DecLmHeadP
     half_t *xn = reinterpret_cast<half_t *>(smem);                         // [cols]
     float *part = reinterpret_cast<float *>(smem + (((size_t)P.cols * 2 + 15) & ~(size_t)15));
     const int tid = threadIdx.x, lane = tid & 63;
-    const int gw = blockIdx.x * (DEC_THREADS / 64) + (tid >> 6);
-    const int row0 = gw * P.rows_per_wave;
-    const int row_end = min(row0 + P.rows_per_wave, P.rows);
+    const int gw = blockIdx.x * DEC_WAVES + __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = gridDim.x * DEC_WAVES;
+    const int nbatch = (P.rows + R - 1) / R;
     const int chunks = P.cols >> 3;
 
-    u32x4 cur[R][NJ];
+    auto load_batch = [&](u32x4 (&dst)[R][NJ], int b) {
 #pragma unroll
-    for (int rr = 0; rr < R; rr++)
+        for (int rr = 0; rr < R; rr++) {
+            const int row = min(b * R + rr, P.rows - 1);          // clamped, unconditional (see WRowQ4::load)
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int c = lane + 64 * j;
-            cur[rr][j] = u32x4{0, 0, 0, 0};
-            if (row0 + rr < row_end && c < chunks)
-                cur[rr][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(P.W + (size_t)(row0 + rr) * P.cols) + c);
+            for (int j = 0; j < NJ; j++) {
+                const int c = min(lane + 64 * j, chunks - 1);
+                dst[rr][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(P.W + (size_t)row * P.cols) + c);
+            }
         }
+    };
+    u32x4 cur[R][NJ];
+    load_batch(cur, gw);
 
+    for (int c = tid; c < chunks; c += DEC_THREADS)
+        *reinterpret_cast<half8_t *>(xn + (size_t)c * 8) = *reinterpret_cast<const half8_t *>(P.x + (size_t)c * 8);
     float scale = 1.0f;
     if constexpr (NORM == 1) {
-        if (tid < 128) part[tid] = rms_partial(P.x, P.cols, tid, 128);
+        __syncthreads();
+        if (tid < 128) part[tid] = rms_partial(xn, P.cols, tid, 128);
         __syncthreads();
         if (tid == 0) part[128] = rms_scale_from_partials(part, 128, P.cols, P.eps);
         __syncthreads();
         scale = part[128];
-    }
-    for (int c = tid; c < chunks; c += DEC_THREADS) {
-        half8_t xv = *reinterpret_cast<const half8_t *>(P.x + (size_t)c * 8);
-        if constexpr (NORM == 1) {
+        for (int c = tid; c < chunks; c += DEC_THREADS) {
+            half8_t xv = *reinterpret_cast<const half8_t *>(xn + (size_t)c * 8);
             half8_t wv, bv;
             if (P.norm_w) wv = *reinterpret_cast<const half8_t *>(P.norm_w + (size_t)c * 8);
             if (P.norm_b) bv = *reinterpret_cast<const half8_t *>(P.norm_b + (size_t)c * 8);
@@ -357,12 +496,16 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_f16(const DecLmHeadP
                 }
                 xv[i] = f2h(t);
             }
+            *reinterpret_cast<half8_t *>(xn + (size_t)c * 8) = xv;
+            if (P.xn_out && blockIdx.x == 0) *reinterpret_cast<half8_t *>(P.xn_out + (size_t)c * 8) = xv;
         }
-        *reinterpret_cast<half8_t *>(xn + (size_t)c * 8) = xv;
-        if (P.xn_out && blockIdx.x == 0) *reinterpret_cast<half8_t *>(P.xn_out + (size_t)c * 8) = xv;
+    } else {
+        if (P.xn_out && blockIdx.x == 0)
+            for (int c = tid; c < chunks; c += DEC_THREADS)
+                *reinterpret_cast<half8_t *>(P.xn_out + (size_t)c * 8) = *reinterpret_cast<const half8_t *>(xn + (size_t)c * 8);
     }
     __syncthreads();
-    if (row0 >= P.rows) return;
+    if (gw >= nbatch) return;
     u32x4 xr[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -370,25 +513,16 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_f16(const DecLmHeadP
         xr[j] = u32x4{0, 0, 0, 0};
         if (c < chunks) xr[j] = *reinterpret_cast<const u32x4 *>(xn + (size_t)c * 8);
     }
-    for (int r = row0; r < row_end; r += R) {
+    for (int b = gw; b < nbatch; b += W) {
         u32x4 nxt[R][NJ];
-        const bool more = r + R < row_end;
-#pragma unroll
-        for (int rr = 0; rr < R; rr++)
-#pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                const int c = lane + 64 * j;
-                nxt[rr][j] = u32x4{0, 0, 0, 0};
-                if (more && r + R + rr < row_end && c < chunks)
-                    nxt[rr][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(P.W + (size_t)(r + R + rr) * P.cols) + c);
-            }
+        load_batch(nxt, b + W);
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
             float acc = 0.0f;
 #pragma unroll
             for (int j = 0; j < NJ; j++) acc = dot8_f16(cur[rr][j], xr[j], acc);
             acc = wave_sum(acc);
-            if (lane == 0 && r + rr < row_end) P.logits[r + rr] = f2h(acc);
+            if (lane == 0 && b * R + rr < P.rows) P.logits[b * R + rr] = f2h(acc);
         }
 #pragma unroll
         for (int rr = 0; rr < R; rr++)
@@ -399,65 +533,115 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_f16(const DecLmHeadP
 
 // ------------------------------------------------------------------ attention
 struct DecAttnParams {
-    half_t *q;                 // [heads*head_dim]   (RoPE applied in LDS, not written back)
+    const half_t *q;           // [heads*head_dim]   pre-RoPE
     const half_t *k_new;       // [kv_heads*head_dim] pre-RoPE
     const half_t *v_new;       // [kv_heads*head_dim]
     uint8_t *kcache, *vcache;  // [max_ctx][kv_row_bytes]
     const int *state;          // state[1] = position of the new token
-    int heads, kv_heads, head_dim, kv_q8;
-    float kq_scale, rope_theta;
-    int rope_order, rope_dims, rope_cols;
+    const float *rope_tab;     // [head_dim/2][2] cos,sin of this step (k_dec_gather)
+    int heads, kv_heads, kv_q8;
+    float kq_scale;
+    int rope_order, rope_cols;
     int alibi, alibi_base, alibi_total;
     half_t *out;               // [heads*head_dim]
     int max_ctx;
 };
 
-// One workgroup (256 threads) per query head.  Scores for the cached rows are
-// computed one key per lane with the reference's k-ordered fp32 dot (bit-exact
-// S), the new token's K/V come straight from registers/LDS (and are written to
-// the cache by the first head of each KV group), softmax in LDS, then P.V with
-// the context split over 256/head_dim thread groups.
-template <bool Q8>
+// rotate one pair with a precomputed (cos, sin); same expressions as rope_rotate
+__device__ __forceinline__ void rope_apply(half_t *row, int col, float c, float s, int order, int rope_cols)
+{
+    int i0, i1;
+    if (order == 2) { if (2 * col >= rope_cols) return; i0 = col; i1 = col + rope_cols / 2; }
+    else { i0 = 2 * col; i1 = 2 * col + 1; }
+    const float x0 = h2f(row[i0]), x1 = h2f(row[i1]);
+    float a = x0 * c, bq = x1 * s, d = x0 * s, e = x1 * c;
+    row[i0] = f2h(a - bq);
+    row[i1] = f2h(d + e);
+}
+
+// One workgroup (256 threads) per query head.
+//  * K rows: one key per lane, whole row slice in registers (loads issued at
+//    kernel entry, before q/k/v staging), fp32 fma in d order == Gemm_Alg2 order,
+//    so S is bit-exact with the reference arithmetic.
+//  * V rows: thread (d-group of 8, key residue mod 256/(HD/8)); loads for the
+//    first key chunk are also issued at entry.  Partials are combined in a fixed
+//    order through LDS.
+//  * the new token's K/V never round-trip through HBM: they come from LDS and are
+//    written to the cache by the first head of each KV group.
+template <int HD, bool Q8>
 __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int hd = P.head_dim;
+    constexpr int DG = HD / 8;            // threads covering one V row (8 dims each)
+    constexpr int NSPLIT = 256 / DG;      // key residues handled in parallel
     const int pos = P.state[1];
     const int n_ctx = pos + 1;
-    half_t *qs = reinterpret_cast<half_t *>(smem);                 // [hd] rotated q
-    half_t *kn = qs + hd;                                          // [hd] rotated (and Q8 round-tripped) new k
-    half_t *vn = kn + hd;                                          // [hd] new v (Q8 round-tripped)
-    float *red = reinterpret_cast<float *>(vn + hd);               // [16]
-    float *opart = red + 16;                                       // [256]
-    half_t *S = reinterpret_cast<half_t *>(opart + 256);           // [n_ctx]
+    half_t *qs = reinterpret_cast<half_t *>(smem);                 // [HD] rotated q
+    half_t *kn = qs + HD;                                          // [HD] rotated (and Q8 round-tripped) new k
+    half_t *vn = kn + HD;                                          // [HD] new v (Q8 round-tripped)
+    float *red = reinterpret_cast<float *>(vn + HD);               // [16]
+    float *opart = red + 16;                                       // [NSPLIT][HD]
+    half_t *S = reinterpret_cast<half_t *>(opart + NSPLIT * HD);   // [n_ctx]
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int group = P.heads / P.kv_heads;
     const int kvh = h / group;
     const bool writer = (h % group) == 0;
-    const int kv_dim = P.kv_heads * hd;
+    const int kv_dim = P.kv_heads * HD;
     const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
+    const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
+
+    // ---- issue the first chunk of K (key = tid) and V loads before anything else
+    constexpr int KW = Q8 ? (HD / 32) * 17 : HD / 2;    // 16-bit-pair words (Q8: 34 B per block) / dwords
+    uint32_t kreg[Q8 ? 1 : HD / 2];
+    uint16_t kreg8[Q8 ? (HD / 32) * 17 : 1];
+    (void)KW;
+    const bool k0_ok = tid < pos;                       // cached rows only; row `pos` comes from LDS
+    if (k0_ok) {
+        const uint8_t *rowp = P.kcache + (size_t)tid * row_bytes + head_off;
+        if constexpr (Q8) {
+#pragma unroll
+            for (int i = 0; i < (HD / 32) * 17; i++) kreg8[i] = reinterpret_cast<const uint16_t *>(rowp)[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < HD / 8; i++) {
+                const u32x4 t = reinterpret_cast<const u32x4 *>(rowp)[i];
+                kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
+            }
+        }
+    }
+    const int dg = tid % DG, sp = tid / DG;
+    constexpr int VPRE = 256 / NSPLIT;                  // prefetched V keys per thread: j = sp + NSPLIT*i (256 keys)
+    u32x4 vreg[Q8 ? 1 : VPRE];
+    if constexpr (!Q8) {
+#pragma unroll
+        for (int i = 0; i < VPRE; i++) {
+            const int j = sp + NSPLIT * i;
+            vreg[i] = u32x4{0, 0, 0, 0};
+            if (j < pos) vreg[i] = reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg];
+        }
+    }
 
     // ---- stage q, k_new, v_new; RoPE on q and k (TensorOpr::PositionEmbedding, F16 in/out)
-    for (int d = tid; d < hd; d += 256) {
-        qs[d] = P.q[(size_t)h * hd + d];
-        kn[d] = P.k_new[(size_t)kvh * hd + d];
-        vn[d] = P.v_new[(size_t)kvh * hd + d];
+    for (int d = tid; d < HD; d += 256) {
+        qs[d] = P.q[(size_t)h * HD + d];
+        kn[d] = P.k_new[(size_t)kvh * HD + d];
+        vn[d] = P.v_new[(size_t)kvh * HD + d];
     }
     __syncthreads();
     if (P.rope_order != 0) {
-        for (int c = tid; c < hd; c += 256) {     // first hd/2 threads rotate q, next hd/2 rotate k
-            if (c < hd / 2) rope_rotate(qs, c, pos, P.rope_theta, P.rope_order, P.rope_dims, P.rope_cols);
-            else rope_rotate(kn, c - hd / 2, pos, P.rope_theta, P.rope_order, P.rope_dims, P.rope_cols);
+        if (tid < HD) {     // threads [0,HD/2) rotate q pairs, [HD/2,HD) rotate k pairs
+            const int c = tid < HD / 2 ? tid : tid - HD / 2;
+            const float cs = P.rope_tab[2 * c], sn = P.rope_tab[2 * c + 1];
+            rope_apply(tid < HD / 2 ? qs : kn, c, cs, sn, P.rope_order, P.rope_cols);
         }
         __syncthreads();
     }
     // ---- KV store of the new row (LayerKVCache::SetKRows/SetVRows, kv_cache.cc:159-249)
     if constexpr (Q8) {
-        // quantise 32-element blocks of this head's slice (head_dim % 32 == 0), round-trip for local use
-        const int nb = hd / 32;
-        for (int b = wave; b < 2 * nb; b += 4) {
-            half_t *src = b < nb ? kn : vn;
-            const int bb = b < nb ? b : b - nb;
+        constexpr int NB = HD / 32;
+        for (int b = wave; b < 2 * NB; b += 4) {
+            half_t *src = b < NB ? kn : vn;
+            const int bb = b < NB ? b : b - NB;
             if (lane < 32) {
                 const float val = h2f(src[bb * 32 + lane]);
                 float mx = fabsf(val);
@@ -468,8 +652,8 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
                 qv = min(max(qv, -128), 127);
                 const half_t sch = f2h(sc);
                 if (writer) {
-                    uint8_t *cache = b < nb ? P.kcache : P.vcache;
-                    uint8_t *blk = cache + (size_t)pos * row_bytes + (size_t)((kvh * hd) / 32 + bb) * 34;
+                    uint8_t *cache = b < NB ? P.kcache : P.vcache;
+                    uint8_t *blk = cache + (size_t)pos * row_bytes + head_off + (size_t)bb * 34;
                     blk[2 + lane] = (uint8_t)(int8_t)qv;
                     if (lane == 0) *reinterpret_cast<uint16_t *>(blk) = __builtin_bit_cast(uint16_t, sch);
                 }
@@ -478,38 +662,54 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
         }
         __syncthreads();
     } else {
-        if (writer) {
-            half_t *kc = reinterpret_cast<half_t *>(P.kcache + (size_t)pos * row_bytes) + (size_t)kvh * hd;
-            half_t *vc = reinterpret_cast<half_t *>(P.vcache + (size_t)pos * row_bytes) + (size_t)kvh * hd;
-            for (int d = tid; d < hd; d += 256) { kc[d] = kn[d]; vc[d] = vn[d]; }
+        if (writer && tid < HD) {
+            reinterpret_cast<half_t *>(P.kcache + (size_t)pos * row_bytes + head_off)[tid] = kn[tid];
+            reinterpret_cast<half_t *>(P.vcache + (size_t)pos * row_bytes + head_off)[tid] = vn[tid];
         }
     }
 
     // ---- scores: one key per lane, fp32 fma in d order (Gemm_Alg2_Kernel order, products exact)
-    const float alpha = 1.0f / sqrtf((float)hd) / P.kq_scale;
+    const float alpha = 1.0f / sqrtf((float)HD) / P.kq_scale;
     const float mk = P.alibi ? alibi_slope(h + P.alibi_base, P.alibi_total) : 0.0f;
     float lmax = -INFINITY;
     for (int j = tid; j < n_ctx; j += 256) {
         float c = 0.0f;
         if (j == pos) {
-            for (int d = 0; d < hd; d++) c = __builtin_fmaf(h2f(qs[d]), h2f(kn[d]), c);
-        } else if constexpr (Q8) {
-            const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + (size_t)((kvh * hd) / 32) * 34;
-            for (int b = 0; b < hd / 32; b++) {
-                const uint8_t *blk = rowp + (size_t)b * 34;
-                const float sc = hbits2f(*reinterpret_cast<const uint16_t *>(blk));
 #pragma unroll 8
-                for (int i = 0; i < 32; i++) {
-                    const float kvv = h2f(f2h((float)(int)(int8_t)blk[2 + i] * sc));
-                    c = __builtin_fmaf(h2f(qs[b * 32 + i]), kvv, c);
+            for (int d = 0; d < HD; d++) c = __builtin_fmaf(h2f(qs[d]), h2f(kn[d]), c);
+        } else {
+            if (j >= 256) {      // later chunks: load now (first chunk was prefetched)
+                const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
+                if constexpr (Q8) {
+#pragma unroll
+                    for (int i = 0; i < (HD / 32) * 17; i++) kreg8[i] = reinterpret_cast<const uint16_t *>(rowp)[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < HD / 8; i++) {
+                        const u32x4 t = reinterpret_cast<const u32x4 *>(rowp)[i];
+                        kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
+                    }
                 }
             }
-        } else {
-            const half8_t *rowp = reinterpret_cast<const half8_t *>(P.kcache + (size_t)j * row_bytes) + (size_t)(kvh * hd) / 8;
-            for (int d8 = 0; d8 < hd / 8; d8++) {
-                const half8_t kv8 = rowp[d8];
+            if constexpr (Q8) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) c = __builtin_fmaf(h2f(qs[d8 * 8 + i]), (float)kv8[i], c);
+                for (int b = 0; b < HD / 32; b++) {
+                    const float sc = hbits2f(kreg8[b * 17]);
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const uint32_t w16 = kreg8[b * 17 + 1 + (i >> 1)];
+                        const int qv = (int)(int8_t)((w16 >> ((i & 1) * 8)) & 0xFF);
+                        const float kvv = h2f(f2h((float)qv * sc));
+                        c = __builtin_fmaf(h2f(qs[b * 32 + i]), kvv, c);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < HD / 2; i++) {
+                    const half2_t k2 = __builtin_bit_cast(half2_t, kreg[i]);
+                    c = __builtin_fmaf(h2f(qs[2 * i]), (float)k2[0], c);
+                    c = __builtin_fmaf(h2f(qs[2 * i + 1]), (float)k2[1], c);
+                }
             }
         }
         half_t s = f2h(alpha * c);
@@ -534,49 +734,82 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     for (int j = tid; j < n_ctx; j += 256) S[j] = f2h(h2f(S[j]) * inv);
     __syncthreads();
 
-    // ---- O = P.V : thread (split, d); each split walks its slice of the context in order
-    const int nsplit = 256 / hd > 0 ? 256 / hd : 1;
-    const int d = tid % hd, sp = tid / hd;
-    float c = 0.0f;
-    if (sp < nsplit) {
-        const int per = (n_ctx + nsplit - 1) / nsplit;
-        const int j0 = sp * per, j1 = min(n_ctx, j0 + per);
-        for (int j = j0; j < j1; j++) {
-            float vv;
-            if (j == pos) vv = h2f(vn[d]);
-            else if constexpr (Q8) {
-                const uint8_t *blk = P.vcache + (size_t)j * row_bytes + (size_t)((kvh * hd + d) / 32) * 34;
-                vv = h2f(f2h((float)(int)(int8_t)blk[2 + ((kvh * hd + d) & 31)] * hbits2f(*reinterpret_cast<const uint16_t *>(blk))));
-            } else {
-                vv = h2f(reinterpret_cast<const half_t *>(P.vcache + (size_t)j * row_bytes)[(size_t)kvh * hd + d]);
-            }
-            c = __builtin_fmaf(h2f(S[j]), vv, c);
+    // ---- O = P.V : thread (sp, dg) accumulates keys j = sp + NSPLIT*i for its 8 dims
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = 0.0f;
+    auto acc_v = [&](float pj, const u32x4 vv) {
+        const half8_t v8 = __builtin_bit_cast(half8_t, vv);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, (float)v8[e], o[e]);
+    };
+    auto acc_new = [&](float pj) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, h2f(vn[dg * 8 + e]), o[e]);
+    };
+    auto acc_q8 = [&](float pj, int j) {
+        const uint8_t *blk = P.vcache + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
+        const float sc = hbits2f(*reinterpret_cast<const uint16_t *>(blk));
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int qv = (int)(int8_t)blk[2 + (dg % 4) * 8 + e];
+            o[e] = __builtin_fmaf(pj, h2f(f2h((float)qv * sc)), o[e]);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < VPRE; i++) {        // first 256 keys: V rows already in registers (static indexing)
+        const int j = sp + NSPLIT * i;
+        if (j < n_ctx) {
+            const float pj = h2f(S[j]);
+            if (j == pos) acc_new(pj);
+            else if constexpr (Q8) acc_q8(pj, j);
+            else acc_v(pj, vreg[i]);
         }
     }
-    opart[tid] = c;
+    for (int j = sp + NSPLIT * VPRE; j < n_ctx; j += NSPLIT) {
+        const float pj = h2f(S[j]);
+        if (j == pos) acc_new(pj);
+        else if constexpr (Q8) acc_q8(pj, j);
+        else acc_v(pj, reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
     __syncthreads();
-    if (tid < hd) {
-        float o = opart[tid];
-        for (int s2 = 1; s2 < nsplit; s2++) o = o + opart[s2 * hd + tid];
-        P.out[(size_t)h * hd + tid] = f2h(o);
+    if (tid < HD) {
+        float acc = opart[tid];
+        for (int s2 = 1; s2 < NSPLIT; s2++) acc = acc + opart[s2 * HD + tid];
+        P.out[(size_t)h * HD + tid] = f2h(acc);
     }
 }
 
 __host__ __device__ inline size_t dec_attn_smem(int head_dim, int max_ctx)
 {
-    return (size_t)head_dim * 3 * 2 + 16 * 4 + 256 * 4 + (((size_t)max_ctx * 2 + 15) & ~(size_t)15) + 16;
+    const size_t nsplit = 256 / (head_dim / 8);
+    return (size_t)head_dim * 3 * 2 + 16 * 4 + nsplit * head_dim * 4 + (((size_t)max_ctx * 2 + 15) & ~(size_t)15) + 16;
 }
 
 // ------------------------------------------------------------- small kernels
 // state[0] = current token id, state[1] = its position, state[2] = steps done;
 // state[8 + i] = i-th generated token of the current launch batch.
+// Also fills the step's RoPE table: tab[c] = (cos, sin) of pos * theta_scale^c,
+// the same expression rope_rotate() evaluates per element (ifa_math.h).
 __global__ void __launch_bounds__(256) k_dec_gather(const half_t *__restrict__ embd, const int *__restrict__ state,
-                                                    int dim, int vocab, half_t *__restrict__ x)
+                                                    int dim, int vocab, half_t *__restrict__ x,
+                                                    float *__restrict__ rope_tab, int head_dim, float theta,
+                                                    int rope_dims)
 {
     int tok = state[0];
     tok = min(max(tok, 0), vocab - 1);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim / 8; c += gridDim.x * blockDim.x)
         reinterpret_cast<u32x4 *>(x)[c] = reinterpret_cast<const u32x4 *>(embd + (size_t)tok * dim)[c];
+    if (blockIdx.x == 0 && rope_tab) {
+        const int pos = state[1];
+        for (int c = threadIdx.x; c < head_dim / 2; c += blockDim.x) {
+            float cs, sn;
+            rope_angle(c, pos, theta, rope_dims, cs, sn);
+            rope_tab[2 * c] = cs; rope_tab[2 * c + 1] = sn;
+        }
+    }
 }
 
 // greedy top-1 over the logits (first maximum wins); writes the token ring and advances the state

@@ -52,6 +52,9 @@ struct ifa_model {
     half_t *att = nullptr, *a = nullptr, *f = nullptr, *t1 = nullptr, *t2 = nullptr, *logits = nullptr;
     uint8_t *xq = nullptr;
     int *state = nullptr;          // device: see k_dec_gather
+    float *rope_tab = nullptr;     // device: [head_dim/2][2]
+    long long *trace = nullptr;    // device: [2048][8] optional kernel phase stamps
+    int opt_trace = 0, opt_bench_mode = 0, opt_touch_stride = 65536;
     int *tokens_dev = nullptr;
     int *host_pinned = nullptr;    // pinned staging for state / tokens
     int scratch_tokens = 0;
@@ -74,49 +77,75 @@ static void free_tensor(Tensor &t)
 static bool is_q4(int dt) { return dt == Q4_B32T1A || dt == Q4_B32T1B; }
 
 // ------------------------------------------------------------------ dispatch
-template <int EPI, int NORM>
-static int launch_dec_gemv_q4(const DecGemvParams &P, int nsets, int max_rows, int rpw_opt, hipStream_t s)
+// reads one dword every `stride` bytes: warms the TLB / pulls lines towards L2+MALL
+__global__ void __launch_bounds__(256) k_touch(const uint8_t *__restrict__ p, size_t bytes, size_t stride, int *sink)
 {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    int acc = 0;
+    for (; i < bytes; i += (size_t)gridDim.x * blockDim.x * stride) acc += *reinterpret_cast<const int *>(p + i);
+    if (acc == 0x7FFFFFFF) *sink = acc;
+}
+
+static long long *g_trace_ptr = nullptr;   // set by ifa_model_time_kernel when the "trace" option is on
+static int g_num_cus = 0;
+static int num_cus()
+{
+    if (!g_num_cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+// One resident wave set; each wave owns RW rows per pass (strided), all loads up front.
+template <int EPI, int NORM>
+static int launch_dec_gemv_q4(const DecGemvParams &P0, int wgs_per_cu_opt, hipStream_t s)
+{
+    DecGemvParams P = P0;
+    P.trace = g_trace_ptr;
+    P.total_rows = 0;
+    for (int i = 0; i < P.nsets; i++) P.total_rows += P.set[i].rows;
     const int nj = (P.nblk + 63) / 64;
     if (nj < 1 || nj > 8) return ifa_fail(IFA_ERR_ARG, "fused GEMV supports up to 16384 columns (got %d)", P.cols);
-    const int R = nj <= 4 ? 2 : 1;
-    int rpw = rpw_opt > 0 ? rpw_opt : (max_rows + 3071) / 3072;
-    rpw = ((rpw + R - 1) / R) * R;
-    if (rpw < R) rpw = R;
-    DecGemvParams Q = P;
-    Q.rows_per_wave = rpw;
-    const unsigned waves = (unsigned)((max_rows + rpw - 1) / rpw);
-    dim3 grid((waves + (DEC_THREADS / 64) - 1) / (DEC_THREADS / 64), (unsigned)nsets);
+    const int nm = EPI == EPI_GLU ? 2 : 1;
+    // rows in flight per wave, bounded by registers: nm * RW * nj * 5 VGPRs
+    // exactly one workgroup per CU (a second one would queue its activation behind the first one's weights)
+    int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 1;
+    int wgs = std::min(num_cus() * per_cu, (P.total_rows + DEC_WAVES - 1) / DEC_WAVES);
+    if (wgs < 1) wgs = 1;
+    dim3 grid((unsigned)wgs);
     const size_t smem = xlds_bytes(P.cols);
-#define IFA_DG(NJV, RV) \
-    case NJV: { \
-        auto kern = k_dec_gemv_q4<NJV, RV, EPI, NORM>; \
+#define IFA_DG2(NJV, RWV) { auto kern = k_dec_gemv_q4<NJV, RWV, EPI, NORM>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        kern<<<grid, dim3(DEC_THREADS), smem, s>>>(Q); \
-    } break;
+        kern<<<grid, dim3(DEC_THREADS), smem, s>>>(P); }
+#define IFA_DG(NJV, RWA, RWB) \
+    case NJV: { if (nm == 2) IFA_DG2(NJV, RWB) else IFA_DG2(NJV, RWA) } break;
     switch (nj) {
-        IFA_DG(1, 2) IFA_DG(2, 2) IFA_DG(3, 2) IFA_DG(4, 2) IFA_DG(5, 1) IFA_DG(6, 1) IFA_DG(7, 1) IFA_DG(8, 1)
+        IFA_DG(1, 6, 6) IFA_DG(2, 6, 6) IFA_DG(3, 4, 3) IFA_DG(4, 4, 2) IFA_DG(5, 2, 2) IFA_DG(6, 2, 1) IFA_DG(7, 2, 1) IFA_DG(8, 2, 1)
     }
 #undef IFA_DG
+#undef IFA_DG2
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
 
-static int launch_lmhead(const DecLmHeadParams &P, int norm, int rpw_opt, hipStream_t s)
+static int launch_lmhead(const DecLmHeadParams &P, int norm, int wgs_per_cu_opt, hipStream_t s)
 {
     const int chunks = P.cols / 8;
     const int nj = (chunks + 63) / 64;
     if (P.cols % 8 != 0 || nj < 1 || nj > 8) return ifa_fail(IFA_ERR_ARG, "fused lm_head supports cols %% 8 == 0 and <= 4096 (got %d)", P.cols);
-    DecLmHeadParams Q = P;
-    int rpw = rpw_opt > 0 ? rpw_opt : 4;
-    Q.rows_per_wave = rpw;
-    const unsigned waves = (unsigned)((P.rows + rpw - 1) / rpw);
-    dim3 grid((waves + 7) / 8);
+    const int R = nj <= 4 ? 2 : 1;
+    const int nbatch = (P.rows + R - 1) / R;
+    const int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 2;
+    int wgs = std::min(num_cus() * per_cu, (nbatch + DEC_WAVES - 1) / DEC_WAVES);
+    if (wgs < 1) wgs = 1;
+    dim3 grid((unsigned)wgs);
     const size_t smem = (((size_t)P.cols * 2 + 15) & ~(size_t)15) + 132 * 4 + 16;
-#define IFA_LM(NJV) \
-    case NJV: if (norm) k_dec_lmhead_f16<NJV, 2, 1><<<grid, dim3(DEC_THREADS), smem, s>>>(Q); \
-              else k_dec_lmhead_f16<NJV, 2, 0><<<grid, dim3(DEC_THREADS), smem, s>>>(Q); break;
-    switch (nj) { IFA_LM(1) IFA_LM(2) IFA_LM(3) IFA_LM(4) IFA_LM(5) IFA_LM(6) IFA_LM(7) IFA_LM(8) }
+#define IFA_LM(NJV, RV) \
+    case NJV: if (norm) k_dec_lmhead_f16<NJV, RV, 1><<<grid, dim3(DEC_THREADS), smem, s>>>(P); \
+              else k_dec_lmhead_f16<NJV, RV, 0><<<grid, dim3(DEC_THREADS), smem, s>>>(P); break;
+    switch (nj) { IFA_LM(1, 2) IFA_LM(2, 2) IFA_LM(3, 2) IFA_LM(4, 2) IFA_LM(5, 1) IFA_LM(6, 1) IFA_LM(7, 1) IFA_LM(8, 1) }
 #undef IFA_LM
     IFA_LAUNCH_CHECK();
     return IFA_OK;
@@ -131,9 +160,10 @@ static bool fused_supported(const ifa_model *m, std::string *why)
     if (c.experts > 0) return fail("MoE uses the op-by-op path");
     if (c.parallel_attn || c.share_input) return fail("parallel-attention models use the op-by-op path");
     if (!c.full_quant_gemv) return fail("full_quant_gemv disabled");
-    if (c.head_dim > 256 || 256 % c.head_dim != 0) return fail("head_dim must divide 256");
+    if (c.head_dim != 32 && c.head_dim != 64 && c.head_dim != 128) return fail("fused attention supports head_dim 32/64/128");
     if (c.kv_dtype == Q8_B32T2 && c.head_dim % 32 != 0) return fail("Q8 KV needs head_dim % 32 == 0");
     if (c.dim % 32 != 0 || c.ffn % 32 != 0) return fail("dim/ffn must be multiples of 32");
+    if (c.dim > 8192) return fail("fused norm prologue supports dim <= 8192");
     for (const Layer &L : m->layers) {
         const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W2};
         for (int id : ids) {
@@ -161,13 +191,12 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
     P.multi_base = 0.0f; P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32;
     const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
     half_t *outs[3] = {m->q, m->k, m->v};
-    int max_rows = 0;
     for (int i = 0; i < 3; i++) {
         P.set[i].W[0] = (const uint8_t *)L.t[ids[i]].tiled; P.set[i].bias[0] = (const half_t *)L.t[bids[i]].data;
         P.set[i].y = outs[i]; P.set[i].rows = (int)L.t[ids[i]].rows;
-        max_rows = std::max(max_rows, P.set[i].rows);
     }
-    return launch_dec_gemv_q4<EPI_PLAIN, 1>(P, 3, max_rows, m->opt_rpw_qkv, m->stream);
+    P.nsets = 3;
+    return launch_dec_gemv_q4<EPI_PLAIN, 1>(P, m->opt_rpw_qkv, m->stream);
 }
 
 static int launch_attn(ifa_model *m, int l)
@@ -177,14 +206,21 @@ static int launch_attn(ifa_model *m, int l)
     const int rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f);
     DecAttnParams A; memset(&A, 0, sizeof(A));
     A.q = m->q; A.k_new = m->k; A.v_new = m->v; A.kcache = (uint8_t *)L.kcache; A.vcache = (uint8_t *)L.vcache;
-    A.state = m->state; A.heads = c.heads; A.kv_heads = c.kv_heads; A.head_dim = c.head_dim;
-    A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale; A.rope_theta = c.rope_theta;
-    A.rope_order = c.rope_order; A.rope_dims = rope_dims; A.rope_cols = rope_dims;
+    A.state = m->state; A.rope_tab = m->rope_tab; A.heads = c.heads; A.kv_heads = c.kv_heads;
+    A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale;
+    A.rope_order = c.rope_order; A.rope_cols = rope_dims;
     A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
     A.out = m->att; A.max_ctx = c.max_ctx;
     const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx);
-    if (A.kv_q8) k_dec_attn<true><<<dim3(c.heads), dim3(256), asmem, m->stream>>>(A);
-    else k_dec_attn<false><<<dim3(c.heads), dim3(256), asmem, m->stream>>>(A);
+    const dim3 grid((unsigned)c.heads), block(256);
+#define IFA_ATTN(HDV) \
+    case HDV: if (A.kv_q8) k_dec_attn<HDV, true><<<grid, block, asmem, m->stream>>>(A); \
+              else k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A); break;
+    switch (c.head_dim) {
+        IFA_ATTN(32) IFA_ATTN(64) IFA_ATTN(128)
+    default: return ifa_fail(IFA_ERR_ARG, "fused attention: head_dim %d", c.head_dim);
+    }
+#undef IFA_ATTN
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
@@ -195,8 +231,8 @@ static int launch_wo(ifa_model *m, int l, const half_t *x)
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->att; P.cols = (int)L.t[T_WO].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
     P.set[0].W[0] = (const uint8_t *)L.t[T_WO].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
-    P.set[0].y = m->a; P.set[0].rows = (int)L.t[T_WO].rows; P.residual = x;
-    return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, 1, P.set[0].rows, m->opt_rpw_wo, m->stream);
+    P.set[0].y = m->a; P.set[0].rows = (int)L.t[T_WO].rows; P.residual = x; P.nsets = 1;
+    return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, m->opt_rpw_wo, m->stream);
 }
 
 static int launch_ffn13(ifa_model *m, int l)
@@ -207,12 +243,12 @@ static int launch_ffn13(ifa_model *m, int l)
     P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
     P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32; P.act_kind = c.act_kind;
     P.set[0].W[0] = (const uint8_t *)L.t[T_W1].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W1_B].data;
-    P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows;
+    P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows; P.nsets = 1;
     if (L.t[T_W3].present()) {
         P.set[0].W[1] = (const uint8_t *)L.t[T_W3].tiled; P.set[0].bias[1] = (const half_t *)L.t[T_W3_B].data;
-        return launch_dec_gemv_q4<EPI_GLU, 1>(P, 1, P.set[0].rows, m->opt_rpw_ffn, m->stream);
+        return launch_dec_gemv_q4<EPI_GLU, 1>(P, m->opt_rpw_ffn, m->stream);
     }
-    return launch_dec_gemv_q4<EPI_ACT, 1>(P, 1, P.set[0].rows, m->opt_rpw_ffn, m->stream);
+    return launch_dec_gemv_q4<EPI_ACT, 1>(P, m->opt_rpw_ffn, m->stream);
 }
 
 static int launch_w2(ifa_model *m, int l, half_t *xnext)
@@ -221,8 +257,8 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext)
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
     P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
-    P.set[0].y = xnext; P.set[0].rows = (int)L.t[T_W2].rows; P.residual = m->a;
-    return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, 1, P.set[0].rows, m->opt_rpw_w2, m->stream);
+    P.set[0].y = xnext; P.set[0].rows = (int)L.t[T_W2].rows; P.residual = m->a; P.nsets = 1;
+    return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, m->opt_rpw_w2, m->stream);
 }
 
 static int launch_lm(ifa_model *m, const half_t *x)
@@ -239,7 +275,9 @@ static int enqueue_fused_step(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
     hipStream_t s = m->stream;
-    k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows, m->x);
+    k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows, m->x,
+                                               c.rope_order ? m->rope_tab : nullptr, c.head_dim, c.rope_theta,
+                                               (int)(c.head_dim * c.partial_rotary + 0.5f));
     IFA_LAUNCH_CHECK();
     half_t *x = m->x, *xnext = m->x2;
     int rc;
@@ -450,6 +488,7 @@ int ifa_model_destroy(ifa_model *m)
     for (half_t **b : bufs) if (*b) (void)hipFree(*b);
     if (m->xq) (void)hipFree(m->xq);
     if (m->state) (void)hipFree(m->state);
+    if (m->rope_tab) (void)hipFree(m->rope_tab);
     if (m->tokens_dev) (void)hipFree(m->tokens_dev);
     if (m->host_pinned) (void)hipHostFree(m->host_pinned);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -528,6 +567,7 @@ int ifa_model_finalize(ifa_model *m)
     if (!m->state) {
         IFA_HIP_CHECK(hipMalloc((void **)&m->state, sizeof(int) * (8 + ifa_model::RING)));
         IFA_HIP_CHECK(hipMemsetAsync(m->state, 0, sizeof(int) * (8 + ifa_model::RING), m->stream));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->rope_tab, sizeof(float) * (size_t)c.head_dim));
         IFA_HIP_CHECK(hipHostMalloc((void **)&m->host_pinned, sizeof(int) * (8 + ifa_model::RING), hipHostMallocDefault));
     }
     int rc = ensure_scratch(m, 1);
@@ -554,7 +594,8 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     IFA_REQUIRE(m && name, "ifa_model_set_option: null pointer");
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
-        {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}};
+        {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
@@ -640,6 +681,7 @@ int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr,
     const ifa_model_config &c = m->cfg;
     size_t b = 0; void *p = nullptr;
     if (!strcmp(name, "logits")) { p = m->logits; b = (size_t)c.vocab * 2; }
+    else if (!strcmp(name, "trace")) { p = m->trace; b = m->trace ? sizeof(long long) * 2048 * 8 : 0; }
     else if (!strcmp(name, "hidden")) { p = m->xn; b = (size_t)c.dim * 2; }
     else if (!strcmp(name, "kcache") || !strcmp(name, "vcache")) {
         IFA_REQUIRE(layer >= 0 && layer < c.layers && m->finalized, "ifa_model_get_buffer: layer %d", layer);
@@ -681,8 +723,18 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
     hipStream_t s = m->stream;
     m->host_pinned[0] = 1; m->host_pinned[1] = std::min(m->cfg.max_ctx - 1, 64); m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
+    auto touch_layer = [&](int l) {
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids) {
+            const Tensor &t = m->layers[(size_t)l].t[id];
+            if (!t.tiled) continue;
+            const size_t bytes = t.rows * ifa_row_bytes(t.dtype, t.cols);
+            k_touch<<<dim3(8), dim3(256), 0, s>>>((const uint8_t *)t.tiled, bytes, (size_t)m->opt_touch_stride, m->state + 7);
+        }
+    };
     auto one = [&](int i) -> int {
-        const int l = i % m->cfg.layers;     // rotate over layers: distinct weights every launch
+        const int l = m->opt_bench_mode == 1 ? 0 : i % m->cfg.layers;     // rotate over layers: distinct weights every launch
+        if (m->opt_bench_mode == 2) touch_layer(l);
         switch (which) {
         case 0: return launch_qkv(m, l, m->x);
         case 1: return launch_attn(m, l);
@@ -692,13 +744,22 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
         default: return launch_lm(m, m->x);
         }
     };
+    k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, m->cfg.dim, (int)m->g[T_EMBD].rows, m->x,
+                                               m->cfg.rope_order ? m->rope_tab : nullptr, m->cfg.head_dim, m->cfg.rope_theta,
+                                               (int)(m->cfg.head_dim * m->cfg.partial_rotary + 0.5f));
     for (int i = 0; i < 3; i++) if ((rc = one(i))) return rc;
+    if (m->opt_trace) {
+        if (!m->trace) IFA_HIP_CHECK(hipMalloc((void **)&m->trace, sizeof(long long) * 2048 * 8));
+        IFA_HIP_CHECK(hipMemsetAsync(m->trace, 0, sizeof(long long) * 2048 * 8, s));
+        g_trace_ptr = m->trace;
+    }
     hipEvent_t e0, e1;
     IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1));
     IFA_HIP_CHECK(hipEventRecord(e0, s));
     for (int i = 0; i < iters; i++) if ((rc = one(i))) return rc;
     IFA_HIP_CHECK(hipEventRecord(e1, s));
     IFA_HIP_CHECK(hipStreamSynchronize(s));
+    g_trace_ptr = nullptr;
     float ms = 0;
     IFA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -6,24 +6,54 @@
 namespace ifa {
 
 // Tensor_RmsNorm_Kernel (src/kernels/unary_tensor_opr.h:216-289): thread `tid`
-// of `nthreads` sums its contiguous chunk; each add is done in double and
-// rounded back to float exactly like `sum += (double)x*(double)x` on a float sum.
+// of `nthreads` sums its contiguous chunk with `sum += (double)x*(double)x` on a
+// float accumulator.  For F16 inputs that is bit-identical to an fp32 fma chain:
+// x*x is exact in fp32 (11-bit significands), and the double-precision add of
+// two floats followed by rounding to float equals the correctly rounded fp32 add
+// (exact in double when the exponents are within 29 bits; otherwise the addend is
+// far below half an ulp and both round to the larger operand).  The oracle keeps
+// the double formulation; tests/ check the two agree bit for bit.
 __device__ __forceinline__ float rms_partial(const half_t *src, int cols, int tid, int nthreads)
 {
     const int x_len = (cols + nthreads - 1) / nthreads;
     const int xs0 = tid * x_len, xe = min((tid + 1) * x_len, cols);
     float sum = 0.0f;
+    if ((x_len & 7) == 0 && xe - xs0 == x_len && ((reinterpret_cast<uintptr_t>(src + xs0) & 15) == 0)) {          // vector loads first, then the ordered chain
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        for (int xi = xs0; xi < xe; xi += 8) {
+            const h8 v = *reinterpret_cast<const h8 *>(src + xi);
+#pragma unroll
+            for (int i = 0; i < 8; i++) sum = __builtin_fmaf((float)v[i], (float)v[i], sum);
+        }
+        return sum;
+    }
     for (int xi = xs0; xi < xe; xi++) {
-        double v = (double)h2f(src[xi]);
-        sum = (float)((double)sum + v * v);
+        const float v = h2f(src[xi]);
+        sum = __builtin_fmaf(v, v, sum);
     }
     return sum;
 }
 
 __device__ __forceinline__ float rms_scale_from_partials(const float *part, int n, int cols, float eps)
 {
+    // strictly ordered sum (thread 0 of the reference kernel); reads are issued in
+    // batches of 64 values so the LDS latency is paid twice, not once per element
     float total = 0.0f;
-    for (int i = 0; i < n; i++) total = total + part[i];
+    int i0 = 0;
+    if ((reinterpret_cast<uintptr_t>(part) & 15) == 0) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (; i0 + 64 <= n; i0 += 64) {
+            f4 buf[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) buf[i] = reinterpret_cast<const f4 *>(part + i0)[i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                total = total + buf[i][0]; total = total + buf[i][1];
+                total = total + buf[i][2]; total = total + buf[i][3];
+            }
+        }
+    }
+    for (int i = i0; i < n; i++) total = total + part[i];
     float mean = total / (float)cols;
     return 1.0f / sqrtf(mean + eps);
 }
