@@ -98,8 +98,11 @@ int ifa_gemv(int w_dtype, const void *W, size_t rows, size_t cols,
              int x_dtype, const void *x, const void *bias_f16, void *y_f16, ifa_stream stream);
 
 /* Re-tile reference-layout rows into the row-local plane layout the fused
- * decode kernels stream (DESIGN.md "HBM layout"); same byte count per row.
- * Supported for the AX8-eligible types; src and dst must not alias. */
+ * decode kernels stream (DESIGN.md "HBM layout"): same bytes per row, row stride
+ * padded to a multiple of 16 (ifa_tiled_row_bytes; 0 for types without a tiled
+ * layout).  Supported for the AX8-eligible types; src and dst must not alias;
+ * dst holds rows * ifa_tiled_row_bytes(dtype, cols) bytes. */
+size_t ifa_tiled_row_bytes(int dtype, size_t cols);
 int ifa_repack_weights(int dtype, const void *src, size_t rows, size_t cols, void *dst, ifa_stream stream);
 /* same GEMV as ifa_gemv(x_dtype = Q8) reading the re-tiled layout */
 int ifa_gemv_tiled(int w_dtype, const void *Wt, size_t rows, size_t cols,
@@ -211,6 +214,28 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps,
 /* debugging taps: "logits", "hidden", "kcache", "vcache" (device pointers) */
 int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr, size_t *bytes);
 void *ifa_model_stream(ifa_model *m);
+/* run the worker on a caller-owned stream (e.g. the one the caller's RCCL collectives are ordered on) */
+int ifa_model_set_stream(ifa_model *m, ifa_stream stream);
+
+/* ---- tensor-parallel decode (BY_TENSOR partition, src/transformer/network_builder.cc:1594-1686):
+ * the worker holds heads/tp_size heads, kv_heads/tp_size KV heads and ffn/tp_size FFN rows; the
+ * caller sums the two partial [dim] F16 vectors per layer over the group exactly where the
+ * reference calls DistributeAndMergeTensors (inference_worker.cc:1378-1391, :1882-1895).
+ * All calls only enqueue work on the worker's stream.
+ *   begin(token,pos)            token < 0: use the id already in the device state
+ *   attn(l, partial)            norm + QKV + attention + Wo product (no bias/residual)
+ *   post_attn(l, reduced)       + bias, + residual
+ *   ffn(l, partial)             norm + W1/W3 + act + W2 product
+ *   post_ffn(l, reduced)        + bias, + residual -> next layer input
+ *   logits(shard_out)           final norm + this rank's vocabulary rows of lm_head
+ *   set_token(dev_ptr)          next token id from device memory (after the distributed argmax) */
+int ifa_model_tp_begin(ifa_model *m, int token, int pos);
+int ifa_model_tp_attn(ifa_model *m, int layer, void *partial_out_f16);
+int ifa_model_tp_post_attn(ifa_model *m, int layer, const void *reduced_f16);
+int ifa_model_tp_ffn(ifa_model *m, int layer, void *partial_out_f16);
+int ifa_model_tp_post_ffn(ifa_model *m, int layer, const void *reduced_f16);
+int ifa_model_tp_logits(ifa_model *m, void *logits_shard_out_f16);
+int ifa_model_tp_set_token(ifa_model *m, const int *token_dev);
 /* reference-layout copy of a loaded tensor (device pointer); returns 1 if the tensor is not set */
 int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols);
 /* Average duration (HIP events on the worker's stream) of `iters` back-to-back

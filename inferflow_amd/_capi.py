@@ -64,6 +64,7 @@ SIGNATURES = {
     "ifa_dequantize": (_i, [_i, _vp, _sz, _sz, _vp, _vp]),
     "ifa_quantize_act_q8": (_i, [_vp, _sz, _sz, _vp, _vp]),
     "ifa_gemv": (_i, [_i, _vp, _sz, _sz, _i, _vp, _vp, _vp, _vp]),
+    "ifa_tiled_row_bytes": (_sz, [_i, _sz]),
     "ifa_repack_weights": (_i, [_i, _vp, _sz, _sz, _vp, _vp]),
     "ifa_gemv_tiled": (_i, [_i, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "ifa_layernorm": (_i, [_i, _vp, _sz, _sz, _vp, _vp, _f, _f, _vp, _vp]),
@@ -89,6 +90,14 @@ SIGNATURES = {
     "ifa_model_get_buffer": (_i, [_vp, C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "ifa_model_stream": (_vp, [_vp]),
     "ifa_model_time_kernel": (_i, [_vp, _i, _i, _vp]),
+    "ifa_model_set_stream": (_i, [_vp, _vp]),
+    "ifa_model_tp_begin": (_i, [_vp, _i, _i]),
+    "ifa_model_tp_attn": (_i, [_vp, _i, _vp]),
+    "ifa_model_tp_post_attn": (_i, [_vp, _i, _vp]),
+    "ifa_model_tp_ffn": (_i, [_vp, _i, _vp]),
+    "ifa_model_tp_post_ffn": (_i, [_vp, _i, _vp]),
+    "ifa_model_tp_logits": (_i, [_vp, _vp]),
+    "ifa_model_tp_set_token": (_i, [_vp, _vp]),
     "ifa_model_get_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
 }
 

@@ -26,6 +26,7 @@
 #pragma once
 #include "ifa_device.h"
 #include "ifa_math.h"
+#include "ifa_tiled.h"
 
 namespace ifa {
 
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_q4(const DecGemvParams
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (SGPR)
     const int gw = blockIdx.x * DEC_WAVES + wave;
     const int W = gridDim.x * DEC_WAVES;
-    const size_t row_bytes = (size_t)P.nblk * 20;
+    const size_t row_bytes = tiled_row_bytes(Q4_B32T1A, (size_t)P.nblk);
     constexpr int NM = (EPI == EPI_GLU) ? 2 : 1;
     const int npass = (P.total_rows + RW * W - 1) / (RW * W);
 

@@ -46,6 +46,7 @@ struct ifa_model {
     std::vector<Layer> layers;
     Tensor g[10];
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     bool finalized = false;
     // scratch
     half_t *x = nullptr, *x2 = nullptr, *xn = nullptr, *hn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
@@ -169,7 +170,7 @@ static bool fused_supported(const ifa_model *m, std::string *why)
         for (int id : ids) {
             const Tensor &t = L.t[id];
             if (!t.present() || !is_q4(t.dtype) || !t.tiled) return fail("fused path needs Q4_B32T1 weights (tiled)");
-            if (t.cols > 16384 || (t.cols / 32) % 4 != 0) return fail("fused path needs cols % 128 == 0 and <= 16384");
+            if (t.cols > 16384 || t.cols % 32 != 0) return fail("fused path needs cols % 32 == 0 and <= 16384");
         }
         if (L.t[T_W3].present() && (!is_q4(L.t[T_W3].dtype) || !L.t[T_W3].tiled)) return fail("w3 must be Q4_B32T1");
         if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present()) return fail("pre-norm weights required");
@@ -225,13 +226,19 @@ static int launch_attn(ifa_model *m, int l)
     return IFA_OK;
 }
 
-static int launch_wo(ifa_model *m, int l, const half_t *x)
+// partial != nullptr (tensor parallel): write the un-merged product there, no bias, no residual
+static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nullptr)
 {
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->att; P.cols = (int)L.t[T_WO].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
-    P.set[0].W[0] = (const uint8_t *)L.t[T_WO].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
-    P.set[0].y = m->a; P.set[0].rows = (int)L.t[T_WO].rows; P.residual = x; P.nsets = 1;
+    P.set[0].W[0] = (const uint8_t *)L.t[T_WO].tiled; P.set[0].rows = (int)L.t[T_WO].rows; P.nsets = 1;
+    if (partial) {
+        P.set[0].y = partial;
+        return launch_dec_gemv_q4<EPI_PLAIN, 0>(P, m->opt_rpw_wo, m->stream);
+    }
+    P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
+    P.set[0].y = m->a; P.residual = x;
     return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, m->opt_rpw_wo, m->stream);
 }
 
@@ -251,22 +258,27 @@ static int launch_ffn13(ifa_model *m, int l)
     return launch_dec_gemv_q4<EPI_ACT, 1>(P, m->opt_rpw_ffn, m->stream);
 }
 
-static int launch_w2(ifa_model *m, int l, half_t *xnext)
+static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullptr)
 {
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
-    P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
-    P.set[0].y = xnext; P.set[0].rows = (int)L.t[T_W2].rows; P.residual = m->a; P.nsets = 1;
+    P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].rows = (int)L.t[T_W2].rows; P.nsets = 1;
+    if (partial) {
+        P.set[0].y = partial;
+        return launch_dec_gemv_q4<EPI_PLAIN, 0>(P, m->opt_rpw_w2, m->stream);
+    }
+    P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
+    P.set[0].y = xnext; P.residual = m->a;
     return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, m->opt_rpw_w2, m->stream);
 }
 
-static int launch_lm(ifa_model *m, const half_t *x)
+static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr)
 {
     const ifa_model_config &c = m->cfg;
     DecLmHeadParams H; memset(&H, 0, sizeof(H));
     H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
-    H.eps = c.eps; H.cols = c.dim; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = m->logits;
+    H.eps = c.eps; H.cols = c.dim; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = logits_out ? logits_out : m->logits;
     H.rows = (int)m->g[T_LM_HEAD].rows; H.xn_out = m->xn;
     return launch_lmhead(H, m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, m->stream);
 }
@@ -491,7 +503,7 @@ int ifa_model_destroy(ifa_model *m)
     if (m->rope_tab) (void)hipFree(m->rope_tab);
     if (m->tokens_dev) (void)hipFree(m->tokens_dev);
     if (m->host_pinned) (void)hipHostFree(m->host_pinned);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return IFA_OK;
 }
@@ -521,7 +533,7 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
     const bool is_matrix = tensor_id == T_WQ || tensor_id == T_WK || tensor_id == T_WV || tensor_id == T_WO
         || tensor_id == T_W1 || tensor_id == T_W2 || tensor_id == T_W3;
     if (is_matrix && ax8_eligible(dtype)) {
-        IFA_HIP_CHECK(hipMalloc(&t->tiled, bytes));
+        IFA_HIP_CHECK(hipMalloc(&t->tiled, rows * ifa_tiled_row_bytes(dtype, cols)));
         int rc = ifa_repack_weights(dtype, t->data, rows, cols, t->tiled, m->stream);
         if (rc) return rc;
     }
@@ -695,6 +707,108 @@ int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr,
 
 void *ifa_model_stream(ifa_model *m) { return m ? (void *)m->stream : nullptr; }
 
+int ifa_model_set_stream(ifa_model *m, ifa_stream stream)
+{
+    IFA_REQUIRE(m, "ifa_model_set_stream: null model");
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    if (m->stream) IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (m->stream && m->own_stream) IFA_HIP_CHECK(hipStreamDestroy(m->stream));
+    m->stream = ifa_s(stream);
+    m->own_stream = false;
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    return IFA_OK;
+}
+
+// ---- tensor-parallel decode, one segment per call (the caller all-reduces between them):
+// the reference's DistributeAndMergeTensors sits exactly at these two seams
+// (src/transformer/inference_worker.cc:1378-1391, :1882-1895).
+__global__ void k_tp_set_state(int *state, int token, int pos)
+{
+    if (token >= 0) state[0] = token;
+    state[1] = pos;
+}
+
+static int tp_ready(ifa_model *m)
+{
+    IFA_REQUIRE(m && m->finalized, "tensor-parallel step: model not finalized");
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    std::string why;
+    if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
+    return ensure_scratch(m, 1);
+}
+
+int ifa_model_tp_begin(ifa_model *m, int token, int pos)
+{
+    int rc = tp_ready(m);
+    if (rc) return rc;
+    IFA_REQUIRE(pos >= 0 && pos < m->cfg.max_ctx, "ifa_model_tp_begin: position %d outside max_ctx %d", pos, m->cfg.max_ctx);
+    const ifa_model_config &c = m->cfg;
+    k_tp_set_state<<<1, 1, 0, m->stream>>>(m->state, token, pos);     // token < 0: keep the id already on the device
+    k_dec_gather<<<dim3(2), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows,
+                                                       m->x, c.rope_order ? m->rope_tab : nullptr, c.head_dim, c.rope_theta,
+                                                       (int)(c.head_dim * c.partial_rotary + 0.5f));
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_model_tp_attn(ifa_model *m, int layer, void *partial_out_f16)
+{
+    IFA_REQUIRE(m && partial_out_f16 && layer >= 0 && layer < m->cfg.layers, "ifa_model_tp_attn: bad arguments");
+    int rc;
+    if ((rc = launch_qkv(m, layer, m->x))) return rc;
+    if ((rc = launch_attn(m, layer))) return rc;
+    return launch_wo(m, layer, m->x, (half_t *)partial_out_f16);
+}
+
+int ifa_model_tp_post_attn(ifa_model *m, int layer, const void *reduced_f16)
+{
+    IFA_REQUIRE(m && reduced_f16 && layer >= 0 && layer < m->cfg.layers, "ifa_model_tp_post_attn: bad arguments");
+    const size_t D = (size_t)m->cfg.dim;
+    const Tensor &b = m->layers[(size_t)layer].t[T_WO_B];
+    const void *src = reduced_f16;
+    int rc;
+    if (b.present()) {     // bias once, after the merge (inference_worker.cc:1388-1390)
+        if ((rc = ifa_add(reduced_f16, b.data, D, 0, m->a, m->stream))) return rc;
+        src = m->a;
+    }
+    return ifa_add(m->x, src, D, 0, m->a, m->stream);      // Add(out, layer_input, out)
+}
+
+int ifa_model_tp_ffn(ifa_model *m, int layer, void *partial_out_f16)
+{
+    IFA_REQUIRE(m && partial_out_f16 && layer >= 0 && layer < m->cfg.layers, "ifa_model_tp_ffn: bad arguments");
+    int rc;
+    if ((rc = launch_ffn13(m, layer))) return rc;
+    return launch_w2(m, layer, nullptr, (half_t *)partial_out_f16);
+}
+
+int ifa_model_tp_post_ffn(ifa_model *m, int layer, const void *reduced_f16)
+{
+    IFA_REQUIRE(m && reduced_f16 && layer >= 0 && layer < m->cfg.layers, "ifa_model_tp_post_ffn: bad arguments");
+    const size_t D = (size_t)m->cfg.dim;
+    const Tensor &b = m->layers[(size_t)layer].t[T_W2_B];
+    const void *src = reduced_f16;
+    int rc;
+    if (b.present()) {
+        if ((rc = ifa_add(reduced_f16, b.data, D, 0, m->f, m->stream))) return rc;
+        src = m->f;
+    }
+    return ifa_add(src, m->a, D, 0, m->x, m->stream);       // Add(layer_out, ff_out, residual)
+}
+
+int ifa_model_tp_logits(ifa_model *m, void *logits_shard_out_f16)
+{
+    IFA_REQUIRE(m && logits_shard_out_f16, "ifa_model_tp_logits: bad arguments");
+    return launch_lm(m, m->x, (half_t *)logits_shard_out_f16);
+}
+
+int ifa_model_tp_set_token(ifa_model *m, const int *token_dev)
+{
+    IFA_REQUIRE(m && token_dev, "ifa_model_tp_set_token: bad arguments");
+    IFA_HIP_CHECK(hipMemcpyAsync(m->state, token_dev, sizeof(int), hipMemcpyDeviceToDevice, m->stream));
+    return IFA_OK;
+}
+
 int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols)
 {
     IFA_REQUIRE(m && tensor_id >= 0 && tensor_id < T_MAX, "ifa_model_get_tensor: bad arguments");
@@ -728,7 +842,7 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
         for (int id : ids) {
             const Tensor &t = m->layers[(size_t)l].t[id];
             if (!t.tiled) continue;
-            const size_t bytes = t.rows * ifa_row_bytes(t.dtype, t.cols);
+            const size_t bytes = t.rows * ifa_tiled_row_bytes(t.dtype, t.cols);
             k_touch<<<dim3(8), dim3(256), 0, s>>>((const uint8_t *)t.tiled, bytes, (size_t)m->opt_touch_stride, m->state + 7);
         }
     };

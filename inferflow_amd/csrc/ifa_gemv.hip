@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_gemv_ax8_generic(const uint8_t *__restr
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const uint8_t *wrow = W + (size_t)row * nblk * BB;
+    const uint8_t *wrow = W + (size_t)row * (TILED ? tiled_row_bytes(DT, (size_t)nblk) : (size_t)nblk * BB);
     float acc = 0.0f;
     for (int blk = lane; blk < nblk; blk += 64) {
         RawBlock<BB> b;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) k_gemv_q4b32(const uint8_t *__restrict__ 
     const int row0 = gw * rows_per_wave;
     if (row0 >= rows) return;
     const int row_end = min(row0 + rows_per_wave, rows);
-    const size_t row_bytes = (size_t)nblk * 20;
+    const size_t row_bytes = TILED ? tiled_row_bytes(Q4_B32T1A, (size_t)nblk) : (size_t)nblk * 20;
 
     int xe[NJ][4], xo[NJ][4];
     float xs[NJ], xsf[NJ];
@@ -267,7 +267,7 @@ static int launch_ax8(int w_dtype, const void *W, size_t rows, size_t cols, cons
     const uint8_t *Wp = (const uint8_t *)W; const uint8_t *xp = (const uint8_t *)xq8;
     const half_t *bp = (const half_t *)bias; half_t *yp = (half_t *)y;
     // fast path: Q4_B32T1, rows of 16-byte aligned planes
-    if ((w_dtype == Q4_B32T1A || w_dtype == Q4_B32T1B) && nblk % 4 == 0 && nblk <= 512) {
+    if ((w_dtype == Q4_B32T1A || w_dtype == Q4_B32T1B) && nblk <= 512) {
         int nj = (int)((nblk + 63) / 64);
         int rpw = rows >= 8192 ? 4 : 2;
         unsigned waves = ifa_cdiv(rows, (size_t)rpw), grid = ifa_cdiv(waves, 4);

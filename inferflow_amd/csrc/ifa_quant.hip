@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_repack(const uint8_t *__restrict__ src,
     if (bi >= (size_t)rows * nblk) return;
     int row = (int)(bi / nblk), blk = (int)(bi % nblk);
     const uint8_t *s = src + bi * BB;
-    uint8_t *drow = dst + (size_t)row * nblk * BB;
+    uint8_t *drow = dst + (size_t)row * tiled_row_bytes(DT, (size_t)nblk);
 #pragma unroll
     for (int p = 0; p < L::NPLANES; p++) {
         uint8_t *d = drow + (size_t)L::plane_start(p) * nblk + (size_t)blk * L::plane_len(p);
@@ -131,6 +131,13 @@ int ifa_quantize_act_q8(const void *src_f16, size_t rows, size_t cols, void *dst
     k_quantize_act_q8<<<dim3(ifa_cdiv(cols, 256), (unsigned)rows), dim3(256), 0, ifa_s(stream)>>>((const half_t *)src_f16, (uint8_t *)dst, (int)cols, row_bytes);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
+}
+
+size_t ifa_tiled_row_bytes(int dtype, size_t cols)
+{
+    int cap = block_capacity(dtype);
+    if (cap <= 1 || !ax8_eligible(dtype)) return 0;
+    return tiled_row_bytes(dtype, (cols + (size_t)cap - 1) / (size_t)cap);
 }
 
 int ifa_repack_weights(int dtype, const void *src, size_t rows, size_t cols, void *dst, ifa_stream stream)

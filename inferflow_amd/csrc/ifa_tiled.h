@@ -8,7 +8,7 @@
 //     row = [plane0 of block 0..nblk-1][plane1 of block 0..nblk-1]...
 // plane0 is always the big low-bits plane (16 or 32 B per block) so that lane l
 // reading block l+64j issues an aligned global_load_dwordx4 and a whole wave
-// covers a contiguous 1-2 KiB.  The reference AoS layout stays the interchange
+// covers a contiguous 1-2 KiB.  The row stride is padded to 16 bytes (tiled_row_bytes).  The reference AoS layout stays the interchange
 // format (ifa_quantize / ifa_dequantize / goldens); ifa_repack_weights converts.
 #pragma once
 #include "ifa_device.h"
@@ -16,6 +16,14 @@
 namespace ifa {
 
 template <int DT> struct TiledLayout;
+
+// Row stride of the tiled layout: the reference row (nblk * block bytes) padded to a
+// multiple of 16 so that every row's big plane starts 16-byte aligned for any width
+// (e.g. 43 blocks per row when Llama-2-7B's W2 is column-sliced 8 ways).
+__host__ __device__ inline size_t tiled_row_bytes(int dtype, size_t nblk)
+{
+    return (nblk * (size_t)block_bytes(dtype) + 15) / 16 * 16;
+}
 
 // each plane p copies AoS bytes [src_off, src_off+len)
 #define IFA_TILED(DTV, N, LENS, OFFS)                                                        \

@@ -95,6 +95,31 @@ class DecodeWorker:
             out = out.view(np.uint16)
         return d.value, out, r.value, c.value
 
+    # ---- tensor-parallel segments (enqueue only; the caller all-reduces in between) ----
+    def set_stream(self, stream_ptr):
+        check(lib().ifa_model_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def tp_begin(self, token, pos):
+        check(lib().ifa_model_tp_begin(self._h, int(token), int(pos)))
+
+    def tp_attn(self, layer, partial):
+        check(lib().ifa_model_tp_attn(self._h, layer, C.c_void_p(partial.data_ptr())))
+
+    def tp_post_attn(self, layer, reduced):
+        check(lib().ifa_model_tp_post_attn(self._h, layer, C.c_void_p(reduced.data_ptr())))
+
+    def tp_ffn(self, layer, partial):
+        check(lib().ifa_model_tp_ffn(self._h, layer, C.c_void_p(partial.data_ptr())))
+
+    def tp_post_ffn(self, layer, reduced):
+        check(lib().ifa_model_tp_post_ffn(self._h, layer, C.c_void_p(reduced.data_ptr())))
+
+    def tp_logits(self, shard_out):
+        check(lib().ifa_model_tp_logits(self._h, C.c_void_p(shard_out.data_ptr())))
+
+    def tp_set_token(self, token_dev_int32):
+        check(lib().ifa_model_tp_set_token(self._h, C.c_void_p(token_dev_int32.data_ptr())))
+
     def buffer(self, name, layer=0):
         p, n = C.c_void_p(), C.c_size_t()
         check(lib().ifa_model_get_buffer(self._h, name.encode(), layer, C.byref(p), C.byref(n)))

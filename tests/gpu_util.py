@@ -95,7 +95,7 @@ def gemv(w_dtype, W, rows, cols, x, x_dtype, bias=None):
 
 
 def repack(dtype, W, rows, cols):
-    out = torch.empty_like(W)
+    out = torch.zeros((rows, capi().ifa_tiled_row_bytes(dtype, cols)), dtype=torch.uint8, device="cuda")
     ia.check(capi().ifa_repack_weights(dtype, p(W), rows, cols, p(out), stream()))
     return out
 

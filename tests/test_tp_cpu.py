@@ -1,0 +1,78 @@
+"""CPU (gloo, world_size 2): the tensor-parallel partition rules of inferflow_amd.tp
+reproduce the single-device result when the per-rank partial products -- computed
+here with the ORACLE, since there is no GPU -- are summed across ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as o
+    from inferflow_amd import dtypes as dt, tp, worker as W
+    shape = dict(dim=256, layers=1, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=64)
+    tp.check_divisible(shape, world)
+    s = tp.shard_shape(shape, world)
+    assert s["heads"] == 2 and s["kv_heads"] == 1 and s["ffn"] == 256
+    rng = np.random.default_rng(5)                      # same full tensors on every rank
+    x = rng.normal(0, 1.0, (1, 256)).astype(np.float16)
+    w1 = rng.normal(0, 0.06, (512, 256)).astype(np.float16)
+    w2 = rng.normal(0, 0.06, (256, 512)).astype(np.float16)
+    d = dt.Q4_B32T1A
+    # column-parallel then row-parallel pair (w1 rows split, w2 columns split)
+    w1_r = np.ascontiguousarray(tp.slice_tensor(W.T_W1, w1, rank, world))
+    w2_r = np.ascontiguousarray(tp.slice_tensor(W.T_W2, w2, rank, world))
+    assert w1_r.shape == (256, 256) and w2_r.shape == (256, 256)
+    xq = o.quantize_act_q8(x)
+    t_r = o.gemv_ax8(d, o.quantize(d, w1_r), 256, 256, xq)            # this rank's 256 FFN rows
+    part = o.gemv_ax8(d, o.quantize(d, w2_r), 256, 256, o.quantize_act_q8(t_r[None, :]))
+    red = torch.from_numpy(part.astype(np.float32))
+    dist.all_reduce(red)                                              # the exchange step
+    # single-device reference
+    t_full = o.gemv_ax8(d, o.quantize(d, w1), 512, 256, xq)
+    full = o.gemv_ax8(d, o.quantize(d, w2), 256, 512, o.quantize_act_q8(t_full[None, :]))
+    # slicing at block boundaries keeps every quant block identical, so the only
+    # difference is one extra fp16 rounding of each partial sum
+    err = np.abs(red.numpy() - full.astype(np.float32)).max()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, t_r.tobytes())
+    t_cat = np.concatenate([np.frombuffer(b, np.float16) for b in gathered])
+    q.put((rank, float(err), bool(np.array_equal(t_cat.view(np.uint16), t_full.view(np.uint16)))))
+    dist.destroy_process_group()
+
+
+def test_tp_partition_matches_single_device():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, rows_equal in res:
+        assert rows_equal, "row-split GEMV outputs must be bit-identical to the unsplit ones"
+        assert err <= 4e-3, "column-split partial sums differ from the unsplit product by %g" % err
+
+
+def test_divisibility_rules():
+    sys.path.insert(0, ROOT)
+    from inferflow_amd import tp, synth
+    tp.check_divisible(synth.SHAPES["llama2_7b"], 8)
+    with pytest.raises(ValueError):
+        tp.check_divisible(dict(synth.SHAPES["llama2_7b"], kv_heads=4), 8)
+    s = tp.shard_shape(synth.SHAPES["llama2_7b"], 8)
+    assert (s["heads"], s["kv_heads"], s["ffn"]) == (4, 4, 1376)
