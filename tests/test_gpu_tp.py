@@ -39,7 +39,7 @@ def _rank_main(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    r = tp.TPRunner("test_mha", dt.Q4_B32T1A, dt.F16, 32, world, rank, 0, std=0.06)
+    r = tp.TPRunner("test_gqa", dt.Q4_B32T1A, dt.F16, 32, world, rank, 0, std=0.06)
     for i, t in enumerate(PROMPT):
         r.step(int(t), i)
     torch.cuda.synchronize()
@@ -49,6 +49,8 @@ def _rank_main(rank, world, port, q):
         q.put(torch.cat(shards).float().cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        q.close(); q.join_thread()
 
 
 def test_tp_world2_matches_single_device_logits():
@@ -59,15 +61,16 @@ def test_tp_world2_matches_single_device_logits():
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    lg_tp = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    single = tp.TPRunner("test_mha", dt.Q4_B32T1A, dt.F16, 32, 1, 0, 0, std=0.06)
+        p.join(timeout=180)
+        assert p.exitcode == 0, "rank process failed (exit code %r)" % (p.exitcode,)
+    lg_tp = q.get(timeout=10)
+    single = tp.TPRunner("test_gqa", dt.Q4_B32T1A, dt.F16, 32, 1, 0, 0, std=0.06)
     for i, t in enumerate(PROMPT):
         single.step(int(t), i)
     torch.cuda.synchronize()
     lg_1 = single.logits.float().cpu().numpy()
     cos = float((lg_tp * lg_1).sum() / (np.linalg.norm(lg_tp) * np.linalg.norm(lg_1)))
     # extra fp16 rounding of the two partial sums per layer, re-quantised downstream
-    assert cos >= 0.9995 and np.abs(lg_tp - lg_1).max() <= 0.03, (cos, np.abs(lg_tp - lg_1).max())
+    tol = 0.02 * float(np.abs(lg_1).max()) + 0.02     # ~2 % of the logit range (|logit| up to ~4 here)
+    assert cos >= 0.9995 and np.abs(lg_tp - lg_1).max() <= tol, (cos, np.abs(lg_tp - lg_1).max(), tol)

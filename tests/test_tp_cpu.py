@@ -59,10 +59,10 @@ def test_tp_partition_matches_single_device():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+        p.join(timeout=120)
+        assert p.exitcode == 0, "rank process failed (exit code %r)" % (p.exitcode,)
+    res = [q.get(timeout=10) for _ in procs]
     for rank, err, rows_equal in res:
         assert rows_equal, "row-split GEMV outputs must be bit-identical to the unsplit ones"
         assert err <= 4e-3, "column-split partial sums differ from the unsplit product by %g" % err
