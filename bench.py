@@ -65,7 +65,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("IFA_FORCE_TP"):
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -108,9 +108,8 @@ def main():
         wall = float(tmax.item())
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     tok_s = steps / wall
@@ -137,7 +136,7 @@ def main():
         "last_tokens": [int(t) for t in toks[-4:]],
     }
     # ---- roofline of the dominant kernel, timed live with HIP events on the worker's stream
-    if world == 1 and runner.worker is not None:
+    if world == 1 and hasattr(runner, "export_host_tensors") and not os.environ.get("IFA_FORCE_TP"):
         s = runner.shape
         ffn_rows, d = s["ffn"], s["dim"]
         ffn13_bytes = 2 * ffn_rows * dt.row_bytes(dt.Q4_B32T1A, d)
@@ -156,7 +155,7 @@ def main():
                            "bytes_per_launch": ffn13_bytes, "us_per_launch": us}
         out["kernels"] = per_kernel
     # ---- CPU baseline (oracle port) on a bounded sample
-    if world == 1 and not args.no_cpu_baseline and runner.worker is not None:
+    if world == 1 and not args.no_cpu_baseline and not os.environ.get("IFA_FORCE_TP"):
         try:
             threads = min(os.cpu_count() or 1, 128)
             host = runner.export_host_tensors()
@@ -172,7 +171,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

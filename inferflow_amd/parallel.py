@@ -43,7 +43,8 @@ class SingleRunner:
 
 
 def build_runner(shape_name, wdtype, kv_dtype, max_ctx, world=1, rank=0, local_rank=0):
-    if world == 1:
+    import os
+    if world == 1 and not os.environ.get("IFA_FORCE_TP"):
         return SingleRunner(shape_name, wdtype, kv_dtype, max_ctx, device=local_rank)
     from .tp import TPRunner
     return TPRunner(shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank)

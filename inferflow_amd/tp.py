@@ -89,7 +89,11 @@ class TPRunner:
     """Greedy batch-1 decode over a tensor-parallel group (all ranks call the same methods)."""
 
     def __init__(self, shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank, group=None, **overrides):
+        import os
         self.world, self.rank, self.group = world, rank, group
+        # IFA_FORCE_TP=1 with one rank: still issue the collectives (plumbing check on a 1-GPU box)
+        self.force_collectives = bool(os.environ.get("IFA_FORCE_TP")) and dist.is_initialized()
+        self.worker = None
         self.worker, self.shape, self.local_shape = build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank,
                                                                     device=local_rank, **overrides)
         ok, why = self.worker.fused_supported()
@@ -110,7 +114,7 @@ class TPRunner:
         self.vs = vs
 
     def _all_reduce(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self, token, pos):
@@ -162,4 +166,4 @@ class TPRunner:
         return [int(x) for x in out.cpu().numpy()], e0.elapsed_time(e1)
 
     def export_host_tensors(self):
-        raise NotImplementedError("CPU baseline runs at N=1 only")
+        raise NotImplementedError("CPU baseline runs on the single-worker runner only")
