@@ -97,6 +97,14 @@ int ifa_quantize_act_q8(const void *src_f16, size_t rows, size_t cols, void *dst
 int ifa_gemv(int w_dtype, const void *W, size_t rows, size_t cols,
              int x_dtype, const void *x, const void *bias_f16, void *y_f16, ifa_stream stream);
 
+/* ---- prefill / batched linear layer (MatrixMultiplication's T>1 branch,
+ * src/transformer/inference_worker.cc:2374-2415: TensorOpr::Dequantize + CublasEngine::GemmEx
+ * F16xF16->F16 with fp32 accumulate + Transpose).  Y[tokens][rows] (F16) = X[tokens][cols] (F16)
+ * . W[rows][cols]^T (+bias); W in any block format (reference layout) or F16.  The weights are
+ * dequantised to half in registers and fed to v_mfma_f32_32x32x16_f16; no F16 copy of W exists. */
+int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x_f16, size_t tokens,
+             const void *bias_f16, void *y_f16, ifa_stream stream);
+
 /* Re-tile reference-layout rows into the row-local plane layout the fused
  * decode kernels stream (DESIGN.md "HBM layout"): same bytes per row, row stride
  * padded to a multiple of 16 (ifa_tiled_row_bytes; 0 for types without a tiled

@@ -360,8 +360,10 @@ static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const T
         if (rc) return rc;
         return ifa_gemv(W.dtype, W.data, N, K, Q8_B32T2, m->xq, b, C, s);
     }
-    // T > 1 (or ineligible types): weights dequantised to half, fp32 accumulate per row
-    // (the reference dequantises the whole tensor and calls cublasGemmEx; same arithmetic)
+    // T > 1: MFMA GEMM with the dequantisation fused in (the reference dequantises the whole
+    // tensor and calls cublasGemmEx; same arithmetic: half weights x half activations, fp32 accumulate)
+    if (T > 1 && K % 8 == 0) return ifa_gemm(W.dtype, W.data, N, K, A, (size_t)T, b, C, s);
+    // T == 1 with ineligible types: weights dequantised to half, fp32 accumulate per row
     for (int t = 0; t < T; t++) {
         int rc = ifa_gemv(W.dtype, W.data, N, K, F16, A + (size_t)t * K, b, C + (size_t)t * N, s);
         if (rc) return rc;

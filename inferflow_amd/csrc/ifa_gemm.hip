@@ -1,0 +1,198 @@
+// ifa_gemm.hip -- prefill / batched linear layer:  Y[T][N] = X[T][K] . W[N][K]^T (+bias)
+//
+// Reference (MatrixMultiplication, src/transformer/inference_worker.cc:2374-2415):
+// dequantise the WHOLE weight tensor to F16 scratch (TensorOpr::Dequantize), cublasGemmEx
+// F16 x F16 -> F16 with fp32 accumulation (src/tensor/cublas_engine.cu:420-436), transpose.
+// Here the dequantisation is fused into the GEMM: every lane decodes the quant block it needs
+// straight into its MFMA B-operand registers (values rounded to half exactly like the
+// reference's dequant tensor), the activation tile is staged through LDS, products go to
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate), one F16 rounding at the end, bias as a half add.
+// No full-tensor F16 copy is written or re-read, and no transpose.
+//
+// MFMA 32x32x16 operand mapping (cdna_hip_programming.md §3): lane (i = lane&31, g = lane>>5)
+// holds A[i][8g..8g+7] and B[8g..8g+7][i]; D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*g.
+// Tokens are the A rows, weight rows the B columns.  k is consumed in a permuted order
+// (lane half g works through quant block 2*step+g): the sum over k does not care.
+#include <algorithm>
+#include "ifa_host.h"
+#include "ifa_codec.h"
+
+namespace ifa {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GEMM_THREADS = 256;     // 4 waves, 32 weight rows each
+constexpr int GEMM_ROWS = 128;
+
+// weights of quant block `b` of row `n` as CAP halfs (reference rounding: half(q*scale+base))
+template <int DT, int CAP>
+__device__ __forceinline__ void load_block_f16(const uint8_t *__restrict__ W, size_t row, int nblk, int b, bool ok,
+                                               half_t (&v)[CAP])
+{
+    if constexpr (DT == F16) {
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(W + (row * (size_t)nblk + (size_t)b) * (CAP * 2));
+#pragma unroll
+        for (int i = 0; i < CAP / 8; i++) {
+            u32x4 t = ok ? p[i] : u32x4{0, 0, 0, 0};
+            const half8_t h = __builtin_bit_cast(half8_t, t);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[8 * i + e] = h[e];
+        }
+    } else if constexpr (DT == Q4_B32T1A || DT == Q4_B32T1B) {
+        // 20-byte blocks are 4-byte aligned: five dword loads, q*scale+base as one fp32 fma
+        // (q*scale is exact in fp32, so the fma rounds exactly like the reference's mul + add)
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(W + (row * (size_t)nblk + (size_t)b) * 20);
+        const uint32_t sb = p[0];
+        const float base = hbits2f((uint16_t)(sb & 0xFFFFu)), scale = hbits2f((uint16_t)(sb >> 16));
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t c = p[1 + w];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float q = (float)((c >> (4 * e)) & 0xFu);
+                v[8 * w + e] = ok ? f2h(__builtin_fmaf(q, scale, base)) : (half_t)0;
+            }
+        }
+    } else {
+        constexpr int BB = block_bytes(DT);
+        RawBlock<BB> blk;
+        blk.load(W + (row * (size_t)nblk + (size_t)b) * BB);
+        int q[CAP]; float scale, base;
+        decode_block<DT>(blk, q, scale, base);
+#pragma unroll
+        for (int i = 0; i < CAP; i++) v[i] = ok ? f2h(block_value<DT>(q[i], scale, base)) : (half_t)0;
+    }
+}
+
+// SPLITK = false: 4 waves x 32 rows per workgroup, all waves walk the whole K (large T).
+// SPLITK = true : the 4 waves share ONE 32-row tile and take every 4th K step each (their own
+//                 LDS slab, no workgroup barrier in the loop), partial tiles summed through LDS at
+//                 the end: 4x more workgroups when T is small and the layer is weight-stream bound.
+template <int DT, int MT, bool SPLITK>
+__global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restrict__ W, int N, int nblk,
+                                                         const half_t *__restrict__ X, int T, int K,
+                                                         const half_t *__restrict__ bias, half_t *__restrict__ Y)
+{
+    constexpr int CAP = (DT == F16) ? 32 : block_capacity(DT);
+    constexpr int KSTEP = 2 * CAP;                 // one quant block per lane half and step
+    constexpr int XROW = KSTEP * 2 + 16;           // bytes per staged activation row (+16: bank spread)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int n = SPLITK ? blockIdx.x * 32 + i : blockIdx.x * GEMM_ROWS + wave * 32 + i;
+    const size_t nrow = (size_t)min(n, N - 1);
+    char *slab = SPLITK ? smem + (size_t)wave * (32 * MT * XROW) : smem;
+    const int t0 = blockIdx.y * 32 * MT;
+    f32x16_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[mt][r] = 0.0f;
+
+    const int nsteps = (nblk + 1) / 2;
+    for (int step = SPLITK ? wave : 0; step < nsteps; step += SPLITK ? 4 : 1) {
+        // ---- stage X[t0 .. t0+32*MT)[step*KSTEP .. +KSTEP) into LDS (zero-filled past T / K)
+        if constexpr (SPLITK) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+        constexpr int CHUNKS_PER_ROW = KSTEP / 8;
+        for (int c = SPLITK ? lane : tid; c < 32 * MT * CHUNKS_PER_ROW; c += SPLITK ? 64 : GEMM_THREADS) {
+            const int r = c / CHUNKS_PER_ROW, cc = c % CHUNKS_PER_ROW;
+            const int tok = t0 + r, k = step * KSTEP + cc * 8;
+            u32x4 val = u32x4{0, 0, 0, 0};
+            if (tok < T && k < K) val = *reinterpret_cast<const u32x4 *>(X + (size_t)tok * K + k);
+            *reinterpret_cast<u32x4 *>(slab + (size_t)r * XROW + (size_t)cc * 16) = val;
+        }
+        // ---- this lane's quant block for the step, decoded to half in registers
+        const int b = 2 * step + g;
+        half_t v[CAP];
+        load_block_f16<DT, CAP>(W, nrow, nblk, min(b, nblk - 1), b < nblk, v);
+        if constexpr (SPLITK) __builtin_amdgcn_wave_barrier(); else __syncthreads();   // one wave's LDS ops are ordered
+#pragma unroll
+        for (int m = 0; m < CAP / 8; m++) {
+            half8_t bfrag;
+#pragma unroll
+            for (int e = 0; e < 8; e++) bfrag[e] = v[8 * m + e];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const half8_t afrag = *reinterpret_cast<const half8_t *>(slab + (size_t)(mt * 32 + i) * XROW
+                                                                       + (size_t)(g * CAP + 8 * m) * 2);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (SPLITK) {     // sum the 4 partial tiles: wave w parks its tile, wave 0 adds them in order 0,1,2,3
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem);      // [3][MT][16][64]
+        if (wave > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[(((wave - 1) * MT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mt][r] = acc[mt][r] + red[((w * MT + mt) * 16 + r) * 64 + lane];
+    }
+    if (n >= N) return;
+    const float bv = bias ? h2f(bias[n]) : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tok = t0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (tok < T) {
+                half_t y = f2h(acc[mt][r]);
+                if (bias) y = f2h(h2f(y) + bv);
+                Y[(size_t)tok * N + n] = y;
+            }
+        }
+}
+
+} // namespace ifa
+
+using namespace ifa;
+
+template <int DT>
+static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t T, const void *bias, void *Y, hipStream_t s)
+{
+    constexpr int CAP = (DT == F16) ? 32 : block_capacity(DT);
+    const int nblk = (int)(K / CAP);
+    constexpr int MT = 2;
+    const size_t slab = (size_t)32 * MT * (2 * CAP * 2 + 16);
+    if (T <= 128) {      // weight-stream bound: 32-row tiles, K split over the 4 waves
+        dim3 grid(ifa_cdiv(N, 32), ifa_cdiv(T, 32 * MT));
+        const size_t smem = std::max(4 * slab, (size_t)3 * MT * 16 * 64 * 4);
+        k_gemm_q<DT, MT, true><<<grid, dim3(GEMM_THREADS), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
+                                                                     (int)K, (const half_t *)bias, (half_t *)Y);
+    } else {
+        dim3 grid(ifa_cdiv(N, GEMM_ROWS), ifa_cdiv(T, 32 * MT));
+        k_gemm_q<DT, MT, false><<<grid, dim3(GEMM_THREADS), slab, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
+                                                                      (int)K, (const half_t *)bias, (half_t *)Y);
+    }
+    return IFA_OK;
+}
+
+extern "C" int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x_f16, size_t tokens,
+                        const void *bias_f16, void *y_f16, ifa_stream stream)
+{
+    IFA_REQUIRE(W && x_f16 && y_f16, "ifa_gemm: null pointer");
+    if (rows == 0 || tokens == 0) return IFA_OK;
+    const int cap = w_dtype == F16 ? 32 : block_capacity(w_dtype);
+    IFA_REQUIRE(cap > 1, "ifa_gemm: unsupported weight dtype %d", w_dtype);
+    IFA_REQUIRE(cols > 0 && cols % (size_t)cap == 0 && cols % 8 == 0, "ifa_gemm: cols %zu must be a multiple of %d", cols, cap);
+    IFA_REQUIRE(rows < (1u << 30) && cols < (1u << 30) && tokens <= 65535u * 64u, "ifa_gemm: shape too large");
+    hipStream_t s = ifa_s(stream);
+    if (w_dtype == F16) {
+        launch_gemm<F16>(W, rows, cols, x_f16, tokens, bias_f16, y_f16, s);
+    } else {
+        IFA_DISPATCH_QUANT_DTYPE(w_dtype, launch_gemm<DT>(W, rows, cols, x_f16, tokens, bias_f16, y_f16, s));
+    }
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}

@@ -112,3 +112,10 @@ def half_ulp_diff(a, b):
         u = np.ascontiguousarray(x).view(np.uint16).astype(np.int32)
         return np.where(u & 0x8000, 0x8000 - u, u)
     return np.abs(key(a) - key(b))
+
+
+def gemm(w_dtype, W, rows, cols, x, bias=None):
+    tokens = x.shape[0]
+    y = empty_f16(tokens, rows)
+    ia.check(capi().ifa_gemm(w_dtype, p(W), rows, cols, p(x), tokens, p(bias), p(y), stream()))
+    return y

@@ -281,3 +281,36 @@ def test_attention(kv_dtype, heads, kv_heads, hd, n_ctx, qt, alibi):
                                     heads, kv_heads, hd, kq_scale, alibi, 0, heads, g.p(out), g.stream()))
     # P differs by expf implementation and sum order (<= 1 half ulp per weight); O is a convex mix of |v| ~ 1
     assert np.abs(g.host(out).astype(np.float32) - exp.astype(np.float32)).max() <= 6e-3
+
+
+# ------------------------------------------------------------ prefill GEMM (MFMA)
+GEMM_TYPES = [dt.Q4_B32T1A, dt.Q3H_B64T1, dt.Q8_B32T2, dt.Q6_B64T1, dt.Q2_B32T1B, dt.Q4_B16, dt.F16]
+
+
+@pytest.mark.parametrize("d", GEMM_TYPES, ids=IDS(GEMM_TYPES))
+@pytest.mark.parametrize("T,rows,cols", [(5, 70, 256), (64, 128, 1024), (33, 200, 4096), (130, 96, 192)])
+def test_gemm_prefill_matches_per_token_oracle(d, T, rows, cols):
+    """Y[t] must equal the reference's dequantise-to-half + fp32-accumulate product per token
+    (orc_gemv_f16x); the MFMA sums the same exact products in a different order."""
+    if cols % dt.block_capacity(d):
+        pytest.skip("cols not a multiple of the block capacity")
+    rng = np.random.default_rng(T + rows + cols + d)
+    w = rng.normal(0, 0.05, (rows, cols)).astype(np.float16)
+    if d == dt.Q4_B16:
+        w = np.clip(w.astype(np.float32), -0.9, 1.4).astype(np.float16)
+    x = rng.normal(0, 1.0, (T, cols)).astype(np.float16)
+    bias = rng.normal(0, 0.5, rows).astype(np.float16)
+    Wq = w if d == dt.F16 else o.quantize(d, w)
+    y = g.host(g.gemm(d, g.dev(Wq), rows, cols, g.dev(x), g.dev(bias)))
+    for t in (0, T // 2, T - 1):
+        y_orc, y64 = o.gemv_f16x(d, Wq, rows, cols, x[t], bias=bias, want_f64=True)
+        # different fp32 summation order: <= 2 half ulps, except where cancellation leaves |y| tiny
+        ulp = g.half_ulp_diff(y[t], y_orc)
+        small = np.abs(y[t].astype(np.float32) - y_orc.astype(np.float32)) <= 1e-3 * float(np.abs(y64).mean() + 1e-6)
+        assert ((ulp <= 2) | small).all(), (t, ulp.max())
+        assert ((ulp != 0) & ~small).sum() <= max(2, 0.1 * ulp.size)
+        assert np.allclose(y[t].astype(np.float64), y64, rtol=2e-3, atol=2e-3 * float(np.abs(y64).mean() + 1))
+    # no bias, and T == 1 degenerate tile
+    y1 = g.host(g.gemm(d, g.dev(Wq), rows, cols, g.dev(x[:1])))
+    y_orc = o.gemv_f16x(d, Wq, rows, cols, x[0])
+    assert g.half_ulp_diff(y1[0], y_orc).max() <= 1
