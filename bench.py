@@ -25,14 +25,14 @@ HBM_PEAK_GBPS = 8000.0      # MI355X spec (MI355X_MICROARCH.md)
 PROMPT_LEN = 16
 
 
-def cpu_baseline(wk_host_tensors, shape, n_tokens, threads):
+def cpu_baseline(wk_host_tensors, shape, n_tokens, threads, kv_dtype):
     """Oracle port (test infrastructure used as the measured CPU baseline, never as the product)."""
     import numpy as np
     import oracle as o
     from inferflow_amd import dtypes as dt
     max_ctx = PROMPT_LEN + n_tokens + 4
     m = o.Model(dim=shape["dim"], layers=shape["layers"], heads=shape["heads"], kv_heads=shape["kv_heads"],
-                head_dim=shape["head_dim"], ffn=shape["ffn"], vocab=shape["vocab"], max_ctx=max_ctx, kv_dtype=dt.F16)
+                head_dim=shape["head_dim"], ffn=shape["ffn"], vocab=shape["vocab"], max_ctx=max_ctx, kv_dtype=kv_dtype)
     for (layer, tid), (dtype, arr, rows, cols) in wk_host_tensors.items():
         m.set_tensor(max(layer, 0), tid, dtype, arr, rows, cols)
     rng = np.random.default_rng(42)
@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--shape", default="llama2_7b")
+    ap.add_argument("--wdtype", default="q4", help="weight format: q4 (Q4_B32T1A, the headline config), q3h, q8, q4_b64, q5, q6")
+    ap.add_argument("--kv-dtype", default="f16", help="KV cache: f16 or q8 (configs[2] = --wdtype q3h --kv-dtype q8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     args = ap.parse_args()
@@ -74,10 +76,14 @@ def main():
         torch.cuda.set_device(0)
 
     from inferflow_amd import parallel
+    # the reference's .ini spellings (device_weight_data_type / device_kv_cache_data_type)
+    WD = {"q4": dt.Q4_B32T1A, "q3h": dt.Q3H_B64T1, "q8": dt.Q8_B32T2, "q4_b64": dt.Q4_B64T1, "q5": dt.Q5_B64T1, "q6": dt.Q6_B64T1}
+    wd = WD[args.wdtype.lower()]
+    kvd = {"f16": dt.F16, "q8": dt.Q8_B32T2}[args.kv_dtype.lower()]
     steps, warmup = args.steps, args.warmup
     max_ctx = PROMPT_LEN + warmup + steps + 8
     t_build = time.perf_counter()
-    runner = parallel.build_runner(args.shape, dt.Q4_B32T1A, dt.F16, max_ctx, world, rank, local_rank)
+    runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank)
     t_build = time.perf_counter() - t_build
 
     rng = np.random.default_rng(42)
@@ -114,18 +120,18 @@ def main():
 
     tok_s = steps / wall
     n_avg = PROMPT_LEN + warmup + steps / 2.0
-    w_bytes = synth.weight_bytes(args.shape, dt.Q4_B32T1A)
-    kv_bytes = synth.kv_bytes_per_ctx_row(args.shape, dt.F16)
+    w_bytes = synth.weight_bytes(args.shape, wd)
+    kv_bytes = synth.kv_bytes_per_ctx_row(args.shape, kvd)
     bytes_per_token = w_bytes + kv_bytes * n_avg
     out = {
-        "metric": "decode tokens/sec, Llama-2-7B Q4 batch=1 greedy (whole job)",
+        "metric": "decode tokens/sec, Llama-2-7B %s batch=1 greedy (whole job)" % ("Q4" if wd == dt.Q4_B32T1A else dt.name(wd)),
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": wall * 1e3 / steps, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "i8 (Q8 activations x Q4 weights, i32 dot, f32 scale, f16 I/O)",
+        "vs_baseline": None, "dtype": "i8 (Q8 activations x %s weights, i32 dot, f32 scale, f16 I/O)" % dt.name(wd),
         "data": "synthetic",
-        "config": {"workload": "%s decode, Q4_B32T1A weights + F16 lm_head, F16 KV cache, batch 1 greedy, "
-                               "%d-token prompt, context %d..%d" % (args.shape, PROMPT_LEN, PROMPT_LEN + warmup,
-                                                                  PROMPT_LEN + warmup + steps),
+        "config": {"workload": "%s decode, %s weights + F16 lm_head, %s KV cache, batch 1 greedy, "
+                               "%d-token prompt, context %d..%d" % (args.shape, dt.name(wd), dt.name(kvd), PROMPT_LEN,
+                                                                  PROMPT_LEN + warmup, PROMPT_LEN + warmup + steps),
                    "parallelism": "tp%d" % world if world > 1 else "single", "weights_bytes": w_bytes,
                    "bytes_per_token": bytes_per_token},
         "gpu_event_ms_per_step": gpu_ms / steps if gpu_ms and gpu_ms > 0 else None,
@@ -139,17 +145,17 @@ def main():
     if world == 1 and hasattr(runner, "export_host_tensors") and not os.environ.get("IFA_FORCE_TP"):
         s = runner.shape
         ffn_rows, d = s["ffn"], s["dim"]
-        ffn13_bytes = 2 * ffn_rows * dt.row_bytes(dt.Q4_B32T1A, d)
+        ffn13_bytes = 2 * ffn_rows * dt.row_bytes(wd, d)
         us = runner.worker.time_kernel(3, 320)
         per_kernel = {}
         names = ["qkv", "attn", "wo", "ffn13", "w2", "lm_head"]
-        kb = [(s["heads"] + 2 * s["kv_heads"]) * s["head_dim"] * dt.row_bytes(dt.Q4_B32T1A, d), None,
-              d * dt.row_bytes(dt.Q4_B32T1A, s["heads"] * s["head_dim"]), ffn13_bytes,
-              d * dt.row_bytes(dt.Q4_B32T1A, ffn_rows), s["vocab"] * d * 2]
+        kb = [(s["heads"] + 2 * s["kv_heads"]) * s["head_dim"] * dt.row_bytes(wd, d), None,
+              d * dt.row_bytes(wd, s["heads"] * s["head_dim"]), ffn13_bytes,
+              d * dt.row_bytes(wd, ffn_rows), s["vocab"] * d * 2]
         for i, nm in enumerate(names):
             u = runner.worker.time_kernel(i, 160)
             per_kernel[nm] = {"us": u, "GBps": (kb[i] / u / 1e3) if kb[i] else None}
-        out["roofline"] = {"bound": "hbm", "kernel": "k_dec_gemv_q4<EPI_GLU> (fused RMSNorm+Q8 quant+W1/W3 GEMV+SiLU*mul)",
+        out["roofline"] = {"bound": "hbm", "kernel": "k_dec_gemv<%s, EPI_GLU> (fused RMSNorm+Q8 quant+W1/W3 GEMV+SiLU*mul)" % dt.name(wd),
                            "achieved": ffn13_bytes / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": None,
                            "bytes_per_launch": ffn13_bytes, "us_per_launch": us}
@@ -160,13 +166,13 @@ def main():
             threads = min(os.cpu_count() or 1, 128)
             host = runner.export_host_tensors()
             n_cpu = args.cpu_tokens or 8
-            v, secs = cpu_baseline(host, runner.shape, n_cpu, threads)
+            v, secs = cpu_baseline(host, runner.shape, n_cpu, threads, kvd)
             if secs < 5 and not args.cpu_tokens:      # fast host: take a longer sample (~10-30 s)
                 n_cpu = int(min(256, max(8, 15.0 / (secs / n_cpu))))
-                v, secs = cpu_baseline(host, runner.shape, n_cpu, threads)
+                v, secs = cpu_baseline(host, runner.shape, n_cpu, threads, kvd)
             out["cpu_baseline"] = {"value": v, "unit": "tokens/s", "cores": threads, "kind": "port",
-                                   "sample": "%s Q4 decode of %d tokens after a 4-token prompt, oracle C port "
-                                             "(OpenMP), %.1f s" % (args.shape, n_cpu, secs)}
+                                   "sample": "%s %s decode of %d tokens after a 4-token prompt, oracle C port "
+                                             "(OpenMP), %.1f s" % (args.shape, dt.name(wd), n_cpu, secs)}
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}

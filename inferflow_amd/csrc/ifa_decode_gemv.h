@@ -1,0 +1,26 @@
+// ifa_decode_gemv.h -- launcher of the fused decode GEMV (k_dec_gemv, ifa_decode_kernels.h).
+// One translation unit per weight format instantiates the kernels (ifa_dgemv_*.hip) so the
+// formats compile in parallel; ifa_dgemv_q4b32.hip also holds the dtype dispatcher.
+#pragma once
+#include "ifa_host.h"
+#include "ifa_decode_kernels.h"
+
+namespace ifa {
+
+// blocks-per-lane limit of each format's instantiations (cols <= 64 * capacity * MAXNJ)
+template <int DT> struct DecGemvLimits { static constexpr int MAXNJ = 4; };
+template <> struct DecGemvLimits<Q4_B32T1A> { static constexpr int MAXNJ = 8; };
+template <> struct DecGemvLimits<Q8_B32T2> { static constexpr int MAXNJ = 6; };
+
+// true if the fused GEMV can stream a [rows][cols] tensor of this dtype
+bool dec_gemv_supported(int w_dtype, size_t cols);
+
+// epi: DecEpilogue, norm: 0/1.  P.nblk / P.total_rows are filled in here.
+int dec_gemv_launch(int w_dtype, int epi, int norm, const DecGemvParams &P, int wgs_per_cu, hipStream_t s, long long *trace);
+
+template <int DT>
+int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu, hipStream_t s);
+
+int dec_num_cus();
+
+} // namespace ifa

@@ -1,0 +1,55 @@
+// ifa_decode_gemv_impl.h -- included by exactly one ifa_dgemv_<format>.hip per format.
+#pragma once
+#include <algorithm>
+#include "ifa_decode_gemv.h"
+
+namespace ifa {
+
+// rows (EPI_GLU: row pairs) a wave keeps in flight: bounded by registers, NM * RW * NJ * DW VGPRs
+template <int DT>
+constexpr int dec_rw(int nj, int nm)
+{
+    if (DT == Q4_B32T1A) {      // tuned on Llama-2-7B shapes (DESIGN.md "Kernel timeline")
+        constexpr int a[9] = {0, 6, 6, 4, 4, 2, 2, 2, 2}, b[9] = {0, 6, 6, 3, 2, 2, 1, 1, 1};
+        return nm == 2 ? b[nj] : a[nj];
+    }
+    int rw = 72 / (nm * nj * DecFmt<DT, 1>::DW);
+    return rw < 1 ? 1 : (rw > 6 ? 6 : rw);
+}
+
+template <int DT, int EPI, int NORM>
+static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStream_t s)
+{
+    constexpr int NM = EPI == EPI_GLU ? 2 : 1;
+    const int nj = (P.nblk + 63) / 64;
+    if (nj < 1 || nj > DecGemvLimits<DT>::MAXNJ)
+        return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit of dtype %d", P.cols, DT);
+    // exactly one workgroup per CU (a second one would queue its activation behind the first one's weights)
+    const int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 1;
+    int wgs = std::min(dec_num_cus() * per_cu, (P.total_rows + DEC_WAVES - 1) / DEC_WAVES);
+    if (wgs < 1) wgs = 1;
+    const dim3 grid((unsigned)wgs);
+    const size_t smem = xlds_bytes(P.cols);
+#define IFA_DG(NJV) \
+    case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ) { \
+        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(NJV, NM), EPI, NORM>; \
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        kern<<<grid, dim3(DEC_THREADS), smem, s>>>(P); } break;
+    switch (nj) { IFA_DG(1) IFA_DG(2) IFA_DG(3) IFA_DG(4) IFA_DG(5) IFA_DG(6) IFA_DG(7) IFA_DG(8) }
+#undef IFA_DG
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+template <int DT>
+int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu, hipStream_t s)
+{
+    if (epi == EPI_PLAIN && norm == 1) return dec_gemv_launch_en<DT, EPI_PLAIN, 1>(P, wgs_per_cu, s);
+    if (epi == EPI_PLAIN && norm == 0) return dec_gemv_launch_en<DT, EPI_PLAIN, 0>(P, wgs_per_cu, s);
+    if (epi == EPI_RESIDUAL && norm == 0) return dec_gemv_launch_en<DT, EPI_RESIDUAL, 0>(P, wgs_per_cu, s);
+    if (epi == EPI_GLU && norm == 1) return dec_gemv_launch_en<DT, EPI_GLU, 1>(P, wgs_per_cu, s);
+    if (epi == EPI_ACT && norm == 1) return dec_gemv_launch_en<DT, EPI_ACT, 1>(P, wgs_per_cu, s);
+    return ifa_fail(IFA_ERR_ARG, "fused GEMV: no kernel for epilogue %d / norm %d", epi, norm);
+}
+
+} // namespace ifa

@@ -27,11 +27,10 @@
 #include "ifa_device.h"
 #include "ifa_math.h"
 #include "ifa_tiled.h"
+#include "ifa_decode_formats.h"
 
 namespace ifa {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
@@ -203,7 +202,7 @@ template <int NJ>
 struct XRegsQ4 {
     int xe[NJ][4], xo[NJ][4];
     float xs[NJ], xsf[NJ];
-    __device__ __forceinline__ void load(const XLds &L, int lane, int nblk)
+    __device__ __forceinline__ void load(const int8_t *codes, const float *scale, const float *xsum, int lane, int nblk)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
@@ -212,16 +211,16 @@ struct XRegsQ4 {
 #pragma unroll
             for (int w = 0; w < 4; w++) { xe[j][w] = 0; xo[j][w] = 0; }
             if (blk < nblk) {
-                const u32x4 a = *reinterpret_cast<const u32x4 *>(L.codes + (size_t)blk * 32);
-                const u32x4 b = *reinterpret_cast<const u32x4 *>(L.codes + (size_t)blk * 32 + 16);
+                const u32x4 a = *reinterpret_cast<const u32x4 *>(codes + (size_t)blk * 32);
+                const u32x4 b = *reinterpret_cast<const u32x4 *>(codes + (size_t)blk * 32 + 16);
                 const uint32_t d[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
                 for (int w = 0; w < 4; w++) {
                     xe[j][w] = (int)__builtin_amdgcn_perm(d[2 * w + 1], d[2 * w], 0x06040200u);
                     xo[j][w] = (int)__builtin_amdgcn_perm(d[2 * w + 1], d[2 * w], 0x07050301u);
                 }
-                xs[j] = L.scale[blk];
-                xsf[j] = L.xsum[blk];
+                xs[j] = scale[blk];
+                xsf[j] = xsum[blk];
             }
         }
     }
@@ -274,6 +273,15 @@ struct WRowQ4 {
     }
 };
 
+// format -> register images.  DW = VGPRs one block of one row costs a lane (sizes the rows in flight).
+template <int DT, int NJ> struct DecFmt;
+template <int NJ> struct DecFmt<Q4_B32T1A, NJ> { using X = XRegsQ4<NJ>; using W = WRowQ4<NJ>; static constexpr int DW = 5; };
+template <int NJ> struct DecFmt<Q8_B32T2, NJ> { using X = XRegsNat<NJ>; using W = WRowQ8T2<NJ>; static constexpr int DW = 9; };
+template <int NJ> struct DecFmt<Q4_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ4B64<NJ>; static constexpr int DW = 9; };
+template <int NJ> struct DecFmt<Q3H_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ3H<NJ>; static constexpr int DW = 8; };
+template <int NJ> struct DecFmt<Q5_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ5B64<NJ>; static constexpr int DW = 11; };
+template <int NJ> struct DecFmt<Q6_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ6B64<NJ>; static constexpr int DW = 13; };
+
 // ------------------------------------------------------------- kernel params
 enum DecEpilogue { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GLU = 2, EPI_ACT = 3 };
 
@@ -288,7 +296,7 @@ struct DecGemvParams {
     const half_t *x;           // activation [cols]
     const half_t *norm_w, *norm_b;
     float multi_base, eps;
-    int cols, nblk;
+    int cols, nblk;            // nblk = WEIGHT blocks per row (cols / block capacity of the format)
     DecMatSet set[3];          // rows of the sets are concatenated into one virtual row space
     int nsets, total_rows;
     const half_t *residual;    // EPI_RESIDUAL: y = half(residual + y)
@@ -342,8 +350,8 @@ __device__ __forceinline__ DecRow dec_locate(const DecGemvParams &P, int v)
 //   4. the remaining rows -- all of them at once, nothing waits on them until the dots;
 //   5. every wave reduces its RW rows as independent chains, then lane i finishes row i
 //      (bias / residual / activation) so the epilogue's loads overlap too.
-template <int NJ, int RW, int EPI, int NORM>
-__global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_q4(const DecGemvParams P)
+template <int DT, int NJ, int RW, int EPI, int NORM>
+__global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const XLds L = xlds_carve(smem, P.cols);
@@ -351,14 +359,15 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_q4(const DecGemvParams
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (SGPR)
     const int gw = blockIdx.x * DEC_WAVES + wave;
     const int W = gridDim.x * DEC_WAVES;
-    const size_t row_bytes = tiled_row_bytes(Q4_B32T1A, (size_t)P.nblk);
+    using Fmt = DecFmt<DT, NJ>;
+    const size_t row_bytes = tiled_row_bytes(DT, (size_t)P.nblk);
     constexpr int NM = (EPI == EPI_GLU) ? 2 : 1;
     const int npass = (P.total_rows + RW * W - 1) / (RW * W);
 
     const bool tr = P.trace != nullptr && threadIdx.x == 64;
     if (tr) P.trace[blockIdx.x * 8 + 0] = wall_clock64();
 
-    WRowQ4<NJ> w[NM][RW];
+    typename Fmt::W w[NM][RW];
     auto load_rows = [&](int pass, int i0, int i1) {
 #pragma unroll
         for (int i = 0; i < RW; i++) {
@@ -373,7 +382,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_q4(const DecGemvParams
     // rows requested BEFORE the cooperative prologue: what the CU's memory pipeline accepts
     // without blocking (~32-48 KiB per CU); a barrier behind blocked loads would only
     // release once the slowest wave's requests have been accepted, i.e. late in the stream
-    constexpr int D1 = (NM * NJ >= 6) ? 1 : (NM * NJ >= 3 ? 1 : 2);
+    constexpr int D1 = (NM * NJ * Fmt::DW >= 15) ? 1 : 2;
 
     {
         constexpr int MAXC = NORM ? 2 : 4;
@@ -390,8 +399,8 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_q4(const DecGemvParams
     }
     if (tr) P.trace[blockIdx.x * 8 + 2] = wall_clock64();
     if (gw >= P.total_rows) return;
-    XRegsQ4<NJ> X;
-    X.load(L, lane, P.nblk);
+    typename Fmt::X X;
+    X.load(L.codes, L.scale, L.xsum, lane, P.nblk);
     if (tr) P.trace[blockIdx.x * 8 + 3] = wall_clock64();
 
     for (int pass = 0; pass < npass; pass++) {
@@ -794,7 +803,7 @@ __host__ __device__ inline size_t dec_attn_smem(int head_dim, int max_ctx)
 // state[8 + i] = i-th generated token of the current launch batch.
 // Also fills the step's RoPE table: tab[c] = (cos, sin) of pos * theta_scale^c,
 // the same expression rope_rotate() evaluates per element (ifa_math.h).
-__global__ void __launch_bounds__(256) k_dec_gather(const half_t *__restrict__ embd, const int *__restrict__ state,
+static __global__ void __launch_bounds__(256) k_dec_gather(const half_t *__restrict__ embd, const int *__restrict__ state,
                                                     int dim, int vocab, half_t *__restrict__ x,
                                                     float *__restrict__ rope_tab, int head_dim, float theta,
                                                     int rope_dims)
@@ -814,7 +823,7 @@ __global__ void __launch_bounds__(256) k_dec_gather(const half_t *__restrict__ e
 }
 
 // greedy top-1 over the logits (first maximum wins); writes the token ring and advances the state
-__global__ void __launch_bounds__(1024) k_dec_argmax_advance(const half_t *__restrict__ v, int n, int *__restrict__ state,
+static __global__ void __launch_bounds__(1024) k_dec_argmax_advance(const half_t *__restrict__ v, int n, int *__restrict__ state,
                                                              int ring)
 {
     __shared__ float bv[16];

@@ -15,6 +15,7 @@
 #include <vector>
 #include "ifa_host.h"
 #include "ifa_decode_kernels.h"
+#include "ifa_decode_gemv.h"
 
 using namespace ifa;
 
@@ -76,6 +77,8 @@ static void free_tensor(Tensor &t)
 }
 
 static bool is_q4(int dt) { return dt == Q4_B32T1A || dt == Q4_B32T1B; }
+// same tiled layout and arithmetic (the A/B variants differ only in how the quantizer picked base/scale)
+static bool same_fmt(int a, int b) { return a == b || (is_q4(a) && is_q4(b)); }
 
 // ------------------------------------------------------------------ dispatch
 // reads one dword every `stride` bytes: warms the TLB / pulls lines towards L2+MALL
@@ -88,47 +91,12 @@ __global__ void __launch_bounds__(256) k_touch(const uint8_t *__restrict__ p, si
 }
 
 static long long *g_trace_ptr = nullptr;   // set by ifa_model_time_kernel when the "trace" option is on
-static int g_num_cus = 0;
-static int num_cus()
-{
-    if (!g_num_cus) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
-    return g_num_cus;
-}
+static int num_cus() { return dec_num_cus(); }
 
-// One resident wave set; each wave owns RW rows per pass (strided), all loads up front.
 template <int EPI, int NORM>
-static int launch_dec_gemv_q4(const DecGemvParams &P0, int wgs_per_cu_opt, hipStream_t s)
+static int launch_dec_gemv(int w_dtype, const DecGemvParams &P, int wgs_per_cu_opt, hipStream_t s)
 {
-    DecGemvParams P = P0;
-    P.trace = g_trace_ptr;
-    P.total_rows = 0;
-    for (int i = 0; i < P.nsets; i++) P.total_rows += P.set[i].rows;
-    const int nj = (P.nblk + 63) / 64;
-    if (nj < 1 || nj > 8) return ifa_fail(IFA_ERR_ARG, "fused GEMV supports up to 16384 columns (got %d)", P.cols);
-    const int nm = EPI == EPI_GLU ? 2 : 1;
-    // rows in flight per wave, bounded by registers: nm * RW * nj * 5 VGPRs
-    // exactly one workgroup per CU (a second one would queue its activation behind the first one's weights)
-    int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 1;
-    int wgs = std::min(num_cus() * per_cu, (P.total_rows + DEC_WAVES - 1) / DEC_WAVES);
-    if (wgs < 1) wgs = 1;
-    dim3 grid((unsigned)wgs);
-    const size_t smem = xlds_bytes(P.cols);
-#define IFA_DG2(NJV, RWV) { auto kern = k_dec_gemv_q4<NJV, RWV, EPI, NORM>; \
-        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        kern<<<grid, dim3(DEC_THREADS), smem, s>>>(P); }
-#define IFA_DG(NJV, RWA, RWB) \
-    case NJV: { if (nm == 2) IFA_DG2(NJV, RWB) else IFA_DG2(NJV, RWA) } break;
-    switch (nj) {
-        IFA_DG(1, 6, 6) IFA_DG(2, 6, 6) IFA_DG(3, 4, 3) IFA_DG(4, 4, 2) IFA_DG(5, 2, 2) IFA_DG(6, 2, 1) IFA_DG(7, 2, 1) IFA_DG(8, 2, 1)
-    }
-#undef IFA_DG
-#undef IFA_DG2
-    IFA_LAUNCH_CHECK();
-    return IFA_OK;
+    return dec_gemv_launch(w_dtype, EPI, NORM, P, wgs_per_cu_opt, s, g_trace_ptr);
 }
 
 static int launch_lmhead(const DecLmHeadParams &P, int norm, int wgs_per_cu_opt, hipStream_t s)
@@ -169,12 +137,12 @@ static bool fused_supported(const ifa_model *m, std::string *why)
         const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W2};
         for (int id : ids) {
             const Tensor &t = L.t[id];
-            if (!t.present() || !is_q4(t.dtype) || !t.tiled) return fail("fused path needs Q4_B32T1 weights (tiled)");
-            if (t.cols > 16384 || t.cols % 32 != 0) return fail("fused path needs cols % 32 == 0 and <= 16384");
+            if (!t.present() || !t.tiled) return fail("fused path needs weights in an int8-GEMV format (Q4/Q8/Q3H/Q5/Q6 block types)");
+            if (!dec_gemv_supported(t.dtype, t.cols)) return fail("fused GEMV: too many columns for this weight format");
         }
-        if (L.t[T_W3].present() && (!is_q4(L.t[T_W3].dtype) || !L.t[T_W3].tiled)) return fail("w3 must be Q4_B32T1");
+        if (L.t[T_W3].present() && (!L.t[T_W3].tiled || !same_fmt(L.t[T_W3].dtype, L.t[T_W1].dtype))) return fail("w1/w3 dtype mismatch");
         if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present()) return fail("pre-norm weights required");
-        if (L.t[T_WQ].dtype != L.t[T_WK].dtype || L.t[T_WQ].dtype != L.t[T_WV].dtype) return fail("wq/wk/wv dtype mismatch");
+        if (!same_fmt(L.t[T_WQ].dtype, L.t[T_WK].dtype) || !same_fmt(L.t[T_WQ].dtype, L.t[T_WV].dtype)) return fail("wq/wk/wv dtype mismatch");
     }
     const Tensor &lm = m->g[T_LM_HEAD];
     if (!lm.present() || lm.dtype != F16 || lm.cols > 4096 || lm.cols % 8 != 0) return fail("fused lm_head needs F16 weights, cols <= 4096");
@@ -197,7 +165,7 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
         P.set[i].y = outs[i]; P.set[i].rows = (int)L.t[ids[i]].rows;
     }
     P.nsets = 3;
-    return launch_dec_gemv_q4<EPI_PLAIN, 1>(P, m->opt_rpw_qkv, m->stream);
+    return launch_dec_gemv<EPI_PLAIN, 1>(L.t[T_WQ].dtype, P, m->opt_rpw_qkv, m->stream);
 }
 
 static int launch_attn(ifa_model *m, int l)
@@ -235,11 +203,11 @@ static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nul
     P.set[0].W[0] = (const uint8_t *)L.t[T_WO].tiled; P.set[0].rows = (int)L.t[T_WO].rows; P.nsets = 1;
     if (partial) {
         P.set[0].y = partial;
-        return launch_dec_gemv_q4<EPI_PLAIN, 0>(P, m->opt_rpw_wo, m->stream);
+        return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
     }
     P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
     P.set[0].y = m->a; P.residual = x;
-    return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, m->opt_rpw_wo, m->stream);
+    return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
 }
 
 static int launch_ffn13(ifa_model *m, int l)
@@ -253,9 +221,9 @@ static int launch_ffn13(ifa_model *m, int l)
     P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows; P.nsets = 1;
     if (L.t[T_W3].present()) {
         P.set[0].W[1] = (const uint8_t *)L.t[T_W3].tiled; P.set[0].bias[1] = (const half_t *)L.t[T_W3_B].data;
-        return launch_dec_gemv_q4<EPI_GLU, 1>(P, m->opt_rpw_ffn, m->stream);
+        return launch_dec_gemv<EPI_GLU, 1>(L.t[T_W1].dtype, P, m->opt_rpw_ffn, m->stream);
     }
-    return launch_dec_gemv_q4<EPI_ACT, 1>(P, m->opt_rpw_ffn, m->stream);
+    return launch_dec_gemv<EPI_ACT, 1>(L.t[T_W1].dtype, P, m->opt_rpw_ffn, m->stream);
 }
 
 static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullptr)
@@ -266,11 +234,11 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
     P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].rows = (int)L.t[T_W2].rows; P.nsets = 1;
     if (partial) {
         P.set[0].y = partial;
-        return launch_dec_gemv_q4<EPI_PLAIN, 0>(P, m->opt_rpw_w2, m->stream);
+        return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
     }
     P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
     P.set[0].y = xnext; P.residual = m->a;
-    return launch_dec_gemv_q4<EPI_RESIDUAL, 0>(P, m->opt_rpw_w2, m->stream);
+    return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
 }
 
 static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr)

@@ -12,6 +12,10 @@ NAMES = {
     Q4_B32T1B: "q4_b32t1b", Q4_B64T1: "q4_b64t1", Q3H_B64T1: "q3h_b64t1", Q3_B32T1A: "q3_b32t1a",
     Q3_B32T1B: "q3_b32t1b", Q2_B32T1A: "q2_b32t1a", Q2_B32T1B: "q2_b32t1b",
 }
+def name(dt):
+    return NAMES.get(dt, "dtype%d" % dt).upper()
+
+
 QUANT = [k for k in NAMES if k >= 7]
 AX8 = [Q8_B32T2, Q6_B64T1, Q5_B64T1, Q4_B32T1A, Q4_B32T1B, Q4_B64T1, Q3H_B64T1]
 

@@ -15,7 +15,15 @@ CASES = [
     ("test_gqa", dt.Q4_B32T1A, dt.F16),
     ("test_mha", dt.Q4_B32T1A, dt.Q8_B32T2),
     ("test_gqa", dt.Q4_B32T1B, dt.Q8_B32T2),
+    # the other int8-GEMV weight formats through the same fused kernels (C3 = Q3H + Q8 KV)
+    ("test_gqa", dt.Q3H_B64T1, dt.Q8_B32T2),
+    ("test_mha", dt.Q8_B32T2, dt.F16),
+    ("test_gqa", dt.Q4_B64T1, dt.F16),
+    ("test_mha", dt.Q5_B64T1, dt.Q8_B32T2),
+    ("test_gqa", dt.Q6_B64T1, dt.F16),
 ]
+CASE_IDS = ["gqa_q4_kvf16", "mha_q4_kvq8", "gqa_q4b_kvq8", "gqa_q3h_kvq8", "mha_q8_kvf16", "gqa_q4b64_kvf16",
+            "mha_q5_kvq8", "gqa_q6_kvf16"]
 
 
 def _logits_close(a, b):
@@ -24,7 +32,7 @@ def _logits_close(a, b):
     return cos, float(np.abs(a - b).max())
 
 
-@pytest.mark.parametrize("shape,wd,kvd", CASES, ids=["gqa_q4_kvf16", "mha_q4_kvq8", "gqa_q4b_kvq8"])
+@pytest.mark.parametrize("shape,wd,kvd", CASES, ids=CASE_IDS)
 def test_forward_and_fused_decode_match_oracle(shape, wd, kvd):
     max_ctx = 64
     wk, host, s = synth.build(shape, wd, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)

@@ -34,3 +34,25 @@ def test_llama2_7b_fused_equals_unfused_and_is_idempotent():
     assert np.array_equal(fused, eager)
     assert (fused >= 0).all() and (fused < s["vocab"]).all()
     wk.close()
+
+
+@pytest.mark.parametrize("wd,kvd", [(dt.Q3H_B64T1, dt.Q8_B32T2), (dt.Q8_B32T2, dt.F16), (dt.Q4_B64T1, dt.F16),
+                                    (dt.Q5_B64T1, dt.F16), (dt.Q6_B64T1, dt.Q8_B32T2)],
+                         ids=["q3h_kvq8", "q8", "q4b64", "q5b64", "q6b64_kvq8"])
+def test_llama2_7b_width_other_formats_fused_equals_unfused(wd, kvd):
+    """Full Llama-2-7B widths (4096 / 11008 columns: 1-6 blocks per lane), 2 layers: the fused kernels of
+    every int8-GEMV weight format against the op-level kernels, bit for bit."""
+    wk, _, s = synth.build("llama2_7b", wd, kvd, max_ctx=48, layers=2)
+    ok, why = wk.fused_supported()
+    assert ok, why
+    prompt = np.random.default_rng(7).integers(3, s["vocab"], 5).astype(np.int32)
+    tok = wk.forward(prompt, 0)
+    fused, _ = wk.decode(tok, len(prompt), 5)
+    logits_fused = wk.read_buffer("logits").copy()
+    wk.set_option("fused", 0)
+    unfused, _ = wk.decode(tok, len(prompt), 5)
+    logits_unfused = wk.read_buffer("logits").copy()
+    wk.set_option("fused", 1)
+    assert np.array_equal(logits_fused, logits_unfused)
+    assert np.array_equal(fused, unfused)
+    wk.close()
