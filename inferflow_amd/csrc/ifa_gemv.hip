@@ -72,7 +72,16 @@ __global__ void __launch_bounds__(256) k_gemv_ax8_generic(const uint8_t *__restr
     float acc = 0.0f;
     for (int blk = lane; blk < nblk; blk += 64) {
         RawBlock<BB> b;
-        if constexpr (TILED) {
+        if constexpr (TILED && DT == Q3H_B64T1) {    // byte-transposed pair codes -> reference block
+            uint8_t d28[28], a[32];
+            const uint8_t *p0 = wrow + (size_t)blk * 16, *p1 = wrow + (size_t)16 * nblk + (size_t)blk * 8;
+            const uint8_t *p2 = wrow + (size_t)24 * nblk + (size_t)blk * 8;
+            for (int i = 0; i < 16; i++) d28[i] = p0[i];
+            for (int i = 0; i < 8; i++) d28[16 + i] = p1[i];
+            for (int i = 0; i < 4; i++) { a[i] = p2[i]; d28[24 + i] = p2[4 + i]; }
+            q3h_tiled_to_aos(d28, a);
+            for (int i = 0; i < 16; i++) b.w[i] = (uint16_t)(a[2 * i] | (a[2 * i + 1] << 8));
+        } else if constexpr (TILED) {
             using L = TiledLayout<DT>;
 #pragma unroll
             for (int p = 0; p < L::NPLANES; p++) {

@@ -43,7 +43,8 @@ IFA_TILED(Q4_B32T1B, 2, IFA_ARR(16, 4), IFA_ARR(4, 0))
 IFA_TILED(Q8_B32T2, 2, IFA_ARR(32, 2), IFA_ARR(2, 0))
 // Q4_B64T1 {base, scale, data[32]}                               -> [data32][base,scale]
 IFA_TILED(Q4_B64T1, 2, IFA_ARR(32, 4), IFA_ARR(4, 0))
-// Q3H_B64T1 {base, scale, data_h[4], data_m[8], data[16]}        -> [data16][data_m8][base,scale,data_h4]
+// Q3H_B64T1 {base, scale, data_h[4], data_m[8], data[16]}: plane SIZES [16][8][8] as listed, but the 28 code
+// bytes are byte-transposed, not copied (q3h_aos_to_tiled below): [D0..D3][D4,D5][base,scale,D6]
 IFA_TILED(Q3H_B64T1, 3, IFA_ARR(16, 8, 8), IFA_ARR(16, 8, 0))
 // Q6_B64T1 {base, scale, data_h[16], data[32]}                   -> [data32][data_h16][base,scale]
 IFA_TILED(Q6_B64T1, 3, IFA_ARR(32, 16, 4), IFA_ARR(20, 4, 0))
@@ -52,5 +53,51 @@ IFA_TILED(Q5_B64T1, 3, IFA_ARR(32, 8, 4), IFA_ARR(12, 4, 0))
 
 #undef IFA_TILED
 #undef IFA_ARR
+
+// ---- Q3H_B64T1: the reference splits each 7-bit pair code over three bit planes (4 + 2 + 1 bits,
+// quantization.h:823-851).  Re-assembling them per weight costs ~4 VALU ops per element, which makes the
+// GEMV compute-bound; the tiled form therefore stores whole pair codes:
+//   D[w] byte b (w = 0..6) = p[4w+b] | bit w of p[28+b] << 7        (p[k] = code of elements 2k, 2k+1)
+// Same 32 bytes per block; lossless (q3h_tiled_to_aos is the inverse).
+__host__ __device__ inline void q3h_pairs_from_aos(const uint8_t *aos, uint8_t *p)
+{
+    for (int idx = 0; idx < 8; idx++) {
+        const uint32_t u16v = (uint32_t)aos[16 + 2 * idx] | ((uint32_t)aos[17 + 2 * idx] << 8);
+        const uint32_t m8 = aos[8 + idx];
+        const uint32_t hb = aos[4 + idx / 2];
+        const uint32_t h8 = (idx % 2 == 0) ? (hb & 0x0F) : (hb >> 4);
+        for (int n = 0; n < 4; n++)
+            p[4 * idx + n] = (uint8_t)(((u16v >> (4 * n)) & 0xF) | (((m8 >> (2 * n)) & 3) << 4) | (((h8 >> n) & 1) << 6));
+    }
+}
+
+__host__ __device__ inline void q3h_aos_to_tiled(const uint8_t *aos, uint8_t *d28)   // d28: D0..D6 as 28 bytes
+{
+    uint8_t p[32];
+    q3h_pairs_from_aos(aos, p);
+    for (int w = 0; w < 7; w++)
+        for (int b = 0; b < 4; b++) d28[4 * w + b] = (uint8_t)(p[4 * w + b] | (((p[28 + b] >> w) & 1) << 7));
+}
+
+__host__ __device__ inline void q3h_tiled_to_aos(const uint8_t *d28, uint8_t *aos)   // fills aos[4..31]
+{
+    uint8_t p[32];
+    for (int b = 0; b < 4; b++) p[28 + b] = 0;
+    for (int w = 0; w < 7; w++)
+        for (int b = 0; b < 4; b++) {
+            p[4 * w + b] = d28[4 * w + b] & 0x7F;
+            p[28 + b] = (uint8_t)(p[28 + b] | ((d28[4 * w + b] >> 7) << w));
+        }
+    for (int i = 4; i < 32; i++) aos[i] = 0;
+    for (int idx = 0; idx < 8; idx++)
+        for (int n = 0; n < 4; n++) {
+            const uint32_t v = p[4 * idx + n];
+            const uint32_t nib = (v & 0xF) << (4 * n);
+            aos[16 + 2 * idx] = (uint8_t)(aos[16 + 2 * idx] | (nib & 0xFF));
+            aos[17 + 2 * idx] = (uint8_t)(aos[17 + 2 * idx] | (nib >> 8));
+            aos[8 + idx] = (uint8_t)(aos[8 + idx] | (((v >> 4) & 3) << (2 * n)));
+            aos[4 + idx / 2] = (uint8_t)(aos[4 + idx / 2] | (((v >> 6) & 1) << (n + 4 * (idx % 2))));
+        }
+}
 
 } // namespace ifa
