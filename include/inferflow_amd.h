@@ -203,6 +203,12 @@ int ifa_model_set_tensor_f16(ifa_model *m, int layer, int tensor_id, int expert,
 int ifa_model_finalize(ifa_model *m);
 int ifa_model_reset(ifa_model *m);
 /* options: "fused" (1), "graph" (1), "rpw_qkv|rpw_wo|rpw_ffn|rpw_w2|rpw_lm" (0 = auto) */
+/* Independent KV caches inside one worker, one per concurrent query -- the reference keeps a LayerKVCache set
+ * per query processor (QueryStateTable, src/transformer/query_state_table.h:19-85; KVCache::Init, kv_cache.cc:278-319).
+ * ifa_model_kv_slots grows the number of caches to n_slots (slot 0 exists after finalize); ifa_model_select_kv
+ * makes one of them the cache that forward()/decode() read and write (each slot keeps its own captured graph). */
+int ifa_model_kv_slots(ifa_model *m, int n_slots);
+int ifa_model_select_kv(ifa_model *m, int slot);
 int ifa_model_set_option(ifa_model *m, const char *name, int value);
 /* 1 if the fused batch-1 decode kernels cover this model, else 0 (+ reason) */
 int ifa_model_fused_supported(ifa_model *m, char *why, size_t why_len);

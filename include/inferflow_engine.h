@@ -1,0 +1,48 @@
+/* inferflow_engine.h -- C ABI over the C++ InferenceEngine facade (inferflow_amd/host/inference_engine.h).
+ *
+ * What a non-C++ caller (ctypes, cgo, JNI ...) binds to drive the reference's serving loop
+ *   LoadConfig -> Init -> AddQuery -> { Infer -> CommitInferenceResult }* -> RemoveQuery
+ * (InferenceEngine, src/transformer/inference_engine.h:32-129; driver loop src/tools/llm_inference.cc:345-457).
+ * Return conventions are the reference's: 0/false = failure with the text in ifa_engine_last_error(),
+ * AddQuery: > 0 query id, 0 busy, < 0 error.
+ */
+#ifndef INFERFLOW_ENGINE_H
+#define INFERFLOW_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ifa_engine ifa_engine;
+
+/* InferenceEngine::LoadConfig(config_path, section, data_root_dir) + Init(); NULL on failure */
+ifa_engine *ifa_engine_create(const char *ini_path, const char *section, const char *data_root_dir);
+void ifa_engine_destroy(ifa_engine *e);
+const char *ifa_engine_last_error(void);
+
+/* AddQuery(tokens, QueryOptions{strategy greedy}) */
+int ifa_engine_add_query(ifa_engine *e, const int *tokens, int n_tokens);
+int ifa_engine_query_count(ifa_engine *e);
+int ifa_engine_remove_query(ifa_engine *e, int query_id);           /* 1 removed, 0 unknown id */
+
+/* Infer(): one step for every active query.  Writes up to `capacity` (query id, greedy next token) pairs and
+ * returns how many were produced, or -1.  With return_output_tensors = true the F16 logits of the most recent
+ * step of a query can be fetched with ifa_engine_last_logits. */
+int ifa_engine_infer(ifa_engine *e, int *query_ids, int *next_tokens, int capacity);
+/* CommitInferenceResult({query_id: {token, is_end}}) */
+int ifa_engine_commit(ifa_engine *e, const int *query_ids, const int *tokens, const int *is_end, int n);
+/* rows/cols of the logits kept from the last Infer() for this query; copies min(capacity, rows*cols) halfs */
+int ifa_engine_last_logits(ifa_engine *e, int query_id, uint16_t *dst_f16, size_t capacity, int *rows, int *cols);
+
+/* extension: n greedy steps with device-side token feedback (graph replay); returns tokens written or -1 */
+int ifa_engine_generate(ifa_engine *e, int query_id, int n_steps, int *out_tokens, float *gpu_ms);
+
+/* facts of the loaded model: "vocab_size", "embd_dims", "hidden_dim", "decoder_layers", "decoder_heads",
+ * "decoder_kv_heads", "max_context_len", "device_weight_data_type", "device_kv_cache_data_type"; -1 if unknown */
+int ifa_engine_model_info(ifa_engine *e, const char *key);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

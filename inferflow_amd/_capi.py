@@ -88,6 +88,8 @@ SIGNATURES = {
     "ifa_model_fused_supported": (_i, [_vp, C.c_char_p, _sz]),
     "ifa_model_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ifa_model_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ifa_model_kv_slots": (_i, [_vp, _i]),
+    "ifa_model_select_kv": (_i, [_vp, _i]),
     "ifa_model_get_buffer": (_i, [_vp, C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "ifa_model_stream": (_vp, [_vp]),
     "ifa_model_time_kernel": (_i, [_vp, _i, _i, _vp]),
@@ -100,6 +102,23 @@ SIGNATURES = {
     "ifa_model_tp_logits": (_i, [_vp, _vp]),
     "ifa_model_tp_set_token": (_i, [_vp, _vp]),
     "ifa_model_get_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
+}
+
+
+# include/inferflow_engine.h (the C++ InferenceEngine facade)
+_ip = C.POINTER(C.c_int)
+ENGINE_SIGNATURES = {
+    "ifa_engine_create": (_vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+    "ifa_engine_destroy": (None, [_vp]),
+    "ifa_engine_last_error": (C.c_char_p, []),
+    "ifa_engine_add_query": (_i, [_vp, _ip, _i]),
+    "ifa_engine_query_count": (_i, [_vp]),
+    "ifa_engine_remove_query": (_i, [_vp, _i]),
+    "ifa_engine_infer": (_i, [_vp, _ip, _ip, _i]),
+    "ifa_engine_commit": (_i, [_vp, _ip, _ip, _ip, _i]),
+    "ifa_engine_last_logits": (_i, [_vp, _i, _vp, _sz, _ip, _ip]),
+    "ifa_engine_generate": (_i, [_vp, _i, _i, _ip, C.POINTER(_f)]),
+    "ifa_engine_model_info": (_i, [_vp, C.c_char_p]),
 }
 
 
@@ -116,7 +135,7 @@ class ModelConfig(C.Structure):
 
 def _declare(L):
     missing = []
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(ENGINE_SIGNATURES.items()):
         try:
             fn = getattr(L, name)
         except AttributeError:
@@ -125,4 +144,4 @@ def _declare(L):
         fn.restype = res
         fn.argtypes = args
     if missing:
-        raise ImportError("libinferflow_amd.so lacks symbols declared in include/inferflow_amd.h: %s" % missing)
+        raise ImportError("libinferflow_amd.so lacks symbols declared in include/*.h: %s" % missing)

@@ -30,15 +30,29 @@ def _hipcc():
     return None
 
 
+HOST = os.path.join(_HERE, "host")
+BIN_DIR = os.path.join(_HERE, "bin")
+CLI_PATH = os.path.join(BIN_DIR, "ifa_llm_inference")
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function"]
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def host_sources():
+    """The C++ InferenceEngine facade (plain g++: it reaches the GPU only through the C ABI)."""
+    return sorted(s for s in glob.glob(os.path.join(HOST, "*.cc")) if not s.endswith("_main.cc"))
 
 
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
+    if not os.path.exists(CLI_PATH):
+        return True
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
+    deps += glob.glob(os.path.join(HOST, "*.cc")) + glob.glob(os.path.join(HOST, "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -66,6 +80,19 @@ def build_library(force=False, verbose=False, jobs=None):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    inc = os.path.join(_HERE, "..", "include")
+    host_hdr_t = max([os.path.getmtime(h) for h in glob.glob(os.path.join(HOST, "*.h")) + glob.glob(os.path.join(inc, "*.h"))] + [0])
+    cxx = shutil.which("g++") or hipcc
+    for src in host_sources():
+        obj = os.path.join(obj_dir, "host_" + os.path.basename(src) + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > host_hdr_t):
+            continue
+        cmd = [cxx] + HOST_FLAGS + ["-I", inc, "-I", HOST, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     failed = []
     for src, p in procs:
         out, _ = p.communicate()
@@ -79,6 +106,10 @@ def build_library(force=False, verbose=False, jobs=None):
     if any(os.path.basename(s).startswith("ifa_comm") for s in sources()):
         link += ["-L/opt/rocm/lib", "-lrccl"]
     subprocess.check_call(link)
+    # the llm_inference-style driver, linked against the library next to it
+    os.makedirs(BIN_DIR, exist_ok=True)
+    subprocess.check_call([cxx] + HOST_FLAGS + ["-I", inc, "-I", HOST, os.path.join(HOST, "llm_inference_main.cc"), "-o", CLI_PATH,
+                           "-L", LIB_DIR, "-linferflow_amd", "-Wl,-rpath,$ORIGIN/../lib"])
     return LIB_PATH
 
 

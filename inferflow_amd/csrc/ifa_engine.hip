@@ -64,10 +64,25 @@ struct ifa_model {
     // decode graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // independent KV caches ("query slots", one per concurrent query like the reference's per-query
+    // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
+    struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    std::vector<KvSlot> slots;
+    int cur_slot = 0;
     // options
     int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
     static constexpr int RING = 1024;
 };
+
+static void drop_graphs(ifa_model *m)
+{
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+    for (auto &sl : m->slots) {
+        if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
+        if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
+    }
+}
 
 static void free_tensor(Tensor &t)
 {
@@ -145,7 +160,12 @@ static bool fused_supported(const ifa_model *m, std::string *why)
         if (!same_fmt(L.t[T_WQ].dtype, L.t[T_WK].dtype) || !same_fmt(L.t[T_WQ].dtype, L.t[T_WV].dtype)) return fail("wq/wk/wv dtype mismatch");
     }
     const Tensor &lm = m->g[T_LM_HEAD];
-    if (!lm.present() || lm.dtype != F16 || lm.cols > 4096 || lm.cols % 8 != 0) return fail("fused lm_head needs F16 weights, cols <= 4096");
+    if (!lm.present()) return fail("lm_head missing");
+    if (lm.dtype == F16) {
+        if (lm.cols > 4096 || lm.cols % 8 != 0) return fail("fused F16 lm_head needs cols <= 4096");
+    } else if (!lm.tiled || !dec_gemv_supported(lm.dtype, lm.cols) || !m->g[T_OUT_NORM].present()) {
+        return fail("fused lm_head needs F16 or an int8-GEMV weight format (with an output norm)");
+    }
     if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return fail("F16 embeddings required");
     return true;
 }
@@ -244,6 +264,15 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
 static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr)
 {
     const ifa_model_config &c = m->cfg;
+    const Tensor &lmt = m->g[T_LM_HEAD];
+    if (lmt.dtype != F16) {      // quantised lm_head (<= 20-layer models, network_builder.cc:839-844): same fused GEMV as the layers
+        DecGemvParams P; memset(&P, 0, sizeof(P));
+        P.x = x; P.norm_w = (const half_t *)m->g[T_OUT_NORM].data; P.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
+        P.eps = c.eps; P.cols = c.dim; P.xn_out = m->xn;
+        P.set[0].W[0] = (const uint8_t *)lmt.tiled; P.set[0].rows = (int)lmt.rows; P.nsets = 1;
+        P.set[0].y = logits_out ? logits_out : m->logits;
+        return launch_dec_gemv<EPI_PLAIN, 1>(lmt.dtype, P, m->opt_rpw_lm, m->stream);
+    }
     DecLmHeadParams H; memset(&H, 0, sizeof(H));
     H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
     H.eps = c.eps; H.cols = c.dim; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = logits_out ? logits_out : m->logits;
@@ -300,8 +329,7 @@ static int ensure_scratch(ifa_model *m, int T)
     IFA_HIP_CHECK(hipMalloc((void **)&m->tokens_dev, sizeof(int) * (size_t)T));
     m->scratch_tokens = T;
     // buffers moved: any captured graph is stale
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+    drop_graphs(m);
     return IFA_OK;
 }
 
@@ -458,8 +486,11 @@ int ifa_model_destroy(ifa_model *m)
     if (!m) return IFA_OK;
     (void)hipSetDevice(m->cfg.device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) (void)hipGraphDestroy(m->graph);
+    drop_graphs(m);
+    for (auto &sl : m->slots) {
+        for (void *p : sl.k) if (p) (void)hipFree(p);
+        for (void *p : sl.v) if (p) (void)hipFree(p);
+    }
     for (Layer &L : m->layers) {
         for (Tensor &t : L.t) free_tensor(t);
         if (L.kcache) (void)hipFree(L.kcache);
@@ -500,7 +531,7 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
     IFA_HIP_CHECK(hipMalloc(&t->data, bytes));
     IFA_HIP_CHECK(hipMemcpyAsync(t->data, dev_src, bytes, hipMemcpyDeviceToDevice, m->stream));
     t->dtype = dtype; t->rows = rows; t->cols = cols;
-    const bool is_matrix = tensor_id == T_WQ || tensor_id == T_WK || tensor_id == T_WV || tensor_id == T_WO
+    const bool is_matrix = (layer < 0 && tensor_id == T_LM_HEAD) || tensor_id == T_WQ || tensor_id == T_WK || tensor_id == T_WV || tensor_id == T_WO
         || tensor_id == T_W1 || tensor_id == T_W2 || tensor_id == T_W3;
     if (is_matrix && ax8_eligible(dtype)) {
         IFA_HIP_CHECK(hipMalloc(&t->tiled, rows * ifa_tiled_row_bytes(dtype, cols)));
@@ -508,7 +539,7 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
         if (rc) return rc;
     }
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    drop_graphs(m);
     return IFA_OK;
 }
 
@@ -571,6 +602,47 @@ int ifa_model_reset(ifa_model *m)
     return IFA_OK;
 }
 
+int ifa_model_kv_slots(ifa_model *m, int n_slots)
+{
+    IFA_REQUIRE(m && m->finalized, "ifa_model_kv_slots: model not finalized");
+    IFA_REQUIRE(n_slots >= 1 && n_slots <= 4096, "ifa_model_kv_slots: n_slots %d", n_slots);
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    if (m->slots.empty()) m->slots.resize(1);        // slot 0 = the cache finalize() made (active, nothing parked)
+    IFA_REQUIRE((int)m->slots.size() <= n_slots, "ifa_model_kv_slots: cannot shrink below %zu slots", m->slots.size());
+    const size_t bytes = m->kv_row_bytes * (size_t)m->cfg.max_ctx;
+    while ((int)m->slots.size() < n_slots) {
+        ifa_model::KvSlot sl;
+        for (size_t l = 0; l < m->layers.size(); l++) {
+            void *k = nullptr, *v = nullptr;
+            IFA_HIP_CHECK(hipMalloc(&k, bytes));
+            IFA_HIP_CHECK(hipMalloc(&v, bytes));
+            IFA_HIP_CHECK(hipMemsetAsync(k, 0, bytes, m->stream));
+            IFA_HIP_CHECK(hipMemsetAsync(v, 0, bytes, m->stream));
+            sl.k.push_back(k); sl.v.push_back(v);
+        }
+        m->slots.push_back(std::move(sl));
+    }
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return IFA_OK;
+}
+
+int ifa_model_select_kv(ifa_model *m, int slot)
+{
+    IFA_REQUIRE(m && m->finalized, "ifa_model_select_kv: model not finalized");
+    if (m->slots.empty()) m->slots.resize(1);
+    IFA_REQUIRE(slot >= 0 && slot < (int)m->slots.size(), "ifa_model_select_kv: slot %d of %zu", slot, m->slots.size());
+    if (slot == m->cur_slot) return IFA_OK;
+    ifa_model::KvSlot &out = m->slots[(size_t)m->cur_slot], &in = m->slots[(size_t)slot];
+    out.k.clear(); out.v.clear();
+    for (Layer &L : m->layers) { out.k.push_back(L.kcache); out.v.push_back(L.vcache); }
+    out.graph = m->graph; out.exec = m->graph_exec;
+    for (size_t l = 0; l < m->layers.size(); l++) { m->layers[l].kcache = in.k[l]; m->layers[l].vcache = in.v[l]; }
+    m->graph = in.graph; m->graph_exec = in.exec;
+    in.k.clear(); in.v.clear(); in.graph = nullptr; in.exec = nullptr;
+    m->cur_slot = slot;
+    return IFA_OK;
+}
+
 int ifa_model_set_option(ifa_model *m, const char *name, int value)
 {
     IFA_REQUIRE(m && name, "ifa_model_set_option: null pointer");
@@ -581,7 +653,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
-            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            drop_graphs(m);
             return IFA_OK;
         }
     return ifa_fail(IFA_ERR_ARG, "ifa_model_set_option: unknown option '%s'", name);
@@ -685,7 +757,7 @@ int ifa_model_set_stream(ifa_model *m, ifa_stream stream)
     if (m->stream && m->own_stream) IFA_HIP_CHECK(hipStreamDestroy(m->stream));
     m->stream = ifa_s(stream);
     m->own_stream = false;
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    drop_graphs(m);
     return IFA_OK;
 }
 

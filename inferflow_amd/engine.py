@@ -1,0 +1,94 @@
+"""Python view of the C++ InferenceEngine facade (inferflow_amd/host/inference_engine.h) through
+include/inferflow_engine.h -- the reference's serving loop, same names and return conventions:
+
+    eng = InferenceEngine.from_ini("llm_inference.ini", "transformer_engine")
+    qid = eng.add_query(tokens)              # > 0 id, 0 busy, < 0 error
+    while ...:
+        for query_id, next_token in eng.infer():
+            eng.commit({query_id: (next_token, False)})
+    eng.remove_query(qid)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class InferenceEngine:
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def _err():
+        return _capi.lib().ifa_engine_last_error().decode(errors="replace")
+
+    @classmethod
+    def from_ini(cls, ini_path, section="transformer_engine", data_root_dir=""):
+        h = _capi.lib().ifa_engine_create(str(ini_path).encode(), section.encode(), data_root_dir.encode())
+        if not h:
+            raise EngineError("LoadConfig/Init failed: " + cls._err())
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            _capi.lib().ifa_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_query(self, tokens):
+        arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
+        return _capi.lib().ifa_engine_add_query(self._h, arr, len(tokens))
+
+    def query_count(self):
+        return _capi.lib().ifa_engine_query_count(self._h)
+
+    def remove_query(self, query_id):
+        return bool(_capi.lib().ifa_engine_remove_query(self._h, query_id))
+
+    def infer(self, capacity=64):
+        """One Infer(): [(query_id, greedy next token)] for the queries that advanced."""
+        ids = (C.c_int * capacity)()
+        toks = (C.c_int * capacity)()
+        n = _capi.lib().ifa_engine_infer(self._h, ids, toks, capacity)
+        if n < 0:
+            raise EngineError("Infer failed: " + self._err())
+        return [(ids[i], toks[i]) for i in range(min(n, capacity))]
+
+    def commit(self, query_map):
+        """query_map: {query_id: token} or {query_id: (token, is_end)}"""
+        n = len(query_map)
+        ids = (C.c_int * n)(); toks = (C.c_int * n)(); ends = (C.c_int * n)()
+        for i, (q, v) in enumerate(query_map.items()):
+            tok, end = v if isinstance(v, tuple) else (v, False)
+            ids[i], toks[i], ends[i] = q, int(tok), int(bool(end))
+        return bool(_capi.lib().ifa_engine_commit(self._h, ids, toks, ends, n))
+
+    def last_logits(self, query_id):
+        rows, cols = C.c_int(0), C.c_int(0)
+        if not _capi.lib().ifa_engine_last_logits(self._h, query_id, None, 0, C.byref(rows), C.byref(cols)):
+            raise EngineError(self._err())
+        out = np.zeros((rows.value, cols.value), np.float16)
+        if out.size:
+            _capi.lib().ifa_engine_last_logits(self._h, query_id, out.ctypes.data_as(C.c_void_p), out.size, C.byref(rows), C.byref(cols))
+        return out
+
+    def generate(self, query_id, n_steps):
+        out = (C.c_int * max(1, n_steps))()
+        ms = C.c_float(0)
+        n = _capi.lib().ifa_engine_generate(self._h, query_id, n_steps, out, C.byref(ms))
+        if n < 0:
+            raise EngineError("Generate failed: " + self._err())
+        return [out[i] for i in range(n)], ms.value
+
+    def model_info(self, key):
+        return _capi.lib().ifa_engine_model_info(self._h, key.encode())

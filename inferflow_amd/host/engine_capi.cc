@@ -1,0 +1,106 @@
+// engine_capi.cc -- C ABI of the InferenceEngine facade (include/inferflow_engine.h)
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "inferflow_engine.h"
+#include "inference_engine.h"
+
+using namespace inferflow_amd;
+
+struct ifa_engine {
+    InferenceEngine engine;
+    std::map<int, QueryInferenceResult> last;     // per query: result of the most recent step
+};
+
+extern "C" {
+
+const char *ifa_engine_last_error(void) { return EngineLastError(); }
+
+ifa_engine *ifa_engine_create(const char *ini_path, const char *section, const char *data_root_dir)
+{
+    if (!ini_path || !section) { EngineSetError("ifa_engine_create: null argument"); return nullptr; }
+    InferenceConfig cfg;
+    if (!InferenceEngine::LoadConfig(cfg, ini_path, section, data_root_dir ? data_root_dir : "")) return nullptr;
+    ifa_engine *e = new ifa_engine();
+    if (!e->engine.Init(cfg)) { delete e; return nullptr; }
+    return e;
+}
+
+void ifa_engine_destroy(ifa_engine *e) { delete e; }
+
+int ifa_engine_add_query(ifa_engine *e, const int *tokens, int n_tokens)
+{
+    if (!e || !tokens || n_tokens <= 0) { EngineSetError("ifa_engine_add_query: bad arguments"); return -1; }
+    return e->engine.AddQuery(std::vector<int>(tokens, tokens + n_tokens), QueryOptions());
+}
+
+int ifa_engine_query_count(ifa_engine *e) { return e ? e->engine.QueryCount() : -1; }
+
+int ifa_engine_remove_query(ifa_engine *e, int query_id)
+{
+    if (!e) return 0;
+    e->last.erase(query_id);
+    return e->engine.RemoveQuery(query_id) ? 1 : 0;
+}
+
+int ifa_engine_infer(ifa_engine *e, int *query_ids, int *next_tokens, int capacity)
+{
+    if (!e) { EngineSetError("ifa_engine_infer: null engine"); return -1; }
+    InferenceResult res;
+    if (!e->engine.Infer(res)) return -1;
+    int n = 0;
+    for (QueryInferenceResult &item : res.items) {
+        if (n < capacity && query_ids && next_tokens) { query_ids[n] = item.query_id; next_tokens[n] = item.next_tokens.empty() ? -1 : item.next_tokens[0].id; }
+        n++;
+        e->last[item.query_id] = std::move(item);
+    }
+    return n;
+}
+
+int ifa_engine_commit(ifa_engine *e, const int *query_ids, const int *tokens, const int *is_end, int n)
+{
+    if (!e || !query_ids || !tokens || n < 0) { EngineSetError("ifa_engine_commit: bad arguments"); return 0; }
+    std::map<int, QueryNextToken> m;
+    for (int i = 0; i < n; i++) { QueryNextToken t; t.id = tokens[i]; t.is_end = is_end && is_end[i]; m[query_ids[i]] = t; }
+    return e->engine.CommitInferenceResult(m) ? 1 : 0;
+}
+
+int ifa_engine_last_logits(ifa_engine *e, int query_id, uint16_t *dst_f16, size_t capacity, int *rows, int *cols)
+{
+    if (!e) return 0;
+    auto it = e->last.find(query_id);
+    if (it == e->last.end()) { EngineSetError("no result for query %d", query_id); return 0; }
+    if (rows) *rows = it->second.output_rows;
+    if (cols) *cols = it->second.output_cols;
+    if (dst_f16) memcpy(dst_f16, it->second.output_tensor.data(), std::min(capacity, it->second.output_tensor.size()) * 2);
+    return 1;
+}
+
+int ifa_engine_generate(ifa_engine *e, int query_id, int n_steps, int *out_tokens, float *gpu_ms)
+{
+    if (!e || !out_tokens) { EngineSetError("ifa_engine_generate: bad arguments"); return -1; }
+    std::vector<int> toks;
+    if (!e->engine.Generate(query_id, n_steps, toks, gpu_ms)) return -1;
+    for (size_t i = 0; i < toks.size(); i++) out_tokens[i] = toks[i];
+    return (int)toks.size();
+}
+
+int ifa_engine_model_info(ifa_engine *e, const char *key)
+{
+    if (!e || !key) return -1;
+    const ModelSpec &s = e->engine.model_spec();
+    const std::string k = key;
+    if (k == "vocab_size") return s.hyper_params.vocab_size;
+    if (k == "embd_dims") return s.hyper_params.embd_dims;
+    if (k == "hidden_dim") return s.hyper_params.hidden_dim;
+    if (k == "decoder_layers") return s.hyper_params.decoder_layers;
+    if (k == "decoder_heads") return s.hyper_params.decoder_heads;
+    if (k == "decoder_kv_heads") return s.hyper_params.decoder_kv_heads;
+    if (k == "max_context_len") return s.max_context_len > 0 ? s.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
+    if (k == "device_weight_data_type") return s.device_weight_data_type;
+    if (k == "device_kv_cache_data_type") return s.device_kv_cache_data_type;
+    return -1;
+}
+
+} // extern "C"

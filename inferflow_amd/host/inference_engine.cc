@@ -1,0 +1,261 @@
+// inference_engine.cc -- InferenceEngine over the MI355X decode worker (see inference_engine.h).
+// Step semantics follow InferenceEngine::Infer_Std (src/transformer/inference_engine.cc:1161-1220):
+// every Infer() advances each active query by one step -- the whole pending prompt on the first
+// step (prefill), one token afterwards -- and reports the candidates of the next token; the caller
+// picks one and commits it with CommitInferenceResult (llm_inference.cc:345-457).
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "inferflow_amd.h"
+#include "inference_engine.h"
+#include "ifa_ini.h"
+
+namespace inferflow_amd {
+
+InferenceEngine::InferenceEngine() {}
+InferenceEngine::~InferenceEngine() { Clear(); }
+
+void InferenceEngine::Clear()
+{
+    if (model_) { ifa_model_destroy(model_); model_ = nullptr; }
+    if (logits_dev_) { ifa_free(logits_dev_); logits_dev_ = nullptr; logits_rows_ = 0; }
+    queries_.clear();
+}
+
+static bool LoadDeviceGroups(std::vector<std::vector<int>> &groups, const IniConfig &cfg, const std::string &section, const std::string &key)
+{
+    // "0;1" = two groups (by layer), "0&1" = one group of two (by tensor)  (inference_engine.cc:1738-1783)
+    groups.clear();
+    std::string str;
+    cfg.GetItem(section, key, str);
+    for (std::string tok : IniConfig::Split(str, ",;")) {
+        tok = IniConfig::Trim(tok);
+        if (tok.empty()) continue;
+        std::vector<int> sub;
+        for (std::string s : IniConfig::Split(tok, "&|")) { s = IniConfig::Trim(s); if (!s.empty()) sub.push_back(atoi(s.c_str())); }
+        groups.push_back(sub);
+    }
+    for (size_t g = 1; g < groups.size(); g++)
+        if (groups[g].size() != groups[0].size()) {
+            EngineSetError("All device groups should have the same size: %zu vs. %zu", groups[0].size(), groups[g].size());
+            return false;
+        }
+    return true;
+}
+
+static bool LoadModelSpec(ModelSpec &spec, const IniConfig &cfg, const std::string &section)
+{
+    if (!cfg.GetItem(section, "model_dir", spec.dir) || spec.dir.empty()) {
+        EngineSetError("The directory of model \"%s\" should not be empty", spec.sid.c_str()); return false;
+    }
+    if (spec.dir.back() != '/' && spec.dir.back() != '\\') spec.dir += '/';
+    if (!cfg.GetItem(section, "model_specification_file", spec.spec_file)) cfg.GetItem(section, "model_spec_file", spec.spec_file);
+    if (spec.spec_file.empty()) { EngineSetError("The specification file of model \"%s\" should not be empty", spec.sid.c_str()); return false; }
+    cfg.GetItem(section, "decoding_strategy", spec.decoding_strategy);
+    cfg.GetItem(section, "decoder_input_template", spec.decoder_input_template);
+    cfg.GetItem(section, "prompt_template", spec.decoder_input_template);
+    std::string str;
+    if (cfg.GetItem(section, "device_weight_data_type", str) && !str.empty()) {
+        const int dt = ifa_dtype_from_name(IniConfig::Lower(str).c_str());
+        if (dt < 0) { EngineSetError("Invalid device_weight_data_type for model %s", spec.sid.c_str()); return false; }
+        spec.device_weight_data_type = dt;
+    }
+    str.clear();
+    if (cfg.GetItem(section, "device_kv_cache_data_type", str) && !str.empty()) {
+        const int dt = ifa_dtype_from_name(IniConfig::Lower(str).c_str());
+        if (dt < 0) { EngineSetError("Invalid device_kv_cache_data_type for model %s", spec.sid.c_str()); return false; }
+        // element size >= 2 -> F16, anything smaller -> Q8_B32T2   (inference_engine.cc:1701-1703)
+        spec.device_kv_cache_data_type = (dt == IFA_F32 || dt == IFA_F16) ? IFA_F16 : IFA_Q8_B32T2;
+    }
+    cfg.GetItem(section, "tensor_quant_threshold", spec.tensor_quant_threshold);
+    if (!LoadDeviceGroups(spec.device_groups, cfg, section, "devices")) return false;
+    cfg.GetItem(section, "max_context_len", spec.max_context_len);
+    const bool is_abs = !spec.spec_file.empty() && spec.spec_file[0] == '/';
+    return LoadModelSpecJson(spec, is_abs ? spec.spec_file : spec.dir + spec.spec_file);
+}
+
+bool InferenceEngine::LoadConfig(InferenceConfig &config, const std::string &config_path,
+                                 const std::string &section, const std::string &data_root_dir)
+{
+    IniConfig cfg; std::string err;
+    if (!cfg.Load(config_path, &err)) { EngineSetError("Failed to load the configuration file: %s", err.c_str()); return false; }
+    std::string root = data_root_dir;
+    if (root.empty()) { IniConfig probe; probe.Load(config_path); probe.GetItem("app_env.base", "data_root_dir", root); }
+    if (!root.empty()) cfg.AddMacro("data_root_dir", root);
+    config.data_dir = root;
+    std::string global_model_dir;
+    cfg.GetItem("main", "global_model_dir", global_model_dir);
+    cfg.AddMacro("global_model_dir", global_model_dir);
+    if (!cfg.HasSection(section)) { EngineSetError("Section [%s] is missing in %s", section.c_str(), config_path.c_str()); return false; }
+    if (!LoadDeviceGroups(config.device_groups, cfg, section, "devices")) return false;
+    if (config.device_groups.empty()) config.device_groups.push_back({0});
+    int cpu_layers = 0;
+    if (cfg.GetItem(section, "cpu_layer_count", cpu_layers)) config.decoder_cpu_layer_count = cpu_layers;
+    cfg.GetItem(section, "encoder_cpu_layer_count", config.encoder_cpu_layer_count);
+    cfg.GetItem(section, "decoder_cpu_layer_count", config.decoder_cpu_layer_count);
+    std::string models;
+    if (!cfg.GetItem(section, "models", models) || IniConfig::Trim(models).empty()) {
+        EngineSetError("Item \"models\" is missing in section [%s]", section.c_str()); return false;
+    }
+    config.models.clear();
+    for (std::string name : IniConfig::Split(models, ",;")) {
+        name = IniConfig::Trim(name);
+        if (name.empty()) continue;
+        ModelSpec spec; spec.sid = name;
+        cfg.AddMacro("model_name", name);
+        if (!LoadModelSpec(spec, cfg, "model." + name)) return false;
+        if (spec.device_groups.empty()) spec.device_groups = config.device_groups;
+        config.models.push_back(spec);
+    }
+    cfg.GetItem(section, "max_concurrent_queries", config.max_concurrent_queries);
+    cfg.GetItem(section, "cpu_threads", config.cpu_threads);
+    cfg.GetItem(section, "return_output_tensors", config.return_output_tensors);
+    cfg.GetItem(section, "is_study_mode", config.debug.is_study_mode);
+    cfg.GetItem(section, "show_tensors", config.debug.show_tensors);
+    return true;
+}
+
+bool InferenceEngine::Init(const InferenceConfig &cfg)
+{
+    Clear();
+    config_ = cfg;
+    if (cfg.models.empty()) { EngineSetError("No model is configured"); return false; }
+    if (cfg.models.size() > 1) { EngineSetError("One model per engine (got %zu)", cfg.models.size()); return false; }
+    spec_ = cfg.models[0];
+    if (cfg.decoder_cpu_layer_count > 0) { EngineSetError("decoder_cpu_layer_count > 0: CPU layers are outside this engine"); return false; }
+    const auto &groups = spec_.device_groups.empty() ? cfg.device_groups : spec_.device_groups;
+    if (groups.size() > 1 || (!groups.empty() && groups[0].size() > 1)) {
+        EngineSetError("multi-GPU partitions run one process per GPU (python -m torch.distributed.run ... inferflow_amd.tp); "
+                       "this engine instance takes one device"); return false;
+    }
+    device_ = groups.empty() || groups[0].empty() ? 0 : groups[0][0];
+    if (device_ < 0 || device_ >= ifa_device_count()) { EngineSetError("device %d is not available (%d visible)", device_, ifa_device_count()); return false; }
+    if (!BuildWorker(&model_, spec_, device_)) return false;
+    // one KV cache per concurrent query, like the reference's per-query LayerKVCache sets
+    kv_slots_ = std::max(1, std::min(config_.max_concurrent_queries, 64));
+    if (ifa_model_kv_slots(model_, kv_slots_) != IFA_OK) { EngineSetError("KV caches for %d queries: %s", kv_slots_, ifa_last_error()); Clear(); return false; }
+    return true;
+}
+
+int InferenceEngine::AddQuery(const std::vector<int> &tokens, const QueryOptions &query_options)
+{
+    if (!model_) { EngineSetError("The engine is not initialized"); return -1; }
+    if (tokens.empty()) { EngineSetError("Empty query"); return -1; }
+    const int max_ctx = spec_.max_context_len > 0 ? spec_.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
+    if ((int)tokens.size() >= max_ctx) { EngineSetError("The query has %zu tokens; max_context_len is %d", tokens.size(), max_ctx); return -1; }
+    for (int t : tokens)
+        if (t < 0 || t >= spec_.hyper_params.vocab_size) { EngineSetError("Token id %d is out of range", t); return -1; }
+    if ((int)queries_.size() >= std::min(config_.max_concurrent_queries, kv_slots_)) return 0;      // busy
+    Query q; q.id = next_query_id_++; q.tokens = tokens; q.options = query_options;
+    std::vector<bool> used((size_t)kv_slots_, false);
+    for (const auto &kv : queries_) used[(size_t)kv.second.kv_slot] = true;
+    while (q.kv_slot < kv_slots_ && used[(size_t)q.kv_slot]) q.kv_slot++;
+    queries_[q.id] = q;
+    return q.id;
+}
+
+int InferenceEngine::QueryCount() const { return (int)queries_.size(); }
+
+bool InferenceEngine::RemoveQuery(int query_id)
+{
+    return queries_.erase(query_id) != 0;
+}
+
+bool InferenceEngine::Infer(InferenceResult &res)
+{
+    res.items.clear(); res.perf_stat.time_map.clear();
+    if (!model_) { EngineSetError("The engine is not initialized"); return false; }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int V = spec_.hyper_params.vocab_size;
+    const int max_ctx = spec_.max_context_len > 0 ? spec_.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
+    for (auto &kv : queries_) {
+        Query &q = kv.second;
+        if (q.ended) continue;
+        if ((int)q.tokens.size() >= max_ctx) { q.ended = true; continue; }
+        const int n_new = (int)q.tokens.size() - q.processed;
+        if (n_new <= 0) continue;                                    // nothing committed since the last step
+        if (ifa_model_select_kv(model_, q.kv_slot) != IFA_OK) { EngineSetError("select_kv: %s", ifa_last_error()); return false; }
+        QueryInferenceResult item; item.query_id = q.id; item.prefix_len = q.processed;
+        int next = -1;
+        const bool want_tensor = config_.return_output_tensors;
+        if (n_new == 1 && !want_tensor) {                            // decode: fused graph-replayed step
+            if (ifa_model_decode(model_, q.tokens.back(), q.processed, 1, &next, nullptr) != IFA_OK) {
+                EngineSetError("decode step failed: %s", ifa_last_error()); return false;
+            }
+        } else {
+            void *lg = nullptr;
+            if (want_tensor) {
+                if ((size_t)n_new > logits_rows_) {
+                    if (logits_dev_) ifa_free(logits_dev_);
+                    logits_dev_ = nullptr; logits_rows_ = 0;
+                    if (ifa_malloc(&logits_dev_, (size_t)n_new * V * 2) != IFA_OK) { EngineSetError("logits buffer: %s", ifa_last_error()); return false; }
+                    logits_rows_ = (size_t)n_new;
+                }
+                lg = logits_dev_;
+            }
+            if (ifa_model_forward(model_, q.tokens.data() + q.processed, n_new, q.processed, lg, &next) != IFA_OK) {
+                EngineSetError("forward step failed: %s", ifa_last_error()); return false;
+            }
+            if (want_tensor) {
+                item.output_rows = n_new; item.output_cols = V;
+                item.output_tensor.resize((size_t)n_new * V);
+                if (ifa_memcpy_d2h(item.output_tensor.data(), lg, (size_t)n_new * V * 2, ifa_model_stream(model_)) != IFA_OK
+                    || ifa_stream_sync(ifa_model_stream(model_)) != IFA_OK) { EngineSetError("logits copy: %s", ifa_last_error()); return false; }
+            }
+        }
+        q.processed = (int)q.tokens.size();
+        IdWeight w; w.id = next; w.weight = 1.0f;
+        item.next_tokens.push_back(w);
+        res.items.push_back(std::move(item));
+    }
+    res.perf_stat.time_map[0] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
+bool InferenceEngine::CommitInferenceResult(const std::map<int, QueryNextToken> &query_map)
+{
+    bool ok = true;
+    for (const auto &kv : query_map) {
+        auto it = queries_.find(kv.first);
+        if (it == queries_.end()) { EngineSetError("Query %d does not exist", kv.first); ok = false; continue; }
+        Query &q = it->second;
+        if (kv.second.id < 0 || kv.second.id >= spec_.hyper_params.vocab_size) { EngineSetError("Token id %d is out of range", kv.second.id); ok = false; continue; }
+        q.tokens.push_back(kv.second.id);
+        if (kv.second.is_end) q.ended = true;
+    }
+    return ok;
+}
+
+bool InferenceEngine::Generate(int query_id, int n_steps, std::vector<int> &new_tokens, float *gpu_ms)
+{
+    new_tokens.clear();
+    auto it = queries_.find(query_id);
+    if (!model_ || it == queries_.end()) { EngineSetError("Query %d does not exist", query_id); return false; }
+    Query &q = it->second;
+    if (n_steps <= 0) return true;
+    if (ifa_model_select_kv(model_, q.kv_slot) != IFA_OK) { EngineSetError("select_kv: %s", ifa_last_error()); return false; }
+    int next = -1;
+    const int pending = (int)q.tokens.size() - q.processed;
+    if (pending > 1 || q.processed == 0) {            // prefill whatever is pending; yields the first new token
+        if (ifa_model_forward(model_, q.tokens.data() + q.processed, pending, q.processed, nullptr, &next) != IFA_OK) {
+            EngineSetError("forward step failed: %s", ifa_last_error()); return false;
+        }
+        q.processed = (int)q.tokens.size();
+        q.tokens.push_back(next); new_tokens.push_back(next);
+        n_steps--;
+    } else if (pending == 0) { EngineSetError("Query %d has no committed token to continue from", query_id); return false; }
+    if (n_steps > 0) {
+        std::vector<int> out((size_t)n_steps);
+        float ms = 0;
+        if (ifa_model_decode(model_, q.tokens.back(), q.processed, n_steps, out.data(), &ms) != IFA_OK) {
+            EngineSetError("decode failed: %s", ifa_last_error()); return false;
+        }
+        if (gpu_ms) *gpu_ms = ms;
+        for (int t : out) { q.tokens.push_back(t); new_tokens.push_back(t); }
+        q.processed = (int)q.tokens.size() - 1;
+    }
+    return true;
+}
+
+} // namespace inferflow_amd

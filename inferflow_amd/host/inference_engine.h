@@ -1,0 +1,158 @@
+// inference_engine.h -- the reference's InferenceEngine surface over the MI355X decode worker.
+//
+// Mirrors src/transformer/inference_engine.h:32-129 (class InferenceEngine),
+// inference_types.h:18-179 (InferenceConfig, QueryNextToken, InferenceResult ...) and
+// model.h:72-151 (ModelSpec): same member names, same argument meaning, same error convention
+// (bool / query-id returns, a message through LogError -> ifa_engine_last_error(), never throws).
+// The host side is plain C++ and reaches the GPU only through the C ABI of include/inferflow_amd.h.
+//
+// Scope: token-id queries, greedy decoding (sampling_strategy.cc:372-386), one
+// model per engine, one device group of one GPU per process (multi-GPU tensor parallelism runs one
+// process per GPU through inferflow_amd.tp / torch.distributed).  Tokenizers, prompt templates, the
+// HTTP service and the non-greedy samplers are outside the hot path.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+struct ifa_model;
+
+namespace inferflow_amd {
+
+struct ModelHyperParams {          // ModelHyperParams, model.h:24-70
+    int vocab_size = 0, output_vocab_size = 0;
+    int embd_dims = 0, hidden_dim = 0;
+    int decoder_layers = 0, decoder_heads = 0, decoder_kv_heads = 0;
+    int training_context_len = 0;
+    int experts = 0, in_use_experts = 0, moe_top_k = 2;
+    bool moe_norm_top_k_prob = true;
+};
+
+enum class TensorNormAlg { STD = 0, RMS = 1 };
+enum class ActivationFn { SILU = 0, GELU = 1, RELU = 2 };
+enum class PositionEmbeddingAlg { EMPTY = 0, ROPE = 1, ALIBI = 2 };
+
+struct ModelSpec {
+    std::string sid;
+    ModelHyperParams hyper_params;
+    std::string dir, spec_file, config_file;
+    std::vector<std::string> model_files;
+    std::string model_file_format;          // "llama2.c" | "safetensors" | "synthetic"
+    std::string network_structure = "transformer.llama";
+    TensorNormAlg norm_alg = TensorNormAlg::STD;
+    ActivationFn activation_fn = ActivationFn::SILU;
+    PositionEmbeddingAlg pos_embedding_alg = PositionEmbeddingAlg::ROPE;
+    float rope_theta = 10000.0f, partial_rotary_factor = 1.0f, kq_scale = 1.0f;
+    int qk_column_order = 0, qkv_format = 0;
+    bool is_parallel_attn = false, mlp_attn_share_input = false;
+    std::string tensor_name_prefix;
+    std::map<std::string, std::string> tensor_name_map;
+    std::string decoding_strategy;
+    std::string decoder_input_template;     // kept for round-tripping the .ini; unused (token-id queries)
+    int device_weight_data_type = 1;        // ElementType ids = ifa_dtype; F16
+    int device_kv_cache_data_type = 8;      // Q8_B32T2 (the reference's default, model.h:137)
+    int tensor_quant_threshold = 2000 * 2000;
+    static const int DEFAULT_MAX_CONTEXT_LEN = 1024;
+    int max_context_len = -1;
+    std::vector<std::vector<int>> device_groups;
+    // "synthetic" models only: N(0, synthetic_std) weights from seed 1000 + 16*layer + tensor_id
+    float synthetic_std = 0.02f;
+};
+
+struct InferenceConfig {
+    struct DebugOptions { bool is_study_mode = false, show_tensors = false, enable_perf_stat = true; };
+    std::vector<ModelSpec> models;
+    std::string data_dir;
+    int max_concurrent_queries = 10;
+    std::vector<std::vector<int>> device_groups;
+    int encoder_cpu_layer_count = 0, decoder_cpu_layer_count = 0, cpu_threads = 8;
+    std::map<std::string, std::string> prompt_templates;
+    bool return_output_tensors = false;
+    DebugOptions debug;
+};
+
+struct QueryOptions {               // SamplingStrategy::QueryOptions (sampling_strategy.h)
+    int strategy_id = 0;            // 0 = greedy (the only one on the hot path)
+    int random_seed = 0;
+    float temperature = 1.0f;
+    int max_output_len = -1;
+};
+
+struct IdWeight { int id = 0; float weight = 0; };
+
+struct QueryInferenceResult {
+    int query_id = 0;
+    int prefix_len = 0;
+    std::vector<IdWeight> next_tokens;          // [0] = greedy choice, weight = its logit
+    std::vector<uint16_t> output_tensor;        // F16 logits [output_rows][output_cols] if return_output_tensors
+    int output_rows = 0, output_cols = 0;
+};
+
+struct QueryNextToken { int id = 0; bool is_end = false; };
+
+struct InferencePerfStat { std::map<uint32_t, float> time_map; };   // key 0: GPU step wall ms
+
+struct InferenceResult {
+    std::vector<QueryInferenceResult> items;
+    InferencePerfStat perf_stat;
+};
+
+class InferenceEngine {
+public:
+    InferenceEngine();
+    ~InferenceEngine();
+    InferenceEngine(const InferenceEngine &) = delete;
+    InferenceEngine &operator=(const InferenceEngine &) = delete;
+    void Clear();
+
+    static bool LoadConfig(InferenceConfig &config, const std::string &config_path,
+                           const std::string &section, const std::string &data_root_dir = "");
+    bool Init(const InferenceConfig &cfg);
+
+    // > 0: query id, 0: busy (max_concurrent_queries reached), < 0: error
+    int AddQuery(const std::vector<int> &tokens, const QueryOptions &query_options);
+    int QueryCount() const;
+    // one step for every active query: prefill of the pending tokens, or one decode step
+    bool Infer(InferenceResult &res);
+    bool CommitInferenceResult(const std::map<int, QueryNextToken> &query_map);
+    bool RemoveQuery(int query_id);
+
+    // Extension: n greedy steps with the token fed back on the device (hipGraph replay, no host
+    // round trip per token).  Equivalent to n x {Infer, CommitInferenceResult(greedy)}.
+    bool Generate(int query_id, int n_steps, std::vector<int> &new_tokens, float *gpu_ms = nullptr);
+
+    const ModelSpec &model_spec() const { return spec_; }
+    std::string Version() const { return "inferflow_amd 0.1 (MI355X)"; }
+    int default_device_id() const { return device_; }
+    ifa_model *worker() { return model_; }
+
+private:
+    struct Query {
+        int id = 0;
+        std::vector<int> tokens;    // committed tokens (prompt + generated)
+        int processed = 0;          // tokens whose KV rows are in the cache
+        QueryOptions options;
+        bool ended = false;
+        int kv_slot = 0;            // this query's KV cache inside the worker (ifa_model_select_kv)
+    };
+    InferenceConfig config_;
+    ModelSpec spec_;
+    ifa_model *model_ = nullptr;
+    int device_ = 0;
+    int next_query_id_ = 1;
+    int kv_slots_ = 1;
+    std::map<int, Query> queries_;
+    void *logits_dev_ = nullptr;
+    size_t logits_rows_ = 0;
+};
+
+// error text of the last failed call on this thread (the reference logs through LogError)
+const char *EngineLastError();
+void EngineSetError(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// model loading (model_loader.cc)
+bool LoadModelSpecJson(ModelSpec &spec, const std::string &path);
+bool BuildWorker(ifa_model **out, ModelSpec &spec, int device);
+
+} // namespace inferflow_amd

@@ -1,0 +1,468 @@
+// model_loader.cc -- model_spec.json + weight files -> an ifa_model worker.
+//
+// Formats (ModelReader, src/transformer/model_reader.cc):
+//   "llama2.c"     7 x int32 header + F32 tensors grouped by kind (:3248-3430)
+//   "safetensors"  HF llama-style tensor names, F32 / F16 / BF16 payloads, config.json hyper-parameters
+//   "synthetic"    no files: N(0, std) weights generated on the host (benchmarks / smoke tests)
+// Weights are handed over as F16 and quantised ON THE DEVICE with the reference rule
+// (ifa_model_set_tensor_f16 -> Quantization::QuantizeRow_*), tensor by tensor, following
+// NetworkBuilder's dtype policy: device_weight_data_type for matrices of at least
+// tensor_quant_threshold elements, F16 otherwise (network_builder.cc:1550-1562); the lm_head is
+// quantised only for <= 20-layer models (:839-844); norms and embeddings stay F16.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <thread>
+
+#include "inferflow_amd.h"
+#include "inference_engine.h"
+#include "ifa_ini.h"
+#include "ifa_json.h"
+
+namespace inferflow_amd {
+
+static thread_local char g_err[1024] = "";
+const char *EngineLastError() { return g_err; }
+void EngineSetError(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- fp conversions (round to nearest even, like the reference's half_float / __float2half_rn)
+static uint16_t F32ToF16(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                 // rounds to inf
+    if (x < 0x38800000u) {                                                    // subnormal half
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+        const int shift = 126 - e;                                            // 14..24
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = (x - 0x38000000u) >> 13;
+    const uint32_t rem = x & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) r++;
+    return (uint16_t)(sign | r);
+}
+static float BF16ToF32(uint16_t b) { uint32_t x = (uint32_t)b << 16; float f; memcpy(&f, &x, 4); return f; }
+
+// ---------------------------------------------------------------- spec json
+static std::string ReadFile(const std::string &path, bool *ok)
+{
+    std::ifstream f(path, std::ios::binary);
+    *ok = (bool)f;
+    std::stringstream ss; ss << f.rdbuf();
+    return ss.str();
+}
+
+bool LoadModelSpecJson(ModelSpec &spec, const std::string &path)
+{
+    bool ok = false;
+    const std::string text = ReadFile(path, &ok);
+    if (!ok) { EngineSetError("Cannot open the model specification file %s", path.c_str()); return false; }
+    JsonValue root; JsonParser jp; std::string err;
+    if (!jp.Parse(text, root, &err) || root.type != JsonValue::Object) {
+        EngineSetError("Invalid JSON in %s: %s", path.c_str(), err.c_str()); return false;
+    }
+    root.GetString("config_file", spec.config_file);
+    if (const JsonValue *files = root.Get("model_files"))
+        for (const JsonValue &f : files->arr) if (f.type == JsonValue::String) spec.model_files.push_back(f.str);
+    root.GetString("model_file_format", spec.model_file_format);
+    spec.model_file_format = IniConfig::Lower(spec.model_file_format);
+    ModelHyperParams &hp = spec.hyper_params;
+    root.GetNumber("vocab_size", hp.vocab_size);
+    root.GetNumber("output_vocab_size", hp.output_vocab_size);
+    root.GetNumber("qkv_format", spec.qkv_format);
+    const JsonValue *ns = root.Get("network_structure");
+    if (!ns || ns->type != JsonValue::Object) { EngineSetError("%s: network_structure is missing", path.c_str()); return false; }
+    ns->GetString("type", spec.network_structure);
+    std::string s;
+    if (ns->GetString("normalization_function", s)) {
+        s = IniConfig::Lower(s);
+        if (s == "rms") spec.norm_alg = TensorNormAlg::RMS;
+        else if (s == "std" || s == "layer_norm" || s == "standard") spec.norm_alg = TensorNormAlg::STD;
+        else { EngineSetError("Invalid normalization_function: %s", s.c_str()); return false; }
+    }
+    if (ns->GetString("activation_function", s)) {
+        s = IniConfig::Lower(s);
+        if (s == "silu") spec.activation_fn = ActivationFn::SILU;
+        else if (s == "gelu") spec.activation_fn = ActivationFn::GELU;
+        else if (s == "relu") spec.activation_fn = ActivationFn::RELU;
+        else { EngineSetError("Invalid activation_function: %s", s.c_str()); return false; }
+    }
+    if (ns->GetString("position_embedding", s)) {
+        s = IniConfig::Lower(s);
+        if (s == "rope") spec.pos_embedding_alg = PositionEmbeddingAlg::ROPE;
+        else if (s == "alibi") spec.pos_embedding_alg = PositionEmbeddingAlg::ALIBI;
+        else if (s.empty() || s == "empty" || s == "none") spec.pos_embedding_alg = PositionEmbeddingAlg::EMPTY;
+        else { EngineSetError("Unsupported position_embedding: %s", s.c_str()); return false; }
+    }
+    ns->GetNumber("rope_theta", spec.rope_theta);
+    ns->GetNumber("partial_rotary_factor", spec.partial_rotary_factor);
+    ns->GetNumber("qk_column_order", spec.qk_column_order);
+    ns->GetNumber("qkv_format", spec.qkv_format);
+    ns->GetNumber("kq_scale", spec.kq_scale);
+    ns->GetBool("is_parallel_attn", spec.is_parallel_attn);
+    ns->GetBool("mlp_attn_share_input", spec.mlp_attn_share_input);
+    ns->GetNumber("expert_count", hp.experts);
+    ns->GetNumber("moe_top_k", hp.moe_top_k);
+    ns->GetBool("moe_norm_top_k_prob", hp.moe_norm_top_k_prob);
+    ns->GetString("tensor_name_prefix", spec.tensor_name_prefix);
+    if (const JsonValue *tm = ns->Get("tensor_name_mapping"))
+        for (const auto &kv : tm->obj) if (kv.second.type == JsonValue::String) spec.tensor_name_map[kv.first] = kv.second.str;
+    // "synthetic": shapes come from the spec itself
+    if (const JsonValue *h = root.Get("hyper_params")) {
+        h->GetNumber("vocab_size", hp.vocab_size); h->GetNumber("embd_dims", hp.embd_dims);
+        h->GetNumber("hidden_dim", hp.hidden_dim); h->GetNumber("decoder_layers", hp.decoder_layers);
+        h->GetNumber("decoder_heads", hp.decoder_heads); h->GetNumber("decoder_kv_heads", hp.decoder_kv_heads);
+        h->GetNumber("training_context_len", hp.training_context_len);
+    }
+    root.GetNumber("synthetic_std", spec.synthetic_std);
+    return true;
+}
+
+// --------------------------------------------------------------- uploading
+namespace {
+
+struct Uploader {
+    ifa_model *m = nullptr;
+    const ModelSpec *spec = nullptr;
+    void *dev = nullptr; size_t dev_bytes = 0;
+    ~Uploader() { if (dev) ifa_free(dev); }
+
+    static bool IsQuant(int dt) { return dt >= 7; }
+    int MatrixType(size_t rows, size_t cols) const
+    {
+        const int wdt = spec->device_weight_data_type;
+        if (!IsQuant(wdt)) return wdt == IFA_F32 ? IFA_F16 : wdt;       // F16 compute either way
+        const int cap = ifa_block_capacity(wdt);
+        if ((long long)(rows * cols) < (long long)spec->tensor_quant_threshold || cap <= 0 || cols % (size_t)cap != 0) return IFA_F16;
+        return wdt;
+    }
+    bool Put(int layer, int tid, int target, const uint16_t *f16, size_t rows, size_t cols)
+    {
+        const size_t bytes = rows * cols * 2;
+        if (bytes > dev_bytes) {
+            if (dev) ifa_free(dev);
+            dev = nullptr; dev_bytes = 0;
+            if (ifa_malloc(&dev, bytes) != IFA_OK) { EngineSetError("device allocation of %zu bytes failed: %s", bytes, ifa_last_error()); return false; }
+            dev_bytes = bytes;
+        }
+        if (ifa_memcpy_h2d(dev, f16, bytes, nullptr) != IFA_OK || ifa_stream_sync(nullptr) != IFA_OK
+            || ifa_model_set_tensor_f16(m, layer, tid, -1, target, dev, rows, cols) != IFA_OK) {
+            EngineSetError("uploading tensor %d of layer %d failed: %s", tid, layer, ifa_last_error());
+            return false;
+        }
+        return true;
+    }
+};
+
+int RopeOrder(const ModelSpec &spec)
+{
+    if (spec.pos_embedding_alg != PositionEmbeddingAlg::ROPE) return 0;
+    return spec.qk_column_order == 2 ? 2 : 1;          // unary_tensor_opr.h:661-735: order 2 = (c, c + dims/2) pairs
+}
+
+bool CreateWorker(ifa_model **out, const ModelSpec &spec, int device)
+{
+    const ModelHyperParams &hp = spec.hyper_params;
+    if (hp.embd_dims <= 0 || hp.decoder_layers <= 0 || hp.decoder_heads <= 0 || hp.vocab_size <= 0 || hp.hidden_dim <= 0) {
+        EngineSetError("model %s: incomplete hyper-parameters", spec.sid.c_str()); return false;
+    }
+    if (hp.experts > 0) { EngineSetError("model %s: MoE models are loaded through the Python worker for now", spec.sid.c_str()); return false; }
+    ifa_model_config c; memset(&c, 0, sizeof(c));
+    c.dim = hp.embd_dims; c.layers = hp.decoder_layers; c.heads = hp.decoder_heads;
+    c.kv_heads = hp.decoder_kv_heads > 0 ? hp.decoder_kv_heads : hp.decoder_heads;
+    c.head_dim = hp.embd_dims / hp.decoder_heads; c.ffn = hp.hidden_dim; c.vocab = hp.vocab_size;
+    c.max_ctx = spec.max_context_len > 0 ? spec.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
+    c.norm_kind = spec.norm_alg == TensorNormAlg::RMS ? 0 : 1;
+    c.act_kind = (int)spec.activation_fn; c.is_glu = 1;
+    c.rope_order = RopeOrder(spec); c.use_alibi = spec.pos_embedding_alg == PositionEmbeddingAlg::ALIBI;
+    c.parallel_attn = spec.is_parallel_attn; c.share_input = spec.mlp_attn_share_input;
+    c.rope_theta = spec.rope_theta; c.partial_rotary = spec.partial_rotary_factor; c.kq_scale = spec.kq_scale; c.eps = 1e-5f;
+    c.kv_dtype = spec.device_kv_cache_data_type == IFA_Q8_B32T2 ? IFA_Q8_B32T2 : IFA_F16;
+    c.full_quant_gemv = 1; c.tp_rank = 0; c.tp_size = 1; c.device = device;
+    if (ifa_model_create(&c, out) != IFA_OK) { EngineSetError("ifa_model_create: %s", ifa_last_error()); return false; }
+    return true;
+}
+
+int LmHeadType(const ModelSpec &spec, size_t rows, size_t cols)
+{
+    const int wdt = spec.device_weight_data_type;
+    if (!Uploader::IsQuant(wdt) || spec.hyper_params.decoder_layers > 20) return IFA_F16;
+    const int cap = ifa_block_capacity(wdt);
+    (void)rows;
+    return (cap > 0 && cols % (size_t)cap == 0) ? wdt : IFA_F16;
+}
+
+// ---------------------------------------------------------------- llama2.c
+bool LoadLlama2DotC(ifa_model **out, ModelSpec &spec, int device)
+{
+    const std::string path = spec.dir + (spec.model_files.empty() ? "" : spec.model_files[0]);
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) { EngineSetError("Failed to open file %s", path.c_str()); return false; }
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{fp};
+    uint32_t magic = 0; int version = 0;
+    if (fread(&magic, 4, 1, fp) != 1) { EngineSetError("Failed to read the magic number"); return false; }
+    if (magic == 0x616b3432u) {
+        if (fread(&version, 4, 1, fp) != 1 || version != 1) { EngineSetError("llama2.c version %d is not supported", version); return false; }
+    } else fseek(fp, 0, SEEK_SET);
+    int h[7];
+    if (fread(h, 4, 7, fp) != 7) { EngineSetError("Failed to read the llama2.c header"); return false; }
+    ModelHyperParams &hp = spec.hyper_params;
+    hp.embd_dims = h[0]; hp.hidden_dim = h[1]; hp.decoder_layers = h[2]; hp.decoder_heads = h[3]; hp.decoder_kv_heads = h[4];
+    bool shared = h[5] >= 0;
+    hp.vocab_size = abs(h[5]); hp.training_context_len = h[6];
+    if (version == 1) {
+        uint8_t v8 = 0;
+        if (fread(&v8, 1, 1, fp) != 1) { EngineSetError("Failed to read the shared-classifier flag"); return false; }
+        shared = v8 != 0;
+        fseek(fp, 256, SEEK_SET);      // the v1 header is padded to 256 bytes
+    }
+    if (hp.embd_dims <= 0 || hp.decoder_heads <= 0 || hp.embd_dims % hp.decoder_heads != 0) { EngineSetError("bad llama2.c header in %s", path.c_str()); return false; }
+    if (!CreateWorker(out, spec, device)) return false;
+    Uploader up; up.m = *out; up.spec = &spec;
+    const size_t D = (size_t)hp.embd_dims, F = (size_t)hp.hidden_dim, V = (size_t)hp.vocab_size, L = (size_t)hp.decoder_layers;
+    const size_t HS = D / (size_t)hp.decoder_heads, KV = (size_t)hp.decoder_kv_heads * HS;
+    std::vector<float> f32; std::vector<uint16_t> f16;
+    auto read = [&](size_t rows, size_t cols) -> bool {
+        f32.resize(rows * cols); f16.resize(rows * cols);
+        if (fread(f32.data(), 4, rows * cols, fp) != rows * cols) { EngineSetError("%s is truncated", path.c_str()); return false; }
+        for (size_t i = 0; i < rows * cols; i++) f16[i] = F32ToF16(f32[i]);
+        return true;
+    };
+    std::vector<uint16_t> embd;
+    if (!read(V, D)) return false;
+    embd = f16;
+    if (!up.Put(-1, IFA_T_EMBD, IFA_F16, f16.data(), V, D)) return false;
+    struct Kind { int tid; size_t rows, cols; bool matrix; };
+    const Kind kinds[] = {{IFA_T_ATTN_NORM, 1, D, false}, {IFA_T_WQ, D, D, true}, {IFA_T_WK, KV, D, true}, {IFA_T_WV, KV, D, true},
+                          {IFA_T_WO, D, D, true}, {IFA_T_FFN_NORM, 1, D, false}, {IFA_T_W1, F, D, true}, {IFA_T_W2, D, F, true},
+                          {IFA_T_W3, F, D, true}};
+    for (const Kind &k : kinds)                 // grouped by kind: [L][rows][cols] each
+        for (size_t l = 0; l < L; l++) {
+            if (!read(k.rows, k.cols)) return false;
+            const int target = k.matrix ? up.MatrixType(k.rows, k.cols) : IFA_F16;
+            if (!up.Put((int)l, k.tid, target, f16.data(), k.rows, k.cols)) return false;
+        }
+    if (!read(1, D) || !up.Put(-1, IFA_T_OUT_NORM, IFA_F16, f16.data(), 1, D)) return false;
+    // model_reader.cc:3420-3421 skips training_context_len * head_size BYTES here (the legacy RoPE tables are
+    // 4x that); kept as is so that unshared-classifier files load exactly what the reference loads
+    fseek(fp, (long)((size_t)hp.training_context_len * HS), SEEK_CUR);
+    if (!shared) { if (!read(V, D)) return false; } else f16 = embd;
+    if (!up.Put(-1, IFA_T_LM_HEAD, LmHeadType(spec, V, D), f16.data(), V, D)) return false;
+    return true;
+}
+
+// ------------------------------------------------------------- safetensors
+struct StEntry { std::string file; std::string dtype; std::vector<size_t> shape; size_t begin = 0, end = 0, data_off = 0; };
+
+bool IndexSafetensors(const std::string &path, std::map<std::string, StEntry> &index)
+{
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) { EngineSetError("Failed to open file %s", path.c_str()); return false; }
+    uint64_t hlen = 0;
+    bool ok = fread(&hlen, 8, 1, fp) == 1 && hlen > 0 && hlen < (1ull << 30);
+    std::string header;
+    if (ok) { header.resize((size_t)hlen); ok = fread(&header[0], 1, (size_t)hlen, fp) == (size_t)hlen; }
+    fclose(fp);
+    if (!ok) { EngineSetError("%s: bad safetensors header", path.c_str()); return false; }
+    JsonValue root; JsonParser jp; std::string err;
+    if (!jp.Parse(header, root, &err) || root.type != JsonValue::Object) { EngineSetError("%s: %s", path.c_str(), err.c_str()); return false; }
+    for (const auto &kv : root.obj) {
+        if (kv.first == "__metadata__" || kv.second.type != JsonValue::Object) continue;
+        StEntry e; e.file = path; e.data_off = 8 + (size_t)hlen;
+        kv.second.GetString("dtype", e.dtype);
+        if (const JsonValue *sh = kv.second.Get("shape")) for (const JsonValue &d : sh->arr) e.shape.push_back((size_t)d.num);
+        const JsonValue *off = kv.second.Get("data_offsets");
+        if (!off || off->arr.size() != 2) { EngineSetError("%s: tensor %s has no data_offsets", path.c_str(), kv.first.c_str()); return false; }
+        e.begin = (size_t)off->arr[0].num; e.end = (size_t)off->arr[1].num;
+        index[kv.first] = e;
+    }
+    return true;
+}
+
+bool ReadStTensor(const StEntry &e, size_t rows, size_t cols, std::vector<uint16_t> &f16, const std::string &name)
+{
+    size_t n = 1; for (size_t d : e.shape) n *= d;
+    if (n != rows * cols) { EngineSetError("tensor %s: %zu elements, expected %zu x %zu", name.c_str(), n, rows, cols); return false; }
+    const size_t esz = e.dtype == "F32" ? 4 : (e.dtype == "F16" || e.dtype == "BF16") ? 2 : 0;
+    if (!esz || e.end - e.begin != n * esz) { EngineSetError("tensor %s: unsupported dtype %s", name.c_str(), e.dtype.c_str()); return false; }
+    FILE *fp = fopen(e.file.c_str(), "rb");
+    if (!fp) { EngineSetError("Failed to open file %s", e.file.c_str()); return false; }
+    std::vector<uint8_t> raw(n * esz);
+    fseek(fp, (long)(e.data_off + e.begin), SEEK_SET);
+    const bool ok = fread(raw.data(), 1, raw.size(), fp) == raw.size();
+    fclose(fp);
+    if (!ok) { EngineSetError("%s is truncated (tensor %s)", e.file.c_str(), name.c_str()); return false; }
+    f16.resize(n);
+    if (e.dtype == "F16") memcpy(f16.data(), raw.data(), n * 2);
+    else if (e.dtype == "BF16") { const uint16_t *p = (const uint16_t *)raw.data(); for (size_t i = 0; i < n; i++) f16[i] = F32ToF16(BF16ToF32(p[i])); }
+    else { const float *p = (const float *)raw.data(); for (size_t i = 0; i < n; i++) f16[i] = F32ToF16(p[i]); }
+    return true;
+}
+
+bool LoadHfConfig(ModelSpec &spec)
+{
+    if (spec.config_file.empty()) return true;
+    bool ok = false;
+    const std::string text = ReadFile(spec.dir + spec.config_file, &ok);
+    if (!ok) { EngineSetError("Cannot open %s%s", spec.dir.c_str(), spec.config_file.c_str()); return false; }
+    JsonValue root; JsonParser jp; std::string err;
+    if (!jp.Parse(text, root, &err)) { EngineSetError("%s: %s", spec.config_file.c_str(), err.c_str()); return false; }
+    ModelHyperParams &hp = spec.hyper_params;
+    // the key aliases ModelReader::LoadModelSpecJson accepts (model_reader.cc:470-560)
+    for (const char *k : {"d_model", "n_embed", "n_embd", "hidden_size"}) root.GetNumber(k, hp.embd_dims);
+    for (const char *k : {"n_layer", "num_layers", "num_hidden_layers"}) root.GetNumber(k, hp.decoder_layers);
+    for (const char *k : {"n_head", "num_attention_heads"}) root.GetNumber(k, hp.decoder_heads);
+    for (const char *k : {"num_kv_heads", "num_key_value_heads"}) root.GetNumber(k, hp.decoder_kv_heads);
+    for (const char *k : {"ffn_hidden_size", "intermediate_size"}) root.GetNumber(k, hp.hidden_dim);
+    if (hp.vocab_size <= 0) root.GetNumber("vocab_size", hp.vocab_size);
+    root.GetNumber("max_position_embeddings", hp.training_context_len);
+    root.GetNumber("rope_theta", spec.rope_theta);
+    if (hp.decoder_kv_heads <= 0) hp.decoder_kv_heads = hp.decoder_heads;
+    return true;
+}
+
+bool LoadSafetensors(ifa_model **out, ModelSpec &spec, int device)
+{
+    if (!LoadHfConfig(spec)) return false;
+    std::map<std::string, StEntry> index;
+    for (const std::string &f : spec.model_files) {
+        if (f.size() > 5 && f.compare(f.size() - 5, 5, ".json") == 0) continue;     // *.index.json
+        if (!IndexSafetensors(spec.dir + f, index)) return false;
+    }
+    // file name -> standard name: strip the prefix, then apply tensor_name_mapping
+    std::map<std::string, StEntry> by_std;
+    for (const auto &kv : index) {
+        std::string name = kv.first;
+        if (!spec.tensor_name_prefix.empty() && name.compare(0, spec.tensor_name_prefix.size(), spec.tensor_name_prefix) == 0)
+            name = name.substr(spec.tensor_name_prefix.size());
+        for (const auto &mp : spec.tensor_name_map) {
+            size_t p = name.find(mp.first);
+            if (p != std::string::npos) name.replace(p, mp.first.size(), mp.second);
+        }
+        by_std[name] = kv.second;
+    }
+    if (!CreateWorker(out, spec, device)) return false;
+    const ModelHyperParams &hp = spec.hyper_params;
+    Uploader up; up.m = *out; up.spec = &spec;
+    const size_t D = (size_t)hp.embd_dims, F = (size_t)hp.hidden_dim, V = (size_t)hp.vocab_size;
+    const size_t HS = D / (size_t)hp.decoder_heads, KV = (size_t)hp.decoder_kv_heads * HS;
+    std::vector<uint16_t> f16;
+    auto put = [&](const std::string &name, int layer, int tid, size_t rows, size_t cols, bool matrix, bool required) -> int {
+        auto it = by_std.find(name);
+        if (it == by_std.end()) { if (required) EngineSetError("tensor %s is missing", name.c_str()); return required ? -1 : 0; }
+        if (!ReadStTensor(it->second, rows, cols, f16, name)) return -1;
+        const int target = tid == IFA_T_LM_HEAD ? LmHeadType(spec, rows, cols) : (matrix ? up.MatrixType(rows, cols) : IFA_F16);
+        return up.Put(layer, tid, target, f16.data(), rows, cols) ? 1 : -1;
+    };
+    if (put("embed_tokens.weight", -1, IFA_T_EMBD, V, D, false, true) < 0) return false;
+    const std::vector<uint16_t> embd = f16;
+    for (int l = 0; l < hp.decoder_layers; l++) {
+        const std::string p = "layers." + std::to_string(l) + ".";
+        struct E { const char *name; int tid; size_t rows, cols; bool matrix; };
+        const E es[] = {{"input_layernorm.weight", IFA_T_ATTN_NORM, 1, D, false},
+                        {"self_attn.q_proj.weight", IFA_T_WQ, D, D, true}, {"self_attn.k_proj.weight", IFA_T_WK, KV, D, true},
+                        {"self_attn.v_proj.weight", IFA_T_WV, KV, D, true}, {"self_attn.o_proj.weight", IFA_T_WO, D, D, true},
+                        {"post_attention_layernorm.weight", IFA_T_FFN_NORM, 1, D, false},
+                        {"mlp.gate_proj.weight", IFA_T_W1, F, D, true}, {"mlp.down_proj.weight", IFA_T_W2, D, F, true},
+                        {"mlp.up_proj.weight", IFA_T_W3, F, D, true}};
+        for (const E &e : es) if (put(p + e.name, l, e.tid, e.rows, e.cols, e.matrix, true) < 0) return false;
+        const E bs[] = {{"self_attn.q_proj.bias", IFA_T_WQ_B, 1, D, false}, {"self_attn.k_proj.bias", IFA_T_WK_B, 1, KV, false},
+                        {"self_attn.v_proj.bias", IFA_T_WV_B, 1, KV, false}};
+        for (const E &e : bs) if (put(p + e.name, l, e.tid, e.rows, e.cols, false, false) < 0) return false;
+    }
+    if (put("norm.weight", -1, IFA_T_OUT_NORM, 1, D, false, true) < 0) return false;
+    int rc = put("lm_head.weight", -1, IFA_T_LM_HEAD, V, D, true, false);
+    if (rc < 0) return false;
+    if (rc == 0) {       // tied embeddings
+        by_std["lm_head.weight"] = by_std["embed_tokens.weight"];
+        if (put("lm_head.weight", -1, IFA_T_LM_HEAD, V, D, true, true) < 0) return false;
+    }
+    return true;
+}
+
+// --------------------------------------------------------------- synthetic
+// counter-based generator: value i of a tensor depends only on (seed, i), so the result is
+// independent of the number of host threads
+inline uint64_t Mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+void FillNormalF16(std::vector<uint16_t> &out, size_t n, uint64_t seed, float std_dev)
+{
+    out.resize(n);
+    const unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> ts;
+    const size_t pairs = (n + 1) / 2;
+    for (unsigned t = 0; t < nt; t++)
+        ts.emplace_back([&, t]() {
+            for (size_t p = pairs * t / nt; p < pairs * (t + 1) / nt; p++) {
+                const uint64_t a = Mix64(seed * 0x100000001B3ull + 2 * p), b = Mix64(seed * 0x100000001B3ull + 2 * p + 1);
+                const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+                const double r = sqrt(-2.0 * log(u1)), th = 6.283185307179586 * u2;
+                out[2 * p] = F32ToF16((float)(r * cos(th)) * std_dev);
+                if (2 * p + 1 < n) out[2 * p + 1] = F32ToF16((float)(r * sin(th)) * std_dev);
+            }
+        });
+    for (auto &t : ts) t.join();
+}
+
+bool LoadSynthetic(ifa_model **out, ModelSpec &spec, int device)
+{
+    ModelHyperParams &hp = spec.hyper_params;
+    if (hp.decoder_kv_heads <= 0) hp.decoder_kv_heads = hp.decoder_heads;
+    if (!CreateWorker(out, spec, device)) return false;
+    Uploader up; up.m = *out; up.spec = &spec;
+    const size_t D = (size_t)hp.embd_dims, F = (size_t)hp.hidden_dim, V = (size_t)hp.vocab_size;
+    const size_t HS = D / (size_t)hp.decoder_heads, KV = (size_t)hp.decoder_kv_heads * HS;
+    std::vector<uint16_t> w, ones(D, 0x3C00);
+    FillNormalF16(w, V * D, 999, spec.synthetic_std);
+    if (!up.Put(-1, IFA_T_EMBD, IFA_F16, w.data(), V, D)) return false;
+    if (!up.Put(-1, IFA_T_OUT_NORM, IFA_F16, ones.data(), 1, D)) return false;
+    FillNormalF16(w, V * D, 998, spec.synthetic_std);
+    if (!up.Put(-1, IFA_T_LM_HEAD, LmHeadType(spec, V, D), w.data(), V, D)) return false;
+    for (int l = 0; l < hp.decoder_layers; l++) {
+        if (!up.Put(l, IFA_T_ATTN_NORM, IFA_F16, ones.data(), 1, D) || !up.Put(l, IFA_T_FFN_NORM, IFA_F16, ones.data(), 1, D)) return false;
+        struct E { int tid; size_t rows, cols; };
+        const E es[] = {{IFA_T_WQ, D, D}, {IFA_T_WK, KV, D}, {IFA_T_WV, KV, D}, {IFA_T_WO, D, D}, {IFA_T_W1, F, D}, {IFA_T_W3, F, D}, {IFA_T_W2, D, F}};
+        for (const E &e : es) {
+            FillNormalF16(w, e.rows * e.cols, 1000 + (uint64_t)l * 16 + (uint64_t)e.tid, spec.synthetic_std);
+            if (!up.Put(l, e.tid, up.MatrixType(e.rows, e.cols), w.data(), e.rows, e.cols)) return false;
+        }
+    }
+    return true;
+}
+
+} // namespace
+
+bool BuildWorker(ifa_model **out, ModelSpec &spec, int device)
+{
+    *out = nullptr;
+    if (ifa_set_device(device) != IFA_OK) { EngineSetError("ifa_set_device(%d): %s", device, ifa_last_error()); return false; }
+    bool ok = false;
+    const std::string &fmt = spec.model_file_format;
+    if (fmt == "llama2.c" || fmt == "llama2_c") ok = LoadLlama2DotC(out, spec, device);
+    else if (fmt == "safetensors") ok = LoadSafetensors(out, spec, device);
+    else if (fmt == "synthetic") ok = LoadSynthetic(out, spec, device);
+    else EngineSetError("model %s: model_file_format \"%s\" is not supported (llama2.c, safetensors, synthetic)", spec.sid.c_str(), fmt.c_str());
+    if (ok && ifa_model_finalize(*out) != IFA_OK) { EngineSetError("ifa_model_finalize: %s", ifa_last_error()); ok = false; }
+    if (!ok && *out) { ifa_model_destroy(*out); *out = nullptr; }
+    return ok;
+}
+
+} // namespace inferflow_amd

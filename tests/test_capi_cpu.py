@@ -12,8 +12,8 @@ import oracle as o
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "inferflow_amd.h")).read()
+def _declared(header="inferflow_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ifa_[a-z0-9_]+)\s*\(", text)))
 
@@ -28,6 +28,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_signatures_cover_header():
     assert sorted(_capi.SIGNATURES) == _declared()
+
+
+def test_engine_header_is_exported_and_bound():
+    names = _declared("inferflow_engine.h")
+    assert sorted(_capi.ENGINE_SIGNATURES) == names and len(names) >= 10
+    L = ia.lib()
+    for n in names:
+        assert hasattr(L, n), "missing symbol " + n
 
 
 def test_registry_matches_oracle():

@@ -1,0 +1,108 @@
+"""-m gpu: the C++ InferenceEngine facade (LoadConfig -> Init -> AddQuery -> Infer -> Commit) on tiny
+llama2.c / safetensors / synthetic model directories, against the whole-model oracle."""
+import numpy as np
+import pytest
+
+import oracle as o
+from inferflow_amd import dtypes as dt
+from inferflow_amd.engine import InferenceEngine, EngineError
+from tests import engine_fixtures as fx
+from tests.model_util import oracle_model_from_host
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(w, wd, kvd, rope_order, ctx=64):
+    s = fx.SHAPE
+    host = fx.host_tensors(w, s, wd)
+    return oracle_model_from_host(host, s, ctx, kvd, rope_order=rope_order)
+
+
+def _close(a, b):
+    a = a.astype(np.float32); b = b.astype(np.float32)
+    cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    return cos, float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("fmt,wd_name,wd,kv_name,kvd,qk", [
+    ("llama2.c", "Q4", dt.Q4_B32T1A, "Q8", dt.Q8_B32T2, 0),
+    ("llama2.c", "Q3H", dt.Q3H_B64T1, "F16", dt.F16, 0),
+    ("safetensors", "Q8", dt.Q8_B32T2, "Q8", dt.Q8_B32T2, 2),
+    ("safetensors", "F16", dt.F16, "F16", dt.F16, 2),
+], ids=["llama2c_q4_kvq8", "llama2c_q3h_kvf16", "safetensors_q8_kvq8", "safetensors_f16"])
+def test_serving_loop_matches_oracle(tmp_path, fmt, wd_name, wd, kv_name, kvd, qk):
+    ini, w = fx.write_model_dir(str(tmp_path), fmt=fmt, wd=wd_name, kvd=kv_name, qk_order=qk)
+    eng = InferenceEngine.from_ini(ini)
+    assert eng.model_info("decoder_kv_heads") == 2 and eng.model_info("vocab_size") == 1000
+    assert eng.model_info("device_weight_data_type") == wd and eng.model_info("device_kv_cache_data_type") == kvd
+    om = _oracle(w, wd, kvd, rope_order=2 if qk == 2 else 1)
+    prompt = np.random.default_rng(3).integers(3, 1000, 9).astype(np.int32)
+    qid = eng.add_query(prompt)
+    assert qid > 0 and eng.query_count() == 1
+    # step 1 = prefill of the whole prompt, with the full logits tensor (return_output_tensors)
+    (q, tok), = eng.infer()
+    assert q == qid
+    tok_o, lg_o = om.forward(prompt, 0, nthreads=4)
+    lg = eng.last_logits(qid)
+    assert lg.shape == (9, 1000)
+    cos, mad = _close(lg, lg_o)
+    assert cos >= 0.9995 and mad <= 0.03, (cos, mad)          # same stated tolerance as tests/test_gpu_engine.py
+    cur, pos = tok, len(prompt)
+    for step in range(10):
+        t_or, l_or = om.forward(np.array([cur], np.int32), pos, nthreads=4)
+        assert eng.commit({qid: cur})
+        (q, tok), = eng.infer()
+        top2 = np.sort(l_or[0].astype(np.float32))[-2:]
+        if top2[1] - top2[0] > 0.05:
+            assert tok == t_or, "step %d" % step
+        cur, pos = tok, pos + 1
+    assert eng.infer() == []                 # nothing committed since the last step
+    assert eng.remove_query(qid) and eng.query_count() == 0 and not eng.remove_query(qid)
+    eng.close()
+
+
+def test_generate_equals_step_loop_and_queries_are_independent(tmp_path):
+    ini, _ = fx.write_model_dir(str(tmp_path), fmt="synthetic", wd="Q4", kvd="F16", ret="false", maxq=2)
+    eng = InferenceEngine.from_ini(ini)
+    rng = np.random.default_rng(11)
+    pa, pb = rng.integers(3, 1000, 7), rng.integers(3, 1000, 5)
+    qa = eng.add_query(pa)
+    gen, ms = eng.generate(qa, 12)
+    assert len(gen) == 12 and ms > 0
+    # the same prompt through Infer/Commit, interleaved with a second query sharing the worker
+    qa2, qb = eng.add_query(pa), 0
+    assert qa2 > 0
+    assert eng.add_query(pb) == 0            # busy: max_concurrent_queries = 2
+    assert eng.remove_query(qa)
+    qb = eng.add_query(pb)
+    assert qb > 0
+    out_a, out_b = [], []
+    for _ in range(12):
+        res = dict(eng.infer())
+        assert set(res) == {qa2, qb}
+        out_a.append(res[qa2]); out_b.append(res[qb])
+        eng.commit({qa2: res[qa2], qb: res[qb]})
+    assert out_a == gen
+    # query b alone gives the same tokens as when interleaved
+    eng.remove_query(qa2); eng.remove_query(qb)
+    qb2 = eng.add_query(pb)
+    gen_b, _ = eng.generate(qb2, 12)
+    assert gen_b == out_b
+    eng.close()
+
+
+def test_engine_errors_follow_the_reference_conventions(tmp_path):
+    ini, _ = fx.write_model_dir(str(tmp_path), fmt="synthetic", wd="Q4", kvd="Q8", ctx=32)
+    eng = InferenceEngine.from_ini(ini)
+    assert eng.add_query([]) < 0
+    assert eng.add_query([5, 1000]) < 0                      # token id out of range
+    assert eng.add_query(list(range(3, 40))) < 0             # longer than max_context_len
+    q = eng.add_query([5, 6, 7])
+    assert q > 0
+    assert not eng.commit({q + 1: 5})                        # unknown query
+    assert not eng.commit({q: 99999})
+    eng.close()
+    bad = str(tmp_path / "bad.ini")
+    open(bad, "w").write(open(ini).read().replace("device_weight_data_type = Q4", "device_weight_data_type = Q7"))
+    with pytest.raises(EngineError, match="device_weight_data_type"):
+        InferenceEngine.from_ini(bad)
