@@ -143,6 +143,10 @@ int ifa_mul(const void *a_f16, const void *b_f16, size_t n, void *c_f16, ifa_str
 /* c = a + b, b broadcast with period b_period elements (0 = same size) */
 int ifa_add(const void *a_f16, const void *b_f16, size_t n, size_t b_period, void *c_f16, ifa_stream stream);
 int ifa_scale(const void *a_f16, float s, size_t n, void *c_f16, ifa_stream stream);
+/* TensorOpr::AddByRowIndex (tensor_opr.cu:1519-1548, kernel binary_tensor_opr.h:80-125), the MoE scatter-add:
+ * B[row_idx[r]][:] = hfma(A[r][:], weights[r], B[row_idx[r]][:]) in half precision (weights may be NULL = 1). */
+int ifa_add_by_row_index(void *b_f16, const void *a_f16, size_t rows, size_t cols, const int *row_idx_dev,
+                         const void *weights_f16_dev, ifa_stream stream);
 
 /* ---- attention over a KV cache (inference_worker.cc:983-1405, :1639-1724) */
 /* q F16 [q_tokens][heads][head_dim]; caches [n_ctx rows][kv_heads*head_dim] in

@@ -37,6 +37,7 @@ struct Tensor {
 
 struct Layer {
     Tensor t[T_MAX];
+    std::vector<Tensor> experts;   // [expert][3]: w1, w2, w3 (MoE layers)
     void *kcache = nullptr, *vcache = nullptr;
 };
 
@@ -53,6 +54,8 @@ struct ifa_model {
     half_t *x = nullptr, *x2 = nullptr, *xn = nullptr, *hn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
     half_t *att = nullptr, *a = nullptr, *f = nullptr, *t1 = nullptr, *t2 = nullptr, *logits = nullptr;
     uint8_t *xq = nullptr;
+    half_t *moe_gate = nullptr, *moe_out = nullptr;   // MoE: router probabilities [T][experts], one expert's output row
+    int *moe_idx = nullptr, *moe_pin = nullptr;        // MoE: {row index, half weight} of the pending scatter-add (device / pinned)
     int *state = nullptr;          // device: see k_dec_gather
     float *rope_tab = nullptr;     // device: [head_dim/2][2]
     long long *trace = nullptr;    // device: [2048][8] optional kernel phase stamps
@@ -323,6 +326,11 @@ static int ensure_scratch(ifa_model *m, int T)
         || (rc = re(m->a, T * D)) || (rc = re(m->f, T * D)) || (rc = re(m->t1, T * F)) || (rc = re(m->t2, T * F))
         || (rc = re(m->logits, (size_t)T * c.vocab)))
         return rc;
+    if (c.experts > 0) {
+        if ((rc = re(m->moe_gate, (size_t)T * c.experts)) || (rc = re(m->moe_out, D))) return rc;
+        if (!m->moe_idx) IFA_HIP_CHECK(hipMalloc((void **)&m->moe_idx, 16));
+        if (!m->moe_pin) IFA_HIP_CHECK(hipHostMalloc((void **)&m->moe_pin, 16, hipHostMallocDefault));
+    }
     if (m->xq) IFA_HIP_CHECK(hipFree(m->xq));
     IFA_HIP_CHECK(hipMalloc((void **)&m->xq, (maxcols / 32 + 1) * 34));
     if (m->tokens_dev) IFA_HIP_CHECK(hipFree(m->tokens_dev));
@@ -371,6 +379,75 @@ static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, cons
 {
     return ifa_layernorm(m->cfg.norm_kind, x, (size_t)T, (size_t)m->cfg.dim, w.present() ? w.data : nullptr,
                          b.present() ? b.data : nullptr, 0.0f, m->cfg.eps, y, m->stream);
+}
+
+// w2 . (act(w1 . x) [* (w3 . x)])   (ProcessGpuLayer_FeedForward, inference_worker.cc:1726-1922)
+static int ffn_dense(ifa_model *m, const half_t *x, int T, const Tensor &w1, const Tensor &b1, const Tensor &w3, const Tensor &b3,
+                     const Tensor &w2, const Tensor &b2, half_t *out)
+{
+    int rc;
+    ifa_stream s = (ifa_stream)m->stream;
+    if ((rc = matmul(m, x, T, w1, b1, m->t1))) return rc;
+    if ((rc = ifa_activation(m->cfg.act_kind, 0, m->t1, (size_t)T, w1.rows, m->t1, s))) return rc;
+    if (w3.present()) {
+        if ((rc = matmul(m, x, T, w3, b3, m->t2))) return rc;
+        if ((rc = ifa_mul(m->t1, m->t2, (size_t)T * w1.rows, m->t1, s))) return rc;
+    }
+    return matmul(m, m->t1, T, w2, b2, out);
+}
+
+// Mixture of experts (ProcessGpuLayer_Moe, inference_worker.cc:1924-2146): router GEMV -> softmax -> D2H ->
+// host top-k (HostTensorOpr::BuildRowsForMoE, host_tensor_opr.cc:190-244: probabilities below 1e-5 are dropped,
+// optional renormalisation) -> the selected experts' FFNs in ascending expert order, each row on the T=1
+// path -> B[row] = hfma(out, weight, B[row]) (AddByRowIdx_Kernel).  Result in m->f.
+static int moe_ffn(ifa_model *m, Layer &L, const half_t *ff_n, int T)
+{
+    const ifa_model_config &c = m->cfg;
+    const size_t D = (size_t)c.dim; const int E = c.experts;
+    ifa_stream s = (ifa_stream)m->stream;
+    int rc;
+    IFA_REQUIRE(E <= 64 && c.moe_top_k >= 1 && c.moe_top_k <= 8, "MoE: experts %d / top_k %d out of range", E, c.moe_top_k);
+    IFA_REQUIRE((int)L.experts.size() == E * 3, "MoE: expert tensors missing");
+    Tensor none;
+    half_t *gate = m->moe_gate;
+    if ((rc = matmul(m, ff_n, T, L.t[T_MOE_GATE], none, gate))) return rc;
+    if ((rc = ifa_softmax(gate, E, T, 1, -1, 1.0f, s))) return rc;
+    std::vector<uint16_t> probs_h((size_t)T * E);
+    IFA_HIP_CHECK(hipMemcpyAsync(probs_h.data(), gate, probs_h.size() * 2, hipMemcpyDeviceToHost, m->stream));
+    IFA_HIP_CHECK(hipMemsetAsync(m->f, 0, (size_t)T * D * 2, m->stream));
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    for (int t = 0; t < T; t++) {
+        float probs[64]; int idx[8]; float w[8]; bool used[64] = {false};
+        for (int e = 0; e < E; e++) probs[e] = (float)__builtin_bit_cast(_Float16, probs_h[(size_t)t * E + e]);
+        int n = 0;
+        for (int k = 0; k < c.moe_top_k && k < E; k++) {          // first maximum wins, like the host sort
+            int best = -1;
+            for (int e = 0; e < E; e++) if (!used[e] && (best < 0 || probs[e] > probs[best])) best = e;
+            if (best < 0) break;
+            used[best] = true;
+            if (probs[best] < 0.00001f) continue;
+            idx[n] = best; w[n] = probs[best]; n++;
+        }
+        if (c.moe_norm_topk && n > 0) {
+            float sum = 0.0f;
+            for (int i = 0; i < n; i++) sum = sum + w[i];
+            for (int i = 0; i < n; i++) w[i] = w[i] / sum;
+        }
+        for (int e = 0; e < E; e++)
+            for (int j = 0; j < n; j++) {
+                if (idx[j] != e) continue;
+                const Tensor *ew = &L.experts[(size_t)e * 3];
+                if ((rc = ffn_dense(m, ff_n + (size_t)t * D, 1, ew[0], none, ew[2], none, ew[1], none, m->moe_out))) return rc;
+                // one (row index, weight) pair per call: staged through the pinned buffer, consumed by the kernel below
+                m->moe_pin[0] = t;
+                const _Float16 wh = (_Float16)w[j];
+                memcpy(&m->moe_pin[1], &wh, 2);
+                IFA_HIP_CHECK(hipMemcpyAsync(m->moe_idx, m->moe_pin, 8, hipMemcpyHostToDevice, m->stream));
+                if ((rc = ifa_add_by_row_index(m->f, m->moe_out, 1, D, m->moe_idx, m->moe_idx + 1, s))) return rc;
+                IFA_HIP_CHECK(hipStreamSynchronize(m->stream));      // the pinned pair is reused by the next one
+            }
+    }
+    return IFA_OK;
 }
 
 static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token)
@@ -424,13 +501,11 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
             if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn))) return rc;
             ff_n = m->hn;
         }
-        if ((rc = matmul(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], m->t1))) return rc;
-        if ((rc = ifa_activation(c.act_kind, 0, m->t1, (size_t)T, L.t[T_W1].rows, m->t1, s))) return rc;
-        if (L.t[T_W3].present()) {
-            if ((rc = matmul(m, ff_n, T, L.t[T_W3], L.t[T_W3_B], m->t2))) return rc;
-            if ((rc = ifa_mul(m->t1, m->t2, (size_t)T * L.t[T_W1].rows, m->t1, s))) return rc;
+        if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
+            if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
+        } else {
+            if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
         }
-        if ((rc = matmul(m, m->t1, T, L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
         if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
         if (c.parallel_attn || c.share_input)
             if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
@@ -493,6 +568,7 @@ int ifa_model_destroy(ifa_model *m)
     }
     for (Layer &L : m->layers) {
         for (Tensor &t : L.t) free_tensor(t);
+        for (Tensor &t : L.experts) free_tensor(t);
         if (L.kcache) (void)hipFree(L.kcache);
         if (L.vcache) (void)hipFree(L.vcache);
     }
@@ -514,7 +590,8 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
 {
     IFA_REQUIRE(m && dev_src, "ifa_model_set_tensor: null pointer");
     IFA_REQUIRE(tensor_id >= 0 && tensor_id < T_MAX, "ifa_model_set_tensor: tensor id %d", tensor_id);
-    IFA_REQUIRE(expert < 0, "ifa_model_set_tensor: MoE experts are not supported yet");
+    IFA_REQUIRE(expert < 0 || (expert < m->cfg.experts && layer >= 0 && (tensor_id == T_W1 || tensor_id == T_W2 || tensor_id == T_W3)),
+                "ifa_model_set_tensor: expert %d (of %d) / tensor %d", expert, m->cfg.experts, tensor_id);
     IFA_REQUIRE(block_capacity(dtype) > 0 && dtype != F32, "ifa_model_set_tensor: dtype %d", dtype);
     IFA_REQUIRE(cols % (size_t)block_capacity(dtype) == 0, "ifa_model_set_tensor: cols %zu vs block capacity", cols);
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
@@ -522,7 +599,11 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
     if (tensor_id < 10) t = &m->g[tensor_id];
     else {
         IFA_REQUIRE(layer >= 0 && layer < m->cfg.layers, "ifa_model_set_tensor: layer %d", layer);
-        t = &m->layers[(size_t)layer].t[tensor_id];
+        Layer &L = m->layers[(size_t)layer];
+        if (expert >= 0) {
+            if (L.experts.empty()) L.experts.resize((size_t)m->cfg.experts * 3);
+            t = &L.experts[(size_t)expert * 3 + (tensor_id == T_W1 ? 0 : (tensor_id == T_W2 ? 1 : 2))];
+        } else t = &L.t[tensor_id];
     }
     free_tensor(*t);
     // load time: the source may have been produced on another stream (e.g. the caller's default stream)

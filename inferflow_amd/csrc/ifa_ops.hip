@@ -181,6 +181,18 @@ __global__ void __launch_bounds__(1024) k_argmax(const half_t *__restrict__ v, s
     }
 }
 
+// B[idx[r]][:] = hfma(A[r][:], w[r], B[idx[r]][:])   (AddByRowIdx_Kernel, src/kernels/binary_tensor_opr.h:80-125)
+__global__ void __launch_bounds__(256) k_add_by_row_index(half_t *__restrict__ B, const half_t *__restrict__ A, int rows, int cols,
+                                                          const int *__restrict__ idx, const half_t *__restrict__ w)
+{
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows || c >= cols) return;
+    const half_t wr = w ? w[r] : (half_t)1.0f;
+    half_t *b = B + (size_t)idx[r] * cols + c;
+    *b = __builtin_fmaf16(A[(size_t)r * cols + c], wr, *b);
+}
+
 } // namespace ifa
 
 using namespace ifa;
@@ -282,6 +294,18 @@ int ifa_argmax(const void *logits, size_t n, int *out_index_dev, ifa_stream stre
     IFA_REQUIRE(logits && out_index_dev, "ifa_argmax: null pointer");
     IFA_REQUIRE(n > 0 && n < 0x7FFFFFFFu, "ifa_argmax: n %zu", n);
     k_argmax<<<dim3(1), dim3(1024), 0, ifa_s(stream)>>>((const half_t *)logits, n, out_index_dev);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_add_by_row_index(void *b_f16, const void *a_f16, size_t rows, size_t cols, const int *row_idx_dev,
+                         const void *weights_f16_dev, ifa_stream stream)
+{
+    IFA_REQUIRE(b_f16 && a_f16 && row_idx_dev, "ifa_add_by_row_index: null pointer");
+    if (rows == 0 || cols == 0) return IFA_OK;
+    IFA_REQUIRE(rows < 65536 && cols < (1u << 30), "ifa_add_by_row_index: shape too large");
+    k_add_by_row_index<<<dim3(ifa_cdiv(cols, 256), (unsigned)rows), dim3(256), 0, ifa_s(stream)>>>(
+        (half_t *)b_f16, (const half_t *)a_f16, (int)rows, (int)cols, row_idx_dev, (const half_t *)weights_f16_dev);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }

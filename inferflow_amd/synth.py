@@ -16,6 +16,9 @@ SHAPES = {
     # small GQA shapes for parity tests
     "test_gqa": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000),
     "test_mha": dict(dim=256, layers=3, heads=8, kv_heads=8, head_dim=32, ffn=640, vocab=777),
+    # Mixtral-8x7B (data/models/mixtral_8x7b_instruct_v0.1) and a small MoE shape for parity tests
+    "mixtral_8x7b": dict(dim=4096, layers=32, heads=32, kv_heads=8, head_dim=128, ffn=14336, vocab=32000, experts=8, moe_top_k=2),
+    "test_moe": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000, experts=4, moe_top_k=2),
 }
 
 MATRICES = [(W.T_WQ, "q"), (W.T_WK, "kv"), (W.T_WV, "kv"), (W.T_WO, "o"), (W.T_W1, "up"), (W.T_W3, "up"), (W.T_W2, "down")]
@@ -44,11 +47,12 @@ def build(shape_name, wdtype=dt.Q4_B32T1A, kv_dtype=dt.F16, max_ctx=1024, quant_
     host = {} if keep_host else None
     dev = "cuda:%d" % device
 
-    def put(layer, tid, target, t16):
+    def put(layer, tid, target, t16, expert=-1):
         rows, cols = (1, t16.numel()) if t16.dim() == 1 else t16.shape
-        wk.set_tensor_f16(layer, tid, target, t16, rows, cols)
+        wk.set_tensor_f16(layer, tid, target, t16, rows, cols, expert=expert)
         if keep_host:
-            host[(layer, tid)] = (target, t16.cpu().view(torch.int16).numpy().view("float16").copy(), rows, cols)
+            key = (layer, tid) if expert < 0 else (layer, tid, expert)
+            host[key] = (target, t16.cpu().view(torch.int16).numpy().view("float16").copy(), rows, cols)
 
     put(-1, W.T_EMBD, dt.F16, gen_f16((s["vocab"], s["dim"]), 999, std, dev))
     put(-1, W.T_OUT_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
@@ -56,11 +60,18 @@ def build(shape_name, wdtype=dt.Q4_B32T1A, kv_dtype=dt.F16, max_ctx=1024, quant_
     for layer in range(s["layers"]):
         put(layer, W.T_ATTN_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
         put(layer, W.T_FFN_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
+        n_exp = s.get("experts", 0)
         for tid, kind in MATRICES:
             rows, cols = _shape(kind, s)
-            t16 = gen_f16((rows, cols), 1000 + layer * 16 + tid, std, dev)
             target = wdtype if rows * cols >= quant_threshold else dt.F16
+            if n_exp and tid in (W.T_W1, W.T_W2, W.T_W3):       # one FFN per expert (ProcessGpuLayer_Moe)
+                for e in range(n_exp):
+                    put(layer, tid, target, gen_f16((rows, cols), 100000 + (layer * 64 + e) * 16 + tid, std, dev), expert=e)
+                continue
+            t16 = gen_f16((rows, cols), 1000 + layer * 16 + tid, std, dev)
             put(layer, tid, target, t16)
+        if n_exp:   # router: always F16 (far below tensor_quant_threshold)
+            put(layer, W.T_MOE_GATE, dt.F16, gen_f16((n_exp, s["dim"]), 1000 + layer * 16 + W.T_MOE_GATE, std, dev))
     wk.finalize()
     return wk, host, s
 

@@ -32,14 +32,15 @@ class DecodeWorker:
         check(lib().ifa_model_create(C.byref(cfg), C.byref(self._h)))
 
     # ---- weights -----------------------------------------------------------
-    def set_tensor(self, layer, tid, dtype, dev_tensor, rows, cols):
-        """dev_tensor: torch cuda tensor holding reference-layout blocks (uint8) or F16 values."""
-        check(lib().ifa_model_set_tensor(self._h, layer, tid, -1, dtype, C.c_void_p(dev_tensor.data_ptr()), rows, cols))
+    def set_tensor(self, layer, tid, dtype, dev_tensor, rows, cols, expert=-1):
+        """dev_tensor: torch cuda tensor holding reference-layout blocks (uint8) or F16 values.
+        expert >= 0: the W1/W2/W3 of one MoE expert of that layer."""
+        check(lib().ifa_model_set_tensor(self._h, layer, tid, expert, dtype, C.c_void_p(dev_tensor.data_ptr()), rows, cols))
 
-    def set_tensor_f16(self, layer, tid, target_dtype, dev_f16, rows=None, cols=None):
+    def set_tensor_f16(self, layer, tid, target_dtype, dev_f16, rows=None, cols=None, expert=-1):
         if rows is None:
             rows, cols = (1, dev_f16.numel()) if dev_f16.dim() == 1 else dev_f16.shape
-        check(lib().ifa_model_set_tensor_f16(self._h, layer, tid, -1, target_dtype,
+        check(lib().ifa_model_set_tensor_f16(self._h, layer, tid, expert, target_dtype,
                                              C.c_void_p(dev_f16.data_ptr()), rows, cols))
 
     def finalize(self):

@@ -314,3 +314,18 @@ def test_gemm_prefill_matches_per_token_oracle(d, T, rows, cols):
     y1 = g.host(g.gemm(d, g.dev(Wq), rows, cols, g.dev(x[:1])))
     y_orc = o.gemv_f16x(d, Wq, rows, cols, x[0])
     assert g.half_ulp_diff(y1[0], y_orc).max() <= 1
+
+
+def test_add_by_row_index_is_a_half_fma_scatter():
+    # AddByRowIdx_Kernel (binary_tensor_opr.h:80-125): B[idx[r]] = hfma(A[r], w[r], B[idx[r]])
+    rng = np.random.default_rng(9)
+    A = rng.normal(0, 1, (5, 300)).astype(np.float16)
+    B = rng.normal(0, 1, (7, 300)).astype(np.float16)
+    idx = np.array([6, 0, 3, 2, 5], np.int32)
+    w = rng.uniform(0, 1, 5).astype(np.float16)
+    Bd = g.dev(B)
+    ia.check(g.capi().ifa_add_by_row_index(g.p(Bd), g.p(g.dev(A)), 5, 300, g.p(g.dev(idx)), g.p(g.dev(w)), g.stream()))
+    expect = B.copy()
+    for r in range(5):   # exact fma in double, one rounding to half
+        expect[idx[r]] = (A[r].astype(np.float64) * float(w[r]) + B[idx[r]].astype(np.float64)).astype(np.float16)
+    assert np.array_equal(g.host(Bd).view(np.uint16), expect.view(np.uint16))
