@@ -155,9 +155,18 @@ def main():
         for i, nm in enumerate(names):
             u = runner.worker.time_kernel(i, 160)
             per_kernel[nm] = {"us": u, "GBps": (kb[i] / u / 1e3) if kb[i] else None}
+        # HBM bytes per launch of that kernel from the PMC pass (rocprofv3 --pmc FETCH_SIZE, own run; summary and
+        # correction in profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py); null for other formats
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if wd == dt.Q4_B32T1A and args.shape == "llama2_7b":
+                traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if k.startswith("ifa::k_dec_gemv<13, 2, 6, 2, 1>")][0]
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "k_dec_gemv<%s, EPI_GLU> (fused RMSNorm+Q8 quant+W1/W3 GEMV+SiLU*mul)" % dt.name(wd),
                            "achieved": ffn13_bytes / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": None,
+                           "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic,
                            "bytes_per_launch": ffn13_bytes, "us_per_launch": us}
         out["kernels"] = per_kernel
     # ---- CPU baseline (oracle port) on a bounded sample
