@@ -584,8 +584,6 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int DG = HD / 8;            // threads covering one V row (8 dims each)
     constexpr int NSPLIT = 256 / DG;      // key residues handled in parallel
-    const int pos = P.state[1];
-    const int n_ctx = pos + 1;
     half_t *qs = reinterpret_cast<half_t *>(smem);                 // [HD] rotated q
     half_t *kn = qs + HD;                                          // [HD] rotated (and Q8 round-tripped) new k
     half_t *vn = kn + HD;                                          // [HD] new v (Q8 round-tripped)
@@ -600,17 +598,33 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
     const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
 
-    // ---- issue the first chunk of K (key = tid) and V loads before anything else
-    constexpr int KW = Q8 ? (HD / 32) * 17 : HD / 2;    // 16-bit-pair words (Q8: 34 B per block) / dwords
+    // ---- issue the first chunk of K (key = tid) and V loads before anything else.  Keys past the context
+    // re-read row `pos` (one row for all of them: no extra traffic, never used) instead of being masked off:
+    // loads under an exec mask make every later wait a vmcnt(0)
+    const int pos = P.state[1];
+    const int n_ctx = pos + 1;
+    // Q8 rows: a head's slice is (HD/32)*34 bytes, 8-byte aligned for HD=128, 4-byte for HD=64, 2-byte for HD=32
+    constexpr int KBYTES = (HD / 32) * 34;
+    constexpr int KALIGN = HD == 128 ? 8 : (HD == 64 ? 4 : 2);
     uint32_t kreg[Q8 ? 1 : HD / 2];
-    uint16_t kreg8[Q8 ? (HD / 32) * 17 : 1];
-    (void)KW;
-    const bool k0_ok = tid < pos;                       // cached rows only; row `pos` comes from LDS
-    if (k0_ok) {
-        const uint8_t *rowp = P.kcache + (size_t)tid * row_bytes + head_off;
+    uint32_t kq32[(Q8 && KALIGN >= 4) ? KBYTES / 4 : 1];
+    uint16_t kq16[(Q8 && KALIGN < 4) ? KBYTES / 2 : 1];
+    auto load_k = [&](int j) {
+        const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
         if constexpr (Q8) {
+            if constexpr (KALIGN == 8) {
 #pragma unroll
-            for (int i = 0; i < (HD / 32) * 17; i++) kreg8[i] = reinterpret_cast<const uint16_t *>(rowp)[i];
+                for (int i = 0; i < KBYTES / 8; i++) {
+                    const u32x2 t = reinterpret_cast<const u32x2 *>(rowp)[i];
+                    kq32[2 * i] = t[0]; kq32[2 * i + 1] = t[1];
+                }
+            } else if constexpr (KALIGN == 4) {
+#pragma unroll
+                for (int i = 0; i < KBYTES / 4; i++) kq32[i] = reinterpret_cast<const uint32_t *>(rowp)[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < KBYTES / 2; i++) kq16[i] = reinterpret_cast<const uint16_t *>(rowp)[i];
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < HD / 8; i++) {
@@ -618,16 +632,28 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
                 kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
             }
         }
-    }
+    };
+    // byte B (compile-time) of the Q8 slice held in registers
+    auto kbyte = [&](int B) -> uint32_t {
+        if constexpr (KALIGN >= 4) return (kq32[B >> 2] >> (8 * (B & 3))) & 0xFFu;
+        else return (kq16[B >> 1] >> (8 * (B & 1))) & 0xFFu;
+    };
+    load_k(min(tid, pos));
     const int dg = tid % DG, sp = tid / DG;
     constexpr int VPRE = 256 / NSPLIT;                  // prefetched V keys per thread: j = sp + NSPLIT*i (256 keys)
     u32x4 vreg[Q8 ? 1 : VPRE];
-    if constexpr (!Q8) {
+    uint16_t vq[Q8 ? VPRE : 1][5];                      // Q8: {scale, 4 x 2 codes} of this thread's 8 dims, 2-byte aligned
+    const size_t vq_off = head_off + (size_t)(dg / 4) * 34;
 #pragma unroll
-        for (int i = 0; i < VPRE; i++) {
-            const int j = sp + NSPLIT * i;
-            vreg[i] = u32x4{0, 0, 0, 0};
-            if (j < pos) vreg[i] = reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg];
+    for (int i = 0; i < VPRE; i++) {
+        const int j = min(sp + NSPLIT * i, pos);
+        if constexpr (!Q8) {
+            vreg[i] = reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg];
+        } else {
+            const uint16_t *blk = reinterpret_cast<const uint16_t *>(P.vcache + (size_t)j * row_bytes + vq_off);
+            vq[i][0] = blk[0];
+#pragma unroll
+            for (int e = 0; e < 4; e++) vq[i][1 + e] = blk[1 + (dg % 4) * 4 + e];
         }
     }
 
@@ -688,27 +714,14 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
 #pragma unroll 8
             for (int d = 0; d < HD; d++) c = __builtin_fmaf(h2f(qs[d]), h2f(kn[d]), c);
         } else {
-            if (j >= 256) {      // later chunks: load now (first chunk was prefetched)
-                const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
-                if constexpr (Q8) {
-#pragma unroll
-                    for (int i = 0; i < (HD / 32) * 17; i++) kreg8[i] = reinterpret_cast<const uint16_t *>(rowp)[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < HD / 8; i++) {
-                        const u32x4 t = reinterpret_cast<const u32x4 *>(rowp)[i];
-                        kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
-                    }
-                }
-            }
+            if (j >= 256) load_k(j);      // later chunks: load now (first chunk was prefetched)
             if constexpr (Q8) {
 #pragma unroll
                 for (int b = 0; b < HD / 32; b++) {
-                    const float sc = hbits2f(kreg8[b * 17]);
+                    const float sc = hbits2f((uint16_t)(kbyte(b * 34) | (kbyte(b * 34 + 1) << 8)));
 #pragma unroll
                     for (int i = 0; i < 32; i++) {
-                        const uint32_t w16 = kreg8[b * 17 + 1 + (i >> 1)];
-                        const int qv = (int)(int8_t)((w16 >> ((i & 1) * 8)) & 0xFF);
+                        const int qv = (int)(int8_t)kbyte(b * 34 + 2 + i);
                         const float kvv = h2f(f2h((float)qv * sc));
                         c = __builtin_fmaf(h2f(qs[b * 32 + i]), kvv, c);
                     }
@@ -772,8 +785,14 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
         if (j < n_ctx) {
             const float pj = h2f(S[j]);
             if (j == pos) acc_new(pj);
-            else if constexpr (Q8) acc_q8(pj, j);
-            else acc_v(pj, vreg[i]);
+            else if constexpr (Q8) {
+                const float sc = hbits2f(vq[i][0]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int qv = (int)(int8_t)((vq[i][1 + (e >> 1)] >> (8 * (e & 1))) & 0xFF);
+                    o[e] = __builtin_fmaf(pj, h2f(f2h((float)qv * sc)), o[e]);
+                }
+            } else acc_v(pj, vreg[i]);
         }
     }
     for (int j = sp + NSPLIT * VPRE; j < n_ctx; j += NSPLIT) {
