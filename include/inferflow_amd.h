@@ -240,13 +240,14 @@ int ifa_model_set_stream(ifa_model *m, ifa_stream stream);
  * caller sums the two partial [dim] F16 vectors per layer over the group exactly where the
  * reference calls DistributeAndMergeTensors (inference_worker.cc:1378-1391, :1882-1895).
  * All calls only enqueue work on the worker's stream.
- *   begin(token,pos)            token < 0: use the id already in the device state
+ *   begin(token,pos)            token < 0 / pos < 0: keep the id / position already in the device state
  *   attn(l, partial)            norm + QKV + attention + Wo product (no bias/residual)
  *   post_attn(l, reduced)       + bias, + residual
  *   ffn(l, partial)             norm + W1/W3 + act + W2 product
  *   post_ffn(l, reduced)        + bias, + residual -> next layer input
  *   logits(shard_out)           final norm + this rank's vocabulary rows of lm_head
- *   set_token(dev_ptr)          next token id from device memory (after the distributed argmax) */
+ *   set_token(dev_ptr)          next token id from device memory (after the distributed argmax); advances the
+ *                               device-side position, so begin(-1,-1) ... set_token() is replayable as a hipGraph */
 int ifa_model_tp_begin(ifa_model *m, int token, int pos);
 int ifa_model_tp_attn(ifa_model *m, int layer, void *partial_out_f16);
 int ifa_model_tp_post_attn(ifa_model *m, int layer, const void *reduced_f16);

@@ -848,7 +848,15 @@ int ifa_model_set_stream(ifa_model *m, ifa_stream stream)
 __global__ void k_tp_set_state(int *state, int token, int pos)
 {
     if (token >= 0) state[0] = token;
-    state[1] = pos;
+    if (pos >= 0) state[1] = pos;
+}
+
+// the step's token (chosen across the group) becomes the next input; the position advances on the device
+// so that a captured step can be replayed (hipGraph) without the host
+__global__ void k_tp_set_token(int *state, const int *token)
+{
+    state[0] = *token;
+    state[1] = state[1] + 1;
 }
 
 static int tp_ready(ifa_model *m)
@@ -864,7 +872,7 @@ int ifa_model_tp_begin(ifa_model *m, int token, int pos)
 {
     int rc = tp_ready(m);
     if (rc) return rc;
-    IFA_REQUIRE(pos >= 0 && pos < m->cfg.max_ctx, "ifa_model_tp_begin: position %d outside max_ctx %d", pos, m->cfg.max_ctx);
+    IFA_REQUIRE(pos >= -1 && pos < m->cfg.max_ctx, "ifa_model_tp_begin: position %d outside max_ctx %d", pos, m->cfg.max_ctx);
     const ifa_model_config &c = m->cfg;
     k_tp_set_state<<<1, 1, 0, m->stream>>>(m->state, token, pos);     // token < 0: keep the id already on the device
     k_dec_gather<<<dim3(2), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows,
@@ -928,7 +936,8 @@ int ifa_model_tp_logits(ifa_model *m, void *logits_shard_out_f16)
 int ifa_model_tp_set_token(ifa_model *m, const int *token_dev)
 {
     IFA_REQUIRE(m && token_dev, "ifa_model_tp_set_token: bad arguments");
-    IFA_HIP_CHECK(hipMemcpyAsync(m->state, token_dev, sizeof(int), hipMemcpyDeviceToDevice, m->stream));
+    k_tp_set_token<<<1, 1, 0, m->stream>>>(m->state, token_dev);
+    IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
 

@@ -101,9 +101,14 @@ class TPRunner:
             raise RuntimeError("fused decode path unavailable on rank %d: %s" % (rank, why))
         dev = "cuda:%d" % local_rank
         self.dev = dev
-        # the worker enqueues on torch's current stream so that its kernels and the
-        # collectives are ordered without extra events
-        self.worker.set_stream(torch.cuda.current_stream().cuda_stream)
+        # the worker enqueues on the same (side) stream as the collectives, so that they are ordered without
+        # extra events and a whole step can be captured into one hipGraph
+        self.stream = torch.cuda.Stream(device=dev)
+        self.worker.set_stream(self.stream.cuda_stream)
+        self.graph = None
+        # capturable collectives exist on the nccl (= RCCL) backend only; gloo (CPU tests) stays eager
+        self.use_graph = os.environ.get("IFA_TP_GRAPH", "1") != "0" and (
+            not dist.is_initialized() or dist.get_backend(group) == "nccl")
         d, vs = self.shape["dim"], self.shape["vocab"] // world
         self.buf_a = torch.zeros(d, dtype=torch.float16, device=dev)
         self.buf_f = torch.zeros(d, dtype=torch.float16, device=dev)
@@ -112,13 +117,19 @@ class TPRunner:
         self.gathered = torch.zeros(world * 2, dtype=torch.float32, device=dev)
         self.tok_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.vs = vs
+        self._rank_off = torch.tensor(float(rank * vs), dtype=torch.float32, device=dev)
+        self._big = torch.tensor(3.0e9, dtype=torch.float32, device=dev)
 
     def _all_reduce(self, t):
         if self.world > 1 or self.force_collectives:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self, token, pos):
-        """One decode step; `token` < 0 reuses the id produced by the previous step on the device."""
+        """One decode step; `token` < 0 / `pos` < 0 reuse the id / position held in the device state."""
+        with torch.cuda.stream(self.stream):
+            return self._step_body(token, pos)
+
+    def _step_body(self, token, pos):
         wk = self.worker
         wk.tp_begin(token, pos)
         for l in range(self.shape["layers"]):
@@ -132,7 +143,7 @@ class TPRunner:
         # distributed greedy argmax: (max value, global index) per rank, first maximum wins
         v, i = torch.max(self.logits.float(), dim=0)
         self.best[0] = v
-        self.best[1] = (i + self.rank * self.vs).float()
+        self.best[1] = i.float() + self._rank_off
         if self.world > 1:
             parts = list(self.gathered.view(self.world, 2).unbind(0))
             dist.all_gather(parts, self.best, group=self.group)
@@ -140,7 +151,7 @@ class TPRunner:
         else:
             g = self.best.view(1, 2)
         top = g[:, 0].max()
-        cand = torch.where(g[:, 0] == top, g[:, 1], torch.full_like(g[:, 1], 3.0e9))
+        cand = torch.where(g[:, 0] == top, g[:, 1], self._big)
         self.tok_dev[0] = cand.min().to(torch.int32)
         wk.tp_set_token(self.tok_dev)
         return self.tok_dev
@@ -152,18 +163,54 @@ class TPRunner:
             tok = self.step(int(t), i)
         return int(tok.item())
 
+    def _capture(self):
+        """One whole step (worker kernels + RCCL collectives + distributed argmax) as a hipGraph that reads
+        and advances the token / position in device memory.  Any failure leaves the eager path in place."""
+        import sys
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                tok = self._step_body(-1, -1)
+                self.ring.index_copy_(0, self.ring_pos, tok)
+                self.ring_pos.add_(1)
+            torch.cuda.synchronize()
+            self.graph = g
+        except Exception as e:       # keep going eagerly: correctness does not depend on the graph
+            print("inferflow_amd.tp: step capture unavailable (%r); running eager steps" % (e,), file=sys.stderr)
+            self.graph = None
+            self.use_graph = False
+            torch.cuda.synchronize()
+
     def decode(self, tok, pos, n):
-        out = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        if not hasattr(self, "ring") or self.ring.numel() < n:
+            self.ring = torch.zeros(max(n, 1024), dtype=torch.int32, device=self.dev)
+            self.ring_pos = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.graph = None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        t = self.step(int(tok), pos)
-        out[0] = t[0]
-        for i in range(1, n):
-            t = self.step(-1, pos + i)
-            out[i] = t[0]
-        e1.record()
+        with torch.cuda.stream(self.stream):
+            self.ring_pos.zero_()
+            # the state (token, position) is seeded by one eager step; the rest replays the captured step
+            t = self._step_body(int(tok), pos)
+            self.ring.index_copy_(0, self.ring_pos, t)
+            self.ring_pos.add_(1)
+        if n > 1 and self.use_graph and self.graph is None:
+            # the capture itself executes nothing, but it runs after the eager step above has created every
+            # communicator / workspace the collectives need
+            self._capture()
+        with torch.cuda.stream(self.stream):
+            e0.record(self.stream)
+            for i in range(1, n):
+                if self.graph is not None:
+                    self.graph.replay()
+                else:
+                    t = self._step_body(-1, pos + i)
+                    self.ring.index_copy_(0, self.ring_pos, t)
+                    self.ring_pos.add_(1)
+            e1.record(self.stream)
         torch.cuda.synchronize()
-        return [int(x) for x in out.cpu().numpy()], e0.elapsed_time(e1)
+        ms = e0.elapsed_time(e1) if n > 1 else 0.0
+        return [int(x) for x in self.ring[:n].cpu().numpy()], ms
 
     def export_host_tensors(self):
         raise NotImplementedError("CPU baseline runs on the single-worker runner only")
