@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--shape", default="llama2_7b")
     ap.add_argument("--wdtype", default="q4", help="weight format: q4 (Q4_B32T1A, the headline config), q3h, q8, q4_b64, q5, q6")
     ap.add_argument("--kv-dtype", default="f16", help="KV cache: f16 or q8 (configs[2] = --wdtype q3h --kv-dtype q8)")
+    ap.add_argument("--groups", type=int, default=1, help="device groups (layer ranges) of the HYBRID partition; "
+                    "gpus // groups ranks per group are tensor-parallel (default 1 = pure tensor parallelism)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     args = ap.parse_args()
@@ -83,7 +85,7 @@ def main():
     steps, warmup = args.steps, args.warmup
     max_ctx = PROMPT_LEN + warmup + steps + 8
     t_build = time.perf_counter()
-    runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank)
+    runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank, groups=args.groups)
     t_build = time.perf_counter() - t_build
 
     rng = np.random.default_rng(42)
@@ -132,7 +134,8 @@ def main():
         "config": {"workload": "%s decode, %s weights + F16 lm_head, %s KV cache, batch 1 greedy, "
                                "%d-token prompt, context %d..%d" % (args.shape, dt.name(wd), dt.name(kvd), PROMPT_LEN,
                                                                   PROMPT_LEN + warmup, PROMPT_LEN + warmup + steps),
-                   "parallelism": "tp%d" % world if world > 1 else "single", "weights_bytes": w_bytes,
+                   "parallelism": ("single" if world == 1 else "tp%d" % world if args.groups == 1
+                                   else "hybrid: %d layer groups x tp%d" % (args.groups, world // args.groups)), "weights_bytes": w_bytes,
                    "bytes_per_token": bytes_per_token},
         "gpu_event_ms_per_step": gpu_ms / steps if gpu_ms and gpu_ms > 0 else None,
         "token_hbm_GBps": bytes_per_token * tok_s / 1e9,

@@ -249,6 +249,13 @@ int ifa_model_set_stream(ifa_model *m, ifa_stream stream);
  *   set_token(dev_ptr)          next token id from device memory (after the distributed argmax); advances the
  *                               device-side position, so begin(-1,-1) ... set_token() is replayable as a hipGraph */
 int ifa_model_tp_begin(ifa_model *m, int token, int pos);
+/* BY_LAYER / HYBRID partition (MultiGpuStrategy, src/transformer/model.h:61-66; layer ranges per device group:
+ * NetworkBuilder::SplitGpuLayers, network_builder.cc:2094-2118): a worker that holds a layer range only starts its
+ * step from the previous group's output instead of an embedding row, and hands its last layer's output on.
+ *   begin_hidden(x, pos)   layer input from device memory ([dim] F16); pos < 0 keeps the device-side position
+ *   hidden(x_out)          copy of the current layer input/output vector (after the last local layer) */
+int ifa_model_tp_begin_hidden(ifa_model *m, const void *x_f16, int pos);
+int ifa_model_tp_hidden(ifa_model *m, void *x_out_f16);
 int ifa_model_tp_attn(ifa_model *m, int layer, void *partial_out_f16);
 int ifa_model_tp_post_attn(ifa_model *m, int layer, const void *reduced_f16);
 int ifa_model_tp_ffn(ifa_model *m, int layer, void *partial_out_f16);

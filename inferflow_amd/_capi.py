@@ -96,6 +96,8 @@ SIGNATURES = {
     "ifa_model_time_kernel": (_i, [_vp, _i, _i, _vp]),
     "ifa_model_set_stream": (_i, [_vp, _vp]),
     "ifa_model_tp_begin": (_i, [_vp, _i, _i]),
+    "ifa_model_tp_begin_hidden": (_i, [_vp, _vp, _i]),
+    "ifa_model_tp_hidden": (_i, [_vp, _vp]),
     "ifa_model_tp_attn": (_i, [_vp, _i, _vp]),
     "ifa_model_tp_post_attn": (_i, [_vp, _i, _vp]),
     "ifa_model_tp_ffn": (_i, [_vp, _i, _vp]),

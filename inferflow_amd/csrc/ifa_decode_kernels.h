@@ -827,10 +827,12 @@ static __global__ void __launch_bounds__(256) k_dec_gather(const half_t *__restr
                                                     float *__restrict__ rope_tab, int head_dim, float theta,
                                                     int rope_dims)
 {
-    int tok = state[0];
-    tok = min(max(tok, 0), vocab - 1);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim / 8; c += gridDim.x * blockDim.x)
-        reinterpret_cast<u32x4 *>(x)[c] = reinterpret_cast<const u32x4 *>(embd + (size_t)tok * dim)[c];
+    if (embd) {      // null: the layer input arrives from the previous pipeline stage, only the RoPE table is needed
+        int tok = state[0];
+        tok = min(max(tok, 0), vocab - 1);
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim / 8; c += gridDim.x * blockDim.x)
+            reinterpret_cast<u32x4 *>(x)[c] = reinterpret_cast<const u32x4 *>(embd + (size_t)tok * dim)[c];
+    }
     if (blockIdx.x == 0 && rope_tab) {
         const int pos = state[1];
         for (int c = threadIdx.x; c < head_dim / 2; c += blockDim.x) {

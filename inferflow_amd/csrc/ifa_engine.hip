@@ -163,13 +163,14 @@ static bool fused_supported(const ifa_model *m, std::string *why)
         if (!same_fmt(L.t[T_WQ].dtype, L.t[T_WK].dtype) || !same_fmt(L.t[T_WQ].dtype, L.t[T_WV].dtype)) return fail("wq/wk/wv dtype mismatch");
     }
     const Tensor &lm = m->g[T_LM_HEAD];
-    if (!lm.present()) return fail("lm_head missing");
-    if (lm.dtype == F16) {
+    // a pipeline stage (BY_LAYER partition) may hold neither embeddings nor lm_head: checked where they are used
+    if (!lm.present()) { /* middle / first stage */ }
+    else if (lm.dtype == F16) {
         if (lm.cols > 4096 || lm.cols % 8 != 0) return fail("fused F16 lm_head needs cols <= 4096");
     } else if (!lm.tiled || !dec_gemv_supported(lm.dtype, lm.cols) || !m->g[T_OUT_NORM].present()) {
         return fail("fused lm_head needs F16 or an int8-GEMV weight format (with an output norm)");
     }
-    if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return fail("F16 embeddings required");
+    if (m->g[T_EMBD].present() && m->g[T_EMBD].dtype != F16) return fail("F16 embeddings required");
     return true;
 }
 
@@ -764,6 +765,7 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     IFA_REQUIRE(n_steps > 0 && n_steps <= ifa_model::RING, "ifa_model_decode: n_steps %d (max %d per call)", n_steps, ifa_model::RING);
     IFA_REQUIRE(start_pos >= 0 && start_pos + n_steps <= m->cfg.max_ctx, "ifa_model_decode: positions [%d,%d) exceed max_ctx %d",
                 start_pos, start_pos + n_steps, m->cfg.max_ctx);
+    IFA_REQUIRE(m->g[T_EMBD].present() && m->g[T_LM_HEAD].present(), "ifa_model_decode: embeddings / lm_head missing (pipeline stage worker)");
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
     if (!m->opt_fused || !fused_supported(m, &why)) {
@@ -873,12 +875,35 @@ int ifa_model_tp_begin(ifa_model *m, int token, int pos)
     int rc = tp_ready(m);
     if (rc) return rc;
     IFA_REQUIRE(pos >= -1 && pos < m->cfg.max_ctx, "ifa_model_tp_begin: position %d outside max_ctx %d", pos, m->cfg.max_ctx);
+    IFA_REQUIRE(m->g[T_EMBD].present(), "ifa_model_tp_begin: this worker holds no embeddings (use ifa_model_tp_begin_hidden)");
     const ifa_model_config &c = m->cfg;
     k_tp_set_state<<<1, 1, 0, m->stream>>>(m->state, token, pos);     // token < 0: keep the id already on the device
     k_dec_gather<<<dim3(2), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows,
                                                        m->x, c.rope_order ? m->rope_tab : nullptr, c.head_dim, c.rope_theta,
                                                        (int)(c.head_dim * c.partial_rotary + 0.5f));
     IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_model_tp_begin_hidden(ifa_model *m, const void *x_f16, int pos)
+{
+    int rc = tp_ready(m);
+    if (rc) return rc;
+    IFA_REQUIRE(x_f16, "ifa_model_tp_begin_hidden: null input");
+    IFA_REQUIRE(pos >= -1 && pos < m->cfg.max_ctx, "ifa_model_tp_begin_hidden: position %d outside max_ctx %d", pos, m->cfg.max_ctx);
+    const ifa_model_config &c = m->cfg;
+    IFA_HIP_CHECK(hipMemcpyAsync(m->x, x_f16, (size_t)c.dim * 2, hipMemcpyDeviceToDevice, m->stream));
+    k_tp_set_state<<<1, 1, 0, m->stream>>>(m->state, -1, pos);
+    k_dec_gather<<<dim3(1), dim3(256), 0, m->stream>>>(nullptr, m->state, c.dim, 1, m->x, c.rope_order ? m->rope_tab : nullptr,
+                                                       c.head_dim, c.rope_theta, (int)(c.head_dim * c.partial_rotary + 0.5f));
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_model_tp_hidden(ifa_model *m, void *x_out_f16)
+{
+    IFA_REQUIRE(m && m->finalized && x_out_f16, "ifa_model_tp_hidden: bad arguments");
+    IFA_HIP_CHECK(hipMemcpyAsync(x_out_f16, m->x, (size_t)m->cfg.dim * 2, hipMemcpyDeviceToDevice, m->stream));
     return IFA_OK;
 }
 
@@ -930,6 +955,7 @@ int ifa_model_tp_post_ffn(ifa_model *m, int layer, const void *reduced_f16)
 int ifa_model_tp_logits(ifa_model *m, void *logits_shard_out_f16)
 {
     IFA_REQUIRE(m && logits_shard_out_f16, "ifa_model_tp_logits: bad arguments");
+    IFA_REQUIRE(m->g[T_LM_HEAD].present(), "ifa_model_tp_logits: this worker holds no lm_head (not the last pipeline stage)");
     return launch_lm(m, m->x, (half_t *)logits_shard_out_f16);
 }
 

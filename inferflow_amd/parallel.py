@@ -42,9 +42,10 @@ class SingleRunner:
         return host
 
 
-def build_runner(shape_name, wdtype, kv_dtype, max_ctx, world=1, rank=0, local_rank=0):
+def build_runner(shape_name, wdtype, kv_dtype, max_ctx, world=1, rank=0, local_rank=0, groups=1):
+    """groups = number of device groups (layer ranges); world // groups ranks per group are tensor-parallel."""
     import os
     if world == 1 and not os.environ.get("IFA_FORCE_TP"):
         return SingleRunner(shape_name, wdtype, kv_dtype, max_ctx, device=local_rank)
     from .tp import TPRunner
-    return TPRunner(shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank)
+    return TPRunner(shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank, groups=groups)

@@ -13,6 +13,13 @@ Partition = the reference's BY_TENSOR strategy
 Exchange = two sum all-reduces of one [dim] F16 vector per layer (after wo, after w2),
 exactly where the reference calls DistributeAndMergeTensors.  At batch-1 decode the
 payload is 8 KB, i.e. latency-bound.
+
+HYBRID / BY_LAYER (MultiGpuStrategy, src/transformer/model.h:61-66): `groups` device groups each own a
+contiguous layer range (NetworkBuilder::SplitGpuLayers, network_builder.cc:2094-2118: ceil(L/G) layers per
+group, the last group takes the rest); inside a group the layers are tensor-parallel as above.  rank =
+group * group_size + tp_rank, the reference's "devices = 0&1;2&3" order.  The [dim] F16 layer output goes
+to the same tp_rank of the next group with a send/recv pair (the reference's DeviceCopy between workers,
+inference_worker.cc:2300-2335); the last group owns the lm_head and broadcasts the chosen token.
 """
 import numpy as np
 import torch
@@ -43,6 +50,19 @@ def shard_shape(shape, world):
     return s
 
 
+def split_layers(n_layers, groups):
+    """[(start, end)] per device group, NetworkBuilder::SplitGpuLayers (network_builder.cc:2094-2118);
+    groups that would be empty are dropped like the reference does."""
+    per = (n_layers + groups - 1) // groups
+    out = []
+    for g in range(groups):
+        start = g * per
+        end = n_layers if g + 1 == groups else min((g + 1) * per, n_layers)   # (the reference does not clamp: it
+        if end > start:                                                        #  assumes groups divide the layers)
+            out.append((start, end))
+    return out
+
+
 def slice_tensor(tid, full, rank, world):
     """full: 2-D tensor/array [rows][cols] of one weight; returns this rank's slice (a view)."""
     rows, cols = full.shape
@@ -55,11 +75,16 @@ def slice_tensor(tid, full, rank, world):
     return full
 
 
-def build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank, device=0, std=0.02, **overrides):
+def build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank, device=0, std=0.02, layer_range=None,
+                    first_stage=True, last_stage=True, **overrides):
+    """world / rank: size of and position in the TENSOR-parallel group.  layer_range (start, end): the
+    global layers this worker holds (BY_LAYER / HYBRID); the worker numbers them 0..n-1 locally."""
     full = dict(synth.SHAPES[shape_name])
     full.update({k: v for k, v in overrides.items() if k in full})
     check_divisible(full, world)
     s = shard_shape(full, world)
+    l0, l1 = layer_range if layer_range is not None else (0, full["layers"])
+    s["layers"] = l1 - l0
     wk = W.DecodeWorker(max_ctx=max_ctx, kv_dtype=kv_dtype, device=device, tp_rank=rank, tp_size=world, **s)
     dev = "cuda:%d" % device
 
@@ -68,19 +93,21 @@ def build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank, device=0
         rows, cols = (1, t16.numel()) if t16.dim() == 1 else t16.shape
         wk.set_tensor_f16(layer, tid, target, t16, rows, cols)
 
-    put(-1, W.T_EMBD, dt.F16, synth.gen_f16((full["vocab"], full["dim"]), 999, std, dev))
-    put(-1, W.T_OUT_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
-    lm = synth.gen_f16((full["vocab"], full["dim"]), 998, std, dev)
-    vs = full["vocab"] // world
-    put(-1, W.T_LM_HEAD, dt.F16, lm[rank * vs:(rank + 1) * vs])
-    del lm
-    for layer in range(full["layers"]):
-        put(layer, W.T_ATTN_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
-        put(layer, W.T_FFN_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
+    if first_stage:
+        put(-1, W.T_EMBD, dt.F16, synth.gen_f16((full["vocab"], full["dim"]), 999, std, dev))
+    if last_stage:
+        put(-1, W.T_OUT_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
+        lm = synth.gen_f16((full["vocab"], full["dim"]), 998, std, dev)
+        vs = full["vocab"] // world
+        put(-1, W.T_LM_HEAD, dt.F16, lm[rank * vs:(rank + 1) * vs])
+        del lm
+    for layer in range(l0, l1):
+        put(layer - l0, W.T_ATTN_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
+        put(layer - l0, W.T_FFN_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
         for tid, kind in synth.MATRICES:
             rows, cols = synth._shape(kind, full)
             t16 = synth.gen_f16((rows, cols), 1000 + layer * 16 + tid, std, dev)   # same stream of values as N=1
-            put(layer, tid, wdtype, slice_tensor(tid, t16, rank, world))
+            put(layer - l0, tid, wdtype, slice_tensor(tid, t16, rank, world))
     wk.finalize()
     return wk, full, s
 
@@ -88,14 +115,38 @@ def build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank, device=0
 class TPRunner:
     """Greedy batch-1 decode over a tensor-parallel group (all ranks call the same methods)."""
 
-    def __init__(self, shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank, group=None, **overrides):
+    def __init__(self, shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank, group=None, groups=1, **overrides):
+        """world / rank: all processes of the job.  groups > 1: HYBRID partition, `groups` layer ranges of
+        world // groups tensor-parallel ranks each (every rank must construct the runner: new_group is collective)."""
         import os
+        if world % groups:
+            raise ValueError("world size %d is not a multiple of the number of device groups %d" % (world, groups))
+        n_layers = dict(synth.SHAPES[shape_name], **{k: v for k, v in overrides.items() if k == "layers"})["layers"]
+        ranges = split_layers(n_layers, groups)
+        groups = len(ranges)
+        self.job_world, self.job_rank = world, rank
+        self.n_stages, self.stage = groups, 0
+        self.layer_range = (0, n_layers)
+        if groups > 1:
+            tp_size = world // groups
+            self.stage, tp_rank = rank // tp_size, rank % tp_size
+            my_group = None
+            for g in range(groups):            # collective: every rank creates every group, in the same order
+                pg = dist.new_group(list(range(g * tp_size, (g + 1) * tp_size))) if tp_size > 1 else None
+                if g == self.stage:
+                    my_group = pg
+            self.layer_range = ranges[self.stage]
+            self.prev_rank = rank - tp_size if self.stage > 0 else None
+            self.next_rank = rank + tp_size if self.stage + 1 < groups else None
+            self.token_src = (groups - 1) * tp_size          # first rank of the last group announces the token
+            world, rank, group = tp_size, tp_rank, my_group
         self.world, self.rank, self.group = world, rank, group
         # IFA_FORCE_TP=1 with one rank: still issue the collectives (plumbing check on a 1-GPU box)
         self.force_collectives = bool(os.environ.get("IFA_FORCE_TP")) and dist.is_initialized()
         self.worker = None
-        self.worker, self.shape, self.local_shape = build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank,
-                                                                    device=local_rank, **overrides)
+        self.worker, self.shape, self.local_shape = build_tp_worker(
+            shape_name, wdtype, kv_dtype, max_ctx, world, rank, device=local_rank, layer_range=self.layer_range,
+            first_stage=self.stage == 0, last_stage=self.stage == self.n_stages - 1, **overrides)
         ok, why = self.worker.fused_supported()
         if not ok:
             raise RuntimeError("fused decode path unavailable on rank %d: %s" % (rank, why))
@@ -107,8 +158,9 @@ class TPRunner:
         self.worker.set_stream(self.stream.cuda_stream)
         self.graph = None
         # capturable collectives exist on the nccl (= RCCL) backend only; gloo (CPU tests) stays eager
-        self.use_graph = os.environ.get("IFA_TP_GRAPH", "1") != "0" and (
+        self.use_graph = os.environ.get("IFA_TP_GRAPH", "1") != "0" and self.n_stages == 1 and (
             not dist.is_initialized() or dist.get_backend(group) == "nccl")
+        self.hidden = torch.zeros(self.shape["dim"], dtype=torch.float16, device=dev)   # stage-to-stage layer output
         d, vs = self.shape["dim"], self.shape["vocab"] // world
         self.buf_a = torch.zeros(d, dtype=torch.float16, device=dev)
         self.buf_f = torch.zeros(d, dtype=torch.float16, device=dev)
@@ -119,6 +171,21 @@ class TPRunner:
         self.vs = vs
         self._rank_off = torch.tensor(float(rank * vs), dtype=torch.float32, device=dev)
         self._big = torch.tensor(3.0e9, dtype=torch.float32, device=dev)
+
+    # gloo (CPU / single-GPU tests) has no device send/recv: stage through the host there
+    def _send(self, t, dst):
+        if dist.get_backend() == "nccl":
+            dist.send(t, dst=dst)
+        else:
+            dist.send(t.cpu(), dst=dst)
+
+    def _recv(self, t, src):
+        if dist.get_backend() == "nccl":
+            dist.recv(t, src=src)
+        else:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            dist.recv(h, src=src)
+            t.copy_(h)
 
     def _all_reduce(self, t):
         if self.world > 1 or self.force_collectives:
@@ -131,14 +198,25 @@ class TPRunner:
 
     def _step_body(self, token, pos):
         wk = self.worker
-        wk.tp_begin(token, pos)
-        for l in range(self.shape["layers"]):
+        if self.stage == 0:
+            wk.tp_begin(token, pos)
+        else:
+            self._recv(self.hidden, self.prev_rank)
+            wk.tp_begin_hidden(self.hidden, pos)
+        for l in range(self.layer_range[1] - self.layer_range[0]):
             wk.tp_attn(l, self.buf_a)
             self._all_reduce(self.buf_a)
             wk.tp_post_attn(l, self.buf_a)
             wk.tp_ffn(l, self.buf_f)
             self._all_reduce(self.buf_f)
             wk.tp_post_ffn(l, self.buf_f)
+        if self.n_stages > 1:
+            if self.next_rank is not None:         # not the last group: hand the layer output on, then wait for the token
+                wk.tp_hidden(self.hidden)
+                self._send(self.hidden, self.next_rank)
+                dist.broadcast(self.tok_dev, src=self.token_src)
+                wk.tp_set_token(self.tok_dev)
+                return self.tok_dev
         wk.tp_logits(self.logits)
         # distributed greedy argmax: (max value, global index) per rank, first maximum wins
         v, i = torch.max(self.logits.float(), dim=0)
@@ -153,6 +231,8 @@ class TPRunner:
         top = g[:, 0].max()
         cand = torch.where(g[:, 0] == top, g[:, 1], self._big)
         self.tok_dev[0] = cand.min().to(torch.int32)
+        if self.n_stages > 1:
+            dist.broadcast(self.tok_dev, src=self.token_src)
         wk.tp_set_token(self.tok_dev)
         return self.tok_dev
 

@@ -103,6 +103,12 @@ class DecodeWorker:
     def tp_begin(self, token, pos):
         check(lib().ifa_model_tp_begin(self._h, int(token), int(pos)))
 
+    def tp_begin_hidden(self, x_dev_f16, pos):
+        check(lib().ifa_model_tp_begin_hidden(self._h, C.c_void_p(x_dev_f16.data_ptr()), int(pos)))
+
+    def tp_hidden(self, x_out_dev_f16):
+        check(lib().ifa_model_tp_hidden(self._h, C.c_void_p(x_out_dev_f16.data_ptr())))
+
     def tp_attn(self, layer, partial):
         check(lib().ifa_model_tp_attn(self._h, layer, C.c_void_p(partial.data_ptr())))
 

@@ -33,38 +33,80 @@ def test_tp_world1_equals_fused_decode():
     assert ms > 0
 
 
-def _rank_main(rank, world, port, q):
+def _rank_main(rank, world, port, q, groups=1, n_decode=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    r = tp.TPRunner("test_gqa", dt.Q4_B32T1A, dt.F16, 32, world, rank, 0, std=0.06)
+    r = tp.TPRunner("test_gqa", dt.Q4_B32T1A, dt.F16, 32, world, rank, 0, std=0.06, groups=groups)
+    tok = None
     for i, t in enumerate(PROMPT):
-        r.step(int(t), i)
+        tok = r.step(int(t), i)
     torch.cuda.synchronize()
-    shards = [torch.zeros_like(r.logits) for _ in range(world)]
-    dist.all_gather(shards, r.logits)
+    toks, first = [], int(tok.item())        # (tok aliases the runner's device token: read it before decoding)
+    if n_decode:
+        toks, _ = r.decode(first, len(PROMPT), n_decode)
+    # the last device group holds the lm_head shards; gather them in tp_rank order on rank 0
+    vs = r.logits.numel()
+    mine = r.logits if r.stage == r.n_stages - 1 else torch.zeros_like(r.logits)
+    shards = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(shards, mine)
     if rank == 0:
-        q.put(torch.cat(shards).float().cpu().numpy())
+        tp_size = world // r.n_stages
+        last = shards[(r.n_stages - 1) * tp_size:]
+        q.put((torch.cat(last).float().cpu().numpy(), [int(t) for t in toks], first))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
         q.close(); q.join_thread()
 
 
-def test_tp_world2_matches_single_device_logits():
-    world = 2
+def _run_ranks(world, groups=1, n_decode=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400)
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 400) + 7 * groups + world
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, groups, n_decode)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=180)
         assert p.exitcode == 0, "rank process failed (exit code %r)" % (p.exitcode,)
-    lg_tp = q.get(timeout=10)
+    return q.get(timeout=10)
+
+
+def test_by_layer_world2_is_identical_to_one_device():
+    """BY_LAYER partition (2 device groups of 1): same kernels on the same numbers, only the [dim] F16 layer
+    output crosses the group boundary -> logits and greedy tokens are bit-identical to the single worker."""
+    lg_pp, toks_pp, first_pp = _run_ranks(2, groups=2, n_decode=6)
+    single = tp.TPRunner("test_gqa", dt.Q4_B32T1A, dt.F16, 32, 1, 0, 0, std=0.06)
+    tok = None
+    for i, t in enumerate(PROMPT):
+        tok = single.step(int(t), i)
+    torch.cuda.synchronize()
+    first_1 = int(tok.item())
+    assert first_1 == first_pp
+    toks_1, _ = single.decode(first_1, len(PROMPT), 6)
+    assert toks_pp == toks_1
+    # (logits after the decode steps: same state on both sides)
+    assert np.array_equal(lg_pp, single.logits.float().cpu().numpy())
+
+
+def test_hybrid_2x2_matches_single_device_logits():
+    """HYBRID: 2 device groups (layer ranges) x 2 tensor-parallel ranks, 4 processes on one GPU."""
+    lg_h, _, _ = _run_ranks(4, groups=2)
+    single = tp.TPRunner("test_gqa", dt.Q4_B32T1A, dt.F16, 32, 1, 0, 0, std=0.06)
+    for i, t in enumerate(PROMPT):
+        single.step(int(t), i)
+    torch.cuda.synchronize()
+    lg_1 = single.logits.float().cpu().numpy()
+    cos = float((lg_h * lg_1).sum() / (np.linalg.norm(lg_h) * np.linalg.norm(lg_1)))
+    tol = 0.02 * float(np.abs(lg_1).max()) + 0.02
+    assert cos >= 0.9995 and np.abs(lg_h - lg_1).max() <= tol, (cos, np.abs(lg_h - lg_1).max(), tol)
+
+
+def test_tp_world2_matches_single_device_logits():
+    lg_tp, _, _ = _run_ranks(2)
     single = tp.TPRunner("test_gqa", dt.Q4_B32T1A, dt.F16, 32, 1, 0, 0, std=0.06)
     for i, t in enumerate(PROMPT):
         single.step(int(t), i)

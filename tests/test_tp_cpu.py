@@ -76,3 +76,18 @@ def test_divisibility_rules():
         tp.check_divisible(dict(synth.SHAPES["llama2_7b"], kv_heads=4), 8)
     s = tp.shard_shape(synth.SHAPES["llama2_7b"], 8)
     assert (s["heads"], s["kv_heads"], s["ffn"]) == (4, 4, 1376)
+
+
+def test_split_layers_follows_the_reference_rule():
+    # NetworkBuilder::SplitGpuLayers (network_builder.cc:2094-2118): ceil(L/G) per group, last group takes the rest,
+    # empty groups dropped
+    from inferflow_amd import tp
+    assert tp.split_layers(32, 1) == [(0, 32)]
+    assert tp.split_layers(32, 2) == [(0, 16), (16, 32)]
+    assert tp.split_layers(60, 8) == [(0, 8), (8, 16), (16, 24), (24, 32), (32, 40), (40, 48), (48, 56), (56, 60)]
+    assert tp.split_layers(6, 4) == [(0, 2), (2, 4), (4, 6)]        # 4th group would be empty
+    assert tp.split_layers(5, 2) == [(0, 3), (3, 5)]
+    for L in range(1, 40):
+        for G in range(1, 9):
+            r = tp.split_layers(L, G)
+            assert r[0][0] == 0 and r[-1][1] == L and all(a[1] == b[0] for a, b in zip(r, r[1:]))
