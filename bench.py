@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--kv-dtype", default="f16", help="KV cache: f16 or q8 (configs[2] = --wdtype q3h --kv-dtype q8)")
     ap.add_argument("--groups", type=int, default=1, help="device groups (layer ranges) of the HYBRID partition; "
                     "gpus // groups ranks per group are tensor-parallel (default 1 = pure tensor parallelism)")
+    ap.add_argument("--prefill-lens", default="128,1024", help="extra prompt lengths whose prefill rate is reported (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     args = ap.parse_args()
@@ -83,7 +84,8 @@ def main():
     wd = WD[args.wdtype.lower()]
     kvd = {"f16": dt.F16, "q8": dt.Q8_B32T2}[args.kv_dtype.lower()]
     steps, warmup = args.steps, args.warmup
-    max_ctx = PROMPT_LEN + warmup + steps + 8
+    prefill_lens = [int(x) for x in args.prefill_lens.split(",") if x] if world == 1 else []
+    max_ctx = max([PROMPT_LEN + warmup + steps + 8] + [n + 8 for n in prefill_lens])
     t_build = time.perf_counter()
     runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank, groups=args.groups)
     t_build = time.perf_counter() - t_build
@@ -172,6 +174,20 @@ def main():
                            "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic,
                            "bytes_per_launch": ffn13_bytes, "us_per_launch": us}
         out["kernels"] = per_kernel
+    # ---- prefill rate at longer prompts (16 / 128 / 1024-token prompts), outside the timed decode region
+    if world == 1 and hasattr(runner, "worker") and not os.environ.get("IFA_FORCE_TP"):
+        pf = {str(PROMPT_LEN): PROMPT_LEN / prefill_s}
+        for n in prefill_lens:
+            pr = rng.integers(3, runner.shape["vocab"], n).astype(np.int32)
+            runner.worker.forward(pr, 0)                     # warm-up (scratch buffers grow on first use)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            runner.worker.forward(pr, 0)
+            torch.cuda.synchronize()
+            pf[str(n)] = n / (time.perf_counter() - t0)
+        out["prefill_tok_s_by_prompt_len"] = pf
+        flops_per_token = 2.0 * (w_bytes - runner.shape["vocab"] * runner.shape["dim"] * 2) / dt.row_bytes(wd, 32) * 32
+        out["prefill_linear_TFLOPs_at_longest"] = pf[str(max([PROMPT_LEN] + prefill_lens))] * flops_per_token / 1e12
     # ---- CPU baseline (oracle port) on a bounded sample
     if world == 1 and not args.no_cpu_baseline and not os.environ.get("IFA_FORCE_TP"):
         try:

@@ -89,9 +89,175 @@ __global__ void __launch_bounds__(256) k_attention(const half_t *__restrict__ q,
     }
 }
 
+
+// ---------------------------------------------------------------- prefill (q_tokens >= 4): MFMA tiles
+// One workgroup per (32-query tile, head); same three stages and the same rounding points as k_attention
+// (S and P are half tensors between the stages, like the reference's Gemm_Alg2 -> SoftMax -> Gemm_Alg2), but
+//   S tile  = Q[32 x HD] . K^T          v_mfma_f32_32x32x16_f16, keys of a 32-block = B columns, straight from the cache
+//   P       = row softmax of the [32 x n_keys] half tile kept in LDS (a wave per 8 rows)
+//   O tile  = P . V                     V blocks transposed through LDS ([dim][key]) so a lane's 8 keys are contiguous
+// fp32 accumulation in MFMA order instead of index order (products of halfs are exact either way).
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+// 8 consecutive elements e0..e0+7 (e0 % 8 == 0) of kv-row j as halfs
+template <bool Q8>
+__device__ __forceinline__ half8v kv_load8(const uint8_t *cache, size_t row_bytes, int j, int e0)
+{
+    if constexpr (Q8) {
+        const uint8_t *blk = cache + (size_t)j * row_bytes + (size_t)(e0 >> 5) * 34;
+        const uint16_t *p16 = reinterpret_cast<const uint16_t *>(blk);
+        const float scale = hbits2f(p16[0]);
+        half8v r;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t two = p16[1 + ((e0 & 31) >> 1) + w];
+            r[2 * w] = f2h((float)(int)(int8_t)(two & 0xFF) * scale);
+            r[2 * w + 1] = f2h((float)(int)(int8_t)(two >> 8) * scale);
+        }
+        return r;
+    } else {
+        return __builtin_bit_cast(half8v, *reinterpret_cast<const u32x4v *>(cache + (size_t)j * row_bytes + (size_t)e0 * 2));
+    }
+}
+
+constexpr int PF_QT = 32;            // queries per workgroup
+constexpr int PF_VROW = 40;          // halfs per row of the transposed V block (32 keys + pad: conflict-free b128 reads)
+
+__host__ __device__ inline int pf_nkp(int n_keys) { return (n_keys + 31) / 32 * 32 + 8; }
+
+template <int HD, bool Q8>
+__global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict__ q, const uint8_t *__restrict__ kc,
+                                                        const uint8_t *__restrict__ vc, int n_ctx, int q_tokens,
+                                                        int prefix_len, int heads, int kv_heads, float kq_scale,
+                                                        int alibi, int alibi_base, int alibi_total, half_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 16;          // MFMA k-steps over the head dimension
+    constexpr int NT = HD / 32;          // 32-wide output tiles
+    const int t0 = blockIdx.x * PF_QT, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int kvh = h / (heads / kv_heads);
+    const int kv_dim = kv_heads * HD;
+    const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
+    const int hoff = kvh * HD;
+    const int t_last = min(t0 + PF_QT, q_tokens) - 1;
+    const int n_keys = min(n_ctx, prefix_len + t_last + 1);      // causal bound of the whole tile
+    const int nkb = (n_keys + 31) / 32;
+    const int NKP = pf_nkp(n_keys);
+    half_t *S = reinterpret_cast<half_t *>(smem);                                   // [32][NKP]
+    half_t *Vt = S + (size_t)PF_QT * NKP;                                           // [HD][PF_VROW]
+    const float alpha = 1.0f / sqrtf((float)HD) / kq_scale;
+    const float mk = alibi ? alibi_slope(h + alibi_base, alibi_total) : 0.0f;
+
+    // ---- S = half(alpha * Q.K^T) (+ALiBi), key blocks strided over the waves
+    {
+        half8v qa[KS];
+        const int tq = min(t0 + i, q_tokens - 1);
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++)
+            qa[s2] = __builtin_bit_cast(half8v, *reinterpret_cast<const u32x4v *>(q + ((size_t)tq * heads + h) * HD + 16 * s2 + 8 * g));
+        for (int kb = wave; kb < nkb; kb += 4) {
+            const int j = min(32 * kb + i, n_ctx - 1);
+            f32x16v acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; s2++) {
+                const half8v kf = kv_load8<Q8>(kc, row_bytes, j, hoff + 16 * s2 + 8 * g);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s2], kf, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+                half_t sv = f2h(alpha * acc[r]);
+                if (alibi) { float a = (float)(32 * kb + i) * mk; sv = f2h(a + h2f(sv)); }
+                S[(size_t)row * NKP + 32 * kb + i] = sv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- P = softmax rows (Tensor_SoftMax_Alg2_Kernel rounding: half(e), then half(half(e) * 1/sum))
+    for (int rr = 0; rr < 8; rr++) {
+        const int row = 8 * wave + rr;
+        const int t = t0 + row;
+        half_t *Sr = S + (size_t)row * NKP;
+        const int n_valid = t < q_tokens ? min(n_ctx, prefix_len + t + 1) : 0;
+        float lmax = -INFINITY;
+        for (int j = lane; j < n_valid; j += 64) lmax = fmaxf(lmax, kq_scale * h2f(Sr[j]));
+        lmax = wave_max(lmax);
+        float lsum = 0.0f;
+        for (int j = lane; j < 32 * nkb; j += 64) {
+            float e = 0.0f;
+            if (j < n_valid) e = expf(kq_scale * h2f(Sr[j]) - lmax);
+            lsum += e;
+            Sr[j] = f2h(e);
+        }
+        lsum = wave_sum(lsum);
+        const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;      // rows past q_tokens: all zero
+        for (int j = lane; j < 32 * nkb; j += 64) Sr[j] = f2h(h2f(Sr[j]) * inv);
+    }
+    // ---- O = P.V
+    f32x16v oacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[r] = 0.0f;
+    constexpr int CH = HD / 8;               // 16-byte chunks per V row
+    constexpr int KPI = 256 / CH;            // keys staged per pass of the workgroup
+    for (int kt = 0; kt < nkb; kt++) {
+        __syncthreads();                     // previous block consumed (and, first time, P complete)
+#pragma unroll
+        for (int it = 0; it < (32 + KPI - 1) / KPI; it++) {
+            const int key = tid / CH + it * KPI, ch = tid % CH;
+            if (key < 32) {
+                const int j = min(32 * kt + key, n_ctx - 1);
+                const half8v v8 = kv_load8<Q8>(vc, row_bytes, j, hoff + 8 * ch);
+#pragma unroll
+                for (int e = 0; e < 8; e++) Vt[(size_t)(8 * ch + e) * PF_VROW + key] = v8[e];
+            }
+        }
+        __syncthreads();
+        if (wave < NT) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const half8v pf = *reinterpret_cast<const half8v *>(S + (size_t)i * NKP + 32 * kt + 16 * s2 + 8 * g);
+                const half8v vf = *reinterpret_cast<const half8v *>(Vt + (size_t)(32 * wave + i) * PF_VROW + 16 * s2 + 8 * g);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, oacc, 0, 0, 0);
+            }
+        }
+    }
+    if (wave < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (t < q_tokens) out[((size_t)t * heads + h) * HD + 32 * wave + i] = f2h(oacc[r]);
+        }
+    }
+}
+
 } // namespace ifa
 
 using namespace ifa;
+
+template <int HD>
+static int launch_attention_mfma(const void *q, const void *kcache, const void *vcache, int kv_dtype, int n_ctx, int q_tokens,
+                                 int prefix_len, int heads, int kv_heads, float kq_scale, int alibi, int alibi_base,
+                                 int alibi_total, void *out, size_t smem, hipStream_t s)
+{
+    dim3 grid((unsigned)((q_tokens + PF_QT - 1) / PF_QT), (unsigned)heads);
+    if (kv_dtype == Q8_B32T2) {
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_attention_mfma<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        k_attention_mfma<HD, true><<<grid, dim3(256), smem, s>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens,
+                                                                 prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base, alibi_total, (half_t *)out);
+    } else {
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_attention_mfma<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        k_attention_mfma<HD, false><<<grid, dim3(256), smem, s>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens,
+                                                                  prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base, alibi_total, (half_t *)out);
+    }
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
 
 extern "C" int ifa_attention(const void *q, const void *kcache, const void *vcache, int kv_dtype, int n_ctx,
                              int q_tokens, int prefix_len, int heads, int kv_heads, int head_dim, float kq_scale,
@@ -104,6 +270,17 @@ extern "C" int ifa_attention(const void *q, const void *kcache, const void *vcac
     IFA_REQUIRE(n_ctx > 0 && q_tokens > 0 && prefix_len >= 0, "ifa_attention: n_ctx %d q_tokens %d prefix %d", n_ctx, q_tokens, prefix_len);
     IFA_REQUIRE(n_ctx <= 65536 && q_tokens <= 65535, "ifa_attention: context too long for the op-level kernel");
     IFA_REQUIRE(kq_scale > 0, "ifa_attention: kq_scale must be > 0");
+    const int total_heads = alibi_total_heads > 0 ? alibi_total_heads : heads;
+    // prefill: MFMA tiles whenever the [32 x n_keys] score tile fits the 160 KiB LDS (~2300 keys)
+    const size_t smem_mfma = (size_t)PF_QT * pf_nkp(n_ctx) * 2 + (size_t)head_dim * PF_VROW * 2 + 64;
+    if (q_tokens >= 4 && smem_mfma <= 150 * 1024 && (head_dim == 32 || head_dim == 64 || head_dim == 128)) {
+        hipStream_t hs = ifa_s(stream);
+        switch (head_dim) {
+        case 32: return launch_attention_mfma<32>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_mfma, hs);
+        case 64: return launch_attention_mfma<64>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_mfma, hs);
+        default: return launch_attention_mfma<128>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_mfma, hs);
+        }
+    }
     size_t smem = (((size_t)n_ctx * 2 + 15) & ~(size_t)15) + 64;
     dim3 grid((unsigned)heads, (unsigned)q_tokens);
     if (kv_dtype == Q8_B32T2) {
