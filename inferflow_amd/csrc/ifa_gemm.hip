@@ -66,6 +66,55 @@ __device__ __forceinline__ void load_block_f16(const uint8_t *__restrict__ W, si
     }
 }
 
+// the same block in two steps -- raw bytes now, halfs later -- so that the next K step's loads are in flight
+// while the current one is multiplied
+template <int DT, int CAP>
+struct WRaw {
+    static constexpr int BB = (DT == F16) ? CAP * 2 : block_bytes(DT);
+    static constexpr bool Q4FAST = (DT == Q4_B32T1A || DT == Q4_B32T1B);
+    u32x4 f16v[(DT == F16) ? CAP / 8 : 1];
+    uint32_t q4[Q4FAST ? 5 : 1];
+    RawBlock<(DT == F16 || Q4FAST) ? 2 : BB> blk;
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ W, size_t row, int nblk, int b)
+    {
+        const uint8_t *p = W + (row * (size_t)nblk + (size_t)b) * BB;
+        if constexpr (DT == F16) {
+#pragma unroll
+            for (int i = 0; i < CAP / 8; i++) f16v[i] = reinterpret_cast<const u32x4 *>(p)[i];
+        } else if constexpr (Q4FAST) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) q4[i] = reinterpret_cast<const uint32_t *>(p)[i];
+        } else {
+            blk.load(p);
+        }
+    }
+    __device__ __forceinline__ void decode(bool ok, half_t (&v)[CAP]) const
+    {
+        if constexpr (DT == F16) {
+#pragma unroll
+            for (int i = 0; i < CAP / 8; i++) {
+                const half8_t h = __builtin_bit_cast(half8_t, ok ? f16v[i] : u32x4{0, 0, 0, 0});
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[8 * i + e] = h[e];
+            }
+        } else if constexpr (Q4FAST) {
+            const float base = hbits2f((uint16_t)(q4[0] & 0xFFFFu)), scale = hbits2f((uint16_t)(q4[0] >> 16));
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float qv = (float)((q4[1 + w] >> (4 * e)) & 0xFu);
+                    v[8 * w + e] = ok ? f2h(__builtin_fmaf(qv, scale, base)) : (half_t)0;   // q*scale exact: fma == mul + add
+                }
+        } else {
+            int q[CAP]; float scale, base;
+            decode_block<DT>(blk, q, scale, base);
+#pragma unroll
+            for (int i = 0; i < CAP; i++) v[i] = ok ? f2h(block_value<DT>(q[i], scale, base)) : (half_t)0;
+        }
+    }
+};
+
 // SPLITK = false: 4 waves x 32 rows per workgroup, all waves walk the whole K (large T).
 // SPLITK = true : the 4 waves share ONE 32-row tile and take every 4th K step each (their own
 //                 LDS slab, no workgroup barrier in the loop), partial tiles summed through LDS at
@@ -92,11 +141,55 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
         for (int r = 0; r < 16; r++) acc[mt][r] = 0.0f;
 
     const int nsteps = (nblk + 1) / 2;
-    for (int step = SPLITK ? wave : 0; step < nsteps; step += SPLITK ? 4 : 1) {
-        // ---- stage X[t0 .. t0+32*MT)[step*KSTEP .. +KSTEP) into LDS (zero-filled past T / K)
-        if constexpr (SPLITK) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-        constexpr int CHUNKS_PER_ROW = KSTEP / 8;
-        for (int c = SPLITK ? lane : tid; c < 32 * MT * CHUNKS_PER_ROW; c += SPLITK ? 64 : GEMM_THREADS) {
+    constexpr int CHUNKS_PER_ROW = KSTEP / 8;
+    if constexpr (!SPLITK) {
+        // ---- software-pipelined: the activation chunks and the weight block of step s+1 are requested before
+        // step s is multiplied (one LDS buffer, registers carry the next step)
+        constexpr int NCH = 32 * MT * CHUNKS_PER_ROW / GEMM_THREADS;      // 16-byte activation chunks per thread and step
+        u32x4 xa[NCH];
+        WRaw<DT, CAP> wr;
+        auto fetch = [&](int step) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int idx = tid + c * GEMM_THREADS;
+                const int r = idx / CHUNKS_PER_ROW, cc = idx % CHUNKS_PER_ROW;
+                const int tok = min(t0 + r, T - 1), k = min(step * KSTEP + cc * 8, K - 8);
+                xa[c] = *reinterpret_cast<const u32x4 *>(X + (size_t)tok * K + k);   // clamped, masked when stored
+            }
+            wr.load(W, nrow, nblk, min(2 * step + g, nblk - 1));
+        };
+        fetch(0);
+        for (int step = 0; step < nsteps; step++) {
+            __syncthreads();                         // the previous step's fragments have been read
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int idx = tid + c * GEMM_THREADS;
+                const int r = idx / CHUNKS_PER_ROW, cc = idx % CHUNKS_PER_ROW;
+                const bool ok = (t0 + r < T) && (step * KSTEP + cc * 8 < K);
+                *reinterpret_cast<u32x4 *>(smem + (size_t)r * XROW + (size_t)cc * 16) = ok ? xa[c] : u32x4{0, 0, 0, 0};
+            }
+            half_t v[CAP];
+            wr.decode(2 * step + g < nblk, v);
+            if (step + 1 < nsteps) fetch(step + 1);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < CAP / 8; m++) {
+                half8_t bfrag;
+#pragma unroll
+                for (int e = 0; e < 8; e++) bfrag[e] = v[8 * m + e];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const half8_t afrag = *reinterpret_cast<const half8_t *>(smem + (size_t)(mt * 32 + i) * XROW
+                                                                           + (size_t)(g * CAP + 8 * m) * 2);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    } else
+    for (int step = wave; step < nsteps; step += 4) {
+        // ---- stage X[t0 .. t0+32*MT)[step*KSTEP .. +KSTEP) into this wave's LDS slab (zero-filled past T / K)
+        __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < 32 * MT * CHUNKS_PER_ROW; c += 64) {
             const int r = c / CHUNKS_PER_ROW, cc = c % CHUNKS_PER_ROW;
             const int tok = t0 + r, k = step * KSTEP + cc * 8;
             u32x4 val = u32x4{0, 0, 0, 0};
@@ -107,7 +200,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
         const int b = 2 * step + g;
         half_t v[CAP];
         load_block_f16<DT, CAP>(W, nrow, nblk, min(b, nblk - 1), b < nblk, v);
-        if constexpr (SPLITK) __builtin_amdgcn_wave_barrier(); else __syncthreads();   // one wave's LDS ops are ordered
+        __builtin_amdgcn_wave_barrier();     // one wave's LDS ops are ordered
 #pragma unroll
         for (int m = 0; m < CAP / 8; m++) {
             half8_t bfrag;
@@ -165,6 +258,14 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
     const int nblk = (int)(K / CAP);
     constexpr int MT = 2;
     const size_t slab = (size_t)32 * MT * (2 * CAP * 2 + 16);
+    if (T > 128 && ifa_cdiv(N, GEMM_ROWS) * ifa_cdiv(T, 128) >= 256) {
+        // enough tiles to fill the chip twice over with 128-token tiles: the dequantised block is reused for 4 MFMA tiles
+        constexpr int MT4 = 4;
+        dim3 grid(ifa_cdiv(N, GEMM_ROWS), ifa_cdiv(T, 32 * MT4));
+        k_gemm_q<DT, MT4, false><<<grid, dim3(GEMM_THREADS), 2 * slab, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
+                                                                           (int)K, (const half_t *)bias, (half_t *)Y);
+        return IFA_OK;
+    }
     if (T <= 128) {      // weight-stream bound: 32-row tiles, K split over the 4 waves
         dim3 grid(ifa_cdiv(N, 32), ifa_cdiv(T, 32 * MT));
         const size_t smem = std::max(4 * slab, (size_t)3 * MT * 16 * 64 * 4);
