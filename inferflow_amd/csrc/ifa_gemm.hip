@@ -185,32 +185,55 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
                 }
             }
         }
-    } else
-    for (int step = wave; step < nsteps; step += 4) {
-        // ---- stage X[t0 .. t0+32*MT)[step*KSTEP .. +KSTEP) into this wave's LDS slab (zero-filled past T / K)
-        __builtin_amdgcn_wave_barrier();
-        for (int c = lane; c < 32 * MT * CHUNKS_PER_ROW; c += 64) {
-            const int r = c / CHUNKS_PER_ROW, cc = c % CHUNKS_PER_ROW;
-            const int tok = t0 + r, k = step * KSTEP + cc * 8;
-            u32x4 val = u32x4{0, 0, 0, 0};
-            if (tok < T && k < K) val = *reinterpret_cast<const u32x4 *>(X + (size_t)tok * K + k);
-            *reinterpret_cast<u32x4 *>(slab + (size_t)r * XROW + (size_t)cc * 16) = val;
-        }
-        // ---- this lane's quant block for the step, decoded to half in registers
-        const int b = 2 * step + g;
-        half_t v[CAP];
-        load_block_f16<DT, CAP>(W, nrow, nblk, min(b, nblk - 1), b < nblk, v);
-        __builtin_amdgcn_wave_barrier();     // one wave's LDS ops are ordered
+    } else {
+        // ---- split-K (small T): wave w owns K steps w, w+4, ...; two register sets keep the loads of its next two
+        // steps in flight while one step is multiplied (the layer is weight-stream bound here, latency is everything)
+        constexpr int NCHW = 32 * MT * CHUNKS_PER_ROW / 64;               // activation chunks per lane and step
+        struct Stage { u32x4 xa[NCHW]; WRaw<DT, CAP> wr; };
+        Stage sa, sb;
+        auto fetch = [&](Stage &st, int step) {
 #pragma unroll
-        for (int m = 0; m < CAP / 8; m++) {
-            half8_t bfrag;
+            for (int c = 0; c < NCHW; c++) {
+                const int idx = lane + c * 64;
+                const int r = idx / CHUNKS_PER_ROW, cc = idx % CHUNKS_PER_ROW;
+                const int tok = min(t0 + r, T - 1), k = min(step * KSTEP + cc * 8, K - 8);
+                st.xa[c] = *reinterpret_cast<const u32x4 *>(X + (size_t)tok * K + k);
+            }
+            st.wr.load(W, nrow, nblk, min(2 * step + g, nblk - 1));
+        };
+        auto consume = [&](const Stage &st, int step) {
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int e = 0; e < 8; e++) bfrag[e] = v[8 * m + e];
+            for (int c = 0; c < NCHW; c++) {
+                const int idx = lane + c * 64;
+                const int r = idx / CHUNKS_PER_ROW, cc = idx % CHUNKS_PER_ROW;
+                const bool ok = (t0 + r < T) && (step * KSTEP + cc * 8 < K);
+                *reinterpret_cast<u32x4 *>(slab + (size_t)r * XROW + (size_t)cc * 16) = ok ? st.xa[c] : u32x4{0, 0, 0, 0};
+            }
+            half_t v[CAP];
+            st.wr.decode(2 * step + g < nblk, v);
+            __builtin_amdgcn_wave_barrier();     // one wave's LDS ops are ordered
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                const half8_t afrag = *reinterpret_cast<const half8_t *>(slab + (size_t)(mt * 32 + i) * XROW
-                                                                       + (size_t)(g * CAP + 8 * m) * 2);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[mt], 0, 0, 0);
+            for (int m = 0; m < CAP / 8; m++) {
+                half8_t bfrag;
+#pragma unroll
+                for (int e = 0; e < 8; e++) bfrag[e] = v[8 * m + e];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const half8_t afrag = *reinterpret_cast<const half8_t *>(slab + (size_t)(mt * 32 + i) * XROW
+                                                                           + (size_t)(g * CAP + 8 * m) * 2);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[mt], 0, 0, 0);
+                }
+            }
+        };
+        if (wave < nsteps) fetch(sa, wave);
+        if (wave + 4 < nsteps) fetch(sb, wave + 4);
+        for (int step = wave; step < nsteps; step += 8) {
+            consume(sa, step);
+            if (step + 8 < nsteps) fetch(sa, step + 8);
+            if (step + 4 < nsteps) {
+                consume(sb, step + 4);
+                if (step + 12 < nsteps) fetch(sb, step + 12);
             }
         }
     }
@@ -264,6 +287,14 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
         dim3 grid(ifa_cdiv(N, GEMM_ROWS), ifa_cdiv(T, 32 * MT4));
         k_gemm_q<DT, MT4, false><<<grid, dim3(GEMM_THREADS), 2 * slab, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
                                                                            (int)K, (const half_t *)bias, (half_t *)Y);
+        return IFA_OK;
+    }
+    if (T <= 32) {       // one 32-token tile: half the activation staging of the 64-token variant
+        constexpr int MT1 = 1;
+        dim3 grid(ifa_cdiv(N, 32), 1);
+        const size_t smem = std::max(4 * (slab / 2), (size_t)3 * MT1 * 16 * 64 * 4);
+        k_gemm_q<DT, MT1, true><<<grid, dim3(GEMM_THREADS), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
+                                                                      (int)K, (const half_t *)bias, (half_t *)Y);
         return IFA_OK;
     }
     if (T <= 128) {      // weight-stream bound: 32-row tiles, K split over the 4 waves
