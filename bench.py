@@ -128,7 +128,9 @@ def main():
     kv_bytes = synth.kv_bytes_per_ctx_row(args.shape, kvd)
     bytes_per_token = w_bytes + kv_bytes * n_avg
     out = {
-        "metric": "decode tokens/sec, Llama-2-7B %s batch=1 greedy (whole job)" % ("Q4" if wd == dt.Q4_B32T1A else dt.name(wd)),
+        "metric": "decode tokens/sec, %s %s batch=1 greedy (whole job)" % (
+            {"llama2_7b": "Llama-2-7B", "mixtral_8x7b": "Mixtral-8x7B"}.get(args.shape, args.shape),
+            "Q4" if wd == dt.Q4_B32T1A else dt.name(wd)),
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": wall * 1e3 / steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "i8 (Q8 activations x %s weights, i32 dot, f32 scale, f16 I/O)" % dt.name(wd),
@@ -147,7 +149,8 @@ def main():
         "last_tokens": [int(t) for t in toks[-4:]],
     }
     # ---- roofline of the dominant kernel, timed live with HIP events on the worker's stream
-    if world == 1 and hasattr(runner, "export_host_tensors") and not os.environ.get("IFA_FORCE_TP"):
+    is_moe = bool(runner.shape.get("experts", 0))
+    if world == 1 and hasattr(runner, "export_host_tensors") and not os.environ.get("IFA_FORCE_TP") and not is_moe:
         s = runner.shape
         ffn_rows, d = s["ffn"], s["dim"]
         ffn13_bytes = 2 * ffn_rows * dt.row_bytes(wd, d)
@@ -189,7 +192,7 @@ def main():
         flops_per_token = 2.0 * (w_bytes - runner.shape["vocab"] * runner.shape["dim"] * 2) / dt.row_bytes(wd, 32) * 32
         out["prefill_linear_TFLOPs_at_longest"] = pf[str(max([PROMPT_LEN] + prefill_lens))] * flops_per_token / 1e12
     # ---- CPU baseline (oracle port) on a bounded sample
-    if world == 1 and not args.no_cpu_baseline and not os.environ.get("IFA_FORCE_TP"):
+    if world == 1 and not args.no_cpu_baseline and not os.environ.get("IFA_FORCE_TP") and not is_moe:
         try:
             threads = min(os.cpu_count() or 1, 128)
             host = runner.export_host_tensors()

@@ -49,6 +49,8 @@ int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu
     if (epi == EPI_RESIDUAL && norm == 0) return dec_gemv_launch_en<DT, EPI_RESIDUAL, 0>(P, wgs_per_cu, s);
     if (epi == EPI_GLU && norm == 1) return dec_gemv_launch_en<DT, EPI_GLU, 1>(P, wgs_per_cu, s);
     if (epi == EPI_ACT && norm == 1) return dec_gemv_launch_en<DT, EPI_ACT, 1>(P, wgs_per_cu, s);
+    if (epi == EPI_MOE_ACC && norm == 0) return dec_gemv_launch_en<DT, EPI_MOE_ACC, 0>(P, wgs_per_cu, s);
+    if (epi == EPI_MOE_LAST && norm == 0) return dec_gemv_launch_en<DT, EPI_MOE_LAST, 0>(P, wgs_per_cu, s);
     return ifa_fail(IFA_ERR_ARG, "fused GEMV: no kernel for epilogue %d / norm %d", epi, norm);
 }
 

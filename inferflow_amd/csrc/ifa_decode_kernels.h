@@ -283,7 +283,8 @@ template <int NJ> struct DecFmt<Q5_B64T1, NJ> { using X = XRegsB64<NJ>; using W 
 template <int NJ> struct DecFmt<Q6_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ6B64<NJ>; static constexpr int DW = 13; };
 
 // ------------------------------------------------------------- kernel params
-enum DecEpilogue { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GLU = 2, EPI_ACT = 3 };
+// EPI_MOE_ACC / EPI_MOE_LAST: y = hfma(product, w_expert, y) (AddByRowIdx_Kernel); LAST also adds the residual(s)
+enum DecEpilogue { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GLU = 2, EPI_ACT = 3, EPI_MOE_ACC = 4, EPI_MOE_LAST = 5 };
 
 struct DecMatSet {
     const uint8_t *W[2];     // tiled rows; W[1] only for EPI_GLU (w3)
@@ -303,6 +304,13 @@ struct DecGemvParams {
     const half_t *residual2;   // optional second add (parallel-attn / shared-input models)
     int act_kind;
     half_t *xn_out;            // optional copy of the normalised activation
+    // mixture of experts: the weights of set 0 come from a device-side table indexed by the expert id the router
+    // kernel chose for slot `moe_slot` (w_table[4*e + {0: w1, 1: w3, 2: w2}]); moe_w[slot] = its half weight
+    const uint8_t *const *w_table;
+    const int *moe_sel;
+    const half_t *moe_w;
+    const half_t *moe_acc;     // running sum over the experts visited so far (read when moe_slot > 0)
+    int moe_slot, moe_tab_off;
     long long *trace;          // optional [gridDim.x][8] wall-clock stamps (100 MHz) for tuning
 };
 
@@ -367,6 +375,13 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
     const bool tr = P.trace != nullptr && threadIdx.x == 64;
     if (tr) P.trace[blockIdx.x * 8 + 0] = wall_clock64();
 
+    // MoE: the expert's matrices, looked up once (uniform scalar loads) from the router's choice
+    const uint8_t *moeW0 = nullptr, *moeW1 = nullptr;
+    if (P.w_table) {
+        const int e = P.moe_sel[P.moe_slot];
+        moeW0 = P.w_table[4 * e + P.moe_tab_off];
+        if constexpr (NM == 2) moeW1 = P.w_table[4 * e + P.moe_tab_off + 1];
+    }
     typename Fmt::W w[NM][RW];
     auto load_rows = [&](int pass, int i0, int i1) {
 #pragma unroll
@@ -374,8 +389,9 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
             if (i < i0 || i >= i1) continue;
             const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);   // clamped: rows past the end re-read the last row
             const DecRow d = dec_locate(P, v);
-            w[0][i].load(d.W0 + (size_t)d.row * row_bytes, P.nblk, lane);
-            if constexpr (NM == 2) w[1][i].load(d.W1 + (size_t)d.row * row_bytes, P.nblk, lane);
+            const uint8_t *W0 = moeW0 ? moeW0 : d.W0;
+            w[0][i].load(W0 + (size_t)d.row * row_bytes, P.nblk, lane);
+            if constexpr (NM == 2) { const uint8_t *W1 = moeW0 ? moeW1 : d.W1; w[1][i].load(W1 + (size_t)d.row * row_bytes, P.nblk, lane); }
         }
     };
     auto load_pass = [&](int pass) { load_rows(pass, 0, RW); };
@@ -434,6 +450,14 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
                 y = f2h(h2f(act) * h2f(t2));                        // TensorOpr::Mul
             } else if constexpr (EPI == EPI_ACT) {
                 y = f2h(act_fn(h2f(y), P.act_kind));
+            } else if constexpr (EPI == EPI_MOE_ACC || EPI == EPI_MOE_LAST) {
+                const half_t wexp = P.moe_w[P.moe_slot];
+                const half_t prev = P.moe_slot == 0 ? (half_t)0 : P.moe_acc[row];
+                y = __builtin_fmaf16(y, wexp, prev);                    // TensorOpr::AddByRowIndex
+                if constexpr (EPI == EPI_MOE_LAST) {
+                    y = f2h(h2f(y) + h2f(P.residual[row]));             // + residual (Add(ff_out, residual))
+                    if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
+                }
             }
             d.y[row] = y;
         }

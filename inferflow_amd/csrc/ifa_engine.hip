@@ -38,6 +38,7 @@ struct Tensor {
 struct Layer {
     Tensor t[T_MAX];
     std::vector<Tensor> experts;   // [expert][3]: w1, w2, w3 (MoE layers)
+    void *moe_table = nullptr;     // device: [expert][4] tiled pointers {w1, w3, w2, -} for the fused decode kernels
     void *kcache = nullptr, *vcache = nullptr;
 };
 
@@ -55,6 +56,7 @@ struct ifa_model {
     half_t *att = nullptr, *a = nullptr, *f = nullptr, *t1 = nullptr, *t2 = nullptr, *logits = nullptr;
     uint8_t *xq = nullptr;
     half_t *moe_gate = nullptr, *moe_out = nullptr;   // MoE: router probabilities [T][experts], one expert's output row
+    int *moe_route = nullptr;                          // device: fused decode routing, [0..7] expert ids, halfs at byte 32: weights
     int *moe_idx = nullptr, *moe_pin = nullptr;        // MoE: {row index, half weight} of the pending scatter-add (device / pinned)
     int *state = nullptr;          // device: see k_dec_gather
     float *rope_tab = nullptr;     // device: [head_dim/2][2]
@@ -144,7 +146,7 @@ static bool fused_supported(const ifa_model *m, std::string *why)
     const ifa_model_config &c = m->cfg;
     auto fail = [&](const char *s) { if (why) *why = s; return false; };
     if (c.norm_kind != 0) return fail("std-norm models use the op-by-op path");
-    if (c.experts > 0) return fail("MoE uses the op-by-op path");
+    if (c.experts > 64 || (c.experts > 0 && (c.moe_top_k < 1 || c.moe_top_k > 8))) return fail("MoE: experts / top_k out of range");
     if (c.parallel_attn || c.share_input) return fail("parallel-attention models use the op-by-op path");
     if (!c.full_quant_gemv) return fail("full_quant_gemv disabled");
     if (c.head_dim != 32 && c.head_dim != 64 && c.head_dim != 128) return fail("fused attention supports head_dim 32/64/128");
@@ -152,8 +154,22 @@ static bool fused_supported(const ifa_model *m, std::string *why)
     if (c.dim % 32 != 0 || c.ffn % 32 != 0) return fail("dim/ffn must be multiples of 32");
     if (c.dim > 8192) return fail("fused norm prologue supports dim <= 8192");
     for (const Layer &L : m->layers) {
-        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W2};
-        for (int id : ids) {
+        const bool moe = c.experts > 0 && L.t[T_MOE_GATE].present();
+        if (moe) {
+            if ((int)L.experts.size() != c.experts * 3 || !L.moe_table) return fail("MoE: expert tensors missing");
+            for (int e = 0; e < c.experts; e++)
+                for (int k = 0; k < 3; k++) {
+                    const Tensor &t = L.experts[(size_t)e * 3 + k];
+                    if (!t.present() || !t.tiled || !dec_gemv_supported(t.dtype, t.cols)) return fail("MoE: expert weights must be in an int8-GEMV format");
+                    if (!same_fmt(t.dtype, L.experts[(size_t)(k == 1 ? 1 : 0)].dtype) || t.rows != L.experts[(size_t)k].rows) return fail("MoE: experts differ in dtype / shape");
+                }
+        }
+        const int ids_dense[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W2};
+        const int ids_moe[] = {T_WQ, T_WK, T_WV, T_WO};
+        const int *ids = moe ? ids_moe : ids_dense;
+        const int n_ids = moe ? 4 : 6;
+        for (int ii = 0; ii < n_ids; ii++) {
+            const int id = ids[ii];
             const Tensor &t = L.t[id];
             if (!t.present() || !t.tiled) return fail("fused path needs weights in an int8-GEMV format (Q4/Q8/Q3H/Q5/Q6 block types)");
             if (!dec_gemv_supported(t.dtype, t.cols)) return fail("fused GEMV: too many columns for this weight format");
@@ -234,13 +250,31 @@ static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nul
     return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
 }
 
-static int launch_ffn13(ifa_model *m, int l)
+static void moe_params(ifa_model *m, Layer &L, DecGemvParams &P, int slot, int tab_off)
+{
+    P.w_table = (const uint8_t *const *)L.moe_table;
+    P.moe_sel = m->moe_route;
+    P.moe_w = reinterpret_cast<const half_t *>(reinterpret_cast<const char *>(m->moe_route) + 32);
+    P.moe_acc = m->f;
+    P.moe_slot = slot; P.moe_tab_off = tab_off;
+}
+
+// moe_slot >= 0: the FFN of the expert the router put in that slot (weights through L.moe_table)
+static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1)
 {
     const ifa_model_config &c = m->cfg;
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
     P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32; P.act_kind = c.act_kind;
+    if (moe_slot >= 0) {
+        const Tensor &e1 = L.experts[0], &e3 = L.experts[2];
+        moe_params(m, L, P, moe_slot, 0);
+        P.set[0].W[0] = (const uint8_t *)e1.tiled; P.set[0].W[1] = (const uint8_t *)e3.tiled;   // (replaced by the table lookup)
+        P.set[0].y = m->t1; P.set[0].rows = (int)e1.rows; P.nsets = 1;
+        if (e3.present()) return launch_dec_gemv<EPI_GLU, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
+        return launch_dec_gemv<EPI_ACT, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
+    }
     P.set[0].W[0] = (const uint8_t *)L.t[T_W1].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W1_B].data;
     P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows; P.nsets = 1;
     if (L.t[T_W3].present()) {
@@ -250,10 +284,20 @@ static int launch_ffn13(ifa_model *m, int l)
     return launch_dec_gemv<EPI_ACT, 1>(L.t[T_W1].dtype, P, m->opt_rpw_ffn, m->stream);
 }
 
-static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullptr)
+static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullptr, int moe_slot = -1, bool moe_last = false,
+                     const half_t *residual2 = nullptr)
 {
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
+    if (moe_slot >= 0) {
+        const Tensor &e2 = L.experts[1];
+        moe_params(m, L, P, moe_slot, 2);
+        P.x = m->t1; P.cols = (int)e2.cols; P.eps = m->cfg.eps;
+        P.set[0].W[0] = (const uint8_t *)e2.tiled; P.set[0].rows = (int)e2.rows; P.nsets = 1;
+        P.set[0].y = moe_last ? xnext : m->f; P.residual = m->a; P.residual2 = residual2;
+        if (moe_last) return launch_dec_gemv<EPI_MOE_LAST, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
+        return launch_dec_gemv<EPI_MOE_ACC, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
+    }
     P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
     P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].rows = (int)L.t[T_W2].rows; P.nsets = 1;
     if (partial) {
@@ -284,6 +328,58 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
     return launch_lmhead(H, m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, m->stream);
 }
 
+// Device-side counterpart of the host routing in moe_ffn (HostTensorOpr::BuildRowsForMoE, host_tensor_opr.cc:190-244):
+// top-k by repeated first-maximum, probabilities below 1e-5 dropped, optional renormalisation, experts then visited in
+// ascending id order.  Unused slots get weight 0 (hfma(y, 0, acc) == acc).  One thread: E <= 64, k <= 8.
+__global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k, int norm, int *__restrict__ sel, half_t *__restrict__ wout)
+{
+    if (threadIdx.x != 0) return;
+    float probs[64]; int idx[8]; float w[8]; bool used[64];
+    for (int e = 0; e < E; e++) { probs[e] = h2f(probs_h[e]); used[e] = false; }
+    int n = 0;
+    for (int k = 0; k < top_k && k < E; k++) {
+        int best = -1;
+        for (int e = 0; e < E; e++) if (!used[e] && (best < 0 || probs[e] > probs[best])) best = e;
+        if (best < 0) break;
+        used[best] = true;
+        if (probs[best] < 0.00001f) continue;
+        idx[n] = best; w[n] = probs[best]; n++;
+    }
+    if (norm && n > 0) {
+        float sum = 0.0f;
+        for (int i2 = 0; i2 < n; i2++) sum = sum + w[i2];
+        for (int i2 = 0; i2 < n; i2++) w[i2] = w[i2] / sum;
+    }
+    int slot = 0;
+    for (int e = 0; e < E; e++)
+        for (int j = 0; j < n; j++)
+            if (idx[j] == e) { sel[slot] = e; wout[slot] = f2h(w[j]); slot++; }
+    for (; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
+}
+
+static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const Tensor &bias, half_t *C);
+static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y);
+
+// router of one MoE layer on the device: the same norm / GEMV / softmax kernels the op path runs, then k_moe_topk
+static int launch_moe_router(ifa_model *m, int l)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    int rc;
+    Tensor none;
+    const half_t *ff_n = m->a;
+    if (L.t[T_FFN_NORM].present()) {
+        if ((rc = norm_rows(m, m->a, 1, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn))) return rc;
+        ff_n = m->hn;
+    }
+    if ((rc = matmul(m, ff_n, 1, L.t[T_MOE_GATE], none, m->moe_gate))) return rc;
+    if ((rc = ifa_softmax(m->moe_gate, c.experts, 1, 1, -1, 1.0f, (ifa_stream)m->stream))) return rc;
+    k_moe_topk<<<1, 64, 0, m->stream>>>(m->moe_gate, c.experts, c.moe_top_k, c.moe_norm_topk, m->moe_route,
+                                        reinterpret_cast<half_t *>(reinterpret_cast<char *>(m->moe_route) + 32));
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
 static int enqueue_fused_step(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
@@ -298,8 +394,17 @@ static int enqueue_fused_step(ifa_model *m)
         if ((rc = launch_qkv(m, l, x))) return rc;
         if ((rc = launch_attn(m, l))) return rc;
         if ((rc = launch_wo(m, l, x))) return rc;
-        if ((rc = launch_ffn13(m, l))) return rc;
-        if ((rc = launch_w2(m, l, xnext))) return rc;
+        Layer &L = m->layers[(size_t)l];
+        if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
+            if ((rc = launch_moe_router(m, l))) return rc;
+            for (int k = 0; k < c.moe_top_k; k++) {
+                if ((rc = launch_ffn13(m, l, k))) return rc;
+                if ((rc = launch_w2(m, l, xnext, nullptr, k, k + 1 == c.moe_top_k))) return rc;
+            }
+        } else {
+            if ((rc = launch_ffn13(m, l))) return rc;
+            if ((rc = launch_w2(m, l, xnext))) return rc;
+        }
         std::swap(x, xnext);
     }
     if ((rc = launch_lm(m, x))) return rc;
@@ -330,6 +435,7 @@ static int ensure_scratch(ifa_model *m, int T)
     if (c.experts > 0) {
         if ((rc = re(m->moe_gate, (size_t)T * c.experts)) || (rc = re(m->moe_out, D))) return rc;
         if (!m->moe_idx) IFA_HIP_CHECK(hipMalloc((void **)&m->moe_idx, 16));
+        if (!m->moe_route) { IFA_HIP_CHECK(hipMalloc((void **)&m->moe_route, 64)); IFA_HIP_CHECK(hipMemsetAsync(m->moe_route, 0, 64, m->stream)); }
         if (!m->moe_pin) IFA_HIP_CHECK(hipHostMalloc((void **)&m->moe_pin, 16, hipHostMallocDefault));
     }
     if (m->xq) IFA_HIP_CHECK(hipFree(m->xq));
@@ -570,6 +676,7 @@ int ifa_model_destroy(ifa_model *m)
     for (Layer &L : m->layers) {
         for (Tensor &t : L.t) free_tensor(t);
         for (Tensor &t : L.experts) free_tensor(t);
+        if (L.moe_table) (void)hipFree(L.moe_table);
         if (L.kcache) (void)hipFree(L.kcache);
         if (L.vcache) (void)hipFree(L.vcache);
     }
@@ -657,6 +764,16 @@ int ifa_model_finalize(ifa_model *m)
             IFA_HIP_CHECK(hipMalloc(&L.vcache, m->kv_row_bytes * (size_t)c.max_ctx));
             IFA_HIP_CHECK(hipMemsetAsync(L.kcache, 0, m->kv_row_bytes * (size_t)c.max_ctx, m->stream));
             IFA_HIP_CHECK(hipMemsetAsync(L.vcache, 0, m->kv_row_bytes * (size_t)c.max_ctx, m->stream));
+        }
+        if (c.experts > 0 && (int)L.experts.size() == c.experts * 3) {      // pointer table for the fused MoE kernels
+            std::vector<void *> tab((size_t)c.experts * 4, nullptr);
+            for (int e = 0; e < c.experts; e++) {
+                tab[(size_t)e * 4 + 0] = L.experts[(size_t)e * 3 + 0].tiled;
+                tab[(size_t)e * 4 + 1] = L.experts[(size_t)e * 3 + 2].tiled;
+                tab[(size_t)e * 4 + 2] = L.experts[(size_t)e * 3 + 1].tiled;
+            }
+            if (!L.moe_table) IFA_HIP_CHECK(hipMalloc(&L.moe_table, tab.size() * sizeof(void *)));
+            IFA_HIP_CHECK(hipMemcpy(L.moe_table, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice));
         }
     }
     if (!m->state) {

@@ -83,7 +83,12 @@ def weight_bytes(shape_name, wdtype=dt.Q4_B32T1A, quant_threshold=TENSOR_QUANT_T
     for tid, kind in MATRICES:
         rows, cols = _shape(kind, s)
         d = wdtype if rows * cols >= quant_threshold else dt.F16
-        per_layer += rows * dt.row_bytes(d, cols)
+        n = rows * dt.row_bytes(d, cols)
+        if s.get("experts", 0) and tid in (W.T_W1, W.T_W2, W.T_W3):
+            n *= s["moe_top_k"]                  # a token streams its top-k experts only
+        per_layer += n
+    if s.get("experts", 0):
+        per_layer += s["experts"] * s["dim"] * 2     # F16 router
     lm_head = s["vocab"] * s["dim"] * 2
     return per_layer * s["layers"] + lm_head
 

@@ -182,26 +182,34 @@ def test_other_wirings_through_the_op_path(name, cfg, bias):
     wk.close()
 
 
-def test_moe_layers_match_oracle():
-    """Mixtral-style mixture of experts (ProcessGpuLayer_Moe): router GEMV, softmax, host top-2 with
-    renormalisation, expert FFNs in ascending order, half-precision scatter-add."""
+@pytest.mark.parametrize("wd,kvd", [(dt.Q4_B32T1A, dt.F16), (dt.Q3H_B64T1, dt.Q8_B32T2)], ids=["q4", "q3h_kvq8"])
+def test_moe_layers_match_oracle(wd, kvd):
+    """Mixtral-style mixture of experts (ProcessGpuLayer_Moe): router GEMV, softmax, top-2 with renormalisation,
+    expert FFNs in ascending order, half-precision scatter-add -- op path (host routing, like the reference) and
+    fused decode (device routing, expert weights through a pointer table) against the oracle and each other."""
     max_ctx = 48
-    wk, host, s = synth.build("test_moe", dt.Q4_B32T1A, dt.F16, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
-    om = oracle_model_from_host(host, s, max_ctx, dt.F16)
+    wk, host, s = synth.build("test_moe", wd, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
+    om = oracle_model_from_host(host, s, max_ctx, kvd)
     ok, why = wk.fused_supported()
-    assert not ok and "MoE" in why
+    assert ok, why
     prompt = np.random.default_rng(5).integers(3, s["vocab"], 6).astype(np.int32)
     lg = torch.empty((len(prompt), s["vocab"]), dtype=torch.float16, device="cuda")
     tok = wk.forward(prompt, 0, lg)
     tok_o, lg_o = om.forward(prompt, 0, nthreads=4)
     cos, mad = _logits_close(g.host(lg), lg_o)
     assert cos >= 0.9995 and mad <= 0.03, (cos, mad)
-    cur, toks = tok, []
-    gpu_toks, _ = wk.decode(tok, len(prompt), 8)          # falls back to the op-by-op step (MoE is not fused)
-    for i in range(8):
+    n = 10
+    fused, _ = wk.decode(tok, len(prompt), n)
+    logits_fused = wk.read_buffer("logits").copy()
+    cur = tok
+    for i in range(n):
         t_or, l_or = om.forward(np.array([cur], np.int32), len(prompt) + i, nthreads=4)
         top2 = np.sort(l_or[0].astype(np.float32))[-2:]
         if top2[1] - top2[0] > 0.05:
-            assert int(gpu_toks[i]) == t_or, "step %d" % i
-        cur = int(gpu_toks[i])
+            assert int(fused[i]) == t_or, "step %d" % i
+        cur = int(fused[i])
+    wk.set_option("fused", 0)
+    unfused, _ = wk.decode(tok, len(prompt), n)        # op-by-op steps with the reference's host-side routing
+    assert np.array_equal(fused, unfused)
+    assert np.array_equal(logits_fused, wk.read_buffer("logits"))
     wk.close()
