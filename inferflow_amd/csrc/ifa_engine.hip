@@ -55,9 +55,10 @@ struct ifa_model {
     half_t *x = nullptr, *x2 = nullptr, *xn = nullptr, *hn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
     half_t *att = nullptr, *a = nullptr, *f = nullptr, *t1 = nullptr, *t2 = nullptr, *logits = nullptr;
     uint8_t *xq = nullptr;
-    half_t *moe_gate = nullptr, *moe_out = nullptr;   // MoE: router probabilities [T][experts], one expert's output row
+    half_t *moe_gate = nullptr, *moe_out = nullptr;   // MoE: router probabilities [T][experts], one expert's output rows
+    half_t *moe_in = nullptr, *moe_wdev = nullptr;    // MoE: one expert's gathered input rows; per-row weights
     int *moe_route = nullptr;                          // device: fused decode routing, [0..7] expert ids, halfs at byte 32: weights
-    int *moe_idx = nullptr, *moe_pin = nullptr;        // MoE: {row index, half weight} of the pending scatter-add (device / pinned)
+    int *moe_idx = nullptr, *moe_pin = nullptr;        // MoE: row lists of all experts, back to back (device / pinned staging)
     int *state = nullptr;          // device: see k_dec_gather
     float *rope_tab = nullptr;     // device: [head_dim/2][2]
     long long *trace = nullptr;    // device: [2048][8] optional kernel phase stamps
@@ -433,10 +434,15 @@ static int ensure_scratch(ifa_model *m, int T)
         || (rc = re(m->logits, (size_t)T * c.vocab)))
         return rc;
     if (c.experts > 0) {
-        if ((rc = re(m->moe_gate, (size_t)T * c.experts)) || (rc = re(m->moe_out, D))) return rc;
-        if (!m->moe_idx) IFA_HIP_CHECK(hipMalloc((void **)&m->moe_idx, 16));
+        const size_t cap = (size_t)T * (size_t)std::max(1, c.moe_top_k);
+        if ((rc = re(m->moe_gate, (size_t)T * c.experts)) || (rc = re(m->moe_out, (size_t)T * D)) || (rc = re(m->moe_in, (size_t)T * D))
+            || (rc = re(m->moe_wdev, cap)))
+            return rc;
+        if (m->moe_idx) IFA_HIP_CHECK(hipFree(m->moe_idx));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->moe_idx, cap * sizeof(int)));
+        if (m->moe_pin) IFA_HIP_CHECK(hipHostFree(m->moe_pin));
+        IFA_HIP_CHECK(hipHostMalloc((void **)&m->moe_pin, cap * (sizeof(int) + 2) + 16, hipHostMallocDefault));
         if (!m->moe_route) { IFA_HIP_CHECK(hipMalloc((void **)&m->moe_route, 64)); IFA_HIP_CHECK(hipMemsetAsync(m->moe_route, 0, 64, m->stream)); }
-        if (!m->moe_pin) IFA_HIP_CHECK(hipHostMalloc((void **)&m->moe_pin, 16, hipHostMallocDefault));
     }
     if (m->xq) IFA_HIP_CHECK(hipFree(m->xq));
     IFA_HIP_CHECK(hipMalloc((void **)&m->xq, (maxcols / 32 + 1) * 34));
@@ -523,6 +529,9 @@ static int moe_ffn(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     IFA_HIP_CHECK(hipMemcpyAsync(probs_h.data(), gate, probs_h.size() * 2, hipMemcpyDeviceToHost, m->stream));
     IFA_HIP_CHECK(hipMemsetAsync(m->f, 0, (size_t)T * D * 2, m->stream));
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    // per expert: the rows routed to it (token order) and their weights  (BuildRowsForMoE)
+    std::vector<std::vector<int>> rows((size_t)E);
+    std::vector<std::vector<uint16_t>> wts((size_t)E);
     for (int t = 0; t < T; t++) {
         float probs[64]; int idx[8]; float w[8]; bool used[64] = {false};
         for (int e = 0; e < E; e++) probs[e] = (float)__builtin_bit_cast(_Float16, probs_h[(size_t)t * E + e]);
@@ -540,20 +549,37 @@ static int moe_ffn(ifa_model *m, Layer &L, const half_t *ff_n, int T)
             for (int i = 0; i < n; i++) sum = sum + w[i];
             for (int i = 0; i < n; i++) w[i] = w[i] / sum;
         }
-        for (int e = 0; e < E; e++)
-            for (int j = 0; j < n; j++) {
-                if (idx[j] != e) continue;
-                const Tensor *ew = &L.experts[(size_t)e * 3];
-                if ((rc = ffn_dense(m, ff_n + (size_t)t * D, 1, ew[0], none, ew[2], none, ew[1], none, m->moe_out))) return rc;
-                // one (row index, weight) pair per call: staged through the pinned buffer, consumed by the kernel below
-                m->moe_pin[0] = t;
-                const _Float16 wh = (_Float16)w[j];
-                memcpy(&m->moe_pin[1], &wh, 2);
-                IFA_HIP_CHECK(hipMemcpyAsync(m->moe_idx, m->moe_pin, 8, hipMemcpyHostToDevice, m->stream));
-                if ((rc = ifa_add_by_row_index(m->f, m->moe_out, 1, D, m->moe_idx, m->moe_idx + 1, s))) return rc;
-                IFA_HIP_CHECK(hipStreamSynchronize(m->stream));      // the pinned pair is reused by the next one
-            }
+        for (int j = 0; j < n; j++) {
+            const _Float16 wh = (_Float16)w[j];
+            rows[(size_t)idx[j]].push_back(t);
+            wts[(size_t)idx[j]].push_back(__builtin_bit_cast(uint16_t, wh));
+        }
     }
+    // one upload of every (row, weight) list, experts back to back
+    const size_t cap = (size_t)T * (size_t)c.moe_top_k;
+    int *pin_rows = m->moe_pin; uint16_t *pin_w = reinterpret_cast<uint16_t *>(m->moe_pin + cap);
+    size_t off = 0;
+    std::vector<size_t> start((size_t)E, 0);
+    for (int e = 0; e < E; e++) {
+        start[(size_t)e] = off;
+        for (size_t r = 0; r < rows[(size_t)e].size(); r++) { pin_rows[off + r] = rows[(size_t)e][r]; pin_w[off + r] = wts[(size_t)e][r]; }
+        off += rows[(size_t)e].size();
+    }
+    IFA_HIP_CHECK(hipMemcpyAsync(m->moe_idx, pin_rows, off * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    IFA_HIP_CHECK(hipMemcpyAsync(m->moe_wdev, pin_w, off * 2, hipMemcpyHostToDevice, m->stream));
+    // expert by expert (ascending id): gather its rows, FFN on them as one matrix (T = 1 -> GEMV path, else the
+    // MFMA GEMM, exactly the split MatrixMultiplication makes), scatter-add weight * output
+    for (int e = 0; e < E; e++) {
+        const int n = (int)rows[(size_t)e].size();
+        if (n == 0) continue;
+        const int *idx_dev = m->moe_idx + start[(size_t)e];
+        k_gather_rows<<<dim3(4, (unsigned)n), dim3(256), 0, m->stream>>>(ff_n, idx_dev, n, (int)D, T, m->moe_in);
+        IFA_LAUNCH_CHECK();
+        const Tensor *ew = &L.experts[(size_t)e * 3];
+        if ((rc = ffn_dense(m, m->moe_in, n, ew[0], none, ew[2], none, ew[1], none, m->moe_out))) return rc;
+        if ((rc = ifa_add_by_row_index(m->f, m->moe_out, (size_t)n, D, idx_dev, m->moe_wdev + start[(size_t)e], s))) return rc;
+    }
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));      // the pinned lists are reused by the next MoE layer
     return IFA_OK;
 }
 

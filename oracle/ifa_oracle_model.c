@@ -248,28 +248,42 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
             rc = matmul(m, ff_n, T, &L->t[ORC_T_MOE_GATE], NULL, gate);
             if (rc == 0) {
                 orc_softmax(gate, E, T, 1, -1, 1.0f);
-                orc_f16 *eo = (orc_f16 *)malloc(sizeof(orc_f16) * D);
                 memset(f, 0, sizeof(orc_f16) * (size_t)T * D);
-                for (int t = 0; t < T && rc == 0; t++) {
+                /* HostTensorOpr::BuildRowsForMoE (host_tensor_opr.cc:190-244): per expert the list of rows routed to
+                 * it (token order) and their weights; then expert by expert (serial loop :2053-2121): gather the
+                 * rows, run the FFN on them as ONE matrix (GEMV path for a single row, dequant+GEMM path otherwise:
+                 * MatrixMultiplication, :2374-2415), scatter-add w * out (AddByRowIdx_Kernel: B = hfma(A, w, B)). */
+                int *rows = (int *)malloc(sizeof(int) * (size_t)T * (size_t)E);
+                float *wts = (float *)malloc(sizeof(float) * (size_t)T * (size_t)E);
+                int *cnt = (int *)calloc((size_t)E, sizeof(int));
+                for (int t = 0; t < T; t++) {
                     float probs[64]; int idx[8]; float w[8];
                     for (int e = 0; e < E; e++) probs[e] = orc_h2f(gate[(size_t)t * (size_t)E + (size_t)e]);
                     int n = orc_moe_topk(probs, E, c->moe_top_k, c->moe_norm_topk, idx, w);
-                    /* experts visited in ascending id order (serial loop :2053-2121) */
-                    for (int e = 0; e < E && rc == 0; e++) {
-                        for (int j = 0; j < n; j++) {
-                            if (idx[j] != e) continue;
-                            const orc_tensor *ew = &L->experts[e * 3];
-                            rc = ffn_dense(m, ff_n + (size_t)t * D, 1, &ew[0], NULL, &ew[2], NULL, &ew[1], NULL, eo);
-                            /* AddByRowIdx_Kernel binary_tensor_opr.h:80-125: B = hfma(A, w, B) */
-                            orc_f16 wh = orc_f2h(w[j]);
-                            for (size_t d = 0; d < D; d++) {
-                                double p = (double)orc_h2f(eo[d]) * (double)orc_h2f(wh) + (double)orc_h2f(f[(size_t)t * D + d]);
-                                f[(size_t)t * D + d] = orc_f2h((float)p);
-                            }
+                    for (int j = 0; j < n; j++) {
+                        int e = idx[j];
+                        rows[(size_t)e * T + cnt[e]] = t; wts[(size_t)e * T + cnt[e]] = w[j]; cnt[e]++;
+                    }
+                }
+                orc_f16 *ein = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
+                orc_f16 *eo = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
+                for (int e = 0; e < E && rc == 0; e++) {
+                    int n = cnt[e];
+                    if (n == 0) continue;
+                    for (int r = 0; r < n; r++)
+                        memcpy(ein + (size_t)r * D, ff_n + (size_t)rows[(size_t)e * T + r] * D, D * sizeof(orc_f16));
+                    const orc_tensor *ew = &L->experts[e * 3];
+                    rc = ffn_dense(m, ein, n, &ew[0], NULL, &ew[2], NULL, &ew[1], NULL, eo);
+                    for (int r = 0; r < n && rc == 0; r++) {
+                        size_t t = (size_t)rows[(size_t)e * T + r];
+                        orc_f16 wh = orc_f2h(wts[(size_t)e * T + r]);
+                        for (size_t d = 0; d < D; d++) {
+                            double p = (double)orc_h2f(eo[(size_t)r * D + d]) * (double)orc_h2f(wh) + (double)orc_h2f(f[t * D + d]);
+                            f[t * D + d] = orc_f2h((float)p);
                         }
                     }
                 }
-                free(eo);
+                free(ein); free(eo); free(rows); free(wts); free(cnt);
             }
             free(gate);
         } else {
