@@ -295,6 +295,10 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
         moe_params(m, L, P, moe_slot, 2);
         P.x = m->t1; P.cols = (int)e2.cols; P.eps = m->cfg.eps;
         P.set[0].W[0] = (const uint8_t *)e2.tiled; P.set[0].rows = (int)e2.rows; P.nsets = 1;
+        if (partial) {      // tensor parallel: accumulate the weighted shard products; merged and finished by the caller
+            P.set[0].y = partial; P.moe_acc = partial;
+            return launch_dec_gemv<EPI_MOE_ACC, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
+        }
         P.set[0].y = moe_last ? xnext : m->f; P.residual = m->a; P.residual2 = residual2;
         if (moe_last) return launch_dec_gemv<EPI_MOE_LAST, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
         return launch_dec_gemv<EPI_MOE_ACC, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
@@ -1077,6 +1081,15 @@ int ifa_model_tp_ffn(ifa_model *m, int layer, void *partial_out_f16)
 {
     IFA_REQUIRE(m && partial_out_f16 && layer >= 0 && layer < m->cfg.layers, "ifa_model_tp_ffn: bad arguments");
     int rc;
+    Layer &L = m->layers[(size_t)layer];
+    if (m->cfg.experts > 0 && L.t[T_MOE_GATE].present()) {     // MoE: every rank routes identically (replicated gate)
+        if ((rc = launch_moe_router(m, layer))) return rc;
+        for (int k = 0; k < m->cfg.moe_top_k; k++) {
+            if ((rc = launch_ffn13(m, layer, k))) return rc;
+            if ((rc = launch_w2(m, layer, nullptr, (half_t *)partial_out_f16, k, false))) return rc;
+        }
+        return IFA_OK;
+    }
     if ((rc = launch_ffn13(m, layer))) return rc;
     return launch_w2(m, layer, nullptr, (half_t *)partial_out_f16);
 }

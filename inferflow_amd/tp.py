@@ -88,10 +88,10 @@ def build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank, device=0
     wk = W.DecodeWorker(max_ctx=max_ctx, kv_dtype=kv_dtype, device=device, tp_rank=rank, tp_size=world, **s)
     dev = "cuda:%d" % device
 
-    def put(layer, tid, target, t16):
+    def put(layer, tid, target, t16, expert=-1):
         t16 = t16.contiguous()
         rows, cols = (1, t16.numel()) if t16.dim() == 1 else t16.shape
-        wk.set_tensor_f16(layer, tid, target, t16, rows, cols)
+        wk.set_tensor_f16(layer, tid, target, t16, rows, cols, expert=expert)
 
     if first_stage:
         put(-1, W.T_EMBD, dt.F16, synth.gen_f16((full["vocab"], full["dim"]), 999, std, dev))
@@ -104,10 +104,18 @@ def build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank, device=0
     for layer in range(l0, l1):
         put(layer - l0, W.T_ATTN_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
         put(layer - l0, W.T_FFN_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
+        n_exp = full.get("experts", 0)
         for tid, kind in synth.MATRICES:
             rows, cols = synth._shape(kind, full)
+            if n_exp and tid in (W.T_W1, W.T_W2, W.T_W3):      # experts: sliced like the dense FFN, one set per expert
+                for e in range(n_exp):
+                    t16 = synth.gen_f16((rows, cols), 100000 + (layer * 64 + e) * 16 + tid, std, dev)
+                    put(layer - l0, tid, wdtype, slice_tensor(tid, t16, rank, world), expert=e)
+                continue
             t16 = synth.gen_f16((rows, cols), 1000 + layer * 16 + tid, std, dev)   # same stream of values as N=1
             put(layer - l0, tid, wdtype, slice_tensor(tid, t16, rank, world))
+        if n_exp:       # replicated router
+            put(layer - l0, W.T_MOE_GATE, dt.F16, synth.gen_f16((n_exp, full["dim"]), 1000 + layer * 16 + W.T_MOE_GATE, std, dev))
     wk.finalize()
     return wk, full, s
 

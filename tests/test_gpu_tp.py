@@ -33,13 +33,13 @@ def test_tp_world1_equals_fused_decode():
     assert ms > 0
 
 
-def _rank_main(rank, world, port, q, groups=1, n_decode=0):
+def _rank_main(rank, world, port, q, groups=1, n_decode=0, shape="test_gqa"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    r = tp.TPRunner("test_gqa", dt.Q4_B32T1A, dt.F16, 32, world, rank, 0, std=0.06, groups=groups)
+    r = tp.TPRunner(shape, dt.Q4_B32T1A, dt.F16, 32, world, rank, 0, std=0.06, groups=groups)
     tok = None
     for i, t in enumerate(PROMPT):
         tok = r.step(int(t), i)
@@ -62,11 +62,11 @@ def _rank_main(rank, world, port, q, groups=1, n_decode=0):
         q.close(); q.join_thread()
 
 
-def _run_ranks(world, groups=1, n_decode=0):
+def _run_ranks(world, groups=1, n_decode=0, shape="test_gqa"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 400) + 7 * groups + world
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, groups, n_decode)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, groups, n_decode, shape)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -115,4 +115,18 @@ def test_tp_world2_matches_single_device_logits():
     cos = float((lg_tp * lg_1).sum() / (np.linalg.norm(lg_tp) * np.linalg.norm(lg_1)))
     # extra fp16 rounding of the two partial sums per layer, re-quantised downstream
     tol = 0.02 * float(np.abs(lg_1).max()) + 0.02     # ~2 % of the logit range (|logit| up to ~4 here)
+    assert cos >= 0.9995 and np.abs(lg_tp - lg_1).max() <= tol, (cos, np.abs(lg_tp - lg_1).max(), tol)
+
+
+def test_moe_tp_world2_matches_single_device_logits():
+    """Mixture of experts under tensor parallelism (configs[4] layout): every expert's FFN is sliced like the dense
+    FFN, the router is replicated, each rank accumulates its weighted shard products before the merge."""
+    lg_tp, _, _ = _run_ranks(2, shape="test_moe")
+    single = tp.TPRunner("test_moe", dt.Q4_B32T1A, dt.F16, 32, 1, 0, 0, std=0.06)
+    for i, t in enumerate(PROMPT):
+        single.step(int(t), i)
+    torch.cuda.synchronize()
+    lg_1 = single.logits.float().cpu().numpy()
+    cos = float((lg_tp * lg_1).sum() / (np.linalg.norm(lg_tp) * np.linalg.norm(lg_1)))
+    tol = 0.02 * float(np.abs(lg_1).max()) + 0.02
     assert cos >= 0.9995 and np.abs(lg_tp - lg_1).max() <= tol, (cos, np.abs(lg_tp - lg_1).max(), tol)
