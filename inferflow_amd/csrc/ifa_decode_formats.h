@@ -43,11 +43,11 @@ template <int NJ>
 struct XRegsB64 {
     int xe[NJ][2][4], xo[NJ][2][4];
     float xs[NJ][2], xsf[NJ][2];
-    __device__ __forceinline__ void load(const int8_t *codes, const float *scale, const float *xsum, int lane, int nblk)
+    __device__ __forceinline__ void load(const int8_t *codes, const float *scale, const float *xsum, int lane, int nblk, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = lane + 64 * j;
+            const int blk = blk0 + lane + 64 * j;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 xs[j][h] = 0.0f; xsf[j][h] = 0.0f;
@@ -79,11 +79,11 @@ template <int NJ>
 struct XRegsNat {
     int xn[NJ][8];
     float xs[NJ];
-    __device__ __forceinline__ void load(const int8_t *codes, const float *scale, const float *, int lane, int nblk)
+    __device__ __forceinline__ void load(const int8_t *codes, const float *scale, const float *, int lane, int nblk, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = lane + 64 * j;
+            const int blk = blk0 + lane + 64 * j;
             xs[j] = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; w++) xn[j][w] = 0;
@@ -106,19 +106,19 @@ template <int NJ>
 struct WRowQ8T2 {
     u32x4 c0[NJ], c1[NJ];
     uint16_t sc[NJ];
-    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane)
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = min(lane + 64 * j, nblk - 1);
+            const int blk = min(blk0 + lane + 64 * j, nblk - 1);
             c0[j] = nt_load<u32x4>(wrow + (size_t)blk * 32);
             c1[j] = nt_load<u32x4>(wrow + (size_t)blk * 32 + 16);
             sc[j] = nt_load<uint16_t>(wrow + (size_t)nblk * 32 + (size_t)blk * 2);
         }
     }
-    __device__ __forceinline__ float dot(const XRegsNat<NJ> &X) const
+    __device__ __forceinline__ float dot(const XRegsNat<NJ> &X, float acc0 = 0.0f) const
     {
-        float acc = 0.0f;
+        float acc = acc0;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             int d = 0;
@@ -139,19 +139,19 @@ template <int NJ>
 struct WRowQ4B64 {
     u32x4 c[NJ][2];
     uint32_t sb[NJ];
-    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane)
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = min(lane + 64 * j, nblk - 1);
+            const int blk = min(blk0 + lane + 64 * j, nblk - 1);
             c[j][0] = nt_load<u32x4>(wrow + (size_t)blk * 32);
             c[j][1] = nt_load<u32x4>(wrow + (size_t)blk * 32 + 16);
             sb[j] = nt_load<uint32_t>(wrow + (size_t)nblk * 32 + (size_t)blk * 4);
         }
     }
-    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X) const
+    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X, float acc0 = 0.0f) const
     {
-        float acc = 0.0f;
+        float acc = acc0;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const float base = hbits2f((uint16_t)(sb[j] & 0xFFFFu)), scale = hbits2f((uint16_t)(sb[j] >> 16));
@@ -178,20 +178,20 @@ struct WRowQ5B64 {
     u32x4 c[NJ][2];
     u32x2 hb[NJ];
     uint32_t sb[NJ];
-    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane)
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = min(lane + 64 * j, nblk - 1);
+            const int blk = min(blk0 + lane + 64 * j, nblk - 1);
             c[j][0] = nt_load<u32x4>(wrow + (size_t)blk * 32);
             c[j][1] = nt_load<u32x4>(wrow + (size_t)blk * 32 + 16);
             hb[j] = nt_load<u32x2>(wrow + (size_t)nblk * 32 + (size_t)blk * 8);
             sb[j] = nt_load<uint32_t>(wrow + (size_t)nblk * 40 + (size_t)blk * 4);
         }
     }
-    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X) const
+    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X, float acc0 = 0.0f) const
     {
-        float acc = 0.0f;
+        float acc = acc0;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const float base = hbits2f((uint16_t)(sb[j] & 0xFFFFu)), scale = hbits2f((uint16_t)(sb[j] >> 16));
@@ -222,11 +222,11 @@ struct WRowQ6B64 {
     u32x4 c[NJ][2];
     u32x4 hb[NJ];
     uint32_t sb[NJ];
-    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane)
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = min(lane + 64 * j, nblk - 1);
+            const int blk = min(blk0 + lane + 64 * j, nblk - 1);
             c[j][0] = nt_load<u32x4>(wrow + (size_t)blk * 32);
             c[j][1] = nt_load<u32x4>(wrow + (size_t)blk * 32 + 16);
             hb[j] = nt_load<u32x4>(wrow + (size_t)nblk * 32 + (size_t)blk * 16);
@@ -240,9 +240,9 @@ struct WRowQ6B64 {
         const uint32_t u = (t & 0x0033u) | ((t & 0x3300u) << 8);
         return ((u & 0x00030003u) << 4) | ((u & 0x00300030u) << 8);
     }
-    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X) const
+    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X, float acc0 = 0.0f) const
     {
-        float acc = 0.0f;
+        float acc = acc0;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const float base = hbits2f((uint16_t)(sb[j] & 0xFFFFu)), scale = hbits2f((uint16_t)(sb[j] >> 16));
@@ -276,11 +276,11 @@ struct WRowQ3H {
     u32x4 c[NJ];
     u32x2 m[NJ];
     u32x2 sbh[NJ];   // [0] = base | scale<<16, [1] = D6
-    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane)
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = min(lane + 64 * j, nblk - 1);
+            const int blk = min(blk0 + lane + 64 * j, nblk - 1);
             c[j] = nt_load<u32x4>(wrow + (size_t)blk * 16);
             m[j] = nt_load<u32x2>(wrow + (size_t)nblk * 16 + (size_t)blk * 8);
             sbh[j] = nt_load<u32x2>(wrow + (size_t)nblk * 24 + (size_t)blk * 8);
@@ -295,9 +295,9 @@ struct WRowQ3H {
         // bytes [ra.1, rb.1, ra.3, rb.3]: quotients in the high nibbles
         return (__builtin_amdgcn_perm(rb, ra, 0x07030501u) >> 4) & 0x0F0F0F0Fu;
     }
-    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X) const
+    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X, float acc0 = 0.0f) const
     {
-        float acc = 0.0f;
+        float acc = acc0;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const float base = hbits2f((uint16_t)(sbh[j][0] & 0xFFFFu)), scale = hbits2f((uint16_t)(sbh[j][0] >> 16));

@@ -14,6 +14,8 @@ template <> struct DecGemvLimits<Q8_B32T2> { static constexpr int MAXNJ = 6; };
 
 // true if the fused GEMV can stream a [rows][cols] tensor of this dtype
 bool dec_gemv_supported(int w_dtype, size_t cols);
+// same for matrices whose input is neither normalised nor gated (wo, w2): up to 4 register chunks / 32768 columns
+bool dec_gemv_supported_long(int w_dtype, size_t cols);
 
 // epi: DecEpilogue, norm: 0/1.  P.nblk / P.total_rows are filled in here.
 int dec_gemv_launch(int w_dtype, int epi, int norm, const DecGemvParams &P, int wgs_per_cu, hipStream_t s, long long *trace);

@@ -22,8 +22,32 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
 {
     constexpr int NM = EPI == EPI_GLU ? 2 : 1;
     const int nj = (P.nblk + 63) / 64;
-    if (nj < 1 || nj > DecGemvLimits<DT>::MAXNJ)
-        return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit of dtype %d", P.cols, DT);
+    if (nj < 1) return ifa_fail(IFA_ERR_ARG, "fused GEMV: no columns");
+    if (nj > DecGemvLimits<DT>::MAXNJ) {
+        // long rows (w2 / wo of 34B-70B models): chunked kernel, no norm prologue, no GLU pair
+        if constexpr (NORM == 0 && EPI != EPI_GLU && EPI != EPI_ACT) {
+            constexpr int MJ = DecGemvLimits<DT>::MAXNJ;
+            const int nchunk = (nj + MJ - 1) / MJ;
+            const int njl = (nj + nchunk - 1) / nchunk;
+            if (nchunk > 4 || P.cols > 32768) return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit of dtype %d", P.cols, DT);
+            const int per_cu_l = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 1;
+            int wgs_l = std::min(dec_num_cus() * per_cu_l, (P.total_rows + DEC_WAVES - 1) / DEC_WAVES);
+            if (wgs_l < 1) wgs_l = 1;
+            const size_t smem_l = xlds_bytes(P.cols);
+#define IFA_DGL(NJV) \
+    case NJV: if constexpr (NJV <= MJ) { \
+        constexpr int RWL = dec_rw<DT>(NJV, 1) >= 2 ? dec_rw<DT>(NJV, 1) / 2 : 1; \
+        auto kern = k_dec_gemv_long<DT, NJV, RWL, EPI>; \
+        if (smem_l > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l)); \
+        kern<<<dim3((unsigned)wgs_l), dim3(DEC_THREADS), smem_l, s>>>(P); } break;
+            switch (njl) { IFA_DGL(1) IFA_DGL(2) IFA_DGL(3) IFA_DGL(4) IFA_DGL(5) IFA_DGL(6) IFA_DGL(7) IFA_DGL(8) }
+#undef IFA_DGL
+            IFA_LAUNCH_CHECK();
+            return IFA_OK;
+        } else {
+            return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit of dtype %d for a normalised / gated input", P.cols, DT);
+        }
+    }
     // exactly one workgroup per CU (a second one would queue its activation behind the first one's weights)
     const int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 1;
     int wgs = std::min(dec_num_cus() * per_cu, (P.total_rows + DEC_WAVES - 1) / DEC_WAVES);

@@ -202,11 +202,11 @@ template <int NJ>
 struct XRegsQ4 {
     int xe[NJ][4], xo[NJ][4];
     float xs[NJ], xsf[NJ];
-    __device__ __forceinline__ void load(const int8_t *codes, const float *scale, const float *xsum, int lane, int nblk)
+    __device__ __forceinline__ void load(const int8_t *codes, const float *scale, const float *xsum, int lane, int nblk, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = lane + 64 * j;
+            const int blk = blk0 + lane + 64 * j;
             xs[j] = 0.0f; xsf[j] = 0.0f;
 #pragma unroll
             for (int w = 0; w < 4; w++) { xe[j][w] = 0; xo[j][w] = 0; }
@@ -235,11 +235,11 @@ struct WRowQ4 {
     // for OLDER data (e.g. the activation) turns into vmcnt(0), i.e. "wait for the whole
     // weight stream".  Lanes past the row end re-read the last block; their activation
     // registers are zero, so they contribute exactly 0.
-    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane)
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const int blk = min(lane + 64 * j, nblk - 1);
+            const int blk = min(blk0 + lane + 64 * j, nblk - 1);
 #if IFA_NT_WEIGHTS
             c[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow + (size_t)blk * 16));
             sb[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(wrow + (size_t)nblk * 16 + (size_t)blk * 4));
@@ -250,9 +250,9 @@ struct WRowQ4 {
         }
     }
     // lane-partial of sum_blk xs*(dot*scale + xsum*base); same expression as ax8_term (ifa_gemv.hip)
-    __device__ __forceinline__ float dot(const XRegsQ4<NJ> &X) const
+    __device__ __forceinline__ float dot(const XRegsQ4<NJ> &X, float acc0 = 0.0f) const
     {
-        float acc = 0.0f;
+        float acc = acc0;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             int d = 0;
@@ -348,6 +348,33 @@ __device__ __forceinline__ DecRow dec_locate(const DecGemvParams &P, int v)
     return d;
 }
 
+// lane-local end of a row: bias, then the epilogue of the fused op sequence
+template <int EPI>
+__device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const DecRow d, float a0, float a1)
+{
+    const int row = d.row;
+    half_t y = dec_bias(a0, d.b0, row);
+    if constexpr (EPI == EPI_RESIDUAL) {
+        y = f2h(h2f(P.residual[row]) + h2f(y));             // TensorOpr::Add (half add)
+        if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
+    } else if constexpr (EPI == EPI_GLU) {
+        half_t t2 = dec_bias(a1, d.b1, row);
+        half_t act = f2h(act_fn(h2f(y), P.act_kind));       // TensorOpr::Activation -> F16
+        y = f2h(h2f(act) * h2f(t2));                        // TensorOpr::Mul
+    } else if constexpr (EPI == EPI_ACT) {
+        y = f2h(act_fn(h2f(y), P.act_kind));
+    } else if constexpr (EPI == EPI_MOE_ACC || EPI == EPI_MOE_LAST) {
+        const half_t wexp = P.moe_w[P.moe_slot];
+        const half_t prev = P.moe_slot == 0 ? (half_t)0 : P.moe_acc[row];
+        y = __builtin_fmaf16(y, wexp, prev);                // TensorOpr::AddByRowIndex
+        if constexpr (EPI == EPI_MOE_LAST) {
+            y = f2h(h2f(y) + h2f(P.residual[row]));         // + residual (Add(ff_out, residual))
+            if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
+        }
+    }
+    d.y[row] = y;
+}
+
 // RW = rows (EPI_GLU: row pairs) per wave and pass; rows are strided over the waves
 // (v = (pass*RW + i)*W + wave) so neighbouring waves stream neighbouring rows.
 // Order of memory traffic inside the kernel (measured, see DESIGN.md "Kernel timeline"):
@@ -438,31 +465,80 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
         }
         const int v = (pass * RW + lane) * W + gw;
         if (lane < RW && v < P.total_rows) {
-            const DecRow d = dec_locate(P, v);
-            const int row = d.row;
-            half_t y = dec_bias(a0, d.b0, row);
-            if constexpr (EPI == EPI_RESIDUAL) {
-                y = f2h(h2f(P.residual[row]) + h2f(y));             // TensorOpr::Add (half add)
-                if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
-            } else if constexpr (EPI == EPI_GLU) {
-                half_t t2 = dec_bias(a1, d.b1, row);
-                half_t act = f2h(act_fn(h2f(y), P.act_kind));       // TensorOpr::Activation -> F16
-                y = f2h(h2f(act) * h2f(t2));                        // TensorOpr::Mul
-            } else if constexpr (EPI == EPI_ACT) {
-                y = f2h(act_fn(h2f(y), P.act_kind));
-            } else if constexpr (EPI == EPI_MOE_ACC || EPI == EPI_MOE_LAST) {
-                const half_t wexp = P.moe_w[P.moe_slot];
-                const half_t prev = P.moe_slot == 0 ? (half_t)0 : P.moe_acc[row];
-                y = __builtin_fmaf16(y, wexp, prev);                    // TensorOpr::AddByRowIndex
-                if constexpr (EPI == EPI_MOE_LAST) {
-                    y = f2h(h2f(y) + h2f(P.residual[row]));             // + residual (Add(ff_out, residual))
-                    if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
-                }
-            }
-            d.y[row] = y;
+            dec_finish_row<EPI>(P, dec_locate(P, v), a0, a1);
         }
     }
     if (tr) P.trace[blockIdx.x * 8 + 7] = wall_clock64();
+}
+
+// Rows longer than a lane's register image (cols > 64 * NJmax blocks: w2 of 34B-70B models, 20480-32768 columns):
+// the row is walked in chunks of 64*NJ blocks; the (pass, chunk) sequence is software-pipelined over two register
+// sets, the activation slice of a chunk is re-read from LDS, and every lane continues ONE accumulation chain over
+// its blocks in ascending order (dot(X, acc)), so results are bit-identical to the single-chunk kernel / op path.
+// No norm prologue and no GLU pair (only Wo / W2-type matrices get this long).
+template <int DT, int NJ, int RW, int EPI>
+__global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_long(const DecGemvParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const XLds L = xlds_carve(smem, P.cols);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * DEC_WAVES + wave;
+    const int W = gridDim.x * DEC_WAVES;
+    using Fmt = DecFmt<DT, NJ>;
+    const size_t row_bytes = tiled_row_bytes(DT, (size_t)P.nblk);
+    const int npass = (P.total_rows + RW * W - 1) / (RW * W);
+    const int nchunk = (P.nblk + 64 * NJ - 1) / (64 * NJ);
+    const int Q = npass * nchunk;
+    const uint8_t *moeW0 = nullptr;
+    if (P.w_table) moeW0 = P.w_table[4 * P.moe_sel[P.moe_slot] + P.moe_tab_off];
+    typename Fmt::W wa[RW], wb[RW];
+    auto load_q = [&](typename Fmt::W (&w)[RW], int q, int i0, int i1) {
+        const int pass = q / nchunk, chunk = q - pass * nchunk;
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            if (i < i0 || i >= i1) continue;
+            const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);
+            const DecRow d = dec_locate(P, v);
+            const uint8_t *W0 = moeW0 ? moeW0 : d.W0;
+            w[i].load(W0 + (size_t)d.row * row_bytes, P.nblk, lane, chunk * 64 * NJ);
+        }
+    };
+    {
+        XPre<0, 8> pre;                       // up to 32768 columns
+        pre.issue(P.x, nullptr, nullptr, P.cols);
+        __syncthreads();
+        load_q(wa, 0, 0, 1);
+        pre.finish(nullptr, nullptr, 0.0f, P.eps, P.cols, L, nullptr, nullptr);
+        load_q(wa, 0, 1, RW);
+    }
+    if (gw >= P.total_rows) return;
+    float a[RW];
+#pragma unroll
+    for (int i = 0; i < RW; i++) a[i] = 0.0f;
+    auto compute = [&](typename Fmt::W (&w)[RW], int q) {
+        const int pass = q / nchunk, chunk = q - pass * nchunk;
+        typename Fmt::X X;
+        X.load(L.codes, L.scale, L.xsum, lane, P.nblk, chunk * 64 * NJ);
+#pragma unroll
+        for (int i = 0; i < RW; i++) a[i] = w[i].dot(X, a[i]);
+        if (chunk + 1 < nchunk) return;
+#pragma unroll
+        for (int i = 0; i < RW; i++) a[i] = wave_sum(a[i]);
+        float a0 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < RW; i++) { if (lane == i) a0 = a[i]; a[i] = 0.0f; }
+        const int v = (pass * RW + lane) * W + gw;
+        if (lane < RW && v < P.total_rows) dec_finish_row<EPI>(P, dec_locate(P, v), a0, 0.0f);
+    };
+    for (int q = 0; q < Q; q += 2) {
+        if (q + 1 < Q) load_q(wb, q + 1, 0, RW);
+        compute(wa, q);
+        if (q + 1 < Q) {
+            if (q + 2 < Q) load_q(wa, q + 2, 0, RW);
+            compute(wb, q + 1);
+        }
+    }
 }
 
 // ------------------------------------------------- final norm + F16 lm_head

@@ -34,13 +34,21 @@ bool dec_gemv_supported(int w_dtype, size_t cols)
     return cols % cap == 0 && cols / cap <= (size_t)(64 * mnj);
 }
 
+bool dec_gemv_supported_long(int w_dtype, size_t cols)
+{
+    const int mnj = dec_maxnj(w_dtype);
+    if (mnj == 0 || cols == 0 || cols > 32768) return false;
+    const size_t cap = (size_t)block_capacity(w_dtype);
+    return cols % cap == 0 && cols / cap <= (size_t)(64 * mnj * 4);
+}
+
 int dec_gemv_launch(int w_dtype, int epi, int norm, const DecGemvParams &P0, int wgs_per_cu, hipStream_t s, long long *trace)
 {
     DecGemvParams P = P0;
     P.trace = trace;
     P.total_rows = 0;
     for (int i = 0; i < P.nsets; i++) P.total_rows += P.set[i].rows;
-    if (!dec_gemv_supported(w_dtype, (size_t)P.cols))
+    if (!dec_gemv_supported_long(w_dtype, (size_t)P.cols))
         return ifa_fail(IFA_ERR_ARG, "fused GEMV: dtype %d with %d columns is not supported", w_dtype, P.cols);
     P.nblk = P.cols / block_capacity(w_dtype);
     switch (w_dtype) {

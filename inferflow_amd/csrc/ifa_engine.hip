@@ -124,7 +124,7 @@ static int launch_lmhead(const DecLmHeadParams &P, int norm, int wgs_per_cu_opt,
 {
     const int chunks = P.cols / 8;
     const int nj = (chunks + 63) / 64;
-    if (P.cols % 8 != 0 || nj < 1 || nj > 8) return ifa_fail(IFA_ERR_ARG, "fused lm_head supports cols %% 8 == 0 and <= 4096 (got %d)", P.cols);
+    if (P.cols % 8 != 0 || nj < 1 || nj > 16) return ifa_fail(IFA_ERR_ARG, "fused lm_head supports cols %% 8 == 0 and <= 8192 (got %d)", P.cols);
     const int R = nj <= 4 ? 2 : 1;
     const int nbatch = (P.rows + R - 1) / R;
     const int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 2;
@@ -135,7 +135,8 @@ static int launch_lmhead(const DecLmHeadParams &P, int norm, int wgs_per_cu_opt,
 #define IFA_LM(NJV, RV) \
     case NJV: if (norm) k_dec_lmhead_f16<NJV, RV, 1><<<grid, dim3(DEC_THREADS), smem, s>>>(P); \
               else k_dec_lmhead_f16<NJV, RV, 0><<<grid, dim3(DEC_THREADS), smem, s>>>(P); break;
-    switch (nj) { IFA_LM(1, 2) IFA_LM(2, 2) IFA_LM(3, 2) IFA_LM(4, 2) IFA_LM(5, 1) IFA_LM(6, 1) IFA_LM(7, 1) IFA_LM(8, 1) }
+    switch (nj) { IFA_LM(1, 2) IFA_LM(2, 2) IFA_LM(3, 2) IFA_LM(4, 2) IFA_LM(5, 1) IFA_LM(6, 1) IFA_LM(7, 1) IFA_LM(8, 1)
+                  IFA_LM(9, 1) IFA_LM(10, 1) IFA_LM(11, 1) IFA_LM(12, 1) IFA_LM(13, 1) IFA_LM(14, 1) IFA_LM(15, 1) IFA_LM(16, 1) }
 #undef IFA_LM
     IFA_LAUNCH_CHECK();
     return IFA_OK;
@@ -161,7 +162,8 @@ static bool fused_supported(const ifa_model *m, std::string *why)
             for (int e = 0; e < c.experts; e++)
                 for (int k = 0; k < 3; k++) {
                     const Tensor &t = L.experts[(size_t)e * 3 + k];
-                    if (!t.present() || !t.tiled || !dec_gemv_supported(t.dtype, t.cols)) return fail("MoE: expert weights must be in an int8-GEMV format");
+                    if (!t.present() || !t.tiled || !(k == 1 ? dec_gemv_supported_long(t.dtype, t.cols) : dec_gemv_supported(t.dtype, t.cols)))
+                        return fail("MoE: expert weights must be in an int8-GEMV format");
                     if (!same_fmt(t.dtype, L.experts[(size_t)(k == 1 ? 1 : 0)].dtype) || t.rows != L.experts[(size_t)k].rows) return fail("MoE: experts differ in dtype / shape");
                 }
         }
@@ -173,7 +175,9 @@ static bool fused_supported(const ifa_model *m, std::string *why)
             const int id = ids[ii];
             const Tensor &t = L.t[id];
             if (!t.present() || !t.tiled) return fail("fused path needs weights in an int8-GEMV format (Q4/Q8/Q3H/Q5/Q6 block types)");
-            if (!dec_gemv_supported(t.dtype, t.cols)) return fail("fused GEMV: too many columns for this weight format");
+            const bool plain_input = id == T_WO || id == T_W2;      // neither normalised nor gated: long rows allowed
+            if (!(plain_input ? dec_gemv_supported_long(t.dtype, t.cols) : dec_gemv_supported(t.dtype, t.cols)))
+                return fail("fused GEMV: too many columns for this weight format");
         }
         if (L.t[T_W3].present() && (!L.t[T_W3].tiled || !same_fmt(L.t[T_W3].dtype, L.t[T_W1].dtype))) return fail("w1/w3 dtype mismatch");
         if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present()) return fail("pre-norm weights required");
@@ -183,7 +187,7 @@ static bool fused_supported(const ifa_model *m, std::string *why)
     // a pipeline stage (BY_LAYER partition) may hold neither embeddings nor lm_head: checked where they are used
     if (!lm.present()) { /* middle / first stage */ }
     else if (lm.dtype == F16) {
-        if (lm.cols > 4096 || lm.cols % 8 != 0) return fail("fused F16 lm_head needs cols <= 4096");
+        if (lm.cols > 8192 || lm.cols % 8 != 0) return fail("fused F16 lm_head needs cols <= 8192");
     } else if (!lm.tiled || !dec_gemv_supported(lm.dtype, lm.cols) || !m->g[T_OUT_NORM].present()) {
         return fail("fused lm_head needs F16 or an int8-GEMV weight format (with an output norm)");
     }

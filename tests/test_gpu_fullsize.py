@@ -56,3 +56,23 @@ def test_llama2_7b_width_other_formats_fused_equals_unfused(wd, kvd):
     assert np.array_equal(logits_fused, logits_unfused)
     assert np.array_equal(fused, unfused)
     wk.close()
+
+
+@pytest.mark.parametrize("shape,wd", [("yi_34b", dt.Q4_B32T1A), ("yi_34b", dt.Q3H_B64T1), ("llama2_70b", dt.Q4_B32T1A),
+                                      ("llama2_70b", dt.Q8_B32T2)],
+                         ids=["yi34b_q4", "yi34b_q3h", "70b_q4", "70b_q8"])
+def test_long_rows_fused_equals_unfused(shape, wd):
+    """w2 rows of 20480 / 28672 columns do not fit a lane's register image: the chunked, software-pipelined kernel
+    (k_dec_gemv_long) must continue the same per-lane accumulation chain -> bit-identical to the op-level GEMV."""
+    wk, _, s = synth.build(shape, wd, dt.F16, max_ctx=40, layers=2, vocab=8000)
+    ok, why = wk.fused_supported()
+    assert ok, why
+    prompt = np.random.default_rng(11).integers(3, s["vocab"], 4).astype(np.int32)
+    tok = wk.forward(prompt, 0)
+    fused, _ = wk.decode(tok, len(prompt), 4)
+    logits_fused = wk.read_buffer("logits").copy()
+    wk.set_option("fused", 0)
+    unfused, _ = wk.decode(tok, len(prompt), 4)
+    assert np.array_equal(logits_fused, wk.read_buffer("logits"))
+    assert np.array_equal(fused, unfused)
+    wk.close()
