@@ -911,6 +911,212 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     }
 }
 
+// ------------------------------------------------------------ long contexts: keys split over workgroups
+// k_dec_attn keeps one workgroup per head, which is latency-optimal for a few hundred keys but reads the whole
+// K/V history of a head through ONE compute unit (4K keys: ~190 us per layer).  Past a threshold the decode step
+// uses three kernels instead, with the SAME rounding points (S and P are half, global max and sum):
+//   k_dec_attn_scores  (head, split): RoPE, KV store of the new row, S_j = half(alpha q.k_j) for its keys -> workspace,
+//                                      local maximum
+//   k_dec_attn_pv      (head, split): global max, the full-row sum of exp (recomputed per split: a few thousand
+//                                      expf), P_j = half(half(e_j) * 1/sum) for its keys, partial P.V in fp32
+//   k_dec_attn_combine (head)       : sum of the partial outputs in split order -> half
+constexpr int DEC_ATTN_SPLITS = 8;
+
+struct DecAttnSplitWs {
+    half_t *S;        // [heads][max_ctx]
+    float *lmax;      // [heads][DEC_ATTN_SPLITS]
+    float *opart;     // [heads][DEC_ATTN_SPLITS][head_dim]
+};
+
+__device__ __forceinline__ void dec_split_range(int n_ctx, int s, int &j0, int &j1)
+{
+    const int chunk = ((n_ctx + DEC_ATTN_SPLITS - 1) / DEC_ATTN_SPLITS + 63) / 64 * 64;
+    j0 = min(s * chunk, n_ctx); j1 = min(j0 + chunk, n_ctx);
+}
+
+template <int HD, bool Q8>
+__global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, const DecAttnSplitWs ws)
+{
+    __shared__ __attribute__((aligned(16))) half_t qs[HD];
+    __shared__ __attribute__((aligned(16))) half_t kn[HD];
+    __shared__ __attribute__((aligned(16))) half_t vn[HD];
+    __shared__ float red[4];
+    const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = P.state[1], n_ctx = pos + 1;
+    int j0, j1; dec_split_range(n_ctx, sidx, j0, j1);
+    const int group = P.heads / P.kv_heads, kvh = h / group;
+    const bool has_new = pos >= j0 && pos < j1;             // this split owns the new token's row
+    const bool writer = has_new && (h % group) == 0;
+    const int kv_dim = P.kv_heads * HD;
+    const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
+    const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
+    for (int d = tid; d < HD; d += 256) {
+        qs[d] = P.q[(size_t)h * HD + d];
+        kn[d] = P.k_new[(size_t)kvh * HD + d];
+        vn[d] = P.v_new[(size_t)kvh * HD + d];
+    }
+    __syncthreads();
+    if (P.rope_order != 0) {
+        if (tid < HD) {
+            const int c = tid < HD / 2 ? tid : tid - HD / 2;
+            rope_apply(tid < HD / 2 ? qs : kn, c, P.rope_tab[2 * c], P.rope_tab[2 * c + 1], P.rope_order, P.rope_cols);
+        }
+        __syncthreads();
+    }
+    if (has_new) {      // KV store of the new row (and its Q8 round trip), as in k_dec_attn
+        if constexpr (Q8) {
+            constexpr int NB = HD / 32;
+            for (int b = wave; b < 2 * NB; b += 4) {
+                half_t *src = b < NB ? kn : vn;
+                const int bb = b < NB ? b : b - NB;
+                if (lane < 32) {
+                    const float val = h2f(src[bb * 32 + lane]);
+                    float mx = fabsf(val);
+#pragma unroll
+                    for (int m2 = 16; m2 > 0; m2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m2, 32));
+                    const float sc = mx / 127;
+                    int qv = sc <= 0.000001f ? 0 : (int)roundf(val / sc);
+                    qv = min(max(qv, -128), 127);
+                    const half_t sch = f2h(sc);
+                    if (writer) {
+                        uint8_t *cache = b < NB ? P.kcache : P.vcache;
+                        uint8_t *blk = cache + (size_t)pos * row_bytes + head_off + (size_t)bb * 34;
+                        blk[2 + lane] = (uint8_t)(int8_t)qv;
+                        if (lane == 0) *reinterpret_cast<uint16_t *>(blk) = __builtin_bit_cast(uint16_t, sch);
+                    }
+                    src[bb * 32 + lane] = f2h((float)qv * h2f(sch));
+                }
+            }
+            __syncthreads();
+        } else if (writer && tid < HD) {
+            reinterpret_cast<half_t *>(P.kcache + (size_t)pos * row_bytes + head_off)[tid] = kn[tid];
+            reinterpret_cast<half_t *>(P.vcache + (size_t)pos * row_bytes + head_off)[tid] = vn[tid];
+        }
+    }
+    const float alpha = 1.0f / sqrtf((float)HD) / P.kq_scale;
+    const float mk = P.alibi ? alibi_slope(h + P.alibi_base, P.alibi_total) : 0.0f;
+    float lmax = -INFINITY;
+    for (int j = j0 + tid; j < j1; j += 256) {
+        float c = 0.0f;
+        if (j == pos) {
+#pragma unroll 8
+            for (int d = 0; d < HD; d++) c = __builtin_fmaf(h2f(qs[d]), h2f(kn[d]), c);
+        } else {
+            const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
+            if constexpr (Q8) {
+#pragma unroll
+                for (int b = 0; b < HD / 32; b++) {
+                    const uint16_t *p16 = reinterpret_cast<const uint16_t *>(rowp + b * 34);
+                    const float sc = hbits2f(p16[0]);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t two = p16[1 + i];
+                        const float k0 = h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), k1 = h2f(f2h((float)(int)(int8_t)(two >> 8) * sc));
+                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i]), k0, c);
+                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i + 1]), k1, c);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < HD / 8; i++) {
+                    const half8_t k8 = __builtin_bit_cast(half8_t, reinterpret_cast<const u32x4 *>(rowp)[i]);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) c = __builtin_fmaf(h2f(qs[8 * i + e]), (float)k8[e], c);
+                }
+            }
+        }
+        half_t sv = f2h(alpha * c);
+        if (P.alibi) { float a = (float)j * mk; sv = f2h(a + h2f(sv)); }
+        ws.S[(size_t)h * P.max_ctx + j] = sv;
+        lmax = fmaxf(lmax, P.kq_scale * h2f(sv));
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    if (tid == 0) ws.lmax[h * DEC_ATTN_SPLITS + sidx] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <int HD, bool Q8>
+__global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, const DecAttnSplitWs ws)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DG = HD / 8, NSPLIT = 256 / DG;
+    float *red = reinterpret_cast<float *>(smem);                    // [8]
+    float *opart = red + 8;                                          // [NSPLIT][HD]
+    half_t *Pl = reinterpret_cast<half_t *>(opart + NSPLIT * HD);    // this split's probabilities
+    const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = P.state[1], n_ctx = pos + 1;
+    int j0, j1; dec_split_range(n_ctx, sidx, j0, j1);
+    const int group = P.heads / P.kv_heads, kvh = h / group;
+    const int kv_dim = P.kv_heads * HD;
+    const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
+    const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
+    const half_t *Sg = ws.S + (size_t)h * P.max_ctx;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s2 = 0; s2 < DEC_ATTN_SPLITS; s2++) mx = fmaxf(mx, ws.lmax[h * DEC_ATTN_SPLITS + s2]);
+    // the full-row sum, in the same order as the one-workgroup kernel (strided by 256, wave tree, 4 waves)
+    float lsum = 0.0f;
+    for (int j = tid; j < n_ctx; j += 256) lsum += expf(P.kq_scale * h2f(Sg[j]) - mx);
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / (((red[0] + red[1]) + red[2]) + red[3]);
+    for (int j = j0 + tid; j < j1; j += 256) {
+        const half_t eh = f2h(expf(P.kq_scale * h2f(Sg[j]) - mx));
+        Pl[j - j0] = f2h(h2f(eh) * inv);
+    }
+    __syncthreads();
+    const int dg = tid % DG, sp = tid / DG;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = 0.0f;
+    for (int j = j0 + sp; j < j1; j += NSPLIT) {
+        const float pj = h2f(Pl[j - j0]);
+        if constexpr (Q8) {
+            const uint8_t *blk = P.vcache + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
+            const uint16_t *p16 = reinterpret_cast<const uint16_t *>(blk);
+            const float sc = hbits2f(p16[0]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t two = p16[1 + (dg % 4) * 4 + e];
+                o[2 * e] = __builtin_fmaf(pj, h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), o[2 * e]);
+                o[2 * e + 1] = __builtin_fmaf(pj, h2f(f2h((float)(int)(int8_t)(two >> 8) * sc)), o[2 * e + 1]);
+            }
+        } else {
+            const half8_t v8 = __builtin_bit_cast(half8_t, reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, (float)v8[e], o[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
+    __syncthreads();
+    if (tid < HD) {
+        float acc = opart[tid];
+        for (int s2 = 1; s2 < NSPLIT; s2++) acc = acc + opart[s2 * HD + tid];
+        ws.opart[((size_t)h * DEC_ATTN_SPLITS + sidx) * HD + tid] = acc;
+    }
+}
+
+template <int HD>
+__global__ void __launch_bounds__(HD) k_dec_attn_combine(const DecAttnSplitWs ws, half_t *__restrict__ out)
+{
+    const int h = blockIdx.x, d = threadIdx.x;
+    const float *p = ws.opart + (size_t)h * DEC_ATTN_SPLITS * HD + d;
+    float acc = p[0];
+#pragma unroll
+    for (int s2 = 1; s2 < DEC_ATTN_SPLITS; s2++) acc = acc + p[(size_t)s2 * HD];
+    out[(size_t)h * HD + d] = f2h(acc);
+}
+
+__host__ __device__ inline size_t dec_attn_pv_smem(int head_dim, int max_ctx)
+{
+    const size_t nsplit = 256 / (head_dim / 8);
+    const size_t chunk = (((size_t)max_ctx + DEC_ATTN_SPLITS - 1) / DEC_ATTN_SPLITS + 63) / 64 * 64;
+    return 8 * 4 + nsplit * head_dim * 4 + chunk * 2 + 16;
+}
+
 __host__ __device__ inline size_t dec_attn_smem(int head_dim, int max_ctx)
 {
     const size_t nsplit = 256 / (head_dim / 8);

@@ -70,6 +70,9 @@ struct ifa_model {
     // decode graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
+    DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr};
+    int attn_split = 0, opt_attn_split_ctx = 512;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -225,6 +228,23 @@ static int launch_attn(ifa_model *m, int l)
     A.rope_order = c.rope_order; A.rope_cols = rope_dims;
     A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
     A.out = m->att; A.max_ctx = c.max_ctx;
+    if (m->attn_split) {
+        const dim3 g2((unsigned)c.heads, DEC_ATTN_SPLITS);
+        const size_t psmem = dec_attn_pv_smem(c.head_dim, c.max_ctx);
+#define IFA_ATTN_S(HDV) \
+    case HDV: if (A.kv_q8) { k_dec_attn_scores<HDV, true><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
+                             k_dec_attn_pv<HDV, true><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
+              else { k_dec_attn_scores<HDV, false><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
+                     k_dec_attn_pv<HDV, false><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
+              k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att); break;
+        switch (c.head_dim) {
+            IFA_ATTN_S(32) IFA_ATTN_S(64) IFA_ATTN_S(128)
+        default: return ifa_fail(IFA_ERR_ARG, "fused attention: head_dim %d", c.head_dim);
+        }
+#undef IFA_ATTN_S
+        IFA_LAUNCH_CHECK();
+        return IFA_OK;
+    }
     const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx);
     const dim3 grid((unsigned)c.heads), block(256);
 #define IFA_ATTN(HDV) \
@@ -714,6 +734,9 @@ int ifa_model_destroy(ifa_model *m)
         if (L.kcache) (void)hipFree(L.kcache);
         if (L.vcache) (void)hipFree(L.vcache);
     }
+    if (m->attn_ws.S) (void)hipFree(m->attn_ws.S);
+    if (m->attn_ws.lmax) (void)hipFree(m->attn_ws.lmax);
+    if (m->attn_ws.opart) (void)hipFree(m->attn_ws.opart);
     for (Tensor &t : m->g) free_tensor(t);
     half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits};
     for (half_t **b : bufs) if (*b) (void)hipFree(*b);
@@ -810,6 +833,11 @@ int ifa_model_finalize(ifa_model *m)
             IFA_HIP_CHECK(hipMemcpy(L.moe_table, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice));
         }
     }
+    if (!m->attn_ws.S) {
+        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.S, (size_t)c.heads * c.max_ctx * 2));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.lmax, (size_t)c.heads * DEC_ATTN_SPLITS * 4));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.opart, (size_t)c.heads * DEC_ATTN_SPLITS * c.head_dim * 4));
+    }
     if (!m->state) {
         IFA_HIP_CHECK(hipMalloc((void **)&m->state, sizeof(int) * (8 + ifa_model::RING)));
         IFA_HIP_CHECK(hipMemsetAsync(m->state, 0, sizeof(int) * (8 + ifa_model::RING), m->stream));
@@ -882,7 +910,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
@@ -935,6 +963,10 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     int rc = ensure_scratch(m, 1);
     if (rc) return rc;
     hipStream_t s = m->stream;
+    // attention variant of this call: one workgroup per head, or keys split over workgroups once the context the
+    // call reaches passes the threshold (the captured step is re-captured when the variant changes)
+    const int want_split = (m->opt_attn_split_ctx > 0 && start_pos + n_steps > m->opt_attn_split_ctx) ? 1 : 0;
+    if (want_split != m->attn_split) { m->attn_split = want_split; drop_graphs(m); }
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
     if (m->opt_graph && !m->graph_exec) {
