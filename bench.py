@@ -129,7 +129,8 @@ def main():
     bytes_per_token = w_bytes + kv_bytes * n_avg
     out = {
         "metric": "decode tokens/sec, %s %s batch=1 greedy (whole job)" % (
-            {"llama2_7b": "Llama-2-7B", "mixtral_8x7b": "Mixtral-8x7B"}.get(args.shape, args.shape),
+            {"llama2_7b": "Llama-2-7B", "mixtral_8x7b": "Mixtral-8x7B", "yi_34b": "Yi-34B", "falcon_40b": "Falcon-40B",
+             "llama2_70b": "Llama-2-70B"}.get(args.shape, args.shape),
             "Q4" if wd == dt.Q4_B32T1A else dt.name(wd)),
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": wall * 1e3 / steps, "higher_is_better": True, "scaling": "strong",
@@ -153,7 +154,7 @@ def main():
     if world == 1 and hasattr(runner, "export_host_tensors") and not os.environ.get("IFA_FORCE_TP") and not is_moe:
         s = runner.shape
         ffn_rows, d = s["ffn"], s["dim"]
-        ffn13_bytes = 2 * ffn_rows * dt.row_bytes(wd, d)
+        ffn13_bytes = (2 if s.get("is_glu", 1) else 1) * ffn_rows * dt.row_bytes(wd, d)
         us = runner.worker.time_kernel(3, 320)
         per_kernel = {}
         names = ["qkv", "attn", "wo", "ffn13", "w2", "lm_head"]

@@ -54,8 +54,11 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     if (wgs < 1) wgs = 1;
     const dim3 grid((unsigned)wgs);
     const size_t smem = xlds_bytes(P.cols);
+    // inputs that are normalised or feed an activation are [dim] vectors (dim <= 8192): <= 4 blocks per lane of a B32 format
+    constexpr int NJCAP = (NORM != 0 || EPI == EPI_GLU || EPI == EPI_ACT) ? 4 : 8;
+    if (nj > NJCAP) return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit for a normalised / gated input", P.cols);
 #define IFA_DG(NJV) \
-    case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ) { \
+    case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ && NJV <= NJCAP) { \
         auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(NJV, NM), EPI, NORM>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         kern<<<grid, dim3(DEC_THREADS), smem, s>>>(P); } break;
@@ -73,6 +76,8 @@ int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu
     if (epi == EPI_RESIDUAL && norm == 0) return dec_gemv_launch_en<DT, EPI_RESIDUAL, 0>(P, wgs_per_cu, s);
     if (epi == EPI_GLU && norm == 1) return dec_gemv_launch_en<DT, EPI_GLU, 1>(P, wgs_per_cu, s);
     if (epi == EPI_ACT && norm == 1) return dec_gemv_launch_en<DT, EPI_ACT, 1>(P, wgs_per_cu, s);
+    if (epi == EPI_GLU && norm == 0) return dec_gemv_launch_en<DT, EPI_GLU, 0>(P, wgs_per_cu, s);
+    if (epi == EPI_ACT && norm == 0) return dec_gemv_launch_en<DT, EPI_ACT, 0>(P, wgs_per_cu, s);
     if (epi == EPI_MOE_ACC && norm == 0) return dec_gemv_launch_en<DT, EPI_MOE_ACC, 0>(P, wgs_per_cu, s);
     if (epi == EPI_MOE_LAST && norm == 0) return dec_gemv_launch_en<DT, EPI_MOE_LAST, 0>(P, wgs_per_cu, s);
     return ifa_fail(IFA_ERR_ARG, "fused GEMV: no kernel for epilogue %d / norm %d", epi, norm);

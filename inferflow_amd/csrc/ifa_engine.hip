@@ -150,9 +150,8 @@ static bool fused_supported(const ifa_model *m, std::string *why)
 {
     const ifa_model_config &c = m->cfg;
     auto fail = [&](const char *s) { if (why) *why = s; return false; };
-    if (c.norm_kind != 0) return fail("std-norm models use the op-by-op path");
     if (c.experts > 64 || (c.experts > 0 && (c.moe_top_k < 1 || c.moe_top_k > 8))) return fail("MoE: experts / top_k out of range");
-    if (c.parallel_attn || c.share_input) return fail("parallel-attention models use the op-by-op path");
+    if (c.experts > 0 && (c.norm_kind != 0 || c.parallel_attn || c.share_input)) return fail("MoE layers need the sequential RMS-norm wiring");
     if (!c.full_quant_gemv) return fail("full_quant_gemv disabled");
     if (c.head_dim != 32 && c.head_dim != 64 && c.head_dim != 128) return fail("fused attention supports head_dim 32/64/128");
     if (c.kv_dtype == Q8_B32T2 && c.head_dim % 32 != 0) return fail("Q8 KV needs head_dim % 32 == 0");
@@ -183,7 +182,8 @@ static bool fused_supported(const ifa_model *m, std::string *why)
                 return fail("fused GEMV: too many columns for this weight format");
         }
         if (L.t[T_W3].present() && (!L.t[T_W3].tiled || !same_fmt(L.t[T_W3].dtype, L.t[T_W1].dtype))) return fail("w1/w3 dtype mismatch");
-        if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present()) return fail("pre-norm weights required");
+        if (!L.t[T_ATTN_NORM].present()) return fail("pre-norm weights required");
+        if (!L.t[T_FFN_NORM].present() && !c.parallel_attn) return fail("ffn pre-norm weights required");
         if (!same_fmt(L.t[T_WQ].dtype, L.t[T_WK].dtype) || !same_fmt(L.t[T_WQ].dtype, L.t[T_WV].dtype)) return fail("wq/wk/wv dtype mismatch");
     }
     const Tensor &lm = m->g[T_LM_HEAD];
@@ -199,6 +199,13 @@ static bool fused_supported(const ifa_model *m, std::string *why)
 }
 
 // --------------------------------------------------- fused step (enqueue only)
+// Std-norm models (Falcon, Bloom, OPT ...): the norm runs as the op-level kernel (same arithmetic as the op path by
+// construction) into `dst`, and the GEMV that follows takes it without a norm prologue.
+static int sep_norm(ifa_model *m, const half_t *x, const Tensor &w, const Tensor &b, half_t *dst)
+{
+    return ifa_layernorm(m->cfg.norm_kind, x, 1, (size_t)m->cfg.dim, w.data, b.data, 0.0f, m->cfg.eps, dst, (ifa_stream)m->stream);
+}
+
 static int launch_qkv(ifa_model *m, int l, const half_t *x)
 {
     const ifa_model_config &c = m->cfg;
@@ -206,6 +213,13 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = x; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
     P.multi_base = 0.0f; P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32;
+    P.xn_out = m->xn;                              // the normalised input (parallel-attention models feed it to the FFN)
+    const bool std_norm = c.norm_kind != 0;
+    if (std_norm) {
+        int rc = sep_norm(m, x, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn);
+        if (rc) return rc;
+        P.x = m->xn; P.norm_w = nullptr; P.norm_b = nullptr; P.xn_out = nullptr;
+    }
     const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
     half_t *outs[3] = {m->q, m->k, m->v};
     for (int i = 0; i < 3; i++) {
@@ -213,6 +227,7 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
         P.set[i].y = outs[i]; P.set[i].rows = (int)L.t[ids[i]].rows;
     }
     P.nsets = 3;
+    if (std_norm) return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WQ].dtype, P, m->opt_rpw_qkv, m->stream);
     return launch_dec_gemv<EPI_PLAIN, 1>(L.t[T_WQ].dtype, P, m->opt_rpw_qkv, m->stream);
 }
 
@@ -272,6 +287,8 @@ static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nul
     }
     P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
     P.set[0].y = m->a; P.residual = x;
+    if (m->cfg.parallel_attn || m->cfg.share_input)      // the residual is added once, after the FFN (inference_worker.cc:847-851)
+        return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
     return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
 }
 
@@ -285,7 +302,7 @@ static void moe_params(ifa_model *m, Layer &L, DecGemvParams &P, int slot, int t
 }
 
 // moe_slot >= 0: the FFN of the expert the router put in that slot (weights through L.moe_table)
-static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1)
+static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_layer = nullptr)
 {
     const ifa_model_config &c = m->cfg;
     Layer &L = m->layers[(size_t)l];
@@ -302,11 +319,22 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1)
     }
     P.set[0].W[0] = (const uint8_t *)L.t[T_W1].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W1_B].data;
     P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows; P.nsets = 1;
-    if (L.t[T_W3].present()) {
-        P.set[0].W[1] = (const uint8_t *)L.t[T_W3].tiled; P.set[0].bias[1] = (const half_t *)L.t[T_W3_B].data;
-        return launch_dec_gemv<EPI_GLU, 1>(L.t[T_W1].dtype, P, m->opt_rpw_ffn, m->stream);
+    // FFN input (inference_worker.cc:853-872): the attention's normalised input (parallel attention), the layer input
+    // (shared input) or the attention output + residual; then the FFN pre-norm if the model has one
+    const half_t *ff_in = c.parallel_attn ? m->xn : (c.share_input ? x_layer : m->a);
+    bool need_norm = L.t[T_FFN_NORM].present();
+    P.x = ff_in;
+    if (need_norm && c.norm_kind != 0) {
+        int rc = sep_norm(m, ff_in, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn);
+        if (rc) return rc;
+        P.x = m->hn; need_norm = false;
     }
-    return launch_dec_gemv<EPI_ACT, 1>(L.t[T_W1].dtype, P, m->opt_rpw_ffn, m->stream);
+    if (!need_norm) { P.norm_w = nullptr; P.norm_b = nullptr; }
+    const bool glu = L.t[T_W3].present();
+    if (glu) { P.set[0].W[1] = (const uint8_t *)L.t[T_W3].tiled; P.set[0].bias[1] = (const half_t *)L.t[T_W3_B].data; }
+    const int dtw = L.t[T_W1].dtype;
+    if (need_norm) return glu ? launch_dec_gemv<EPI_GLU, 1>(dtw, P, m->opt_rpw_ffn, m->stream) : launch_dec_gemv<EPI_ACT, 1>(dtw, P, m->opt_rpw_ffn, m->stream);
+    return glu ? launch_dec_gemv<EPI_GLU, 0>(dtw, P, m->opt_rpw_ffn, m->stream) : launch_dec_gemv<EPI_ACT, 0>(dtw, P, m->opt_rpw_ffn, m->stream);
 }
 
 static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullptr, int moe_slot = -1, bool moe_last = false,
@@ -334,7 +362,7 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
         return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
     }
     P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
-    P.set[0].y = xnext; P.residual = m->a;
+    P.set[0].y = xnext; P.residual = m->a; P.residual2 = residual2;     // + layer input for parallel / shared-input models
     return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
 }
 
@@ -349,6 +377,14 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
         P.set[0].W[0] = (const uint8_t *)lmt.tiled; P.set[0].rows = (int)lmt.rows; P.nsets = 1;
         P.set[0].y = logits_out ? logits_out : m->logits;
         return launch_dec_gemv<EPI_PLAIN, 1>(lmt.dtype, P, m->opt_rpw_lm, m->stream);
+    }
+    if (c.norm_kind != 0 && m->g[T_OUT_NORM].present()) {      // std final norm: op-level kernel, then the plain GEMV
+        int rc = sep_norm(m, x, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn);
+        if (rc) return rc;
+        DecLmHeadParams H2; memset(&H2, 0, sizeof(H2));
+        H2.x = m->xn; H2.eps = c.eps; H2.cols = c.dim; H2.W = (const half_t *)lmt.data; H2.logits = logits_out ? logits_out : m->logits;
+        H2.rows = (int)lmt.rows;
+        return launch_lmhead(H2, 0, m->opt_rpw_lm, m->stream);
     }
     DecLmHeadParams H; memset(&H, 0, sizeof(H));
     H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
@@ -431,8 +467,9 @@ static int enqueue_fused_step(ifa_model *m)
                 if ((rc = launch_w2(m, l, xnext, nullptr, k, k + 1 == c.moe_top_k))) return rc;
             }
         } else {
-            if ((rc = launch_ffn13(m, l))) return rc;
-            if ((rc = launch_w2(m, l, xnext))) return rc;
+            const bool extra = c.parallel_attn || c.share_input;
+            if ((rc = launch_ffn13(m, l, -1, x))) return rc;
+            if ((rc = launch_w2(m, l, xnext, nullptr, -1, false, extra ? x : nullptr))) return rc;
         }
         std::swap(x, xnext);
     }
@@ -1050,6 +1087,8 @@ static int tp_ready(ifa_model *m)
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
     if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
+    if (m->cfg.norm_kind != 0 || m->cfg.parallel_attn || m->cfg.share_input)
+        return ifa_fail(IFA_ERR_STATE, "tensor-parallel segments cover the sequential RMS-norm wiring only");
     return ensure_scratch(m, 1);
 }
 

@@ -19,6 +19,10 @@ SHAPES = {
     # data/models/yi_34b_chat (configs[3]) and a Llama-2-70B-shaped model: w2 rows of 20480 / 28672 columns
     "yi_34b": dict(dim=7168, layers=60, heads=56, kv_heads=8, head_dim=128, ffn=20480, vocab=64000),
     "llama2_70b": dict(dim=8192, layers=80, heads=64, kv_heads=8, head_dim=128, ffn=28672, vocab=32000),
+    # data/models/falcon_40b_instruct (configs[3]): LayerNorm, GELU, plain (non-gated) MLP, attention and MLP both read
+    # the layer input through their own norm (mlp_attn_share_input), 128 heads of 64 over 8 KV heads
+    "falcon_40b": dict(dim=8192, layers=60, heads=128, kv_heads=8, head_dim=64, ffn=32768, vocab=65024,
+                       norm_kind=1, act_kind=1, is_glu=0, share_input=1, rope_order=2),
     # Mixtral-8x7B (data/models/mixtral_8x7b_instruct_v0.1) and a small MoE shape for parity tests
     "mixtral_8x7b": dict(dim=4096, layers=32, heads=32, kv_heads=8, head_dim=128, ffn=14336, vocab=32000, experts=8, moe_top_k=2),
     "test_moe": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000, experts=4, moe_top_k=2),
@@ -65,6 +69,8 @@ def build(shape_name, wdtype=dt.Q4_B32T1A, kv_dtype=dt.F16, max_ctx=1024, quant_
         put(layer, W.T_FFN_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
         n_exp = s.get("experts", 0)
         for tid, kind in MATRICES:
+            if tid == W.T_W3 and not s.get("is_glu", 1):
+                continue
             rows, cols = _shape(kind, s)
             target = wdtype if rows * cols >= quant_threshold else dt.F16
             if n_exp and tid in (W.T_W1, W.T_W2, W.T_W3):       # one FFN per expert (ProcessGpuLayer_Moe)
@@ -84,6 +90,8 @@ def weight_bytes(shape_name, wdtype=dt.Q4_B32T1A, quant_threshold=TENSOR_QUANT_T
     s = SHAPES[shape_name]
     per_layer = 0
     for tid, kind in MATRICES:
+        if tid == W.T_W3 and not s.get("is_glu", 1):
+            continue
         rows, cols = _shape(kind, s)
         d = wdtype if rows * cols >= quant_threshold else dt.F16
         n = rows * dt.row_bytes(d, cols)

@@ -159,26 +159,40 @@ def _build_custom(shape, wd, kvd, max_ctx, cfg, with_bias=False, std=0.06):
     return wk, om, s
 
 
-@pytest.mark.parametrize("name,cfg,bias", [("falcon_like", FALCON_LIKE, True),
+FALCON40_LIKE = dict(norm_kind=1, act_kind=1, is_glu=0, share_input=1, rope_order=2)      # two norms on the layer input
+BLOOM_LIKE = dict(norm_kind=1, act_kind=1, is_glu=0, rope_order=0, use_alibi=1)             # sequential, std norm, ALiBi
+RMS_PARALLEL = dict(parallel_attn=1)                                                       # llama-style weights, parallel wiring
+
+
+@pytest.mark.parametrize("name,cfg,bias", [("falcon_like", FALCON_LIKE, True), ("falcon40_like", FALCON40_LIKE, False),
+                                            ("bloom_like", BLOOM_LIKE, True), ("rms_parallel", RMS_PARALLEL, False),
                                             ("llama_bias_q8kv", dict(), True)])
-def test_other_wirings_through_the_op_path(name, cfg, bias):
-    """Std-norm / GELU / parallel-attention / bias models decode through the op-by-op path
-    (the fused kernels only cover llama-style layers this round) and match the oracle."""
+def test_other_wirings_fused_and_op_path(name, cfg, bias):
+    """Std-norm / GELU / non-gated FFN / parallel attention / shared input / ALiBi / bias models: the op-by-op path
+    against the oracle, and the fused decode (norm as its own launch for std-norm models, residuals folded into the
+    W2 epilogue) bit for bit against the op-by-op decode."""
     kvd = dt.Q8_B32T2 if "q8kv" in name else dt.F16
     wk, om, s = _build_custom("test_gqa", dt.Q4_B32T1A, kvd, 32, cfg, with_bias=bias)
+    ok, why = wk.fused_supported()
+    assert ok, why
     prompt = np.array([7, 99, 512, 3, 41], np.int32)
     lg = torch.empty((len(prompt), s["vocab"]), dtype=torch.float16, device="cuda")
     tok = wk.forward(prompt, 0, lg)
-    tok_o, lg_o = om.forward(prompt, 0)
+    tok_o, lg_o = om.forward(prompt, 0, nthreads=4)
     cos, mad = _logits_close(g.host(lg), lg_o)
     assert cos >= 0.9995 and mad <= 0.02 * float(np.abs(lg_o.astype(np.float32)).max()) + 0.02, (cos, mad)
-    toks, _ = wk.decode(tok, len(prompt), 6)          # falls back to forward() when the fused path does not apply
+    toks, _ = wk.decode(tok, len(prompt), 6)
+    lg_fused = wk.read_buffer("logits").copy()
     cur = tok
     for i in range(6):
-        t_o, l_o = om.forward(np.array([cur], np.int32), len(prompt) + i)
+        t_o, l_o = om.forward(np.array([cur], np.int32), len(prompt) + i, nthreads=4)
         top2 = np.sort(l_o[0].astype(np.float32))[-2:]
         assert int(toks[i]) == t_o or top2[1] - top2[0] <= 0.05, "step %d" % i
         cur = int(toks[i])
+    wk.set_option("fused", 0)
+    toks_ops, _ = wk.decode(tok, len(prompt), 6)
+    assert np.array_equal(toks, toks_ops)
+    assert np.array_equal(lg_fused, wk.read_buffer("logits"))
     wk.close()
 
 
