@@ -20,12 +20,12 @@ constexpr int dec_rw(int nj, int nm)
 template <int DT, int EPI, int NORM>
 static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStream_t s)
 {
-    constexpr int NM = EPI == EPI_GLU ? 2 : 1;
+    constexpr int NM = epi_is_glu(EPI) ? 2 : 1;
     const int nj = (P.nblk + 63) / 64;
     if (nj < 1) return ifa_fail(IFA_ERR_ARG, "fused GEMV: no columns");
     if (nj > DecGemvLimits<DT>::MAXNJ) {
         // long rows (w2 / wo of 34B-70B models): chunked kernel, no norm prologue, no GLU pair
-        if constexpr (NORM == 0 && EPI != EPI_GLU && EPI != EPI_ACT) {
+        if constexpr (NORM == 0 && (EPI == EPI_PLAIN || EPI == EPI_RESIDUAL || EPI == EPI_MOE_ACC || EPI == EPI_MOE_LAST)) {
             constexpr int MJ = DecGemvLimits<DT>::MAXNJ;
             const int nchunk = (nj + MJ - 1) / MJ;
             const int njl = (nj + nchunk - 1) / nchunk;
@@ -55,7 +55,7 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     const dim3 grid((unsigned)wgs);
     const size_t smem = xlds_bytes(P.cols);
     // inputs that are normalised or feed an activation are [dim] vectors (dim <= 8192): <= 4 blocks per lane of a B32 format
-    constexpr int NJCAP = (NORM != 0 || EPI == EPI_GLU || EPI == EPI_ACT) ? 4 : 8;
+    constexpr int NJCAP = (NORM != 0 || EPI == EPI_GLU || EPI == EPI_ACT || EPI == EPI_MOE_GLU || EPI == EPI_MOE_ACT) ? 4 : 8;
     if (nj > NJCAP) return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit for a normalised / gated input", P.cols);
 #define IFA_DG(NJV) \
     case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ && NJV <= NJCAP) { \
@@ -78,6 +78,8 @@ int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu
     if (epi == EPI_ACT && norm == 1) return dec_gemv_launch_en<DT, EPI_ACT, 1>(P, wgs_per_cu, s);
     if (epi == EPI_GLU && norm == 0) return dec_gemv_launch_en<DT, EPI_GLU, 0>(P, wgs_per_cu, s);
     if (epi == EPI_ACT && norm == 0) return dec_gemv_launch_en<DT, EPI_ACT, 0>(P, wgs_per_cu, s);
+    if (epi == EPI_MOE_GLU && norm == 1) return dec_gemv_launch_en<DT, EPI_MOE_GLU, 1>(P, wgs_per_cu, s);
+    if (epi == EPI_MOE_ACT && norm == 1) return dec_gemv_launch_en<DT, EPI_MOE_ACT, 1>(P, wgs_per_cu, s);
     if (epi == EPI_MOE_ACC && norm == 0) return dec_gemv_launch_en<DT, EPI_MOE_ACC, 0>(P, wgs_per_cu, s);
     if (epi == EPI_MOE_LAST && norm == 0) return dec_gemv_launch_en<DT, EPI_MOE_LAST, 0>(P, wgs_per_cu, s);
     return ifa_fail(IFA_ERR_ARG, "fused GEMV: no kernel for epilogue %d / norm %d", epi, norm);

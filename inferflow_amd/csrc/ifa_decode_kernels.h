@@ -284,7 +284,11 @@ template <int NJ> struct DecFmt<Q6_B64T1, NJ> { using X = XRegsB64<NJ>; using W 
 
 // ------------------------------------------------------------- kernel params
 // EPI_MOE_ACC / EPI_MOE_LAST: y = hfma(product, w_expert, y) (AddByRowIdx_Kernel); LAST also adds the residual(s)
-enum DecEpilogue { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GLU = 2, EPI_ACT = 3, EPI_MOE_ACC = 4, EPI_MOE_LAST = 5 };
+// EPI_MOE_GLU / EPI_MOE_ACT: EPI_GLU / EPI_ACT of an expert.  Only the MOE epilogues contain the table lookup: a
+// run-time `if (P.w_table)` in the dense kernels cost them ~2 us each (weight pointers forced through VGPRs).
+enum DecEpilogue { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GLU = 2, EPI_ACT = 3, EPI_MOE_ACC = 4, EPI_MOE_LAST = 5, EPI_MOE_GLU = 6, EPI_MOE_ACT = 7 };
+constexpr bool epi_is_moe(int epi) { return epi >= EPI_MOE_ACC; }
+constexpr bool epi_is_glu(int epi) { return epi == EPI_GLU || epi == EPI_MOE_GLU; }
 
 struct DecMatSet {
     const uint8_t *W[2];     // tiled rows; W[1] only for EPI_GLU (w3)
@@ -357,11 +361,11 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
     if constexpr (EPI == EPI_RESIDUAL) {
         y = f2h(h2f(P.residual[row]) + h2f(y));             // TensorOpr::Add (half add)
         if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
-    } else if constexpr (EPI == EPI_GLU) {
+    } else if constexpr (EPI == EPI_GLU || EPI == EPI_MOE_GLU) {
         half_t t2 = dec_bias(a1, d.b1, row);
         half_t act = f2h(act_fn(h2f(y), P.act_kind));       // TensorOpr::Activation -> F16
         y = f2h(h2f(act) * h2f(t2));                        // TensorOpr::Mul
-    } else if constexpr (EPI == EPI_ACT) {
+    } else if constexpr (EPI == EPI_ACT || EPI == EPI_MOE_ACT) {
         y = f2h(act_fn(h2f(y), P.act_kind));
     } else if constexpr (EPI == EPI_MOE_ACC || EPI == EPI_MOE_LAST) {
         const half_t wexp = P.moe_w[P.moe_slot];
@@ -396,7 +400,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
     const int W = gridDim.x * DEC_WAVES;
     using Fmt = DecFmt<DT, NJ>;
     const size_t row_bytes = tiled_row_bytes(DT, (size_t)P.nblk);
-    constexpr int NM = (EPI == EPI_GLU) ? 2 : 1;
+    constexpr int NM = epi_is_glu(EPI) ? 2 : 1;
     const int npass = (P.total_rows + RW * W - 1) / (RW * W);
 
     const bool tr = P.trace != nullptr && threadIdx.x == 64;
@@ -404,8 +408,8 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
 
     // MoE: the expert's matrices, looked up once (uniform scalar loads) from the router's choice
     const uint8_t *moeW0 = nullptr, *moeW1 = nullptr;
-    if (P.w_table) {
-        const int e = P.moe_sel[P.moe_slot];
+    if constexpr (epi_is_moe(EPI)) {
+        const int e = __builtin_amdgcn_readfirstlane(P.moe_sel[P.moe_slot]);
         moeW0 = P.w_table[4 * e + P.moe_tab_off];
         if constexpr (NM == 2) moeW1 = P.w_table[4 * e + P.moe_tab_off + 1];
     }
@@ -416,9 +420,9 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
             if (i < i0 || i >= i1) continue;
             const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);   // clamped: rows past the end re-read the last row
             const DecRow d = dec_locate(P, v);
-            const uint8_t *W0 = moeW0 ? moeW0 : d.W0;
+            const uint8_t *W0 = epi_is_moe(EPI) ? moeW0 : d.W0;
             w[0][i].load(W0 + (size_t)d.row * row_bytes, P.nblk, lane);
-            if constexpr (NM == 2) { const uint8_t *W1 = moeW0 ? moeW1 : d.W1; w[1][i].load(W1 + (size_t)d.row * row_bytes, P.nblk, lane); }
+            if constexpr (NM == 2) { const uint8_t *W1 = epi_is_moe(EPI) ? moeW1 : d.W1; w[1][i].load(W1 + (size_t)d.row * row_bytes, P.nblk, lane); }
         }
     };
     auto load_pass = [&](int pass) { load_rows(pass, 0, RW); };
@@ -491,7 +495,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_long(const DecGemvPara
     const int nchunk = (P.nblk + 64 * NJ - 1) / (64 * NJ);
     const int Q = npass * nchunk;
     const uint8_t *moeW0 = nullptr;
-    if (P.w_table) moeW0 = P.w_table[4 * P.moe_sel[P.moe_slot] + P.moe_tab_off];
+    if constexpr (epi_is_moe(EPI)) moeW0 = P.w_table[4 * __builtin_amdgcn_readfirstlane(P.moe_sel[P.moe_slot]) + P.moe_tab_off];
     typename Fmt::W wa[RW], wb[RW];
     auto load_q = [&](typename Fmt::W (&w)[RW], int q, int i0, int i1) {
         const int pass = q / nchunk, chunk = q - pass * nchunk;
@@ -500,7 +504,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_long(const DecGemvPara
             if (i < i0 || i >= i1) continue;
             const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);
             const DecRow d = dec_locate(P, v);
-            const uint8_t *W0 = moeW0 ? moeW0 : d.W0;
+            const uint8_t *W0 = epi_is_moe(EPI) ? moeW0 : d.W0;
             w[i].load(W0 + (size_t)d.row * row_bytes, P.nblk, lane, chunk * 64 * NJ);
         }
     };

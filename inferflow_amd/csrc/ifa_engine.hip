@@ -213,7 +213,7 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = x; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
     P.multi_base = 0.0f; P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32;
-    P.xn_out = m->xn;                              // the normalised input (parallel-attention models feed it to the FFN)
+    if (c.parallel_attn) P.xn_out = m->xn;         // the normalised input: parallel-attention models feed it to the FFN
     const bool std_norm = c.norm_kind != 0;
     if (std_norm) {
         int rc = sep_norm(m, x, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn);
@@ -314,8 +314,8 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
         moe_params(m, L, P, moe_slot, 0);
         P.set[0].W[0] = (const uint8_t *)e1.tiled; P.set[0].W[1] = (const uint8_t *)e3.tiled;   // (replaced by the table lookup)
         P.set[0].y = m->t1; P.set[0].rows = (int)e1.rows; P.nsets = 1;
-        if (e3.present()) return launch_dec_gemv<EPI_GLU, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
-        return launch_dec_gemv<EPI_ACT, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
+        if (e3.present()) return launch_dec_gemv<EPI_MOE_GLU, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
+        return launch_dec_gemv<EPI_MOE_ACT, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
     }
     P.set[0].W[0] = (const uint8_t *)L.t[T_W1].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W1_B].data;
     P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows; P.nsets = 1;
@@ -1242,7 +1242,7 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
         case 0: return launch_qkv(m, l, m->x);
         case 1: return launch_attn(m, l);
         case 2: return launch_wo(m, l, m->x);
-        case 3: return launch_ffn13(m, l);
+        case 3: return launch_ffn13(m, l, -1, m->x);
         case 4: return launch_w2(m, l, m->x2);
         default: return launch_lm(m, m->x);
         }

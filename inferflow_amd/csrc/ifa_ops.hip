@@ -30,22 +30,75 @@ __global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x,
         if (tid == 0) stat[0] = rms_scale_from_partials(part, 128, cols, eps);
         __syncthreads();
         const float scale = stat[0];
-        const int x_len = (cols + 127) / 128;
-        const int xs0 = tid * x_len, xe = min((tid + 1) * x_len, cols);
-        for (int xi = xs0; xi < xe; xi++)
-            dst[xi] = f2h(rms_apply(h2f(src[xi]), scale, w ? w + xi : nullptr, b ? b + xi : nullptr, multi_base));
+        if ((cols & 7) == 0) {       // element-wise: 16-byte accesses, chunks interleaved over the threads
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            for (int c = tid; c < cols / 8; c += 128) {
+                const h8 xv = reinterpret_cast<const h8 *>(src)[c];
+                h8 wv, bv, ov;
+                if (w) wv = reinterpret_cast<const h8 *>(w)[c];
+                if (w && b) bv = reinterpret_cast<const h8 *>(b)[c];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float v = (float)xv[e] * scale;          // rms_apply
+                    if (w) {
+                        const float mlt = multi_base + (float)wv[e];
+                        v = v * mlt;
+                        if (b) v = v + (float)bv[e];
+                    }
+                    ov[e] = f2h(v);
+                }
+                reinterpret_cast<h8 *>(dst)[c] = ov;
+            }
+        } else {
+            const int x_len = (cols + 127) / 128;
+            const int xs0 = tid * x_len, xe = min((tid + 1) * x_len, cols);
+            for (int xi = xs0; xi < xe; xi++)
+                dst[xi] = f2h(rms_apply(h2f(src[xi]), scale, w ? w + xi : nullptr, b ? b + xi : nullptr, multi_base));
+        }
     } else {
+        // the row is staged in LDS with wide loads first: the strided per-thread sums below (the reference's order)
+        // would otherwise walk global memory one 2-byte load at a time on a latency chain
+        extern __shared__ __attribute__((aligned(16))) char smem_row[];
+        half_t *row = reinterpret_cast<half_t *>(smem_row);
+        if ((cols & 7) == 0) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            for (int c = tid; c < cols / 8; c += 128) reinterpret_cast<u4 *>(row)[c] = reinterpret_cast<const u4 *>(src)[c];
+        } else {
+            for (int xi = tid; xi < cols; xi += 128) row[xi] = src[xi];
+        }
+        __syncthreads();
+        src = row;
         float sum = 0.0f, sum2 = 0.0f;
-        for (int xi = tid; xi < cols; xi += 128) {
-            double v = (double)h2f(src[xi]);
-            sum = (float)((double)sum + v);
-            sum2 = (float)((double)sum2 + v * v);
+        int xi = tid;
+        for (; xi + 7 * 128 < cols; xi += 8 * 128) {     // 8 LDS reads in flight, then the ordered chain
+            half_t hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) hv[u] = src[xi + u * 128];
+            // Tensor_StdNorm_Kernel adds in double and rounds to float each step; for half inputs that equals the fp32
+            // add / fma (v and v*v are exact in fp32; see rms_partial in ifa_math.h for the rounding argument)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float v = h2f(hv[u]);
+                sum = sum + v;
+                sum2 = __builtin_fmaf(v, v, sum2);
+            }
+        }
+        for (; xi < cols; xi += 128) {
+            const float v = h2f(src[xi]);
+            sum = sum + v;
+            sum2 = __builtin_fmaf(v, v, sum2);
         }
         part[tid] = sum; part2[tid] = sum2;
         __syncthreads();
         if (tid == 0) {
             float ts = 0.0f, ts2 = 0.0f;
-            for (int i = 0; i < 128; i++) { ts = ts + part[i]; ts2 = ts2 + part2[i]; }
+            for (int i0 = 0; i0 < 128; i0 += 32) {           // strictly ordered, LDS reads batched
+                float a[32], b2[32];
+#pragma unroll
+                for (int i = 0; i < 32; i++) { a[i] = part[i0 + i]; b2[i] = part2[i0 + i]; }
+#pragma unroll
+                for (int i = 0; i < 32; i++) { ts = ts + a[i]; ts2 = ts2 + b2[i]; }
+            }
             float mean = ts / (float)cols;
             float mm = mean * mean;
             float var = ts2 / (float)cols - mm;
@@ -54,11 +107,29 @@ __global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x,
         }
         __syncthreads();
         const float mean = stat[0], scale = stat[1];
-        for (int xi = tid; xi < cols; xi += 128) {
-            float v = (h2f(src[xi]) - mean) * scale;
-            if (w) v = v * h2f(w[xi]);
-            if (w && b) v = v + h2f(b[xi]);
-            dst[xi] = f2h(v);
+        if ((cols & 7) == 0) {       // element-wise: 8 contiguous elements per thread and step, 16-byte accesses
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            for (int c = tid; c < cols / 8; c += 128) {
+                const h8 xv = reinterpret_cast<const h8 *>(src)[c];
+                h8 wv, bv, ov;
+                if (w) wv = reinterpret_cast<const h8 *>(w)[c];
+                if (w && b) bv = reinterpret_cast<const h8 *>(b)[c];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float v = ((float)xv[e] - mean) * scale;
+                    if (w) v = v * (float)wv[e];
+                    if (w && b) v = v + (float)bv[e];
+                    ov[e] = f2h(v);
+                }
+                reinterpret_cast<h8 *>(dst)[c] = ov;
+            }
+        } else {
+            for (int xi = tid; xi < cols; xi += 128) {
+                float v = (h2f(src[xi]) - mean) * scale;
+                if (w) v = v * h2f(w[xi]);
+                if (w && b) v = v + h2f(b[xi]);
+                dst[xi] = f2h(v);
+            }
         }
     }
 }
@@ -209,7 +280,7 @@ int ifa_layernorm(int kind, const void *x, size_t rows, size_t cols, const void 
     if (kind == 0)
         k_layernorm<0><<<dim3((unsigned)rows), dim3(128), 0, ifa_s(stream)>>>((const half_t *)x, (int)cols, (const half_t *)w, (const half_t *)b, multi_base, eps, (half_t *)y);
     else
-        k_layernorm<1><<<dim3((unsigned)rows), dim3(128), 0, ifa_s(stream)>>>((const half_t *)x, (int)cols, (const half_t *)w, (const half_t *)b, multi_base, eps, (half_t *)y);
+        k_layernorm<1><<<dim3((unsigned)rows), dim3(128), (cols * 2 + 15) & ~(size_t)15, ifa_s(stream)>>>((const half_t *)x, (int)cols, (const half_t *)w, (const half_t *)b, multi_base, eps, (half_t *)y);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
