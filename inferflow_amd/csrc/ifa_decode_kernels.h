@@ -290,24 +290,26 @@ enum DecEpilogue { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GLU = 2, EPI_ACT = 3, EP
 constexpr bool epi_is_moe(int epi) { return epi >= EPI_MOE_ACC; }
 constexpr bool epi_is_glu(int epi) { return epi == EPI_GLU || epi == EPI_MOE_GLU; }
 
-struct DecMatSet {
-    const uint8_t *W[2];     // tiled rows; W[1] only for EPI_GLU (w3)
-    const half_t *bias[2];
-    half_t *y;
-    int rows;
-};
-
+// Kernel arguments.  Kept under 256 bytes with the fields the prologue needs first: when the struct grew past 256 B
+// the kernels whose first instructions read the tail (xn_out, trace) started ~0.7 us later (second kernarg fetch).
+// Up to three matrices ("sets") are concatenated into one virtual row space (Wq|Wk|Wv); EPI_GLU pairs W0[0] with W1.
 struct DecGemvParams {
     const half_t *x;           // activation [cols]
     const half_t *norm_w, *norm_b;
     float multi_base, eps;
     int cols, nblk;            // nblk = WEIGHT blocks per row (cols / block capacity of the format)
-    DecMatSet set[3];          // rows of the sets are concatenated into one virtual row space
     int nsets, total_rows;
-    const half_t *residual;    // EPI_RESIDUAL: y = half(residual + y)
-    const half_t *residual2;   // optional second add (parallel-attn / shared-input models)
+    const uint8_t *W0[3];      // tiled rows of each set
+    const uint8_t *W1;         // w3 (EPI_GLU), paired with W0[0]
+    int rows[3];
     int act_kind;
     half_t *xn_out;            // optional copy of the normalised activation
+    long long *trace;          // optional [gridDim.x][8] wall-clock stamps (100 MHz) for tuning
+    half_t *y[3];
+    const half_t *b0[3];
+    const half_t *b1;
+    const half_t *residual;    // EPI_RESIDUAL: y = half(residual + y)
+    const half_t *residual2;   // optional second add (parallel-attn / shared-input models)
     // mixture of experts: the weights of set 0 come from a device-side table indexed by the expert id the router
     // kernel chose for slot `moe_slot` (w_table[4*e + {0: w1, 1: w3, 2: w2}]); moe_w[slot] = its half weight
     const uint8_t *const *w_table;
@@ -315,8 +317,8 @@ struct DecGemvParams {
     const half_t *moe_w;
     const half_t *moe_acc;     // running sum over the experts visited so far (read when moe_slot > 0)
     int moe_slot, moe_tab_off;
-    long long *trace;          // optional [gridDim.x][8] wall-clock stamps (100 MHz) for tuning
 };
+static_assert(sizeof(DecGemvParams) <= 256, "DecGemvParams must stay within 256 bytes of kernel arguments");
 
 __device__ __forceinline__ half_t dec_bias(float acc, const half_t *bias, int row)
 {
@@ -338,17 +340,17 @@ struct DecRow {
 
 __device__ __forceinline__ DecRow dec_locate(const DecGemvParams &P, int v)
 {
-    const int r0 = P.set[0].rows, r1 = P.set[1].rows;
+    const int r0 = P.rows[0], r1 = P.rows[1];
     DecRow d;
     const bool in1 = P.nsets > 1 && v >= r0;
     const bool in2 = P.nsets > 2 && v >= r0 + r1;
     d.si = in2 ? 2 : (in1 ? 1 : 0);
     d.row = in2 ? v - r0 - r1 : (in1 ? v - r0 : v);
-    d.W0 = in2 ? P.set[2].W[0] : (in1 ? P.set[1].W[0] : P.set[0].W[0]);
-    d.W1 = in2 ? P.set[2].W[1] : (in1 ? P.set[1].W[1] : P.set[0].W[1]);
-    d.b0 = in2 ? P.set[2].bias[0] : (in1 ? P.set[1].bias[0] : P.set[0].bias[0]);
-    d.b1 = in2 ? P.set[2].bias[1] : (in1 ? P.set[1].bias[1] : P.set[0].bias[1]);
-    d.y = in2 ? P.set[2].y : (in1 ? P.set[1].y : P.set[0].y);
+    d.W0 = in2 ? P.W0[2] : (in1 ? P.W0[1] : P.W0[0]);
+    d.W1 = P.W1;
+    d.b0 = in2 ? P.b0[2] : (in1 ? P.b0[1] : P.b0[0]);
+    d.b1 = P.b1;
+    d.y = in2 ? P.y[2] : (in1 ? P.y[1] : P.y[0]);
     return d;
 }
 

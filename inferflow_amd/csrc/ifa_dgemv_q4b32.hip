@@ -47,7 +47,7 @@ int dec_gemv_launch(int w_dtype, int epi, int norm, const DecGemvParams &P0, int
     DecGemvParams P = P0;
     P.trace = trace;
     P.total_rows = 0;
-    for (int i = 0; i < P.nsets; i++) P.total_rows += P.set[i].rows;
+    for (int i = 0; i < P.nsets; i++) P.total_rows += P.rows[i];
     if (!dec_gemv_supported_long(w_dtype, (size_t)P.cols))
         return ifa_fail(IFA_ERR_ARG, "fused GEMV: dtype %d with %d columns is not supported", w_dtype, P.cols);
     P.nblk = P.cols / block_capacity(w_dtype);

@@ -223,8 +223,8 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
     const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
     half_t *outs[3] = {m->q, m->k, m->v};
     for (int i = 0; i < 3; i++) {
-        P.set[i].W[0] = (const uint8_t *)L.t[ids[i]].tiled; P.set[i].bias[0] = (const half_t *)L.t[bids[i]].data;
-        P.set[i].y = outs[i]; P.set[i].rows = (int)L.t[ids[i]].rows;
+        P.W0[i] = (const uint8_t *)L.t[ids[i]].tiled; P.b0[i] = (const half_t *)L.t[bids[i]].data;
+        P.y[i] = outs[i]; P.rows[i] = (int)L.t[ids[i]].rows;
     }
     P.nsets = 3;
     if (std_norm) return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WQ].dtype, P, m->opt_rpw_qkv, m->stream);
@@ -280,13 +280,13 @@ static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nul
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->att; P.cols = (int)L.t[T_WO].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
-    P.set[0].W[0] = (const uint8_t *)L.t[T_WO].tiled; P.set[0].rows = (int)L.t[T_WO].rows; P.nsets = 1;
+    P.W0[0] = (const uint8_t *)L.t[T_WO].tiled; P.rows[0] = (int)L.t[T_WO].rows; P.nsets = 1;
     if (partial) {
-        P.set[0].y = partial;
+        P.y[0] = partial;
         return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
     }
-    P.set[0].bias[0] = (const half_t *)L.t[T_WO_B].data;
-    P.set[0].y = m->a; P.residual = x;
+    P.b0[0] = (const half_t *)L.t[T_WO_B].data;
+    P.y[0] = m->a; P.residual = x;
     if (m->cfg.parallel_attn || m->cfg.share_input)      // the residual is added once, after the FFN (inference_worker.cc:847-851)
         return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
     return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
@@ -312,13 +312,13 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
     if (moe_slot >= 0) {
         const Tensor &e1 = L.experts[0], &e3 = L.experts[2];
         moe_params(m, L, P, moe_slot, 0);
-        P.set[0].W[0] = (const uint8_t *)e1.tiled; P.set[0].W[1] = (const uint8_t *)e3.tiled;   // (replaced by the table lookup)
-        P.set[0].y = m->t1; P.set[0].rows = (int)e1.rows; P.nsets = 1;
+        P.W0[0] = (const uint8_t *)e1.tiled; P.W1 = (const uint8_t *)e3.tiled;   // (replaced by the table lookup)
+        P.y[0] = m->t1; P.rows[0] = (int)e1.rows; P.nsets = 1;
         if (e3.present()) return launch_dec_gemv<EPI_MOE_GLU, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
         return launch_dec_gemv<EPI_MOE_ACT, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
     }
-    P.set[0].W[0] = (const uint8_t *)L.t[T_W1].tiled; P.set[0].bias[0] = (const half_t *)L.t[T_W1_B].data;
-    P.set[0].y = m->t1; P.set[0].rows = (int)L.t[T_W1].rows; P.nsets = 1;
+    P.W0[0] = (const uint8_t *)L.t[T_W1].tiled; P.b0[0] = (const half_t *)L.t[T_W1_B].data;
+    P.y[0] = m->t1; P.rows[0] = (int)L.t[T_W1].rows; P.nsets = 1;
     // FFN input (inference_worker.cc:853-872): the attention's normalised input (parallel attention), the layer input
     // (shared input) or the attention output + residual; then the FFN pre-norm if the model has one
     const half_t *ff_in = c.parallel_attn ? m->xn : (c.share_input ? x_layer : m->a);
@@ -331,7 +331,7 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
     }
     if (!need_norm) { P.norm_w = nullptr; P.norm_b = nullptr; }
     const bool glu = L.t[T_W3].present();
-    if (glu) { P.set[0].W[1] = (const uint8_t *)L.t[T_W3].tiled; P.set[0].bias[1] = (const half_t *)L.t[T_W3_B].data; }
+    if (glu) { P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.b1 = (const half_t *)L.t[T_W3_B].data; }
     const int dtw = L.t[T_W1].dtype;
     if (need_norm) return glu ? launch_dec_gemv<EPI_GLU, 1>(dtw, P, m->opt_rpw_ffn, m->stream) : launch_dec_gemv<EPI_ACT, 1>(dtw, P, m->opt_rpw_ffn, m->stream);
     return glu ? launch_dec_gemv<EPI_GLU, 0>(dtw, P, m->opt_rpw_ffn, m->stream) : launch_dec_gemv<EPI_ACT, 0>(dtw, P, m->opt_rpw_ffn, m->stream);
@@ -346,23 +346,23 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
         const Tensor &e2 = L.experts[1];
         moe_params(m, L, P, moe_slot, 2);
         P.x = m->t1; P.cols = (int)e2.cols; P.eps = m->cfg.eps;
-        P.set[0].W[0] = (const uint8_t *)e2.tiled; P.set[0].rows = (int)e2.rows; P.nsets = 1;
+        P.W0[0] = (const uint8_t *)e2.tiled; P.rows[0] = (int)e2.rows; P.nsets = 1;
         if (partial) {      // tensor parallel: accumulate the weighted shard products; merged and finished by the caller
-            P.set[0].y = partial; P.moe_acc = partial;
+            P.y[0] = partial; P.moe_acc = partial;
             return launch_dec_gemv<EPI_MOE_ACC, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
         }
-        P.set[0].y = moe_last ? xnext : m->f; P.residual = m->a; P.residual2 = residual2;
+        P.y[0] = moe_last ? xnext : m->f; P.residual = m->a; P.residual2 = residual2;
         if (moe_last) return launch_dec_gemv<EPI_MOE_LAST, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
         return launch_dec_gemv<EPI_MOE_ACC, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
     }
     P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
-    P.set[0].W[0] = (const uint8_t *)L.t[T_W2].tiled; P.set[0].rows = (int)L.t[T_W2].rows; P.nsets = 1;
+    P.W0[0] = (const uint8_t *)L.t[T_W2].tiled; P.rows[0] = (int)L.t[T_W2].rows; P.nsets = 1;
     if (partial) {
-        P.set[0].y = partial;
+        P.y[0] = partial;
         return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
     }
-    P.set[0].bias[0] = (const half_t *)L.t[T_W2_B].data;
-    P.set[0].y = xnext; P.residual = m->a; P.residual2 = residual2;     // + layer input for parallel / shared-input models
+    P.b0[0] = (const half_t *)L.t[T_W2_B].data;
+    P.y[0] = xnext; P.residual = m->a; P.residual2 = residual2;     // + layer input for parallel / shared-input models
     return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
 }
 
@@ -374,8 +374,8 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
         DecGemvParams P; memset(&P, 0, sizeof(P));
         P.x = x; P.norm_w = (const half_t *)m->g[T_OUT_NORM].data; P.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
         P.eps = c.eps; P.cols = c.dim; P.xn_out = m->xn;
-        P.set[0].W[0] = (const uint8_t *)lmt.tiled; P.set[0].rows = (int)lmt.rows; P.nsets = 1;
-        P.set[0].y = logits_out ? logits_out : m->logits;
+        P.W0[0] = (const uint8_t *)lmt.tiled; P.rows[0] = (int)lmt.rows; P.nsets = 1;
+        P.y[0] = logits_out ? logits_out : m->logits;
         return launch_dec_gemv<EPI_PLAIN, 1>(lmt.dtype, P, m->opt_rpw_lm, m->stream);
     }
     if (c.norm_kind != 0 && m->g[T_OUT_NORM].present()) {      // std final norm: op-level kernel, then the plain GEMV
