@@ -19,6 +19,8 @@ HIPCC_FLAGS = [
     "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
     # exact-rounding parity with the host-compiled reference codecs
     "-ffp-contract=off",
+    # leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+), see k_dec_gemv
+    "-mllvm", "-amdgpu-kernarg-preload-count=8",
     "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
 ]
 

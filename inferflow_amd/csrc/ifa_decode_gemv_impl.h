@@ -61,7 +61,7 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ && NJV <= NJCAP) { \
         auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(NJV, NM), EPI, NORM>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        kern<<<grid, dim3(DEC_THREADS), smem, s>>>(P); } break;
+        kern<<<grid, dim3(DEC_THREADS), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, P); } break;
     switch (nj) { IFA_DG(1) IFA_DG(2) IFA_DG(3) IFA_DG(4) IFA_DG(5) IFA_DG(6) IFA_DG(7) IFA_DG(8) }
 #undef IFA_DG
     IFA_LAUNCH_CHECK();

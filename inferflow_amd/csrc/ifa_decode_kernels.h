@@ -392,10 +392,19 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
 //   5. every wave reduces its RW rows as independent chains, then lane i finishes row i
 //      (bias / residual / activation) so the epilogue's loads overlap too.
 template <int DT, int NJ, int RW, int EPI, int NORM>
-__global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
+__global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols,
+                                                          const DecGemvParams P)
 {
+    // px / pnw / pnb / pcols repeat P.x / P.norm_w / P.norm_b / P.cols as leading scalar arguments: with
+    // -amdgpu-kernarg-preload-count they arrive in SGPRs at wave launch, so the activation requests -- the head of
+    // the kernel's critical path -- do not wait for the first scalar load of the argument block
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const XLds L = xlds_carve(smem, P.cols);
+    // the activation requests go out first, from preloaded arguments only (nothing here waits for a scalar load)
+    constexpr int MAXC = NORM ? 2 : 4;
+    XPre<NORM, MAXC> pre;
+    pre.issue(px, pnw, pnb, pcols);
+    const long long t_start = wall_clock64();
+    const XLds L = xlds_carve(smem, pcols);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (SGPR)
     const int gw = blockIdx.x * DEC_WAVES + wave;
@@ -406,7 +415,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
     const int npass = (P.total_rows + RW * W - 1) / (RW * W);
 
     const bool tr = P.trace != nullptr && threadIdx.x == 64;
-    if (tr) P.trace[blockIdx.x * 8 + 0] = wall_clock64();
+    if (tr) P.trace[blockIdx.x * 8 + 0] = t_start;
 
     // MoE: the expert's matrices, looked up once (uniform scalar loads) from the router's choice
     const uint8_t *moeW0 = nullptr, *moeW1 = nullptr;
@@ -434,9 +443,6 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const DecGemvParams P)
     constexpr int D1 = (NM * NJ * Fmt::DW >= 15) ? 1 : 2;
 
     {
-        constexpr int MAXC = NORM ? 2 : 4;
-        XPre<NORM, MAXC> pre;
-        pre.issue(P.x, P.norm_w, P.norm_b, P.cols);
         // the CU's memory queue is FIFO across waves: make sure every wave's activation
         // request is queued before ANY wave floods it with weight requests
         __syncthreads();
