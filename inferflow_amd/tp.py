@@ -258,7 +258,8 @@ class TPRunner:
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.stream):
+            # thread_local: the process group's watchdog thread keeps polling its events while this thread captures
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                 tok = self._step_body(-1, -1)
                 self.ring.index_copy_(0, self.ring_pos, tok)
                 self.ring_pos.add_(1)
