@@ -229,6 +229,12 @@ int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int pr
  * n_steps replays on the worker's stream. */
 int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps,
                      int *out_tokens_host, float *elapsed_ms);
+/* Dynamic batching: ONE new token for each of n queries in one step (QueryStateTable + Infer_Std over several queries,
+ * src/transformer/inference_engine.cc:1054-1220).  Row r is token tokens[r] at position positions[r] of the query whose
+ * KV cache is slot kv_slots[r] (ifa_model_kv_slots; slots must be distinct).  The linear layers run once over the n rows
+ * (the weights are streamed once for all queries), attention per row on its own cache.  logits_out: optional [n][vocab] F16. */
+int ifa_model_decode_batch(ifa_model *m, int n, const int *tokens_host, const int *positions_host, const int *kv_slots_host,
+                           int *next_tokens_host, void *logits_out_dev);
 /* debugging taps: "logits", "hidden", "kcache", "vcache" (device pointers) */
 int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr, size_t *bytes);
 void *ifa_model_stream(ifa_model *m);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ifa_add_by_row_index": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "ifa_model_kv_slots": (_i, [_vp, _i]),
     "ifa_model_select_kv": (_i, [_vp, _i]),
+    "ifa_model_decode_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ifa_model_get_buffer": (_i, [_vp, C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "ifa_model_stream": (_vp, [_vp]),
     "ifa_model_time_kernel": (_i, [_vp, _i, _i, _vp]),

@@ -31,17 +31,22 @@ __device__ __forceinline__ float kv_elem(const uint8_t *cache, size_t row_bytes,
     }
 }
 
+// rows != nullptr: dynamic batching -- row t is ONE new token of its own query: K/V cache and context length come from
+// rows[t] (the query's KV cache set), smem is sized for the longest context of the batch
+struct AttnRow { const uint8_t *kc, *vc; int n_ctx, pad; };
+
 template <bool Q8>
 __global__ void __launch_bounds__(256) k_attention(const half_t *__restrict__ q, const uint8_t *__restrict__ kc,
                                                    const uint8_t *__restrict__ vc, int n_ctx, int q_tokens,
                                                    int prefix_len, int heads, int kv_heads, int head_dim,
                                                    float kq_scale, int alibi, int alibi_base, int alibi_total,
-                                                   half_t *__restrict__ out)
+                                                   half_t *__restrict__ out, const AttnRow *__restrict__ rows = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t *S = reinterpret_cast<half_t *>(smem);                       // [n_ctx]
-    float *red = reinterpret_cast<float *>(smem + (((size_t)n_ctx * 2 + 15) & ~(size_t)15));  // [8]
+    float *red = reinterpret_cast<float *>(smem + (((size_t)n_ctx * 2 + 15) & ~(size_t)15));  // [8]  (n_ctx: batch maximum)
     const int h = blockIdx.x, t = blockIdx.y;
+    if (rows) { kc = rows[t].kc; vc = rows[t].vc; n_ctx = rows[t].n_ctx; prefix_len = n_ctx - 1 - t; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kvh = h / (heads / kv_heads);
     const int kv_dim = kv_heads * head_dim;
@@ -254,6 +259,28 @@ static int launch_attention_mfma(const void *q, const void *kcache, const void *
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_attention_mfma<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         k_attention_mfma<HD, false><<<grid, dim3(256), smem, s>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens,
                                                                   prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base, alibi_total, (half_t *)out);
+    }
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// engine-internal: n query rows, each one token on its own KV cache (rows_dev[t]); max_ctx = longest context
+extern "C" int ifa_attention_rows(const void *q, const void *rows_dev, int kv_dtype, int n_rows, int max_ctx, int heads, int kv_heads,
+                                  int head_dim, float kq_scale, int alibi, int alibi_base_head, int alibi_total_heads, void *out,
+                                  ifa_stream stream)
+{
+    IFA_REQUIRE(q && rows_dev && out && n_rows > 0 && max_ctx > 0, "ifa_attention_rows: bad arguments");
+    const size_t smem = (((size_t)max_ctx * 2 + 15) & ~(size_t)15) + 64;
+    dim3 grid((unsigned)heads, (unsigned)n_rows);
+    const int total_heads = alibi_total_heads > 0 ? alibi_total_heads : heads;
+    if (kv_dtype == Q8_B32T2) {
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_attention<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        k_attention<true><<<grid, dim3(256), smem, ifa_s(stream)>>>((const half_t *)q, nullptr, nullptr, max_ctx, n_rows, 0, heads, kv_heads, head_dim, kq_scale,
+                                                                    alibi, alibi_base_head, total_heads, (half_t *)out, (const AttnRow *)rows_dev);
+    } else {
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        k_attention<false><<<grid, dim3(256), smem, ifa_s(stream)>>>((const half_t *)q, nullptr, nullptr, max_ctx, n_rows, 0, heads, kv_heads, head_dim, kq_scale,
+                                                                     alibi, alibi_base_head, total_heads, (half_t *)out, (const AttnRow *)rows_dev);
     }
     IFA_LAUNCH_CHECK();
     return IFA_OK;

@@ -70,6 +70,9 @@ struct ifa_model {
     // decode graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // dynamic batching tables (forward_batch)
+    void *batch_tab_dev = nullptr, *batch_tab_pin = nullptr;
+    size_t batch_tab_bytes = 0;
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr};
     int attn_split = 0, opt_attn_split_ctx = 512;
@@ -730,6 +733,152 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     return IFA_OK;
 }
 
+// ------------------------------------------------ dynamic batching: one new token for each of n queries
+// (QueryStateTable + Infer_Std over several queries, src/transformer/inference_engine.cc:1054-1220): the linear layers
+// run once over the n rows (weights streamed once: MFMA GEMM), RoPE / KV store / attention per row on the KV cache
+// set of its query.
+struct AttnRowH { const void *kc, *vc; int n_ctx, pad; };
+extern "C" int ifa_attention_rows(const void *q, const void *rows_dev, int kv_dtype, int n_rows, int max_ctx, int heads, int kv_heads,
+                                  int head_dim, float kq_scale, int alibi, int alibi_base_head, int alibi_total_heads, void *out,
+                                  ifa_stream stream);
+extern "C" int ifa_rope_rows(void *x, int head_dim, int heads, int tokens, const int *positions_dev, float theta, int order,
+                             float partial_rotary_factor, ifa_stream stream);
+
+// row r of k / v -> position rows[r].n_ctx - 1 of its query's cache (F16 copy or Q8_B32T2 quantisation, 32 lanes per block)
+template <bool Q8>
+__global__ void __launch_bounds__(256) k_kv_store_rows(const half_t *__restrict__ k, const half_t *__restrict__ v, int kv_dim,
+                                                       size_t row_bytes, const AttnRowH *__restrict__ rows)
+{
+    const int r = blockIdx.x, which = blockIdx.y;
+    const half_t *src = (which ? v : k) + (size_t)r * kv_dim;
+    uint8_t *dst = (uint8_t *)(which ? rows[r].vc : rows[r].kc) + (size_t)(rows[r].n_ctx - 1) * row_bytes;
+    if constexpr (!Q8) {
+        for (int c = threadIdx.x; c < kv_dim; c += 256) reinterpret_cast<half_t *>(dst)[c] = src[c];
+    } else {
+        const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        for (int b = grp; b < kv_dim / 32; b += 8) {      // Tensor_QuantizeQ8_B32T2_Alg2_Kernel (tensor_quant.h:44-82)
+            const float val = h2f(src[b * 32 + lane]);
+            float mx = fabsf(val);
+#pragma unroll
+            for (int m2 = 16; m2 > 0; m2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m2, 32));
+            const float sc = mx / 127;
+            int qv = sc <= 0.000001f ? 0 : (int)roundf(val / sc);
+            qv = min(max(qv, -128), 127);
+            uint8_t *blk = dst + (size_t)b * 34;
+            blk[2 + lane] = (uint8_t)(int8_t)qv;
+            if (lane == 0) *reinterpret_cast<uint16_t *>(blk) = __builtin_bit_cast(uint16_t, f2h(sc));
+        }
+    }
+}
+
+static void *kv_ptr(ifa_model *m, size_t layer, int slot, bool is_v)
+{
+    if (slot == m->cur_slot || m->slots.empty()) return is_v ? m->layers[layer].vcache : m->layers[layer].kcache;
+    const ifa_model::KvSlot &sl = m->slots[(size_t)slot];
+    return is_v ? sl.v[layer] : sl.k[layer];
+}
+
+static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int *pos_host, const int *slot_host, int *next_tokens,
+                         void *logits_out)
+{
+    const ifa_model_config &c = m->cfg;
+    const int n_slots = m->slots.empty() ? 1 : (int)m->slots.size();
+    int max_ctx = 0;
+    for (int r = 0; r < n; r++) {
+        if (pos_host[r] < 0 || pos_host[r] >= c.max_ctx) return ifa_fail(IFA_ERR_ARG, "decode_batch: position %d outside max_ctx %d", pos_host[r], c.max_ctx);
+        if (slot_host[r] < 0 || slot_host[r] >= n_slots) return ifa_fail(IFA_ERR_ARG, "decode_batch: KV slot %d of %d", slot_host[r], n_slots);
+        for (int r2 = 0; r2 < r; r2++) if (slot_host[r2] == slot_host[r]) return ifa_fail(IFA_ERR_ARG, "decode_batch: KV slot %d used twice", slot_host[r]);
+        max_ctx = std::max(max_ctx, pos_host[r] + 1);
+    }
+    int rc = ensure_scratch(m, n);
+    if (rc) return rc;
+    ifa_stream s = m->stream;
+    const int T = n;
+    const size_t D = c.dim, KVD = (size_t)c.kv_heads * c.head_dim, L_ = m->layers.size();
+    if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return ifa_fail(IFA_ERR_STATE, "F16 embeddings not set");
+    // per-step tables: positions, and for every layer the (k cache, v cache, context) of each row's query
+    const size_t tab_bytes = L_ * (size_t)n * sizeof(AttnRowH) + (size_t)n * sizeof(int);
+    if (tab_bytes > m->batch_tab_bytes) {
+        if (m->batch_tab_dev) IFA_HIP_CHECK(hipFree(m->batch_tab_dev));
+        if (m->batch_tab_pin) IFA_HIP_CHECK(hipHostFree(m->batch_tab_pin));
+        IFA_HIP_CHECK(hipMalloc(&m->batch_tab_dev, tab_bytes));
+        IFA_HIP_CHECK(hipHostMalloc(&m->batch_tab_pin, tab_bytes, hipHostMallocDefault));
+        m->batch_tab_bytes = tab_bytes;
+    }
+    AttnRowH *rows_h = (AttnRowH *)m->batch_tab_pin;
+    int *pos_pin = (int *)(rows_h + L_ * (size_t)n);
+    for (size_t l = 0; l < L_; l++)
+        for (int r = 0; r < n; r++) {
+            AttnRowH &a = rows_h[l * (size_t)n + r];
+            a.kc = kv_ptr(m, l, slot_host[r], false); a.vc = kv_ptr(m, l, slot_host[r], true); a.n_ctx = pos_host[r] + 1; a.pad = 0;
+        }
+    for (int r = 0; r < n; r++) pos_pin[r] = pos_host[r];
+    IFA_HIP_CHECK(hipMemcpyAsync(m->batch_tab_dev, m->batch_tab_pin, tab_bytes, hipMemcpyHostToDevice, m->stream));
+    const AttnRowH *rows_d = (const AttnRowH *)m->batch_tab_dev;
+    const int *pos_d = (const int *)(rows_d + L_ * (size_t)n);
+    IFA_HIP_CHECK(hipMemcpyAsync(m->tokens_dev, tokens_host, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, m->stream));
+    k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->tokens_dev, T, (int)D,
+                                                                      (int)m->g[T_EMBD].rows, m->x);
+    IFA_LAUNCH_CHECK();
+    half_t *x = m->x;
+    const Tensor none;
+    for (int l = 0; l < c.layers; l++) {
+        Layer &L = m->layers[(size_t)l];
+        const half_t *attn_in = x;
+        if (L.t[T_ATTN_NORM].present()) {
+            if ((rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn))) return rc;
+            attn_in = m->xn;
+        }
+        if ((rc = matmul(m, attn_in, T, L.t[T_WQ], L.t[T_WQ_B], m->q))) return rc;
+        if ((rc = matmul(m, attn_in, T, L.t[T_WK], L.t[T_WK_B], m->k))) return rc;
+        if ((rc = matmul(m, attn_in, T, L.t[T_WV], L.t[T_WV_B], m->v))) return rc;
+        if (c.rope_order != 0) {
+            if ((rc = ifa_rope_rows(m->q, c.head_dim, c.heads, T, pos_d, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
+            if ((rc = ifa_rope_rows(m->k, c.head_dim, c.kv_heads, T, pos_d, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
+        }
+        const AttnRowH *lr = rows_d + (size_t)l * (size_t)n;
+        if (c.kv_dtype == Q8_B32T2) k_kv_store_rows<true><<<dim3((unsigned)n, 2), dim3(256), 0, m->stream>>>(m->k, m->v, (int)KVD, m->kv_row_bytes, lr);
+        else k_kv_store_rows<false><<<dim3((unsigned)n, 2), dim3(256), 0, m->stream>>>(m->k, m->v, (int)KVD, m->kv_row_bytes, lr);
+        IFA_LAUNCH_CHECK();
+        if ((rc = ifa_attention_rows(m->q, lr, c.kv_dtype, n, max_ctx, c.heads, c.kv_heads, c.head_dim, c.use_alibi ? 1.0f : c.kq_scale,
+                                     c.use_alibi, c.tp_rank * c.heads, c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
+        if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
+        if (!c.parallel_attn && !c.share_input)
+            if ((rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
+        const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
+        const half_t *ff_n = ff_in;
+        if (L.t[T_FFN_NORM].present()) {
+            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn))) return rc;
+            ff_n = m->hn;
+        }
+        if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
+            if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
+        } else {
+            if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
+        }
+        if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
+        if (c.parallel_attn || c.share_input)
+            if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
+        std::swap(m->x, m->f);
+        x = m->x;
+    }
+    const half_t *hfin = x;
+    if (m->g[T_OUT_NORM].present()) {
+        if ((rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn))) return rc;
+        hfin = m->xn;
+    }
+    const Tensor &lm = m->g[T_LM_HEAD];
+    const size_t V = lm.rows;
+    if ((rc = matmul(m, hfin, T, lm, none, m->logits))) return rc;
+    if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
+    for (int r = 0; r < n; r++)
+        if ((rc = ifa_argmax(m->logits + (size_t)r * V, V, m->state + 8 + r, s))) return rc;
+    IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (next_tokens) for (int r = 0; r < n; r++) next_tokens[r] = m->host_pinned[8 + r];
+    return IFA_OK;
+}
+
 extern "C" {
 
 int ifa_model_create(const ifa_model_config *cfg, ifa_model **out)
@@ -771,6 +920,8 @@ int ifa_model_destroy(ifa_model *m)
         if (L.kcache) (void)hipFree(L.kcache);
         if (L.vcache) (void)hipFree(L.vcache);
     }
+    if (m->batch_tab_dev) (void)hipFree(m->batch_tab_dev);
+    if (m->batch_tab_pin) (void)hipHostFree(m->batch_tab_pin);
     if (m->attn_ws.S) (void)hipFree(m->attn_ws.S);
     if (m->attn_ws.lmax) (void)hipFree(m->attn_ws.lmax);
     if (m->attn_ws.opart) (void)hipFree(m->attn_ws.opart);
@@ -1030,6 +1181,15 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     if (out_tokens_host) memcpy(out_tokens_host, m->host_pinned + 8, sizeof(int) * (size_t)n_steps);
     return IFA_OK;
+}
+
+int ifa_model_decode_batch(ifa_model *m, int n, const int *tokens_host, const int *positions_host, const int *kv_slots_host,
+                           int *next_tokens_host, void *logits_out_dev)
+{
+    IFA_REQUIRE(m && m->finalized, "ifa_model_decode_batch: model not finalized");
+    IFA_REQUIRE(n >= 1 && n <= ifa_model::RING && tokens_host && positions_host && kv_slots_host, "ifa_model_decode_batch: bad arguments");
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    return forward_batch(m, n, tokens_host, positions_host, kv_slots_host, next_tokens_host, logits_out_dev);
 }
 
 int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr, size_t *bytes)

@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x,
 
 // PosEmbedding_Rope_Order2_Kernel / _Std_Kernel (unary_tensor_opr.h:661-740)
 __global__ void __launch_bounds__(256) k_rope(half_t *__restrict__ x, int head_dim, int heads, int tokens, int pos0,
-                                              float theta, int order, int rope_dims, int rope_cols)
+                                              float theta, int order, int rope_dims, int rope_cols,
+                                              const int *__restrict__ pos_tab = nullptr)
 {
     const int half_dim = head_dim / 2;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) k_rope(half_t *__restrict__ x, int head_d
     const size_t rowi = idx / half_dim;
     const int t = (int)(rowi / heads);
     half_t *row = x + rowi * head_dim;
-    rope_rotate(row, col, pos0 + t, theta, order, rope_dims, rope_cols);
+    rope_rotate(row, col, pos_tab ? pos_tab[t] : pos0 + t, theta, order, rope_dims, rope_cols);   // pos_tab: one position per row
 }
 
 // PosEmbedding_Alibi_Std_Kernel (unary_tensor_opr.h:742-762)
@@ -298,6 +299,22 @@ int ifa_rope(void *x, int head_dim, int heads, int tokens, int pos0, float theta
     int rope_dims = rope_cols;
     size_t total = (size_t)tokens * heads * (head_dim / 2);
     k_rope<<<dim3(ifa_cdiv(total, 256)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, pos0, theta, order, rope_dims, rope_cols);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_rope_rows(void *x, int head_dim, int heads, int tokens, const int *positions_dev, float theta, int order,
+                  float partial_rotary_factor, ifa_stream stream)
+{
+    IFA_REQUIRE(x && positions_dev, "ifa_rope_rows: null pointer");
+    IFA_REQUIRE(order == 1 || order == 2, "ifa_rope_rows: order %d", order);
+    IFA_REQUIRE(head_dim > 0 && head_dim % 2 == 0, "ifa_rope_rows: head_dim %d", head_dim);
+    if (tokens <= 0 || heads <= 0) return IFA_OK;
+    if (partial_rotary_factor <= 0) partial_rotary_factor = 1.0f;
+    int rope_cols = (int)(head_dim * partial_rotary_factor + 0.5f);
+    size_t total = (size_t)tokens * heads * (head_dim / 2);
+    k_rope<<<dim3(ifa_cdiv(total, 256)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, 0, theta, order, rope_cols,
+                                                                       rope_cols, positions_dev);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }

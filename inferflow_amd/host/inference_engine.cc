@@ -169,6 +169,47 @@ bool InferenceEngine::Infer(InferenceResult &res)
     const auto t0 = std::chrono::steady_clock::now();
     const int V = spec_.hyper_params.vocab_size;
     const int max_ctx = spec_.max_context_len > 0 ? spec_.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
+    // dynamic batching: every query that advances by exactly one token joins ONE step -- the linear layers stream
+    // the weights once for all of them (ifa_model_decode_batch); prefills and single queries take the paths below
+    std::vector<Query *> batch;
+    for (auto &kv : queries_) {
+        Query &q = kv.second;
+        if (!q.ended && (int)q.tokens.size() < max_ctx && q.processed > 0 && (int)q.tokens.size() - q.processed == 1) batch.push_back(&q);
+    }
+    if (batch.size() >= 2) {
+        const int n = (int)batch.size();
+        std::vector<int> toks((size_t)n), pos((size_t)n), slots((size_t)n), next((size_t)n, -1);
+        for (int r = 0; r < n; r++) { toks[(size_t)r] = batch[(size_t)r]->tokens.back(); pos[(size_t)r] = batch[(size_t)r]->processed; slots[(size_t)r] = batch[(size_t)r]->kv_slot; }
+        void *lg = nullptr;
+        if (config_.return_output_tensors) {
+            if ((size_t)n > logits_rows_) {
+                if (logits_dev_) ifa_free(logits_dev_);
+                logits_dev_ = nullptr; logits_rows_ = 0;
+                if (ifa_malloc(&logits_dev_, (size_t)n * V * 2) != IFA_OK) { EngineSetError("logits buffer: %s", ifa_last_error()); return false; }
+                logits_rows_ = (size_t)n;
+            }
+            lg = logits_dev_;
+        }
+        if (ifa_model_decode_batch(model_, n, toks.data(), pos.data(), slots.data(), next.data(), lg) != IFA_OK) {
+            EngineSetError("batched decode step failed: %s", ifa_last_error()); return false;
+        }
+        std::vector<uint16_t> all;
+        if (lg) {
+            all.resize((size_t)n * V);
+            if (ifa_memcpy_d2h(all.data(), lg, all.size() * 2, ifa_model_stream(model_)) != IFA_OK || ifa_stream_sync(ifa_model_stream(model_)) != IFA_OK) {
+                EngineSetError("logits copy: %s", ifa_last_error()); return false;
+            }
+        }
+        for (int r = 0; r < n; r++) {
+            Query &q = *batch[(size_t)r];
+            QueryInferenceResult item; item.query_id = q.id; item.prefix_len = q.processed;
+            if (lg) { item.output_rows = 1; item.output_cols = V; item.output_tensor.assign(all.begin() + (size_t)r * V, all.begin() + (size_t)(r + 1) * V); }
+            q.processed = (int)q.tokens.size();
+            IdWeight w; w.id = next[(size_t)r]; w.weight = 1.0f;
+            item.next_tokens.push_back(w);
+            res.items.push_back(std::move(item));
+        }
+    }
     for (auto &kv : queries_) {
         Query &q = kv.second;
         if (q.ended) continue;

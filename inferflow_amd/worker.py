@@ -67,6 +67,24 @@ class DecodeWorker:
                                       C.byref(nxt)))
         return nxt.value
 
+    def kv_slots(self, n):
+        """Independent KV caches, one per concurrent query (slot 0 exists after finalize)."""
+        check(lib().ifa_model_kv_slots(self._h, int(n)))
+
+    def select_kv(self, slot):
+        check(lib().ifa_model_select_kv(self._h, int(slot)))
+
+    def decode_batch(self, tokens, positions, slots, logits_out=None):
+        """One new token for each of n queries (dynamic batching); returns the n greedy next tokens."""
+        toks = np.ascontiguousarray(tokens, np.int32)
+        pos = np.ascontiguousarray(positions, np.int32)
+        sl = np.ascontiguousarray(slots, np.int32)
+        out = np.zeros(toks.size, np.int32)
+        check(lib().ifa_model_decode_batch(self._h, toks.size, toks.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
+                                           sl.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                           C.c_void_p(logits_out.data_ptr()) if logits_out is not None else None))
+        return out
+
     def decode(self, first_token, start_pos, n_steps, timed=True):
         """Greedy batch-1 decode with the fused kernels; returns (tokens, gpu_ms)."""
         out = np.zeros(n_steps, np.int32)
