@@ -111,6 +111,7 @@ bool InferenceEngine::LoadConfig(InferenceConfig &config, const std::string &con
     cfg.GetItem(section, "max_concurrent_queries", config.max_concurrent_queries);
     cfg.GetItem(section, "cpu_threads", config.cpu_threads);
     cfg.GetItem(section, "return_output_tensors", config.return_output_tensors);
+    cfg.GetItem(section, "dynamic_batching_min_queries", config.dynamic_batching_min_queries);
     cfg.GetItem(section, "is_study_mode", config.debug.is_study_mode);
     cfg.GetItem(section, "show_tensors", config.debug.show_tensors);
     return true;
@@ -176,7 +177,7 @@ bool InferenceEngine::Infer(InferenceResult &res)
         Query &q = kv.second;
         if (!q.ended && (int)q.tokens.size() < max_ctx && q.processed > 0 && (int)q.tokens.size() - q.processed == 1) batch.push_back(&q);
     }
-    if (batch.size() >= 2) {
+    if ((int)batch.size() >= std::max(2, config_.dynamic_batching_min_queries)) {
         const int n = (int)batch.size();
         std::vector<int> toks((size_t)n), pos((size_t)n), slots((size_t)n), next((size_t)n, -1);
         for (int r = 0; r < n; r++) { toks[(size_t)r] = batch[(size_t)r]->tokens.back(); pos[(size_t)r] = batch[(size_t)r]->processed; slots[(size_t)r] = batch[(size_t)r]->kv_slot; }

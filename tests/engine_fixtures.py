@@ -96,6 +96,7 @@ decoder_cpu_layer_count = 0
 cpu_threads = 8
 max_concurrent_queries = {maxq}
 return_output_tensors = {ret}
+dynamic_batching_min_queries = 2
 
 [model.{name}]
 model_dir = ${{config_dir}}

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Aggregate decode rate with dynamic batching (Llama-2-7B Q4): n queries advance one token per step."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from inferflow_amd import dtypes as dt, synth
+shape = sys.argv[1] if len(sys.argv) > 1 else "llama2_7b"
+wk, _, s = synth.build(shape, dt.Q4_B32T1A, dt.F16, max_ctx=256)
+NMAX = 32
+wk.kv_slots(NMAX)
+rng = np.random.default_rng(3)
+first = []
+for i in range(NMAX):
+    wk.select_kv(i)
+    first.append(wk.forward(rng.integers(3, s["vocab"], 16).astype(np.int32), 0))
+for n in (1, 2, 4, 8, 16, 32):
+    cur, pos = list(first[:n]), [16] * n
+    steps = 24
+    for w in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for st in range(steps):
+            if n == 1:
+                wk.select_kv(0)
+                cur = [int(wk.decode(cur[0], pos[0], 1)[0][0])]
+            else:
+                cur = [int(t) for t in wk.decode_batch(cur, pos, list(range(n)))]
+            pos = [p + 1 for p in pos]
+        torch.cuda.synchronize(); dt_s = time.perf_counter() - t0
+    print(json.dumps({"shape": shape, "queries": n, "ms_per_step": dt_s * 1e3 / steps, "aggregate_tok_s": n * steps / dt_s}), flush=True)
