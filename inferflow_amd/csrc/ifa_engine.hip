@@ -11,6 +11,7 @@
 //    device (no host round trip inside a batch of steps).
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include "ifa_host.h"
@@ -73,9 +74,10 @@ struct ifa_model {
     // dynamic batching tables (forward_batch)
     void *batch_tab_dev = nullptr, *batch_tab_pin = nullptr;
     size_t batch_tab_bytes = 0;
+    std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr};
-    int attn_split = 0, opt_attn_split_ctx = 512;
+    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -94,6 +96,8 @@ static void drop_graphs(ifa_model *m)
         if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
         if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
     }
+    for (auto &kv : m->batch_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    m->batch_graphs.clear();
 }
 
 static void free_tensor(Tensor &t)
@@ -797,8 +801,9 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     const size_t D = c.dim, KVD = (size_t)c.kv_heads * c.head_dim, L_ = m->layers.size();
     if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return ifa_fail(IFA_ERR_STATE, "F16 embeddings not set");
     // per-step tables: positions, and for every layer the (k cache, v cache, context) of each row's query
-    const size_t tab_bytes = L_ * (size_t)n * sizeof(AttnRowH) + (size_t)n * sizeof(int);
+    const size_t tab_bytes = L_ * (size_t)n * sizeof(AttnRowH) + 2 * (size_t)n * sizeof(int);
     if (tab_bytes > m->batch_tab_bytes) {
+        drop_graphs(m);                            // the captured steps hold the old table addresses
         if (m->batch_tab_dev) IFA_HIP_CHECK(hipFree(m->batch_tab_dev));
         if (m->batch_tab_pin) IFA_HIP_CHECK(hipHostFree(m->batch_tab_pin));
         IFA_HIP_CHECK(hipMalloc(&m->batch_tab_dev, tab_bytes));
@@ -812,12 +817,32 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
             AttnRowH &a = rows_h[l * (size_t)n + r];
             a.kc = kv_ptr(m, l, slot_host[r], false); a.vc = kv_ptr(m, l, slot_host[r], true); a.n_ctx = pos_host[r] + 1; a.pad = 0;
         }
-    for (int r = 0; r < n; r++) pos_pin[r] = pos_host[r];
-    IFA_HIP_CHECK(hipMemcpyAsync(m->batch_tab_dev, m->batch_tab_pin, tab_bytes, hipMemcpyHostToDevice, m->stream));
+    for (int r = 0; r < n; r++) { pos_pin[r] = pos_host[r]; pos_pin[n + r] = tokens_host[r]; }
     const AttnRowH *rows_d = (const AttnRowH *)m->batch_tab_dev;
     const int *pos_d = (const int *)(rows_d + L_ * (size_t)n);
-    IFA_HIP_CHECK(hipMemcpyAsync(m->tokens_dev, tokens_host, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, m->stream));
-    k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->tokens_dev, T, (int)D,
+    const int *tok_d = pos_d + n;
+    // Everything the device does in a step depends on the step only through the tables above (fixed addresses), so
+    // for dense models the whole step -- table upload included -- is captured once per batch size and replayed.
+    bool has_moe = false;
+    for (const Layer &Lc : m->layers) has_moe = has_moe || (c.experts > 0 && Lc.t[T_MOE_GATE].present());
+    // (measured on Llama-2-7B Q4: the batched step is bound by the small-T GEMM kernels, ~6.7 ms with or without the
+    //  graph, so replay is opt-in: set_option("batch_graph", 1))
+    const bool use_graph = m->opt_batch_graph && m->opt_graph && !has_moe && !logits_out;
+    const int attn_ctx = use_graph ? c.max_ctx : max_ctx;     // LDS sizing of the attention kernel must not depend on the step
+    if (use_graph) {
+        auto it = m->batch_graphs.find(n);
+        if (it != m->batch_graphs.end()) {
+            IFA_HIP_CHECK(hipGraphLaunch(it->second, m->stream));
+            IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+            if (next_tokens) for (int r = 0; r < n; r++) next_tokens[r] = m->host_pinned[8 + r];
+            return IFA_OK;
+        }
+        IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+        IFA_HIP_CHECK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    }
+    auto body = [&]() -> int {
+    IFA_HIP_CHECK(hipMemcpyAsync(m->batch_tab_dev, m->batch_tab_pin, tab_bytes, hipMemcpyHostToDevice, m->stream));
+    k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, tok_d, T, (int)D,
                                                                       (int)m->g[T_EMBD].rows, m->x);
     IFA_LAUNCH_CHECK();
     half_t *x = m->x;
@@ -840,7 +865,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         if (c.kv_dtype == Q8_B32T2) k_kv_store_rows<true><<<dim3((unsigned)n, 2), dim3(256), 0, m->stream>>>(m->k, m->v, (int)KVD, m->kv_row_bytes, lr);
         else k_kv_store_rows<false><<<dim3((unsigned)n, 2), dim3(256), 0, m->stream>>>(m->k, m->v, (int)KVD, m->kv_row_bytes, lr);
         IFA_LAUNCH_CHECK();
-        if ((rc = ifa_attention_rows(m->q, lr, c.kv_dtype, n, max_ctx, c.heads, c.kv_heads, c.head_dim, c.use_alibi ? 1.0f : c.kq_scale,
+        if ((rc = ifa_attention_rows(m->q, lr, c.kv_dtype, n, attn_ctx, c.heads, c.kv_heads, c.head_dim, c.use_alibi ? 1.0f : c.kq_scale,
                                      c.use_alibi, c.tp_rank * c.heads, c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
         if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
         if (!c.parallel_attn && !c.share_input)
@@ -874,6 +899,21 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     for (int r = 0; r < n; r++)
         if ((rc = ifa_argmax(m->logits + (size_t)r * V, V, m->state + 8 + r, s))) return rc;
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+    return IFA_OK;
+    };
+    rc = body();
+    if (use_graph) {
+        // forward ops swap m->x / m->f per layer: an odd layer count would leave them exchanged between replays
+        hipGraph_t gph = nullptr;
+        hipError_t e = hipStreamEndCapture(m->stream, &gph);
+        if (rc) { if (gph) (void)hipGraphDestroy(gph); return rc; }
+        if (e != hipSuccess) return ifa_fail(IFA_ERR_HIP, "hipStreamEndCapture (batched step): %s", hipGetErrorString(e));
+        hipGraphExec_t ex = nullptr;
+        IFA_HIP_CHECK(hipGraphInstantiate(&ex, gph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(gph);
+        m->batch_graphs[n] = ex;
+        IFA_HIP_CHECK(hipGraphLaunch(ex, m->stream));
+    } else if (rc) return rc;
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (next_tokens) for (int r = 0; r < n; r++) next_tokens[r] = m->host_pinned[8 + r];
     return IFA_OK;
@@ -1098,7 +1138,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
