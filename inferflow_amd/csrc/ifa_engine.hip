@@ -77,7 +77,7 @@ struct ifa_model {
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr};
-    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0;
+    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -429,6 +429,8 @@ __global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k,
     for (; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
 }
 
+extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens,
+                                const void *bias_f16, void *y_f16, ifa_stream stream);
 static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const Tensor &bias, half_t *C);
 static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y);
 
@@ -548,6 +550,11 @@ static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const T
         int rc = ifa_quantize_act_q8(A, 1, K, m->xq, s);
         if (rc) return rc;
         return ifa_gemv(W.dtype, W.data, N, K, Q8_B32T2, m->xq, b, C, s);
+    }
+    // a handful of rows (dynamic batching, very short prompts): weight-streaming kernel on the tiled layout
+    if (T >= 2 && T <= 8 && is_q4(W.dtype) && W.tiled && m->opt_gemm_rows) {
+        int rc = ifa_gemm_rows_q4(W.tiled, N, K, A, (size_t)T, b, C, s);
+        if (rc != IFA_ERR_STATE) return rc;
     }
     // T > 1: MFMA GEMM with the dequantisation fused in (the reference dequantises the whole
     // tensor and calls cublasGemmEx; same arithmetic: half weights x half activations, fp32 accumulate)
@@ -1138,7 +1145,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;

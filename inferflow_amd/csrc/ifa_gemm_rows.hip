@@ -1,0 +1,165 @@
+// ifa_gemm_rows.hip -- Y[T][N] = X[T][K] . W[N][K]^T for a HANDFUL of rows (2 <= T <= 8): dynamic batching of decode
+// steps and very short prompts.
+//
+// Same contract as ifa_gemm (the reference's T > 1 branch: weights dequantised to half, half activations, fp32
+// accumulation, one F16 rounding, bias as a half add: MatrixMultiplication, inference_worker.cc:2374-2415), but
+// organised like the decode GEMV instead of MFMA tiles: at this size the layer is a pure weight stream, and a 32x32
+// MFMA tile with 2-8 live rows cannot keep enough bytes in flight (measured 16 us per 4096^2 Q4 matrix against ~4 us
+// of streaming).  One workgroup per CU, every wave owns RW rows per pass from the row-local plane layout
+// (ifa_tiled.h), all T activation rows sit in LDS in a chunk-major image (lane-consecutive 16-byte reads), each
+// weight block is dequantised once and multiplied into the T accumulators with v_fma_mix (half operands, fp32 sum).
+#include <algorithm>
+#include "ifa_host.h"
+#include "ifa_decode_kernels.h"
+
+namespace ifa {
+
+typedef _Float16 half8r __attribute__((ext_vector_type(8)));
+
+constexpr int GR_THREADS = 512, GR_WAVES = 8;
+
+// LDS image: 16-byte chunk q (0..3) of block b of token t at ((t * 4 + q) * nblk + b) * 16
+// A wave walks its rows block-column by block-column (64 blocks = 2048 weights of each of its RW rows per step); the
+// next step's 20 bytes per lane and row are requested before the current ones are multiplied.
+template <int TB, int RW>
+__global__ void __launch_bounds__(GR_THREADS) k_gemm_rows_q4(const uint8_t *__restrict__ Wt, int rows, int nblk,
+                                                             const half_t *__restrict__ X, int T, int t0,
+                                                             const half_t *__restrict__ bias, half_t *__restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gw = blockIdx.x * GR_WAVES + wave, W = gridDim.x * GR_WAVES;
+    const int K = nblk * 32;
+    const size_t row_bytes = tiled_row_bytes(Q4_B32T1A, (size_t)nblk);
+    // ---- activations first (the CU's memory queue is FIFO: see k_dec_gemv), then the first weights
+    const int nchunks = TB * nblk * 4;
+    for (int c = tid; c < nchunks; c += GR_THREADS) {
+        const int t = c / (nblk * 4), rem = c - t * (nblk * 4);      // rem = b * 4 + q in the source row
+        const int b = rem >> 2, q = rem & 3;
+        const int tt = min(t0 + t, T - 1);                            // rows past T: duplicates, never stored
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(X + (size_t)tt * K + (size_t)rem * 8);
+        *reinterpret_cast<u32x4 *>(smem + ((size_t)(t * 4 + q) * nblk + b) * 16) = v;
+    }
+    const int nj = (nblk + 63) / 64;
+    const int npass = (rows + RW * W - 1) / (RW * W);
+    const int nsteps = npass * nj;
+    struct Slice { u32x4 c[RW]; uint32_t sb[RW]; };
+    auto fetch = [&](Slice &sl, int step) {
+        const int pass = step / nj, j = step - pass * nj;
+        const int blk = min(lane + 64 * j, nblk - 1);
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            const int v = min((pass * RW + i) * W + gw, rows - 1);
+            const uint8_t *wrow = Wt + (size_t)v * row_bytes;
+            sl.c[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow + (size_t)blk * 16));
+            sl.sb[i] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(wrow + (size_t)nblk * 16 + (size_t)blk * 4));
+        }
+    };
+    Slice cur, nxt;
+    fetch(cur, 0);
+    if (nsteps > 1) fetch(nxt, 1);
+    __syncthreads();
+    if (gw >= rows) return;
+    float acc[RW][TB];
+#pragma unroll
+    for (int i = 0; i < RW; i++)
+#pragma unroll
+        for (int t = 0; t < TB; t++) acc[i][t] = 0.0f;
+    for (int step = 0; step < nsteps; step++) {
+        const int pass = step / nj, j = step - pass * nj;
+        const int blk = lane + 64 * j;
+        const bool ok = blk < nblk;
+        const int bc = min(blk, nblk - 1);
+        float base[RW], scale[RW];
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            base[i] = hbits2f((uint16_t)(cur.sb[i] & 0xFFFFu));
+            scale[i] = ok ? hbits2f((uint16_t)(cur.sb[i] >> 16)) : 0.0f;
+            if (!ok) base[i] = 0.0f;                                  // lanes past the row end contribute exactly 0
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            half8r xv[TB];
+#pragma unroll
+            for (int t = 0; t < TB; t++) xv[t] = *reinterpret_cast<const half8r *>(smem + ((size_t)(t * 4 + q) * nblk + bc) * 16);
+#pragma unroll
+            for (int i = 0; i < RW; i++) {
+                const uint32_t cw = cur.c[i][q];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    // byte (e>>1) of the word: low nibble = element 8q+2(e>>1), high nibble = the next one
+                    const uint32_t nib = (cw >> (8 * (e >> 1) + 4 * (e & 1))) & 0xFu;
+                    const half_t wh = f2h(__builtin_fmaf((float)nib, scale[i], base[i]));   // the reference's dequantised half
+#pragma unroll
+                    for (int t = 0; t < TB; t++) acc[i][t] = __builtin_fmaf((float)wh, (float)xv[t][e], acc[i][t]);
+                }
+            }
+        }
+        cur = nxt;
+        if (step + 2 < nsteps) fetch(nxt, step + 2);
+        if (j + 1 < nj) continue;
+        // ---- end of a pass: reduce, lane (i * TB + t) finishes element (row i, token t)
+        float mine = 0.0f;
+#pragma unroll
+        for (int i = 0; i < RW; i++)
+#pragma unroll
+            for (int t = 0; t < TB; t++) {
+                const float r = wave_sum(acc[i][t]);
+                if (lane == i * TB + t) mine = r;
+                acc[i][t] = 0.0f;
+            }
+        if (lane < RW * TB) {
+            const int i = lane / TB, t = lane % TB;
+            const int row = (pass * RW + i) * W + gw;
+            if (row < rows && t0 + t < T) {
+                half_t y = f2h(mine);
+                if (bias) y = f2h(h2f(y) + h2f(bias[row]));
+                Y[(size_t)(t0 + t) * rows + row] = y;
+            }
+        }
+    }
+}
+
+} // namespace ifa
+
+using namespace ifa;
+
+static int gr_num_cus()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// Q4_B32T1 tiled weights only; returns IFA_ERR_STATE (untouched outputs) when the shape is not covered so that the
+// caller can fall back to ifa_gemm.
+extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens,
+                                const void *bias_f16, void *y_f16, ifa_stream stream)
+{
+    IFA_REQUIRE(Wt_tiled && x_f16 && y_f16, "ifa_gemm_rows_q4: null pointer");
+    if (tokens < 2 || tokens > 8 || cols % 32 != 0 || rows == 0) return IFA_ERR_STATE;
+    const int nblk = (int)(cols / 32);
+    hipStream_t s = ifa_s(stream);
+    int wgs = std::min(gr_num_cus(), (int)((rows + GR_WAVES - 1) / GR_WAVES));
+    if (wgs < 1) wgs = 1;
+    // tokens per launch: the LDS image is TB * cols * 2 bytes (<= 128 KiB)
+    int tb = tokens <= 2 ? 2 : (tokens <= 4 ? 4 : 8);
+    while ((size_t)tb * cols * 2 > 128 * 1024 && tb > 2) tb /= 2;
+    if ((size_t)tb * cols * 2 > 128 * 1024) return IFA_ERR_STATE;
+    for (size_t t0 = 0; t0 < tokens; t0 += (size_t)tb) {
+        const size_t smem = (size_t)tb * cols * 2;
+#define IFA_GR(TBV, RWV) { auto kern = k_gemm_rows_q4<TBV, RWV>; \
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        kern<<<dim3((unsigned)wgs), dim3(GR_THREADS), smem, s>>>((const uint8_t *)Wt_tiled, (int)rows, nblk, (const half_t *)x_f16, (int)tokens, (int)t0, \
+                                                                  (const half_t *)bias_f16, (half_t *)y_f16); }
+        if (tb == 2) IFA_GR(2, 2) else if (tb == 4) IFA_GR(4, 2) else IFA_GR(8, 2)
+#undef IFA_GR
+        IFA_LAUNCH_CHECK();
+    }
+    return IFA_OK;
+}

@@ -70,8 +70,8 @@ struct InferenceConfig {
     std::map<std::string, std::string> prompt_templates;
     bool return_output_tensors = false;
     // extension: queries advancing by one token share ONE batched step (MFMA GEMM over the rows) from this many on;
-    // below it each runs the fused single-query decode (measured break-even on Llama-2-7B Q4: ~5 queries)
-    int dynamic_batching_min_queries = 5;
+    // below it each runs the fused single-query decode (measured break-even on Llama-2-7B Q4: 3 queries)
+    int dynamic_batching_min_queries = 3;
     DebugOptions debug;
 };
 

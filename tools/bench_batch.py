@@ -8,6 +8,7 @@ shape = sys.argv[1] if len(sys.argv) > 1 else "llama2_7b"
 wk, _, s = synth.build(shape, dt.Q4_B32T1A, dt.F16, max_ctx=256)
 NMAX = 32
 wk.kv_slots(NMAX)
+if "graph" in sys.argv: wk.set_option("batch_graph", 1)
 rng = np.random.default_rng(3)
 first = []
 for i in range(NMAX):
