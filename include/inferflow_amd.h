@@ -183,6 +183,10 @@ typedef struct {
     int experts, moe_top_k, moe_norm_topk;
     int tp_rank, tp_size;/* tensor-parallel shard of this worker (heads/kv_heads/ffn are per-shard) */
     int device;          /* HIP device ordinal */
+    /* RMS weight = base + w (attn_pre_norm_base / ffn_pre_norm_base / output_norm_base: Gemma) and TensorOpr::Scale of
+     * the attention output, the FFN output and the last layer's output (attn_out_scale / ffn_out_scale / out_scale:
+     * MiniCPM; inference_worker.cc:568-570, 842-843, 928-929).  Scales <= 0 mean 1. */
+    float attn_norm_base, ffn_norm_base, out_norm_base, attn_out_scale, ffn_out_scale, out_scale;
 } ifa_model_config;
 
 /* tensor ids for ifa_model_set_tensor (StdDeviceNetwork, src/transformer/model.h:168-276) */

@@ -108,6 +108,7 @@ static void free_tensor(Tensor &t)
 }
 
 static bool is_q4(int dt) { return dt == Q4_B32T1A || dt == Q4_B32T1B; }
+static bool scale_on(float s) { return s < 0.9999f || s > 1.0001f; }     // the reference's test for "scale != 1"
 // same tiled layout and arithmetic (the A/B variants differ only in how the quantizer picked base/scale)
 static bool same_fmt(int a, int b) { return a == b || (is_q4(a) && is_q4(b)); }
 
@@ -158,6 +159,8 @@ static bool fused_supported(const ifa_model *m, std::string *why)
     const ifa_model_config &c = m->cfg;
     auto fail = [&](const char *s) { if (why) *why = s; return false; };
     if (c.experts > 64 || (c.experts > 0 && (c.moe_top_k < 1 || c.moe_top_k > 8))) return fail("MoE: experts / top_k out of range");
+    if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale))
+        return fail("models with output scales (attn_out_scale / ffn_out_scale / out_scale) use the op-by-op path");
     if (c.experts > 0 && (c.norm_kind != 0 || c.parallel_attn || c.share_input)) return fail("MoE layers need the sequential RMS-norm wiring");
     if (!c.full_quant_gemv) return fail("full_quant_gemv disabled");
     if (c.head_dim != 32 && c.head_dim != 64 && c.head_dim != 128) return fail("fused attention supports head_dim 32/64/128");
@@ -219,7 +222,7 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = x; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
-    P.multi_base = 0.0f; P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32;
+    P.multi_base = c.attn_norm_base; P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32;
     if (c.parallel_attn) P.xn_out = m->xn;         // the normalised input: parallel-attention models feed it to the FFN
     const bool std_norm = c.norm_kind != 0;
     if (std_norm) {
@@ -315,7 +318,7 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
-    P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32; P.act_kind = c.act_kind;
+    P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32; P.act_kind = c.act_kind; P.multi_base = c.ffn_norm_base;
     if (moe_slot >= 0) {
         const Tensor &e1 = L.experts[0], &e3 = L.experts[2];
         moe_params(m, L, P, moe_slot, 0);
@@ -380,7 +383,7 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
     if (lmt.dtype != F16) {      // quantised lm_head (<= 20-layer models, network_builder.cc:839-844): same fused GEMV as the layers
         DecGemvParams P; memset(&P, 0, sizeof(P));
         P.x = x; P.norm_w = (const half_t *)m->g[T_OUT_NORM].data; P.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
-        P.eps = c.eps; P.cols = c.dim; P.xn_out = m->xn;
+        P.eps = c.eps; P.cols = c.dim; P.xn_out = m->xn; P.multi_base = c.out_norm_base;
         P.W0[0] = (const uint8_t *)lmt.tiled; P.rows[0] = (int)lmt.rows; P.nsets = 1;
         P.y[0] = logits_out ? logits_out : m->logits;
         return launch_dec_gemv<EPI_PLAIN, 1>(lmt.dtype, P, m->opt_rpw_lm, m->stream);
@@ -396,7 +399,7 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
     DecLmHeadParams H; memset(&H, 0, sizeof(H));
     H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
     H.eps = c.eps; H.cols = c.dim; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = logits_out ? logits_out : m->logits;
-    H.rows = (int)m->g[T_LM_HEAD].rows; H.xn_out = m->xn;
+    H.rows = (int)m->g[T_LM_HEAD].rows; H.xn_out = m->xn; H.multi_base = c.out_norm_base;
     return launch_lmhead(H, m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, m->stream);
 }
 
@@ -432,7 +435,7 @@ __global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k,
 extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens,
                                 const void *bias_f16, void *y_f16, ifa_stream stream);
 static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const Tensor &bias, half_t *C);
-static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y);
+static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y, float base = 0.0f);
 
 // router of one MoE layer on the device: the same norm / GEMV / softmax kernels the op path runs, then k_moe_topk
 static int launch_moe_router(ifa_model *m, int l)
@@ -567,10 +570,10 @@ static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const T
     return IFA_OK;
 }
 
-static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y)
+static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y, float base)
 {
     return ifa_layernorm(m->cfg.norm_kind, x, (size_t)T, (size_t)m->cfg.dim, w.present() ? w.data : nullptr,
-                         b.present() ? b.data : nullptr, 0.0f, m->cfg.eps, y, m->stream);
+                         b.present() ? b.data : nullptr, base, m->cfg.eps, y, m->stream);
 }
 
 // w2 . (act(w1 . x) [* (w3 . x)])   (ProcessGpuLayer_FeedForward, inference_worker.cc:1726-1922)
@@ -682,7 +685,7 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         Layer &L = m->layers[l];
         const half_t *attn_in = x;
         if (L.t[T_ATTN_NORM].present()) {
-            if ((rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn))) return rc;
+            if ((rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn, c.attn_norm_base))) return rc;
             attn_in = m->xn;
         }
         if ((rc = matmul(m, attn_in, T, L.t[T_WQ], L.t[T_WQ_B], m->q))) return rc;
@@ -705,12 +708,13 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
                                 c.head_dim, c.use_alibi ? 1.0f : c.kq_scale, c.use_alibi, c.tp_rank * c.heads,
                                 c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
         if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
+        if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
         if (!c.parallel_attn && !c.share_input)
             if ((rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
         const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
         const half_t *ff_n = ff_in;
         if (L.t[T_FFN_NORM].present()) {
-            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn))) return rc;
+            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
             ff_n = m->hn;
         }
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
@@ -718,15 +722,17 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         } else {
             if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
         }
+        if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
         if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
         if (c.parallel_attn || c.share_input)
             if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
         std::swap(m->x, m->f);
         x = m->x;
     }
+    if (scale_on(c.out_scale) && (rc = ifa_scale(x, c.out_scale, (size_t)T * D, x, s))) return rc;
     const half_t *hfin = x;
     if (m->g[T_OUT_NORM].present()) {
-        if ((rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn))) return rc;
+        if ((rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn, c.out_norm_base))) return rc;
         hfin = m->xn;
     } else {
         IFA_HIP_CHECK(hipMemcpyAsync(m->xn, x, (size_t)T * D * 2, hipMemcpyDeviceToDevice, m->stream));
@@ -858,7 +864,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         Layer &L = m->layers[(size_t)l];
         const half_t *attn_in = x;
         if (L.t[T_ATTN_NORM].present()) {
-            if ((rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn))) return rc;
+            if ((rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn, c.attn_norm_base))) return rc;
             attn_in = m->xn;
         }
         if ((rc = matmul(m, attn_in, T, L.t[T_WQ], L.t[T_WQ_B], m->q))) return rc;
@@ -875,12 +881,13 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         if ((rc = ifa_attention_rows(m->q, lr, c.kv_dtype, n, attn_ctx, c.heads, c.kv_heads, c.head_dim, c.use_alibi ? 1.0f : c.kq_scale,
                                      c.use_alibi, c.tp_rank * c.heads, c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
         if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
+        if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
         if (!c.parallel_attn && !c.share_input)
             if ((rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
         const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
         const half_t *ff_n = ff_in;
         if (L.t[T_FFN_NORM].present()) {
-            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn))) return rc;
+            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
             ff_n = m->hn;
         }
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
@@ -888,15 +895,17 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         } else {
             if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
         }
+        if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
         if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
         if (c.parallel_attn || c.share_input)
             if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
         std::swap(m->x, m->f);
         x = m->x;
     }
+    if (scale_on(c.out_scale) && (rc = ifa_scale(x, c.out_scale, (size_t)T * D, x, s))) return rc;
     const half_t *hfin = x;
     if (m->g[T_OUT_NORM].present()) {
-        if ((rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn))) return rc;
+        if ((rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn, c.out_norm_base))) return rc;
         hfin = m->xn;
     }
     const Tensor &lm = m->g[T_LM_HEAD];
@@ -943,6 +952,7 @@ int ifa_model_create(const ifa_model_config *cfg, ifa_model **out)
     if (m->cfg.kq_scale <= 0) m->cfg.kq_scale = 1.0f;
     if (m->cfg.partial_rotary <= 0) m->cfg.partial_rotary = 1.0f;
     if (m->cfg.tp_size <= 0) m->cfg.tp_size = 1;
+    for (float *sc : {&m->cfg.attn_out_scale, &m->cfg.ffn_out_scale, &m->cfg.out_scale}) if (*sc <= 0.0f) *sc = 1.0f;
     m->layers.resize((size_t)cfg->layers);
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete m; return ifa_fail(IFA_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -973,8 +983,13 @@ int ifa_model_destroy(ifa_model *m)
     if (m->attn_ws.lmax) (void)hipFree(m->attn_ws.lmax);
     if (m->attn_ws.opart) (void)hipFree(m->attn_ws.opart);
     for (Tensor &t : m->g) free_tensor(t);
-    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits};
+    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits,
+                       &m->moe_gate, &m->moe_out, &m->moe_in, &m->moe_wdev};
     for (half_t **b : bufs) if (*b) (void)hipFree(*b);
+    if (m->moe_idx) (void)hipFree(m->moe_idx);
+    if (m->moe_route) (void)hipFree(m->moe_route);
+    if (m->moe_pin) (void)hipHostFree(m->moe_pin);
+    if (m->trace) (void)hipFree(m->trace);
     if (m->xq) (void)hipFree(m->xq);
     if (m->state) (void)hipFree(m->state);
     if (m->rope_tab) (void)hipFree(m->rope_tab);

@@ -114,6 +114,12 @@ bool LoadModelSpecJson(ModelSpec &spec, const std::string &path)
     ns->GetNumber("qk_column_order", spec.qk_column_order);
     ns->GetNumber("qkv_format", spec.qkv_format);
     ns->GetNumber("kq_scale", spec.kq_scale);
+    ns->GetNumber("attn_pre_norm_base", spec.attn_pre_norm_base);
+    ns->GetNumber("ffn_pre_norm_base", spec.ffn_pre_norm_base);
+    ns->GetNumber("output_norm_base", spec.output_norm_base);
+    ns->GetNumber("attn_out_scale", spec.attn_out_scale);
+    ns->GetNumber("ffn_out_scale", spec.ffn_out_scale);
+    ns->GetNumber("out_scale", spec.out_scale);
     ns->GetBool("is_parallel_attn", spec.is_parallel_attn);
     ns->GetBool("mlp_attn_share_input", spec.mlp_attn_share_input);
     ns->GetNumber("expert_count", hp.experts);
@@ -194,6 +200,8 @@ bool CreateWorker(ifa_model **out, const ModelSpec &spec, int device)
     c.rope_theta = spec.rope_theta; c.partial_rotary = spec.partial_rotary_factor; c.kq_scale = spec.kq_scale; c.eps = 1e-5f;
     c.kv_dtype = spec.device_kv_cache_data_type == IFA_Q8_B32T2 ? IFA_Q8_B32T2 : IFA_F16;
     c.full_quant_gemv = 1; c.tp_rank = 0; c.tp_size = 1; c.device = device;
+    c.attn_norm_base = spec.attn_pre_norm_base; c.ffn_norm_base = spec.ffn_pre_norm_base; c.out_norm_base = spec.output_norm_base;
+    c.attn_out_scale = spec.attn_out_scale; c.ffn_out_scale = spec.ffn_out_scale; c.out_scale = spec.out_scale;
     if (ifa_model_create(&c, out) != IFA_OK) { EngineSetError("ifa_model_create: %s", ifa_last_error()); return false; }
     return true;
 }

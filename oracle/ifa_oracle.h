@@ -109,6 +109,10 @@ typedef struct {
     int kv_dtype;       /* ORC_F16 or ORC_Q8_B32T2 */
     int full_quant_gemv;/* 1: activations quantised to Q8 before eligible GEMVs */
     int experts, moe_top_k, moe_norm_topk;
+    /* ModelSpec::{attn_pre_norm_base, ffn_pre_norm_base, output_norm_base} (RMS weight = base + w, e.g. Gemma) and
+     * {attn_out_scale, ffn_out_scale, out_scale} (TensorOpr::Scale, inference_worker.cc:568-570,842-843,928-929; MiniCPM);
+     * scales <= 0 mean 1 */
+    float attn_norm_base, ffn_norm_base, out_norm_base, attn_out_scale, ffn_out_scale, out_scale;
 } orc_model_cfg;
 
 typedef struct orc_model orc_model;

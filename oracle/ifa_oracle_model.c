@@ -137,13 +137,15 @@ static int matmul(const orc_model *m, const orc_f16 *A, int T, const orc_tensor 
     return 0;
 }
 
+static int scale_on(float s) { return s > 0.0f && (s < 0.9999f || s > 1.0001f); }
+
 static void norm_rows(const orc_model *m, const orc_f16 *x, int T, const orc_tensor *w,
-                      const orc_tensor *b, orc_f16 *y)
+                      const orc_tensor *b, orc_f16 *y, float base)
 {
     const orc_f16 *wp = w && w->data ? (const orc_f16 *)w->data : NULL;
     const orc_f16 *bp = b && b->data ? (const orc_f16 *)b->data : NULL;
     if (m->cfg.norm_kind == 0)
-        orc_rmsnorm(x, (size_t)T, (size_t)m->cfg.dim, wp, bp, 0.0f, m->cfg.eps, 128, y);
+        orc_rmsnorm(x, (size_t)T, (size_t)m->cfg.dim, wp, bp, base, m->cfg.eps, 128, y);
     else
         orc_stdnorm(x, (size_t)T, (size_t)m->cfg.dim, wp, bp, m->cfg.eps, 128, y);
 }
@@ -211,7 +213,7 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
         /* attention pre-norm (inference_worker.cc:1038) */
         const orc_f16 *attn_in = x;
         if (L->t[ORC_T_ATTN_NORM].data) {
-            norm_rows(m, x, T, &L->t[ORC_T_ATTN_NORM], &L->t[ORC_T_ATTN_NORM_B], xn);
+            norm_rows(m, x, T, &L->t[ORC_T_ATTN_NORM], &L->t[ORC_T_ATTN_NORM_B], xn, c->attn_norm_base);
             attn_in = xn;
         }
         rc = matmul(m, attn_in, T, &L->t[ORC_T_WQ], &L->t[ORC_T_WQ_B], q); if (rc) break;
@@ -233,12 +235,13 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
                       c->kv_heads, c->head_dim, c->use_alibi ? 1.0f : c->kq_scale, c->use_alibi,
                       0, c->heads, att);
         rc = matmul(m, att, T, &L->t[ORC_T_WO], &L->t[ORC_T_WO_B], a); if (rc) break;
+        if (scale_on(c->attn_out_scale)) orc_scale(a, c->attn_out_scale, (size_t)T * D, a);   /* :842-843 */
         /* residual (inference_worker.cc:847-851) */
         if (!c->parallel_attn && !c->share_input) orc_add(x, a, (size_t)T * D, 0, a);
         const orc_f16 *ff_in = c->parallel_attn ? attn_in : (c->share_input ? x : a);
         const orc_f16 *ff_n = ff_in;
         if (L->t[ORC_T_FFN_NORM].data) {
-            norm_rows(m, ff_in, T, &L->t[ORC_T_FFN_NORM], &L->t[ORC_T_FFN_NORM_B], hn);
+            norm_rows(m, ff_in, T, &L->t[ORC_T_FFN_NORM], &L->t[ORC_T_FFN_NORM_B], hn, c->ffn_norm_base);
             ff_n = hn;
         }
         if (c->experts > 0 && L->t[ORC_T_MOE_GATE].data) {
@@ -291,6 +294,7 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
                            &L->t[ORC_T_W3_B], &L->t[ORC_T_W2], &L->t[ORC_T_W2_B], f);
         }
         if (rc) break;
+        if (scale_on(c->ffn_out_scale)) orc_scale(f, c->ffn_out_scale, (size_t)T * D, f);      /* :928-929 */
         /* layer_out = ff_out + residual (+ layer_input) (inference_worker.cc:936-947) */
         orc_add(f, a, (size_t)T * D, 0, f);
         if (c->parallel_attn || c->share_input) orc_add(f, x, (size_t)T * D, 0, f);
@@ -298,9 +302,10 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
     }
     if (rc == 0) {
         /* ProcessPostLayer, inference_worker.cc:552-624 */
+        if (scale_on(m->cfg.out_scale)) orc_scale(x, m->cfg.out_scale, (size_t)T * D, x);      /* :568-570, in place */
         const orc_f16 *hfin = x;
         if (m->g[ORC_T_OUT_NORM].data) {
-            norm_rows(m, x, T, &m->g[ORC_T_OUT_NORM], &m->g[ORC_T_OUT_NORM_B], xn);
+            norm_rows(m, x, T, &m->g[ORC_T_OUT_NORM], &m->g[ORC_T_OUT_NORM_B], xn, m->cfg.out_norm_base);
             hfin = xn;
         }
         memcpy(m->last_hidden, hfin + (size_t)(T - 1) * D, D * 2);
