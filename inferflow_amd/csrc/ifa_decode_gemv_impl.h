@@ -17,7 +17,7 @@ constexpr int dec_rw(int nj, int nm)
     return rw < 1 ? 1 : (rw > 6 ? 6 : rw);
 }
 
-template <int DT, int EPI, int NORM>
+template <int DT, int EPI, int NORM, bool XADD = false>
 static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStream_t s)
 {
     constexpr int NM = epi_is_glu(EPI) ? 2 : 1;
@@ -25,7 +25,7 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     if (nj < 1) return ifa_fail(IFA_ERR_ARG, "fused GEMV: no columns");
     if (nj > DecGemvLimits<DT>::MAXNJ) {
         // long rows (w2 / wo of 34B-70B models): chunked kernel, no norm prologue, no GLU pair
-        if constexpr (NORM == 0 && (EPI == EPI_PLAIN || EPI == EPI_RESIDUAL || EPI == EPI_MOE_ACC || EPI == EPI_MOE_LAST)) {
+        if constexpr (NORM == 0 && !XADD && (EPI == EPI_PLAIN || EPI == EPI_RESIDUAL || EPI == EPI_MOE_ACC || EPI == EPI_MOE_LAST)) {
             constexpr int MJ = DecGemvLimits<DT>::MAXNJ;
             const int nchunk = (nj + MJ - 1) / MJ;
             const int njl = (nj + nchunk - 1) / nchunk;
@@ -59,7 +59,7 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     if (nj > NJCAP) return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit for a normalised / gated input", P.cols);
 #define IFA_DG(NJV) \
     case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ && NJV <= NJCAP) { \
-        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(NJV, NM), EPI, NORM>; \
+        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(NJV, NM), EPI, NORM, XADD>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         kern<<<grid, dim3(DEC_THREADS), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, P); } break;
     switch (nj) { IFA_DG(1) IFA_DG(2) IFA_DG(3) IFA_DG(4) IFA_DG(5) IFA_DG(6) IFA_DG(7) IFA_DG(8) }
@@ -71,6 +71,12 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
 template <int DT>
 int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu, hipStream_t s)
 {
+    if (P.x_add) {      // tensor-parallel seams: the sum of the layer input and the merged product is formed in the prologue
+        if (epi == EPI_PLAIN && norm == 1) return dec_gemv_launch_en<DT, EPI_PLAIN, 1, true>(P, wgs_per_cu, s);
+        if (epi == EPI_GLU && norm == 1) return dec_gemv_launch_en<DT, EPI_GLU, 1, true>(P, wgs_per_cu, s);
+        if (epi == EPI_ACT && norm == 1) return dec_gemv_launch_en<DT, EPI_ACT, 1, true>(P, wgs_per_cu, s);
+        return ifa_fail(IFA_ERR_ARG, "fused GEMV: no x_add kernel for epilogue %d / norm %d", epi, norm);
+    }
     if (epi == EPI_PLAIN && norm == 1) return dec_gemv_launch_en<DT, EPI_PLAIN, 1>(P, wgs_per_cu, s);
     if (epi == EPI_PLAIN && norm == 0) return dec_gemv_launch_en<DT, EPI_PLAIN, 0>(P, wgs_per_cu, s);
     if (epi == EPI_RESIDUAL && norm == 0) return dec_gemv_launch_en<DT, EPI_RESIDUAL, 0>(P, wgs_per_cu, s);

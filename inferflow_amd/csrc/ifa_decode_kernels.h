@@ -96,10 +96,43 @@ __device__ __forceinline__ XLds xlds_carve(char *smem, int cols)
 // stream they would only arrive once that stream has drained).
 //   XPre pre; pre.issue(...);   ... issue weight loads ...;   pre.finish(...);
 // Must be executed by all DEC_THREADS threads.  cols % 32 == 0, cols <= 8*DEC_THREADS*MAXC.
-template <int NORM, int MAXC>
+// XADD: the activation is the sum x + (add [+ add_bias]) of two vectors (tensor parallelism: layer input + the
+// all-reduced product, bias once after the merge); the sum -- two half additions in TensorOpr::Add order -- replaces x
+// and workgroup 0 stores it for the residual that follows.
+template <int NORM, int MAXC, bool XADD = false>
 struct XPre {
     half8_t xv[MAXC];
     half8_t wv[NORM ? MAXC : 1], bv[NORM ? MAXC : 1];
+    half8_t av[XADD ? MAXC : 1], abv[XADD ? MAXC : 1];
+
+    __device__ __forceinline__ void issue_add(const half_t *__restrict__ add, const half_t *__restrict__ add_bias, int cols)
+    {
+        const int chunks = cols >> 3;
+#pragma unroll
+        for (int k = 0; k < MAXC; k++) {
+            const int c = threadIdx.x + k * DEC_THREADS;
+            if (c < chunks) {
+                av[k] = *reinterpret_cast<const half8_t *>(add + (size_t)c * 8);
+                if (add_bias) abv[k] = *reinterpret_cast<const half8_t *>(add_bias + (size_t)c * 8);
+            }
+        }
+    }
+    __device__ __forceinline__ void apply_add(const half_t *__restrict__ add_bias, int cols, half_t *__restrict__ sum_out)
+    {
+        const int chunks = cols >> 3;
+#pragma unroll
+        for (int k = 0; k < MAXC; k++) {
+            const int c = threadIdx.x + k * DEC_THREADS;
+            if (c >= chunks) continue;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                half_t t = av[k][i];
+                if (add_bias) t = f2h(h2f(t) + h2f(abv[k][i]));       // Add(reduced, bias)
+                xv[k][i] = f2h(h2f(xv[k][i]) + h2f(t));               // Add(layer_input, .)
+            }
+            if (sum_out && blockIdx.x == 0) *reinterpret_cast<half8_t *>(sum_out + (size_t)c * 8) = xv[k];
+        }
+    }
 
     __device__ __forceinline__ void issue(const half_t *__restrict__ x, const half_t *__restrict__ nw,
                                           const half_t *__restrict__ nb, int cols)
@@ -310,6 +343,8 @@ struct DecGemvParams {
     const half_t *b1;
     const half_t *residual;    // EPI_RESIDUAL: y = half(residual + y)
     const half_t *residual2;   // optional second add (parallel-attn / shared-input models)
+    const half_t *x_add, *x_add_bias;   // XADD kernels: activation = x + (x_add [+ x_add_bias]), stored to xsum_out
+    half_t *xsum_out;
     // mixture of experts: the weights of set 0 come from a device-side table indexed by the expert id the router
     // kernel chose for slot `moe_slot` (w_table[4*e + {0: w1, 1: w3, 2: w2}]); moe_w[slot] = its half weight
     const uint8_t *const *w_table;
@@ -391,7 +426,7 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
 //   4. the remaining rows -- all of them at once, nothing waits on them until the dots;
 //   5. every wave reduces its RW rows as independent chains, then lane i finishes row i
 //      (bias / residual / activation) so the epilogue's loads overlap too.
-template <int DT, int NJ, int RW, int EPI, int NORM>
+template <int DT, int NJ, int RW, int EPI, int NORM, bool XADD = false>
 __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols,
                                                           const DecGemvParams P)
 {
@@ -401,8 +436,9 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const half_t *px, cons
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the activation requests go out first, from preloaded arguments only (nothing here waits for a scalar load)
     constexpr int MAXC = NORM ? 2 : 4;
-    XPre<NORM, MAXC> pre;
+    XPre<NORM, MAXC, XADD> pre;
     pre.issue(px, pnw, pnb, pcols);
+    if constexpr (XADD) pre.issue_add(P.x_add, P.x_add_bias, pcols);
     const long long t_start = wall_clock64();
     const XLds L = xlds_carve(smem, pcols);
     const int lane = threadIdx.x & 63;
@@ -448,6 +484,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const half_t *px, cons
         __syncthreads();
         load_rows(0, 0, D1);
         if (tr) P.trace[blockIdx.x * 8 + 1] = wall_clock64();
+        if constexpr (XADD) pre.apply_add(P.x_add_bias, P.cols, P.xsum_out);
         pre.finish(P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out,
                    (P.trace != nullptr && threadIdx.x == 0) ? P.trace + blockIdx.x * 8 : nullptr);
         load_rows(0, D1, RW);

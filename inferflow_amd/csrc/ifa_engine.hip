@@ -71,6 +71,10 @@ struct ifa_model {
     // decode graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // tensor parallelism: a seam's "layer input + merged product (+ bias)" waiting to be formed in the prologue of the
+    // GEMV that consumes it (instead of one or two tiny add kernels per seam)
+    struct PendingAdd { const half_t *x = nullptr, *add = nullptr, *bias = nullptr; half_t *out = nullptr; bool on = false; } pend;
+    int opt_tp_fuse_add = 1;
     // dynamic batching tables (forward_batch)
     void *batch_tab_dev = nullptr, *batch_tab_pin = nullptr;
     size_t batch_tab_bytes = 0;
@@ -237,6 +241,10 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
         P.y[i] = outs[i]; P.rows[i] = (int)L.t[ids[i]].rows;
     }
     P.nsets = 3;
+    if (m->pend.on && !std_norm) {      // x = pend.x + merged product: formed in this kernel's prologue, stored as the new layer input
+        P.x = m->pend.x; P.x_add = m->pend.add; P.x_add_bias = m->pend.bias; P.xsum_out = m->pend.out;
+        m->pend.on = false;
+    }
     if (std_norm) return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WQ].dtype, P, m->opt_rpw_qkv, m->stream);
     return launch_dec_gemv<EPI_PLAIN, 1>(L.t[T_WQ].dtype, P, m->opt_rpw_qkv, m->stream);
 }
@@ -343,6 +351,10 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
     const bool glu = L.t[T_W3].present();
     if (glu) { P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.b1 = (const half_t *)L.t[T_W3_B].data; }
     const int dtw = L.t[T_W1].dtype;
+    if (need_norm && m->pend.on && P.x == m->pend.out) {     // the FFN input is the pending sum
+        P.x = m->pend.x; P.x_add = m->pend.add; P.x_add_bias = m->pend.bias; P.xsum_out = m->pend.out;
+        m->pend.on = false;
+    }
     if (need_norm) return glu ? launch_dec_gemv<EPI_GLU, 1>(dtw, P, m->opt_rpw_ffn, m->stream) : launch_dec_gemv<EPI_ACT, 1>(dtw, P, m->opt_rpw_ffn, m->stream);
     return glu ? launch_dec_gemv<EPI_GLU, 0>(dtw, P, m->opt_rpw_ffn, m->stream) : launch_dec_gemv<EPI_ACT, 0>(dtw, P, m->opt_rpw_ffn, m->stream);
 }
@@ -1160,7 +1172,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"tp_fuse_add", &m->opt_tp_fuse_add}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
@@ -1314,10 +1326,13 @@ static int tp_ready(ifa_model *m)
     return ensure_scratch(m, 1);
 }
 
+static int tp_flush_pending(ifa_model *m);
+
 int ifa_model_tp_begin(ifa_model *m, int token, int pos)
 {
     int rc = tp_ready(m);
     if (rc) return rc;
+    m->pend.on = false;
     IFA_REQUIRE(pos >= -1 && pos < m->cfg.max_ctx, "ifa_model_tp_begin: position %d outside max_ctx %d", pos, m->cfg.max_ctx);
     IFA_REQUIRE(m->g[T_EMBD].present(), "ifa_model_tp_begin: this worker holds no embeddings (use ifa_model_tp_begin_hidden)");
     const ifa_model_config &c = m->cfg;
@@ -1334,6 +1349,7 @@ int ifa_model_tp_begin_hidden(ifa_model *m, const void *x_f16, int pos)
     int rc = tp_ready(m);
     if (rc) return rc;
     IFA_REQUIRE(x_f16, "ifa_model_tp_begin_hidden: null input");
+    m->pend.on = false;
     IFA_REQUIRE(pos >= -1 && pos < m->cfg.max_ctx, "ifa_model_tp_begin_hidden: position %d outside max_ctx %d", pos, m->cfg.max_ctx);
     const ifa_model_config &c = m->cfg;
     IFA_HIP_CHECK(hipMemcpyAsync(m->x, x_f16, (size_t)c.dim * 2, hipMemcpyDeviceToDevice, m->stream));
@@ -1347,6 +1363,7 @@ int ifa_model_tp_begin_hidden(ifa_model *m, const void *x_f16, int pos)
 int ifa_model_tp_hidden(ifa_model *m, void *x_out_f16)
 {
     IFA_REQUIRE(m && m->finalized && x_out_f16, "ifa_model_tp_hidden: bad arguments");
+    { int rcf = tp_flush_pending(m); if (rcf) return rcf; }
     IFA_HIP_CHECK(hipMemcpyAsync(x_out_f16, m->x, (size_t)m->cfg.dim * 2, hipMemcpyDeviceToDevice, m->stream));
     return IFA_OK;
 }
@@ -1360,11 +1377,33 @@ int ifa_model_tp_attn(ifa_model *m, int layer, void *partial_out_f16)
     return launch_wo(m, layer, m->x, (half_t *)partial_out_f16);
 }
 
+// form a pending seam sum with the op-level add kernels (when no fused consumer follows)
+static int tp_flush_pending(ifa_model *m)
+{
+    if (!m->pend.on) return IFA_OK;
+    m->pend.on = false;
+    const size_t D = (size_t)m->cfg.dim;
+    const half_t *src = m->pend.add;
+    int rc;
+    if (m->pend.bias) {
+        if ((rc = ifa_add(m->pend.add, m->pend.bias, D, 0, m->f, m->stream))) return rc;
+        src = m->f;
+    }
+    return ifa_add(m->pend.x, src, D, 0, m->pend.out, m->stream);
+}
+
 int ifa_model_tp_post_attn(ifa_model *m, int layer, const void *reduced_f16)
 {
     IFA_REQUIRE(m && reduced_f16 && layer >= 0 && layer < m->cfg.layers, "ifa_model_tp_post_attn: bad arguments");
     const size_t D = (size_t)m->cfg.dim;
     const Tensor &b = m->layers[(size_t)layer].t[T_WO_B];
+    const Layer &Lp = m->layers[(size_t)layer];
+    if (m->opt_tp_fuse_add && Lp.t[T_FFN_NORM].present() && !(m->cfg.experts > 0 && Lp.t[T_MOE_GATE].present())) {
+        // a = x + (reduced + bias): left to the W1/W3 kernel's prologue (ifa_model_tp_ffn)
+        m->pend.x = m->x; m->pend.add = (const half_t *)reduced_f16; m->pend.bias = (const half_t *)b.data; m->pend.out = m->a;
+        m->pend.on = true;
+        return IFA_OK;
+    }
     const void *src = reduced_f16;
     int rc;
     if (b.present()) {     // bias once, after the merge (inference_worker.cc:1388-1390)
@@ -1396,6 +1435,12 @@ int ifa_model_tp_post_ffn(ifa_model *m, int layer, const void *reduced_f16)
     IFA_REQUIRE(m && reduced_f16 && layer >= 0 && layer < m->cfg.layers, "ifa_model_tp_post_ffn: bad arguments");
     const size_t D = (size_t)m->cfg.dim;
     const Tensor &b = m->layers[(size_t)layer].t[T_W2_B];
+    if (m->opt_tp_fuse_add && layer + 1 < m->cfg.layers) {
+        // next layer input = a + (reduced + bias): left to the next QKV kernel's prologue (ifa_model_tp_attn)
+        m->pend.x = m->a; m->pend.add = (const half_t *)reduced_f16; m->pend.bias = (const half_t *)b.data; m->pend.out = m->x;
+        m->pend.on = true;
+        return IFA_OK;
+    }
     const void *src = reduced_f16;
     int rc;
     if (b.present()) {
@@ -1409,6 +1454,7 @@ int ifa_model_tp_logits(ifa_model *m, void *logits_shard_out_f16)
 {
     IFA_REQUIRE(m && logits_shard_out_f16, "ifa_model_tp_logits: bad arguments");
     IFA_REQUIRE(m->g[T_LM_HEAD].present(), "ifa_model_tp_logits: this worker holds no lm_head (not the last pipeline stage)");
+    { int rcf = tp_flush_pending(m); if (rcf) return rcf; }
     return launch_lm(m, m->x, (half_t *)logits_shard_out_f16);
 }
 
