@@ -388,7 +388,38 @@ bool LoadSafetensors(ifa_model **out, ModelSpec &spec, int device)
                         {"post_attention_layernorm.weight", IFA_T_FFN_NORM, 1, D, false},
                         {"mlp.gate_proj.weight", IFA_T_W1, F, D, true}, {"mlp.down_proj.weight", IFA_T_W2, D, F, true},
                         {"mlp.up_proj.weight", IFA_T_W3, F, D, true}};
-        for (const E &e : es) if (put(p + e.name, l, e.tid, e.rows, e.cols, e.matrix, true) < 0) return false;
+        // fused QKV checkpoints (Falcon, Bloom, GPT-NeoX ...): one [QD + 2 KVD][D] tensor whose rows are split exactly like
+        // the reference splits the fused product (Attention_CalculateCurQKV, inference_worker.cc:1503-1548):
+        //   qkv_format 0: per KV group {its h query heads, k, v};  qkv_format 1: all q | all k | all v
+        bool fused_qkv = false;
+        for (const char *fname : {"self_attn.qkv_proj.weight", "self_attention.query_key_value.weight", "attention.query_key_value.weight"}) {
+            auto it = by_std.find(p + fname);
+            if (it == by_std.end()) continue;
+            const size_t QDr = D, total = QDr + 2 * KV;
+            if (!ReadStTensor(it->second, total, D, f16, p + fname)) return false;
+            const size_t groups = (size_t)hp.decoder_kv_heads, hq = (size_t)hp.decoder_heads / groups;
+            std::vector<uint16_t> q(QDr * D), k(KV * D), v(KV * D);
+            if (spec.qkv_format == 0) {
+                for (size_t g = 0; g < groups; g++) {
+                    const uint16_t *src = f16.data() + g * (hq + 2) * HS * D;
+                    memcpy(q.data() + g * hq * HS * D, src, hq * HS * D * 2);
+                    memcpy(k.data() + g * HS * D, src + hq * HS * D, HS * D * 2);
+                    memcpy(v.data() + g * HS * D, src + (hq + 1) * HS * D, HS * D * 2);
+                }
+            } else {
+                memcpy(q.data(), f16.data(), QDr * D * 2);
+                memcpy(k.data(), f16.data() + QDr * D, KV * D * 2);
+                memcpy(v.data(), f16.data() + (QDr + KV) * D, KV * D * 2);
+            }
+            if (!up.Put(l, IFA_T_WQ, up.MatrixType(QDr, D), q.data(), QDr, D) || !up.Put(l, IFA_T_WK, up.MatrixType(KV, D), k.data(), KV, D)
+                || !up.Put(l, IFA_T_WV, up.MatrixType(KV, D), v.data(), KV, D)) return false;
+            fused_qkv = true;
+            break;
+        }
+        for (const E &e : es) {
+            if (fused_qkv && (e.tid == IFA_T_WQ || e.tid == IFA_T_WK || e.tid == IFA_T_WV)) continue;
+            if (put(p + e.name, l, e.tid, e.rows, e.cols, e.matrix, true) < 0) return false;
+        }
         const E bs[] = {{"self_attn.q_proj.bias", IFA_T_WQ_B, 1, D, false}, {"self_attn.k_proj.bias", IFA_T_WK_B, 1, KV, false},
                         {"self_attn.v_proj.bias", IFA_T_WV_B, 1, KV, false}};
         for (const E &e : bs) if (put(p + e.name, l, e.tid, e.rows, e.cols, false, false) < 0) return false;

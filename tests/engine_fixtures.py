@@ -53,12 +53,30 @@ HF_NAMES = {W.T_ATTN_NORM: "input_layernorm.weight", W.T_WQ: "self_attn.q_proj.w
             W.T_W1: "mlp.gate_proj.weight", W.T_W2: "mlp.down_proj.weight", W.T_W3: "mlp.up_proj.weight"}
 
 
-def write_safetensors(path, w, s=SHAPE, dtype="F16"):
-    """Minimal safetensors writer (8-byte header length, JSON header, raw little-endian payload)."""
+def fuse_qkv(w, l, s, fmt):
+    """[q; k; v] rows in the two layouts of ModelSpec::qkv_format (0: per KV group {q heads, k, v}; 1: q | k | v)."""
+    q, k, v = w[(l, W.T_WQ)], w[(l, W.T_WK)], w[(l, W.T_WV)]
+    if fmt == 1:
+        return np.concatenate([q, k, v], 0)
+    hd, groups = s["head_dim"], s["kv_heads"]
+    hq = s["heads"] // groups
+    parts = []
+    for g in range(groups):
+        parts += [q[g * hq * hd:(g + 1) * hq * hd], k[g * hd:(g + 1) * hd], v[g * hd:(g + 1) * hd]]
+    return np.concatenate(parts, 0)
+
+
+def write_safetensors(path, w, s=SHAPE, dtype="F16", fused_qkv=None):
+    """Minimal safetensors writer (8-byte header length, JSON header, raw little-endian payload).
+    fused_qkv: None, or the qkv_format (0 / 1) of a single self_attn.qkv_proj tensor replacing q/k/v_proj."""
     tensors = {"model.embed_tokens.weight": w[(-1, W.T_EMBD)], "model.norm.weight": w[(-1, W.T_OUT_NORM)].reshape(-1),
                "lm_head.weight": w[(-1, W.T_LM_HEAD)]}
     for (l, tid), arr in w.items():
         if l >= 0:
+            if fused_qkv is not None and tid in (W.T_WQ, W.T_WK, W.T_WV):
+                if tid == W.T_WQ:
+                    tensors["model.layers.%d.self_attn.qkv_proj.weight" % l] = fuse_qkv(w, l, s, fused_qkv)
+                continue
             tensors["model.layers.%d.%s" % (l, HF_NAMES[tid])] = arr.reshape(-1) if arr.shape[0] == 1 else arr
     header, blobs, off = {}, [], 0
     for name, arr in tensors.items():
@@ -110,7 +128,7 @@ prompt_template = {{bos}}{{query}}
 
 
 def write_model_dir(d, fmt="llama2.c", wd="Q4", kvd="Q8", thr=0, ctx=64, ret="true", maxq=6, s=SHAPE, seed=5, qk_order=0,
-                    st_dtype="F16", hyper=None):
+                    st_dtype="F16", hyper=None, fused_qkv=None):
     """Returns (ini_path, weights dict or None)."""
     os.makedirs(d, exist_ok=True)
     spec = json.loads(json.dumps(SPEC))
@@ -123,7 +141,9 @@ def write_model_dir(d, fmt="llama2.c", wd="Q4", kvd="Q8", thr=0, ctx=64, ret="tr
         w = make_weights(s, seed)
         spec.update(model_file_format="safetensors", model_files=["model.safetensors.index.json", "model.safetensors"], config_file="config.json")
         spec["network_structure"]["tensor_name_prefix"] = "model."
-        write_safetensors(os.path.join(d, "model.safetensors"), w, s, st_dtype)
+        write_safetensors(os.path.join(d, "model.safetensors"), w, s, st_dtype, fused_qkv)
+        if fused_qkv is not None:
+            spec["network_structure"]["qkv_format"] = fused_qkv
         json.dump({"hidden_size": s["dim"], "intermediate_size": s["ffn"], "num_hidden_layers": s["layers"],
                    "num_attention_heads": s["heads"], "num_key_value_heads": s["kv_heads"], "vocab_size": s["vocab"],
                    "max_position_embeddings": 2048, "rope_theta": 10000.0}, open(os.path.join(d, "config.json"), "w"))

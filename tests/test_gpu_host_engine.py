@@ -119,3 +119,22 @@ def test_engine_errors_follow_the_reference_conventions(tmp_path):
     open(bad, "w").write(open(ini).read().replace("device_weight_data_type = Q4", "device_weight_data_type = Q7"))
     with pytest.raises(EngineError, match="device_weight_data_type"):
         InferenceEngine.from_ini(bad)
+
+
+@pytest.mark.parametrize("qkv_format", [0, 1])
+def test_fused_qkv_checkpoints_load_like_separate_tensors(tmp_path, qkv_format):
+    """One self_attn.qkv_proj tensor in either ModelSpec::qkv_format must give exactly the model its separate
+    q/k/v_proj tensors give (the reference splits the fused product, the loader splits the rows: same numbers)."""
+    outs = []
+    for sub, fused in (("sep", None), ("fused", qkv_format)):
+        ini, _ = fx.write_model_dir(str(tmp_path / sub), fmt="safetensors", wd="Q4", kvd="F16", qk_order=2, fused_qkv=fused)
+        eng = InferenceEngine.from_ini(ini)
+        qid = eng.add_query([5, 9, 100, 42, 7])
+        (q, tok), = eng.infer()
+        lg = eng.last_logits(qid).copy()
+        assert eng.commit({qid: tok})
+        toks, _ = eng.generate(qid, 8)
+        outs.append((tok, lg, toks))
+        eng.close()
+    assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2]
+    assert np.array_equal(outs[0][1], outs[1][1])
