@@ -38,6 +38,12 @@ int ifa_engine_last_logits(ifa_engine *e, int query_id, uint16_t *dst_f16, size_
 /* extension: n greedy steps with device-side token feedback (graph replay); returns tokens written or -1 */
 int ifa_engine_generate(ifa_engine *e, int query_id, int n_steps, int *out_tokens, float *gpu_ms);
 
+/* the reference's perplexity harness (src/tools/perplexity.cc:41-284) over a token-id stream: windows of max_length
+ * every `stride` tokens, each scored from its whole-prompt logits; needs return_output_tensors = true in the .ini and
+ * no active query.  1 ok (PPL, its error estimate, scored-token count), 0 failure. */
+int ifa_engine_perplexity(ifa_engine *e, const int *tokens, int n_tokens, int max_length, int stride,
+                          double *ppl, double *ppl_stderr, long long *count);
+
 /* facts of the loaded model: "vocab_size", "embd_dims", "hidden_dim", "decoder_layers", "decoder_heads",
  * "decoder_kv_heads", "max_context_len", "device_weight_data_type", "device_kv_cache_data_type"; -1 if unknown */
 int ifa_engine_model_info(ifa_engine *e, const char *key);

@@ -112,6 +112,8 @@ def build_library(force=False, verbose=False, jobs=None):
     os.makedirs(BIN_DIR, exist_ok=True)
     subprocess.check_call([cxx] + HOST_FLAGS + ["-I", inc, "-I", HOST, os.path.join(HOST, "llm_inference_main.cc"), "-o", CLI_PATH,
                            "-L", LIB_DIR, "-linferflow_amd", "-Wl,-rpath,$ORIGIN/../lib"])
+    subprocess.check_call([cxx] + HOST_FLAGS + ["-I", inc, "-I", HOST, os.path.join(HOST, "perplexity_main.cc"), "-o",
+                           os.path.join(BIN_DIR, "ifa_perplexity"), "-L", LIB_DIR, "-linferflow_amd", "-Wl,-rpath,$ORIGIN/../lib"])
     return LIB_PATH
 
 

@@ -90,5 +90,13 @@ class InferenceEngine:
             raise EngineError("Generate failed: " + self._err())
         return [out[i] for i in range(n)], ms.value
 
+    def perplexity(self, tokens, max_length=512, stride=512):
+        """(PPL, error estimate, scored tokens) of a token-id stream -- the reference's perplexity tool."""
+        arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
+        ppl, err, cnt = C.c_double(0), C.c_double(0), C.c_longlong(0)
+        if not _capi.lib().ifa_engine_perplexity(self._h, arr, len(tokens), max_length, stride, C.byref(ppl), C.byref(err), C.byref(cnt)):
+            raise EngineError("perplexity failed: " + self._err())
+        return ppl.value, err.value, cnt.value
+
     def model_info(self, key):
         return _capi.lib().ifa_engine_model_info(self._h, key.encode())

@@ -5,6 +5,7 @@
 
 #include "inferflow_engine.h"
 #include "inference_engine.h"
+#include "perplexity.h"
 
 using namespace inferflow_amd;
 
@@ -84,6 +85,18 @@ int ifa_engine_generate(ifa_engine *e, int query_id, int n_steps, int *out_token
     if (!e->engine.Generate(query_id, n_steps, toks, gpu_ms)) return -1;
     for (size_t i = 0; i < toks.size(); i++) out_tokens[i] = toks[i];
     return (int)toks.size();
+}
+
+int ifa_engine_perplexity(ifa_engine *e, const int *tokens, int n_tokens, int max_length, int stride,
+                          double *ppl, double *ppl_stderr, long long *count)
+{
+    if (!e || !tokens || n_tokens <= 0) { EngineSetError("ifa_engine_perplexity: bad arguments"); return 0; }
+    PerplexityResult r;
+    if (!ComputePerplexity(e->engine, std::vector<int>(tokens, tokens + n_tokens), max_length, stride, r)) return 0;
+    if (ppl) *ppl = r.ppl;
+    if (ppl_stderr) *ppl_stderr = r.ppl_stderr;
+    if (count) *count = r.count;
+    return 1;
 }
 
 int ifa_engine_model_info(ifa_engine *e, const char *key)
