@@ -101,9 +101,14 @@ int ifa_gemv(int w_dtype, const void *W, size_t rows, size_t cols,
  * src/transformer/inference_worker.cc:2374-2415: TensorOpr::Dequantize + CublasEngine::GemmEx
  * F16xF16->F16 with fp32 accumulate + Transpose).  Y[tokens][rows] (F16) = X[tokens][cols] (F16)
  * . W[rows][cols]^T (+bias); W in any block format (reference layout) or F16.  The weights are
- * dequantised to half in registers and fed to v_mfma_f32_32x32x16_f16; no F16 copy of W exists. */
+ * dequantised to half in registers and fed to v_mfma_f32_32x32x16_f16; no F16 copy of W exists.
+ * From ifa_gemm_library_min_tokens() tokens on (default 129: past the split-K kernel, MFMA-bound) the weights are instead dequantised once
+ * into a per-stream F16 scratch and multiplied by hipBLASLt (bound at run time; same arithmetic). */
 int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x_f16, size_t tokens,
              const void *bias_f16, void *y_f16, ifa_stream stream);
+/* sets the token count from which ifa_gemm hands the product to hipBLASLt (0 = never, < 0 = only query);
+ * returns the previous threshold, or 0 when hipBLASLt could not be loaded.  Environment: IFA_GEMM_LT_MIN_TOKENS. */
+int ifa_gemm_library_min_tokens(int min_tokens);
 
 /* Re-tile reference-layout rows into the row-local plane layout the fused
  * decode kernels stream (DESIGN.md "HBM layout"): same bytes per row, row stride

@@ -274,6 +274,11 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
 
 using namespace ifa;
 
+namespace ifa {
+bool gemm_lt_wanted(size_t tokens);                  // ifa_gemm_lt.hip
+int gemm_lt(int w_dtype, const void *W, size_t N, size_t K, const void *X, size_t T, const void *bias, void *Y, hipStream_t s);
+}
+
 template <int DT>
 static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t T, const void *bias, void *Y, hipStream_t s)
 {
@@ -320,6 +325,11 @@ extern "C" int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, co
     IFA_REQUIRE(cols > 0 && cols % (size_t)cap == 0 && cols % 8 == 0, "ifa_gemm: cols %zu must be a multiple of %d", cols, cap);
     IFA_REQUIRE(rows < (1u << 30) && cols < (1u << 30) && tokens <= 65535u * 64u, "ifa_gemm: shape too large");
     hipStream_t s = ifa_s(stream);
+    // MFMA-bound sizes: dequantise once + the library's F16 GEMM (ifa_gemm_lt.hip); anything it declines runs below
+    if (gemm_lt_wanted(tokens) && gemm_lt(w_dtype, W, rows, cols, x_f16, tokens, bias_f16, y_f16, s) == IFA_OK) {
+        IFA_LAUNCH_CHECK();
+        return IFA_OK;
+    }
     if (w_dtype == F16) {
         launch_gemm<F16>(W, rows, cols, x_f16, tokens, bias_f16, y_f16, s);
     } else {

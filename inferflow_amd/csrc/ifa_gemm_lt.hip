@@ -1,0 +1,183 @@
+// ifa_gemm_lt.hip -- large-T linear layer: dequantise once, then the library's F16 GEMM.
+//
+// Where the prompt is long enough that the layer is MFMA-bound (T > 128 by default: past the split-K kernel of ifa_gemm.hip) the weight traffic of a full
+// F16 copy is noise (4096x4096: 10 MB read + 33 MB written, ~10 us, against a 35-90 us GEMM) and hipBLASLt's
+// 256x256-tile kernels reach 0.9-1.2 PFLOP/s where the fused dequantise-in-registers kernel of ifa_gemm.hip
+// reaches 0.4-0.6 (profiles/r01_gemm_mfma_microbench.log, tools/probes/lib_gemm_probe.py).  This is the
+// reference's own decomposition (TensorOpr::Dequantize + cublasGemmEx, inference_worker.cc:2374-2415) minus its
+// transpose: Y[T][N] (row-major) is the column-major N x T product W (N x K, "T" operand, ld K) . X^T (K x T, ld K).
+// Same arithmetic: weights rounded to half exactly like the dequant tensor, F16 x F16 products, fp32 accumulate,
+// one F16 rounding, bias as a half add afterwards.  Below the threshold the fused kernel stays (weight-stream bound).
+//
+// hipBLASLt is bound at run time (dlopen) so that libinferflow_amd.so itself links only the HIP runtime; when the
+// library is absent ifa_gemm keeps using its own kernel for every T.
+#include <dlfcn.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <hipblaslt/hipblaslt.h>
+#include "ifa_host.h"
+#include "ifa_codec.h"
+
+namespace ifa {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Q4_B32T1A/B -> F16, coalesced: 4 lanes per 20-byte block, 8 values (one 16-byte store) each
+__global__ void __launch_bounds__(256) k_dequant_q4_f16(const uint32_t *__restrict__ W, half_t *__restrict__ out, size_t nblocks)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t b = gid >> 2;
+    if (b >= nblocks) return;
+    const int part = (int)(gid & 3);
+    const uint32_t sb = W[b * 5], c = W[b * 5 + 1 + part];
+    const float base = hbits2f((uint16_t)(sb & 0xFFFFu)), scale = hbits2f((uint16_t)(sb >> 16));
+    half_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = f2h(__builtin_fmaf((float)((c >> (4 * e)) & 0xFu), scale, base));   // q*scale exact: fma == mul + add
+    *reinterpret_cast<u32x4 *>(out + gid * 8) = *reinterpret_cast<const u32x4 *>(v);
+}
+
+__global__ void __launch_bounds__(256) k_add_bias_rows(half_t *__restrict__ Y, const half_t *__restrict__ bias, size_t total, int N)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) Y[i] = f2h(h2f(Y[i]) + h2f(bias[i % (size_t)N]));
+}
+
+struct LtApi {
+    bool ok = false;
+    decltype(&hipblasLtCreate) Create = nullptr;
+    decltype(&hipblasLtMatrixLayoutCreate) LayoutCreate = nullptr;
+    decltype(&hipblasLtMatmulDescCreate) DescCreate = nullptr;
+    decltype(&hipblasLtMatmulDescSetAttribute) DescSet = nullptr;
+    decltype(&hipblasLtMatmulPreferenceCreate) PrefCreate = nullptr;
+    decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
+    decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
+    decltype(&hipblasLtMatmul) Matmul = nullptr;
+};
+
+static const LtApi &lt_api()
+{
+    static LtApi api = [] {
+        LtApi a;
+        void *so = nullptr;
+        for (const char *name : {"libhipblaslt.so.1", "libhipblaslt.so", "/opt/rocm/lib/libhipblaslt.so.1"})
+            if ((so = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!so) return a;
+#define IFA_LT_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(so, #sym))
+        IFA_LT_SYM(Create, hipblasLtCreate); IFA_LT_SYM(LayoutCreate, hipblasLtMatrixLayoutCreate);
+        IFA_LT_SYM(DescCreate, hipblasLtMatmulDescCreate); IFA_LT_SYM(DescSet, hipblasLtMatmulDescSetAttribute);
+        IFA_LT_SYM(PrefCreate, hipblasLtMatmulPreferenceCreate); IFA_LT_SYM(PrefSet, hipblasLtMatmulPreferenceSetAttribute);
+        IFA_LT_SYM(Heuristic, hipblasLtMatmulAlgoGetHeuristic); IFA_LT_SYM(Matmul, hipblasLtMatmul);
+#undef IFA_LT_SYM
+        a.ok = a.Create && a.LayoutCreate && a.DescCreate && a.DescSet && a.PrefCreate && a.PrefSet && a.Heuristic && a.Matmul;
+        return a;
+    }();
+    return api;
+}
+
+struct LtPlan {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
+    hipblasLtMatmulAlgo_t algo;
+    size_t workspace = 0;
+    bool ok = false;
+};
+
+// one context per (device, stream): the F16 scratch copy of the weights is reused call after call on that stream
+struct LtContext {
+    hipblasLtHandle_t handle = nullptr;
+    void *workspace = nullptr;
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::map<std::tuple<size_t, size_t, size_t>, LtPlan> plans;
+};
+constexpr size_t LT_WORKSPACE = (size_t)64 << 20;
+
+static std::mutex g_lt_mutex;
+static std::map<std::pair<int, hipStream_t>, LtContext> g_lt_ctx;
+static int g_lt_min_tokens = -1;          // -1: not initialised (environment IFA_GEMM_LT_MIN_TOKENS, default 129 = past the split-K kernel); 0: never
+
+static int lt_min_tokens()
+{
+    if (g_lt_min_tokens < 0) {
+        const char *e = getenv("IFA_GEMM_LT_MIN_TOKENS");
+        g_lt_min_tokens = e ? std::max(0, atoi(e)) : 129;
+    }
+    return g_lt_min_tokens;
+}
+
+bool gemm_lt_wanted(size_t tokens)
+{
+    const int mt = lt_min_tokens();
+    return mt > 0 && tokens >= (size_t)mt && lt_api().ok;
+}
+
+// IFA_OK, or IFA_ERR_STATE when the library cannot take this problem (the caller then runs its own kernel)
+int gemm_lt(int w_dtype, const void *W, size_t N, size_t K, const void *X, size_t T, const void *bias, void *Y, hipStream_t s)
+{
+    const LtApi &api = lt_api();
+    if (!api.ok) return IFA_ERR_STATE;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return IFA_ERR_STATE;
+    std::lock_guard<std::mutex> lock(g_lt_mutex);
+    LtContext &ctx = g_lt_ctx[{dev, s}];
+    if (!ctx.handle) {
+        if (api.Create(&ctx.handle) != HIPBLAS_STATUS_SUCCESS) { ctx.handle = nullptr; return IFA_ERR_STATE; }
+        if (hipMalloc(&ctx.workspace, LT_WORKSPACE) != hipSuccess) { ctx.workspace = nullptr; return IFA_ERR_STATE; }
+    }
+    const void *Wh = W;
+    if (w_dtype != F16) {
+        const size_t need = N * K * 2;
+        if (need > ctx.scratch_bytes) {
+            if (ctx.scratch) { (void)hipStreamSynchronize(s); (void)hipFree(ctx.scratch); }
+            ctx.scratch = nullptr; ctx.scratch_bytes = 0;
+            if (hipMalloc(&ctx.scratch, need) != hipSuccess) return IFA_ERR_STATE;
+            ctx.scratch_bytes = need;
+        }
+        if (w_dtype == Q4_B32T1A || w_dtype == Q4_B32T1B) {
+            const size_t nblocks = N * (K / 32);
+            k_dequant_q4_f16<<<dim3((unsigned)ifa_cdiv(nblocks * 4, 256)), dim3(256), 0, s>>>((const uint32_t *)W, (half_t *)ctx.scratch, nblocks);
+        } else if (ifa_dequantize(w_dtype, W, N, K, ctx.scratch, (ifa_stream)s) != IFA_OK) {
+            return IFA_ERR_STATE;
+        }
+        Wh = ctx.scratch;
+    }
+    LtPlan &p = ctx.plans[std::make_tuple(N, K, T)];
+    if (!p.desc) {
+        const int32_t op_t = HIPBLAS_OP_T, op_n = HIPBLAS_OP_N;
+        hipblasLtMatmulPreference_t pref = nullptr;
+        hipblasLtMatmulHeuristicResult_t res[1];
+        int found = 0;
+        const uint64_t ws = LT_WORKSPACE;
+        p.ok = api.DescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS
+            && api.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_t, sizeof(op_t)) == HIPBLAS_STATUS_SUCCESS
+            && api.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op_n, sizeof(op_n)) == HIPBLAS_STATUS_SUCCESS
+            && api.LayoutCreate(&p.a, HIP_R_16F, K, N, (int64_t)K) == HIPBLAS_STATUS_SUCCESS       // W^T as stored: K x N, ld K
+            && api.LayoutCreate(&p.b, HIP_R_16F, K, T, (int64_t)K) == HIPBLAS_STATUS_SUCCESS       // X^T: K x T, ld K
+            && api.LayoutCreate(&p.c, HIP_R_16F, N, T, (int64_t)N) == HIPBLAS_STATUS_SUCCESS       // Y^T: N x T, ld N
+            && api.PrefCreate(&pref) == HIPBLAS_STATUS_SUCCESS
+            && api.PrefSet(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws)) == HIPBLAS_STATUS_SUCCESS
+            && api.Heuristic(ctx.handle, p.desc, p.a, p.b, p.c, p.c, pref, 1, res, &found) == HIPBLAS_STATUS_SUCCESS
+            && found > 0 && res[0].state == HIPBLAS_STATUS_SUCCESS && res[0].workspaceSize <= LT_WORKSPACE;
+        if (p.ok) { p.algo = res[0].algo; p.workspace = res[0].workspaceSize; }
+        if (!p.desc) p.desc = reinterpret_cast<hipblasLtMatmulDesc_t>(1);      // remember the failure
+    }
+    if (!p.ok) return IFA_ERR_STATE;
+    const float alpha = 1.0f, beta = 0.0f;
+    if (api.Matmul(ctx.handle, p.desc, &alpha, Wh, p.a, X, p.b, &beta, Y, p.c, Y, p.c, &p.algo, ctx.workspace, p.workspace, s)
+        != HIPBLAS_STATUS_SUCCESS)
+        return IFA_ERR_STATE;
+    if (bias) k_add_bias_rows<<<dim3((unsigned)ifa_cdiv(T * N, 256)), dim3(256), 0, s>>>((half_t *)Y, (const half_t *)bias, T * N, (int)N);
+    return IFA_OK;
+}
+
+} // namespace ifa
+
+extern "C" int ifa_gemm_library_min_tokens(int min_tokens)
+{
+    std::lock_guard<std::mutex> lock(ifa::g_lt_mutex);
+    const int prev = ifa::lt_min_tokens();
+    if (min_tokens >= 0) ifa::g_lt_min_tokens = min_tokens;
+    return ifa::lt_api().ok ? prev : 0;
+}

@@ -24,20 +24,45 @@ __global__ void __launch_bounds__(256) k_quantize_blocks(const SrcT *__restrict_
     b.store(dst + bi * BB);
 }
 
+// 256 blocks per workgroup: the packed bytes arrive through LDS with coalesced loads (a thread-per-block walk of
+// 20..68-byte structs touches every line BB/2 times), one thread decodes one block, values leave as 16-byte stores
 template <int DT>
 __global__ void __launch_bounds__(256) k_dequantize_blocks(const uint8_t *__restrict__ src, half_t *__restrict__ dst,
                                                            size_t total_blocks)
 {
     constexpr int CAP = block_capacity(DT), BB = block_bytes(DT);
-    size_t bi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (bi >= total_blocks) return;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) uint16_t raw[256 * BB / 2];
+    const int tid = threadIdx.x;
+    const size_t b0 = (size_t)blockIdx.x * 256;
+    const int n = (int)min((size_t)256, total_blocks - b0);
+    const uint8_t *s = src + b0 * BB;
+    const int nh = n * BB / 2;                              // 16-bit words of this workgroup's blocks
+    if ((reinterpret_cast<uintptr_t>(s) & 3) == 0) {
+        for (int i = tid; i < nh / 2; i += 256) reinterpret_cast<uint32_t *>(raw)[i] = reinterpret_cast<const uint32_t *>(s)[i];
+        if ((nh & 1) && tid == 0) raw[nh - 1] = reinterpret_cast<const uint16_t *>(s)[nh - 1];
+    } else {
+        for (int i = tid; i < nh; i += 256) raw[i] = reinterpret_cast<const uint16_t *>(s)[i];
+    }
+    __syncthreads();
+    if (tid >= n) return;
     RawBlock<BB> b;
-    b.load(src + bi * BB);
+    b.load(reinterpret_cast<const uint8_t *>(raw) + tid * BB);
     int q[CAP]; float scale, base;
     decode_block<DT>(b, q, scale, base);
-    half_t *o = dst + bi * CAP;
+    half_t *o = dst + (b0 + tid) * CAP;
+    if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
 #pragma unroll
-    for (int i = 0; i < CAP; i++) o[i] = f2h(block_value<DT>(q[i], scale, base));
+        for (int c = 0; c < CAP / 8; c++) {
+            half_t v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = f2h(block_value<DT>(q[8 * c + e], scale, base));
+            *reinterpret_cast<u32x4 *>(o + 8 * c) = *reinterpret_cast<const u32x4 *>(v);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CAP; i++) o[i] = f2h(block_value<DT>(q[i], scale, base));
+    }
 }
 
 // Tensor_QuantizeQ8_B32T2_Alg2_Kernel (src/kernels/tensor_quant.h:44-82): one
