@@ -164,22 +164,35 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
 #pragma unroll
         for (int s2 = 0; s2 < KS; s2++)
             qa[s2] = __builtin_bit_cast(half8v, *reinterpret_cast<const u32x4v *>(q + ((size_t)tq * heads + h) * HD + 16 * s2 + 8 * g));
-        for (int kb = wave; kb < nkb; kb += 4) {
+        // two register sets of K fragments: the next block of this wave is in flight while one is multiplied
+        half8v ka[KS], kb2[KS];
+        auto kload = [&](half8v (&kf)[KS], int kb) {
             const int j = min(32 * kb + i, n_ctx - 1);
+#pragma unroll
+            for (int s2 = 0; s2 < KS; s2++) kf[s2] = kv_load8<Q8>(kc, row_bytes, j, hoff + 16 * s2 + 8 * g);
+        };
+        auto kscore = [&](const half8v (&kf)[KS], int kb) {
             f32x16v acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 #pragma unroll
-            for (int s2 = 0; s2 < KS; s2++) {
-                const half8v kf = kv_load8<Q8>(kc, row_bytes, j, hoff + 16 * s2 + 8 * g);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s2], kf, acc, 0, 0, 0);
-            }
+            for (int s2 = 0; s2 < KS; s2++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s2], kf[s2], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
                 half_t sv = f2h(alpha * acc[r]);
                 if (alibi) { float a = (float)(32 * kb + i) * mk; sv = f2h(a + h2f(sv)); }
                 S[(size_t)row * NKP + 32 * kb + i] = sv;
+            }
+        };
+        if (wave < nkb) kload(ka, wave);
+        if (wave + 4 < nkb) kload(kb2, wave + 4);
+        for (int kb = wave; kb < nkb; kb += 8) {
+            kscore(ka, kb);
+            if (kb + 8 < nkb) kload(ka, kb + 8);
+            if (kb + 4 < nkb) {
+                kscore(kb2, kb + 4);
+                if (kb + 12 < nkb) kload(kb2, kb + 12);
             }
         }
     }
@@ -210,19 +223,27 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
     for (int r = 0; r < 16; r++) oacc[r] = 0.0f;
     constexpr int CH = HD / 8;               // 16-byte chunks per V row
     constexpr int KPI = 256 / CH;            // keys staged per pass of the workgroup
-    for (int kt = 0; kt < nkb; kt++) {
-        __syncthreads();                     // previous block consumed (and, first time, P complete)
+    constexpr int NIT = (32 + KPI - 1) / KPI;
+    half8v va[NIT], vb[NIT];                 // V rows of the next two key blocks, requested two blocks ahead
+    auto vload = [&](half8v (&v)[NIT], int kt) {
 #pragma unroll
-        for (int it = 0; it < (32 + KPI - 1) / KPI; it++) {
+        for (int it = 0; it < NIT; it++) {
+            const int key = tid / CH + it * KPI, ch = tid % CH;
+            const int j = min(32 * kt + min(key, 31), n_ctx - 1);
+            v[it] = kv_load8<Q8>(vc, row_bytes, j, hoff + 8 * ch);
+        }
+    };
+    auto vstage = [&](const half8v (&v)[NIT]) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
             const int key = tid / CH + it * KPI, ch = tid % CH;
             if (key < 32) {
-                const int j = min(32 * kt + key, n_ctx - 1);
-                const half8v v8 = kv_load8<Q8>(vc, row_bytes, j, hoff + 8 * ch);
 #pragma unroll
-                for (int e = 0; e < 8; e++) Vt[(size_t)(8 * ch + e) * PF_VROW + key] = v8[e];
+                for (int e = 0; e < 8; e++) Vt[(size_t)(8 * ch + e) * PF_VROW + key] = v[it][e];
             }
         }
-        __syncthreads();
+    };
+    auto pv = [&](int kt) {
         if (wave < NT) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
@@ -230,6 +251,22 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
                 const half8v vf = *reinterpret_cast<const half8v *>(Vt + (size_t)(32 * wave + i) * PF_VROW + 16 * s2 + 8 * g);
                 oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, oacc, 0, 0, 0);
             }
+        }
+    };
+    if (nkb > 0) vload(va, 0);
+    if (nkb > 1) vload(vb, 1);
+    for (int kt = 0; kt < nkb; kt += 2) {
+        __syncthreads();                     // previous block consumed (and, first time, P complete)
+        vstage(va);
+        if (kt + 2 < nkb) vload(va, kt + 2);
+        __syncthreads();
+        pv(kt);
+        if (kt + 1 < nkb) {
+            __syncthreads();
+            vstage(vb);
+            if (kt + 3 < nkb) vload(vb, kt + 3);
+            __syncthreads();
+            pv(kt + 1);
         }
     }
     if (wave < NT) {

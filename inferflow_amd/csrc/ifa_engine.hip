@@ -444,6 +444,7 @@ __global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k,
     for (; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
 }
 
+extern "C" int ifa_activation_mul(int kind, const void *a, const void *b, size_t n, void *c, ifa_stream stream);
 extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens,
                                 const void *bias_f16, void *y_f16, ifa_stream stream);
 static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const Tensor &bias, half_t *C);
@@ -595,11 +596,10 @@ static int ffn_dense(ifa_model *m, const half_t *x, int T, const Tensor &w1, con
     int rc;
     ifa_stream s = (ifa_stream)m->stream;
     if ((rc = matmul(m, x, T, w1, b1, m->t1))) return rc;
-    if ((rc = ifa_activation(m->cfg.act_kind, 0, m->t1, (size_t)T, w1.rows, m->t1, s))) return rc;
     if (w3.present()) {
         if ((rc = matmul(m, x, T, w3, b3, m->t2))) return rc;
-        if ((rc = ifa_mul(m->t1, m->t2, (size_t)T * w1.rows, m->t1, s))) return rc;
-    }
+        if ((rc = ifa_activation_mul(m->cfg.act_kind, m->t1, m->t2, (size_t)T * w1.rows, m->t1, s))) return rc;
+    } else if ((rc = ifa_activation(m->cfg.act_kind, 0, m->t1, (size_t)T, w1.rows, m->t1, s))) return rc;
     return matmul(m, m->t1, T, w2, b2, out);
 }
 

@@ -135,19 +135,28 @@ __global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x,
 }
 
 // PosEmbedding_Rope_Order2_Kernel / _Std_Kernel (unary_tensor_opr.h:661-740)
+// One thread per (token, rotated pair): the angle (two powf, cosf, sinf -- the dominant cost of the per-element
+// form) is evaluated once and applied to that pair of every head with rope_rotate's expressions.
 __global__ void __launch_bounds__(256) k_rope(half_t *__restrict__ x, int head_dim, int heads, int tokens, int pos0,
                                               float theta, int order, int rope_dims, int rope_cols,
                                               const int *__restrict__ pos_tab = nullptr)
 {
     const int half_dim = head_dim / 2;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)tokens * heads * half_dim;
-    if (idx >= total) return;
+    if (idx >= (size_t)tokens * half_dim) return;
     const int col = (int)(idx % half_dim);
-    const size_t rowi = idx / half_dim;
-    const int t = (int)(rowi / heads);
-    half_t *row = x + rowi * head_dim;
-    rope_rotate(row, col, pos_tab ? pos_tab[t] : pos0 + t, theta, order, rope_dims, rope_cols);   // pos_tab: one position per row
+    const int t = (int)(idx / half_dim);
+    if (order == 2 && 2 * col >= rope_cols) return;
+    float c, s;
+    rope_angle(col, pos_tab ? pos_tab[t] : pos0 + t, theta, rope_dims, c, s);      // pos_tab: one position per row
+    const int i0 = order == 2 ? col : 2 * col, i1 = order == 2 ? col + rope_cols / 2 : 2 * col + 1;
+    half_t *row = x + (size_t)t * heads * head_dim;
+    for (int h = 0; h < heads; h++, row += head_dim) {
+        const float x0 = h2f(row[i0]), x1 = h2f(row[i1]);
+        float a = x0 * c, bq = x1 * s, d = x0 * s, e = x1 * c;
+        row[i0] = f2h(a - bq);
+        row[i1] = f2h(d + e);
+    }
 }
 
 // PosEmbedding_Alibi_Std_Kernel (unary_tensor_opr.h:742-762)
@@ -208,6 +217,21 @@ __global__ void __launch_bounds__(256) k_activation(const half_t *__restrict__ x
     float fx = act_fn(h2f(x[in_off]), kind);
     if (is_glu) fx = fx * h2f(x[in_off + cols]);
     y[idx] = f2h(fx);
+}
+
+// Activation followed by Mul in one pass (8 elements per thread), each with its own half rounding like the two ops
+__global__ void __launch_bounds__(256) k_act_mul(const half_t *__restrict__ a, const half_t *__restrict__ b, size_t n8, int kind,
+                                                 half_t *__restrict__ c)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const u32x4 ra = reinterpret_cast<const u32x4 *>(a)[i], rb = reinterpret_cast<const u32x4 *>(b)[i];
+    const half_t *ha = reinterpret_cast<const half_t *>(&ra), *hb = reinterpret_cast<const half_t *>(&rb);
+    half_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2h(h2f(f2h(act_fn(h2f(ha[e]), kind))) * h2f(hb[e]));
+    reinterpret_cast<u32x4 *>(c)[i] = *reinterpret_cast<const u32x4 *>(o);
 }
 
 __global__ void __launch_bounds__(256) k_mul(const half_t *a, const half_t *b, size_t n, half_t *c)
@@ -297,7 +321,7 @@ int ifa_rope(void *x, int head_dim, int heads, int tokens, int pos0, float theta
     // src/tensor/tensor_opr.cu:701-702 (F16 path passes rope_dims, appendix A12)
     int rope_cols = (int)(head_dim * partial_rotary_factor + 0.5f);
     int rope_dims = rope_cols;
-    size_t total = (size_t)tokens * heads * (head_dim / 2);
+    size_t total = (size_t)tokens * (head_dim / 2);
     k_rope<<<dim3(ifa_cdiv(total, 256)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, pos0, theta, order, rope_dims, rope_cols);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
@@ -312,7 +336,7 @@ int ifa_rope_rows(void *x, int head_dim, int heads, int tokens, const int *posit
     if (tokens <= 0 || heads <= 0) return IFA_OK;
     if (partial_rotary_factor <= 0) partial_rotary_factor = 1.0f;
     int rope_cols = (int)(head_dim * partial_rotary_factor + 0.5f);
-    size_t total = (size_t)tokens * heads * (head_dim / 2);
+    size_t total = (size_t)tokens * (head_dim / 2);
     k_rope<<<dim3(ifa_cdiv(total, 256)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, 0, theta, order, rope_cols,
                                                                        rope_cols, positions_dev);
     IFA_LAUNCH_CHECK();
@@ -346,6 +370,21 @@ int ifa_activation(int kind, int is_glu, const void *x, size_t rows, size_t cols
     IFA_REQUIRE(kind >= 0 && kind <= 2, "ifa_activation: kind %d", kind);
     if (rows * cols == 0) return IFA_OK;
     k_activation<<<dim3(ifa_cdiv(rows * cols, 256)), dim3(256), 0, ifa_s(stream)>>>((const half_t *)x, rows, cols, kind, is_glu, (half_t *)y);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// engine-internal: c = Mul(Activation(a), b) -- TensorOpr::Activation + TensorOpr::Mul of the gated FFN in one launch
+int ifa_activation_mul(int kind, const void *a, const void *b, size_t n, void *c, ifa_stream stream)
+{
+    IFA_REQUIRE(a && b && c, "ifa_activation_mul: null pointer");
+    IFA_REQUIRE(kind >= 0 && kind <= 2, "ifa_activation_mul: kind %d", kind);
+    if (n == 0) return IFA_OK;
+    if (n % 8 || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15)) {
+        int rc = ifa_activation(kind, 0, a, 1, n, c, stream);
+        return rc ? rc : ifa_mul(c, b, n, c, stream);
+    }
+    k_act_mul<<<dim3(ifa_cdiv(n / 8, 256)), dim3(256), 0, ifa_s(stream)>>>((const half_t *)a, (const half_t *)b, n / 8, kind, (half_t *)c);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
