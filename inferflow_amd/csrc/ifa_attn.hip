@@ -132,6 +132,8 @@ constexpr int PF_VROW = 40;          // halfs per row of the transposed V block 
 
 __host__ __device__ inline int pf_nkp(int n_keys) { return (n_keys + 31) / 32 * 32 + 8; }
 
+__device__ unsigned long long g_attn_trace[8];     // wall_clock64 stamps of the longest tile of head 0 (tools/probes)
+
 template <int HD, bool Q8>
 __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict__ q, const uint8_t *__restrict__ kc,
                                                         const uint8_t *__restrict__ vc, int n_ctx, int q_tokens,
@@ -141,7 +143,15 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16;          // MFMA k-steps over the head dimension
     constexpr int NT = HD / 32;          // 32-wide output tiles
-    const int t0 = blockIdx.x * PF_QT, h = blockIdx.y;
+    // workgroups go to the 8 XCDs round-robin in launch order: give every XCD a fixed eighth of the heads, so a head's
+    // K/V rows (re-read by each of its query tiles) stay in ONE 4 MB L2, and start the longest (last) tiles first
+    int tile = blockIdx.x, h = blockIdx.y;
+    if (heads % 8 == 0) {
+        const int w = blockIdx.y * gridDim.x + blockIdx.x, xcd = w & 7, r = w >> 3;
+        h = (r / (int)gridDim.x) * 8 + xcd;
+        tile = (int)gridDim.x - 1 - r % (int)gridDim.x;
+    }
+    const int t0 = tile * PF_QT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, g = lane >> 5;
     const int kvh = h / (heads / kv_heads);
@@ -157,6 +167,8 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
     const float alpha = 1.0f / sqrtf((float)HD) / kq_scale;
     const float mk = alibi ? alibi_slope(h + alibi_base, alibi_total) : 0.0f;
 
+    const bool tracer = h == 0 && tile == (int)gridDim.x - 1 && tid == 0;
+    if (tracer) g_attn_trace[0] = wall_clock64();
     // ---- S = half(alpha * Q.K^T) (+ALiBi), key blocks strided over the waves
     {
         half8v qa[KS];
@@ -197,26 +209,58 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
         }
     }
     __syncthreads();
+    if (tracer) g_attn_trace[1] = wall_clock64();
     // ---- P = softmax rows (Tensor_SoftMax_Alg2_Kernel rounding: half(e), then half(half(e) * 1/sum))
+    // 16-byte LDS accesses, 8 scores per lane and step (a 2-byte walk is one LDS round trip per element); the phase is
+    // VALU-bound (32 x n_keys exponentials per workgroup), so whole chunks skip the per-element causal mask
     for (int rr = 0; rr < 8; rr++) {
         const int row = 8 * wave + rr;
         const int t = t0 + row;
         half_t *Sr = S + (size_t)row * NKP;
         const int n_valid = t < q_tokens ? min(n_ctx, prefix_len + t + 1) : 0;
+        const int nch = 4 * nkb;
         float lmax = -INFINITY;
-        for (int j = lane; j < n_valid; j += 64) lmax = fmaxf(lmax, kq_scale * h2f(Sr[j]));
+        for (int c = lane; c < nch; c += 64) {
+            const half8v v = *reinterpret_cast<const half8v *>(Sr + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (8 * c + e < n_valid) lmax = fmaxf(lmax, kq_scale * h2f(v[e]));
+        }
         lmax = wave_max(lmax);
         float lsum = 0.0f;
-        for (int j = lane; j < 32 * nkb; j += 64) {
-            float e = 0.0f;
-            if (j < n_valid) e = expf(kq_scale * h2f(Sr[j]) - lmax);
-            lsum += e;
-            Sr[j] = f2h(e);
+        for (int c = lane; c < nch; c += 64) {
+            const half8v v = *reinterpret_cast<const half8v *>(Sr + 8 * c);
+            half8v o;
+            if (8 * c + 8 <= n_valid) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float ev = __expf(kq_scale * h2f(v[e]) - lmax);
+                    lsum += ev;
+                    o[e] = f2h(ev);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float ev = 0.0f;
+                    if (8 * c + e < n_valid) ev = __expf(kq_scale * h2f(v[e]) - lmax);
+                    lsum += ev;
+                    o[e] = f2h(ev);
+                }
+            }
+            *reinterpret_cast<half8v *>(Sr + 8 * c) = o;
         }
         lsum = wave_sum(lsum);
         const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;      // rows past q_tokens: all zero
-        for (int j = lane; j < 32 * nkb; j += 64) Sr[j] = f2h(h2f(Sr[j]) * inv);
+        const int nch_valid = min(nch, (n_valid + 7) / 8);        // beyond: already zero
+        for (int c = lane; c < nch_valid; c += 64) {
+            const half8v v = *reinterpret_cast<const half8v *>(Sr + 8 * c);
+            half8v o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = f2h(h2f(v[e]) * inv);
+            *reinterpret_cast<half8v *>(Sr + 8 * c) = o;
+        }
     }
+    if (tracer) g_attn_trace[2] = wall_clock64();
     // ---- O = P.V
     f32x16v oacc;
 #pragma unroll
@@ -225,21 +269,35 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
     constexpr int KPI = 256 / CH;            // keys staged per pass of the workgroup
     constexpr int NIT = (32 + KPI - 1) / KPI;
     half8v va[NIT], vb[NIT];                 // V rows of the next two key blocks, requested two blocks ahead
+    // lane bits: key parity | key pair (8) | chunk low (4); waves: chunk high, then further key groups.  Lane pairs swap
+    // halves of their rows so that every lane stores (even key, odd key) dwords of 4 dims: half the LDS stores of a
+    // 2-byte transpose, spread over 32 banks instead of 8
+    const int vpar = tid & 1, vpair = (tid >> 1) & 7;
+    const int vch = ((tid >> 4) & 3) + 4 * ((tid >> 6) % (CH / 4));
+    const int vkey0 = 16 * ((tid >> 6) / (CH / 4)) + 2 * vpair;             // even key of the lane pair within a pass
     auto vload = [&](half8v (&v)[NIT], int kt) {
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int key = tid / CH + it * KPI, ch = tid % CH;
-            const int j = min(32 * kt + min(key, 31), n_ctx - 1);
-            v[it] = kv_load8<Q8>(vc, row_bytes, j, hoff + 8 * ch);
+            const int key = min(vkey0 + vpar + it * KPI, 31);
+            const int j = min(32 * kt + key, n_ctx - 1);
+            v[it] = kv_load8<Q8>(vc, row_bytes, j, hoff + 8 * vch);
         }
     };
     auto vstage = [&](const half8v (&v)[NIT]) {
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int key = tid / CH + it * KPI, ch = tid % CH;
+            const u32x4v w = __builtin_bit_cast(u32x4v, v[it]);
+            const uint32_t m0 = vpar ? w[2] : w[0], m1 = vpar ? w[3] : w[1];            // the 4 dims this lane stores
+            const uint32_t r0 = __shfl_xor(vpar ? w[0] : w[2], 1), r1 = __shfl_xor(vpar ? w[1] : w[3], 1);
+            const uint32_t e0 = vpar ? r0 : m0, e1 = vpar ? r1 : m1;                      // even key's values
+            const uint32_t o0 = vpar ? m0 : r0, o1 = vpar ? m1 : r1;                      // odd key's values
+            const int key = vkey0 + it * KPI;
             if (key < 32) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) Vt[(size_t)(8 * ch + e) * PF_VROW + key] = v[it][e];
+                uint32_t *dst = reinterpret_cast<uint32_t *>(Vt + (size_t)(8 * vch + 4 * vpar) * PF_VROW + key);
+                dst[0 * PF_VROW / 2] = (e0 & 0xFFFFu) | (o0 << 16);
+                dst[1 * PF_VROW / 2] = (e0 >> 16) | (o0 & 0xFFFF0000u);
+                dst[2 * PF_VROW / 2] = (e1 & 0xFFFFu) | (o1 << 16);
+                dst[3 * PF_VROW / 2] = (e1 >> 16) | (o1 & 0xFFFF0000u);
             }
         }
     };
@@ -269,6 +327,7 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
             pv(kt + 1);
         }
     }
+    if (tracer) g_attn_trace[3] = wall_clock64();
     if (wave < NT) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -298,6 +357,12 @@ static int launch_attention_mfma(const void *q, const void *kcache, const void *
                                                                   prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base, alibi_total, (half_t *)out);
     }
     IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+extern "C" int ifa_debug_attn_trace(unsigned long long *out8)
+{
+    IFA_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ifa::g_attn_trace), 64));
     return IFA_OK;
 }
 
