@@ -186,32 +186,36 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
             }
         }
     } else {
-        // ---- split-K (small T): wave w owns K steps w, w+4, ...; two register sets keep the loads of its next two
-        // steps in flight while one step is multiplied (the layer is weight-stream bound here, latency is everything)
+        // ---- split-K (small T): wave w owns K steps w, w+4, ...; NST register sets keep the loads of its next NST
+        // steps in flight while one step is multiplied: the layer is a weight stream here, and what a CU can stream is
+        // (bytes in flight) / latency -- two sets left 10 KB per CU in flight, 0.66 TB/s for the whole chip
         constexpr int NCHW = 32 * MT * CHUNKS_PER_ROW / 64;               // activation chunks per lane and step
+        constexpr int NST = 4;
         struct Stage { u32x4 xa[NCHW]; WRaw<DT, CAP> wr; };
-        Stage sa, sb;
-        auto fetch = [&](Stage &st, int step) {
+        Stage st[NST];
+        auto fetch = [&](Stage &sg, int step) {
 #pragma unroll
             for (int c = 0; c < NCHW; c++) {
                 const int idx = lane + c * 64;
                 const int r = idx / CHUNKS_PER_ROW, cc = idx % CHUNKS_PER_ROW;
                 const int tok = min(t0 + r, T - 1), k = min(step * KSTEP + cc * 8, K - 8);
-                st.xa[c] = *reinterpret_cast<const u32x4 *>(X + (size_t)tok * K + k);
+                sg.xa[c] = *reinterpret_cast<const u32x4 *>(X + (size_t)tok * K + k);
             }
-            st.wr.load(W, nrow, nblk, min(2 * step + g, nblk - 1));
+            sg.wr.load(W, nrow, nblk, min(2 * step + g, nblk - 1));
         };
-        auto consume = [&](const Stage &st, int step) {
+        // every load is unconditional (clamped step, masked when consumed): a load under a branch makes the compiler wait
+        // vmcnt(0) at the join, which drains the whole ring at every step
+        auto consume = [&](const Stage &sg, int step, bool valid) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c = 0; c < NCHW; c++) {
                 const int idx = lane + c * 64;
                 const int r = idx / CHUNKS_PER_ROW, cc = idx % CHUNKS_PER_ROW;
-                const bool ok = (t0 + r < T) && (step * KSTEP + cc * 8 < K);
-                *reinterpret_cast<u32x4 *>(slab + (size_t)r * XROW + (size_t)cc * 16) = ok ? st.xa[c] : u32x4{0, 0, 0, 0};
+                const bool ok = valid && (t0 + r < T) && (step * KSTEP + cc * 8 < K);
+                *reinterpret_cast<u32x4 *>(slab + (size_t)r * XROW + (size_t)cc * 16) = ok ? sg.xa[c] : u32x4{0, 0, 0, 0};
             }
             half_t v[CAP];
-            st.wr.decode(2 * step + g < nblk, v);
+            sg.wr.decode(valid && 2 * step + g < nblk, v);
             __builtin_amdgcn_wave_barrier();     // one wave's LDS ops are ordered
 #pragma unroll
             for (int m = 0; m < CAP / 8; m++) {
@@ -226,14 +230,16 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
                 }
             }
         };
-        if (wave < nsteps) fetch(sa, wave);
-        if (wave + 4 < nsteps) fetch(sb, wave + 4);
-        for (int step = wave; step < nsteps; step += 8) {
-            consume(sa, step);
-            if (step + 8 < nsteps) fetch(sa, step + 8);
-            if (step + 4 < nsteps) {
-                consume(sb, step + 4);
-                if (step + 12 < nsteps) fetch(sb, step + 12);
+        const int last = nsteps - 1;
+        const int rounds = ((nsteps - wave + 3) / 4 + NST - 1) / NST;      // this wave's steps, in rounds of NST
+#pragma unroll
+        for (int u = 0; u < NST; u++) fetch(st[u], min(wave + 4 * u, last));
+        for (int r = 0; r < rounds; r++) {
+#pragma unroll
+            for (int u = 0; u < NST; u++) {
+                const int su = wave + 4 * (r * NST + u);
+                consume(st[u], su, su < nsteps);
+                fetch(st[u], min(su + 4 * NST, last));
             }
         }
     }

@@ -150,8 +150,10 @@ __global__ void __launch_bounds__(256) k_rope(half_t *__restrict__ x, int head_d
     float c, s;
     rope_angle(col, pos_tab ? pos_tab[t] : pos0 + t, theta, rope_dims, c, s);      // pos_tab: one position per row
     const int i0 = order == 2 ? col : 2 * col, i1 = order == 2 ? col + rope_cols / 2 : 2 * col + 1;
-    half_t *row = x + (size_t)t * heads * head_dim;
-    for (int h = 0; h < heads; h++, row += head_dim) {
+    // blockIdx.y splits the heads when there are too few (token, pair) threads to fill the chip (short prompts)
+    const int hpb = (heads + (int)gridDim.y - 1) / (int)gridDim.y, h0 = (int)blockIdx.y * hpb, h1 = min(heads, h0 + hpb);
+    half_t *row = x + ((size_t)t * heads + h0) * head_dim;
+    for (int h = h0; h < h1; h++, row += head_dim) {
         const float x0 = h2f(row[i0]), x1 = h2f(row[i1]);
         float a = x0 * c, bq = x1 * s, d = x0 * s, e = x1 * c;
         row[i0] = f2h(a - bq);
@@ -310,6 +312,13 @@ int ifa_layernorm(int kind, const void *x, size_t rows, size_t cols, const void 
     return IFA_OK;
 }
 
+static unsigned rope_head_split(size_t token_pairs, int heads)
+{
+    // aim at >= 32K threads in flight; one head per thread at most
+    size_t want = (32768 + token_pairs - 1) / token_pairs;
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(want, (size_t)heads));
+}
+
 int ifa_rope(void *x, int head_dim, int heads, int tokens, int pos0, float theta, int order,
              float partial_rotary_factor, ifa_stream stream)
 {
@@ -322,7 +331,7 @@ int ifa_rope(void *x, int head_dim, int heads, int tokens, int pos0, float theta
     int rope_cols = (int)(head_dim * partial_rotary_factor + 0.5f);
     int rope_dims = rope_cols;
     size_t total = (size_t)tokens * (head_dim / 2);
-    k_rope<<<dim3(ifa_cdiv(total, 256)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, pos0, theta, order, rope_dims, rope_cols);
+    k_rope<<<dim3(ifa_cdiv(total, 256), rope_head_split(total, heads)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, pos0, theta, order, rope_dims, rope_cols);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
@@ -337,7 +346,7 @@ int ifa_rope_rows(void *x, int head_dim, int heads, int tokens, const int *posit
     if (partial_rotary_factor <= 0) partial_rotary_factor = 1.0f;
     int rope_cols = (int)(head_dim * partial_rotary_factor + 0.5f);
     size_t total = (size_t)tokens * (head_dim / 2);
-    k_rope<<<dim3(ifa_cdiv(total, 256)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, 0, theta, order, rope_cols,
+    k_rope<<<dim3(ifa_cdiv(total, 256), rope_head_split(total, heads)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, 0, theta, order, rope_cols,
                                                                        rope_cols, positions_dev);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
