@@ -23,6 +23,20 @@ const char *ifa_engine_last_error(void);
 
 /* AddQuery(tokens, QueryOptions{strategy greedy}) */
 int ifa_engine_add_query(ifa_engine *e, const int *tokens, int n_tokens);
+/* AddQuery with SamplingStrategy::QueryOptions: strategy_id = SamplingStrategyId (0 Auto = the model's decoding_strategy or
+ * greedy, 1 sample.std, 2 greedy, 3 top_k, 4 top_p; FSD ... Mirostat: < 0 with a message), random_seed != 0 seeds the
+ * query's generator (sslib Random = the java.util.Random LCG), temperature as in SamplingStrategy::SoftMax */
+int ifa_engine_add_query_ex(ifa_engine *e, const int *tokens, int n_tokens, int strategy_id, int random_seed, float temperature);
+/* GetSamplingStrategyId(name): "sample.top_p", "greedy", ...; NULL/"" = the loaded model's default; 0 if unknown */
+int ifa_engine_strategy_id(ifa_engine *e, const char *name);
+/* host-only (no GPU): StdSamplingStrategy::ChooseTokens (src/transformer/sampling_strategy.cc:359-431) on one F16 logits
+ * row, n_draws consecutive draws from a generator seeded with `seed`; writes the drawn ids / pool probabilities and the
+ * pool after the top_p / max_k cut; returns the pool size or -1 */
+int ifa_sampling_choose(const uint16_t *logits_f16, int vocab, int strategy_id, int max_k, float top_p, int pool_size,
+                        float temperature, long long seed, int n_draws, int *out_ids, float *out_probs,
+                        int *pool_ids, float *pool_probs, int pool_capacity);
+/* the first n NextDouble() values of the generator seeded with `seed` (known-answer tests of the LCG) */
+int ifa_sampling_random_doubles(long long seed, int n, double *out);
 int ifa_engine_query_count(ifa_engine *e);
 int ifa_engine_remove_query(ifa_engine *e, int query_id);           /* 1 removed, 0 unknown id */
 

@@ -45,9 +45,16 @@ class InferenceEngine:
         except Exception:
             pass
 
-    def add_query(self, tokens):
+    def add_query(self, tokens, strategy=None, seed=0, temperature=1.0):
+        """strategy: None (the model's default) or a name / SamplingStrategyId ("sample.top_p", "greedy", 1 ...)"""
         arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
-        return _capi.lib().ifa_engine_add_query(self._h, arr, len(tokens))
+        if strategy is None and seed == 0 and temperature == 1.0:
+            return _capi.lib().ifa_engine_add_query(self._h, arr, len(tokens))
+        sid = 0 if strategy is None else (strategy if isinstance(strategy, int) else self.strategy_id(strategy))
+        return _capi.lib().ifa_engine_add_query_ex(self._h, arr, len(tokens), int(sid), int(seed), float(temperature))
+
+    def strategy_id(self, name=""):
+        return _capi.lib().ifa_engine_strategy_id(self._h, (name or "").encode())
 
     def query_count(self):
         return _capi.lib().ifa_engine_query_count(self._h)
@@ -100,3 +107,21 @@ class InferenceEngine:
 
     def model_info(self, key):
         return _capi.lib().ifa_engine_model_info(self._h, key.encode())
+
+
+def sampling_choose(logits_f16, strategy_id, max_k=8, top_p=0.9, pool_size=50, temperature=1.0, seed=1, n_draws=1):
+    """Host-only StdSamplingStrategy::ChooseTokens on one F16 logits row: (drawn ids, their probabilities, pool ids, pool probs)."""
+    lg = np.ascontiguousarray(logits_f16, np.float16)
+    ids = (C.c_int * max(1, n_draws))(); pr = (C.c_float * max(1, n_draws))()
+    pid = (C.c_int * 256)(); ppr = (C.c_float * 256)()
+    n = _capi.lib().ifa_sampling_choose(lg.ctypes.data_as(C.c_void_p), lg.size, int(strategy_id), max_k, top_p, pool_size, temperature,
+                                        int(seed), n_draws, ids, pr, pid, ppr, 256)
+    if n < 0:
+        raise EngineError(_capi.lib().ifa_engine_last_error().decode(errors="replace"))
+    return [ids[i] for i in range(n_draws)], [pr[i] for i in range(n_draws)], [pid[i] for i in range(min(n, 256))], [ppr[i] for i in range(min(n, 256))]
+
+
+def random_doubles(seed, n):
+    out = (C.c_double * n)()
+    _capi.lib().ifa_sampling_random_doubles(int(seed), n, out)
+    return [out[i] for i in range(n)]

@@ -1,4 +1,5 @@
 // engine_capi.cc -- C ABI of the InferenceEngine facade (include/inferflow_engine.h)
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -34,6 +35,44 @@ int ifa_engine_add_query(ifa_engine *e, const int *tokens, int n_tokens)
 {
     if (!e || !tokens || n_tokens <= 0) { EngineSetError("ifa_engine_add_query: bad arguments"); return -1; }
     return e->engine.AddQuery(std::vector<int>(tokens, tokens + n_tokens), QueryOptions());
+}
+
+int ifa_engine_add_query_ex(ifa_engine *e, const int *tokens, int n_tokens, int strategy_id, int random_seed, float temperature)
+{
+    if (!e || !tokens || n_tokens <= 0) { EngineSetError("ifa_engine_add_query_ex: bad arguments"); return -1; }
+    QueryOptions opt; opt.strategy_id = strategy_id; opt.random_seed = random_seed; opt.temperature = temperature;
+    return e->engine.AddQuery(std::vector<int>(tokens, tokens + n_tokens), opt);
+}
+
+int ifa_engine_strategy_id(ifa_engine *e, const char *name)
+{
+    return (int)(e ? e->engine.GetSamplingStrategyId(name ? name : "") : SamplingStrategyIdFromName(name ? name : ""));
+}
+
+int ifa_sampling_choose(const uint16_t *logits_f16, int vocab, int strategy_id, int max_k, float top_p, int pool_size,
+                        float temperature, long long seed, int n_draws, int *out_ids, float *out_probs,
+                        int *pool_ids, float *pool_probs, int pool_capacity)
+{
+    if (!logits_f16 || vocab <= 0 || n_draws < 0) { EngineSetError("ifa_sampling_choose: bad arguments"); return -1; }
+    StdSamplingConfig cfg; cfg.max_k = max_k; cfg.top_p = top_p; cfg.pool_size = pool_size;
+    JavaRandom rng((uint64_t)seed);
+    int pool_n = 0;
+    for (int d = 0; d < std::max(1, n_draws); d++) {
+        SamplingOutput out;
+        if (!ChooseTokens(out, logits_f16, vocab, (SamplingStrategyId)strategy_id, cfg, temperature, rng)) { EngineSetError("ifa_sampling_choose: unsupported strategy %d", strategy_id); return -1; }
+        if (d < n_draws && !out.selected.empty()) { if (out_ids) out_ids[d] = out.selected[0].id; if (out_probs) out_probs[d] = out.selected[0].weight; }
+        pool_n = (int)out.token_pool.size();
+        for (int i = 0; i < pool_n && i < pool_capacity; i++) { if (pool_ids) pool_ids[i] = out.token_pool[(size_t)i].id; if (pool_probs) pool_probs[i] = out.token_pool[(size_t)i].weight; }
+    }
+    return pool_n;
+}
+
+int ifa_sampling_random_doubles(long long seed, int n, double *out)
+{
+    if (!out || n < 0) return 0;
+    JavaRandom rng((uint64_t)seed);
+    for (int i = 0; i < n; i++) out[i] = rng.NextDouble();
+    return n;
 }
 
 int ifa_engine_query_count(ifa_engine *e) { return e ? e->engine.QueryCount() : -1; }

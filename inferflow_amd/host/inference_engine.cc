@@ -132,6 +132,13 @@ bool InferenceEngine::Init(const InferenceConfig &cfg)
     }
     device_ = groups.empty() || groups[0].empty() ? 0 : groups[0][0];
     if (device_ < 0 || device_ >= ifa_device_count()) { EngineSetError("device %d is not available (%d visible)", device_, ifa_device_count()); return false; }
+    default_strategy_ = SamplingStrategyId::Greedy; default_sampling_ = StdSamplingConfig();
+    if (!spec_.decoding_strategy.empty()) {
+        SamplingStrategyId sid; std::string err;
+        if (!ParseDecodingStrategy(spec_.decoding_strategy, sid, default_sampling_, &err)) { EngineSetError("%s for model %s", err.c_str(), spec_.sid.c_str()); return false; }
+        if (sid != SamplingStrategyId::Auto) default_strategy_ = sid;
+        if (!IsStdFamily(default_strategy_)) { EngineSetError("decoding_strategy \"%s\" of model %s is not supported (greedy, sample.std, top_k, top_p)", spec_.decoding_strategy.c_str(), spec_.sid.c_str()); return false; }
+    }
     if (!BuildWorker(&model_, spec_, device_)) return false;
     // one KV cache per concurrent query, like the reference's per-query LayerKVCache sets
     kv_slots_ = std::max(1, std::min(config_.max_concurrent_queries, 64));
@@ -147,8 +154,14 @@ int InferenceEngine::AddQuery(const std::vector<int> &tokens, const QueryOptions
     if ((int)tokens.size() >= max_ctx) { EngineSetError("The query has %zu tokens; max_context_len is %d", tokens.size(), max_ctx); return -1; }
     for (int t : tokens)
         if (t < 0 || t >= spec_.hyper_params.vocab_size) { EngineSetError("Token id %d is out of range", t); return -1; }
+    SamplingStrategyId strategy = (SamplingStrategyId)query_options.strategy_id;
+    if (query_options.strategy_id < 0 || query_options.strategy_id > (int)SamplingStrategyId::Mirostat) { EngineSetError("Invalid strategy id %d", query_options.strategy_id); return -1; }
+    if (strategy == SamplingStrategyId::Auto) strategy = default_strategy_;
+    if (!IsStdFamily(strategy)) { EngineSetError("Decoding strategy %d is not supported (greedy, sample.std, top_k, top_p)", query_options.strategy_id); return -1; }
     if ((int)queries_.size() >= std::min(config_.max_concurrent_queries, kv_slots_)) return 0;      // busy
     Query q; q.id = next_query_id_++; q.tokens = tokens; q.options = query_options;
+    q.strategy = strategy; q.sampling = default_sampling_;
+    if (query_options.random_seed != 0) q.rng.SetSeed((uint64_t)(int64_t)query_options.random_seed);    // SamplingStrategy::BeginQuery
     std::vector<bool> used((size_t)kv_slots_, false);
     for (const auto &kv : queries_) used[(size_t)kv.second.kv_slot] = true;
     while (q.kv_slot < kv_slots_ && used[(size_t)q.kv_slot]) q.kv_slot++;
@@ -157,6 +170,25 @@ int InferenceEngine::AddQuery(const std::vector<int> &tokens, const QueryOptions
 }
 
 int InferenceEngine::QueryCount() const { return (int)queries_.size(); }
+
+SamplingStrategyId InferenceEngine::GetSamplingStrategyId(const std::string &str) const
+{
+    if (str.empty()) return default_strategy_;
+    return SamplingStrategyIdFromName(str);
+}
+
+// SampleTokens (inference_engine.cc:1986-2042) for the non-greedy strategies: the logits row comes to the host
+bool InferenceEngine::SampleRow(Query &q, const uint16_t *logits_row, QueryInferenceResult &item)
+{
+    SamplingOutput out;
+    if (!ChooseTokens(out, logits_row, spec_.hyper_params.vocab_size, q.strategy, q.sampling, q.options.temperature, q.rng, -1,
+                      &q.eos_bypassing_count) || out.selected.empty()) {
+        EngineSetError("Sampling failed for query %d", q.id); return false;
+    }
+    item.next_tokens.clear();
+    item.next_tokens.push_back(out.selected[0]);
+    return true;
+}
 
 bool InferenceEngine::RemoveQuery(int query_id)
 {
@@ -182,7 +214,9 @@ bool InferenceEngine::Infer(InferenceResult &res)
         std::vector<int> toks((size_t)n), pos((size_t)n), slots((size_t)n), next((size_t)n, -1);
         for (int r = 0; r < n; r++) { toks[(size_t)r] = batch[(size_t)r]->tokens.back(); pos[(size_t)r] = batch[(size_t)r]->processed; slots[(size_t)r] = batch[(size_t)r]->kv_slot; }
         void *lg = nullptr;
-        if (config_.return_output_tensors) {
+        bool any_sampled = false;
+        for (Query *bq : batch) any_sampled = any_sampled || bq->strategy != SamplingStrategyId::Greedy;
+        if (config_.return_output_tensors || any_sampled) {
             if ((size_t)n > logits_rows_) {
                 if (logits_dev_) ifa_free(logits_dev_);
                 logits_dev_ = nullptr; logits_rows_ = 0;
@@ -204,10 +238,11 @@ bool InferenceEngine::Infer(InferenceResult &res)
         for (int r = 0; r < n; r++) {
             Query &q = *batch[(size_t)r];
             QueryInferenceResult item; item.query_id = q.id; item.prefix_len = q.processed;
-            if (lg) { item.output_rows = 1; item.output_cols = V; item.output_tensor.assign(all.begin() + (size_t)r * V, all.begin() + (size_t)(r + 1) * V); }
+            if (lg && config_.return_output_tensors) { item.output_rows = 1; item.output_cols = V; item.output_tensor.assign(all.begin() + (size_t)r * V, all.begin() + (size_t)(r + 1) * V); }
             q.processed = (int)q.tokens.size();
             IdWeight w; w.id = next[(size_t)r]; w.weight = 1.0f;
             item.next_tokens.push_back(w);
+            if (q.strategy != SamplingStrategyId::Greedy && !SampleRow(q, all.data() + (size_t)r * V, item)) return false;
             res.items.push_back(std::move(item));
         }
     }
@@ -220,7 +255,8 @@ bool InferenceEngine::Infer(InferenceResult &res)
         if (ifa_model_select_kv(model_, q.kv_slot) != IFA_OK) { EngineSetError("select_kv: %s", ifa_last_error()); return false; }
         QueryInferenceResult item; item.query_id = q.id; item.prefix_len = q.processed;
         int next = -1;
-        const bool want_tensor = config_.return_output_tensors;
+        const bool sampled = q.strategy != SamplingStrategyId::Greedy;
+        const bool want_tensor = config_.return_output_tensors || sampled;
         if (n_new == 1 && !want_tensor) {                            // decode: fused graph-replayed step
             if (ifa_model_decode(model_, q.tokens.back(), q.processed, 1, &next, nullptr) != IFA_OK) {
                 EngineSetError("decode step failed: %s", ifa_last_error()); return false;
@@ -239,16 +275,24 @@ bool InferenceEngine::Infer(InferenceResult &res)
             if (ifa_model_forward(model_, q.tokens.data() + q.processed, n_new, q.processed, lg, &next) != IFA_OK) {
                 EngineSetError("forward step failed: %s", ifa_last_error()); return false;
             }
-            if (want_tensor) {
+            std::vector<uint16_t> last_row;
+            if (config_.return_output_tensors) {
                 item.output_rows = n_new; item.output_cols = V;
                 item.output_tensor.resize((size_t)n_new * V);
                 if (ifa_memcpy_d2h(item.output_tensor.data(), lg, (size_t)n_new * V * 2, ifa_model_stream(model_)) != IFA_OK
                     || ifa_stream_sync(ifa_model_stream(model_)) != IFA_OK) { EngineSetError("logits copy: %s", ifa_last_error()); return false; }
+            } else if (sampled) {                                    // sampling only: the last row is all the host needs
+                last_row.resize((size_t)V);
+                if (ifa_memcpy_d2h(last_row.data(), (const uint16_t *)lg + (size_t)(n_new - 1) * V, (size_t)V * 2, ifa_model_stream(model_)) != IFA_OK
+                    || ifa_stream_sync(ifa_model_stream(model_)) != IFA_OK) { EngineSetError("logits copy: %s", ifa_last_error()); return false; }
+            }
+            if (sampled) {
+                const uint16_t *row = config_.return_output_tensors ? item.output_tensor.data() + (size_t)(n_new - 1) * V : last_row.data();
+                if (!SampleRow(q, row, item)) return false;
             }
         }
         q.processed = (int)q.tokens.size();
-        IdWeight w; w.id = next; w.weight = 1.0f;
-        item.next_tokens.push_back(w);
+        if (item.next_tokens.empty()) { IdWeight w; w.id = next; w.weight = 1.0f; item.next_tokens.push_back(w); }
         res.items.push_back(std::move(item));
     }
     res.perf_stat.time_map[0] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#include "sampling_strategy.h"
+
 struct ifa_model;
 
 namespace inferflow_amd {
@@ -77,19 +79,18 @@ struct InferenceConfig {
     DebugOptions debug;
 };
 
-struct QueryOptions {               // SamplingStrategy::QueryOptions (sampling_strategy.h)
-    int strategy_id = 0;            // 0 = greedy (the only one on the hot path)
-    int random_seed = 0;
+struct QueryOptions {               // SamplingStrategy::QueryOptions (sampling_strategy.h:75-81)
+    int strategy_id = 0;            // SamplingStrategyId: 0 Auto (the model's decoding_strategy, greedy if none), 1 sample.std,
+                                    // 2 greedy (device argmax, the hot path), 3 top_k, 4 top_p; others are rejected
+    int random_seed = 0;            // != 0: seeds the query's generator (reproducible draws)
     float temperature = 1.0f;
     int max_output_len = -1;
 };
 
-struct IdWeight { int id = 0; float weight = 0; };
-
 struct QueryInferenceResult {
     int query_id = 0;
     int prefix_len = 0;
-    std::vector<IdWeight> next_tokens;          // [0] = greedy choice, weight = its logit
+    std::vector<IdWeight> next_tokens;          // [0] = the chosen token (greedy: weight 1; sampled: its pool probability)
     std::vector<uint16_t> output_tensor;        // F16 logits [output_rows][output_cols] if return_output_tensors
     int output_rows = 0, output_cols = 0;
 };
@@ -127,6 +128,8 @@ public:
     // round trip per token).  Equivalent to n x {Infer, CommitInferenceResult(greedy)}.
     bool Generate(int query_id, int n_steps, std::vector<int> &new_tokens, float *gpu_ms = nullptr);
 
+    // id of a strategy name ("sample.top_p" ...); empty: the model's own decoding_strategy
+    SamplingStrategyId GetSamplingStrategyId(const std::string &str = "") const;
     const ModelSpec &model_spec() const { return spec_; }
     std::string Version() const { return "inferflow_amd 0.1 (MI355X)"; }
     int default_device_id() const { return device_; }
@@ -140,13 +143,20 @@ private:
         QueryOptions options;
         bool ended = false;
         int kv_slot = 0;            // this query's KV cache inside the worker (ifa_model_select_kv)
+        SamplingStrategyId strategy = SamplingStrategyId::Greedy;
+        StdSamplingConfig sampling; // per query copy, like StdQueryData::config
+        JavaRandom rng;
+        int eos_bypassing_count = 0;
     };
+    bool SampleRow(Query &q, const uint16_t *logits_row, QueryInferenceResult &item);
     InferenceConfig config_;
     ModelSpec spec_;
     ifa_model *model_ = nullptr;
     int device_ = 0;
     int next_query_id_ = 1;
     int kv_slots_ = 1;
+    SamplingStrategyId default_strategy_ = SamplingStrategyId::Greedy;
+    StdSamplingConfig default_sampling_;
     std::map<int, Query> queries_;
     void *logits_dev_ = nullptr;
     size_t logits_rows_ = 0;

@@ -1,0 +1,159 @@
+// sampling_strategy.cc -- see sampling_strategy.h
+#include "sampling_strategy.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <ctime>
+#include <map>
+
+#include "ifa_json.h"
+
+namespace inferflow_amd {
+
+static inline float HalfToFloat(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+
+JavaRandom::JavaRandom() { SetSeed((uint64_t)time(nullptr)); }
+
+SamplingStrategyId SamplingStrategyIdFromName(const std::string &name)
+{
+    static const std::map<std::string, SamplingStrategyId> names = {
+        {"std", SamplingStrategyId::StdSampling}, {"sample.std", SamplingStrategyId::StdSampling},
+        {"greedy", SamplingStrategyId::Greedy}, {"sample.greedy", SamplingStrategyId::Greedy},
+        {"top_k", SamplingStrategyId::TopK}, {"sample.top_k", SamplingStrategyId::TopK},
+        {"top_p", SamplingStrategyId::TopP}, {"sample.top_p", SamplingStrategyId::TopP},
+        {"fsd", SamplingStrategyId::FSD}, {"sample.fsd", SamplingStrategyId::FSD},
+        {"random_fsd", SamplingStrategyId::RandomizedFSD}, {"sample.random_fsd", SamplingStrategyId::RandomizedFSD},
+        {"min_p", SamplingStrategyId::MinP}, {"tfs", SamplingStrategyId::TFS}, {"typical", SamplingStrategyId::Typical},
+        {"mirostat", SamplingStrategyId::Mirostat}};
+    auto it = names.find(name);
+    return it == names.end() ? SamplingStrategyId::Auto : it->second;
+}
+
+bool ParseDecodingStrategy(const std::string &text, SamplingStrategyId &id, StdSamplingConfig &cfg, std::string *err)
+{
+    id = SamplingStrategyId::Auto;
+    size_t a = 0;
+    while (a < text.size() && isspace((unsigned char)text[a])) a++;
+    if (a == text.size()) return true;                          // empty: Auto (greedy here)
+    if (text[a] != '{') {
+        size_t b = text.size();
+        while (b > a && isspace((unsigned char)text[b - 1])) b--;
+        id = SamplingStrategyIdFromName(text.substr(a, b - a));
+        if (id == SamplingStrategyId::Auto) { if (err) *err = "Invalid decoding_strategy"; return false; }
+        return true;
+    }
+    JsonValue doc; JsonParser parser; std::string perr;
+    if (!parser.Parse(text, doc, &perr)) { if (err) *err = "Invalid JSON format in the decoding strategy configuration: " + perr; return false; }
+    std::string name;
+    if (!doc.GetString("name", name)) { if (err) *err = "The \"name\" field is missing in the decoding strategy configuration"; return false; }
+    id = SamplingStrategyIdFromName(name);
+    if (id == SamplingStrategyId::Auto) { if (err) *err = "Invalid decoding_strategy"; return false; }
+    doc.GetNumber("min_k", cfg.min_k); doc.GetNumber("max_k", cfg.max_k); doc.GetNumber("top_p", cfg.top_p);
+    doc.GetNumber("pool_size", cfg.pool_size); doc.GetNumber("eos_bypassing_max", cfg.eos_bypassing_max);
+    return true;
+}
+
+void SortedTopK(const uint16_t *logits, int n, int k, std::vector<IdWeight> &pool)
+{
+    pool.clear();
+    if (n <= 0 || k <= 0) return;
+    // "a ranks before b": higher logit, or the same logit and the lower id
+    auto before = [](const IdWeight &a, const IdWeight &b) { return a.weight > b.weight || (a.weight == b.weight && a.id < b.id); };
+    // bounded heap whose top is the worst kept item
+    std::vector<IdWeight> heap;
+    heap.reserve((size_t)k + 1);
+    for (int i = 0; i < n; i++) {
+        IdWeight it; it.id = i; it.weight = HalfToFloat(logits[i]);
+        if (it.weight != it.weight) continue;                   // NaN never enters an ordered set
+        if ((int)heap.size() < k) { heap.push_back(it); std::push_heap(heap.begin(), heap.end(), before); }
+        else if (before(it, heap.front())) {
+            std::pop_heap(heap.begin(), heap.end(), before);
+            heap.back() = it;
+            std::push_heap(heap.begin(), heap.end(), before);
+        }
+    }
+    std::sort(heap.begin(), heap.end(), before);
+    pool.swap(heap);
+}
+
+void SoftMaxPool(std::vector<IdWeight> &items, float temperature)
+{
+    if (items.empty()) return;
+    std::stable_sort(items.begin(), items.end(), [](const IdWeight &a, const IdWeight &b) { return a.weight > b.weight; });
+    if (temperature < 0.001f) temperature = 0.001f;
+    float max_value = items[0].weight;
+    for (const IdWeight &it : items) max_value = std::max(max_value, it.weight);
+    float sum = 0;
+    for (IdWeight &it : items) { it.weight = (float)exp((it.weight - max_value) / temperature); sum += it.weight; }
+    if (sum < 0.00001f) sum = 0.00001f;
+    for (IdWeight &it : items) it.weight /= sum;
+}
+
+IdWeight DrawOne(JavaRandom &rng, const std::vector<IdWeight> &pool)
+{
+    IdWeight none;
+    if (pool.empty()) return none;
+    std::vector<double> base(pool.size());
+    double upper = 0;
+    for (size_t i = 0; i < pool.size(); i++) { base[i] = upper; upper += std::max(0.0, (double)pool[i].weight); }
+    const double r = rng.NextDouble(0, upper);
+    // the reference's interval search, including its tie behaviour at the interval ends
+    uint32_t begin = 0, end = (uint32_t)pool.size() - 1, mid = begin;
+    while (begin < end) {
+        mid = (end + begin) / 2;
+        if (r < base[mid]) end = mid;
+        else if (r > base[mid + 1]) { begin = mid + 1; mid = begin; }
+        else break;
+    }
+    return pool[mid];
+}
+
+bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, SamplingStrategyId strategy,
+                  const StdSamplingConfig &cfg, float temperature, JavaRandom &rng, int eos_id, int *eos_bypassing_count)
+{
+    out = SamplingOutput();
+    if (!logits || vocab <= 0 || !IsStdFamily(strategy)) return false;
+    int max_queue_len = 1;
+    float top_p = 1.0f;
+    if (strategy != SamplingStrategyId::Greedy) max_queue_len = std::min(cfg.pool_size, vocab);
+    if (strategy == SamplingStrategyId::StdSampling || strategy == SamplingStrategyId::TopP) top_p = cfg.top_p;
+    std::vector<IdWeight> pool;
+    SortedTopK(logits, vocab, max_queue_len, pool);
+    SoftMaxPool(pool, temperature);
+    const int top_k = std::min((int)pool.size(), cfg.max_k);
+    float cumulative = 0;
+    for (const IdWeight &it : pool) {                            // topp_topk_filter_on_sorted, sampling_strategy.cc:29-43
+        cumulative += it.weight;
+        out.token_pool.push_back(it);
+        if (cumulative >= top_p || (int)out.token_pool.size() >= top_k) break;
+    }
+    if (out.token_pool.empty()) return true;
+    out.selected.push_back(DrawOne(rng, out.token_pool));
+    if (eos_id >= 0) {
+        if (out.token_pool[0].id == eos_id && out.selected[0].id != eos_id) out.flag = 1;
+        if (cfg.eos_bypassing_max > 0 && out.selected[0].id == eos_id && out.token_pool.size() > 1 && eos_bypassing_count
+            && *eos_bypassing_count < cfg.eos_bypassing_max) {
+            out.flag = 2;
+            for (const IdWeight &it : out.token_pool)
+                if (it.id != eos_id) { out.selected[0] = it; (*eos_bypassing_count)++; break; }
+        }
+    }
+    return true;
+}
+
+} // namespace inferflow_amd

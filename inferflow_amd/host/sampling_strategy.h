@@ -1,0 +1,76 @@
+// sampling_strategy.h -- the reference's standard decoding strategies on the host:
+// Greedy, StdSampling ("sample.std"), TopK and TopP of StdSamplingStrategy
+// (src/transformer/sampling_strategy.cc:235-431): top-`pool_size` of the logits in TopKQueue order,
+// SoftMax with temperature over that pool, top_p / max_k cut, one draw with the engine's generator.
+// The generator is sslib's Random (3rd_party/sslib/random.h:15-121) = the published java.util.Random
+// LCG, so a seeded query draws the same tokens as the reference given the same logits.
+// FSD / RandomizedFSD / MinP / TFS / Typical / Mirostat are not restated (AddQuery rejects them).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace inferflow_amd {
+
+struct IdWeight { int id = 0; float weight = 0; };
+
+enum class SamplingStrategyId {     // DecodingStrategyId, sampling_strategy.h:55-68
+    Auto = 0, StdSampling, Greedy, TopK, TopP, FSD, RandomizedFSD, MinP, TFS, Typical, Mirostat
+};
+
+// "sample.std", "greedy", "sample.top_p", ... (decoding_strategies.cc:96-111); Auto when unknown
+SamplingStrategyId SamplingStrategyIdFromName(const std::string &name);
+inline bool IsStdFamily(SamplingStrategyId id)
+{
+    return id == SamplingStrategyId::StdSampling || id == SamplingStrategyId::Greedy || id == SamplingStrategyId::TopK
+        || id == SamplingStrategyId::TopP;
+}
+
+class JavaRandom {                  // sslib::Random: seed' = (seed * 0x5DEECE66D + 0xB) mod 2^48
+public:
+    JavaRandom();                                   // seeded from the clock, like the reference's default
+    explicit JavaRandom(uint64_t seed) { SetSeed(seed); }
+    void SetSeed(uint64_t seed) { seed_ = (seed ^ MULTIPLIER) & MASK; }
+    int32_t Next(int bits)
+    {
+        seed_ = (seed_ * MULTIPLIER + ADDEND) & MASK;
+        return (int32_t)(seed_ >> (48 - bits));
+    }
+    double NextDouble() { return (double)(((int64_t)Next(26) << 27) + Next(27)) / (double)(1LL << 53); }
+    double NextDouble(double from, double to) { return from + NextDouble() * (to - from); }
+
+private:
+    static constexpr uint64_t MULTIPLIER = 0x5DEECE66DULL, ADDEND = 0xBULL, MASK = (1ULL << 48) - 1;
+    uint64_t seed_ = 0;
+};
+
+struct StdSamplingConfig {          // StdSamplingStrategy::Config, sampling_strategy.h:242-249
+    int min_k = 1, max_k = 8;
+    float top_p = 0.9f;
+    int pool_size = 50;
+    int eos_bypassing_max = 0;
+};
+
+struct SamplingOutput {
+    std::vector<IdWeight> token_pool;   // probabilities after the top_p / max_k cut, descending
+    std::vector<IdWeight> selected;     // the drawn token (weight = its probability in the pool)
+    int flag = 0;                       // 1: the top token is EOS but another one was drawn; 2: EOS bypassed
+};
+
+// model.<name>.decoding_strategy: a name, or {"name": "sample.top_p", "top_p": 0.9, "max_k": 8, ...}
+bool ParseDecodingStrategy(const std::string &text, SamplingStrategyId &id, StdSamplingConfig &cfg, std::string *err = nullptr);
+
+// the k best (logit, id) pairs, best first; equal logits: lower id first (TopKQueue::LessWeight, top_k_queue.h:13-22)
+void SortedTopK(const uint16_t *logits_f16, int n, int k, std::vector<IdWeight> &pool);
+// SamplingStrategy::SoftMax (sampling_strategy.cc:107-147): temperature floor 0.001, sum floor 1e-5
+void SoftMaxPool(std::vector<IdWeight> &items, float temperature);
+// Random::RandomSampling(output, input, 1) (random.cc:75-146): one draw proportional to the weights
+IdWeight DrawOne(JavaRandom &rng, const std::vector<IdWeight> &pool);
+
+// StdSamplingStrategy::ChooseTokens (sampling_strategy.cc:359-431).  eos_id < 0: the model has no EOS notion here
+// (token-id queries), the EOS flags / bypassing are skipped.  *eos_bypassing_count is the query's running count.
+bool ChooseTokens(SamplingOutput &out, const uint16_t *logits_f16, int vocab, SamplingStrategyId strategy,
+                  const StdSamplingConfig &cfg, float temperature, JavaRandom &rng, int eos_id = -1,
+                  int *eos_bypassing_count = nullptr);
+
+} // namespace inferflow_amd

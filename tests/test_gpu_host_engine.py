@@ -138,3 +138,70 @@ def test_fused_qkv_checkpoints_load_like_separate_tensors(tmp_path, qkv_format):
         eng.close()
     assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2]
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_sampled_queries_draw_from_the_engines_logits_with_the_reference_generator(tmp_path):
+    """sample.top_p / sample.std / top_k queries: the engine brings the last logits row to the host and draws with the
+    query's java.util.Random generator -- same tokens as oracle/sampling.py on the logits the engine returns; a seed
+    reproduces the sequence; greedy and sampled queries share batched steps."""
+    from oracle import sampling as S
+    ini, _ = fx.write_model_dir(str(tmp_path), fmt="llama2.c", wd="Q4", kvd="F16", maxq=6)        # return_output_tensors = true
+    eng = InferenceEngine.from_ini(ini)
+    assert eng.strategy_id("sample.top_p") == S.TOP_P and eng.strategy_id("greedy") == S.GREEDY and eng.strategy_id("") == S.GREEDY
+    prompt = list(np.random.default_rng(5).integers(3, 1000, 7))
+
+    def run(strategy, seed, temperature, steps=8):
+        qid = eng.add_query(prompt, strategy=strategy, seed=seed, temperature=temperature)
+        assert qid > 0
+        rng, toks = S.JavaRandom(seed), []
+        for _ in range(steps):
+            (q, tok), = eng.infer()
+            lg = eng.last_logits(qid)
+            (want, _), _ = S.choose_tokens(lg[-1], eng.strategy_id(strategy), rng, temperature=temperature)
+            assert tok == want
+            toks.append(tok)
+            assert eng.commit({qid: tok})
+        assert eng.remove_query(qid)
+        return toks
+
+    a = run("sample.top_p", 11, 1.0)
+    assert run("sample.top_p", 11, 1.0) == a                    # same seed, same text
+    b = run("sample.std", 12, 1.3)
+    c = run("top_k", 13, 0.8)
+    assert len({tuple(a), tuple(b), tuple(c)}) == 3
+    # three queries advance together (dynamic batching from 2 queries on in this .ini): two sampled, one greedy
+    q1 = eng.add_query(prompt, strategy="sample.std", seed=21, temperature=1.5)
+    q2 = eng.add_query(prompt)
+    q3 = eng.add_query(prompt, strategy="top_k", seed=23)
+    rngs = {q1: (S.JavaRandom(21), S.STD, 1.5), q3: (S.JavaRandom(23), S.TOP_K, 1.0)}
+    for _ in range(5):
+        res = dict(eng.infer())
+        assert set(res) == {q1, q2, q3}
+        for q, (rng, sid, temp) in rngs.items():
+            (want, _), _ = S.choose_tokens(eng.last_logits(q)[-1], sid, rng, temperature=temp)
+            assert res[q] == want
+        assert res[q2] == int(np.argmax(eng.last_logits(q2)[-1].astype(np.float32)))
+        assert eng.commit(res)
+    # unsupported strategies are refused with a message, ids out of range too
+    assert eng.add_query(prompt, strategy="fsd") < 0 and "not supported" in InferenceEngine._err()
+    assert eng.add_query(prompt, strategy=99) < 0
+    eng.close()
+
+
+def test_model_decoding_strategy_from_the_ini(tmp_path):
+    ini, _ = fx.write_model_dir(str(tmp_path), fmt="llama2.c", wd="Q4", kvd="F16", ret="false")
+    text = open(ini).read().replace("prompt_template =", 'decoding_strategy = {"name":"sample.top_p", "top_p":0.5, "max_k":3}\nprompt_template =')
+    open(ini, "w").write(text)
+    eng = InferenceEngine.from_ini(ini)
+    assert eng.strategy_id("") == 4                               # Auto resolves to the model's strategy
+    qid = eng.add_query([1, 5, 9, 200], seed=3)                   # strategy Auto
+    seen = set()
+    for _ in range(12):
+        (q, tok), = eng.infer()
+        seen.add(tok)
+        assert eng.commit({qid: tok})
+    assert len(seen) > 1                                          # not the greedy fixed point of this tiny model
+    eng.close()
+    open(ini, "w").write(text.replace('{"name":"sample.top_p", "top_p":0.5, "max_k":3}', "sample.fsd"))
+    with pytest.raises(EngineError, match="not supported"):
+        InferenceEngine.from_ini(ini)

@@ -1,0 +1,59 @@
+"""CPU: the host-side decoding strategies (inferflow_amd/host/sampling_strategy.cc through the C ABI, no GPU involved)
+against the Python restatement in oracle/sampling.py and the published java.util.Random known answers."""
+import numpy as np
+import pytest
+
+from inferflow_amd import engine as E
+from oracle import sampling as S
+
+
+def test_generator_is_the_java_util_random_lcg():
+    r = S.JavaRandom(42)
+    assert [r.next(32), r.next(32)] == [-1170105035, 234785527]          # new java.util.Random(42).nextInt() x2
+    got = E.random_doubles(42, 5)
+    r = S.JavaRandom(42)
+    assert got == [r.next_double() for _ in range(5)]
+    assert got[0] == 0.7275636800328681                                   # new java.util.Random(42).nextDouble()
+    r = S.JavaRandom(-7 & ((1 << 64) - 1))                                # negative seeds: (uint64_t)(int64_t)seed
+    assert E.random_doubles(-7, 3) == [r.next_double() for _ in range(3)]
+
+
+@pytest.mark.parametrize("strategy", [S.STD, S.GREEDY, S.TOP_K, S.TOP_P])
+@pytest.mark.parametrize("temperature", [1.0, 0.7, 0.0005])
+def test_choose_tokens_matches_the_restated_reference(strategy, temperature):
+    rng = np.random.default_rng(100 * strategy + int(temperature * 10))
+    for case in range(6):
+        vocab = [1000, 37, 5, 32000, 64, 1][case]
+        logits = (rng.normal(0, 2.0, vocab)).astype(np.float16)
+        if case == 2:
+            logits[:] = logits[0]                                       # all equal: ties go to the lower id
+        if case == 4:
+            logits[10:20] = np.float16(3.5)                             # a plateau of equal best values
+        seed = 1234 + case
+        ids, probs, pool_ids, pool_probs = E.sampling_choose(logits, strategy, max_k=8, top_p=0.9, pool_size=50,
+                                                             temperature=temperature, seed=seed, n_draws=20)
+        r = S.JavaRandom(seed)
+        for d in range(20):
+            (tok, p), cut = S.choose_tokens(logits, strategy, r, max_k=8, top_p=0.9, pool_size=50, temperature=temperature)
+            assert ids[d] == tok, (case, d)
+            assert abs(probs[d] - float(p)) <= 2e-6 * max(1.0, float(p))
+        assert pool_ids == [i for i, _ in cut]
+        assert np.allclose(pool_probs, [float(w) for _, w in cut], rtol=1e-5, atol=1e-7)
+        if strategy == S.GREEDY:
+            assert pool_ids == [int(np.flatnonzero(logits == logits.max())[0])] and len(set(ids)) == 1
+
+
+def test_pool_cuts_follow_top_p_and_max_k():
+    logits = np.array([5.0, 4.0, 3.0, 2.0, 1.0, 0.0, -1.0, -2.0, -3.0, -4.0], np.float16)
+    _, _, pool, probs = E.sampling_choose(logits, S.TOP_K, max_k=3, top_p=0.5, pool_size=50)
+    assert pool == [0, 1, 2]                                            # top_k ignores top_p
+    _, _, pool, probs = E.sampling_choose(logits, S.TOP_P, max_k=8, top_p=0.6, pool_size=50)
+    assert pool == [0]                                                  # p0 = 0.636 >= 0.6 closes the pool
+    _, _, pool, probs = E.sampling_choose(logits, S.STD, max_k=8, top_p=0.99, pool_size=4)
+    assert pool == [0, 1, 2, 3] and abs(sum(probs) - 1.0) < 1e-5         # softmax over the 4-entry pool only
+    # the draws follow the pool probabilities
+    ids, _, pool, probs = E.sampling_choose(logits, S.TOP_K, max_k=4, top_p=1.0, pool_size=50, seed=7, n_draws=4000)
+    freq = np.bincount(ids, minlength=10)[:4] / 4000.0
+    assert np.abs(freq - np.array(probs)).max() < 0.03
+    with pytest.raises(E.EngineError):
+        E.sampling_choose(logits, 5)                                    # FSD: not restated
