@@ -9,6 +9,7 @@
 //  * ifa_model_decode(): batch-1 greedy decode with the fused kernels of
 //    ifa_decode_kernels.h, one hipGraph replay per token, token fed back on the
 //    device (no host round trip inside a batch of steps).
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -687,6 +688,8 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     ifa_stream s = m->stream;
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim;
     if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return ifa_fail(IFA_ERR_STATE, "F16 embeddings not set");
+    static const bool trace_host = getenv("IFA_TRACE_FORWARD") != nullptr;
+    const auto host_t0 = std::chrono::steady_clock::now();
     IFA_HIP_CHECK(hipMemcpyAsync(m->tokens_dev, tokens_host, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, m->stream));
     k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->tokens_dev, T, (int)D,
                                                                       (int)m->g[T_EMBD].rows, m->x);
@@ -757,7 +760,11 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
     if ((rc = ifa_argmax(m->logits + (size_t)(T - 1) * V, V, m->state, s))) return rc;
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    const auto host_t1 = std::chrono::steady_clock::now();
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (trace_host)      // how much of a step is the host enqueuing (launch-bound) vs the GPU draining what was enqueued
+        fprintf(stderr, "forward T=%d: enqueue %.3f ms, total %.3f ms\n", T, std::chrono::duration<double, std::milli>(host_t1 - host_t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());
     if (next_token) *next_token = m->host_pinned[0];
     return IFA_OK;
 }
