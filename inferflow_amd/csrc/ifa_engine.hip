@@ -445,6 +445,11 @@ __global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k,
     for (; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
 }
 
+extern "C" int ifa_add_layernorm(int kind, const void *a, const void *addend, size_t rows, size_t cols, const void *w, const void *b,
+                                 float multi_base, float eps, void *sum_out, void *y, ifa_stream stream);
+extern "C" int ifa_rope_qk_store(void *q, void *k, const void *v, int head_dim, int heads, int kv_heads, int tokens, int pos0, float theta,
+                                 int order, float partial_rotary_factor, void *kcache_rows, void *vcache_rows, size_t cache_row_elems,
+                                 ifa_stream stream);
 extern "C" int ifa_activation_mul(int kind, const void *a, const void *b, size_t n, void *c, ifa_stream stream);
 extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens,
                                 const void *bias_f16, void *y_f16, ifa_stream stream);
@@ -696,26 +701,40 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     IFA_LAUNCH_CHECK();
     half_t *x = m->x;
     const Tensor none;
+    // small element-wise ops are one launch where the wiring allows it (each keeps its own half rounding): RoPE(q) + RoPE(k)
+    // + the F16 cache rows; the residual Add + the norm that follows it (a layer is ~17 launches otherwise, and at short
+    // prompts every one of them is a fixed ~5 us)
+    const bool seq_wiring = !c.parallel_attn && !c.share_input;
+    bool xn_ready = false;           // m->xn already holds the next norm's output (fused into the previous layer's last Add)
     for (int l = 0; l < c.layers; l++) {
         Layer &L = m->layers[l];
         const half_t *attn_in = x;
         if (L.t[T_ATTN_NORM].present()) {
-            if ((rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn, c.attn_norm_base))) return rc;
+            if (!xn_ready && (rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn, c.attn_norm_base))) return rc;
             attn_in = m->xn;
         }
+        xn_ready = false;
         if ((rc = matmul(m, attn_in, T, L.t[T_WQ], L.t[T_WQ_B], m->q))) return rc;
         if ((rc = matmul(m, attn_in, T, L.t[T_WK], L.t[T_WK_B], m->k))) return rc;
         if ((rc = matmul(m, attn_in, T, L.t[T_WV], L.t[T_WV_B], m->v))) return rc;
-        if (c.rope_order != 0) {
-            if ((rc = ifa_rope(m->q, c.head_dim, c.heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
-            if ((rc = ifa_rope(m->k, c.head_dim, c.kv_heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
-        }
         uint8_t *kdst = (uint8_t *)L.kcache + (size_t)prefix_len * m->kv_row_bytes;
         uint8_t *vdst = (uint8_t *)L.vcache + (size_t)prefix_len * m->kv_row_bytes;
-        if (c.kv_dtype == Q8_B32T2) {
+        const bool kv_f16 = c.kv_dtype != Q8_B32T2;
+        bool kv_stored = false;
+        if (c.rope_order != 0) {
+            rc = ifa_rope_qk_store(m->q, m->k, m->v, c.head_dim, c.heads, c.kv_heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary,
+                                   kv_f16 ? kdst : nullptr, kv_f16 ? vdst : nullptr, m->kv_row_bytes / 2, s);
+            if (rc == IFA_OK) kv_stored = kv_f16;
+            else if (rc != IFA_ERR_STATE) return rc;
+            else {
+                if ((rc = ifa_rope(m->q, c.head_dim, c.heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
+                if ((rc = ifa_rope(m->k, c.head_dim, c.kv_heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
+            }
+        }
+        if (!kv_f16) {
             if ((rc = ifa_quantize_act_q8(m->k, T, KVD, kdst, s))) return rc;
             if ((rc = ifa_quantize_act_q8(m->v, T, KVD, vdst, s))) return rc;
-        } else {
+        } else if (!kv_stored) {
             IFA_HIP_CHECK(hipMemcpyAsync(kdst, m->k, (size_t)T * m->kv_row_bytes, hipMemcpyDeviceToDevice, m->stream));
             IFA_HIP_CHECK(hipMemcpyAsync(vdst, m->v, (size_t)T * m->kv_row_bytes, hipMemcpyDeviceToDevice, m->stream));
         }
@@ -724,13 +743,18 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
                                 c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
         if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
         if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
-        if (!c.parallel_attn && !c.share_input)
-            if ((rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
         const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
         const half_t *ff_n = ff_in;
-        if (L.t[T_FFN_NORM].present()) {
-            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
+        if (seq_wiring && L.t[T_FFN_NORM].present()) {          // Add(x, attn out) + ffn norm
+            if ((rc = ifa_add_layernorm(c.norm_kind, x, m->a, (size_t)T, D, L.t[T_FFN_NORM].data, L.t[T_FFN_NORM_B].present() ? L.t[T_FFN_NORM_B].data : nullptr,
+                                        c.ffn_norm_base, c.eps, m->a, m->hn, s))) return rc;
             ff_n = m->hn;
+        } else {
+            if (seq_wiring && (rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
+            if (L.t[T_FFN_NORM].present()) {
+                if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
+                ff_n = m->hn;
+            }
         }
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
             if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
@@ -738,16 +762,26 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
             if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
         }
         if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
-        if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
-        if (c.parallel_attn || c.share_input)
-            if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
+        // Add(ffn out, a) + the norm in front of what comes next: the next layer's attention norm, or the output norm
+        const bool last_layer = l + 1 == c.layers;
+        const Tensor &nw = last_layer ? m->g[T_OUT_NORM] : m->layers[l + 1].t[T_ATTN_NORM];
+        const Tensor &nb = last_layer ? m->g[T_OUT_NORM_B] : m->layers[l + 1].t[T_ATTN_NORM_B];
+        if (seq_wiring && nw.present() && !(last_layer && scale_on(c.out_scale))) {
+            if ((rc = ifa_add_layernorm(c.norm_kind, m->f, m->a, (size_t)T, D, nw.data, nb.present() ? nb.data : nullptr,
+                                        last_layer ? c.out_norm_base : c.attn_norm_base, c.eps, m->f, m->xn, s))) return rc;
+            xn_ready = true;
+        } else {
+            if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
+            if (c.parallel_attn || c.share_input)
+                if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
+        }
         std::swap(m->x, m->f);
         x = m->x;
     }
     if (scale_on(c.out_scale) && (rc = ifa_scale(x, c.out_scale, (size_t)T * D, x, s))) return rc;
     const half_t *hfin = x;
     if (m->g[T_OUT_NORM].present()) {
-        if ((rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn, c.out_norm_base))) return rc;
+        if (!xn_ready && (rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn, c.out_norm_base))) return rc;
         hfin = m->xn;
     } else {
         IFA_HIP_CHECK(hipMemcpyAsync(m->xn, x, (size_t)T * D * 2, hipMemcpyDeviceToDevice, m->stream));

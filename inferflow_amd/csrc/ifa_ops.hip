@@ -16,14 +16,39 @@ namespace ifa {
 template <int KIND>
 __global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x, int cols,
                                                    const half_t *__restrict__ w, const half_t *__restrict__ b,
-                                                   float multi_base, float eps, half_t *__restrict__ y)
+                                                   float multi_base, float eps, half_t *__restrict__ y,
+                                                   const half_t *__restrict__ add = nullptr, half_t *__restrict__ sum_out = nullptr)
 {
     __shared__ float part[128];
     __shared__ float part2[128];
     __shared__ float stat[2];
+    extern __shared__ __attribute__((aligned(16))) char smem_row[];
     const int tid = threadIdx.x;
     const half_t *src = x + (size_t)blockIdx.x * cols;
     half_t *dst = y + (size_t)blockIdx.x * cols;
+    bool staged = false;
+    if (add) {      // TensorOpr::Add in front of the norm, same launch: the half-rounded sum goes to sum_out and to LDS
+        half_t *row = reinterpret_cast<half_t *>(smem_row);
+        const half_t *ad = add + (size_t)blockIdx.x * cols;
+        half_t *so = sum_out + (size_t)blockIdx.x * cols;
+        if ((cols & 7) == 0) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            for (int c = tid; c < cols / 8; c += 128) {
+                const h8 a8 = reinterpret_cast<const h8 *>(src)[c], b8 = reinterpret_cast<const h8 *>(ad)[c];
+                h8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o8[e] = f2h((float)a8[e] + (float)b8[e]);
+                reinterpret_cast<h8 *>(row)[c] = o8; reinterpret_cast<h8 *>(so)[c] = o8;
+            }
+        } else {
+            for (int xi = tid; xi < cols; xi += 128) {
+                const half_t v = f2h(h2f(src[xi]) + h2f(ad[xi]));
+                row[xi] = v; so[xi] = v;
+            }
+        }
+        __syncthreads();
+        src = row; staged = true;
+    }
     if constexpr (KIND == 0) {
         part[tid] = rms_partial(src, cols, tid, 128);
         __syncthreads();
@@ -58,16 +83,17 @@ __global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x,
     } else {
         // the row is staged in LDS with wide loads first: the strided per-thread sums below (the reference's order)
         // would otherwise walk global memory one 2-byte load at a time on a latency chain
-        extern __shared__ __attribute__((aligned(16))) char smem_row[];
         half_t *row = reinterpret_cast<half_t *>(smem_row);
-        if ((cols & 7) == 0) {
-            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-            for (int c = tid; c < cols / 8; c += 128) reinterpret_cast<u4 *>(row)[c] = reinterpret_cast<const u4 *>(src)[c];
-        } else {
-            for (int xi = tid; xi < cols; xi += 128) row[xi] = src[xi];
+        if (!staged) {
+            if ((cols & 7) == 0) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                for (int c = tid; c < cols / 8; c += 128) reinterpret_cast<u4 *>(row)[c] = reinterpret_cast<const u4 *>(src)[c];
+            } else {
+                for (int xi = tid; xi < cols; xi += 128) row[xi] = src[xi];
+            }
+            __syncthreads();
+            src = row;
         }
-        __syncthreads();
-        src = row;
         float sum = 0.0f, sum2 = 0.0f;
         int xi = tid;
         for (; xi + 7 * 128 < cols; xi += 8 * 128) {     // 8 LDS reads in flight, then the ordered chain
@@ -158,6 +184,51 @@ __global__ void __launch_bounds__(256) k_rope(half_t *__restrict__ x, int head_d
         float a = x0 * c, bq = x1 * s, d = x0 * s, e = x1 * c;
         row[i0] = f2h(a - bq);
         row[i1] = f2h(d + e);
+    }
+}
+
+// PositionEmbedding(q), PositionEmbedding(k), SetKRows, SetVRows of a prefill step in ONE launch, a workgroup per token:
+// the token's head_dim/2 angles are evaluated once (LDS), q is rotated in place, k is rotated through LDS and leaves as
+// 16-byte stores to the k buffer and -- F16 caches -- to its cache row, v is copied to its cache row.
+__global__ void __launch_bounds__(256) k_rope_qk_store(half_t *__restrict__ q, half_t *__restrict__ k, const half_t *__restrict__ v,
+                                                       int head_dim, int heads, int kv_heads, int pos0, float theta, int order,
+                                                       int rope_dims, int rope_cols, half_t *__restrict__ kcache,
+                                                       half_t *__restrict__ vcache, size_t cache_row_elems)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_rk[];
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const int t = blockIdx.x, tid = threadIdx.x, half_dim = head_dim / 2;
+    float *cs = reinterpret_cast<float *>(smem_rk);                       // [half_dim][2]
+    half_t *krow = reinterpret_cast<half_t *>(cs + 2 * half_dim);         // [kv_heads * head_dim]
+    const int kv_dim = kv_heads * head_dim;
+    for (int c = tid; c < half_dim; c += 256) {
+        float co = 1.0f, si = 0.0f;
+        if (order != 2 || 2 * c < rope_cols) rope_angle(c, pos0 + t, theta, rope_dims, co, si);
+        cs[2 * c] = co; cs[2 * c + 1] = si;
+    }
+    const half_t *ksrc = k + (size_t)t * kv_dim;
+    for (int c = tid; c < kv_dim / 8; c += 256) reinterpret_cast<u4 *>(krow)[c] = reinterpret_cast<const u4 *>(ksrc)[c];
+    if (vcache)
+        for (int c = tid; c < kv_dim / 8; c += 256)
+            reinterpret_cast<u4 *>(vcache + (size_t)t * cache_row_elems)[c] = reinterpret_cast<const u4 *>(v + (size_t)t * kv_dim)[c];
+    __syncthreads();
+    auto rotate = [&](half_t *row, int col) {                              // rope_rotate's expressions (ifa_math.h)
+        if (order == 2 && 2 * col >= rope_cols) return;
+        const int i0 = order == 2 ? col : 2 * col, i1 = order == 2 ? col + rope_cols / 2 : 2 * col + 1;
+        const float c = cs[2 * col], sn = cs[2 * col + 1];
+        const float x0 = h2f(row[i0]), x1 = h2f(row[i1]);
+        float a = x0 * c, bq = x1 * sn, d = x0 * sn, e = x1 * c;
+        row[i0] = f2h(a - bq);
+        row[i1] = f2h(d + e);
+    };
+    half_t *qrow = q + (size_t)t * heads * head_dim;
+    for (int p = tid; p < heads * half_dim; p += 256) rotate(qrow + (size_t)(p / half_dim) * head_dim, p % half_dim);
+    for (int p = tid; p < kv_heads * half_dim; p += 256) rotate(krow + (size_t)(p / half_dim) * head_dim, p % half_dim);
+    __syncthreads();
+    for (int c = tid; c < kv_dim / 8; c += 256) {
+        const u4 kv8 = reinterpret_cast<const u4 *>(krow)[c];
+        reinterpret_cast<u4 *>(k + (size_t)t * kv_dim)[c] = kv8;
+        if (kcache) reinterpret_cast<u4 *>(kcache + (size_t)t * cache_row_elems)[c] = kv8;
     }
 }
 
@@ -297,6 +368,26 @@ using namespace ifa;
 
 extern "C" {
 
+// engine-internal: sum_out = a + addend (TensorOpr::Add, half rounding), y = LayerNormalization(sum_out) in one launch
+int ifa_add_layernorm(int kind, const void *a, const void *addend, size_t rows, size_t cols, const void *w, const void *b,
+                      float multi_base, float eps, void *sum_out, void *y, ifa_stream stream)
+{
+    IFA_REQUIRE(a && addend && sum_out && y, "ifa_add_layernorm: null pointer");
+    IFA_REQUIRE(kind == 0 || kind == 1, "ifa_add_layernorm: kind %d", kind);
+    IFA_REQUIRE(b == nullptr || w != nullptr, "ifa_add_layernorm: bias without weight");
+    if (rows == 0 || cols == 0) return IFA_OK;
+    const size_t smem = (cols * 2 + 15) & ~(size_t)15;
+    IFA_REQUIRE(smem <= 64 * 1024, "ifa_add_layernorm: %zu columns", cols);
+    if (kind == 0)
+        k_layernorm<0><<<dim3((unsigned)rows), dim3(128), smem, ifa_s(stream)>>>((const half_t *)a, (int)cols, (const half_t *)w, (const half_t *)b, multi_base, eps,
+                                                                                 (half_t *)y, (const half_t *)addend, (half_t *)sum_out);
+    else
+        k_layernorm<1><<<dim3((unsigned)rows), dim3(128), smem, ifa_s(stream)>>>((const half_t *)a, (int)cols, (const half_t *)w, (const half_t *)b, multi_base, eps,
+                                                                                 (half_t *)y, (const half_t *)addend, (half_t *)sum_out);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
 int ifa_layernorm(int kind, const void *x, size_t rows, size_t cols, const void *w, const void *b,
                   float multi_base, float eps, void *y, ifa_stream stream)
 {
@@ -332,6 +423,27 @@ int ifa_rope(void *x, int head_dim, int heads, int tokens, int pos0, float theta
     int rope_dims = rope_cols;
     size_t total = (size_t)tokens * (head_dim / 2);
     k_rope<<<dim3(ifa_cdiv(total, 256), rope_head_split(total, heads)), dim3(256), 0, ifa_s(stream)>>>((half_t *)x, head_dim, heads, tokens, pos0, theta, order, rope_dims, rope_cols);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// engine-internal: RoPE of q and k (+ the F16 cache rows of k and v when kcache_rows / vcache_rows are given: the rows of
+// positions pos0 .. pos0 + tokens - 1, cache_row_elems halfs apart) in one launch; IFA_ERR_STATE when the shape is not covered
+int ifa_rope_qk_store(void *q, void *k, const void *v, int head_dim, int heads, int kv_heads, int tokens, int pos0, float theta,
+                      int order, float partial_rotary_factor, void *kcache_rows, void *vcache_rows, size_t cache_row_elems,
+                      ifa_stream stream)
+{
+    IFA_REQUIRE(q && k, "ifa_rope_qk_store: null pointer");
+    if (tokens <= 0) return IFA_OK;
+    const int kv_dim = kv_heads * head_dim;
+    if ((order != 1 && order != 2) || head_dim % 2 || kv_dim % 8 || (vcache_rows && !v)) return IFA_ERR_STATE;
+    if (partial_rotary_factor <= 0) partial_rotary_factor = 1.0f;
+    const int rope_cols = (int)(head_dim * partial_rotary_factor + 0.5f);
+    const size_t smem = (size_t)head_dim * 4 + (size_t)kv_dim * 2;
+    if (smem > 64 * 1024 || (((uintptr_t)k | (uintptr_t)kcache_rows | (uintptr_t)vcache_rows | (uintptr_t)v) & 15) || (cache_row_elems % 8)) return IFA_ERR_STATE;
+    k_rope_qk_store<<<dim3((unsigned)tokens), dim3(256), smem, ifa_s(stream)>>>((half_t *)q, (half_t *)k, (const half_t *)v, head_dim, heads, kv_heads, pos0,
+                                                                               theta, order, rope_cols, rope_cols, (half_t *)kcache_rows,
+                                                                               (half_t *)vcache_rows, cache_row_elems);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
