@@ -98,19 +98,25 @@ struct WRaw {
                 for (int e = 0; e < 8; e++) v[8 * i + e] = h[e];
             }
         } else if constexpr (Q4FAST) {
-            const float base = hbits2f((uint16_t)(q4[0] & 0xFFFFu)), scale = hbits2f((uint16_t)(q4[0] >> 16));
+            // masked blocks: scale = base = 0 gives exact zeros (two selects instead of one per value); nibbles are spread
+            // into bytes first so that each value is ONE v_cvt_f32_ubyteN instead of a bit-field extract + convert
+            const float base = ok ? hbits2f((uint16_t)(q4[0] & 0xFFFFu)) : 0.0f, scale = ok ? hbits2f((uint16_t)(q4[0] >> 16)) : 0.0f;
 #pragma unroll
-            for (int w = 0; w < 4; w++)
+            for (int w = 0; w < 4; w++) {
+                const uint32_t lo = q4[1 + w] & 0x0F0F0F0Fu, hi = (q4[1 + w] >> 4) & 0x0F0F0F0Fu;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const float qv = (float)((q4[1 + w] >> (4 * e)) & 0xFu);
-                    v[8 * w + e] = ok ? f2h(__builtin_fmaf(qv, scale, base)) : (half_t)0;   // q*scale exact: fma == mul + add
+                for (int b = 0; b < 4; b++) {
+                    const float q0 = (float)((lo >> (8 * b)) & 0xFFu), q1 = (float)((hi >> (8 * b)) & 0xFFu);
+                    v[8 * w + 2 * b] = f2h(__builtin_fmaf(q0, scale, base));           // q*scale exact: fma == mul + add
+                    v[8 * w + 2 * b + 1] = f2h(__builtin_fmaf(q1, scale, base));
                 }
+            }
         } else {
             int q[CAP]; float scale, base;
             decode_block<DT>(blk, q, scale, base);
+            if (!ok) { scale = 0.0f; base = 0.0f; }          // codes are finite integers: exact zeros, no per-value select
 #pragma unroll
-            for (int i = 0; i < CAP; i++) v[i] = ok ? f2h(block_value<DT>(q[i], scale, base)) : (half_t)0;
+            for (int i = 0; i < CAP; i++) v[i] = f2h(block_value<DT>(q[i], scale, base));
         }
     }
 };
@@ -119,8 +125,8 @@ struct WRaw {
 // SPLITK = true : the 4 waves share ONE 32-row tile and take every 4th K step each (their own
 //                 LDS slab, no workgroup barrier in the loop), partial tiles summed through LDS at
 //                 the end: 4x more workgroups when T is small and the layer is weight-stream bound.
-template <int DT, int MT, bool SPLITK>
-__global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restrict__ W, int N, int nblk,
+template <int DT, int MT, bool SPLITK, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) k_gemm_q(const uint8_t *__restrict__ W, int N, int nblk,
                                                          const half_t *__restrict__ X, int T, int K,
                                                          const half_t *__restrict__ bias, half_t *__restrict__ Y)
 {
@@ -128,6 +134,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
     constexpr int KSTEP = 2 * CAP;                 // one quant block per lane half and step
     constexpr int XROW = KSTEP * 2 + 16;           // bytes per staged activation row (+16: bank spread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(SPLITK || NW == 4, "the non-split variant is 4 waves x 32 rows");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, g = lane >> 5;
     const int n = SPLITK ? blockIdx.x * 32 + i : blockIdx.x * GEMM_ROWS + wave * 32 + i;
@@ -231,21 +238,21 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
             }
         };
         const int last = nsteps - 1;
-        const int rounds = ((nsteps - wave + 3) / 4 + NST - 1) / NST;      // this wave's steps, in rounds of NST
+        const int rounds = ((nsteps - wave + NW - 1) / NW + NST - 1) / NST;      // this wave's steps, in rounds of NST
 #pragma unroll
-        for (int u = 0; u < NST; u++) fetch(st[u], min(wave + 4 * u, last));
+        for (int u = 0; u < NST; u++) fetch(st[u], min(wave + NW * u, last));
         for (int r = 0; r < rounds; r++) {
 #pragma unroll
             for (int u = 0; u < NST; u++) {
-                const int su = wave + 4 * (r * NST + u);
+                const int su = wave + NW * (r * NST + u);
                 consume(st[u], su, su < nsteps);
-                fetch(st[u], min(su + 4 * NST, last));
+                fetch(st[u], min(su + NW * NST, last));
             }
         }
     }
-    if constexpr (SPLITK) {     // sum the 4 partial tiles: wave w parks its tile, wave 0 adds them in order 0,1,2,3
+    if constexpr (SPLITK) {     // sum the NW partial tiles: wave w parks its tile, wave 0 adds them in order 0,1,2,...
         __syncthreads();
-        float *red = reinterpret_cast<float *>(smem);      // [3][MT][16][64]
+        float *red = reinterpret_cast<float *>(smem);      // [NW - 1][MT][16][64]
         if (wave > 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
@@ -255,7 +262,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_q(const uint8_t *__restri
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
-        for (int w = 0; w < 3; w++)
+        for (int w = 0; w < NW - 1; w++)
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -301,17 +308,18 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
         return IFA_OK;
     }
     if (T <= 32) {       // one 32-token tile: half the activation staging of the 64-token variant
-        constexpr int MT1 = 1;
-        dim3 grid(ifa_cdiv(N, 32), 1);
-        const size_t smem = std::max(4 * (slab / 2), (size_t)3 * MT1 * 16 * 64 * 4);
-        k_gemm_q<DT, MT1, true><<<grid, dim3(GEMM_THREADS), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
+        constexpr int MT1 = 1, NW = (CAP <= 32 && DT != F16) ? 8 : 4;   // 8 waves share a tile's K range (64-value blocks: 4, the stages would spill): 128 tiles of a 4096-row matrix leave half the CUs idle,
+        dim3 grid(ifa_cdiv(N, 32), 1);      // the serial length of a wave (dequantisation VALU + load waits) is what counts
+        const size_t smem = std::max(NW * (slab / 2), (size_t)(NW - 1) * MT1 * 16 * 64 * 4);
+        k_gemm_q<DT, MT1, true, NW><<<grid, dim3(NW * 64), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
                                                                       (int)K, (const half_t *)bias, (half_t *)Y);
         return IFA_OK;
     }
     if (T <= 128) {      // weight-stream bound: 32-row tiles, K split over the 4 waves
         dim3 grid(ifa_cdiv(N, 32), ifa_cdiv(T, 32 * MT));
-        const size_t smem = std::max(4 * slab, (size_t)3 * MT * 16 * 64 * 4);
-        k_gemm_q<DT, MT, true><<<grid, dim3(GEMM_THREADS), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
+        constexpr int NW = 4;               // (8 waves x 64-token tiles need more than 256 registers per lane)
+        const size_t smem = std::max(NW * slab, (size_t)(NW - 1) * MT * 16 * 64 * 4);
+        k_gemm_q<DT, MT, true, NW><<<grid, dim3(NW * 64), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T,
                                                                      (int)K, (const half_t *)bias, (half_t *)Y);
     } else {
         dim3 grid(ifa_cdiv(N, GEMM_ROWS), ifa_cdiv(T, 32 * MT));
