@@ -15,6 +15,7 @@
 namespace ifa {
 
 typedef _Float16 half8r __attribute__((ext_vector_type(8)));
+typedef _Float16 half2r __attribute__((ext_vector_type(2)));
 
 constexpr int GR_THREADS = 512, GR_WAVES = 8;
 
@@ -86,13 +87,20 @@ __global__ void __launch_bounds__(GR_THREADS) k_gemm_rows_q4(const uint8_t *__re
 #pragma unroll
             for (int i = 0; i < RW; i++) {
                 const uint32_t cw = cur.c[i][q];
+                // byte b of the word: low nibble = element 8q+2b, high nibble = the next one.  Nibbles spread into bytes so
+                // each value is one v_cvt_f32_ubyteN; the two halves of a byte and the matching activation pair go through
+                // ONE v_dot2_f32_f16 (two half products + fp32 accumulate): half the multiply-adds of a v_fma_mix per value
+                const uint32_t lo = cw & 0x0F0F0F0Fu, hi = (cw >> 4) & 0x0F0F0F0Fu;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    // byte (e>>1) of the word: low nibble = element 8q+2(e>>1), high nibble = the next one
-                    const uint32_t nib = (cw >> (8 * (e >> 1) + 4 * (e & 1))) & 0xFu;
-                    const half_t wh = f2h(__builtin_fmaf((float)nib, scale[i], base[i]));   // the reference's dequantised half
+                for (int b = 0; b < 4; b++) {
+                    half2r w2;
+                    w2[0] = f2h(__builtin_fmaf((float)((lo >> (8 * b)) & 0xFFu), scale[i], base[i]));   // the reference's dequantised half
+                    w2[1] = f2h(__builtin_fmaf((float)((hi >> (8 * b)) & 0xFFu), scale[i], base[i]));
 #pragma unroll
-                    for (int t = 0; t < TB; t++) acc[i][t] = __builtin_fmaf((float)wh, (float)xv[t][e], acc[i][t]);
+                    for (int t = 0; t < TB; t++) {
+                        half2r x2; x2[0] = xv[t][2 * b]; x2[1] = xv[t][2 * b + 1];
+                        acc[i][t] = __builtin_amdgcn_fdot2(w2, x2, acc[i][t], false);
+                    }
                 }
             }
         }

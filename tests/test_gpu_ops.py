@@ -351,6 +351,34 @@ def test_gemm_library_path_matches_the_fused_kernel_and_the_oracle(d):
     assert (g.half_ulp_diff(y_own, y_lib) <= 2).mean() >= 0.995
 
 
+@pytest.mark.parametrize("T,rows,cols", [(2, 70, 256), (3, 128, 4096), (4, 200, 1024), (7, 96, 2048), (8, 64, 11008)])
+@pytest.mark.parametrize("d", [dt.Q4_B32T1A, dt.Q4_B32T1B], ids=IDS([dt.Q4_B32T1A, dt.Q4_B32T1B]))
+def test_gemm_rows_streaming_kernel_matches_per_token_oracle(d, T, rows, cols):
+    """The 2..8-row weight-streaming GEMM of the dynamic-batching step (csrc/ifa_gemm_rows.hip, tiled layout): same
+    contract as ifa_gemm -- weights dequantised to half, half activations, fp32 accumulation, one F16 rounding."""
+    import ctypes as C
+    L = g.capi()
+    L.ifa_gemm_rows_q4.restype = C.c_int
+    L.ifa_gemm_rows_q4.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(T + rows + cols + d)
+    w = rng.normal(0, 0.05, (rows, cols)).astype(np.float16)
+    x = rng.normal(0, 1.0, (T, cols)).astype(np.float16)
+    bias = rng.normal(0, 0.5, rows).astype(np.float16)
+    Wq = o.quantize(d, w)
+    Wt = g.repack(d, g.dev(Wq), rows, cols)
+    for b in (bias, None):
+        y = g.empty_f16(T, rows)
+        rc = L.ifa_gemm_rows_q4(g.p(Wt), rows, cols, g.p(g.dev(x)), T, g.p(g.dev(b)) if b is not None else None, g.p(y), g.stream())
+        assert rc == 0
+        y = g.host(y)
+        for t in range(T):
+            y_orc, y64 = o.gemv_f16x(d, Wq, rows, cols, x[t], bias=b, want_f64=True)
+            ulp = g.half_ulp_diff(y[t], y_orc)
+            small = np.abs(y[t].astype(np.float32) - y_orc.astype(np.float32)) <= 1e-3 * float(np.abs(y64).mean() + 1e-6)
+            assert ((ulp <= 2) | small).all(), (t, ulp.max())
+            assert np.allclose(y[t].astype(np.float64), y64, rtol=2e-3, atol=2e-3 * float(np.abs(y64).mean() + 1))
+
+
 def test_add_by_row_index_is_a_half_fma_scatter():
     # AddByRowIdx_Kernel (binary_tensor_opr.h:80-125): B[idx[r]] = hfma(A[r], w[r], B[idx[r]])
     rng = np.random.default_rng(9)
