@@ -913,13 +913,16 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     IFA_LAUNCH_CHECK();
     half_t *x = m->x;
     const Tensor none;
+    const bool seq_wiring = !c.parallel_attn && !c.share_input;
+    bool xn_ready = false;           // see forward_ops: every residual Add is fused with the norm that follows it
     for (int l = 0; l < c.layers; l++) {
         Layer &L = m->layers[(size_t)l];
         const half_t *attn_in = x;
         if (L.t[T_ATTN_NORM].present()) {
-            if ((rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn, c.attn_norm_base))) return rc;
+            if (!xn_ready && (rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn, c.attn_norm_base))) return rc;
             attn_in = m->xn;
         }
+        xn_ready = false;
         if ((rc = matmul(m, attn_in, T, L.t[T_WQ], L.t[T_WQ_B], m->q))) return rc;
         if ((rc = matmul(m, attn_in, T, L.t[T_WK], L.t[T_WK_B], m->k))) return rc;
         if ((rc = matmul(m, attn_in, T, L.t[T_WV], L.t[T_WV_B], m->v))) return rc;
@@ -935,13 +938,18 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
                                      c.use_alibi, c.tp_rank * c.heads, c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
         if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
         if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
-        if (!c.parallel_attn && !c.share_input)
-            if ((rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
         const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
         const half_t *ff_n = ff_in;
-        if (L.t[T_FFN_NORM].present()) {
-            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
+        if (seq_wiring && L.t[T_FFN_NORM].present()) {
+            if ((rc = ifa_add_layernorm(c.norm_kind, x, m->a, (size_t)T, D, L.t[T_FFN_NORM].data, L.t[T_FFN_NORM_B].present() ? L.t[T_FFN_NORM_B].data : nullptr,
+                                        c.ffn_norm_base, c.eps, m->a, m->hn, s))) return rc;
             ff_n = m->hn;
+        } else {
+            if (seq_wiring && (rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
+            if (L.t[T_FFN_NORM].present()) {
+                if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
+                ff_n = m->hn;
+            }
         }
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
             if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
@@ -949,16 +957,25 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
             if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
         }
         if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
-        if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
-        if (c.parallel_attn || c.share_input)
-            if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
+        const bool last_layer = l + 1 == c.layers;
+        const Tensor &nw = last_layer ? m->g[T_OUT_NORM] : m->layers[(size_t)l + 1].t[T_ATTN_NORM];
+        const Tensor &nb = last_layer ? m->g[T_OUT_NORM_B] : m->layers[(size_t)l + 1].t[T_ATTN_NORM_B];
+        if (seq_wiring && nw.present() && !(last_layer && scale_on(c.out_scale))) {
+            if ((rc = ifa_add_layernorm(c.norm_kind, m->f, m->a, (size_t)T, D, nw.data, nb.present() ? nb.data : nullptr,
+                                        last_layer ? c.out_norm_base : c.attn_norm_base, c.eps, m->f, m->xn, s))) return rc;
+            xn_ready = true;
+        } else {
+            if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
+            if (c.parallel_attn || c.share_input)
+                if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
+        }
         std::swap(m->x, m->f);
         x = m->x;
     }
     if (scale_on(c.out_scale) && (rc = ifa_scale(x, c.out_scale, (size_t)T * D, x, s))) return rc;
     const half_t *hfin = x;
     if (m->g[T_OUT_NORM].present()) {
-        if ((rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn, c.out_norm_base))) return rc;
+        if (!xn_ready && (rc = norm_rows(m, x, T, m->g[T_OUT_NORM], m->g[T_OUT_NORM_B], m->xn, c.out_norm_base))) return rc;
         hfin = m->xn;
     }
     const Tensor &lm = m->g[T_LM_HEAD];
