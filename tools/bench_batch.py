@@ -14,7 +14,7 @@ first = []
 for i in range(NMAX):
     wk.select_kv(i)
     first.append(wk.forward(rng.integers(3, s["vocab"], 16).astype(np.int32), 0))
-for n in (1, 2, 4, 8, 16, 32):
+for n in [int(v) for v in os.environ.get("IFA_BATCH_SIZES", "1,2,4,8,16,32").split(",")]:
     cur, pos = list(first[:n]), [16] * n
     steps = 24
     for w in range(2):
