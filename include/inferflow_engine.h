@@ -58,6 +58,9 @@ int ifa_engine_generate(ifa_engine *e, int query_id, int n_steps, int *out_token
 int ifa_engine_perplexity(ifa_engine *e, const int *tokens, int n_tokens, int max_length, int stride,
                           double *ppl, double *ppl_stderr, long long *count);
 
+/* host-only: -log softmax(logits)[token_id] of one F16 logits row with the tool's arithmetic (perplexity.cc:100-119); < 0 on bad arguments */
+double ifa_perplexity_token_nll(const uint16_t *logits_f16, int vocab, int token_id);
+
 /* facts of the loaded model: "vocab_size", "embd_dims", "hidden_dim", "decoder_layers", "decoder_heads",
  * "decoder_kv_heads", "max_context_len", "device_weight_data_type", "device_kv_cache_data_type"; -1 if unknown */
 int ifa_engine_model_info(ifa_engine *e, const char *key);

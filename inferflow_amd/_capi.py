@@ -128,6 +128,7 @@ ENGINE_SIGNATURES = {
     "ifa_engine_last_logits": (_i, [_vp, _i, _vp, _sz, _ip, _ip]),
     "ifa_engine_generate": (_i, [_vp, _i, _i, _ip, C.POINTER(_f)]),
     "ifa_engine_perplexity": (_i, [_vp, _ip, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "ifa_perplexity_token_nll": (C.c_double, [_vp, _i, _i]),
     "ifa_engine_model_info": (_i, [_vp, C.c_char_p]),
 }
 

@@ -67,6 +67,12 @@ int ifa_sampling_choose(const uint16_t *logits_f16, int vocab, int strategy_id, 
     return pool_n;
 }
 
+double ifa_perplexity_token_nll(const uint16_t *logits_f16, int vocab, int token_id)
+{
+    if (!logits_f16 || vocab <= 0 || token_id < 0 || token_id >= vocab) { EngineSetError("ifa_perplexity_token_nll: bad arguments"); return -1.0; }
+    return TokenNll(logits_f16, vocab, token_id);
+}
+
 int ifa_sampling_random_doubles(long long seed, int n, double *out)
 {
     if (!out || n < 0) return 0;

@@ -7,25 +7,10 @@
 #include <ctime>
 #include <map>
 
+#include "half_bits.h"
 #include "ifa_json.h"
 
 namespace inferflow_amd {
-
-static inline float HalfToFloat(uint16_t h)
-{
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
-    if (exp == 0) {
-        if (man == 0) bits = sign;
-        else {
-            int e = -1;
-            do { man <<= 1; e++; } while (!(man & 0x400u));
-            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
-        }
-    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
-    else bits = sign | ((exp + 112u) << 23) | (man << 13);
-    float f; memcpy(&f, &bits, 4); return f;
-}
 
 JavaRandom::JavaRandom() { SetSeed((uint64_t)time(nullptr)); }
 
@@ -78,7 +63,7 @@ void SortedTopK(const uint16_t *logits, int n, int k, std::vector<IdWeight> &poo
     std::vector<IdWeight> heap;
     heap.reserve((size_t)k + 1);
     for (int i = 0; i < n; i++) {
-        IdWeight it; it.id = i; it.weight = HalfToFloat(logits[i]);
+        IdWeight it; it.id = i; it.weight = HalfBitsToFloat(logits[i]);
         if (it.weight != it.weight) continue;                   // NaN never enters an ordered set
         if ((int)heap.size() < k) { heap.push_back(it); std::push_heap(heap.begin(), heap.end(), before); }
         else if (before(it, heap.front())) {

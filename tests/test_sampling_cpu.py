@@ -57,3 +57,23 @@ def test_pool_cuts_follow_top_p_and_max_k():
     assert np.abs(freq - np.array(probs)).max() < 0.03
     with pytest.raises(E.EngineError):
         E.sampling_choose(logits, 5)                                    # FSD: not restated
+
+
+def test_perplexity_token_nll_is_the_tools_float_log_softmax():
+    """perplexity.cc:100-119: float max, double sum of expf(logit - max), nll = -(logit[tok] - max - log(sum))."""
+    import ctypes as C
+    from inferflow_amd import _capi
+    rng = np.random.default_rng(4)
+    for vocab in (7, 1000, 32000):
+        lg = rng.normal(0, 3.0, vocab).astype(np.float16)
+        lg[vocab // 2] = np.float16(9.5)
+        for tok in (0, vocab // 2, vocab - 1):
+            got = _capi.lib().ifa_perplexity_token_nll(lg.ctypes.data_as(C.c_void_p), vocab, tok)
+            f = lg.astype(np.float32)
+            m = f.max()
+            want = -(float(f[tok] - m) - float(np.log(np.exp(f - m, dtype=np.float32).astype(np.float64).sum())))
+            assert abs(got - want) <= 1e-6 * max(1.0, abs(want))
+    assert _capi.lib().ifa_perplexity_token_nll(lg.ctypes.data_as(C.c_void_p), 10, 10) < 0
+    sub = np.array([0x0001, 0x03FF, 0x8001, 0x7BFF, 0x0000], np.uint16).view(np.float16)        # subnormals, max, zero
+    got = _capi.lib().ifa_perplexity_token_nll(sub.ctypes.data_as(C.c_void_p), 5, 3)
+    assert abs(got) < 1e-6                                                                        # 65504 dominates: p = 1
