@@ -47,6 +47,18 @@ __device__ __forceinline__ float h2f(half_t h) { return (float)h; }
 // once from the exact result; the reference rounds to fp32 first, then to fp16.
 __device__ __forceinline__ half_t f2h(float f) { asm volatile("" : "+v"(f)); return (half_t)f; }
 __device__ __forceinline__ float hbits2f(uint16_t b) { return (float)__builtin_bit_cast(half_t, b); }
+// byte B of a word as a float: ONE v_cvt_f32_ubyteN (the compiler extracts the byte first and converts with ubyte0:
+// two instructions per value, measured in the dequantising GEMM kernels where they are a fifth of the VALU stream)
+template <int B>
+__device__ __forceinline__ float ubyte_f32(uint32_t w)
+{
+    float f;
+    if constexpr (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w));
+    else if constexpr (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w));
+    else if constexpr (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w));
+    return f;
+}
 __device__ __forceinline__ uint16_t f2hbits(float f) { return __builtin_bit_cast(uint16_t, f2h(f)); }
 
 // ---- wave64 reductions -----------------------------------------------------

@@ -104,11 +104,12 @@ struct WRaw {
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const uint32_t lo = q4[1 + w] & 0x0F0F0F0Fu, hi = (q4[1 + w] >> 4) & 0x0F0F0F0Fu;
+                const float ql[4] = {ubyte_f32<0>(lo), ubyte_f32<1>(lo), ubyte_f32<2>(lo), ubyte_f32<3>(lo)};
+                const float qh[4] = {ubyte_f32<0>(hi), ubyte_f32<1>(hi), ubyte_f32<2>(hi), ubyte_f32<3>(hi)};
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                    const float q0 = (float)((lo >> (8 * b)) & 0xFFu), q1 = (float)((hi >> (8 * b)) & 0xFFu);
-                    v[8 * w + 2 * b] = f2h(__builtin_fmaf(q0, scale, base));           // q*scale exact: fma == mul + add
-                    v[8 * w + 2 * b + 1] = f2h(__builtin_fmaf(q1, scale, base));
+                    v[8 * w + 2 * b] = f2h(__builtin_fmaf(ql[b], scale, base));        // q*scale exact: fma == mul + add
+                    v[8 * w + 2 * b + 1] = f2h(__builtin_fmaf(qh[b], scale, base));
                 }
             }
         } else {

@@ -32,9 +32,15 @@ __global__ void __launch_bounds__(256) k_dequant_q4_f16(const uint32_t *__restri
     const int part = (int)(gid & 3);
     const uint32_t sb = W[b * 5], c = W[b * 5 + 1 + part];
     const float base = hbits2f((uint16_t)(sb & 0xFFFFu)), scale = hbits2f((uint16_t)(sb >> 16));
+    const uint32_t lo = c & 0x0F0F0F0Fu, hi = (c >> 4) & 0x0F0F0F0Fu;         // value 2b = low nibble of byte b, 2b+1 = its high nibble
+    const float ql[4] = {ubyte_f32<0>(lo), ubyte_f32<1>(lo), ubyte_f32<2>(lo), ubyte_f32<3>(lo)};
+    const float qh[4] = {ubyte_f32<0>(hi), ubyte_f32<1>(hi), ubyte_f32<2>(hi), ubyte_f32<3>(hi)};
     half_t v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = f2h(__builtin_fmaf((float)((c >> (4 * e)) & 0xFu), scale, base));   // q*scale exact: fma == mul + add
+    for (int b = 0; b < 4; b++) {
+        v[2 * b] = f2h(__builtin_fmaf(ql[b], scale, base));                     // q*scale exact: fma == mul + add
+        v[2 * b + 1] = f2h(__builtin_fmaf(qh[b], scale, base));
+    }
     *reinterpret_cast<u32x4 *>(out + gid * 8) = *reinterpret_cast<const u32x4 *>(v);
 }
 

@@ -91,11 +91,13 @@ __global__ void __launch_bounds__(GR_THREADS) k_gemm_rows_q4(const uint8_t *__re
                 // each value is one v_cvt_f32_ubyteN; the two halves of a byte and the matching activation pair go through
                 // ONE v_dot2_f32_f16 (two half products + fp32 accumulate): half the multiply-adds of a v_fma_mix per value
                 const uint32_t lo = cw & 0x0F0F0F0Fu, hi = (cw >> 4) & 0x0F0F0F0Fu;
+                const float ql[4] = {ubyte_f32<0>(lo), ubyte_f32<1>(lo), ubyte_f32<2>(lo), ubyte_f32<3>(lo)};
+                const float qh[4] = {ubyte_f32<0>(hi), ubyte_f32<1>(hi), ubyte_f32<2>(hi), ubyte_f32<3>(hi)};
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     half2r w2;
-                    w2[0] = f2h(__builtin_fmaf((float)((lo >> (8 * b)) & 0xFFu), scale[i], base[i]));   // the reference's dequantised half
-                    w2[1] = f2h(__builtin_fmaf((float)((hi >> (8 * b)) & 0xFFu), scale[i], base[i]));
+                    w2[0] = f2h(__builtin_fmaf(ql[b], scale[i], base[i]));   // the reference's dequantised half
+                    w2[1] = f2h(__builtin_fmaf(qh[b], scale[i], base[i]));
 #pragma unroll
                     for (int t = 0; t < TB; t++) {
                         half2r x2; x2[0] = xv[t][2 * b]; x2[1] = xv[t][2 * b + 1];
