@@ -109,6 +109,9 @@ int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x
 /* sets the token count from which ifa_gemm hands the product to hipBLASLt (0 = never, < 0 = only query);
  * returns the previous threshold, or 0 when hipBLASLt could not be loaded.  Environment: IFA_GEMM_LT_MIN_TOKENS. */
 int ifa_gemm_library_min_tokens(int min_tokens);
+/* frees the F16 scratch / workspace the library path keeps for this stream on the current device (call before destroying
+ * a stream that ran ifa_gemm with >= that many tokens; ifa_model_destroy / ifa_model_set_stream do it for the worker's) */
+int ifa_gemm_release_stream(ifa_stream stream);
 
 /* Re-tile reference-layout rows into the row-local plane layout the fused
  * decode kernels stream (DESIGN.md "HBM layout"): same bytes per row, row stride

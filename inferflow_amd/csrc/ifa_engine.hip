@@ -1065,6 +1065,7 @@ int ifa_model_destroy(ifa_model *m)
     if (m->rope_tab) (void)hipFree(m->rope_tab);
     if (m->tokens_dev) (void)hipFree(m->tokens_dev);
     if (m->host_pinned) (void)hipHostFree(m->host_pinned);
+    if (m->stream) (void)ifa_gemm_release_stream((ifa_stream)m->stream);
     if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return IFA_OK;
@@ -1349,6 +1350,7 @@ int ifa_model_set_stream(ifa_model *m, ifa_stream stream)
     IFA_REQUIRE(m, "ifa_model_set_stream: null model");
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     if (m->stream) IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (m->stream) (void)ifa_gemm_release_stream((ifa_stream)m->stream);
     if (m->stream && m->own_stream) IFA_HIP_CHECK(hipStreamDestroy(m->stream));
     m->stream = ifa_s(stream);
     m->own_stream = false;

@@ -60,6 +60,9 @@ struct LtApi {
     decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
     decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
     decltype(&hipblasLtMatmul) Matmul = nullptr;
+    decltype(&hipblasLtDestroy) Destroy = nullptr;                                  // optional: teardown only
+    decltype(&hipblasLtMatmulDescDestroy) DescDestroy = nullptr;
+    decltype(&hipblasLtMatrixLayoutDestroy) LayoutDestroy = nullptr;
 };
 
 static const LtApi &lt_api()
@@ -75,6 +78,7 @@ static const LtApi &lt_api()
         IFA_LT_SYM(DescCreate, hipblasLtMatmulDescCreate); IFA_LT_SYM(DescSet, hipblasLtMatmulDescSetAttribute);
         IFA_LT_SYM(PrefCreate, hipblasLtMatmulPreferenceCreate); IFA_LT_SYM(PrefSet, hipblasLtMatmulPreferenceSetAttribute);
         IFA_LT_SYM(Heuristic, hipblasLtMatmulAlgoGetHeuristic); IFA_LT_SYM(Matmul, hipblasLtMatmul);
+        IFA_LT_SYM(Destroy, hipblasLtDestroy); IFA_LT_SYM(DescDestroy, hipblasLtMatmulDescDestroy); IFA_LT_SYM(LayoutDestroy, hipblasLtMatrixLayoutDestroy);
 #undef IFA_LT_SYM
         a.ok = a.Create && a.LayoutCreate && a.DescCreate && a.DescSet && a.PrefCreate && a.PrefSet && a.Heuristic && a.Matmul;
         return a;
@@ -179,6 +183,27 @@ int gemm_lt(int w_dtype, const void *W, size_t N, size_t K, const void *X, size_
 }
 
 } // namespace ifa
+
+extern "C" int ifa_gemm_release_stream(ifa_stream stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return IFA_OK;
+    std::lock_guard<std::mutex> lock(ifa::g_lt_mutex);
+    auto it = ifa::g_lt_ctx.find({dev, ifa_s(stream)});
+    if (it == ifa::g_lt_ctx.end()) return IFA_OK;
+    (void)hipStreamSynchronize(ifa_s(stream));
+    const ifa::LtApi &api = ifa::lt_api();
+    for (auto &kv : it->second.plans) {
+        ifa::LtPlan &p = kv.second;
+        if (p.ok && api.DescDestroy) (void)api.DescDestroy(p.desc);
+        if (api.LayoutDestroy) { if (p.a) (void)api.LayoutDestroy(p.a); if (p.b) (void)api.LayoutDestroy(p.b); if (p.c) (void)api.LayoutDestroy(p.c); }
+    }
+    if (it->second.handle && api.Destroy) (void)api.Destroy(it->second.handle);
+    if (it->second.scratch) (void)hipFree(it->second.scratch);
+    if (it->second.workspace) (void)hipFree(it->second.workspace);
+    ifa::g_lt_ctx.erase(it);
+    return IFA_OK;
+}
 
 extern "C" int ifa_gemm_library_min_tokens(int min_tokens)
 {
