@@ -73,6 +73,28 @@ double ifa_perplexity_token_nll(const uint16_t *logits_f16, int vocab, int token
     return TokenNll(logits_f16, vocab, token_id);
 }
 
+int ifa_sampling_choose_ex(const uint16_t *logits_f16, int vocab, int strategy_id, const float *params9, float temperature,
+                           long long seed, int n_draws, int *out_ids, float *out_probs, int *pool_ids, float *pool_probs,
+                           int pool_capacity, float *mirostat_mu_inout)
+{
+    if (!logits_f16 || vocab <= 0 || n_draws < 0 || !params9) { EngineSetError("ifa_sampling_choose_ex: bad arguments"); return -1; }
+    SamplingConfig cfg;
+    cfg.max_k = (int)params9[0]; cfg.top_p = params9[1]; cfg.pool_size = (int)params9[2]; cfg.min_p = params9[3]; cfg.tfs_z = params9[4];
+    cfg.typical_p = params9[5]; cfg.mirostat_eta = params9[6]; cfg.mirostat_tau = params9[7]; cfg.eos_bypassing_max = (int)params9[8];
+    JavaRandom rng((uint64_t)seed);
+    float mu = mirostat_mu_inout ? *mirostat_mu_inout : __builtin_nanf("");
+    int pool_n = 0;
+    for (int d = 0; d < std::max(1, n_draws); d++) {
+        SamplingOutput out;
+        if (!ChooseTokens(out, logits_f16, vocab, (SamplingStrategyId)strategy_id, cfg, temperature, rng, -1, nullptr, &mu)) { EngineSetError("ifa_sampling_choose_ex: unsupported strategy %d", strategy_id); return -1; }
+        if (d < n_draws && !out.selected.empty()) { if (out_ids) out_ids[d] = out.selected[0].id; if (out_probs) out_probs[d] = out.selected[0].weight; }
+        pool_n = (int)out.token_pool.size();
+        for (int i = 0; i < pool_n && i < pool_capacity; i++) { if (pool_ids) pool_ids[i] = out.token_pool[(size_t)i].id; if (pool_probs) pool_probs[i] = out.token_pool[(size_t)i].weight; }
+    }
+    if (mirostat_mu_inout) *mirostat_mu_inout = mu;
+    return pool_n;
+}
+
 int ifa_sampling_random_doubles(long long seed, int n, double *out)
 {
     if (!out || n < 0) return 0;

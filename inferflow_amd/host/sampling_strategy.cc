@@ -50,6 +50,8 @@ bool ParseDecodingStrategy(const std::string &text, SamplingStrategyId &id, StdS
     if (id == SamplingStrategyId::Auto) { if (err) *err = "Invalid decoding_strategy"; return false; }
     doc.GetNumber("min_k", cfg.min_k); doc.GetNumber("max_k", cfg.max_k); doc.GetNumber("top_p", cfg.top_p);
     doc.GetNumber("pool_size", cfg.pool_size); doc.GetNumber("eos_bypassing_max", cfg.eos_bypassing_max);
+    doc.GetNumber("min_p", cfg.min_p); doc.GetNumber("z", cfg.tfs_z); doc.GetNumber("p", cfg.typical_p);      // (extension: the reference
+    doc.GetNumber("eta", cfg.mirostat_eta); doc.GetNumber("tau", cfg.mirostat_tau);                          //  fixes these at their defaults)
     return true;
 }
 
@@ -108,24 +110,91 @@ IdWeight DrawOne(JavaRandom &rng, const std::vector<IdWeight> &pool)
     return pool[mid];
 }
 
+// the pool cut of each strategy on the sorted, softmaxed pool (first entry = most probable)
+static void CutMinP(const std::vector<IdWeight> &pool, float min_p, std::vector<IdWeight> &out)
+{   // MinPSamplingStrategy::ChooseTokens, sampling_strategy.cc:716-724
+    const float scale = pool[0].weight;
+    out.assign(1, pool[0]);
+    for (size_t i = 1; i < pool.size(); i++) {
+        if (pool[i].weight < min_p * scale) break;
+        out.push_back(pool[i]);
+    }
+}
+
+static void CutTailFree(const std::vector<IdWeight> &pool, float z, std::vector<IdWeight> &out)
+{   // TFSSamplingStrategy::ChooseTokens, sampling_strategy.cc:807-838 (the cumulative sum starts at the SECOND |second difference|)
+    out.assign(1, pool[0]);
+    if (pool.size() < 3) return;            // the reference sizes its difference vectors pool - 1 / pool - 2: undefined below 3
+    std::vector<float> d1(pool.size() - 1), d2(pool.size() - 2);
+    for (size_t i = 0; i < d1.size(); i++) d1[i] = pool[i].weight - pool[i + 1].weight;
+    for (size_t i = 0; i < d2.size(); i++) d2[i] = std::abs(d1[i] - d1[i + 1]);
+    float sum = 0.0f;
+    for (float v : d2) sum += v;
+    if (sum > 1e-6f) { for (float &v : d2) v /= sum; }
+    else { for (float &v : d2) v = 1.0f / (float)d2.size(); }
+    float cum = 0.0f;
+    for (size_t i = 1; i < d2.size(); i++) {
+        cum += d2[i];
+        if (cum > z) break;
+        out.push_back(pool[i]);
+    }
+}
+
+static void CutTypical(const std::vector<IdWeight> &pool, float p, std::vector<IdWeight> &out)
+{   // TypicalSamplingStrategy::ChooseTokens, sampling_strategy.cc:921-951 (the first kept entry is not counted in the mass)
+    float entropy = 0.0f;
+    for (const IdWeight &it : pool) entropy += -it.weight * logf(it.weight);
+    std::vector<float> shifted(pool.size());
+    for (size_t i = 0; i < pool.size(); i++) shifted[i] = fabsf(-logf(pool[i].weight) - entropy);
+    std::vector<size_t> idx(pool.size());
+    for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return shifted[a] < shifted[b]; });
+    out.assign(1, pool[idx[0]]);
+    float cum = 0.0f;
+    for (size_t i = 1; i < idx.size(); i++) {
+        cum += pool[idx[i]].weight;
+        if (cum > p) break;
+        out.push_back(pool[idx[i]]);
+    }
+}
+
 bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, SamplingStrategyId strategy,
-                  const StdSamplingConfig &cfg, float temperature, JavaRandom &rng, int eos_id, int *eos_bypassing_count)
+                  const SamplingConfig &cfg, float temperature, JavaRandom &rng, int eos_id, int *eos_bypassing_count,
+                  float *mirostat_mu)
 {
     out = SamplingOutput();
-    if (!logits || vocab <= 0 || !IsStdFamily(strategy)) return false;
+    if (!logits || vocab <= 0 || !IsSupportedStrategy(strategy)) return false;
     int max_queue_len = 1;
     float top_p = 1.0f;
     if (strategy != SamplingStrategyId::Greedy) max_queue_len = std::min(cfg.pool_size, vocab);
     if (strategy == SamplingStrategyId::StdSampling || strategy == SamplingStrategyId::TopP) top_p = cfg.top_p;
     std::vector<IdWeight> pool;
     SortedTopK(logits, vocab, max_queue_len, pool);
+    if (pool.empty()) return true;
+    const std::vector<IdWeight> raw = pool;                     // logits of the pool (Mirostat re-normalises a prefix of them)
     SoftMaxPool(pool, temperature);
-    const int top_k = std::min((int)pool.size(), cfg.max_k);
-    float cumulative = 0;
-    for (const IdWeight &it : pool) {                            // topp_topk_filter_on_sorted, sampling_strategy.cc:29-43
-        cumulative += it.weight;
-        out.token_pool.push_back(it);
-        if (cumulative >= top_p || (int)out.token_pool.size() >= top_k) break;
+    if (IsStdFamily(strategy)) {
+        const int top_k = std::min((int)pool.size(), cfg.max_k);
+        float cumulative = 0;
+        for (const IdWeight &it : pool) {                        // topp_topk_filter_on_sorted, sampling_strategy.cc:29-43
+            cumulative += it.weight;
+            out.token_pool.push_back(it);
+            if (cumulative >= top_p || (int)out.token_pool.size() >= top_k) break;
+        }
+    } else if (strategy == SamplingStrategyId::MinP) CutMinP(pool, cfg.min_p, out.token_pool);
+    else if (strategy == SamplingStrategyId::TFS) CutTailFree(pool, cfg.tfs_z, out.token_pool);
+    else if (strategy == SamplingStrategyId::Typical) CutTypical(pool, cfg.typical_p, out.token_pool);
+    else {                                                       // Mirostat, sampling_strategy.cc:1036-1056
+        float mu = (mirostat_mu && *mirostat_mu == *mirostat_mu) ? *mirostat_mu : 2.0f * cfg.mirostat_tau;
+        size_t n = 0;
+        while (n < pool.size() && !(-log2f(pool[n].weight) > mu)) n++;
+        if (n == 0) n = 1;
+        // SoftMaxPool sorted `pool`; the same order applied to the raw logits (stable sort of equal keys, like above)
+        std::vector<IdWeight> prefix(raw);
+        std::stable_sort(prefix.begin(), prefix.end(), [](const IdWeight &a, const IdWeight &b) { return a.weight > b.weight; });
+        prefix.resize(n);
+        SoftMaxPool(prefix, temperature);
+        out.token_pool = prefix;
     }
     if (out.token_pool.empty()) return true;
     out.selected.push_back(DrawOne(rng, out.token_pool));
@@ -137,6 +206,12 @@ bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, Sampli
             for (const IdWeight &it : out.token_pool)
                 if (it.id != eos_id) { out.selected[0] = it; (*eos_bypassing_count)++; break; }
         }
+    }
+    if (strategy == SamplingStrategyId::Mirostat && mirostat_mu) {       // :1091-1096
+        float mu = (*mirostat_mu == *mirostat_mu) ? *mirostat_mu : 2.0f * cfg.mirostat_tau;
+        float w = out.selected[0].weight;
+        for (const IdWeight &it : out.token_pool) if (it.id == out.selected[0].id) { w = it.weight; break; }
+        *mirostat_mu = mu - cfg.mirostat_eta * (-log2f(w) - cfg.mirostat_tau);
     }
     return true;
 }

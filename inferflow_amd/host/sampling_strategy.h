@@ -4,7 +4,9 @@
 // SoftMax with temperature over that pool, top_p / max_k cut, one draw with the engine's generator.
 // The generator is sslib's Random (3rd_party/sslib/random.h:15-121) = the published java.util.Random
 // LCG, so a seeded query draws the same tokens as the reference given the same logits.
-// FSD / RandomizedFSD / MinP / TFS / Typical / Mirostat are not restated (AddQuery rejects them).
+// Also MinP (:696-760), TFS (:787-876), Typical (:901-990) and Mirostat (:1015-1098), which cut the same
+// softmaxed pool by their own rule before the draw.  FSD / RandomizedFSD (n-gram penalties over the
+// generated text) are not restated: AddQuery rejects them.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -25,6 +27,11 @@ inline bool IsStdFamily(SamplingStrategyId id)
     return id == SamplingStrategyId::StdSampling || id == SamplingStrategyId::Greedy || id == SamplingStrategyId::TopK
         || id == SamplingStrategyId::TopP;
 }
+inline bool IsSupportedStrategy(SamplingStrategyId id)
+{
+    return IsStdFamily(id) || id == SamplingStrategyId::MinP || id == SamplingStrategyId::TFS || id == SamplingStrategyId::Typical
+        || id == SamplingStrategyId::Mirostat;
+}
 
 class JavaRandom {                  // sslib::Random: seed' = (seed * 0x5DEECE66D + 0xB) mod 2^48
 public:
@@ -44,12 +51,17 @@ private:
     uint64_t seed_ = 0;
 };
 
-struct StdSamplingConfig {          // StdSamplingStrategy::Config, sampling_strategy.h:242-249
-    int min_k = 1, max_k = 8;
+struct SamplingConfig {             // the Config structs of sampling_strategy.h (:242-249, :379-384, :419-424, :459-464, :499-505)
+    int min_k = 1, max_k = 8;       // Std family
     float top_p = 0.9f;
-    int pool_size = 50;
+    int pool_size = 50;             // every strategy: size of the softmaxed candidate pool
     int eos_bypassing_max = 0;
+    float min_p = 0.05f;            // MinP: keep p >= min_p * p_max
+    float tfs_z = 0.95f;            // TFS: mass of the normalised |second differences| to keep
+    float typical_p = 0.95f;        // Typical: mass, in order of |-log p - entropy|
+    float mirostat_eta = 0.1f, mirostat_tau = 5.0f;   // Mirostat v2: mu starts at 2 tau, mu -= eta (surprise - tau)
 };
+typedef SamplingConfig StdSamplingConfig;
 
 struct SamplingOutput {
     std::vector<IdWeight> token_pool;   // probabilities after the top_p / max_k cut, descending
@@ -69,8 +81,9 @@ IdWeight DrawOne(JavaRandom &rng, const std::vector<IdWeight> &pool);
 
 // StdSamplingStrategy::ChooseTokens (sampling_strategy.cc:359-431).  eos_id < 0: the model has no EOS notion here
 // (token-id queries), the EOS flags / bypassing are skipped.  *eos_bypassing_count is the query's running count.
+// *mirostat_mu: the query's running mu (Mirostat only; NaN or null = start at 2 tau).
 bool ChooseTokens(SamplingOutput &out, const uint16_t *logits_f16, int vocab, SamplingStrategyId strategy,
-                  const StdSamplingConfig &cfg, float temperature, JavaRandom &rng, int eos_id = -1,
-                  int *eos_bypassing_count = nullptr);
+                  const SamplingConfig &cfg, float temperature, JavaRandom &rng, int eos_id = -1,
+                  int *eos_bypassing_count = nullptr, float *mirostat_mu = nullptr);
 
 } // namespace inferflow_amd

@@ -79,3 +79,77 @@ def choose_tokens(logits_f16, strategy, rng, max_k=8, top_p=0.9, pool_size=50, t
         if cum >= np.float32(p) or len(cut) >= top_k:
             break
     return draw_one(rng, cut), cut
+
+
+# ---- MinP / TFS / Typical / Mirostat (sampling_strategy.cc:696-760, :787-876, :901-990, :1015-1098)
+MIN_P, TFS, TYPICAL, MIROSTAT = 7, 8, 9, 10
+F = np.float32
+
+
+def cut_min_p(pool, min_p=0.05):
+    out = [pool[0]]
+    for it in pool[1:]:
+        if F(it[1]) < F(F(min_p) * F(pool[0][1])):
+            break
+        out.append(it)
+    return out
+
+
+def cut_tfs(pool, z=0.95):
+    out = [pool[0]]
+    if len(pool) < 3:
+        return out
+    w = [F(p) for _, p in pool]
+    d1 = [F(w[i] - w[i + 1]) for i in range(len(w) - 1)]
+    d2 = [F(abs(F(d1[i] - d1[i + 1]))) for i in range(len(d1) - 1)]
+    s = F(0)
+    for v in d2:
+        s = F(s + v)
+    d2 = [F(v / s) for v in d2] if s > F(1e-6) else [F(F(1.0) / F(len(d2))) for _ in d2]
+    cum = F(0)
+    for i in range(1, len(d2)):
+        cum = F(cum + d2[i])
+        if cum > F(z):
+            break
+        out.append(pool[i])
+    return out
+
+
+def cut_typical(pool, p=0.95):
+    w = [F(x) for _, x in pool]
+    ent = F(0)
+    for x in w:
+        ent = F(ent + F(-x * F(np.log(x, dtype=np.float32))))
+    shifted = [F(abs(F(F(-np.log(x, dtype=np.float32)) - ent))) for x in w]
+    idx = sorted(range(len(pool)), key=lambda i: (float(shifted[i]), i))
+    out = [pool[idx[0]]]
+    cum = F(0)
+    for i in idx[1:]:
+        cum = F(cum + w[i])
+        if cum > F(p):
+            break
+        out.append(pool[i])
+    return out
+
+
+def choose_tokens_ex(logits_f16, strategy, rng, temperature=1.0, pool_size=50, min_p=0.05, z=0.95, typical_p=0.95, eta=0.1, tau=5.0, mu=None):
+    """Returns ((token, prob), cut pool, mu after the draw)."""
+    n = np.asarray(logits_f16).size
+    raw = sorted_top_k(logits_f16, min(pool_size, n))
+    pool = softmax_pool(raw, temperature)
+    if strategy == MIN_P:
+        cut = cut_min_p(pool, min_p)
+    elif strategy == TFS:
+        cut = cut_tfs(pool, z)
+    elif strategy == TYPICAL:
+        cut = cut_typical(pool, typical_p)
+    else:
+        mu = F(2.0 * tau) if mu is None else F(mu)
+        k = 0
+        while k < len(pool) and not (F(-np.log2(F(pool[k][1]), dtype=np.float32)) > mu):
+            k += 1
+        cut = softmax_pool(raw[:max(k, 1)], temperature)
+    sel = draw_one(rng, cut)
+    if strategy == MIROSTAT:
+        mu = F(mu - F(eta) * F(F(-np.log2(F(sel[1]), dtype=np.float32)) - F(tau)))
+    return sel, cut, mu

@@ -77,3 +77,47 @@ def test_perplexity_token_nll_is_the_tools_float_log_softmax():
     sub = np.array([0x0001, 0x03FF, 0x8001, 0x7BFF, 0x0000], np.uint16).view(np.float16)        # subnormals, max, zero
     got = _capi.lib().ifa_perplexity_token_nll(sub.ctypes.data_as(C.c_void_p), 5, 3)
     assert abs(got) < 1e-6                                                                        # 65504 dominates: p = 1
+
+
+@pytest.mark.parametrize("strategy", [S.MIN_P, S.TFS, S.TYPICAL, S.MIROSTAT])
+@pytest.mark.parametrize("temperature", [1.0, 0.6])
+def test_pool_cutting_strategies_match_the_restated_reference(strategy, temperature):
+    """min_p / tfs / typical / mirostat: the same pool and the same draws as oracle/sampling.py, Mirostat's mu carried
+    from draw to draw like the query's state."""
+    rng = np.random.default_rng(7 * strategy + int(10 * temperature))
+    for case, vocab in enumerate([1000, 60, 3, 32000, 2]):
+        logits = rng.normal(0, 2.5, vocab).astype(np.float16)
+        if case == 1:
+            logits[5:9] = np.float16(4.0)
+        seed = 99 + case
+        r = S.JavaRandom(seed)
+        mu_o, mu_e = None, None
+        for d in range(12):
+            (tok, p), cut, mu_o = S.choose_tokens_ex(logits, strategy, r, temperature=temperature, mu=mu_o)
+            # the engine side is stateless per call: replay the generator to draw d by asking for d + 1 draws
+            ids, probs, pool_ids, pool_probs, mu_e = E.sampling_choose_ex(logits, strategy, temperature=temperature, seed=seed, n_draws=d + 1)
+            assert ids[d] == tok, (case, d)
+            assert abs(probs[d] - float(p)) <= 3e-6 * max(1.0, float(p))
+            if strategy != S.MIROSTAT:            # (Mirostat's pool depends on mu: compared through the drawn tokens and mu)
+                assert pool_ids == [i for i, _ in cut]
+                assert np.allclose(pool_probs, [float(w) for _, w in cut], rtol=2e-5, atol=1e-7)
+        if strategy == S.MIROSTAT:
+            assert abs(mu_e - float(mu_o)) <= 1e-4 * max(1.0, abs(float(mu_o)))
+
+
+def test_pool_cutting_rules_on_a_known_distribution():
+    logits = np.log(np.array([0.5, 0.2, 0.1, 0.08, 0.05, 0.04, 0.02, 0.01], np.float64)).astype(np.float16)
+    _, _, pool, probs, _ = E.sampling_choose_ex(logits, S.MIN_P, min_p=0.15)
+    assert pool == [0, 1, 2, 3]                                   # p >= 0.15 * 0.5 = 0.075
+    _, _, pool, _, _ = E.sampling_choose_ex(logits, S.MIN_P, min_p=0.5)
+    assert pool == [0]
+    _, _, pool, _, _ = E.sampling_choose_ex(logits, S.TYPICAL, typical_p=0.3)
+    assert len(pool) >= 1 and pool[0] in range(8)
+    # Mirostat: mu = 2 tau = 2 keeps tokens with surprise <= 2 bits (p >= 0.25): only token 0, so every draw is token 0 ...
+    ids, _, pool, _, mu = E.sampling_choose_ex(logits, S.MIROSTAT, tau=1.0, eta=0.5, seed=3, n_draws=3)
+    assert ids[0] == 0
+    # ... and the observed surprise (0 bits after renormalising a 1-token pool) raises mu by eta * tau each time, admitting more tokens
+    ids, _, pool, _, mu = E.sampling_choose_ex(logits, S.MIROSTAT, tau=1.0, eta=0.5, seed=3, n_draws=1)
+    assert abs(mu - 2.5) < 1e-5
+    with pytest.raises(E.EngineError):
+        E.sampling_choose_ex(logits, 5)                           # FSD needs the n-gram state of the text: not restated
