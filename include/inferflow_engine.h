@@ -24,7 +24,7 @@ const char *ifa_engine_last_error(void);
 /* AddQuery(tokens, QueryOptions{strategy greedy}) */
 int ifa_engine_add_query(ifa_engine *e, const int *tokens, int n_tokens);
 /* AddQuery with SamplingStrategy::QueryOptions: strategy_id = SamplingStrategyId (0 Auto = the model's decoding_strategy or
- * greedy, 1 sample.std, 2 greedy, 3 top_k, 4 top_p, 7 min_p, 8 tfs, 9 typical, 10 mirostat; 5 / 6 (FSD): < 0 with a message), random_seed != 0 seeds the
+ * greedy, 1 sample.std, 2 greedy, 3 top_k, 4 top_p, 5 fsd, 6 random_fsd, 7 min_p, 8 tfs, 9 typical, 10 mirostat), random_seed != 0 seeds the
  * query's generator (sslib Random = the java.util.Random LCG), temperature as in SamplingStrategy::SoftMax */
 int ifa_engine_add_query_ex(ifa_engine *e, const int *tokens, int n_tokens, int strategy_id, int random_seed, float temperature);
 /* GetSamplingStrategyId(name): "sample.top_p", "greedy", ...; NULL/"" = the loaded model's default; 0 if unknown */
@@ -35,11 +35,12 @@ int ifa_engine_strategy_id(ifa_engine *e, const char *name);
 int ifa_sampling_choose(const uint16_t *logits_f16, int vocab, int strategy_id, int max_k, float top_p, int pool_size,
                         float temperature, long long seed, int n_draws, int *out_ids, float *out_probs,
                         int *pool_ids, float *pool_probs, int pool_capacity);
-/* the same for every restated strategy (adds 7 min_p, 8 tfs, 9 typical, 10 mirostat): params9 = {max_k, top_p, pool_size, min_p, tfs z,
+/* the same for every strategy (adds 5 fsd, 6 random_fsd -- text_tokens = the query's tokens so far, consecutive draws extend the
+ * n-gram model with the drawn tokens -- 7 min_p, 8 tfs, 9 typical, 10 mirostat): params9 = {max_k, top_p, pool_size, min_p, tfs z,
  * typical p, mirostat eta, mirostat tau, eos_bypassing_max}; *mirostat_mu_inout (nullable; NaN = unset -> 2 tau) carries mu across calls */
 int ifa_sampling_choose_ex(const uint16_t *logits_f16, int vocab, int strategy_id, const float *params9, float temperature,
                            long long seed, int n_draws, int *out_ids, float *out_probs, int *pool_ids, float *pool_probs,
-                           int pool_capacity, float *mirostat_mu_inout);
+                           int pool_capacity, float *mirostat_mu_inout, const int *text_tokens, int n_text);
 /* the first n NextDouble() values of the generator seeded with `seed` (known-answer tests of the LCG) */
 int ifa_sampling_random_doubles(long long seed, int n, double *out);
 int ifa_engine_query_count(ifa_engine *e);

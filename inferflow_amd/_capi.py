@@ -121,7 +121,7 @@ ENGINE_SIGNATURES = {
     "ifa_engine_add_query_ex": (_i, [_vp, _ip, _i, _i, _i, _f]),
     "ifa_engine_strategy_id": (_i, [_vp, C.c_char_p]),
     "ifa_sampling_choose": (_i, [_vp, _i, _i, _i, _f, _i, _f, C.c_longlong, _i, _ip, C.POINTER(_f), _ip, C.POINTER(_f), _i]),
-    "ifa_sampling_choose_ex": (_i, [_vp, _i, _i, C.POINTER(_f), _f, C.c_longlong, _i, _ip, C.POINTER(_f), _ip, C.POINTER(_f), _i, C.POINTER(_f)]),
+    "ifa_sampling_choose_ex": (_i, [_vp, _i, _i, C.POINTER(_f), _f, C.c_longlong, _i, _ip, C.POINTER(_f), _ip, C.POINTER(_f), _i, C.POINTER(_f), _ip, _i]),
     "ifa_sampling_random_doubles": (_i, [C.c_longlong, _i, C.POINTER(C.c_double)]),
     "ifa_engine_query_count": (_i, [_vp]),
     "ifa_engine_remove_query": (_i, [_vp, _i]),

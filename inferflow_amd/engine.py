@@ -122,15 +122,16 @@ def sampling_choose(logits_f16, strategy_id, max_k=8, top_p=0.9, pool_size=50, t
 
 
 def sampling_choose_ex(logits_f16, strategy_id, temperature=1.0, seed=1, n_draws=1, mu=None, max_k=8, top_p=0.9, pool_size=50, min_p=0.05,
-                       z=0.95, typical_p=0.95, eta=0.1, tau=5.0):
+                       z=0.95, typical_p=0.95, eta=0.1, tau=5.0, text=()):
     """Any restated strategy (incl. min_p 7, tfs 8, typical 9, mirostat 10): (ids, probs, pool ids, pool probs, mu after the draws)."""
     lg = np.ascontiguousarray(logits_f16, np.float16)
     params = (C.c_float * 9)(max_k, top_p, pool_size, min_p, z, typical_p, eta, tau, 0)
     ids = (C.c_int * max(1, n_draws))(); pr = (C.c_float * max(1, n_draws))()
     pid = (C.c_int * 256)(); ppr = (C.c_float * 256)()
     m = C.c_float(float("nan") if mu is None else mu)
+    txt = (C.c_int * max(1, len(text)))(*[int(t) for t in text])
     n = _capi.lib().ifa_sampling_choose_ex(lg.ctypes.data_as(C.c_void_p), lg.size, int(strategy_id), params, temperature, int(seed), n_draws,
-                                           ids, pr, pid, ppr, 256, C.byref(m))
+                                           ids, pr, pid, ppr, 256, C.byref(m), txt, len(text))
     if n < 0:
         raise EngineError(_capi.lib().ifa_engine_last_error().decode(errors="replace"))
     return [ids[i] for i in range(n_draws)], [pr[i] for i in range(n_draws)], [pid[i] for i in range(min(n, 256))], [ppr[i] for i in range(min(n, 256))], m.value

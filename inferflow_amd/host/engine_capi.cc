@@ -58,8 +58,8 @@ int ifa_sampling_choose(const uint16_t *logits_f16, int vocab, int strategy_id, 
     JavaRandom rng((uint64_t)seed);
     int pool_n = 0;
     for (int d = 0; d < std::max(1, n_draws); d++) {
-        SamplingOutput out;
-        if (!ChooseTokens(out, logits_f16, vocab, (SamplingStrategyId)strategy_id, cfg, temperature, rng)) { EngineSetError("ifa_sampling_choose: unsupported strategy %d", strategy_id); return -1; }
+        SamplingOutput out; SamplingState st;
+        if (!IsStdFamily((SamplingStrategyId)strategy_id) || !ChooseTokens(out, logits_f16, vocab, (SamplingStrategyId)strategy_id, cfg, temperature, rng, st)) { EngineSetError("ifa_sampling_choose: unsupported strategy %d", strategy_id); return -1; }
         if (d < n_draws && !out.selected.empty()) { if (out_ids) out_ids[d] = out.selected[0].id; if (out_probs) out_probs[d] = out.selected[0].weight; }
         pool_n = (int)out.token_pool.size();
         for (int i = 0; i < pool_n && i < pool_capacity; i++) { if (pool_ids) pool_ids[i] = out.token_pool[(size_t)i].id; if (pool_probs) pool_probs[i] = out.token_pool[(size_t)i].weight; }
@@ -75,23 +75,26 @@ double ifa_perplexity_token_nll(const uint16_t *logits_f16, int vocab, int token
 
 int ifa_sampling_choose_ex(const uint16_t *logits_f16, int vocab, int strategy_id, const float *params9, float temperature,
                            long long seed, int n_draws, int *out_ids, float *out_probs, int *pool_ids, float *pool_probs,
-                           int pool_capacity, float *mirostat_mu_inout)
+                           int pool_capacity, float *mirostat_mu_inout, const int *text_tokens, int n_text)
 {
     if (!logits_f16 || vocab <= 0 || n_draws < 0 || !params9) { EngineSetError("ifa_sampling_choose_ex: bad arguments"); return -1; }
     SamplingConfig cfg;
     cfg.max_k = (int)params9[0]; cfg.top_p = params9[1]; cfg.pool_size = (int)params9[2]; cfg.min_p = params9[3]; cfg.tfs_z = params9[4];
     cfg.typical_p = params9[5]; cfg.mirostat_eta = params9[6]; cfg.mirostat_tau = params9[7]; cfg.eos_bypassing_max = (int)params9[8];
+    cfg.rfsd_top_p = cfg.top_p;            // (RandomizedFSD's sampling branch has its own top_p: 0.93 by default, here the caller's)
     JavaRandom rng((uint64_t)seed);
-    float mu = mirostat_mu_inout ? *mirostat_mu_inout : __builtin_nanf("");
+    SamplingState st;
+    if (mirostat_mu_inout) st.mirostat_mu = *mirostat_mu_inout;
+    const std::vector<int> text(text_tokens, text_tokens + (text_tokens ? std::max(0, n_text) : 0));
     int pool_n = 0;
     for (int d = 0; d < std::max(1, n_draws); d++) {
         SamplingOutput out;
-        if (!ChooseTokens(out, logits_f16, vocab, (SamplingStrategyId)strategy_id, cfg, temperature, rng, -1, nullptr, &mu)) { EngineSetError("ifa_sampling_choose_ex: unsupported strategy %d", strategy_id); return -1; }
+        if (!ChooseTokens(out, logits_f16, vocab, (SamplingStrategyId)strategy_id, cfg, temperature, rng, st, text)) { EngineSetError("ifa_sampling_choose_ex: unsupported strategy %d", strategy_id); return -1; }
         if (d < n_draws && !out.selected.empty()) { if (out_ids) out_ids[d] = out.selected[0].id; if (out_probs) out_probs[d] = out.selected[0].weight; }
         pool_n = (int)out.token_pool.size();
         for (int i = 0; i < pool_n && i < pool_capacity; i++) { if (pool_ids) pool_ids[i] = out.token_pool[(size_t)i].id; if (pool_probs) pool_probs[i] = out.token_pool[(size_t)i].weight; }
     }
-    if (mirostat_mu_inout) *mirostat_mu_inout = mu;
+    if (mirostat_mu_inout) *mirostat_mu_inout = st.mirostat_mu;
     return pool_n;
 }
 

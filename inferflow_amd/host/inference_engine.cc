@@ -137,7 +137,7 @@ bool InferenceEngine::Init(const InferenceConfig &cfg)
         SamplingStrategyId sid; std::string err;
         if (!ParseDecodingStrategy(spec_.decoding_strategy, sid, default_sampling_, &err)) { EngineSetError("%s for model %s", err.c_str(), spec_.sid.c_str()); return false; }
         if (sid != SamplingStrategyId::Auto) default_strategy_ = sid;
-        if (!IsSupportedStrategy(default_strategy_)) { EngineSetError("decoding_strategy \"%s\" of model %s is not supported (greedy, sample.std, top_k, top_p, min_p, tfs, typical, mirostat)", spec_.decoding_strategy.c_str(), spec_.sid.c_str()); return false; }
+        if (!IsSupportedStrategy(default_strategy_)) { EngineSetError("decoding_strategy \"%s\" of model %s is not supported", spec_.decoding_strategy.c_str(), spec_.sid.c_str()); return false; }
     }
     if (!BuildWorker(&model_, spec_, device_)) return false;
     // one KV cache per concurrent query, like the reference's per-query LayerKVCache sets
@@ -157,7 +157,7 @@ int InferenceEngine::AddQuery(const std::vector<int> &tokens, const QueryOptions
     SamplingStrategyId strategy = (SamplingStrategyId)query_options.strategy_id;
     if (query_options.strategy_id < 0 || query_options.strategy_id > (int)SamplingStrategyId::Mirostat) { EngineSetError("Invalid strategy id %d", query_options.strategy_id); return -1; }
     if (strategy == SamplingStrategyId::Auto) strategy = default_strategy_;
-    if (!IsSupportedStrategy(strategy)) { EngineSetError("Decoding strategy %d is not supported (greedy, sample.std, top_k, top_p, min_p, tfs, typical, mirostat)", query_options.strategy_id); return -1; }
+    if (!IsSupportedStrategy(strategy)) { EngineSetError("Decoding strategy %d is not supported", query_options.strategy_id); return -1; }
     if ((int)queries_.size() >= std::min(config_.max_concurrent_queries, kv_slots_)) return 0;      // busy
     Query q; q.id = next_query_id_++; q.tokens = tokens; q.options = query_options;
     q.strategy = strategy; q.sampling = default_sampling_;
@@ -181,8 +181,8 @@ SamplingStrategyId InferenceEngine::GetSamplingStrategyId(const std::string &str
 bool InferenceEngine::SampleRow(Query &q, const uint16_t *logits_row, QueryInferenceResult &item)
 {
     SamplingOutput out;
-    if (!ChooseTokens(out, logits_row, spec_.hyper_params.vocab_size, q.strategy, q.sampling, q.options.temperature, q.rng, -1,
-                      &q.eos_bypassing_count, &q.mirostat_mu) || out.selected.empty()) {
+    if (!ChooseTokens(out, logits_row, spec_.hyper_params.vocab_size, q.strategy, q.sampling, q.options.temperature, q.rng,
+                      q.sampling_state, q.tokens) || out.selected.empty()) {
         EngineSetError("Sampling failed for query %d", q.id); return false;
     }
     item.next_tokens.clear();

@@ -81,7 +81,7 @@ struct InferenceConfig {
 
 struct QueryOptions {               // SamplingStrategy::QueryOptions (sampling_strategy.h:75-81)
     int strategy_id = 0;            // SamplingStrategyId: 0 Auto (the model's decoding_strategy, greedy if none), 1 sample.std,
-                                    // 2 greedy (device argmax, the hot path), 3 top_k, 4 top_p, 7 min_p, 8 tfs, 9 typical, 10 mirostat; 5/6 (FSD) are rejected
+                                    // 2 greedy (device argmax, the hot path), 3 top_k, 4 top_p, 5 fsd, 6 random_fsd, 7 min_p, 8 tfs, 9 typical, 10 mirostat
     int random_seed = 0;            // != 0: seeds the query's generator (reproducible draws)
     float temperature = 1.0f;
     int max_output_len = -1;
@@ -146,8 +146,7 @@ private:
         SamplingStrategyId strategy = SamplingStrategyId::Greedy;
         StdSamplingConfig sampling; // per query copy, like StdQueryData::config
         JavaRandom rng;
-        int eos_bypassing_count = 0;
-        float mirostat_mu = __builtin_nanf("");   // Mirostat: unset -> 2 tau at the first draw (MirostatSamplingStrategy::NewQueryData)
+        SamplingState sampling_state;   // Mirostat's mu, the FSD n-gram model, the EOS bypass count
     };
     bool SampleRow(Query &q, const uint16_t *logits_row, QueryInferenceResult &item);
     InferenceConfig config_;

@@ -158,9 +158,77 @@ static void CutTypical(const std::vector<IdWeight> &pool, float p, std::vector<I
     }
 }
 
+void NGramModel::Initialize(const std::vector<int> &tokens)
+{
+    tokens_ = tokens;
+    following_.assign((size_t)std::max(n_, 1), {});
+    const int len = (int)tokens.size();
+    for (int order = 1; order <= n_; order++)
+        for (int i = 0; i + order <= len; i++)
+            following_[(size_t)order - 1][std::vector<int>(tokens.begin() + i, tokens.begin() + i + order - 1)].push_back(tokens[(size_t)(i + order - 1)]);
+}
+
+void NGramModel::Update(int new_token)
+{
+    if (following_.empty()) following_.assign((size_t)std::max(n_, 1), {});   // (the reference indexes the unsized vector here)
+    for (int i = 0; i < n_; i++) {
+        if ((int)tokens_.size() < i) continue;
+        following_[(size_t)i][std::vector<int>(tokens_.end() - i, tokens_.end())].push_back(new_token);
+    }
+    tokens_.push_back(new_token);
+}
+
+std::map<int, float> NGramModel::Penalize(const std::vector<int> &candidates)
+{
+    std::map<int, float> penalty;
+    if ((int)tokens_.size() < n_ - 1 || following_.empty()) return penalty;
+    for (int cand : candidates) {
+        float remaining = 1, score = 0;
+        for (int i = n_ - 1; i >= 0; i--) {
+            const std::vector<int> key(tokens_.end() - i, tokens_.end());
+            const std::vector<int> &next = following_[(size_t)i][key];
+            int count = 0;
+            for (int v : next) count += v == cand;
+            if (count == 0) continue;                      // (remaining is NOT reduced for a context that never saw the candidate)
+            const int total = (int)next.size();
+            if (i == 0) score += remaining * ((float)count / (float)total);
+            else score += remaining * beta_ * ((float)count / (float)(total + 1));
+            remaining = remaining - remaining * beta_;
+        }
+        penalty[cand] = score;                             // no stop-word list here (sw_coeff applies to none)
+    }
+    return penalty;
+}
+
+// get_sorted_topk (sampling_strategy.cc:17-27): the k best by (weight, lower id first)
+static std::vector<IdWeight> SortedTopKOfPool(const std::vector<IdWeight> &pool, int k)
+{
+    std::vector<IdWeight> v(pool);
+    std::stable_sort(v.begin(), v.end(), [](const IdWeight &a, const IdWeight &b) { return a.weight > b.weight || (a.weight == b.weight && a.id < b.id); });
+    if ((int)v.size() > k) v.resize((size_t)std::max(k, 0));
+    return v;
+}
+
+static void FsdPick(SamplingOutput &out, std::vector<IdWeight> pool, const SamplingConfig &cfg, float temperature, SamplingState &state,
+                    const std::vector<int> &text)
+{   // FsdSamplingStrategy::ChooseTokens, sampling_strategy.cc:476-503
+    SoftMaxPool(pool, temperature);
+    pool = SortedTopKOfPool(pool, cfg.fsd_k);
+    std::vector<int> ids;
+    for (const IdWeight &it : pool) ids.push_back(it.id);
+    if (!state.fsd_started) { state.ngram = NGramModel(cfg.fsd_n, cfg.fsd_beta); state.ngram.Initialize(text); state.fsd_started = true; }
+    const std::map<int, float> penalty = state.ngram.Penalize(ids);
+    for (IdWeight &it : pool) {
+        auto pn = penalty.find(it.id);
+        if (pn != penalty.end()) it.weight = (1 - cfg.fsd_alpha) * it.weight - cfg.fsd_alpha * pn->second;
+    }
+    out.token_pool = SortedTopKOfPool(pool, (int)pool.size());
+    out.selected.push_back(out.token_pool[0]);
+}
+
 bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, SamplingStrategyId strategy,
-                  const SamplingConfig &cfg, float temperature, JavaRandom &rng, int eos_id, int *eos_bypassing_count,
-                  float *mirostat_mu)
+                  const SamplingConfig &cfg, float temperature, JavaRandom &rng, SamplingState &state,
+                  const std::vector<int> &text, int eos_id)
 {
     out = SamplingOutput();
     if (!logits || vocab <= 0 || !IsSupportedStrategy(strategy)) return false;
@@ -172,8 +240,15 @@ bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, Sampli
     SortedTopK(logits, vocab, max_queue_len, pool);
     if (pool.empty()) return true;
     const std::vector<IdWeight> raw = pool;                     // logits of the pool (Mirostat re-normalises a prefix of them)
-    SoftMaxPool(pool, temperature);
-    if (IsStdFamily(strategy)) {
+    bool drawn = false;
+    if (strategy == SamplingStrategyId::FSD) { FsdPick(out, pool, cfg, temperature, state, text); drawn = true; }
+    else if (strategy == SamplingStrategyId::RandomizedFSD) {    // :587-626: after 10 tokens always FSD, before that a coin per token
+        if (state.fsd_new_tokens >= 10 || rng.NextFloat(0.0f, 1.0f) >= 0.5f) { FsdPick(out, pool, cfg, temperature, state, text); drawn = true; }
+        else top_p = cfg.rfsd_top_p;
+    }
+    if (!drawn) SoftMaxPool(pool, temperature);
+    if (drawn) {
+    } else if (IsStdFamily(strategy) || strategy == SamplingStrategyId::RandomizedFSD) {
         const int top_k = std::min((int)pool.size(), cfg.max_k);
         float cumulative = 0;
         for (const IdWeight &it : pool) {                        // topp_topk_filter_on_sorted, sampling_strategy.cc:29-43
@@ -185,7 +260,7 @@ bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, Sampli
     else if (strategy == SamplingStrategyId::TFS) CutTailFree(pool, cfg.tfs_z, out.token_pool);
     else if (strategy == SamplingStrategyId::Typical) CutTypical(pool, cfg.typical_p, out.token_pool);
     else {                                                       // Mirostat, sampling_strategy.cc:1036-1056
-        float mu = (mirostat_mu && *mirostat_mu == *mirostat_mu) ? *mirostat_mu : 2.0f * cfg.mirostat_tau;
+        const float mu = state.mirostat_mu == state.mirostat_mu ? state.mirostat_mu : 2.0f * cfg.mirostat_tau;
         size_t n = 0;
         while (n < pool.size() && !(-log2f(pool[n].weight) > mu)) n++;
         if (n == 0) n = 1;
@@ -197,21 +272,26 @@ bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, Sampli
         out.token_pool = prefix;
     }
     if (out.token_pool.empty()) return true;
-    out.selected.push_back(DrawOne(rng, out.token_pool));
+    if (!drawn) out.selected.push_back(DrawOne(rng, out.token_pool));
     if (eos_id >= 0) {
         if (out.token_pool[0].id == eos_id && out.selected[0].id != eos_id) out.flag = 1;
-        if (cfg.eos_bypassing_max > 0 && out.selected[0].id == eos_id && out.token_pool.size() > 1 && eos_bypassing_count
-            && *eos_bypassing_count < cfg.eos_bypassing_max) {
+        if (cfg.eos_bypassing_max > 0 && out.selected[0].id == eos_id && out.token_pool.size() > 1
+            && state.eos_bypassing_count < cfg.eos_bypassing_max) {
             out.flag = 2;
             for (const IdWeight &it : out.token_pool)
-                if (it.id != eos_id) { out.selected[0] = it; (*eos_bypassing_count)++; break; }
+                if (it.id != eos_id) { out.selected[0] = it; state.eos_bypassing_count++; break; }
         }
     }
-    if (strategy == SamplingStrategyId::Mirostat && mirostat_mu) {       // :1091-1096
-        float mu = (*mirostat_mu == *mirostat_mu) ? *mirostat_mu : 2.0f * cfg.mirostat_tau;
+    if (strategy == SamplingStrategyId::Mirostat) {             // :1091-1096
+        const float mu = state.mirostat_mu == state.mirostat_mu ? state.mirostat_mu : 2.0f * cfg.mirostat_tau;
         float w = out.selected[0].weight;
         for (const IdWeight &it : out.token_pool) if (it.id == out.selected[0].id) { w = it.weight; break; }
-        *mirostat_mu = mu - cfg.mirostat_eta * (-log2f(w) - cfg.mirostat_tau);
+        state.mirostat_mu = mu - cfg.mirostat_eta * (-log2f(w) - cfg.mirostat_tau);
+    }
+    if (strategy == SamplingStrategyId::FSD || strategy == SamplingStrategyId::RandomizedFSD) {
+        if (!state.fsd_started && !state.ngram.initialized()) state.ngram = NGramModel(cfg.fsd_n, cfg.fsd_beta);
+        state.ngram.Update(out.selected[0].id);                  // the model follows what was SELECTED here, like the reference
+        state.fsd_new_tokens++;
     }
     return true;
 }

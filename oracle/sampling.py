@@ -153,3 +153,89 @@ def choose_tokens_ex(logits_f16, strategy, rng, temperature=1.0, pool_size=50, m
     if strategy == MIROSTAT:
         mu = F(mu - F(eta) * F(F(-np.log2(F(sel[1]), dtype=np.float32)) - F(tau)))
     return sel, cut, mu
+
+
+# ---- FSD / RandomizedFSD (sampling_strategy.cc:457-541, :569-667; NGram: sampling_strategy.h:125-236)
+FSD, RANDOM_FSD = 5, 6
+
+
+class NGram:
+    def __init__(self, n=3, beta=0.9):
+        self.n, self.beta, self.tokens, self.following = n, F(beta), [], None
+
+    def initialize(self, tokens):
+        self.tokens = list(tokens)
+        self.following = [dict() for _ in range(self.n)]
+        for order in range(1, self.n + 1):
+            for i in range(0, len(tokens) - order + 1):
+                gram = tuple(tokens[i:i + order])
+                self.following[order - 1].setdefault(gram[:-1], []).append(gram[-1])
+
+    def update(self, tok):
+        if self.following is None:
+            self.following = [dict() for _ in range(self.n)]
+        for i in range(self.n):
+            if len(self.tokens) < i:
+                continue
+            key = tuple(self.tokens[len(self.tokens) - i:]) if i else ()
+            self.following[i].setdefault(key, []).append(tok)
+        self.tokens.append(tok)
+
+    def penalize(self, cands):
+        pen = {}
+        if len(self.tokens) < self.n - 1 or self.following is None:
+            return pen
+        for c in cands:
+            remaining, score = F(1), F(0)
+            for i in range(self.n - 1, -1, -1):
+                key = tuple(self.tokens[len(self.tokens) - i:]) if i else ()
+                nxt = self.following[i].get(key, [])
+                cnt = sum(1 for v in nxt if v == c)
+                if cnt == 0:
+                    continue
+                if i == 0:
+                    score = F(score + F(remaining * F(F(cnt) / F(len(nxt)))))
+                else:
+                    score = F(score + F(F(remaining * self.beta) * F(F(cnt) / F(len(nxt) + 1))))
+                remaining = F(remaining - F(remaining * self.beta))
+            pen[c] = score
+        return pen
+
+
+def _top_k_of_pool(pool, k):
+    return sorted(pool, key=lambda it: (-float(it[1]), it[0]))[:k]
+
+
+class FsdState:
+    def __init__(self, n=3, beta=0.9):
+        self.ngram, self.started, self.new_tokens = NGram(n, beta), False, 0
+
+
+def _fsd_pick(raw, temperature, st, text, k, alpha):
+    pool = _top_k_of_pool(softmax_pool(raw, temperature), k)
+    if not st.started:
+        st.ngram.initialize(text)
+        st.started = True
+    pen = st.ngram.penalize([i for i, _ in pool])
+    pool = [(i, F(F(F(1) - F(alpha)) * F(w) - F(F(alpha) * pen[i])) if i in pen else w) for i, w in pool]
+    cut = _top_k_of_pool(pool, len(pool))
+    return cut[0], cut
+
+
+def choose_tokens_fsd(logits_f16, strategy, rng, st, text, temperature=1.0, pool_size=50, k=6, alpha=0.5, max_k=8, top_p=0.93):
+    n = np.asarray(logits_f16).size
+    raw = sorted_top_k(logits_f16, min(pool_size, n))
+    if strategy == FSD or st.new_tokens >= 10 or F(F(rng.next(24)) / F(1 << 24)) >= F(0.5):
+        sel, cut = _fsd_pick(raw, temperature, st, text, k, alpha)
+    else:
+        pool = softmax_pool(raw, temperature)
+        cut, cum = [], F(0)
+        for item in pool:
+            cum = F(cum + item[1])
+            cut.append(item)
+            if cum >= F(top_p) or len(cut) >= min(len(pool), max_k):
+                break
+        sel = draw_one(rng, cut)
+    st.ngram.update(sel[0])
+    st.new_tokens += 1
+    return sel, cut

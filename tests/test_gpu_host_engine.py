@@ -182,9 +182,17 @@ def test_sampled_queries_draw_from_the_engines_logits_with_the_reference_generat
             assert res[q] == want
         assert res[q2] == int(np.argmax(eng.last_logits(q2)[-1].astype(np.float32)))
         assert eng.commit(res)
-    # unsupported strategies are refused with a message, ids out of range too
-    assert eng.add_query(prompt, strategy="fsd") < 0 and "not supported" in InferenceEngine._err()
-    assert eng.add_query(prompt, strategy=99) < 0
+    for q in (q1, q2, q3):
+        assert eng.remove_query(q)
+    # every other strategy of the reference runs too (host side, tests/test_sampling_cpu.py); ids out of range are refused
+    for name in ("fsd", "random_fsd", "min_p", "tfs", "typical", "mirostat"):
+        q = eng.add_query(prompt, strategy=name, seed=5)
+        assert q > 0, name
+        for _ in range(3):
+            (qq, tok), = eng.infer()
+            assert 0 <= tok < 1000 and eng.commit({q: tok})
+        assert eng.remove_query(q)
+    assert eng.add_query(prompt, strategy=99) < 0 and "Invalid strategy id" in InferenceEngine._err()
     eng.close()
 
 
@@ -202,6 +210,6 @@ def test_model_decoding_strategy_from_the_ini(tmp_path):
         assert eng.commit({qid: tok})
     assert len(seen) > 1                                          # not the greedy fixed point of this tiny model
     eng.close()
-    open(ini, "w").write(text.replace('{"name":"sample.top_p", "top_p":0.5, "max_k":3}', "sample.fsd"))
-    with pytest.raises(EngineError, match="not supported"):
+    open(ini, "w").write(text.replace('{"name":"sample.top_p", "top_p":0.5, "max_k":3}', "sample.nonsense"))
+    with pytest.raises(EngineError, match="Invalid decoding_strategy"):
         InferenceEngine.from_ini(ini)

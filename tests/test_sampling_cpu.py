@@ -56,7 +56,7 @@ def test_pool_cuts_follow_top_p_and_max_k():
     freq = np.bincount(ids, minlength=10)[:4] / 4000.0
     assert np.abs(freq - np.array(probs)).max() < 0.03
     with pytest.raises(E.EngineError):
-        E.sampling_choose(logits, 5)                                    # FSD: not restated
+        E.sampling_choose(logits, 7)                                    # not a member of the Std family: use sampling_choose_ex
 
 
 def test_perplexity_token_nll_is_the_tools_float_log_softmax():
@@ -120,4 +120,27 @@ def test_pool_cutting_rules_on_a_known_distribution():
     ids, _, pool, _, mu = E.sampling_choose_ex(logits, S.MIROSTAT, tau=1.0, eta=0.5, seed=3, n_draws=1)
     assert abs(mu - 2.5) < 1e-5
     with pytest.raises(E.EngineError):
-        E.sampling_choose_ex(logits, 5)                           # FSD needs the n-gram state of the text: not restated
+        E.sampling_choose_ex(logits, 11)                          # past the last SamplingStrategyId
+
+
+@pytest.mark.parametrize("strategy", [S.FSD, S.RANDOM_FSD])
+def test_fsd_strategies_match_the_restated_reference(strategy):
+    """FSD / RandomizedFSD: top-6 probabilities discounted by the n-gram model of the query's own text (prompt + what was
+    selected so far); RandomizedFSD tosses the generator's coin per token for its first 10 tokens."""
+    rng = np.random.default_rng(31 + strategy)
+    for case in range(4):
+        vocab = [50, 200, 12, 32000][case]
+        logits = rng.normal(0, 1.5, vocab).astype(np.float16)
+        text = [int(t) for t in rng.integers(0, min(vocab, 8), [40, 3, 1, 25][case])]      # a small alphabet: plenty of repeated n-grams
+        seed, n = 500 + case, 16
+        ids, probs, pool_ids, pool_probs, _ = E.sampling_choose_ex(logits, strategy, seed=seed, n_draws=n, text=text, top_p=0.93)
+        r, st = S.JavaRandom(seed), S.FsdState()
+        for d in range(n):
+            (tok, w), cut = S.choose_tokens_fsd(logits, strategy, r, st, text)
+            assert ids[d] == tok, (case, d)
+            assert abs(probs[d] - float(w)) <= 3e-6
+        assert pool_ids == [i for i, _ in cut]
+    # the penalty bites: a candidate that always followed the current context loses against a fresh one of similar probability
+    logits = np.full(10, -10.0, np.float16); logits[3] = 2.0; logits[4] = 1.9
+    ids, _, pool, w, _ = E.sampling_choose_ex(logits, S.FSD, n_draws=1, text=[1, 2, 3, 1, 2, 3, 1, 2])
+    assert ids[0] == 4 and pool[0] == 4 and w[pool.index(3)] < 0.2
