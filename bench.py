@@ -197,7 +197,8 @@ def main():
     # ---- CPU baseline (oracle port) on a bounded sample
     if world == 1 and not args.no_cpu_baseline and not os.environ.get("IFA_FORCE_TP") and not is_moe:
         try:
-            threads = min(os.cpu_count() or 1, 128)
+            import oracle as _o
+            threads = min(_o.usable_cpus(), 128)        # affinity and cgroup quota, not the visible CPU count
             host = runner.export_host_tensors()
             n_cpu = args.cpu_tokens or 8
             v, secs = cpu_baseline(host, runner.shape, n_cpu, threads, kvd)

@@ -18,6 +18,9 @@
  */
 #include "ifa_oracle.h"
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <string.h>
 #include <stdlib.h>
 
@@ -657,6 +660,20 @@ static int ax8_eligible(int dtype)
     }
 }
 
+/* default OpenMP team size of this library (oracle.py passes the CPUs the process may really use) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* tests switch the specialised loops off to compare them with the general ones */
+static int g_orc_slow_paths = 0;
+void orc_set_slow_paths(int on) { g_orc_slow_paths = on; }
+
 int orc_gemv_ax8(int dtype_w, const uint8_t *W, size_t rows, size_t cols,
                  const uint8_t *xq8, orc_f16 *y, double *y_f64)
 {
@@ -675,6 +692,51 @@ int orc_gemv_ax8(int dtype_w, const uint8_t *W, size_t rows, size_t cols,
         xs[k] = s;
     }
     const int per_lane = cap == 32 ? 8 : 16; /* elements a lane covers per block */
+    /* Q4_B32T1 without the fp64 shadow sum: the same float operations in the same order as the general loop below
+     * (tests/test_oracle_cpu.py checks the two bit for bit), with the nibbles multiplied straight out of the block and the
+     * per-part sums of x hoisted out of the row loop -- this is the loop bench.py's cpu_baseline spends its time in */
+    if ((dtype_w == ORC_Q4_B32T1A || dtype_w == ORC_Q4_B32T1B) && !y_f64 && !g_orc_slow_paths) {
+        int32_t *xsum = (int32_t *)malloc(sizeof(int32_t) * nb * 4);
+        if (!xsum) { free(xq); free(xs); return -1; }
+        for (size_t k = 0; k < nb; k++)
+            for (int part = 0; part < 4; part++) {
+                int g2 = 0;
+                for (int i = 0; i < 8; i++) g2 += xq[k * 32 + (size_t)part * 8 + (size_t)i];
+                xsum[k * 4 + (size_t)part] = g2;
+            }
+        #pragma omp parallel for schedule(static)
+        for (long r = 0; r < (long)rows; r++) {
+            float lanes[32];
+            for (int l = 0; l < 32; l++) lanes[l] = 0.0f;
+            const uint8_t *row = W + (size_t)r * nb * 20;
+            for (size_t k = 0; k < nb; k++) {
+                const uint8_t *b = row + k * 20;
+                const float base = orc_h2f(rd16(b)), scale = orc_h2f(rd16(b + 2));
+                const int32_t *xv = xq + k * 32;
+                const float sx = xs[k];
+                for (int part = 0; part < 4; part++) {
+                    const uint8_t *c = b + 4 + part * 4;
+                    int gs = 0;
+                    for (int i = 0; i < 4; i++) gs += (c[i] & 0x0F) * xv[part * 8 + 2 * i] + (c[i] >> 4) * xv[part * 8 + 2 * i + 1];
+                    const int lane = (int)(k % 8) * 4 + part;
+                    float t = scale * (float)gs;
+                    t = t * sx;
+                    lanes[lane] = lanes[lane] + t;
+                    float u = base * (float)xsum[k * 4 + (size_t)part];
+                    u = u * sx;
+                    lanes[lane] = lanes[lane] + u;
+                }
+            }
+            for (int mask = 16; mask > 0; mask >>= 1) {
+                float nv[32];
+                for (int l = 0; l < 32; l++) nv[l] = lanes[l] + lanes[l ^ mask];
+                memcpy(lanes, nv, sizeof(nv));
+            }
+            y[r] = orc_f2h(lanes[0]);
+        }
+        free(xsum); free(xq); free(xs);
+        return 0;
+    }
     #pragma omp parallel for schedule(static)
     for (long r = 0; r < (long)rows; r++) {
         float lanes[32];

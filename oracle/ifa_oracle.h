@@ -61,6 +61,8 @@ int orc_quantize_act_q8(const orc_f16 *src, size_t rows, size_t cols, uint8_t *d
 int orc_quantize_q8_b32t2_host(const orc_f16 *src, size_t rows, size_t cols, uint8_t *dst);
 
 /* GEMV y[rows] = W[rows][cols] . x */
+void orc_set_num_threads(int n);   /* default OpenMP team size */
+void orc_set_slow_paths(int on);   /* 1: general loops only (tests compare the specialised ones against them) */
 int orc_gemv_ax8(int dtype_w, const uint8_t *W, size_t rows, size_t cols,
                  const uint8_t *xq8, orc_f16 *y, double *y_f64 /* nullable */);
 int orc_gemv_f16x(int dtype_w, const uint8_t *W, size_t rows, size_t cols,

@@ -46,6 +46,25 @@ def build(force=False):
     return so
 
 
+def usable_cpus():
+    """CPUs this process can actually run on: the affinity mask capped by the cgroup CPU quota (a container may see 256
+    logical CPUs and own 16 of them; OpenMP's default of one thread per visible CPU then runs 16x oversubscribed)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 _lib = None
 _ref = None
 
@@ -55,6 +74,7 @@ def lib():
     if _lib is None:
         so = build()
         L = C.CDLL(so)
+        L.orc_set_num_threads(C.c_int(usable_cpus()))      # the default for every OpenMP loop of the oracle
         L.orc_block_capacity.restype = C.c_int
         L.orc_block_bytes.restype = C.c_int
         L.orc_row_bytes.restype = C.c_size_t

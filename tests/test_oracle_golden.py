@@ -99,3 +99,24 @@ def test_act_quant_semantics():
     # np.round is half-to-even, roundf is half-away: exclude exact .5 ties
     tie = np.abs(np.abs(xf / np.maximum(s32[..., None], 1e-30)) % 1 - 0.5) < 1e-6
     assert np.array_equal(codes[~tie], np.clip(expect, -128, 127).astype(np.int8)[~tie])
+
+
+def test_specialised_q4_gemv_loop_is_bit_identical_to_the_general_one():
+    """orc_gemv_ax8 has a Q4_B32T1 loop without the fp64 shadow sum (what bench.py's cpu_baseline times); it must produce
+    the same halves as the general per-block loop, which the golden fixtures and the GPU kernels are pinned to."""
+    import os
+    from oracle import oracle as om
+    rng = np.random.default_rng(12)
+    for d in (o.Q4_B32T1A, o.Q4_B32T1B):
+        for rows, cols in ((7, 32), (33, 256), (64, 4096), (5, 11008)):
+            w = rng.normal(0, 0.05, (rows, cols)).astype(np.float16)
+            Wq = o.quantize(d, w)
+            xq = o.quantize_act_q8(rng.normal(0, 1.5, (1, cols)).astype(np.float16)).reshape(-1)
+            fast = np.asarray(o.gemv_ax8(d, Wq, rows, cols, xq)).view(np.uint16).copy()
+            om.lib().orc_set_slow_paths(1)
+            try:
+                slow = np.asarray(o.gemv_ax8(d, Wq, rows, cols, xq)).view(np.uint16).copy()
+            finally:
+                om.lib().orc_set_slow_paths(0)
+            assert np.array_equal(fast, slow), (d, rows, cols)
+    assert 1 <= o.usable_cpus() <= (os.cpu_count() or 1)
