@@ -170,8 +170,9 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if wd == dt.Q4_B32T1A and args.shape == "llama2_7b":
+                import re                                                                     # <DT 13, NJ 2, RW any, EPI_GLU 2, NORM 1, ...>
                 traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()     # demangled or mangled name
-                           if k.startswith("ifa::k_dec_gemv<13, 2, 6, 2, 1>") or k.startswith("_ZN3ifa10k_dec_gemvILi13ELi2ELi6ELi2ELi1E")][0]
+                           if re.match(r"ifa::k_dec_gemv<13, 2, \d+, 2, 1", k) or re.match(r"_ZN3ifa10k_dec_gemvILi13ELi2ELi\d+ELi2ELi1E", k)][0]
         except Exception:
             traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "k_dec_gemv<%s, EPI_GLU> (fused RMSNorm+Q8 quant+W1/W3 GEMV+SiLU*mul)" % dt.name(wd),

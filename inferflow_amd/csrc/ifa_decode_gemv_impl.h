@@ -7,14 +7,23 @@ namespace ifa {
 
 // rows (EPI_GLU: row pairs) a wave keeps in flight: bounded by registers, NM * RW * NJ * DW VGPRs
 template <int DT>
-constexpr int dec_rw(int nj, int nm)
+constexpr int dec_rw(int nj, int nm, int th = DEC_THREADS)
 {
     if (DT == Q4_B32T1A) {      // tuned on Llama-2-7B shapes (DESIGN.md "Kernel timeline")
         constexpr int a[9] = {0, 6, 6, 4, 4, 2, 2, 2, 2}, b[9] = {0, 6, 6, 3, 2, 2, 1, 1, 1};
-        return nm == 2 ? b[nj] : a[nj];
+        const int rw = nm == 2 ? b[nj] : a[nj];
+        return th > DEC_THREADS ? (rw + 1) / 2 : rw;       // 1024 threads: 128 registers per lane, half the rows per wave
     }
     int rw = 72 / (nm * nj * DecFmt<DT, 1>::DW);
     return rw < 1 ? 1 : (rw > 6 ? 6 : rw);
+}
+
+// Workgroup size by kernel shape, measured on Llama-2-7B Q4: the gated W1/W3 kernel and the short Wo kernel
+// (2 blocks per lane) gain from four waves per SIMD (issue stalls overlap), QKV and the long-row W2 kernel lose
+template <int DT>
+constexpr int dec_threads(int epi, int norm, int nj, bool xadd)
+{
+    return (DT == Q4_B32T1A && nj == 2 && !xadd && (epi == EPI_GLU || (epi == EPI_RESIDUAL && norm == 0))) ? 1024 : DEC_THREADS;
 }
 
 template <int DT, int EPI, int NORM, bool XADD = false>
@@ -50,7 +59,8 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     }
     // exactly one workgroup per CU (a second one would queue its activation behind the first one's weights)
     const int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 1;
-    int wgs = std::min(dec_num_cus() * per_cu, (P.total_rows + DEC_WAVES - 1) / DEC_WAVES);
+    const int waves = dec_threads<DT>(EPI, NORM, nj, XADD) / 64;
+    int wgs = std::min(dec_num_cus() * per_cu, (P.total_rows + waves - 1) / waves);
     if (wgs < 1) wgs = 1;
     const dim3 grid((unsigned)wgs);
     const size_t smem = xlds_bytes(P.cols);
@@ -59,9 +69,10 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     if (nj > NJCAP) return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit for a normalised / gated input", P.cols);
 #define IFA_DG(NJV) \
     case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ && NJV <= NJCAP) { \
-        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(NJV, NM), EPI, NORM, XADD>; \
+        constexpr int THV = dec_threads<DT>(EPI, NORM, NJV, XADD); \
+        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(NJV, NM, THV), EPI, NORM, XADD, THV>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        kern<<<grid, dim3(DEC_THREADS), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, P); } break;
+        kern<<<grid, dim3(THV), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, P); } break;
     switch (nj) { IFA_DG(1) IFA_DG(2) IFA_DG(3) IFA_DG(4) IFA_DG(5) IFA_DG(6) IFA_DG(7) IFA_DG(8) }
 #undef IFA_DG
     IFA_LAUNCH_CHECK();

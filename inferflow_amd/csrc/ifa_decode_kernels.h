@@ -110,7 +110,7 @@ struct XPre {
         const int chunks = cols >> 3;
 #pragma unroll
         for (int k = 0; k < MAXC; k++) {
-            const int c = threadIdx.x + k * DEC_THREADS;
+            const int c = threadIdx.x + k * (int)blockDim.x;
             if (c < chunks) {
                 av[k] = *reinterpret_cast<const half8_t *>(add + (size_t)c * 8);
                 if (add_bias) abv[k] = *reinterpret_cast<const half8_t *>(add_bias + (size_t)c * 8);
@@ -122,7 +122,7 @@ struct XPre {
         const int chunks = cols >> 3;
 #pragma unroll
         for (int k = 0; k < MAXC; k++) {
-            const int c = threadIdx.x + k * DEC_THREADS;
+            const int c = threadIdx.x + k * (int)blockDim.x;
             if (c >= chunks) continue;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -140,7 +140,7 @@ struct XPre {
         const int chunks = cols >> 3;
 #pragma unroll
         for (int k = 0; k < MAXC; k++) {
-            const int c = threadIdx.x + k * DEC_THREADS;
+            const int c = threadIdx.x + k * (int)blockDim.x;
             if (c < chunks) {
                 xv[k] = *reinterpret_cast<const half8_t *>(x + (size_t)c * 8);
                 if constexpr (NORM == 1) {
@@ -161,7 +161,7 @@ struct XPre {
         if constexpr (NORM == 1) {
 #pragma unroll
             for (int k = 0; k < MAXC; k++) {
-                const int c = tid + k * DEC_THREADS;
+                const int c = tid + k * (int)blockDim.x;
                 if (c < chunks) *reinterpret_cast<half8_t *>(L.xh + (size_t)c * 8) = xv[k];
             }
             __syncthreads();
@@ -178,7 +178,7 @@ struct XPre {
         }
 #pragma unroll
         for (int k = 0; k < MAXC; k++) {
-            const int c = tid + k * DEC_THREADS;
+            const int c = tid + k * (int)blockDim.x;
             if (c >= chunks) continue;       // whole quads (4 lanes = one block) are in or out together
             float v[8];
             if constexpr (NORM == 1) {
@@ -426,8 +426,10 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
 //   4. the remaining rows -- all of them at once, nothing waits on them until the dots;
 //   5. every wave reduces its RW rows as independent chains, then lane i finishes row i
 //      (bias / residual / activation) so the epilogue's loads overlap too.
-template <int DT, int NJ, int RW, int EPI, int NORM, bool XADD = false>
-__global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols,
+// TH = threads per workgroup: 512 (two waves per SIMD, 256 registers each) or 1024 (four waves per SIMD, 128 registers, half
+// the rows in flight per wave) -- chosen per kernel shape by the launcher (ifa_decode_gemv_impl.h)
+template <int DT, int NJ, int RW, int EPI, int NORM, bool XADD = false, int TH = DEC_THREADS>
+__global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols,
                                                           const DecGemvParams P)
 {
     // px / pnw / pnb / pcols repeat P.x / P.norm_w / P.norm_b / P.cols as leading scalar arguments: with
@@ -443,8 +445,8 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv(const half_t *px, cons
     const XLds L = xlds_carve(smem, pcols);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (SGPR)
-    const int gw = blockIdx.x * DEC_WAVES + wave;
-    const int W = gridDim.x * DEC_WAVES;
+    const int gw = blockIdx.x * (TH / 64) + wave;
+    const int W = gridDim.x * (TH / 64);
     using Fmt = DecFmt<DT, NJ>;
     const size_t row_bytes = tiled_row_bytes(DT, (size_t)P.nblk);
     constexpr int NM = epi_is_glu(EPI) ? 2 : 1;
