@@ -168,6 +168,10 @@ int ifa_attention(const void *q_f16, const void *kcache, const void *vcache, int
 
 /* ---- greedy argmax over F16 logits (SampleTokens top-1) ------------------ */
 int ifa_argmax(const void *logits_f16, size_t n, int *out_index_dev, ifa_stream stream);
+/* the same over the ALLOWED ids: excluded_dev = {count (<= 3), id, id, id} in device memory (nullable) -- the ids
+ * SamplingStrategy::GetSortedTopK never offers to its queue: the vocabulary's unk id and Invalid-type tokens
+ * (src/transformer/sampling_strategy.cc:281-297) */
+int ifa_argmax_masked(const void *logits_f16, size_t n, const int *excluded_dev, int *out_index_dev, ifa_stream stream);
 
 /* ======================================================================== */
 /* Per-device decode worker: counterpart of GpuInferenceWorker                */
@@ -226,6 +230,10 @@ int ifa_model_reset(ifa_model *m);
 int ifa_model_kv_slots(ifa_model *m, int n_slots);
 int ifa_model_select_kv(ifa_model *m, int slot);
 int ifa_model_set_option(ifa_model *m, const char *name, int value);
+/* up to 3 token ids the worker's greedy argmax (forward / decode / decode_batch) never selects: the unk id and
+ * Invalid-type tokens GetSortedTopK skips (sampling_strategy.cc:281-297).  None by default at this level; the engine
+ * facade sets the model's unk id. */
+int ifa_model_set_excluded_tokens(ifa_model *m, const int *ids_host, int n);
 /* 1 if the fused batch-1 decode kernels cover this model, else 0 (+ reason) */
 int ifa_model_fused_supported(ifa_model *m, char *why, size_t why_len);
 /* One Infer() step for one query: n_tokens new tokens at positions

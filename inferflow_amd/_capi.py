@@ -80,6 +80,7 @@ SIGNATURES = {
     "ifa_scale": (_i, [_vp, _f, _sz, _vp, _vp]),
     "ifa_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "ifa_argmax": (_i, [_vp, _sz, _vp, _vp]),
+    "ifa_argmax_masked": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "ifa_model_create": (_i, [_vp, C.POINTER(_vp)]),
     "ifa_model_destroy": (_i, [_vp]),
     "ifa_model_set_tensor": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _sz]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "ifa_model_finalize": (_i, [_vp]),
     "ifa_model_reset": (_i, [_vp]),
     "ifa_model_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "ifa_model_set_excluded_tokens": (_i, [_vp, _vp, _i]),
     "ifa_model_fused_supported": (_i, [_vp, C.c_char_p, _sz]),
     "ifa_model_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ifa_model_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),

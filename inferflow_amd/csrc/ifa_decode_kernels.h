@@ -1175,7 +1175,8 @@ __host__ __device__ inline size_t dec_attn_smem(int head_dim, int max_ctx)
 }
 
 // ------------------------------------------------------------- small kernels
-// state[0] = current token id, state[1] = its position, state[2] = steps done;
+// state[0] = current token id, state[1] = its position, state[2] = steps done; state[3..6] = excluded ids (see
+// k_dec_argmax_advance);
 // state[8 + i] = i-th generated token of the current launch batch.
 // Also fills the step's RoPE table: tab[c] = (cos, sin) of pos * theta_scale^c,
 // the same expression rope_rotate() evaluates per element (ifa_math.h).
@@ -1200,14 +1201,19 @@ static __global__ void __launch_bounds__(256) k_dec_gather(const half_t *__restr
     }
 }
 
-// greedy top-1 over the logits (first maximum wins); writes the token ring and advances the state
+// greedy top-1 over the logits (first maximum wins); writes the token ring and advances the state.
+// state[3] = number of excluded ids (<= 3), state[4..6] = the ids GetSortedTopK never offers to the queue (the
+// vocabulary's unk id, Invalid-type tokens: sampling_strategy.cc:281-297)
 static __global__ void __launch_bounds__(1024) k_dec_argmax_advance(const half_t *__restrict__ v, int n, int *__restrict__ state,
                                                              int ring)
 {
     __shared__ float bv[16];
     __shared__ int bi[16];
+    const int ne = min(max(state[3], 0), 3);
+    const int e0 = ne > 0 ? state[4] : -1, e1 = ne > 1 ? state[5] : -1, e2 = ne > 2 ? state[6] : -1;
     float best = -INFINITY; int besti = 0x7FFFFFFF;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (i == e0 || i == e1 || i == e2) continue;
         float f = h2f(v[i]);
         if (f > best || (f == best && i < besti)) { best = f; besti = i; }
     }

@@ -792,7 +792,7 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     if (logits_out) { if ((rc = matmul(m, hfin, T, lm, none, m->logits))) return rc; }
     else { if ((rc = matmul(m, hfin + (size_t)t0 * D, 1, lm, none, m->logits + (size_t)t0 * V))) return rc; }
     if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
-    if ((rc = ifa_argmax(m->logits + (size_t)(T - 1) * V, V, m->state, s))) return rc;
+    if ((rc = ifa_argmax_masked(m->logits + (size_t)(T - 1) * V, V, m->state + 3, m->state, s))) return rc;
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     const auto host_t1 = std::chrono::steady_clock::now();
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -983,7 +983,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     if ((rc = matmul(m, hfin, T, lm, none, m->logits))) return rc;
     if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
     for (int r = 0; r < n; r++)
-        if ((rc = ifa_argmax(m->logits + (size_t)r * V, V, m->state + 8 + r, s))) return rc;
+        if ((rc = ifa_argmax_masked(m->logits + (size_t)r * V, V, m->state + 3, m->state + 8 + r, s))) return rc;
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
     return IFA_OK;
     };
@@ -1239,6 +1239,20 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
             return IFA_OK;
         }
     return ifa_fail(IFA_ERR_ARG, "ifa_model_set_option: unknown option '%s'", name);
+}
+
+// ids the greedy selection never offers (GetSortedTopK skips the vocabulary's unk id and Invalid-type tokens,
+// src/transformer/sampling_strategy.cc:281-297): kept in the device state next to token / position so that the
+// captured step needs no re-capture when they change
+int ifa_model_set_excluded_tokens(ifa_model *m, const int *ids_host, int n)
+{
+    IFA_REQUIRE(m && m->finalized, "ifa_model_set_excluded_tokens: model not finalized");
+    IFA_REQUIRE(n >= 0 && n <= 3 && (n == 0 || ids_host), "ifa_model_set_excluded_tokens: n %d (0..3)", n);
+    int v[4] = {n, -1, -1, -1};
+    for (int i = 0; i < n; i++) v[1 + i] = ids_host[i];
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    IFA_HIP_CHECK(hipMemcpy(m->state + 3, v, sizeof(v), hipMemcpyHostToDevice));
+    return IFA_OK;
 }
 
 int ifa_model_fused_supported(ifa_model *m, char *why, size_t why_len)

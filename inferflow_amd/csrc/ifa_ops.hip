@@ -324,12 +324,17 @@ __global__ void __launch_bounds__(256) k_scale(const half_t *a, float s, size_t 
 }
 
 // greedy top-1: first maximum wins (GetSortedTopK, sampling_strategy.cc:372-386)
-__global__ void __launch_bounds__(1024) k_argmax(const half_t *__restrict__ v, size_t n, int *__restrict__ out)
+// excl: optional {count (<= 3), id, id, id}: ids the queue is never offered -- the vocabulary's unk id and Invalid-type
+// tokens (sampling_strategy.cc:281-297)
+__global__ void __launch_bounds__(1024) k_argmax(const half_t *__restrict__ v, size_t n, int *__restrict__ out, const int *__restrict__ excl)
 {
     __shared__ float bv[16];
     __shared__ int bi[16];
+    const int ne = excl ? min(max(excl[0], 0), 3) : 0;
+    const int e0 = ne > 0 ? excl[1] : -1, e1 = ne > 1 ? excl[2] : -1, e2 = ne > 2 ? excl[3] : -1;
     float best = -INFINITY; int besti = 0x7FFFFFFF;
     for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        if ((int)i == e0 || (int)i == e1 || (int)i == e2) continue;
         float f = h2f(v[i]);
         if (f > best || (f == best && (int)i < besti)) { best = f; besti = (int)i; }
     }
@@ -541,7 +546,16 @@ int ifa_argmax(const void *logits, size_t n, int *out_index_dev, ifa_stream stre
 {
     IFA_REQUIRE(logits && out_index_dev, "ifa_argmax: null pointer");
     IFA_REQUIRE(n > 0 && n < 0x7FFFFFFFu, "ifa_argmax: n %zu", n);
-    k_argmax<<<dim3(1), dim3(1024), 0, ifa_s(stream)>>>((const half_t *)logits, n, out_index_dev);
+    k_argmax<<<dim3(1), dim3(1024), 0, ifa_s(stream)>>>((const half_t *)logits, n, out_index_dev, nullptr);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_argmax_masked(const void *logits, size_t n, const int *excluded_dev, int *out_index_dev, ifa_stream stream)
+{
+    IFA_REQUIRE(logits && out_index_dev, "ifa_argmax_masked: null pointer");
+    IFA_REQUIRE(n > 0 && n < 0x7FFFFFFFu, "ifa_argmax_masked: n %zu", n);
+    k_argmax<<<dim3(1), dim3(1024), 0, ifa_s(stream)>>>((const half_t *)logits, n, out_index_dev, excluded_dev);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }

@@ -140,6 +140,14 @@ bool InferenceEngine::Init(const InferenceConfig &cfg)
         if (!IsSupportedStrategy(default_strategy_)) { EngineSetError("decoding_strategy \"%s\" of model %s is not supported", spec_.decoding_strategy.c_str(), spec_.sid.c_str()); return false; }
     }
     if (!BuildWorker(&model_, spec_, device_)) return false;
+    {   // the ids greedy / sampled selection never offers (GetSortedTopK): device argmax and host pool alike
+        std::vector<int> excl;
+        if (spec_.unk_token_id >= 0 && spec_.unk_token_id < spec_.hyper_params.vocab_size) excl.push_back(spec_.unk_token_id);
+        for (int id : spec_.invalid_token_ids)
+            if (id >= 0 && id < spec_.hyper_params.vocab_size && excl.size() < 3 && std::find(excl.begin(), excl.end(), id) == excl.end()) excl.push_back(id);
+        default_sampling_.excluded_ids = excl;
+        if (ifa_model_set_excluded_tokens(model_, excl.data(), (int)excl.size()) != IFA_OK) { EngineSetError("excluded tokens: %s", ifa_last_error()); Clear(); return false; }
+    }
     // one KV cache per concurrent query, like the reference's per-query LayerKVCache sets
     kv_slots_ = std::max(1, std::min(config_.max_concurrent_queries, 64));
     if (ifa_model_kv_slots(model_, kv_slots_) != IFA_OK) { EngineSetError("KV caches for %d queries: %s", kv_slots_, ifa_last_error()); Clear(); return false; }

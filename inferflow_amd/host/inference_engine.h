@@ -53,6 +53,10 @@ struct ModelSpec {
     std::string tensor_name_prefix;
     std::map<std::string, std::string> tensor_name_map;
     std::string decoding_strategy;
+    // ids SamplingStrategy::GetSortedTopK never offers (sampling_strategy.cc:281-297): the vocabulary's unk id
+    // (StdVocabulary::unk_id_, default 0; -1: none) and Invalid-type tokens
+    int unk_token_id = 0;
+    std::vector<int> invalid_token_ids;
     std::string decoder_input_template;     // kept for round-tripping the .ini; unused (token-id queries)
     int device_weight_data_type = 1;        // ElementType ids = ifa_dtype; F16
     int device_kv_cache_data_type = 8;      // Q8_B32T2 (the reference's default, model.h:137)

@@ -85,6 +85,11 @@ bool LoadModelSpecJson(ModelSpec &spec, const std::string &path)
     root.GetNumber("vocab_size", hp.vocab_size);
     root.GetNumber("output_vocab_size", hp.output_vocab_size);
     root.GetNumber("qkv_format", spec.qkv_format);
+    // token-id engine: the vocabulary's unk id as a number (the reference resolves "unk_token" through its tokenizer,
+    // model_reader.cc:156-170, :714; StdVocabulary's default is 0); -1: none.  Plus up to two Invalid-type token ids.
+    root.GetNumber("unk_token_id", spec.unk_token_id);
+    if (const JsonValue *inv = root.Get("invalid_token_ids"))
+        for (const JsonValue &v : inv->arr) if (v.type == JsonValue::Number) spec.invalid_token_ids.push_back((int)v.num);
     const JsonValue *ns = root.Get("network_structure");
     if (!ns || ns->type != JsonValue::Object) { EngineSetError("%s: network_structure is missing", path.c_str()); return false; }
     ns->GetString("type", spec.network_structure);

@@ -55,7 +55,7 @@ bool ParseDecodingStrategy(const std::string &text, SamplingStrategyId &id, StdS
     return true;
 }
 
-void SortedTopK(const uint16_t *logits, int n, int k, std::vector<IdWeight> &pool)
+void SortedTopK(const uint16_t *logits, int n, int k, std::vector<IdWeight> &pool, const std::vector<int> &excluded)
 {
     pool.clear();
     if (n <= 0 || k <= 0) return;
@@ -65,6 +65,7 @@ void SortedTopK(const uint16_t *logits, int n, int k, std::vector<IdWeight> &poo
     std::vector<IdWeight> heap;
     heap.reserve((size_t)k + 1);
     for (int i = 0; i < n; i++) {
+        if (!excluded.empty() && std::find(excluded.begin(), excluded.end(), i) != excluded.end()) continue;
         IdWeight it; it.id = i; it.weight = HalfBitsToFloat(logits[i]);
         if (it.weight != it.weight) continue;                   // NaN never enters an ordered set
         if ((int)heap.size() < k) { heap.push_back(it); std::push_heap(heap.begin(), heap.end(), before); }
@@ -237,7 +238,7 @@ bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, Sampli
     if (strategy != SamplingStrategyId::Greedy) max_queue_len = std::min(cfg.pool_size, vocab);
     if (strategy == SamplingStrategyId::StdSampling || strategy == SamplingStrategyId::TopP) top_p = cfg.top_p;
     std::vector<IdWeight> pool;
-    SortedTopK(logits, vocab, max_queue_len, pool);
+    SortedTopK(logits, vocab, max_queue_len, pool, cfg.excluded_ids);
     if (pool.empty()) return true;
     const std::vector<IdWeight> raw = pool;                     // logits of the pool (Mirostat re-normalises a prefix of them)
     bool drawn = false;

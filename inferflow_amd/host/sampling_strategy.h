@@ -63,6 +63,7 @@ struct SamplingConfig {             // the Config structs of sampling_strategy.h
     int fsd_k = 6, fsd_n = 3;       // FSD: candidates kept, n-gram order
     float fsd_alpha = 0.5f, fsd_beta = 0.9f;          // weight' = (1 - alpha) p - alpha penalty; back-off factor
     float rfsd_top_p = 0.93f;       // RandomizedFSD's sampling branch
+    std::vector<int> excluded_ids;  // ids GetSortedTopK never offers: the unk id and Invalid-type tokens (:281-297)
 };
 typedef SamplingConfig StdSamplingConfig;
 
@@ -102,7 +103,9 @@ struct SamplingOutput {
 bool ParseDecodingStrategy(const std::string &text, SamplingStrategyId &id, StdSamplingConfig &cfg, std::string *err = nullptr);
 
 // the k best (logit, id) pairs, best first; equal logits: lower id first (TopKQueue::LessWeight, top_k_queue.h:13-22)
-void SortedTopK(const uint16_t *logits_f16, int n, int k, std::vector<IdWeight> &pool);
+// excluded: ids never offered to the queue -- the vocabulary's unk id and Invalid-type tokens (:281-297)
+void SortedTopK(const uint16_t *logits_f16, int n, int k, std::vector<IdWeight> &pool,
+                const std::vector<int> &excluded = std::vector<int>());
 // SamplingStrategy::SoftMax (sampling_strategy.cc:107-147): temperature floor 0.001, sum floor 1e-5
 void SoftMaxPool(std::vector<IdWeight> &items, float temperature);
 // Random::RandomSampling(output, input, 1) (random.cc:75-146): one draw proportional to the weights

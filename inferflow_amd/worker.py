@@ -53,6 +53,11 @@ class DecodeWorker:
     def set_option(self, name, value):
         check(lib().ifa_model_set_option(self._h, name.encode(), int(value)))
 
+    def set_excluded_tokens(self, ids):
+        """ids (<= 3) the greedy argmax never selects (unk / Invalid-type tokens, sampling_strategy.cc:281-297)"""
+        a = np.ascontiguousarray(ids, np.int32)
+        check(lib().ifa_model_set_excluded_tokens(self._h, a.ctypes.data_as(C.c_void_p), a.size))
+
     def fused_supported(self):
         buf = C.create_string_buffer(256)
         ok = lib().ifa_model_fused_supported(self._h, buf, 256)

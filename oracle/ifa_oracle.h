@@ -115,6 +115,9 @@ typedef struct {
      * {attn_out_scale, ffn_out_scale, out_scale} (TensorOpr::Scale, inference_worker.cc:568-570,842-843,928-929; MiniCPM);
      * scales <= 0 mean 1 */
     float attn_norm_base, ffn_norm_base, out_norm_base, attn_out_scale, ffn_out_scale, out_scale;
+    /* id the greedy selection never offers: the vocabulary's unk id (GetSortedTopK, sampling_strategy.cc:281-297;
+     * StdVocabulary's default is 0); < 0: none */
+    int unk_id;
 } orc_model_cfg;
 
 typedef struct orc_model orc_model;

@@ -318,9 +318,15 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
         if (rc == 0) {
             /* greedy = top-1 (sampling_strategy.cc:372-386); first max wins */
             const orc_f16 *row = lg + (size_t)(T - 1) * V;
-            int best = 0; float bv = orc_h2f(row[0]);
-            for (size_t i = 1; i < V; i++) { float vv = orc_h2f(row[i]); if (vv > bv) { bv = vv; best = (int)i; } }
-            rc = best;
+            /* greedy = top-1 of GetSortedTopK (sampling_strategy.cc:281-297, 372-386): first maximum over the ids
+             * other than the unk id */
+            int best = -1; float bv = 0.0f;
+            for (size_t i = 0; i < V; i++) {
+                if ((int)i == m->cfg.unk_id) continue;
+                float vv = orc_h2f(row[i]);
+                if (best < 0 || vv > bv) { bv = vv; best = (int)i; }
+            }
+            rc = best < 0 ? 0 : best;
         } else rc = -10;
         if (!logits_out) free(lg);
     } else {
