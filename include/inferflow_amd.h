@@ -261,6 +261,36 @@ void *ifa_model_stream(ifa_model *m);
 /* run the worker on a caller-owned stream (e.g. the one the caller's RCCL collectives are ordered on) */
 int ifa_model_set_stream(ifa_model *m, ifa_stream stream);
 
+/* ======================================================================== */
+/* Collectives of the multi-GPU partitions (RCCL over xGMI; csrc/ifa_comm.hip) */
+/* -- what GpuInferenceWorker::DistributeAndMergeTensors / MergeTensors /     */
+/* DeviceCopy (src/transformer/inference_worker.cc:2148-2335) and             */
+/* GpuInfGlobalData (src/transformer/gpu_inf_global_data.cu:25-199) do with   */
+/* host-side spin-waits and serial copies.  Enqueue-only, explicit stream,    */
+/* capturable; one communicator per (rank, group).                            */
+/* ======================================================================== */
+typedef struct ifa_comm ifa_comm;
+#define IFA_COMM_ID_BYTES 128
+/* one process per GPU: rank 0 makes the id, ships the 128 bytes over any host channel, every rank joins */
+int ifa_comm_unique_id(void *id_out_128);
+int ifa_comm_init_rank(const void *id_128, int nranks, int rank, int device, ifa_comm **out);
+/* one process, one host thread per GPU (the engine facade, like inference_engine.cc:1203-1206): all ranks at once */
+int ifa_comm_init_all(const int *device_ids, int n, ifa_comm **comms_out);
+int ifa_comm_destroy(ifa_comm *c);
+int ifa_comm_rank(const ifa_comm *c);
+int ifa_comm_size(const ifa_comm *c);
+/* one host thread issuing the calls of several ranks brackets them with group_start / group_end */
+int ifa_comm_group_start(void);
+int ifa_comm_group_end(void);
+/* BY_TENSOR merge: element-wise sum of the ranks' partial [count] F16 vectors (in place allowed) */
+int ifa_allreduce_sum_f16(ifa_comm *c, const void *send_f16, void *recv_f16, size_t count, ifa_stream stream);
+/* recv = the ranks' `bytes_per_rank` blocks in rank order (distributed argmax over a vocabulary-sharded lm_head) */
+int ifa_allgather(ifa_comm *c, const void *send, void *recv, size_t bytes_per_rank, ifa_stream stream);
+int ifa_broadcast(ifa_comm *c, void *buf, size_t bytes, int root, ifa_stream stream);
+/* BY_LAYER hand-over of the [T][dim] F16 layer output between device groups (DeviceCopy, :2300-2335) */
+int ifa_send(ifa_comm *c, const void *buf, size_t bytes, int peer, ifa_stream stream);
+int ifa_recv(ifa_comm *c, void *buf, size_t bytes, int peer, ifa_stream stream);
+
 /* ---- tensor-parallel decode (BY_TENSOR partition, src/transformer/network_builder.cc:1594-1686):
  * the worker holds heads/tp_size heads, kv_heads/tp_size KV heads and ffn/tp_size FFN rows; the
  * caller sums the two partial [dim] F16 vectors per layer over the group exactly where the
@@ -288,6 +318,20 @@ int ifa_model_tp_ffn(ifa_model *m, int layer, void *partial_out_f16);
 int ifa_model_tp_post_ffn(ifa_model *m, int layer, const void *reduced_f16);
 int ifa_model_tp_logits(ifa_model *m, void *logits_shard_out_f16);
 int ifa_model_tp_set_token(ifa_model *m, const int *token_dev);
+/* The whole multi-GPU greedy decode from C: the segments above + the collectives of csrc/ifa_comm.hip on the worker's
+ * stream, a distributed argmax over the vocabulary-sharded lm_head, token / position fed back in device memory; the step
+ * is captured once as a hipGraph (tensor-parallel groups) and replayed per token.  Every rank calls it with the same
+ * arguments (one host thread or process per GPU).  out_tokens_host[n_steps]: the generated ids on every rank. */
+typedef struct {
+    ifa_comm *tp;          /* this worker's tensor-parallel group (NULL / size 1: nothing to merge) */
+    ifa_comm *world;       /* all ranks of the job: hand-over between layer groups + token broadcast (n_stages > 1) */
+    int stage, n_stages;   /* BY_LAYER / HYBRID: this worker's device group, number of groups (1 = BY_TENSOR only) */
+    int prev_rank, next_rank, token_src;   /* ranks in `world`; -1 = none */
+    int vocab_offset;      /* first vocabulary row of this rank's lm_head shard */
+    int force_collectives; /* issue the collectives even in a group of one (plumbing check on a 1-GPU box) */
+} ifa_tp_topology;
+int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_token, int start_pos, int n_steps,
+                        int *out_tokens_host, float *elapsed_ms);
 /* reference-layout copy of a loaded tensor (device pointer); returns 1 if the tensor is not set */
 int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols);
 /* Average duration (HIP events on the worker's stream) of `iters` back-to-back

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libinferflow_amd.so")
+# IFA_LIB: another build of the SAME library (tools/sweep_variants.py: one .so per tuning setting); tuning only
+_LIB_PATH = os.environ.get("IFA_LIB") or os.path.join(_HERE, "lib", "libinferflow_amd.so")
 _lib = None
 
 
@@ -109,6 +110,20 @@ SIGNATURES = {
     "ifa_model_tp_post_ffn": (_i, [_vp, _i, _vp]),
     "ifa_model_tp_logits": (_i, [_vp, _vp]),
     "ifa_model_tp_set_token": (_i, [_vp, _vp]),
+    "ifa_comm_unique_id": (_i, [_vp]),
+    "ifa_comm_init_rank": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
+    "ifa_comm_init_all": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "ifa_comm_destroy": (_i, [_vp]),
+    "ifa_comm_rank": (_i, [_vp]),
+    "ifa_comm_size": (_i, [_vp]),
+    "ifa_comm_group_start": (_i, []),
+    "ifa_comm_group_end": (_i, []),
+    "ifa_allreduce_sum_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "ifa_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "ifa_broadcast": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "ifa_send": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "ifa_recv": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "ifa_model_tp_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ifa_model_get_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
 }
 
@@ -159,5 +174,7 @@ def _declare(L):
             continue
         fn.restype = res
         fn.argtypes = args
+    if missing and os.environ.get("IFA_LIB"):
+        return      # a tuning build (tools/sweep_variants.py) may predate the newest entry points; bench.py does not call them
     if missing:
         raise ImportError("libinferflow_amd.so lacks symbols declared in include/*.h: %s" % missing)

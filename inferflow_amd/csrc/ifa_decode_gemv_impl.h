@@ -5,11 +5,43 @@
 
 namespace ifa {
 
+// Tuning overrides (tools/sweep_variants.py builds one library per setting): 0 = the table below
+#ifndef IFA_T_TH_QKV
+#define IFA_T_TH_QKV 0
+#endif
+#ifndef IFA_T_TH_WO
+#define IFA_T_TH_WO 0
+#endif
+#ifndef IFA_T_TH_GLU
+#define IFA_T_TH_GLU 0
+#endif
+#ifndef IFA_T_TH_W2
+#define IFA_T_TH_W2 0
+#endif
+#ifndef IFA_T_RW_QKV
+#define IFA_T_RW_QKV 0
+#endif
+#ifndef IFA_T_RW_WO
+#define IFA_T_RW_WO 0
+#endif
+#ifndef IFA_T_RW_GLU
+#define IFA_T_RW_GLU 0
+#endif
+#ifndef IFA_T_RW_W2
+#define IFA_T_RW_W2 0
+#endif
+
+// which of the four per-layer kernels a template instance is (by epilogue / prologue), for the overrides above
+constexpr int dec_role(int epi, int norm) { return epi == EPI_GLU ? 2 : (epi == EPI_RESIDUAL ? (norm == 2 ? 1 : 3) : (epi == EPI_PLAIN && norm == 1 ? 0 : -1)); }
+
 // rows (EPI_GLU: row pairs) a wave keeps in flight: bounded by registers, NM * RW * NJ * DW VGPRs
 template <int DT>
-constexpr int dec_rw(int nj, int nm, int th = DEC_THREADS)
+constexpr int dec_rw(int epi, int norm, int nj, int nm, int th = DEC_THREADS)
 {
     if (DT == Q4_B32T1A) {      // tuned on Llama-2-7B shapes (DESIGN.md "Kernel timeline")
+        const int role = dec_role(epi, norm);
+        const int forced = role == 0 ? IFA_T_RW_QKV : role == 1 ? IFA_T_RW_WO : role == 2 ? IFA_T_RW_GLU : role == 3 ? IFA_T_RW_W2 : 0;
+        if (forced > 0) return forced;
         constexpr int a[9] = {0, 6, 6, 4, 4, 2, 2, 2, 2}, b[9] = {0, 6, 6, 3, 2, 2, 1, 1, 1};
         const int rw = nm == 2 ? b[nj] : a[nj];
         return th > DEC_THREADS ? (rw + 1) / 2 : rw;       // 1024 threads: 128 registers per lane, half the rows per wave
@@ -23,7 +55,12 @@ constexpr int dec_rw(int nj, int nm, int th = DEC_THREADS)
 template <int DT>
 constexpr int dec_threads(int epi, int norm, int nj, bool xadd)
 {
-    return (DT == Q4_B32T1A && nj == 2 && !xadd && (epi == EPI_GLU || (epi == EPI_RESIDUAL && norm == 0))) ? 1024 : DEC_THREADS;
+    if (DT == Q4_B32T1A && !xadd) {
+        const int role = dec_role(epi, norm);
+        const int forced = role == 0 ? IFA_T_TH_QKV : role == 1 ? IFA_T_TH_WO : role == 2 ? IFA_T_TH_GLU : role == 3 ? IFA_T_TH_W2 : 0;
+        if (forced > 0) return forced;
+    }
+    return (DT == Q4_B32T1A && nj == 2 && !xadd && (epi == EPI_GLU || (epi == EPI_RESIDUAL && norm != 1))) ? 1024 : DEC_THREADS;
 }
 
 template <int DT, int EPI, int NORM, bool XADD = false>
@@ -45,7 +82,7 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
             const size_t smem_l = xlds_bytes(P.cols);
 #define IFA_DGL(NJV) \
     case NJV: if constexpr (NJV <= MJ) { \
-        constexpr int RWL = dec_rw<DT>(NJV, 1) >= 2 ? dec_rw<DT>(NJV, 1) / 2 : 1; \
+        constexpr int RWL = dec_rw<DT>(-1, 0, NJV, 1) >= 2 ? dec_rw<DT>(-1, 0, NJV, 1) / 2 : 1; \
         auto kern = k_dec_gemv_long<DT, NJV, RWL, EPI>; \
         if (smem_l > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l)); \
         kern<<<dim3((unsigned)wgs_l), dim3(DEC_THREADS), smem_l, s>>>(P); } break;
@@ -65,12 +102,12 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     const dim3 grid((unsigned)wgs);
     const size_t smem = xlds_bytes(P.cols);
     // inputs that are normalised or feed an activation are [dim] vectors (dim <= 8192): <= 4 blocks per lane of a B32 format
-    constexpr int NJCAP = (NORM != 0 || EPI == EPI_GLU || EPI == EPI_ACT || EPI == EPI_MOE_GLU || EPI == EPI_MOE_ACT) ? 4 : 8;
+    constexpr int NJCAP = (NORM == 1 || EPI == EPI_GLU || EPI == EPI_ACT || EPI == EPI_MOE_GLU || EPI == EPI_MOE_ACT) ? 4 : 8;
     if (nj > NJCAP) return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit for a normalised / gated input", P.cols);
 #define IFA_DG(NJV) \
     case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ && NJV <= NJCAP) { \
         constexpr int THV = dec_threads<DT>(EPI, NORM, NJV, XADD); \
-        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(NJV, NM, THV), EPI, NORM, XADD, THV>; \
+        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(EPI, NORM, NJV, NM, THV), EPI, NORM, XADD, THV>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         kern<<<grid, dim3(THV), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, P); } break;
     switch (nj) { IFA_DG(1) IFA_DG(2) IFA_DG(3) IFA_DG(4) IFA_DG(5) IFA_DG(6) IFA_DG(7) IFA_DG(8) }
@@ -91,6 +128,8 @@ int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu
     if (epi == EPI_PLAIN && norm == 1) return dec_gemv_launch_en<DT, EPI_PLAIN, 1>(P, wgs_per_cu, s);
     if (epi == EPI_PLAIN && norm == 0) return dec_gemv_launch_en<DT, EPI_PLAIN, 0>(P, wgs_per_cu, s);
     if (epi == EPI_RESIDUAL && norm == 0) return dec_gemv_launch_en<DT, EPI_RESIDUAL, 0>(P, wgs_per_cu, s);
+    if (epi == EPI_RESIDUAL && norm == 2) return dec_gemv_launch_en<DT, EPI_RESIDUAL, 2>(P, wgs_per_cu, s);
+    if (epi == EPI_PLAIN && norm == 2) return dec_gemv_launch_en<DT, EPI_PLAIN, 2>(P, wgs_per_cu, s);
     if (epi == EPI_GLU && norm == 1) return dec_gemv_launch_en<DT, EPI_GLU, 1>(P, wgs_per_cu, s);
     if (epi == EPI_ACT && norm == 1) return dec_gemv_launch_en<DT, EPI_ACT, 1>(P, wgs_per_cu, s);
     if (epi == EPI_GLU && norm == 0) return dec_gemv_launch_en<DT, EPI_GLU, 0>(P, wgs_per_cu, s);

@@ -34,16 +34,44 @@ namespace ifa {
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
-// q = roundf(v / qs) exactly as Tensor_QuantizeQ8_B32T2_Alg2_Kernel computes it, without
-// paying an IEEE division per element: t = v * (1/qs) is within a few ulp of v/qs, so
-// round-to-nearest of t equals roundf(v/qs) unless t sits within 2^-9 of a half-integer
-// (then the true division decides).  |v/qs| <= 127 so 2^-9 dwarfs the ~2^-16 error of t.
-__device__ __forceinline__ int q8_round_div(float v, float qs, float rqs)
+// q = roundf(v / qs) exactly as Tensor_QuantizeQ8_B32T2_Alg2_Kernel computes it (src/kernels/tensor_quant.h:61-81),
+// without paying an IEEE division per element: t = v * (1/qs) is within 1.5 ulp of the exact quotient and the fp32
+// quotient within 0.5 ulp, |v/qs| <= 127, so the two are less than 2^-15 apart and round-to-nearest of t equals
+// roundf(v/qs) unless t sits within 2^-14 of a half-integer; then the true division decides.  The slow path is ONE
+// copy of the eight divisions behind a flag (it is taken for ~0.1 % of the chunks): the previous form -- a branch with an
+// inlined division per element -- made the single-shot prologue the bulk of the kernel's code (40 divisions, 112 exec
+// branches in the Wo kernel) and ran the division for every fifth wave-instruction.
+__device__ __forceinline__ void q8_round_div8(const float (&v)[8], float qs, int (&q)[8])
 {
-    const float t = v * rqs;
-    const float k = __builtin_rintf(t);
-    if (__builtin_expect(fabsf(fabsf(t - k) - 0.5f) < 0.001953125f, 0)) return (int)roundf(v / qs);
-    return (int)k;
+    const float rqs = 1.0f / qs;
+    bool risky = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float t = v[i] * rqs;
+        const float k = __builtin_rintf(t);
+        risky |= fabsf(fabsf(t - k) - 0.5f) < 0.00006103515625f;
+        q[i] = (int)k;
+    }
+    if (__builtin_expect(risky, 0)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = (int)roundf(v[i] / qs);
+    }
+    if (qs <= 0.000001f) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = min(max(q[i], -128), 127);
+}
+
+// one value (attention epilogue: a lane per element)
+__device__ __forceinline__ int q8_round_div1(float v, float qs)
+{
+    if (qs <= 0.000001f) return 0;
+    const float t = v * (1.0f / qs);
+    float k = __builtin_rintf(t);
+    if (__builtin_expect(fabsf(fabsf(t - k) - 0.5f) < 0.00006103515625f, 0)) k = roundf(v / qs);
+    return min(max((int)k, -128), 127);
 }
 
 #ifndef IFA_NT_WEIGHTS
@@ -88,14 +116,31 @@ __device__ __forceinline__ XLds xlds_carve(char *smem, int cols)
     return l;
 }
 
-// Prologue shared by every decode GEMV kernel.  NORM: 0 none, 1 RMS.
+// Global image of a quantised activation left by the kernel that PRODUCED it (k_dec_attn for Wo): the same three
+// arrays as the LDS image -- int8 codes [cols], fp32 value of the fp16-rounded block scale [cols/32], code sums
+// [cols/32] -- so the consuming GEMV starts streaming at once instead of re-quantising the vector on every CU.
+struct XqImage {
+    int8_t *codes; float *scale; float *xsum;
+};
+__host__ __device__ inline size_t xq_image_bytes(int cols) { return (((size_t)cols + 15) / 16 * 16) + ((size_t)cols / 32) * 8 + 16; }
+__host__ __device__ inline XqImage xq_image_carve(void *base, int cols)
+{
+    XqImage q;
+    q.codes = reinterpret_cast<int8_t *>(base);
+    q.scale = reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (((size_t)cols + 15) / 16 * 16));
+    q.xsum = q.scale + cols / 32;
+    return q;
+}
+
+// Prologue shared by every decode GEMV kernel.  NORM: 0 none, 1 RMS (2: no prologue at all, the activation arrives
+// quantised in an XqImage).
 //   xn = NORM ? half(rms(x)) : x ;  Q8_B32T2 quantisation of xn exactly as
 //   Tensor_QuantizeQ8_B32T2_Alg2_Kernel (src/kernels/tensor_quant.h:44-82).
 // Split in two so that the activation loads are the FIRST memory operations of
 // the kernel (loads return in issue order per wave: issued after the weight
 // stream they would only arrive once that stream has drained).
 //   XPre pre; pre.issue(...);   ... issue weight loads ...;   pre.finish(...);
-// Must be executed by all DEC_THREADS threads.  cols % 32 == 0, cols <= 8*DEC_THREADS*MAXC.
+// Must be executed by all threads of the workgroup.  cols % 32 == 0, cols <= 8*blockDim*MAXC.
 // XADD: the activation is the sum x + (add [+ add_bias]) of two vectors (tensor parallelism: layer input + the
 // all-reduced product, bias once after the merge); the sum -- two half additions in TensorOpr::Add order -- replaces x
 // and workgroup 0 stores it for the residual that follows.
@@ -159,20 +204,24 @@ struct XPre {
         const int chunks = cols >> 3;
         float scale = 1.0f;
         if constexpr (NORM == 1) {
+            // sum of squares in the canonical order of ifa_math.h: chunk c = tid + k*blockDim is lane c % 64 of group
+            // c / 64 = wave + k * (blockDim / 64); no staging of x, one barrier
+            const int lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
 #pragma unroll
             for (int k = 0; k < MAXC; k++) {
                 const int c = tid + k * (int)blockDim.x;
-                if (c < chunks) *reinterpret_cast<half8_t *>(L.xh + (size_t)c * 8) = xv[k];
+                half8_t v8 = xv[k];
+                if (c >= chunks) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v8[i] = (half_t)0;
+                }
+                const float pg = wave_sum(rms_chunk_sq(v8));
+                if (lane == 0) L.part[wave + k * nwaves] = pg;
             }
             __syncthreads();
-            if (trc) trc[4] = wall_clock64();
-            if (tid < 128) L.part[tid] = rms_partial(L.xh, cols, tid, 128);
-            __syncthreads();
             if (trc) trc[5] = wall_clock64();
-            if (tid == 0) L.part[128] = rms_scale_from_partials(L.part, 128, cols, eps);
-            __syncthreads();
+            scale = rms_scale_of(rms_total(L.part, (chunks + 63) >> 6), cols, eps);
             if (trc) trc[6] = wall_clock64();
-            scale = L.part[128];
         } else {
             if (trc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
         }
@@ -206,14 +255,10 @@ struct XPre {
             mx = fmaxf(mx, dpp_xor1(mx));
             mx = fmaxf(mx, dpp_xor2(mx));
             const float qs = mx / 127;
-            const float rqs = 1.0f / qs;
             int q[8]; int s = 0;
+            q8_round_div8(v, qs, q);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int qq = qs <= 0.000001f ? 0 : q8_round_div(v[i], qs, rqs);
-                qq = min(max(qq, -128), 127);
-                q[i] = qq; s += qq;
-            }
+            for (int i = 0; i < 8; i++) s += q[i];
             s += dpp_xor1(s);
             s += dpp_xor2(s);
             u32x2 packed;
@@ -235,26 +280,27 @@ template <int NJ>
 struct XRegsQ4 {
     int xe[NJ][4], xo[NJ][4];
     float xs[NJ], xsf[NJ];
+    // unconditional reads with the block index clamped (LDS image, or the global image a producing kernel left: loads
+    // under an exec mask would make every later vmcnt wait a vmcnt(0)); blocks past the end are zeroed by selects
     __device__ __forceinline__ void load(const int8_t *codes, const float *scale, const float *xsum, int lane, int nblk, int blk0 = 0)
     {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int blk = blk0 + lane + 64 * j;
-            xs[j] = 0.0f; xsf[j] = 0.0f;
+            const bool ok = blk < nblk;
+            const int cb = ok ? blk : nblk - 1;
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(codes + (size_t)cb * 32);
+            const u32x4 b = *reinterpret_cast<const u32x4 *>(codes + (size_t)cb * 32 + 16);
+            const float sc = scale[cb], su = xsum[cb];
+            const uint32_t d[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
-            for (int w = 0; w < 4; w++) { xe[j][w] = 0; xo[j][w] = 0; }
-            if (blk < nblk) {
-                const u32x4 a = *reinterpret_cast<const u32x4 *>(codes + (size_t)blk * 32);
-                const u32x4 b = *reinterpret_cast<const u32x4 *>(codes + (size_t)blk * 32 + 16);
-                const uint32_t d[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    xe[j][w] = (int)__builtin_amdgcn_perm(d[2 * w + 1], d[2 * w], 0x06040200u);
-                    xo[j][w] = (int)__builtin_amdgcn_perm(d[2 * w + 1], d[2 * w], 0x07050301u);
-                }
-                xs[j] = scale[blk];
-                xsf[j] = xsum[blk];
+            for (int w = 0; w < 4; w++) {
+                const int e = (int)__builtin_amdgcn_perm(d[2 * w + 1], d[2 * w], 0x06040200u);
+                const int o = (int)__builtin_amdgcn_perm(d[2 * w + 1], d[2 * w], 0x07050301u);
+                xe[j][w] = ok ? e : 0; xo[j][w] = ok ? o : 0;
             }
+            xs[j] = ok ? sc : 0.0f;
+            xsf[j] = ok ? su : 0.0f;
         }
     }
 };
@@ -345,6 +391,7 @@ struct DecGemvParams {
     const half_t *residual2;   // optional second add (parallel-attn / shared-input models)
     const half_t *x_add, *x_add_bias;   // XADD kernels: activation = x + (x_add [+ x_add_bias]), stored to xsum_out
     half_t *xsum_out;
+    const int8_t *xq;          // NORM == 2: the activation already quantised by the producing kernel (xq_image layout)
     // mixture of experts: the weights of set 0 come from a device-side table indexed by the expert id the router
     // kernel chose for slot `moe_slot` (w_table[4*e + {0: w1, 1: w3, 2: w2}]); moe_w[slot] = its half weight
     const uint8_t *const *w_table;
@@ -390,14 +437,16 @@ __device__ __forceinline__ DecRow dec_locate(const DecGemvParams &P, int v)
 }
 
 // lane-local end of a row: bias, then the epilogue of the fused op sequence
+// res / res2: P.residual[row] / P.residual2[row], requested right behind the row's weights (EPI_RESIDUAL)
 template <int EPI>
-__device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const DecRow d, float a0, float a1)
+__device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const DecRow d, float a0, float a1, half_t res = (half_t)0,
+                                               half_t res2 = (half_t)0)
 {
     const int row = d.row;
     half_t y = dec_bias(a0, d.b0, row);
     if constexpr (EPI == EPI_RESIDUAL) {
-        y = f2h(h2f(P.residual[row]) + h2f(y));             // TensorOpr::Add (half add)
-        if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
+        y = f2h(h2f(res) + h2f(y));                         // TensorOpr::Add (half add)
+        if (P.residual2) y = f2h(h2f(y) + h2f(res2));
     } else if constexpr (EPI == EPI_GLU || EPI == EPI_MOE_GLU) {
         half_t t2 = dec_bias(a1, d.b1, row);
         half_t act = f2h(act_fn(h2f(y), P.act_kind));       // TensorOpr::Activation -> F16
@@ -437,10 +486,12 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     // the kernel's critical path -- do not wait for the first scalar load of the argument block
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the activation requests go out first, from preloaded arguments only (nothing here waits for a scalar load)
-    constexpr int MAXC = NORM ? 2 : 4;
-    XPre<NORM, MAXC, XADD> pre;
-    pre.issue(px, pnw, pnb, pcols);
-    if constexpr (XADD) pre.issue_add(P.x_add, P.x_add_bias, pcols);
+    constexpr int MAXC = NORM == 2 ? 1 : (NJ * 256 + TH - 1) / TH;      // cols <= 64 * 32 * NJ: chunks of 8 per thread
+    XPre<NORM == 2 ? 0 : NORM, MAXC, XADD> pre;
+    if constexpr (NORM != 2) {
+        pre.issue(px, pnw, pnb, pcols);
+        if constexpr (XADD) pre.issue_add(P.x_add, P.x_add_bias, pcols);
+    }
     const long long t_start = wall_clock64();
     const XLds L = xlds_carve(smem, pcols);
     const int lane = threadIdx.x & 63;
@@ -467,7 +518,11 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
 #pragma unroll
         for (int i = 0; i < RW; i++) {
             if (i < i0 || i >= i1) continue;
-            const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);   // clamped: rows past the end re-read the last row
+            // rows past the end: not requested at all (a wave-uniform, i.e. scalar, branch -- gw is an SGPR; only the
+            // first row of a pass is clamped so that every wave owns defined registers).  Clamped re-reads of the last
+            // row used to fill the CU's request window with duplicates: 2 of 3 requests of the Wo kernel, 10 % of W1/W3
+            if (i > 0 && (pass * RW + i) * W + gw >= P.total_rows) continue;
+            const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);
             const DecRow d = dec_locate(P, v);
             const uint8_t *W0 = epi_is_moe(EPI) ? moeW0 : d.W0;
             w[0][i].load(W0 + (size_t)d.row * row_bytes, P.nblk, lane);
@@ -475,12 +530,33 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         }
     };
     auto load_pass = [&](int pass) { load_rows(pass, 0, RW); };
+    // the residual value(s) lane i adds to row i of a pass are requested right behind that pass's weights (clamped,
+    // unconditional): issued from the epilogue they were a second memory round trip at the very end of the kernel
+    half_t res = (half_t)0, res2 = (half_t)0;
+    auto load_epi = [&](int pass) {
+        if constexpr (EPI == EPI_RESIDUAL) {
+            const int v = min((pass * RW + min(lane, RW - 1)) * W + gw, P.total_rows - 1);
+            const int row = dec_locate(P, v).row;
+            res = P.residual[row];
+            if (P.residual2) res2 = P.residual2[row];
+        }
+    };
     // rows requested BEFORE the cooperative prologue: what the CU's memory pipeline accepts
     // without blocking (~32-48 KiB per CU); a barrier behind blocked loads would only
     // release once the slowest wave's requests have been accepted, i.e. late in the stream
     constexpr int D1 = (NM * NJ * Fmt::DW >= 15) ? 1 : 2;
 
-    {
+    typename Fmt::X X;
+    if constexpr (NORM == 2) {
+        // the producing kernel left the quantised activation: a wave's requests are its slice of it, then its rows --
+        // no cooperative step, no barrier, no LDS
+        const XqImage Q = xq_image_carve(const_cast<int8_t *>(P.xq), pcols);
+        X.load(Q.codes, Q.scale, Q.xsum, lane, P.nblk);
+        load_rows(0, 0, RW);
+        load_epi(0);
+        if (tr) { P.trace[blockIdx.x * 8 + 1] = wall_clock64(); P.trace[blockIdx.x * 8 + 2] = wall_clock64(); }
+        if (gw >= P.total_rows) return;
+    } else {
         // the CU's memory queue is FIFO across waves: make sure every wave's activation
         // request is queued before ANY wave floods it with weight requests
         __syncthreads();
@@ -490,15 +566,15 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         pre.finish(P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out,
                    (P.trace != nullptr && threadIdx.x == 0) ? P.trace + blockIdx.x * 8 : nullptr);
         load_rows(0, D1, RW);
+        load_epi(0);
+        if (tr) P.trace[blockIdx.x * 8 + 2] = wall_clock64();
+        if (gw >= P.total_rows) return;
+        X.load(L.codes, L.scale, L.xsum, lane, P.nblk);
     }
-    if (tr) P.trace[blockIdx.x * 8 + 2] = wall_clock64();
-    if (gw >= P.total_rows) return;
-    typename Fmt::X X;
-    X.load(L.codes, L.scale, L.xsum, lane, P.nblk);
     if (tr) P.trace[blockIdx.x * 8 + 3] = wall_clock64();
 
     for (int pass = 0; pass < npass; pass++) {
-        if (pass > 0) load_pass(pass);
+        if (pass > 0) { load_pass(pass); load_epi(pass); }
         float a[NM][RW];
 #pragma unroll
         for (int i = 0; i < RW; i++)
@@ -516,7 +592,7 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         }
         const int v = (pass * RW + lane) * W + gw;
         if (lane < RW && v < P.total_rows) {
-            dec_finish_row<EPI>(P, dec_locate(P, v), a0, a1);
+            dec_finish_row<EPI>(P, dec_locate(P, v), a0, a1, res, res2);
         }
     }
     if (tr) P.trace[blockIdx.x * 8 + 7] = wall_clock64();
@@ -580,7 +656,12 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_gemv_long(const DecGemvPara
 #pragma unroll
         for (int i = 0; i < RW; i++) { if (lane == i) a0 = a[i]; a[i] = 0.0f; }
         const int v = (pass * RW + lane) * W + gw;
-        if (lane < RW && v < P.total_rows) dec_finish_row<EPI>(P, dec_locate(P, v), a0, 0.0f);
+        if (lane < RW && v < P.total_rows) {
+            const DecRow d = dec_locate(P, v);
+            half_t res = (half_t)0, res2 = (half_t)0;
+            if constexpr (EPI == EPI_RESIDUAL) { res = P.residual[d.row]; if (P.residual2) res2 = P.residual2[d.row]; }
+            dec_finish_row<EPI>(P, d, a0, 0.0f, res, res2);
+        }
     };
     for (int q = 0; q < Q; q += 2) {
         if (q + 1 < Q) load_q(wb, q + 1, 0, RW);
@@ -636,12 +717,20 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_f16(const DecLmHeadP
         *reinterpret_cast<half8_t *>(xn + (size_t)c * 8) = *reinterpret_cast<const half8_t *>(P.x + (size_t)c * 8);
     float scale = 1.0f;
     if constexpr (NORM == 1) {
+        // canonical sum of squares (ifa_math.h): a wave butterfly per 64 chunks, groups added in ascending order
+        const int ngroups = (chunks + 63) >> 6;
         __syncthreads();
-        if (tid < 128) part[tid] = rms_partial(xn, P.cols, tid, 128);
+        for (int g = tid >> 6; g < ngroups; g += DEC_WAVES) {
+            const int c = 64 * g + lane;
+            half8_t v8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v8[i] = (half_t)0;
+            if (c < chunks) v8 = *reinterpret_cast<const half8_t *>(xn + (size_t)c * 8);
+            const float pg = wave_sum(rms_chunk_sq(v8));
+            if (lane == 0) part[g] = pg;
+        }
         __syncthreads();
-        if (tid == 0) part[128] = rms_scale_from_partials(part, 128, P.cols, P.eps);
-        __syncthreads();
-        scale = part[128];
+        scale = rms_scale_of(rms_total(part, ngroups), P.cols, P.eps);
         for (int c = tid; c < chunks; c += DEC_THREADS) {
             half8_t xv = *reinterpret_cast<const half8_t *>(xn + (size_t)c * 8);
             half8_t wv, bv;
@@ -706,7 +795,28 @@ struct DecAttnParams {
     int alibi, alibi_base, alibi_total;
     half_t *out;               // [heads*head_dim]
     int max_ctx;
+    int8_t *xq;                // optional XqImage of `out` (Q8_B32T2, the quantiser the Wo GEMV would run in its prologue)
 };
+
+// Quantize(kqv_merged) (inference_worker.cc:1339-1346) done where the vector is produced: a head is HD/32 whole
+// Q8_B32T2 blocks, so the blocks are local to the head's workgroup and the codes are those of the Alg2 quantizer
+// (tensor_quant.h:44-82) bit for bit.  Called by threads [0, HD) of the workgroup of head h with their output value.
+template <int HD>
+__device__ __forceinline__ void dec_attn_emit_q8(int8_t *xq, int cols, int h, int d, half_t yh)
+{
+    const XqImage Q = xq_image_carve(xq, cols);
+    const float val = h2f(yh);
+    const float mx = half_wave_max(fabsf(val));
+    const float qs = mx / 127;
+    const int qv = q8_round_div1(val, qs);
+    const int sum = half_wave_sum_i32(qv);
+    Q.codes[(size_t)h * HD + d] = (int8_t)qv;
+    if ((d & 31) == 0) {
+        const int blk = (h * HD + d) >> 5;
+        Q.scale[blk] = h2f(f2h(qs));
+        Q.xsum[blk] = (float)sum;
+    }
+}
 
 // rotate one pair with a precomputed (cos, sin); same expressions as rope_rotate
 __device__ __forceinline__ void rope_apply(half_t *row, int col, float c, float s, int order, int rope_cols)
@@ -958,7 +1068,9 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     if (tid < HD) {
         float acc = opart[tid];
         for (int s2 = 1; s2 < NSPLIT; s2++) acc = acc + opart[s2 * HD + tid];
-        P.out[(size_t)h * HD + tid] = f2h(acc);
+        const half_t yh = f2h(acc);
+        P.out[(size_t)h * HD + tid] = yh;
+        if (P.xq) dec_attn_emit_q8<HD>(P.xq, P.heads * HD, h, tid, yh);
     }
 }
 
@@ -1151,14 +1263,16 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
 }
 
 template <int HD>
-__global__ void __launch_bounds__(HD) k_dec_attn_combine(const DecAttnSplitWs ws, half_t *__restrict__ out)
+__global__ void __launch_bounds__(HD) k_dec_attn_combine(const DecAttnSplitWs ws, half_t *__restrict__ out, int8_t *xq, int heads)
 {
     const int h = blockIdx.x, d = threadIdx.x;
     const float *p = ws.opart + (size_t)h * DEC_ATTN_SPLITS * HD + d;
     float acc = p[0];
 #pragma unroll
     for (int s2 = 1; s2 < DEC_ATTN_SPLITS; s2++) acc = acc + p[(size_t)s2 * HD];
-    out[(size_t)h * HD + d] = f2h(acc);
+    const half_t yh = f2h(acc);
+    out[(size_t)h * HD + d] = yh;
+    if (xq) dec_attn_emit_q8<HD>(xq, heads * HD, h, d, yh);
 }
 
 __host__ __device__ inline size_t dec_attn_pv_smem(int head_dim, int max_ctx)

@@ -105,6 +105,17 @@ __device__ __forceinline__ float half_wave_max(float v)
     return v;
 }
 
+// sum over each aligned group of 32 lanes (exact: integers)
+__device__ __forceinline__ int half_wave_sum_i32(int v)
+{
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_half_mirror(v);
+    v += dpp_mirror(v);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+
 // 8 half x 8 half products accumulated in fp32 (products of halfs are exact in fp32)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8v_t __attribute__((ext_vector_type(8)));

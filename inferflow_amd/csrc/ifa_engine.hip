@@ -57,6 +57,7 @@ struct ifa_model {
     half_t *x = nullptr, *x2 = nullptr, *xn = nullptr, *hn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
     half_t *att = nullptr, *a = nullptr, *f = nullptr, *t1 = nullptr, *t2 = nullptr, *logits = nullptr;
     uint8_t *xq = nullptr;
+    int8_t *attq = nullptr;        // XqImage of the attention output (Q8_B32T2), written by the fused attention kernels for the Wo GEMV
     half_t *moe_gate = nullptr, *moe_out = nullptr;   // MoE: router probabilities [T][experts], one expert's output rows
     half_t *moe_in = nullptr, *moe_wdev = nullptr;    // MoE: one expert's gathered input rows; per-row weights
     int *moe_route = nullptr;                          // device: fused decode routing, [0..7] expert ids, halfs at byte 32: weights
@@ -89,12 +90,21 @@ struct ifa_model {
     std::vector<KvSlot> slots;
     int cur_slot = 0;
     // options
+    int opt_attn_q8 = 1;
+    // multi-GPU decode driven from C (ifa_model_tp_decode): merge buffers, the distributed argmax's scratch, the captured step
+    half_t *tp_a = nullptr, *tp_f = nullptr, *tp_hid = nullptr, *tp_logits = nullptr;
+    float *tp_best = nullptr, *tp_gather = nullptr;
+    int *tp_tok = nullptr;
+    hipGraph_t tp_graph = nullptr;
+    hipGraphExec_t tp_graph_exec = nullptr;
     int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
     static constexpr int RING = 1024;
 };
 
 static void drop_graphs(ifa_model *m)
 {
+    if (m->tp_graph_exec) { (void)hipGraphExecDestroy(m->tp_graph_exec); m->tp_graph_exec = nullptr; }
+    if (m->tp_graph) { (void)hipGraphDestroy(m->tp_graph); m->tp_graph = nullptr; }
     if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
     if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
     for (auto &sl : m->slots) {
@@ -261,7 +271,7 @@ static int launch_attn(ifa_model *m, int l)
     A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale;
     A.rope_order = c.rope_order; A.rope_cols = rope_dims;
     A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
-    A.out = m->att; A.max_ctx = c.max_ctx;
+    A.out = m->att; A.max_ctx = c.max_ctx; A.xq = m->attq;
     if (m->attn_split) {
         const dim3 g2((unsigned)c.heads, DEC_ATTN_SPLITS);
         const size_t psmem = dec_attn_pv_smem(c.head_dim, c.max_ctx);
@@ -270,7 +280,7 @@ static int launch_attn(ifa_model *m, int l)
                              k_dec_attn_pv<HDV, true><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
               else { k_dec_attn_scores<HDV, false><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
                      k_dec_attn_pv<HDV, false><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
-              k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att); break;
+              k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att, m->attq, c.heads); break;
         switch (c.head_dim) {
             IFA_ATTN_S(32) IFA_ATTN_S(64) IFA_ATTN_S(128)
         default: return ifa_fail(IFA_ERR_ARG, "fused attention: head_dim %d", c.head_dim);
@@ -300,15 +310,22 @@ static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nul
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->att; P.cols = (int)L.t[T_WO].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
     P.W0[0] = (const uint8_t *)L.t[T_WO].tiled; P.rows[0] = (int)L.t[T_WO].rows; P.nsets = 1;
+    // the attention kernel left its output quantised (XqImage): the GEMV needs no prologue.  Rows longer than a lane's
+    // register image (chunked kernel) keep the in-kernel quantiser
+    const bool preq = m->attq && m->opt_attn_q8 && P.cols == m->cfg.heads * m->cfg.head_dim && dec_gemv_supported(L.t[T_WO].dtype, (size_t)P.cols);
+    if (preq) P.xq = m->attq;
     if (partial) {
         P.y[0] = partial;
-        return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
+        return preq ? launch_dec_gemv<EPI_PLAIN, 2>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream)
+                    : launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
     }
     P.b0[0] = (const half_t *)L.t[T_WO_B].data;
     P.y[0] = m->a; P.residual = x;
     if (m->cfg.parallel_attn || m->cfg.share_input)      // the residual is added once, after the FFN (inference_worker.cc:847-851)
-        return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
-    return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
+        return preq ? launch_dec_gemv<EPI_PLAIN, 2>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream)
+                    : launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
+    return preq ? launch_dec_gemv<EPI_RESIDUAL, 2>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream)
+                : launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
 }
 
 static void moe_params(ifa_model *m, Layer &L, DecGemvParams &P, int slot, int tab_off)
@@ -542,6 +559,7 @@ static int ensure_scratch(ifa_model *m, int T)
     }
     if (m->xq) IFA_HIP_CHECK(hipFree(m->xq));
     IFA_HIP_CHECK(hipMalloc((void **)&m->xq, (maxcols / 32 + 1) * 34));
+    if (!m->attq) IFA_HIP_CHECK(hipMalloc((void **)&m->attq, xq_image_bytes(c.heads * c.head_dim)));
     if (m->tokens_dev) IFA_HIP_CHECK(hipFree(m->tokens_dev));
     IFA_HIP_CHECK(hipMalloc((void **)&m->tokens_dev, sizeof(int) * (size_t)T));
     m->scratch_tokens = T;
@@ -1061,6 +1079,9 @@ int ifa_model_destroy(ifa_model *m)
     if (m->moe_pin) (void)hipHostFree(m->moe_pin);
     if (m->trace) (void)hipFree(m->trace);
     if (m->xq) (void)hipFree(m->xq);
+    if (m->attq) (void)hipFree(m->attq);
+    { void *tpb[] = {m->tp_a, m->tp_f, m->tp_hid, m->tp_logits, m->tp_best, m->tp_gather, m->tp_tok};
+      for (void *b : tpb) if (b) (void)hipFree(b); }
     if (m->state) (void)hipFree(m->state);
     if (m->rope_tab) (void)hipFree(m->rope_tab);
     if (m->tokens_dev) (void)hipFree(m->tokens_dev);
@@ -1231,7 +1252,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"tp_fuse_add", &m->opt_tp_fuse_add}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
@@ -1383,10 +1404,14 @@ __global__ void k_tp_set_state(int *state, int token, int pos)
 
 // the step's token (chosen across the group) becomes the next input; the position advances on the device
 // so that a captured step can be replayed (hipGraph) without the host
-__global__ void k_tp_set_token(int *state, const int *token)
+__global__ void k_tp_set_token(int *state, const int *token, int ring)
 {
-    state[0] = *token;
+    const int t = *token;
+    const int step = state[2];
+    state[8 + (step % ring)] = t;       // the launch batch's token ring, like k_dec_argmax_advance
+    state[0] = t;
     state[1] = state[1] + 1;
+    state[2] = step + 1;
 }
 
 static int tp_ready(ifa_model *m)
@@ -1535,8 +1560,169 @@ int ifa_model_tp_logits(ifa_model *m, void *logits_shard_out_f16)
 int ifa_model_tp_set_token(ifa_model *m, const int *token_dev)
 {
     IFA_REQUIRE(m && token_dev, "ifa_model_tp_set_token: bad arguments");
-    k_tp_set_token<<<1, 1, 0, m->stream>>>(m->state, token_dev);
+    k_tp_set_token<<<1, 1, 0, m->stream>>>(m->state, token_dev, ifa_model::RING);
     IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// ---- the whole multi-GPU decode step driven from C: worker segments + RCCL collectives (csrc/ifa_comm.hip) on the
+// worker's stream, the distributed greedy argmax over the vocabulary-sharded lm_head, token / position fed back in
+// device memory; captured once as a hipGraph and replayed per token (tensor-parallel groups; pipelines run eagerly).
+// (value, global id) of the best allowed logit of this rank's shard; first maximum wins
+__global__ void __launch_bounds__(1024) k_tp_local_best(const half_t *__restrict__ v, int n, int vocab_offset, const int *__restrict__ excl,
+                                                        float *__restrict__ best_out)
+{
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int ne = excl ? min(max(excl[0], 0), 3) : 0;
+    const int e0 = ne > 0 ? excl[1] : -1, e1 = ne > 1 ? excl[2] : -1, e2 = ne > 2 ? excl[3] : -1;
+    float best = -INFINITY; int besti = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int gid = vocab_offset + i;
+        if (gid == e0 || gid == e1 || gid == e2) continue;
+        const float f = h2f(v[i]);
+        if (f > best || (f == best && gid < besti)) { best = f; besti = gid; }
+    }
+#pragma unroll
+    for (int mk = 32; mk > 0; mk >>= 1) {
+        const float ob = __shfl_xor(best, mk); const int oi = __shfl_xor(besti, mk);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+            if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        best_out[0] = best;
+        reinterpret_cast<int *>(best_out)[1] = besti;
+    }
+}
+
+// the group's choice: highest value, lowest id among equals
+__global__ void k_tp_pick(const float *__restrict__ gathered, int nranks, int *__restrict__ token)
+{
+    if (threadIdx.x != 0) return;
+    float best = -INFINITY; int besti = 0x7FFFFFFF;
+    for (int r = 0; r < nranks; r++) {
+        const float f = gathered[2 * r];
+        const int gid = reinterpret_cast<const int *>(gathered)[2 * r + 1];
+        if (f > best || (f == best && gid < besti)) { best = f; besti = gid; }
+    }
+    *token = besti == 0x7FFFFFFF ? 0 : besti;
+}
+
+static int tp_buffers(ifa_model *m)
+{
+    if (m->tp_a) return IFA_OK;
+    const ifa_model_config &c = m->cfg;
+    const size_t D = (size_t)c.dim;
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_a, D * 2));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_f, D * 2));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_hid, D * 2));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_logits, std::max<size_t>(m->g[T_LM_HEAD].rows, 1) * 2));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_best, 8));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_gather, 8 * 64));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_tok, 4));
+    return IFA_OK;
+}
+
+static int tp_step(ifa_model *m, const ifa_tp_topology &t, int token, int pos)
+{
+    const ifa_model_config &c = m->cfg;
+    const size_t D = (size_t)c.dim;
+    ifa_stream s = (ifa_stream)m->stream;
+    const int tp_size = t.tp ? ifa_comm_size(t.tp) : 1;
+    const bool merge = t.tp && (tp_size > 1 || t.force_collectives);
+    int rc;
+    if (t.stage == 0) { if ((rc = ifa_model_tp_begin(m, token, pos))) return rc; }
+    else {
+        if ((rc = ifa_recv(t.world, m->tp_hid, D * 2, t.prev_rank, s))) return rc;
+        if ((rc = ifa_model_tp_begin_hidden(m, m->tp_hid, pos))) return rc;
+    }
+    for (int l = 0; l < c.layers; l++) {
+        if ((rc = ifa_model_tp_attn(m, l, m->tp_a))) return rc;
+        if (merge && (rc = ifa_allreduce_sum_f16(t.tp, m->tp_a, m->tp_a, D, s))) return rc;
+        if ((rc = ifa_model_tp_post_attn(m, l, m->tp_a))) return rc;
+        if ((rc = ifa_model_tp_ffn(m, l, m->tp_f))) return rc;
+        if (merge && (rc = ifa_allreduce_sum_f16(t.tp, m->tp_f, m->tp_f, D, s))) return rc;
+        if ((rc = ifa_model_tp_post_ffn(m, l, m->tp_f))) return rc;
+    }
+    if (t.n_stages > 1 && t.next_rank >= 0) {      // not the last group: hand the layer output on, then wait for the token
+        if ((rc = ifa_model_tp_hidden(m, m->tp_hid))) return rc;
+        if ((rc = ifa_send(t.world, m->tp_hid, D * 2, t.next_rank, s))) return rc;
+        if ((rc = ifa_broadcast(t.world, m->tp_tok, 4, t.token_src, s))) return rc;
+        return ifa_model_tp_set_token(m, m->tp_tok);
+    }
+    if ((rc = ifa_model_tp_logits(m, m->tp_logits))) return rc;
+    k_tp_local_best<<<1, 1024, 0, m->stream>>>(m->tp_logits, (int)m->g[T_LM_HEAD].rows, t.vocab_offset, m->state + 3, m->tp_best);
+    IFA_LAUNCH_CHECK();
+    const float *gathered = m->tp_best;
+    int n_g = 1;
+    if (merge) {
+        if ((rc = ifa_allgather(t.tp, m->tp_best, m->tp_gather, 8, s))) return rc;
+        gathered = m->tp_gather; n_g = tp_size;
+    }
+    k_tp_pick<<<1, 64, 0, m->stream>>>(gathered, n_g, m->tp_tok);
+    IFA_LAUNCH_CHECK();
+    if (t.n_stages > 1 && (rc = ifa_broadcast(t.world, m->tp_tok, 4, t.token_src, s))) return rc;
+    return ifa_model_tp_set_token(m, m->tp_tok);
+}
+
+int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_token, int start_pos, int n_steps,
+                        int *out_tokens_host, float *elapsed_ms)
+{
+    IFA_REQUIRE(m && topo && out_tokens_host, "ifa_model_tp_decode: null pointer");
+    IFA_REQUIRE(n_steps >= 1 && n_steps <= ifa_model::RING, "ifa_model_tp_decode: n_steps %d (1..%d)", n_steps, ifa_model::RING);
+    IFA_REQUIRE(start_pos >= 0 && start_pos + n_steps <= m->cfg.max_ctx, "ifa_model_tp_decode: positions %d..%d exceed max_ctx %d",
+                start_pos, start_pos + n_steps, m->cfg.max_ctx);
+    const ifa_tp_topology &t = *topo;
+    const int tp_size = t.tp ? ifa_comm_size(t.tp) : 1;
+    IFA_REQUIRE(tp_size <= 64, "ifa_model_tp_decode: group of %d ranks", tp_size);
+    IFA_REQUIRE(t.n_stages >= 1 && t.stage >= 0 && t.stage < t.n_stages, "ifa_model_tp_decode: stage %d of %d", t.stage, t.n_stages);
+    IFA_REQUIRE(t.n_stages == 1 || t.world, "ifa_model_tp_decode: layer groups need the job-wide communicator");
+    int rc = tp_ready(m);
+    if (rc) return rc;
+    if ((rc = tp_buffers(m))) return rc;
+    hipStream_t s = m->stream;
+    // the step counter restarts: the token ring of this call begins at state[8]
+    m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
+    IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
+    // step 0 runs eagerly: it creates whatever the collectives allocate lazily, so that the capture below records pure launches
+    if ((rc = tp_step(m, t, first_token, start_pos))) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (elapsed_ms) { IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1)); }
+    const bool use_graph = m->opt_graph && t.n_stages == 1 && n_steps > 1;
+    if (use_graph && !m->tp_graph_exec) {
+        IFA_HIP_CHECK(hipStreamSynchronize(s));
+        IFA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        rc = tp_step(m, t, -1, -1);
+        hipGraph_t gph = nullptr;
+        hipError_t e = hipStreamEndCapture(s, &gph);
+        if (rc || e != hipSuccess) {
+            if (gph) (void)hipGraphDestroy(gph);
+            (void)hipGetLastError();
+            m->tp_graph_exec = nullptr;      // eager steps below: correctness does not depend on the graph
+        } else {
+            m->tp_graph = gph;
+            if (hipGraphInstantiate(&m->tp_graph_exec, gph, nullptr, nullptr, 0) != hipSuccess) { m->tp_graph_exec = nullptr; (void)hipGetLastError(); }
+        }
+    }
+    if (e0) IFA_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 1; i < n_steps; i++) {
+        if (use_graph && m->tp_graph_exec) IFA_HIP_CHECK(hipGraphLaunch(m->tp_graph_exec, s));
+        else if ((rc = tp_step(m, t, -1, -1))) return rc;
+    }
+    if (e1) IFA_HIP_CHECK(hipEventRecord(e1, s));
+    IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n_steps, hipMemcpyDeviceToHost, s));
+    IFA_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < n_steps; i++) out_tokens_host[i] = m->host_pinned[8 + i];
+    if (elapsed_ms) {
+        float ms = 0.0f;
+        IFA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *elapsed_ms = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
     return IFA_OK;
 }
 

@@ -5,55 +5,34 @@
 
 namespace ifa {
 
-// Tensor_RmsNorm_Kernel (src/kernels/unary_tensor_opr.h:216-289): thread `tid`
-// of `nthreads` sums its contiguous chunk with `sum += (double)x*(double)x` on a
-// float accumulator.  For F16 inputs that is bit-identical to an fp32 fma chain:
-// x*x is exact in fp32 (11-bit significands), and the double-precision add of
-// two floats followed by rounding to float equals the correctly rounded fp32 add
-// (exact in double when the exponents are within 29 bits; otherwise the addend is
-// far below half an ulp and both round to the larger operand).  The oracle keeps
-// the double formulation; tests/ check the two agree bit for bit.
-__device__ __forceinline__ float rms_partial(const half_t *src, int cols, int tid, int nthreads)
+// RMS statistics.  Tensor_RmsNorm_Kernel (src/kernels/unary_tensor_opr.h:216-289) sums x*x over 128 strided per-thread
+// chunks and lets thread 0 add the 128 partials one after the other; the value is mean(x^2) in fp32 either way, only
+// the ORDER of the fp32 additions is the reference's launch geometry.  Every kernel here (op level, fused decode
+// prologues, lm_head) uses ONE order that needs no serial chain and no staging barrier -- so all paths stay bit-identical
+// to each other -- and the parity tests compare with the oracle's restated reference order within one half ulp of the
+// normalised value (tests/test_gpu_ops.py states the bound):
+//   p_c   = fma chain over the 8 elements of chunk c, ascending, from 0          (rms_chunk_sq)
+//   P_g   = wave butterfly sum of p_{64g} .. p_{64g+63}                           (wave_sum: lane = c % 64)
+//   total = ((0 + P_0) + P_1) + ...  ascending g                                  (rms_total)
+// Missing elements / chunks count as zeros (adding +0 is exact).
+typedef _Float16 rms_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float rms_chunk_sq(const rms_h8 v)
 {
-    const int x_len = (cols + nthreads - 1) / nthreads;
-    const int xs0 = tid * x_len, xe = min((tid + 1) * x_len, cols);
-    float sum = 0.0f;
-    if ((x_len & 7) == 0 && xe - xs0 == x_len && ((reinterpret_cast<uintptr_t>(src + xs0) & 15) == 0)) {          // vector loads first, then the ordered chain
-        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        for (int xi = xs0; xi < xe; xi += 8) {
-            const h8 v = *reinterpret_cast<const h8 *>(src + xi);
+    float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) sum = __builtin_fmaf((float)v[i], (float)v[i], sum);
-        }
-        return sum;
-    }
-    for (int xi = xs0; xi < xe; xi++) {
-        const float v = h2f(src[xi]);
-        sum = __builtin_fmaf(v, v, sum);
-    }
-    return sum;
+    for (int i = 0; i < 8; i++) s = __builtin_fmaf((float)v[i], (float)v[i], s);
+    return s;
 }
 
-__device__ __forceinline__ float rms_scale_from_partials(const float *part, int n, int cols, float eps)
+__device__ __forceinline__ float rms_total(const float *group_sums, int ngroups)
 {
-    // strictly ordered sum (thread 0 of the reference kernel); reads are issued in
-    // batches of 64 values so the LDS latency is paid twice, not once per element
     float total = 0.0f;
-    int i0 = 0;
-    if ((reinterpret_cast<uintptr_t>(part) & 15) == 0) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        for (; i0 + 64 <= n; i0 += 64) {
-            f4 buf[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) buf[i] = reinterpret_cast<const f4 *>(part + i0)[i];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                total = total + buf[i][0]; total = total + buf[i][1];
-                total = total + buf[i][2]; total = total + buf[i][3];
-            }
-        }
-    }
-    for (int i = i0; i < n; i++) total = total + part[i];
+    for (int g = 0; g < ngroups; g++) total = total + group_sums[g];
+    return total;
+}
+
+__device__ __forceinline__ float rms_scale_of(float total, int cols, float eps)
+{
     float mean = total / (float)cols;
     return 1.0f / sqrtf(mean + eps);
 }

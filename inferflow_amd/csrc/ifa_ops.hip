@@ -11,8 +11,8 @@ namespace ifa {
 
 // Tensor_RmsNorm_Kernel / Tensor_StdNorm_Kernel (src/kernels/unary_tensor_opr.h:216-289, :68-149),
 // launcher block (128,1), grid (1,rows) (src/tensor/tensor_opr.cu:511-520, :568-577).
-// Same partial-sum structure (128 partials, serial final sum) so the fp32 result
-// is bit-identical to the restated reference.
+// Std norm keeps the reference's partial-sum structure (128 partials, serial final sum); RMS uses the canonical order
+// of ifa_math.h shared with the fused decode prologues (no serial chain; <= 1 half ulp from the reference's order).
 template <int KIND>
 __global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x, int cols,
                                                    const half_t *__restrict__ w, const half_t *__restrict__ b,
@@ -50,11 +50,27 @@ __global__ void __launch_bounds__(128) k_layernorm(const half_t *__restrict__ x,
         src = row; staged = true;
     }
     if constexpr (KIND == 0) {
-        part[tid] = rms_partial(src, cols, tid, 128);
+        // the canonical order of ifa_math.h (chunk chains, wave butterfly per 64 chunks, ascending groups)
+        const int nchunks = (cols + 7) >> 3, ngroups = (nchunks + 63) >> 6;
+        const int wv_ = tid >> 6, ln_ = tid & 63;
+        for (int g = wv_; g < ngroups; g += 2) {
+            const int c = 64 * g + ln_;
+            rms_h8 v8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v8[e] = (half_t)0;
+            if (c < nchunks) {
+                const half_t *pc = src + (size_t)c * 8;
+                if (c * 8 + 8 <= cols && (reinterpret_cast<uintptr_t>(pc) & 15) == 0) v8 = *reinterpret_cast<const rms_h8 *>(pc);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) if (c * 8 + e < cols) v8[e] = pc[e];
+                }
+            }
+            const float pg = wave_sum(rms_chunk_sq(v8));
+            if (ln_ == 0) part[g] = pg;
+        }
         __syncthreads();
-        if (tid == 0) stat[0] = rms_scale_from_partials(part, 128, cols, eps);
-        __syncthreads();
-        const float scale = stat[0];
+        const float scale = rms_scale_of(rms_total(part, ngroups), cols, eps);
         if ((cols & 7) == 0) {       // element-wise: 16-byte accesses, chunks interleaved over the threads
             typedef _Float16 h8 __attribute__((ext_vector_type(8)));
             for (int c = tid; c < cols / 8; c += 128) {
@@ -400,6 +416,7 @@ int ifa_layernorm(int kind, const void *x, size_t rows, size_t cols, const void 
     IFA_REQUIRE(kind == 0 || kind == 1, "ifa_layernorm: kind %d", kind);
     IFA_REQUIRE(b == nullptr || w != nullptr, "ifa_layernorm: bias without weight");
     if (rows == 0 || cols == 0) return IFA_OK;
+    IFA_REQUIRE(cols <= 65536, "ifa_layernorm: %zu columns (limit 65536)", cols);
     if (kind == 0)
         k_layernorm<0><<<dim3((unsigned)rows), dim3(128), 0, ifa_s(stream)>>>((const half_t *)x, (int)cols, (const half_t *)w, (const half_t *)b, multi_base, eps, (half_t *)y);
     else

@@ -174,3 +174,64 @@ class DecodeWorker:
             self.close()
         except Exception:
             pass
+
+
+class TpTopology(C.Structure):
+    """ifa_tp_topology (include/inferflow_amd.h)"""
+    _fields_ = [("tp", C.c_void_p), ("world", C.c_void_p), ("stage", C.c_int), ("n_stages", C.c_int), ("prev_rank", C.c_int),
+                ("next_rank", C.c_int), ("token_src", C.c_int), ("vocab_offset", C.c_int), ("force_collectives", C.c_int)]
+
+
+class Comm:
+    """One rank's communicator of csrc/ifa_comm.hip (RCCL).  unique_id() on rank 0 -> ship the 128 bytes -> Comm(id, ...)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().ifa_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id, nranks, rank, device=0):
+        self._h = C.c_void_p()
+        self._id = C.create_string_buffer(bytes(unique_id), 128)
+        check(lib().ifa_comm_init_rank(self._id, int(nranks), int(rank), int(device), C.byref(self._h)))
+        self.rank, self.nranks = rank, nranks
+
+    def all_reduce_f16(self, t, stream=None):
+        check(lib().ifa_allreduce_sum_f16(self._h, C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(stream)))
+
+    def all_gather(self, src, dst, stream=None):
+        check(lib().ifa_allgather(self._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel() * src.element_size(), C.c_void_p(stream)))
+
+    def broadcast(self, t, root, stream=None):
+        check(lib().ifa_broadcast(self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), int(root), C.c_void_p(stream)))
+
+    def send(self, t, peer, stream=None):
+        check(lib().ifa_send(self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), int(peer), C.c_void_p(stream)))
+
+    def recv(self, t, peer, stream=None):
+        check(lib().ifa_recv(self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), int(peer), C.c_void_p(stream)))
+
+    def close(self):
+        if self._h:
+            lib().ifa_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tp_decode(worker, first_token, start_pos, n_steps, tp=None, world=None, stage=0, n_stages=1, prev_rank=-1, next_rank=-1,
+              token_src=0, vocab_offset=0, force_collectives=False):
+    """ifa_model_tp_decode: the whole multi-GPU greedy decode driven from C (segments + RCCL collectives + distributed
+    argmax, hipGraph per step).  Returns (tokens, gpu_ms of steps 1..n-1)."""
+    topo = TpTopology(tp._h if tp is not None else None, world._h if world is not None else None, stage, n_stages, prev_rank,
+                      next_rank, token_src, vocab_offset, 1 if force_collectives else 0)
+    out = np.zeros(n_steps, np.int32)
+    ms = C.c_float(0.0)
+    check(lib().ifa_model_tp_decode(worker._h, C.byref(topo), int(first_token), int(start_pos), int(n_steps),
+                                    out.ctypes.data_as(C.c_void_p), C.byref(ms)))
+    return out, ms.value

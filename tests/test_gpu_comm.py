@@ -1,0 +1,89 @@
+"""-m gpu: the collectives of the C ABI (csrc/ifa_comm.hip, RCCL) and the C-driven multi-GPU decode loop
+(ifa_model_tp_decode).  A 1-GPU box can only form a communicator of ONE rank (RCCL refuses two ranks on a device), which
+still runs every call through RCCL -- including inside the captured step; groups of 2+ ranks run where >= 2 GPUs are
+visible and skip cleanly otherwise.  The partition arithmetic of larger groups is covered on CPU (tests/test_tp_cpu.py)
+and with gloo ranks sharing one GPU (tests/test_gpu_tp.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from inferflow_amd import dtypes as dt, synth, tp
+from inferflow_amd import worker as W
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROMPT = np.array([5, 17, 400, 33, 2, 77], np.int32)
+
+
+def test_comm_of_one_rank_runs_every_collective():
+    c = W.Comm(W.Comm.unique_id(), 1, 0, 0)
+    assert c.nranks == 1
+    x = torch.randn(4096, device="cuda").half()
+    ref = x.clone()
+    c.all_reduce_f16(x)
+    g = torch.zeros(8, dtype=torch.uint8, device="cuda")
+    src = torch.arange(8, dtype=torch.uint8, device="cuda")
+    c.all_gather(src, g)
+    c.broadcast(x, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and torch.equal(g, src)
+    with pytest.raises(Exception):
+        c.send(x, 0)          # a rank cannot send to itself: argument error, not a hang
+    c.close()
+
+
+def test_c_driven_tp_decode_equals_fused_decode_and_python_runner():
+    """world = 1: the tensor-parallel shard IS the model, so the C-driven loop (segments + forced RCCL collectives + the
+    distributed argmax, captured as one hipGraph per step) must give the fused single-worker decode's tokens bit for bit."""
+    wk, _, s = synth.build("test_gqa", dt.Q4_B32T1A, dt.F16, max_ctx=48, quant_threshold=0, std=0.06)
+    tok = wk.forward(PROMPT, 0)
+    ref, _ = wk.decode(tok, len(PROMPT), 12)
+    c = W.Comm(W.Comm.unique_id(), 1, 0, 0)
+    wk.forward(PROMPT, 0)                                  # same KV prefix again
+    got, ms = W.tp_decode(wk, tok, len(PROMPT), 12, tp=c, force_collectives=True)
+    assert [int(t) for t in got] == [int(t) for t in ref] and ms > 0
+    wk.forward(PROMPT, 0)
+    got2, _ = W.tp_decode(wk, tok, len(PROMPT), 12)        # no communicator at all: plain segments
+    assert [int(t) for t in got2] == [int(t) for t in ref]
+    # excluded ids reach the distributed argmax too
+    wk.set_excluded_tokens([int(ref[0])])
+    wk.forward(PROMPT, 0)
+    got3, _ = W.tp_decode(wk, tok, len(PROMPT), 4, tp=c, force_collectives=True)
+    assert int(got3[0]) != int(ref[0])
+    wk.set_excluded_tokens([])
+    c.close(); wk.close()
+
+
+def _rank(rank, world, uid, q):
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(rank)
+    c = W.Comm(uid, world, rank, rank)
+    x = torch.full((4096,), float(rank + 1), device="cuda:%d" % rank).half()
+    c.all_reduce_f16(x)
+    h = torch.full((256,), float(rank), device="cuda:%d" % rank).half()
+    if rank == 0:
+        c.send(h, 1)
+    elif rank == 1:
+        c.recv(h, 0)
+    torch.cuda.synchronize()
+    q.put((rank, float(x[0].item()), float(h[0].item())))
+    c.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+def test_allreduce_and_send_recv_over_two_gpus():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = W.Comm.unique_id()
+    ps = [ctx.Process(target=_rank, args=(r, 2, uid, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert res[0][1] == 3.0 and res[1][1] == 3.0 and res[1][2] == 0.0
