@@ -332,6 +332,11 @@ typedef struct {
 } ifa_tp_topology;
 int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_token, int start_pos, int n_steps,
                         int *out_tokens_host, float *elapsed_ms);
+/* One Infer() step of a query over the partition: n_tokens new tokens at [start_pos, start_pos + n_tokens) fed through
+ * the decode path one after the other; *next_token_host = greedy next token of the last one (every rank).
+ * logits_shard_out_dev (nullable; last device group): this rank's lm_head rows of every token, [n_tokens][rows] F16. */
+int ifa_model_tp_prefill(ifa_model *m, const ifa_tp_topology *topo, const int *tokens_host, int n_tokens, int start_pos,
+                         void *logits_shard_out_dev, int *next_token_host);
 /* reference-layout copy of a loaded tensor (device pointer); returns 1 if the tensor is not set */
 int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols);
 /* Average duration (HIP events on the worker's stream) of `iters` back-to-back

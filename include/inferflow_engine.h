@@ -68,8 +68,18 @@ int ifa_engine_perplexity(ifa_engine *e, const int *tokens, int n_tokens, int ma
 double ifa_perplexity_token_nll(const uint16_t *logits_f16, int vocab, int token_id);
 
 /* facts of the loaded model: "vocab_size", "embd_dims", "hidden_dim", "decoder_layers", "decoder_heads",
- * "decoder_kv_heads", "max_context_len", "device_weight_data_type", "device_kv_cache_data_type"; -1 if unknown */
+ * "decoder_kv_heads", "max_context_len", "device_weight_data_type", "device_kv_cache_data_type", "partition_ranks"
+ * (workers of the multi-GPU partition; 1 = single device); -1 if unknown */
 int ifa_engine_model_info(ifa_engine *e, const char *key);
+
+/* host-only: the partition rules the engine applies to "devices = 0&1;2&3" (BY_TENSOR slices of
+ * network_builder.cc:1594-1686 / device_tensor_builder.cu:203-239, layer ranges of NetworkBuilder::SplitGpuLayers
+ * :2094-2118).  slice: 1 + {row0, row1, col0, col1, local layer} of tensor (layer, tensor_id) [rows][cols] for the worker
+ * at (stage, tp_rank), 0 if it holds none of it, -1 on bad arguments.  split_layers: number of groups written as
+ * (start, end) pairs. */
+int ifa_partition_slice(int stage, int n_stages, int tp_rank, int tp_size, int layer0, int layer1, int layer, int tensor_id,
+                        size_t rows, size_t cols, size_t *out5);
+int ifa_partition_split_layers(int n_layers, int n_groups, int *out_pairs, int capacity_pairs);
 
 #ifdef __cplusplus
 }

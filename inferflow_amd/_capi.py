@@ -124,6 +124,7 @@ SIGNATURES = {
     "ifa_send": (_i, [_vp, _vp, _sz, _i, _vp]),
     "ifa_recv": (_i, [_vp, _vp, _sz, _i, _vp]),
     "ifa_model_tp_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ifa_model_tp_prefill": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ifa_model_get_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
 }
 
@@ -149,6 +150,8 @@ ENGINE_SIGNATURES = {
     "ifa_engine_perplexity": (_i, [_vp, _ip, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ifa_perplexity_token_nll": (C.c_double, [_vp, _i, _i]),
     "ifa_engine_model_info": (_i, [_vp, C.c_char_p]),
+    "ifa_partition_slice": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _sz, _sz, C.POINTER(_sz)]),
+    "ifa_partition_split_layers": (_i, [_i, _i, _ip, _i]),
 }
 
 

@@ -42,6 +42,7 @@ constexpr int dec_rw(int epi, int norm, int nj, int nm, int th = DEC_THREADS)
         const int role = dec_role(epi, norm);
         const int forced = role == 0 ? IFA_T_RW_QKV : role == 1 ? IFA_T_RW_WO : role == 2 ? IFA_T_RW_GLU : role == 3 ? IFA_T_RW_W2 : 0;
         if (forced > 0) return forced;
+        if (norm == 2 && nj == 2 && nm == 1) return th > DEC_THREADS ? 1 : 2;    // Wo without a prologue: 16 rows per CU, all requested at once (sweep r02)
         constexpr int a[9] = {0, 6, 6, 4, 4, 2, 2, 2, 2}, b[9] = {0, 6, 6, 3, 2, 2, 1, 1, 1};
         const int rw = nm == 2 ? b[nj] : a[nj];
         return th > DEC_THREADS ? (rw + 1) / 2 : rw;       // 1024 threads: 128 registers per lane, half the rows per wave
@@ -60,7 +61,7 @@ constexpr int dec_threads(int epi, int norm, int nj, bool xadd)
         const int forced = role == 0 ? IFA_T_TH_QKV : role == 1 ? IFA_T_TH_WO : role == 2 ? IFA_T_TH_GLU : role == 3 ? IFA_T_TH_W2 : 0;
         if (forced > 0) return forced;
     }
-    return (DT == Q4_B32T1A && nj == 2 && !xadd && (epi == EPI_GLU || (epi == EPI_RESIDUAL && norm != 1))) ? 1024 : DEC_THREADS;
+    return (DT == Q4_B32T1A && nj == 2 && !xadd && (epi == EPI_GLU || (epi == EPI_RESIDUAL && norm == 0))) ? 1024 : DEC_THREADS;
 }
 
 template <int DT, int EPI, int NORM, bool XADD = false>

@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     // the kernel's critical path -- do not wait for the first scalar load of the argument block
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the activation requests go out first, from preloaded arguments only (nothing here waits for a scalar load)
-    constexpr int MAXC = NORM == 2 ? 1 : (NJ * 256 + TH - 1) / TH;      // cols <= 64 * 32 * NJ: chunks of 8 per thread
+    constexpr int MAXC = NORM == 2 ? 1 : (NJ * 8 * block_capacity(DT) + TH - 1) / TH;      // cols <= 64 * capacity * NJ: chunks of 8 per thread
     XPre<NORM == 2 ? 0 : NORM, MAXC, XADD> pre;
     if constexpr (NORM != 2) {
         pre.issue(px, pnw, pnb, pcols);
@@ -515,18 +515,28 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     }
     typename Fmt::W w[NM][RW];
     auto load_rows = [&](int pass, int i0, int i1) {
-#pragma unroll
-        for (int i = 0; i < RW; i++) {
-            if (i < i0 || i >= i1) continue;
-            // rows past the end: not requested at all (a wave-uniform, i.e. scalar, branch -- gw is an SGPR; only the
-            // first row of a pass is clamped so that every wave owns defined registers).  Clamped re-reads of the last
-            // row used to fill the CU's request window with duplicates: 2 of 3 requests of the Wo kernel, 10 % of W1/W3
-            if (i > 0 && (pass * RW + i) * W + gw >= P.total_rows) continue;
+        // rows past the end are not requested at all: clamped re-reads of the last row used to fill the CU's request
+        // window with duplicates (2 of 3 requests of the Wo kernel, 10 % of W1/W3).  `full` is wave-uniform (gw is an
+        // SGPR): a wave whose pass is complete -- every wave of most launches -- takes the straight-line path without
+        // per-row branches; only the first row of a pass is clamped, so that every wave owns defined registers
+        const bool full = (pass * RW + RW - 1) * W + gw < P.total_rows;
+        auto one = [&](int i) {
             const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);
             const DecRow d = dec_locate(P, v);
             const uint8_t *W0 = epi_is_moe(EPI) ? moeW0 : d.W0;
             w[0][i].load(W0 + (size_t)d.row * row_bytes, P.nblk, lane);
             if constexpr (NM == 2) { const uint8_t *W1 = epi_is_moe(EPI) ? moeW1 : d.W1; w[1][i].load(W1 + (size_t)d.row * row_bytes, P.nblk, lane); }
+        };
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < RW; i++) { if (i < i0 || i >= i1) continue; one(i); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RW; i++) {
+                if (i < i0 || i >= i1) continue;
+                if (i > 0 && (pass * RW + i) * W + gw >= P.total_rows) continue;
+                one(i);
+            }
         }
     };
     auto load_pass = [&](int pass) { load_rows(pass, 0, RW); };

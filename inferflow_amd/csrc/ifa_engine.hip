@@ -1235,6 +1235,9 @@ int ifa_model_select_kv(ifa_model *m, int slot)
     if (m->slots.empty()) m->slots.resize(1);
     IFA_REQUIRE(slot >= 0 && slot < (int)m->slots.size(), "ifa_model_select_kv: slot %d of %zu", slot, m->slots.size());
     if (slot == m->cur_slot) return IFA_OK;
+    // the captured multi-GPU step holds the outgoing slot's cache pointers
+    if (m->tp_graph_exec) { (void)hipGraphExecDestroy(m->tp_graph_exec); m->tp_graph_exec = nullptr; }
+    if (m->tp_graph) { (void)hipGraphDestroy(m->tp_graph); m->tp_graph = nullptr; }
     ifa_model::KvSlot &out = m->slots[(size_t)m->cur_slot], &in = m->slots[(size_t)slot];
     out.k.clear(); out.v.clear();
     for (Layer &L : m->layers) { out.k.push_back(L.kcache); out.v.push_back(L.vcache); }
@@ -1366,6 +1369,7 @@ int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr,
     const ifa_model_config &c = m->cfg;
     size_t b = 0; void *p = nullptr;
     if (!strcmp(name, "logits")) { p = m->logits; b = (size_t)c.vocab * 2; }
+    else if (!strcmp(name, "tp_logits")) { p = m->tp_logits; b = m->tp_logits ? m->g[T_LM_HEAD].rows * 2 : 0; }
     else if (!strcmp(name, "trace")) { p = m->trace; b = m->trace ? sizeof(long long) * 2048 * 8 : 0; }
     else if (!strcmp(name, "hidden")) { p = m->xn; b = (size_t)c.dim * 2; }
     else if (!strcmp(name, "kcache") || !strcmp(name, "vcache")) {
@@ -1627,7 +1631,8 @@ static int tp_buffers(ifa_model *m)
     return IFA_OK;
 }
 
-static int tp_step(ifa_model *m, const ifa_tp_topology &t, int token, int pos)
+// want_token = false (all but the last token of a prompt): the layers run, the lm_head / argmax / token exchange do not
+static int tp_step(ifa_model *m, const ifa_tp_topology &t, int token, int pos, bool want_token = true, void *logits_copy = nullptr)
 {
     const ifa_model_config &c = m->cfg;
     const size_t D = (size_t)c.dim;
@@ -1651,10 +1656,14 @@ static int tp_step(ifa_model *m, const ifa_tp_topology &t, int token, int pos)
     if (t.n_stages > 1 && t.next_rank >= 0) {      // not the last group: hand the layer output on, then wait for the token
         if ((rc = ifa_model_tp_hidden(m, m->tp_hid))) return rc;
         if ((rc = ifa_send(t.world, m->tp_hid, D * 2, t.next_rank, s))) return rc;
+        if (!want_token) return IFA_OK;
         if ((rc = ifa_broadcast(t.world, m->tp_tok, 4, t.token_src, s))) return rc;
         return ifa_model_tp_set_token(m, m->tp_tok);
     }
+    if (!want_token && !logits_copy) { m->pend.on = false; return IFA_OK; }     // (the pending seam sum of the last layer is not needed)
     if ((rc = ifa_model_tp_logits(m, m->tp_logits))) return rc;
+    if (logits_copy) IFA_HIP_CHECK(hipMemcpyAsync(logits_copy, m->tp_logits, m->g[T_LM_HEAD].rows * 2, hipMemcpyDeviceToDevice, m->stream));
+    if (!want_token) return IFA_OK;
     k_tp_local_best<<<1, 1024, 0, m->stream>>>(m->tp_logits, (int)m->g[T_LM_HEAD].rows, t.vocab_offset, m->state + 3, m->tp_best);
     IFA_LAUNCH_CHECK();
     const float *gathered = m->tp_best;
@@ -1669,47 +1678,84 @@ static int tp_step(ifa_model *m, const ifa_tp_topology &t, int token, int pos)
     return ifa_model_tp_set_token(m, m->tp_tok);
 }
 
+static int tp_check(ifa_model *m, const ifa_tp_topology *topo, const char *who)
+{
+    IFA_REQUIRE(m && topo, "%s: null pointer", who);
+    const ifa_tp_topology &t = *topo;
+    const int tp_size = t.tp ? ifa_comm_size(t.tp) : 1;
+    IFA_REQUIRE(tp_size <= 64, "%s: group of %d ranks", who, tp_size);
+    IFA_REQUIRE(t.n_stages >= 1 && t.stage >= 0 && t.stage < t.n_stages, "%s: stage %d of %d", who, t.stage, t.n_stages);
+    IFA_REQUIRE(t.n_stages == 1 || t.world, "%s: layer groups need the job-wide communicator", who);
+    int rc = tp_ready(m);
+    if (rc) return rc;
+    return tp_buffers(m);
+}
+
+// One Infer() step of a query over the partition: n_tokens new tokens at positions [start_pos, start_pos + n_tokens),
+// fed through the decode path one after the other (the merges are [dim] vectors); the greedy next token of the last
+// one comes back on every rank.  logits_shard_out_dev (nullable, last device group): this rank's lm_head rows of every
+// token, [n_tokens][shard rows] F16 (return_output_tensors).
+int ifa_model_tp_prefill(ifa_model *m, const ifa_tp_topology *topo, const int *tokens_host, int n_tokens, int start_pos,
+                         void *logits_shard_out_dev, int *next_token_host)
+{
+    IFA_REQUIRE(tokens_host && n_tokens >= 1, "ifa_model_tp_prefill: no tokens");
+    int rc = tp_check(m, topo, "ifa_model_tp_prefill");
+    if (rc) return rc;
+    IFA_REQUIRE(start_pos >= 0 && start_pos + n_tokens <= m->cfg.max_ctx, "ifa_model_tp_prefill: positions %d..%d exceed max_ctx %d",
+                start_pos, start_pos + n_tokens, m->cfg.max_ctx);
+    const size_t shard = m->g[T_LM_HEAD].present() ? m->g[T_LM_HEAD].rows * 2 : 0;
+    m->host_pinned[0] = tokens_host[0]; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
+    IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    for (int i = 0; i < n_tokens; i++) {
+        void *lg = (logits_shard_out_dev && shard) ? (char *)logits_shard_out_dev + (size_t)i * shard : nullptr;
+        if ((rc = tp_step(m, *topo, tokens_host[i], start_pos + i, i + 1 == n_tokens, lg))) return rc;
+    }
+    IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 4, m->tp_tok, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (next_token_host) *next_token_host = m->host_pinned[4];
+    return IFA_OK;
+}
+
 int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_token, int start_pos, int n_steps,
                         int *out_tokens_host, float *elapsed_ms)
 {
-    IFA_REQUIRE(m && topo && out_tokens_host, "ifa_model_tp_decode: null pointer");
+    IFA_REQUIRE(out_tokens_host, "ifa_model_tp_decode: null pointer");
     IFA_REQUIRE(n_steps >= 1 && n_steps <= ifa_model::RING, "ifa_model_tp_decode: n_steps %d (1..%d)", n_steps, ifa_model::RING);
+    int rc = tp_check(m, topo, "ifa_model_tp_decode");
+    if (rc) return rc;
     IFA_REQUIRE(start_pos >= 0 && start_pos + n_steps <= m->cfg.max_ctx, "ifa_model_tp_decode: positions %d..%d exceed max_ctx %d",
                 start_pos, start_pos + n_steps, m->cfg.max_ctx);
     const ifa_tp_topology &t = *topo;
-    const int tp_size = t.tp ? ifa_comm_size(t.tp) : 1;
-    IFA_REQUIRE(tp_size <= 64, "ifa_model_tp_decode: group of %d ranks", tp_size);
-    IFA_REQUIRE(t.n_stages >= 1 && t.stage >= 0 && t.stage < t.n_stages, "ifa_model_tp_decode: stage %d of %d", t.stage, t.n_stages);
-    IFA_REQUIRE(t.n_stages == 1 || t.world, "ifa_model_tp_decode: layer groups need the job-wide communicator");
-    int rc = tp_ready(m);
-    if (rc) return rc;
-    if ((rc = tp_buffers(m))) return rc;
     hipStream_t s = m->stream;
     // the step counter restarts: the token ring of this call begins at state[8]
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
-    // step 0 runs eagerly: it creates whatever the collectives allocate lazily, so that the capture below records pure launches
-    if ((rc = tp_step(m, t, first_token, start_pos))) return rc;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (elapsed_ms) { IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1)); }
-    const bool use_graph = m->opt_graph && t.n_stages == 1 && n_steps > 1;
-    if (use_graph && !m->tp_graph_exec) {
-        IFA_HIP_CHECK(hipStreamSynchronize(s));
-        IFA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        rc = tp_step(m, t, -1, -1);
-        hipGraph_t gph = nullptr;
-        hipError_t e = hipStreamEndCapture(s, &gph);
-        if (rc || e != hipSuccess) {
-            if (gph) (void)hipGraphDestroy(gph);
-            (void)hipGetLastError();
-            m->tp_graph_exec = nullptr;      // eager steps below: correctness does not depend on the graph
-        } else {
-            m->tp_graph = gph;
-            if (hipGraphInstantiate(&m->tp_graph_exec, gph, nullptr, nullptr, 0) != hipSuccess) { m->tp_graph_exec = nullptr; (void)hipGetLastError(); }
+    const bool use_graph = m->opt_graph && t.n_stages == 1;
+    int done = 0;
+    if (!(use_graph && m->tp_graph_exec)) {
+        // the first step runs eagerly: it creates whatever the collectives allocate lazily, so that the capture below
+        // records pure launches
+        if ((rc = tp_step(m, t, first_token, start_pos))) return rc;
+        done = 1;
+        if (use_graph) {
+            IFA_HIP_CHECK(hipStreamSynchronize(s));
+            IFA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = tp_step(m, t, -1, -1);
+            hipGraph_t gph = nullptr;
+            hipError_t e = hipStreamEndCapture(s, &gph);
+            if (rc || e != hipSuccess) {
+                if (gph) (void)hipGraphDestroy(gph);
+                (void)hipGetLastError();
+                m->tp_graph_exec = nullptr;      // eager steps below: correctness does not depend on the graph
+            } else {
+                m->tp_graph = gph;
+                if (hipGraphInstantiate(&m->tp_graph_exec, gph, nullptr, nullptr, 0) != hipSuccess) { m->tp_graph_exec = nullptr; (void)hipGetLastError(); }
+            }
         }
     }
-    if (e0) IFA_HIP_CHECK(hipEventRecord(e0, s));
-    for (int i = 1; i < n_steps; i++) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (elapsed_ms) { IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1)); IFA_HIP_CHECK(hipEventRecord(e0, s)); }
+    for (int i = done; i < n_steps; i++) {
         if (use_graph && m->tp_graph_exec) IFA_HIP_CHECK(hipGraphLaunch(m->tp_graph_exec, s));
         else if ((rc = tp_step(m, t, -1, -1))) return rc;
     }

@@ -183,7 +183,30 @@ int ifa_engine_model_info(ifa_engine *e, const char *key)
     if (k == "max_context_len") return s.max_context_len > 0 ? s.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
     if (k == "device_weight_data_type") return s.device_weight_data_type;
     if (k == "device_kv_cache_data_type") return s.device_kv_cache_data_type;
+    if (k == "partition_ranks") return e->engine.PartitionRanks();
     return -1;
+}
+
+// host-only: the partition rules of the multi-GPU engine (model_loader.cc) for tests and tools
+int ifa_partition_slice(int stage, int n_stages, int tp_rank, int tp_size, int layer0, int layer1, int layer, int tensor_id,
+                        size_t rows, size_t cols, size_t *out5)
+{
+    if (!out5) return -1;
+    WorkerPlan w; w.stage = stage; w.n_stages = n_stages; w.tp_rank = tp_rank; w.tp_size = tp_size; w.layer0 = layer0; w.layer1 = layer1;
+    w.first_stage = stage == 0; w.last_stage = stage + 1 == n_stages;
+    TensorSlice sl;
+    if (!SliceForWorker(w, layer, tensor_id, rows, cols, sl)) return 0;
+    out5[0] = sl.row0; out5[1] = sl.row1; out5[2] = sl.col0; out5[3] = sl.col1; out5[4] = (size_t)sl.local_layer;
+    return 1;
+}
+
+int ifa_partition_split_layers(int n_layers, int n_groups, int *out_pairs, int capacity_pairs)
+{
+    if (!out_pairs || n_groups < 1) return -1;
+    std::vector<std::pair<int, int>> r;
+    SplitGpuLayers(n_layers, n_groups, r);
+    for (size_t i = 0; i < r.size() && (int)i < capacity_pairs; i++) { out_pairs[2 * i] = r[i].first; out_pairs[2 * i + 1] = r[i].second; }
+    return (int)r.size();
 }
 
 } // extern "C"

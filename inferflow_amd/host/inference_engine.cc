@@ -5,7 +5,11 @@
 // picks one and commits it with CommitInferenceResult (llm_inference.cc:345-457).
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #include "inferflow_amd.h"
 #include "inference_engine.h"
@@ -13,11 +17,88 @@
 
 namespace inferflow_amd {
 
+// ---------------------------------------------------------------------------------------------- multi-GPU partitions
+// One worker (ifa_model) and one persistent host thread per GPU.  The reference creates and joins a thread per GPU inside
+// every Infer() (inference_engine.cc:1203-1206, 1261-1283) and lets the workers rendezvous through GpuInfGlobalData's
+// mutex; here the threads live as long as the engine and every exchange is a collective of the C ABI enqueued on the
+// worker's stream (csrc/ifa_comm.hip), so a thread only ever blocks at the end of its step.
+struct InferenceEngine::MultiGpu {
+    std::vector<WorkerPlan> plans;
+    std::vector<ifa_comm *> world, tp;          // per rank (world: only with several device groups; tp: only with groups of > 1)
+    std::vector<ifa_tp_topology> topo;
+    std::vector<void *> shard_dev;              // per rank: logits shard buffer [rows][V / P] (last group only)
+    size_t shard_rows = 0;
+    int G = 1, P = 1;
+    bool force_collectives = false;
+    // thread pool
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<int(int)> job;
+    uint64_t generation = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<std::string> errors;
+
+    void Start()
+    {
+        const int n = (int)plans.size();
+        errors.assign((size_t)n, std::string());
+        for (int r = 0; r < n; r++)
+            threads.emplace_back([this, r]() {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::function<int(int)> fn;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_job.wait(lk, [&] { return stop || generation != seen; });
+                        if (stop) return;
+                        seen = generation; fn = job;
+                    }
+                    const int rc = fn(r);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        errors[(size_t)r] = rc == 0 ? std::string() : std::string(ifa_last_error());   // (thread-local message)
+                        if (rc != 0 && errors[(size_t)r].empty()) errors[(size_t)r] = "error " + std::to_string(rc);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    // fn(rank) on every rank's thread at once; false + message if any failed
+    bool Run(const std::function<int(int)> &fn, const char *what)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = fn; pending = (int)plans.size(); generation++;
+        }
+        cv_job.notify_all();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        for (size_t r = 0; r < errors.size(); r++)
+            if (!errors[r].empty()) { EngineSetError("%s failed on rank %zu (device %d): %s", what, r, plans[r].device, errors[r].c_str()); return false; }
+        return true;
+    }
+    ~MultiGpu()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_job.notify_all();
+        for (std::thread &t : threads) if (t.joinable()) t.join();
+        for (size_t r = 0; r < plans.size(); r++) {
+            if (r < shard_dev.size() && shard_dev[r]) { ifa_set_device(plans[r].device); ifa_free(shard_dev[r]); }
+            if (plans[r].model) ifa_model_destroy(plans[r].model);
+        }
+        for (ifa_comm *c : tp) if (c) ifa_comm_destroy(c);
+        for (ifa_comm *c : world) if (c) ifa_comm_destroy(c);
+    }
+};
+
 InferenceEngine::InferenceEngine() {}
 InferenceEngine::~InferenceEngine() { Clear(); }
 
 void InferenceEngine::Clear()
 {
+    if (multi_) { delete multi_; multi_ = nullptr; model_ = nullptr; }
     if (model_) { ifa_model_destroy(model_); model_ = nullptr; }
     if (logits_dev_) { ifa_free(logits_dev_); logits_dev_ = nullptr; logits_rows_ = 0; }
     queries_.clear();
@@ -112,6 +193,7 @@ bool InferenceEngine::LoadConfig(InferenceConfig &config, const std::string &con
     cfg.GetItem(section, "cpu_threads", config.cpu_threads);
     cfg.GetItem(section, "return_output_tensors", config.return_output_tensors);
     cfg.GetItem(section, "dynamic_batching_min_queries", config.dynamic_batching_min_queries);
+    cfg.GetItem(section, "force_partition_path", config.force_partition_path);
     cfg.GetItem(section, "is_study_mode", config.debug.is_study_mode);
     cfg.GetItem(section, "show_tensors", config.debug.show_tensors);
     return true;
@@ -126,11 +208,11 @@ bool InferenceEngine::Init(const InferenceConfig &cfg)
     spec_ = cfg.models[0];
     if (cfg.decoder_cpu_layer_count > 0) { EngineSetError("decoder_cpu_layer_count > 0: CPU layers are outside this engine"); return false; }
     const auto &groups = spec_.device_groups.empty() ? cfg.device_groups : spec_.device_groups;
-    if (groups.size() > 1 || (!groups.empty() && groups[0].size() > 1)) {
-        EngineSetError("multi-GPU partitions run one process per GPU (python -m torch.distributed.run ... inferflow_amd.tp); "
-                       "this engine instance takes one device"); return false;
-    }
+    const bool multi = groups.size() > 1 || (!groups.empty() && groups[0].size() > 1) || cfg.force_partition_path;
     device_ = groups.empty() || groups[0].empty() ? 0 : groups[0][0];
+    for (const auto &g : groups)
+        for (int d : g)
+            if (d < 0 || d >= ifa_device_count()) { EngineSetError("device %d is not available (%d visible)", d, ifa_device_count()); return false; }
     if (device_ < 0 || device_ >= ifa_device_count()) { EngineSetError("device %d is not available (%d visible)", device_, ifa_device_count()); return false; }
     default_strategy_ = SamplingStrategyId::Greedy; default_sampling_ = StdSamplingConfig();
     if (!spec_.decoding_strategy.empty()) {
@@ -139,18 +221,126 @@ bool InferenceEngine::Init(const InferenceConfig &cfg)
         if (sid != SamplingStrategyId::Auto) default_strategy_ = sid;
         if (!IsSupportedStrategy(default_strategy_)) { EngineSetError("decoding_strategy \"%s\" of model %s is not supported", spec_.decoding_strategy.c_str(), spec_.sid.c_str()); return false; }
     }
-    if (!BuildWorker(&model_, spec_, device_)) return false;
+    if (multi) {
+        std::vector<std::vector<int>> gs = groups;
+        if (gs.empty()) gs.push_back({device_});
+        if (!InitMulti(gs)) { Clear(); return false; }
+    } else if (!BuildWorker(&model_, spec_, device_)) return false;
     {   // the ids greedy / sampled selection never offers (GetSortedTopK): device argmax and host pool alike
         std::vector<int> excl;
         if (spec_.unk_token_id >= 0 && spec_.unk_token_id < spec_.hyper_params.vocab_size) excl.push_back(spec_.unk_token_id);
         for (int id : spec_.invalid_token_ids)
             if (id >= 0 && id < spec_.hyper_params.vocab_size && excl.size() < 3 && std::find(excl.begin(), excl.end(), id) == excl.end()) excl.push_back(id);
         default_sampling_.excluded_ids = excl;
-        if (ifa_model_set_excluded_tokens(model_, excl.data(), (int)excl.size()) != IFA_OK) { EngineSetError("excluded tokens: %s", ifa_last_error()); Clear(); return false; }
+        std::vector<ifa_model *> all;
+        if (multi_) for (WorkerPlan &w : multi_->plans) all.push_back(w.model); else all.push_back(model_);
+        for (ifa_model *mm : all)
+            if (ifa_model_set_excluded_tokens(mm, excl.data(), (int)excl.size()) != IFA_OK) { EngineSetError("excluded tokens: %s", ifa_last_error()); Clear(); return false; }
     }
     // one KV cache per concurrent query, like the reference's per-query LayerKVCache sets
     kv_slots_ = std::max(1, std::min(config_.max_concurrent_queries, 64));
-    if (ifa_model_kv_slots(model_, kv_slots_) != IFA_OK) { EngineSetError("KV caches for %d queries: %s", kv_slots_, ifa_last_error()); Clear(); return false; }
+    {
+        std::vector<ifa_model *> all;
+        if (multi_) for (WorkerPlan &w : multi_->plans) all.push_back(w.model); else all.push_back(model_);
+        for (ifa_model *mm : all)
+            if (ifa_model_kv_slots(mm, kv_slots_) != IFA_OK) { EngineSetError("KV caches for %d queries: %s", kv_slots_, ifa_last_error()); Clear(); return false; }
+    }
+    return true;
+}
+
+// devices = G groups of P: workers in the reference's order (rank = group * P + position), layer ranges by
+// SplitGpuLayers, BY_TENSOR slices inside a group (model_loader.cc), one communicator per group + one for the job
+bool InferenceEngine::InitMulti(const std::vector<std::vector<int>> &groups)
+{
+    const int G = (int)groups.size(), P = (int)groups[0].size();
+    if (P < 1) { EngineSetError("empty device group"); return false; }
+    multi_ = new MultiGpu();
+    MultiGpu &M = *multi_;
+    M.G = G; M.P = P; M.force_collectives = config_.force_partition_path;
+    std::vector<int> all_devices;
+    for (int g = 0; g < G; g++)
+        for (int r = 0; r < P; r++) {
+            WorkerPlan w;
+            w.device = groups[(size_t)g][(size_t)r]; w.stage = g; w.n_stages = G; w.tp_rank = r; w.tp_size = P;
+            M.plans.push_back(w);
+            all_devices.push_back(w.device);
+        }
+    for (size_t i = 0; i < all_devices.size(); i++)
+        for (size_t j = i + 1; j < all_devices.size(); j++)
+            if (all_devices[i] == all_devices[j]) { EngineSetError("device %d appears twice in `devices`", all_devices[i]); return false; }
+    if (!BuildWorkers(M.plans, spec_)) return false;
+    const int R = G * P;
+    M.world.assign((size_t)R, nullptr); M.tp.assign((size_t)R, nullptr);
+    if (G > 1 && ifa_comm_init_all(all_devices.data(), R, M.world.data()) != IFA_OK) { EngineSetError("job communicator: %s", ifa_last_error()); return false; }
+    if (P > 1 || M.force_collectives)
+        for (int g = 0; g < G; g++)
+            if (ifa_comm_init_all(groups[(size_t)g].data(), P, M.tp.data() + (size_t)g * P) != IFA_OK) { EngineSetError("group communicator: %s", ifa_last_error()); return false; }
+    const int V = spec_.hyper_params.vocab_size;
+    M.topo.resize((size_t)R);
+    for (int i = 0; i < R; i++) {
+        ifa_tp_topology &t = M.topo[(size_t)i];
+        memset(&t, 0, sizeof(t));
+        const int g = i / P, r = i % P;
+        t.tp = M.tp[(size_t)i]; t.world = M.world[(size_t)i];
+        t.stage = g; t.n_stages = G;
+        t.prev_rank = g > 0 ? i - P : -1; t.next_rank = g + 1 < G ? i + P : -1;
+        t.token_src = (G - 1) * P;                  // first rank of the last group announces the token
+        t.vocab_offset = r * (V / P);
+        t.force_collectives = M.force_collectives ? 1 : 0;
+    }
+    M.shard_dev.assign((size_t)R, nullptr);
+    M.Start();
+    model_ = M.plans[0].model;      // (handle for model_info-style queries; steps go through the rank threads)
+    return true;
+}
+
+// one step of one query on every rank: n_new tokens from q.processed on; `next` = the greedy next token.  want_tensor:
+// item.output_tensor receives the [n_new][vocab] logits assembled from the last group's vocabulary shards.
+bool InferenceEngine::MultiStep(Query &q, int n_new, bool want_tensor, QueryInferenceResult &item, int &next)
+{
+    MultiGpu &M = *multi_;
+    const int R = (int)M.plans.size(), P = M.P, V = spec_.hyper_params.vocab_size;
+    const size_t shard = (size_t)V / (size_t)P;
+    if (want_tensor && (size_t)n_new > M.shard_rows) {
+        for (int i = (M.G - 1) * P; i < R; i++) {
+            ifa_set_device(M.plans[(size_t)i].device);
+            if (M.shard_dev[(size_t)i]) { ifa_free(M.shard_dev[(size_t)i]); M.shard_dev[(size_t)i] = nullptr; }
+            if (ifa_malloc(&M.shard_dev[(size_t)i], (size_t)n_new * shard * 2) != IFA_OK) { EngineSetError("logits buffer: %s", ifa_last_error()); return false; }
+        }
+        M.shard_rows = (size_t)n_new;
+    }
+    std::vector<int> nexts((size_t)R, -1);
+    std::vector<std::vector<uint16_t>> host((size_t)R);
+    const int *toks = q.tokens.data() + q.processed;
+    const int start = q.processed, slot = q.kv_slot;
+    const bool ok = M.Run([&](int i) -> int {
+        ifa_model *mm = M.plans[(size_t)i].model;
+        int rc = ifa_model_select_kv(mm, slot);
+        if (rc) return rc;
+        void *lg = want_tensor ? M.shard_dev[(size_t)i] : nullptr;
+        if (n_new == 1 && !lg) rc = ifa_model_tp_decode(mm, &M.topo[(size_t)i], toks[0], start, 1, &nexts[(size_t)i], nullptr);
+        else rc = ifa_model_tp_prefill(mm, &M.topo[(size_t)i], toks, n_new, start, lg, &nexts[(size_t)i]);
+        if (rc) return rc;
+        if (lg) {
+            host[(size_t)i].resize((size_t)n_new * shard);
+            rc = ifa_memcpy_d2h(host[(size_t)i].data(), lg, (size_t)n_new * shard * 2, ifa_model_stream(mm));
+            if (!rc) rc = ifa_stream_sync(ifa_model_stream(mm));
+        }
+        return rc;
+    }, n_new == 1 ? "decode step" : "prompt step");
+    if (!ok) return false;
+    next = nexts[(size_t)(R - 1)];
+    for (int i = 0; i < R; i++)
+        if (nexts[(size_t)i] != next) { EngineSetError("ranks disagree on the next token (%d vs %d)", nexts[(size_t)i], next); return false; }
+    if (want_tensor) {
+        item.output_rows = n_new; item.output_cols = V;
+        item.output_tensor.resize((size_t)n_new * V);
+        for (int r = 0; r < P; r++) {
+            const std::vector<uint16_t> &h = host[(size_t)((M.G - 1) * P + r)];
+            for (int row = 0; row < n_new; row++)
+                memcpy(&item.output_tensor[(size_t)row * V + (size_t)r * shard], &h[(size_t)row * shard], shard * 2);
+        }
+    }
     return true;
 }
 
@@ -178,6 +368,7 @@ int InferenceEngine::AddQuery(const std::vector<int> &tokens, const QueryOptions
 }
 
 int InferenceEngine::QueryCount() const { return (int)queries_.size(); }
+int InferenceEngine::PartitionRanks() const { return multi_ ? (int)multi_->plans.size() : 1; }
 
 SamplingStrategyId InferenceEngine::GetSamplingStrategyId(const std::string &str) const
 {
@@ -215,7 +406,7 @@ bool InferenceEngine::Infer(InferenceResult &res)
     std::vector<Query *> batch;
     for (auto &kv : queries_) {
         Query &q = kv.second;
-        if (!q.ended && (int)q.tokens.size() < max_ctx && q.processed > 0 && (int)q.tokens.size() - q.processed == 1) batch.push_back(&q);
+        if (!multi_ && !q.ended && (int)q.tokens.size() < max_ctx && q.processed > 0 && (int)q.tokens.size() - q.processed == 1) batch.push_back(&q);
     }
     if ((int)batch.size() >= std::max(2, config_.dynamic_batching_min_queries)) {
         const int n = (int)batch.size();
@@ -260,11 +451,20 @@ bool InferenceEngine::Infer(InferenceResult &res)
         if ((int)q.tokens.size() >= max_ctx) { q.ended = true; continue; }
         const int n_new = (int)q.tokens.size() - q.processed;
         if (n_new <= 0) continue;                                    // nothing committed since the last step
-        if (ifa_model_select_kv(model_, q.kv_slot) != IFA_OK) { EngineSetError("select_kv: %s", ifa_last_error()); return false; }
         QueryInferenceResult item; item.query_id = q.id; item.prefix_len = q.processed;
         int next = -1;
         const bool sampled = q.strategy != SamplingStrategyId::Greedy;
         const bool want_tensor = config_.return_output_tensors || sampled;
+        if (multi_) {                                                // partition over several GPUs: every rank steps at once
+            if (!MultiStep(q, n_new, want_tensor, item, next)) return false;
+            if (sampled && !SampleRow(q, item.output_tensor.data() + (size_t)(n_new - 1) * V, item)) return false;
+            if (!config_.return_output_tensors) { item.output_tensor.clear(); item.output_rows = item.output_cols = 0; }
+            q.processed = (int)q.tokens.size();
+            if (item.next_tokens.empty()) { IdWeight w; w.id = next; w.weight = 1.0f; item.next_tokens.push_back(w); }
+            res.items.push_back(std::move(item));
+            continue;
+        }
+        if (ifa_model_select_kv(model_, q.kv_slot) != IFA_OK) { EngineSetError("select_kv: %s", ifa_last_error()); return false; }
         if (n_new == 1 && !want_tensor) {                            // decode: fused graph-replayed step
             if (ifa_model_decode(model_, q.tokens.back(), q.processed, 1, &next, nullptr) != IFA_OK) {
                 EngineSetError("decode step failed: %s", ifa_last_error()); return false;
@@ -328,6 +528,44 @@ bool InferenceEngine::Generate(int query_id, int n_steps, std::vector<int> &new_
     if (!model_ || it == queries_.end()) { EngineSetError("Query %d does not exist", query_id); return false; }
     Query &q = it->second;
     if (n_steps <= 0) return true;
+    if (q.ended) { EngineSetError("Query %d has ended", query_id); return false; }
+    if (q.strategy != SamplingStrategyId::Greedy) { EngineSetError("Generate() decodes greedily on the device; query %d uses strategy %d (use Infer / CommitInferenceResult)", query_id, (int)q.strategy); return false; }
+    {   // nothing is touched unless the whole request fits (the device token ring holds 1024 steps per call)
+        const int max_ctx = spec_.max_context_len > 0 ? spec_.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
+        if ((int)q.tokens.size() + n_steps > max_ctx) { EngineSetError("Generate: %zu tokens + %d steps exceed max_context_len %d", q.tokens.size(), n_steps, max_ctx); return false; }
+    }
+    if (multi_) {
+        MultiGpu &M = *multi_;
+        const int R = (int)M.plans.size();
+        const int pending = (int)q.tokens.size() - q.processed;
+        if (pending <= 0) { EngineSetError("Query %d has no committed token to continue from", query_id); return false; }
+        int next = -1;
+        if (pending > 1 || q.processed == 0) {
+            QueryInferenceResult item;
+            if (!MultiStep(q, pending, false, item, next)) return false;
+            q.processed = (int)q.tokens.size();
+            q.tokens.push_back(next); new_tokens.push_back(next);
+            n_steps--;
+        }
+        float ms_total = 0;
+        while (n_steps > 0) {
+            const int k = std::min(n_steps, 1024);
+            std::vector<std::vector<int>> outs((size_t)R, std::vector<int>((size_t)k));
+            std::vector<float> ms((size_t)R, 0.0f);
+            const int first = q.tokens.back(), start = q.processed, slot = q.kv_slot;
+            if (!M.Run([&](int i) -> int {
+                    ifa_model *mm = M.plans[(size_t)i].model;
+                    int rc = ifa_model_select_kv(mm, slot);
+                    return rc ? rc : ifa_model_tp_decode(mm, &M.topo[(size_t)i], first, start, k, outs[(size_t)i].data(), &ms[(size_t)i]);
+                }, "decode")) return false;
+            for (int t : outs[(size_t)(R - 1)]) { q.tokens.push_back(t); new_tokens.push_back(t); }
+            q.processed = (int)q.tokens.size() - 1;
+            ms_total += *std::max_element(ms.begin(), ms.end());
+            n_steps -= k;
+        }
+        if (gpu_ms) *gpu_ms = ms_total;
+        return true;
+    }
     if (ifa_model_select_kv(model_, q.kv_slot) != IFA_OK) { EngineSetError("select_kv: %s", ifa_last_error()); return false; }
     int next = -1;
     const int pending = (int)q.tokens.size() - q.processed;
@@ -339,16 +577,20 @@ bool InferenceEngine::Generate(int query_id, int n_steps, std::vector<int> &new_
         q.tokens.push_back(next); new_tokens.push_back(next);
         n_steps--;
     } else if (pending == 0) { EngineSetError("Query %d has no committed token to continue from", query_id); return false; }
-    if (n_steps > 0) {
-        std::vector<int> out((size_t)n_steps);
+    float ms_total = 0;
+    while (n_steps > 0) {                              // the device token ring holds 1024 steps per call
+        const int k = std::min(n_steps, 1024);
+        std::vector<int> out((size_t)k);
         float ms = 0;
-        if (ifa_model_decode(model_, q.tokens.back(), q.processed, n_steps, out.data(), &ms) != IFA_OK) {
+        if (ifa_model_decode(model_, q.tokens.back(), q.processed, k, out.data(), &ms) != IFA_OK) {
             EngineSetError("decode failed: %s", ifa_last_error()); return false;
         }
-        if (gpu_ms) *gpu_ms = ms;
+        ms_total += ms;
         for (int t : out) { q.tokens.push_back(t); new_tokens.push_back(t); }
         q.processed = (int)q.tokens.size() - 1;
+        n_steps -= k;
     }
+    if (gpu_ms) *gpu_ms = ms_total;
     return true;
 }
 

@@ -6,10 +6,11 @@
 // (bool / query-id returns, a message through LogError -> ifa_engine_last_error(), never throws).
 // The host side is plain C++ and reaches the GPU only through the C ABI of include/inferflow_amd.h.
 //
-// Scope: token-id queries, greedy decoding (sampling_strategy.cc:372-386), one
-// model per engine, one device group of one GPU per process (multi-GPU tensor parallelism runs one
-// process per GPU through inferflow_amd.tp / torch.distributed).  Tokenizers, prompt templates, the
-// HTTP service and the non-greedy samplers are outside the hot path.
+// Scope: token-id queries, one model per engine.  `devices` takes the reference's grammar
+// (inference_engine.cc:1738-1783): "0" one GPU; "0&1" one device group, tensor parallel (BY_TENSOR); "0;1" two groups,
+// consecutive layer ranges (BY_LAYER); "0&1;2&3" HYBRID -- one worker and one host thread per GPU inside this process,
+// the exchanges through the C ABI collectives (RCCL).  Tokenizers, prompt templates and the HTTP service are outside
+// the hot path.
 #pragma once
 #include <cstdint>
 #include <map>
@@ -19,6 +20,7 @@
 #include "sampling_strategy.h"
 
 struct ifa_model;
+struct ifa_comm;
 
 namespace inferflow_amd {
 
@@ -80,6 +82,9 @@ struct InferenceConfig {
     // extension: queries advancing by one token share ONE batched step (MFMA GEMM over the rows) from this many on;
     // below it each runs the fused single-query decode (measured break-even on Llama-2-7B Q4: 3 queries)
     int dynamic_batching_min_queries = 3;
+    // extension (tests on a 1-GPU box): run a single device through the partition path -- rank thread, communicator of
+    // one rank, the C-driven step with its collectives -- instead of the plain single-worker path
+    bool force_partition_path = false;
     DebugOptions debug;
 };
 
@@ -137,6 +142,7 @@ public:
     const ModelSpec &model_spec() const { return spec_; }
     std::string Version() const { return "inferflow_amd 0.1 (MI355X)"; }
     int default_device_id() const { return device_; }
+    int PartitionRanks() const;     // workers of the multi-GPU partition (1: single device)
     ifa_model *worker() { return model_; }
 
 private:
@@ -153,6 +159,12 @@ private:
         SamplingState sampling_state;   // Mirostat's mu, the FSD n-gram model, the EOS bypass count
     };
     bool SampleRow(Query &q, const uint16_t *logits_row, QueryInferenceResult &item);
+    // ---- multi-GPU partitions (devices = 0&1 | 0;1 | 0&1;2&3): one worker and one host thread per GPU, like the
+    // reference's Infer_TensorParallelism / Infer_Std over GpuInferenceWorker threads (inference_engine.cc:1161-1296)
+    struct MultiGpu;
+    MultiGpu *multi_ = nullptr;
+    bool InitMulti(const std::vector<std::vector<int>> &groups);
+    bool MultiStep(Query &q, int n_new, bool want_tensor, QueryInferenceResult &item, int &next);
     InferenceConfig config_;
     ModelSpec spec_;
     ifa_model *model_ = nullptr;
@@ -173,5 +185,22 @@ void EngineSetError(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 // model loading (model_loader.cc)
 bool LoadModelSpecJson(ModelSpec &spec, const std::string &path);
 bool BuildWorker(ifa_model **out, ModelSpec &spec, int device);
+
+// One worker of a multi-GPU partition (MultiGpuStrategy BY_LAYER / BY_TENSOR / HYBRID, src/transformer/model.h:61-66;
+// "devices = 0&1;2&3": groups separated by ';' hold consecutive layer ranges, devices joined by '&' share every layer).
+struct WorkerPlan {
+    int device = 0;
+    int stage = 0, n_stages = 1;        // device group (layer range) of this worker
+    int tp_rank = 0, tp_size = 1;       // position inside the group
+    int layer0 = 0, layer1 = -1;        // global layers [layer0, layer1); layer1 < 0: all (filled in by the loader)
+    bool first_stage = true, last_stage = true;
+    ifa_model *model = nullptr;
+};
+struct TensorSlice { size_t row0, row1, col0, col1; int local_layer; };
+// the slice of tensor (layer, tid) [rows][cols] worker w holds; false: none of it
+bool SliceForWorker(const WorkerPlan &w, int layer, int tid, size_t rows, size_t cols, TensorSlice &sl);
+void SplitGpuLayers(int n_layers, int n_groups, std::vector<std::pair<int, int>> &ranges);
+// plans: one entry per (group, rank) in the reference's device order; layer ranges are assigned from the checkpoint's layer count
+bool BuildWorkers(std::vector<WorkerPlan> &plans, ModelSpec &spec);
 
 } // namespace inferflow_amd

@@ -145,13 +145,52 @@ bool LoadModelSpecJson(ModelSpec &spec, const std::string &path)
 }
 
 // --------------------------------------------------------------- uploading
+// layer range [layer0, layer1) of device group g of n (NetworkBuilder::SplitGpuLayers, network_builder.cc:2094-2118:
+// ceil(L / n) layers per group, the last group takes the rest)
+void SplitGpuLayers(int n_layers, int n_groups, std::vector<std::pair<int, int>> &ranges)
+{
+    ranges.clear();
+    const int per = (n_layers + n_groups - 1) / n_groups;
+    for (int g = 0; g < n_groups; g++) {
+        const int start = g * per;
+        const int end = g + 1 == n_groups ? n_layers : std::min((g + 1) * per, n_layers);
+        if (end > start) ranges.push_back(std::make_pair(start, end));
+    }
+}
+
+// Which slice of a tensor a worker of a multi-GPU partition holds (the reference's BY_TENSOR rule,
+// src/transformer/network_builder.cc:1594-1686, device_tensor_builder.cu:203-239): wq / wk / wv / w1 / w3 and their biases
+// by contiguous ROW ranges (heads, KV heads and FFN rows are split), wo / w2 by contiguous COLUMN ranges (whole quant
+// blocks), the lm_head by vocabulary rows; norms, embeddings, wo / w2 biases (added once after the merge) replicated.
+// Returns false when the worker does not hold the tensor at all (other layer group, embeddings / lm_head of another stage).
+bool SliceForWorker(const WorkerPlan &w, int layer, int tid, size_t rows, size_t cols, TensorSlice &sl)
+{
+    sl = TensorSlice{0, rows, 0, cols, layer};
+    if (layer >= 0) {
+        if (layer < w.layer0 || layer >= w.layer1) return false;
+        sl.local_layer = layer - w.layer0;
+    } else {
+        if (tid == IFA_T_EMBD && !w.first_stage) return false;
+        if ((tid == IFA_T_OUT_NORM || tid == IFA_T_OUT_NORM_B || tid == IFA_T_LM_HEAD) && !w.last_stage) return false;
+    }
+    const size_t P = (size_t)std::max(1, w.tp_size), r = (size_t)w.tp_rank;
+    if (P == 1) return true;
+    const bool row_split = tid == IFA_T_WQ || tid == IFA_T_WK || tid == IFA_T_WV || tid == IFA_T_W1 || tid == IFA_T_W3 || (tid == IFA_T_LM_HEAD && layer < 0);
+    const bool bias_split = tid == IFA_T_WQ_B || tid == IFA_T_WK_B || tid == IFA_T_WV_B || tid == IFA_T_W1_B || tid == IFA_T_W3_B;
+    const bool col_split = tid == IFA_T_WO || tid == IFA_T_W2;
+    if (row_split) { sl.row0 = r * (rows / P); sl.row1 = sl.row0 + rows / P; }
+    else if (col_split || bias_split) { sl.col0 = r * (cols / P); sl.col1 = sl.col0 + cols / P; }
+    return true;
+}
+
 namespace {
 
 struct Uploader {
-    ifa_model *m = nullptr;
+    std::vector<WorkerPlan> *plans = nullptr;
     const ModelSpec *spec = nullptr;
-    void *dev = nullptr; size_t dev_bytes = 0;
-    ~Uploader() { if (dev) ifa_free(dev); }
+    std::vector<void *> dev; std::vector<size_t> dev_bytes;
+    std::vector<uint16_t> staging;
+    ~Uploader() { for (size_t i = 0; i < dev.size(); i++) if (dev[i]) { ifa_set_device((*plans)[i].device); ifa_free(dev[i]); } }
 
     static bool IsQuant(int dt) { return dt >= 7; }
     int MatrixType(size_t rows, size_t cols) const
@@ -164,17 +203,39 @@ struct Uploader {
     }
     bool Put(int layer, int tid, int target, const uint16_t *f16, size_t rows, size_t cols)
     {
-        const size_t bytes = rows * cols * 2;
-        if (bytes > dev_bytes) {
-            if (dev) ifa_free(dev);
-            dev = nullptr; dev_bytes = 0;
-            if (ifa_malloc(&dev, bytes) != IFA_OK) { EngineSetError("device allocation of %zu bytes failed: %s", bytes, ifa_last_error()); return false; }
-            dev_bytes = bytes;
-        }
-        if (ifa_memcpy_h2d(dev, f16, bytes, nullptr) != IFA_OK || ifa_stream_sync(nullptr) != IFA_OK
-            || ifa_model_set_tensor_f16(m, layer, tid, -1, target, dev, rows, cols) != IFA_OK) {
-            EngineSetError("uploading tensor %d of layer %d failed: %s", tid, layer, ifa_last_error());
-            return false;
+        if (dev.empty()) { dev.assign(plans->size(), nullptr); dev_bytes.assign(plans->size(), 0); }
+        for (size_t wi = 0; wi < plans->size(); wi++) {
+            WorkerPlan &w = (*plans)[wi];
+            TensorSlice sl;
+            if (!SliceForWorker(w, layer, tid, rows, cols, sl)) continue;
+            const size_t srows = sl.row1 - sl.row0, scols = sl.col1 - sl.col0;
+            int tgt = target;
+            if (IsQuant(tgt)) {
+                const int cap = ifa_block_capacity(tgt);
+                if (cap <= 0 || scols % (size_t)cap != 0) {
+                    EngineSetError("tensor %d of layer %d: %zu columns per rank do not hold whole %d-element blocks", tid, layer, scols, cap);
+                    return false;
+                }
+            }
+            const uint16_t *src = f16 + sl.row0 * cols;
+            if (scols != cols) {        // column range: repack the rows contiguously
+                staging.resize(srows * scols);
+                for (size_t r = 0; r < srows; r++) memcpy(&staging[r * scols], f16 + (sl.row0 + r) * cols + sl.col0, scols * 2);
+                src = staging.data();
+            }
+            const size_t bytes = srows * scols * 2;
+            if (ifa_set_device(w.device) != IFA_OK) { EngineSetError("ifa_set_device(%d): %s", w.device, ifa_last_error()); return false; }
+            if (bytes > dev_bytes[wi]) {
+                if (dev[wi]) ifa_free(dev[wi]);
+                dev[wi] = nullptr; dev_bytes[wi] = 0;
+                if (ifa_malloc(&dev[wi], bytes) != IFA_OK) { EngineSetError("device allocation of %zu bytes failed: %s", bytes, ifa_last_error()); return false; }
+                dev_bytes[wi] = bytes;
+            }
+            if (ifa_memcpy_h2d(dev[wi], src, bytes, nullptr) != IFA_OK || ifa_stream_sync(nullptr) != IFA_OK
+                || ifa_model_set_tensor_f16(w.model, sl.local_layer, tid, -1, tgt, dev[wi], srows, scols) != IFA_OK) {
+                EngineSetError("uploading tensor %d of layer %d failed: %s", tid, layer, ifa_last_error());
+                return false;
+            }
         }
         return true;
     }
@@ -186,28 +247,48 @@ int RopeOrder(const ModelSpec &spec)
     return spec.qk_column_order == 2 ? 2 : 1;          // unary_tensor_opr.h:661-735: order 2 = (c, c + dims/2) pairs
 }
 
-bool CreateWorker(ifa_model **out, const ModelSpec &spec, int device)
+bool CreateWorkers(std::vector<WorkerPlan> &plans, const ModelSpec &spec)
 {
     const ModelHyperParams &hp = spec.hyper_params;
     if (hp.embd_dims <= 0 || hp.decoder_layers <= 0 || hp.decoder_heads <= 0 || hp.vocab_size <= 0 || hp.hidden_dim <= 0) {
         EngineSetError("model %s: incomplete hyper-parameters", spec.sid.c_str()); return false;
     }
     if (hp.experts > 0) { EngineSetError("model %s: MoE models are loaded through the Python worker for now", spec.sid.c_str()); return false; }
-    ifa_model_config c; memset(&c, 0, sizeof(c));
-    c.dim = hp.embd_dims; c.layers = hp.decoder_layers; c.heads = hp.decoder_heads;
-    c.kv_heads = hp.decoder_kv_heads > 0 ? hp.decoder_kv_heads : hp.decoder_heads;
-    c.head_dim = hp.embd_dims / hp.decoder_heads; c.ffn = hp.hidden_dim; c.vocab = hp.vocab_size;
-    c.max_ctx = spec.max_context_len > 0 ? spec.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
-    c.norm_kind = spec.norm_alg == TensorNormAlg::RMS ? 0 : 1;
-    c.act_kind = (int)spec.activation_fn; c.is_glu = 1;
-    c.rope_order = RopeOrder(spec); c.use_alibi = spec.pos_embedding_alg == PositionEmbeddingAlg::ALIBI;
-    c.parallel_attn = spec.is_parallel_attn; c.share_input = spec.mlp_attn_share_input;
-    c.rope_theta = spec.rope_theta; c.partial_rotary = spec.partial_rotary_factor; c.kq_scale = spec.kq_scale; c.eps = 1e-5f;
-    c.kv_dtype = spec.device_kv_cache_data_type == IFA_Q8_B32T2 ? IFA_Q8_B32T2 : IFA_F16;
-    c.full_quant_gemv = 1; c.tp_rank = 0; c.tp_size = 1; c.device = device;
-    c.attn_norm_base = spec.attn_pre_norm_base; c.ffn_norm_base = spec.ffn_pre_norm_base; c.out_norm_base = spec.output_norm_base;
-    c.attn_out_scale = spec.attn_out_scale; c.ffn_out_scale = spec.ffn_out_scale; c.out_scale = spec.out_scale;
-    if (ifa_model_create(&c, out) != IFA_OK) { EngineSetError("ifa_model_create: %s", ifa_last_error()); return false; }
+    const int kv_heads = hp.decoder_kv_heads > 0 ? hp.decoder_kv_heads : hp.decoder_heads;
+    for (WorkerPlan &w : plans) {
+        if (w.layer1 < 0) {         // layer range of the worker's device group
+            std::vector<std::pair<int, int>> ranges;
+            SplitGpuLayers(hp.decoder_layers, std::max(1, w.n_stages), ranges);
+            if ((int)ranges.size() != std::max(1, w.n_stages)) {
+                EngineSetError("model %s: %d layers cannot be spread over %d device groups", spec.sid.c_str(), hp.decoder_layers, w.n_stages);
+                return false;
+            }
+            w.layer0 = ranges[(size_t)w.stage].first; w.layer1 = ranges[(size_t)w.stage].second;
+            w.first_stage = w.stage == 0; w.last_stage = w.stage + 1 == std::max(1, w.n_stages);
+        }
+        const int P = std::max(1, w.tp_size);
+        // the reference's own constraints (network_builder.cc:1207-1213) + whole blocks per rank
+        if (hp.decoder_heads % P || kv_heads % P || hp.hidden_dim % P || hp.vocab_size % P) {
+            EngineSetError("model %s: heads (%d), kv heads (%d), hidden_dim (%d) and vocab (%d) must be divisible by the device-group size %d",
+                           spec.sid.c_str(), hp.decoder_heads, kv_heads, hp.hidden_dim, hp.vocab_size, P);
+            return false;
+        }
+        ifa_model_config c; memset(&c, 0, sizeof(c));
+        c.dim = hp.embd_dims; c.layers = w.layer1 - w.layer0; c.heads = hp.decoder_heads / P;
+        c.kv_heads = kv_heads / P;
+        c.head_dim = hp.embd_dims / hp.decoder_heads; c.ffn = hp.hidden_dim / P; c.vocab = hp.vocab_size;
+        c.max_ctx = spec.max_context_len > 0 ? spec.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;
+        c.norm_kind = spec.norm_alg == TensorNormAlg::RMS ? 0 : 1;
+        c.act_kind = (int)spec.activation_fn; c.is_glu = 1;
+        c.rope_order = RopeOrder(spec); c.use_alibi = spec.pos_embedding_alg == PositionEmbeddingAlg::ALIBI;
+        c.parallel_attn = spec.is_parallel_attn; c.share_input = spec.mlp_attn_share_input;
+        c.rope_theta = spec.rope_theta; c.partial_rotary = spec.partial_rotary_factor; c.kq_scale = spec.kq_scale; c.eps = 1e-5f;
+        c.kv_dtype = spec.device_kv_cache_data_type == IFA_Q8_B32T2 ? IFA_Q8_B32T2 : IFA_F16;
+        c.full_quant_gemv = 1; c.tp_rank = w.tp_rank; c.tp_size = P; c.device = w.device;
+        c.attn_norm_base = spec.attn_pre_norm_base; c.ffn_norm_base = spec.ffn_pre_norm_base; c.out_norm_base = spec.output_norm_base;
+        c.attn_out_scale = spec.attn_out_scale; c.ffn_out_scale = spec.ffn_out_scale; c.out_scale = spec.out_scale;
+        if (ifa_model_create(&c, &w.model) != IFA_OK) { EngineSetError("ifa_model_create (device %d): %s", w.device, ifa_last_error()); return false; }
+    }
     return true;
 }
 
@@ -221,7 +302,7 @@ int LmHeadType(const ModelSpec &spec, size_t rows, size_t cols)
 }
 
 // ---------------------------------------------------------------- llama2.c
-bool LoadLlama2DotC(ifa_model **out, ModelSpec &spec, int device)
+bool LoadLlama2DotC(std::vector<WorkerPlan> &plans, ModelSpec &spec)
 {
     const std::string path = spec.dir + (spec.model_files.empty() ? "" : spec.model_files[0]);
     FILE *fp = fopen(path.c_str(), "rb");
@@ -245,8 +326,8 @@ bool LoadLlama2DotC(ifa_model **out, ModelSpec &spec, int device)
         fseek(fp, 256, SEEK_SET);      // the v1 header is padded to 256 bytes
     }
     if (hp.embd_dims <= 0 || hp.decoder_heads <= 0 || hp.embd_dims % hp.decoder_heads != 0) { EngineSetError("bad llama2.c header in %s", path.c_str()); return false; }
-    if (!CreateWorker(out, spec, device)) return false;
-    Uploader up; up.m = *out; up.spec = &spec;
+    if (!CreateWorkers(plans, spec)) return false;
+    Uploader up; up.plans = &plans; up.spec = &spec;
     const size_t D = (size_t)hp.embd_dims, F = (size_t)hp.hidden_dim, V = (size_t)hp.vocab_size, L = (size_t)hp.decoder_layers;
     const size_t HS = D / (size_t)hp.decoder_heads, KV = (size_t)hp.decoder_kv_heads * HS;
     std::vector<float> f32; std::vector<uint16_t> f16;
@@ -349,7 +430,7 @@ bool LoadHfConfig(ModelSpec &spec)
     return true;
 }
 
-bool LoadSafetensors(ifa_model **out, ModelSpec &spec, int device)
+bool LoadSafetensors(std::vector<WorkerPlan> &plans, ModelSpec &spec)
 {
     if (!LoadHfConfig(spec)) return false;
     std::map<std::string, StEntry> index;
@@ -369,9 +450,9 @@ bool LoadSafetensors(ifa_model **out, ModelSpec &spec, int device)
         }
         by_std[name] = kv.second;
     }
-    if (!CreateWorker(out, spec, device)) return false;
+    if (!CreateWorkers(plans, spec)) return false;
     const ModelHyperParams &hp = spec.hyper_params;
-    Uploader up; up.m = *out; up.spec = &spec;
+    Uploader up; up.plans = &plans; up.spec = &spec;
     const size_t D = (size_t)hp.embd_dims, F = (size_t)hp.hidden_dim, V = (size_t)hp.vocab_size;
     const size_t HS = D / (size_t)hp.decoder_heads, KV = (size_t)hp.decoder_kv_heads * HS;
     std::vector<uint16_t> f16;
@@ -466,12 +547,12 @@ void FillNormalF16(std::vector<uint16_t> &out, size_t n, uint64_t seed, float st
     for (auto &t : ts) t.join();
 }
 
-bool LoadSynthetic(ifa_model **out, ModelSpec &spec, int device)
+bool LoadSynthetic(std::vector<WorkerPlan> &plans, ModelSpec &spec)
 {
     ModelHyperParams &hp = spec.hyper_params;
     if (hp.decoder_kv_heads <= 0) hp.decoder_kv_heads = hp.decoder_heads;
-    if (!CreateWorker(out, spec, device)) return false;
-    Uploader up; up.m = *out; up.spec = &spec;
+    if (!CreateWorkers(plans, spec)) return false;
+    Uploader up; up.plans = &plans; up.spec = &spec;
     const size_t D = (size_t)hp.embd_dims, F = (size_t)hp.hidden_dim, V = (size_t)hp.vocab_size;
     const size_t HS = D / (size_t)hp.decoder_heads, KV = (size_t)hp.decoder_kv_heads * HS;
     std::vector<uint16_t> w, ones(D, 0x3C00);
@@ -494,19 +575,30 @@ bool LoadSynthetic(ifa_model **out, ModelSpec &spec, int device)
 
 } // namespace
 
+bool BuildWorkers(std::vector<WorkerPlan> &plans, ModelSpec &spec)
+{
+    for (WorkerPlan &w : plans) w.model = nullptr;
+    bool ok = false;
+    const std::string &fmt = spec.model_file_format;
+    // layer ranges are only known once the checkpoint's header is read: plans with layer1 < 0 are completed by FinishPlans
+    if (fmt == "llama2.c" || fmt == "llama2_c") ok = LoadLlama2DotC(plans, spec);
+    else if (fmt == "safetensors") ok = LoadSafetensors(plans, spec);
+    else if (fmt == "synthetic") ok = LoadSynthetic(plans, spec);
+    else EngineSetError("model %s: model_file_format \"%s\" is not supported (llama2.c, safetensors, synthetic)", spec.sid.c_str(), fmt.c_str());
+    for (WorkerPlan &w : plans)
+        if (ok && ifa_model_finalize(w.model) != IFA_OK) { EngineSetError("ifa_model_finalize: %s", ifa_last_error()); ok = false; }
+    if (!ok) for (WorkerPlan &w : plans) if (w.model) { ifa_model_destroy(w.model); w.model = nullptr; }
+    return ok;
+}
+
 bool BuildWorker(ifa_model **out, ModelSpec &spec, int device)
 {
     *out = nullptr;
-    if (ifa_set_device(device) != IFA_OK) { EngineSetError("ifa_set_device(%d): %s", device, ifa_last_error()); return false; }
-    bool ok = false;
-    const std::string &fmt = spec.model_file_format;
-    if (fmt == "llama2.c" || fmt == "llama2_c") ok = LoadLlama2DotC(out, spec, device);
-    else if (fmt == "safetensors") ok = LoadSafetensors(out, spec, device);
-    else if (fmt == "synthetic") ok = LoadSynthetic(out, spec, device);
-    else EngineSetError("model %s: model_file_format \"%s\" is not supported (llama2.c, safetensors, synthetic)", spec.sid.c_str(), fmt.c_str());
-    if (ok && ifa_model_finalize(*out) != IFA_OK) { EngineSetError("ifa_model_finalize: %s", ifa_last_error()); ok = false; }
-    if (!ok && *out) { ifa_model_destroy(*out); *out = nullptr; }
-    return ok;
+    std::vector<WorkerPlan> plans(1);
+    plans[0].device = device;
+    if (!BuildWorkers(plans, spec)) return false;
+    *out = plans[0].model;
+    return true;
 }
 
 } // namespace inferflow_amd

@@ -109,7 +109,8 @@ inference_engine_config = ${{config_dir}}/engine.ini
 
 [transformer_engine]
 models = {name}
-devices = 0
+devices = {devices}
+force_partition_path = {force_partition}
 decoder_cpu_layer_count = 0
 cpu_threads = 8
 max_concurrent_queries = {maxq}
@@ -128,7 +129,7 @@ prompt_template = {{bos}}{{query}}
 
 
 def write_model_dir(d, fmt="llama2.c", wd="Q4", kvd="Q8", thr=0, ctx=64, ret="true", maxq=6, s=SHAPE, seed=5, qk_order=0,
-                    st_dtype="F16", hyper=None, fused_qkv=None, std=0.06, shared_classifier=False):
+                    st_dtype="F16", hyper=None, fused_qkv=None, std=0.06, shared_classifier=False, devices="0", force_partition="false"):
     """Returns (ini_path, weights dict or None)."""
     os.makedirs(d, exist_ok=True)
     spec = json.loads(json.dumps(SPEC))
@@ -154,7 +155,8 @@ def write_model_dir(d, fmt="llama2.c", wd="Q4", kvd="Q8", thr=0, ctx=64, ret="tr
         spec["synthetic_std"] = 0.06
     json.dump(spec, open(os.path.join(d, "model_spec.json"), "w"), indent=2)
     ini = os.path.join(d, "engine.ini")
-    open(ini, "w").write(INI.format(name="tiny_test", wd=wd, kvd=kvd, thr=thr, ctx=ctx, ret=ret, maxq=maxq))
+    open(ini, "w").write(INI.format(name="tiny_test", wd=wd, kvd=kvd, thr=thr, ctx=ctx, ret=ret, maxq=maxq, devices=devices,
+                                   force_partition=force_partition))
     return ini, w
 
 

@@ -91,3 +91,42 @@ def test_split_layers_follows_the_reference_rule():
         for G in range(1, 9):
             r = tp.split_layers(L, G)
             assert r[0][0] == 0 and r[-1][1] == L and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def test_engine_partition_rules_match_the_python_partition():
+    """The C++ engine's multi-GPU partition (host/model_loader.cc: SliceForWorker, SplitGpuLayers -- what `devices =
+    0&1;2&3` loads onto each worker) against inferflow_amd.tp (slice_tensor / split_layers), which the gloo test above and
+    the GPU tests exercise; host-only entry points of the C ABI."""
+    import ctypes as C
+    import inferflow_amd as ia
+    from inferflow_amd import tp, worker as W
+    L = ia.lib()
+    for n_layers, groups in [(32, 1), (32, 2), (60, 4), (7, 2), (5, 3), (2, 4)]:
+        out = (C.c_int * 16)()
+        n = L.ifa_partition_split_layers(n_layers, groups, out, 8)
+        got = [(out[2 * i], out[2 * i + 1]) for i in range(n)]
+        assert got == tp.split_layers(n_layers, groups), (n_layers, groups)
+    rows, cols = 64, 96
+    full = np.arange(rows * cols, dtype=np.int64).reshape(rows, cols)
+    out5 = (C.c_size_t * 5)()
+    for P in (1, 2, 4):
+        for r in range(P):
+            for tid in (W.T_WQ, W.T_WK, W.T_WV, W.T_W1, W.T_W3, W.T_WO, W.T_W2, W.T_ATTN_NORM):
+                assert L.ifa_partition_slice(0, 1, r, P, 0, 4, 2, tid, rows, cols, out5) == 1
+                exp = tp.slice_tensor(tid, full, r, P)
+                got = full[out5[0]:out5[1], out5[2]:out5[3]]
+                assert np.array_equal(got, exp) and out5[4] == 2, (P, r, tid)
+            # lm_head: vocabulary rows; biases of row-split matrices: the matching element range of the [1][n] vector
+            assert L.ifa_partition_slice(0, 1, r, P, 0, 4, -1, W.T_LM_HEAD, rows, cols, out5) == 1
+            assert (out5[0], out5[1], out5[2], out5[3]) == (r * rows // P, (r + 1) * rows // P, 0, cols)
+            assert L.ifa_partition_slice(0, 1, r, P, 0, 4, 1, W.T_W1_B, 1, cols, out5) == 1
+            assert (out5[0], out5[1], out5[2], out5[3]) == (0, 1, r * cols // P, (r + 1) * cols // P)
+            assert L.ifa_partition_slice(0, 1, r, P, 0, 4, 1, W.T_WO_B, 1, cols, out5) == 1      # added once after the merge: replicated
+            assert (out5[2], out5[3]) == (0, cols)
+    # layer groups: a worker holds its range only, embeddings on the first group, lm_head / output norm on the last
+    assert L.ifa_partition_slice(1, 2, 0, 1, 16, 32, 3, W.T_WQ, rows, cols, out5) == 0
+    assert L.ifa_partition_slice(1, 2, 0, 1, 16, 32, 20, W.T_WQ, rows, cols, out5) == 1 and out5[4] == 4
+    assert L.ifa_partition_slice(1, 2, 0, 1, 16, 32, -1, W.T_EMBD, rows, cols, out5) == 0
+    assert L.ifa_partition_slice(0, 2, 0, 1, 0, 16, -1, W.T_EMBD, rows, cols, out5) == 1
+    assert L.ifa_partition_slice(0, 2, 0, 1, 0, 16, -1, W.T_LM_HEAD, rows, cols, out5) == 0
+    assert L.ifa_partition_slice(1, 2, 0, 1, 16, 32, -1, W.T_LM_HEAD, rows, cols, out5) == 1
