@@ -86,6 +86,11 @@ def main():
     steps, warmup = args.steps, args.warmup
     prefill_lens = [int(x) for x in args.prefill_lens.split(",") if x] if world == 1 else []
     max_ctx = max([PROMPT_LEN + warmup + steps + 8] + [n + 8 for n in prefill_lens])
+    # RCCL prints a version banner on stdout when its first communicator is created: stdout carries ONE JSON line, so
+    # everything up to the final print goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     t_build = time.perf_counter()
     runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank, groups=args.groups)
     t_build = time.perf_counter() - t_build
@@ -140,7 +145,9 @@ def main():
                                "%d-token prompt, context %d..%d" % (args.shape, dt.name(wd), dt.name(kvd), PROMPT_LEN,
                                                                   PROMPT_LEN + warmup, PROMPT_LEN + warmup + steps),
                    "parallelism": ("single" if world == 1 else "tp%d" % world if args.groups == 1
-                                   else "hybrid: %d layer groups x tp%d" % (args.groups, world // args.groups)), "weights_bytes": w_bytes,
+                                   else "hybrid: %d layer groups x tp%d" % (args.groups, world // args.groups)),
+                   "collectives": getattr(runner, "backend", "torch.distributed (nccl = RCCL)") if (world > 1 or os.environ.get("IFA_FORCE_TP")) else None,
+                   "weights_bytes": w_bytes,
                    "bytes_per_token": bytes_per_token},
         "gpu_event_ms_per_step": gpu_ms / steps if gpu_ms and gpu_ms > 0 else None,
         "token_hbm_GBps": bytes_per_token * tok_s / 1e9,
@@ -212,6 +219,8 @@ def main():
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -1424,8 +1424,6 @@ static int tp_ready(ifa_model *m)
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
     if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
-    if (m->cfg.norm_kind != 0 || m->cfg.parallel_attn || m->cfg.share_input)
-        return ifa_fail(IFA_ERR_STATE, "tensor-parallel segments cover the sequential RMS-norm wiring only");
     return ensure_scratch(m, 1);
 }
 
@@ -1501,7 +1499,17 @@ int ifa_model_tp_post_attn(ifa_model *m, int layer, const void *reduced_f16)
     const size_t D = (size_t)m->cfg.dim;
     const Tensor &b = m->layers[(size_t)layer].t[T_WO_B];
     const Layer &Lp = m->layers[(size_t)layer];
-    if (m->opt_tp_fuse_add && Lp.t[T_FFN_NORM].present() && !(m->cfg.experts > 0 && Lp.t[T_MOE_GATE].present())) {
+    if (m->cfg.parallel_attn || m->cfg.share_input) {
+        // parallel attention / shared MLP input (Falcon, GPT-J/NeoX style; inference_worker.cc:847-851, 941-947): the
+        // attention branch does NOT take the residual here -- attention output, FFN output and the layer input are summed
+        // once after the FFN (ifa_model_tp_post_ffn).  a = merged product (+ bias once, after the merge :1388-1390)
+        if (b.present()) return ifa_add(reduced_f16, b.data, D, 0, m->a, m->stream);
+        IFA_HIP_CHECK(hipMemcpyAsync(m->a, reduced_f16, D * 2, hipMemcpyDeviceToDevice, m->stream));
+        return IFA_OK;
+    }
+    // the seam sum can ride in the consumer's prologue only where that prologue exists: RMS-norm models (Std-norm ones
+    // run the op-level norm kernel in front of a prologue-free GEMV)
+    if (m->opt_tp_fuse_add && m->cfg.norm_kind == 0 && Lp.t[T_FFN_NORM].present() && !(m->cfg.experts > 0 && Lp.t[T_MOE_GATE].present())) {
         // a = x + (reduced + bias): left to the W1/W3 kernel's prologue (ifa_model_tp_ffn)
         m->pend.x = m->x; m->pend.add = (const half_t *)reduced_f16; m->pend.bias = (const half_t *)b.data; m->pend.out = m->a;
         m->pend.on = true;
@@ -1529,7 +1537,7 @@ int ifa_model_tp_ffn(ifa_model *m, int layer, void *partial_out_f16)
         }
         return IFA_OK;
     }
-    if ((rc = launch_ffn13(m, layer))) return rc;
+    if ((rc = launch_ffn13(m, layer, -1, m->x))) return rc;       // (m->x: the layer input, the FFN input of shared-input models)
     return launch_w2(m, layer, nullptr, (half_t *)partial_out_f16);
 }
 
@@ -1538,7 +1546,19 @@ int ifa_model_tp_post_ffn(ifa_model *m, int layer, const void *reduced_f16)
     IFA_REQUIRE(m && reduced_f16 && layer >= 0 && layer < m->cfg.layers, "ifa_model_tp_post_ffn: bad arguments");
     const size_t D = (size_t)m->cfg.dim;
     const Tensor &b = m->layers[(size_t)layer].t[T_W2_B];
-    if (m->opt_tp_fuse_add && layer + 1 < m->cfg.layers) {
+    if (m->cfg.parallel_attn || m->cfg.share_input) {
+        // next layer input = ((merged FFN product + bias) + attention output) + layer input: the order of the fused
+        // single-device epilogue (residual, then residual2; inference_worker.cc:936, 941-947)
+        const void *src = reduced_f16;
+        int rc;
+        if (b.present()) {
+            if ((rc = ifa_add(reduced_f16, b.data, D, 0, m->f, m->stream))) return rc;
+            src = m->f;
+        }
+        if ((rc = ifa_add(m->a, src, D, 0, m->f, m->stream))) return rc;
+        return ifa_add(m->f, m->x, D, 0, m->x, m->stream);
+    }
+    if (m->opt_tp_fuse_add && m->cfg.norm_kind == 0 && layer + 1 < m->cfg.layers) {
         // next layer input = a + (reduced + bias): left to the next QKV kernel's prologue (ifa_model_tp_attn)
         m->pend.x = m->a; m->pend.add = (const half_t *)reduced_f16; m->pend.bias = (const half_t *)b.data; m->pend.out = m->x;
         m->pend.on = true;

@@ -47,5 +47,9 @@ def build_runner(shape_name, wdtype, kv_dtype, max_ctx, world=1, rank=0, local_r
     import os
     if world == 1 and not os.environ.get("IFA_FORCE_TP"):
         return SingleRunner(shape_name, wdtype, kv_dtype, max_ctx, device=local_rank)
-    from .tp import TPRunner
+    from .tp import CTPRunner, TPRunner
+    # the C path (collectives of the C ABI, the step driven from C) unless IFA_TP_BACKEND=torch asks for the round-1
+    # runner (torch.distributed collectives around the worker segments)
+    if os.environ.get("IFA_TP_BACKEND", "c") != "torch":
+        return CTPRunner(shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank, groups=groups)
     return TPRunner(shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank, groups=groups)

@@ -26,6 +26,9 @@ SHAPES = {
     # Mixtral-8x7B (data/models/mixtral_8x7b_instruct_v0.1) and a small MoE shape for parity tests
     "mixtral_8x7b": dict(dim=4096, layers=32, heads=32, kv_heads=8, head_dim=128, ffn=14336, vocab=32000, experts=8, moe_top_k=2),
     "test_moe": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000, experts=4, moe_top_k=2),
+    # a small Falcon-40B-like wiring (LayerNorm, GELU, plain MLP, shared MLP / attention input, grouped KV heads)
+    "test_falcon": dict(dim=256, layers=2, heads=8, kv_heads=2, head_dim=32, ffn=512, vocab=1000,
+                        norm_kind=1, act_kind=1, is_glu=0, share_input=1, rope_order=2),
 }
 
 MATRICES = [(W.T_WQ, "q"), (W.T_WK, "kv"), (W.T_WV, "kv"), (W.T_WO, "o"), (W.T_W1, "up"), (W.T_W3, "up"), (W.T_W2, "down")]

@@ -106,6 +106,8 @@ def build_tp_worker(shape_name, wdtype, kv_dtype, max_ctx, world, rank, device=0
         put(layer - l0, W.T_FFN_NORM, dt.F16, torch.ones(full["dim"], dtype=torch.float16, device=dev))
         n_exp = full.get("experts", 0)
         for tid, kind in synth.MATRICES:
+            if tid == W.T_W3 and not full.get("is_glu", 1):
+                continue
             rows, cols = synth._shape(kind, full)
             if n_exp and tid in (W.T_W1, W.T_W2, W.T_W3):      # experts: sliced like the dense FFN, one set per expert
                 for e in range(n_exp):
@@ -300,6 +302,79 @@ class TPRunner:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) if n > 1 else 0.0
         return [int(x) for x in self.ring[:n].cpu().numpy()], ms
+
+    def export_host_tensors(self):
+        raise NotImplementedError("CPU baseline runs on the single-worker runner only")
+
+
+class CTPRunner:
+    """The same partition driven from C: every exchange is a collective of the C ABI (csrc/ifa_comm.hip, RCCL) enqueued on
+    the worker's stream by ifa_model_tp_prefill / ifa_model_tp_decode, the step is one hipGraph.  torch.distributed only
+    carries the 128-byte communicator ids at start-up (any host channel would do)."""
+
+    backend = "c-abi (ifa_comm.hip: RCCL all-reduce / all-gather / send / recv / broadcast)"
+
+    def __init__(self, shape_name, wdtype, kv_dtype, max_ctx, world, rank, local_rank, groups=1, **overrides):
+        import os
+        if world % groups:
+            raise ValueError("world size %d is not a multiple of the number of device groups %d" % (world, groups))
+        n_layers = dict(synth.SHAPES[shape_name], **{k: v for k, v in overrides.items() if k == "layers"})["layers"]
+        ranges = split_layers(n_layers, groups)
+        groups = len(ranges)
+        tp_size = world // groups
+        self.stage, self.tp_rank = rank // tp_size, rank % tp_size
+        self.n_stages, self.world, self.rank = groups, world, rank
+        self.force_collectives = bool(os.environ.get("IFA_FORCE_TP"))
+        dev = "cuda:%d" % local_rank
+
+        def share_id(src, make):
+            """128-byte RCCL id from job rank `src` to everybody"""
+            buf = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if make:
+                buf.copy_(torch.frombuffer(bytearray(W.Comm.unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(buf, src=src)
+            return bytes(buf.cpu().numpy().tobytes())
+
+        self.world_comm = None
+        if groups > 1:
+            self.world_comm = W.Comm(share_id(0, rank == 0), world, rank, local_rank)
+        self.tp_comm = None
+        if tp_size > 1 or self.force_collectives:
+            ids = [share_id(g * tp_size, rank == g * tp_size) for g in range(groups)]     # collective: same order on every rank
+            self.tp_comm = W.Comm(ids[self.stage], tp_size, self.tp_rank, local_rank)
+        self.worker, self.shape, self.local_shape = build_tp_worker(
+            shape_name, wdtype, kv_dtype, max_ctx, tp_size, self.tp_rank, device=local_rank, layer_range=ranges[self.stage],
+            first_stage=self.stage == 0, last_stage=self.stage == groups - 1, **overrides)
+        ok, why = self.worker.fused_supported()
+        if not ok:
+            raise RuntimeError("fused decode path unavailable on rank %d: %s" % (rank, why))
+        self.topo = dict(tp=self.tp_comm, world=self.world_comm, stage=self.stage, n_stages=groups,
+                         prev_rank=rank - tp_size if self.stage > 0 else -1,
+                         next_rank=rank + tp_size if self.stage + 1 < groups else -1,
+                         token_src=(groups - 1) * tp_size, vocab_offset=self.tp_rank * (self.shape["vocab"] // tp_size),
+                         force_collectives=self.force_collectives)
+
+    def prefill(self, prompt):
+        import ctypes as C
+        from ._capi import check, lib
+        toks = np.ascontiguousarray(prompt, np.int32)
+        topo = W.TpTopology(self.topo["tp"]._h if self.topo["tp"] else None, self.topo["world"]._h if self.topo["world"] else None,
+                            self.topo["stage"], self.topo["n_stages"], self.topo["prev_rank"], self.topo["next_rank"],
+                            self.topo["token_src"], self.topo["vocab_offset"], 1 if self.topo["force_collectives"] else 0)
+        nxt = C.c_int(-1)
+        check(lib().ifa_model_tp_prefill(self.worker._h, C.byref(topo), toks.ctypes.data_as(C.c_void_p), toks.size, 0, None, C.byref(nxt)))
+        return nxt.value
+
+    def decode(self, tok, pos, n):
+        out, ms_total = [], 0.0
+        while n > 0:
+            k = min(n, 1024)
+            t, ms = W.tp_decode(self.worker, tok, pos, k, **self.topo)
+            out.extend(int(x) for x in t)
+            ms_total += ms
+            tok, pos, n = int(t[-1]), pos + k, n - k
+        return out, ms_total
 
     def export_host_tensors(self):
         raise NotImplementedError("CPU baseline runs on the single-worker runner only")

@@ -47,11 +47,16 @@ def test_bad_spec_json(tmp_path):
         InferenceEngine.from_ini(ini)
 
 
-def test_multi_gpu_groups_are_refused_by_the_single_process_engine(tmp_path):
+def test_device_groups_are_validated_before_anything_is_loaded(tmp_path):
+    """devices = 0&1;2 -> groups of different sizes (inference_engine.cc:1738-1783); a device named twice; a device
+    that does not exist: all refused with the reference's kind of message, on a box with or without GPUs"""
     ini, _ = fx.write_model_dir(str(tmp_path), fmt="synthetic")
     text = open(ini).read()
-    open(ini, "w").write(text.replace("devices = 0", "devices = 0&1"))
-    with pytest.raises(EngineError, match="one process per GPU"):
+    open(ini, "w").write(text.replace("devices = 0", "devices = 0&1;2"))
+    with pytest.raises(EngineError, match="same size"):
+        InferenceEngine.from_ini(ini)
+    open(ini, "w").write(text.replace("devices = 0", "devices = 0&977"))
+    with pytest.raises(EngineError, match="not available"):
         InferenceEngine.from_ini(ini)
 
 
