@@ -118,6 +118,12 @@ typedef struct {
     /* id the greedy selection never offers: the vocabulary's unk id (GetSortedTopK, sampling_strategy.cc:281-297;
      * StdVocabulary's default is 0); < 0: none */
     int unk_id;
+    /* BY_TENSOR partition restated (network_builder.cc:1594-1686; merge: inference_worker.cc:2148-2195, :1378-1391,
+     * :1882-1895): with tp_merge = P > 1 the wo and w2 products are formed as P partial products over contiguous column
+     * ranges, each rounded to F16 like a rank's output tensor, summed in half in rank order 0, 1, 2 ..., and the bias
+     * is added once after the merge.  Row-split matrices (wq/wk/wv/w1/w3), head-split attention and the block-local Q8
+     * activation quantiser give the same values on any number of ranks, so this is the partition's whole arithmetic. */
+    int tp_merge;
 } orc_model_cfg;
 
 typedef struct orc_model orc_model;

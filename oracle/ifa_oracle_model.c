@@ -137,6 +137,34 @@ static int matmul(const orc_model *m, const orc_f16 *A, int T, const orc_tensor 
     return 0;
 }
 
+/* The same product as P column-range partials merged in rank order (see orc_model_cfg.tp_merge). */
+static int matmul_merged(const orc_model *m, const orc_f16 *A, int T, const orc_tensor *W,
+                         const orc_tensor *bias, orc_f16 *C)
+{
+    const int P = m->cfg.tp_merge;
+    if (P <= 1) return matmul(m, A, T, W, bias, C);
+    if (!W->data) return -1;
+    const size_t K = W->cols, N = W->rows, Kp = K / (size_t)P;
+    const size_t cap = is_quant(W->dtype) ? (size_t)orc_block_capacity(W->dtype) : 1;
+    if (K % (size_t)P || Kp % cap || (is_quant(W->dtype) && Kp % 32)) return -20;
+    const size_t rb_full = orc_row_bytes(W->dtype, K), rb = orc_row_bytes(W->dtype, Kp);
+    uint8_t *ws = (uint8_t *)malloc(rb * N);
+    orc_f16 *as = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * Kp);
+    orc_f16 *part = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * N);
+    int rc = 0;
+    for (int p = 0; p < P && rc == 0; p++) {
+        for (size_t r = 0; r < N; r++) memcpy(ws + r * rb, (const uint8_t *)W->data + r * rb_full + (size_t)p * rb, rb);
+        for (int t = 0; t < T; t++) memcpy(as + (size_t)t * Kp, A + (size_t)t * K + (size_t)p * Kp, Kp * sizeof(orc_f16));
+        orc_tensor sub = *W;
+        sub.data = ws; sub.cols = Kp;
+        rc = matmul(m, as, T, &sub, NULL, p == 0 ? C : part);
+        if (rc == 0 && p > 0) orc_add(C, part, (size_t)T * N, 0, C);       /* MergeTensors: half add, rank order */
+    }
+    if (rc == 0 && bias && bias->data) orc_add(C, (const orc_f16 *)bias->data, (size_t)T * N, N, C);   /* bias once, after the merge */
+    free(ws); free(as); free(part);
+    return rc;
+}
+
 static int scale_on(float s) { return s > 0.0f && (s < 0.9999f || s > 1.0001f); }
 
 static void norm_rows(const orc_model *m, const orc_f16 *x, int T, const orc_tensor *w,
@@ -165,7 +193,7 @@ static int ffn_dense(const orc_model *m, const orc_f16 *in, int T, const orc_ten
             if (rc == 0) orc_mul(t1, t2, (size_t)T * F, t1);
         }
     }
-    if (rc == 0) rc = matmul(m, t1, T, w2, w2b, out);
+    if (rc == 0) rc = matmul_merged(m, t1, T, w2, w2b, out);
     (void)D;
     free(t1); free(t2);
     return rc;
@@ -234,7 +262,7 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
         orc_attention(q, L->kcache, L->vcache, kvt, prefix_len + T, T, prefix_len, c->heads,
                       c->kv_heads, c->head_dim, c->use_alibi ? 1.0f : c->kq_scale, c->use_alibi,
                       0, c->heads, att);
-        rc = matmul(m, att, T, &L->t[ORC_T_WO], &L->t[ORC_T_WO_B], a); if (rc) break;
+        rc = matmul_merged(m, att, T, &L->t[ORC_T_WO], &L->t[ORC_T_WO_B], a); if (rc) break;
         if (scale_on(c->attn_out_scale)) orc_scale(a, c->attn_out_scale, (size_t)T * D, a);   /* :842-843 */
         /* residual (inference_worker.cc:847-851) */
         if (!c->parallel_attn && !c->share_input) orc_add(x, a, (size_t)T * D, 0, a);

@@ -22,11 +22,11 @@ def _close(a, b):
     return cos, float(np.abs(a - b).max())
 
 
-def _run_against_oracle(tmp_path, devices, force, wd_name="Q4", wd=dt.Q4_B32T1A, kv_name="F16", kvd=dt.F16, steps=12):
+def _run_against_oracle(tmp_path, devices, force, wd_name="Q4", wd=dt.Q4_B32T1A, kv_name="F16", kvd=dt.F16, steps=12, tp_merge=1):
     ini, w = fx.write_model_dir(str(tmp_path), fmt="llama2.c", wd=wd_name, kvd=kv_name, devices=devices, force_partition=force)
     eng = InferenceEngine.from_ini(ini)
     s = fx.SHAPE
-    om = oracle_model_from_host(fx.host_tensors(w, s, wd), s, 64, kvd, rope_order=1, unk_id=0)
+    om = oracle_model_from_host(fx.host_tensors(w, s, wd), s, 64, kvd, rope_order=1, unk_id=0, tp_merge=tp_merge)
     prompt = np.random.default_rng(3).integers(3, 1000, 9).astype(np.int32)
     qid = eng.add_query(prompt)
     (q, tok), = eng.infer()                           # the prompt through the partition, full logits assembled from the shards
@@ -48,7 +48,9 @@ def _run_against_oracle(tmp_path, devices, force, wd_name="Q4", wd=dt.Q4_B32T1A,
         (q, tok), = eng.infer()
         row = eng.last_logits(qid)
         cos, mad = _close(row[0], l_or[0])
-        assert cos >= 0.9995 and mad <= LOGIT_TOL, (step, cos, mad)
+        # decode steps on a Q4 model: one activation code flipping at a rounding tie moves a logit by a few 1e-2
+        # (tests/test_gpu_engine.py uses the same relative term for quantised decode logits)
+        assert cos >= 0.9995 and mad <= LOGIT_TOL + 0.01 * float(np.abs(l_or[0].astype(np.float32)).max()), (step, cos, mad)
         lo = l_or[0].astype(np.float32).copy(); lo[0] = -np.inf
         top2 = np.sort(lo)[-2:]
         if top2[1] - top2[0] > LOGIT_TOL:
@@ -89,9 +91,9 @@ def test_partition_path_follows_single_worker_path(tmp_path):
 @pytest.mark.skipif(NGPU < 2, reason="needs 2 GPUs")
 @pytest.mark.parametrize("devices", ["0&1", "0;1"], ids=["by_tensor", "by_layer"])
 def test_two_gpu_partitions_match_oracle(tmp_path, devices):
-    assert _run_against_oracle(tmp_path, devices, "false") == 2
+    assert _run_against_oracle(tmp_path, devices, "false", tp_merge=2 if "&" in devices else 1) == 2
 
 
 @pytest.mark.skipif(NGPU < 4, reason="needs 4 GPUs")
 def test_hybrid_2x2_matches_oracle(tmp_path):
-    assert _run_against_oracle(tmp_path, "0&1;2&3", "false") == 4
+    assert _run_against_oracle(tmp_path, "0&1;2&3", "false", tp_merge=2) == 4
