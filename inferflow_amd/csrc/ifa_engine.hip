@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(256) k_touch(const uint8_t *__restrict__ p, si
     if (acc == 0x7FFFFFFF) *sink = acc;
 }
 
+static constexpr size_t IFA_LDS_LIMIT = 160 * 1024;      // LDS per workgroup on gfx950 (MI355X_MICROARCH.md)
 static long long *g_trace_ptr = nullptr;   // set by ifa_model_time_kernel when the "trace" option is on
 static int num_cus() { return dec_num_cus(); }
 
@@ -180,6 +181,7 @@ static bool fused_supported(const ifa_model *m, std::string *why)
     if (!c.full_quant_gemv) return fail("full_quant_gemv disabled");
     if (c.head_dim != 32 && c.head_dim != 64 && c.head_dim != 128) return fail("fused attention supports head_dim 32/64/128");
     if (c.kv_dtype == Q8_B32T2 && c.head_dim % 32 != 0) return fail("Q8 KV needs head_dim % 32 == 0");
+    if (dec_attn_pv_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT) return fail("max_context_len too large for the fused attention kernels' LDS (decode falls back to the op-by-op path)");
     if (c.dim % 32 != 0 || c.ffn % 32 != 0) return fail("dim/ffn must be multiples of 32");
     if (c.dim > 8192) return fail("fused norm prologue supports dim <= 8192");
     for (const Layer &L : m->layers) {
@@ -272,13 +274,19 @@ static int launch_attn(ifa_model *m, int l)
     A.rope_order = c.rope_order; A.rope_cols = rope_dims;
     A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
     A.out = m->att; A.max_ctx = c.max_ctx; A.xq = m->attq;
-    if (m->attn_split) {
+    // the one-workgroup kernel keeps a head's score row [max_ctx] in LDS: past the device limit (160 KiB: ~75K tokens of
+    // context at head_dim 128) the keys-split-over-workgroups kernels run from position 0 on (scores in global memory)
+    const bool lds_split = dec_attn_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT;
+    if (m->attn_split || lds_split) {
         const dim3 g2((unsigned)c.heads, DEC_ATTN_SPLITS);
         const size_t psmem = dec_attn_pv_smem(c.head_dim, c.max_ctx);
+        if (psmem > IFA_LDS_LIMIT) return ifa_fail(IFA_ERR_ARG, "fused attention: max_context_len %d needs %zu bytes of LDS per workgroup", c.max_ctx, psmem);
 #define IFA_ATTN_S(HDV) \
     case HDV: if (A.kv_q8) { k_dec_attn_scores<HDV, true><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
+                             if (psmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_pv<HDV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmem)); \
                              k_dec_attn_pv<HDV, true><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
               else { k_dec_attn_scores<HDV, false><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
+                     if (psmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_pv<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmem)); \
                      k_dec_attn_pv<HDV, false><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
               k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att, m->attq, c.heads); break;
         switch (c.head_dim) {
@@ -291,9 +299,12 @@ static int launch_attn(ifa_model *m, int l)
     }
     const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx);
     const dim3 grid((unsigned)c.heads), block(256);
+    // (attention_lds_ok() routed contexts whose score row does not fit the 160 KiB LDS to the split kernels above)
 #define IFA_ATTN(HDV) \
-    case HDV: if (A.kv_q8) k_dec_attn<HDV, true><<<grid, block, asmem, m->stream>>>(A); \
-              else k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A); break;
+    case HDV: if (A.kv_q8) { if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
+                             k_dec_attn<HDV, true><<<grid, block, asmem, m->stream>>>(A); } \
+              else { if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
+                     k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A); } break;
     switch (c.head_dim) {
         IFA_ATTN(32) IFA_ATTN(64) IFA_ATTN(128)
     default: return ifa_fail(IFA_ERR_ARG, "fused attention: head_dim %d", c.head_dim);
@@ -1101,6 +1112,36 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
                 "ifa_model_set_tensor: expert %d (of %d) / tensor %d", expert, m->cfg.experts, tensor_id);
     IFA_REQUIRE(block_capacity(dtype) > 0 && dtype != F32, "ifa_model_set_tensor: dtype %d", dtype);
     IFA_REQUIRE(cols % (size_t)block_capacity(dtype) == 0, "ifa_model_set_tensor: cols %zu vs block capacity", cols);
+    {   // the scratch buffers are sized from the config and the kernels are launched with the tensor's dimensions: a
+        // mismatch would write out of bounds on the device, so it is refused here (per-shard dimensions under TP)
+        const ifa_model_config &c = m->cfg;
+        const size_t D = (size_t)c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = (size_t)c.ffn;
+        size_t er = 0, ec = 0;        // expected rows / cols; 0 = free
+        bool vec = false;             // [1][n] vectors (norm weights, biases) may also arrive as [n][1]
+        switch (tensor_id) {
+        case T_EMBD: ec = D; break;
+        case T_LM_HEAD: ec = D; break;                      // rows: the vocabulary (or this rank's shard of it)
+        case T_OUT_NORM: case T_OUT_NORM_B: case T_ATTN_NORM: case T_ATTN_NORM_B: case T_FFN_NORM: case T_FFN_NORM_B:
+        case T_WO_B: case T_W2_B: vec = true; ec = D; break;
+        case T_WQ: er = QD; ec = D; break;
+        case T_WK: case T_WV: er = KVD; ec = D; break;
+        case T_WO: er = D; ec = QD; break;
+        case T_W1: case T_W3: er = F; ec = D; break;
+        case T_W2: er = D; ec = F; break;
+        case T_MOE_GATE: er = (size_t)c.experts; ec = D; break;
+        case T_WQ_B: vec = true; ec = QD; break;
+        case T_WK_B: case T_WV_B: vec = true; ec = KVD; break;
+        case T_W1_B: case T_W3_B: vec = true; ec = F; break;
+        default: break;
+        }
+        if (vec) IFA_REQUIRE(rows * cols == ec, "ifa_model_set_tensor: tensor %d holds %zu x %zu values, the model needs %zu", tensor_id, rows, cols, ec);
+        else {
+            IFA_REQUIRE(ec == 0 || cols == ec, "ifa_model_set_tensor: tensor %d has %zu columns, the model needs %zu", tensor_id, cols, ec);
+            IFA_REQUIRE(er == 0 || rows == er, "ifa_model_set_tensor: tensor %d has %zu rows, the model needs %zu", tensor_id, rows, er);
+        }
+        if (tensor_id == T_LM_HEAD && layer < 0) IFA_REQUIRE(rows <= (size_t)c.vocab, "ifa_model_set_tensor: lm_head has %zu rows, vocab is %d", rows, c.vocab);
+        if (tensor_id == T_EMBD) IFA_REQUIRE(rows <= (size_t)c.vocab, "ifa_model_set_tensor: %zu embedding rows, vocab is %d", rows, c.vocab);
+    }
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     Tensor *t;
     if (tensor_id < 10) t = &m->g[tensor_id];

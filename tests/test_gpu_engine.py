@@ -10,6 +10,7 @@ from tests import gpu_util as g
 from tests.model_util import oracle_model_from_host
 
 pytestmark = pytest.mark.gpu
+LOGIT_TOL = 0.03      # stated bound on |dlogit| vs the oracle (logit std ~0.5); greedy ids are compared whenever the oracle's top-2 gap exceeds it
 
 CASES = [
     ("test_gqa", dt.Q4_B32T1A, dt.F16),
@@ -51,21 +52,24 @@ def test_forward_and_fused_decode_match_oracle(shape, wd, kvd):
     # re-quantisation; stated bound: cosine >= 0.9995 and |dlogit| <= 0.03 (logit std ~0.5)
     assert cos >= 0.9995 and mad <= 0.03, (cos, mad)
     top2 = np.sort(lg_orc[-1].astype(np.float32))[-2:]
-    if top2[1] - top2[0] > 0.05:
+    if top2[1] - top2[0] > LOGIT_TOL:
         assert tok_gpu == tok_orc
 
-    # --- fused + graph decode vs oracle, greedy, token by token
+    # --- fused + graph decode vs oracle, greedy, token by token: the ids must be the oracle's whenever the oracle's
+    # top-2 gap exceeds the stated logit tolerance; steps inside it (a tie at this precision) follow the GPU and are counted
     n_steps = 12
     toks_fused, ms = wk.decode(tok_gpu, len(prompt), n_steps)
     assert ms > 0
-    cur = tok_gpu
+    cur, excused = tok_gpu, 0
     for i in range(n_steps):
         t_or, l_or = om.forward(np.array([cur], np.int32), len(prompt) + i)
         top2 = np.sort(l_or[0].astype(np.float32))[-2:]
-        if top2[1] - top2[0] <= 0.05:       # near tie: either choice is within tolerance; follow the GPU
+        if top2[1] - top2[0] <= LOGIT_TOL:
+            excused += int(int(toks_fused[i]) != t_or)
             cur = int(toks_fused[i]); continue
         assert int(toks_fused[i]) == t_or, "step %d" % i
         cur = t_or
+    assert excused <= 2, excused
 
     # --- fused decode == op-by-op decode on the same worker (same rounding points)
     wk.reset()
@@ -117,7 +121,7 @@ def test_long_prompt_prefill_through_the_library_gemm_matches_oracle(wd, kvd):
     cos2, mad2 = _logits_close(g.host(lg), lg_lib)
     assert cos2 >= 0.9999 and mad2 <= 0.02, (cos2, mad2)
     top2 = np.sort(lg_orc[-1].astype(np.float32))[-2:]
-    if top2[1] - top2[0] > 0.05:
+    if top2[1] - top2[0] > LOGIT_TOL:
         assert tok_lib == tok_orc == tok_own
     # a second pass over the same prompt reuses the per-stream context (scratch copy, plans) and reproduces the logits
     wk.reset()
@@ -227,7 +231,7 @@ def test_other_wirings_fused_and_op_path(name, cfg, bias):
     for i in range(6):
         t_o, l_o = om.forward(np.array([cur], np.int32), len(prompt) + i, nthreads=4)
         top2 = np.sort(l_o[0].astype(np.float32))[-2:]
-        assert int(toks[i]) == t_o or top2[1] - top2[0] <= 0.05, "step %d" % i
+        assert int(toks[i]) == t_o or top2[1] - top2[0] <= LOGIT_TOL, "step %d" % i
         cur = int(toks[i])
     wk.set_option("fused", 0)
     toks_ops, _ = wk.decode(tok, len(prompt), 6)
@@ -259,7 +263,7 @@ def test_moe_layers_match_oracle(wd, kvd):
     for i in range(n):
         t_or, l_or = om.forward(np.array([cur], np.int32), len(prompt) + i, nthreads=4)
         top2 = np.sort(l_or[0].astype(np.float32))[-2:]
-        if top2[1] - top2[0] > 0.05:
+        if top2[1] - top2[0] > LOGIT_TOL:
             assert int(fused[i]) == t_or, "step %d" % i
         cur = int(fused[i])
     wk.set_option("fused", 0)
@@ -292,7 +296,7 @@ def test_long_context_split_attention_matches_single_workgroup_kernel(kvd):
     om.forward(prompt, 0, nthreads=8)
     t_or, l_or = om.forward(np.array([tok], np.int32), len(prompt), nthreads=8)
     top2 = np.sort(l_or[0].astype(np.float32))[-2:]
-    if top2[1] - top2[0] > 0.05:
+    if top2[1] - top2[0] > LOGIT_TOL:
         assert int(got[0]) == t_or
     wk.close()
 
@@ -308,10 +312,14 @@ def test_dynamic_batching_rows_are_independent_queries(kvd):
     wk.kv_slots(6)
     rng = np.random.default_rng(23)
     prompts = [rng.integers(3, V, n).astype(np.int32) for n in (5, 11, 8)]
+    # one ORACLE per query (own KV cache), with the arithmetic of the reference's T > 1 branch that a batched step runs
+    # (F16 activations on dequantised weights: MatrixMultiplication, inference_worker.cc:2374-2415)
+    oms = [oracle_model_from_host(host, s, 64, kvd, full_quant_gemv=0) for _ in prompts]
     first = []
     for i, pr in enumerate(prompts):          # slots 0..2 (batched) and 3..5 (each query alone) hold the same prefills
         wk.select_kv(i); first.append(wk.forward(pr, 0))
         wk.select_kv(3 + i); assert wk.forward(pr, 0) == first[i]
+        oms[i].forward(pr, 0, want_logits=False, nthreads=4)
     cur = list(first)
     pos = [len(p) for p in prompts]
     lg = torch.empty((3, V), dtype=torch.float16, device="cuda")
@@ -321,6 +329,13 @@ def test_dynamic_batching_rows_are_independent_queries(kvd):
     for step in range(6):
         nxt = wk.decode_batch(cur, pos, [0, 1, 2], lg)
         rows = g.host(lg).copy()
+        for i in range(3):                     # every batched row against the oracle of its query, engine-test tolerance
+            t_o, l_o = oms[i].forward(np.array([cur[i]], np.int32), pos[i], nthreads=4)
+            cos_o, mad_o = _logits_close(rows[i], l_o[0])
+            assert cos_o >= 0.9995 and mad_o <= LOGIT_TOL, (step, i, cos_o, mad_o)
+            top2 = np.sort(l_o[0].astype(np.float32))[-2:]
+            if top2[1] - top2[0] > LOGIT_TOL:
+                assert int(nxt[i]) == t_o, (step, i)
         for i in range(3):                     # the same step for query i alone, on its own copy of the cache
             wk.select_kv(3 + i)
             t1 = wk.forward(np.array([cur[i]], np.int32), pos[i], lg1)

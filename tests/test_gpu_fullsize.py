@@ -59,11 +59,13 @@ def test_llama2_7b_width_other_formats_fused_equals_unfused(wd, kvd):
 
 
 @pytest.mark.parametrize("shape,wd", [("yi_34b", dt.Q4_B32T1A), ("yi_34b", dt.Q3H_B64T1), ("llama2_70b", dt.Q4_B32T1A),
-                                      ("llama2_70b", dt.Q8_B32T2)],
-                         ids=["yi34b_q4", "yi34b_q3h", "70b_q4", "70b_q8"])
+                                      ("llama2_70b", dt.Q8_B32T2), ("falcon_40b", dt.Q4_B32T1A)],
+                         ids=["yi34b_q4", "yi34b_q3h", "70b_q4", "70b_q8", "falcon40b_q4"])
 def test_long_rows_fused_equals_unfused(shape, wd):
-    """w2 rows of 20480 / 28672 columns do not fit a lane's register image: the chunked, software-pipelined kernel
-    (k_dec_gemv_long) must continue the same per-lane accumulation chain -> bit-identical to the op-level GEMV."""
+    """w2 rows of 20480 / 28672 / 32768 columns do not fit a lane's register image: the chunked, software-pipelined kernel
+    (k_dec_gemv_long) must continue the same per-lane accumulation chain -> bit-identical to the op-level GEMV.
+    falcon_40b: full Falcon-40B widths (configs[3]): 8192 / 32768 columns, 128 heads of 64 over 8 KV heads, LayerNorm,
+    GELU, plain MLP, shared MLP / attention input."""
     wk, _, s = synth.build(shape, wd, dt.F16, max_ctx=40, layers=2, vocab=8000)
     ok, why = wk.fused_supported()
     assert ok, why
