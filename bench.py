@@ -171,20 +171,25 @@ def main():
         for i, nm in enumerate(names):
             u = runner.worker.time_kernel(i, 160)
             per_kernel[nm] = {"us": u, "GBps": (kb[i] / u / 1e3) if kb[i] else None}
-        # HBM bytes per launch of that kernel from the PMC pass (rocprofv3 --pmc FETCH_SIZE, own run; summary and
-        # correction in profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py); null for other formats
-        traffic = None
+        # HBM bytes per launch of that kernel from the PMC pass (rocprofv3 --pmc FETCH_SIZE, own run: tools/profile_r02.sh;
+        # summary and correction in profiles/r02_pmc_traffic.json, produced by tools/pmc_summary.py).  The file names the
+        # build it was taken with (hash of the kernel sources): numbers of another build are NOT reported
+        traffic, traffic_note = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if wd == dt.Q4_B32T1A and args.shape == "llama2_7b":
+            from inferflow_amd.build import source_hash
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            if pmc.get("source_hash") != source_hash():
+                traffic_note = "profiles/r02_pmc_traffic.json was taken with kernel sources %s, this build is %s: stale, not reported" % (
+                    pmc.get("source_hash"), source_hash())
+            elif wd == dt.Q4_B32T1A and args.shape == "llama2_7b":
                 import re                                                                     # <DT 13, NJ 2, RW any, EPI_GLU 2, NORM 1, ...>
                 traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()     # demangled or mangled name
                            if re.match(r"ifa::k_dec_gemv<13, 2, \d+, 2, 1", k) or re.match(r"_ZN3ifa10k_dec_gemvILi13ELi2ELi\d+ELi2ELi1E", k)][0]
-        except Exception:
-            traffic = None
+        except Exception as e:
+            traffic, traffic_note = None, "no PMC summary: %r" % (e,)
         out["roofline"] = {"bound": "hbm", "kernel": "k_dec_gemv<%s, EPI_GLU> (fused RMSNorm+Q8 quant+W1/W3 GEMV+SiLU*mul)" % dt.name(wd),
                            "achieved": ffn13_bytes / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic,
+                           "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
                            "bytes_per_launch": ffn13_bytes, "us_per_launch": us}
         out["kernels"] = per_kernel
     # ---- prefill rate at longer prompts (16 / 128 / 1024-token prompts), outside the timed decode region

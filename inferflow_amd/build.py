@@ -47,6 +47,15 @@ def host_sources():
     return sorted(s for s in glob.glob(os.path.join(HOST, "*.cc")) if not s.endswith("_main.cc"))
 
 
+def source_hash():
+    """Identity of the kernel sources a profile was taken with (bench.py refuses PMC numbers of another build)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True

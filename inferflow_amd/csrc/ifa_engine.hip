@@ -324,7 +324,7 @@ static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nul
     // the attention kernel left its output quantised (XqImage): the GEMV needs no prologue.  Rows longer than a lane's
     // register image (chunked kernel) keep the in-kernel quantiser
     const bool preq = m->attq && m->opt_attn_q8 && P.cols == m->cfg.heads * m->cfg.head_dim && dec_gemv_supported(L.t[T_WO].dtype, (size_t)P.cols);
-    if (preq) P.xq = m->attq;
+    if (preq) P.x = reinterpret_cast<const half_t *>(m->attq);      // NORM == 2 kernels read the quantised image through P.x
     if (partial) {
         P.y[0] = partial;
         return preq ? launch_dec_gemv<EPI_PLAIN, 2>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream)

@@ -5,12 +5,16 @@ per decode kernel the average FETCH_SIZE per launch, corrected as MI355X_MICROAR
 calibrated here on the F16 lm_head kernel whose byte count is known exactly).
 
     cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d OUT -o pmc -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline
-    python tools/pmc_summary.py OUT/pmc_counter_collection.csv profiles/r01_pmc_traffic.json
+    python tools/pmc_summary.py OUT/pmc_counter_collection.csv profiles/r02_pmc_traffic.json
 """
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from inferflow_amd.build import source_hash  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
@@ -18,7 +22,7 @@ for r in csv.DictReader(open(src)):
     n = r["Kernel_Name"]
     if "k_dec" in n and r["Counter_Name"] == "FETCH_SIZE":
         agg[n.replace("void ", "").split("(")[0]].append(float(r["Counter_Value"]))
-out = {"counter": "FETCH_SIZE (KiB, rocprofv3 --pmc, own pass)", "correction": "bytes = KiB * 1024 * 2 (gfx950: 128-B requests tallied at 64 B)",
+out = {"source_hash": source_hash(), "counter": "FETCH_SIZE (KiB, rocprofv3 --pmc, own pass)", "correction": "bytes = KiB * 1024 * 2 (gfx950: 128-B requests tallied at 64 B)",
        "kernels": {}}
 for k, v in sorted(agg.items()):
     out["kernels"][k] = {"launches": len(v), "fetch_kib_avg": sum(v) / len(v), "hbm_bytes_per_launch": sum(v) / len(v) * 1024 * 2}
