@@ -47,6 +47,47 @@ def cpu_baseline(wk_host_tensors, shape, n_tokens, threads, kv_dtype):
     return n_tokens / dt_s, dt_s
 
 
+def reference_cpu_baseline(n_tokens=128):
+    """Times the reference's CPU inference path (the real thing, not a port) and this engine on one checkpoint."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import oracle as o
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen_model_fixtures as gmf
+    from inferflow_amd.engine import InferenceEngine
+    from tests import engine_fixtures as fx
+    if not os.path.exists(gmf.DRIVER):
+        raise RuntimeError("oracle/_ref/ifa_ref_engine is not built (needs /root/reference at build time)")
+    shape = dict(dim=288, layers=6, heads=6, kv_heads=6, head_dim=48, ffn=768, vocab=32000)      # stories15M (llm_inference.tiny.ini)
+    threads = min(o.usable_cpus(), 16)
+    d = tempfile.mkdtemp(prefix="ifa_ref_cpu_")
+    try:
+        ini, _ = gmf.write_ref_model_dir(d + "/", shape, seed=15, std=0.05, ctx=256, shared=True)
+        txt = open(ini).read().replace("cpu_threads = 4", "cpu_threads = %d" % threads).replace("return_output_tensors = true", "return_output_tensors = false")
+        open(ini, "w").write(txt)
+        prompt = np.random.default_rng(15).integers(3, shape["vocab"], PROMPT_LEN).astype(np.int32)
+        r = gmf.run_reference(ini, prompt, n_tokens + 1, quiet=True)
+        ref_tok_s = n_tokens / (r["decode_ms"] / 1e3)
+        # this engine on the same file (F16 weights like the tiny .ini; op-by-op path: 48-wide heads are outside the fused kernels)
+        gdir = os.path.join(d, "gpu")
+        gini, _ = fx.write_model_dir(gdir, fmt="llama2.c", wd="F16", kvd="F16", ctx=256, s=shape, seed=15, std=0.05, shared_classifier=True, ret="false")
+        eng = InferenceEngine.from_ini(gini)
+        qid = eng.add_query(prompt)
+        eng.generate(qid, 8)
+        t0 = time.perf_counter()
+        gen, _ = eng.generate(qid, n_tokens)
+        gpu_tok_s = n_tokens / (time.perf_counter() - t0)
+        eng.close()
+        return {"value": ref_tok_s, "unit": "tokens/s", "cores": threads, "kind": "reference",
+                "sample": "the reference's CPU path (oracle/_ref/ifa_ref_engine) on a stories15M-shaped llama2.c checkpoint (configs[0]: "
+                          "d 288, 6 layers, vocab 32000, F32 weights), %d-token prompt + %d greedy tokens, cpu_threads %d; prefill %.1f ms"
+                          % (PROMPT_LEN, n_tokens, threads, r["prefill_ms"]),
+                "gpu_same_checkpoint_tok_s": gpu_tok_s}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +265,14 @@ def main():
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
+    # ---- the REFERENCE's own CPU path (oracle/_ref/ifa_ref_engine: /root/reference sources compiled by oracle/Makefile,
+    # travels prebuilt) on configs[0] -- the stories15M-shaped llama2.c checkpoint of bin/llm_inference.tiny.ini, the case
+    # the reference itself runs on CPU -- with this engine on the very same checkpoint next to it
+    if world == 1 and not args.no_cpu_baseline and not os.environ.get("IFA_FORCE_TP"):
+        try:
+            out["cpu_baseline_reference"] = reference_cpu_baseline()
+        except Exception as e:
+            out["cpu_baseline_reference"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)

@@ -109,6 +109,11 @@ int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x
 /* sets the token count from which ifa_gemm hands the product to hipBLASLt (0 = never, < 0 = only query);
  * returns the previous threshold, or 0 when hipBLASLt could not be loaded.  Environment: IFA_GEMM_LT_MIN_TOKENS. */
 int ifa_gemm_library_min_tokens(int min_tokens);
+/* opt-in (default 0): tokens > 128 through the large-tile MFMA kernel (128 tokens x 256 / 128 weight rows per workgroup, the
+ * weight tile dequantised once per step into LDS by loader waves, MFMA waves beside them).  Bit-identical results to
+ * the other routes; slower than both in round 2 (profiles/r02_gemm_big.log), kept for the next round's work.  < 0 only
+ * queries; returns the previous setting */
+int ifa_gemm_big_tiles(int on);
 /* frees the F16 scratch / workspace the library path keeps for this stream on the current device (call before destroying
  * a stream that ran ifa_gemm with >= that many tokens; ifa_model_destroy / ifa_model_set_stream do it for the worker's) */
 int ifa_gemm_release_stream(ifa_stream stream);

@@ -284,6 +284,144 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_q(const uint8_t *__restrict__ 
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large T (prefill, MFMA-bound): 128 tokens x BN (256 / 128) weight rows per workgroup, K walked in steps of 64.
+//  * the weight tile is dequantised ONCE per workgroup and step into LDS (values rounded to half exactly like the
+//    reference's Dequantize tensor) and shared by the MFMA waves -- the small-T kernel above decodes a block per lane
+//    and MFMA tile, which bounds it at ~0.5 PFLOP/s (VALU per MFMA);
+//  * wave specialisation: waves 0-3 only multiply (a 2 x 2 grid of 64-token x BN/2-row sub-tiles, fragments from LDS),
+//    waves 4-7 only load and dequantise the NEXT step's tiles into the other LDS buffer.  The matrix pipe and the
+//    VALU of a SIMD run side by side (MI355X_MICROARCH.md "Wave scheduling"), so a step costs max(MFMA, dequantisation)
+//    instead of their sum; one barrier per step hands the buffers over;
+//  * rows of both LDS tiles are padded to 144 bytes: the 16-byte fragment reads of 16 consecutive lanes hit 16 disjoint
+//    groups of 4 banks (measured: SQ_LDS_BANK_CONFLICT = 0).
+// Same arithmetic as k_gemm_q: fp32 accumulation of half products, one F16 rounding, bias as a half add.
+constexpr int BIG_BM = 128, BIG_BK = 64, BIG_ROWB = BIG_BK * 2 + 16;     // LDS row stride in bytes
+
+template <int DT, int BN>
+__global__ void __launch_bounds__(512) k_gemm_big(const uint8_t *__restrict__ W, int N, int nblk,
+                                                  const half_t *__restrict__ X, int T, int K,
+                                                  const half_t *__restrict__ bias, half_t *__restrict__ Y, int dbg)
+{
+    constexpr int CAP = (DT == F16) ? 32 : block_capacity(DT);
+    constexpr int BPS = BIG_BK / CAP;                   // quant blocks per row and step (2 or 1)
+    constexpr int WB = (BN * BPS + 255) / 256;          // blocks a loader thread dequantises per step
+    constexpr int NT = BN / 64;                         // 32-row accumulator tiles per MFMA wave along N (4 or 2)
+    constexpr size_t TILE = (size_t)(BIG_BM + BN) * BIG_ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BN, t0 = blockIdx.y * BIG_BM;
+    const int nsteps = (K + BIG_BK - 1) / BIG_BK;
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int lt = tid - 256;
+        u32x4 xa[4];
+        WRaw<DT, CAP> wr[WB];
+        auto fetch = [&](int step) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {               // 128 rows x 8 chunks of 8 halfs
+                const int idx = lt + c * 256;
+                const int r = idx >> 3, cc = idx & 7;
+                const int tok = min(t0 + r, T - 1), k = min(step * BIG_BK + cc * 8, K - 8);
+                xa[c] = *reinterpret_cast<const u32x4 *>(X + (size_t)tok * K + k);
+            }
+#pragma unroll
+            for (int j = 0; j < WB; j++) {
+                const int idx = min(lt + j * 256, BN * BPS - 1);
+                const int nl = idx / BPS, b = idx % BPS;
+                wr[j].load(W, (size_t)min(n0 + nl, N - 1), nblk, min(step * BPS + b, nblk - 1));
+            }
+        };
+        auto stage = [&](int step) {                    // registers -> LDS buffer (step & 1)
+            char *As = smem + (size_t)(step & 1) * TILE, *Bs = As + (size_t)BIG_BM * BIG_ROWB;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int idx = lt + c * 256;
+                const int r = idx >> 3, cc = idx & 7;
+                const bool ok = (t0 + r < T) && (step * BIG_BK + cc * 8 < K);
+                *reinterpret_cast<u32x4 *>(As + (size_t)r * BIG_ROWB + (size_t)cc * 16) = ok ? xa[c] : u32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < WB; j++) {
+                const int idx = lt + j * 256;
+                if (idx >= BN * BPS) continue;
+                const int nl = idx / BPS, b = idx % BPS;
+                if (dbg & 1) continue;                  // (ablation: no dequantisation, no B stores)
+                half_t v[CAP];
+                wr[j].decode(step * BPS + b < nblk, v);
+#pragma unroll
+                for (int m = 0; m < CAP / 8; m++) {
+                    half8_t h;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) h[e] = v[8 * m + e];
+                    *reinterpret_cast<half8_t *>(Bs + (size_t)nl * BIG_ROWB + (size_t)(b * CAP + 8 * m) * 2) = h;
+                }
+            }
+        };
+        fetch(0);
+        stage(0);
+        if (nsteps > 1) fetch(1);
+        __syncthreads();                                // tile 0 is ready
+        for (int step = 0; step < nsteps; step++) {
+            // the MFMA waves multiply tile `step`; tile step + 1 goes into the other buffer (its previous content,
+            // tile step - 1, was released by the barrier that ended the previous iteration)
+            if (step + 1 < nsteps) {
+                stage(step + 1);
+                if (step + 2 < nsteps) fetch(step + 2);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- MFMA waves
+    const int i = lane & 31, g = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;            // this wave's 64-token x (BN/2)-row sub-tile
+    f32x16_t acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+    __syncthreads();                                    // tile 0 is ready
+    for (int step = 0; step < nsteps; step++) {
+        const char *As = smem + (size_t)(step & 1) * TILE, *Bs = As + (size_t)BIG_BM * BIG_ROWB;
+#pragma unroll
+        for (int ks = 0; ks < BIG_BK / 16; ks++) {
+            if (dbg & 2) continue;                      // (ablation: no fragment reads, no MFMAs)
+            half8_t af[2], bf[NT];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+                af[a] = *reinterpret_cast<const half8_t *>(As + (size_t)(wm * 64 + a * 32 + i) * BIG_ROWB + (size_t)(ks * 16 + 8 * g) * 2);
+#pragma unroll
+            for (int b = 0; b < NT; b++)
+                bf[b] = *reinterpret_cast<const half8_t *>(Bs + (size_t)(wn * (BN / 2) + b * 32 + i) * BIG_ROWB + (size_t)(ks * 16 + 8 * g) * 2);
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();                                // this tile may be overwritten, the next one is complete
+    }
+#pragma unroll
+    for (int b = 0; b < NT; b++) {
+        const int n = n0 + wn * (BN / 2) + b * 32 + i;
+        if (n >= N) continue;
+        const float bv = bias ? h2f(bias[n]) : 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tok = t0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (tok < T) {
+                    half_t y = f2h(acc[a][b][r]);
+                    if (bias) y = f2h(h2f(y) + bv);
+                    Y[(size_t)tok * N + n] = y;
+                }
+            }
+    }
+}
+
 } // namespace ifa
 
 using namespace ifa;
@@ -293,6 +431,14 @@ bool gemm_lt_wanted(size_t tokens);                  // ifa_gemm_lt.hip
 int gemm_lt(int w_dtype, const void *W, size_t N, size_t K, const void *X, size_t T, const void *bias, void *Y, hipStream_t s);
 }
 
+static int gemm_num_cus()
+{
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t prop; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+    return n;
+}
+static int g_gemm_big = 0;       // ifa_gemm_big_tiles(1): opt-in large-tile kernel for T > 128 (round 2: 0.44-0.52 PFLOP/s, behind the other routes; its load skeleton alone costs 57 % of its time -- tools/probes/gemm_big_ablation.py)
+
 template <int DT>
 static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t T, const void *bias, void *Y, hipStream_t s)
 {
@@ -300,6 +446,27 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
     const int nblk = (int)(K / CAP);
     constexpr int MT = 2;
     const size_t slab = (size_t)32 * MT * (2 * CAP * 2 + 16);
+    if (T > 128 && K % 8 == 0 && g_gemm_big) {
+        // MFMA-bound: the weight tile dequantised once per workgroup into LDS by loader waves, 128 x 256 output tiles
+        // (128 x 128 when the wider tile would leave compute units without a workgroup)
+        const bool wide = (size_t)ifa_cdiv(N, 256) * ifa_cdiv(T, BIG_BM) >= (size_t)gemm_num_cus();
+        if (wide) {
+            dim3 grid(ifa_cdiv(N, 256), ifa_cdiv(T, BIG_BM));
+            const size_t smem = 2 * (size_t)(BIG_BM + 256) * BIG_ROWB;
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_gemm_big<DT, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+            k_gemm_big<DT, 256><<<grid, dim3(512), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T, (int)K,
+                                                              (const half_t *)bias, (half_t *)Y, g_gemm_big >> 4);
+        } else {
+            dim3 grid(ifa_cdiv(N, 128), ifa_cdiv(T, BIG_BM));
+            const size_t smem = 2 * (size_t)(BIG_BM + 128) * BIG_ROWB;
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_gemm_big<DT, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+            k_gemm_big<DT, 128><<<grid, dim3(512), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T, (int)K,
+                                                              (const half_t *)bias, (half_t *)Y, g_gemm_big >> 4);
+        }
+        return IFA_OK;
+    }
     if (T > 128 && ifa_cdiv(N, GEMM_ROWS) * ifa_cdiv(T, 128) >= 256) {
         // enough tiles to fill the chip twice over with 128-token tiles: the dequantised block is reused for 4 MFMA tiles
         constexpr int MT4 = 4;
@@ -328,6 +495,13 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
                                                                       (int)K, (const half_t *)bias, (half_t *)Y);
     }
     return IFA_OK;
+}
+
+extern "C" int ifa_gemm_big_tiles(int on)
+{
+    const int prev = g_gemm_big;
+    if (on >= 0) g_gemm_big = on;      // bit 0: on; bits 4..: ablation switches of k_gemm_big (measurement)
+    return prev;
 }
 
 extern "C" int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x_f16, size_t tokens,
