@@ -281,6 +281,10 @@ int ifa_comm_unique_id(void *id_out_128);
 int ifa_comm_init_rank(const void *id_128, int nranks, int rank, int device, ifa_comm **out);
 /* one process, one host thread per GPU (the engine facade, like inference_engine.cc:1203-1206): all ranks at once */
 int ifa_comm_init_all(const int *device_ids, int n, ifa_comm **comms_out);
+/* a device list that names ONE device n times makes an in-process loopback group instead (RCCL refuses two ranks on a
+ * device): kernels / copies on that device with a host rendezvous between the rank threads -- host-synchronous, not
+ * capturable (ifa_comm_capturable() == 0); for exercising the multi-rank paths on a 1-GPU box */
+int ifa_comm_capturable(const ifa_comm *c);
 int ifa_comm_destroy(ifa_comm *c);
 int ifa_comm_rank(const ifa_comm *c);
 int ifa_comm_size(const ifa_comm *c);
@@ -338,10 +342,16 @@ typedef struct {
 int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_token, int start_pos, int n_steps,
                         int *out_tokens_host, float *elapsed_ms);
 /* One Infer() step of a query over the partition: n_tokens new tokens at [start_pos, start_pos + n_tokens) fed through
- * the decode path one after the other; *next_token_host = greedy next token of the last one (every rank).
+ * the partition: n_tokens > 1 as ONE T > 1 step (row-sliced MFMA GEMMs, [T][dim] merges after wo and w2, [T][dim]
+ * hand-over between layer groups), a single token through the decode path; *next_token_host = greedy next token of the
+ * last one (every rank).
  * logits_shard_out_dev (nullable; last device group): this rank's lm_head rows of every token, [n_tokens][rows] F16. */
 int ifa_model_tp_prefill(ifa_model *m, const ifa_tp_topology *topo, const int *tokens_host, int n_tokens, int start_pos,
                          void *logits_shard_out_dev, int *next_token_host);
+/* ifa_model_decode_batch over a tensor-parallel group (one new token for each of n queries; merges over [n][dim], one
+ * distributed argmax per row); logits_shard_out_dev: optional [n][this rank's lm_head rows] F16 */
+int ifa_model_tp_decode_batch(ifa_model *m, const ifa_tp_topology *topo, int n, const int *tokens_host, const int *positions_host,
+                              const int *kv_slots_host, int *next_tokens_host, void *logits_shard_out_dev);
 /* reference-layout copy of a loaded tensor (device pointer); returns 1 if the tensor is not set */
 int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols);
 /* Average duration (HIP events on the worker's stream) of `iters` back-to-back

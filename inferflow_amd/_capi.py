@@ -115,6 +115,7 @@ SIGNATURES = {
     "ifa_comm_init_rank": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     "ifa_comm_init_all": (_i, [_vp, _i, C.POINTER(_vp)]),
     "ifa_comm_destroy": (_i, [_vp]),
+    "ifa_comm_capturable": (_i, [_vp]),
     "ifa_comm_rank": (_i, [_vp]),
     "ifa_comm_size": (_i, [_vp]),
     "ifa_comm_group_start": (_i, []),
@@ -126,6 +127,7 @@ SIGNATURES = {
     "ifa_recv": (_i, [_vp, _vp, _sz, _i, _vp]),
     "ifa_model_tp_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ifa_model_tp_prefill": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "ifa_model_tp_decode_batch": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ifa_model_get_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
 }
 

@@ -15,16 +15,70 @@
 //     bytes to its peers by any host channel, every rank calls ifa_comm_init_rank;
 //   * one process, one host thread per GPU (the C++ InferenceEngine, like the reference's one sslib::Thread per
 //     GPU, inference_engine.cc:1203-1206): ifa_comm_init_all creates the communicators of all ranks at once.
+//
+// Loopback groups: RCCL refuses a communicator with two ranks on one device, which is all a 1-GPU box can offer.  When
+// ifa_comm_init_all is given a device list with duplicates, the ranks become an in-process group whose collectives are
+// plain kernels / copies on that device with a host rendezvous between the rank threads (host-synchronous, not
+// capturable: ifa_comm_capturable() == 0).  Same results by construction (sums in half, rank order); it exists so that
+// the multi-rank paths -- engine threads, slicing, merges, hand-over, distributed argmax -- run in the GPU tests.
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "ifa_host.h"
+#include "ifa_device.h"
+
+namespace {
+
+struct LocalGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    const void *sendp[64];
+    void *recvp[64];
+    struct Slot { const void *src = nullptr; size_t bytes = 0; bool full = false; } slots[64][64];
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = gen;
+        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+struct PtrTable { const void *send[64]; void *recv[64]; };
+
+// recv_r[i] = ((send_0[i] + send_1[i]) + send_2[i]) ... in half, rank order (MergeTensors, inference_worker.cc:2197-2260)
+__global__ void __launch_bounds__(256) k_local_allreduce_f16(const PtrTable t, int n, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ifa::half_t acc = reinterpret_cast<const ifa::half_t *>(t.send[0])[i];
+    for (int r = 1; r < n; r++) acc = ifa::f2h(ifa::h2f(acc) + ifa::h2f(reinterpret_cast<const ifa::half_t *>(t.send[r])[i]));
+    for (int r = 0; r < n; r++) reinterpret_cast<ifa::half_t *>(t.recv[r])[i] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_local_allgather(const PtrTable t, int n, size_t bytes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bytes * (size_t)n) return;
+    const int src = (int)(i / bytes);
+    const uint8_t v = reinterpret_cast<const uint8_t *>(t.send[src])[i % bytes];
+    for (int r = 0; r < n; r++) reinterpret_cast<uint8_t *>(t.recv[r])[i] = v;
+}
+
+} // namespace
 
 struct ifa_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
+    std::shared_ptr<LocalGroup> local;      // loopback group (ranks sharing a device); comm == nullptr then
 };
 
 #define IFA_NCCL_CHECK(expr)                                                                  \
@@ -64,6 +118,19 @@ int ifa_comm_init_rank(const void *id_128, int nranks, int rank, int device, ifa
 int ifa_comm_init_all(const int *device_ids, int n, ifa_comm **comms_out)
 {
     IFA_REQUIRE(device_ids && comms_out && n >= 1 && n <= 64, "ifa_comm_init_all: n %d", n);
+    bool dup = false;
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) dup = dup || device_ids[i] == device_ids[j];
+    if (dup) {          // ranks sharing a device: in-process loopback group (see the header of this file)
+        for (int i = 1; i < n; i++) IFA_REQUIRE(device_ids[i] == device_ids[0], "ifa_comm_init_all: a loopback group lives on ONE device");
+        auto grp = std::make_shared<LocalGroup>();
+        grp->n = n;
+        for (int i = 0; i < n; i++) {
+            ifa_comm *c = new ifa_comm();
+            c->rank = i; c->nranks = n; c->device = device_ids[i]; c->local = grp;
+            comms_out[i] = c;
+        }
+        return IFA_OK;
+    }
     std::vector<ncclComm_t> cs((size_t)n);
     IFA_NCCL_CHECK(ncclCommInitAll(cs.data(), n, device_ids));
     for (int i = 0; i < n; i++) {
@@ -82,6 +149,7 @@ int ifa_comm_destroy(ifa_comm *c)
     return IFA_OK;
 }
 
+int ifa_comm_capturable(const ifa_comm *c) { return (c && c->local) ? 0 : 1; }
 int ifa_comm_rank(const ifa_comm *c) { return c ? c->rank : -1; }
 int ifa_comm_size(const ifa_comm *c) { return c ? c->nranks : 0; }
 
@@ -91,41 +159,110 @@ int ifa_comm_group_end(void) { IFA_NCCL_CHECK(ncclGroupEnd()); return IFA_OK; }
 
 int ifa_allreduce_sum_f16(ifa_comm *c, const void *send_f16, void *recv_f16, size_t count, ifa_stream stream)
 {
-    IFA_REQUIRE(c && c->comm && send_f16 && recv_f16, "ifa_allreduce_sum_f16: null pointer");
+    IFA_REQUIRE(c && (c->comm || c->local) && send_f16 && recv_f16, "ifa_allreduce_sum_f16: null pointer");
     if (count == 0) return IFA_OK;
+    if (c->local) {
+        LocalGroup &g = *c->local;
+        IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
+        { std::lock_guard<std::mutex> lk(g.mu); g.sendp[c->rank] = send_f16; g.recvp[c->rank] = recv_f16; }
+        g.barrier();
+        if (c->rank == 0) {
+            PtrTable t; memset(&t, 0, sizeof(t));
+            for (int r = 0; r < g.n; r++) { t.send[r] = g.sendp[r]; t.recv[r] = g.recvp[r]; }
+            k_local_allreduce_f16<<<dim3(ifa_cdiv(count, 256)), dim3(256), 0, ifa_s(stream)>>>(t, g.n, count);
+            IFA_LAUNCH_CHECK();
+            IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
+        }
+        g.barrier();
+        return IFA_OK;
+    }
     IFA_NCCL_CHECK(ncclAllReduce(send_f16, recv_f16, count, ncclFloat16, ncclSum, c->comm, ifa_s(stream)));
     return IFA_OK;
 }
 
 int ifa_allgather(ifa_comm *c, const void *send, void *recv, size_t bytes_per_rank, ifa_stream stream)
 {
-    IFA_REQUIRE(c && c->comm && send && recv, "ifa_allgather: null pointer");
+    IFA_REQUIRE(c && (c->comm || c->local) && send && recv, "ifa_allgather: null pointer");
     if (bytes_per_rank == 0) return IFA_OK;
+    if (c->local) {
+        LocalGroup &g = *c->local;
+        IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
+        { std::lock_guard<std::mutex> lk(g.mu); g.sendp[c->rank] = send; g.recvp[c->rank] = recv; }
+        g.barrier();
+        if (c->rank == 0) {
+            PtrTable t; memset(&t, 0, sizeof(t));
+            for (int r = 0; r < g.n; r++) { t.send[r] = g.sendp[r]; t.recv[r] = g.recvp[r]; }
+            k_local_allgather<<<dim3(ifa_cdiv(bytes_per_rank * (size_t)g.n, 256)), dim3(256), 0, ifa_s(stream)>>>(t, g.n, bytes_per_rank);
+            IFA_LAUNCH_CHECK();
+            IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
+        }
+        g.barrier();
+        return IFA_OK;
+    }
     IFA_NCCL_CHECK(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, c->comm, ifa_s(stream)));
     return IFA_OK;
 }
 
 int ifa_broadcast(ifa_comm *c, void *buf, size_t bytes, int root, ifa_stream stream)
 {
-    IFA_REQUIRE(c && c->comm && buf, "ifa_broadcast: null pointer");
+    IFA_REQUIRE(c && (c->comm || c->local) && buf, "ifa_broadcast: null pointer");
     IFA_REQUIRE(root >= 0 && root < c->nranks, "ifa_broadcast: root %d of %d", root, c->nranks);
     if (bytes == 0) return IFA_OK;
+    if (c->local) {
+        LocalGroup &g = *c->local;
+        IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
+        { std::lock_guard<std::mutex> lk(g.mu); g.recvp[c->rank] = buf; }
+        g.barrier();
+        if (c->rank != root) {
+            IFA_HIP_CHECK(hipMemcpyAsync(buf, g.recvp[root], bytes, hipMemcpyDeviceToDevice, ifa_s(stream)));
+            IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
+        }
+        g.barrier();
+        return IFA_OK;
+    }
     IFA_NCCL_CHECK(ncclBroadcast(buf, buf, bytes, ncclInt8, root, c->comm, ifa_s(stream)));
     return IFA_OK;
 }
 
 int ifa_send(ifa_comm *c, const void *buf, size_t bytes, int peer, ifa_stream stream)
 {
-    IFA_REQUIRE(c && c->comm && buf, "ifa_send: null pointer");
+    IFA_REQUIRE(c && (c->comm || c->local) && buf, "ifa_send: null pointer");
     IFA_REQUIRE(peer >= 0 && peer < c->nranks && peer != c->rank, "ifa_send: peer %d (rank %d of %d)", peer, c->rank, c->nranks);
+    if (c->local) {      // rendezvous: the receiver copies, then releases the slot
+        LocalGroup &g = *c->local;
+        IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
+        std::unique_lock<std::mutex> lk(g.mu);
+        LocalGroup::Slot &sl = g.slots[c->rank][peer];
+        g.cv.wait(lk, [&] { return !sl.full; });
+        sl.src = buf; sl.bytes = bytes; sl.full = true;
+        g.cv.notify_all();
+        g.cv.wait(lk, [&] { return !sl.full; });
+        return IFA_OK;
+    }
     IFA_NCCL_CHECK(ncclSend(buf, bytes, ncclInt8, peer, c->comm, ifa_s(stream)));
     return IFA_OK;
 }
 
 int ifa_recv(ifa_comm *c, void *buf, size_t bytes, int peer, ifa_stream stream)
 {
-    IFA_REQUIRE(c && c->comm && buf, "ifa_recv: null pointer");
+    IFA_REQUIRE(c && (c->comm || c->local) && buf, "ifa_recv: null pointer");
     IFA_REQUIRE(peer >= 0 && peer < c->nranks && peer != c->rank, "ifa_recv: peer %d (rank %d of %d)", peer, c->rank, c->nranks);
+    if (c->local) {
+        LocalGroup &g = *c->local;
+        const void *src = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(g.mu);
+            LocalGroup::Slot &sl = g.slots[peer][c->rank];
+            g.cv.wait(lk, [&] { return sl.full; });
+            IFA_REQUIRE(sl.bytes == bytes, "ifa_recv: %zu bytes expected, the peer sends %zu", bytes, sl.bytes);
+            src = sl.src;
+        }
+        IFA_HIP_CHECK(hipMemcpyAsync(buf, src, bytes, hipMemcpyDeviceToDevice, ifa_s(stream)));
+        IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
+        { std::lock_guard<std::mutex> lk(g.mu); g.slots[peer][c->rank].full = false; }
+        g.cv.notify_all();
+        return IFA_OK;
+    }
     IFA_NCCL_CHECK(ncclRecv(buf, bytes, ncclInt8, peer, c->comm, ifa_s(stream)));
     return IFA_OK;
 }

@@ -97,6 +97,8 @@ struct ifa_model {
     int *tp_tok = nullptr;
     hipGraph_t tp_graph = nullptr;
     hipGraphExec_t tp_graph_exec = nullptr;
+    const ifa_tp_topology *topo = nullptr;     // set by the partition entry points for the duration of a T > 1 / batched step
+    size_t tp_rows_cap = 0;                    // rows the distributed-argmax scratch (tp_best / tp_gather / tp_tok) holds
     int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
     static constexpr int RING = 1024;
 };
@@ -625,6 +627,109 @@ static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, cons
 }
 
 // w2 . (act(w1 . x) [* (w3 . x)])   (ProcessGpuLayer_FeedForward, inference_worker.cc:1726-1922)
+// ---- distributed greedy argmax over a vocabulary-sharded lm_head (one workgroup per row)
+// (value, global id) of the best allowed logit of this rank's shard; first maximum wins
+__global__ void __launch_bounds__(1024) k_tp_local_best(const half_t *__restrict__ v_all, size_t row_stride, int n, int vocab_offset,
+                                                        const int *__restrict__ excl, float *__restrict__ best_all)
+{
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const half_t *v = v_all + (size_t)blockIdx.x * row_stride;
+    float *best_out = best_all + 2 * (size_t)blockIdx.x;
+    const int ne = excl ? min(max(excl[0], 0), 3) : 0;
+    const int e0 = ne > 0 ? excl[1] : -1, e1 = ne > 1 ? excl[2] : -1, e2 = ne > 2 ? excl[3] : -1;
+    float best = -INFINITY; int besti = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int gid = vocab_offset + i;
+        if (gid == e0 || gid == e1 || gid == e2) continue;
+        const float f = h2f(v[i]);
+        if (f > best || (f == best && gid < besti)) { best = f; besti = gid; }
+    }
+#pragma unroll
+    for (int mk = 32; mk > 0; mk >>= 1) {
+        const float ob = __shfl_xor(best, mk); const int oi = __shfl_xor(besti, mk);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+            if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        best_out[0] = best;
+        reinterpret_cast<int *>(best_out)[1] = besti;
+    }
+}
+
+// the group's choice per row: highest value, lowest id among equals.  gathered: [rank][row][2]
+__global__ void k_tp_pick(const float *__restrict__ gathered, int nranks, int n_rows, int *__restrict__ token)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    float best = -INFINITY; int besti = 0x7FFFFFFF;
+    for (int k = 0; k < nranks; k++) {
+        const float f = gathered[2 * ((size_t)k * n_rows + r)];
+        const int gid = reinterpret_cast<const int *>(gathered)[2 * ((size_t)k * n_rows + r) + 1];
+        if (f > best || (f == best && gid < besti)) { best = f; besti = gid; }
+    }
+    token[r] = besti == 0x7FFFFFFF ? 0 : besti;
+}
+
+// scratch of the distributed argmax for n_rows rows
+static int tp_argmax_scratch(ifa_model *m, size_t n_rows)
+{
+    if (n_rows <= m->tp_rows_cap) return IFA_OK;
+    if (m->tp_best) IFA_HIP_CHECK(hipFree(m->tp_best));
+    if (m->tp_gather) IFA_HIP_CHECK(hipFree(m->tp_gather));
+    if (m->tp_tok) IFA_HIP_CHECK(hipFree(m->tp_tok));
+    m->tp_best = nullptr; m->tp_gather = nullptr; m->tp_tok = nullptr;
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_best, 8 * n_rows));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_gather, 8 * 64 * n_rows));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_tok, 4 * n_rows));
+    m->tp_rows_cap = n_rows;
+    drop_graphs(m);
+    return IFA_OK;
+}
+
+// tokens[r] (device, m->tp_tok) = the group's greedy choice for row r of this rank's logits shard [n_rows][row_stride]
+static int tp_pick_rows(ifa_model *m, const ifa_tp_topology &t, const half_t *shard, size_t row_stride, int shard_rows, int n_rows)
+{
+    int rc = tp_argmax_scratch(m, (size_t)n_rows);
+    if (rc) return rc;
+    ifa_stream s = (ifa_stream)m->stream;
+    const int tp_size = t.tp ? ifa_comm_size(t.tp) : 1;
+    const bool merge = t.tp && (tp_size > 1 || t.force_collectives);
+    k_tp_local_best<<<dim3((unsigned)n_rows), 1024, 0, m->stream>>>(shard, row_stride, shard_rows, t.vocab_offset, m->state + 3, m->tp_best);
+    IFA_LAUNCH_CHECK();
+    const float *gathered = m->tp_best;
+    int n_g = 1;
+    if (merge) {
+        if ((rc = ifa_allgather(t.tp, m->tp_best, m->tp_gather, 8 * (size_t)n_rows, s))) return rc;
+        gathered = m->tp_gather; n_g = tp_size;
+    }
+    k_tp_pick<<<dim3((unsigned)((n_rows + 63) / 64)), 64, 0, m->stream>>>(gathered, n_g, n_rows, m->tp_tok);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// ---- tensor-parallel T > 1 / batched steps: the same op sequence, with the reference's merge
+// (DistributeAndMergeTensors, inference_worker.cc:2148-2195) after the two column-sliced products of a layer
+static bool tp_merging(const ifa_model *m)
+{
+    const ifa_tp_topology *t = m->topo;
+    return t && t->tp && (ifa_comm_size(t->tp) > 1 || t->force_collectives);
+}
+// buf[T][dim] holds this rank's partial product (computed WITHOUT bias): sum over the group, then the bias once
+static int tp_merge_rows(ifa_model *m, half_t *buf, int T, const Tensor &bias)
+{
+    if (!tp_merging(m)) return IFA_OK;
+    const size_t D = (size_t)m->cfg.dim;
+    int rc = ifa_allreduce_sum_f16(m->topo->tp, buf, buf, (size_t)T * D, (ifa_stream)m->stream);
+    if (rc) return rc;
+    if (bias.present()) return ifa_add(buf, bias.data, (size_t)T * D, D, buf, (ifa_stream)m->stream);
+    return IFA_OK;
+}
+
 static int ffn_dense(ifa_model *m, const half_t *x, int T, const Tensor &w1, const Tensor &b1, const Tensor &w3, const Tensor &b3,
                      const Tensor &w2, const Tensor &b2, half_t *out)
 {
@@ -721,13 +826,18 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     if (rc) return rc;
     ifa_stream s = m->stream;
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim;
-    if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return ifa_fail(IFA_ERR_STATE, "F16 embeddings not set");
+    const ifa_tp_topology *tp = m->topo;            // multi-GPU partition (ifa_model_tp_prefill): merges + stage hand-over
+    const bool first_stage = !tp || tp->stage == 0, last_stage = !tp || tp->next_rank < 0 || tp->n_stages == 1;
+    const bool merging = tp_merging(m);
+    if (first_stage && (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16)) return ifa_fail(IFA_ERR_STATE, "F16 embeddings not set");
     static const bool trace_host = getenv("IFA_TRACE_FORWARD") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
-    IFA_HIP_CHECK(hipMemcpyAsync(m->tokens_dev, tokens_host, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, m->stream));
-    k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->tokens_dev, T, (int)D,
-                                                                      (int)m->g[T_EMBD].rows, m->x);
-    IFA_LAUNCH_CHECK();
+    if (first_stage) {
+        IFA_HIP_CHECK(hipMemcpyAsync(m->tokens_dev, tokens_host, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, m->stream));
+        k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->tokens_dev, T, (int)D,
+                                                                          (int)m->g[T_EMBD].rows, m->x);
+        IFA_LAUNCH_CHECK();
+    } else if ((rc = ifa_recv(tp->world, m->x, (size_t)T * D * 2, tp->prev_rank, s))) return rc;     // the previous group's [T][dim] output
     half_t *x = m->x;
     const Tensor none;
     // small element-wise ops are one launch where the wiring allows it (each keeps its own half rounding): RoPE(q) + RoPE(k)
@@ -770,7 +880,8 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         if ((rc = ifa_attention(m->q, L.kcache, L.vcache, c.kv_dtype, prefix_len + T, T, prefix_len, c.heads, c.kv_heads,
                                 c.head_dim, c.use_alibi ? 1.0f : c.kq_scale, c.use_alibi, c.tp_rank * c.heads,
                                 c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
-        if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
+        if ((rc = matmul(m, m->att, T, L.t[T_WO], merging ? none : L.t[T_WO_B], m->a))) return rc;
+        if ((rc = tp_merge_rows(m, m->a, T, L.t[T_WO_B]))) return rc;       // BY_TENSOR: sum of the ranks' partial products, bias after
         if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
         const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
         const half_t *ff_n = ff_in;
@@ -787,8 +898,10 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         }
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
             if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
+            if ((rc = tp_merge_rows(m, m->f, T, none))) return rc;          // every expert sliced like the dense FFN: one merge of the weighted sums
         } else {
-            if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
+            if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], merging ? none : L.t[T_W2_B], m->f))) return rc;
+            if ((rc = tp_merge_rows(m, m->f, T, L.t[T_W2_B]))) return rc;
         }
         if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
         // Add(ffn out, a) + the norm in front of what comes next: the next layer's attention norm, or the output norm
@@ -807,6 +920,15 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         std::swap(m->x, m->f);
         x = m->x;
     }
+    if (!last_stage) {       // BY_LAYER / HYBRID: hand the [T][dim] output to the next device group, then learn the token
+        if ((rc = ifa_send(tp->world, x, (size_t)T * D * 2, tp->next_rank, s))) return rc;
+        if ((rc = tp_argmax_scratch(m, 1))) return rc;
+        if ((rc = ifa_broadcast(tp->world, m->tp_tok, 4, tp->token_src, s))) return rc;
+        IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned, m->tp_tok, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+        if (next_token) *next_token = m->host_pinned[0];
+        return IFA_OK;
+    }
     if (scale_on(c.out_scale) && (rc = ifa_scale(x, c.out_scale, (size_t)T * D, x, s))) return rc;
     const half_t *hfin = x;
     if (m->g[T_OUT_NORM].present()) {
@@ -816,13 +938,19 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         IFA_HIP_CHECK(hipMemcpyAsync(m->xn, x, (size_t)T * D * 2, hipMemcpyDeviceToDevice, m->stream));
     }
     const Tensor &lm = m->g[T_LM_HEAD];
-    const size_t V = lm.rows;
+    const size_t V = lm.rows;                        // (this rank's vocabulary shard under tensor parallelism)
     int t0 = logits_out ? 0 : T - 1;
     if (logits_out) { if ((rc = matmul(m, hfin, T, lm, none, m->logits))) return rc; }
     else { if ((rc = matmul(m, hfin + (size_t)t0 * D, 1, lm, none, m->logits + (size_t)t0 * V))) return rc; }
     if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
-    if ((rc = ifa_argmax_masked(m->logits + (size_t)(T - 1) * V, V, m->state + 3, m->state, s))) return rc;
-    IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if (tp) {                // distributed argmax of the last row over the group's shards (+ announcement to the other groups)
+        if ((rc = tp_pick_rows(m, *tp, m->logits + (size_t)(T - 1) * V, V, (int)V, 1))) return rc;
+        if (tp->n_stages > 1 && (rc = ifa_broadcast(tp->world, m->tp_tok, 4, tp->token_src, s))) return rc;
+        IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned, m->tp_tok, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    } else {
+        if ((rc = ifa_argmax_masked(m->logits + (size_t)(T - 1) * V, V, m->state + 3, m->state, s))) return rc;
+        IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    }
     const auto host_t1 = std::chrono::steady_clock::now();
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (trace_host)      // how much of a step is the host enqueuing (launch-bound) vs the GPU draining what was enqueued
@@ -895,6 +1023,9 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     const int T = n;
     const size_t D = c.dim, KVD = (size_t)c.kv_heads * c.head_dim, L_ = m->layers.size();
     if (!m->g[T_EMBD].present() || m->g[T_EMBD].dtype != F16) return ifa_fail(IFA_ERR_STATE, "F16 embeddings not set");
+    const ifa_tp_topology *tp = m->topo;            // tensor-parallel group (ifa_model_tp_decode_batch): merges + distributed argmax
+    if (tp && tp->n_stages > 1) return ifa_fail(IFA_ERR_ARG, "decode_batch: layer groups are not batched (tensor-parallel groups only)");
+    const bool merging = tp_merging(m);
     // per-step tables: positions, and for every layer the (k cache, v cache, context) of each row's query
     const size_t tab_bytes = L_ * (size_t)n * sizeof(AttnRowH) + 2 * (size_t)n * sizeof(int);
     if (tab_bytes > m->batch_tab_bytes) {
@@ -922,7 +1053,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     for (const Layer &Lc : m->layers) has_moe = has_moe || (c.experts > 0 && Lc.t[T_MOE_GATE].present());
     // (measured on Llama-2-7B Q4: the batched step is bound by the small-T GEMM kernels, ~6.7 ms with or without the
     //  graph, so replay is opt-in: set_option("batch_graph", 1))
-    const bool use_graph = m->opt_batch_graph && m->opt_graph && !has_moe && !logits_out;
+    const bool use_graph = m->opt_batch_graph && m->opt_graph && !has_moe && !logits_out && !tp;
     const int attn_ctx = use_graph ? c.max_ctx : max_ctx;     // LDS sizing of the attention kernel must not depend on the step
     if (use_graph) {
         auto it = m->batch_graphs.find(n);
@@ -965,7 +1096,8 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         IFA_LAUNCH_CHECK();
         if ((rc = ifa_attention_rows(m->q, lr, c.kv_dtype, n, attn_ctx, c.heads, c.kv_heads, c.head_dim, c.use_alibi ? 1.0f : c.kq_scale,
                                      c.use_alibi, c.tp_rank * c.heads, c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
-        if ((rc = matmul(m, m->att, T, L.t[T_WO], L.t[T_WO_B], m->a))) return rc;
+        if ((rc = matmul(m, m->att, T, L.t[T_WO], merging ? none : L.t[T_WO_B], m->a))) return rc;
+        if ((rc = tp_merge_rows(m, m->a, T, L.t[T_WO_B]))) return rc;
         if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
         const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
         const half_t *ff_n = ff_in;
@@ -982,8 +1114,10 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         }
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
             if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
+            if ((rc = tp_merge_rows(m, m->f, T, none))) return rc;
         } else {
-            if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
+            if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], merging ? none : L.t[T_W2_B], m->f))) return rc;
+            if ((rc = tp_merge_rows(m, m->f, T, L.t[T_W2_B]))) return rc;
         }
         if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
         const bool last_layer = l + 1 == c.layers;
@@ -1011,6 +1145,11 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     const size_t V = lm.rows;
     if ((rc = matmul(m, hfin, T, lm, none, m->logits))) return rc;
     if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
+    if (tp) {                // one distributed argmax per row over the group's vocabulary shards
+        if ((rc = tp_pick_rows(m, *tp, m->logits, V, (int)V, n))) return rc;
+        IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->tp_tok, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+        return IFA_OK;
+    }
     for (int r = 0; r < n; r++)
         if ((rc = ifa_argmax_masked(m->logits + (size_t)r * V, V, m->state + 3, m->state + 8 + r, s))) return rc;
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
@@ -1633,50 +1772,6 @@ int ifa_model_tp_set_token(ifa_model *m, const int *token_dev)
 // ---- the whole multi-GPU decode step driven from C: worker segments + RCCL collectives (csrc/ifa_comm.hip) on the
 // worker's stream, the distributed greedy argmax over the vocabulary-sharded lm_head, token / position fed back in
 // device memory; captured once as a hipGraph and replayed per token (tensor-parallel groups; pipelines run eagerly).
-// (value, global id) of the best allowed logit of this rank's shard; first maximum wins
-__global__ void __launch_bounds__(1024) k_tp_local_best(const half_t *__restrict__ v, int n, int vocab_offset, const int *__restrict__ excl,
-                                                        float *__restrict__ best_out)
-{
-    __shared__ float bv[16];
-    __shared__ int bi[16];
-    const int ne = excl ? min(max(excl[0], 0), 3) : 0;
-    const int e0 = ne > 0 ? excl[1] : -1, e1 = ne > 1 ? excl[2] : -1, e2 = ne > 2 ? excl[3] : -1;
-    float best = -INFINITY; int besti = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int gid = vocab_offset + i;
-        if (gid == e0 || gid == e1 || gid == e2) continue;
-        const float f = h2f(v[i]);
-        if (f > best || (f == best && gid < besti)) { best = f; besti = gid; }
-    }
-#pragma unroll
-    for (int mk = 32; mk > 0; mk >>= 1) {
-        const float ob = __shfl_xor(best, mk); const int oi = __shfl_xor(besti, mk);
-        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++)
-            if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
-        best_out[0] = best;
-        reinterpret_cast<int *>(best_out)[1] = besti;
-    }
-}
-
-// the group's choice: highest value, lowest id among equals
-__global__ void k_tp_pick(const float *__restrict__ gathered, int nranks, int *__restrict__ token)
-{
-    if (threadIdx.x != 0) return;
-    float best = -INFINITY; int besti = 0x7FFFFFFF;
-    for (int r = 0; r < nranks; r++) {
-        const float f = gathered[2 * r];
-        const int gid = reinterpret_cast<const int *>(gathered)[2 * r + 1];
-        if (f > best || (f == best && gid < besti)) { best = f; besti = gid; }
-    }
-    *token = besti == 0x7FFFFFFF ? 0 : besti;
-}
-
 static int tp_buffers(ifa_model *m)
 {
     if (m->tp_a) return IFA_OK;
@@ -1686,10 +1781,7 @@ static int tp_buffers(ifa_model *m)
     IFA_HIP_CHECK(hipMalloc((void **)&m->tp_f, D * 2));
     IFA_HIP_CHECK(hipMalloc((void **)&m->tp_hid, D * 2));
     IFA_HIP_CHECK(hipMalloc((void **)&m->tp_logits, std::max<size_t>(m->g[T_LM_HEAD].rows, 1) * 2));
-    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_best, 8));
-    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_gather, 8 * 64));
-    IFA_HIP_CHECK(hipMalloc((void **)&m->tp_tok, 4));
-    return IFA_OK;
+    return tp_argmax_scratch(m, 1);
 }
 
 // want_token = false (all but the last token of a prompt): the layers run, the lm_head / argmax / token exchange do not
@@ -1725,16 +1817,7 @@ static int tp_step(ifa_model *m, const ifa_tp_topology &t, int token, int pos, b
     if ((rc = ifa_model_tp_logits(m, m->tp_logits))) return rc;
     if (logits_copy) IFA_HIP_CHECK(hipMemcpyAsync(logits_copy, m->tp_logits, m->g[T_LM_HEAD].rows * 2, hipMemcpyDeviceToDevice, m->stream));
     if (!want_token) return IFA_OK;
-    k_tp_local_best<<<1, 1024, 0, m->stream>>>(m->tp_logits, (int)m->g[T_LM_HEAD].rows, t.vocab_offset, m->state + 3, m->tp_best);
-    IFA_LAUNCH_CHECK();
-    const float *gathered = m->tp_best;
-    int n_g = 1;
-    if (merge) {
-        if ((rc = ifa_allgather(t.tp, m->tp_best, m->tp_gather, 8, s))) return rc;
-        gathered = m->tp_gather; n_g = tp_size;
-    }
-    k_tp_pick<<<1, 64, 0, m->stream>>>(gathered, n_g, m->tp_tok);
-    IFA_LAUNCH_CHECK();
+    if ((rc = tp_pick_rows(m, t, m->tp_logits, m->g[T_LM_HEAD].rows, (int)m->g[T_LM_HEAD].rows, 1))) return rc;
     if (t.n_stages > 1 && (rc = ifa_broadcast(t.world, m->tp_tok, 4, t.token_src, s))) return rc;
     return ifa_model_tp_set_token(m, m->tp_tok);
 }
@@ -1764,6 +1847,15 @@ int ifa_model_tp_prefill(ifa_model *m, const ifa_tp_topology *topo, const int *t
     if (rc) return rc;
     IFA_REQUIRE(start_pos >= 0 && start_pos + n_tokens <= m->cfg.max_ctx, "ifa_model_tp_prefill: positions %d..%d exceed max_ctx %d",
                 start_pos, start_pos + n_tokens, m->cfg.max_ctx);
+    if (n_tokens > 1) {
+        // T > 1: the op-by-op step over all tokens at once (row-sliced GEMMs on the MFMA kernels, [T][dim] merges after
+        // wo and w2, [T][dim] hand-over between layer groups) -- the reference's MatrixMultiplication branch for T > 1
+        // (inference_worker.cc:2364-2432) with its merge of token_num x dim values (:2148-2195)
+        m->topo = topo;
+        rc = forward_ops(m, tokens_host, n_tokens, start_pos, logits_shard_out_dev, next_token_host);
+        m->topo = nullptr;
+        return rc;
+    }
     const size_t shard = m->g[T_LM_HEAD].present() ? m->g[T_LM_HEAD].rows * 2 : 0;
     m->host_pinned[0] = tokens_host[0]; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
@@ -1775,6 +1867,20 @@ int ifa_model_tp_prefill(ifa_model *m, const ifa_tp_topology *topo, const int *t
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (next_token_host) *next_token_host = m->host_pinned[4];
     return IFA_OK;
+}
+
+// Dynamic batching over a tensor-parallel group: one new token for each of n queries (ifa_model_decode_batch) with the
+// two merges per layer over [n][dim] and one distributed argmax per row
+int ifa_model_tp_decode_batch(ifa_model *m, const ifa_tp_topology *topo, int n, const int *tokens_host, const int *positions_host,
+                              const int *kv_slots_host, int *next_tokens_host, void *logits_shard_out_dev)
+{
+    IFA_REQUIRE(n >= 1 && n <= ifa_model::RING && tokens_host && positions_host && kv_slots_host, "ifa_model_tp_decode_batch: bad arguments");
+    int rc = tp_check(m, topo, "ifa_model_tp_decode_batch");
+    if (rc) return rc;
+    m->topo = topo;
+    rc = forward_batch(m, n, tokens_host, positions_host, kv_slots_host, next_tokens_host, logits_shard_out_dev);
+    m->topo = nullptr;
+    return rc;
 }
 
 int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_token, int start_pos, int n_steps,
@@ -1791,7 +1897,7 @@ int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_tok
     // the step counter restarts: the token ring of this call begins at state[8]
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
-    const bool use_graph = m->opt_graph && t.n_stages == 1;
+    const bool use_graph = m->opt_graph && t.n_stages == 1 && (!t.tp || ifa_comm_capturable(t.tp));
     int done = 0;
     if (!(use_graph && m->tp_graph_exec)) {
         // the first step runs eagerly: it creates whatever the collectives allocate lazily, so that the capture below

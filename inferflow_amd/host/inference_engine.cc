@@ -265,9 +265,14 @@ bool InferenceEngine::InitMulti(const std::vector<std::vector<int>> &groups)
             M.plans.push_back(w);
             all_devices.push_back(w.device);
         }
-    for (size_t i = 0; i < all_devices.size(); i++)
-        for (size_t j = i + 1; j < all_devices.size(); j++)
-            if (all_devices[i] == all_devices[j]) { EngineSetError("device %d appears twice in `devices`", all_devices[i]); return false; }
+    // a device named more than once: only as "every rank on ONE device" (loopback groups of the C ABI: the multi-rank
+    // paths on a 1-GPU box, tests); anything else is a configuration mistake
+    bool dup = false, all_same = true;
+    for (size_t i = 0; i < all_devices.size(); i++) {
+        all_same = all_same && all_devices[i] == all_devices[0];
+        for (size_t j = i + 1; j < all_devices.size(); j++) dup = dup || all_devices[i] == all_devices[j];
+    }
+    if (dup && !all_same) { EngineSetError("a device appears twice in `devices`"); return false; }
     if (!BuildWorkers(M.plans, spec_)) return false;
     const int R = G * P;
     M.world.assign((size_t)R, nullptr); M.tp.assign((size_t)R, nullptr);

@@ -58,6 +58,53 @@ def test_c_driven_tp_decode_equals_fused_decode_and_python_runner():
     c.close(); wk.close()
 
 
+def test_loopback_group_collectives_between_rank_threads():
+    """ifa_comm_init_all with one device named n times: the in-process loopback group (what lets the multi-rank engine
+    paths run on a 1-GPU box).  Rank threads call the collectives concurrently, like the engine's rank threads."""
+    import ctypes as C
+    import threading
+    import inferflow_amd as ia
+    L = ia.lib()
+    n = 3
+    devs = (C.c_int * n)(0, 0, 0)
+    comms = (C.c_void_p * n)()
+    ia.check(L.ifa_comm_init_all(devs, n, comms))
+    assert L.ifa_comm_capturable(comms[0]) == 0 and L.ifa_comm_size(comms[1]) == n and L.ifa_comm_rank(comms[2]) == 2
+    xs = [torch.full((1000,), float(r + 1), device="cuda").half() * 0.25 for r in range(n)]
+    g_in = [torch.full((8,), r, dtype=torch.uint8, device="cuda") for r in range(n)]
+    g_out = [torch.zeros(8 * n, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    h = [torch.full((64,), float(r), device="cuda").half() for r in range(n)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def rank(r):
+        try:
+            st = torch.cuda.Stream()
+            sp = C.c_void_p(st.cuda_stream)
+            ia.check(L.ifa_allreduce_sum_f16(comms[r], C.c_void_p(xs[r].data_ptr()), C.c_void_p(xs[r].data_ptr()), 1000, sp))
+            ia.check(L.ifa_allgather(comms[r], C.c_void_p(g_in[r].data_ptr()), C.c_void_p(g_out[r].data_ptr()), 8, sp))
+            ia.check(L.ifa_broadcast(comms[r], C.c_void_p(h[r].data_ptr()), 128, 1, sp))
+            if r == 0:
+                ia.check(L.ifa_send(comms[r], C.c_void_p(xs[r].data_ptr()), 2000, 2, sp))
+            if r == 2:
+                ia.check(L.ifa_recv(comms[r], C.c_void_p(xs[r].data_ptr()), 2000, 0, sp))
+            st.synchronize()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert not errs and all(not t.is_alive() for t in ts)
+    torch.cuda.synchronize()
+    assert all(float(x[0]) == 1.5 for x in xs)                      # 0.25 + 0.5 + 0.75
+    assert all(g.cpu().tolist() == [0] * 8 + [1] * 8 + [2] * 8 for g in g_out)
+    assert all(float(t[0]) == 1.0 for t in h)
+    for c in comms:
+        L.ifa_comm_destroy(c)
+
+
 def _rank(rank, world, uid, q):
     sys.path.insert(0, ROOT)
     torch.cuda.set_device(rank)
