@@ -197,6 +197,21 @@ class Comm:
         check(lib().ifa_comm_init_rank(self._id, int(nranks), int(rank), int(device), C.byref(self._h)))
         self.rank, self.nranks = rank, nranks
 
+    @classmethod
+    def init_all(cls, devices):
+        """One communicator per entry of `devices` in THIS process (rank threads); a device named several times makes the
+        in-process loopback group (see csrc/ifa_comm.hip)."""
+        n = len(devices)
+        devs = (C.c_int * n)(*devices)
+        hs = (C.c_void_p * n)()
+        check(lib().ifa_comm_init_all(devs, n, hs))
+        out = []
+        for r in range(n):
+            c = cls.__new__(cls)
+            c._h, c._id, c.rank, c.nranks = C.c_void_p(hs[r]), None, r, n
+            out.append(c)
+        return out
+
     def all_reduce_f16(self, t, stream=None):
         check(lib().ifa_allreduce_sum_f16(self._h, C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(stream)))
 
@@ -222,6 +237,29 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def tp_decode_batch(worker, tokens, positions, slots, tp=None, vocab_offset=0, logits_shard_out=None, force_collectives=False):
+    """ifa_model_tp_decode_batch: one new token for each of n queries over a tensor-parallel group; returns the n tokens"""
+    topo = TpTopology(tp._h if tp is not None else None, None, 0, 1, -1, -1, 0, vocab_offset, 1 if force_collectives else 0)
+    toks = np.ascontiguousarray(tokens, np.int32); pos = np.ascontiguousarray(positions, np.int32); sl = np.ascontiguousarray(slots, np.int32)
+    out = np.zeros(toks.size, np.int32)
+    check(lib().ifa_model_tp_decode_batch(worker._h, C.byref(topo), toks.size, toks.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
+                                          sl.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                          C.c_void_p(logits_shard_out.data_ptr()) if logits_shard_out is not None else None))
+    return out
+
+
+def tp_prefill(worker, tokens, start_pos, tp=None, world=None, stage=0, n_stages=1, prev_rank=-1, next_rank=-1, token_src=0,
+               vocab_offset=0, logits_shard_out=None, force_collectives=False):
+    """ifa_model_tp_prefill: n tokens as one T > 1 step over the partition; returns the greedy next token"""
+    topo = TpTopology(tp._h if tp is not None else None, world._h if world is not None else None, stage, n_stages, prev_rank,
+                      next_rank, token_src, vocab_offset, 1 if force_collectives else 0)
+    toks = np.ascontiguousarray(tokens, np.int32)
+    nxt = C.c_int(-1)
+    check(lib().ifa_model_tp_prefill(worker._h, C.byref(topo), toks.ctypes.data_as(C.c_void_p), toks.size, int(start_pos),
+                                     C.c_void_p(logits_shard_out.data_ptr()) if logits_shard_out is not None else None, C.byref(nxt)))
+    return nxt.value
 
 
 def tp_decode(worker, first_token, start_pos, n_steps, tp=None, world=None, stage=0, n_stages=1, prev_rank=-1, next_rank=-1,

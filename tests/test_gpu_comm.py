@@ -105,6 +105,80 @@ def test_loopback_group_collectives_between_rank_threads():
         L.ifa_comm_destroy(c)
 
 
+def test_batched_decode_over_a_tensor_parallel_group_matches_oracle():
+    """Dynamic batching under BY_TENSOR (configs[4] shape of work: several queries, one step, merges over [n][dim]): two
+    rank threads on one GPU (loopback group), three queries on their own KV slots, every row against the oracle of its
+    query with the merge restated and the T > 1 arithmetic (F16 activations) of a batched step."""
+    import threading
+    from inferflow_amd import tp as tpmod
+    from tests.model_util import oracle_model_from_host
+    P = 2
+    wk1, host, s = synth.build("test_gqa", dt.Q4_B32T1A, dt.F16, max_ctx=64, quant_threshold=0, std=0.06, keep_host=True)
+    wk1.close()
+    V = s["vocab"]
+    workers = [tpmod.build_tp_worker("test_gqa", dt.Q4_B32T1A, dt.F16, 64, P, r, device=0, std=0.06)[0] for r in range(P)]
+    comms = W.Comm.init_all([0] * P)
+    rng = np.random.default_rng(23)
+    prompts = [rng.integers(3, V, n).astype(np.int32) for n in (5, 11, 8)]
+    oms = [oracle_model_from_host(host, s, 64, dt.F16, full_quant_gemv=0, tp_merge=P) for _ in prompts]
+    for wk in workers:
+        wk.kv_slots(3)
+    firsts = [[None] * 3 for _ in range(P)]
+    shards = [torch.zeros((3, V // P), dtype=torch.float16, device="cuda") for _ in range(P)]
+    outs = [None] * P
+    errs = []
+
+    def on_ranks(fn):
+        ts = [threading.Thread(target=lambda r=r: _guard(fn, r, errs)) for r in range(P)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert not errs, errs
+        assert all(not t.is_alive() for t in ts)
+
+    def prefill(r):
+        for i, pr in enumerate(prompts):
+            workers[r].select_kv(i)
+            firsts[r][i] = W.tp_prefill(workers[r], pr, 0, tp=comms[r], vocab_offset=r * (V // P))
+    on_ranks(prefill)
+    assert firsts[0] == firsts[1]
+    first_o = []
+    for i, pr in enumerate(prompts):
+        t_o, l_o = oms[i].forward(pr, 0, nthreads=4)
+        first_o.append(t_o)
+        top2 = np.sort(l_o[-1].astype(np.float32))[-2:]
+        if top2[1] - top2[0] > 0.03:
+            assert firsts[0][i] == t_o
+    cur, pos = list(firsts[0]), [len(p) for p in prompts]
+    for step in range(4):
+        def one(r):
+            outs[r] = W.tp_decode_batch(workers[r], cur, pos, [0, 1, 2], tp=comms[r], vocab_offset=r * (V // P), logits_shard_out=shards[r])
+        on_ranks(one)
+        assert list(outs[0]) == list(outs[1])
+        rows = torch.cat(shards, 1).float().cpu().numpy()
+        for i in range(3):
+            t_o, l_o = oms[i].forward(np.array([cur[i]], np.int32), pos[i], nthreads=4)
+            a, b = rows[i], l_o[0].astype(np.float32)
+            cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+            assert cos >= 0.9995 and np.abs(a - b).max() <= 0.03, (step, i, cos, np.abs(a - b).max())
+            top2 = np.sort(b)[-2:]
+            if top2[1] - top2[0] > 0.03:
+                assert int(outs[0][i]) == t_o, (step, i)
+        cur, pos = [int(t) for t in outs[0]], [p + 1 for p in pos]
+    for c in comms:
+        c.close()
+    for wk in workers:
+        wk.close()
+
+
+def _guard(fn, r, errs):
+    try:
+        fn(r)
+    except Exception as e:      # pragma: no cover
+        errs.append((r, repr(e)))
+
+
 def _rank(rank, world, uid, q):
     sys.path.insert(0, ROOT)
     torch.cuda.set_device(rank)
