@@ -172,6 +172,15 @@ int ifa_attention(const void *q_f16, const void *kcache, const void *vcache, int
                   void *out_f16, ifa_stream stream);
 
 /* ---- greedy argmax over F16 logits (SampleTokens top-1) ------------------ */
+/* MoE routing of `tokens` softmaxed router rows [tokens][experts] on the device -- the per-row part of
+ * HostTensorOpr::BuildRowsForMoE (src/tensor/host_tensor_opr.cc:190-244): top_k by repeated first maximum, probabilities
+ * below 1e-5 dropped, optional renormalisation over the kept ones.  sel_out [tokens][top_k]: expert ids in ascending
+ * order (-1 = unused slot), weights_out [tokens][top_k] F16.  (The reference copies the probabilities to the host.) */
+int ifa_moe_route_topk(const void *probs_f16, size_t tokens, int experts, int top_k, int norm_top_k_prob, int *sel_out_dev,
+                       void *weights_out_f16_dev, ifa_stream stream);
+/* LayerKVCache::SetKRows / SetVRows (src/transformer/kv_cache.cc:159-249): `tokens` F16 rows [kv_dim] into rows
+ * [first_row, first_row + tokens) of a K or V cache of dtype F16 (copy) or Q8_B32T2 (the Alg2 quantiser) */
+int ifa_kv_store(int kv_dtype, const void *rows_f16, size_t tokens, size_t kv_dim, void *cache, size_t first_row, ifa_stream stream);
 int ifa_argmax(const void *logits_f16, size_t n, int *out_index_dev, ifa_stream stream);
 /* the same over the ALLOWED ids: excluded_dev = {count (<= 3), id, id, id} in device memory (nullable) -- the ids
  * SamplingStrategy::GetSortedTopK never offers to its queue: the vocabulary's unk id and Invalid-type tokens

@@ -81,6 +81,8 @@ SIGNATURES = {
     "ifa_add": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "ifa_scale": (_i, [_vp, _f, _sz, _vp, _vp]),
     "ifa_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
+    "ifa_moe_route_topk": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp, _vp]),
+    "ifa_kv_store": (_i, [_i, _vp, _sz, _sz, _vp, _sz, _vp]),
     "ifa_argmax": (_i, [_vp, _sz, _vp, _vp]),
     "ifa_argmax_masked": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "ifa_model_create": (_i, [_vp, C.POINTER(_vp)]),

@@ -873,8 +873,11 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     // ---- issue the first chunk of K (key = tid) and V loads before anything else.  Keys past the context
     // re-read row `pos` (one row for all of them: no extra traffic, never used) instead of being masked off:
     // loads under an exec mask make every later wait a vmcnt(0)
+    // (the position comes from device memory: nothing below waits for it before the first K / V requests are out --
+    // rows past the context are clamped against the cache's last row instead, any row of the cache is valid memory)
     const int pos = P.state[1];
     const int n_ctx = pos + 1;
+    const int last_row = P.max_ctx - 1;
     // Q8 rows: a head's slice is (HD/32)*34 bytes, 8-byte aligned for HD=128, 4-byte for HD=64, 2-byte for HD=32
     constexpr int KBYTES = (HD / 32) * 34;
     constexpr int KALIGN = HD == 128 ? 8 : (HD == 64 ? 4 : 2);
@@ -910,7 +913,13 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
         if constexpr (KALIGN >= 4) return (kq32[B >> 2] >> (8 * (B & 3))) & 0xFFu;
         else return (kq16[B >> 1] >> (8 * (B & 1))) & 0xFFu;
     };
-    load_k(min(tid, pos));
+    load_k(min(tid, last_row));
+    // this step's (cos, sin) pair of the thread that will rotate: requested now, used after the staging barrier
+    float rope_cs = 1.0f, rope_sn = 0.0f;
+    if (P.rope_order != 0) {
+        const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
+        rope_cs = P.rope_tab[2 * c]; rope_sn = P.rope_tab[2 * c + 1];
+    }
     const int dg = tid % DG, sp = tid / DG;
     constexpr int VPRE = 256 / NSPLIT;                  // prefetched V keys per thread: j = sp + NSPLIT*i (256 keys)
     u32x4 vreg[Q8 ? 1 : VPRE];
@@ -918,7 +927,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     const size_t vq_off = head_off + (size_t)(dg / 4) * 34;
 #pragma unroll
     for (int i = 0; i < VPRE; i++) {
-        const int j = min(sp + NSPLIT * i, pos);
+        const int j = min(sp + NSPLIT * i, last_row);
         if constexpr (!Q8) {
             vreg[i] = reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg];
         } else {
@@ -939,8 +948,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     if (P.rope_order != 0) {
         if (tid < HD) {     // threads [0,HD/2) rotate q pairs, [HD/2,HD) rotate k pairs
             const int c = tid < HD / 2 ? tid : tid - HD / 2;
-            const float cs = P.rope_tab[2 * c], sn = P.rope_tab[2 * c + 1];
-            rope_apply(tid < HD / 2 ? qs : kn, c, cs, sn, P.rope_order, P.rope_cols);
+            rope_apply(tid < HD / 2 ? qs : kn, c, rope_cs, rope_sn, P.rope_order, P.rope_cols);
         }
         __syncthreads();
     }

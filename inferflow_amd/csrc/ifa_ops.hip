@@ -383,6 +383,38 @@ __global__ void __launch_bounds__(256) k_add_by_row_index(half_t *__restrict__ B
     *b = __builtin_fmaf16(A[(size_t)r * cols + c], wr, *b);
 }
 
+// HostTensorOpr::BuildRowsForMoE's per-row part (src/tensor/host_tensor_opr.cc:190-244) on the device, one thread per
+// token row: top-k by repeated first-maximum over the softmaxed router row, probabilities below 1e-5 dropped, optional
+// renormalisation over the kept ones; the kept (expert, weight) pairs in ASCENDING expert id (the order the reference
+// visits experts in), unused slots expert -1 / weight 0.
+__global__ void __launch_bounds__(64) k_moe_route_rows(const half_t *__restrict__ probs_h, int T, int E, int top_k, int norm,
+                                                       int *__restrict__ sel, half_t *__restrict__ wout)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float probs[64]; int idx[8]; float w[8]; bool used[64];
+    for (int e = 0; e < E; e++) { probs[e] = h2f(probs_h[(size_t)t * E + e]); used[e] = false; }
+    int n = 0;
+    for (int k = 0; k < top_k && k < E; k++) {
+        int best = -1;
+        for (int e = 0; e < E; e++) if (!used[e] && (best < 0 || probs[e] > probs[best])) best = e;
+        if (best < 0) break;
+        used[best] = true;
+        if (probs[best] < 0.00001f) continue;
+        idx[n] = best; w[n] = probs[best]; n++;
+    }
+    if (norm && n > 0) {
+        float sum = 0.0f;
+        for (int i2 = 0; i2 < n; i2++) sum = sum + w[i2];
+        for (int i2 = 0; i2 < n; i2++) w[i2] = w[i2] / sum;
+    }
+    int slot = 0;
+    for (int e = 0; e < E; e++)
+        for (int j = 0; j < n; j++)
+            if (idx[j] == e) { sel[(size_t)t * top_k + slot] = e; wout[(size_t)t * top_k + slot] = f2h(w[j]); slot++; }
+    for (; slot < top_k; slot++) { sel[(size_t)t * top_k + slot] = -1; wout[(size_t)t * top_k + slot] = (half_t)0; }
+}
+
 } // namespace ifa
 
 using namespace ifa;
@@ -575,6 +607,32 @@ int ifa_argmax_masked(const void *logits, size_t n, const int *excluded_dev, int
     k_argmax<<<dim3(1), dim3(1024), 0, ifa_s(stream)>>>((const half_t *)logits, n, out_index_dev, excluded_dev);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
+}
+
+int ifa_moe_route_topk(const void *probs_f16, size_t tokens, int experts, int top_k, int norm_top_k_prob, int *sel_out_dev,
+                       void *weights_out_f16_dev, ifa_stream stream)
+{
+    IFA_REQUIRE(probs_f16 && sel_out_dev && weights_out_f16_dev, "ifa_moe_route_topk: null pointer");
+    IFA_REQUIRE(experts >= 1 && experts <= 64 && top_k >= 1 && top_k <= 8, "ifa_moe_route_topk: experts %d / top_k %d out of range", experts, top_k);
+    if (tokens == 0) return IFA_OK;
+    k_moe_route_rows<<<dim3(ifa_cdiv(tokens, 64)), dim3(64), 0, ifa_s(stream)>>>((const half_t *)probs_f16, (int)tokens, experts, top_k, norm_top_k_prob,
+                                                                                  sel_out_dev, (half_t *)weights_out_f16_dev);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int ifa_kv_store(int kv_dtype, const void *rows_f16, size_t tokens, size_t kv_dim, void *cache, size_t first_row, ifa_stream stream)
+{
+    IFA_REQUIRE(rows_f16 && cache, "ifa_kv_store: null pointer");
+    IFA_REQUIRE(kv_dtype == F16 || kv_dtype == Q8_B32T2, "ifa_kv_store: cache dtype %d (F16 or Q8_B32T2)", kv_dtype);
+    if (tokens == 0 || kv_dim == 0) return IFA_OK;
+    if (kv_dtype == F16) {       // SetKRows / SetVRows, same-type branch: a row copy (kv_cache.cc:159-201)
+        IFA_HIP_CHECK(hipMemcpyAsync((char *)cache + first_row * kv_dim * 2, rows_f16, tokens * kv_dim * 2, hipMemcpyDeviceToDevice, ifa_s(stream)));
+        return IFA_OK;
+    }
+    IFA_REQUIRE(kv_dim % 32 == 0, "ifa_kv_store: Q8 rows need kv_dim %% 32 == 0 (got %zu)", kv_dim);
+    // quantising branch: TensorOpr::Quantize -> the Alg2 kernel (kv_cache.cc:203-249)
+    return ifa_quantize_act_q8(rows_f16, tokens, kv_dim, (char *)cache + first_row * ifa_row_bytes(Q8_B32T2, kv_dim), stream);
 }
 
 int ifa_add_by_row_index(void *b_f16, const void *a_f16, size_t rows, size_t cols, const int *row_idx_dev,

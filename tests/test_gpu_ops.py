@@ -419,3 +419,43 @@ def test_add_by_row_index_is_a_half_fma_scatter():
     for r in range(5):   # exact fma in double, one rounding to half
         expect[idx[r]] = (A[r].astype(np.float64) * float(w[r]) + B[idx[r]].astype(np.float64)).astype(np.float16)
     assert np.array_equal(g.host(Bd).view(np.uint16), expect.view(np.uint16))
+
+
+# ------------------------------------------------- MoE routing / KV store exports
+def test_moe_route_topk_matches_oracle_rows():
+    """ifa_moe_route_topk: the per-row part of BuildRowsForMoE on the device (host_tensor_opr.cc:190-244) -- experts and
+    weights bit for bit with the oracle's restatement, incl. the < 1e-5 drop rule and the renormalisation switch."""
+    rng = np.random.default_rng(8)
+    for E, k, norm in [(8, 2, 1), (4, 2, 0), (16, 4, 1), (3, 3, 1)]:
+        T = 37
+        logits = rng.normal(0, 3.0, (T, E)).astype(np.float32)
+        logits[5] = np.array([30.0] + [-30.0] * (E - 1), np.float32)          # one-hot row: the other experts fall below 1e-5
+        probs = (np.exp(logits - logits.max(1, keepdims=True)) / np.exp(logits - logits.max(1, keepdims=True)).sum(1, keepdims=True)).astype(np.float16)
+        sel = torch.zeros((T, k), dtype=torch.int32, device="cuda")
+        wts = torch.zeros((T, k), dtype=torch.float16, device="cuda")
+        ia.check(g.capi().ifa_moe_route_topk(g.p(g.dev(probs)), T, E, k, norm, g.p(sel), g.p(wts), g.stream()))
+        sel_h, w_h = sel.cpu().numpy(), g.host(wts)
+        for t in range(T):
+            idx, w = o.moe_topk(probs[t].astype(np.float32), k, bool(norm))
+            order = np.argsort(idx, kind="stable")
+            exp_sel = [int(idx[i]) for i in order] + [-1] * (k - len(idx))
+            exp_w = [np.float16(w[i]) for i in order] + [np.float16(0)] * (k - len(idx))
+            assert sel_h[t].tolist() == exp_sel, (E, k, t)
+            assert np.array_equal(w_h[t].view(np.uint16), np.array(exp_w, np.float16).view(np.uint16)), (E, k, t)
+        assert sel_h[5].tolist()[0] == 0 and (k == 1 or sel_h[5][1] == -1)
+
+
+@pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["f16", "q8"])
+def test_kv_store_rows(kvd):
+    """ifa_kv_store = LayerKVCache::SetKRows / SetVRows (kv_cache.cc:159-249): F16 rows copied, Q8 rows through the Alg2
+    quantiser -- the cache bytes the oracle's quantiser produces, at the requested row offset, neighbours untouched."""
+    rng = np.random.default_rng(3)
+    T, kv_dim, max_ctx, row0 = 5, 256, 16, 7
+    rows = rng.normal(0, 1.0, (T, kv_dim)).astype(np.float16)
+    rb = dt.row_bytes(kvd, kv_dim)
+    cache = torch.full((max_ctx * rb,), 0xAB, dtype=torch.uint8, device="cuda")
+    ia.check(g.capi().ifa_kv_store(kvd, g.p(g.dev(rows)), T, kv_dim, g.p(cache), row0, g.stream()))
+    got = cache.cpu().numpy().reshape(max_ctx, rb)
+    exp = rows.view(np.uint8).reshape(T, rb) if kvd == dt.F16 else o.quantize_act_q8(rows).reshape(T, rb)
+    assert np.array_equal(got[row0:row0 + T], exp)
+    assert (got[:row0] == 0xAB).all() and (got[row0 + T:] == 0xAB).all()
