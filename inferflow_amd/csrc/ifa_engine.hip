@@ -18,6 +18,7 @@
 #include "ifa_host.h"
 #include "ifa_decode_kernels.h"
 #include "ifa_decode_gemv.h"
+#include "ifa_moe.h"
 
 using namespace ifa;
 
@@ -41,6 +42,7 @@ struct Layer {
     Tensor t[T_MAX];
     std::vector<Tensor> experts;   // [expert][3]: w1, w2, w3 (MoE layers)
     void *moe_table = nullptr;     // device: [expert][4] tiled pointers {w1, w3, w2, -} for the fused decode kernels
+    void *moe_table_aos = nullptr; // device: [expert][3] reference-layout pointers {w1, w2, w3} for the grouped T > 1 launches
     void *kcache = nullptr, *vcache = nullptr;
 };
 
@@ -62,6 +64,12 @@ struct ifa_model {
     half_t *moe_in = nullptr, *moe_wdev = nullptr;    // MoE: one expert's gathered input rows; per-row weights
     int *moe_route = nullptr;                          // device: fused decode routing, [0..7] expert ids, halfs at byte 32: weights
     int *moe_idx = nullptr, *moe_pin = nullptr;        // MoE: row lists of all experts, back to back (device / pinned staging)
+    // MoE over T > 1 rows without the host (moe_ffn_device): routing, lists, gathered rows of ALL experts at once
+    int *moe_sel = nullptr, *moe_epos = nullptr, *moe_counts = nullptr;
+    half_t *moe_selw = nullptr, *moe_g1 = nullptr, *moe_g3 = nullptr, *moe_gin = nullptr, *moe_gout = nullptr;
+    uint8_t *moe_xq_in = nullptr, *moe_xq_mid = nullptr;
+    void *moe_tiles = nullptr, *moe_singles = nullptr;
+    int opt_moe_device = 1;
     int *state = nullptr;          // device: see k_dec_gather
     float *rope_tab = nullptr;     // device: [head_dim/2][2]
     long long *trace = nullptr;    // device: [2048][8] optional kernel phase stamps
@@ -483,6 +491,15 @@ extern "C" int ifa_rope_qk_store(void *q, void *k, const void *v, int head_dim, 
 extern "C" int ifa_activation_mul(int kind, const void *a, const void *b, size_t n, void *c, ifa_stream stream);
 extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens,
                                 const void *bias_f16, void *y_f16, ifa_stream stream);
+namespace ifa {     // ifa_moe.hip / ifa_gemm.hip / ifa_gemv.hip
+int moe_build_lists(const int *sel, const void *wsel, int T, int top_k, int E, int tile_rows, int *idx, void *wdev, int *epos, MoeTile *tiles,
+                    MoeSingle *singles, int *counts, hipStream_t s);
+int moe_gather(const void *src, const int *idx, const int *counts, int max_entries, int dim, void *dst, hipStream_t s);
+int moe_combine(const void *y, const int *epos, const void *wsel, int T, int top_k, int dim, void *out, hipStream_t s);
+int gemm_q_grouped(int w_dtype, const MoeGroup &grp, size_t N, size_t K, const void *X, void *Y, int max_tiles, int tile_rows, hipStream_t s);
+int gemv_ax8_grouped(int w_dtype, const MoeGroup &grp, size_t rows, size_t cols, const void *xq8_rows, void *y_rows, int max_singles,
+                     hipStream_t s);
+}
 static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const Tensor &bias, half_t *C);
 static int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y, float base = 0.0f);
 
@@ -569,6 +586,20 @@ static int ensure_scratch(ifa_model *m, int T)
         if (m->moe_pin) IFA_HIP_CHECK(hipHostFree(m->moe_pin));
         IFA_HIP_CHECK(hipHostMalloc((void **)&m->moe_pin, cap * (sizeof(int) + 2) + 16, hipHostMallocDefault));
         if (!m->moe_route) { IFA_HIP_CHECK(hipMalloc((void **)&m->moe_route, 64)); IFA_HIP_CHECK(hipMemsetAsync(m->moe_route, 0, 64, m->stream)); }
+        // device-routed path: every expert's rows at once (cap entries)
+        void **raw[] = {(void **)&m->moe_sel, (void **)&m->moe_epos, (void **)&m->moe_counts, (void **)&m->moe_xq_in, (void **)&m->moe_xq_mid,
+                        &m->moe_tiles, &m->moe_singles};
+        for (void **p : raw) if (*p) { IFA_HIP_CHECK(hipFree(*p)); *p = nullptr; }
+        IFA_HIP_CHECK(hipMalloc((void **)&m->moe_sel, cap * sizeof(int)));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->moe_epos, cap * sizeof(int)));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->moe_counts, 16 * sizeof(int)));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->moe_xq_in, cap * (D / 32 + 1) * 34));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->moe_xq_mid, cap * (F / 32 + 1) * 34));
+        IFA_HIP_CHECK(hipMalloc(&m->moe_tiles, (cap / 64 + (size_t)c.experts + 1) * sizeof(MoeTile)));
+        IFA_HIP_CHECK(hipMalloc(&m->moe_singles, ((size_t)c.experts + 1) * sizeof(MoeSingle)));
+        if ((rc = re(m->moe_selw, cap)) || (rc = re(m->moe_g1, cap * F)) || (rc = re(m->moe_g3, cap * F)) || (rc = re(m->moe_gin, cap * D))
+            || (rc = re(m->moe_gout, cap * D)))
+            return rc;
     }
     if (m->xq) IFA_HIP_CHECK(hipFree(m->xq));
     IFA_HIP_CHECK(hipMalloc((void **)&m->xq, (maxcols / 32 + 1) * 34));
@@ -747,8 +778,12 @@ static int ffn_dense(ifa_model *m, const half_t *x, int T, const Tensor &w1, con
 // host top-k (HostTensorOpr::BuildRowsForMoE, host_tensor_opr.cc:190-244: probabilities below 1e-5 are dropped,
 // optional renormalisation) -> the selected experts' FFNs in ascending expert order, each row on the T=1
 // path -> B[row] = hfma(out, weight, B[row]) (AddByRowIdx_Kernel).  Result in m->f.
+static bool moe_device_ok(const ifa_model *m, const Layer &L);
+static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T);
+
 static int moe_ffn(ifa_model *m, Layer &L, const half_t *ff_n, int T)
 {
+    if (T > 1 && moe_device_ok(m, L)) return moe_ffn_device(m, L, ff_n, T);
     const ifa_model_config &c = m->cfg;
     const size_t D = (size_t)c.dim; const int E = c.experts;
     ifa_stream s = (ifa_stream)m->stream;
@@ -815,6 +850,62 @@ static int moe_ffn(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     }
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));      // the pinned lists are reused by the next MoE layer
     return IFA_OK;
+}
+
+// The same layer without the host (T > 1 rows; ifa_moe.h): routing and the per-expert row lists are built on the device,
+// the rows of ALL experts are gathered once (experts ascending, token order inside an expert -- the reference's order), and
+// each of the three products is ONE grouped launch over the experts with >= 2 rows (MFMA GEMM tiles, the reference's T > 1
+// branch: F16 activations on dequantised weights) plus ONE over the single-row experts (the int8-activation GEMV of its
+// T = 1 branch, bit-identical to the op-level kernel).  No D2H copy, no stream synchronisation.  Result in m->f.
+static bool moe_device_ok(const ifa_model *m, const Layer &L)
+{
+    const ifa_model_config &c = m->cfg;
+    if (!m->opt_moe_device || !L.moe_table_aos || (int)L.experts.size() != c.experts * 3) return false;
+    const Tensor &w1 = L.experts[0], &w2 = L.experts[1], &w3 = L.experts[2];
+    if (!w3.present() || !ax8_eligible(w1.dtype) || !m->cfg.full_quant_gemv || w1.cols % 32 || w2.cols % 32) return false;
+    for (int e = 0; e < c.experts; e++)
+        for (int k3 = 0; k3 < 3; k3++) {
+            const Tensor &t = L.experts[(size_t)e * 3 + k3], &r = L.experts[(size_t)k3];
+            if (!t.present() || t.dtype != r.dtype || t.rows != r.rows || t.cols != r.cols) return false;
+        }
+    return true;
+}
+
+static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
+{
+    const ifa_model_config &c = m->cfg;
+    const size_t D = (size_t)c.dim, F = L.experts[0].rows;
+    const int E = c.experts, K = c.moe_top_k, cap = T * K;
+    ifa_stream s = (ifa_stream)m->stream;
+    int rc;
+    Tensor none;
+    if ((rc = matmul(m, ff_n, T, L.t[T_MOE_GATE], none, m->moe_gate))) return rc;
+    if ((rc = ifa_softmax(m->moe_gate, E, T, 1, -1, 1.0f, s))) return rc;
+    if ((rc = ifa_moe_route_topk(m->moe_gate, (size_t)T, E, K, c.moe_norm_topk, m->moe_sel, m->moe_selw, s))) return rc;
+    // rows per expert on average >= 96: 128-row tiles (each decoded weight block feeds four MFMA tiles); else 64-row split-K tiles
+    const int tile_rows = (cap / std::max(1, E) >= 96) ? 128 : 64;
+    if ((rc = moe_build_lists(m->moe_sel, m->moe_selw, T, K, E, tile_rows, m->moe_idx, m->moe_wdev, m->moe_epos, (MoeTile *)m->moe_tiles,
+                              (MoeSingle *)m->moe_singles, m->moe_counts, m->stream))) return rc;
+    if ((rc = moe_gather(ff_n, m->moe_idx, m->moe_counts, cap, (int)D, m->moe_gin, m->stream))) return rc;
+    MoeGroup g;
+    g.tiles = (const MoeTile *)m->moe_tiles; g.singles = (const MoeSingle *)m->moe_singles; g.counts = m->moe_counts;
+    g.wtab = (const uint8_t *const *)L.moe_table_aos; g.on = 1;
+    const int wdt = L.experts[0].dtype;
+    const int max_tiles = cap / tile_rows + E, max_singles = std::min(E, cap);
+    // single-row experts take the quantised row (TensorOpr::Quantize in front of Gemv_AX, inference_worker.cc:1772-1774)
+    if ((rc = ifa_quantize_act_q8(m->moe_gin, (size_t)cap, D, m->moe_xq_in, s))) return rc;
+    g.which = 0;
+    if ((rc = gemm_q_grouped(wdt, g, F, D, m->moe_gin, m->moe_g1, max_tiles, tile_rows, m->stream))) return rc;
+    if ((rc = gemv_ax8_grouped(wdt, g, F, D, m->moe_xq_in, m->moe_g1, max_singles, m->stream))) return rc;
+    g.which = 2;
+    if ((rc = gemm_q_grouped(wdt, g, F, D, m->moe_gin, m->moe_g3, max_tiles, tile_rows, m->stream))) return rc;
+    if ((rc = gemv_ax8_grouped(wdt, g, F, D, m->moe_xq_in, m->moe_g3, max_singles, m->stream))) return rc;
+    if ((rc = ifa_activation_mul(c.act_kind, m->moe_g1, m->moe_g3, (size_t)cap * F, m->moe_g1, s))) return rc;
+    if ((rc = ifa_quantize_act_q8(m->moe_g1, (size_t)cap, F, m->moe_xq_mid, s))) return rc;
+    g.which = 1;
+    if ((rc = gemm_q_grouped(wdt, g, D, F, m->moe_g1, m->moe_gout, max_tiles, tile_rows, m->stream))) return rc;
+    if ((rc = gemv_ax8_grouped(wdt, g, D, F, m->moe_xq_mid, m->moe_gout, max_singles, m->stream))) return rc;
+    return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, m->f, m->stream);
 }
 
 static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token)
@@ -1212,6 +1303,7 @@ int ifa_model_destroy(ifa_model *m)
         for (Tensor &t : L.t) free_tensor(t);
         for (Tensor &t : L.experts) free_tensor(t);
         if (L.moe_table) (void)hipFree(L.moe_table);
+        if (L.moe_table_aos) (void)hipFree(L.moe_table_aos);
         if (L.kcache) (void)hipFree(L.kcache);
         if (L.vcache) (void)hipFree(L.vcache);
     }
@@ -1230,6 +1322,9 @@ int ifa_model_destroy(ifa_model *m)
     if (m->trace) (void)hipFree(m->trace);
     if (m->xq) (void)hipFree(m->xq);
     if (m->attq) (void)hipFree(m->attq);
+    { void *mb[] = {m->moe_sel, m->moe_epos, m->moe_counts, m->moe_selw, m->moe_g1, m->moe_g3, m->moe_gin, m->moe_gout, m->moe_xq_in,
+                    m->moe_xq_mid, m->moe_tiles, m->moe_singles};
+      for (void *b : mb) if (b) (void)hipFree(b); }
     { void *tpb[] = {m->tp_a, m->tp_f, m->tp_hid, m->tp_logits, m->tp_best, m->tp_gather, m->tp_tok};
       for (void *b : tpb) if (b) (void)hipFree(b); }
     if (m->state) (void)hipFree(m->state);
@@ -1353,6 +1448,10 @@ int ifa_model_finalize(ifa_model *m)
             }
             if (!L.moe_table) IFA_HIP_CHECK(hipMalloc(&L.moe_table, tab.size() * sizeof(void *)));
             IFA_HIP_CHECK(hipMemcpy(L.moe_table, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice));
+            std::vector<void *> aos((size_t)c.experts * 3, nullptr);
+            for (int e = 0; e < c.experts; e++) for (int k3 = 0; k3 < 3; k3++) aos[(size_t)e * 3 + k3] = L.experts[(size_t)e * 3 + k3].data;
+            if (!L.moe_table_aos) IFA_HIP_CHECK(hipMalloc(&L.moe_table_aos, aos.size() * sizeof(void *)));
+            IFA_HIP_CHECK(hipMemcpy(L.moe_table_aos, aos.data(), aos.size() * sizeof(void *), hipMemcpyHostToDevice));
         }
     }
     if (!m->attn_ws.S) {
@@ -1435,7 +1534,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;

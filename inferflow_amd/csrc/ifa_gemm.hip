@@ -14,8 +14,10 @@
 // Tokens are the A rows, weight rows the B columns.  k is consumed in a permuted order
 // (lane half g works through quant block 2*step+g): the sum over k does not care.
 #include <algorithm>
+#include <type_traits>
 #include "ifa_host.h"
 #include "ifa_codec.h"
+#include "ifa_moe.h"
 
 namespace ifa {
 
@@ -126,10 +128,12 @@ struct WRaw {
 // SPLITK = true : the 4 waves share ONE 32-row tile and take every 4th K step each (their own
 //                 LDS slab, no workgroup barrier in the loop), partial tiles summed through LDS at
 //                 the end: 4x more workgroups when T is small and the layer is weight-stream bound.
+// grp.on: grouped launch (mixture of experts, ifa_moe.h): blockIdx.y is a tile of <= 32*MT rows of ONE expert -- its
+// weights come from the pointer table, its activation / output rows start at the tile's entry offset
 template <int DT, int MT, bool SPLITK, int NW = 4>
 __global__ void __launch_bounds__(NW * 64) k_gemm_q(const uint8_t *__restrict__ W, int N, int nblk,
                                                          const half_t *__restrict__ X, int T, int K,
-                                                         const half_t *__restrict__ bias, half_t *__restrict__ Y)
+                                                         const half_t *__restrict__ bias, half_t *__restrict__ Y, const MoeGroup grp = MoeGroup())
 {
     constexpr int CAP = (DT == F16) ? 32 : block_capacity(DT);
     constexpr int KSTEP = 2 * CAP;                 // one quant block per lane half and step
@@ -141,7 +145,14 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_q(const uint8_t *__restrict__ 
     const int n = SPLITK ? blockIdx.x * 32 + i : blockIdx.x * GEMM_ROWS + wave * 32 + i;
     const size_t nrow = (size_t)min(n, N - 1);
     char *slab = SPLITK ? smem + (size_t)wave * (32 * MT * XROW) : smem;
-    const int t0 = blockIdx.y * 32 * MT;
+    int t0 = blockIdx.y * 32 * MT;
+    if (grp.on) {
+        if ((int)blockIdx.y >= grp.counts[1]) return;
+        const MoeTile tl = grp.tiles[blockIdx.y];
+        W = grp.wtab[tl.expert * 3 + grp.which];
+        X += (size_t)tl.row0 * K; Y += (size_t)tl.row0 * N;
+        T = tl.nrows; t0 = 0;
+    }
     f32x16_t acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -495,6 +506,39 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
                                                                       (int)K, (const half_t *)bias, (half_t *)Y);
     }
     return IFA_OK;
+}
+
+// Grouped product of a mixture-of-experts step (ifa_moe.h): every tile of the device-side table is <= 64 rows of one
+// expert; weight-stream regime (the split-K kernel of the T <= 128 range), max_tiles = upper bound of the table's length
+namespace ifa {
+int gemm_q_grouped(int w_dtype, const MoeGroup &grp, size_t N, size_t K, const void *X, void *Y, int max_tiles, int tile_rows, hipStream_t s)
+{
+    const int cap = w_dtype == F16 ? 32 : block_capacity(w_dtype);
+    if (cap <= 1 || K % (size_t)cap != 0 || K % 8 != 0) return ifa_fail(IFA_ERR_ARG, "grouped GEMM: dtype %d / cols %zu", w_dtype, K);
+    if (tile_rows != 64 && tile_rows != 128) return ifa_fail(IFA_ERR_ARG, "grouped GEMM: tile of %d rows", tile_rows);
+    if (max_tiles <= 0) return IFA_OK;
+    auto launch = [&](auto tag) {
+        constexpr int DT = decltype(tag)::value;
+        constexpr int CAP = (DT == F16) ? 32 : block_capacity(DT);
+        const size_t slab = (size_t)32 * 2 * (2 * CAP * 2 + 16);
+        if (tile_rows == 64) {          // few rows per expert: weight-stream regime, 32-row tiles with K split over 4 waves
+            constexpr int MT = 2, NW = 4;
+            const size_t smem = std::max(NW * slab, (size_t)(NW - 1) * MT * 16 * 64 * 4);
+            dim3 grid(ifa_cdiv(N, 32), (unsigned)max_tiles);
+            k_gemm_q<DT, MT, true, NW><<<grid, dim3(NW * 64), smem, s>>>(nullptr, (int)N, (int)(K / CAP), (const half_t *)X, 0, (int)K, nullptr,
+                                                                         (half_t *)Y, grp);
+        } else {                        // long prompts: 128 rows x 128 weight rows per workgroup, each decoded block feeds 4 MFMA tiles
+            constexpr int MT4 = 4;
+            dim3 grid(ifa_cdiv(N, GEMM_ROWS), (unsigned)max_tiles);
+            k_gemm_q<DT, MT4, false><<<grid, dim3(GEMM_THREADS), 2 * slab, s>>>(nullptr, (int)N, (int)(K / CAP), (const half_t *)X, 0, (int)K, nullptr,
+                                                                               (half_t *)Y, grp);
+        }
+    };
+    if (w_dtype == F16) launch(std::integral_constant<int, F16>());
+    else { IFA_DISPATCH_QUANT_DTYPE(w_dtype, launch(std::integral_constant<int, DT>())); }
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
 }
 
 extern "C" int ifa_gemm_big_tiles(int on)

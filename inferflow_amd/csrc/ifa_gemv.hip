@@ -17,6 +17,7 @@
 #include "ifa_host.h"
 #include "ifa_codec.h"
 #include "ifa_tiled.h"
+#include "ifa_moe.h"
 
 namespace ifa {
 
@@ -107,6 +108,61 @@ __global__ void __launch_bounds__(256) k_gemv_ax8_generic(const uint8_t *__restr
     }
     acc = wave_sum(acc);
     if (lane == 0) y[row] = finish_row(acc, bias, row);
+}
+
+// The same kernel over the single-row experts of a mixture-of-experts step (ifa_moe.h): blockIdx.y = index into the
+// device-side list; the expert's weights come from the pointer table, x / y are the entry's row of the gathered
+// (quantised) activation / output buffers.  Same loop, same ax8_term: bit-identical to the op-level GEMV.
+template <int DT>
+__global__ void __launch_bounds__(256) k_gemv_ax8_grouped(const MoeGroup grp, int rows, int nblk, const uint8_t *__restrict__ xq8_rows,
+                                                          size_t xq_row_bytes, half_t *__restrict__ y_rows)
+{
+    constexpr int CAP = block_capacity(DT), BB = block_bytes(DT);
+    if ((int)blockIdx.y >= grp.counts[2]) return;
+    const MoeSingle sg = grp.singles[blockIdx.y];
+    const uint8_t *W = grp.wtab[sg.expert * 3 + grp.which];
+    const uint8_t *xq8 = xq8_rows + (size_t)sg.pos * xq_row_bytes;
+    half_t *y = y_rows + (size_t)sg.pos * rows;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint8_t *wrow = W + (size_t)row * ((size_t)nblk * BB);
+    float acc = 0.0f;
+    for (int blk = lane; blk < nblk; blk += 64) {
+        RawBlock<BB> b;
+        b.load(wrow + (size_t)blk * BB);
+        int q[CAP]; float scale, base;
+        decode_block<DT>(b, q, scale, base);
+#pragma unroll
+        for (int h = 0; h < CAP / 32; h++) {
+            int xq[32]; float xs; int xsum;
+            load_x_block(xq8, blk * (CAP / 32) + h, xq, xs, xsum);
+            int dot = 0;
+#pragma unroll
+            for (int i = 0; i < 32; i++) dot += q[32 * h + i] * xq[i];
+            acc = acc + ax8_term<DT>(dot, xsum, scale, base, xs);
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = finish_row(acc, nullptr, row);
+}
+
+int gemv_ax8_grouped(int w_dtype, const MoeGroup &grp, size_t rows, size_t cols, const void *xq8_rows, void *y_rows, int max_singles,
+                     hipStream_t s)
+{
+    if (!ax8_eligible(w_dtype)) return ifa_fail(IFA_ERR_DTYPE, "grouped int8 GEMV: dtype %d", w_dtype);
+    if (max_singles <= 0) return IFA_OK;
+    const int cap = block_capacity(w_dtype);
+    const size_t xrb = cols / 32 * 34;
+    const dim3 grid(ifa_cdiv(rows, 4), (unsigned)max_singles);
+    switch (w_dtype) {
+#define IFA_GG(DTV) case DTV: k_gemv_ax8_grouped<DTV><<<grid, dim3(256), 0, s>>>(grp, (int)rows, (int)(cols / cap), (const uint8_t *)xq8_rows, xrb, (half_t *)y_rows); break;
+    IFA_GG(Q8_B32T2) IFA_GG(Q6_B64T1) IFA_GG(Q5_B64T1) IFA_GG(Q4_B32T1A) IFA_GG(Q4_B32T1B) IFA_GG(Q4_B64T1) IFA_GG(Q3H_B64T1)
+#undef IFA_GG
+    default: return ifa_fail(IFA_ERR_DTYPE, "grouped int8 GEMV: dtype %d", w_dtype);
+    }
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
 }
 
 // ----------------------------------------------------- fast Q4_B32T1 (tiled/AoS)
