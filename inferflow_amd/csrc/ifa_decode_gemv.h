@@ -20,6 +20,11 @@ bool dec_gemv_supported_long(int w_dtype, size_t cols);
 // epi: DecEpilogue, norm: 0/1.  P.nblk / P.total_rows are filled in here.
 int dec_gemv_launch(int w_dtype, int epi, int norm, const DecGemvParams &P, int wgs_per_cu, hipStream_t s, long long *trace);
 
+// fp16-activation variant (ifa_dgemv_f16x.hip): F16 tensors and the block formats outside the int8 path, weights in the
+// reference byte layout; cols % 8 == 0, cols <= 32768
+bool dec_gemv_h_supported(int w_dtype, size_t cols);
+int dec_gemv_h_launch(int w_dtype, int epi, int norm, const DecGemvParams &P, hipStream_t s);
+
 template <int DT>
 int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu, hipStream_t s);
 

@@ -854,8 +854,9 @@ template <int HD, bool Q8>
 __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(HD % 8 == 0 && HD <= 128 && (!Q8 || HD % 32 == 0), "head size: multiples of 8 up to 128 (Q8 rows: whole 32-blocks)");
     constexpr int DG = HD / 8;            // threads covering one V row (8 dims each)
-    constexpr int NSPLIT = 256 / DG;      // key residues handled in parallel
+    constexpr int NSPLIT = 256 / DG;      // key residues handled in parallel (head sizes 48 / 80 / 96: the last 256 % DG threads idle)
     half_t *qs = reinterpret_cast<half_t *>(smem);                 // [HD] rotated q
     half_t *kn = qs + HD;                                          // [HD] rotated (and Q8 round-tripped) new k
     half_t *vn = kn + HD;                                          // [HD] new v (Q8 round-tripped)
@@ -921,6 +922,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
         rope_cs = P.rope_tab[2 * c]; rope_sn = P.rope_tab[2 * c + 1];
     }
     const int dg = tid % DG, sp = tid / DG;
+    const bool vact = (256 % DG == 0) || sp < NSPLIT;   // this thread takes part in P.V
     constexpr int VPRE = 256 / NSPLIT;                  // prefetched V keys per thread: j = sp + NSPLIT*i (256 keys)
     u32x4 vreg[Q8 ? 1 : VPRE];
     uint16_t vq[Q8 ? VPRE : 1][5];                      // Q8: {scale, 4 x 2 codes} of this thread's 8 dims, 2-byte aligned
@@ -1062,7 +1064,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
 #pragma unroll
     for (int i = 0; i < VPRE; i++) {        // first 256 keys: V rows already in registers (static indexing)
         const int j = sp + NSPLIT * i;
-        if (j < n_ctx) {
+        if (j < n_ctx && vact) {
             const float pj = h2f(S[j]);
             if (j == pos) acc_new(pj);
             else if constexpr (Q8) {
@@ -1075,21 +1077,23 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
             } else acc_v(pj, vreg[i]);
         }
     }
-    for (int j = sp + NSPLIT * VPRE; j < n_ctx; j += NSPLIT) {
+    for (int j = vact ? sp + NSPLIT * VPRE : n_ctx; j < n_ctx; j += NSPLIT) {
         const float pj = h2f(S[j]);
         if (j == pos) acc_new(pj);
         else if constexpr (Q8) acc_q8(pj, j);
         else acc_v(pj, reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg]);
     }
+    if (vact) {
 #pragma unroll
-    for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
+        for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
+    }
     __syncthreads();
     if (tid < HD) {
         float acc = opart[tid];
         for (int s2 = 1; s2 < NSPLIT; s2++) acc = acc + opart[s2 * HD + tid];
         const half_t yh = f2h(acc);
         P.out[(size_t)h * HD + tid] = yh;
-        if (P.xq) dec_attn_emit_q8<HD>(P.xq, P.heads * HD, h, tid, yh);
+        if constexpr (HD % 32 == 0) { if (P.xq) dec_attn_emit_q8<HD>(P.xq, P.heads * HD, h, tid, yh); }
     }
 }
 
@@ -1250,10 +1254,11 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
     }
     __syncthreads();
     const int dg = tid % DG, sp = tid / DG;
+    const bool vact = (256 % DG == 0) || sp < NSPLIT;
     float o[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) o[i] = 0.0f;
-    for (int j = j0 + sp; j < j1; j += NSPLIT) {
+    for (int j = vact ? j0 + sp : j1; j < j1; j += NSPLIT) {
         const float pj = h2f(Pl[j - j0]);
         if constexpr (Q8) {
             const uint8_t *blk = P.vcache + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
@@ -1271,8 +1276,10 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
             for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, (float)v8[e], o[e]);
         }
     }
+    if (vact) {
 #pragma unroll
-    for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
+        for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
+    }
     __syncthreads();
     if (tid < HD) {
         float acc = opart[tid];
@@ -1291,7 +1298,7 @@ __global__ void __launch_bounds__(HD) k_dec_attn_combine(const DecAttnSplitWs ws
     for (int s2 = 1; s2 < DEC_ATTN_SPLITS; s2++) acc = acc + p[(size_t)s2 * HD];
     const half_t yh = f2h(acc);
     out[(size_t)h * HD + d] = yh;
-    if (xq) dec_attn_emit_q8<HD>(xq, heads * HD, h, d, yh);
+    if constexpr (HD % 32 == 0) { if (xq) dec_attn_emit_q8<HD>(xq, heads * HD, h, d, yh); }
 }
 
 __host__ __device__ inline size_t dec_attn_pv_smem(int head_dim, int max_ctx)

@@ -68,7 +68,7 @@ struct ifa_model {
     int *moe_sel = nullptr, *moe_epos = nullptr, *moe_counts = nullptr;
     half_t *moe_selw = nullptr, *moe_g1 = nullptr, *moe_g3 = nullptr, *moe_gin = nullptr, *moe_gout = nullptr;
     uint8_t *moe_xq_in = nullptr, *moe_xq_mid = nullptr;
-    void *moe_tiles = nullptr, *moe_singles = nullptr;
+    void *moe_tiles = nullptr, *moe_singles = nullptr, *moe_smalls = nullptr;
     int opt_moe_device = 1;
     int *state = nullptr;          // device: see k_dec_gather
     float *rope_tab = nullptr;     // device: [head_dim/2][2]
@@ -151,9 +151,25 @@ static constexpr size_t IFA_LDS_LIMIT = 160 * 1024;      // LDS per workgroup on
 static long long *g_trace_ptr = nullptr;   // set by ifa_model_time_kernel when the "trace" option is on
 static int num_cus() { return dec_num_cus(); }
 
+// The fused GEMV of a weight tensor: int8-path formats stream their tiled copy (k_dec_gemv), everything else -- F16
+// tensors, Q8_B32T1 / Q5_B32T1 / Q4_B16 / Q3_B32T1 / Q2_B32T1 -- the reference-layout bytes with fp16 activations
+// (k_dec_gemv_h).  wbytes() hands out the matching pointer.
+static bool fused_int8(int w_dtype) { return ax8_eligible(w_dtype); }
+static const uint8_t *wbytes(const Tensor &t) { return (const uint8_t *)(fused_int8(t.dtype) ? t.tiled : t.data); }
+static bool fused_ok(const Tensor &t, bool long_rows)
+{
+    if (!t.present()) return false;
+    if (fused_int8(t.dtype)) return t.tiled && (long_rows ? dec_gemv_supported_long(t.dtype, t.cols) : dec_gemv_supported(t.dtype, t.cols));
+    return dec_gemv_h_supported(t.dtype, t.cols) && (long_rows || t.cols <= 8192);
+}
+
 template <int EPI, int NORM>
 static int launch_dec_gemv(int w_dtype, const DecGemvParams &P, int wgs_per_cu_opt, hipStream_t s)
 {
+    if (!fused_int8(w_dtype)) {
+        if constexpr (NORM == 2 || epi_is_moe(EPI)) return ifa_fail(IFA_ERR_STATE, "fused GEMV: dtype %d has no kernel for this launch", w_dtype);
+        else return dec_gemv_h_launch(w_dtype, EPI, NORM, P, s);
+    }
     return dec_gemv_launch(w_dtype, EPI, NORM, P, wgs_per_cu_opt, s, g_trace_ptr);
 }
 
@@ -189,7 +205,8 @@ static bool fused_supported(const ifa_model *m, std::string *why)
         return fail("models with output scales (attn_out_scale / ffn_out_scale / out_scale) use the op-by-op path");
     if (c.experts > 0 && (c.norm_kind != 0 || c.parallel_attn || c.share_input)) return fail("MoE layers need the sequential RMS-norm wiring");
     if (!c.full_quant_gemv) return fail("full_quant_gemv disabled");
-    if (c.head_dim != 32 && c.head_dim != 64 && c.head_dim != 128) return fail("fused attention supports head_dim 32/64/128");
+    if (c.head_dim != 32 && c.head_dim != 48 && c.head_dim != 64 && c.head_dim != 80 && c.head_dim != 96 && c.head_dim != 128)
+        return fail("fused attention supports head_dim 32/48/64/80/96/128");
     if (c.kv_dtype == Q8_B32T2 && c.head_dim % 32 != 0) return fail("Q8 KV needs head_dim % 32 == 0");
     if (dec_attn_pv_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT) return fail("max_context_len too large for the fused attention kernels' LDS (decode falls back to the op-by-op path)");
     if (c.dim % 32 != 0 || c.ffn % 32 != 0) return fail("dim/ffn must be multiples of 32");
@@ -213,23 +230,22 @@ static bool fused_supported(const ifa_model *m, std::string *why)
         for (int ii = 0; ii < n_ids; ii++) {
             const int id = ids[ii];
             const Tensor &t = L.t[id];
-            if (!t.present() || !t.tiled) return fail("fused path needs weights in an int8-GEMV format (Q4/Q8/Q3H/Q5/Q6 block types)");
+            if (!t.present()) return fail("fused path: a layer's weight matrix is missing");
             const bool plain_input = id == T_WO || id == T_W2;      // neither normalised nor gated: long rows allowed
-            if (!(plain_input ? dec_gemv_supported_long(t.dtype, t.cols) : dec_gemv_supported(t.dtype, t.cols)))
-                return fail("fused GEMV: too many columns for this weight format");
+            if (!fused_ok(t, plain_input)) return fail("fused GEMV: columns out of range for this weight format (or cols % 8 != 0 for fp16 activations)");
         }
-        if (L.t[T_W3].present() && (!L.t[T_W3].tiled || !same_fmt(L.t[T_W3].dtype, L.t[T_W1].dtype))) return fail("w1/w3 dtype mismatch");
+        if (L.t[T_W3].present() && (!fused_ok(L.t[T_W3], false) || !same_fmt(L.t[T_W3].dtype, L.t[T_W1].dtype))) return fail("w1/w3 dtype mismatch");
         if (!L.t[T_ATTN_NORM].present()) return fail("pre-norm weights required");
         if (!L.t[T_FFN_NORM].present() && !c.parallel_attn) return fail("ffn pre-norm weights required");
-        if (!same_fmt(L.t[T_WQ].dtype, L.t[T_WK].dtype) || !same_fmt(L.t[T_WQ].dtype, L.t[T_WV].dtype)) return fail("wq/wk/wv dtype mismatch");
+        // (wq / wk / wv of different formats -- grouped-query models under the tensor_quant_threshold rule -- get one launch each)
     }
     const Tensor &lm = m->g[T_LM_HEAD];
     // a pipeline stage (BY_LAYER partition) may hold neither embeddings nor lm_head: checked where they are used
     if (!lm.present()) { /* middle / first stage */ }
     else if (lm.dtype == F16) {
         if (lm.cols > 8192 || lm.cols % 8 != 0) return fail("fused F16 lm_head needs cols <= 8192");
-    } else if (!lm.tiled || !dec_gemv_supported(lm.dtype, lm.cols) || !m->g[T_OUT_NORM].present()) {
-        return fail("fused lm_head needs F16 or an int8-GEMV weight format (with an output norm)");
+    } else if (!fused_ok(lm, false) || !m->g[T_OUT_NORM].present()) {
+        return fail("fused lm_head: columns out of range for its weight format (or no output norm)");
     }
     if (m->g[T_EMBD].present() && m->g[T_EMBD].dtype != F16) return fail("F16 embeddings required");
     return true;
@@ -260,7 +276,7 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
     const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
     half_t *outs[3] = {m->q, m->k, m->v};
     for (int i = 0; i < 3; i++) {
-        P.W0[i] = (const uint8_t *)L.t[ids[i]].tiled; P.b0[i] = (const half_t *)L.t[bids[i]].data;
+        P.W0[i] = wbytes(L.t[ids[i]]); P.b0[i] = (const half_t *)L.t[bids[i]].data;
         P.y[i] = outs[i]; P.rows[i] = (int)L.t[ids[i]].rows;
     }
     P.nsets = 3;
@@ -268,8 +284,24 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
         P.x = m->pend.x; P.x_add = m->pend.add; P.x_add_bias = m->pend.bias; P.xsum_out = m->pend.out;
         m->pend.on = false;
     }
-    if (std_norm) return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WQ].dtype, P, m->opt_rpw_qkv, m->stream);
-    return launch_dec_gemv<EPI_PLAIN, 1>(L.t[T_WQ].dtype, P, m->opt_rpw_qkv, m->stream);
+    auto go = [&](int dtype, const DecGemvParams &Q) {
+        if (std_norm) return launch_dec_gemv<EPI_PLAIN, 0>(dtype, Q, m->opt_rpw_qkv, m->stream);
+        return launch_dec_gemv<EPI_PLAIN, 1>(dtype, Q, m->opt_rpw_qkv, m->stream);
+    };
+    if (same_fmt(L.t[T_WQ].dtype, L.t[T_WK].dtype) && same_fmt(L.t[T_WQ].dtype, L.t[T_WV].dtype)) return go(L.t[T_WQ].dtype, P);
+    // mixed formats (e.g. wq quantised, wk / wv left F16 by the threshold rule): one launch per matrix; the first one forms
+    // a pending sum, the others read the stored result
+    for (int i = 0; i < 3; i++) {
+        DecGemvParams Q = P;
+        Q.nsets = 1; Q.W0[0] = P.W0[i]; Q.b0[0] = P.b0[i]; Q.y[0] = P.y[i]; Q.rows[0] = P.rows[i];
+        if (i > 0) {
+            Q.xn_out = nullptr;
+            if (P.x_add) { Q.x = P.xsum_out; Q.x_add = nullptr; Q.x_add_bias = nullptr; Q.xsum_out = nullptr; }
+        }
+        int rc = go(L.t[ids[i]].dtype, Q);
+        if (rc) return rc;
+    }
+    return IFA_OK;
 }
 
 static int launch_attn(ifa_model *m, int l)
@@ -283,7 +315,7 @@ static int launch_attn(ifa_model *m, int l)
     A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale;
     A.rope_order = c.rope_order; A.rope_cols = rope_dims;
     A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
-    A.out = m->att; A.max_ctx = c.max_ctx; A.xq = m->attq;
+    A.out = m->att; A.max_ctx = c.max_ctx; A.xq = (c.head_dim % 32 == 0) ? m->attq : nullptr;
     // the one-workgroup kernel keeps a head's score row [max_ctx] in LDS: past the device limit (160 KiB: ~75K tokens of
     // context at head_dim 128) the keys-split-over-workgroups kernels run from position 0 on (scores in global memory)
     const bool lds_split = dec_attn_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT;
@@ -298,11 +330,18 @@ static int launch_attn(ifa_model *m, int l)
               else { k_dec_attn_scores<HDV, false><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
                      if (psmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_pv<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmem)); \
                      k_dec_attn_pv<HDV, false><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
-              k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att, m->attq, c.heads); break;
+              k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att, A.xq, c.heads); break;
+        // head sizes that are not whole Q8 blocks (48, 80) exist with an F16 KV cache only
+#define IFA_ATTN_SF(HDV) \
+    case HDV: k_dec_attn_scores<HDV, false><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
+              if (psmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_pv<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmem)); \
+              k_dec_attn_pv<HDV, false><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); \
+              k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att, A.xq, c.heads); break;
         switch (c.head_dim) {
-            IFA_ATTN_S(32) IFA_ATTN_S(64) IFA_ATTN_S(128)
+            IFA_ATTN_S(32) IFA_ATTN_S(64) IFA_ATTN_S(96) IFA_ATTN_S(128) IFA_ATTN_SF(48) IFA_ATTN_SF(80)
         default: return ifa_fail(IFA_ERR_ARG, "fused attention: head_dim %d", c.head_dim);
         }
+#undef IFA_ATTN_SF
 #undef IFA_ATTN_S
         IFA_LAUNCH_CHECK();
         return IFA_OK;
@@ -315,10 +354,14 @@ static int launch_attn(ifa_model *m, int l)
                              k_dec_attn<HDV, true><<<grid, block, asmem, m->stream>>>(A); } \
               else { if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
                      k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A); } break;
+#define IFA_ATTN_F(HDV) \
+    case HDV: if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
+              k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A); break;
     switch (c.head_dim) {
-        IFA_ATTN(32) IFA_ATTN(64) IFA_ATTN(128)
+        IFA_ATTN(32) IFA_ATTN(64) IFA_ATTN(96) IFA_ATTN(128) IFA_ATTN_F(48) IFA_ATTN_F(80)
     default: return ifa_fail(IFA_ERR_ARG, "fused attention: head_dim %d", c.head_dim);
     }
+#undef IFA_ATTN_F
 #undef IFA_ATTN
     IFA_LAUNCH_CHECK();
     return IFA_OK;
@@ -330,10 +373,11 @@ static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nul
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
     P.x = m->att; P.cols = (int)L.t[T_WO].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
-    P.W0[0] = (const uint8_t *)L.t[T_WO].tiled; P.rows[0] = (int)L.t[T_WO].rows; P.nsets = 1;
+    P.W0[0] = wbytes(L.t[T_WO]); P.rows[0] = (int)L.t[T_WO].rows; P.nsets = 1;
     // the attention kernel left its output quantised (XqImage): the GEMV needs no prologue.  Rows longer than a lane's
     // register image (chunked kernel) keep the in-kernel quantiser
-    const bool preq = m->attq && m->opt_attn_q8 && P.cols == m->cfg.heads * m->cfg.head_dim && dec_gemv_supported(L.t[T_WO].dtype, (size_t)P.cols);
+    const bool preq = m->attq && m->opt_attn_q8 && m->cfg.head_dim % 32 == 0 && P.cols == m->cfg.heads * m->cfg.head_dim && fused_int8(L.t[T_WO].dtype)
+        && dec_gemv_supported(L.t[T_WO].dtype, (size_t)P.cols);
     if (preq) P.x = reinterpret_cast<const half_t *>(m->attq);      // NORM == 2 kernels read the quantised image through P.x
     if (partial) {
         P.y[0] = partial;
@@ -374,7 +418,7 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
         if (e3.present()) return launch_dec_gemv<EPI_MOE_GLU, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
         return launch_dec_gemv<EPI_MOE_ACT, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
     }
-    P.W0[0] = (const uint8_t *)L.t[T_W1].tiled; P.b0[0] = (const half_t *)L.t[T_W1_B].data;
+    P.W0[0] = wbytes(L.t[T_W1]); P.b0[0] = (const half_t *)L.t[T_W1_B].data;
     P.y[0] = m->t1; P.rows[0] = (int)L.t[T_W1].rows; P.nsets = 1;
     // FFN input (inference_worker.cc:853-872): the attention's normalised input (parallel attention), the layer input
     // (shared input) or the attention output + residual; then the FFN pre-norm if the model has one
@@ -388,7 +432,7 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
     }
     if (!need_norm) { P.norm_w = nullptr; P.norm_b = nullptr; }
     const bool glu = L.t[T_W3].present();
-    if (glu) { P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.b1 = (const half_t *)L.t[T_W3_B].data; }
+    if (glu) { P.W1 = wbytes(L.t[T_W3]); P.b1 = (const half_t *)L.t[T_W3_B].data; }
     const int dtw = L.t[T_W1].dtype;
     if (need_norm && m->pend.on && P.x == m->pend.out) {     // the FFN input is the pending sum
         P.x = m->pend.x; P.x_add = m->pend.add; P.x_add_bias = m->pend.bias; P.xsum_out = m->pend.out;
@@ -417,7 +461,7 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
         return launch_dec_gemv<EPI_MOE_ACC, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
     }
     P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
-    P.W0[0] = (const uint8_t *)L.t[T_W2].tiled; P.rows[0] = (int)L.t[T_W2].rows; P.nsets = 1;
+    P.W0[0] = wbytes(L.t[T_W2]); P.rows[0] = (int)L.t[T_W2].rows; P.nsets = 1;
     if (partial) {
         P.y[0] = partial;
         return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
@@ -435,7 +479,7 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
         DecGemvParams P; memset(&P, 0, sizeof(P));
         P.x = x; P.norm_w = (const half_t *)m->g[T_OUT_NORM].data; P.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
         P.eps = c.eps; P.cols = c.dim; P.xn_out = m->xn; P.multi_base = c.out_norm_base;
-        P.W0[0] = (const uint8_t *)lmt.tiled; P.rows[0] = (int)lmt.rows; P.nsets = 1;
+        P.W0[0] = wbytes(lmt); P.rows[0] = (int)lmt.rows; P.nsets = 1;
         P.y[0] = logits_out ? logits_out : m->logits;
         return launch_dec_gemv<EPI_PLAIN, 1>(lmt.dtype, P, m->opt_rpw_lm, m->stream);
     }
@@ -492,8 +536,10 @@ extern "C" int ifa_activation_mul(int kind, const void *a, const void *b, size_t
 extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens,
                                 const void *bias_f16, void *y_f16, ifa_stream stream);
 namespace ifa {     // ifa_moe.hip / ifa_gemm.hip / ifa_gemv.hip
-int moe_build_lists(const int *sel, const void *wsel, int T, int top_k, int E, int tile_rows, int *idx, void *wdev, int *epos, MoeTile *tiles,
-                    MoeSingle *singles, int *counts, hipStream_t s);
+int moe_build_lists(const int *sel, const void *wsel, int T, int top_k, int E, int tile_rows, int small_max, int *idx, void *wdev, int *epos,
+                    MoeTile *tiles, MoeSingle *singles, MoeTile *smalls, int *counts, hipStream_t s);
+int gemm_rows_q4_grouped_cap(size_t cols);
+int gemm_rows_q4_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, hipStream_t s);
 int moe_gather(const void *src, const int *idx, const int *counts, int max_entries, int dim, void *dst, hipStream_t s);
 int moe_combine(const void *y, const int *epos, const void *wsel, int T, int top_k, int dim, void *out, hipStream_t s);
 int gemm_q_grouped(int w_dtype, const MoeGroup &grp, size_t N, size_t K, const void *X, void *Y, int max_tiles, int tile_rows, hipStream_t s);
@@ -588,7 +634,7 @@ static int ensure_scratch(ifa_model *m, int T)
         if (!m->moe_route) { IFA_HIP_CHECK(hipMalloc((void **)&m->moe_route, 64)); IFA_HIP_CHECK(hipMemsetAsync(m->moe_route, 0, 64, m->stream)); }
         // device-routed path: every expert's rows at once (cap entries)
         void **raw[] = {(void **)&m->moe_sel, (void **)&m->moe_epos, (void **)&m->moe_counts, (void **)&m->moe_xq_in, (void **)&m->moe_xq_mid,
-                        &m->moe_tiles, &m->moe_singles};
+                        &m->moe_tiles, &m->moe_singles, &m->moe_smalls};
         for (void **p : raw) if (*p) { IFA_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         IFA_HIP_CHECK(hipMalloc((void **)&m->moe_sel, cap * sizeof(int)));
         IFA_HIP_CHECK(hipMalloc((void **)&m->moe_epos, cap * sizeof(int)));
@@ -597,6 +643,7 @@ static int ensure_scratch(ifa_model *m, int T)
         IFA_HIP_CHECK(hipMalloc((void **)&m->moe_xq_mid, cap * (F / 32 + 1) * 34));
         IFA_HIP_CHECK(hipMalloc(&m->moe_tiles, (cap / 64 + (size_t)c.experts + 1) * sizeof(MoeTile)));
         IFA_HIP_CHECK(hipMalloc(&m->moe_singles, ((size_t)c.experts + 1) * sizeof(MoeSingle)));
+        IFA_HIP_CHECK(hipMalloc(&m->moe_smalls, ((size_t)c.experts + 1) * sizeof(MoeTile)));
         if ((rc = re(m->moe_selw, cap)) || (rc = re(m->moe_g1, cap * F)) || (rc = re(m->moe_g3, cap * F)) || (rc = re(m->moe_gin, cap * D))
             || (rc = re(m->moe_gout, cap * D)))
             return rc;
@@ -884,27 +931,39 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     if ((rc = ifa_moe_route_topk(m->moe_gate, (size_t)T, E, K, c.moe_norm_topk, m->moe_sel, m->moe_selw, s))) return rc;
     // rows per expert on average >= 96: 128-row tiles (each decoded weight block feeds four MFMA tiles); else 64-row split-K tiles
     const int tile_rows = (cap / std::max(1, E) >= 96) ? 128 : 64;
-    if ((rc = moe_build_lists(m->moe_sel, m->moe_selw, T, K, E, tile_rows, m->moe_idx, m->moe_wdev, m->moe_epos, (MoeTile *)m->moe_tiles,
-                              (MoeSingle *)m->moe_singles, m->moe_counts, m->stream))) return rc;
+    // a handful of rows per expert (dynamic batching): experts with 2..small_max rows stream their tiled Q4 weights once
+    // (ifa_gemm_rows.hip) instead of filling a 64-row MFMA tile with mostly padding
+    const int wdt = L.experts[0].dtype;
+    const bool rows_kernel = is_q4(wdt) && m->opt_gemm_rows && L.moe_table && cap <= 8 * E
+        && gemm_rows_q4_grouped_cap(D) > 0 && gemm_rows_q4_grouped_cap(F) > 0;
+    const int small_max = rows_kernel ? 8 : 0;
+    if ((rc = moe_build_lists(m->moe_sel, m->moe_selw, T, K, E, tile_rows, small_max, m->moe_idx, m->moe_wdev, m->moe_epos, (MoeTile *)m->moe_tiles,
+                              (MoeSingle *)m->moe_singles, (MoeTile *)m->moe_smalls, m->moe_counts, m->stream))) return rc;
+    MoeSmallGroup sg;
+    sg.smalls = (const MoeTile *)m->moe_smalls; sg.counts = m->moe_counts; sg.wtab_tiled = (const uint8_t *const *)L.moe_table; sg.which_tiled = 0;
+    const int max_smalls = rows_kernel ? std::min(E, cap / 2) : 0;
     if ((rc = moe_gather(ff_n, m->moe_idx, m->moe_counts, cap, (int)D, m->moe_gin, m->stream))) return rc;
     MoeGroup g;
     g.tiles = (const MoeTile *)m->moe_tiles; g.singles = (const MoeSingle *)m->moe_singles; g.counts = m->moe_counts;
     g.wtab = (const uint8_t *const *)L.moe_table_aos; g.on = 1;
-    const int wdt = L.experts[0].dtype;
     const int max_tiles = cap / tile_rows + E, max_singles = std::min(E, cap);
     // single-row experts take the quantised row (TensorOpr::Quantize in front of Gemv_AX, inference_worker.cc:1772-1774)
     if ((rc = ifa_quantize_act_q8(m->moe_gin, (size_t)cap, D, m->moe_xq_in, s))) return rc;
     g.which = 0;
     if ((rc = gemm_q_grouped(wdt, g, F, D, m->moe_gin, m->moe_g1, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, F, D, m->moe_xq_in, m->moe_g1, max_singles, m->stream))) return rc;
-    g.which = 2;
+    if (max_smalls && (rc = gemm_rows_q4_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls, m->stream))) return rc;
+    g.which = 2; sg.which_tiled = 1;
     if ((rc = gemm_q_grouped(wdt, g, F, D, m->moe_gin, m->moe_g3, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, F, D, m->moe_xq_in, m->moe_g3, max_singles, m->stream))) return rc;
+    if (max_smalls && (rc = gemm_rows_q4_grouped(sg, F, D, m->moe_gin, m->moe_g3, max_smalls, m->stream))) return rc;
     if ((rc = ifa_activation_mul(c.act_kind, m->moe_g1, m->moe_g3, (size_t)cap * F, m->moe_g1, s))) return rc;
     if ((rc = ifa_quantize_act_q8(m->moe_g1, (size_t)cap, F, m->moe_xq_mid, s))) return rc;
     g.which = 1;
     if ((rc = gemm_q_grouped(wdt, g, D, F, m->moe_g1, m->moe_gout, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, D, F, m->moe_xq_mid, m->moe_gout, max_singles, m->stream))) return rc;
+    sg.which_tiled = 2;
+    if (max_smalls && (rc = gemm_rows_q4_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls, m->stream))) return rc;
     return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, m->f, m->stream);
 }
 
@@ -1323,7 +1382,7 @@ int ifa_model_destroy(ifa_model *m)
     if (m->xq) (void)hipFree(m->xq);
     if (m->attq) (void)hipFree(m->attq);
     { void *mb[] = {m->moe_sel, m->moe_epos, m->moe_counts, m->moe_selw, m->moe_g1, m->moe_g3, m->moe_gin, m->moe_gout, m->moe_xq_in,
-                    m->moe_xq_mid, m->moe_tiles, m->moe_singles};
+                    m->moe_xq_mid, m->moe_tiles, m->moe_singles, m->moe_smalls};
       for (void *b : mb) if (b) (void)hipFree(b); }
     { void *tpb[] = {m->tp_a, m->tp_f, m->tp_hid, m->tp_logits, m->tp_best, m->tp_gather, m->tp_tok};
       for (void *b : tpb) if (b) (void)hipFree(b); }

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include "ifa_host.h"
 #include "ifa_decode_kernels.h"
+#include "ifa_moe.h"
 
 namespace ifa {
 
@@ -23,11 +24,9 @@ constexpr int GR_THREADS = 512, GR_WAVES = 8;
 // A wave walks its rows block-column by block-column (64 blocks = 2048 weights of each of its RW rows per step); the
 // next step's 20 bytes per lane and row are requested before the current ones are multiplied.
 template <int TB, int RW>
-__global__ void __launch_bounds__(GR_THREADS) k_gemm_rows_q4(const uint8_t *__restrict__ Wt, int rows, int nblk,
-                                                             const half_t *__restrict__ X, int T, int t0,
-                                                             const half_t *__restrict__ bias, half_t *__restrict__ Y)
+__device__ __forceinline__ void gemm_rows_chunk(const uint8_t *__restrict__ Wt, int rows, int nblk, const half_t *__restrict__ X, int T, int t0,
+                                                const half_t *__restrict__ bias, half_t *__restrict__ Y, char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gw = blockIdx.x * GR_WAVES + wave, W = gridDim.x * GR_WAVES;
@@ -61,7 +60,7 @@ __global__ void __launch_bounds__(GR_THREADS) k_gemm_rows_q4(const uint8_t *__re
     fetch(cur, 0);
     if (nsteps > 1) fetch(nxt, 1);
     __syncthreads();
-    if (gw >= rows) return;
+    if (gw >= rows) return;              // (from this chunk: a grouped caller's next chunk starts with a barrier all waves reach)
     float acc[RW][TB];
 #pragma unroll
     for (int i = 0; i < RW; i++)
@@ -131,6 +130,37 @@ __global__ void __launch_bounds__(GR_THREADS) k_gemm_rows_q4(const uint8_t *__re
     }
 }
 
+template <int TB, int RW>
+__global__ void __launch_bounds__(GR_THREADS) k_gemm_rows_q4(const uint8_t *__restrict__ Wt, int rows, int nblk,
+                                                             const half_t *__restrict__ X, int T, int t0,
+                                                             const half_t *__restrict__ bias, half_t *__restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_rows_chunk<TB, RW>(Wt, rows, nblk, X, T, t0, bias, Y, smem);
+}
+
+// Mixture of experts, a handful of rows per expert (ifa_moe.h "smalls"): blockIdx.y is one expert's group of 2..8
+// consecutive rows of the gathered activations; its tiled weights come from the pointer table.  Groups of more rows than
+// the LDS image holds at this K (tb_cap) are walked in chunks (the weights are streamed once per chunk).
+template <int RW>
+__global__ void __launch_bounds__(GR_THREADS) k_gemm_rows_q4_grouped(const MoeSmallGroup grp, int rows, int nblk, const half_t *__restrict__ X,
+                                                                     half_t *__restrict__ Y, int tb_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.y >= grp.counts[3]) return;
+    const MoeTile g = grp.smalls[blockIdx.y];
+    const uint8_t *Wt = grp.wtab_tiled[4 * g.expert + grp.which_tiled];
+    const half_t *Xg = X + (size_t)g.row0 * nblk * 32;
+    half_t *Yg = Y + (size_t)g.row0 * rows;
+    for (int t0 = 0; t0 < g.nrows; t0 += tb_cap) {
+        const int n = min(tb_cap, g.nrows - t0);
+        if (t0 > 0) __syncthreads();             // the previous chunk's LDS image has been read
+        if (n <= 2) gemm_rows_chunk<2, RW>(Wt, rows, nblk, Xg, g.nrows, t0, nullptr, Yg, smem);
+        else if (n <= 4) gemm_rows_chunk<4, RW>(Wt, rows, nblk, Xg, g.nrows, t0, nullptr, Yg, smem);
+        else gemm_rows_chunk<8, RW>(Wt, rows, nblk, Xg, g.nrows, t0, nullptr, Yg, smem);
+    }
+}
+
 } // namespace ifa
 
 using namespace ifa;
@@ -172,4 +202,32 @@ extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, 
         IFA_LAUNCH_CHECK();
     }
     return IFA_OK;
+}
+
+namespace ifa {
+// rows / cols of ONE expert matrix; X / Y: the gathered activations / outputs of all entries.  Returns IFA_ERR_STATE when
+// the shape is not covered (the caller then leaves those experts to the MFMA tiles: small_max = 0).
+int gemm_rows_q4_grouped_cap(size_t cols)
+{
+    if (cols % 32 != 0) return 0;
+    int tb = 8;
+    while ((size_t)tb * cols * 2 > 128 * 1024 && tb > 2) tb /= 2;
+    return (size_t)tb * cols * 2 > 128 * 1024 ? 0 : tb;
+}
+
+int gemm_rows_q4_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, hipStream_t s)
+{
+    const int tb = gemm_rows_q4_grouped_cap(cols);
+    if (tb == 0 || rows == 0) return ifa_fail(IFA_ERR_STATE, "grouped rows GEMM: %zu columns", cols);
+    if (max_groups <= 0) return IFA_OK;
+    // the experts share the chip: about two workgroups per CU over all groups
+    int wgs = std::max(16, 2 * gr_num_cus() / max_groups);
+    wgs = std::min(wgs, (int)((rows + GR_WAVES - 1) / GR_WAVES));
+    const size_t smem = (size_t)tb * cols * 2;
+    auto kern = k_gemm_rows_q4_grouped<2>;
+    if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    kern<<<dim3((unsigned)wgs, (unsigned)max_groups), dim3(GR_THREADS), smem, s>>>(grp, (int)rows, (int)(cols / 32), (const half_t *)X, (half_t *)Y, tb);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
 }

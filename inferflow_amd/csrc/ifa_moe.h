@@ -6,6 +6,8 @@
 //               an expert's rows are contiguous in the gathered activation / output buffers
 //   tiles     : <= 64 (or 128, for long prompts) consecutive entries of ONE expert that has >= 2 rows -> one MFMA GEMM tile (the reference's T > 1
 //               branch of MatrixMultiplication: F16 activations on dequantised weights)
+//   smalls    : experts with 2 .. small_max rows (dynamic batching: a handful of rows per expert) -> the same T > 1
+//               arithmetic from the weight-streaming kernel (ifa_gemm_rows.hip) instead of a mostly empty MFMA tile
 //   singles   : experts with exactly one row -> the int8-activation GEMV arithmetic (its T = 1 branch)
 #pragma once
 #include <stdint.h>
@@ -15,7 +17,7 @@ namespace ifa {
 struct MoeTile { int expert, row0, nrows, pad; };
 struct MoeSingle { int expert, pos; };
 
-// counters written by k_moe_build: [0] entries, [1] tiles, [2] singles
+// counters written by k_moe_build: [0] entries, [1] tiles, [2] singles, [3] smalls
 struct MoeGroup {
     const MoeTile *tiles;
     const MoeSingle *singles;
@@ -23,6 +25,13 @@ struct MoeGroup {
     const uint8_t *const *wtab;     // [expert][3] reference-layout (AoS) weight pointers {w1, w2, w3}
     int which;                      // 0 w1, 1 w2, 2 w3
     int on;                         // 0: plain (ungrouped) launch
+};
+// the small-group launch: its list and the TILED weight pointers ([expert][4]: {w1, w3, w2, -}, the fused decode kernels' table)
+struct MoeSmallGroup {
+    const MoeTile *smalls;
+    const int *counts;
+    const uint8_t *const *wtab_tiled;
+    int which_tiled;                // 0 w1, 1 w3, 2 w2
 };
 
 } // namespace ifa

@@ -12,8 +12,9 @@ namespace ifa {
 //   idx[pos] = token row of entry pos, wdev[pos] = its weight, epos[t * top_k + j] = pos of row t's j-th expert (-1 none)
 //   tiles / singles / counts as described in ifa_moe.h
 __global__ void __launch_bounds__(1024) k_moe_build(const int *__restrict__ sel, const half_t *__restrict__ wsel, int T, int top_k, int E, int tile_rows,
-                                                    int *__restrict__ idx, half_t *__restrict__ wdev, int *__restrict__ epos,
-                                                    MoeTile *__restrict__ tiles, MoeSingle *__restrict__ singles, int *__restrict__ counts)
+                                                    int small_max, int *__restrict__ idx, half_t *__restrict__ wdev, int *__restrict__ epos,
+                                                    MoeTile *__restrict__ tiles, MoeSingle *__restrict__ singles, MoeTile *__restrict__ smalls,
+                                                    int *__restrict__ counts)
 {
     __shared__ int cnt[64], start[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
@@ -27,15 +28,16 @@ __global__ void __launch_bounds__(1024) k_moe_build(const int *__restrict__ sel,
     }
     __syncthreads();
     if (tid == 0) {
-        int off = 0, nt = 0, ns = 0;
+        int off = 0, nt = 0, ns = 0, nm = 0;
         for (int e = 0; e < E; e++) {
             start[e] = off;
             const int c = cnt[e];
             if (c == 1) { singles[ns].expert = e; singles[ns].pos = off; ns++; }
+            else if (c >= 2 && c <= small_max) { smalls[nm].expert = e; smalls[nm].row0 = off; smalls[nm].nrows = c; smalls[nm].pad = 0; nm++; }
             else for (int r = 0; r < c; r += tile_rows) { tiles[nt].expert = e; tiles[nt].row0 = off + r; tiles[nt].nrows = min(tile_rows, c - r); tiles[nt].pad = 0; nt++; }
             off += c;
         }
-        counts[0] = off; counts[1] = nt; counts[2] = ns;
+        counts[0] = off; counts[1] = nt; counts[2] = ns; counts[3] = nm;
     }
     __syncthreads();
     // stable fill: a wave per expert walks the entries in order, 64 at a time (ballot + prefix count)
@@ -81,10 +83,10 @@ __global__ void __launch_bounds__(256) k_moe_combine(const half_t *__restrict__ 
     out[(size_t)t * dim + d] = acc;
 }
 
-int moe_build_lists(const int *sel, const void *wsel, int T, int top_k, int E, int tile_rows, int *idx, void *wdev, int *epos, MoeTile *tiles,
-                    MoeSingle *singles, int *counts, hipStream_t s)
+int moe_build_lists(const int *sel, const void *wsel, int T, int top_k, int E, int tile_rows, int small_max, int *idx, void *wdev, int *epos,
+                    MoeTile *tiles, MoeSingle *singles, MoeTile *smalls, int *counts, hipStream_t s)
 {
-    k_moe_build<<<1, 1024, 0, s>>>(sel, (const half_t *)wsel, T, top_k, E, tile_rows, idx, (half_t *)wdev, epos, tiles, singles, counts);
+    k_moe_build<<<1, 1024, 0, s>>>(sel, (const half_t *)wsel, T, top_k, E, tile_rows, small_max, idx, (half_t *)wdev, epos, tiles, singles, smalls, counts);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }

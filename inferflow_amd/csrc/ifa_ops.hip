@@ -387,32 +387,55 @@ __global__ void __launch_bounds__(256) k_add_by_row_index(half_t *__restrict__ B
 // token row: top-k by repeated first-maximum over the softmaxed router row, probabilities below 1e-5 dropped, optional
 // renormalisation over the kept ones; the kept (expert, weight) pairs in ASCENDING expert id (the order the reference
 // visits experts in), unused slots expert -1 / weight 0.
-__global__ void __launch_bounds__(64) k_moe_route_rows(const half_t *__restrict__ probs_h, int T, int E, int top_k, int norm,
-                                                       int *__restrict__ sel, half_t *__restrict__ wout)
+// One wave per row: lane e holds expert e's probability (E <= 64).
+__global__ void __launch_bounds__(256) k_moe_route_rows(const half_t *__restrict__ probs_h, int T, int E, int top_k, int norm,
+                                                        int *__restrict__ sel, half_t *__restrict__ wout)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
-    float probs[64]; int idx[8]; float w[8]; bool used[64];
-    for (int e = 0; e < E; e++) { probs[e] = h2f(probs_h[(size_t)t * E + e]); used[e] = false; }
+    const float p = lane < E ? h2f(probs_h[(size_t)t * E + lane]) : -INFINITY;
+    bool used = lane >= E;
+    int idx[8]; float w[8];
     int n = 0;
-    for (int k = 0; k < top_k && k < E; k++) {
-        int best = -1;
-        for (int e = 0; e < E; e++) if (!used[e] && (best < 0 || probs[e] > probs[best])) best = e;
-        if (best < 0) break;
-        used[best] = true;
-        if (probs[best] < 0.00001f) continue;
-        idx[n] = best; w[n] = probs[best]; n++;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        idx[k] = 0x7FFFFFFF; w[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= top_k || k >= E) break;
+        const float mx = wave_max(used ? -INFINITY : p);
+        const unsigned long long cand = __ballot(!used && p == mx);       // first maximum wins, like the host sort
+        if (!cand) break;
+        const int best = __ffsll((long long)cand) - 1;
+        if (lane == best) used = true;
+        const float pb = __shfl(p, best);
+        if (pb < 0.00001f) continue;
+        // (n is wave-uniform: a static slot per k would leave holes, so the kept pairs are compacted with selects)
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j == n) { idx[j] = best; w[j] = pb; }
+        n++;
     }
     if (norm && n > 0) {
         float sum = 0.0f;
-        for (int i2 = 0; i2 < n; i2++) sum = sum + w[i2];
-        for (int i2 = 0; i2 < n; i2++) w[i2] = w[i2] / sum;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j < n) sum = sum + w[j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j < n) w[j] = w[j] / sum;
     }
-    int slot = 0;
-    for (int e = 0; e < E; e++)
-        for (int j = 0; j < n; j++)
-            if (idx[j] == e) { sel[(size_t)t * top_k + slot] = e; wout[(size_t)t * top_k + slot] = f2h(w[j]); slot++; }
-    for (; slot < top_k; slot++) { sel[(size_t)t * top_k + slot] = -1; wout[(size_t)t * top_k + slot] = (half_t)0; }
+    if (lane != 0) return;
+    // kept pairs in ascending expert id: slot of pair j = number of kept experts below it
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j >= n) continue;
+        int rank = 0;
+#pragma unroll
+        for (int j2 = 0; j2 < 8; j2++) rank += (j2 < n && idx[j2] < idx[j]) ? 1 : 0;
+        sel[(size_t)t * top_k + rank] = idx[j];
+        wout[(size_t)t * top_k + rank] = f2h(w[j]);
+    }
+    for (int slot = n; slot < top_k; slot++) { sel[(size_t)t * top_k + slot] = -1; wout[(size_t)t * top_k + slot] = (half_t)0; }
 }
 
 } // namespace ifa
@@ -615,7 +638,7 @@ int ifa_moe_route_topk(const void *probs_f16, size_t tokens, int experts, int to
     IFA_REQUIRE(probs_f16 && sel_out_dev && weights_out_f16_dev, "ifa_moe_route_topk: null pointer");
     IFA_REQUIRE(experts >= 1 && experts <= 64 && top_k >= 1 && top_k <= 8, "ifa_moe_route_topk: experts %d / top_k %d out of range", experts, top_k);
     if (tokens == 0) return IFA_OK;
-    k_moe_route_rows<<<dim3(ifa_cdiv(tokens, 64)), dim3(64), 0, ifa_s(stream)>>>((const half_t *)probs_f16, (int)tokens, experts, top_k, norm_top_k_prob,
+    k_moe_route_rows<<<dim3(ifa_cdiv(tokens, 4)), dim3(256), 0, ifa_s(stream)>>>((const half_t *)probs_f16, (int)tokens, experts, top_k, norm_top_k_prob,
                                                                                   sel_out_dev, (half_t *)weights_out_f16_dev);
     IFA_LAUNCH_CHECK();
     return IFA_OK;

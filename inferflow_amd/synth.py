@@ -13,6 +13,7 @@ SHAPES = {
     "llama2_7b": dict(dim=4096, layers=32, heads=32, kv_heads=32, head_dim=128, ffn=11008, vocab=32000),
     # bin/llm_inference.tiny.ini shape (stories15M)
     "tiny15m": dict(dim=288, layers=6, heads=6, kv_heads=6, head_dim=48, ffn=768, vocab=32000),
+    "test_tiny": dict(dim=288, layers=2, heads=6, kv_heads=6, head_dim=48, ffn=768, vocab=1000),   # stories15M layers, small vocabulary
     # small GQA shapes for parity tests
     "test_gqa": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000),
     "test_mha": dict(dim=256, layers=3, heads=8, kv_heads=8, head_dim=32, ffn=640, vocab=777),

@@ -22,9 +22,24 @@ CASES = [
     ("test_gqa", dt.Q4_B64T1, dt.F16),
     ("test_mha", dt.Q5_B64T1, dt.Q8_B32T2),
     ("test_gqa", dt.Q6_B64T1, dt.F16),
+    # fp16-activation tensors in the same 5-launch step (k_dec_gemv_h): whole F16 models (bin/llm_inference.tiny.ini is one,
+    # 48-wide heads), the block formats outside the int8 path (gemv.h:632-1497), and layers the tensor_quant_threshold rule
+    # leaves partly F16 (network_builder.cc:1557-1562: here wk / wv stay F16 next to a quantised wq)
+    ("test_tiny", dt.F16, dt.F16),
+    ("tiny15m", dt.F16, dt.F16),
+    ("test_gqa", dt.F16, dt.Q8_B32T2),
+    ("test_gqa", dt.Q8_B32T1, dt.F16),
+    ("test_mha", dt.Q5_B32T1, dt.Q8_B32T2),
+    ("test_gqa", dt.Q4_B16, dt.F16),
+    ("test_gqa", dt.Q3_B32T1A, dt.F16),
+    ("test_mha", dt.Q2_B32T1B, dt.F16),
+    ("test_gqa", dt.Q4_B32T1A, dt.F16, 40000),
+    ("test_gqa", dt.Q3H_B64T1, dt.Q8_B32T2, 100000),
 ]
 CASE_IDS = ["gqa_q4_kvf16", "mha_q4_kvq8", "gqa_q4b_kvq8", "gqa_q3h_kvq8", "mha_q8_kvf16", "gqa_q4b64_kvf16",
-            "mha_q5_kvq8", "gqa_q6_kvf16"]
+            "mha_q5_kvq8", "gqa_q6_kvf16", "tiny_f16_hd48", "tiny15m_f16", "gqa_f16_kvq8", "gqa_q8t1", "mha_q5b32_kvq8",
+            "gqa_q4b16", "gqa_q3", "mha_q2", "gqa_q4_kv_f16_by_threshold", "gqa_q3h_only_ffn_quantised"]
+CASES = [c if len(c) == 4 else c + (0,) for c in CASES]
 
 
 def _logits_close(a, b):
@@ -33,10 +48,10 @@ def _logits_close(a, b):
     return cos, float(np.abs(a - b).max())
 
 
-@pytest.mark.parametrize("shape,wd,kvd", CASES, ids=CASE_IDS)
-def test_forward_and_fused_decode_match_oracle(shape, wd, kvd):
+@pytest.mark.parametrize("shape,wd,kvd,threshold", CASES, ids=CASE_IDS)
+def test_forward_and_fused_decode_match_oracle(shape, wd, kvd, threshold):
     max_ctx = 64
-    wk, host, s = synth.build(shape, wd, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
+    wk, host, s = synth.build(shape, wd, kvd, max_ctx=max_ctx, quant_threshold=threshold, std=0.06, keep_host=True)
     om = oracle_model_from_host(host, s, max_ctx, kvd)
     ok, why = wk.fused_supported()
     assert ok, why

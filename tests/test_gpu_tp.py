@@ -21,12 +21,12 @@ PROMPT = np.array([5, 17, 400, 33, 2, 77], np.int32)
 LOGIT_TOL = 0.03          # the engine tests' bound (tests/test_gpu_engine.py): cos >= 0.9995, |dlogit| <= 0.03 (logit std ~0.5)
 
 
-def _oracle_run(shape, n_decode=0, ctx=32, tp_merge=1):
+def _oracle_run(shape, n_decode=0, ctx=32, tp_merge=1, wd=dt.Q4_B32T1A):
     """The oracle on the SAME synthetic tensors (same seeds as the shards), fed token by token like the partition's decode
     path, with the BY_TENSOR merge of `tp_merge` ranks restated (wo / w2 products as per-rank partials rounded to F16 and
     summed in half in rank order, bias after the merge: orc_model_cfg.tp_merge); returns (logits after the last fed
     token, first greedy id, greedy ids of the n_decode steps, top-2 gaps of those steps)."""
-    wk, host, s = synth.build(shape, dt.Q4_B32T1A, dt.F16, max_ctx=ctx, quant_threshold=0, std=0.06, keep_host=True)
+    wk, host, s = synth.build(shape, wd, dt.F16, max_ctx=ctx, quant_threshold=0, std=0.06, keep_host=True)
     wk.close()
     extra = {k: s[k] for k in ("norm_kind", "act_kind", "is_glu", "share_input", "rope_order") if k in s}
     om = oracle_model_from_host(host, s, ctx, dt.F16, tp_merge=tp_merge, **extra)
@@ -66,13 +66,13 @@ def test_tp_world1_equals_fused_decode():
     assert ms > 0
 
 
-def _rank_main(rank, world, port, q, groups=1, n_decode=0, shape="test_gqa"):
+def _rank_main(rank, world, port, q, groups=1, n_decode=0, shape="test_gqa", wd=dt.Q4_B32T1A):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    r = tp.TPRunner(shape, dt.Q4_B32T1A, dt.F16, 32, world, rank, 0, std=0.06, groups=groups)
+    r = tp.TPRunner(shape, wd, dt.F16, 32, world, rank, 0, std=0.06, groups=groups)
     tok = None
     for i, t in enumerate(PROMPT):
         tok = r.step(int(t), i)
@@ -97,11 +97,11 @@ def _rank_main(rank, world, port, q, groups=1, n_decode=0, shape="test_gqa"):
         q.close(); q.join_thread()
 
 
-def _run_ranks(world, groups=1, n_decode=0, shape="test_gqa"):
+def _run_ranks(world, groups=1, n_decode=0, shape="test_gqa", wd=dt.Q4_B32T1A):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 400) + 7 * groups + world
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, groups, n_decode, shape)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, groups, n_decode, shape, wd)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -128,14 +128,20 @@ def test_by_layer_world2_matches_oracle_and_is_identical_to_one_device():
     _check_logits(lg_p, lg_o, "by-layer prompt logits")
 
 
-@pytest.mark.parametrize("world,groups,shape", [(2, 1, "test_gqa"), (4, 2, "test_gqa"), (2, 1, "test_moe"), (2, 1, "test_falcon"),
-                                               (2, 2, "test_falcon")],
-                         ids=["by_tensor_2", "hybrid_2x2", "moe_by_tensor_2", "falcon_by_tensor_2", "falcon_by_layer_2"])
-def test_partitions_match_oracle(world, groups, shape):
+Q4 = dt.Q4_B32T1A
+
+
+@pytest.mark.parametrize("world,groups,shape,wd", [(2, 1, "test_gqa", Q4), (4, 2, "test_gqa", Q4), (2, 1, "test_moe", Q4), (2, 1, "test_falcon", Q4),
+                                                  (2, 2, "test_falcon", Q4), (2, 1, "test_gqa", dt.F16), (4, 2, "test_gqa", dt.Q3_B32T1A),
+                                                  (2, 1, "test_falcon", dt.F16)],
+                         ids=["by_tensor_2", "hybrid_2x2", "moe_by_tensor_2", "falcon_by_tensor_2", "falcon_by_layer_2",
+                              "f16_by_tensor_2", "q3_hybrid_2x2", "falcon_f16_by_tensor_2"])
+def test_partitions_match_oracle(world, groups, shape, wd):
     """BY_TENSOR (2 ranks), HYBRID (2 layer groups x 2 ranks), MoE experts sliced like the dense FFN, and the Falcon-style
-    wiring (LayerNorm, GELU, shared MLP / attention input, 8 heads over 2 KV heads) under both partitions."""
-    lg_p, _, _, first = _run_ranks(world, groups=groups, shape=shape)
-    lg_o, first_o, _, _ = _oracle_run(shape, n_decode=0, tp_merge=world // groups)
+    wiring (LayerNorm, GELU, shared MLP / attention input, 8 heads over 2 KV heads) under both partitions; F16 and
+    fp16-activation block formats go through the same seams (k_dec_gemv_h)."""
+    lg_p, _, _, first = _run_ranks(world, groups=groups, shape=shape, wd=wd)
+    lg_o, first_o, _, _ = _oracle_run(shape, n_decode=0, tp_merge=world // groups, wd=wd)
     if shape == "test_moe":
         # the reference has no tensor-parallel MoE to restate (SURVEY 8e): each rank here accumulates its weighted expert
         # products before the merge, the oracle merges per expert -- one more half rounding apart; stated bound 0.05
