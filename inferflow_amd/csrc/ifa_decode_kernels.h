@@ -807,6 +807,7 @@ struct DecAttnParams {
     half_t *out;               // [heads*head_dim]
     int max_ctx;
     int8_t *xq;                // optional XqImage of `out` (Q8_B32T2, the quantiser the Wo GEMV would run in its prologue)
+    long long *trace;          // optional [heads][8] wall-clock stamps (100 MHz) for tuning
 };
 
 // Quantize(kqv_merged) (inference_worker.cc:1339-1346) done where the vector is produced: a head is HD/32 whole
@@ -850,8 +851,16 @@ __device__ __forceinline__ void rope_apply(half_t *row, int col, float c, float 
 //    order through LDS.
 //  * the new token's K/V never round-trip through HBM: they come from LDS and are
 //    written to the cache by the first head of each KV group.
+// pq / pkc / pvc / pheads / pkvh repeat the new token's q|k|v vector (ONE buffer: q, then k at + heads*HD, then v at
+// + (heads + kv_heads)*HD), the layer's K / V cache and the head counts as leading scalar arguments: a by-value struct is
+// fetched with scalar loads (cold after every kernel boundary), these 8 dwords are preloaded into SGPRs at wave launch, so
+// the q / k / v values and the first 256 K / V rows are requested with the kernel's first instructions.  The caches hold
+// at least DEC_ATTN_MIN_ROWS rows (the engine pads the allocation), so that first chunk needs no clamp.
+constexpr int DEC_ATTN_MIN_ROWS = 256;
+
 template <int HD, bool Q8>
-__global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
+__global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_t *pkc, const uint8_t *pvc, int pheads, int pkvh,
+                                                  const DecAttnParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(HD % 8 == 0 && HD <= 128 && (!Q8 || HD % 32 == 0), "head size: multiples of 8 up to 128 (Q8 rows: whole 32-blocks)");
@@ -864,21 +873,16 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     float *opart = red + 16;                                       // [NSPLIT][HD]
     half_t *S = reinterpret_cast<half_t *>(opart + NSPLIT * HD);   // [n_ctx]
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int group = P.heads / P.kv_heads;
+    const int group = pheads / pkvh;
     const int kvh = h / group;
     const bool writer = (h % group) == 0;
-    const int kv_dim = P.kv_heads * HD;
+    const int kv_dim = pkvh * HD;
     const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
     const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
 
-    // ---- issue the first chunk of K (key = tid) and V loads before anything else.  Keys past the context
-    // re-read row `pos` (one row for all of them: no extra traffic, never used) instead of being masked off:
-    // loads under an exec mask make every later wait a vmcnt(0)
-    // (the position comes from device memory: nothing below waits for it before the first K / V requests are out --
-    // rows past the context are clamped against the cache's last row instead, any row of the cache is valid memory)
-    const int pos = P.state[1];
-    const int n_ctx = pos + 1;
-    const int last_row = P.max_ctx - 1;
+    // ---- issue the new token's values, then the first chunk of K (key = tid) and V loads before anything else.  Keys
+    // past the context are loaded too (never used) instead of being masked off: loads under an exec mask make every later
+    // wait a vmcnt(0), and the position comes from device memory -- nothing here waits for it, or for the argument block
     // Q8 rows: a head's slice is (HD/32)*34 bytes, 8-byte aligned for HD=128, 4-byte for HD=64, 2-byte for HD=32
     constexpr int KBYTES = (HD / 32) * 34;
     constexpr int KALIGN = HD == 128 ? 8 : (HD == 64 ? 4 : 2);
@@ -886,7 +890,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     uint32_t kq32[(Q8 && KALIGN >= 4) ? KBYTES / 4 : 1];
     uint16_t kq16[(Q8 && KALIGN < 4) ? KBYTES / 2 : 1];
     auto load_k = [&](int j) {
-        const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
+        const uint8_t *rowp = pkc + (size_t)j * row_bytes + head_off;
         if constexpr (Q8) {
             if constexpr (KALIGN == 8) {
 #pragma unroll
@@ -914,13 +918,11 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
         if constexpr (KALIGN >= 4) return (kq32[B >> 2] >> (8 * (B & 3))) & 0xFFu;
         else return (kq16[B >> 1] >> (8 * (B & 1))) & 0xFFu;
     };
-    load_k(min(tid, last_row));
-    // this step's (cos, sin) pair of the thread that will rotate: requested now, used after the staging barrier
-    float rope_cs = 1.0f, rope_sn = 0.0f;
-    if (P.rope_order != 0) {
-        const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
-        rope_cs = P.rope_tab[2 * c]; rope_sn = P.rope_tab[2 * c + 1];
-    }
+    // the new token's q / k / v values and this step's (cos, sin) pair FIRST: loads return in issue order, and behind the
+    // 128 KB of K / V rows below these few bytes arrived 1.5 us later than they had to (phase stamps)
+    const int dq = min(tid, HD - 1);
+    const half_t q_in = pq[(size_t)h * HD + dq], k_in = pq[(size_t)(pheads + kvh) * HD + dq], v_in = pq[(size_t)(pheads + pkvh + kvh) * HD + dq];
+    load_k(tid);                       // (tid < DEC_ATTN_MIN_ROWS <= rows of the cache)
     const int dg = tid % DG, sp = tid / DG;
     const bool vact = (256 % DG == 0) || sp < NSPLIT;   // this thread takes part in P.V
     constexpr int VPRE = 256 / NSPLIT;                  // prefetched V keys per thread: j = sp + NSPLIT*i (256 keys)
@@ -929,24 +931,32 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     const size_t vq_off = head_off + (size_t)(dg / 4) * 34;
 #pragma unroll
     for (int i = 0; i < VPRE; i++) {
-        const int j = min(sp + NSPLIT * i, last_row);
+        const int j = min(sp + NSPLIT * i, DEC_ATTN_MIN_ROWS - 1);
         if constexpr (!Q8) {
-            vreg[i] = reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg];
+            vreg[i] = reinterpret_cast<const u32x4 *>(pvc + (size_t)j * row_bytes + head_off)[dg];
         } else {
-            const uint16_t *blk = reinterpret_cast<const uint16_t *>(P.vcache + (size_t)j * row_bytes + vq_off);
+            const uint16_t *blk = reinterpret_cast<const uint16_t *>(pvc + (size_t)j * row_bytes + vq_off);
             vq[i][0] = blk[0];
 #pragma unroll
             for (int e = 0; e < 4; e++) vq[i][1 + e] = blk[1 + (dg % 4) * 4 + e];
         }
     }
 
-    // ---- stage q, k_new, v_new; RoPE on q and k (TensorOpr::PositionEmbedding, F16 in/out)
-    for (int d = tid; d < HD; d += 256) {
-        qs[d] = P.q[(size_t)h * HD + d];
-        kn[d] = P.k_new[(size_t)kvh * HD + d];
-        vn[d] = P.v_new[(size_t)kvh * HD + d];
+    // ---- everything below may wait for the argument block: the position, this step's (cos, sin) pair of the thread that
+    // will rotate (requested now, used after the staging barrier)
+    const bool tr = P.trace != nullptr && tid == 0;
+    if (tr) P.trace[h * 8 + 0] = wall_clock64();
+    const int pos = P.state[1];
+    const int n_ctx = pos + 1;
+    float rope_cs = 1.0f, rope_sn = 0.0f;
+    if (P.rope_order != 0) {
+        const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
+        rope_cs = P.rope_tab[2 * c]; rope_sn = P.rope_tab[2 * c + 1];
     }
+    // ---- stage q, k_new, v_new; RoPE on q and k (TensorOpr::PositionEmbedding, F16 in/out)
+    if (tid < HD) { qs[tid] = q_in; kn[tid] = k_in; vn[tid] = v_in; }
     __syncthreads();
+    if (tr) P.trace[h * 8 + 1] = wall_clock64();
     if (P.rope_order != 0) {
         if (tid < HD) {     // threads [0,HD/2) rotate q pairs, [HD/2,HD) rotate k pairs
             const int c = tid < HD / 2 ? tid : tid - HD / 2;
@@ -987,16 +997,27 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     }
 
     // ---- scores: one key per lane, fp32 fma in d order (Gemm_Alg2_Kernel order, products exact)
+    if (tr) P.trace[h * 8 + 2] = wall_clock64();
     const float alpha = 1.0f / sqrtf((float)HD) / P.kq_scale;
     const float mk = P.alibi ? alibi_slope(h + P.alibi_base, P.alibi_total) : 0.0f;
     float lmax = -INFINITY;
     for (int j = tid; j < n_ctx; j += 256) {
         float c = 0.0f;
-        if (j == pos) {
+        if (Q8 && j == pos) {
 #pragma unroll 8
             for (int d = 0; d < HD; d++) c = __builtin_fmaf(h2f(qs[d]), h2f(kn[d]), c);
         } else {
-            if (j >= 256) load_k(j);      // later chunks: load now (first chunk was prefetched)
+            if constexpr (!Q8) {
+                // the new token's key comes from LDS into the same registers (wide reads) and takes the common path: a
+                // scalar loop over LDS here kept the whole workgroup waiting at the next barrier for ~0.7 us
+                if (j == pos) {
+#pragma unroll
+                    for (int i = 0; i < HD / 8; i++) {
+                        const u32x4 t = reinterpret_cast<const u32x4 *>(kn)[i];
+                        kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
+                    }
+                } else if (j >= 256) load_k(j);      // later chunks: load now (first chunk was prefetched)
+            } else if (j >= 256) load_k(j);
             if constexpr (Q8) {
 #pragma unroll
                 for (int b = 0; b < HD / 32; b++) {
@@ -1022,9 +1043,11 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
         S[j] = s;
         lmax = fmaxf(lmax, P.kq_scale * h2f(s));
     }
+    if (tr) P.trace[h * 8 + 3] = wall_clock64();
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
+    if (tr) P.trace[h * 8 + 4] = wall_clock64();
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float lsum = 0.0f;
     for (int j = tid; j < n_ctx; j += 256) {
@@ -1038,6 +1061,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
     const float inv = 1.0f / (((red[4] + red[5]) + red[6]) + red[7]);
     for (int j = tid; j < n_ctx; j += 256) S[j] = f2h(h2f(S[j]) * inv);
     __syncthreads();
+    if (tr) P.trace[h * 8 + 5] = wall_clock64();
 
     // ---- O = P.V : thread (sp, dg) accumulates keys j = sp + NSPLIT*i for its 8 dims
     float o[8];
@@ -1087,6 +1111,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
 #pragma unroll
         for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
     }
+    if (tr) P.trace[h * 8 + 6] = wall_clock64();
     __syncthreads();
     if (tid < HD) {
         float acc = opart[tid];
@@ -1095,6 +1120,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const DecAttnParams P)
         P.out[(size_t)h * HD + tid] = yh;
         if constexpr (HD % 32 == 0) { if (P.xq) dec_attn_emit_q8<HD>(P.xq, P.heads * HD, h, tid, yh); }
     }
+    if (tr) P.trace[h * 8 + 7] = wall_clock64();
 }
 
 // ------------------------------------------------------------ long contexts: keys split over workgroups

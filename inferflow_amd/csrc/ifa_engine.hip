@@ -57,6 +57,7 @@ struct ifa_model {
     bool finalized = false;
     // scratch
     half_t *x = nullptr, *x2 = nullptr, *xn = nullptr, *hn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
+    half_t *dqkv = nullptr;     // the decode step's q | k | v vector as ONE buffer (k_dec_attn addresses k and v from q's pointer)
     half_t *att = nullptr, *a = nullptr, *f = nullptr, *t1 = nullptr, *t2 = nullptr, *logits = nullptr;
     uint8_t *xq = nullptr;
     int8_t *attq = nullptr;        // XqImage of the attention output (Q8_B32T2), written by the fused attention kernels for the Wo GEMV
@@ -274,7 +275,8 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
         P.x = m->xn; P.norm_w = nullptr; P.norm_b = nullptr; P.xn_out = nullptr;
     }
     const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
-    half_t *outs[3] = {m->q, m->k, m->v};
+    const size_t QDd = (size_t)c.heads * c.head_dim, KVDd = (size_t)c.kv_heads * c.head_dim;
+    half_t *outs[3] = {m->dqkv, m->dqkv + QDd, m->dqkv + QDd + KVDd};
     for (int i = 0; i < 3; i++) {
         P.W0[i] = wbytes(L.t[ids[i]]); P.b0[i] = (const half_t *)L.t[bids[i]].data;
         P.y[i] = outs[i]; P.rows[i] = (int)L.t[ids[i]].rows;
@@ -310,12 +312,12 @@ static int launch_attn(ifa_model *m, int l)
     Layer &L = m->layers[(size_t)l];
     const int rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f);
     DecAttnParams A; memset(&A, 0, sizeof(A));
-    A.q = m->q; A.k_new = m->k; A.v_new = m->v; A.kcache = (uint8_t *)L.kcache; A.vcache = (uint8_t *)L.vcache;
+    A.q = m->dqkv; A.k_new = m->dqkv + (size_t)c.heads * c.head_dim; A.v_new = A.k_new + (size_t)c.kv_heads * c.head_dim; A.kcache = (uint8_t *)L.kcache; A.vcache = (uint8_t *)L.vcache;
     A.state = m->state; A.rope_tab = m->rope_tab; A.heads = c.heads; A.kv_heads = c.kv_heads;
     A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale;
     A.rope_order = c.rope_order; A.rope_cols = rope_dims;
     A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
-    A.out = m->att; A.max_ctx = c.max_ctx; A.xq = (c.head_dim % 32 == 0) ? m->attq : nullptr;
+    A.out = m->att; A.max_ctx = c.max_ctx; A.xq = (c.head_dim % 32 == 0) ? m->attq : nullptr; A.trace = g_trace_ptr;
     // the one-workgroup kernel keeps a head's score row [max_ctx] in LDS: past the device limit (160 KiB: ~75K tokens of
     // context at head_dim 128) the keys-split-over-workgroups kernels run from position 0 on (scores in global memory)
     const bool lds_split = dec_attn_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT;
@@ -351,12 +353,12 @@ static int launch_attn(ifa_model *m, int l)
     // (attention_lds_ok() routed contexts whose score row does not fit the 160 KiB LDS to the split kernels above)
 #define IFA_ATTN(HDV) \
     case HDV: if (A.kv_q8) { if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
-                             k_dec_attn<HDV, true><<<grid, block, asmem, m->stream>>>(A); } \
+                             k_dec_attn<HDV, true><<<grid, block, asmem, m->stream>>>(A.q, A.kcache, A.vcache, A.heads, A.kv_heads, A); } \
               else { if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
-                     k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A); } break;
+                     k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A.q, A.kcache, A.vcache, A.heads, A.kv_heads, A); } break;
 #define IFA_ATTN_F(HDV) \
     case HDV: if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
-              k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A); break;
+              k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A.q, A.kcache, A.vcache, A.heads, A.kv_heads, A); break;
     switch (c.head_dim) {
         IFA_ATTN(32) IFA_ATTN(64) IFA_ATTN(96) IFA_ATTN(128) IFA_ATTN_F(48) IFA_ATTN_F(80)
     default: return ifa_fail(IFA_ERR_ARG, "fused attention: head_dim %d", c.head_dim);
@@ -622,6 +624,7 @@ static int ensure_scratch(ifa_model *m, int T)
         || (rc = re(m->a, T * D)) || (rc = re(m->f, T * D)) || (rc = re(m->t1, T * F)) || (rc = re(m->t2, T * F))
         || (rc = re(m->logits, (size_t)T * c.vocab)))
         return rc;
+    if (!m->dqkv) IFA_HIP_CHECK(hipMalloc((void **)&m->dqkv, (QD + 2 * KVD) * sizeof(half_t)));
     if (c.experts > 0) {
         const size_t cap = (size_t)T * (size_t)std::max(1, c.moe_top_k);
         if ((rc = re(m->moe_gate, (size_t)T * c.experts)) || (rc = re(m->moe_out, (size_t)T * D)) || (rc = re(m->moe_in, (size_t)T * D))
@@ -1372,7 +1375,7 @@ int ifa_model_destroy(ifa_model *m)
     if (m->attn_ws.lmax) (void)hipFree(m->attn_ws.lmax);
     if (m->attn_ws.opart) (void)hipFree(m->attn_ws.opart);
     for (Tensor &t : m->g) free_tensor(t);
-    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits,
+    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->dqkv, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits,
                        &m->moe_gate, &m->moe_out, &m->moe_in, &m->moe_wdev};
     for (half_t **b : bufs) if (*b) (void)hipFree(*b);
     if (m->moe_idx) (void)hipFree(m->moe_idx);
@@ -1493,10 +1496,12 @@ int ifa_model_finalize(ifa_model *m)
     m->kv_row_bytes = ifa_row_bytes(c.kv_dtype, KVD);
     for (Layer &L : m->layers) {
         if (!L.kcache) {   // KVCache::Init (kv_cache.cc:278-319): (kv_dim, max_ctx) per layer
-            IFA_HIP_CHECK(hipMalloc(&L.kcache, m->kv_row_bytes * (size_t)c.max_ctx));
-            IFA_HIP_CHECK(hipMalloc(&L.vcache, m->kv_row_bytes * (size_t)c.max_ctx));
-            IFA_HIP_CHECK(hipMemsetAsync(L.kcache, 0, m->kv_row_bytes * (size_t)c.max_ctx, m->stream));
-            IFA_HIP_CHECK(hipMemsetAsync(L.vcache, 0, m->kv_row_bytes * (size_t)c.max_ctx, m->stream));
+            // (at least DEC_ATTN_MIN_ROWS rows are allocated: the fused attention kernel requests its first 256 rows unclamped)
+            const size_t kv_alloc = m->kv_row_bytes * (size_t)std::max(c.max_ctx, DEC_ATTN_MIN_ROWS);
+            IFA_HIP_CHECK(hipMalloc(&L.kcache, kv_alloc));
+            IFA_HIP_CHECK(hipMalloc(&L.vcache, kv_alloc));
+            IFA_HIP_CHECK(hipMemsetAsync(L.kcache, 0, kv_alloc, m->stream));
+            IFA_HIP_CHECK(hipMemsetAsync(L.vcache, 0, kv_alloc, m->stream));
         }
         if (c.experts > 0 && (int)L.experts.size() == c.experts * 3) {      // pointer table for the fused MoE kernels
             std::vector<void *> tab((size_t)c.experts * 4, nullptr);
@@ -1550,7 +1555,7 @@ int ifa_model_kv_slots(ifa_model *m, int n_slots)
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     if (m->slots.empty()) m->slots.resize(1);        // slot 0 = the cache finalize() made (active, nothing parked)
     IFA_REQUIRE((int)m->slots.size() <= n_slots, "ifa_model_kv_slots: cannot shrink below %zu slots", m->slots.size());
-    const size_t bytes = m->kv_row_bytes * (size_t)m->cfg.max_ctx;
+    const size_t bytes = m->kv_row_bytes * (size_t)std::max(m->cfg.max_ctx, DEC_ATTN_MIN_ROWS);
     while ((int)m->slots.size() < n_slots) {
         ifa_model::KvSlot sl;
         for (size_t l = 0; l < m->layers.size(); l++) {

@@ -21,3 +21,11 @@ for mode, stride in [(0, 0)]:
         med = [float(np.nanmedian(rel[:, i])) if not np.all(np.isnan(rel[:, i])) else -1 for i in range(8)]
         print("mode", mode, "stride", stride, nm, "event_us %.1f" % us, "kernel_span %.2f" % float(np.nanmax(rel[:, 7])),
               "med:", " ".join("%s=%.1f" % (labels[i][:8], med[i]) for i in (1, 4, 5, 6, 2, 3, 7)), flush=True)
+
+    # attention (one workgroup per head): stamps of thread 0
+    alab = ["start", "qkv_staged", "rope_kv", "scores", "max", "probs", "pv", "end"]
+    us = wk.time_kernel(1, 37)
+    tr = wk.read_buffer("trace").view(np.int64).reshape(2048, 8)[:s["heads"]]
+    rel = (tr - tr[:, :1]) * 0.01
+    print("attn event_us %.1f" % us, "med:", " ".join("%s=%.2f" % (alab[i], float(np.median(rel[:, i]))) for i in range(1, 8)),
+          "skew of starts %.2f" % ((tr[:, 0].max() - tr[:, 0].min()) * 0.01), flush=True)
