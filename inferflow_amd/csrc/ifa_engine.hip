@@ -541,6 +541,9 @@ namespace ifa {     // ifa_moe.hip / ifa_gemm.hip / ifa_gemv.hip
 int moe_build_lists(const int *sel, const void *wsel, int T, int top_k, int E, int tile_rows, int small_max, int *idx, void *wdev, int *epos,
                     MoeTile *tiles, MoeSingle *singles, MoeTile *smalls, int *counts, hipStream_t s);
 int gemm_rows_q4_grouped_cap(size_t cols);
+bool gemm_rows_use_mfma();
+bool gemm_rows_mfma_ok(size_t rows, size_t cols, size_t tokens);
+int gemm_rows_mfma_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, int max_rows, hipStream_t s);
 int gemm_rows_q4_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, hipStream_t s);
 int moe_gather(const void *src, const int *idx, const int *counts, int max_entries, int dim, void *dst, hipStream_t s);
 int moe_combine(const void *y, const int *epos, const void *wsel, int T, int top_k, int dim, void *out, hipStream_t s);
@@ -686,7 +689,7 @@ static int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const T
         return ifa_gemv(W.dtype, W.data, N, K, Q8_B32T2, m->xq, b, C, s);
     }
     // a handful of rows (dynamic batching, very short prompts): weight-streaming kernel on the tiled layout
-    if (T >= 2 && T <= 8 && is_q4(W.dtype) && W.tiled && m->opt_gemm_rows) {
+    if (T >= 2 && T <= 16 && is_q4(W.dtype) && W.tiled && m->opt_gemm_rows) {
         int rc = ifa_gemm_rows_q4(W.tiled, N, K, A, (size_t)T, b, C, s);
         if (rc != IFA_ERR_STATE) return rc;
     }
@@ -937,9 +940,13 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     // a handful of rows per expert (dynamic batching): experts with 2..small_max rows stream their tiled Q4 weights once
     // (ifa_gemm_rows.hip) instead of filling a 64-row MFMA tile with mostly padding
     const int wdt = L.experts[0].dtype;
+    const bool rows_mfma = gemm_rows_use_mfma() && gemm_rows_mfma_ok(F, D, 2) && gemm_rows_mfma_ok(D, F, 2);     // matrix-core variant: up to 16 rows
     const bool rows_kernel = is_q4(wdt) && m->opt_gemm_rows && L.moe_table && cap <= 8 * E
-        && gemm_rows_q4_grouped_cap(D) > 0 && gemm_rows_q4_grouped_cap(F) > 0;
+        && (rows_mfma || (gemm_rows_q4_grouped_cap(D) > 0 && gemm_rows_q4_grouped_cap(F) > 0));
     const int small_max = rows_kernel ? 8 : 0;
+    auto rows_grouped = [&](const MoeSmallGroup &q, size_t rows, size_t cols, const void *X, void *Y, int ng) {
+        return rows_mfma ? gemm_rows_mfma_grouped(q, rows, cols, X, Y, ng, small_max, m->stream) : gemm_rows_q4_grouped(q, rows, cols, X, Y, ng, m->stream);
+    };
     if ((rc = moe_build_lists(m->moe_sel, m->moe_selw, T, K, E, tile_rows, small_max, m->moe_idx, m->moe_wdev, m->moe_epos, (MoeTile *)m->moe_tiles,
                               (MoeSingle *)m->moe_singles, (MoeTile *)m->moe_smalls, m->moe_counts, m->stream))) return rc;
     MoeSmallGroup sg;
@@ -955,18 +962,18 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     g.which = 0;
     if ((rc = gemm_q_grouped(wdt, g, F, D, m->moe_gin, m->moe_g1, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, F, D, m->moe_xq_in, m->moe_g1, max_singles, m->stream))) return rc;
-    if (max_smalls && (rc = gemm_rows_q4_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls, m->stream))) return rc;
+    if (max_smalls && (rc = rows_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls))) return rc;
     g.which = 2; sg.which_tiled = 1;
     if ((rc = gemm_q_grouped(wdt, g, F, D, m->moe_gin, m->moe_g3, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, F, D, m->moe_xq_in, m->moe_g3, max_singles, m->stream))) return rc;
-    if (max_smalls && (rc = gemm_rows_q4_grouped(sg, F, D, m->moe_gin, m->moe_g3, max_smalls, m->stream))) return rc;
+    if (max_smalls && (rc = rows_grouped(sg, F, D, m->moe_gin, m->moe_g3, max_smalls))) return rc;
     if ((rc = ifa_activation_mul(c.act_kind, m->moe_g1, m->moe_g3, (size_t)cap * F, m->moe_g1, s))) return rc;
     if ((rc = ifa_quantize_act_q8(m->moe_g1, (size_t)cap, F, m->moe_xq_mid, s))) return rc;
     g.which = 1;
     if ((rc = gemm_q_grouped(wdt, g, D, F, m->moe_g1, m->moe_gout, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, D, F, m->moe_xq_mid, m->moe_gout, max_singles, m->stream))) return rc;
     sg.which_tiled = 2;
-    if (max_smalls && (rc = gemm_rows_q4_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls, m->stream))) return rc;
+    if (max_smalls && (rc = rows_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls))) return rc;
     return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, m->f, m->stream);
 }
 

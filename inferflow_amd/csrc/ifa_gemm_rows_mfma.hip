@@ -1,0 +1,325 @@
+// ifa_gemm_rows_mfma.hip -- Y[T][N] = X[T][K] . W[N][K]^T for 2 <= T <= 16 rows (dynamic batching of decode steps, very
+// short prompts, MoE experts with a handful of rows) on v_mfma_f32_16x16x32_f16, streaming the tiled Q4_B32T1 weights
+// ONCE at the decode GEMV's rate.
+//
+// Same contract as ifa_gemm / ifa_gemm_rows_q4 (the reference's T > 1 branch: weights dequantised to half, half
+// activations, fp32 accumulation, one F16 rounding, bias as a half add: MatrixMultiplication,
+// src/transformer/inference_worker.cc:2374-2415).  The fdot2 kernel of ifa_gemm_rows.hip spends T/2 + 3 VALU operations
+// per weight and is VALU-bound at ~1.7-2 TB/s; here a weight costs its dequantisation only (the products run on the
+// matrix cores), and a 16 x 16 tile wastes little of them at 2..16 rows.
+//
+// Work decomposition (one workgroup of 8 waves per CU):
+//   * tile = 16 consecutive weight rows; the K range of a tile is SPLIT over the 8 waves -- wave w takes "supersteps"
+//     (128 columns = 4 blocks = one 64-byte line of codes per row) w, w + 8, ... -- so every wave of the chip has requests
+//     in flight from the first instruction (a 4096-row matrix is only 256 tiles); partial 16 x 16 tiles are summed
+//     through LDS in wave order (deterministic);
+//   * a wave's share of a tile and chunk is 16 rows x 16 blocks (512 columns).  It is REQUESTED coalesced -- 256 contiguous
+//     code bytes per row, four rows per request (+ one request for the 16 x 16 (base, scale) words) -- because 16-row x
+//     64-byte requests (each lane its own MFMA operand) ran at 2.4 TB/s against 3.5 TB/s for contiguous ones; the wave then
+//     turns the 5 KB through its own LDS patch (no barrier: one wave) into the MFMA layout: lane (r = lane % 16,
+//     g = lane / 16) reads block 4s + g of row r.  The block's four 8-element quarters feed FOUR MFMAs as k-group g:
+//     MFMA q of a superstep multiplies the columns {32 (4s + g) + 8 q .. + 8 : g = 0..3} -- the B fragments are read from
+//     LDS with the same permutation, so the sum over k is the plain dot product in another (fixed) order;
+//   * the activation rows sit in LDS as F16, 4096 columns at a time (row stride + 16 B: conflict-free 16-byte reads);
+//     longer rows (w2) are walked in chunks with the accumulators kept in registers.
+#include <algorithm>
+#include "ifa_host.h"
+#include "ifa_decode_kernels.h"
+#include "ifa_moe.h"
+
+namespace ifa {
+
+typedef _Float16 h8m __attribute__((ext_vector_type(8)));
+typedef float f4m __attribute__((ext_vector_type(4)));
+typedef float f2m __attribute__((ext_vector_type(2)));
+typedef _Float16 h2m __attribute__((ext_vector_type(2)));
+
+constexpr int GM_THREADS = 512, GM_WAVES = 8;
+constexpr int GM_CHUNK_SUP = 32;                         // supersteps per LDS chunk (4096 columns): 4 per wave
+constexpr int GM_CHUNK_COLS = GM_CHUNK_SUP * 128;
+constexpr int GM_ROW_STRIDE = GM_CHUNK_COLS * 2 + 16;    // bytes per activation row in LDS
+
+struct GmGrp { u32x4 c[4]; u32x4 sb; };
+constexpr int GM_PATCH_BYTES = 16 * 272 + 16 * 80;        // per-wave transposition patch (codes + (base, scale) words)
+#define GM_XIMG_BYTES(TXV) ((size_t)(TXV) * GM_ROW_STRIDE)
+
+// MAXT: tiles per workgroup (tile = blockIdx.x + i * gridDim.x); TX: activation rows staged per thread (>= T, power of two)
+// Every global load below is UNCONDITIONAL (clamped or redirected addresses): loads inside branches make the compiler's
+// vmcnt bookkeeping conservative -- every wait became vmcnt(0), i.e. for all three groups in flight (ISA of the first version).
+template <int MAXT, int TX>
+__device__ __forceinline__ void gemm_rows_mfma_body(const uint8_t *__restrict__ Wt, int rows, int nblk, const half_t *__restrict__ X, int T,
+                                                    const half_t *__restrict__ bias, half_t *__restrict__ Y, char *smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int K = nblk * 32;
+    const int nsup = nblk >> 2;                                   // nblk % 4 == 0 (checked by the launcher)
+    const int nchunk = (nsup + GM_CHUNK_SUP - 1) / GM_CHUNK_SUP;
+    const int ntiles = (rows + 15) >> 4;
+    const size_t row_bytes = tiled_row_bytes(Q4_B32T1A, (size_t)nblk);
+    const int trow = min(r, T - 1);                               // B operand: token of this lane (columns past T: duplicates, never stored)
+
+    // a group = this wave's 16 rows x 16 blocks of (tile, chunk): blocks blk0 .. blk0 + 15, blk0 = 128 chunk + 16 wave
+    // valid == false (past the last group): all lanes re-read the first bytes of the matrix -- one cache line, no branch
+    auto fetch = [&](GmGrp &q, int it, int chunk, bool valid) {
+        const int tile = min((int)blockIdx.x + it * (int)gridDim.x, ntiles - 1);
+        const int blk0 = chunk * (GM_CHUNK_SUP * 4) + wave * 16;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {          // codes: lane l -> row 4i + l / 16, block l % 16 (256 contiguous bytes per row)
+            const int row = valid ? min(tile * 16 + 4 * i + (lane >> 4), rows - 1) : 0;
+            const int blk = valid ? min(blk0 + (lane & 15), nblk - 1) : 0;
+            q.c[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)blk * 16));
+        }
+        {                                       // (base, scale): lane l -> row l / 4, blocks 4 (l % 4) .. + 3 (64 contiguous bytes per row)
+            const int row = valid ? min(tile * 16 + (lane >> 2), rows - 1) : 0;
+            const int blk = valid ? min(blk0 + 4 * (lane & 3), nblk - 4) : 0;
+            q.sb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)nblk * 16 + (size_t)blk * 4));
+        }
+    };
+    char *patch = smem + GM_XIMG_BYTES(TX) + (size_t)wave * GM_PATCH_BYTES;        // this wave's transposition patch
+    auto compute = [&](const GmGrp &q, int chunk, f4m &acc) {
+        // ---- through the patch: rows of 16 code blocks at a 272-byte stride, rows of 16 (base, scale) words at 80 bytes
+        // (both strides make the 16-row reads below conflict-free)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            *reinterpret_cast<u32x4 *>(patch + (size_t)(4 * i + (lane >> 4)) * 272 + (size_t)(lane & 15) * 16) = q.c[i];
+        *reinterpret_cast<u32x4 *>(patch + 16 * 272 + (size_t)(lane >> 2) * 80 + (size_t)(lane & 3) * 16) = q.sb;
+        const int blk0 = chunk * (GM_CHUNK_SUP * 4) + wave * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (blk0 + 4 * j >= nblk) continue;                    // wave-uniform: past the row end (nblk % 4 == 0)
+            const u32x4 cw4 = *reinterpret_cast<const u32x4 *>(patch + (size_t)r * 272 + (size_t)(4 * j + g) * 16);
+            const uint32_t sbw = *reinterpret_cast<const uint32_t *>(patch + 16 * 272 + (size_t)r * 80 + (size_t)(4 * j + g) * 4);
+            const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale = hbits2f((uint16_t)(sbw >> 16));
+            const char *xrow = smem + (size_t)trow * GM_ROW_STRIDE + (size_t)((wave * 16 + 4 * j + g) * 32) * 2;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                const uint32_t cw = cw4[s4];
+                // byte b of the word: low nibble = element 8 s4 + 2b, high nibble = the next one (ifa_gemm_rows.hip)
+                const uint32_t lo = cw & 0x0F0F0F0Fu, hi = (cw >> 4) & 0x0F0F0F0Fu;
+                // two weights per v_pk_fma_f32 + v_cvt_pk_f16_f32 (round to nearest even): the reference's dequantised halves
+                const f2m s2 = {scale, scale}, b2 = {base, base};
+                const f2m q0 = {ubyte_f32<0>(lo), ubyte_f32<0>(hi)}, q1 = {ubyte_f32<1>(lo), ubyte_f32<1>(hi)};
+                const f2m q2 = {ubyte_f32<2>(lo), ubyte_f32<2>(hi)}, q3 = {ubyte_f32<3>(lo), ubyte_f32<3>(hi)};
+                const h2m w0 = __builtin_convertvector(__builtin_elementwise_fma(q0, s2, b2), h2m);
+                const h2m w1 = __builtin_convertvector(__builtin_elementwise_fma(q1, s2, b2), h2m);
+                const h2m w2 = __builtin_convertvector(__builtin_elementwise_fma(q2, s2, b2), h2m);
+                const h2m w3 = __builtin_convertvector(__builtin_elementwise_fma(q3, s2, b2), h2m);
+                const h8m a = {w0[0], w0[1], w1[0], w1[1], w2[0], w2[1], w3[0], w3[1]};
+                const h8m b = *reinterpret_cast<const h8m *>(xrow + s4 * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+            }
+        }
+    };
+
+    f4m acc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) acc[i] = f4m{0.0f, 0.0f, 0.0f, 0.0f};
+    // three groups of requests in flight per wave (a group = 4 supersteps = 5 KB per wave): one group ahead left every wave
+    // waiting ~half of the time for HBM
+    GmGrp cur, n1, n2;
+    const int nq = nchunk * MAXT;                                  // (chunk, tile) pairs in execution order: chunk outer
+    auto fetch_q = [&](GmGrp &q, int qi) { const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, ch, qi < nq); };
+    // The CU's memory pipeline is FIFO across waves (ifa_decode_kernels.h): the activation rows of the first chunk are
+    // requested by all threads, and a barrier passed, BEFORE any weight request -- else they arrive behind the weights.
+    // A full chunk is 512 16-byte pieces per row: piece tid of row k is thread tid's k-th request.
+    u32x4 xv[TX];
+    auto x_request = [&](int chunk) {
+        const int c0 = chunk * GM_CHUNK_COLS;
+        const int per_row = min(GM_CHUNK_COLS, K - c0) >> 3;
+#pragma unroll
+        for (int k = 0; k < TX; k++)       // rows past T and pieces past the row end: clamped (duplicates), never stored
+            xv[k] = *reinterpret_cast<const u32x4 *>(X + (size_t)min(k, T - 1) * K + c0 + (size_t)min(tid, per_row - 1) * 8);
+    };
+    auto x_store = [&](int chunk) {
+        const int per_row = min(GM_CHUNK_COLS, K - chunk * GM_CHUNK_COLS) >> 3;
+#pragma unroll
+        for (int k = 0; k < TX; k++)
+            if (k < T && tid < per_row) *reinterpret_cast<u32x4 *>(smem + (size_t)k * GM_ROW_STRIDE + (size_t)tid * 16) = xv[k];
+    };
+    x_request(0);
+    __syncthreads();
+    fetch_q(cur, 0);
+    fetch_q(n1, 1);
+    fetch_q(n2, 2);
+    for (int chunk = 0; chunk < nchunk; chunk++) {
+        if (chunk > 0) {
+            __syncthreads();                                       // the previous chunk's fragments have been read
+            x_request(chunk);
+        }
+        x_store(chunk);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MAXT; it++) {
+            const int qi = chunk * MAXT + it;
+            compute(cur, chunk, acc[it]);
+            cur = n1; n1 = n2;
+            fetch_q(n2, qi + 3);
+        }
+    }
+    // ---- sum the 8 waves' partial tiles in wave order, then bias and store: thread e of the first 256 owns element
+    // (m = (l >> 4) * 4 + i, n = l & 15) of every tile, l = e >> 2, i = e & 3 (the MFMA's C layout)
+    __syncthreads();                                               // the activation image is free: partials take its place
+    float *part = reinterpret_cast<float *>(smem);                 // [MAXT][8 waves][256]
+#pragma unroll
+    for (int it = 0; it < MAXT; it++)
+        *reinterpret_cast<f4m *>(part + ((size_t)(it * GM_WAVES + wave) * 64 + lane) * 4) = acc[it];
+    __syncthreads();
+    if (tid < 256) {
+        const int l = tid >> 2, i = tid & 3;
+        const int m = (l >> 4) * 4 + i, n = l & 15;
+#pragma unroll
+        for (int it = 0; it < MAXT; it++) {
+            const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+            const int row = tile * 16 + m;
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < GM_WAVES; w++) sum = sum + part[(size_t)(it * GM_WAVES + w) * 256 + tid];
+            if (tile < ntiles && row < rows && n < T) {
+                half_t y = f2h(sum);
+                if (bias) y = f2h(h2f(y) + h2f(bias[row]));
+                Y[(size_t)n * rows + row] = y;
+            }
+        }
+    }
+}
+
+template <int MAXT, int TX>
+__global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma(const uint8_t *__restrict__ Wt, int rows, int nblk, const half_t *__restrict__ X, int T,
+                                                               const half_t *__restrict__ bias, half_t *__restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_rows_mfma_body<MAXT, TX>(Wt, rows, nblk, X, T, bias, Y, smem);
+}
+
+// Mixture of experts (ifa_moe.h "smalls"): blockIdx.y is one expert's group of 2..16 consecutive rows of the gathered
+// activations; its tiled weights come from the pointer table.
+template <int MAXT, int TX>
+__global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma_grouped(const MoeSmallGroup grp, int rows, int nblk, const half_t *__restrict__ X,
+                                                                       half_t *__restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.y >= grp.counts[3]) return;
+    const MoeTile gq = grp.smalls[blockIdx.y];
+    const uint8_t *Wt = grp.wtab_tiled[4 * gq.expert + grp.which_tiled];
+    gemm_rows_mfma_body<MAXT, TX>(Wt, rows, nblk, X + (size_t)gq.row0 * nblk * 32, gq.nrows, nullptr, Y + (size_t)gq.row0 * rows, smem);
+}
+
+static int gm_num_cus()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : 8); }
+static size_t gm_smem(int T, int maxt)
+{
+    const size_t ximg = GM_XIMG_BYTES(gm_tx(T)) + (size_t)GM_WAVES * GM_PATCH_BYTES;
+    const size_t parts = (size_t)maxt * GM_WAVES * 256 * 4;
+    return std::max(ximg, parts);
+}
+
+bool gemm_rows_mfma_ok(size_t rows, size_t cols, size_t tokens)
+{
+    return tokens >= 2 && tokens <= 16 && cols % 128 == 0 && rows > 0 && rows < (1u << 24) && cols <= 65536;      // (9..16 rows: two passes of <= 8)
+}
+
+static int gm_geometry(size_t rows, int grid_cap, int *wgs, int *maxt)
+{
+    const int ntiles = (int)((rows + 15) / 16);
+    int w = std::min(grid_cap, ntiles);
+    int mt = (ntiles + w - 1) / w;
+    if (mt > 8) { mt = 8; w = (ntiles + 7) / 8; }                // (more workgroups than CUs: they queue)
+    if (mt == 5) mt = 6;
+    if (mt == 7) mt = 8;
+    *wgs = w; *maxt = mt;
+    return IFA_OK;
+}
+
+template <int MT, int TX>
+static int gm_launch_tx(int wgs, size_t smem, const void *Wt, size_t rows, size_t cols, const void *x, size_t tokens, const void *bias, void *y, hipStream_t s)
+{
+    auto kern = k_gemm_rows_mfma<MT, TX>;
+    if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    kern<<<dim3((unsigned)wgs), dim3(GM_THREADS), smem, s>>>((const uint8_t *)Wt, (int)rows, (int)(cols / 32), (const half_t *)x, (int)tokens,
+                                                             (const half_t *)bias, (half_t *)y);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+template <int MT>
+static int gm_launch(int wgs, size_t smem, const void *Wt, size_t rows, size_t cols, const void *x, size_t tokens, const void *bias, void *y, hipStream_t s)
+{
+    if (tokens <= 2) return gm_launch_tx<MT, 2>(wgs, smem, Wt, rows, cols, x, tokens, bias, y, s);
+    if (tokens <= 4) return gm_launch_tx<MT, 4>(wgs, smem, Wt, rows, cols, x, tokens, bias, y, s);
+    return gm_launch_tx<MT, 8>(wgs, smem, Wt, rows, cols, x, tokens, bias, y, s);
+}
+
+template <int MT, int TX>
+static int gm_launch_grouped_tx(int wgs, int groups, size_t smem, const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, hipStream_t s)
+{
+    auto kern = k_gemm_rows_mfma_grouped<MT, TX>;
+    if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    kern<<<dim3((unsigned)wgs, (unsigned)groups), dim3(GM_THREADS), smem, s>>>(grp, (int)rows, (int)(cols / 32), (const half_t *)X, (half_t *)Y);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+template <int MT>
+static int gm_launch_grouped(int wgs, int groups, int max_rows, size_t smem, const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, hipStream_t s)
+{
+    return gm_launch_grouped_tx<MT, 8>(wgs, groups, smem, grp, rows, cols, X, Y, s);
+}
+
+int gemm_rows_mfma(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens, const void *bias_f16, void *y_f16,
+                   hipStream_t s)
+{
+    if (!gemm_rows_mfma_ok(rows, cols, tokens)) return IFA_ERR_STATE;
+    int wgs, maxt;
+    gm_geometry(rows, gm_num_cus(), &wgs, &maxt);
+    // the LDS holds 8 activation rows of a 4096-column chunk next to the waves' patches: 9..16 rows take two passes
+    for (size_t t0 = 0; t0 < tokens; t0 += 8) {
+        const size_t tn = std::min<size_t>(8, tokens - t0);
+        const void *xp = (const half_t *)x_f16 + t0 * cols;
+        void *yp = (half_t *)y_f16 + t0 * rows;
+        const size_t smem = gm_smem((int)tn, maxt);
+        int rc;
+        switch (maxt) {
+        case 1: rc = gm_launch<1>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
+        case 2: rc = gm_launch<2>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
+        case 3: rc = gm_launch<3>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
+        case 4: rc = gm_launch<4>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
+        case 6: rc = gm_launch<6>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
+        default: rc = gm_launch<8>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
+        }
+        if (rc) return rc;
+    }
+    return IFA_OK;
+}
+
+// rows / cols of ONE expert matrix; X / Y: the gathered activations / outputs of all entries; groups of 2..16 rows
+int gemm_rows_mfma_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, int max_rows, hipStream_t s)
+{
+    if (!gemm_rows_mfma_ok(rows, cols, 2)) return ifa_fail(IFA_ERR_STATE, "grouped rows GEMM: %zu x %zu", rows, cols);
+    if (max_groups <= 0) return IFA_OK;
+    int wgs, maxt;
+    gm_geometry(rows, std::max(32, 2 * gm_num_cus() / max_groups), &wgs, &maxt);     // the experts share the chip
+    if (max_rows > 8) return ifa_fail(IFA_ERR_ARG, "grouped rows GEMM: groups of up to %d rows (limit 8)", max_rows);
+    const size_t smem = gm_smem(8, maxt);
+    switch (maxt) {
+    case 1: return gm_launch_grouped<1>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
+    case 2: return gm_launch_grouped<2>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
+    case 3: return gm_launch_grouped<3>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
+    case 4: return gm_launch_grouped<4>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
+    case 6: return gm_launch_grouped<6>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
+    default: return gm_launch_grouped<8>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
+    }
+}
+
+} // namespace ifa

@@ -378,11 +378,14 @@ def test_gemm_library_path_matches_the_fused_kernel_and_the_oracle(d):
     assert (g.half_ulp_diff(y_own, y_lib) <= 2).mean() >= 0.995
 
 
-@pytest.mark.parametrize("T,rows,cols", [(2, 70, 256), (3, 128, 4096), (4, 200, 1024), (7, 96, 2048), (8, 64, 11008)])
+@pytest.mark.parametrize("T,rows,cols", [(2, 70, 256), (3, 128, 4096), (4, 200, 1024), (7, 96, 2048), (8, 64, 11008), (12, 100, 4096), (16, 48, 5120),
+                                          (5, 4500, 384), (8, 64, 2080)])
 @pytest.mark.parametrize("d", [dt.Q4_B32T1A, dt.Q4_B32T1B], ids=IDS([dt.Q4_B32T1A, dt.Q4_B32T1B]))
 def test_gemm_rows_streaming_kernel_matches_per_token_oracle(d, T, rows, cols):
-    """The 2..8-row weight-streaming GEMM of the dynamic-batching step (csrc/ifa_gemm_rows.hip, tiled layout): same
-    contract as ifa_gemm -- weights dequantised to half, half activations, fp32 accumulation, one F16 rounding."""
+    """The 2..16-row weight-streaming GEMMs of the dynamic-batching step (tiled layout): csrc/ifa_gemm_rows_mfma.hip
+    (matrix cores, row length % 128 == 0, several tiles per workgroup at 4500 rows, a partial LDS chunk at 5120 columns) and
+    csrc/ifa_gemm_rows.hip (2..8 rows, any row length % 32: the 2080-column case) -- same contract as ifa_gemm: weights
+    dequantised to half, half activations, fp32 accumulation, one F16 rounding."""
     import ctypes as C
     L = g.capi()
     L.ifa_gemm_rows_q4.restype = C.c_int
