@@ -808,7 +808,12 @@ struct DecAttnParams {
     int max_ctx;
     int8_t *xq;                // optional XqImage of `out` (Q8_B32T2, the quantiser the Wo GEMV would run in its prologue)
     long long *trace;          // optional [heads][8] wall-clock stamps (100 MHz) for tuning
+    // batched step (k_dec_attn<.., BATCH = true>, grid (heads, queries)): query b reads q|k|v at q + b * q_stride, its cache
+    // pointers and context from batch_rows[b], its RoPE pairs at rope_tab + b * head_dim, and writes out + b * heads * head_dim
+    const void *batch_rows;    // DecAttnBatchRow[queries]
+    int q_stride;
 };
+struct DecAttnBatchRow { const uint8_t *kc, *vc; int n_ctx, pad; };
 
 // Quantize(kqv_merged) (inference_worker.cc:1339-1346) done where the vector is produced: a head is HD/32 whole
 // Q8_B32T2 blocks, so the blocks are local to the head's workgroup and the codes are those of the Alg2 quantizer
@@ -858,11 +863,21 @@ __device__ __forceinline__ void rope_apply(half_t *row, int col, float c, float 
 // at least DEC_ATTN_MIN_ROWS rows (the engine pads the allocation), so that first chunk needs no clamp.
 constexpr int DEC_ATTN_MIN_ROWS = 256;
 
-template <int HD, bool Q8>
+template <int HD, bool Q8, bool BATCH = false>
 __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_t *pkc, const uint8_t *pvc, int pheads, int pkvh,
                                                   const DecAttnParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int pos_b = 0;
+    if constexpr (BATCH) {      // the query's cache pointers and position come from the step's table (one scalar fetch)
+        const DecAttnBatchRow br = reinterpret_cast<const DecAttnBatchRow *>(P.batch_rows)[blockIdx.y];
+        pkc = br.kc; pvc = br.vc; pos_b = br.n_ctx - 1;
+        pq += (size_t)blockIdx.y * P.q_stride;
+    }
+    uint8_t *const kcw = BATCH ? const_cast<uint8_t *>(pkc) : P.kcache;      // the cache rows this workgroup may write
+    uint8_t *const vcw = BATCH ? const_cast<uint8_t *>(pvc) : P.vcache;
+    const float *const rope_tab = BATCH ? P.rope_tab + (size_t)blockIdx.y * HD : P.rope_tab;
+    half_t *const outp = BATCH ? P.out + (size_t)blockIdx.y * pheads * HD : P.out;
     static_assert(HD % 8 == 0 && HD <= 128 && (!Q8 || HD % 32 == 0), "head size: multiples of 8 up to 128 (Q8 rows: whole 32-blocks)");
     constexpr int DG = HD / 8;            // threads covering one V row (8 dims each)
     constexpr int NSPLIT = 256 / DG;      // key residues handled in parallel (head sizes 48 / 80 / 96: the last 256 % DG threads idle)
@@ -946,12 +961,12 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     // will rotate (requested now, used after the staging barrier)
     const bool tr = P.trace != nullptr && tid == 0;
     if (tr) P.trace[h * 8 + 0] = wall_clock64();
-    const int pos = P.state[1];
+    const int pos = BATCH ? pos_b : P.state[1];
     const int n_ctx = pos + 1;
     float rope_cs = 1.0f, rope_sn = 0.0f;
     if (P.rope_order != 0) {
         const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
-        rope_cs = P.rope_tab[2 * c]; rope_sn = P.rope_tab[2 * c + 1];
+        rope_cs = rope_tab[2 * c]; rope_sn = rope_tab[2 * c + 1];
     }
     // ---- stage q, k_new, v_new; RoPE on q and k (TensorOpr::PositionEmbedding, F16 in/out)
     if (tid < HD) { qs[tid] = q_in; kn[tid] = k_in; vn[tid] = v_in; }
@@ -980,7 +995,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
                 qv = min(max(qv, -128), 127);
                 const half_t sch = f2h(sc);
                 if (writer) {
-                    uint8_t *cache = b < NB ? P.kcache : P.vcache;
+                    uint8_t *cache = b < NB ? kcw : vcw;
                     uint8_t *blk = cache + (size_t)pos * row_bytes + head_off + (size_t)bb * 34;
                     blk[2 + lane] = (uint8_t)(int8_t)qv;
                     if (lane == 0) *reinterpret_cast<uint16_t *>(blk) = __builtin_bit_cast(uint16_t, sch);
@@ -991,8 +1006,8 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         __syncthreads();
     } else {
         if (writer && tid < HD) {
-            reinterpret_cast<half_t *>(P.kcache + (size_t)pos * row_bytes + head_off)[tid] = kn[tid];
-            reinterpret_cast<half_t *>(P.vcache + (size_t)pos * row_bytes + head_off)[tid] = vn[tid];
+            reinterpret_cast<half_t *>(kcw + (size_t)pos * row_bytes + head_off)[tid] = kn[tid];
+            reinterpret_cast<half_t *>(vcw + (size_t)pos * row_bytes + head_off)[tid] = vn[tid];
         }
     }
 
@@ -1077,7 +1092,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, h2f(vn[dg * 8 + e]), o[e]);
     };
     auto acc_q8 = [&](float pj, int j) {
-        const uint8_t *blk = P.vcache + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
+        const uint8_t *blk = pvc + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
         const float sc = hbits2f(*reinterpret_cast<const uint16_t *>(blk));
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -1105,7 +1120,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         const float pj = h2f(S[j]);
         if (j == pos) acc_new(pj);
         else if constexpr (Q8) acc_q8(pj, j);
-        else acc_v(pj, reinterpret_cast<const u32x4 *>(P.vcache + (size_t)j * row_bytes + head_off)[dg]);
+        else acc_v(pj, reinterpret_cast<const u32x4 *>(pvc + (size_t)j * row_bytes + head_off)[dg]);
     }
     if (vact) {
 #pragma unroll
@@ -1117,8 +1132,8 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         float acc = opart[tid];
         for (int s2 = 1; s2 < NSPLIT; s2++) acc = acc + opart[s2 * HD + tid];
         const half_t yh = f2h(acc);
-        P.out[(size_t)h * HD + tid] = yh;
-        if constexpr (HD % 32 == 0) { if (P.xq) dec_attn_emit_q8<HD>(P.xq, P.heads * HD, h, tid, yh); }
+        outp[(size_t)h * HD + tid] = yh;
+        if constexpr (HD % 32 == 0 && !BATCH) { if (P.xq) dec_attn_emit_q8<HD>(P.xq, P.heads * HD, h, tid, yh); }
     }
     if (tr) P.trace[h * 8 + 7] = wall_clock64();
 }
@@ -1346,6 +1361,25 @@ __host__ __device__ inline size_t dec_attn_smem(int head_dim, int max_ctx)
 // state[8 + i] = i-th generated token of the current launch batch.
 // Also fills the step's RoPE table: tab[c] = (cos, sin) of pos * theta_scale^c,
 // the same expression rope_rotate() evaluates per element (ifa_math.h).
+// batched step: embedding row of every query's token (grid (x, queries)) and its RoPE table rope_tab[query][head_dim]
+static __global__ void __launch_bounds__(256) k_dec_batch_gather(const half_t *__restrict__ embd, const int *__restrict__ tokens,
+                                                                 const int *__restrict__ positions, int dim, int vocab, half_t *__restrict__ x,
+                                                                 float *__restrict__ rope_tab, int head_dim, float theta, int rope_dims)
+{
+    const int b = blockIdx.y;
+    const int tok = min(max(tokens[b], 0), vocab - 1);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim / 8; c += gridDim.x * blockDim.x)
+        reinterpret_cast<u32x4 *>(x + (size_t)b * dim)[c] = reinterpret_cast<const u32x4 *>(embd + (size_t)tok * dim)[c];
+    if (blockIdx.x == 0 && rope_tab) {
+        const int pos = positions[b];
+        for (int c = threadIdx.x; c < head_dim / 2; c += blockDim.x) {
+            float cs, sn;
+            rope_angle(c, pos, theta, rope_dims, cs, sn);
+            rope_tab[(size_t)b * head_dim + 2 * c] = cs; rope_tab[(size_t)b * head_dim + 2 * c + 1] = sn;
+        }
+    }
+}
+
 static __global__ void __launch_bounds__(256) k_dec_gather(const half_t *__restrict__ embd, const int *__restrict__ state,
                                                     int dim, int vocab, half_t *__restrict__ x,
                                                     float *__restrict__ rope_tab, int head_dim, float theta,

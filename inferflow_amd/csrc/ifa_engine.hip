@@ -19,6 +19,7 @@
 #include "ifa_decode_kernels.h"
 #include "ifa_decode_gemv.h"
 #include "ifa_moe.h"
+#include "ifa_gemm_rows_mfma.h"
 
 using namespace ifa;
 
@@ -58,6 +59,9 @@ struct ifa_model {
     // scratch
     half_t *x = nullptr, *x2 = nullptr, *xn = nullptr, *hn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
     half_t *dqkv = nullptr;     // the decode step's q | k | v vector as ONE buffer (k_dec_attn addresses k and v from q's pointer)
+    half_t *bqkv = nullptr;     // fused batched step: [queries][q | k | v]
+    float *brope = nullptr;     // fused batched step: [queries][head_dim] (cos, sin) pairs
+    size_t bqkv_rows = 0;
     half_t *att = nullptr, *a = nullptr, *f = nullptr, *t1 = nullptr, *t2 = nullptr, *logits = nullptr;
     uint8_t *xq = nullptr;
     int8_t *attq = nullptr;        // XqImage of the attention output (Q8_B32T2), written by the fused attention kernels for the Wo GEMV
@@ -92,7 +96,7 @@ struct ifa_model {
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr};
-    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1;
+    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -628,6 +632,13 @@ static int ensure_scratch(ifa_model *m, int T)
         || (rc = re(m->logits, (size_t)T * c.vocab)))
         return rc;
     if (!m->dqkv) IFA_HIP_CHECK(hipMalloc((void **)&m->dqkv, (QD + 2 * KVD) * sizeof(half_t)));
+    if (T <= 8 && (size_t)T > m->bqkv_rows) {
+        if (m->bqkv) IFA_HIP_CHECK(hipFree(m->bqkv));
+        if (m->brope) IFA_HIP_CHECK(hipFree(m->brope));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->bqkv, 8 * (QD + 2 * KVD) * sizeof(half_t)));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->brope, 8 * (size_t)c.head_dim * sizeof(float)));
+        m->bqkv_rows = 8;
+    }
     if (c.experts > 0) {
         const size_t cap = (size_t)T * (size_t)std::max(1, c.moe_top_k);
         if ((rc = re(m->moe_gate, (size_t)T * c.experts)) || (rc = re(m->moe_out, (size_t)T * D)) || (rc = re(m->moe_in, (size_t)T * D))
@@ -1165,6 +1176,93 @@ static void *kv_ptr(ifa_model *m, size_t layer, int slot, bool is_v)
     return is_v ? sl.v[layer] : sl.k[layer];
 }
 
+
+// ---- the batched step as five launches per layer (the structure of the batch-1 step: ifa_gemm_rows_mfma.hip with the norm
+// prologue / GLU / residual epilogues, k_dec_attn<.., BATCH>): dense models with the sequential RMS wiring, every linear in
+// tiled Q4_B32T1, 2..8 queries.  Everything else takes the op-by-op rows below.
+static bool batch_fused_ok(const ifa_model *m, int n)
+{
+    const ifa_model_config &c = m->cfg;
+    if (!m->opt_batch_fused || !m->opt_gemm_rows || !gemm_rows_use_mfma() || n < 2 || n > 8 || m->topo) return false;
+    if (c.experts > 0 || c.norm_kind != 0 || c.parallel_attn || c.share_input) return false;
+    if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) return false;
+    const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
+    if (D % 128 || QD % 128 || F % 128 || D > 4096 || KVD % 16 || D % 16 || F % 16) return false;
+    if (c.head_dim != 32 && c.head_dim != 48 && c.head_dim != 64 && c.head_dim != 80 && c.head_dim != 96 && c.head_dim != 128) return false;
+    if (c.kv_dtype == Q8_B32T2 && c.head_dim % 32 != 0) return false;
+    if (dec_attn_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT) return false;
+    for (const Layer &L : m->layers) {
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids) if (!L.t[id].present() || !L.t[id].tiled || !is_q4(L.t[id].dtype)) return false;
+        if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present() || L.t[T_ATTN_NORM_B].present() || L.t[T_FFN_NORM_B].present()) return false;
+    }
+    return true;
+}
+
+static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t *xnext, const void *rows_l)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
+    int rc;
+    GmArgs P;
+    auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = n; P.eps = c.eps; P.act_kind = c.act_kind; };
+    // 1. RmsNorm -> wq | wk | wv  (one virtual row space, one [n][q | k | v] output)
+    clear();
+    P.W[0] = (const uint8_t *)L.t[T_WQ].tiled; P.W[1] = (const uint8_t *)L.t[T_WK].tiled; P.W[2] = (const uint8_t *)L.t[T_WV].tiled;
+    P.rows[0] = (int)QD; P.rows[1] = (int)KVD; P.rows[2] = (int)KVD; P.nsets = 3; P.nblk = (int)(D / 32);
+    P.X = x; P.ldx = (int)D; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.multi_base = c.attn_norm_base;
+    P.bias[0] = (const half_t *)L.t[T_WQ_B].data; P.bias[1] = (const half_t *)L.t[T_WK_B].data; P.bias[2] = (const half_t *)L.t[T_WV_B].data;
+    P.Y = m->bqkv; P.ldy = (int)(QD + 2 * KVD);
+    if ((rc = gemm_rows_mfma_launch(P, GM_PLAIN, 1, m->stream))) return rc;
+    // 2. RoPE, KV store, attention of every query on its own cache
+    {
+        const int rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f);
+        DecAttnParams A; memset(&A, 0, sizeof(A));
+        A.q = m->bqkv; A.k_new = m->bqkv + QD; A.v_new = A.k_new + KVD;
+        A.state = m->state; A.rope_tab = m->brope; A.heads = c.heads; A.kv_heads = c.kv_heads;
+        A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale;
+        A.rope_order = c.rope_order; A.rope_cols = rope_dims;
+        A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
+        A.out = m->att; A.max_ctx = c.max_ctx; A.batch_rows = rows_l; A.q_stride = (int)(QD + 2 * KVD);
+        const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx);
+        const dim3 grid((unsigned)c.heads, (unsigned)n), block(256);
+#define IFA_BATTN(HDV, Q8V) { auto kern = k_dec_attn<HDV, Q8V, true>; \
+        if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
+        kern<<<grid, block, asmem, m->stream>>>(A.q, nullptr, nullptr, A.heads, A.kv_heads, A); }
+        switch (c.head_dim) {
+        case 32: if (A.kv_q8) IFA_BATTN(32, true) else IFA_BATTN(32, false) break;
+        case 64: if (A.kv_q8) IFA_BATTN(64, true) else IFA_BATTN(64, false) break;
+        case 96: if (A.kv_q8) IFA_BATTN(96, true) else IFA_BATTN(96, false) break;
+        case 128: if (A.kv_q8) IFA_BATTN(128, true) else IFA_BATTN(128, false) break;
+        case 48: IFA_BATTN(48, false) break;
+        case 80: IFA_BATTN(80, false) break;
+        default: return ifa_fail(IFA_ERR_ARG, "fused batched attention: head_dim %d", c.head_dim);
+        }
+#undef IFA_BATTN
+        IFA_LAUNCH_CHECK();
+    }
+    // 3. wo (+ bias) + residual
+    clear();
+    P.W[0] = (const uint8_t *)L.t[T_WO].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(QD / 32);
+    P.X = m->att; P.ldx = (int)QD; P.bias[0] = (const half_t *)L.t[T_WO_B].data;
+    P.Y = m->a; P.ldy = (int)D; P.res = x; P.ldres = (int)D;
+    if ((rc = gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream))) return rc;
+    // 4. RmsNorm -> w1, w3 -> act(w1 x) * (w3 x)
+    clear();
+    P.W[0] = (const uint8_t *)L.t[T_W1].tiled; P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
+    P.X = m->a; P.ldx = (int)D; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.multi_base = c.ffn_norm_base;
+    P.bias[0] = (const half_t *)L.t[T_W1_B].data; P.bias1 = (const half_t *)L.t[T_W3_B].data;
+    P.Y = m->t1; P.ldy = (int)F;
+    if ((rc = gemm_rows_mfma_launch(P, GM_GLU, 1, m->stream))) return rc;
+    // 5. w2 (+ bias) + residual -> the next layer's input
+    clear();
+    P.W[0] = (const uint8_t *)L.t[T_W2].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(F / 32);
+    P.X = m->t1; P.ldx = (int)F; P.bias[0] = (const half_t *)L.t[T_W2_B].data;
+    P.Y = xnext; P.ldy = (int)D; P.res = m->a; P.ldres = (int)D;
+    return gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream);
+}
+
 static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int *pos_host, const int *slot_host, int *next_tokens,
                          void *logits_out)
 {
@@ -1213,7 +1311,8 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     for (const Layer &Lc : m->layers) has_moe = has_moe || (c.experts > 0 && Lc.t[T_MOE_GATE].present());
     // (measured on Llama-2-7B Q4: the batched step is bound by the small-T GEMM kernels, ~6.7 ms with or without the
     //  graph, so replay is opt-in: set_option("batch_graph", 1))
-    const bool use_graph = m->opt_batch_graph && m->opt_graph && !has_moe && !logits_out && !tp;
+    const bool fused = batch_fused_ok(m, n);          // five launches per layer: launch-bound without a graph, so it is replayed
+    const bool use_graph = (m->opt_batch_graph || fused) && m->opt_graph && !has_moe && !logits_out && !tp;
     const int attn_ctx = use_graph ? c.max_ctx : max_ctx;     // LDS sizing of the attention kernel must not depend on the step
     if (use_graph) {
         auto it = m->batch_graphs.find(n);
@@ -1228,14 +1327,26 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     }
     auto body = [&]() -> int {
     IFA_HIP_CHECK(hipMemcpyAsync(m->batch_tab_dev, m->batch_tab_pin, tab_bytes, hipMemcpyHostToDevice, m->stream));
-    k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, tok_d, T, (int)D,
-                                                                      (int)m->g[T_EMBD].rows, m->x);
+    if (fused)
+        k_dec_batch_gather<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, tok_d, pos_d, (int)D, (int)m->g[T_EMBD].rows,
+                                                                              m->x, c.rope_order ? m->brope : nullptr, c.head_dim, c.rope_theta,
+                                                                              (int)(c.head_dim * c.partial_rotary + 0.5f));
+    else
+        k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, tok_d, T, (int)D,
+                                                                          (int)m->g[T_EMBD].rows, m->x);
     IFA_LAUNCH_CHECK();
     half_t *x = m->x;
     const Tensor none;
     const bool seq_wiring = !c.parallel_attn && !c.share_input;
     bool xn_ready = false;           // see forward_ops: every residual Add is fused with the norm that follows it
-    for (int l = 0; l < c.layers; l++) {
+    if (fused) {
+        for (int l = 0; l < c.layers; l++) {
+            if ((rc = batch_fused_layer(m, l, n, x, m->f, rows_d + (size_t)l * (size_t)n))) return rc;
+            std::swap(m->x, m->f);
+            x = m->x;
+        }
+    }
+    for (int l = fused ? c.layers : 0; l < c.layers; l++) {
         Layer &L = m->layers[(size_t)l];
         const half_t *attn_in = x;
         if (L.t[T_ATTN_NORM].present()) {
@@ -1382,7 +1493,7 @@ int ifa_model_destroy(ifa_model *m)
     if (m->attn_ws.lmax) (void)hipFree(m->attn_ws.lmax);
     if (m->attn_ws.opart) (void)hipFree(m->attn_ws.opart);
     for (Tensor &t : m->g) free_tensor(t);
-    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->dqkv, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits,
+    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->dqkv, &m->bqkv, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits,
                        &m->moe_gate, &m->moe_out, &m->moe_in, &m->moe_wdev};
     for (half_t **b : bufs) if (*b) (void)hipFree(*b);
     if (m->moe_idx) (void)hipFree(m->moe_idx);
@@ -1605,7 +1716,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;

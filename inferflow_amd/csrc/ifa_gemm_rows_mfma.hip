@@ -23,9 +23,11 @@
 //   * the activation rows sit in LDS as F16, 4096 columns at a time (row stride + 16 B: conflict-free 16-byte reads);
 //     longer rows (w2) are walked in chunks with the accumulators kept in registers.
 #include <algorithm>
+#include <cstring>
 #include "ifa_host.h"
 #include "ifa_decode_kernels.h"
 #include "ifa_moe.h"
+#include "ifa_gemm_rows_mfma.h"
 
 namespace ifa {
 
@@ -43,38 +45,83 @@ struct GmGrp { u32x4 c[4]; u32x4 sb; };
 constexpr int GM_PATCH_BYTES = 16 * 272 + 16 * 80;        // per-wave transposition patch (codes + (base, scale) words)
 #define GM_XIMG_BYTES(TXV) ((size_t)(TXV) * GM_ROW_STRIDE)
 
-// MAXT: tiles per workgroup (tile = blockIdx.x + i * gridDim.x); TX: activation rows staged per thread (>= T, power of two)
-// Every global load below is UNCONDITIONAL (clamped or redirected addresses): loads inside branches make the compiler's
-// vmcnt bookkeeping conservative -- every wait became vmcnt(0), i.e. for all three groups in flight (ISA of the first version).
-template <int MAXT, int TX>
-__device__ __forceinline__ void gemm_rows_mfma_body(const uint8_t *__restrict__ Wt, int rows, int nblk, const half_t *__restrict__ X, int T,
-                                                    const half_t *__restrict__ bias, half_t *__restrict__ Y, char *smem)
+struct GmTile { const uint8_t *W0; const half_t *b0; int row0, nrows, vrow0; };
+// The set of a tile is selected among SCALARS read once from the argument block (GmSets): selecting among the struct's
+// fields in place made the compiler spill the whole block to scratch and fetch the chosen field with a VGPR-indexed
+// scratch load in front of every weight request (first version of the fused step: every kernel +6 us).
+struct GmSets { const uint8_t *w0, *w1, *w2; const half_t *b0, *b1, *b2; int r0, r1, r2, nsets; };
+// (`c ? S.a : S.b` on two members is an lvalue conditional: clang selects the ADDRESS and loads once -- through scratch with
+//  a VGPR index when the struct is a local.  gm_sel takes its operands by value, so the select is on values.)
+template <typename V> __device__ __forceinline__ V gm_sel(bool c, V a, V b) { return c ? a : b; }
+__device__ __forceinline__ GmTile gm_locate(const GmSets &S, int vt)
 {
+    const uint8_t *const w0 = S.w0, *const w1 = S.w1, *const w2 = S.w2;
+    const half_t *const b0 = S.b0, *const b1 = S.b1, *const b2 = S.b2;
+    const int r0 = S.r0, r1 = S.r1, r2 = S.r2;
+    const int t0 = (r0 + 15) >> 4, t1 = (r1 + 15) >> 4;
+    const bool in1 = S.nsets > 1 && vt >= t0, in2 = S.nsets > 2 && vt >= t0 + t1;
+    GmTile t;
+    t.W0 = gm_sel(in2, w2, gm_sel(in1, w1, w0));
+    t.b0 = gm_sel(in2, b2, gm_sel(in1, b1, b0));
+    t.nrows = gm_sel(in2, r2, gm_sel(in1, r1, r0));
+    const int lt = gm_sel(in2, vt - t0 - t1, gm_sel(in1, vt - t0, vt));
+    t.row0 = lt * 16;
+    t.vrow0 = gm_sel(in2, r0 + r1, gm_sel(in1, r0, 0)) + lt * 16;
+    return t;
+}
+
+// MAXT: tiles per workgroup (tile = blockIdx.x + i * gridDim.x); TX: activation rows staged per thread (>= T, power of two)
+// EPI: GmEpilogue; NORM: 1 = RMS-normalise the rows while staging them (K <= 4096: one chunk)
+// Every global load below is UNCONDITIONAL (clamped or redirected addresses): loads inside branches make the compiler's
+// vmcnt bookkeeping conservative -- every wait became vmcnt(0), i.e. for all groups in flight (ISA of the first version).
+template <int MAXT, int TX, int EPI, int NORM>
+__device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
+{
+    constexpr int NM = EPI == GM_GLU ? 2 : 1;
+    constexpr int PD = NM == 2 ? 2 : 3;              // groups (GLU: pairs of groups) in flight per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
+    const int nblk = P.nblk, T = P.T;
+    // (readfirstlane: the values are materialised in SGPRs here, so the selects below cannot be folded back into a load
+    //  through a selected ADDRESS of the argument block)
+    auto sp = [](const void *p) {
+        const uint64_t v = (uint64_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    auto si = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const GmSets S = {(const uint8_t *)sp(P.W[0]), (const uint8_t *)sp(P.W[1]), (const uint8_t *)sp(P.W[2]), (const half_t *)sp(P.bias[0]),
+                      (const half_t *)sp(P.bias[1]), (const half_t *)sp(P.bias[2]), si(P.rows[0]), si(P.rows[1]), si(P.rows[2]), si(P.nsets)};
+    const uint8_t *const W1p = P.W1;
+    const half_t *const Xp = P.X, *const nwp = P.norm_w;
+    const int ldx = P.ldx;
     const int K = nblk * 32;
     const int nsup = nblk >> 2;                                   // nblk % 4 == 0 (checked by the launcher)
     const int nchunk = (nsup + GM_CHUNK_SUP - 1) / GM_CHUNK_SUP;
-    const int ntiles = (rows + 15) >> 4;
+    const int ntiles = (P.total_rows + 15) >> 4;                  // (several sets: every set is whole tiles)
     const size_t row_bytes = tiled_row_bytes(Q4_B32T1A, (size_t)nblk);
     const int trow = min(r, T - 1);                               // B operand: token of this lane (columns past T: duplicates, never stored)
 
     // a group = this wave's 16 rows x 16 blocks of (tile, chunk): blocks blk0 .. blk0 + 15, blk0 = 128 chunk + 16 wave
     // valid == false (past the last group): all lanes re-read the first bytes of the matrix -- one cache line, no branch
-    auto fetch = [&](GmGrp &q, int it, int chunk, bool valid) {
-        const int tile = min((int)blockIdx.x + it * (int)gridDim.x, ntiles - 1);
+    auto fetch = [&](GmGrp (&q)[NM], int it, int chunk, bool valid) {
+        const GmTile tl = gm_locate(S, min((int)blockIdx.x + it * (int)gridDim.x, ntiles - 1));
         const int blk0 = chunk * (GM_CHUNK_SUP * 4) + wave * 16;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {          // codes: lane l -> row 4i + l / 16, block l % 16 (256 contiguous bytes per row)
-            const int row = valid ? min(tile * 16 + 4 * i + (lane >> 4), rows - 1) : 0;
-            const int blk = valid ? min(blk0 + (lane & 15), nblk - 1) : 0;
-            q.c[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)blk * 16));
-        }
-        {                                       // (base, scale): lane l -> row l / 4, blocks 4 (l % 4) .. + 3 (64 contiguous bytes per row)
-            const int row = valid ? min(tile * 16 + (lane >> 2), rows - 1) : 0;
-            const int blk = valid ? min(blk0 + 4 * (lane & 3), nblk - 4) : 0;
-            q.sb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)nblk * 16 + (size_t)blk * 4));
+        for (int mm = 0; mm < NM; mm++) {
+            const uint8_t *Wt = mm == 0 ? tl.W0 : W1p;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {      // codes: lane l -> row 4i + l / 16, block l % 16 (256 contiguous bytes per row)
+                const int row = valid ? min(tl.row0 + 4 * i + (lane >> 4), tl.nrows - 1) : 0;
+                const int blk = valid ? min(blk0 + (lane & 15), nblk - 1) : 0;
+                q[mm].c[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)blk * 16));
+            }
+            {                                   // (base, scale): lane l -> row l / 4, blocks 4 (l % 4) .. + 3 (64 contiguous bytes per row)
+                const int row = valid ? min(tl.row0 + (lane >> 2), tl.nrows - 1) : 0;
+                const int blk = valid ? min(blk0 + 4 * (lane & 3), nblk - 4) : 0;
+                q[mm].sb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)nblk * 16 + (size_t)blk * 4));
+            }
         }
     };
     char *patch = smem + GM_XIMG_BYTES(TX) + (size_t)wave * GM_PATCH_BYTES;        // this wave's transposition patch
@@ -113,36 +160,69 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const uint8_t *__restrict__ 
         }
     };
 
-    f4m acc[MAXT];
+    f4m acc[NM][MAXT];
 #pragma unroll
-    for (int i = 0; i < MAXT; i++) acc[i] = f4m{0.0f, 0.0f, 0.0f, 0.0f};
-    // three groups of requests in flight per wave (a group = 4 supersteps = 5 KB per wave): one group ahead left every wave
+    for (int mm = 0; mm < NM; mm++)
+#pragma unroll
+        for (int i = 0; i < MAXT; i++) acc[mm][i] = f4m{0.0f, 0.0f, 0.0f, 0.0f};
+    // PD groups of requests in flight per wave (a group = 4 supersteps = 5 KB per wave): one group ahead left every wave
     // waiting ~half of the time for HBM
-    GmGrp cur, n1, n2;
+    GmGrp buf[PD][NM];
     const int nq = nchunk * MAXT;                                  // (chunk, tile) pairs in execution order: chunk outer
-    auto fetch_q = [&](GmGrp &q, int qi) { const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, ch, qi < nq); };
+    auto fetch_q = [&](GmGrp (&q)[NM], int qi) { const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, ch, qi < nq); };
     // The CU's memory pipeline is FIFO across waves (ifa_decode_kernels.h): the activation rows of the first chunk are
     // requested by all threads, and a barrier passed, BEFORE any weight request -- else they arrive behind the weights.
     // A full chunk is 512 16-byte pieces per row: piece tid of row k is thread tid's k-th request.
     u32x4 xv[TX];
+    u32x4 nwv = {0, 0, 0, 0};
     auto x_request = [&](int chunk) {
         const int c0 = chunk * GM_CHUNK_COLS;
         const int per_row = min(GM_CHUNK_COLS, K - c0) >> 3;
 #pragma unroll
         for (int k = 0; k < TX; k++)       // rows past T and pieces past the row end: clamped (duplicates), never stored
-            xv[k] = *reinterpret_cast<const u32x4 *>(X + (size_t)min(k, T - 1) * K + c0 + (size_t)min(tid, per_row - 1) * 8);
+            xv[k] = *reinterpret_cast<const u32x4 *>(Xp + (size_t)min(k, T - 1) * ldx + c0 + (size_t)min(tid, per_row - 1) * 8);
+        if constexpr (NORM == 1)
+            nwv = *reinterpret_cast<const u32x4 *>((nwp ? nwp : Xp) + (size_t)min(tid, per_row - 1) * 8);   // (no weight: a valid dummy address)
     };
     auto x_store = [&](int chunk) {
         const int per_row = min(GM_CHUNK_COLS, K - chunk * GM_CHUNK_COLS) >> 3;
+        if constexpr (NORM == 1) {
+            // RMS norm of every row in the canonical order of ifa_math.h: piece c = tid is lane c % 64 of group c / 64 = wave
+            float *part = reinterpret_cast<float *>(smem + GM_XIMG_BYTES(TX) + (size_t)GM_WAVES * GM_PATCH_BYTES);     // [TX][8]
+#pragma unroll
+            for (int k = 0; k < TX; k++) {
+                rms_h8 v8 = __builtin_bit_cast(rms_h8, xv[k]);
+                if (tid >= per_row) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v8[i] = (half_t)0;
+                }
+                const float pg = wave_sum(rms_chunk_sq(v8));
+                if (lane == 0) part[k * GM_WAVES + wave] = pg;
+            }
+            __syncthreads();
+            const rms_h8 nw8 = __builtin_bit_cast(rms_h8, nwv);
+#pragma unroll
+            for (int k = 0; k < TX; k++) {
+                const float scale = rms_scale_of(rms_total(part + k * GM_WAVES, (per_row + 63) >> 6), K, P.eps);
+                const rms_h8 v8 = __builtin_bit_cast(rms_h8, xv[k]);
+                rms_h8 o;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float t = (float)v8[i] * scale;
+                    if (nwp) { const float mlt = P.multi_base + (float)nw8[i]; t = t * mlt; }
+                    o[i] = f2h(t);
+                }
+                xv[k] = __builtin_bit_cast(u32x4, o);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < TX; k++)
             if (k < T && tid < per_row) *reinterpret_cast<u32x4 *>(smem + (size_t)k * GM_ROW_STRIDE + (size_t)tid * 16) = xv[k];
     };
     x_request(0);
     __syncthreads();
-    fetch_q(cur, 0);
-    fetch_q(n1, 1);
-    fetch_q(n2, 2);
+#pragma unroll
+    for (int d = 0; d < PD; d++) fetch_q(buf[d], d);
     for (int chunk = 0; chunk < nchunk; chunk++) {
         if (chunk > 0) {
             __syncthreads();                                       // the previous chunk's fragments have been read
@@ -153,47 +233,66 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const uint8_t *__restrict__ 
 #pragma unroll
         for (int it = 0; it < MAXT; it++) {
             const int qi = chunk * MAXT + it;
-            compute(cur, chunk, acc[it]);
-            cur = n1; n1 = n2;
-            fetch_q(n2, qi + 3);
+#pragma unroll
+            for (int mm = 0; mm < NM; mm++) compute(buf[0][mm], chunk, acc[mm][it]);
+#pragma unroll
+            for (int d = 0; d + 1 < PD; d++)
+#pragma unroll
+                for (int mm = 0; mm < NM; mm++) buf[d][mm] = buf[d + 1][mm];
+            fetch_q(buf[PD - 1], qi + PD);
         }
     }
-    // ---- sum the 8 waves' partial tiles in wave order, then bias and store: thread e of the first 256 owns element
+    // ---- sum the 8 waves' partial tiles in wave order, then the epilogue: thread e of the first 256 owns element
     // (m = (l >> 4) * 4 + i, n = l & 15) of every tile, l = e >> 2, i = e & 3 (the MFMA's C layout)
     __syncthreads();                                               // the activation image is free: partials take its place
-    float *part = reinterpret_cast<float *>(smem);                 // [MAXT][8 waves][256]
+    float *part = reinterpret_cast<float *>(smem);                 // [NM][MAXT][8 waves][256]
 #pragma unroll
-    for (int it = 0; it < MAXT; it++)
-        *reinterpret_cast<f4m *>(part + ((size_t)(it * GM_WAVES + wave) * 64 + lane) * 4) = acc[it];
+    for (int mm = 0; mm < NM; mm++)
+#pragma unroll
+        for (int it = 0; it < MAXT; it++)
+            *reinterpret_cast<f4m *>(part + ((size_t)((mm * MAXT + it) * GM_WAVES + wave) * 64 + lane) * 4) = acc[mm][it];
     __syncthreads();
     if (tid < 256) {
         const int l = tid >> 2, i = tid & 3;
         const int m = (l >> 4) * 4 + i, n = l & 15;
 #pragma unroll
         for (int it = 0; it < MAXT; it++) {
-            const int tile = (int)blockIdx.x + it * (int)gridDim.x;
-            const int row = tile * 16 + m;
-            float sum = 0.0f;
+            const int vt = (int)blockIdx.x + it * (int)gridDim.x;
+            const GmTile tl = gm_locate(S, min(vt, ntiles - 1));
+            const int row = tl.row0 + m;
+            float sum[NM];
 #pragma unroll
-            for (int w = 0; w < GM_WAVES; w++) sum = sum + part[(size_t)(it * GM_WAVES + w) * 256 + tid];
-            if (tile < ntiles && row < rows && n < T) {
-                half_t y = f2h(sum);
-                if (bias) y = f2h(h2f(y) + h2f(bias[row]));
-                Y[(size_t)n * rows + row] = y;
+            for (int mm = 0; mm < NM; mm++) {
+                sum[mm] = 0.0f;
+#pragma unroll
+                for (int w = 0; w < GM_WAVES; w++) sum[mm] = sum[mm] + part[(size_t)((mm * MAXT + it) * GM_WAVES + w) * 256 + tid];
+            }
+            if (vt < ntiles && row < tl.nrows && n < T) {
+                half_t y = f2h(sum[0]);
+                if (tl.b0) y = f2h(h2f(y) + h2f(tl.b0[row]));
+                const size_t vrow = (size_t)tl.vrow0 + m;
+                if constexpr (EPI == GM_RESIDUAL) {
+                    y = f2h(h2f(P.res[(size_t)n * P.ldres + vrow]) + h2f(y));          // TensorOpr::Add (half add)
+                } else if constexpr (EPI == GM_GLU) {
+                    half_t y3 = f2h(sum[NM - 1]);
+                    if (P.bias1) y3 = f2h(h2f(y3) + h2f(P.bias1[row]));
+                    const half_t act = f2h(act_fn(h2f(y), P.act_kind));                // TensorOpr::Activation -> F16
+                    y = f2h(h2f(act) * h2f(y3));                                       // TensorOpr::Mul
+                }
+                P.Y[(size_t)n * P.ldy + vrow] = y;
             }
         }
     }
 }
 
-template <int MAXT, int TX>
-__global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma(const uint8_t *__restrict__ Wt, int rows, int nblk, const half_t *__restrict__ X, int T,
-                                                               const half_t *__restrict__ bias, half_t *__restrict__ Y)
+template <int MAXT, int TX, int EPI, int NORM>
+__global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma(const GmArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_rows_mfma_body<MAXT, TX>(Wt, rows, nblk, X, T, bias, Y, smem);
+    gemm_rows_mfma_body<MAXT, TX, EPI, NORM>(P, smem);
 }
 
-// Mixture of experts (ifa_moe.h "smalls"): blockIdx.y is one expert's group of 2..16 consecutive rows of the gathered
+// Mixture of experts (ifa_moe.h "smalls"): blockIdx.y is one expert's group of 2..8 consecutive rows of the gathered
 // activations; its tiled weights come from the pointer table.
 template <int MAXT, int TX>
 __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma_grouped(const MoeSmallGroup grp, int rows, int nblk, const half_t *__restrict__ X,
@@ -202,8 +301,13 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma_grouped(const Moe
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.y >= grp.counts[3]) return;
     const MoeTile gq = grp.smalls[blockIdx.y];
-    const uint8_t *Wt = grp.wtab_tiled[4 * gq.expert + grp.which_tiled];
-    gemm_rows_mfma_body<MAXT, TX>(Wt, rows, nblk, X + (size_t)gq.row0 * nblk * 32, gq.nrows, nullptr, Y + (size_t)gq.row0 * rows, smem);
+    GmArgs P;
+    P.W[0] = grp.wtab_tiled[4 * gq.expert + grp.which_tiled]; P.W[1] = nullptr; P.W[2] = nullptr; P.W1 = nullptr;
+    P.rows[0] = rows; P.rows[1] = 0; P.rows[2] = 0; P.nsets = 1; P.total_rows = rows; P.nblk = nblk; P.T = gq.nrows;
+    P.X = X + (size_t)gq.row0 * nblk * 32; P.ldx = nblk * 32; P.multi_base = 0.0f; P.eps = 0.0f; P.norm_w = nullptr;
+    P.bias[0] = nullptr; P.bias[1] = nullptr; P.bias[2] = nullptr; P.bias1 = nullptr;
+    P.Y = Y + (size_t)gq.row0 * rows; P.res = nullptr; P.ldy = rows; P.ldres = 0; P.act_kind = 0;
+    gemm_rows_mfma_body<MAXT, TX, GM_PLAIN, 0>(P, smem);
 }
 
 static int gm_num_cus()
@@ -218,10 +322,10 @@ static int gm_num_cus()
 }
 
 static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : 8); }
-static size_t gm_smem(int T, int maxt)
+static size_t gm_smem(int T, int maxt, int nm)
 {
-    const size_t ximg = GM_XIMG_BYTES(gm_tx(T)) + (size_t)GM_WAVES * GM_PATCH_BYTES;
-    const size_t parts = (size_t)maxt * GM_WAVES * 256 * 4;
+    const size_t ximg = GM_XIMG_BYTES(gm_tx(T)) + (size_t)GM_WAVES * GM_PATCH_BYTES + 8 * GM_WAVES * 4;      // + the norm's group sums
+    const size_t parts = (size_t)nm * maxt * GM_WAVES * 256 * 4;
     return std::max(ximg, parts);
 }
 
@@ -242,62 +346,88 @@ static int gm_geometry(size_t rows, int grid_cap, int *wgs, int *maxt)
     return IFA_OK;
 }
 
-template <int MT, int TX>
-static int gm_launch_tx(int wgs, size_t smem, const void *Wt, size_t rows, size_t cols, const void *x, size_t tokens, const void *bias, void *y, hipStream_t s)
+template <int MT, int TX, int EPI, int NORM>
+static int gm_launch4(int wgs, size_t smem, const GmArgs &P, hipStream_t s)
 {
-    auto kern = k_gemm_rows_mfma<MT, TX>;
+    auto kern = k_gemm_rows_mfma<MT, TX, EPI, NORM>;
     if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<dim3((unsigned)wgs), dim3(GM_THREADS), smem, s>>>((const uint8_t *)Wt, (int)rows, (int)(cols / 32), (const half_t *)x, (int)tokens,
-                                                             (const half_t *)bias, (half_t *)y);
+    kern<<<dim3((unsigned)wgs), dim3(GM_THREADS), smem, s>>>(P);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
 
-template <int MT>
-static int gm_launch(int wgs, size_t smem, const void *Wt, size_t rows, size_t cols, const void *x, size_t tokens, const void *bias, void *y, hipStream_t s)
+template <int MT, int TX>
+static int gm_launch2(int wgs, size_t smem, const GmArgs &P, int epi, int norm, hipStream_t s)
 {
-    if (tokens <= 2) return gm_launch_tx<MT, 2>(wgs, smem, Wt, rows, cols, x, tokens, bias, y, s);
-    if (tokens <= 4) return gm_launch_tx<MT, 4>(wgs, smem, Wt, rows, cols, x, tokens, bias, y, s);
-    return gm_launch_tx<MT, 8>(wgs, smem, Wt, rows, cols, x, tokens, bias, y, s);
+    if (epi == GM_PLAIN && norm == 0) return gm_launch4<MT, TX, GM_PLAIN, 0>(wgs, smem, P, s);
+    if (epi == GM_PLAIN && norm == 1) return gm_launch4<MT, TX, GM_PLAIN, 1>(wgs, smem, P, s);
+    if (epi == GM_RESIDUAL && norm == 0) return gm_launch4<MT, TX, GM_RESIDUAL, 0>(wgs, smem, P, s);
+    if (epi == GM_GLU && norm == 1) return gm_launch4<MT, TX, GM_GLU, 1>(wgs, smem, P, s);
+    return ifa_fail(IFA_ERR_ARG, "rows GEMM: no kernel for epilogue %d / norm %d", epi, norm);
 }
 
-template <int MT, int TX>
-static int gm_launch_grouped_tx(int wgs, int groups, size_t smem, const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, hipStream_t s)
+template <int MT>
+static int gm_launch1(int wgs, size_t smem, const GmArgs &P, int epi, int norm, hipStream_t s)
 {
-    auto kern = k_gemm_rows_mfma_grouped<MT, TX>;
+    if (P.T <= 2) return gm_launch2<MT, 2>(wgs, smem, P, epi, norm, s);
+    if (P.T <= 4) return gm_launch2<MT, 4>(wgs, smem, P, epi, norm, s);
+    return gm_launch2<MT, 8>(wgs, smem, P, epi, norm, s);
+}
+
+bool gemm_rows_mfma_fused_ok(const GmArgs &P, int epi, int norm)
+{
+    if (P.T < 2 || P.T > 8 || P.nblk <= 0 || P.nblk % 4 != 0 || P.nsets < 1 || P.nsets > 3) return false;
+    if (norm == 1 && P.nblk * 32 > GM_CHUNK_COLS) return false;
+    if (epi == GM_GLU && (P.nsets != 1 || !P.W1)) return false;
+    for (int i = 0; i < P.nsets; i++) if (P.rows[i] <= 0 || (P.nsets > 1 && P.rows[i] % 16 != 0)) return false;
+    return true;
+}
+
+int gemm_rows_mfma_launch(const GmArgs &P0, int epi, int norm, hipStream_t s)
+{
+    GmArgs P = P0;
+    P.total_rows = 0;
+    for (int i = 0; i < P.nsets; i++) P.total_rows += P.rows[i];
+    if (!gemm_rows_mfma_fused_ok(P, epi, norm)) return ifa_fail(IFA_ERR_ARG, "rows GEMM: shape not covered (T %d, %d blocks, %d sets)", P.T, P.nblk, P.nsets);
+    int wgs, maxt;
+    gm_geometry((size_t)P.total_rows, gm_num_cus(), &wgs, &maxt);
+    const size_t smem = gm_smem(P.T, maxt, epi == GM_GLU ? 2 : 1);
+    switch (maxt) {
+    case 1: return gm_launch1<1>(wgs, smem, P, epi, norm, s);
+    case 2: return gm_launch1<2>(wgs, smem, P, epi, norm, s);
+    case 3: return gm_launch1<3>(wgs, smem, P, epi, norm, s);
+    case 4: return gm_launch1<4>(wgs, smem, P, epi, norm, s);
+    case 6: return gm_launch1<6>(wgs, smem, P, epi, norm, s);
+    default: return gm_launch1<8>(wgs, smem, P, epi, norm, s);
+    }
+}
+
+template <int MT>
+static int gm_launch_grouped(int wgs, int groups, size_t smem, const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, hipStream_t s)
+{
+    auto kern = k_gemm_rows_mfma_grouped<MT, 8>;
     if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     kern<<<dim3((unsigned)wgs, (unsigned)groups), dim3(GM_THREADS), smem, s>>>(grp, (int)rows, (int)(cols / 32), (const half_t *)X, (half_t *)Y);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
 
-template <int MT>
-static int gm_launch_grouped(int wgs, int groups, int max_rows, size_t smem, const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, hipStream_t s)
-{
-    return gm_launch_grouped_tx<MT, 8>(wgs, groups, smem, grp, rows, cols, X, Y, s);
-}
-
 int gemm_rows_mfma(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens, const void *bias_f16, void *y_f16,
                    hipStream_t s)
 {
     if (!gemm_rows_mfma_ok(rows, cols, tokens)) return IFA_ERR_STATE;
-    int wgs, maxt;
-    gm_geometry(rows, gm_num_cus(), &wgs, &maxt);
     // the LDS holds 8 activation rows of a 4096-column chunk next to the waves' patches: 9..16 rows take two passes
     for (size_t t0 = 0; t0 < tokens; t0 += 8) {
-        const size_t tn = std::min<size_t>(8, tokens - t0);
-        const void *xp = (const half_t *)x_f16 + t0 * cols;
-        void *yp = (half_t *)y_f16 + t0 * rows;
-        const size_t smem = gm_smem((int)tn, maxt);
-        int rc;
-        switch (maxt) {
-        case 1: rc = gm_launch<1>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
-        case 2: rc = gm_launch<2>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
-        case 3: rc = gm_launch<3>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
-        case 4: rc = gm_launch<4>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
-        case 6: rc = gm_launch<6>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
-        default: rc = gm_launch<8>(wgs, smem, Wt_tiled, rows, cols, xp, tn, bias_f16, yp, s); break;
+        GmArgs P; memset(&P, 0, sizeof(P));
+        P.W[0] = (const uint8_t *)Wt_tiled; P.rows[0] = (int)rows; P.nsets = 1; P.nblk = (int)(cols / 32);
+        P.T = (int)std::min<size_t>(8, tokens - t0);
+        P.X = (const half_t *)x_f16 + t0 * cols; P.ldx = (int)cols;
+        P.bias[0] = (const half_t *)bias_f16;
+        P.Y = (half_t *)y_f16 + t0 * rows; P.ldy = (int)rows;
+        if (P.T == 1) {                          // (a single left-over row: pair it with the previous one)
+            P.T = 2; P.X -= cols; P.Y -= rows;
         }
+        int rc = gemm_rows_mfma_launch(P, GM_PLAIN, 0, s);
         if (rc) return rc;
     }
     return IFA_OK;
@@ -308,17 +438,17 @@ int gemm_rows_mfma_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, c
 {
     if (!gemm_rows_mfma_ok(rows, cols, 2)) return ifa_fail(IFA_ERR_STATE, "grouped rows GEMM: %zu x %zu", rows, cols);
     if (max_groups <= 0) return IFA_OK;
+    if (max_rows > 8) return ifa_fail(IFA_ERR_ARG, "grouped rows GEMM: groups of up to %d rows (limit 8)", max_rows);
     int wgs, maxt;
     gm_geometry(rows, std::max(32, 2 * gm_num_cus() / max_groups), &wgs, &maxt);     // the experts share the chip
-    if (max_rows > 8) return ifa_fail(IFA_ERR_ARG, "grouped rows GEMM: groups of up to %d rows (limit 8)", max_rows);
-    const size_t smem = gm_smem(8, maxt);
+    const size_t smem = gm_smem(8, maxt, 1);
     switch (maxt) {
-    case 1: return gm_launch_grouped<1>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
-    case 2: return gm_launch_grouped<2>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
-    case 3: return gm_launch_grouped<3>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
-    case 4: return gm_launch_grouped<4>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
-    case 6: return gm_launch_grouped<6>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
-    default: return gm_launch_grouped<8>(wgs, max_groups, max_rows, smem, grp, rows, cols, X, Y, s);
+    case 1: return gm_launch_grouped<1>(wgs, max_groups, smem, grp, rows, cols, X, Y, s);
+    case 2: return gm_launch_grouped<2>(wgs, max_groups, smem, grp, rows, cols, X, Y, s);
+    case 3: return gm_launch_grouped<3>(wgs, max_groups, smem, grp, rows, cols, X, Y, s);
+    case 4: return gm_launch_grouped<4>(wgs, max_groups, smem, grp, rows, cols, X, Y, s);
+    case 6: return gm_launch_grouped<6>(wgs, max_groups, smem, grp, rows, cols, X, Y, s);
+    default: return gm_launch_grouped<8>(wgs, max_groups, smem, grp, rows, cols, X, Y, s);
     }
 }
 

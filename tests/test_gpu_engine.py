@@ -399,3 +399,41 @@ def test_dynamic_batching_rows_are_independent_queries(kvd):
     A, B = g.host(lg), g.host(lgp)
     assert np.array_equal(A[0], B[1]) and np.array_equal(A[1], B[2]) and np.array_equal(A[2], B[0])
     wk.close()
+
+
+@pytest.mark.parametrize("n", [2, 5, 8])
+@pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["kvf16", "kvq8"])
+def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, n):
+    """The batched decode step as five launches per layer (norm prologue + wq|wk|wv, batched k_dec_attn, wo + residual,
+    norm + w1/w3 + GLU, w2 + residual: ifa_gemm_rows_mfma.hip, batch_fused_layer) against the op-by-op rows of the same
+    library (same GEMM arithmetic; the attention kernels differ in summation order) and against its own graph replay."""
+    wk, host, s = synth.build("test_mha", dt.Q4_B32T1A, kvd, max_ctx=48, quant_threshold=0, std=0.06, keep_host=True)
+    V = s["vocab"]
+    wk.kv_slots(2 * n)
+    rng = np.random.default_rng(5 + n)
+    prompts = [rng.integers(3, V, 3 + (i * 5) % 11).astype(np.int32) for i in range(n)]
+    cur, pos = [], []
+    for i, pr in enumerate(prompts):
+        wk.select_kv(i); t = wk.forward(pr, 0)
+        wk.select_kv(n + i); assert wk.forward(pr, 0) == t
+        cur.append(t); pos.append(len(pr))
+    lgf = torch.empty((n, V), dtype=torch.float16, device="cuda")
+    lgu = torch.empty((n, V), dtype=torch.float16, device="cuda")
+    for step in range(4):
+        wk.set_option("batch_fused", 1)
+        tf = wk.decode_batch(cur, pos, list(range(n)), lgf)                 # eager (logits requested)
+        wk.set_option("batch_fused", 0)
+        tu = wk.decode_batch(cur, pos, list(range(n, 2 * n)), lgu)          # op-by-op rows on the copies of the caches
+        a, b = g.host(lgf).astype(np.float32), g.host(lgu).astype(np.float32)
+        cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+        assert cos >= 0.9999 and np.abs(a - b).max() <= 0.02, (step, cos, np.abs(a - b).max())
+        wk.set_option("batch_fused", 1)
+        tg = wk.decode_batch(cur, pos, list(range(n)))                      # graph replay of the same step: idempotent on the caches
+        assert [int(t) for t in tg] == [int(t) for t in tf], step
+        gaps = np.sort(a, axis=1)
+        for i in range(n):
+            if gaps[i, -1] - gaps[i, -2] > LOGIT_TOL:
+                assert int(tf[i]) == int(tu[i]), (step, i)
+        cur = [int(t) for t in tf]
+        pos = [p + 1 for p in pos]
+    wk.close()

@@ -45,8 +45,10 @@ def _run_against_oracle(tmp_path, devices, force, wd_name="Q4", wd=dt.Q4_B32T1A,
         row = eng.last_logits(qid)
         cos, mad = _close(row[0], l_or[0])
         # decode steps on a Q4 model: one activation code flipping at a rounding tie moves a logit by a few 1e-2
-        # (tests/test_gpu_engine.py uses the same relative term for quantised decode logits)
-        assert cos >= 0.9995 and mad <= LOGIT_TOL + 0.01 * float(np.abs(l_or[0].astype(np.float32)).max()), (step, cos, mad)
+        # (tests/test_gpu_engine.py uses the same relative term for quantised decode logits); with a Q8 KV cache the
+        # cached rows of the whole prompt carry such flips too (one code = 1/127 of its block's maximum): 1.5 % instead of 1 %
+        rel = 0.015 if kvd == dt.Q8_B32T2 else 0.01
+        assert cos >= 0.9995 and mad <= LOGIT_TOL + rel * float(np.abs(l_or[0].astype(np.float32)).max()), (step, cos, mad)
         lo = l_or[0].astype(np.float32).copy(); lo[0] = -np.inf
         top2 = np.sort(lo)[-2:]
         if top2[1] - top2[0] > LOGIT_TOL:
