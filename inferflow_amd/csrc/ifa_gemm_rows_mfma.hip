@@ -77,8 +77,11 @@ __device__ __forceinline__ GmTile gm_locate(const GmSets &S, int vt)
 template <int MAXT, int TX, int EPI, int NORM>
 __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 {
-    constexpr int NM = EPI == GM_GLU ? 2 : 1;
-    constexpr int PD = NM == 2 ? 2 : 3;              // groups (GLU: pairs of groups) in flight per wave
+    // GM_GLU: a workgroup's tiles come in PAIRS -- `it` even: tile (it / 2) of w1, odd: the same tile of w3 -- so the gated
+    // product keeps the plain kernel's registers and prefetch depth (MAXT counts both; the epilogue pairs the accumulators)
+    constexpr bool GLU = EPI == GM_GLU;
+    static_assert(!GLU || MAXT % 2 == 0, "GM_GLU: tiles per workgroup come in pairs");
+    constexpr int PD = 3;                             // groups in flight per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -105,23 +108,21 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 
     // a group = this wave's 16 rows x 16 blocks of (tile, chunk): blocks blk0 .. blk0 + 15, blk0 = 128 chunk + 16 wave
     // valid == false (past the last group): all lanes re-read the first bytes of the matrix -- one cache line, no branch
-    auto fetch = [&](GmGrp (&q)[NM], int it, int chunk, bool valid) {
-        const GmTile tl = gm_locate(S, min((int)blockIdx.x + it * (int)gridDim.x, ntiles - 1));
+    auto tile_of = [&](int it) { return GLU ? (int)blockIdx.x + (it >> 1) * (int)gridDim.x : (int)blockIdx.x + it * (int)gridDim.x; };
+    auto fetch = [&](GmGrp &q, int it, int chunk, bool valid) {
+        const GmTile tl = gm_locate(S, min(tile_of(it), ntiles - 1));
         const int blk0 = chunk * (GM_CHUNK_SUP * 4) + wave * 16;
+        const uint8_t *Wt = gm_sel(GLU && (it & 1), W1p, tl.W0);       // (by value: see gm_sel)
 #pragma unroll
-        for (int mm = 0; mm < NM; mm++) {
-            const uint8_t *Wt = mm == 0 ? tl.W0 : W1p;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {      // codes: lane l -> row 4i + l / 16, block l % 16 (256 contiguous bytes per row)
-                const int row = valid ? min(tl.row0 + 4 * i + (lane >> 4), tl.nrows - 1) : 0;
-                const int blk = valid ? min(blk0 + (lane & 15), nblk - 1) : 0;
-                q[mm].c[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)blk * 16));
-            }
-            {                                   // (base, scale): lane l -> row l / 4, blocks 4 (l % 4) .. + 3 (64 contiguous bytes per row)
-                const int row = valid ? min(tl.row0 + (lane >> 2), tl.nrows - 1) : 0;
-                const int blk = valid ? min(blk0 + 4 * (lane & 3), nblk - 4) : 0;
-                q[mm].sb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)nblk * 16 + (size_t)blk * 4));
-            }
+        for (int i = 0; i < 4; i++) {          // codes: lane l -> row 4i + l / 16, block l % 16 (256 contiguous bytes per row)
+            const int row = valid ? min(tl.row0 + 4 * i + (lane >> 4), tl.nrows - 1) : 0;
+            const int blk = valid ? min(blk0 + (lane & 15), nblk - 1) : 0;
+            q.c[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)blk * 16));
+        }
+        {                                       // (base, scale): lane l -> row l / 4, blocks 4 (l % 4) .. + 3 (64 contiguous bytes per row)
+            const int row = valid ? min(tl.row0 + (lane >> 2), tl.nrows - 1) : 0;
+            const int blk = valid ? min(blk0 + 4 * (lane & 3), nblk - 4) : 0;
+            q.sb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)nblk * 16 + (size_t)blk * 4));
         }
     };
     char *patch = smem + GM_XIMG_BYTES(TX) + (size_t)wave * GM_PATCH_BYTES;        // this wave's transposition patch
@@ -160,16 +161,14 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
         }
     };
 
-    f4m acc[NM][MAXT];
+    f4m acc[MAXT];
 #pragma unroll
-    for (int mm = 0; mm < NM; mm++)
-#pragma unroll
-        for (int i = 0; i < MAXT; i++) acc[mm][i] = f4m{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < MAXT; i++) acc[i] = f4m{0.0f, 0.0f, 0.0f, 0.0f};
     // PD groups of requests in flight per wave (a group = 4 supersteps = 5 KB per wave): one group ahead left every wave
     // waiting ~half of the time for HBM
-    GmGrp buf[PD][NM];
+    GmGrp buf[PD];
     const int nq = nchunk * MAXT;                                  // (chunk, tile) pairs in execution order: chunk outer
-    auto fetch_q = [&](GmGrp (&q)[NM], int qi) { const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, ch, qi < nq); };
+    auto fetch_q = [&](GmGrp &q, int qi) { const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, ch, qi < nq); };
     // The CU's memory pipeline is FIFO across waves (ifa_decode_kernels.h): the activation rows of the first chunk are
     // requested by all threads, and a barrier passed, BEFORE any weight request -- else they arrive behind the weights.
     // A full chunk is 512 16-byte pieces per row: piece tid of row k is thread tid's k-th request.
@@ -233,48 +232,46 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 #pragma unroll
         for (int it = 0; it < MAXT; it++) {
             const int qi = chunk * MAXT + it;
+            compute(buf[0], chunk, acc[it]);
 #pragma unroll
-            for (int mm = 0; mm < NM; mm++) compute(buf[0][mm], chunk, acc[mm][it]);
-#pragma unroll
-            for (int d = 0; d + 1 < PD; d++)
-#pragma unroll
-                for (int mm = 0; mm < NM; mm++) buf[d][mm] = buf[d + 1][mm];
+            for (int d = 0; d + 1 < PD; d++) buf[d] = buf[d + 1];
             fetch_q(buf[PD - 1], qi + PD);
         }
     }
     // ---- sum the 8 waves' partial tiles in wave order, then the epilogue: thread e of the first 256 owns element
     // (m = (l >> 4) * 4 + i, n = l & 15) of every tile, l = e >> 2, i = e & 3 (the MFMA's C layout)
     __syncthreads();                                               // the activation image is free: partials take its place
-    float *part = reinterpret_cast<float *>(smem);                 // [NM][MAXT][8 waves][256]
+    float *part = reinterpret_cast<float *>(smem);                 // [MAXT][8 waves][256]
 #pragma unroll
-    for (int mm = 0; mm < NM; mm++)
-#pragma unroll
-        for (int it = 0; it < MAXT; it++)
-            *reinterpret_cast<f4m *>(part + ((size_t)((mm * MAXT + it) * GM_WAVES + wave) * 64 + lane) * 4) = acc[mm][it];
+    for (int it = 0; it < MAXT; it++)
+        *reinterpret_cast<f4m *>(part + ((size_t)(it * GM_WAVES + wave) * 64 + lane) * 4) = acc[it];
     __syncthreads();
     if (tid < 256) {
         const int l = tid >> 2, i = tid & 3;
         const int m = (l >> 4) * 4 + i, n = l & 15;
+        auto total = [&](int it) {
+            float sum = 0.0f;
 #pragma unroll
-        for (int it = 0; it < MAXT; it++) {
-            const int vt = (int)blockIdx.x + it * (int)gridDim.x;
+            for (int w = 0; w < GM_WAVES; w++) sum = sum + part[(size_t)(it * GM_WAVES + w) * 256 + tid];
+            return sum;
+        };
+        constexpr int STEP = GLU ? 2 : 1;
+#pragma unroll
+        for (int it = 0; it < MAXT; it += STEP) {
+            const int vt = tile_of(it);
             const GmTile tl = gm_locate(S, min(vt, ntiles - 1));
             const int row = tl.row0 + m;
-            float sum[NM];
-#pragma unroll
-            for (int mm = 0; mm < NM; mm++) {
-                sum[mm] = 0.0f;
-#pragma unroll
-                for (int w = 0; w < GM_WAVES; w++) sum[mm] = sum[mm] + part[(size_t)((mm * MAXT + it) * GM_WAVES + w) * 256 + tid];
-            }
+            const float s0 = total(it);
+            float s1 = 0.0f;
+            if constexpr (GLU) s1 = total(it + 1);
             if (vt < ntiles && row < tl.nrows && n < T) {
-                half_t y = f2h(sum[0]);
+                half_t y = f2h(s0);
                 if (tl.b0) y = f2h(h2f(y) + h2f(tl.b0[row]));
                 const size_t vrow = (size_t)tl.vrow0 + m;
                 if constexpr (EPI == GM_RESIDUAL) {
                     y = f2h(h2f(P.res[(size_t)n * P.ldres + vrow]) + h2f(y));          // TensorOpr::Add (half add)
-                } else if constexpr (EPI == GM_GLU) {
-                    half_t y3 = f2h(sum[NM - 1]);
+                } else if constexpr (GLU) {
+                    half_t y3 = f2h(s1);
                     if (P.bias1) y3 = f2h(h2f(y3) + h2f(P.bias1[row]));
                     const half_t act = f2h(act_fn(h2f(y), P.act_kind));                // TensorOpr::Activation -> F16
                     y = f2h(h2f(act) * h2f(y3));                                       // TensorOpr::Mul
@@ -322,10 +319,10 @@ static int gm_num_cus()
 }
 
 static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : 8); }
-static size_t gm_smem(int T, int maxt, int nm)
+static size_t gm_smem(int T, int maxt)
 {
     const size_t ximg = GM_XIMG_BYTES(gm_tx(T)) + (size_t)GM_WAVES * GM_PATCH_BYTES + 8 * GM_WAVES * 4;      // + the norm's group sums
-    const size_t parts = (size_t)nm * maxt * GM_WAVES * 256 * 4;
+    const size_t parts = (size_t)maxt * GM_WAVES * 256 * 4;
     return std::max(ximg, parts);
 }
 
@@ -362,7 +359,7 @@ static int gm_launch2(int wgs, size_t smem, const GmArgs &P, int epi, int norm, 
     if (epi == GM_PLAIN && norm == 0) return gm_launch4<MT, TX, GM_PLAIN, 0>(wgs, smem, P, s);
     if (epi == GM_PLAIN && norm == 1) return gm_launch4<MT, TX, GM_PLAIN, 1>(wgs, smem, P, s);
     if (epi == GM_RESIDUAL && norm == 0) return gm_launch4<MT, TX, GM_RESIDUAL, 0>(wgs, smem, P, s);
-    if (epi == GM_GLU && norm == 1) return gm_launch4<MT, TX, GM_GLU, 1>(wgs, smem, P, s);
+    if constexpr (MT % 2 == 0) { if (epi == GM_GLU && norm == 1) return gm_launch4<MT, TX, GM_GLU, 1>(wgs, smem, P, s); }
     return ifa_fail(IFA_ERR_ARG, "rows GEMM: no kernel for epilogue %d / norm %d", epi, norm);
 }
 
@@ -391,7 +388,11 @@ int gemm_rows_mfma_launch(const GmArgs &P0, int epi, int norm, hipStream_t s)
     if (!gemm_rows_mfma_fused_ok(P, epi, norm)) return ifa_fail(IFA_ERR_ARG, "rows GEMM: shape not covered (T %d, %d blocks, %d sets)", P.T, P.nblk, P.nsets);
     int wgs, maxt;
     gm_geometry((size_t)P.total_rows, gm_num_cus(), &wgs, &maxt);
-    const size_t smem = gm_smem(P.T, maxt, epi == GM_GLU ? 2 : 1);
+    if (epi == GM_GLU) {                       // pairs of tiles: 1, 2, 3, 4 pairs per workgroup
+        if (maxt > 4) { maxt = 4; wgs = ((P.total_rows + 15) / 16 + 3) / 4; }
+        maxt = maxt == 3 ? 6 : maxt * 2;
+    }
+    const size_t smem = gm_smem(P.T, maxt);
     switch (maxt) {
     case 1: return gm_launch1<1>(wgs, smem, P, epi, norm, s);
     case 2: return gm_launch1<2>(wgs, smem, P, epi, norm, s);
@@ -441,7 +442,7 @@ int gemm_rows_mfma_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, c
     if (max_rows > 8) return ifa_fail(IFA_ERR_ARG, "grouped rows GEMM: groups of up to %d rows (limit 8)", max_rows);
     int wgs, maxt;
     gm_geometry(rows, std::max(32, 2 * gm_num_cus() / max_groups), &wgs, &maxt);     // the experts share the chip
-    const size_t smem = gm_smem(8, maxt, 1);
+    const size_t smem = gm_smem(8, maxt);
     switch (maxt) {
     case 1: return gm_launch_grouped<1>(wgs, max_groups, smem, grp, rows, cols, X, Y, s);
     case 2: return gm_launch_grouped<2>(wgs, max_groups, smem, grp, rows, cols, X, Y, s);
