@@ -96,7 +96,7 @@ struct ifa_model {
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr};
-    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1;
+    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -507,9 +507,8 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
 // Device-side counterpart of the host routing in moe_ffn (HostTensorOpr::BuildRowsForMoE, host_tensor_opr.cc:190-244):
 // top-k by repeated first-maximum, probabilities below 1e-5 dropped, optional renormalisation, experts then visited in
 // ascending id order.  Unused slots get weight 0 (hfma(y, 0, acc) == acc).  One thread: E <= 64, k <= 8.
-__global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k, int norm, int *__restrict__ sel, half_t *__restrict__ wout)
+__device__ __forceinline__ void moe_topk_one(const half_t *__restrict__ probs_h, int E, int top_k, int norm, int *__restrict__ sel, half_t *__restrict__ wout)
 {
-    if (threadIdx.x != 0) return;
     float probs[64]; int idx[8]; float w[8]; bool used[64];
     for (int e = 0; e < E; e++) { probs[e] = h2f(probs_h[e]); used[e] = false; }
     int n = 0;
@@ -531,6 +530,151 @@ __global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k,
         for (int j = 0; j < n; j++)
             if (idx[j] == e) { sel[slot] = e; wout[slot] = f2h(w[j]); slot++; }
     for (; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
+}
+
+__global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k, int norm, int *__restrict__ sel, half_t *__restrict__ wout)
+{
+    if (threadIdx.x != 0) return;
+    moe_topk_one(probs_h, E, top_k, norm, sel, wout);
+}
+
+// The router of a fused decode step in ONE launch (one workgroup of 8 waves): RMS norm of the layer's FFN input, the F16
+// gate GEMV, softmax, top-k -- each with the arithmetic of the kernel it replaces (k_layernorm<0>: canonical RMS order;
+// k_gemv_f16w: lane l takes chunks l, l + 64, ... as one fp32 fma chain, then the wave butterfly; k_softmax: 32-lane
+// max / sum trees, half-rounded exponentials; k_moe_topk), so the routing is bit-identical to the four-launch sequence.
+// The normalised input is also written out (hn) for parity checks.  cols % 8 == 0, cols <= 16384, E <= 64.
+__global__ void __launch_bounds__(512) k_dec_moe_router(const half_t *__restrict__ x, const half_t *__restrict__ nw, const half_t *__restrict__ nb,
+                                                        float multi_base, float eps, int cols, const half_t *__restrict__ gate_w, int E, int top_k,
+                                                        int norm_topk, half_t *__restrict__ hn_out, half_t *__restrict__ probs_out,
+                                                        int *__restrict__ sel, half_t *__restrict__ wout)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t *xs = reinterpret_cast<half_t *>(smem);                                                    // [cols]
+    float *part = reinterpret_cast<float *>(smem + (((size_t)cols * 2 + 15) & ~(size_t)15));         // [64] group sums
+    half_t *probs = reinterpret_cast<half_t *>(part + 64);                                            // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunks = cols >> 3;
+    // the first gate row of every wave does not depend on the input: requested now (clamped, unconditional)
+    u32x4 w_first[8];
+    {
+        const u32x4 *wrow = reinterpret_cast<const u32x4 *>(gate_w + (size_t)min(wave, E - 1) * cols);
+#pragma unroll
+        for (int j = 0; j < 8; j++) w_first[j] = wrow[min(lane + 64 * j, chunks - 1)];
+    }
+    // ---- RMS norm (or a plain copy when the layer has no FFN norm: nw == nullptr and eps < 0)
+    const bool do_norm = eps >= 0.0f;
+    for (int k = 0; k * 512 < chunks; k++) {
+        const int c = tid + k * 512;
+        rms_h8 v8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v8[e] = (half_t)0;
+        if (c < chunks) { v8 = *reinterpret_cast<const rms_h8 *>(x + (size_t)c * 8); *reinterpret_cast<rms_h8 *>(xs + (size_t)c * 8) = v8; }
+        const float pg = wave_sum(rms_chunk_sq(v8));
+        if (lane == 0) part[wave + k * 8] = pg;
+    }
+    __syncthreads();
+    if (do_norm) {
+        const float scale = rms_scale_of(rms_total(part, (chunks + 63) >> 6), cols, eps);
+        for (int c = tid; c < chunks; c += 512) {
+            const rms_h8 v8 = *reinterpret_cast<const rms_h8 *>(xs + (size_t)c * 8);
+            rms_h8 w8 = v8, b8 = v8;           // (one 16-byte request each: element-wise 2-byte loads behind branches took ~12 us)
+            if (nw) w8 = *reinterpret_cast<const rms_h8 *>(nw + (size_t)c * 8);
+            if (nb) b8 = *reinterpret_cast<const rms_h8 *>(nb + (size_t)c * 8);
+            rms_h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const half_t we = w8[e], be = b8[e];
+                o[e] = f2h(rms_apply((float)v8[e], scale, nw ? &we : nullptr, nb ? &be : nullptr, multi_base));
+            }
+            *reinterpret_cast<rms_h8 *>(xs + (size_t)c * 8) = o;
+            if (hn_out) *reinterpret_cast<rms_h8 *>(hn_out + (size_t)c * 8) = o;
+        }
+        __syncthreads();
+    }
+    // ---- gate GEMV: a wave per expert row, eight 16-byte requests in flight per lane (wave w's first expert row was
+    // requested at the top of the kernel, before the norm)
+    for (int e = wave; e < E; e += 8) {
+        const u32x4 *wrow = reinterpret_cast<const u32x4 *>(gate_w + (size_t)e * cols);
+        const u32x4 *xv = reinterpret_cast<const u32x4 *>(xs);
+        float acc = 0.0f;
+        for (int c0 = lane; c0 < chunks; c0 += 512) {
+            u32x4 wr[8];
+            if (e == wave && c0 == lane) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) wr[j] = w_first[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) wr[j] = wrow[min(c0 + 64 * j, chunks - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (c0 + 64 * j < chunks) acc = dot8_f16(wr[j], xv[c0 + 64 * j], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) probs[e] = f2h(acc);
+    }
+    __syncthreads();
+    // ---- softmax over the E gate values (k_softmax with one row, scale 1, no mask) and the top-k, by the first 32 lanes
+    if (tid < 32) {
+        float mx = -INFINITY;
+        for (int xi = tid; xi < E; xi += 32) mx = fmaxf(mx, 1.0f * h2f(probs[xi]));
+#pragma unroll
+        for (int mk = 16; mk > 0; mk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, mk, 32));
+        float sum = 0.0f;
+        for (int xi = tid; xi < E; xi += 32) {
+            const float v = 1.0f * h2f(probs[xi]);
+            const float ex = expf(v - mx);
+            sum = sum + ex;
+            probs[xi] = f2h(ex);
+        }
+#pragma unroll
+        for (int mk = 16; mk > 0; mk >>= 1) sum = sum + __shfl_xor(sum, mk, 32);
+        const float inv = 1.0f / sum;
+        for (int xi = tid; xi < E; xi += 32) { const half_t pr = f2h(h2f(probs[xi]) * inv); probs[xi] = pr; if (probs_out) probs_out[xi] = pr; }
+    }
+    __syncthreads();
+    // ---- top-k by wave 0, lane e = expert e (k_moe_topk's rules: repeated first maximum, probabilities below 1e-5 dropped,
+    // optional renormalisation in pick order, kept experts in ascending id, unused slots expert 0 / weight 0).  The
+    // one-thread form walks local arrays that live in scratch: ~20 us of dependent scratch loads per layer.
+    if (wave == 0) {
+        const float p = lane < E ? h2f(probs[lane]) : -INFINITY;
+        bool used = lane >= E;
+        int idx[8]; float w[8];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { idx[k] = 0x7FFFFFFF; w[k] = 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k >= top_k || k >= E) break;
+            const float mx = wave_max(used ? -INFINITY : p);
+            const unsigned long long cand = __ballot(!used && p == mx);
+            if (!cand) break;
+            const int best = __ffsll((long long)cand) - 1;
+            if (lane == best) used = true;
+            const float pb = __shfl(p, best);
+            if (pb < 0.00001f) continue;
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (j == n) { idx[j] = best; w[j] = pb; }
+            n++;
+        }
+        if (norm_topk && n > 0) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (j < n) sum = sum + w[j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (j < n) w[j] = w[j] / sum;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (j >= n) continue;
+                int rank = 0;
+#pragma unroll
+                for (int j2 = 0; j2 < 8; j2++) rank += (j2 < n && idx[j2] < idx[j]) ? 1 : 0;
+                sel[rank] = idx[j]; wout[rank] = f2h(w[j]);
+            }
+            for (int slot = n; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
+        }
+    }
 }
 
 extern "C" int ifa_add_layernorm(int kind, const void *a, const void *addend, size_t rows, size_t cols, const void *w, const void *b,
@@ -565,9 +709,20 @@ static int launch_moe_router(ifa_model *m, int l)
     Layer &L = m->layers[(size_t)l];
     int rc;
     Tensor none;
+    const Tensor &gw = L.t[T_MOE_GATE];
+    if (m->opt_moe_router_fused && c.norm_kind == 0 && gw.dtype == F16 && c.dim % 8 == 0 && c.dim <= 16384 && c.experts <= 64 && (int)gw.cols == c.dim) {
+        const bool has_norm = L.t[T_FFN_NORM].present();
+        const size_t smem = (((size_t)c.dim * 2 + 15) & ~(size_t)15) + 64 * 4 + 64 * 2;
+        k_dec_moe_router<<<1, 512, smem, m->stream>>>(m->a, has_norm ? (const half_t *)L.t[T_FFN_NORM].data : nullptr,
+                                                      has_norm ? (const half_t *)L.t[T_FFN_NORM_B].data : nullptr, c.ffn_norm_base, has_norm ? c.eps : -1.0f,
+                                                      c.dim, (const half_t *)gw.data, c.experts, c.moe_top_k, c.moe_norm_topk, m->hn, m->moe_gate, m->moe_route,
+                                                      reinterpret_cast<half_t *>(reinterpret_cast<char *>(m->moe_route) + 32));
+        IFA_LAUNCH_CHECK();
+        return IFA_OK;
+    }
     const half_t *ff_n = m->a;
     if (L.t[T_FFN_NORM].present()) {
-        if ((rc = norm_rows(m, m->a, 1, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn))) return rc;
+        if ((rc = norm_rows(m, m->a, 1, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
         ff_n = m->hn;
     }
     if ((rc = matmul(m, ff_n, 1, L.t[T_MOE_GATE], none, m->moe_gate))) return rc;
@@ -1716,7 +1871,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
