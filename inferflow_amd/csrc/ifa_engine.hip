@@ -1122,7 +1122,8 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     MoeGroup g;
     g.tiles = (const MoeTile *)m->moe_tiles; g.singles = (const MoeSingle *)m->moe_singles; g.counts = m->moe_counts;
     g.wtab = (const uint8_t *const *)L.moe_table_aos; g.on = 1;
-    const int max_tiles = cap / tile_rows + E, max_singles = std::min(E, cap);
+    // (T <= small_max: no expert can collect more rows than the small groups take -- the tile list is empty, its launches are skipped)
+    const int max_tiles = (small_max > 0 && T <= small_max) ? 0 : cap / tile_rows + E, max_singles = std::min(E, cap);
     // single-row experts take the quantised row (TensorOpr::Quantize in front of Gemv_AX, inference_worker.cc:1772-1774)
     if ((rc = ifa_quantize_act_q8(m->moe_gin, (size_t)cap, D, m->moe_xq_in, s))) return rc;
     g.which = 0;
@@ -1339,7 +1340,7 @@ static bool batch_fused_ok(const ifa_model *m, int n)
 {
     const ifa_model_config &c = m->cfg;
     if (!m->opt_batch_fused || !m->opt_gemm_rows || !gemm_rows_use_mfma() || n < 2 || n > 8 || m->topo) return false;
-    if (c.experts > 0 || c.norm_kind != 0 || c.parallel_attn || c.share_input) return false;
+    if (c.norm_kind != 0 || c.parallel_attn || c.share_input) return false;
     if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) return false;
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
     if (D % 128 || QD % 128 || F % 128 || D > 4096 || KVD % 16 || D % 16 || F % 16) return false;
@@ -1347,8 +1348,13 @@ static bool batch_fused_ok(const ifa_model *m, int n)
     if (c.kv_dtype == Q8_B32T2 && c.head_dim % 32 != 0) return false;
     if (dec_attn_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT) return false;
     for (const Layer &L : m->layers) {
+        const bool moe = c.experts > 0 && L.t[T_MOE_GATE].present();      // MoE layers: the attention half is fused, the FFN runs moe_ffn
         const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
-        for (int id : ids) if (!L.t[id].present() || !L.t[id].tiled || !is_q4(L.t[id].dtype)) return false;
+        for (int id : ids) {
+            if (moe && (id == T_W1 || id == T_W3 || id == T_W2)) continue;
+            if (!L.t[id].present() || !L.t[id].tiled || !is_q4(L.t[id].dtype)) return false;
+        }
+        if (moe && !moe_device_ok(m, L)) return false;
         if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present() || L.t[T_ATTN_NORM_B].present() || L.t[T_FFN_NORM_B].present()) return false;
     }
     return true;
@@ -1403,6 +1409,13 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     P.X = m->att; P.ldx = (int)QD; P.bias[0] = (const half_t *)L.t[T_WO_B].data;
     P.Y = m->a; P.ldy = (int)D; P.res = x; P.ldres = (int)D;
     if ((rc = gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream))) return rc;
+    if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
+        // mixture of experts: norm, the device-routed expert FFNs over the n rows (moe_ffn_device), residual
+        Tensor none;
+        if ((rc = norm_rows(m, m->a, n, L.t[T_FFN_NORM], none, m->hn, c.ffn_norm_base))) return rc;
+        if ((rc = moe_ffn(m, L, m->hn, n))) return rc;
+        return ifa_add(m->f, m->a, (size_t)n * D, 0, xnext, (ifa_stream)m->stream);
+    }
     // 4. RmsNorm -> w1, w3 -> act(w1 x) * (w3 x)
     clear();
     P.W[0] = (const uint8_t *)L.t[T_W1].tiled; P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
@@ -1467,7 +1480,8 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     // (measured on Llama-2-7B Q4: the batched step is bound by the small-T GEMM kernels, ~6.7 ms with or without the
     //  graph, so replay is opt-in: set_option("batch_graph", 1))
     const bool fused = batch_fused_ok(m, n);          // five launches per layer: launch-bound without a graph, so it is replayed
-    const bool use_graph = (m->opt_batch_graph || fused) && m->opt_graph && !has_moe && !logits_out && !tp;
+    // (MoE layers of the fused step route on the device -- no host round trip -- so they are captured too)
+    const bool use_graph = (m->opt_batch_graph || fused) && m->opt_graph && (!has_moe || fused) && !logits_out && !tp;
     const int attn_ctx = use_graph ? c.max_ctx : max_ctx;     // LDS sizing of the attention kernel must not depend on the step
     if (use_graph) {
         auto it = m->batch_graphs.find(n);

@@ -63,6 +63,7 @@ struct LtApi {
     decltype(&hipblasLtDestroy) Destroy = nullptr;                                  // optional: teardown only
     decltype(&hipblasLtMatmulDescDestroy) DescDestroy = nullptr;
     decltype(&hipblasLtMatrixLayoutDestroy) LayoutDestroy = nullptr;
+    decltype(&hipblasLtMatmulPreferenceDestroy) PrefDestroy = nullptr;
 };
 
 static const LtApi &lt_api()
@@ -79,6 +80,7 @@ static const LtApi &lt_api()
         IFA_LT_SYM(PrefCreate, hipblasLtMatmulPreferenceCreate); IFA_LT_SYM(PrefSet, hipblasLtMatmulPreferenceSetAttribute);
         IFA_LT_SYM(Heuristic, hipblasLtMatmulAlgoGetHeuristic); IFA_LT_SYM(Matmul, hipblasLtMatmul);
         IFA_LT_SYM(Destroy, hipblasLtDestroy); IFA_LT_SYM(DescDestroy, hipblasLtMatmulDescDestroy); IFA_LT_SYM(LayoutDestroy, hipblasLtMatrixLayoutDestroy);
+        IFA_LT_SYM(PrefDestroy, hipblasLtMatmulPreferenceDestroy);
 #undef IFA_LT_SYM
         a.ok = a.Create && a.LayoutCreate && a.DescCreate && a.DescSet && a.PrefCreate && a.PrefSet && a.Heuristic && a.Matmul;
         return a;
@@ -153,6 +155,17 @@ int gemm_lt(int w_dtype, const void *W, size_t N, size_t K, const void *X, size_
         }
         Wh = ctx.scratch;
     }
+    // a serving workload sees many prompt lengths: the plans of a stream are capped (all dropped when the cap is reached;
+    // a plan costs a heuristic query to rebuild)
+    constexpr size_t LT_MAX_PLANS = 256;
+    if (ctx.plans.size() >= LT_MAX_PLANS && !ctx.plans.count(std::make_tuple(N, K, T))) {
+        for (auto &kv : ctx.plans) {
+            LtPlan &q = kv.second;
+            if (q.ok && api.DescDestroy) (void)api.DescDestroy(q.desc);
+            if (api.LayoutDestroy) { if (q.a) (void)api.LayoutDestroy(q.a); if (q.b) (void)api.LayoutDestroy(q.b); if (q.c) (void)api.LayoutDestroy(q.c); }
+        }
+        ctx.plans.clear();
+    }
     LtPlan &p = ctx.plans[std::make_tuple(N, K, T)];
     if (!p.desc) {
         const int32_t op_t = HIPBLAS_OP_T, op_n = HIPBLAS_OP_N;
@@ -171,6 +184,7 @@ int gemm_lt(int w_dtype, const void *W, size_t N, size_t K, const void *X, size_
             && api.Heuristic(ctx.handle, p.desc, p.a, p.b, p.c, p.c, pref, 1, res, &found) == HIPBLAS_STATUS_SUCCESS
             && found > 0 && res[0].state == HIPBLAS_STATUS_SUCCESS && res[0].workspaceSize <= LT_WORKSPACE;
         if (p.ok) { p.algo = res[0].algo; p.workspace = res[0].workspaceSize; }
+        if (pref && api.PrefDestroy) (void)api.PrefDestroy(pref);
         if (!p.desc) p.desc = reinterpret_cast<hipblasLtMatmulDesc_t>(1);      // remember the failure
     }
     if (!p.ok) return IFA_ERR_STATE;

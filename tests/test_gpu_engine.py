@@ -402,12 +402,13 @@ def test_dynamic_batching_rows_are_independent_queries(kvd):
 
 
 @pytest.mark.parametrize("n", [2, 5, 8])
-@pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["kvf16", "kvq8"])
-def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, n):
+@pytest.mark.parametrize("kvd,shape", [(dt.F16, "test_mha"), (dt.Q8_B32T2, "test_mha"), (dt.F16, "test_moe")], ids=["kvf16", "kvq8", "moe"])
+def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, shape, n):
     """The batched decode step as five launches per layer (norm prologue + wq|wk|wv, batched k_dec_attn, wo + residual,
     norm + w1/w3 + GLU, w2 + residual: ifa_gemm_rows_mfma.hip, batch_fused_layer) against the op-by-op rows of the same
-    library (same GEMM arithmetic; the attention kernels differ in summation order) and against its own graph replay."""
-    wk, host, s = synth.build("test_mha", dt.Q4_B32T1A, kvd, max_ctx=48, quant_threshold=0, std=0.06, keep_host=True)
+    library (same GEMM arithmetic; the attention kernels differ in summation order) and against its own graph replay.
+    MoE layers: the attention half fused, the expert FFNs device-routed over the rows, the whole step still one graph."""
+    wk, host, s = synth.build(shape, dt.Q4_B32T1A, kvd, max_ctx=48, quant_threshold=0, std=0.06, keep_host=True)
     V = s["vocab"]
     wk.kv_slots(2 * n)
     rng = np.random.default_rng(5 + n)
