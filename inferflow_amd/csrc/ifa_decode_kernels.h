@@ -508,12 +508,25 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     if (tr) P.trace[blockIdx.x * 8 + 0] = t_start;
 
     // MoE: the expert's matrices, looked up once (uniform scalar loads) from the router's choice
-    const uint8_t *moeW0 = nullptr, *moeW1 = nullptr;
+    // (several sets = several router slots in one launch: set i is the expert of slot moe_slot + i)
+    const uint8_t *moeW0 = nullptr, *moeW1 = nullptr, *moeW0b = nullptr, *moeW1b = nullptr, *moeW0c = nullptr, *moeW1c = nullptr;
     if constexpr (epi_is_moe(EPI)) {
         const int e = __builtin_amdgcn_readfirstlane(P.moe_sel[P.moe_slot]);
         moeW0 = P.w_table[4 * e + P.moe_tab_off];
         if constexpr (NM == 2) moeW1 = P.w_table[4 * e + P.moe_tab_off + 1];
+        moeW0b = moeW0; moeW1b = moeW1; moeW0c = moeW0; moeW1c = moeW1;
+        if (P.nsets > 1) {
+            const int e1 = __builtin_amdgcn_readfirstlane(P.moe_sel[P.moe_slot + 1]);
+            moeW0b = P.w_table[4 * e1 + P.moe_tab_off];
+            if constexpr (NM == 2) moeW1b = P.w_table[4 * e1 + P.moe_tab_off + 1];
+        }
+        if (P.nsets > 2) {
+            const int e2 = __builtin_amdgcn_readfirstlane(P.moe_sel[P.moe_slot + 2]);
+            moeW0c = P.w_table[4 * e2 + P.moe_tab_off];
+            if constexpr (NM == 2) moeW1c = P.w_table[4 * e2 + P.moe_tab_off + 1];
+        }
     }
+    auto moe_pick = [](int si, const uint8_t *a, const uint8_t *b, const uint8_t *c) { return si == 2 ? c : (si == 1 ? b : a); };
     typename Fmt::W w[NM][RW];
     auto load_rows = [&](int pass, int i0, int i1) {
         // rows past the end are not requested at all: clamped re-reads of the last row used to fill the CU's request
@@ -524,9 +537,9 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         auto one = [&](int i) {
             const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);
             const DecRow d = dec_locate(P, v);
-            const uint8_t *W0 = epi_is_moe(EPI) ? moeW0 : d.W0;
+            const uint8_t *W0 = epi_is_moe(EPI) ? moe_pick(d.si, moeW0, moeW0b, moeW0c) : d.W0;
             w[0][i].load(W0 + (size_t)d.row * row_bytes, P.nblk, lane);
-            if constexpr (NM == 2) { const uint8_t *W1 = epi_is_moe(EPI) ? moeW1 : d.W1; w[1][i].load(W1 + (size_t)d.row * row_bytes, P.nblk, lane); }
+            if constexpr (NM == 2) { const uint8_t *W1 = epi_is_moe(EPI) ? moe_pick(d.si, moeW1, moeW1b, moeW1c) : d.W1; w[1][i].load(W1 + (size_t)d.row * row_bytes, P.nblk, lane); }
         };
         if (full) {
 #pragma unroll

@@ -409,7 +409,7 @@ static void moe_params(ifa_model *m, Layer &L, DecGemvParams &P, int slot, int t
 }
 
 // moe_slot >= 0: the FFN of the expert the router put in that slot (weights through L.moe_table)
-static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_layer = nullptr)
+static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_layer = nullptr, int moe_nslots = 1)
 {
     const ifa_model_config &c = m->cfg;
     Layer &L = m->layers[(size_t)l];
@@ -420,7 +420,10 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
         const Tensor &e1 = L.experts[0], &e3 = L.experts[2];
         moe_params(m, L, P, moe_slot, 0);
         P.W0[0] = (const uint8_t *)e1.tiled; P.W1 = (const uint8_t *)e3.tiled;   // (replaced by the table lookup)
-        P.y[0] = m->t1; P.rows[0] = (int)e1.rows; P.nsets = 1;
+        // moe_nslots router slots in one launch: set i = the expert of slot moe_slot + i, its product at t1 + i * ffn
+        const int ns = std::max(1, std::min(3, moe_nslots));
+        for (int i = 0; i < ns; i++) { P.y[i] = m->t1 + (size_t)i * e1.rows; P.rows[i] = (int)e1.rows; P.W0[i] = P.W0[0]; }
+        P.nsets = ns;
         if (e3.present()) return launch_dec_gemv<EPI_MOE_GLU, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
         return launch_dec_gemv<EPI_MOE_ACT, 1>(e1.dtype, P, m->opt_rpw_ffn, m->stream);
     }
@@ -449,14 +452,14 @@ static int launch_ffn13(ifa_model *m, int l, int moe_slot = -1, const half_t *x_
 }
 
 static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullptr, int moe_slot = -1, bool moe_last = false,
-                     const half_t *residual2 = nullptr)
+                     const half_t *residual2 = nullptr, int moe_t1_slot = 0)
 {
     Layer &L = m->layers[(size_t)l];
     DecGemvParams P; memset(&P, 0, sizeof(P));
     if (moe_slot >= 0) {
         const Tensor &e2 = L.experts[1];
         moe_params(m, L, P, moe_slot, 2);
-        P.x = m->t1; P.cols = (int)e2.cols; P.eps = m->cfg.eps;
+        P.x = m->t1 + (size_t)moe_t1_slot * e2.cols; P.cols = (int)e2.cols; P.eps = m->cfg.eps;      // (the gated product of this slot)
         P.W0[0] = (const uint8_t *)e2.tiled; P.rows[0] = (int)e2.rows; P.nsets = 1;
         if (partial) {      // tensor parallel: accumulate the weighted shard products; merged and finished by the caller
             P.y[0] = partial; P.moe_acc = partial;
@@ -750,9 +753,13 @@ static int enqueue_fused_step(ifa_model *m)
         Layer &L = m->layers[(size_t)l];
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
             if ((rc = launch_moe_router(m, l))) return rc;
-            for (int k = 0; k < c.moe_top_k; k++) {
-                if ((rc = launch_ffn13(m, l, k))) return rc;
-                if ((rc = launch_w2(m, l, xnext, nullptr, k, k + 1 == c.moe_top_k))) return rc;
+            // the gated products of up to three router slots share one launch, then one W2 launch per slot (each accumulates
+            // hfma(product, w, acc) in slot order)
+            for (int k0 = 0; k0 < c.moe_top_k; k0 += 3) {
+                const int ns = std::min(3, c.moe_top_k - k0);
+                if ((rc = launch_ffn13(m, l, k0, nullptr, ns))) return rc;
+                for (int k = k0; k < k0 + ns; k++)
+                    if ((rc = launch_w2(m, l, xnext, nullptr, k, k + 1 == c.moe_top_k, nullptr, k - k0))) return rc;
             }
         } else {
             const bool extra = c.parallel_attn || c.share_input;
@@ -783,7 +790,7 @@ static int ensure_scratch(ifa_model *m, int T)
     int rc;
     if ((rc = re(m->x, T * D)) || (rc = re(m->x2, T * D)) || (rc = re(m->xn, T * D)) || (rc = re(m->hn, T * D))
         || (rc = re(m->q, T * QD)) || (rc = re(m->k, T * KVD)) || (rc = re(m->v, T * KVD)) || (rc = re(m->att, T * QD))
-        || (rc = re(m->a, T * D)) || (rc = re(m->f, T * D)) || (rc = re(m->t1, T * F)) || (rc = re(m->t2, T * F))
+        || (rc = re(m->a, T * D)) || (rc = re(m->f, T * D)) || (rc = re(m->t1, std::max<size_t>(T, 3) * F)) || (rc = re(m->t2, T * F))
         || (rc = re(m->logits, (size_t)T * c.vocab)))
         return rc;
     if (!m->dqkv) IFA_HIP_CHECK(hipMalloc((void **)&m->dqkv, (QD + 2 * KVD) * sizeof(half_t)));
