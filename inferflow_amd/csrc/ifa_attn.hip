@@ -11,6 +11,8 @@
 // q.k and P.V are accumulated in fp32 in index order (products of halfs are
 // exact in fp32), so S and O match the restated reference bit-for-bit given the
 // same P; P differs by the device expf and the softmax summation order.
+#include <map>
+#include <mutex>
 #include "ifa_host.h"
 #include "ifa_device.h"
 #include "ifa_math.h"
@@ -134,11 +136,15 @@ __host__ __device__ inline int pf_nkp(int n_keys) { return (n_keys + 31) / 32 * 
 
 __device__ unsigned long long g_attn_trace[8];     // wall_clock64 stamps of the longest tile of head 0 (tools/probes)
 
-template <int HD, bool Q8>
+// SG: the [32 x n_keys] score tile lives in a global workspace (sg_ws: [heads][tiles][32][sg_nkp] halfs) instead of the LDS
+// -- contexts past ~2300 keys, where the tile no longer fits the 160 KiB; same stages, same rounding points, the tile is
+// written once and walked three times through L2 (a fraction of the K / V traffic of the same tile)
+template <int HD, bool Q8, bool SG = false>
 __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict__ q, const uint8_t *__restrict__ kc,
                                                         const uint8_t *__restrict__ vc, int n_ctx, int q_tokens,
                                                         int prefix_len, int heads, int kv_heads, float kq_scale,
-                                                        int alibi, int alibi_base, int alibi_total, half_t *__restrict__ out)
+                                                        int alibi, int alibi_base, int alibi_total, half_t *__restrict__ out,
+                                                        half_t *__restrict__ sg_ws = nullptr, int sg_nkp = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16;          // MFMA k-steps over the head dimension
@@ -161,9 +167,9 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
     const int t_last = min(t0 + PF_QT, q_tokens) - 1;
     const int n_keys = min(n_ctx, prefix_len + t_last + 1);      // causal bound of the whole tile
     const int nkb = (n_keys + 31) / 32;
-    const int NKP = pf_nkp(n_keys);
-    half_t *S = reinterpret_cast<half_t *>(smem);                                   // [32][NKP]
-    half_t *Vt = S + (size_t)PF_QT * NKP;                                           // [HD][PF_VROW]
+    const int NKP = SG ? sg_nkp : pf_nkp(n_keys);
+    half_t *S = SG ? sg_ws + ((size_t)h * gridDim.x + tile) * PF_QT * (size_t)sg_nkp : reinterpret_cast<half_t *>(smem);     // [32][NKP]
+    half_t *Vt = SG ? reinterpret_cast<half_t *>(smem) : S + (size_t)PF_QT * NKP;   // [HD][PF_VROW]
     const float alpha = 1.0f / sqrtf((float)HD) / kq_scale;
     const float mk = alibi ? alibi_slope(h + alibi_base, alibi_total) : 0.0f;
 
@@ -344,19 +350,48 @@ using namespace ifa;
 template <int HD>
 static int launch_attention_mfma(const void *q, const void *kcache, const void *vcache, int kv_dtype, int n_ctx, int q_tokens,
                                  int prefix_len, int heads, int kv_heads, float kq_scale, int alibi, int alibi_base,
-                                 int alibi_total, void *out, size_t smem, hipStream_t s)
+                                 int alibi_total, void *out, size_t smem, hipStream_t s, half_t *sg_ws = nullptr, int sg_nkp = 0)
 {
     dim3 grid((unsigned)((q_tokens + PF_QT - 1) / PF_QT), (unsigned)heads);
-    if (kv_dtype == Q8_B32T2) {
-        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_attention_mfma<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        k_attention_mfma<HD, true><<<grid, dim3(256), smem, s>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens,
-                                                                 prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base, alibi_total, (half_t *)out);
-    } else {
-        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_attention_mfma<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        k_attention_mfma<HD, false><<<grid, dim3(256), smem, s>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens,
-                                                                  prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base, alibi_total, (half_t *)out);
-    }
+#define IFA_PFA(Q8V, SGV) { auto kern = k_attention_mfma<HD, Q8V, SGV>; \
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        kern<<<grid, dim3(256), smem, s>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens, \
+                                           prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base, alibi_total, (half_t *)out, sg_ws, sg_nkp); }
+    if (kv_dtype == Q8_B32T2) { if (sg_ws) IFA_PFA(true, true) else IFA_PFA(true, false) }
+    else { if (sg_ws) IFA_PFA(false, true) else IFA_PFA(false, false) }
+#undef IFA_PFA
     IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// workspace of the global-score-tile variant, one per (device, stream), grown on demand (growth synchronises the stream)
+namespace {
+struct SgWs { void *p = nullptr; size_t bytes = 0; };
+std::mutex g_sg_mutex;
+std::map<std::pair<int, hipStream_t>, SgWs> g_sg_ws;
+}
+namespace ifa {
+void attn_release_stream(int dev, hipStream_t s)          // called by ifa_gemm_release_stream (ifa_gemm_lt.hip)
+{
+    std::lock_guard<std::mutex> lock(g_sg_mutex);
+    auto it = g_sg_ws.find({dev, s});
+    if (it == g_sg_ws.end()) return;
+    if (it->second.p) (void)hipFree(it->second.p);
+    g_sg_ws.erase(it);
+}
+}
+static int sg_workspace(hipStream_t s, size_t bytes, half_t **out)
+{
+    int dev = 0;
+    IFA_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_sg_mutex);
+    SgWs &w = g_sg_ws[{dev, s}];
+    if (bytes > w.bytes) {
+        if (w.p) { IFA_HIP_CHECK(hipStreamSynchronize(s)); IFA_HIP_CHECK(hipFree(w.p)); w.p = nullptr; w.bytes = 0; }
+        IFA_HIP_CHECK(hipMalloc(&w.p, bytes));
+        w.bytes = bytes;
+    }
+    *out = (half_t *)w.p;
     return IFA_OK;
 }
 
@@ -408,6 +443,22 @@ extern "C" int ifa_attention(const void *q, const void *kcache, const void *vcac
         case 32: return launch_attention_mfma<32>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_mfma, hs);
         case 64: return launch_attention_mfma<64>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_mfma, hs);
         default: return launch_attention_mfma<128>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_mfma, hs);
+        }
+    }
+    if (q_tokens >= 4 && (head_dim == 32 || head_dim == 64 || head_dim == 128)) {
+        // longer contexts: the same kernel with its score tiles in a global workspace (the op-level kernel below takes 131 ms
+        // per layer for 2048 queries on 4096 keys)
+        const int nkp = pf_nkp(n_ctx);
+        const size_t tiles = (size_t)((q_tokens + PF_QT - 1) / PF_QT);
+        half_t *ws = nullptr;
+        int rc = sg_workspace(ifa_s(stream), (size_t)heads * tiles * PF_QT * (size_t)nkp * 2, &ws);
+        if (rc) return rc;
+        const size_t smem_v = (size_t)head_dim * PF_VROW * 2 + 64;
+        hipStream_t hs = ifa_s(stream);
+        switch (head_dim) {
+        case 32: return launch_attention_mfma<32>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_v, hs, ws, nkp);
+        case 64: return launch_attention_mfma<64>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_v, hs, ws, nkp);
+        default: return launch_attention_mfma<128>(q, kcache, vcache, kv_dtype, n_ctx, q_tokens, prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, out, smem_v, hs, ws, nkp);
         }
     }
     size_t smem = (((size_t)n_ctx * 2 + 15) & ~(size_t)15) + 64;

@@ -1160,17 +1160,18 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
 //   k_dec_attn_pv      (head, split): global max, the full-row sum of exp (recomputed per split: a few thousand
 //                                      expf), P_j = half(half(e_j) * 1/sum) for its keys, partial P.V in fp32
 //   k_dec_attn_combine (head)       : sum of the partial outputs in split order -> half
-constexpr int DEC_ATTN_SPLITS = 8;
+constexpr int DEC_ATTN_MAX_SPLITS = 32;      // splits per head are chosen per decode call from the context it will reach (8 / 16 / 32)
 
 struct DecAttnSplitWs {
     half_t *S;        // [heads][max_ctx]
-    float *lmax;      // [heads][DEC_ATTN_SPLITS]
-    float *opart;     // [heads][DEC_ATTN_SPLITS][head_dim]
+    float *lmax;      // [heads][nsplits]
+    float *opart;     // [heads][nsplits][head_dim]
+    int nsplits;      // <= DEC_ATTN_MAX_SPLITS
 };
 
-__device__ __forceinline__ void dec_split_range(int n_ctx, int s, int &j0, int &j1)
+__device__ __forceinline__ void dec_split_range(int n_ctx, int nsplits, int s, int &j0, int &j1)
 {
-    const int chunk = ((n_ctx + DEC_ATTN_SPLITS - 1) / DEC_ATTN_SPLITS + 63) / 64 * 64;
+    const int chunk = ((n_ctx + nsplits - 1) / nsplits + 63) / 64 * 64;
     j0 = min(s * chunk, n_ctx); j1 = min(j0 + chunk, n_ctx);
 }
 
@@ -1183,7 +1184,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     __shared__ float red[4];
     const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pos = P.state[1], n_ctx = pos + 1;
-    int j0, j1; dec_split_range(n_ctx, sidx, j0, j1);
+    int j0, j1; dec_split_range(n_ctx, ws.nsplits, sidx, j0, j1);
     const int group = P.heads / P.kv_heads, kvh = h / group;
     const bool has_new = pos >= j0 && pos < j1;             // this split owns the new token's row
     const bool writer = has_new && (h % group) == 0;
@@ -1273,7 +1274,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
-    if (tid == 0) ws.lmax[h * DEC_ATTN_SPLITS + sidx] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (tid == 0) ws.lmax[h * ws.nsplits + sidx] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 template <int HD, bool Q8>
@@ -1286,15 +1287,14 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
     half_t *Pl = reinterpret_cast<half_t *>(opart + NSPLIT * HD);    // this split's probabilities
     const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pos = P.state[1], n_ctx = pos + 1;
-    int j0, j1; dec_split_range(n_ctx, sidx, j0, j1);
+    int j0, j1; dec_split_range(n_ctx, ws.nsplits, sidx, j0, j1);
     const int group = P.heads / P.kv_heads, kvh = h / group;
     const int kv_dim = P.kv_heads * HD;
     const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
     const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
     const half_t *Sg = ws.S + (size_t)h * P.max_ctx;
     float mx = -INFINITY;
-#pragma unroll
-    for (int s2 = 0; s2 < DEC_ATTN_SPLITS; s2++) mx = fmaxf(mx, ws.lmax[h * DEC_ATTN_SPLITS + s2]);
+    for (int s2 = 0; s2 < ws.nsplits; s2++) mx = fmaxf(mx, ws.lmax[h * ws.nsplits + s2]);
     // the full-row sum, in the same order as the one-workgroup kernel (strided by 256, wave tree, 4 waves)
     float lsum = 0.0f;
     for (int j = tid; j < n_ctx; j += 256) lsum += expf(P.kq_scale * h2f(Sg[j]) - mx);
@@ -1338,7 +1338,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
     if (tid < HD) {
         float acc = opart[tid];
         for (int s2 = 1; s2 < NSPLIT; s2++) acc = acc + opart[s2 * HD + tid];
-        ws.opart[((size_t)h * DEC_ATTN_SPLITS + sidx) * HD + tid] = acc;
+        ws.opart[((size_t)h * ws.nsplits + sidx) * HD + tid] = acc;
     }
 }
 
@@ -1346,19 +1346,18 @@ template <int HD>
 __global__ void __launch_bounds__(HD) k_dec_attn_combine(const DecAttnSplitWs ws, half_t *__restrict__ out, int8_t *xq, int heads)
 {
     const int h = blockIdx.x, d = threadIdx.x;
-    const float *p = ws.opart + (size_t)h * DEC_ATTN_SPLITS * HD + d;
+    const float *p = ws.opart + (size_t)h * ws.nsplits * HD + d;
     float acc = p[0];
-#pragma unroll
-    for (int s2 = 1; s2 < DEC_ATTN_SPLITS; s2++) acc = acc + p[(size_t)s2 * HD];
+    for (int s2 = 1; s2 < ws.nsplits; s2++) acc = acc + p[(size_t)s2 * HD];
     const half_t yh = f2h(acc);
     out[(size_t)h * HD + d] = yh;
     if constexpr (HD % 32 == 0) { if (xq) dec_attn_emit_q8<HD>(xq, heads * HD, h, d, yh); }
 }
 
-__host__ __device__ inline size_t dec_attn_pv_smem(int head_dim, int max_ctx)
+__host__ __device__ inline size_t dec_attn_pv_smem(int head_dim, int max_ctx, int nsplits = 8)
 {
     const size_t nsplit = 256 / (head_dim / 8);
-    const size_t chunk = (((size_t)max_ctx + DEC_ATTN_SPLITS - 1) / DEC_ATTN_SPLITS + 63) / 64 * 64;
+    const size_t chunk = (((size_t)max_ctx + nsplits - 1) / nsplits + 63) / 64 * 64;
     return 8 * 4 + nsplit * head_dim * 4 + chunk * 2 + 16;
 }
 

@@ -95,7 +95,7 @@ struct ifa_model {
     size_t batch_tab_bytes = 0;
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
-    DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr};
+    DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr, 8};
     int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
@@ -128,6 +128,14 @@ static void drop_graphs(ifa_model *m)
     }
     for (auto &kv : m->batch_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
     m->batch_graphs.clear();
+}
+
+// keys split over workgroups past attn_split_ctx; 8 splits per head up to 2K keys, 16 up to 8K, 32 beyond (a head's K / V
+// history streams through that many CUs: 8 splits left 16K-key contexts at 2 TB/s).  The captured steps hold the choice.
+static void choose_attn_split(ifa_model *m, int reach)
+{
+    const int want = (m->opt_attn_split_ctx > 0 && reach > m->opt_attn_split_ctx) ? (reach > 8192 ? 32 : (reach > 2048 ? 16 : 8)) : 0;
+    if (want != m->attn_split) { m->attn_split = want; drop_graphs(m); }
 }
 
 static void free_tensor(Tensor &t)
@@ -213,7 +221,7 @@ static bool fused_supported(const ifa_model *m, std::string *why)
     if (c.head_dim != 32 && c.head_dim != 48 && c.head_dim != 64 && c.head_dim != 80 && c.head_dim != 96 && c.head_dim != 128)
         return fail("fused attention supports head_dim 32/48/64/80/96/128");
     if (c.kv_dtype == Q8_B32T2 && c.head_dim % 32 != 0) return fail("Q8 KV needs head_dim % 32 == 0");
-    if (dec_attn_pv_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT) return fail("max_context_len too large for the fused attention kernels' LDS (decode falls back to the op-by-op path)");
+    if (dec_attn_pv_smem(c.head_dim, c.max_ctx, DEC_ATTN_MAX_SPLITS) > IFA_LDS_LIMIT) return fail("max_context_len too large for the fused attention kernels' LDS (decode falls back to the op-by-op path)");
     if (c.dim % 32 != 0 || c.ffn % 32 != 0) return fail("dim/ffn must be multiples of 32");
     if (c.dim > 8192) return fail("fused norm prologue supports dim <= 8192");
     for (const Layer &L : m->layers) {
@@ -326,8 +334,13 @@ static int launch_attn(ifa_model *m, int l)
     // context at head_dim 128) the keys-split-over-workgroups kernels run from position 0 on (scores in global memory)
     const bool lds_split = dec_attn_smem(c.head_dim, c.max_ctx) > IFA_LDS_LIMIT;
     if (m->attn_split || lds_split) {
-        const dim3 g2((unsigned)c.heads, DEC_ATTN_SPLITS);
-        const size_t psmem = dec_attn_pv_smem(c.head_dim, c.max_ctx);
+        // splits per head: 8, or what the decode call chose for the context it will reach (attn_split = 8 / 16 / 32); when only
+        // the LDS forces the split (very large max_context_len) as many as keep a split's probabilities inside the LDS
+        int nsp = m->attn_split > 1 ? m->attn_split : 8;
+        while (nsp < DEC_ATTN_MAX_SPLITS && dec_attn_pv_smem(c.head_dim, c.max_ctx, nsp) > IFA_LDS_LIMIT) nsp *= 2;
+        m->attn_ws.nsplits = nsp;
+        const dim3 g2((unsigned)c.heads, (unsigned)nsp);
+        const size_t psmem = dec_attn_pv_smem(c.head_dim, c.max_ctx, nsp);
         if (psmem > IFA_LDS_LIMIT) return ifa_fail(IFA_ERR_ARG, "fused attention: max_context_len %d needs %zu bytes of LDS per workgroup", c.max_ctx, psmem);
 #define IFA_ATTN_S(HDV) \
     case HDV: if (A.kv_q8) { k_dec_attn_scores<HDV, true><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
@@ -1814,8 +1827,8 @@ int ifa_model_finalize(ifa_model *m)
     }
     if (!m->attn_ws.S) {
         IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.S, (size_t)c.heads * c.max_ctx * 2));
-        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.lmax, (size_t)c.heads * DEC_ATTN_SPLITS * 4));
-        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.opart, (size_t)c.heads * DEC_ATTN_SPLITS * c.head_dim * 4));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.lmax, (size_t)c.heads * DEC_ATTN_MAX_SPLITS * 4));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.opart, (size_t)c.heads * DEC_ATTN_MAX_SPLITS * c.head_dim * 4));
     }
     if (!m->state) {
         IFA_HIP_CHECK(hipMalloc((void **)&m->state, sizeof(int) * (8 + ifa_model::RING)));
@@ -1961,8 +1974,7 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     hipStream_t s = m->stream;
     // attention variant of this call: one workgroup per head, or keys split over workgroups once the context the
     // call reaches passes the threshold (the captured step is re-captured when the variant changes)
-    const int want_split = (m->opt_attn_split_ctx > 0 && start_pos + n_steps > m->opt_attn_split_ctx) ? 1 : 0;
-    if (want_split != m->attn_split) { m->attn_split = want_split; drop_graphs(m); }
+    choose_attn_split(m, start_pos + n_steps);
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
     if (m->opt_graph && !m->graph_exec) {
@@ -2351,6 +2363,7 @@ int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_tok
                 start_pos, start_pos + n_steps, m->cfg.max_ctx);
     const ifa_tp_topology &t = *topo;
     hipStream_t s = m->stream;
+    choose_attn_split(m, start_pos + n_steps);
     // the step counter restarts: the token ring of this call begins at state[8]
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));

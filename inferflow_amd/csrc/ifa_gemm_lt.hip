@@ -198,10 +198,14 @@ int gemm_lt(int w_dtype, const void *W, size_t N, size_t K, const void *X, size_
 
 } // namespace ifa
 
+namespace ifa { void attn_release_stream(int dev, hipStream_t s); }      // ifa_attn.hip: the score-tile workspace of the stream
+
 extern "C" int ifa_gemm_release_stream(ifa_stream stream)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return IFA_OK;
+    (void)hipStreamSynchronize(ifa_s(stream));
+    ifa::attn_release_stream(dev, ifa_s(stream));
     std::lock_guard<std::mutex> lock(ifa::g_lt_mutex);
     auto it = ifa::g_lt_ctx.find({dev, ifa_s(stream)});
     if (it == ifa::g_lt_ctx.end()) return IFA_OK;

@@ -290,7 +290,10 @@ def test_argmax_first_max_wins():
 # ---------------------------------------------------------------- attention
 @pytest.mark.parametrize("kv_dtype", [dt.F16, dt.Q8_B32T2], ids=["kv_f16", "kv_q8"])
 @pytest.mark.parametrize("heads,kv_heads,hd,n_ctx,qt,alibi", [
-    (8, 8, 64, 37, 1, 0), (8, 2, 128, 200, 1, 0), (4, 4, 32, 16, 16, 0), (8, 4, 64, 50, 3, 1)])
+    (8, 8, 64, 37, 1, 0), (8, 2, 128, 200, 1, 0), (4, 4, 32, 16, 16, 0), (8, 4, 64, 50, 3, 1),
+    # prefill tiles: the [32 x keys] score tile in LDS (300 keys) and, past ~2300 keys, in the global workspace (2600 keys,
+    # a chunk of 40 queries behind a 2560-token prefix)
+    (4, 2, 64, 300, 70, 0), (2, 1, 128, 2600, 40, 0), (2, 2, 64, 2500, 33, 1)])
 def test_attention(kv_dtype, heads, kv_heads, hd, n_ctx, qt, alibi):
     rng = np.random.default_rng(heads * 7 + n_ctx)
     prefix = n_ctx - qt
