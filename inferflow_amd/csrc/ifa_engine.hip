@@ -341,18 +341,21 @@ static int launch_attn(ifa_model *m, int l)
         m->attn_ws.nsplits = nsp;
         const dim3 g2((unsigned)c.heads, (unsigned)nsp);
         const size_t psmem = dec_attn_pv_smem(c.head_dim, c.max_ctx, nsp);
+        const size_t ssmem = dec_attn_scores_smem(c.head_dim, false);      // staging of 256 F16 key rows
         if (psmem > IFA_LDS_LIMIT) return ifa_fail(IFA_ERR_ARG, "fused attention: max_context_len %d needs %zu bytes of LDS per workgroup", c.max_ctx, psmem);
 #define IFA_ATTN_S(HDV) \
-    case HDV: if (A.kv_q8) { k_dec_attn_scores<HDV, true><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
+    case HDV: if (A.kv_q8) { k_dec_attn_scores<HDV, true><<<g2, dim3(256), 16, m->stream>>>(A, m->attn_ws); \
                              if (psmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_pv<HDV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmem)); \
                              k_dec_attn_pv<HDV, true><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
-              else { k_dec_attn_scores<HDV, false><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
+              else { if (ssmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_scores<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssmem)); \
+                     k_dec_attn_scores<HDV, false><<<g2, dim3(256), ssmem, m->stream>>>(A, m->attn_ws); \
                      if (psmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_pv<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmem)); \
                      k_dec_attn_pv<HDV, false><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); } \
               k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att, A.xq, c.heads); break;
         // head sizes that are not whole Q8 blocks (48, 80) exist with an F16 KV cache only
 #define IFA_ATTN_SF(HDV) \
-    case HDV: k_dec_attn_scores<HDV, false><<<g2, dim3(256), 0, m->stream>>>(A, m->attn_ws); \
+    case HDV: if (ssmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_scores<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssmem)); \
+              k_dec_attn_scores<HDV, false><<<g2, dim3(256), ssmem, m->stream>>>(A, m->attn_ws); \
               if (psmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn_pv<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmem)); \
               k_dec_attn_pv<HDV, false><<<g2, dim3(256), psmem, m->stream>>>(A, m->attn_ws); \
               k_dec_attn_combine<HDV><<<dim3((unsigned)c.heads), dim3(HDV), 0, m->stream>>>(m->attn_ws, m->att, A.xq, c.heads); break;
