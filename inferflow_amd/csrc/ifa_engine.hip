@@ -810,12 +810,12 @@ static int ensure_scratch(ifa_model *m, int T)
         || (rc = re(m->logits, (size_t)T * c.vocab)))
         return rc;
     if (!m->dqkv) IFA_HIP_CHECK(hipMalloc((void **)&m->dqkv, (QD + 2 * KVD) * sizeof(half_t)));
-    if (T <= 8 && (size_t)T > m->bqkv_rows) {
+    if (T <= 16 && (size_t)T > m->bqkv_rows) {
         if (m->bqkv) IFA_HIP_CHECK(hipFree(m->bqkv));
         if (m->brope) IFA_HIP_CHECK(hipFree(m->brope));
-        IFA_HIP_CHECK(hipMalloc((void **)&m->bqkv, 8 * (QD + 2 * KVD) * sizeof(half_t)));
-        IFA_HIP_CHECK(hipMalloc((void **)&m->brope, 8 * (size_t)c.head_dim * sizeof(float)));
-        m->bqkv_rows = 8;
+        IFA_HIP_CHECK(hipMalloc((void **)&m->bqkv, 16 * (QD + 2 * KVD) * sizeof(half_t)));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->brope, 16 * (size_t)c.head_dim * sizeof(float)));
+        m->bqkv_rows = 16;
     }
     if (c.experts > 0) {
         const size_t cap = (size_t)T * (size_t)std::max(1, c.moe_top_k);
@@ -1358,11 +1358,11 @@ static void *kv_ptr(ifa_model *m, size_t layer, int slot, bool is_v)
 
 // ---- the batched step as five launches per layer (the structure of the batch-1 step: ifa_gemm_rows_mfma.hip with the norm
 // prologue / GLU / residual epilogues, k_dec_attn<.., BATCH>): dense models with the sequential RMS wiring, every linear in
-// tiled Q4_B32T1, 2..8 queries.  Everything else takes the op-by-op rows below.
+// tiled Q4_B32T1, 2..16 queries.  Everything else takes the op-by-op rows below.
 static bool batch_fused_ok(const ifa_model *m, int n)
 {
     const ifa_model_config &c = m->cfg;
-    if (!m->opt_batch_fused || !m->opt_gemm_rows || !gemm_rows_use_mfma() || n < 2 || n > 8 || m->topo) return false;
+    if (!m->opt_batch_fused || !m->opt_gemm_rows || !gemm_rows_use_mfma() || n < 2 || n > 16 || m->topo) return false;
     if (c.norm_kind != 0 || c.parallel_attn || c.share_input) return false;
     if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) return false;
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
@@ -1395,10 +1395,15 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     clear();
     P.W[0] = (const uint8_t *)L.t[T_WQ].tiled; P.W[1] = (const uint8_t *)L.t[T_WK].tiled; P.W[2] = (const uint8_t *)L.t[T_WV].tiled;
     P.rows[0] = (int)QD; P.rows[1] = (int)KVD; P.rows[2] = (int)KVD; P.nsets = 3; P.nblk = (int)(D / 32);
-    P.X = x; P.ldx = (int)D; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.multi_base = c.attn_norm_base;
+    // (9..16 queries: the activation rows are staged in chunks of 2048 columns, so the norm runs as its own launch)
+    const bool norm_fused = n <= 8;
+    Tensor nob;
+    if (!norm_fused && (rc = norm_rows(m, x, n, L.t[T_ATTN_NORM], nob, m->xn, c.attn_norm_base))) return rc;
+    P.X = norm_fused ? x : m->xn; P.ldx = (int)D;
+    if (norm_fused) { P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.multi_base = c.attn_norm_base; }
     P.bias[0] = (const half_t *)L.t[T_WQ_B].data; P.bias[1] = (const half_t *)L.t[T_WK_B].data; P.bias[2] = (const half_t *)L.t[T_WV_B].data;
     P.Y = m->bqkv; P.ldy = (int)(QD + 2 * KVD);
-    if ((rc = gemm_rows_mfma_launch(P, GM_PLAIN, 1, m->stream))) return rc;
+    if ((rc = gemm_rows_mfma_launch(P, GM_PLAIN, norm_fused ? 1 : 0, m->stream))) return rc;
     // 2. RoPE, KV store, attention of every query on its own cache
     {
         const int rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f);
@@ -1442,10 +1447,12 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     // 4. RmsNorm -> w1, w3 -> act(w1 x) * (w3 x)
     clear();
     P.W[0] = (const uint8_t *)L.t[T_W1].tiled; P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
-    P.X = m->a; P.ldx = (int)D; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.multi_base = c.ffn_norm_base;
+    if (!norm_fused && (rc = norm_rows(m, m->a, n, L.t[T_FFN_NORM], nob, m->hn, c.ffn_norm_base))) return rc;
+    P.X = norm_fused ? m->a : m->hn; P.ldx = (int)D;
+    if (norm_fused) { P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.multi_base = c.ffn_norm_base; }
     P.bias[0] = (const half_t *)L.t[T_W1_B].data; P.bias1 = (const half_t *)L.t[T_W3_B].data;
     P.Y = m->t1; P.ldy = (int)F;
-    if ((rc = gemm_rows_mfma_launch(P, GM_GLU, 1, m->stream))) return rc;
+    if ((rc = gemm_rows_mfma_launch(P, GM_GLU, norm_fused ? 1 : 0, m->stream))) return rc;
     // 5. w2 (+ bias) + residual -> the next layer's input
     clear();
     P.W[0] = (const uint8_t *)L.t[T_W2].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(F / 32);

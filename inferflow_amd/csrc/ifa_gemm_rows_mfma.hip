@@ -37,13 +37,23 @@ typedef float f2m __attribute__((ext_vector_type(2)));
 typedef _Float16 h2m __attribute__((ext_vector_type(2)));
 
 constexpr int GM_THREADS = 512, GM_WAVES = 8;
-constexpr int GM_CHUNK_SUP = 32;                         // supersteps per LDS chunk (4096 columns): 4 per wave
-constexpr int GM_CHUNK_COLS = GM_CHUNK_SUP * 128;
-constexpr int GM_ROW_STRIDE = GM_CHUNK_COLS * 2 + 16;    // bytes per activation row in LDS
-
-struct GmGrp { u32x4 c[4]; u32x4 sb; };
-constexpr int GM_PATCH_BYTES = 16 * 272 + 16 * 80;        // per-wave transposition patch (codes + (base, scale) words)
-#define GM_XIMG_BYTES(TXV) ((size_t)(TXV) * GM_ROW_STRIDE)
+// Geometry by CS = supersteps (128 columns) per LDS chunk of the activation rows: 32 (4096 columns: up to 8 rows fit next to
+// the waves' patches) or 16 (2048 columns: up to 16 rows).  A wave's share of a chunk is BPW = CS / 2 blocks per row.
+template <int CS> struct GmGeo {
+    static constexpr int CHUNK_SUP = CS;
+    static constexpr int CHUNK_COLS = CS * 128;
+    static constexpr int ROW_STRIDE = CHUNK_COLS * 2 + 16;      // bytes per activation row in LDS (+16: conflict-free 16-byte reads)
+    static constexpr int BPW = CS * 4 / GM_WAVES;               // blocks of a chunk per wave and row: 16 or 8
+    static constexpr int NJ = BPW / 4;                          // supersteps per group
+    static constexpr int NI = BPW / 4;                          // code requests per group: 64 lanes cover 64 / BPW rows x BPW blocks
+    static constexpr int CSTRIDE = BPW * 16 + 16;               // patch: bytes per row of code blocks
+    static constexpr int SSTRIDE = BPW * 4 + 16;                // patch: bytes per row of (base, scale) words
+    static constexpr int PATCH_BYTES = 16 * CSTRIDE + 16 * SSTRIDE;
+    static constexpr int PIECES = CHUNK_COLS / 8;               // 16-byte pieces per staged row: 512 or 256
+    static constexpr int XR = GM_THREADS / PIECES;              // rows staged side by side: 1 or 2
+};
+constexpr int gm_cs(int tx) { return tx > 8 ? 16 : 32; }
+template <int NI> struct GmGrpT { u32x4 c[NI]; u32x4 sb; };
 
 struct GmTile { const uint8_t *W0; const half_t *b0; int row0, nrows, vrow0; };
 // The set of a tile is selected among SCALARS read once from the argument block (GmSets): selecting among the struct's
@@ -81,6 +91,9 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     // product keeps the plain kernel's registers and prefetch depth (MAXT counts both; the epilogue pairs the accumulators)
     constexpr bool GLU = EPI == GM_GLU;
     static_assert(!GLU || MAXT % 2 == 0, "GM_GLU: tiles per workgroup come in pairs");
+    using G = GmGeo<gm_cs(TX)>;
+    using GmGrp = GmGrpT<G::NI>;
+    static_assert(NORM == 0 || G::CHUNK_SUP == 32, "the norm prologue needs the whole row in one chunk");
     constexpr int PD = 3;                             // groups in flight per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,46 +114,49 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     const int ldx = P.ldx;
     const int K = nblk * 32;
     const int nsup = nblk >> 2;                                   // nblk % 4 == 0 (checked by the launcher)
-    const int nchunk = (nsup + GM_CHUNK_SUP - 1) / GM_CHUNK_SUP;
+    const int nchunk = (nsup + G::CHUNK_SUP - 1) / G::CHUNK_SUP;
     const int ntiles = (P.total_rows + 15) >> 4;                  // (several sets: every set is whole tiles)
     const size_t row_bytes = tiled_row_bytes(Q4_B32T1A, (size_t)nblk);
     const int trow = min(r, T - 1);                               // B operand: token of this lane (columns past T: duplicates, never stored)
 
-    // a group = this wave's 16 rows x 16 blocks of (tile, chunk): blocks blk0 .. blk0 + 15, blk0 = 128 chunk + 16 wave
+    // a group = this wave's 16 rows x BPW blocks of (tile, chunk): blocks blk0 .. blk0 + BPW - 1, blk0 = 4 CS chunk + BPW wave
     // valid == false (past the last group): all lanes re-read the first bytes of the matrix -- one cache line, no branch
     auto tile_of = [&](int it) { return GLU ? (int)blockIdx.x + (it >> 1) * (int)gridDim.x : (int)blockIdx.x + it * (int)gridDim.x; };
+    constexpr int RPI = 64 / G::BPW;               // rows per code request
+    constexpr int LPR = G::BPW / 4;                // lanes per row of (base, scale) words (4 blocks' words each)
     auto fetch = [&](GmGrp &q, int it, int chunk, bool valid) {
         const GmTile tl = gm_locate(S, min(tile_of(it), ntiles - 1));
-        const int blk0 = chunk * (GM_CHUNK_SUP * 4) + wave * 16;
+        const int blk0 = chunk * (G::CHUNK_SUP * 4) + wave * G::BPW;
         const uint8_t *Wt = gm_sel(GLU && (it & 1), W1p, tl.W0);       // (by value: see gm_sel)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {          // codes: lane l -> row 4i + l / 16, block l % 16 (256 contiguous bytes per row)
-            const int row = valid ? min(tl.row0 + 4 * i + (lane >> 4), tl.nrows - 1) : 0;
-            const int blk = valid ? min(blk0 + (lane & 15), nblk - 1) : 0;
+        for (int i = 0; i < G::NI; i++) {      // codes: lane l -> row RPI i + l / BPW, block l % BPW (BPW * 16 contiguous bytes per row)
+            const int row = valid ? min(tl.row0 + RPI * i + lane / G::BPW, tl.nrows - 1) : 0;
+            const int blk = valid ? min(blk0 + (lane % G::BPW), nblk - 1) : 0;
             q.c[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)blk * 16));
         }
-        {                                       // (base, scale): lane l -> row l / 4, blocks 4 (l % 4) .. + 3 (64 contiguous bytes per row)
-            const int row = valid ? min(tl.row0 + (lane >> 2), tl.nrows - 1) : 0;
-            const int blk = valid ? min(blk0 + 4 * (lane & 3), nblk - 4) : 0;
+        {                                       // (base, scale): 16 rows x LPR lanes, four blocks' words per lane (upper lanes: duplicates)
+            const int ls = lane & (16 * LPR - 1);
+            const int row = valid ? min(tl.row0 + ls / LPR, tl.nrows - 1) : 0;
+            const int blk = valid ? min(blk0 + 4 * (ls % LPR), nblk - 4) : 0;
             q.sb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Wt + (size_t)row * row_bytes + (size_t)nblk * 16 + (size_t)blk * 4));
         }
     };
-    char *patch = smem + GM_XIMG_BYTES(TX) + (size_t)wave * GM_PATCH_BYTES;        // this wave's transposition patch
+    char *patch = smem + (size_t)TX * G::ROW_STRIDE + (size_t)wave * G::PATCH_BYTES;        // this wave's transposition patch
     auto compute = [&](const GmGrp &q, int chunk, f4m &acc) {
-        // ---- through the patch: rows of 16 code blocks at a 272-byte stride, rows of 16 (base, scale) words at 80 bytes
-        // (both strides make the 16-row reads below conflict-free)
+        // ---- through the patch: rows of BPW code blocks and rows of BPW (base, scale) words, both at a stride that makes the
+        // 16-row reads below conflict-free
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            *reinterpret_cast<u32x4 *>(patch + (size_t)(4 * i + (lane >> 4)) * 272 + (size_t)(lane & 15) * 16) = q.c[i];
-        *reinterpret_cast<u32x4 *>(patch + 16 * 272 + (size_t)(lane >> 2) * 80 + (size_t)(lane & 3) * 16) = q.sb;
-        const int blk0 = chunk * (GM_CHUNK_SUP * 4) + wave * 16;
+        for (int i = 0; i < G::NI; i++)
+            *reinterpret_cast<u32x4 *>(patch + (size_t)(RPI * i + lane / G::BPW) * G::CSTRIDE + (size_t)(lane % G::BPW) * 16) = q.c[i];
+        if (lane < 16 * LPR) *reinterpret_cast<u32x4 *>(patch + 16 * G::CSTRIDE + (size_t)(lane / LPR) * G::SSTRIDE + (size_t)(lane % LPR) * 16) = q.sb;
+        const int blk0 = chunk * (G::CHUNK_SUP * 4) + wave * G::BPW;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < G::NJ; j++) {
             if (blk0 + 4 * j >= nblk) continue;                    // wave-uniform: past the row end (nblk % 4 == 0)
-            const u32x4 cw4 = *reinterpret_cast<const u32x4 *>(patch + (size_t)r * 272 + (size_t)(4 * j + g) * 16);
-            const uint32_t sbw = *reinterpret_cast<const uint32_t *>(patch + 16 * 272 + (size_t)r * 80 + (size_t)(4 * j + g) * 4);
+            const u32x4 cw4 = *reinterpret_cast<const u32x4 *>(patch + (size_t)r * G::CSTRIDE + (size_t)(4 * j + g) * 16);
+            const uint32_t sbw = *reinterpret_cast<const uint32_t *>(patch + 16 * G::CSTRIDE + (size_t)r * G::SSTRIDE + (size_t)(4 * j + g) * 4);
             const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale = hbits2f((uint16_t)(sbw >> 16));
-            const char *xrow = smem + (size_t)trow * GM_ROW_STRIDE + (size_t)((wave * 16 + 4 * j + g) * 32) * 2;
+            const char *xrow = smem + (size_t)trow * G::ROW_STRIDE + (size_t)((wave * G::BPW + 4 * j + g) * 32) * 2;
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
                 const uint32_t cw = cw4[s4];
@@ -172,24 +188,28 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     // The CU's memory pipeline is FIFO across waves (ifa_decode_kernels.h): the activation rows of the first chunk are
     // requested by all threads, and a barrier passed, BEFORE any weight request -- else they arrive behind the weights.
     // A full chunk is 512 16-byte pieces per row: piece tid of row k is thread tid's k-th request.
-    u32x4 xv[TX];
+    // XR rows are staged side by side: thread tid holds piece tid % PIECES of rows tid / PIECES + XR k
+    constexpr int XK = (TX + G::XR - 1) / G::XR;
+    const int xpiece = tid % G::PIECES, xsub = tid / G::PIECES;
+    u32x4 xv[XK];
     u32x4 nwv = {0, 0, 0, 0};
     auto x_request = [&](int chunk) {
-        const int c0 = chunk * GM_CHUNK_COLS;
-        const int per_row = min(GM_CHUNK_COLS, K - c0) >> 3;
+        const int c0 = chunk * G::CHUNK_COLS;
+        const int per_row = min(G::CHUNK_COLS, K - c0) >> 3;
 #pragma unroll
-        for (int k = 0; k < TX; k++)       // rows past T and pieces past the row end: clamped (duplicates), never stored
-            xv[k] = *reinterpret_cast<const u32x4 *>(Xp + (size_t)min(k, T - 1) * ldx + c0 + (size_t)min(tid, per_row - 1) * 8);
+        for (int k = 0; k < XK; k++)       // rows past T and pieces past the row end: clamped (duplicates), never stored
+            xv[k] = *reinterpret_cast<const u32x4 *>(Xp + (size_t)min(xsub + G::XR * k, T - 1) * ldx + c0 + (size_t)min(xpiece, per_row - 1) * 8);
         if constexpr (NORM == 1)
-            nwv = *reinterpret_cast<const u32x4 *>((nwp ? nwp : Xp) + (size_t)min(tid, per_row - 1) * 8);   // (no weight: a valid dummy address)
+            nwv = *reinterpret_cast<const u32x4 *>((nwp ? nwp : Xp) + (size_t)min(xpiece, per_row - 1) * 8);   // (no weight: a valid dummy address)
     };
     auto x_store = [&](int chunk) {
-        const int per_row = min(GM_CHUNK_COLS, K - chunk * GM_CHUNK_COLS) >> 3;
+        const int per_row = min(G::CHUNK_COLS, K - chunk * G::CHUNK_COLS) >> 3;
         if constexpr (NORM == 1) {
             // RMS norm of every row in the canonical order of ifa_math.h: piece c = tid is lane c % 64 of group c / 64 = wave
-            float *part = reinterpret_cast<float *>(smem + GM_XIMG_BYTES(TX) + (size_t)GM_WAVES * GM_PATCH_BYTES);     // [TX][8]
+            // (NORM variants stage one row per pass: XR == 1)
+            float *part = reinterpret_cast<float *>(smem + (size_t)TX * G::ROW_STRIDE + (size_t)GM_WAVES * G::PATCH_BYTES);     // [TX][8]
 #pragma unroll
-            for (int k = 0; k < TX; k++) {
+            for (int k = 0; k < XK; k++) {
                 rms_h8 v8 = __builtin_bit_cast(rms_h8, xv[k]);
                 if (tid >= per_row) {
 #pragma unroll
@@ -201,7 +221,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             __syncthreads();
             const rms_h8 nw8 = __builtin_bit_cast(rms_h8, nwv);
 #pragma unroll
-            for (int k = 0; k < TX; k++) {
+            for (int k = 0; k < XK; k++) {
                 const float scale = rms_scale_of(rms_total(part + k * GM_WAVES, (per_row + 63) >> 6), K, P.eps);
                 const rms_h8 v8 = __builtin_bit_cast(rms_h8, xv[k]);
                 rms_h8 o;
@@ -215,8 +235,10 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             }
         }
 #pragma unroll
-        for (int k = 0; k < TX; k++)
-            if (k < T && tid < per_row) *reinterpret_cast<u32x4 *>(smem + (size_t)k * GM_ROW_STRIDE + (size_t)tid * 16) = xv[k];
+        for (int k = 0; k < XK; k++) {
+            const int row = xsub + G::XR * k;
+            if (row < T && xpiece < per_row) *reinterpret_cast<u32x4 *>(smem + (size_t)row * G::ROW_STRIDE + (size_t)xpiece * 16) = xv[k];
+        }
     };
     x_request(0);
     __syncthreads();
@@ -318,17 +340,19 @@ static int gm_num_cus()
     return n;
 }
 
-static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : 8); }
+static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : 16)); }
 static size_t gm_smem(int T, int maxt)
 {
-    const size_t ximg = GM_XIMG_BYTES(gm_tx(T)) + (size_t)GM_WAVES * GM_PATCH_BYTES + 8 * GM_WAVES * 4;      // + the norm's group sums
+    const int tx = gm_tx(T);
+    const size_t row = tx > 8 ? GmGeo<16>::ROW_STRIDE : GmGeo<32>::ROW_STRIDE, patch = tx > 8 ? GmGeo<16>::PATCH_BYTES : GmGeo<32>::PATCH_BYTES;
+    const size_t ximg = (size_t)tx * row + (size_t)GM_WAVES * patch + 8 * GM_WAVES * 4;      // + the norm's group sums
     const size_t parts = (size_t)maxt * GM_WAVES * 256 * 4;
     return std::max(ximg, parts);
 }
 
 bool gemm_rows_mfma_ok(size_t rows, size_t cols, size_t tokens)
 {
-    return tokens >= 2 && tokens <= 16 && cols % 128 == 0 && rows > 0 && rows < (1u << 24) && cols <= 65536;      // (9..16 rows: two passes of <= 8)
+    return tokens >= 2 && tokens <= 16 && cols % 128 == 0 && rows > 0 && rows < (1u << 24) && cols <= 65536;
 }
 
 static int gm_geometry(size_t rows, int grid_cap, int *wgs, int *maxt)
@@ -357,9 +381,13 @@ template <int MT, int TX>
 static int gm_launch2(int wgs, size_t smem, const GmArgs &P, int epi, int norm, hipStream_t s)
 {
     if (epi == GM_PLAIN && norm == 0) return gm_launch4<MT, TX, GM_PLAIN, 0>(wgs, smem, P, s);
-    if (epi == GM_PLAIN && norm == 1) return gm_launch4<MT, TX, GM_PLAIN, 1>(wgs, smem, P, s);
     if (epi == GM_RESIDUAL && norm == 0) return gm_launch4<MT, TX, GM_RESIDUAL, 0>(wgs, smem, P, s);
-    if constexpr (MT % 2 == 0) { if (epi == GM_GLU && norm == 1) return gm_launch4<MT, TX, GM_GLU, 1>(wgs, smem, P, s); }
+    if constexpr (TX <= 8) {
+        if (epi == GM_PLAIN && norm == 1) return gm_launch4<MT, TX, GM_PLAIN, 1>(wgs, smem, P, s);
+        if constexpr (MT % 2 == 0) { if (epi == GM_GLU && norm == 1) return gm_launch4<MT, TX, GM_GLU, 1>(wgs, smem, P, s); }
+    } else {
+        if constexpr (MT % 2 == 0) { if (epi == GM_GLU && norm == 0) return gm_launch4<MT, TX, GM_GLU, 0>(wgs, smem, P, s); }
+    }
     return ifa_fail(IFA_ERR_ARG, "rows GEMM: no kernel for epilogue %d / norm %d", epi, norm);
 }
 
@@ -368,13 +396,14 @@ static int gm_launch1(int wgs, size_t smem, const GmArgs &P, int epi, int norm, 
 {
     if (P.T <= 2) return gm_launch2<MT, 2>(wgs, smem, P, epi, norm, s);
     if (P.T <= 4) return gm_launch2<MT, 4>(wgs, smem, P, epi, norm, s);
-    return gm_launch2<MT, 8>(wgs, smem, P, epi, norm, s);
+    if (P.T <= 8) return gm_launch2<MT, 8>(wgs, smem, P, epi, norm, s);
+    return gm_launch2<MT, 16>(wgs, smem, P, epi, norm, s);
 }
 
 bool gemm_rows_mfma_fused_ok(const GmArgs &P, int epi, int norm)
 {
-    if (P.T < 2 || P.T > 8 || P.nblk <= 0 || P.nblk % 4 != 0 || P.nsets < 1 || P.nsets > 3) return false;
-    if (norm == 1 && P.nblk * 32 > GM_CHUNK_COLS) return false;
+    if (P.T < 2 || P.T > 16 || P.nblk <= 0 || P.nblk % 4 != 0 || P.nsets < 1 || P.nsets > 3) return false;
+    if (norm == 1 && (P.nblk * 32 > GmGeo<32>::CHUNK_COLS || P.T > 8)) return false;      // the norm prologue: whole rows in one chunk, <= 8 rows
     if (epi == GM_GLU && (P.nsets != 1 || !P.W1)) return false;
     for (int i = 0; i < P.nsets; i++) if (P.rows[i] <= 0 || (P.nsets > 1 && P.rows[i] % 16 != 0)) return false;
     return true;
@@ -417,21 +446,13 @@ int gemm_rows_mfma(const void *Wt_tiled, size_t rows, size_t cols, const void *x
                    hipStream_t s)
 {
     if (!gemm_rows_mfma_ok(rows, cols, tokens)) return IFA_ERR_STATE;
-    // the LDS holds 8 activation rows of a 4096-column chunk next to the waves' patches: 9..16 rows take two passes
-    for (size_t t0 = 0; t0 < tokens; t0 += 8) {
-        GmArgs P; memset(&P, 0, sizeof(P));
-        P.W[0] = (const uint8_t *)Wt_tiled; P.rows[0] = (int)rows; P.nsets = 1; P.nblk = (int)(cols / 32);
-        P.T = (int)std::min<size_t>(8, tokens - t0);
-        P.X = (const half_t *)x_f16 + t0 * cols; P.ldx = (int)cols;
-        P.bias[0] = (const half_t *)bias_f16;
-        P.Y = (half_t *)y_f16 + t0 * rows; P.ldy = (int)rows;
-        if (P.T == 1) {                          // (a single left-over row: pair it with the previous one)
-            P.T = 2; P.X -= cols; P.Y -= rows;
-        }
-        int rc = gemm_rows_mfma_launch(P, GM_PLAIN, 0, s);
-        if (rc) return rc;
-    }
-    return IFA_OK;
+    GmArgs P; memset(&P, 0, sizeof(P));
+    P.W[0] = (const uint8_t *)Wt_tiled; P.rows[0] = (int)rows; P.nsets = 1; P.nblk = (int)(cols / 32);
+    P.T = (int)tokens;                       // 9..16 rows: activation chunks of 2048 columns (GmGeo<16>)
+    P.X = (const half_t *)x_f16; P.ldx = (int)cols;
+    P.bias[0] = (const half_t *)bias_f16;
+    P.Y = (half_t *)y_f16; P.ldy = (int)rows;
+    return gemm_rows_mfma_launch(P, GM_PLAIN, 0, s);
 }
 
 // rows / cols of ONE expert matrix; X / Y: the gathered activations / outputs of all entries; groups of 2..16 rows
