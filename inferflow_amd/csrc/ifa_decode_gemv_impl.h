@@ -47,8 +47,19 @@ constexpr int dec_rw(int epi, int norm, int nj, int nm, int th = DEC_THREADS)
         const int rw = nm == 2 ? b[nj] : a[nj];
         return th > DEC_THREADS ? (rw + 1) / 2 : rw;       // 1024 threads: 128 registers per lane, half the rows per wave
     }
+    {   // (the sweep overrides apply to whichever format's translation unit is compiled with them)
+        const int role = dec_role(epi, norm);
+        const int forced = role == 0 ? IFA_T_RW_QKV : role == 1 ? IFA_T_RW_WO : role == 2 ? IFA_T_RW_GLU : role == 3 ? IFA_T_RW_W2 : 0;
+        if (forced > 0) return forced;
+    }
+    if (DT == Q3H_B64T1) {      // sweep on Llama-2-7B Q3H + Q8 KV (configs[2]; profiles/r02_sweep_q3h.log): 544 -> ~600 tok/s
+        if (epi == EPI_GLU && nj == 1 && th > DEC_THREADS) return 3;                  // W1/W3 at 1024 threads: 16.7 -> 14.1 us
+        if ((epi == EPI_RESIDUAL || epi == EPI_PLAIN) && norm == 2 && nj == 1) return 2; // Wo without a prologue: 6.3 -> 4.6 us
+        if (epi == EPI_RESIDUAL && norm == 0 && nj == 3) return 2;                    // W2 (11008 columns): 10.4 -> 9.1 us
+    }
     int rw = 72 / (nm * nj * DecFmt<DT, 1>::DW);
-    return rw < 1 ? 1 : (rw > 6 ? 6 : rw);
+    rw = rw < 1 ? 1 : (rw > 6 ? 6 : rw);
+    return th > DEC_THREADS ? (rw + 1) / 2 : rw;           // 1024 threads: 128 registers per lane
 }
 
 // Workgroup size by kernel shape, measured on Llama-2-7B Q4: the gated W1/W3 kernel and the short Wo kernel
@@ -56,11 +67,12 @@ constexpr int dec_rw(int epi, int norm, int nj, int nm, int th = DEC_THREADS)
 template <int DT>
 constexpr int dec_threads(int epi, int norm, int nj, bool xadd)
 {
-    if (DT == Q4_B32T1A && !xadd) {
+    if (!xadd) {
         const int role = dec_role(epi, norm);
         const int forced = role == 0 ? IFA_T_TH_QKV : role == 1 ? IFA_T_TH_WO : role == 2 ? IFA_T_TH_GLU : role == 3 ? IFA_T_TH_W2 : 0;
         if (forced > 0) return forced;
     }
+    if (DT == Q3H_B64T1 && nj == 1 && !xadd && epi == EPI_GLU) return 1024;          // (see dec_rw)
     return (DT == Q4_B32T1A && nj == 2 && !xadd && (epi == EPI_GLU || (epi == EPI_RESIDUAL && norm == 0))) ? 1024 : DEC_THREADS;
 }
 

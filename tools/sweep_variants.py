@@ -30,18 +30,22 @@ DEFAULT = {
 }
 
 
+UNIT = os.environ.get("IFA_SWEEP_UNIT", "ifa_dgemv_q4b32")          # the translation unit the overrides are compiled into
+BENCH_ARGS = os.environ.get("IFA_SWEEP_BENCH_ARGS", "").split()       # e.g. "--wdtype q3h --kv-dtype q8"
+
+
 def build(variants):
     from inferflow_amd import build as b
     b.build_library()
     hipcc = b._hipcc()
     obj_dir = os.path.join(b.LIB_DIR, "obj")
-    others = [os.path.join(obj_dir, f) for f in sorted(os.listdir(obj_dir)) if f.endswith(".o") and not f.startswith("ifa_dgemv_q4b32")]
-    src = os.path.join(b.CSRC, "ifa_dgemv_q4b32.hip")
+    others = [os.path.join(obj_dir, f) for f in sorted(os.listdir(obj_dir)) if f.endswith(".o") and not f.startswith(UNIT)]
+    src = os.path.join(b.CSRC, UNIT + ".hip")
     procs = []
     for name, flags in variants.items():
         d = os.path.join(VDIR, name)
         os.makedirs(d, exist_ok=True)
-        obj = os.path.join(d, "ifa_dgemv_q4b32.o")
+        obj = os.path.join(d, UNIT + ".o")
         hdrs = [os.path.join(b.CSRC, h) for h in os.listdir(b.CSRC) if h.endswith(".h")] + [src]
         if os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in hdrs) \
                 and open(os.path.join(d, "flags.txt")).read().strip() == flags.strip():
@@ -74,7 +78,7 @@ def run(steps):
                 continue
             env = dict(os.environ, IFA_LIB=so)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "8", "--no-cpu-baseline",
-                                "--prefill-lens", ""], env=env, capture_output=True, text=True)
+                                "--prefill-lens", ""] + BENCH_ARGS, env=env, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if not line:
                 print(name, "FAILED", r.stderr[-500:])
