@@ -1465,11 +1465,7 @@ static __global__ void __launch_bounds__(1024) k_dec_argmax_advance(const half_t
     const int ne = min(max(state[3], 0), 3);
     const int e0 = ne > 0 ? state[4] : -1, e1 = ne > 1 ? state[5] : -1, e2 = ne > 2 ? state[6] : -1;
     float best = -INFINITY; int besti = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        if (i == e0 || i == e1 || i == e2) continue;
-        float f = h2f(v[i]);
-        if (f > best || (f == best && i < besti)) { best = f; besti = i; }
-    }
+    argmax_scan(v, (size_t)n, e0, e1, e2, (int)threadIdx.x, (int)blockDim.x, best, besti);
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
         float ob = __shfl_xor(best, m); int oi = __shfl_xor(besti, m);

@@ -702,6 +702,7 @@ extern "C" int ifa_rope_qk_store(void *q, void *k, const void *v, int head_dim, 
                                  int order, float partial_rotary_factor, void *kcache_rows, void *vcache_rows, size_t cache_row_elems,
                                  ifa_stream stream);
 extern "C" int ifa_activation_mul(int kind, const void *a, const void *b, size_t n, void *c, ifa_stream stream);
+extern "C" int ifa_argmax_rows(const void *logits, size_t n, size_t row_stride, size_t rows, int *out_dev, const int *excluded_dev, ifa_stream stream);
 extern "C" int ifa_gemm_rows_q4(const void *Wt_tiled, size_t rows, size_t cols, const void *x_f16, size_t tokens,
                                 const void *bias_f16, void *y_f16, ifa_stream stream);
 namespace ifa {     // ifa_moe.hip / ifa_gemm.hip / ifa_gemv.hip
@@ -1620,8 +1621,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->tp_tok, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
         return IFA_OK;
     }
-    for (int r = 0; r < n; r++)
-        if ((rc = ifa_argmax_masked(m->logits + (size_t)r * V, V, m->state + 3, m->state + 8 + r, s))) return rc;
+    if ((rc = ifa_argmax_rows(m->logits, V, V, (size_t)n, m->state + 8, m->state + 3, s))) return rc;      // one launch for the n rows
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
     return IFA_OK;
     };

@@ -105,4 +105,40 @@ __device__ __forceinline__ float act_fn(float v, int kind)
     return v > 0 ? v : 0.0f;
 }
 
+// Greedy top-1 scan of one thread over its share of n logits: (value descending, index ascending) is a total order, so the
+// scan order is free -- 16-byte requests, four in flight, instead of a 2-byte load per iteration behind a branch (32 serial
+// L2 round trips: 13 us for 32000 logits).  Excluded ids (e0..e2, -1 = none) are never candidates.
+typedef uint32_t am_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 am_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void argmax_scan(const half_t *__restrict__ v, size_t n, int e0, int e1, int e2, int tid, int nthreads,
+                                            float &best, int &besti)
+{
+    const size_t chunks = ((reinterpret_cast<uintptr_t>(v) & 15) == 0) ? (n >> 3) : 0;
+    for (size_t c0 = (size_t)tid; c0 < chunks; c0 += (size_t)4 * nthreads) {
+        am_u32x4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t cu = c0 + (size_t)u * nthreads;
+            r[u] = reinterpret_cast<const am_u32x4 *>(v)[cu < chunks ? cu : chunks - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t cu = c0 + (size_t)u * nthreads;
+            const am_h8 h = __builtin_bit_cast(am_h8, r[u]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int i = (int)(cu * 8) + e;
+                const float f = (float)h[e];
+                const bool ok = cu < chunks && i != e0 && i != e1 && i != e2;
+                if (ok && (f > best || (f == best && i < besti))) { best = f; besti = i; }
+            }
+        }
+    }
+    for (size_t i = chunks * 8 + (size_t)tid; i < n; i += (size_t)nthreads) {
+        if ((int)i == e0 || (int)i == e1 || (int)i == e2) continue;
+        const float f = h2f(v[i]);
+        if (f > best || (f == best && (int)i < besti)) { best = f; besti = (int)i; }
+    }
+}
+
 } // namespace ifa

@@ -342,18 +342,17 @@ __global__ void __launch_bounds__(256) k_scale(const half_t *a, float s, size_t 
 // greedy top-1: first maximum wins (GetSortedTopK, sampling_strategy.cc:372-386)
 // excl: optional {count (<= 3), id, id, id}: ids the queue is never offered -- the vocabulary's unk id and Invalid-type
 // tokens (sampling_strategy.cc:281-297)
-__global__ void __launch_bounds__(1024) k_argmax(const half_t *__restrict__ v, size_t n, int *__restrict__ out, const int *__restrict__ excl)
+// (a workgroup per row: blockIdx.x-th row at v + blockIdx.x * row_stride, result at out[blockIdx.x])
+__global__ void __launch_bounds__(1024) k_argmax(const half_t *__restrict__ v, size_t n, int *__restrict__ out, const int *__restrict__ excl,
+                                                 size_t row_stride = 0)
 {
     __shared__ float bv[16];
     __shared__ int bi[16];
+    v += (size_t)blockIdx.x * row_stride; out += blockIdx.x;
     const int ne = excl ? min(max(excl[0], 0), 3) : 0;
     const int e0 = ne > 0 ? excl[1] : -1, e1 = ne > 1 ? excl[2] : -1, e2 = ne > 2 ? excl[3] : -1;
     float best = -INFINITY; int besti = 0x7FFFFFFF;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-        if ((int)i == e0 || (int)i == e1 || (int)i == e2) continue;
-        float f = h2f(v[i]);
-        if (f > best || (f == best && (int)i < besti)) { best = f; besti = (int)i; }
-    }
+    argmax_scan(v, n, e0, e1, e2, (int)threadIdx.x, (int)blockDim.x, best, besti);
     if (besti == 0x7FFFFFFF) { best = -INFINITY; }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
@@ -640,6 +639,16 @@ int ifa_moe_route_topk(const void *probs_f16, size_t tokens, int experts, int to
     if (tokens == 0) return IFA_OK;
     k_moe_route_rows<<<dim3(ifa_cdiv(tokens, 4)), dim3(256), 0, ifa_s(stream)>>>((const half_t *)probs_f16, (int)tokens, experts, top_k, norm_top_k_prob,
                                                                                   sel_out_dev, (half_t *)weights_out_f16_dev);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// engine-internal: greedy top-1 of `rows` logit rows in one launch (out[r] = argmax of row r)
+int ifa_argmax_rows(const void *logits, size_t n, size_t row_stride, size_t rows, int *out_dev, const int *excluded_dev, ifa_stream stream)
+{
+    IFA_REQUIRE(logits && out_dev && n > 0, "ifa_argmax_rows: bad arguments");
+    if (rows == 0) return IFA_OK;
+    k_argmax<<<dim3((unsigned)rows), dim3(1024), 0, ifa_s(stream)>>>((const half_t *)logits, n, out_dev, excluded_dev, row_stride);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
