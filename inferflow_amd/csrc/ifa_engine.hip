@@ -913,12 +913,7 @@ __global__ void __launch_bounds__(1024) k_tp_local_best(const half_t *__restrict
     const int ne = excl ? min(max(excl[0], 0), 3) : 0;
     const int e0 = ne > 0 ? excl[1] : -1, e1 = ne > 1 ? excl[2] : -1, e2 = ne > 2 ? excl[3] : -1;
     float best = -INFINITY; int besti = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int gid = vocab_offset + i;
-        if (gid == e0 || gid == e1 || gid == e2) continue;
-        const float f = h2f(v[i]);
-        if (f > best || (f == best && gid < besti)) { best = f; besti = gid; }
-    }
+    argmax_scan(v, (size_t)n, e0, e1, e2, (int)threadIdx.x, (int)blockDim.x, best, besti, vocab_offset);
 #pragma unroll
     for (int mk = 32; mk > 0; mk >>= 1) {
         const float ob = __shfl_xor(best, mk); const int oi = __shfl_xor(besti, mk);

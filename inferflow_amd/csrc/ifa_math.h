@@ -110,8 +110,9 @@ __device__ __forceinline__ float act_fn(float v, int kind)
 // L2 round trips: 13 us for 32000 logits).  Excluded ids (e0..e2, -1 = none) are never candidates.
 typedef uint32_t am_u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 am_h8 __attribute__((ext_vector_type(8)));
+// id_offset: the global id of v[0] (a vocabulary shard); ids, exclusions and the result are global ids
 __device__ __forceinline__ void argmax_scan(const half_t *__restrict__ v, size_t n, int e0, int e1, int e2, int tid, int nthreads,
-                                            float &best, int &besti)
+                                            float &best, int &besti, int id_offset = 0)
 {
     const size_t chunks = ((reinterpret_cast<uintptr_t>(v) & 15) == 0) ? (n >> 3) : 0;
     for (size_t c0 = (size_t)tid; c0 < chunks; c0 += (size_t)4 * nthreads) {
@@ -127,7 +128,7 @@ __device__ __forceinline__ void argmax_scan(const half_t *__restrict__ v, size_t
             const am_h8 h = __builtin_bit_cast(am_h8, r[u]);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const int i = (int)(cu * 8) + e;
+                const int i = id_offset + (int)(cu * 8) + e;
                 const float f = (float)h[e];
                 const bool ok = cu < chunks && i != e0 && i != e1 && i != e2;
                 if (ok && (f > best || (f == best && i < besti))) { best = f; besti = i; }
@@ -135,9 +136,10 @@ __device__ __forceinline__ void argmax_scan(const half_t *__restrict__ v, size_t
         }
     }
     for (size_t i = chunks * 8 + (size_t)tid; i < n; i += (size_t)nthreads) {
-        if ((int)i == e0 || (int)i == e1 || (int)i == e2) continue;
+        const int gid = id_offset + (int)i;
+        if (gid == e0 || gid == e1 || gid == e2) continue;
         const float f = h2f(v[i]);
-        if (f > best || (f == best && (int)i < besti)) { best = f; besti = (int)i; }
+        if (f > best || (f == best && gid < besti)) { best = f; besti = gid; }
     }
 }
 
