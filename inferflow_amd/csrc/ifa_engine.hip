@@ -2014,6 +2014,22 @@ int ifa_model_decode_batch(ifa_model *m, int n, const int *tokens_host, const in
     IFA_REQUIRE(m && m->finalized, "ifa_model_decode_batch: model not finalized");
     IFA_REQUIRE(n >= 1 && n <= ifa_model::RING && tokens_host && positions_host && kv_slots_host, "ifa_model_decode_batch: bad arguments");
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    // more queries than the fused five-launch step takes (16): balanced chunks of <= 16, each its own step (the queries are
+    // independent; 32 queries op-by-op took 6.7 ms against 2 x 3.1 ms for two fused steps)
+    if (n > 16 && batch_fused_ok(m, 16)) {
+        for (int c0 = 0; c0 < n; c0++) if (kv_slots_host[c0] < 0) return ifa_fail(IFA_ERR_ARG, "decode_batch: KV slot %d", kv_slots_host[c0]);
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b < a; b++)
+                if (kv_slots_host[a] == kv_slots_host[b]) return ifa_fail(IFA_ERR_ARG, "decode_batch: KV slot %d used twice", kv_slots_host[a]);
+        const int k = (n + 15) / 16, per = (n + k - 1) / k;
+        for (int c0 = 0; c0 < n; c0 += per) {
+            const int nc = std::min(per, n - c0);
+            int rc = forward_batch(m, nc, tokens_host + c0, positions_host + c0, kv_slots_host + c0, next_tokens_host ? next_tokens_host + c0 : nullptr,
+                                   logits_out_dev ? (char *)logits_out_dev + (size_t)c0 * m->g[T_LM_HEAD].rows * 2 : nullptr);
+            if (rc) return rc;
+        }
+        return IFA_OK;
+    }
     return forward_batch(m, n, tokens_host, positions_host, kv_slots_host, next_tokens_host, logits_out_dev);
 }
 

@@ -9,6 +9,7 @@ wk, _, s = synth.build(shape, dt.Q4_B32T1A, dt.F16, max_ctx=256)
 NMAX = 32
 wk.kv_slots(NMAX)
 if "graph" in sys.argv: wk.set_option("batch_graph", 1)
+if os.environ.get("IFA_BATCH_FUSED") == "0": wk.set_option("batch_fused", 0)      # the op-by-op rows for comparison
 rng = np.random.default_rng(3)
 first = []
 for i in range(NMAX):
