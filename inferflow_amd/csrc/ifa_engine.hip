@@ -526,35 +526,54 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
 // Device-side counterpart of the host routing in moe_ffn (HostTensorOpr::BuildRowsForMoE, host_tensor_opr.cc:190-244):
 // top-k by repeated first-maximum, probabilities below 1e-5 dropped, optional renormalisation, experts then visited in
 // ascending id order.  Unused slots get weight 0 (hfma(y, 0, acc) == acc).  One thread: E <= 64, k <= 8.
-__device__ __forceinline__ void moe_topk_one(const half_t *__restrict__ probs_h, int E, int top_k, int norm, int *__restrict__ sel, half_t *__restrict__ wout)
+// top-k of one row by ONE wave, lane e = expert e with probability p (lanes >= E: -inf): k_moe_topk's rules -- repeated first
+// maximum, probabilities below 1e-5 dropped, optional renormalisation in pick order, kept experts in ascending id, unused
+// slots expert 0 / weight 0.  (The one-thread form walked local arrays that live in scratch: ~20 us of dependent loads.)
+__device__ __forceinline__ void moe_topk_wave(float p, int lane, int E, int top_k, int norm_topk, int *__restrict__ sel, half_t *__restrict__ wout)
 {
-    float probs[64]; int idx[8]; float w[8]; bool used[64];
-    for (int e = 0; e < E; e++) { probs[e] = h2f(probs_h[e]); used[e] = false; }
+    bool used = lane >= E;
+    int idx[8]; float w[8];
     int n = 0;
-    for (int k = 0; k < top_k && k < E; k++) {
-        int best = -1;
-        for (int e = 0; e < E; e++) if (!used[e] && (best < 0 || probs[e] > probs[best])) best = e;
-        if (best < 0) break;
-        used[best] = true;
-        if (probs[best] < 0.00001f) continue;
-        idx[n] = best; w[n] = probs[best]; n++;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { idx[k] = 0x7FFFFFFF; w[k] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= top_k || k >= E) break;
+        const float mx = wave_max(used ? -INFINITY : p);
+        const unsigned long long cand = __ballot(!used && p == mx);
+        if (!cand) break;
+        const int best = __ffsll((long long)cand) - 1;
+        if (lane == best) used = true;
+        const float pb = __shfl(p, best);
+        if (pb < 0.00001f) continue;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j == n) { idx[j] = best; w[j] = pb; }
+        n++;
     }
-    if (norm && n > 0) {
+    if (norm_topk && n > 0) {
         float sum = 0.0f;
-        for (int i2 = 0; i2 < n; i2++) sum = sum + w[i2];
-        for (int i2 = 0; i2 < n; i2++) w[i2] = w[i2] / sum;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j < n) sum = sum + w[j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j < n) w[j] = w[j] / sum;
     }
-    int slot = 0;
-    for (int e = 0; e < E; e++)
-        for (int j = 0; j < n; j++)
-            if (idx[j] == e) { sel[slot] = e; wout[slot] = f2h(w[j]); slot++; }
-    for (; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j >= n) continue;
+            int rank = 0;
+#pragma unroll
+            for (int j2 = 0; j2 < 8; j2++) rank += (j2 < n && idx[j2] < idx[j]) ? 1 : 0;
+            sel[rank] = idx[j]; wout[rank] = f2h(w[j]);
+        }
+        for (int slot = n; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
+    }
 }
 
-__global__ void k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k, int norm, int *__restrict__ sel, half_t *__restrict__ wout)
+__global__ void __launch_bounds__(64) k_moe_topk(const half_t *__restrict__ probs_h, int E, int top_k, int norm, int *__restrict__ sel, half_t *__restrict__ wout)
 {
-    if (threadIdx.x != 0) return;
-    moe_topk_one(probs_h, E, top_k, norm, sel, wout);
+    const int lane = threadIdx.x & 63;      // launched with one wave
+    moe_topk_wave(lane < E ? h2f(probs_h[lane]) : -INFINITY, lane, E, top_k, norm, sel, wout);
 }
 
 // The router of a fused decode step in ONE launch (one workgroup of 8 waves): RMS norm of the layer's FFN input, the F16
@@ -654,46 +673,7 @@ __global__ void __launch_bounds__(512) k_dec_moe_router(const half_t *__restrict
     // ---- top-k by wave 0, lane e = expert e (k_moe_topk's rules: repeated first maximum, probabilities below 1e-5 dropped,
     // optional renormalisation in pick order, kept experts in ascending id, unused slots expert 0 / weight 0).  The
     // one-thread form walks local arrays that live in scratch: ~20 us of dependent scratch loads per layer.
-    if (wave == 0) {
-        const float p = lane < E ? h2f(probs[lane]) : -INFINITY;
-        bool used = lane >= E;
-        int idx[8]; float w[8];
-        int n = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) { idx[k] = 0x7FFFFFFF; w[k] = 0.0f; }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (k >= top_k || k >= E) break;
-            const float mx = wave_max(used ? -INFINITY : p);
-            const unsigned long long cand = __ballot(!used && p == mx);
-            if (!cand) break;
-            const int best = __ffsll((long long)cand) - 1;
-            if (lane == best) used = true;
-            const float pb = __shfl(p, best);
-            if (pb < 0.00001f) continue;
-#pragma unroll
-            for (int j = 0; j < 8; j++) if (j == n) { idx[j] = best; w[j] = pb; }
-            n++;
-        }
-        if (norm_topk && n > 0) {
-            float sum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) if (j < n) sum = sum + w[j];
-#pragma unroll
-            for (int j = 0; j < 8; j++) if (j < n) w[j] = w[j] / sum;
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (j >= n) continue;
-                int rank = 0;
-#pragma unroll
-                for (int j2 = 0; j2 < 8; j2++) rank += (j2 < n && idx[j2] < idx[j]) ? 1 : 0;
-                sel[rank] = idx[j]; wout[rank] = f2h(w[j]);
-            }
-            for (int slot = n; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
-        }
-    }
+    if (wave == 0) moe_topk_wave(lane < E ? h2f(probs[lane]) : -INFINITY, lane, E, top_k, norm_topk, sel, wout);
 }
 
 extern "C" int ifa_add_layernorm(int kind, const void *a, const void *addend, size_t rows, size_t cols, const void *w, const void *b,

@@ -1,6 +1,7 @@
 // ifa_gemm_rows_mfma.hip -- Y[T][N] = X[T][K] . W[N][K]^T for 2 <= T <= 16 rows (dynamic batching of decode steps, very
 // short prompts, MoE experts with a handful of rows) on v_mfma_f32_16x16x32_f16, streaming the tiled Q4_B32T1 weights
-// ONCE at the decode GEMV's rate.
+// ONCE.  With the prologue / epilogues of the fused batched decode step (GmArgs: RMS norm while staging, wq | wk | wv as one
+// virtual row space, w1 / w3 as interleaved tile pairs with act(.) * (.), residual add) and a grouped variant for MoE experts.
 //
 // Same contract as ifa_gemm / ifa_gemm_rows_q4 (the reference's T > 1 branch: weights dequantised to half, half
 // activations, fp32 accumulation, one F16 rounding, bias as a half add: MatrixMultiplication,
@@ -9,19 +10,20 @@
 // matrix cores), and a 16 x 16 tile wastes little of them at 2..16 rows.
 //
 // Work decomposition (one workgroup of 8 waves per CU):
-//   * tile = 16 consecutive weight rows; the K range of a tile is SPLIT over the 8 waves -- wave w takes "supersteps"
-//     (128 columns = 4 blocks = one 64-byte line of codes per row) w, w + 8, ... -- so every wave of the chip has requests
-//     in flight from the first instruction (a 4096-row matrix is only 256 tiles); partial 16 x 16 tiles are summed
-//     through LDS in wave order (deterministic);
-//   * a wave's share of a tile and chunk is 16 rows x 16 blocks (512 columns).  It is REQUESTED coalesced -- 256 contiguous
-//     code bytes per row, four rows per request (+ one request for the 16 x 16 (base, scale) words) -- because 16-row x
-//     64-byte requests (each lane its own MFMA operand) ran at 2.4 TB/s against 3.5 TB/s for contiguous ones; the wave then
-//     turns the 5 KB through its own LDS patch (no barrier: one wave) into the MFMA layout: lane (r = lane % 16,
+//   * tile = 16 consecutive weight rows; the K range of a tile is SPLIT over the 8 waves -- within a chunk of the activation
+//     rows (4096 columns, or 2048 for 9..16 rows: GmGeo) wave w takes blocks BPW w .. BPW w + BPW - 1 (BPW = 16 or 8) -- so
+//     every wave of the chip has requests in flight from the first instruction (a 4096-row matrix is only 256 tiles);
+//     partial 16 x 16 tiles are summed through LDS in wave order (deterministic);
+//   * a wave's share of a tile and chunk is 16 rows x BPW blocks.  It is REQUESTED coalesced -- BPW * 16 contiguous code
+//     bytes per row, 64 / BPW rows per request (+ one request for the (base, scale) words) -- because 16-row x 64-byte
+//     requests (each lane its own MFMA operand) ran at 2.4 TB/s against 3.5 TB/s for contiguous ones; the wave then
+//     turns the group through its own LDS patch (no barrier: one wave) into the MFMA layout: lane (r = lane % 16,
 //     g = lane / 16) reads block 4s + g of row r.  The block's four 8-element quarters feed FOUR MFMAs as k-group g:
 //     MFMA q of a superstep multiplies the columns {32 (4s + g) + 8 q .. + 8 : g = 0..3} -- the B fragments are read from
 //     LDS with the same permutation, so the sum over k is the plain dot product in another (fixed) order;
-//   * the activation rows sit in LDS as F16, 4096 columns at a time (row stride + 16 B: conflict-free 16-byte reads);
-//     longer rows (w2) are walked in chunks with the accumulators kept in registers.
+//   * the activation rows sit in LDS as F16, one chunk at a time (row stride + 16 B: conflict-free 16-byte reads); longer
+//     rows (w2) are walked in chunks with the accumulators kept in registers.
+// Measurements behind these choices and what bounds the kernel now: DESIGN.md section 3 "Dynamic batching", section 8.
 #include <algorithm>
 #include <cstring>
 #include "ifa_host.h"

@@ -285,6 +285,12 @@ def test_moe_layers_match_oracle(wd, kvd):
     unfused, _ = wk.decode(tok, len(prompt), n)        # op-by-op steps with the reference's host-side routing
     assert np.array_equal(fused, unfused)
     assert np.array_equal(logits_fused, wk.read_buffer("logits"))
+    # the router as four launches (norm, gate GEMV, softmax, k_moe_topk) instead of the one-launch k_dec_moe_router: same bits
+    wk.set_option("fused", 1); wk.set_option("moe_router_fused", 0)
+    wk.reset(); wk.forward(prompt, 0)
+    four, _ = wk.decode(tok, len(prompt), n)
+    assert np.array_equal(fused, four)
+    assert np.array_equal(logits_fused, wk.read_buffer("logits"))
     wk.close()
 
 
