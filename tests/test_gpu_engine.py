@@ -407,7 +407,7 @@ def test_dynamic_batching_rows_are_independent_queries(kvd):
     wk.close()
 
 
-@pytest.mark.parametrize("n", [2, 5, 8, 11, 16])
+@pytest.mark.parametrize("n", [2, 5, 8, 11, 16, 20])
 @pytest.mark.parametrize("kvd,shape", [(dt.F16, "test_mha"), (dt.Q8_B32T2, "test_mha"), (dt.F16, "test_moe")], ids=["kvf16", "kvq8", "moe"])
 def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, shape, n):
     """The batched decode step as five launches per layer (norm prologue + wq|wk|wv, batched k_dec_attn, wo + residual,
