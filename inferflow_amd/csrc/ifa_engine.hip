@@ -1143,6 +1143,7 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, m->f, m->stream);
 }
 
+static bool batch_fused_ok(const ifa_model *m, int n);
 static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token)
 {
     const ifa_model_config &c = m->cfg;
@@ -1171,7 +1172,72 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     // prompts every one of them is a fixed ~5 us)
     const bool seq_wiring = !c.parallel_attn && !c.share_input;
     bool xn_ready = false;           // m->xn already holds the next norm's output (fused into the previous layer's last Add)
-    for (int l = 0; l < c.layers; l++) {
+    // prompts of 2..16 tokens on a dense Q4 model with the sequential RMS wiring: the linears of a layer as FOUR launches of
+    // the rows GEMM (ifa_gemm_rows_mfma.hip) -- norm prologue + wq | wk | wv into q / k / v, wo + residual, norm + w1 / w3 +
+    // GLU, w2 + residual -- instead of seven products and four element-wise launches (9..16 tokens: the norms stay launches)
+    const bool pf_fused = !tp && T >= 2 && T <= 16 && batch_fused_ok(m, T) && c.experts == 0;
+    for (int l = 0; l < c.layers && pf_fused; l++) {
+        Layer &L = m->layers[l];
+        const size_t F = c.ffn;
+        const bool norm_fused = T <= 8;
+        Tensor nob;
+        GmArgs P;
+        auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = T; P.eps = c.eps; P.act_kind = c.act_kind; };
+        clear();
+        if (!norm_fused && (rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], nob, m->xn, c.attn_norm_base))) return rc;
+        P.W[0] = (const uint8_t *)L.t[T_WQ].tiled; P.W[1] = (const uint8_t *)L.t[T_WK].tiled; P.W[2] = (const uint8_t *)L.t[T_WV].tiled;
+        P.rows[0] = (int)QD; P.rows[1] = (int)KVD; P.rows[2] = (int)KVD; P.nsets = 3; P.nblk = (int)(D / 32);
+        P.X = norm_fused ? x : m->xn; P.ldx = (int)D;
+        if (norm_fused) { P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.multi_base = c.attn_norm_base; }
+        P.bias[0] = (const half_t *)L.t[T_WQ_B].data; P.bias[1] = (const half_t *)L.t[T_WK_B].data; P.bias[2] = (const half_t *)L.t[T_WV_B].data;
+        P.Yset[0] = m->q; P.Yset[1] = m->k; P.Yset[2] = m->v; P.ldyset[0] = (int)QD; P.ldyset[1] = (int)KVD; P.ldyset[2] = (int)KVD;
+        if ((rc = gemm_rows_mfma_launch(P, GM_PLAIN, norm_fused ? 1 : 0, m->stream))) return rc;
+        uint8_t *kdst = (uint8_t *)L.kcache + (size_t)prefix_len * m->kv_row_bytes;
+        uint8_t *vdst = (uint8_t *)L.vcache + (size_t)prefix_len * m->kv_row_bytes;
+        const bool kv_f16 = c.kv_dtype != Q8_B32T2;
+        bool kv_stored = false;
+        if (c.rope_order != 0) {
+            rc = ifa_rope_qk_store(m->q, m->k, m->v, c.head_dim, c.heads, c.kv_heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary,
+                                   kv_f16 ? kdst : nullptr, kv_f16 ? vdst : nullptr, m->kv_row_bytes / 2, s);
+            if (rc == IFA_OK) kv_stored = kv_f16;
+            else if (rc != IFA_ERR_STATE) return rc;
+            else {
+                if ((rc = ifa_rope(m->q, c.head_dim, c.heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
+                if ((rc = ifa_rope(m->k, c.head_dim, c.kv_heads, T, prefix_len, c.rope_theta, c.rope_order, c.partial_rotary, s))) return rc;
+            }
+        }
+        if (!kv_f16) {
+            if ((rc = ifa_quantize_act_q8(m->k, T, KVD, kdst, s))) return rc;
+            if ((rc = ifa_quantize_act_q8(m->v, T, KVD, vdst, s))) return rc;
+        } else if (!kv_stored) {
+            IFA_HIP_CHECK(hipMemcpyAsync(kdst, m->k, (size_t)T * m->kv_row_bytes, hipMemcpyDeviceToDevice, m->stream));
+            IFA_HIP_CHECK(hipMemcpyAsync(vdst, m->v, (size_t)T * m->kv_row_bytes, hipMemcpyDeviceToDevice, m->stream));
+        }
+        if ((rc = ifa_attention(m->q, L.kcache, L.vcache, c.kv_dtype, prefix_len + T, T, prefix_len, c.heads, c.kv_heads,
+                                c.head_dim, c.use_alibi ? 1.0f : c.kq_scale, c.use_alibi, c.tp_rank * c.heads,
+                                c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
+        clear();
+        P.W[0] = (const uint8_t *)L.t[T_WO].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(QD / 32);
+        P.X = m->att; P.ldx = (int)QD; P.bias[0] = (const half_t *)L.t[T_WO_B].data;
+        P.Y = m->a; P.ldy = (int)D; P.res = x; P.ldres = (int)D;
+        if ((rc = gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream))) return rc;
+        clear();
+        if (!norm_fused && (rc = norm_rows(m, m->a, T, L.t[T_FFN_NORM], nob, m->hn, c.ffn_norm_base))) return rc;
+        P.W[0] = (const uint8_t *)L.t[T_W1].tiled; P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
+        P.X = norm_fused ? m->a : m->hn; P.ldx = (int)D;
+        if (norm_fused) { P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.multi_base = c.ffn_norm_base; }
+        P.bias[0] = (const half_t *)L.t[T_W1_B].data; P.bias1 = (const half_t *)L.t[T_W3_B].data;
+        P.Y = m->t1; P.ldy = (int)F;
+        if ((rc = gemm_rows_mfma_launch(P, GM_GLU, norm_fused ? 1 : 0, m->stream))) return rc;
+        clear();
+        P.W[0] = (const uint8_t *)L.t[T_W2].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(F / 32);
+        P.X = m->t1; P.ldx = (int)F; P.bias[0] = (const half_t *)L.t[T_W2_B].data;
+        P.Y = m->f; P.ldy = (int)D; P.res = m->a; P.ldres = (int)D;
+        if ((rc = gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream))) return rc;
+        std::swap(m->x, m->f);
+        x = m->x;
+    }
+    for (int l = pf_fused ? c.layers : 0; l < c.layers; l++) {
         Layer &L = m->layers[l];
         const half_t *attn_in = x;
         if (L.t[T_ATTN_NORM].present()) {

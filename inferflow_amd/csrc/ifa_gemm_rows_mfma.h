@@ -26,6 +26,8 @@ struct GmArgs {
     const half_t *res;             // GM_RESIDUAL: Y = half(res + y)  (TensorOpr::Add)
     int ldy, ldres;
     int act_kind;
+    half_t *Yset[3];               // optional: set i written to its own matrix Yset[i][t * ldyset[i] + row] (q, k, v of a prompt)
+    int ldyset[3];
 };
 
 // rows of 16 per set when nsets > 1, cols % 128 == 0, 2 <= T <= 8; norm == 1 needs cols <= 4096

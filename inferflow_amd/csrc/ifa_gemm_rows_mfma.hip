@@ -57,11 +57,11 @@ template <int CS> struct GmGeo {
 constexpr int gm_cs(int tx) { return tx > 8 ? 16 : 32; }
 template <int NI> struct GmGrpT { u32x4 c[NI]; u32x4 sb; };
 
-struct GmTile { const uint8_t *W0; const half_t *b0; int row0, nrows, vrow0; };
+struct GmTile { const uint8_t *W0; const half_t *b0; half_t *y; int row0, nrows, vrow0, ldy; };
 // The set of a tile is selected among SCALARS read once from the argument block (GmSets): selecting among the struct's
 // fields in place made the compiler spill the whole block to scratch and fetch the chosen field with a VGPR-indexed
 // scratch load in front of every weight request (first version of the fused step: every kernel +6 us).
-struct GmSets { const uint8_t *w0, *w1, *w2; const half_t *b0, *b1, *b2; int r0, r1, r2, nsets; };
+struct GmSets { const uint8_t *w0, *w1, *w2; const half_t *b0, *b1, *b2; half_t *y0, *y1, *y2; int r0, r1, r2, nsets, l0, l1, l2; };
 // (`c ? S.a : S.b` on two members is an lvalue conditional: clang selects the ADDRESS and loads once -- through scratch with
 //  a VGPR index when the struct is a local.  gm_sel takes its operands by value, so the select is on values.)
 template <typename V> __device__ __forceinline__ V gm_sel(bool c, V a, V b) { return c ? a : b; }
@@ -76,6 +76,10 @@ __device__ __forceinline__ GmTile gm_locate(const GmSets &S, int vt)
     t.W0 = gm_sel(in2, w2, gm_sel(in1, w1, w0));
     t.b0 = gm_sel(in2, b2, gm_sel(in1, b1, b0));
     t.nrows = gm_sel(in2, r2, gm_sel(in1, r1, r0));
+    half_t *const y0 = S.y0, *const y1 = S.y1, *const y2 = S.y2;
+    const int l0 = S.l0, l1 = S.l1, l2 = S.l2;
+    t.y = gm_sel(in2, y2, gm_sel(in1, y1, y0));           // the set's output matrix (row 0 of the set) and its row stride
+    t.ldy = gm_sel(in2, l2, gm_sel(in1, l1, l0));
     const int lt = gm_sel(in2, vt - t0 - t1, gm_sel(in1, vt - t0, vt));
     t.row0 = lt * 16;
     t.vrow0 = gm_sel(in2, r0 + r1, gm_sel(in1, r0, 0)) + lt * 16;
@@ -109,8 +113,14 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
         return ((uint64_t)hi << 32) | lo;
     };
     auto si = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    // outputs: one matrix over the virtual rows (Y, ldy), or one matrix per set (Yset, ldyset)
+    const bool per_set = P.Yset[0] != nullptr;
+    half_t *const ya = per_set ? P.Yset[0] : P.Y, *const yb = per_set ? P.Yset[1] : P.Y + P.rows[0],
+           *const yc = per_set ? P.Yset[2] : P.Y + P.rows[0] + P.rows[1];
     const GmSets S = {(const uint8_t *)sp(P.W[0]), (const uint8_t *)sp(P.W[1]), (const uint8_t *)sp(P.W[2]), (const half_t *)sp(P.bias[0]),
-                      (const half_t *)sp(P.bias[1]), (const half_t *)sp(P.bias[2]), si(P.rows[0]), si(P.rows[1]), si(P.rows[2]), si(P.nsets)};
+                      (const half_t *)sp(P.bias[1]), (const half_t *)sp(P.bias[2]), (half_t *)sp(ya), (half_t *)sp(yb), (half_t *)sp(yc),
+                      si(P.rows[0]), si(P.rows[1]), si(P.rows[2]), si(P.nsets),
+                      si(per_set ? P.ldyset[0] : P.ldy), si(per_set ? P.ldyset[1] : P.ldy), si(per_set ? P.ldyset[2] : P.ldy)};
     const uint8_t *const W1p = P.W1;
     const half_t *const Xp = P.X, *const nwp = P.norm_w;
     const int ldx = P.ldx;
@@ -300,7 +310,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
                     const half_t act = f2h(act_fn(h2f(y), P.act_kind));                // TensorOpr::Activation -> F16
                     y = f2h(h2f(act) * h2f(y3));                                       // TensorOpr::Mul
                 }
-                P.Y[(size_t)n * P.ldy + vrow] = y;
+                tl.y[(size_t)n * tl.ldy + row] = y;
             }
         }
     }
@@ -328,6 +338,7 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma_grouped(const Moe
     P.X = X + (size_t)gq.row0 * nblk * 32; P.ldx = nblk * 32; P.multi_base = 0.0f; P.eps = 0.0f; P.norm_w = nullptr;
     P.bias[0] = nullptr; P.bias[1] = nullptr; P.bias[2] = nullptr; P.bias1 = nullptr;
     P.Y = Y + (size_t)gq.row0 * rows; P.res = nullptr; P.ldy = rows; P.ldres = 0; P.act_kind = 0;
+    P.Yset[0] = nullptr; P.Yset[1] = nullptr; P.Yset[2] = nullptr; P.ldyset[0] = 0; P.ldyset[1] = 0; P.ldyset[2] = 0;
     gemm_rows_mfma_body<MAXT, TX, GM_PLAIN, 0>(P, smem);
 }
 

@@ -444,3 +444,51 @@ def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, shape, n
         cur = [int(t) for t in tf]
         pos = [p + 1 for p in pos]
     wk.close()
+
+
+@pytest.mark.parametrize("T", [2, 5, 8, 11, 16])
+@pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["kvf16", "kvq8"])
+def test_fused_short_prompt_layer_matches_op_by_op_layer(kvd, T):
+    """Prompts of 2..16 tokens run a layer's linears as four launches of the rows GEMM (norm prologue + wq|wk|wv written
+    to q / k / v, wo + residual, norm + w1/w3 + GLU, w2 + residual: forward_ops, pf_fused) instead of the op-by-op layer
+    (src/transformer/inference_worker.cc:640-1050).  Both at prefix 0 and as the continuation of a cached prefix; the
+    cache rows it stores must serve the decode steps that follow."""
+    wk, host, s = synth.build("test_mha", dt.Q4_B32T1A, kvd, max_ctx=64, quant_threshold=0, std=0.06, keep_host=True)
+    V = s["vocab"]
+    wk.kv_slots(2)
+    rng = np.random.default_rng(40 + T)
+    head = rng.integers(3, V, 7).astype(np.int32)
+    for prefix in (0, 7):
+        toks = rng.integers(3, V, T).astype(np.int32)
+        lg = {}
+        nxt = {}
+        for slot, fused in ((0, 1), (1, 0)):
+            wk.select_kv(slot)
+            wk.set_option("batch_fused", 0)
+            if prefix:
+                wk.forward(head, 0)
+            wk.set_option("batch_fused", fused)
+            out = torch.empty((T, V), dtype=torch.float16, device="cuda")
+            nxt[fused] = wk.forward(toks, prefix, out)
+            lg[fused] = g.host(out).astype(np.float32)
+        a, b = lg[1], lg[0]
+        cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+        assert cos >= 0.9999 and np.abs(a - b).max() <= 0.02, (prefix, cos, np.abs(a - b).max())
+        top = np.sort(a[-1])
+        if top[-1] - top[-2] > LOGIT_TOL:
+            assert nxt[1] == nxt[0]
+        # decode on both caches from the same token: the fused layer's cache rows against the op-by-op layer's
+        wk.set_option("batch_fused", 1)
+        cur = nxt[0]
+        for step in range(3):
+            outs = []
+            for slot in (0, 1):
+                wk.select_kv(slot)
+                o = torch.empty((1, V), dtype=torch.float16, device="cuda")
+                outs.append((wk.forward(np.array([cur], np.int32), prefix + T + step, o), g.host(o).astype(np.float32)))
+            # (two caches written by kernels with different summation orders: half-rounding differences of the rows add up)
+            da, db = outs[0][1], outs[1][1]
+            dcos = float((da * db).sum() / (np.linalg.norm(da) * np.linalg.norm(db)))
+            assert dcos >= 0.9998 and np.abs(da - db).max() <= 0.05, (prefix, step, dcos, np.abs(da - db).max())
+            cur = outs[1][0]
+    wk.close()
