@@ -20,6 +20,7 @@
 #include "ifa_decode_gemv.h"
 #include "ifa_moe.h"
 #include "ifa_gemm_rows_mfma.h"
+#include "ifa_gemm_big.h"
 
 using namespace ifa;
 
@@ -96,7 +97,7 @@ struct ifa_model {
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr, 8};
-    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1;
+    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -1144,6 +1145,7 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
 }
 
 static bool batch_fused_ok(const ifa_model *m, int n);
+static bool prefill_big_ok(const ifa_model *m);
 static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token)
 {
     const ifa_model_config &c = m->cfg;
@@ -1175,23 +1177,30 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     // prompts of 2..16 tokens on a dense Q4 model with the sequential RMS wiring: the linears of a layer as FOUR launches of
     // the rows GEMM (ifa_gemm_rows_mfma.hip) -- norm prologue + wq | wk | wv into q / k / v, wo + residual, norm + w1 / w3 +
     // GLU, w2 + residual -- instead of seven products and four element-wise launches (9..16 tokens: the norms stay launches)
-    const bool pf_fused = !tp && T >= 2 && T <= 16 && batch_fused_ok(m, T) && c.experts == 0;
+    // Prompts above 128 tokens take the same four launches per layer from the large-tile GEMM (ifa_gemm.hip, k_gemm_big: the
+    // weights dequantised once per workgroup and step into LDS; reference-layout rows), norms as their own launches.
+    const bool pf_big = !tp && T > 128 && prefill_big_ok(m);
+    const bool pf_fused = pf_big || (!tp && T >= 2 && T <= 16 && batch_fused_ok(m, T) && c.experts == 0);
     for (int l = 0; l < c.layers && pf_fused; l++) {
         Layer &L = m->layers[l];
         const size_t F = c.ffn;
-        const bool norm_fused = T <= 8;
+        const bool norm_fused = !pf_big && T <= 8;
+        auto wp = [&](int id) { return (const uint8_t *)(pf_big ? L.t[id].data : L.t[id].tiled); };
+        auto lin = [&](const GmArgs &A, int id, int epi, int norm) {
+            return pf_big ? gemm_big(L.t[id].dtype, A, epi, m->stream) : gemm_rows_mfma_launch(A, epi, norm, m->stream);
+        };
         Tensor nob;
         GmArgs P;
         auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = T; P.eps = c.eps; P.act_kind = c.act_kind; };
         clear();
-        if (!norm_fused && (rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], nob, m->xn, c.attn_norm_base))) return rc;
-        P.W[0] = (const uint8_t *)L.t[T_WQ].tiled; P.W[1] = (const uint8_t *)L.t[T_WK].tiled; P.W[2] = (const uint8_t *)L.t[T_WV].tiled;
+        if (!norm_fused && (rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], pf_big ? L.t[T_ATTN_NORM_B] : nob, m->xn, c.attn_norm_base))) return rc;
+        P.W[0] = wp(T_WQ); P.W[1] = wp(T_WK); P.W[2] = wp(T_WV);
         P.rows[0] = (int)QD; P.rows[1] = (int)KVD; P.rows[2] = (int)KVD; P.nsets = 3; P.nblk = (int)(D / 32);
         P.X = norm_fused ? x : m->xn; P.ldx = (int)D;
         if (norm_fused) { P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.multi_base = c.attn_norm_base; }
         P.bias[0] = (const half_t *)L.t[T_WQ_B].data; P.bias[1] = (const half_t *)L.t[T_WK_B].data; P.bias[2] = (const half_t *)L.t[T_WV_B].data;
         P.Yset[0] = m->q; P.Yset[1] = m->k; P.Yset[2] = m->v; P.ldyset[0] = (int)QD; P.ldyset[1] = (int)KVD; P.ldyset[2] = (int)KVD;
-        if ((rc = gemm_rows_mfma_launch(P, GM_PLAIN, norm_fused ? 1 : 0, m->stream))) return rc;
+        if ((rc = lin(P, T_WQ, GM_PLAIN, norm_fused ? 1 : 0))) return rc;
         uint8_t *kdst = (uint8_t *)L.kcache + (size_t)prefix_len * m->kv_row_bytes;
         uint8_t *vdst = (uint8_t *)L.vcache + (size_t)prefix_len * m->kv_row_bytes;
         const bool kv_f16 = c.kv_dtype != Q8_B32T2;
@@ -1217,23 +1226,23 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
                                 c.head_dim, c.use_alibi ? 1.0f : c.kq_scale, c.use_alibi, c.tp_rank * c.heads,
                                 c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
         clear();
-        P.W[0] = (const uint8_t *)L.t[T_WO].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(QD / 32);
+        P.W[0] = wp(T_WO); P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(QD / 32);
         P.X = m->att; P.ldx = (int)QD; P.bias[0] = (const half_t *)L.t[T_WO_B].data;
         P.Y = m->a; P.ldy = (int)D; P.res = x; P.ldres = (int)D;
-        if ((rc = gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream))) return rc;
+        if ((rc = lin(P, T_WO, GM_RESIDUAL, 0))) return rc;
         clear();
-        if (!norm_fused && (rc = norm_rows(m, m->a, T, L.t[T_FFN_NORM], nob, m->hn, c.ffn_norm_base))) return rc;
-        P.W[0] = (const uint8_t *)L.t[T_W1].tiled; P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
+        if (!norm_fused && (rc = norm_rows(m, m->a, T, L.t[T_FFN_NORM], pf_big ? L.t[T_FFN_NORM_B] : nob, m->hn, c.ffn_norm_base))) return rc;
+        P.W[0] = wp(T_W1); P.W1 = wp(T_W3); P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
         P.X = norm_fused ? m->a : m->hn; P.ldx = (int)D;
         if (norm_fused) { P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.multi_base = c.ffn_norm_base; }
         P.bias[0] = (const half_t *)L.t[T_W1_B].data; P.bias1 = (const half_t *)L.t[T_W3_B].data;
         P.Y = m->t1; P.ldy = (int)F;
-        if ((rc = gemm_rows_mfma_launch(P, GM_GLU, norm_fused ? 1 : 0, m->stream))) return rc;
+        if ((rc = lin(P, T_W1, GM_GLU, norm_fused ? 1 : 0))) return rc;
         clear();
-        P.W[0] = (const uint8_t *)L.t[T_W2].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(F / 32);
+        P.W[0] = wp(T_W2); P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(F / 32);
         P.X = m->t1; P.ldx = (int)F; P.bias[0] = (const half_t *)L.t[T_W2_B].data;
         P.Y = m->f; P.ldy = (int)D; P.res = m->a; P.ldres = (int)D;
-        if ((rc = gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream))) return rc;
+        if ((rc = lin(P, T_W2, GM_RESIDUAL, 0))) return rc;
         std::swap(m->x, m->f);
         x = m->x;
     }
@@ -1421,6 +1430,25 @@ static bool batch_fused_ok(const ifa_model *m, int n)
         }
         if (moe && !moe_device_ok(m, L)) return false;
         if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present() || L.t[T_ATTN_NORM_B].present() || L.t[T_FFN_NORM_B].present()) return false;
+    }
+    return true;
+}
+
+// prompts above 128 tokens as four launches of the large-tile GEMM per layer (forward_ops, pf_big): dense layers with the
+// sequential wiring, every linear a 20-byte-block Q4 tensor (wq / wk / wv of one format), dims in multiples of 64
+static bool prefill_big_ok(const ifa_model *m)
+{
+    const ifa_model_config &c = m->cfg;
+    if (!m->opt_prefill_big || m->topo || c.experts > 0 || c.parallel_attn || c.share_input) return false;
+    if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale)) return false;
+    const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, F = c.ffn;
+    if (D % 64 || QD % 64 || F % 64) return false;
+    for (const Layer &L : m->layers) {
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids)
+            if (!L.t[id].present() || !L.t[id].data || (L.t[id].dtype != Q4_B32T1A && L.t[id].dtype != Q4_B32T1B)) return false;
+        if (L.t[T_WK].dtype != L.t[T_WQ].dtype || L.t[T_WV].dtype != L.t[T_WQ].dtype || L.t[T_W3].dtype != L.t[T_W1].dtype) return false;
+        if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present()) return false;
     }
     return true;
 }
@@ -1956,7 +1984,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;

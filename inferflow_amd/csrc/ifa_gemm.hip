@@ -15,9 +15,13 @@
 // (lane half g works through quant block 2*step+g): the sum over k does not care.
 #include <algorithm>
 #include <type_traits>
+#include <cstring>
 #include "ifa_host.h"
 #include "ifa_codec.h"
 #include "ifa_moe.h"
+#include "ifa_math.h"
+#include "ifa_gemm_rows_mfma.h"
+#include "ifa_gemm_big.h"
 
 namespace ifa {
 
@@ -88,6 +92,36 @@ struct WRaw {
             for (int i = 0; i < 5; i++) q4[i] = reinterpret_cast<const uint32_t *>(p)[i];
         } else {
             blk.load(p);
+        }
+    }
+    // materialise the raw registers here (an empty asm the compiler cannot move a use across)
+    __device__ __forceinline__ void pin()
+    {
+        if constexpr (DT == F16) {
+#pragma unroll
+            for (int i = 0; i < CAP / 8; i++) asm volatile("" : "+v"(f16v[i]));
+        } else if constexpr (Q4FAST) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) asm volatile("" : "+v"(q4[i]));
+        }
+    }
+    // 8 consecutive values (chunk m of the block) -- F16 and the 20-byte Q4 blocks only
+    __device__ __forceinline__ half8_t chunk(int m) const
+    {
+        if constexpr (DT == F16) return __builtin_bit_cast(half8_t, f16v[m]);
+        else {
+            static_assert(Q4FAST || DT == F16, "chunk decoder");
+            const float base = hbits2f((uint16_t)(q4[0] & 0xFFFFu)), scale = hbits2f((uint16_t)(q4[0] >> 16));
+            const uint32_t lo = q4[1 + m] & 0x0F0F0F0Fu, hi = (q4[1 + m] >> 4) & 0x0F0F0F0Fu;
+            const float ql[4] = {ubyte_f32<0>(lo), ubyte_f32<1>(lo), ubyte_f32<2>(lo), ubyte_f32<3>(lo)};
+            const float qh[4] = {ubyte_f32<0>(hi), ubyte_f32<1>(hi), ubyte_f32<2>(hi), ubyte_f32<3>(hi)};
+            half8_t h;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                h[2 * b] = f2h(__builtin_fmaf(ql[b], scale, base));
+                h[2 * b + 1] = f2h(__builtin_fmaf(qh[b], scale, base));
+            }
+            return h;
         }
     }
     __device__ __forceinline__ void decode(bool ok, half_t (&v)[CAP]) const
@@ -296,140 +330,250 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_q(const uint8_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Large T (prefill, MFMA-bound): 128 tokens x BN (256 / 128) weight rows per workgroup, K walked in steps of 64.
+// Large T (prefill, MFMA-bound): BM tokens x BN weight rows per workgroup (256 x 256, 128 x 256 or 128 x 128 by the
+// number of tiles the problem offers), K walked in steps of 64, every wave multiplies AND stages.
 //  * the weight tile is dequantised ONCE per workgroup and step into LDS (values rounded to half exactly like the
-//    reference's Dequantize tensor) and shared by the MFMA waves -- the small-T kernel above decodes a block per lane
-//    and MFMA tile, which bounds it at ~0.5 PFLOP/s (VALU per MFMA);
-//  * wave specialisation: waves 0-3 only multiply (a 2 x 2 grid of 64-token x BN/2-row sub-tiles, fragments from LDS),
-//    waves 4-7 only load and dequantise the NEXT step's tiles into the other LDS buffer.  The matrix pipe and the
-//    VALU of a SIMD run side by side (MI355X_MICROARCH.md "Wave scheduling"), so a step costs max(MFMA, dequantisation)
-//    instead of their sum; one barrier per step hands the buffers over;
-//  * rows of both LDS tiles are padded to 144 bytes: the 16-byte fragment reads of 16 consecutive lanes hit 16 disjoint
-//    groups of 4 banks (measured: SQ_LDS_BANK_CONFLICT = 0).
-// Same arithmetic as k_gemm_q: fp32 accumulation of half products, one F16 rounding, bias as a half add.
-constexpr int BIG_BM = 128, BIG_BK = 64, BIG_ROWB = BIG_BK * 2 + 16;     // LDS row stride in bytes
+//    reference's Dequantize tensor) and shared by the waves -- the small-T kernel above decodes a block per lane and
+//    MFMA tile, which bounds it at ~0.5 PFLOP/s (VALU per MFMA).  One quant block per thread and step: its raw bytes are
+//    requested a step ahead, decoded between the MFMA groups of the current step (VALU in the shadow of the matrix pipe)
+//    and written into the other LDS buffer;
+//  * the activation tile goes HBM / L2 -> LDS directly (global_load_lds_dwordx4, no registers): a wave writes 8 rows x
+//    128 bytes per instruction, a step ahead into the other buffer;
+//  * both LDS images are [rows][64 halfs] with the eight 16-byte chunks of row r at slot c ^ ((r >> 1) & 7): the
+//    fragment reads of 16 consecutive lanes (16 rows, one chunk) cover all 64 banks once.  The direct loads write LDS
+//    linearly, so the permutation is applied to their SOURCE addresses (cdna_hip_programming.md 5.4 rule 21);
+//  * workgroup ids are dealt to the 8 XCDs round-robin: the id is remapped so that an XCD works on consecutive tiles
+//    (token tiles fastest: the tiles of one XCD share weight rows in its L2).
+// Same arithmetic as k_gemm_q: fp32 accumulation of half products in ascending 16-column groups, one F16 rounding, bias as a half add.
+constexpr int PF_BK = 64;
+// weight-tile row of the p-th (row, block) slot: 8 consecutive lanes (4 slots x 2 blocks: one ds_write_b128 group) take
+// rows 0, 2, 4, 6 (then 1, 3, 5, 7) of a group of 8 -- four different swizzle values, 8 distinct 16-byte bank groups
+__device__ __forceinline__ int pf_row_of(int p) { return (p & ~7) | ((p & 3) << 1) | ((p >> 2) & 1); }
+typedef __attribute__((address_space(3))) void pf_lds_t;
+typedef const __attribute__((address_space(1))) void pf_glb_t;
 
-template <int DT, int BN>
-__global__ void __launch_bounds__(512) k_gemm_big(const uint8_t *__restrict__ W, int N, int nblk,
-                                                  const half_t *__restrict__ X, int T, int K,
-                                                  const half_t *__restrict__ bias, half_t *__restrict__ Y, int dbg)
+// Launch arguments: GmArgs (ifa_gemm_rows_mfma.h -- up to three matrices as one row space, per-set or virtual-row
+// outputs, bias, residual, GLU pair; W[] / W1 are REFERENCE-layout rows here) + the tile geometry.
+// EPI: GM_PLAIN | GM_RESIDUAL (Y = half(res + y), TensorOpr::Add) | GM_GLU (a weight tile = BN / 2 rows of w1 and the
+// same BN / 2 rows of w3; the w3 half of the waves hands its products over through LDS; Y = half(act(y1)) * y3).
+struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; };
+
+template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN>
+__global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const BigGeo G)
 {
+    constexpr bool GLU = EPI == GM_GLU;
+    constexpr int BNE = GLU ? BN / 2 : BN;              // rows of ONE matrix per weight tile
+    const int T = P.T, K = G.K, nblk = P.nblk, tiles_m = G.tiles_m;
+    const half_t *__restrict__ X = P.X;
+    constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int CAP = (DT == F16) ? 32 : block_capacity(DT);
-    constexpr int BPS = BIG_BK / CAP;                   // quant blocks per row and step (2 or 1)
-    constexpr int WB = (BN * BPS + 255) / 256;          // blocks a loader thread dequantises per step
-    constexpr int NT = BN / 64;                         // 32-row accumulator tiles per MFMA wave along N (4 or 2)
-    constexpr size_t TILE = (size_t)(BIG_BM + BN) * BIG_ROWB;
+    constexpr int BPS = PF_BK / CAP;                    // quant blocks per row and step
+    constexpr int CPB = CAP / 8;                        // 16-byte chunks of halfs per block
+    constexpr int NB = BN * BPS;                        // blocks of the weight tile per step
+    constexpr int WB = (NB + NT - 1) / NT;              // blocks a thread dequantises per step
+    constexpr int TA = BM / WM / 32, TB = BN / WN / 32; // 32 x 32 accumulator tiles per wave
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int NA = 2;
+    constexpr int AI = BM / 8 / NW;                     // direct-to-LDS instructions per wave and step (8 rows each)
+    static_assert(BPS >= 1 && BM % (16 * NW) == 0, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * BN, t0 = blockIdx.y * BIG_BM;
-    const int nsteps = (K + BIG_BK - 1) / BIG_BK;
-    if (wave >= 4) {
-        // ------------------------------------------------------------------ loader waves
-        const int lt = tid - 256;
-        u32x4 xa[4];
-        WRaw<DT, CAP> wr[WB];
-        auto fetch = [&](int step) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) {               // 128 rows x 8 chunks of 8 halfs
-                const int idx = lt + c * 256;
-                const int r = idx >> 3, cc = idx & 7;
-                const int tok = min(t0 + r, T - 1), k = min(step * BIG_BK + cc * 8, K - 8);
-                xa[c] = *reinterpret_cast<const u32x4 *>(X + (size_t)tok * K + k);
-            }
-#pragma unroll
-            for (int j = 0; j < WB; j++) {
-                const int idx = min(lt + j * 256, BN * BPS - 1);
-                const int nl = idx / BPS, b = idx % BPS;
-                wr[j].load(W, (size_t)min(n0 + nl, N - 1), nblk, min(step * BPS + b, nblk - 1));
-            }
-        };
-        auto stage = [&](int step) {                    // registers -> LDS buffer (step & 1)
-            char *As = smem + (size_t)(step & 1) * TILE, *Bs = As + (size_t)BIG_BM * BIG_ROWB;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int idx = lt + c * 256;
-                const int r = idx >> 3, cc = idx & 7;
-                const bool ok = (t0 + r < T) && (step * BIG_BK + cc * 8 < K);
-                *reinterpret_cast<u32x4 *>(As + (size_t)r * BIG_ROWB + (size_t)cc * 16) = ok ? xa[c] : u32x4{0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int j = 0; j < WB; j++) {
-                const int idx = lt + j * 256;
-                if (idx >= BN * BPS) continue;
-                const int nl = idx / BPS, b = idx % BPS;
-                if (dbg & 1) continue;                  // (ablation: no dequantisation, no B stores)
-                half_t v[CAP];
-                wr[j].decode(step * BPS + b < nblk, v);
-#pragma unroll
-                for (int m = 0; m < CAP / 8; m++) {
-                    half8_t h;
-#pragma unroll
-                    for (int e = 0; e < 8; e++) h[e] = v[8 * m + e];
-                    *reinterpret_cast<half8_t *>(Bs + (size_t)nl * BIG_ROWB + (size_t)(b * CAP + 8 * m) * 2) = h;
-                }
-            }
-        };
-        fetch(0);
-        stage(0);
-        if (nsteps > 1) fetch(1);
-        __syncthreads();                                // tile 0 is ready
-        for (int step = 0; step < nsteps; step++) {
-            // the MFMA waves multiply tile `step`; tile step + 1 goes into the other buffer (its previous content,
-            // tile step - 1, was released by the barrier that ended the previous iteration)
-            if (step + 1 < nsteps) {
-                stage(step + 1);
-                if (step + 2 < nsteps) fetch(step + 2);
-            }
-            __syncthreads();
-        }
-        return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware tile order (bijective for any grid size)
+    int wg;
+    {
+        const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    // ---------------------------------------------------------------------- MFMA waves
+    // tiles in bands of GM token tiles, weight tiles next, token tiles of the band fastest: the workgroups an XCD runs
+    // at the same time form a compact block (GM token tiles x a few weight tiles) whose operand tiles its L2 shares
+    constexpr int GM = 1024 / BM;
+    const int tiles_n = (int)gridDim.x / tiles_m;
+    const int band = wg / (GM * tiles_n), within = wg % (GM * tiles_n), band_m = min(GM, tiles_m - band * GM);
+    const int t0 = (band * GM + within % band_m) * BM, tn = G.tn0 + within / band_m;
+    // weight tile -> (matrix, first row); everything selected by VALUE from the argument block (no indexed struct access)
+    const int set = (tn >= G.tile0[1] ? 1 : 0) + (tn >= G.tile0[2] ? 1 : 0);
+    const int n0 = (tn - (set == 0 ? 0 : (set == 1 ? G.tile0[1] : G.tile0[2]))) * BNE;
+    const int N = set == 0 ? P.rows[0] : (set == 1 ? P.rows[1] : P.rows[2]);
+    const uint8_t *__restrict__ W = set == 0 ? P.W[0] : (set == 1 ? P.W[1] : P.W[2]);
+    const half_t *__restrict__ bias = set == 0 ? P.bias[0] : (set == 1 ? P.bias[1] : P.bias[2]);
+    const int nsteps = K / PF_BK;
+    // ---- activation tile: per-lane source pointers of this wave's 8-row pieces
+    const half_t *xsrc[AI];
+#pragma unroll
+    for (int j = 0; j < AI; j++) {
+        const int row = (wave * AI + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        xsrc[j] = X + (size_t)min(t0 + row, T - 1) * P.ldx + c * 8;
+    }
+    auto stage_x = [&](int step, int buf, int j0, int j1) {
+#pragma unroll
+        for (int j = j0; j < j1; j++)
+            __builtin_amdgcn_global_load_lds((pf_glb_t *)(xsrc[j] + (size_t)step * PF_BK),
+                                             (pf_lds_t *)(smem + (size_t)buf * A_BYTES + (size_t)(wave * AI + j) * 1024), 16, 0, 0);
+    };
+    // ---- weight tile: one (row, block) per thread and j
+    WRaw<DT, CAP> wr[WB];
+    auto fetch_w = [&](int step) {
+#pragma unroll
+        for (int j = 0; j < WB; j++) {
+            const int idx = min(tid + j * NT, NB - 1);
+            const int nl = pf_row_of(idx / BPS);
+            if constexpr (GLU) wr[j].load(nl < BNE ? W : P.W1, (size_t)min(n0 + (nl < BNE ? nl : nl - BNE), N - 1), nblk, step * BPS + idx % BPS);
+            else wr[j].load(W, (size_t)min(n0 + nl, N - 1), nblk, step * BPS + idx % BPS);
+        }
+    };
+    // the raw bytes of the block(s) being dequantised this step (wr is refilled for the step after next meanwhile);
+    // formats without a per-chunk decoder are decoded whole at the head of the step
+    constexpr bool CHUNKED = WRaw<DT, CAP>::Q4FAST || DT == F16;
+    WRaw<DT, CAP> wc[WB];
+    half_t wv[CHUNKED ? 1 : WB][CHUNKED ? 8 : CAP];
+    auto take_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < WB; j++) {
+            if constexpr (CHUNKED) { wc[j] = wr[j]; wc[j].pin(); }
+            else wr[j].decode(true, wv[j]);
+        }
+    };
+    auto store_w = [&](int buf, int m0, int m1) {           // chunks [m0, m1) of every block of this thread
+        char *Bs = smem + (size_t)NA * A_BYTES + (size_t)buf * B_BYTES;
+#pragma unroll
+        for (int j = 0; j < WB; j++) {
+            const int idx = tid + j * NT;
+            if (NB % NT != 0 && idx >= NB) continue;
+            const int nl = pf_row_of(idx / BPS), b = idx % BPS;
+#pragma unroll
+            for (int m = m0; m < m1; m++) {
+                half8_t h;
+                if constexpr (CHUNKED) h = wc[j].chunk(m);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) h[e] = wv[j][8 * m + e];
+                }
+                *reinterpret_cast<half8_t *>(Bs + (size_t)nl * 128 + (size_t)(((b * CPB + m) ^ ((nl >> 1) & 7)) << 4)) = h;
+            }
+        }
+    };
+    // ---- fragments: lane (i, g) reads row i of a 32-row tile, chunk 2 * ks + g
     const int i = lane & 31, g = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;            // this wave's 64-token x (BN/2)-row sub-tile
-    f32x16_t acc[2][NT];
+    const int wm = wave / WN, wn = wave % WN;
+    const int lc = g ^ ((i >> 1) & 7);                  // (2 ks + g) ^ swizzle(i) == (2 ks) ^ lc
+    const int a_off = (wm * (BM / WM) + i) * 128, b_off = NA * A_BYTES + (wn * (BN / WN) + i) * 128;
+    f32x16_t acc[TA][TB];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < TA; a++)
 #pragma unroll
-        for (int b = 0; b < NT; b++)
+        for (int b = 0; b < TB; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
-    __syncthreads();                                    // tile 0 is ready
-    for (int step = 0; step < nsteps; step++) {
-        const char *As = smem + (size_t)(step & 1) * TILE, *Bs = As + (size_t)BIG_BM * BIG_ROWB;
+
+    // K loop.  A step = four MFMA groups (16 columns each) of buffer `cur`; the fragments of a group are requested ahead of
+    // the products of the group before it, a share of the next step's weight chunks is dequantised and stored behind the
+    // first three groups.  The step's barrier sits BEFORE the last group: by then every wave has read its last fragments of
+    // `cur` and finished its part of the next tile, so the first fragments of the next buffer are requested right behind
+    // the barrier and land under the last group's products -- no LDS round trip is exposed at a step boundary.
+    half8_t af[2][TA], bf[2][TB];
+    auto frags = [&](int buf, int ks, half8_t (&fa)[TA], half8_t (&fb)[TB]) {
+        const char *As = smem + (size_t)buf * A_BYTES, *Bs = smem + (size_t)buf * B_BYTES;
+        const int so = ((2 * ks) ^ lc) << 4;
 #pragma unroll
-        for (int ks = 0; ks < BIG_BK / 16; ks++) {
-            if (dbg & 2) continue;                      // (ablation: no fragment reads, no MFMAs)
-            half8_t af[2], bf[NT];
+        for (int a = 0; a < TA; a++) fa[a] = *reinterpret_cast<const half8_t *>(As + a_off + a * 32 * 128 + so);
 #pragma unroll
-            for (int a = 0; a < 2; a++)
-                af[a] = *reinterpret_cast<const half8_t *>(As + (size_t)(wm * 64 + a * 32 + i) * BIG_ROWB + (size_t)(ks * 16 + 8 * g) * 2);
+        for (int b = 0; b < TB; b++) fb[b] = *reinterpret_cast<const half8_t *>(Bs + b_off + b * 32 * 128 + so);
+    };
+    auto mma = [&](const half8_t (&fa)[TA], const half8_t (&fb)[TB]) {
 #pragma unroll
-            for (int b = 0; b < NT; b++)
-                bf[b] = *reinterpret_cast<const half8_t *>(Bs + (size_t)(wn * (BN / 2) + b * 32 + i) * BIG_ROWB + (size_t)(ks * 16 + 8 * g) * 2);
+        for (int a = 0; a < TA; a++)
 #pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < NT; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-        __syncthreads();                                // this tile may be overwritten, the next one is complete
+            for (int b = 0; b < TB; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    };
+
+    stage_x(0, 0, 0, AI);
+    fetch_w(0);
+    take_w();
+    store_w(0, 0, CPB);
+    fetch_w(min(1, nsteps - 1));
+    __syncthreads();
+    frags(0, 0, af[0], bf[0]);
+    for (int step = 0; step + 1 < nsteps; step++) {
+        const int cur = step & 1;
+        // the copy is pinned AHEAD of the direct-to-LDS loads: with one of those in flight the compiler waits vmcnt(0) at
+        // the next use of an ordinary load's result, which would expose the whole latency of the tile just requested
+        take_w();                                        // (the barrier of the previous step waited for its bytes)
+        stage_x(step + 1, cur ^ 1, 0, AI);
+        fetch_w(min(step + 2, nsteps - 1));              // a whole step to land; the last one is a harmless repeat
+        frags(cur, 1, af[1], bf[1]); mma(af[0], bf[0]); store_w(cur ^ 1, 0, (CPB + 2) / 3);
+        frags(cur, 2, af[0], bf[0]); mma(af[1], bf[1]); store_w(cur ^ 1, (CPB + 2) / 3, (2 * CPB + 2) / 3);
+        frags(cur, 3, af[1], bf[1]); mma(af[0], bf[0]); store_w(cur ^ 1, (2 * CPB + 2) / 3, CPB);
+        __syncthreads();
+        frags(cur ^ 1, 0, af[0], bf[0]); mma(af[1], bf[1]);
     }
+    {
+        const int cur = (nsteps - 1) & 1;
+        frags(cur, 1, af[1], bf[1]); mma(af[0], bf[0]);
+        frags(cur, 2, af[0], bf[0]); mma(af[1], bf[1]);
+        frags(cur, 3, af[1], bf[1]); mma(af[0], bf[0]);
+        mma(af[1], bf[1]);
+    }
+    // ---- epilogue
+    half_t *__restrict__ Yo; int ldo, vrow0 = 0;
+    if (P.Yset[0]) { Yo = set == 0 ? P.Yset[0] : (set == 1 ? P.Yset[1] : P.Yset[2]); ldo = set == 0 ? P.ldyset[0] : (set == 1 ? P.ldyset[1] : P.ldyset[2]); }
+    else { Yo = P.Y; ldo = P.ldy; vrow0 = (set >= 1 ? P.rows[0] : 0) + (set >= 2 ? P.rows[1] : 0); }
+    // products -> F16 (+ bias) -> an LDS tile [BM][BN] -> 16-byte pieces of output rows (residual / GLU applied on the way out).
+    // A lane holds ONE output column (32 lanes: 32 adjacent columns of a token row); adjacent lanes trade every other value
+    // (DPP quad swap) so that each writes a (column, column + 1) pair as one dword; rows padded by 64 bytes: the even / odd
+    // lanes of a write land in two different token rows, 16 banks apart.
+    constexpr int WCOLS = BN / WN;                      // weight rows (output columns) of a wave
+    constexpr int CROW = BN * 2 + 64;
+    __syncthreads();                                    // every wave is done with the operand tiles
+    {
+        const bool odd = i & 1;
 #pragma unroll
-    for (int b = 0; b < NT; b++) {
-        const int n = n0 + wn * (BN / 2) + b * 32 + i;
-        if (n >= N) continue;
-        const float bv = bias ? h2f(bias[n]) : 0.0f;
+        for (int b = 0; b < TB; b++) {
+            const int cl = wn * WCOLS + b * 32 + i;
+            float bv = 0.0f; bool hb = false;
+            if constexpr (GLU) {
+                const half_t *bp = cl < BNE ? bias : P.bias1;
+                const int n = n0 + (cl < BNE ? cl : cl - BNE);
+                if (bp) { hb = true; bv = h2f(bp[min(n, N - 1)]); }
+            } else if (bias) { hb = true; bv = h2f(bias[min(n0 + cl, N - 1)]); }
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+            for (int a = 0; a < TA; a++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int tok = t0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (tok < T) {
-                    half_t y = f2h(acc[a][b][r]);
-                    if (bias) y = f2h(h2f(y) + bv);
-                    Y[(size_t)tok * N + n] = y;
+                for (int rp = 0; rp < 8; rp++) {
+                    half_t y0 = f2h(acc[a][b][2 * rp]), y1 = f2h(acc[a][b][2 * rp + 1]);
+                    if (hb) { y0 = f2h(h2f(y0) + bv); y1 = f2h(h2f(y1) + bv); }
+                    const uint32_t u0 = __builtin_bit_cast(uint16_t, y0), u1 = __builtin_bit_cast(uint16_t, y1);
+                    const uint32_t send = odd ? u0 : u1;
+                    const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+                    const uint32_t packed = odd ? (recv | (u1 << 16)) : (u0 | (recv << 16));
+                    const int rr = 2 * rp + (odd ? 1 : 0);
+                    const int tl = wm * (BM / WM) + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+                    *reinterpret_cast<uint32_t *>(smem + (size_t)tl * CROW + (size_t)(cl & ~1) * 2) = packed;
                 }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int VEC = BNE / 8;                    // 16-byte pieces per output row of the tile
+        for (int idx = tid; idx < BM * VEC; idx += NT) {
+            const int tl = idx / VEC, v = idx % VEC, tok = t0 + tl, n = n0 + v * 8;
+            if (tok >= T || n >= N) continue;
+            half8_t y = *reinterpret_cast<const half8_t *>(smem + (size_t)tl * CROW + (size_t)v * 16);
+            if constexpr (GLU) {
+                const half8_t u = *reinterpret_cast<const half8_t *>(smem + (size_t)tl * CROW + (size_t)(BNE + v * 8) * 2);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const half_t act = f2h(act_fn(h2f(y[e]), P.act_kind));                 // TensorOpr::Activation -> F16
+                    y[e] = f2h(h2f(act) * h2f(u[e]));                                      // TensorOpr::Mul
+                }
+            } else if constexpr (EPI == GM_RESIDUAL) {
+                const half8_t r = *reinterpret_cast<const half8_t *>(P.res + (size_t)tok * P.ldres + vrow0 + n);
+#pragma unroll
+                for (int e = 0; e < 8; e++) y[e] = f2h(h2f(r[e]) + h2f(y[e]));             // TensorOpr::Add
             }
+            *reinterpret_cast<half8_t *>(Yo + (size_t)tok * ldo + vrow0 + n) = y;
+        }
     }
 }
 
@@ -450,6 +594,63 @@ static int gemm_num_cus()
 }
 static int g_gemm_big = 0;       // ifa_gemm_big_tiles(1): opt-in large-tile kernel for T > 128 (round 2: 0.44-0.52 PFLOP/s, behind the other routes; its load skeleton alone costs 57 % of its time -- tools/probes/gemm_big_ablation.py)
 
+// tile shape by estimated time: rounds of workgroups over the chip x the measured cost of one round
+// (256 x 256: 1 workgroup per CU; 128 x 256: 1 per CU, 0.68 of the time; 128 x 128: 2 per CU, 0.75 -- 0.41 alone)
+template <int DT, int EPI>
+static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
+{
+    constexpr int CAP = (DT == F16) ? 32 : block_capacity(DT);
+    GmArgs P = P0;
+    const size_t T = (size_t)P.T, cus = (size_t)gemm_num_cus();
+    auto ntiles = [&](size_t bn) {
+        const size_t bne = EPI == GM_GLU ? bn / 2 : bn;
+        size_t n = 0;
+        for (int i = 0; i < P.nsets; i++) n += ifa_cdiv((size_t)P.rows[i], bne);
+        return n;
+    };
+    auto run = [&](auto bm, auto bn, auto wm, auto wn, int tn0, int tn_count) {      // weight tiles [tn0, tn0 + tn_count)
+        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value, WM = decltype(wm)::value, WN = decltype(wn)::value;
+        constexpr int BNE = EPI == GM_GLU ? BN / 2 : BN;
+        BigGeo G;
+        G.tile0[0] = 0;
+        for (int i = 0; i < 3; i++) G.tile0[i + 1] = G.tile0[i] + (i < P.nsets ? (int)ifa_cdiv((size_t)P.rows[i], (size_t)BNE) : 0);
+        for (int i = P.nsets; i < 3; i++) G.tile0[i] = 1 << 30;        // (absent sets are never selected)
+        G.tiles_m = (int)ifa_cdiv(T, (size_t)BM); G.K = P.nblk * CAP; G.tn0 = tn0;
+        const size_t smem = std::max(2 * (size_t)(BM + BN) * 128, (size_t)BM * (BN * 2 + 64));      // operand tiles; the epilogue's output tile
+        auto kern = k_gemm_big<DT, BM, BN, WM, WN, EPI>;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+        kern<<<dim3((unsigned)(G.tiles_m * tn_count)), dim3(WM * WN * 64), smem, s>>>(P, G);
+    };
+    using std::integral_constant;
+    typedef integral_constant<int, 256> I256; typedef integral_constant<int, 128> I128; typedef integral_constant<int, 2> I2; typedef integral_constant<int, 4> I4;
+    const int force = (g_gemm_big >> 8) & 3;        // (measurement: 1 / 2 / 3 force a tile shape)
+    auto rounds = [&](size_t bm, size_t bn, size_t per_cu) { return (double)ifa_cdiv(ifa_cdiv(T, bm) * ntiles(bn), cus * per_cu); };
+    // 256 x 256: whole rounds of the chip; what is left of the last round goes to a second launch of 128-token tiles when
+    // those fit the chip in one go (1024 tokens x 11008 GLU pairs: 86 weight tiles = 64 x 4 workgroups + 22 x 8)
+    const size_t tm256 = ifa_cdiv(T, (size_t)256), tn256 = ntiles(256), per_round = tm256 <= cus ? cus / tm256 : 0;
+    const size_t full_n = per_round ? (tn256 / per_round) * per_round : 0, rem_n = tn256 - full_n;
+    const bool split = full_n > 0 && rem_n > 0 && ifa_cdiv(T, (size_t)128) * rem_n <= cus && tm256 * rem_n < cus * 3 / 4;
+    const size_t n128 = ifa_cdiv(T, (size_t)128) * ntiles(128);
+    const double c256 = CAP > 32 ? 1e30 : (split ? (double)(full_n / per_round) + 0.68 : rounds(256, 256, 1));   // (64-value blocks: the 256 x 256 variant would spill)
+    const double c128x256 = rounds(128, 256, 1) * 0.68;
+    const double c128 = n128 <= cus ? 0.41 : rounds(128, 128, 2) * 0.75;
+    int pick = force;
+    if (!pick) pick = (c256 <= c128x256 && c256 <= c128) ? 1 : (c128x256 <= c128 ? 2 : 3);
+    if (pick == 1 && CAP <= 32) {
+        if (split && !force) {
+            run(I256(), I256(), I2(), I4(), 0, (int)full_n);
+            run(I128(), I256(), I2(), I4(), (int)full_n, (int)rem_n);
+        } else run(I256(), I256(), I2(), I4(), 0, (int)tn256);
+    } else if (pick == 2 || pick == 1)
+        run(I128(), I256(), I2(), I4(), 0, (int)tn256);
+    else
+        run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128));
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+
 template <int DT>
 static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t T, const void *bias, void *Y, hipStream_t s)
 {
@@ -457,26 +658,11 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
     const int nblk = (int)(K / CAP);
     constexpr int MT = 2;
     const size_t slab = (size_t)32 * MT * (2 * CAP * 2 + 16);
-    if (T > 128 && K % 8 == 0 && g_gemm_big) {
-        // MFMA-bound: the weight tile dequantised once per workgroup into LDS by loader waves, 128 x 256 output tiles
-        // (128 x 128 when the wider tile would leave compute units without a workgroup)
-        const bool wide = (size_t)ifa_cdiv(N, 256) * ifa_cdiv(T, BIG_BM) >= (size_t)gemm_num_cus();
-        if (wide) {
-            dim3 grid(ifa_cdiv(N, 256), ifa_cdiv(T, BIG_BM));
-            const size_t smem = 2 * (size_t)(BIG_BM + 256) * BIG_ROWB;
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_gemm_big<DT, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-            k_gemm_big<DT, 256><<<grid, dim3(512), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T, (int)K,
-                                                              (const half_t *)bias, (half_t *)Y, g_gemm_big >> 4);
-        } else {
-            dim3 grid(ifa_cdiv(N, 128), ifa_cdiv(T, BIG_BM));
-            const size_t smem = 2 * (size_t)(BIG_BM + 128) * BIG_ROWB;
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_gemm_big<DT, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-            k_gemm_big<DT, 128><<<grid, dim3(512), smem, s>>>((const uint8_t *)W, (int)N, nblk, (const half_t *)X, (int)T, (int)K,
-                                                              (const half_t *)bias, (half_t *)Y, g_gemm_big >> 4);
-        }
-        return IFA_OK;
+    if (T > 128 && K % PF_BK == 0 && PF_BK % CAP == 0 && N % 8 == 0 && g_gemm_big) {
+        GmArgs P; memset(&P, 0, sizeof(P));
+        P.W[0] = (const uint8_t *)W; P.rows[0] = (int)N; P.nsets = 1; P.nblk = nblk; P.T = (int)T;
+        P.X = (const half_t *)X; P.ldx = (int)K; P.bias[0] = (const half_t *)bias; P.Y = (half_t *)Y; P.ldy = (int)N;
+        return launch_gemm_big<DT, GM_PLAIN>(P, s);
     }
     if (T > 128 && ifa_cdiv(N, GEMM_ROWS) * ifa_cdiv(T, 128) >= 256) {
         // enough tiles to fill the chip twice over with 128-token tiles: the dequantised block is reused for 4 MFMA tiles
@@ -506,6 +692,31 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
                                                                       (int)K, (const half_t *)bias, (half_t *)Y);
     }
     return IFA_OK;
+}
+
+namespace ifa {
+// cols % 64 == 0, 64 % block capacity == 0; fused epilogues (GM_RESIDUAL / GM_GLU) on the 20-byte Q4 blocks
+bool gemm_big_ok(int w_dtype, const GmArgs &P, int epi)
+{
+    const int cap = w_dtype == F16 ? 32 : block_capacity(w_dtype);
+    if (cap <= 1 || PF_BK % cap != 0 || ((size_t)P.nblk * cap) % PF_BK != 0 || P.T < 1 || P.nsets < 1 || P.nsets > 3) return false;
+    if (epi != GM_PLAIN && w_dtype != Q4_B32T1A && w_dtype != Q4_B32T1B) return false;
+    if (epi == GM_GLU && (P.nsets != 1 || !P.W1)) return false;
+    for (int i = 0; i < P.nsets; i++) if (P.rows[i] % 8 != 0) return false;     // (16-byte pieces of output rows)
+    if ((P.Yset[0] ? (P.ldyset[0] | P.ldyset[1] | P.ldyset[2]) : P.ldy) % 8 != 0 || (epi == GM_RESIDUAL && P.ldres % 8 != 0)) return false;
+    return true;
+}
+int gemm_big(int w_dtype, const GmArgs &P, int epi, hipStream_t s)
+{
+    if (!gemm_big_ok(w_dtype, P, epi)) return ifa_fail(IFA_ERR_ARG, "large-tile GEMM: dtype %d / %d blocks per row / epilogue %d", w_dtype, P.nblk, epi);
+    if (epi == GM_PLAIN) {
+        if (w_dtype == F16) return launch_gemm_big<F16, GM_PLAIN>(P, s);
+        IFA_DISPATCH_QUANT_DTYPE(w_dtype, return (launch_gemm_big<DT, GM_PLAIN>(P, s)));
+        return IFA_OK;
+    }
+    if (w_dtype == Q4_B32T1A) return epi == GM_RESIDUAL ? launch_gemm_big<Q4_B32T1A, GM_RESIDUAL>(P, s) : launch_gemm_big<Q4_B32T1A, GM_GLU>(P, s);
+    return epi == GM_RESIDUAL ? launch_gemm_big<Q4_B32T1B, GM_RESIDUAL>(P, s) : launch_gemm_big<Q4_B32T1B, GM_GLU>(P, s);
+}
 }
 
 // Grouped product of a mixture-of-experts step (ifa_moe.h): every tile of the device-side table is <= 64 rows of one

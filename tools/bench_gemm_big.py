@@ -20,7 +20,12 @@ for d in dts:
         st = g.stream()
         res = {"dtype": dt.NAMES[d], "T": T, "rows": rows, "cols": cols}
         outs = {}
-        for name, big, lib in (("own_big", 1, 0), ("own_small", 0, 0), ("library", 0, 2)):
+        variants = [("own_big", 1, 0), ("own_small", 0, 0), ("library", 0, 2)]
+        if "--tiles" in sys.argv:      # force a tile shape: 256 x 256, 128 x 256, 128 x 128
+            variants += [("big_256x256", 1 | (1 << 8), 0), ("big_128x256", 1 | (2 << 8), 0), ("big_128x128", 1 | (3 << 8), 0)]
+        if "--ablate" in sys.argv:
+            variants += [("big_no_dequant", 1 | (1 << 4), 0), ("big_no_mfma", 1 | (2 << 4), 0), ("big_neither", 1 | (3 << 4), 0)]
+        for name, big, lib in variants:
             if lib and not lib_ok:
                 continue
             L.ifa_gemm_big_tiles(big); L.ifa_gemm_library_min_tokens(lib)

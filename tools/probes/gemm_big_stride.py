@@ -1,7 +1,5 @@
 #!/usr/bin/env python3
-"""Ablation of the 256 x 256 prefill GEMM kernel (needs a library built with IFA_GEMM_BIG_ABLATION defined in
-ifa_gemm.hip): parts compiled out -- 1 dequantisation + weight-tile stores, 2 MFMAs, 4 direct-to-LDS activation loads,
-8 fragment reads."""
+"""Is the activation-tile fetch of the prefill GEMM sensitive to the row stride (L2 channel camping)?  Same tile, K varied."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -11,13 +9,12 @@ from tests import gpu_util as g
 L = ia.lib()
 L.ifa_gemm_library_min_tokens(0)
 d = dt.Q4_B32T1A
-for T, rows, cols in [(4096, 4096, 4096), (1024, 11008, 4096)]:
+for T, rows, cols in [(4096, 4096, 4096), (4096, 4096, 4160), (4096, 4096, 4224), (4096, 4096, 4352), (1024, 4096, 4096), (1024, 4096, 4224)]:
     w = (torch.randn(rows, cols, device="cuda") * 0.02).half()
     W = g.quantize(d, w); x = (torch.randn(T, cols, device="cuda") * 0.5).half(); st = g.stream(); y = g.empty_f16(T, rows)
     out = []
-    for name, abl in (("full", 0), ("no_dequant", 1), ("no_mfma", 2), ("no_glds", 4), ("no_frag_reads", 8), ("no_dequant_mfma", 3),
-                      ("no_mfma_frags", 10), ("no_dequant_mfma_frags", 11), ("none", 15)):
-        L.ifa_gemm_big_tiles(1 | (abl << 4) | (1 << 8))
+    for name, mode in (("auto", 1), ("256x256", 1 | (1 << 8)), ("128x128", 1 | (3 << 8)), ("small", 0)):
+        L.ifa_gemm_big_tiles(mode)
         fn = lambda: ia.check(L.ifa_gemm(d, g.p(W), rows, cols, g.p(x), T, None, g.p(y), st))
         for _ in range(3): fn()
         torch.cuda.synchronize()
@@ -25,6 +22,7 @@ for T, rows, cols in [(4096, 4096, 4096), (1024, 11008, 4096)]:
         e0.record()
         for _ in range(20): fn()
         e1.record(); torch.cuda.synchronize()
-        out.append("%s %.1f" % (name, e0.elapsed_time(e1) / 20 * 1e3))
-    print(T, rows, cols, "us:", " | ".join(out), flush=True)
+        t = e0.elapsed_time(e1) / 20 * 1e-3
+        out.append("%s %.1f us %.0f TF" % (name, t * 1e6, 2.0 * T * rows * cols / t / 1e12))
+    print(T, rows, cols, " | ".join(out), flush=True)
 L.ifa_gemm_big_tiles(0)
