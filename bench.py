@@ -250,6 +250,10 @@ def main():
         out["prefill_tok_s_by_prompt_len"] = pf
         flops_per_token = 2.0 * (w_bytes - runner.shape["vocab"] * runner.shape["dim"] * 2) / dt.row_bytes(wd, 32) * 32
         out["prefill_linear_TFLOPs_at_longest"] = pf[str(max([PROMPT_LEN] + prefill_lens))] * flops_per_token / 1e12
+        import inferflow_amd as ia
+        lib_on = bool(ia.lib().ifa_gemm_library_min_tokens(-1))
+        out["prefill_gemm_route"] = ("dequantise-once + hipBLASLt above 128 tokens (opt-in, IFA_GEMM_LT_MIN_TOKENS)" if lib_on else
+                                     "in-tree kernels only (csrc/ifa_gemm.hip: large-tile MFMA kernel above 128 tokens, four launches per layer); library route off")
     # ---- dynamic batching: B queries with their own KV caches, one decode step appends one token to each (the reference's
     # InferenceEngine::Infer over several queries, inference_engine.cc:1300-1406); outside the timed headline region
     if world == 1 and args.batch > 1 and hasattr(runner, "worker") and not os.environ.get("IFA_FORCE_TP"):

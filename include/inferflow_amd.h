@@ -100,19 +100,21 @@ int ifa_gemv(int w_dtype, const void *W, size_t rows, size_t cols,
 /* ---- prefill / batched linear layer (MatrixMultiplication's T>1 branch,
  * src/transformer/inference_worker.cc:2374-2415: TensorOpr::Dequantize + CublasEngine::GemmEx
  * F16xF16->F16 with fp32 accumulate + Transpose).  Y[tokens][rows] (F16) = X[tokens][cols] (F16)
- * . W[rows][cols]^T (+bias); W in any block format (reference layout) or F16.  The weights are
- * dequantised to half in registers and fed to v_mfma_f32_32x32x16_f16; no F16 copy of W exists.
- * From ifa_gemm_library_min_tokens() tokens on (default 129: past the split-K kernel, MFMA-bound) the weights are instead dequantised once
- * into a per-stream F16 scratch and multiplied by hipBLASLt (bound at run time; same arithmetic). */
+ * . W[rows][cols]^T (+bias); W in any block format (reference layout) or F16.  No F16 copy of W exists: up to 128 tokens
+ * every lane dequantises the blocks it needs into its MFMA operand registers (split-K kernels, weight-stream bound);
+ * above 128 tokens (formats with blocks of <= 32 values) a workgroup dequantises its weight tile once per K step into
+ * LDS and 256 x 256 / 128 x 256 / 128 x 128 output tiles are multiplied from there (v_mfma_f32_32x32x16_f16).
+ * OPT-IN: from ifa_gemm_library_min_tokens() tokens on the weights are instead dequantised once into a per-stream F16
+ * scratch and multiplied by hipBLASLt (bound at run time; same arithmetic) -- off unless switched on. */
 int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x_f16, size_t tokens,
              const void *bias_f16, void *y_f16, ifa_stream stream);
-/* sets the token count from which ifa_gemm hands the product to hipBLASLt (0 = never, < 0 = only query);
- * returns the previous threshold, or 0 when hipBLASLt could not be loaded.  Environment: IFA_GEMM_LT_MIN_TOKENS. */
+/* sets the token count from which ifa_gemm hands the product to hipBLASLt (0 = never: the default, < 0 = only query);
+ * returns the previous threshold (0 also when hipBLASLt cannot be loaded).  Environment: IFA_GEMM_LT_MIN_TOKENS. */
 int ifa_gemm_library_min_tokens(int min_tokens);
-/* opt-in (default 0): tokens > 128 through the large-tile MFMA kernel (128 tokens x 256 / 128 weight rows per workgroup, the
- * weight tile dequantised once per step into LDS by loader waves, MFMA waves beside them).  Bit-identical results to
- * the other routes; slower than both in round 2 (profiles/r02_gemm_big.log), kept for the next round's work.  < 0 only
- * queries; returns the previous setting */
+/* 1 when hipBLASLt could be loaded (the opt-in route above is usable), else 0 */
+int ifa_gemm_library_available(void);
+/* the large-tile kernel for tokens > 128 (default 1; 0: the smaller-tile kernels serve every T).  Bit-identical results
+ * either way.  < 0 only queries; returns the previous setting */
 int ifa_gemm_big_tiles(int on);
 /* frees the F16 scratch / workspace the library path keeps for this stream on the current device (call before destroying
  * a stream that ran ifa_gemm with >= that many tokens; ifa_model_destroy / ifa_model_set_stream do it for the worker's) */

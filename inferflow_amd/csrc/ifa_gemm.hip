@@ -592,7 +592,7 @@ static int gemm_num_cus()
     if (!n) { int dev = 0; hipDeviceProp_t prop; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
     return n;
 }
-static int g_gemm_big = 0;       // ifa_gemm_big_tiles(1): opt-in large-tile kernel for T > 128 (round 2: 0.44-0.52 PFLOP/s, behind the other routes; its load skeleton alone costs 57 % of its time -- tools/probes/gemm_big_ablation.py)
+static int g_gemm_big = 1;       // ifa_gemm_big_tiles(0 / 1): the large-tile kernel for T > 128 (default on; blocks of <= 32 values -- the 64-value formats keep k_gemm_q); bits 8-9: force a tile shape (measurement)
 
 // tile shape by estimated time: rounds of workgroups over the chip x the measured cost of one round
 // (256 x 256: 1 workgroup per CU; 128 x 256: 1 per CU, 0.68 of the time; 128 x 128: 2 per CU, 0.75 -- 0.41 alone)
@@ -658,7 +658,7 @@ static int launch_gemm(const void *W, size_t N, size_t K, const void *X, size_t 
     const int nblk = (int)(K / CAP);
     constexpr int MT = 2;
     const size_t slab = (size_t)32 * MT * (2 * CAP * 2 + 16);
-    if (T > 128 && K % PF_BK == 0 && PF_BK % CAP == 0 && N % 8 == 0 && g_gemm_big) {
+    if (T > 128 && K % PF_BK == 0 && CAP <= 32 && PF_BK % CAP == 0 && N % 8 == 0 && (g_gemm_big & 1)) {
         GmArgs P; memset(&P, 0, sizeof(P));
         P.W[0] = (const uint8_t *)W; P.rows[0] = (int)N; P.nsets = 1; P.nblk = nblk; P.T = (int)T;
         P.X = (const half_t *)X; P.ldx = (int)K; P.bias[0] = (const half_t *)bias; P.Y = (half_t *)Y; P.ldy = (int)N;

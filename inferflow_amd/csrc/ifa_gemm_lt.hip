@@ -108,13 +108,14 @@ constexpr size_t LT_WORKSPACE = (size_t)64 << 20;
 
 static std::mutex g_lt_mutex;
 static std::map<std::pair<int, hipStream_t>, LtContext> g_lt_ctx;
-static int g_lt_min_tokens = -1;          // -1: not initialised (environment IFA_GEMM_LT_MIN_TOKENS, default 129 = past the split-K kernel); 0: never
+static int g_lt_min_tokens = -1;          // -1: not initialised (environment IFA_GEMM_LT_MIN_TOKENS); 0: never -- the DEFAULT: the library route is opt-in,
+                                          // the in-tree kernels (ifa_gemm.hip) serve every T unless it is switched on
 
 static int lt_min_tokens()
 {
     if (g_lt_min_tokens < 0) {
         const char *e = getenv("IFA_GEMM_LT_MIN_TOKENS");
-        g_lt_min_tokens = e ? std::max(0, atoi(e)) : 129;
+        g_lt_min_tokens = e ? std::max(0, atoi(e)) : 0;
     }
     return g_lt_min_tokens;
 }
@@ -221,6 +222,11 @@ extern "C" int ifa_gemm_release_stream(ifa_stream stream)
     if (it->second.workspace) (void)hipFree(it->second.workspace);
     ifa::g_lt_ctx.erase(it);
     return IFA_OK;
+}
+
+extern "C" int ifa_gemm_library_available(void)
+{
+    return ifa::lt_api().ok ? 1 : 0;
 }
 
 extern "C" int ifa_gemm_library_min_tokens(int min_tokens)

@@ -110,25 +110,32 @@ def test_forward_and_fused_decode_match_oracle(shape, wd, kvd, threshold):
 
 @pytest.mark.parametrize("wd,kvd", [(dt.Q4_B32T1A, dt.F16), (dt.Q3H_B64T1, dt.Q8_B32T2)], ids=["q4_kvf16", "q3h_kvq8"])
 def test_long_prompt_prefill_through_the_library_gemm_matches_oracle(wd, kvd):
-    """A 150-token prompt: every linear layer takes the dequantise-once + hipBLASLt route (csrc/ifa_gemm_lt.hip), the
-    attention the MFMA prefill kernel.  Same tolerance as the short-prompt case, and the same logits as the
-    fused-kernel route (library switched off)."""
+    """A 150-token prompt on the opt-in route: every linear layer dequantise-once + hipBLASLt (csrc/ifa_gemm_lt.hip), the
+    attention the MFMA prefill kernel.  Same tolerance as the short-prompt case, and the same logits as the default
+    route (library off: the in-tree large-tile kernel, four launches per layer for the Q4 model)."""
     L = g.capi()
-    prev = L.ifa_gemm_library_min_tokens(-1)
-    if prev == 0:
+    if not L.ifa_gemm_library_available():
         pytest.skip("hipBLASLt not loadable on this box")
+    prev = L.ifa_gemm_library_min_tokens(-1)
     max_ctx = 192
     wk, host, s = synth.build("test_gqa", wd, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
     om = oracle_model_from_host(host, s, max_ctx, kvd)
     prompt = np.random.default_rng(8).integers(3, s["vocab"], 150).astype(np.int32)
     lg = torch.empty((len(prompt), s["vocab"]), dtype=torch.float16, device="cuda")
-    tok_lib = wk.forward(prompt, 0, lg)
-    lg_lib = g.host(lg).copy()
-    tok_orc, lg_orc = om.forward(prompt, 0, nthreads=4)
-    cos, mad = _logits_close(lg_lib, lg_orc)
-    assert cos >= 0.9995 and mad <= 0.03, (cos, mad)
     try:
+        L.ifa_gemm_library_min_tokens(129)
+        wk.set_option("prefill_big", 0)
+        tok_lib = wk.forward(prompt, 0, lg)
+        lg_lib = g.host(lg).copy()
+        tok_orc, lg_orc = om.forward(prompt, 0, nthreads=4)
+        cos, mad = _logits_close(lg_lib, lg_orc)
+        assert cos >= 0.9995 and mad <= 0.03, (cos, mad)
+        # a second pass over the same prompt reuses the per-stream context (scratch copy, plans) and reproduces the logits
+        wk.reset()
+        wk.forward(prompt, 0, lg)
+        assert np.array_equal(g.host(lg), lg_lib)
         L.ifa_gemm_library_min_tokens(0)
+        wk.set_option("prefill_big", 1)
         wk.reset()
         tok_own = wk.forward(prompt, 0, lg)
     finally:
@@ -138,10 +145,6 @@ def test_long_prompt_prefill_through_the_library_gemm_matches_oracle(wd, kvd):
     top2 = np.sort(lg_orc[-1].astype(np.float32))[-2:]
     if top2[1] - top2[0] > LOGIT_TOL:
         assert tok_lib == tok_orc == tok_own
-    # a second pass over the same prompt reuses the per-stream context (scratch copy, plans) and reproduces the logits
-    wk.reset()
-    wk.forward(prompt, 0, lg)
-    assert np.array_equal(g.host(lg), lg_lib)
     wk.close()
 
 
@@ -491,4 +494,52 @@ def test_fused_short_prompt_layer_matches_op_by_op_layer(kvd, T):
             dcos = float((da * db).sum() / (np.linalg.norm(da) * np.linalg.norm(db)))
             assert dcos >= 0.9998 and np.abs(da - db).max() <= 0.05, (prefix, step, dcos, np.abs(da - db).max())
             cur = outs[1][0]
+    wk.close()
+
+
+@pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["kvf16", "kvq8"])
+def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd):
+    """Prompts above 128 tokens run a layer's linears as four launches of the large-tile GEMM (csrc/ifa_gemm.hip, k_gemm_big:
+    wq | wk | wv into q / k / v, wo + residual, w1 / w3 + GLU, w2 + residual; forward_ops, pf_big) -- a 170-token prompt and
+    a 160-token continuation of it against the oracle (src/transformer/inference_worker.cc:640-1050) and against the
+    op-by-op layer of the same library (prefill_big = 0), then decode steps on the cache it wrote."""
+    max_ctx = 400
+    wk, host, s = synth.build("test_gqa", dt.Q4_B32T1A, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
+    om = oracle_model_from_host(host, s, max_ctx, kvd)
+    V = s["vocab"]
+    prompt = np.random.default_rng(21).integers(3, V, 330).astype(np.int32)
+    chunks = [(0, 170), (170, 330)]
+    lgs = {}
+    for big in (1, 0):
+        wk.set_option("prefill_big", big)
+        wk.reset()
+        outs = []
+        for a, b in chunks:
+            lg = torch.empty((b - a, V), dtype=torch.float16, device="cuda")
+            tok = wk.forward(prompt[a:b], a, lg)
+            outs.append((tok, g.host(lg).astype(np.float32)))
+        lgs[big] = outs
+    for ci, (a, b) in enumerate(chunks):
+        tok_orc, lg_orc = om.forward(prompt[a:b], a, nthreads=4)
+        cos, mad = _logits_close(lgs[1][ci][1], lg_orc)
+        assert cos >= 0.9995 and mad <= 0.03, (ci, cos, mad)
+        cos2, mad2 = _logits_close(lgs[1][ci][1], lgs[0][ci][1])
+        assert cos2 >= 0.9999 and mad2 <= 0.02, (ci, cos2, mad2)
+        top = np.sort(lg_orc[-1].astype(np.float32))
+        if top[-1] - top[-2] > LOGIT_TOL:
+            assert lgs[1][ci][0] == tok_orc, ci
+    # the op-by-op run came last: rebuild the cache with the large-tile layer, then decode against the oracle
+    wk.set_option("prefill_big", 1)
+    wk.reset()
+    for a, b in chunks:
+        cur = wk.forward(prompt[a:b], a)
+    toks, _ = wk.decode(cur, len(prompt), 4)
+    pos, t_o = len(prompt), cur
+    for step in range(4):
+        nxt, lg_o = om.forward(np.array([t_o], np.int32), pos, nthreads=4)
+        top = np.sort(lg_o[-1].astype(np.float32))
+        if top[-1] - top[-2] <= LOGIT_TOL or int(toks[step]) != int(nxt):
+            assert top[-1] - top[-2] <= LOGIT_TOL, step
+            break
+        t_o, pos = int(nxt), pos + 1
     wk.close()

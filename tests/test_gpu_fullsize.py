@@ -88,9 +88,9 @@ def test_llama2_7b_width_prefill_gemm_regimes_agree(T, rows, cols):
     import torch
     from tests import gpu_util as g
     L = g.capi()
-    prev = L.ifa_gemm_library_min_tokens(-1)
-    if prev == 0:
+    if not L.ifa_gemm_library_available():
         pytest.skip("hipBLASLt not loadable on this box")
+    prev = L.ifa_gemm_library_min_tokens(-1)
     torch.manual_seed(T)
     w = (torch.randn(rows, cols, device="cuda") * 0.02).half()
     W = g.quantize(dt.Q4_B32T1A, w)

@@ -351,9 +351,9 @@ def test_gemm_library_path_matches_the_fused_kernel_and_the_oracle(d):
     """From ifa_gemm_library_min_tokens() tokens on, ifa_gemm dequantises once and calls hipBLASLt (csrc/ifa_gemm_lt.hip):
     same half-rounded weights, fp32 accumulation in another order -> same tolerance as the fused kernel."""
     L = g.capi()
-    prev = L.ifa_gemm_library_min_tokens(-1)
-    if prev == 0 and L.ifa_gemm_library_min_tokens(129) == 0:
+    if not L.ifa_gemm_library_available():
         pytest.skip("hipBLASLt not loadable on this box")
+    prev = L.ifa_gemm_library_min_tokens(-1)
     T, rows, cols = 192, 320, 1024
     rng = np.random.default_rng(77 + d)
     w = rng.normal(0, 0.05, (rows, cols)).astype(np.float16)
@@ -368,7 +368,7 @@ def test_gemm_library_path_matches_the_fused_kernel_and_the_oracle(d):
         y_lib = g.host(g.gemm(d, Wd, rows, cols, xd, bd))
         y_lib_nobias = g.host(g.gemm(d, Wd, rows, cols, xd))
     finally:
-        L.ifa_gemm_library_min_tokens(prev if prev > 0 else 129)
+        L.ifa_gemm_library_min_tokens(prev)
     for t in (0, T // 2, T - 1):
         y_orc, y64 = o.gemv_f16x(d, Wq, rows, cols, x[t], bias=bias, want_f64=True)
         for y in (y_own, y_lib):
@@ -379,6 +379,46 @@ def test_gemm_library_path_matches_the_fused_kernel_and_the_oracle(d):
         assert (g.half_ulp_diff(y_lib_nobias[t], y_nb) <= 2).mean() >= 0.98
     # the two paths agree with each other far inside that tolerance
     assert (g.half_ulp_diff(y_own, y_lib) <= 2).mean() >= 0.995
+
+
+BIG_DT = [dt.Q4_B32T1A, dt.Q4_B32T1B, dt.Q8_B32T2, dt.Q5_B32T1, dt.Q4_B16, dt.F16]
+
+
+@pytest.mark.parametrize("T,rows,cols", [(150, 320, 1024), (300, 136, 512), (257, 520, 192), (513, 264, 2112)])
+@pytest.mark.parametrize("d", BIG_DT, ids=IDS(BIG_DT))
+def test_gemm_large_tile_kernel_matches_per_token_oracle(d, T, rows, cols):
+    """Above 128 tokens ifa_gemm runs the large-tile kernel (csrc/ifa_gemm.hip, k_gemm_big: the weight tile dequantised once
+    per workgroup and K step into swizzled LDS, the activation tile by direct-to-LDS loads, 256 x 256 / 128 x 256 /
+    128 x 128 output tiles, output rows written from an LDS tile).  Every tile shape on the same problem -- ragged token
+    and row counts, a K of 3 and of 33 steps, with and without bias -- against the oracle's per-token product (MatrixMultiplication's
+    T > 1 branch, src/transformer/inference_worker.cc:2374-2415), and bit-identical to each other."""
+    L = g.capi()
+    rng = np.random.default_rng(5 + d + T)
+    w = rng.normal(0, 0.05, (rows, cols)).astype(np.float16)
+    x = rng.normal(0, 1.0, (T, cols)).astype(np.float16)
+    bias = rng.normal(0, 0.5, rows).astype(np.float16)
+    Wq = w if d == dt.F16 else o.quantize(d, w)
+    Wd, xd, bd = g.dev(Wq), g.dev(x), g.dev(bias)
+    prev_big, prev_lib = L.ifa_gemm_big_tiles(-1), L.ifa_gemm_library_min_tokens(-1)
+    ys = {}
+    try:
+        L.ifa_gemm_library_min_tokens(0)
+        for name, mode in (("auto", 1), ("256x256", 1 | (1 << 8)), ("128x256", 1 | (2 << 8)), ("128x128", 1 | (3 << 8)), ("small", 0)):
+            L.ifa_gemm_big_tiles(mode)
+            ys[name] = g.host(g.gemm(d, Wd, rows, cols, xd, bd))
+        L.ifa_gemm_big_tiles(1)
+        y_nobias = g.host(g.gemm(d, Wd, rows, cols, xd))
+    finally:
+        L.ifa_gemm_big_tiles(prev_big); L.ifa_gemm_library_min_tokens(prev_lib)
+    for t in (0, 127, 128, T // 2, T - 1):
+        y_orc, y64 = o.gemv_f16x(d, Wq, rows, cols, x[t], bias=bias, want_f64=True)
+        ulp = g.half_ulp_diff(ys["auto"][t], y_orc)
+        small = np.abs(ys["auto"][t].astype(np.float32) - y_orc.astype(np.float32)) <= 1e-3 * float(np.abs(y64).mean() + 1e-6)
+        assert ((ulp <= 2) | small).all(), (t, ulp.max())
+        assert (g.half_ulp_diff(y_nobias[t], o.gemv_f16x(d, Wq, rows, cols, x[t])) <= 2).mean() >= 0.98
+    for name in ("256x256", "128x256", "128x128"):
+        assert np.array_equal(ys[name], ys["auto"]), name          # same products in the same order whatever the tile
+    assert (g.half_ulp_diff(ys["small"], ys["auto"]) <= 2).mean() >= 0.995
 
 
 @pytest.mark.parametrize("T,rows,cols", [(2, 70, 256), (3, 128, 4096), (4, 200, 1024), (7, 96, 2048), (8, 64, 11008), (12, 100, 4096), (16, 48, 5120),
