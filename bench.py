@@ -250,6 +250,11 @@ def main():
         out["prefill_tok_s_by_prompt_len"] = pf
         flops_per_token = 2.0 * (w_bytes - runner.shape["vocab"] * runner.shape["dim"] * 2) / dt.row_bytes(wd, 32) * 32
         out["prefill_linear_TFLOPs_at_longest"] = pf[str(max([PROMPT_LEN] + prefill_lens))] * flops_per_token / 1e12
+        longest = max([PROMPT_LEN] + prefill_lens)
+        out["prefill_roofline"] = {"bound": "mfma", "achieved": out["prefill_linear_TFLOPs_at_longest"], "peak": 2500.0, "unit": "TFLOP/s",
+                                   "frac": out["prefill_linear_TFLOPs_at_longest"] / 2500.0,
+                                   "note": "flops of the layers' linear products (2 x tokens x weights) / WHOLE prefill time of a %d-token prompt "
+                                           "(attention, norms, RoPE, cache writes, lm_head of the last row included in the time); dense F16 MFMA peak" % longest}
         import inferflow_amd as ia
         lib_on = bool(ia.lib().ifa_gemm_library_min_tokens(-1))
         out["prefill_gemm_route"] = ("dequantise-once + hipBLASLt above 128 tokens (opt-in, IFA_GEMM_LT_MIN_TOKENS)" if lib_on else

@@ -82,7 +82,9 @@ void SortedTopK(const uint16_t *logits, int n, int k, std::vector<IdWeight> &poo
 void SoftMaxPool(std::vector<IdWeight> &items, float temperature)
 {
     if (items.empty()) return;
-    std::stable_sort(items.begin(), items.end(), [](const IdWeight &a, const IdWeight &b) { return a.weight > b.weight; });
+    // std::sort like the reference (sampling_strategy.cc:113): NOT stable -- the order of EQUAL logits in the pool is what the
+    // toolchain's std::sort makes of the (weight desc, lower id first) list the top-k queue hands over
+    std::sort(items.begin(), items.end(), [](const IdWeight &a, const IdWeight &b) { return a.weight > b.weight; });
     if (temperature < 0.001f) temperature = 0.001f;
     float max_value = items[0].weight;
     for (const IdWeight &it : items) max_value = std::max(max_value, it.weight);
@@ -149,7 +151,7 @@ static void CutTypical(const std::vector<IdWeight> &pool, float p, std::vector<I
     for (size_t i = 0; i < pool.size(); i++) shifted[i] = fabsf(-logf(pool[i].weight) - entropy);
     std::vector<size_t> idx(pool.size());
     for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
-    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return shifted[a] < shifted[b]; });
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return shifted[a] < shifted[b]; });        // (std::sort: sampling_strategy.cc:935)
     out.assign(1, pool[idx[0]]);
     float cum = 0.0f;
     for (size_t i = 1; i < idx.size(); i++) {
@@ -265,9 +267,9 @@ bool ChooseTokens(SamplingOutput &out, const uint16_t *logits, int vocab, Sampli
         size_t n = 0;
         while (n < pool.size() && !(-log2f(pool[n].weight) > mu)) n++;
         if (n == 0) n = 1;
-        // SoftMaxPool sorted `pool`; the same order applied to the raw logits (stable sort of equal keys, like above)
+        // SoftMaxPool sorted `pool`; the same order applied to the raw logits (the same std::sort on the same sequence)
         std::vector<IdWeight> prefix(raw);
-        std::stable_sort(prefix.begin(), prefix.end(), [](const IdWeight &a, const IdWeight &b) { return a.weight > b.weight; });
+        std::sort(prefix.begin(), prefix.end(), [](const IdWeight &a, const IdWeight &b) { return a.weight > b.weight; });
         prefix.resize(n);
         SoftMaxPool(prefix, temperature);
         out.token_pool = prefix;

@@ -3,8 +3,12 @@
 Follows src/transformer/sampling_strategy.cc:29-43 (top_p / top_k cut), :107-147 (SoftMax with temperature), :235-304
 (GetSortedTopK through sslib TopKQueue, 3rd_party/sslib/top_k_queue.h:13-22: higher weight first, equal weights: lower id
 first), :359-392 (StdSamplingStrategy::ChooseTokens) and 3rd_party/sslib/random.h:15-121 / random.cc:75-146 (Random =
-the java.util.Random LCG; RandomSampling with count 1).  Pinned by the published java.util.Random known answers
-(seed 42: nextInt() = -1170105035, 234785527; nextDouble() = 0.7275636800328681).
+the java.util.Random LCG; RandomSampling with count 1).  PINNED to the reference itself: tests/golden/ref_sampling.npz holds
+the draws of the reference's own sampling_strategy.cc (compiled where it lies: oracle/Makefile `ref_sampling`, driver
+oracle/ref_sampling_driver.cc, generator tests/golden/gen_sampling_fixtures.py) for all ten strategies, and
+tests/test_sampling_ref_fixtures.py checks this file AND the product's host sampler against them draw for draw -- which is
+how the std::sort tie order below and Mirostat's second SoftMax over the sorted prefix were found.  Also pinned by the
+published java.util.Random known answers (seed 42: nextInt() = -1170105035, 234785527; nextDouble() = 0.7275636800328681).
 """
 import math
 
@@ -34,9 +38,123 @@ def sorted_top_k(logits_f16, k):
     return [(i, float(lg[i])) for i in order[:k]]
 
 
+def std_sort(a, less):
+    """std::sort of libstdc++ (GCC's bits/stl_algo.h, the library the reference is built with here): introsort -- median-of-3
+    quicksort down to runs of 16, heapsort past a depth of 2 * floor(log2 n), one final insertion sort.  NOT stable: the
+    reference sorts its token pool with it (sampling_strategy.cc:113, :935), so which of several EQUAL logits comes first
+    is this algorithm's doing.  Restated from the published algorithm; sorts the list in place."""
+    n = len(a)
+    if n < 2:
+        return a
+
+    def swap(i, j):
+        a[i], a[j] = a[j], a[i]
+
+    def move_median_to_first(result, x, y, z):
+        if less(a[x], a[y]):
+            if less(a[y], a[z]):
+                swap(result, y)
+            elif less(a[x], a[z]):
+                swap(result, z)
+            else:
+                swap(result, x)
+        elif less(a[x], a[z]):
+            swap(result, x)
+        elif less(a[y], a[z]):
+            swap(result, z)
+        else:
+            swap(result, y)
+
+    def unguarded_partition(first, last, pivot):
+        while True:
+            while less(a[first], a[pivot]):
+                first += 1
+            last -= 1
+            while less(a[pivot], a[last]):
+                last -= 1
+            if not first < last:
+                return first
+            swap(first, last)
+            first += 1
+
+    def heap_sort(first, last):                      # std::partial_sort(first, last, last): make_heap + sort_heap
+        def adjust(hole, length, val):
+            top = hole
+            child = hole
+            while child < (length - 1) // 2:
+                child = 2 * (child + 1)
+                if less(a[first + child], a[first + child - 1]):
+                    child -= 1
+                a[first + hole] = a[first + child]
+                hole = child
+            if (length & 1) == 0 and child == (length - 2) // 2:
+                child = 2 * (child + 1)
+                a[first + hole] = a[first + child - 1]
+                hole = child - 1
+            parent = (hole - 1) // 2
+            while hole > top and less(a[first + parent], val):
+                a[first + hole] = a[first + parent]
+                hole = parent
+                parent = (hole - 1) // 2
+            a[first + hole] = val
+        length = last - first
+        if length >= 2:
+            parent = (length - 2) // 2
+            while True:
+                adjust(parent, length, a[first + parent])
+                if parent == 0:
+                    break
+                parent -= 1
+        while last - first > 1:
+            last -= 1
+            val = a[last]
+            a[last] = a[first]
+            adjust(0, last - first, val)
+
+    def introsort_loop(first, last, depth):
+        while last - first > 16:
+            if depth == 0:
+                heap_sort(first, last)
+                return
+            depth -= 1
+            mid = first + (last - first) // 2
+            move_median_to_first(first, first + 1, mid, last - 1)
+            cut = unguarded_partition(first + 1, last, first)
+            introsort_loop(cut, last, depth)
+            last = cut
+
+    def unguarded_linear_insert(i):
+        val = a[i]
+        nxt = i - 1
+        while less(val, a[nxt]):
+            a[i] = a[nxt]
+            i = nxt
+            nxt -= 1
+        a[i] = val
+
+    def insertion_sort(first, last):
+        for i in range(first + 1, last):
+            if less(a[i], a[first]):
+                val = a[i]
+                a[first + 1:i + 1] = a[first:i]
+                a[first] = val
+            else:
+                unguarded_linear_insert(i)
+
+    introsort_loop(0, n, 2 * (n.bit_length() - 1))
+    if n > 16:
+        insertion_sort(0, 16)
+        for i in range(16, n):
+            unguarded_linear_insert(i)
+    else:
+        insertion_sort(0, n)
+    return a
+
+
 def softmax_pool(pool, temperature):
     if not pool:
         return []
+    pool = std_sort(list(pool), lambda x, y: np.float32(x[1]) > np.float32(y[1]))       # SoftMax sorts first (sampling_strategy.cc:113)
     t = max(np.float32(temperature), np.float32(0.001))
     m = max(np.float32(w) for _, w in pool)
     ws = [np.float32(math.exp(float((np.float32(w) - m) / t))) for _, w in pool]
@@ -121,7 +239,7 @@ def cut_typical(pool, p=0.95):
     for x in w:
         ent = F(ent + F(-x * F(np.log(x, dtype=np.float32))))
     shifted = [F(abs(F(F(-np.log(x, dtype=np.float32)) - ent))) for x in w]
-    idx = sorted(range(len(pool)), key=lambda i: (float(shifted[i]), i))
+    idx = std_sort(list(range(len(pool))), lambda x, y: shifted[x] < shifted[y])                # std::sort, sampling_strategy.cc:935
     out = [pool[idx[0]]]
     cum = F(0)
     for i in idx[1:]:
@@ -148,7 +266,8 @@ def choose_tokens_ex(logits_f16, strategy, rng, temperature=1.0, pool_size=50, m
         k = 0
         while k < len(pool) and not (F(-np.log2(F(pool[k][1]), dtype=np.float32)) > mu):
             k += 1
-        cut = softmax_pool(raw[:max(k, 1)], temperature)
+        rawl = dict(raw)                                   # the first k entries of the SORTED pool with their logits, softmaxed (and sorted) again
+        cut = softmax_pool([(i, rawl[i]) for i, _ in pool[:max(k, 1)]], temperature)
     sel = draw_one(rng, cut)
     if strategy == MIROSTAT:
         mu = F(mu - F(eta) * F(F(-np.log2(F(sel[1]), dtype=np.float32)) - F(tau)))

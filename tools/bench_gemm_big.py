@@ -9,7 +9,7 @@ import inferflow_amd as ia
 from inferflow_amd import dtypes as dt
 from tests import gpu_util as g
 L = ia.lib()
-lib_ok = bool(L.ifa_gemm_library_min_tokens(-1))
+lib_ok = bool(L.ifa_gemm_library_available())
 shapes = [(1024, 4096, 4096), (1024, 11008, 4096), (1024, 4096, 11008), (256, 4096, 4096), (512, 11008, 4096), (4096, 4096, 4096), (1000, 4096, 4096)]
 dts = [dt.Q4_B32T1A, dt.Q3H_B64T1, dt.F16] if "--all" in sys.argv else [dt.Q4_B32T1A]
 for d in dts:
@@ -23,8 +23,6 @@ for d in dts:
         variants = [("own_big", 1, 0), ("own_small", 0, 0), ("library", 0, 2)]
         if "--tiles" in sys.argv:      # force a tile shape: 256 x 256, 128 x 256, 128 x 128
             variants += [("big_256x256", 1 | (1 << 8), 0), ("big_128x256", 1 | (2 << 8), 0), ("big_128x128", 1 | (3 << 8), 0)]
-        if "--ablate" in sys.argv:
-            variants += [("big_no_dequant", 1 | (1 << 4), 0), ("big_no_mfma", 1 | (2 << 4), 0), ("big_neither", 1 | (3 << 4), 0)]
         for name, big, lib in variants:
             if lib and not lib_ok:
                 continue
@@ -41,7 +39,7 @@ for d in dts:
             t = e0.elapsed_time(e1) * 1e-3 / n
             res[name + "_us"] = round(t * 1e6, 1); res[name + "_TFLOPs"] = round(2.0 * T * rows * cols / t / 1e12, 1)
             outs[name] = g.host(y).astype(np.float32)
-        L.ifa_gemm_big_tiles(0); L.ifa_gemm_library_min_tokens(129)
+        L.ifa_gemm_big_tiles(1); L.ifa_gemm_library_min_tokens(0)
         ref = outs.get("library", outs["own_small"])
         res["max_abs_diff_vs_ref"] = float(np.abs(outs["own_big"] - ref).max()); res["ref_mean_abs"] = float(np.abs(ref).mean())
         print(json.dumps(res), flush=True)
