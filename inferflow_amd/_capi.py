@@ -68,6 +68,8 @@ SIGNATURES = {
     "ifa_gemm": (_i, [_i, _vp, _sz, _sz, _vp, _sz, _vp, _vp, _vp]),
     "ifa_gemm_library_min_tokens": (_i, [_i]),
     "ifa_gemm_library_available": (_i, []),
+    "ifa_attention_two_pass_min": (_i, [_i]),
+    "ifa_attention_two_pass_min_keys": (_i, [_i]),
     "ifa_gemm_big_tiles": (_i, [_i]),
     "ifa_gemm_release_stream": (_i, [_vp]),
     "ifa_tiled_row_bytes": (_sz, [_i, _sz]),

@@ -343,6 +343,230 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const half_t *__restrict
     }
 }
 
+// ---------------------------------------------------------------- long prompts (q_tokens >= 128): two passes over the keys
+// One workgroup per (128-query tile, head), a wave per 32 queries.  The three-stage kernel above keeps a [32 x n_keys]
+// score tile (LDS, past ~2300 keys a global workspace) and re-reads a head's K / V once per 32 queries: at 4096 tokens it
+// moves more score-tile and K / V bytes through L2 than the matrix cores can hide (1.2 ms per layer).  Here nothing of size
+// n_keys is stored: pass 1 streams the K blocks and keeps each query's running max / sum, pass 2 streams K and V, REcomputes
+// the scores, rounds them exactly like the staged kernel (S half, e = half(exp), P = half(e * 1/sum)) and multiplies by V
+// from registers.  K / V blocks of 32 keys are staged through LDS once per 128 queries.
+//   S^T = K . Q^T: keys are the MFMA rows, so a lane holds 16 keys of ONE query (its column): max / sum / P need no
+//                  cross-lane traffic except one exchange between the lane halves at the end of pass 1;
+//   O^T = V^T . P^T: P^T is then already the B operand (lane = query column, 8 keys per k-step); a lane's registers hold keys
+//                  4g + {0-3, 8-11, 16-19, 24-27}, so the V block is transposed into LDS with its key columns in THAT order
+//                  (f2_col) -- the sum over keys does not care.
+constexpr int F2_QT = 128;
+constexpr int F2_VROW = 40;          // halfs per row of the transposed V block (32 key columns + pad)
+__host__ __device__ constexpr int f2_col(int k) { return (k & 16) | (((k >> 2) & 1) << 3) | (k & 3) | (((k >> 3) & 1) << 2); }
+template <int HD> __device__ __forceinline__ int f2_swz(int row) { return HD == 128 ? (row & 15) : ((row >> 1) & 7); }
+
+template <int HD, bool Q8>
+__global__ void __launch_bounds__(256, 2) k_attention_2pass(const half_t *__restrict__ q, const uint8_t *__restrict__ kc,
+                                                         const uint8_t *__restrict__ vc, int n_ctx, int q_tokens,
+                                                         int prefix_len, int heads, int kv_heads, float kq_scale,
+                                                         int alibi, int alibi_base, int alibi_total, half_t *__restrict__ out)
+{
+    static_assert(HD == 128 || HD == 64, "two-pass attention: head_dim 64 / 128");
+    constexpr int KS = HD / 16, NT = HD / 32, CHK = HD / 8;
+    constexpr int NKC = 32 * CHK / 256;              // 16-byte chunks of the K block per thread
+    // two buffers each: block kb + 1 is staged while block kb is multiplied (one barrier per block)
+    __shared__ __attribute__((aligned(16))) char Ks2[2][32 * HD * 2];             // [key][HD halfs], 16-byte chunks swizzled
+    __shared__ __attribute__((aligned(16))) half_t Vt2[2][HD * F2_VROW];         // [dim][key column]
+    int tile = blockIdx.x, h = blockIdx.y;
+    if (heads % 8 == 0) {            // an XCD keeps a fixed eighth of the heads (their K / V in ONE L2); longest tiles first
+        const int w = blockIdx.y * gridDim.x + blockIdx.x, xcd = w & 7, r = w >> 3;
+        h = (r / (int)gridDim.x) * 8 + xcd;
+        tile = (int)gridDim.x - 1 - r % (int)gridDim.x;
+    }
+    const int t0 = tile * F2_QT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    const int kvh = h / (heads / kv_heads);
+    const int kv_dim = kv_heads * HD;
+    const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
+    const int hoff = kvh * HD;
+    const int n_keys = min(n_ctx, prefix_len + min(t0 + F2_QT, q_tokens));        // causal bound of the whole tile
+    const int nkb = (n_keys + 31) / 32;
+    const int tw = t0 + 32 * wave, tq = tw + i;
+    const int n_valid = tq < q_tokens ? min(n_ctx, prefix_len + tq + 1) : 0;      // keys this lane's query may see
+    const int wave_keys = tw < q_tokens ? min(n_ctx, prefix_len + min(tw + 32, q_tokens)) : 0;
+    const int wave_nkb = (wave_keys + 31) / 32;                                   // blocks past it are fully masked for this wave
+    const float alpha = 1.0f / sqrtf((float)HD) / kq_scale;
+    const float mk = alibi ? alibi_slope(h + alibi_base, alibi_total) : 0.0f;
+
+    half8v qf[KS];
+    {
+        const int tqc = min(tq, q_tokens - 1);
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++)
+            qf[s2] = __builtin_bit_cast(half8v, *reinterpret_cast<const u32x4v *>(q + ((size_t)tqc * heads + h) * HD + 16 * s2 + 8 * g));
+    }
+    // ---- staging: K block rows as they are (swizzled chunks), V block transposed with permuted key columns
+    half8v kreg[NKC];
+    auto kload = [&](int kb) {
+#pragma unroll
+        for (int it = 0; it < NKC; it++) {
+            const int idx = tid + it * 256, row = idx / CHK, c = idx % CHK;
+            kreg[it] = kv_load8<Q8>(kc, row_bytes, min(32 * kb + row, n_ctx - 1), hoff + 8 * c);
+        }
+    };
+    auto kstage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NKC; it++) {
+            const int idx = tid + it * 256, row = idx / CHK, c = idx % CHK;
+            *reinterpret_cast<half8v *>(Ks2[buf] + (size_t)row * (HD * 2) + (size_t)((c ^ f2_swz<HD>(row)) << 4)) = kreg[it];
+        }
+    };
+    constexpr int KPI = 256 / CHK;           // keys staged per pass of the workgroup
+    constexpr int NIT = (32 + KPI - 1) / KPI;
+    half8v vreg[NIT];
+    const int vpar = tid & 1, vpair = (tid >> 1) & 7;
+    const int vch = ((tid >> 4) & 3) + 4 * ((tid >> 6) % (CHK / 4));
+    const int vkey0 = 16 * ((tid >> 6) / (CHK / 4)) + 2 * vpair;                  // even key of the lane pair within a pass
+    auto vload = [&](int kb) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int key = min(vkey0 + vpar + it * KPI, 31);
+            vreg[it] = kv_load8<Q8>(vc, row_bytes, min(32 * kb + key, n_ctx - 1), hoff + 8 * vch);
+        }
+    };
+    auto swap1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); };   // lane ^ 1 (quad_perm [1, 0, 3, 2])
+    auto vstage = [&](int buf) {             // lane pairs trade halves of their rows: (even key, odd key) dwords of 4 dims
+        half_t *Vt = Vt2[buf];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const u32x4v w = __builtin_bit_cast(u32x4v, vreg[it]);
+            const uint32_t m0 = vpar ? w[2] : w[0], m1 = vpar ? w[3] : w[1];
+            const uint32_t r0 = swap1(vpar ? w[0] : w[2]), r1 = swap1(vpar ? w[1] : w[3]);
+            const uint32_t e0 = vpar ? r0 : m0, e1 = vpar ? r1 : m1;              // even key's values
+            const uint32_t o0 = vpar ? m0 : r0, o1 = vpar ? m1 : r1;              // odd key's values
+            const int key = vkey0 + it * KPI;
+            if (key < 32) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(Vt + (size_t)(8 * vch + 4 * vpar) * F2_VROW + f2_col(key));
+                dst[0 * F2_VROW / 2] = (e0 & 0xFFFFu) | (o0 << 16);
+                dst[1 * F2_VROW / 2] = (e0 >> 16) | (o0 & 0xFFFF0000u);
+                dst[2 * F2_VROW / 2] = (e1 & 0xFFFFu) | (o1 << 16);
+                dst[3 * F2_VROW / 2] = (e1 >> 16) | (o1 & 0xFFFF0000u);
+            }
+        }
+    };
+    // scores of key block kb for this wave's 32 queries: x[r] = kq_scale * half(alpha * q.k (+ ALiBi)), key = 32 kb + row(r)
+    // scores of key block kb for this wave's 32 queries:  x[r] = half(alpha * q.k (+ ALiBi)) as float,  key = 32 kb + row(r);
+    // masked keys: -inf.  exp(kq_scale * x - max) is then exp2(fma(log2(e) * kq_scale, x, c)) with c = -log2(e) * kq_scale * max.
+    // (the kernel is VALU-bound -- ~10 instructions per score and pass against 16 MFMAs per 512 scores -- so the mask is
+    // applied only in blocks that reach past the wave's first query, and the exponent is one fma + v_exp_f32)
+    const float l2e_kq = 1.44269504088896341f * kq_scale;
+    const int full_keys = tw < q_tokens ? min(n_ctx, prefix_len + tw + 1) : 0;   // every query of the wave sees keys below this
+    auto scores = [&](int kb, float (&x)[16]) {
+        const char *Ks = Ks2[kb & 1];
+        f32x16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++) {
+            const half8v kf = *reinterpret_cast<const half8v *>(Ks + (size_t)i * (HD * 2) + (size_t)(((2 * s2 + g) ^ f2_swz<HD>(i)) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s2], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            half_t sv = f2h(alpha * acc[r]);
+            if (alibi) sv = f2h((float)(32 * kb + (r & 3) + 8 * (r >> 2) + 4 * g) * mk + h2f(sv));
+            x[r] = h2f(sv);
+        }
+        if (32 * kb + 32 > full_keys) {                   // (wave-uniform: only the blocks on the causal edge)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (32 * kb + (r & 3) + 8 * (r >> 2) + 4 * g >= n_valid) x[r] = -INFINITY;
+        }
+    };
+    auto exp2_fast = [](float v) { return __builtin_amdgcn_exp2f(v); };
+
+    // ---- pass 1: running max / sum of every query over its keys
+    float m = -INFINITY, sum = 0.0f;
+    kload(0);
+    kstage(0);
+    kload(min(1, nkb - 1));
+    __syncthreads();
+    for (int kb = 0; kb < nkb; kb++) {
+        kstage((kb + 1) & 1);                // (block kb + 1, or a harmless repeat of the last one)
+        kload(min(kb + 2, nkb - 1));
+        if (kb < wave_nkb) {
+            float x[16];
+            scores(kb, x);
+            float bm = x[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) bm = fmaxf(bm, x[r]);
+            if (bm > m) { sum *= exp2_fast(l2e_kq * (m - bm)); m = bm; }             // (m = -inf: sum is 0 and stays 0)
+            if (m > -INFINITY) {
+                const float c = -l2e_kq * m;
+#pragma unroll
+                for (int r = 0; r < 16; r++) sum += exp2_fast(__builtin_fmaf(l2e_kq, x[r], c));   // masked: 2^-inf = 0
+            }
+        }
+        __syncthreads();
+    }
+    float M, inv;
+    {
+        const float m2 = __shfl_xor(m, 32), s2v = __shfl_xor(sum, 32);
+        M = fmaxf(m, m2);
+        const float tot = (m > -INFINITY ? sum * exp2_fast(l2e_kq * (m - M)) : 0.0f) + (m2 > -INFINITY ? s2v * exp2_fast(l2e_kq * (m2 - M)) : 0.0f);
+        inv = tot > 0.0f ? 1.0f / tot : 0.0f;
+    }
+    // ---- pass 2: P = half(half(exp(x - M)) / sum) from recomputed scores, O^T += V^T . P^T
+    f32x16v oacc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[nt][r] = 0.0f;
+    kload(0);
+    vload(0);
+    kstage(0);
+    vstage(0);
+    kload(min(1, nkb - 1));
+    vload(min(1, nkb - 1));
+    __syncthreads();
+    for (int kb = 0; kb < nkb; kb++) {
+        kstage((kb + 1) & 1);
+        vstage((kb + 1) & 1);
+        kload(min(kb + 2, nkb - 1));
+        vload(min(kb + 2, nkb - 1));
+        if (kb < wave_nkb) {
+            const half_t *Vt = Vt2[kb & 1];
+            float x[16];
+            scores(kb, x);
+            half8v pb[2];
+            const float c = M > -INFINITY ? -l2e_kq * M : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const half_t e = f2h(exp2_fast(__builtin_fmaf(l2e_kq, x[r], c)));       // masked keys: 2^-inf = 0
+                pb[r >> 3][r & 7] = f2h(h2f(e) * inv);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const half8v vf = *reinterpret_cast<const half8v *>(Vt + (size_t)(32 * nt + i) * F2_VROW + 16 * s2 + 8 * g);
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pb[s2], oacc[nt], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    if (tq < q_tokens) {
+        half_t *orow = out + ((size_t)tq * heads + h) * HD;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+                half4v o4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o4[e] = f2h(oacc[nt][4 * j + e]);
+                *reinterpret_cast<half4v *>(orow + 32 * nt + 8 * j + 4 * g) = o4;
+            }
+    }
+}
+
 } // namespace ifa
 
 using namespace ifa;
@@ -395,6 +619,24 @@ static int sg_workspace(hipStream_t s, size_t bytes, half_t **out)
     return IFA_OK;
 }
 
+static int g_attn_2pass_min = 128;       // chunks of at least this many queries take k_attention_2pass (ifa_attention_two_pass_min) ...
+static int g_attn_2pass_min_keys = 1024; // ... once the context reaches this many keys (below, the staged kernel's 32-query tiles fill the chip better:
+                                         // 1024 tokens 75 vs 77 us, 1536: 126 vs 210, 2048: 176 vs 334, 4096: 522 vs 1202 -- Llama-2-7B heads, profiles/r02_attention_two_pass.log)
+
+extern "C" int ifa_attention_two_pass_min(int min_tokens)
+{
+    const int prev = g_attn_2pass_min;
+    if (min_tokens >= 0) g_attn_2pass_min = min_tokens > 0 ? min_tokens : (1 << 30);
+    return prev;
+}
+
+extern "C" int ifa_attention_two_pass_min_keys(int min_keys)
+{
+    const int prev = g_attn_2pass_min_keys;
+    if (min_keys >= 0) g_attn_2pass_min_keys = min_keys;
+    return prev;
+}
+
 extern "C" int ifa_debug_attn_trace(unsigned long long *out8)
 {
     IFA_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ifa::g_attn_trace), 64));
@@ -435,6 +677,18 @@ extern "C" int ifa_attention(const void *q, const void *kcache, const void *vcac
     IFA_REQUIRE(n_ctx <= 65536 && q_tokens <= 65535, "ifa_attention: context too long for the op-level kernel");
     IFA_REQUIRE(kq_scale > 0, "ifa_attention: kq_scale must be > 0");
     const int total_heads = alibi_total_heads > 0 ? alibi_total_heads : heads;
+    // long prompts: two passes over the keys, 128 queries per workgroup (no score tile)
+    if (q_tokens >= g_attn_2pass_min && n_ctx >= g_attn_2pass_min_keys && (head_dim == 64 || head_dim == 128)) {
+        hipStream_t hs = ifa_s(stream);
+        dim3 grid((unsigned)((q_tokens + F2_QT - 1) / F2_QT), (unsigned)heads);
+#define IFA_F2A(HDV, Q8V) k_attention_2pass<HDV, Q8V><<<grid, dim3(256), 0, hs>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens, \
+                                                                                 prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, (half_t *)out)
+        if (head_dim == 128) { if (kv_dtype == Q8_B32T2) IFA_F2A(128, true); else IFA_F2A(128, false); }
+        else { if (kv_dtype == Q8_B32T2) IFA_F2A(64, true); else IFA_F2A(64, false); }
+#undef IFA_F2A
+        IFA_LAUNCH_CHECK();
+        return IFA_OK;
+    }
     // prefill: MFMA tiles whenever the [32 x n_keys] score tile fits the 160 KiB LDS (~2300 keys)
     const size_t smem_mfma = (size_t)PF_QT * pf_nkp(n_ctx) * 2 + (size_t)head_dim * PF_VROW * 2 + 64;
     if (q_tokens >= 4 && smem_mfma <= 150 * 1024 && (head_dim == 32 || head_dim == 64 || head_dim == 128)) {

@@ -497,6 +497,28 @@ def test_fused_short_prompt_layer_matches_op_by_op_layer(kvd, T):
     wk.close()
 
 
+def test_1100_token_prompt_two_pass_attention_matches_oracle():
+    """Past 1024 keys a chunk of >= 128 queries takes the two-pass attention kernel (csrc/ifa_attn.hip, k_attention_2pass:
+    128 queries per workgroup, scores recomputed in the second pass) inside the four-launch prefill layer: the last rows'
+    logits of a 1100-token prompt and the decode steps behind it against the oracle."""
+    max_ctx = 1152
+    wk, host, s = synth.build("test_gqa", dt.Q4_B32T1A, dt.F16, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
+    om = oracle_model_from_host(host, s, max_ctx, dt.F16)
+    V = s["vocab"]
+    prompt = np.random.default_rng(33).integers(3, V, 1100).astype(np.int32)
+    lg = torch.empty((len(prompt), V), dtype=torch.float16, device="cuda")
+    tok = wk.forward(prompt, 0, lg)
+    tok_orc, lg_orc = om.forward(prompt, 0, nthreads=8)
+    a = g.host(lg).astype(np.float32)
+    for rows in (slice(0, 64), slice(1000, 1100)):
+        cos, mad = _logits_close(a[rows], lg_orc[rows])
+        assert cos >= 0.9995 and mad <= 0.03, (rows, cos, mad)
+    top = np.sort(lg_orc[-1].astype(np.float32))
+    if top[-1] - top[-2] > LOGIT_TOL:
+        assert tok == tok_orc
+    wk.close()
+
+
 @pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["kvf16", "kvq8"])
 def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd):
     """Prompts above 128 tokens run a layer's linears as four launches of the large-tile GEMM (csrc/ifa_gemm.hip, k_gemm_big:

@@ -8,6 +8,8 @@ from tests import gpu_util as g
 L = ia.lib()
 L.ifa_debug_attn_trace.argtypes = [C.c_void_p]
 T, heads, hd = int(os.environ.get("T", "1024")), 32, 128
+if "KEYS" in os.environ: L.ifa_attention_two_pass_min_keys(int(os.environ["KEYS"]))
+if "QMIN" in os.environ: L.ifa_attention_two_pass_min(int(os.environ["QMIN"]))
 q = (torch.randn(T, heads * hd, device="cuda") * 0.5).half()
 kc = (torch.randn(T, heads * hd, device="cuda") * 0.5).half()
 vc = (torch.randn(T, heads * hd, device="cuda") * 0.5).half()
