@@ -358,24 +358,27 @@ typedef const __attribute__((address_space(1))) void pf_glb_t;
 // same BN / 2 rows of w3; the w3 half of the waves hands its products over through LDS; Y = half(act(y1)) * y3).
 struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; };
 
-template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN>
+template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN, int BK = PF_BK>
 __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const BigGeo G)
 {
+    // BK: columns per K step -- 64, or 128 for 128 x 128 tiles that run one workgroup per CU (half the barriers per product)
+    constexpr int ROWB = BK * 2, CPR = BK / 8, RPP = 1024 / ROWB;     // LDS row bytes, 16-byte chunks per row, rows per direct-to-LDS piece
+    auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : (r & 15); };
     constexpr bool GLU = EPI == GM_GLU;
     constexpr int BNE = GLU ? BN / 2 : BN;              // rows of ONE matrix per weight tile
     const int T = P.T, K = G.K, nblk = P.nblk, tiles_m = G.tiles_m;
     const half_t *__restrict__ X = P.X;
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int CAP = (DT == F16) ? 32 : block_capacity(DT);
-    constexpr int BPS = PF_BK / CAP;                    // quant blocks per row and step
+    constexpr int BPS = BK / CAP;                       // quant blocks per row and step
     constexpr int CPB = CAP / 8;                        // 16-byte chunks of halfs per block
     constexpr int NB = BN * BPS;                        // blocks of the weight tile per step
     constexpr int WB = (NB + NT - 1) / NT;              // blocks a thread dequantises per step
     constexpr int TA = BM / WM / 32, TB = BN / WN / 32; // 32 x 32 accumulator tiles per wave
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int NA = 2;
-    constexpr int AI = BM / 8 / NW;                     // direct-to-LDS instructions per wave and step (8 rows each)
-    static_assert(BPS >= 1 && BM % (16 * NW) == 0, "tile geometry");
+    constexpr int AI = BM / RPP / NW;                   // direct-to-LDS instructions per wave and step (1 KB = RPP rows each)
+    static_assert(BPS >= 1 && BM % (2 * RPP * NW) == 0 && (BK == 64 || BK == 128), "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -397,30 +400,34 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     const int N = set == 0 ? P.rows[0] : (set == 1 ? P.rows[1] : P.rows[2]);
     const uint8_t *__restrict__ W = set == 0 ? P.W[0] : (set == 1 ? P.W[1] : P.W[2]);
     const half_t *__restrict__ bias = set == 0 ? P.bias[0] : (set == 1 ? P.bias[1] : P.bias[2]);
-    const int nsteps = K / PF_BK;
+    const int nsteps = K / BK;
     // ---- activation tile: per-lane source pointers of this wave's 8-row pieces
     const half_t *xsrc[AI];
 #pragma unroll
     for (int j = 0; j < AI; j++) {
-        const int row = (wave * AI + j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = (wave * AI + j) * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ swz(row);
         xsrc[j] = X + (size_t)min(t0 + row, T - 1) * P.ldx + c * 8;
     }
     auto stage_x = [&](int step, int buf, int j0, int j1) {
 #pragma unroll
         for (int j = j0; j < j1; j++)
-            __builtin_amdgcn_global_load_lds((pf_glb_t *)(xsrc[j] + (size_t)step * PF_BK),
+            __builtin_amdgcn_global_load_lds((pf_glb_t *)(xsrc[j] + (size_t)step * BK),
                                              (pf_lds_t *)(smem + (size_t)buf * A_BYTES + (size_t)(wave * AI + j) * 1024), 16, 0, 0);
     };
-    // ---- weight tile: one (row, block) per thread and j
+    // ---- weight tile: (row, block) slots over the threads.  BK = 64: two blocks of a row on adjacent lanes, rows in the
+    // order of pf_row_of; BK = 128: consecutive lanes take consecutive rows of ONE block column (8 lanes of a
+    // ds_write_b128 group: 8 different swizzle values) -- both orders are conflict-free on the stores
+    auto slot_row = [](int idx) { return BK == 64 ? pf_row_of(idx / BPS) : idx % BN; };
+    auto slot_blk = [](int idx) { return BK == 64 ? idx % BPS : idx / BN; };
     WRaw<DT, CAP> wr[WB];
     auto fetch_w = [&](int step) {
 #pragma unroll
         for (int j = 0; j < WB; j++) {
             const int idx = min(tid + j * NT, NB - 1);
-            const int nl = pf_row_of(idx / BPS);
-            if constexpr (GLU) wr[j].load(nl < BNE ? W : P.W1, (size_t)min(n0 + (nl < BNE ? nl : nl - BNE), N - 1), nblk, step * BPS + idx % BPS);
-            else wr[j].load(W, (size_t)min(n0 + nl, N - 1), nblk, step * BPS + idx % BPS);
+            const int nl = slot_row(idx), bb = slot_blk(idx);
+            if constexpr (GLU) wr[j].load(nl < BNE ? W : P.W1, (size_t)min(n0 + (nl < BNE ? nl : nl - BNE), N - 1), nblk, step * BPS + bb);
+            else wr[j].load(W, (size_t)min(n0 + nl, N - 1), nblk, step * BPS + bb);
         }
     };
     // the raw bytes of the block(s) being dequantised this step (wr is refilled for the step after next meanwhile);
@@ -441,7 +448,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
         for (int j = 0; j < WB; j++) {
             const int idx = tid + j * NT;
             if (NB % NT != 0 && idx >= NB) continue;
-            const int nl = pf_row_of(idx / BPS), b = idx % BPS;
+            const int nl = slot_row(idx), b = slot_blk(idx);
 #pragma unroll
             for (int m = m0; m < m1; m++) {
                 half8_t h;
@@ -450,15 +457,15 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
 #pragma unroll
                     for (int e = 0; e < 8; e++) h[e] = wv[j][8 * m + e];
                 }
-                *reinterpret_cast<half8_t *>(Bs + (size_t)nl * 128 + (size_t)(((b * CPB + m) ^ ((nl >> 1) & 7)) << 4)) = h;
+                *reinterpret_cast<half8_t *>(Bs + (size_t)nl * ROWB + (size_t)(((b * CPB + m) ^ swz(nl)) << 4)) = h;
             }
         }
     };
     // ---- fragments: lane (i, g) reads row i of a 32-row tile, chunk 2 * ks + g
     const int i = lane & 31, g = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int lc = g ^ ((i >> 1) & 7);                  // (2 ks + g) ^ swizzle(i) == (2 ks) ^ lc
-    const int a_off = (wm * (BM / WM) + i) * 128, b_off = NA * A_BYTES + (wn * (BN / WN) + i) * 128;
+    const int lc = g ^ swz(i);                          // (2 ks + g) ^ swizzle(i) == (2 ks) ^ lc  (tile rows start at multiples of 32)
+    const int a_off = (wm * (BM / WM) + i) * ROWB, b_off = NA * A_BYTES + (wn * (BN / WN) + i) * ROWB;
     f32x16_t acc[TA][TB];
 #pragma unroll
     for (int a = 0; a < TA; a++)
@@ -477,9 +484,9 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
         const char *As = smem + (size_t)buf * A_BYTES, *Bs = smem + (size_t)buf * B_BYTES;
         const int so = ((2 * ks) ^ lc) << 4;
 #pragma unroll
-        for (int a = 0; a < TA; a++) fa[a] = *reinterpret_cast<const half8_t *>(As + a_off + a * 32 * 128 + so);
+        for (int a = 0; a < TA; a++) fa[a] = *reinterpret_cast<const half8_t *>(As + a_off + a * 32 * ROWB + so);
 #pragma unroll
-        for (int b = 0; b < TB; b++) fb[b] = *reinterpret_cast<const half8_t *>(Bs + b_off + b * 32 * 128 + so);
+        for (int b = 0; b < TB; b++) fb[b] = *reinterpret_cast<const half8_t *>(Bs + b_off + b * 32 * ROWB + so);
     };
     auto mma = [&](const half8_t (&fa)[TA], const half8_t (&fb)[TB]) {
 #pragma unroll
@@ -495,6 +502,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     fetch_w(min(1, nsteps - 1));
     __syncthreads();
     frags(0, 0, af[0], bf[0]);
+    constexpr int NKS = BK / 16;                         // MFMA groups per step (even: the fragment sets alternate cleanly)
     for (int step = 0; step + 1 < nsteps; step++) {
         const int cur = step & 1;
         // the copy is pinned AHEAD of the direct-to-LDS loads: with one of those in flight the compiler waits vmcnt(0) at
@@ -502,17 +510,22 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
         take_w();                                        // (the barrier of the previous step waited for its bytes)
         stage_x(step + 1, cur ^ 1, 0, AI);
         fetch_w(min(step + 2, nsteps - 1));              // a whole step to land; the last one is a harmless repeat
-        frags(cur, 1, af[1], bf[1]); mma(af[0], bf[0]); store_w(cur ^ 1, 0, (CPB + 2) / 3);
-        frags(cur, 2, af[0], bf[0]); mma(af[1], bf[1]); store_w(cur ^ 1, (CPB + 2) / 3, (2 * CPB + 2) / 3);
-        frags(cur, 3, af[1], bf[1]); mma(af[0], bf[0]); store_w(cur ^ 1, (2 * CPB + 2) / 3, CPB);
+#pragma unroll
+        for (int ks = 0; ks + 1 < NKS; ks++) {
+            frags(cur, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+            mma(af[ks & 1], bf[ks & 1]);
+            store_w(cur ^ 1, (ks * CPB + NKS - 2) / (NKS - 1), ((ks + 1) * CPB + NKS - 2) / (NKS - 1));
+        }
         __syncthreads();
         frags(cur ^ 1, 0, af[0], bf[0]); mma(af[1], bf[1]);
     }
     {
         const int cur = (nsteps - 1) & 1;
-        frags(cur, 1, af[1], bf[1]); mma(af[0], bf[0]);
-        frags(cur, 2, af[0], bf[0]); mma(af[1], bf[1]);
-        frags(cur, 3, af[1], bf[1]); mma(af[0], bf[0]);
+#pragma unroll
+        for (int ks = 0; ks + 1 < NKS; ks++) {
+            frags(cur, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+            mma(af[ks & 1], bf[ks & 1]);
+        }
         mma(af[1], bf[1]);
     }
     // ---- epilogue
@@ -608,22 +621,22 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         for (int i = 0; i < P.nsets; i++) n += ifa_cdiv((size_t)P.rows[i], bne);
         return n;
     };
-    auto run = [&](auto bm, auto bn, auto wm, auto wn, int tn0, int tn_count) {      // weight tiles [tn0, tn0 + tn_count)
-        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value, WM = decltype(wm)::value, WN = decltype(wn)::value;
+    auto run = [&](auto bm, auto bn, auto wm, auto wn, int tn0, int tn_count, auto bk) {      // weight tiles [tn0, tn0 + tn_count)
+        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value, WM = decltype(wm)::value, WN = decltype(wn)::value, BK = decltype(bk)::value;
         constexpr int BNE = EPI == GM_GLU ? BN / 2 : BN;
         BigGeo G;
         G.tile0[0] = 0;
         for (int i = 0; i < 3; i++) G.tile0[i + 1] = G.tile0[i] + (i < P.nsets ? (int)ifa_cdiv((size_t)P.rows[i], (size_t)BNE) : 0);
         for (int i = P.nsets; i < 3; i++) G.tile0[i] = 1 << 30;        // (absent sets are never selected)
         G.tiles_m = (int)ifa_cdiv(T, (size_t)BM); G.K = P.nblk * CAP; G.tn0 = tn0;
-        const size_t smem = std::max(2 * (size_t)(BM + BN) * 128, (size_t)BM * (BN * 2 + 64));      // operand tiles; the epilogue's output tile
-        auto kern = k_gemm_big<DT, BM, BN, WM, WN, EPI>;
+        const size_t smem = std::max(2 * (size_t)(BM + BN) * (BK * 2), (size_t)BM * (BN * 2 + 64));      // operand tiles; the epilogue's output tile
+        auto kern = k_gemm_big<DT, BM, BN, WM, WN, EPI, BK>;
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
         kern<<<dim3((unsigned)(G.tiles_m * tn_count)), dim3(WM * WN * 64), smem, s>>>(P, G);
     };
     using std::integral_constant;
-    typedef integral_constant<int, 256> I256; typedef integral_constant<int, 128> I128; typedef integral_constant<int, 2> I2; typedef integral_constant<int, 4> I4;
+    typedef integral_constant<int, 256> I256; typedef integral_constant<int, 128> I128; typedef integral_constant<int, 2> I2; typedef integral_constant<int, 4> I4; typedef integral_constant<int, 64> K64;
     const int force = (g_gemm_big >> 8) & 3;        // (measurement: 1 / 2 / 3 force a tile shape)
     auto rounds = [&](size_t bm, size_t bn, size_t per_cu) { return (double)ifa_cdiv(ifa_cdiv(T, bm) * ntiles(bn), cus * per_cu); };
     // 256 x 256: whole rounds of the chip; what is left of the last round goes to a second launch of 128-token tiles when
@@ -639,13 +652,13 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
     if (!pick) pick = (c256 <= c128x256 && c256 <= c128) ? 1 : (c128x256 <= c128 ? 2 : 3);
     if (pick == 1 && CAP <= 32) {
         if (split && !force) {
-            run(I256(), I256(), I2(), I4(), 0, (int)full_n);
-            run(I128(), I256(), I2(), I4(), (int)full_n, (int)rem_n);
-        } else run(I256(), I256(), I2(), I4(), 0, (int)tn256);
+            run(I256(), I256(), I2(), I4(), 0, (int)full_n, K64());
+            run(I128(), I256(), I2(), I4(), (int)full_n, (int)rem_n, K64());
+        } else run(I256(), I256(), I2(), I4(), 0, (int)tn256, K64());
     } else if (pick == 2 || pick == 1)
-        run(I128(), I256(), I2(), I4(), 0, (int)tn256);
+        run(I128(), I256(), I2(), I4(), 0, (int)tn256, K64());
     else
-        run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128));
+        run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64());      // (K steps of 128 columns -- BK = 128 -- measured: 57 -> 72 us at 1024 x 4096 x 4096)
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
