@@ -1232,6 +1232,13 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         if ((rc = lin(P, T_WO, GM_RESIDUAL, 0))) return rc;
         clear();
         if (!norm_fused && (rc = norm_rows(m, m->a, T, L.t[T_FFN_NORM], pf_big ? L.t[T_FFN_NORM_B] : nob, m->hn, c.ffn_norm_base))) return rc;
+        if (c.experts > 0 && L.t[T_MOE_GATE].present()) {      // (pf_big only) mixture of experts: the attention half fused, the expert FFNs device-routed
+            if ((rc = moe_ffn(m, L, m->hn, T))) return rc;
+            if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
+            std::swap(m->x, m->f);
+            x = m->x;
+            continue;
+        }
         P.W[0] = wp(T_W1); P.W1 = wp(T_W3); P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
         P.X = norm_fused ? m->a : m->hn; P.ldx = (int)D;
         if (norm_fused) { P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.multi_base = c.ffn_norm_base; }
@@ -1439,15 +1446,18 @@ static bool batch_fused_ok(const ifa_model *m, int n)
 static bool prefill_big_ok(const ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
-    if (!m->opt_prefill_big || m->topo || c.experts > 0 || c.parallel_attn || c.share_input) return false;
+    if (!m->opt_prefill_big || m->topo || c.parallel_attn || c.share_input) return false;
     if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale)) return false;
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, F = c.ffn;
     if (D % 64 || QD % 64 || F % 64) return false;
     for (const Layer &L : m->layers) {
+        const bool moe = c.experts > 0 && L.t[T_MOE_GATE].present();      // MoE layers: the attention half is fused, the FFN runs moe_ffn
         const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
-        for (int id : ids)
+        for (int id : ids) {
+            if (moe && (id == T_W1 || id == T_W3 || id == T_W2)) continue;
             if (!L.t[id].present() || !L.t[id].data || (L.t[id].dtype != Q4_B32T1A && L.t[id].dtype != Q4_B32T1B)) return false;
-        if (L.t[T_WK].dtype != L.t[T_WQ].dtype || L.t[T_WV].dtype != L.t[T_WQ].dtype || L.t[T_W3].dtype != L.t[T_W1].dtype) return false;
+        }
+        if (L.t[T_WK].dtype != L.t[T_WQ].dtype || L.t[T_WV].dtype != L.t[T_WQ].dtype || (!moe && L.t[T_W3].dtype != L.t[T_W1].dtype)) return false;
         if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present()) return false;
     }
     return true;

@@ -342,8 +342,10 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_q(const uint8_t *__restrict__ 
 //  * both LDS images are [rows][64 halfs] with the eight 16-byte chunks of row r at slot c ^ ((r >> 1) & 7): the
 //    fragment reads of 16 consecutive lanes (16 rows, one chunk) cover all 64 banks once.  The direct loads write LDS
 //    linearly, so the permutation is applied to their SOURCE addresses (cdna_hip_programming.md 5.4 rule 21);
-//  * workgroup ids are dealt to the 8 XCDs round-robin: the id is remapped so that an XCD works on consecutive tiles
-//    (token tiles fastest: the tiles of one XCD share weight rows in its L2).
+//  * workgroup ids are dealt to the 8 XCDs round-robin: the id is remapped so that an XCD works on a compact block of
+//    tiles (bands of 1024 tokens x a few weight tiles) whose operand tiles its L2 shares;
+//  * the step's barrier sits before the last MFMA group of the step (see the K loop), the epilogue rounds the products
+//    to F16, parks them in an LDS tile and writes 16-byte pieces of output rows (residual / GLU applied on the way out).
 // Same arithmetic as k_gemm_q: fp32 accumulation of half products in ascending 16-column groups, one F16 rounding, bias as a half add.
 constexpr int PF_BK = 64;
 // weight-tile row of the p-th (row, block) slot: 8 consecutive lanes (4 slots x 2 blocks: one ds_write_b128 group) take
@@ -355,7 +357,7 @@ typedef const __attribute__((address_space(1))) void pf_glb_t;
 // Launch arguments: GmArgs (ifa_gemm_rows_mfma.h -- up to three matrices as one row space, per-set or virtual-row
 // outputs, bias, residual, GLU pair; W[] / W1 are REFERENCE-layout rows here) + the tile geometry.
 // EPI: GM_PLAIN | GM_RESIDUAL (Y = half(res + y), TensorOpr::Add) | GM_GLU (a weight tile = BN / 2 rows of w1 and the
-// same BN / 2 rows of w3; the w3 half of the waves hands its products over through LDS; Y = half(act(y1)) * y3).
+// same BN / 2 rows of w3, both halves meet in the epilogue's LDS tile: Y = half(half(act(y1)) * y3)).
 struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; };
 
 template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN, int BK = PF_BK>
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     constexpr int WB = (NB + NT - 1) / NT;              // blocks a thread dequantises per step
     constexpr int TA = BM / WM / 32, TB = BN / WN / 32; // 32 x 32 accumulator tiles per wave
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    constexpr int NA = 2;
+    constexpr int NA = 2;                               // LDS: NA activation buffers, then 2 weight buffers
     constexpr int AI = BM / RPP / NW;                   // direct-to-LDS instructions per wave and step (1 KB = RPP rows each)
     static_assert(BPS >= 1 && BM % (2 * RPP * NW) == 0 && (BK == 64 || BK == 128), "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -519,14 +519,15 @@ def test_1100_token_prompt_two_pass_attention_matches_oracle():
     wk.close()
 
 
-@pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["kvf16", "kvq8"])
-def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd):
+@pytest.mark.parametrize("kvd,shape", [(dt.F16, "test_gqa"), (dt.Q8_B32T2, "test_gqa"), (dt.F16, "test_moe")], ids=["kvf16", "kvq8", "moe"])
+def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd, shape):
     """Prompts above 128 tokens run a layer's linears as four launches of the large-tile GEMM (csrc/ifa_gemm.hip, k_gemm_big:
     wq | wk | wv into q / k / v, wo + residual, w1 / w3 + GLU, w2 + residual; forward_ops, pf_big) -- a 170-token prompt and
     a 160-token continuation of it against the oracle (src/transformer/inference_worker.cc:640-1050) and against the
-    op-by-op layer of the same library (prefill_big = 0), then decode steps on the cache it wrote."""
+    op-by-op layer of the same library (prefill_big = 0), then decode steps on the cache it wrote.  Mixture-of-experts
+    layers: the attention half as two such launches, the expert FFNs device-routed over the rows (moe_ffn)."""
     max_ctx = 400
-    wk, host, s = synth.build("test_gqa", dt.Q4_B32T1A, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
+    wk, host, s = synth.build(shape, dt.Q4_B32T1A, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
     om = oracle_model_from_host(host, s, max_ctx, kvd)
     V = s["vocab"]
     prompt = np.random.default_rng(21).integers(3, V, 330).astype(np.int32)
@@ -541,8 +542,16 @@ def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd):
             tok = wk.forward(prompt[a:b], a, lg)
             outs.append((tok, g.host(lg).astype(np.float32)))
         lgs[big] = outs
+    moe = shape == "test_moe"
     for ci, (a, b) in enumerate(chunks):
         tok_orc, lg_orc = om.forward(prompt[a:b], a, nthreads=4)
+        if moe:
+            # a router probability pair closer than the kernels' rounding noise sends a row to another expert (in any of the
+            # three implementations): rows are compared one by one and a few such rows are allowed
+            for other, tol in ((lg_orc, 0.03), (lgs[0][ci][1], 0.02)):
+                rowmax = np.abs(lgs[1][ci][1] - other.astype(np.float32)).max(axis=1)
+                assert np.mean(rowmax <= tol) >= 0.96, (ci, tol, np.sort(rowmax)[-8:])
+            continue
         cos, mad = _logits_close(lgs[1][ci][1], lg_orc)
         assert cos >= 0.9995 and mad <= 0.03, (ci, cos, mad)
         cos2, mad2 = _logits_close(lgs[1][ci][1], lgs[0][ci][1])
@@ -550,6 +559,9 @@ def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd):
         top = np.sort(lg_orc[-1].astype(np.float32))
         if top[-1] - top[-2] > LOGIT_TOL:
             assert lgs[1][ci][0] == tok_orc, ci
+    if moe:
+        wk.close()
+        return
     # the op-by-op run came last: rebuild the cache with the large-tile layer, then decode against the oracle
     wk.set_option("prefill_big", 1)
     wk.reset()
