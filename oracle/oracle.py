@@ -40,6 +40,7 @@ def build(force=False):
     ref_src = os.environ.get("IFA_REFERENCE", "/root/reference")
     need_ref = os.path.exists(os.path.join(ref_src, "src/common/quantization.h")) and (
         force or not os.path.exists(ref_so) or not os.path.exists(os.path.join(_HERE, "_ref", "ifa_ref_sampling"))
+        or not os.path.exists(os.path.join(_HERE, "_ref", "ifa_ref_moe_rows"))
         or os.path.getmtime(os.path.join(_HERE, "ref_quant_wrap.cc")) > os.path.getmtime(ref_so))
     if stale or need_ref:
         subprocess.check_call(["make", "-C", _HERE, "REF=" + ref_src], stdout=subprocess.DEVNULL)
