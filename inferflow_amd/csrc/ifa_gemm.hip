@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <cstring>
+#include <atomic>
 #include "ifa_host.h"
 #include "ifa_codec.h"
 #include "ifa_moe.h"
@@ -633,8 +634,16 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         G.tiles_m = (int)ifa_cdiv(T, (size_t)BM); G.K = P.nblk * CAP; G.tn0 = tn0;
         const size_t smem = std::max(2 * (size_t)(BM + BN) * (BK * 2), (size_t)BM * (BN * 2 + 64));      // operand tiles; the epilogue's output tile
         auto kern = k_gemm_big<DT, BM, BN, WM, WN, EPI, BK>;
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+        // (function attributes are per device: one bit per device of this instantiation -- the C++ engine drives several GPUs
+        // from one process)
+        static std::atomic<uint64_t> attr_set{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr_set.fetch_or(bit, std::memory_order_relaxed);
+        }
         kern<<<dim3((unsigned)(G.tiles_m * tn_count)), dim3(WM * WN * 64), smem, s>>>(P, G);
     };
     using std::integral_constant;
