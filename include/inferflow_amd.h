@@ -172,9 +172,10 @@ int ifa_attention(const void *q_f16, const void *kcache, const void *vcache, int
                   int n_ctx, int q_tokens, int prefix_len, int heads, int kv_heads, int head_dim,
                   float kq_scale, int alibi, int alibi_base_head, int alibi_total_heads,
                   void *out_f16, ifa_stream stream);
-/* chunks of at least min_tokens queries (default 128; 0 = never, < 0 only queries) on contexts of at least min_keys keys
- * (default 1024) take the two-pass kernel: 128 queries per workgroup, K / V blocks staged once per tile, scores recomputed
- * in the second pass instead of a [queries x keys] tile; head_dim 64 / 128.  Same rounding points as the staged kernel.
+/* chunks of at least min_tokens queries (default 64; 0 = never, < 0 only queries) take the two-pass kernels: K / V blocks staged
+ * once per query tile, scores recomputed in the second pass instead of a [queries x keys] tile; head_dim 64 / 128; same rounding
+ * points as the staged 32-query kernel.  Default variant: 64 queries per workgroup, the key blocks split over wave pairs;
+ * on contexts of at least min_keys keys (default: never) chunks of >= 128 queries take the 128-query variant instead.
  * Each returns its previous threshold. */
 int ifa_attention_two_pass_min(int min_tokens);
 int ifa_attention_two_pass_min_keys(int min_keys);

@@ -567,6 +567,263 @@ __global__ void __launch_bounds__(256, 2) k_attention_2pass(const half_t *__rest
     }
 }
 
+template <int HD, bool Q8>
+__global__ void __launch_bounds__(256, 2) k_attention_2pass_ks(const half_t *__restrict__ q, const uint8_t *__restrict__ kc,
+                                                         const uint8_t *__restrict__ vc, int n_ctx, int q_tokens,
+                                                         int prefix_len, int heads, int kv_heads, float kq_scale,
+                                                         int alibi, int alibi_base, int alibi_total, half_t *__restrict__ out)
+{
+    static_assert(HD == 128 || HD == 64, "two-pass attention: head_dim 64 / 128");
+    constexpr int KS = HD / 16, NT = HD / 32, CHK = HD / 8;
+    constexpr int NKC = 32 * CHK / 256;              // 16-byte chunks of the K block per thread
+    // 64 queries per workgroup: waves 0 / 1 take the even key blocks for queries 0-31 / 32-63, waves 2 / 3 the odd ones; a
+    // stage is TWO key blocks (one barrier per 64 keys), the halves' running max / sum and output tiles meet through LDS
+    constexpr int KBYTES = 32 * HD * 2, VHALFS = HD * F2_VROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];                   // [2 stages][2 parities] K blocks, then V blocks
+    auto KsP = [&](int buf, int p) { return smem + (size_t)(buf * 2 + p) * KBYTES; };
+    auto VtP = [&](int buf, int p) { return reinterpret_cast<half_t *>(smem + (size_t)4 * KBYTES) + (size_t)(buf * 2 + p) * VHALFS; };
+    int tile = blockIdx.x, h = blockIdx.y;
+    if (heads % 8 == 0) {            // an XCD keeps a fixed eighth of the heads (their K / V in ONE L2); longest tiles first
+        const int w = blockIdx.y * gridDim.x + blockIdx.x, xcd = w & 7, r = w >> 3;
+        h = (r / (int)gridDim.x) * 8 + xcd;
+        tile = (int)gridDim.x - 1 - r % (int)gridDim.x;
+    }
+    const int t0 = tile * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = wave & 1, kp = wave >> 1;          // query half, key-block parity
+    const int i = lane & 31, g = lane >> 5;
+    const int kvh = h / (heads / kv_heads);
+    const int kv_dim = kv_heads * HD;
+    const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
+    const int hoff = kvh * HD;
+    const int n_keys = min(n_ctx, prefix_len + min(t0 + 64, q_tokens));           // causal bound of the whole tile
+    const int nkb = (n_keys + 31) / 32, nit = (nkb + 1) / 2;
+    const int tw = t0 + 32 * qw, tq = tw + i;
+    const int n_valid = tq < q_tokens ? min(n_ctx, prefix_len + tq + 1) : 0;      // keys this lane's query may see
+    const int wave_keys = tw < q_tokens ? min(n_ctx, prefix_len + min(tw + 32, q_tokens)) : 0;
+    const int wave_nkb = (wave_keys + 31) / 32;                                   // blocks past it are fully masked for this wave
+    const float alpha = 1.0f / sqrtf((float)HD) / kq_scale;
+    const float mk = alibi ? alibi_slope(h + alibi_base, alibi_total) : 0.0f;
+
+    half8v qf[KS];
+    {
+        const int tqc = min(tq, q_tokens - 1);
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++)
+            qf[s2] = __builtin_bit_cast(half8v, *reinterpret_cast<const u32x4v *>(q + ((size_t)tqc * heads + h) * HD + 16 * s2 + 8 * g));
+    }
+    // ---- staging: K block rows as they are (swizzled chunks), V block transposed with permuted key columns
+    half8v kreg[2][NKC];
+    auto kload = [&](int itn) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int kb = min(2 * itn + p, nkb - 1);
+#pragma unroll
+            for (int it = 0; it < NKC; it++) {
+                const int idx = tid + it * 256, row = idx / CHK, c = idx % CHK;
+                kreg[p][it] = kv_load8<Q8>(kc, row_bytes, min(32 * kb + row, n_ctx - 1), hoff + 8 * c);
+            }
+        }
+    };
+    auto kstage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int it = 0; it < NKC; it++) {
+                const int idx = tid + it * 256, row = idx / CHK, c = idx % CHK;
+                *reinterpret_cast<half8v *>(KsP(buf, p) + (size_t)row * (HD * 2) + (size_t)((c ^ f2_swz<HD>(row)) << 4)) = kreg[p][it];
+            }
+    };
+    constexpr int KPI = 256 / CHK;           // keys staged per pass of the workgroup
+    constexpr int NIT = (32 + KPI - 1) / KPI;
+    half8v vreg[2][NIT];
+    const int vpar = tid & 1, vpair = (tid >> 1) & 7;
+    const int vch = ((tid >> 4) & 3) + 4 * ((tid >> 6) % (CHK / 4));
+    const int vkey0 = 16 * ((tid >> 6) / (CHK / 4)) + 2 * vpair;                  // even key of the lane pair within a pass
+    auto vload = [&](int itn) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int kb = min(2 * itn + p, nkb - 1);
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int key = min(vkey0 + vpar + it * KPI, 31);
+                vreg[p][it] = kv_load8<Q8>(vc, row_bytes, min(32 * kb + key, n_ctx - 1), hoff + 8 * vch);
+            }
+        }
+    };
+    auto swap1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); };   // lane ^ 1 (quad_perm [1, 0, 3, 2])
+    auto vstage = [&](int buf) {             // lane pairs trade halves of their rows: (even key, odd key) dwords of 4 dims
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        half_t *Vt = VtP(buf, p);
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const u32x4v w = __builtin_bit_cast(u32x4v, vreg[p][it]);
+            const uint32_t m0 = vpar ? w[2] : w[0], m1 = vpar ? w[3] : w[1];
+            const uint32_t r0 = swap1(vpar ? w[0] : w[2]), r1 = swap1(vpar ? w[1] : w[3]);
+            const uint32_t e0 = vpar ? r0 : m0, e1 = vpar ? r1 : m1;              // even key's values
+            const uint32_t o0 = vpar ? m0 : r0, o1 = vpar ? m1 : r1;              // odd key's values
+            const int key = vkey0 + it * KPI;
+            if (key < 32) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(Vt + (size_t)(8 * vch + 4 * vpar) * F2_VROW + f2_col(key));
+                dst[0 * F2_VROW / 2] = (e0 & 0xFFFFu) | (o0 << 16);
+                dst[1 * F2_VROW / 2] = (e0 >> 16) | (o0 & 0xFFFF0000u);
+                dst[2 * F2_VROW / 2] = (e1 & 0xFFFFu) | (o1 << 16);
+                dst[3 * F2_VROW / 2] = (e1 >> 16) | (o1 & 0xFFFF0000u);
+            }
+        }
+      }
+    };
+    // scores of key block kb for this wave's 32 queries: x[r] = kq_scale * half(alpha * q.k (+ ALiBi)), key = 32 kb + row(r)
+    // scores of key block kb for this wave's 32 queries:  x[r] = half(alpha * q.k (+ ALiBi)) as float,  key = 32 kb + row(r);
+    // masked keys: -inf.  exp(kq_scale * x - max) is then exp2(fma(log2(e) * kq_scale, x, c)) with c = -log2(e) * kq_scale * max.
+    // (the kernel is VALU-bound -- ~10 instructions per score and pass against 16 MFMAs per 512 scores -- so the mask is
+    // applied only in blocks that reach past the wave's first query, and the exponent is one fma + v_exp_f32)
+    const float l2e_kq = 1.44269504088896341f * kq_scale;
+    const int full_keys = tw < q_tokens ? min(n_ctx, prefix_len + tw + 1) : 0;   // every query of the wave sees keys below this
+    auto scores = [&](int kb, int buf, float (&x)[16]) {
+        const char *Ks = KsP(buf, kp);
+        f32x16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++) {
+            const half8v kf = *reinterpret_cast<const half8v *>(Ks + (size_t)i * (HD * 2) + (size_t)(((2 * s2 + g) ^ f2_swz<HD>(i)) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s2], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            half_t sv = f2h(alpha * acc[r]);
+            if (alibi) sv = f2h((float)(32 * kb + (r & 3) + 8 * (r >> 2) + 4 * g) * mk + h2f(sv));
+            x[r] = h2f(sv);
+        }
+        if (32 * kb + 32 > full_keys) {                   // (wave-uniform: only the blocks on the causal edge)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (32 * kb + (r & 3) + 8 * (r >> 2) + 4 * g >= n_valid) x[r] = -INFINITY;
+        }
+    };
+    auto exp2_fast = [](float v) { return __builtin_amdgcn_exp2f(v); };
+
+    // ---- pass 1: running max / sum of every query over its keys
+    float m = -INFINITY, sum = 0.0f;
+    kload(0);
+    kstage(0);
+    kload(min(1, nit - 1));
+    __syncthreads();
+    for (int itn = 0; itn < nit; itn++) {
+        const int kb = 2 * itn + kp;
+        kstage((itn + 1) & 1);               // (the next pair of blocks, or a harmless repeat of the last one)
+        kload(min(itn + 2, nit - 1));
+        if (kb < wave_nkb && kb < nkb) {
+            float x[16];
+            scores(kb, itn & 1, x);
+            float bm = x[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) bm = fmaxf(bm, x[r]);
+            if (bm > m) { sum *= exp2_fast(l2e_kq * (m - bm)); m = bm; }             // (m = -inf: sum is 0 and stays 0)
+            if (m > -INFINITY) {
+                const float c = -l2e_kq * m;
+#pragma unroll
+                for (int r = 0; r < 16; r++) sum += exp2_fast(__builtin_fmaf(l2e_kq, x[r], c));   // masked: 2^-inf = 0
+            }
+        }
+        __syncthreads();
+    }
+    float M, inv;
+    {
+        const float m2 = __shfl_xor(m, 32), s2v = __shfl_xor(sum, 32);
+        float Mw = fmaxf(m, m2);
+        float totw = (m > -INFINITY ? sum * exp2_fast(l2e_kq * (m - Mw)) : 0.0f) + (m2 > -INFINITY ? s2v * exp2_fast(l2e_kq * (m2 - Mw)) : 0.0f);
+        // the two key parities of a query meet through LDS (the staging area is idle between the passes)
+        float *ms = reinterpret_cast<float *>(smem);             // [query half][32][2]
+        if (kp == 1 && g == 0) { ms[(qw * 32 + i) * 2] = Mw; ms[(qw * 32 + i) * 2 + 1] = totw; }
+        __syncthreads();
+        M = Mw; inv = 0.0f;
+        if (kp == 0) {
+            const float m1 = ms[(qw * 32 + i) * 2], t1 = ms[(qw * 32 + i) * 2 + 1];
+            M = fmaxf(Mw, m1);
+            const float tot = (Mw > -INFINITY ? totw * exp2_fast(l2e_kq * (Mw - M)) : 0.0f) + (m1 > -INFINITY ? t1 * exp2_fast(l2e_kq * (m1 - M)) : 0.0f);
+            inv = tot > 0.0f ? 1.0f / tot : 0.0f;
+        }
+        __syncthreads();
+        if (kp == 0 && g == 0) { ms[(qw * 32 + i) * 2] = M; ms[(qw * 32 + i) * 2 + 1] = inv; }
+        __syncthreads();
+        if (kp == 1) { M = ms[(qw * 32 + i) * 2]; inv = ms[(qw * 32 + i) * 2 + 1]; }
+        __syncthreads();
+    }
+    // ---- pass 2: P = half(half(exp(x - M)) / sum) from recomputed scores, O^T += V^T . P^T
+    f32x16v oacc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[nt][r] = 0.0f;
+    kload(0);
+    vload(0);
+    kstage(0);
+    vstage(0);
+    kload(min(1, nit - 1));
+    vload(min(1, nit - 1));
+    __syncthreads();
+    for (int itn = 0; itn < nit; itn++) {
+        const int kb = 2 * itn + kp;
+        kstage((itn + 1) & 1);
+        vstage((itn + 1) & 1);
+        kload(min(itn + 2, nit - 1));
+        vload(min(itn + 2, nit - 1));
+        if (kb < wave_nkb && kb < nkb) {
+            const half_t *Vt = VtP(itn & 1, kp);
+            float x[16];
+            scores(kb, itn & 1, x);
+            half8v pb[2];
+            const float c = M > -INFINITY ? -l2e_kq * M : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const half_t e = f2h(exp2_fast(__builtin_fmaf(l2e_kq, x[r], c)));       // masked keys: 2^-inf = 0
+                pb[r >> 3][r & 7] = f2h(h2f(e) * inv);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const half8v vf = *reinterpret_cast<const half8v *>(Vt + (size_t)(32 * nt + i) * F2_VROW + 16 * s2 + 8 * g);
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pb[s2], oacc[nt], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    {   // the odd-parity half hands its output tiles over (staging area: idle after the last barrier)
+        float *os = reinterpret_cast<float *>(smem);             // [query half][NT][16][64]
+        if (kp == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) os[((qw * NT + nt) * 16 + r) * 64 + lane] = oacc[nt][r];
+        }
+        __syncthreads();
+        if (kp == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) oacc[nt][r] += os[((qw * NT + nt) * 16 + r) * 64 + lane];
+        }
+    }
+    if (kp == 0 && tq < q_tokens) {
+        half_t *orow = out + ((size_t)tq * heads + h) * HD;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+                half4v o4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o4[e] = f2h(oacc[nt][4 * j + e]);
+                *reinterpret_cast<half4v *>(orow + 32 * nt + 8 * j + 4 * g) = o4;
+            }
+    }
+}
+
 } // namespace ifa
 
 using namespace ifa;
@@ -619,9 +876,10 @@ static int sg_workspace(hipStream_t s, size_t bytes, half_t **out)
     return IFA_OK;
 }
 
-static int g_attn_2pass_min = 128;       // chunks of at least this many queries take k_attention_2pass (ifa_attention_two_pass_min) ...
-static int g_attn_2pass_min_keys = 1024; // ... once the context reaches this many keys (below, the staged kernel's 32-query tiles fill the chip better:
-                                         // 1024 tokens 75 vs 77 us, 1536: 126 vs 210, 2048: 176 vs 334, 4096: 522 vs 1202 -- Llama-2-7B heads, profiles/r02_attention_two_pass.log)
+static int g_attn_2pass_min = 64;        // chunks of at least this many queries take the two-pass kernels (ifa_attention_two_pass_min)
+static int g_attn_2pass_min_keys = 1 << 30;      // contexts of at least this many keys: the 128-query variant instead of the 64-query one (never by default;
+                                                 // 128 / 256 / 512 / 1024 / 2048 / 4096 tokens: 64-query 11.9 / 16.9 / 27.4 / 60.2 / 165 / 492 us, staged kernel 15.6 / 18.9 / 32.7 / 77 / 334 / 1202,
+                                                 // 128-query variant - / - / - / 75 / 175 / 519 -- Llama-2-7B heads, profiles/r02_attention_two_pass.log)
 
 extern "C" int ifa_attention_two_pass_min(int min_tokens)
 {
@@ -677,8 +935,24 @@ extern "C" int ifa_attention(const void *q, const void *kcache, const void *vcac
     IFA_REQUIRE(n_ctx <= 65536 && q_tokens <= 65535, "ifa_attention: context too long for the op-level kernel");
     IFA_REQUIRE(kq_scale > 0, "ifa_attention: kq_scale must be > 0");
     const int total_heads = alibi_total_heads > 0 ? alibi_total_heads : heads;
-    // long prompts: two passes over the keys, 128 queries per workgroup (no score tile)
-    if (q_tokens >= g_attn_2pass_min && n_ctx >= g_attn_2pass_min_keys && (head_dim == 64 || head_dim == 128)) {
+    // chunks of >= 64 queries: the two-pass kernel with 64 queries per workgroup and the key blocks split over wave pairs
+    if (q_tokens >= g_attn_2pass_min && !(q_tokens >= 128 && n_ctx >= g_attn_2pass_min_keys) && (head_dim == 64 || head_dim == 128)) {
+        hipStream_t hs = ifa_s(stream);
+        dim3 grid((unsigned)((q_tokens + 63) / 64), (unsigned)heads);
+        const size_t smem = (size_t)4 * 32 * head_dim * 2 + (size_t)4 * head_dim * F2_VROW * 2;
+#define IFA_F2K(HDV, Q8V) { auto kern = k_attention_2pass_ks<HDV, Q8V>; \
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        kern<<<grid, dim3(256), smem, hs>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens, \
+                                            prefix_len, heads, kv_heads, kq_scale, alibi, alibi_base_head, total_heads, (half_t *)out); }
+        if (head_dim == 128) { if (kv_dtype == Q8_B32T2) IFA_F2K(128, true) else IFA_F2K(128, false) }
+        else { if (kv_dtype == Q8_B32T2) IFA_F2K(64, true) else IFA_F2K(64, false) }
+#undef IFA_F2K
+        IFA_LAUNCH_CHECK();
+        return IFA_OK;
+    }
+    // the 128-query variant of it (one wave per 32 queries, every wave walks all key blocks): behind the 64-query one at every
+    // length measured (4096 tokens: 519 vs 492 us), selectable through ifa_attention_two_pass_min_keys
+    if (q_tokens >= 128 && q_tokens >= g_attn_2pass_min && n_ctx >= g_attn_2pass_min_keys && (head_dim == 64 || head_dim == 128)) {
         hipStream_t hs = ifa_s(stream);
         dim3 grid((unsigned)((q_tokens + F2_QT - 1) / F2_QT), (unsigned)heads);
 #define IFA_F2A(HDV, Q8V) k_attention_2pass<HDV, Q8V><<<grid, dim3(256), 0, hs>>>((const half_t *)q, (const uint8_t *)kcache, (const uint8_t *)vcache, n_ctx, q_tokens, \

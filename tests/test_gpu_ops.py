@@ -294,8 +294,9 @@ def test_argmax_first_max_wins():
     # prefill tiles: the [32 x keys] score tile in LDS (300 keys) and, past ~2300 keys, in the global workspace (2600 keys,
     # a chunk of 40 queries behind a 2560-token prefix)
     (4, 2, 64, 300, 70, 0), (2, 1, 128, 2600, 40, 0), (2, 2, 64, 2500, 33, 1),
-    # long prompts (>= 128 queries): the two-pass kernel, 128 queries per workgroup -- whole prompt, a ragged last tile behind
-    # a prefix, ALiBi, a chunk behind 2400 cached tokens
+    # chunks of >= 64 queries: the two-pass kernels (64 queries per workgroup with the key blocks split over wave pairs; the
+    # 128-query variant and the staged kernel on the same inputs below) -- whole prompt, a ragged last tile behind a prefix,
+    # ALiBi, a chunk behind 2400 cached tokens
     (4, 2, 64, 300, 300, 0), (2, 1, 128, 420, 260, 0), (2, 2, 64, 700, 130, 1), (2, 1, 128, 2560, 160, 0)])
 def test_attention(kv_dtype, heads, kv_heads, hd, n_ctx, qt, alibi):
     rng = np.random.default_rng(heads * 7 + n_ctx)
@@ -310,25 +311,25 @@ def test_attention(kv_dtype, heads, kv_heads, hd, n_ctx, qt, alibi):
     kq_scale = 1.0 if alibi else 2.0
     exp = o.attention(q, kc, vc, kv_dtype, n_ctx, prefix, heads, kv_heads, hd, kq_scale, bool(alibi), 0, heads)
     out = g.empty_f16(qt, heads * hd)
-    prev_keys = g.capi().ifa_attention_two_pass_min_keys(0)         # (the two-pass kernel whatever the context length)
-    try:
-        ia.check(g.capi().ifa_attention(g.p(g.dev(q)), g.p(g.dev(kc)), g.p(g.dev(vc)), kv_dtype, n_ctx, qt, prefix,
-                                        heads, kv_heads, hd, kq_scale, alibi, 0, heads, g.p(out), g.stream()))
-    finally:
-        g.capi().ifa_attention_two_pass_min_keys(prev_keys)
+    ia.check(g.capi().ifa_attention(g.p(g.dev(q)), g.p(g.dev(kc)), g.p(g.dev(vc)), kv_dtype, n_ctx, qt, prefix,
+                                    heads, kv_heads, hd, kq_scale, alibi, 0, heads, g.p(out), g.stream()))
     # P differs by expf implementation and sum order (<= 1 half ulp per weight); O is a convex mix of |v| ~ 1
     assert np.abs(g.host(out).astype(np.float32) - exp.astype(np.float32)).max() <= 6e-3
-    if qt >= 128:       # the staged kernel on the same input (two-pass switched off): same rounding points, other sum orders
+    if qt >= 64:        # the other kernels on the same input: same rounding points, other sum orders
         L = g.capi()
-        prev = L.ifa_attention_two_pass_min(0)
-        try:
-            out2 = g.empty_f16(qt, heads * hd)
-            ia.check(L.ifa_attention(g.p(g.dev(q)), g.p(g.dev(kc)), g.p(g.dev(vc)), kv_dtype, n_ctx, qt, prefix,
-                                     heads, kv_heads, hd, kq_scale, alibi, 0, heads, g.p(out2), g.stream()))
-        finally:
-            L.ifa_attention_two_pass_min(prev)
-        assert np.abs(g.host(out2).astype(np.float32) - exp.astype(np.float32)).max() <= 6e-3
-        assert np.abs(g.host(out2).astype(np.float32) - g.host(out).astype(np.float32)).max() <= 4e-3
+        variants = [("staged", lambda: L.ifa_attention_two_pass_min(0), lambda p: L.ifa_attention_two_pass_min(p))]
+        if qt >= 128:
+            variants.append(("128-query", lambda: L.ifa_attention_two_pass_min_keys(0), lambda p: L.ifa_attention_two_pass_min_keys(p)))
+        for name, switch, restore in variants:
+            prev = switch()
+            try:
+                out2 = g.empty_f16(qt, heads * hd)
+                ia.check(L.ifa_attention(g.p(g.dev(q)), g.p(g.dev(kc)), g.p(g.dev(vc)), kv_dtype, n_ctx, qt, prefix,
+                                         heads, kv_heads, hd, kq_scale, alibi, 0, heads, g.p(out2), g.stream()))
+            finally:
+                restore(prev)
+            assert np.abs(g.host(out2).astype(np.float32) - exp.astype(np.float32)).max() <= 6e-3, name
+            assert np.abs(g.host(out2).astype(np.float32) - g.host(out).astype(np.float32)).max() <= 4e-3, name
 
 
 # ------------------------------------------------------------ prefill GEMM (MFMA)
