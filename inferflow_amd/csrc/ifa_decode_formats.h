@@ -26,6 +26,24 @@ struct XLds;   // ifa_decode_kernels.h
 template <typename T>
 __device__ __forceinline__ T nt_load(const void *p) { return __builtin_nontemporal_load(reinterpret_cast<const T *>(p)); }
 
+// Where a weight row's bytes come from: HBM (non-temporal requests, the five-launch kernels) or the LDS ring the
+// persistent layer kernel's loader wave fills (ifa_decode_persist.h; offsets wrap at the ring size).  The WRow*::load_src
+// methods below take either, so both paths decode and accumulate a row with the same code.
+struct WSrcGlobal {
+    const uint8_t *p;
+    template <typename T> __device__ __forceinline__ T ld(uint32_t off) const { return nt_load<T>(p + off); }
+};
+template <uint32_t RING>
+struct WSrcLdsRing {
+    const char *ring; uint32_t base;     // base < RING, row pieces never straddle the end (16-byte granularity)
+    template <typename T> __device__ __forceinline__ T ld(uint32_t off) const
+    {
+        uint32_t a = base + off;
+        a = a >= RING ? a - RING : a;
+        return *reinterpret_cast<const T *>(ring + a);
+    }
+};
+
 // one half block's fp32 contribution (same expression as ax8_term<DT>)
 __device__ __forceinline__ float dec_term(int d, float scale, float base, float xsum, float xs)
 {
@@ -116,6 +134,17 @@ struct WRowQ8T2 {
             sc[j] = nt_load<uint16_t>(wrow + (size_t)nblk * 32 + (size_t)blk * 2);
         }
     }
+    template <class S>
+    __device__ __forceinline__ void load_src(const S &src, int nblk, int lane, int blk0 = 0)
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t blk = (uint32_t)min(blk0 + lane + 64 * j, nblk - 1);
+            c0[j] = src.template ld<u32x4>(blk * 32);
+            c1[j] = src.template ld<u32x4>(blk * 32 + 16);
+            sc[j] = src.template ld<uint16_t>((uint32_t)nblk * 32 + blk * 2);
+        }
+    }
     __device__ __forceinline__ float dot(const XRegsNat<NJ> &X, float acc0 = 0.0f) const
     {
         float acc = acc0;
@@ -147,6 +176,17 @@ struct WRowQ4B64 {
             c[j][0] = nt_load<u32x4>(wrow + (size_t)blk * 32);
             c[j][1] = nt_load<u32x4>(wrow + (size_t)blk * 32 + 16);
             sb[j] = nt_load<uint32_t>(wrow + (size_t)nblk * 32 + (size_t)blk * 4);
+        }
+    }
+    template <class S>
+    __device__ __forceinline__ void load_src(const S &src, int nblk, int lane, int blk0 = 0)
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t blk = (uint32_t)min(blk0 + lane + 64 * j, nblk - 1);
+            c[j][0] = src.template ld<u32x4>(blk * 32);
+            c[j][1] = src.template ld<u32x4>(blk * 32 + 16);
+            sb[j] = src.template ld<uint32_t>((uint32_t)nblk * 32 + blk * 4);
         }
     }
     __device__ __forceinline__ float dot(const XRegsB64<NJ> &X, float acc0 = 0.0f) const
@@ -187,6 +227,18 @@ struct WRowQ5B64 {
             c[j][1] = nt_load<u32x4>(wrow + (size_t)blk * 32 + 16);
             hb[j] = nt_load<u32x2>(wrow + (size_t)nblk * 32 + (size_t)blk * 8);
             sb[j] = nt_load<uint32_t>(wrow + (size_t)nblk * 40 + (size_t)blk * 4);
+        }
+    }
+    template <class S>
+    __device__ __forceinline__ void load_src(const S &src, int nblk, int lane, int blk0 = 0)
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t blk = (uint32_t)min(blk0 + lane + 64 * j, nblk - 1);
+            c[j][0] = src.template ld<u32x4>(blk * 32);
+            c[j][1] = src.template ld<u32x4>(blk * 32 + 16);
+            hb[j] = src.template ld<u32x2>((uint32_t)nblk * 32 + blk * 8);
+            sb[j] = src.template ld<uint32_t>((uint32_t)nblk * 40 + blk * 4);
         }
     }
     __device__ __forceinline__ float dot(const XRegsB64<NJ> &X, float acc0 = 0.0f) const
@@ -231,6 +283,18 @@ struct WRowQ6B64 {
             c[j][1] = nt_load<u32x4>(wrow + (size_t)blk * 32 + 16);
             hb[j] = nt_load<u32x4>(wrow + (size_t)nblk * 32 + (size_t)blk * 16);
             sb[j] = nt_load<uint32_t>(wrow + (size_t)nblk * 48 + (size_t)blk * 4);
+        }
+    }
+    template <class S>
+    __device__ __forceinline__ void load_src(const S &src, int nblk, int lane, int blk0 = 0)
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t blk = (uint32_t)min(blk0 + lane + 64 * j, nblk - 1);
+            c[j][0] = src.template ld<u32x4>(blk * 32);
+            c[j][1] = src.template ld<u32x4>(blk * 32 + 16);
+            hb[j] = src.template ld<u32x4>((uint32_t)nblk * 32 + blk * 16);
+            sb[j] = src.template ld<uint32_t>((uint32_t)nblk * 48 + blk * 4);
         }
     }
     // bit pairs at 0,4,8,12 of t -> bits 4-5 of bytes 0..3
@@ -284,6 +348,17 @@ struct WRowQ3H {
             c[j] = nt_load<u32x4>(wrow + (size_t)blk * 16);
             m[j] = nt_load<u32x2>(wrow + (size_t)nblk * 16 + (size_t)blk * 8);
             sbh[j] = nt_load<u32x2>(wrow + (size_t)nblk * 24 + (size_t)blk * 8);
+        }
+    }
+    template <class S>
+    __device__ __forceinline__ void load_src(const S &src, int nblk, int lane, int blk0 = 0)
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t blk = (uint32_t)min(blk0 + lane + 64 * j, nblk - 1);
+            c[j] = src.template ld<u32x4>(blk * 16);
+            m[j] = src.template ld<u32x2>((uint32_t)nblk * 16 + blk * 8);
+            sbh[j] = src.template ld<u32x2>((uint32_t)nblk * 24 + blk * 8);
         }
     }
     // four quotients p/11, one per byte

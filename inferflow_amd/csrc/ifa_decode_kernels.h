@@ -328,6 +328,16 @@ struct WRowQ4 {
 #endif
         }
     }
+    template <class S>
+    __device__ __forceinline__ void load_src(const S &src, int nblk, int lane, int blk0 = 0)
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t blk = (uint32_t)min(blk0 + lane + 64 * j, nblk - 1);
+            c[j] = src.template ld<u32x4>(blk * 16);
+            sb[j] = src.template ld<uint32_t>((uint32_t)nblk * 16 + blk * 4);
+        }
+    }
     // lane-partial of sum_blk xs*(dot*scale + xsum*base); same expression as ax8_term (ifa_gemv.hip)
     __device__ __forceinline__ float dot(const XRegsQ4<NJ> &X, float acc0 = 0.0f) const
     {

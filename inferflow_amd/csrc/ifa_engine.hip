@@ -21,6 +21,7 @@
 #include "ifa_moe.h"
 #include "ifa_gemm_rows_mfma.h"
 #include "ifa_gemm_big.h"
+#include "ifa_decode_persist_launch.h"
 
 using namespace ifa;
 
@@ -114,6 +115,20 @@ struct ifa_model {
     const ifa_tp_topology *topo = nullptr;     // set by the partition entry points for the duration of a T > 1 / batched step
     size_t tp_rows_cap = 0;                    // rows the distributed-argmax scratch (tp_best / tp_gather / tp_tok) holds
     int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
+    // persistent decode layers (ifa_decode_persist.h): all layers of a token as ONE launch; the five-launch layer stays as
+    // fallback (long contexts, other wirings / formats) and comparator.  persist_mode = what the captured step uses.
+    int opt_persist = 1, opt_persist_ctx = 512, opt_persist_timeout_us = 20000, opt_persist_trace = -1, opt_persist_debug = 0;
+    int opt_debug_layers = 0;                  // > 0: the decode step runs only the first N layers (both paths; tools/debug_persist.py)
+    int persist_mode = 0, ps_state = 0;        // ps_state: 0 unknown, 1 usable (copies built), -1 unsupported
+    std::string ps_why;
+    std::vector<void *> ps_wqkv, ps_w13;       // per layer: wq | wk | wv rows in one buffer; w1 / w3 interleaved row by row
+    std::map<int, void *> ps_tabs;             // per KV slot: device PsLayer[layers]
+    unsigned long long *ps_arena = nullptr;    // granule arenas of the five edges
+    size_t ps_arena_bytes = 0, ps_goff[5] = {0, 0, 0, 0, 0};
+    unsigned *ps_err = nullptr;                // device [4]: code, workgroup, layer, wave
+    long long *ps_trace = nullptr;             // device [workgroups][32]
+    int ps_nja = 0, ps_njb = 0, ps_ncu = 0;
+    size_t ps_smem = 0;
     static constexpr int RING = 1024;
 };
 
@@ -734,6 +749,170 @@ static int launch_moe_router(ifa_model *m, int l)
     return IFA_OK;
 }
 
+// ------------------------------------------------ persistent decode layers (ifa_decode_persist.h)
+// Which models: the sequential RMS-norm wiring with a gated FFN (Llama / Mistral / Yi family), all seven matrices of
+// a layer in ONE int8-GEMV format that has kernels (Q4_B32T1A/B, Q3H_B64T1), heads * head_dim == dim, head_dim 64 / 128,
+// F16 or Q8 KV cache.  Everything else keeps the five-launch layer.
+static bool persist_supported(ifa_model *m, std::string *why)
+{
+    const ifa_model_config &c = m->cfg;
+    auto fail = [&](const char *s) { if (why) *why = s; return false; };
+    std::string w2;
+    if (!fused_supported(m, &w2)) { if (why) *why = w2; return false; }
+    if (c.experts > 0) return fail("persistent decode: mixture-of-experts layers use the five-launch path");
+    if (c.norm_kind != 0 || c.parallel_attn || c.share_input) return fail("persistent decode: sequential RMS-norm wiring only");
+    if (c.tp_size > 1) return fail("persistent decode: single-worker models only");
+    if (c.head_dim != 64 && c.head_dim != 128) return fail("persistent decode: head_dim 64 / 128");
+    if (c.heads * c.head_dim != c.dim) return fail("persistent decode: heads * head_dim must equal dim");
+    if (c.kv_dtype != F16 && c.kv_dtype != Q8_B32T2) return fail("persistent decode: F16 or Q8 KV cache");
+    if (c.dim % 64 != 0 || c.ffn % 64 != 0) return fail("persistent decode: dim / ffn must be multiples of 64");
+    const int ncu = num_cus();
+    if (c.heads > ncu) return fail("persistent decode: more heads than compute units");
+    const int dt0 = m->layers.empty() ? -1 : m->layers[0].t[T_WQ].dtype;
+    if (!(is_q4(dt0) || dt0 == Q3H_B64T1)) return fail("persistent decode: weight format without a persistent kernel");
+    const size_t QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim;
+    for (const Layer &L : m->layers) {
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids) {
+            const Tensor &t = L.t[id];
+            if (!t.present() || !t.tiled || !same_fmt(t.dtype, dt0)) return fail("persistent decode: all seven matrices of a layer must share one int8-GEMV format");
+        }
+        if (L.t[T_WQ].rows != QD || L.t[T_WK].rows != KVD || L.t[T_WV].rows != KVD || L.t[T_WO].rows != (size_t)c.dim || L.t[T_WO].cols != QD
+            || L.t[T_W1].rows != (size_t)c.ffn || L.t[T_W3].rows != (size_t)c.ffn || L.t[T_W2].rows != (size_t)c.dim || L.t[T_W2].cols != (size_t)c.ffn
+            || L.t[T_WQ].cols != (size_t)c.dim || L.t[T_W1].cols != (size_t)c.dim)
+            return fail("persistent decode: unexpected matrix shapes");
+        if (!L.t[T_FFN_NORM].present()) return fail("persistent decode: ffn pre-norm required");
+    }
+    const int cap = block_capacity(dt0);
+    const int nja = (c.dim / cap + 63) / 64, njb = (c.ffn / cap + 63) / 64;
+    if (!dec_persist_has(dt0, nja, njb, c.head_dim)) return fail("persistent decode: no kernel instantiated for this shape");
+    const size_t rb_a = tiled_row_bytes(dt0, (size_t)c.dim / cap), rb_b = tiled_row_bytes(dt0, (size_t)c.ffn / cap);
+    if (4 * rb_a + 4096 > PS_RING || 2 * rb_b + 4096 > PS_RING) return fail("persistent decode: a row batch does not fit the LDS ring");
+    if (((size_t)c.dim / 2 + ncu - 1) / ncu * 2 > (size_t)PS_RES) return fail("persistent decode: too few compute units for this width");
+    if (ps_lds_bytes(std::max(c.dim, c.ffn), c.head_dim) > IFA_LDS_LIMIT) return fail("persistent decode: activation images do not fit the LDS next to the ring");
+    return true;
+}
+
+// load-time copies in the loader's streaming order + the granule arena
+static int persist_build(ifa_model *m)
+{
+    const ifa_model_config &c = m->cfg;
+    const int dt0 = m->layers[0].t[T_WQ].dtype, cap = block_capacity(dt0);
+    const size_t rb_a = tiled_row_bytes(dt0, (size_t)c.dim / cap);
+    const size_t QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim;
+    m->ps_wqkv.assign(m->layers.size(), nullptr); m->ps_w13.assign(m->layers.size(), nullptr);
+    for (size_t l = 0; l < m->layers.size(); l++) {
+        Layer &L = m->layers[l];
+        uint8_t *qkv = nullptr, *w13 = nullptr;
+        IFA_HIP_CHECK(hipMalloc((void **)&qkv, (QD + 2 * KVD) * rb_a));
+        IFA_HIP_CHECK(hipMalloc((void **)&w13, 2 * (size_t)c.ffn * rb_a));
+        m->ps_wqkv[l] = qkv; m->ps_w13[l] = w13;
+        IFA_HIP_CHECK(hipMemcpyAsync(qkv, L.t[T_WQ].tiled, QD * rb_a, hipMemcpyDeviceToDevice, m->stream));
+        IFA_HIP_CHECK(hipMemcpyAsync(qkv + QD * rb_a, L.t[T_WK].tiled, KVD * rb_a, hipMemcpyDeviceToDevice, m->stream));
+        IFA_HIP_CHECK(hipMemcpyAsync(qkv + (QD + KVD) * rb_a, L.t[T_WV].tiled, KVD * rb_a, hipMemcpyDeviceToDevice, m->stream));
+        IFA_HIP_CHECK(hipMemcpy2DAsync(w13, 2 * rb_a, L.t[T_W1].tiled, rb_a, rb_a, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
+        IFA_HIP_CHECK(hipMemcpy2DAsync(w13 + rb_a, 2 * rb_a, L.t[T_W3].tiled, rb_a, rb_a, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
+    }
+    const size_t counts[5] = {(size_t)c.dim / 2, (QD + 2 * KVD) / 2, QD / 4 + QD / 16, (size_t)c.dim / 2, (size_t)c.ffn / 2};
+    size_t off = 0;
+    for (int i = 0; i < 5; i++) { m->ps_goff[i] = off; off += (counts[i] + 63) / 64 * 64; }
+    m->ps_arena_bytes = off * 8;
+    IFA_HIP_CHECK(hipMalloc((void **)&m->ps_arena, m->ps_arena_bytes));
+    IFA_HIP_CHECK(hipMalloc((void **)&m->ps_err, 16));
+    IFA_HIP_CHECK(hipMemsetAsync(m->ps_err, 0, 16, m->stream));
+    m->ps_ncu = num_cus();
+    IFA_HIP_CHECK(hipMalloc((void **)&m->ps_trace, sizeof(long long) * 32 * (size_t)m->ps_ncu));
+    IFA_HIP_CHECK(hipMemsetAsync(m->ps_trace, 0, sizeof(long long) * 32 * (size_t)m->ps_ncu, m->stream));
+    m->ps_nja = (c.dim / cap + 63) / 64; m->ps_njb = (c.ffn / cap + 63) / 64;
+    m->ps_smem = ps_lds_bytes(std::max(c.dim, c.ffn), c.head_dim);
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return IFA_OK;
+}
+
+static void persist_drop(ifa_model *m)
+{
+    for (void *p : m->ps_wqkv) if (p) (void)hipFree(p);
+    for (void *p : m->ps_w13) if (p) (void)hipFree(p);
+    m->ps_wqkv.clear(); m->ps_w13.clear();
+    for (auto &kv : m->ps_tabs) if (kv.second) (void)hipFree(kv.second);
+    m->ps_tabs.clear();
+    if (m->ps_arena) { (void)hipFree(m->ps_arena); m->ps_arena = nullptr; }
+    if (m->ps_err) { (void)hipFree(m->ps_err); m->ps_err = nullptr; }
+    if (m->ps_trace) { (void)hipFree(m->ps_trace); m->ps_trace = nullptr; }
+    m->ps_state = 0; m->persist_mode = 0;
+}
+
+// *usable = 1 if this model can use the persistent launch (copies built on first use)
+static int persist_ready(ifa_model *m, int *usable)
+{
+    *usable = 0;
+    if (m->ps_state == 0) {
+        if (!persist_supported(m, &m->ps_why)) m->ps_state = -1;
+        else {
+            int rc = persist_build(m);
+            if (rc) { persist_drop(m); m->ps_state = -1; return rc; }
+            m->ps_state = 1;
+        }
+    }
+    *usable = m->ps_state > 0 ? 1 : 0;
+    return IFA_OK;
+}
+
+// the layer table of the active KV slot (a slot's cache allocations never move)
+static int persist_table(ifa_model *m, const PsLayer **out)
+{
+    auto it = m->ps_tabs.find(m->cur_slot);
+    if (it == m->ps_tabs.end()) {
+        std::vector<PsLayer> tab(m->layers.size());
+        for (size_t l = 0; l < m->layers.size(); l++) {
+            Layer &L = m->layers[l];
+            PsLayer &d = tab[l];
+            memset(&d, 0, sizeof(d));
+            d.wqkv = (const uint8_t *)m->ps_wqkv[l]; d.wo = (const uint8_t *)L.t[T_WO].tiled;
+            d.w13 = (const uint8_t *)m->ps_w13[l]; d.w2 = (const uint8_t *)L.t[T_W2].tiled;
+            d.attn_norm = (const half_t *)L.t[T_ATTN_NORM].data; d.attn_norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
+            d.ffn_norm = (const half_t *)L.t[T_FFN_NORM].data; d.ffn_norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
+            d.bq = (const half_t *)L.t[T_WQ_B].data; d.bk = (const half_t *)L.t[T_WK_B].data; d.bv = (const half_t *)L.t[T_WV_B].data;
+            d.bo = (const half_t *)L.t[T_WO_B].data; d.b1 = (const half_t *)L.t[T_W1_B].data; d.b3 = (const half_t *)L.t[T_W3_B].data;
+            d.b2 = (const half_t *)L.t[T_W2_B].data;
+            d.kcache = (uint8_t *)L.kcache; d.vcache = (uint8_t *)L.vcache;
+        }
+        void *dev = nullptr;
+        IFA_HIP_CHECK(hipMalloc(&dev, tab.size() * sizeof(PsLayer)));
+        IFA_HIP_CHECK(hipMemcpy(dev, tab.data(), tab.size() * sizeof(PsLayer), hipMemcpyHostToDevice));
+        it = m->ps_tabs.emplace(m->cur_slot, dev).first;
+    }
+    *out = (const PsLayer *)it->second;
+    return IFA_OK;
+}
+
+// layers [l0, l1) of the step as one launch: x_in -> x_out (plain F16 vectors)
+static int launch_persist(ifa_model *m, int l0, int l1, const half_t *x_in, half_t *x_out)
+{
+    const ifa_model_config &c = m->cfg;
+    const PsLayer *tab = nullptr;
+    int rc = persist_table(m, &tab);
+    if (rc) return rc;
+    const int dt0 = m->layers[0].t[T_WQ].dtype, cap = block_capacity(dt0);
+    IFA_HIP_CHECK(hipMemsetAsync(m->ps_arena, 0, m->ps_arena_bytes, m->stream));      // tags of the previous token
+    PsParams P; memset(&P, 0, sizeof(P));
+    P.layers = tab; P.x_in = x_in; P.x_out = x_out; P.state = m->state; P.rope_tab = m->rope_tab;
+    P.g_x = m->ps_arena + m->ps_goff[0]; P.g_qkv = m->ps_arena + m->ps_goff[1]; P.g_att = m->ps_arena + m->ps_goff[2];
+    P.g_a = m->ps_arena + m->ps_goff[3]; P.g_act = m->ps_arena + m->ps_goff[4];
+    P.err = m->ps_err; P.trace = m->opt_persist_trace >= 0 ? m->ps_trace : nullptr; P.trace_layer = m->opt_persist_trace;
+    P.dbg_att = m->opt_persist_debug ? m->att : nullptr;
+    P.layer_begin = l0; P.layer_end = l1;
+    P.dim = c.dim; P.ffn = c.ffn; P.heads = c.heads; P.kv_heads = c.kv_heads;
+    P.nblk_a = c.dim / cap; P.nblk_b = c.ffn / cap;
+    P.row_bytes_a = (unsigned)tiled_row_bytes(dt0, (size_t)P.nblk_a); P.row_bytes_b = (unsigned)tiled_row_bytes(dt0, (size_t)P.nblk_b);
+    P.eps = c.eps; P.attn_norm_base = c.attn_norm_base; P.ffn_norm_base = c.ffn_norm_base;
+    P.kq_scale = c.use_alibi ? 1.0f : c.kq_scale; P.act_kind = c.act_kind;
+    P.rope_order = c.rope_order; P.rope_cols = (int)(c.head_dim * c.partial_rotary + 0.5f);
+    P.alibi = c.use_alibi; P.alibi_base = c.tp_rank * c.heads; P.alibi_total = c.heads * std::max(1, c.tp_size);
+    P.timeout_ticks = (unsigned)std::max(100, m->opt_persist_timeout_us) * 100u;
+    return dec_persist_launch(dt0, m->ps_nja, m->ps_njb, c.head_dim, c.kv_dtype == Q8_B32T2 ? 1 : 0, P, m->ps_ncu, m->ps_smem, m->stream);
+}
+
 static int enqueue_fused_step(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
@@ -744,7 +923,15 @@ static int enqueue_fused_step(ifa_model *m)
     IFA_LAUNCH_CHECK();
     half_t *x = m->x, *xnext = m->x2;
     int rc;
-    for (int l = 0; l < c.layers; l++) {
+    const int n_layers = (m->opt_debug_layers > 0 && m->opt_debug_layers < c.layers) ? m->opt_debug_layers : c.layers;
+    if (m->persist_mode) {
+        if ((rc = launch_persist(m, 0, n_layers, x, xnext))) return rc;
+        if ((rc = launch_lm(m, xnext))) return rc;
+        k_dec_argmax_advance<<<dim3(1), dim3(1024), 0, s>>>(m->logits, (int)m->g[T_LM_HEAD].rows, m->state, ifa_model::RING);
+        IFA_LAUNCH_CHECK();
+        return IFA_OK;
+    }
+    for (int l = 0; l < n_layers; l++) {
         if ((rc = launch_qkv(m, l, x))) return rc;
         if ((rc = launch_attn(m, l))) return rc;
         if ((rc = launch_wo(m, l, x))) return rc;
@@ -1785,6 +1972,7 @@ int ifa_model_destroy(ifa_model *m)
       for (void *b : mb) if (b) (void)hipFree(b); }
     { void *tpb[] = {m->tp_a, m->tp_f, m->tp_hid, m->tp_logits, m->tp_best, m->tp_gather, m->tp_tok};
       for (void *b : tpb) if (b) (void)hipFree(b); }
+    persist_drop(m);
     if (m->state) (void)hipFree(m->state);
     if (m->rope_tab) (void)hipFree(m->rope_tab);
     if (m->tokens_dev) (void)hipFree(m->tokens_dev);
@@ -1861,6 +2049,7 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
     }
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     drop_graphs(m);
+    persist_drop(m);         // the persistent launch's streaming copies and layer tables follow the tensors
     return IFA_OK;
 }
 
@@ -1923,7 +2112,7 @@ int ifa_model_finalize(ifa_model *m)
         IFA_HIP_CHECK(hipMalloc((void **)&m->state, sizeof(int) * (8 + ifa_model::RING)));
         IFA_HIP_CHECK(hipMemsetAsync(m->state, 0, sizeof(int) * (8 + ifa_model::RING), m->stream));
         IFA_HIP_CHECK(hipMalloc((void **)&m->rope_tab, sizeof(float) * (size_t)c.head_dim));
-        IFA_HIP_CHECK(hipHostMalloc((void **)&m->host_pinned, sizeof(int) * (8 + ifa_model::RING), hipHostMallocDefault));
+        IFA_HIP_CHECK(hipHostMalloc((void **)&m->host_pinned, sizeof(int) * (16 + ifa_model::RING), hipHostMallocDefault));
     }
     int rc = ensure_scratch(m, 1);
     if (rc) return rc;
@@ -1994,7 +2183,9 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
+        {"debug_layers", &m->opt_debug_layers}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
@@ -2064,6 +2255,14 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     // attention variant of this call: one workgroup per head, or keys split over workgroups once the context the
     // call reaches passes the threshold (the captured step is re-captured when the variant changes)
     choose_attn_split(m, start_pos + n_steps);
+    {   // one persistent launch for the layers while the context stays short enough for one CU per head
+        int want = 0;
+        if (m->opt_persist && start_pos + n_steps <= std::min(m->opt_persist_ctx, (int)PS_MAX_CTX)) {
+            if ((rc = persist_ready(m, &want))) return rc;
+        }
+        if (want != m->persist_mode) { m->persist_mode = want; drop_graphs(m); }
+        if (want) { const PsLayer *tab = nullptr; if ((rc = persist_table(m, &tab))) return rc; }      // (allocates: not under capture)
+    }
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
     if (m->opt_graph && !m->graph_exec) {
@@ -2086,8 +2285,18 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     }
     if (elapsed_ms) IFA_HIP_CHECK(hipEventRecord(e1, s));
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n_steps, hipMemcpyDeviceToHost, s));
+    int *perr = m->host_pinned + 8 + ifa_model::RING;
+    perr[0] = 0;
+    if (m->persist_mode) IFA_HIP_CHECK(hipMemcpyAsync(perr, m->ps_err, 16, hipMemcpyDeviceToHost, s));
     IFA_HIP_CHECK(hipStreamSynchronize(s));
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    if (perr[0] != 0) {      // a wait inside the persistent launch gave up: the step's results are not valid
+        const unsigned code = (unsigned)perr[0];
+        (void)hipMemsetAsync(m->ps_err, 0, 16, s);
+        (void)hipStreamSynchronize(s);
+        return ifa_fail(IFA_ERR_STATE, "persistent decode launch gave up waiting: phase 0x%x kind %u (workgroup %d, layer %d, wave %d); "
+                        "set option persist=0 to use the five-launch path", code >> 8, code & 0xFFu, perr[1], perr[2], perr[3]);
+    }
     if (out_tokens_host) memcpy(out_tokens_host, m->host_pinned + 8, sizeof(int) * (size_t)n_steps);
     return IFA_OK;
 }
@@ -2126,6 +2335,15 @@ int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr,
     else if (!strcmp(name, "tp_logits")) { p = m->tp_logits; b = m->tp_logits ? m->g[T_LM_HEAD].rows * 2 : 0; }
     else if (!strcmp(name, "trace")) { p = m->trace; b = m->trace ? sizeof(long long) * 2048 * 8 : 0; }
     else if (!strcmp(name, "hidden")) { p = m->xn; b = (size_t)c.dim * 2; }
+    else if (!strcmp(name, "ps_trace")) { p = m->ps_trace; b = m->ps_trace ? sizeof(long long) * 32 * (size_t)m->ps_ncu : 0; }
+    else if (!strcmp(name, "ps_arena")) { p = m->ps_arena; b = m->ps_arena_bytes; }
+    else if (!strcmp(name, "x")) { p = m->x; b = (size_t)c.dim * 2; }
+    else if (!strcmp(name, "x2")) { p = m->x2; b = (size_t)c.dim * 2; }
+    else if (!strcmp(name, "dqkv")) { p = m->dqkv; b = ((size_t)c.heads + 2 * (size_t)c.kv_heads) * c.head_dim * 2; }
+    else if (!strcmp(name, "att")) { p = m->att; b = (size_t)c.heads * c.head_dim * 2; }
+    else if (!strcmp(name, "attq")) { p = m->attq; b = m->attq ? xq_image_bytes(c.heads * c.head_dim) : 0; }
+    else if (!strcmp(name, "a")) { p = m->a; b = (size_t)c.dim * 2; }
+    else if (!strcmp(name, "t1")) { p = m->t1; b = (size_t)c.ffn * 2; }
     else if (!strcmp(name, "kcache") || !strcmp(name, "vcache")) {
         IFA_REQUIRE(layer >= 0 && layer < c.layers && m->finalized, "ifa_model_get_buffer: layer %d", layer);
         p = name[0] == 'k' ? m->layers[(size_t)layer].kcache : m->layers[(size_t)layer].vcache;
@@ -2533,7 +2751,7 @@ int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, voi
 int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
 {
     IFA_REQUIRE(m && m->finalized && avg_us, "ifa_model_time_kernel: bad arguments");
-    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 5, "ifa_model_time_kernel: which %d iters %d", which, iters);
+    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 6, "ifa_model_time_kernel: which %d iters %d", which, iters);
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
     if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
@@ -2551,7 +2769,15 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
             k_touch<<<dim3(8), dim3(256), 0, s>>>((const uint8_t *)t.tiled, bytes, (size_t)m->opt_touch_stride, m->state + 7);
         }
     };
+    if (which == 6) {      // all layers as the one persistent launch
+        int usable = 0;
+        if ((rc = persist_ready(m, &usable))) return rc;
+        if (!usable) return ifa_fail(IFA_ERR_STATE, "persistent decode unavailable: %s", m->ps_why.c_str());
+        const PsLayer *tab = nullptr;
+        if ((rc = persist_table(m, &tab))) return rc;
+    }
     auto one = [&](int i) -> int {
+        if (which == 6) return launch_persist(m, 0, m->cfg.layers, m->x, m->x2);
         const int l = m->opt_bench_mode == 1 ? 0 : i % m->cfg.layers;     // rotate over layers: distinct weights every launch
         if (m->opt_bench_mode == 2) touch_layer(l);
         switch (which) {
