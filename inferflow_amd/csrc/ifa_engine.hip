@@ -115,13 +115,16 @@ struct ifa_model {
     const ifa_tp_topology *topo = nullptr;     // set by the partition entry points for the duration of a T > 1 / batched step
     size_t tp_rows_cap = 0;                    // rows the distributed-argmax scratch (tp_best / tp_gather / tp_tok) holds
     int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
-    // persistent decode layers (ifa_decode_persist.h): all layers of a token as ONE launch; the five-launch layer stays as
-    // fallback (long contexts, other wirings / formats) and comparator.  persist_mode = what the captured step uses.
-    int opt_persist = 1, opt_persist_ctx = 512, opt_persist_timeout_us = 20000, opt_persist_trace = -1, opt_persist_debug = 0;
+    // persistent decode layers (ifa_decode_persist.h): all layers of a token as ONE launch, bit-identical to the five-launch
+    // layer.  Opt-in (option "persist"): measured on MI355X it is SLOWER than five launches for this workload (55 vs 43.5 us
+    // per Llama-2-7B layer) -- the hand-offs cost what the kernel boundaries cost and the 4-bit decode +
+    // Q8 quantiser are issue-bound on the few resident waves.  persist_mode = what the captured step uses.
+    int opt_persist = 0, opt_persist_ctx = 512, opt_persist_timeout_us = 20000, opt_persist_trace = -1, opt_persist_debug = 0, opt_persist_depth = 0, opt_persist_prio = 0;
     int opt_debug_layers = 0;                  // > 0: the decode step runs only the first N layers (both paths; tools/debug_persist.py)
     int persist_mode = 0, ps_state = 0;        // ps_state: 0 unknown, 1 usable (copies built), -1 unsupported
     std::string ps_why;
     std::vector<void *> ps_wqkv, ps_w13;       // per layer: wq | wk | wv rows in one buffer; w1 / w3 interleaved row by row
+    std::vector<void *> ps_bqkv, ps_b13;       // per layer: the biases in the same order (null when the model has none)
     std::map<int, void *> ps_tabs;             // per KV slot: device PsLayer[layers]
     unsigned long long *ps_arena = nullptr;    // granule arenas of the five edges
     size_t ps_arena_bytes = 0, ps_goff[5] = {0, 0, 0, 0, 0};
@@ -801,6 +804,7 @@ static int persist_build(ifa_model *m)
     const size_t rb_a = tiled_row_bytes(dt0, (size_t)c.dim / cap);
     const size_t QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim;
     m->ps_wqkv.assign(m->layers.size(), nullptr); m->ps_w13.assign(m->layers.size(), nullptr);
+    m->ps_bqkv.assign(m->layers.size(), nullptr); m->ps_b13.assign(m->layers.size(), nullptr);
     for (size_t l = 0; l < m->layers.size(); l++) {
         Layer &L = m->layers[l];
         uint8_t *qkv = nullptr, *w13 = nullptr;
@@ -812,6 +816,24 @@ static int persist_build(ifa_model *m)
         IFA_HIP_CHECK(hipMemcpyAsync(qkv + (QD + KVD) * rb_a, L.t[T_WV].tiled, KVD * rb_a, hipMemcpyDeviceToDevice, m->stream));
         IFA_HIP_CHECK(hipMemcpy2DAsync(w13, 2 * rb_a, L.t[T_W1].tiled, rb_a, rb_a, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
         IFA_HIP_CHECK(hipMemcpy2DAsync(w13 + rb_a, 2 * rb_a, L.t[T_W3].tiled, rb_a, rb_a, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
+        // biases (F16 vectors) in the same order; a missing one of a group counts as zeros
+        if (L.t[T_WQ_B].present() || L.t[T_WK_B].present() || L.t[T_WV_B].present()) {
+            half_t *b = nullptr;
+            IFA_HIP_CHECK(hipMalloc((void **)&b, (QD + 2 * KVD) * 2));
+            IFA_HIP_CHECK(hipMemsetAsync(b, 0, (QD + 2 * KVD) * 2, m->stream));
+            if (L.t[T_WQ_B].present()) IFA_HIP_CHECK(hipMemcpyAsync(b, L.t[T_WQ_B].data, QD * 2, hipMemcpyDeviceToDevice, m->stream));
+            if (L.t[T_WK_B].present()) IFA_HIP_CHECK(hipMemcpyAsync(b + QD, L.t[T_WK_B].data, KVD * 2, hipMemcpyDeviceToDevice, m->stream));
+            if (L.t[T_WV_B].present()) IFA_HIP_CHECK(hipMemcpyAsync(b + QD + KVD, L.t[T_WV_B].data, KVD * 2, hipMemcpyDeviceToDevice, m->stream));
+            m->ps_bqkv[l] = b;
+        }
+        if (L.t[T_W1_B].present() || L.t[T_W3_B].present()) {
+            half_t *b = nullptr;
+            IFA_HIP_CHECK(hipMalloc((void **)&b, 2 * (size_t)c.ffn * 2));
+            IFA_HIP_CHECK(hipMemsetAsync(b, 0, 2 * (size_t)c.ffn * 2, m->stream));
+            if (L.t[T_W1_B].present()) IFA_HIP_CHECK(hipMemcpy2DAsync(b, 4, L.t[T_W1_B].data, 2, 2, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
+            if (L.t[T_W3_B].present()) IFA_HIP_CHECK(hipMemcpy2DAsync(b + 1, 4, L.t[T_W3_B].data, 2, 2, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
+            m->ps_b13[l] = b;
+        }
     }
     const size_t counts[5] = {(size_t)c.dim / 2, (QD + 2 * KVD) / 2, QD / 4 + QD / 16, (size_t)c.dim / 2, (size_t)c.ffn / 2};
     size_t off = 0;
@@ -833,7 +855,9 @@ static void persist_drop(ifa_model *m)
 {
     for (void *p : m->ps_wqkv) if (p) (void)hipFree(p);
     for (void *p : m->ps_w13) if (p) (void)hipFree(p);
-    m->ps_wqkv.clear(); m->ps_w13.clear();
+    for (void *p : m->ps_bqkv) if (p) (void)hipFree(p);
+    for (void *p : m->ps_b13) if (p) (void)hipFree(p);
+    m->ps_wqkv.clear(); m->ps_w13.clear(); m->ps_bqkv.clear(); m->ps_b13.clear();
     for (auto &kv : m->ps_tabs) if (kv.second) (void)hipFree(kv.second);
     m->ps_tabs.clear();
     if (m->ps_arena) { (void)hipFree(m->ps_arena); m->ps_arena = nullptr; }
@@ -872,8 +896,7 @@ static int persist_table(ifa_model *m, const PsLayer **out)
             d.w13 = (const uint8_t *)m->ps_w13[l]; d.w2 = (const uint8_t *)L.t[T_W2].tiled;
             d.attn_norm = (const half_t *)L.t[T_ATTN_NORM].data; d.attn_norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
             d.ffn_norm = (const half_t *)L.t[T_FFN_NORM].data; d.ffn_norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
-            d.bq = (const half_t *)L.t[T_WQ_B].data; d.bk = (const half_t *)L.t[T_WK_B].data; d.bv = (const half_t *)L.t[T_WV_B].data;
-            d.bo = (const half_t *)L.t[T_WO_B].data; d.b1 = (const half_t *)L.t[T_W1_B].data; d.b3 = (const half_t *)L.t[T_W3_B].data;
+            d.bqkv = (const half_t *)m->ps_bqkv[l]; d.bo = (const half_t *)L.t[T_WO_B].data; d.b13 = (const half_t *)m->ps_b13[l];
             d.b2 = (const half_t *)L.t[T_W2_B].data;
             d.kcache = (uint8_t *)L.kcache; d.vcache = (uint8_t *)L.vcache;
         }
@@ -910,6 +933,7 @@ static int launch_persist(ifa_model *m, int l0, int l1, const half_t *x_in, half
     P.rope_order = c.rope_order; P.rope_cols = (int)(c.head_dim * c.partial_rotary + 0.5f);
     P.alibi = c.use_alibi; P.alibi_base = c.tp_rank * c.heads; P.alibi_total = c.heads * std::max(1, c.tp_size);
     P.timeout_ticks = (unsigned)std::max(100, m->opt_persist_timeout_us) * 100u;
+    P.tune_depth = m->opt_persist_depth; P.tune_prio = m->opt_persist_prio;
     return dec_persist_launch(dt0, m->ps_nja, m->ps_njb, c.head_dim, c.kv_dtype == Q8_B32T2 ? 1 : 0, P, m->ps_ncu, m->ps_smem, m->stream);
 }
 
@@ -2185,7 +2209,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
         {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
-        {"debug_layers", &m->opt_debug_layers}};
+        {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;

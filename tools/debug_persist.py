@@ -125,6 +125,17 @@ def print_trace(wk, s, tok, pos, layer):
         print("  %-10s med %7.2f  max %7.2f   (+%.2f)" % (lab, med, mx, med - prev))
         if lab not in ("attn_in", "attn_done"):
             prev = med
+    extra = ["partials", "bar1", "quantised", "b0_wait", "b0_data", "b0_done", "b1_wait", "b1_data", "b1_done", "b2_wait", "b2_data", "b2_done"]
+    rel2 = (tr[:, 14:26] - t0) * 0.01
+    rel2[tr[:, 14:26] == 0] = np.nan
+    print("  op 0 detail:", " ".join("%s=%.2f" % (extra[i], float(np.nanmedian(rel2[:, i]))) for i in range(12) if not np.all(np.isnan(rel2[:, i]))))
+    ld = (tr[:, 26:30] - t0) * 0.01
+    print("  loader: qkv issue start %.2f, w13 issue start %.2f, w13 issued %.2f, w2 issued %.2f (medians); ring-full events per layer: median %d" % (
+        float(np.median(ld[:, 0])), float(np.median(ld[:, 1])), float(np.median(ld[:, 2])), float(np.median(ld[:, 3])), int(np.median(tr[:, 25]))))
+    ok = (tr[:, 30] > 0) & (tr[:, 31] > 0) & (tr[:, 13] > 0)
+    if ok.any():
+        mhz = (tr[ok, 31] - tr[ok, 30]) / ((tr[ok, 13] - tr[ok, 0]) * 0.01)
+        print("  shader clock during the layer: median %.0f MHz (min %.0f, max %.0f)" % (float(np.median(mhz)), float(mhz.min()), float(mhz.max())))
 
 
 def main():
@@ -138,11 +149,15 @@ def main():
     ap.add_argument("--trace", type=int, default=-1)
     ap.add_argument("--time", type=int, default=0)
     ap.add_argument("--timeout-us", type=int, default=20000)
+    ap.add_argument("--opt", action="append", default=[], help="name=value worker options (e.g. persist_depth=2)")
     a = ap.parse_args()
     wd = {"q4": dt.Q4_B32T1A, "q3h": dt.Q3H_B64T1}[a.wdtype]
     kv = {"f16": dt.F16, "q8": dt.Q8_B32T2}[a.kv]
     wk, s = build(a.shape, wd, kv, 1024)
     wk.set_option("persist_timeout_us", a.timeout_us)
+    for o in a.opt:
+        k, v = o.split("=")
+        wk.set_option(k, int(v))
     prompt = (np.arange(a.prompt, dtype=np.int32) * 7 + 3) % s["vocab"]
     tok = int(wk.forward(prompt, 0))
     pos = a.prompt
