@@ -172,7 +172,7 @@ def main():
 
     tok_s = steps / wall
     n_avg = PROMPT_LEN + warmup + steps / 2.0
-    w_bytes = synth.weight_bytes(args.shape, wd)
+    w_bytes = synth.weight_bytes(args.shape, wd, streamed=True)      # what the decode kernels read (Q3H: 36 B per 64 weights)
     kv_bytes = synth.kv_bytes_per_ctx_row(args.shape, kvd)
     bytes_per_token = w_bytes + kv_bytes * n_avg
     out = {

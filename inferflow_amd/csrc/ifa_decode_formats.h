@@ -328,76 +328,6 @@ struct WRowQ6B64 {
     }
 };
 
-// Q3H_B64T1: 32 seven-bit pair codes p = q0 + 11*q1 per 64 elements (quantization.h:823-851), streamed
-// from the byte-transposed tiled form (ifa_tiled.h): seven dwords D0..D6 whose bytes are pair codes
-// 0..27 in their low 7 bits; bit 7 of D_w's byte b is bit w of pair code 28+b.
-//   tiled: [D0..D3][D4,D5][base,scale,D6]
-// q1 = p/11 = (372*p + 256) >> 12 for 0 <= p < 128 (two pairs per 32-bit multiply-add, quotient lands in
-// the top nibble of bytes 1 and 3);  q0 = p - 11*q1 is never formed:
-//   sum q0*xe + q1*xo = sum p*xe + sum q1*xo - 11 * sum q1*xe.
-template <int NJ>
-struct WRowQ3H {
-    u32x4 c[NJ];
-    u32x2 m[NJ];
-    u32x2 sbh[NJ];   // [0] = base | scale<<16, [1] = D6
-    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, int blk0 = 0)
-    {
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int blk = min(blk0 + lane + 64 * j, nblk - 1);
-            c[j] = nt_load<u32x4>(wrow + (size_t)blk * 16);
-            m[j] = nt_load<u32x2>(wrow + (size_t)nblk * 16 + (size_t)blk * 8);
-            sbh[j] = nt_load<u32x2>(wrow + (size_t)nblk * 24 + (size_t)blk * 8);
-        }
-    }
-    template <class S>
-    __device__ __forceinline__ void load_src(const S &src, int nblk, int lane, int blk0 = 0)
-    {
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const uint32_t blk = (uint32_t)min(blk0 + lane + 64 * j, nblk - 1);
-            c[j] = src.template ld<u32x4>(blk * 16);
-            m[j] = src.template ld<u32x2>((uint32_t)nblk * 16 + blk * 8);
-            sbh[j] = src.template ld<u32x2>((uint32_t)nblk * 24 + blk * 8);
-        }
-    }
-    // four quotients p/11, one per byte
-    static __device__ __forceinline__ uint32_t div11x4(uint32_t p)
-    {
-        const uint32_t a = p & 0x00FF00FFu;                                   // pairs 0, 2
-        const uint32_t b = __builtin_amdgcn_perm(0u, p, 0x0C030C01u);        // pairs 1, 3 (0x0C selects zero)
-        const uint32_t ra = a * 372u + 0x01000100u, rb = b * 372u + 0x01000100u;
-        // bytes [ra.1, rb.1, ra.3, rb.3]: quotients in the high nibbles
-        return (__builtin_amdgcn_perm(rb, ra, 0x07030501u) >> 4) & 0x0F0F0F0Fu;
-    }
-    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X, float acc0 = 0.0f) const
-    {
-        float acc = acc0;
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const float base = hbits2f((uint16_t)(sbh[j][0] & 0xFFFFu)), scale = hbits2f((uint16_t)(sbh[j][0] >> 16));
-            const uint32_t d0 = c[j][0], d1 = c[j][1], d2 = c[j][2], d3 = c[j][3], d4 = m[j][0], d5 = m[j][1], d6 = sbh[j][1];
-            const uint32_t top = ((d0 >> 7) & 0x01010101u) | ((d1 >> 6) & 0x02020202u) | ((d2 >> 5) & 0x04040404u)
-                               | ((d3 >> 4) & 0x08080808u) | ((d4 >> 3) & 0x10101010u) | ((d5 >> 2) & 0x20202020u)
-                               | ((d6 >> 1) & 0x40404040u);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                int da = 0, db = 0;
-#pragma unroll
-                for (int w = 0; w < 4; w++) {           // code dword 4h+w = pairs of x-block elements 8w .. 8w+7
-                    const int k = 4 * h + w;
-                    const uint32_t Dk = k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : k == 3 ? d3 : k == 4 ? d4 : k == 5 ? d5 : d6;
-                    const uint32_t Pw = k == 7 ? top : (Dk & 0x7F7F7F7Fu);
-                    const uint32_t Q1 = div11x4(Pw);
-                    da = sdot4((int)Pw, X.xe[j][h][w], da);
-                    da = sdot4((int)Q1, X.xo[j][h][w], da);
-                    db = sdot4((int)Q1, X.xe[j][h][w], db);
-                }
-                acc = acc + dec_term(da - 11 * db, scale, base, X.xsf[j][h], X.xs[j][h]);
-            }
-        }
-        return acc;
-    }
-};
+// Q3H_B64T1 rows are streamed as nibble pairs (ifa_tiled.h: q3h_aos_to_nibbles), i.e. as WRowQ4B64 with codes 0..10.
 
 } // namespace ifa

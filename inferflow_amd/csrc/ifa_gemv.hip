@@ -73,15 +73,8 @@ __global__ void __launch_bounds__(256) k_gemv_ax8_generic(const uint8_t *__restr
     float acc = 0.0f;
     for (int blk = lane; blk < nblk; blk += 64) {
         RawBlock<BB> b;
-        if constexpr (TILED && DT == Q3H_B64T1) {    // byte-transposed pair codes -> reference block
-            uint8_t d28[28], a[32];
-            const uint8_t *p0 = wrow + (size_t)blk * 16, *p1 = wrow + (size_t)16 * nblk + (size_t)blk * 8;
-            const uint8_t *p2 = wrow + (size_t)24 * nblk + (size_t)blk * 8;
-            for (int i = 0; i < 16; i++) d28[i] = p0[i];
-            for (int i = 0; i < 8; i++) d28[16 + i] = p1[i];
-            for (int i = 0; i < 4; i++) { a[i] = p2[i]; d28[24 + i] = p2[4 + i]; }
-            q3h_tiled_to_aos(d28, a);
-            for (int i = 0; i < 16; i++) b.w[i] = (uint16_t)(a[2 * i] | (a[2 * i + 1] << 8));
+        if constexpr (TILED && DT == Q3H_B64T1) {
+            // nibble pairs (ifa_tiled.h): the codes are read directly below, b stays unused
         } else if constexpr (TILED) {
             using L = TiledLayout<DT>;
 #pragma unroll
@@ -95,7 +88,12 @@ __global__ void __launch_bounds__(256) k_gemv_ax8_generic(const uint8_t *__restr
             b.load(wrow + (size_t)blk * BB);
         }
         int q[CAP]; float scale, base;
-        decode_block<DT>(b, q, scale, base);
+        if constexpr (TILED && DT == Q3H_B64T1) {
+            const uint8_t *p0 = wrow + (size_t)blk * 32, *p1 = wrow + (size_t)32 * nblk + (size_t)blk * 4;
+#pragma unroll
+            for (int i = 0; i < 32; i++) { const uint32_t d = p0[i]; q[2 * i] = (int)(d & 0x0F); q[2 * i + 1] = (int)(d >> 4); }
+            base = hbits2f((uint16_t)(p1[0] | (p1[1] << 8))); scale = hbits2f((uint16_t)(p1[2] | (p1[3] << 8)));
+        } else decode_block<DT>(b, q, scale, base);
 #pragma unroll
         for (int h = 0; h < CAP / 32; h++) {
             int xq[32]; float xs; int xsum;

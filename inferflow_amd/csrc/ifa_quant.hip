@@ -96,15 +96,13 @@ __global__ void __launch_bounds__(256) k_repack(const uint8_t *__restrict__ src,
     int row = (int)(bi / nblk), blk = (int)(bi % nblk);
     const uint8_t *s = src + bi * BB;
     uint8_t *drow = dst + (size_t)row * tiled_row_bytes(DT, (size_t)nblk);
-    if constexpr (DT == Q3H_B64T1) {      // byte-transposed pair codes (ifa_tiled.h)
-        uint8_t a[32], d28[28];
+    if constexpr (DT == Q3H_B64T1) {      // pair codes expanded to nibble pairs: the Q4_B64T1 tiled block (ifa_tiled.h)
+        uint8_t a[32], n32[32];
         for (int i = 0; i < 32; i++) a[i] = s[i];
-        q3h_aos_to_tiled(a, d28);
-        uint8_t *p0 = drow + (size_t)blk * 16, *p1 = drow + (size_t)16 * nblk + (size_t)blk * 8;
-        uint8_t *p2 = drow + (size_t)24 * nblk + (size_t)blk * 8;
-        for (int i = 0; i < 16; i++) p0[i] = d28[i];
-        for (int i = 0; i < 8; i++) p1[i] = d28[16 + i];
-        for (int i = 0; i < 4; i++) { p2[i] = a[i]; p2[4 + i] = d28[24 + i]; }
+        q3h_aos_to_nibbles(a, n32);
+        uint8_t *p0 = drow + (size_t)blk * 32, *p1 = drow + (size_t)32 * nblk + (size_t)blk * 4;
+        for (int i = 0; i < 32; i++) p0[i] = n32[i];
+        for (int i = 0; i < 4; i++) p1[i] = a[i];
         return;
     }
 #pragma unroll

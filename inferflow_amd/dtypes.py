@@ -36,3 +36,11 @@ def block_bytes(dt):
 def row_bytes(dt, cols):
     c = block_capacity(dt)
     return (cols + c - 1) // c * block_bytes(dt)
+
+
+def streamed_row_bytes(dt, cols):
+    """Bytes of one weight row in the layout the fused decode kernels STREAM (csrc/ifa_tiled.h): the reference block
+    bytes, except Q3H_B64T1 whose pair codes are expanded to nibble pairs at load time (36 instead of 32 per 64 weights)."""
+    c = block_capacity(dt)
+    per_block = 36 if dt == Q3H_B64T1 else block_bytes(dt)
+    return ((cols + c - 1) // c * per_block + 15) // 16 * 16 if dt in AX8 else row_bytes(dt, cols)

@@ -89,8 +89,9 @@ def build(shape_name, wdtype=dt.Q4_B32T1A, kv_dtype=dt.F16, max_ctx=1024, quant_
     return wk, host, s
 
 
-def weight_bytes(shape_name, wdtype=dt.Q4_B32T1A, quant_threshold=TENSOR_QUANT_THRESHOLD):
-    """Algorithmic weight bytes per decoded token, excluding KV."""
+def weight_bytes(shape_name, wdtype=dt.Q4_B32T1A, quant_threshold=TENSOR_QUANT_THRESHOLD, streamed=False):
+    """Algorithmic weight bytes per decoded token, excluding KV.  streamed=True: the bytes of the layout
+    the decode kernels read (differs from the reference block bytes for Q3H_B64T1 only: 36 vs 32 per 64 weights)."""
     s = SHAPES[shape_name]
     per_layer = 0
     for tid, kind in MATRICES:
@@ -98,7 +99,7 @@ def weight_bytes(shape_name, wdtype=dt.Q4_B32T1A, quant_threshold=TENSOR_QUANT_T
             continue
         rows, cols = _shape(kind, s)
         d = wdtype if rows * cols >= quant_threshold else dt.F16
-        n = rows * dt.row_bytes(d, cols)
+        n = rows * (dt.streamed_row_bytes(d, cols) if streamed else dt.row_bytes(d, cols))
         if s.get("experts", 0) and tid in (W.T_W1, W.T_W2, W.T_W3):
             n *= s["moe_top_k"]                  # a token streams its top-k experts only
         per_layer += n
