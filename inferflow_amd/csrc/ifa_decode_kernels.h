@@ -74,6 +74,22 @@ __device__ __forceinline__ int q8_round_div1(float v, float qs)
     return min(max((int)k, -128), 127);
 }
 
+// Four Q8_B32T2 codes (one dword of int8) times their block's F16 scale -> four halves, each EXACTLY
+// half((float)q * scale), the value LayerKVCache::GetKRows / GetVRows hand back (kv_cache.cc:104-157): q in [-128, 127] is
+// exact in half -- built without a conversion as (1024 + (q ^ 0x80)) - 1152: the half with bits 0x6400 | u is 1024 + u --
+// and the product of two halves is exact in fp32, so ONE packed half multiply (round to nearest even) rounds the same
+// exact value the reference rounds.  3 packed instructions per 2 values instead of sign-extend / cvt / mul / cvt per value:
+// the Q8 cache had cost the decode attention 2.3 us per layer over the F16 one (9.8 vs 7.5 us).
+__device__ __forceinline__ void q8x4_dequant_h(uint32_t w, half2_t sc2, half2_t &lo, half2_t &hi)
+{
+    const uint32_t x = w ^ 0x80808080u;
+    const uint32_t a = __builtin_amdgcn_perm(0x64646464u, x, 0x04010400u);      // halves 1024 + u0, 1024 + u1
+    const uint32_t b = __builtin_amdgcn_perm(0x64646464u, x, 0x04030402u);      // halves 1024 + u2, 1024 + u3
+    const half2_t bias = {(half_t)-1152.0f, (half_t)-1152.0f};
+    lo = (__builtin_bit_cast(half2_t, a) + bias) * sc2;
+    hi = (__builtin_bit_cast(half2_t, b) + bias) * sc2;
+}
+
 #ifndef IFA_NT_WEIGHTS
 #define IFA_NT_WEIGHTS 1            // stream weights with the non-temporal policy (read once per token)
 #endif
@@ -1042,8 +1058,20 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     for (int j = tid; j < n_ctx; j += 256) {
         float c = 0.0f;
         if (Q8 && j == pos) {
-#pragma unroll 8
-            for (int d = 0; d < HD; d++) c = __builtin_fmaf(h2f(qs[d]), h2f(kn[d]), c);
+            // the new token's (round-tripped) key: wide LDS reads into registers, then the same chain -- a scalar loop
+            // over LDS kept the whole workgroup waiting at the next barrier for ~0.7 us
+            uint32_t knr[HD / 2];
+#pragma unroll
+            for (int i = 0; i < HD / 8; i++) {
+                const u32x4 t = reinterpret_cast<const u32x4 *>(kn)[i];
+                knr[4 * i] = t[0]; knr[4 * i + 1] = t[1]; knr[4 * i + 2] = t[2]; knr[4 * i + 3] = t[3];
+            }
+#pragma unroll
+            for (int i = 0; i < HD / 2; i++) {
+                const half2_t k2 = __builtin_bit_cast(half2_t, knr[i]);
+                c = __builtin_fmaf(h2f(qs[2 * i]), (float)k2[0], c);
+                c = __builtin_fmaf(h2f(qs[2 * i + 1]), (float)k2[1], c);
+            }
         } else {
             if constexpr (!Q8) {
                 // the new token's key comes from LDS into the same registers (wide reads) and takes the common path: a
@@ -1059,12 +1087,31 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
             if constexpr (Q8) {
 #pragma unroll
                 for (int b = 0; b < HD / 32; b++) {
-                    const float sc = hbits2f((uint16_t)(kbyte(b * 34) | (kbyte(b * 34 + 1) << 8)));
+                    const uint16_t scb = (uint16_t)(kbyte(b * 34) | (kbyte(b * 34 + 1) << 8));
+                    if constexpr (KALIGN >= 4) {
+                        // four codes per dword (q8x4_dequant_h); a block's codes start at byte 34 b + 2 of the slice
+                        const half_t sch = __builtin_bit_cast(half_t, scb);
+                        const half2_t sc2 = {sch, sch};
 #pragma unroll
-                    for (int i = 0; i < 32; i++) {
-                        const int qv = (int)(int8_t)kbyte(b * 34 + 2 + i);
-                        const float kvv = h2f(f2h((float)qv * sc));
-                        c = __builtin_fmaf(h2f(qs[b * 32 + i]), kvv, c);
+                        for (int w4 = 0; w4 < 8; w4++) {
+                            const int B0 = b * 34 + 2 + 4 * w4;
+                            const uint32_t cw = (B0 & 3) == 0 ? kq32[B0 >> 2]
+                                : __builtin_amdgcn_alignbyte(kq32[(B0 >> 2) + 1 < (int)(sizeof(kq32) / 4) ? (B0 >> 2) + 1 : (B0 >> 2)], kq32[B0 >> 2], (B0 & 3));
+                            half2_t lo, hi;
+                            q8x4_dequant_h(cw, sc2, lo, hi);
+                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4]), (float)lo[0], c);
+                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 1]), (float)lo[1], c);
+                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 2]), (float)hi[0], c);
+                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 3]), (float)hi[1], c);
+                        }
+                    } else {
+                        const float sc = hbits2f(scb);
+#pragma unroll
+                        for (int i = 0; i < 32; i++) {
+                            const int qv = (int)(int8_t)kbyte(b * 34 + 2 + i);
+                            const float kvv = h2f(f2h((float)qv * sc));
+                            c = __builtin_fmaf(h2f(qs[b * 32 + i]), kvv, c);
+                        }
                     }
                 }
             } else {
@@ -1114,14 +1161,22 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
 #pragma unroll
         for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, h2f(vn[dg * 8 + e]), o[e]);
     };
+    // 8 codes (four 2-byte pieces) of one Q8 V block times its scale, accumulated in element order
+    auto acc_q8w = [&](float pj, uint16_t scb, uint16_t c0, uint16_t c1, uint16_t c2, uint16_t c3) {
+        const half_t sch = __builtin_bit_cast(half_t, scb);
+        const half2_t sc2 = {sch, sch};
+        half2_t v01, v23, v45, v67;
+        q8x4_dequant_h((uint32_t)c0 | ((uint32_t)c1 << 16), sc2, v01, v23);
+        q8x4_dequant_h((uint32_t)c2 | ((uint32_t)c3 << 16), sc2, v45, v67);
+        o[0] = __builtin_fmaf(pj, (float)v01[0], o[0]); o[1] = __builtin_fmaf(pj, (float)v01[1], o[1]);
+        o[2] = __builtin_fmaf(pj, (float)v23[0], o[2]); o[3] = __builtin_fmaf(pj, (float)v23[1], o[3]);
+        o[4] = __builtin_fmaf(pj, (float)v45[0], o[4]); o[5] = __builtin_fmaf(pj, (float)v45[1], o[5]);
+        o[6] = __builtin_fmaf(pj, (float)v67[0], o[6]); o[7] = __builtin_fmaf(pj, (float)v67[1], o[7]);
+    };
     auto acc_q8 = [&](float pj, int j) {
-        const uint8_t *blk = pvc + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
-        const float sc = hbits2f(*reinterpret_cast<const uint16_t *>(blk));
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int qv = (int)(int8_t)blk[2 + (dg % 4) * 8 + e];
-            o[e] = __builtin_fmaf(pj, h2f(f2h((float)qv * sc)), o[e]);
-        }
+        const uint16_t *blk = reinterpret_cast<const uint16_t *>(pvc + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34);
+        const uint16_t *cp = blk + 1 + (dg % 4) * 4;
+        acc_q8w(pj, blk[0], cp[0], cp[1], cp[2], cp[3]);
     };
 #pragma unroll
     for (int i = 0; i < VPRE; i++) {        // first 256 keys: V rows already in registers (static indexing)
@@ -1129,14 +1184,8 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         if (j < n_ctx && vact) {
             const float pj = h2f(S[j]);
             if (j == pos) acc_new(pj);
-            else if constexpr (Q8) {
-                const float sc = hbits2f(vq[i][0]);
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int qv = (int)(int8_t)((vq[i][1 + (e >> 1)] >> (8 * (e & 1))) & 0xFF);
-                    o[e] = __builtin_fmaf(pj, h2f(f2h((float)qv * sc)), o[e]);
-                }
-            } else acc_v(pj, vreg[i]);
+            else if constexpr (Q8) acc_q8w(pj, vq[i][0], vq[i][1], vq[i][2], vq[i][3], vq[i][4]);
+            else acc_v(pj, vreg[i]);
         }
     }
     for (int j = vact ? sp + NSPLIT * VPRE : n_ctx; j < n_ctx; j += NSPLIT) {

@@ -626,12 +626,19 @@ __device__ __forceinline__ void ps_attention(PsCtx &c, const PsParams &P, const 
                 if constexpr (Q8) {
 #pragma unroll
                     for (int b = 0; b < HD / 32; b++) {
-                        const float sc = hbits2f((uint16_t)(kbyte(b * 34) | (kbyte(b * 34 + 1) << 8)));
+                        const half_t sch = __builtin_bit_cast(half_t, (uint16_t)(kbyte(b * 34) | (kbyte(b * 34 + 1) << 8)));
+                        const half2_t sc2 = {sch, sch};
 #pragma unroll
-                        for (int i = 0; i < 32; i++) {
-                            const int qv = (int)(int8_t)kbyte(b * 34 + 2 + i);
-                            const float kvv = h2f(f2h((float)qv * sc));
-                            cacc = __builtin_fmaf(h2f(qs[b * 32 + i]), kvv, cacc);
+                        for (int w4 = 0; w4 < 8; w4++) {      // four codes per dword (q8x4_dequant_h, ifa_decode_kernels.h)
+                            const int B0 = b * 34 + 2 + 4 * w4;
+                            const uint32_t cw = (B0 & 3) == 0 ? kq32[B0 >> 2]
+                                : __builtin_amdgcn_alignbyte(kq32[(B0 >> 2) + 1 < KBYTES / 4 ? (B0 >> 2) + 1 : (B0 >> 2)], kq32[B0 >> 2], (B0 & 3));
+                            half2_t lo, hi;
+                            q8x4_dequant_h(cw, sc2, lo, hi);
+                            cacc = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4]), (float)lo[0], cacc);
+                            cacc = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 1]), (float)lo[1], cacc);
+                            cacc = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 2]), (float)hi[0], cacc);
+                            cacc = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 3]), (float)hi[1], cacc);
                         }
                     }
                 } else {
@@ -696,14 +703,22 @@ __device__ __forceinline__ void ps_attention(PsCtx &c, const PsParams &P, const 
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, h2f(vn[dg * 8 + e]), o[e]);
         };
+        auto acc_q8w = [&](float pj, uint16_t scb, uint16_t c0, uint16_t c1, uint16_t c2, uint16_t c3) __attribute__((always_inline)) {
+            const half_t sch = __builtin_bit_cast(half_t, scb);
+            const half2_t sc2 = {sch, sch};
+            half2_t v01, v23, v45, v67;
+            q8x4_dequant_h((uint32_t)c0 | ((uint32_t)c1 << 16), sc2, v01, v23);
+            q8x4_dequant_h((uint32_t)c2 | ((uint32_t)c3 << 16), sc2, v45, v67);
+            o[0] = __builtin_fmaf(pj, (float)v01[0], o[0]); o[1] = __builtin_fmaf(pj, (float)v01[1], o[1]);
+            o[2] = __builtin_fmaf(pj, (float)v23[0], o[2]); o[3] = __builtin_fmaf(pj, (float)v23[1], o[3]);
+            o[4] = __builtin_fmaf(pj, (float)v45[0], o[4]); o[5] = __builtin_fmaf(pj, (float)v45[1], o[5]);
+            o[6] = __builtin_fmaf(pj, (float)v67[0], o[6]); o[7] = __builtin_fmaf(pj, (float)v67[1], o[7]);
+        };
         auto acc_q8 = [&](float pj, int j) __attribute__((always_inline)) {
-            const __attribute__((address_space(1))) uint8_t *blk = ps_g(pvc) + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
-            const float sc = hbits2f(*reinterpret_cast<const __attribute__((address_space(1))) uint16_t *>(blk));
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int qv = (int)(int8_t)blk[2 + (dg % 4) * 8 + e];
-                o[e] = __builtin_fmaf(pj, h2f(f2h((float)qv * sc)), o[e]);
-            }
+            const __attribute__((address_space(1))) uint16_t *blk =
+                reinterpret_cast<const __attribute__((address_space(1))) uint16_t *>(ps_g(pvc) + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34);
+            const __attribute__((address_space(1))) uint16_t *cp = blk + 1 + (dg % 4) * 4;
+            acc_q8w(pj, blk[0], cp[0], cp[1], cp[2], cp[3]);
         };
 #pragma unroll
         for (int i = 0; i < VPRE; i++) {        // first 256 keys: V rows already in registers (static indexing)
@@ -711,14 +726,8 @@ __device__ __forceinline__ void ps_attention(PsCtx &c, const PsParams &P, const 
             if (j < n_ctx) {
                 const float pj = h2f(S[j]);
                 if (j == pos) acc_new(pj);
-                else if constexpr (Q8) {
-                    const float sc = hbits2f(vq[i][0]);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int qv = (int)(int8_t)((vq[i][1 + (e >> 1)] >> (8 * (e & 1))) & 0xFF);
-                        o[e] = __builtin_fmaf(pj, h2f(f2h((float)qv * sc)), o[e]);
-                    }
-                } else acc_v(pj, vreg[i]);
+                else if constexpr (Q8) acc_q8w(pj, vq[i][0], vq[i][1], vq[i][2], vq[i][3], vq[i][4]);
+                else acc_v(pj, vreg[i]);
             }
         }
         for (int j = sp + NSPLIT * VPRE; j < n_ctx; j += NSPLIT) {
