@@ -303,6 +303,13 @@ int ifa_comm_init_all(const int *device_ids, int n, ifa_comm **comms_out);
  * device): kernels / copies on that device with a host rendezvous between the rank threads -- host-synchronous, not
  * capturable (ifa_comm_capturable() == 0); for exercising the multi-rank paths on a 1-GPU box */
 int ifa_comm_capturable(const ifa_comm *c);
+/* identity of the communicator OBJECT (a new one at the same address gets a new serial): what a cached, captured step
+ * is keyed on */
+unsigned long long ifa_comm_serial(const ifa_comm *c);
+/* Wake every rank blocked in (or later entering) a collective of this communicator with an error: called by the rank
+ * that failed, or by whoever supervises the ranks (ncclCommAbort, inference_worker.cc has no counterpart: the reference
+ * deadlocks its worker threads in this case).  The communicator can only be destroyed afterwards. */
+int ifa_comm_abort(ifa_comm *c);
 int ifa_comm_destroy(ifa_comm *c);
 int ifa_comm_rank(const ifa_comm *c);
 int ifa_comm_size(const ifa_comm *c);

@@ -121,6 +121,8 @@ SIGNATURES = {
     "ifa_comm_init_all": (_i, [_vp, _i, C.POINTER(_vp)]),
     "ifa_comm_destroy": (_i, [_vp]),
     "ifa_comm_capturable": (_i, [_vp]),
+    "ifa_comm_serial": (C.c_ulonglong, [_vp]),
+    "ifa_comm_abort": (_i, [_vp]),
     "ifa_comm_rank": (_i, [_vp]),
     "ifa_comm_size": (_i, [_vp]),
     "ifa_comm_group_start": (_i, []),

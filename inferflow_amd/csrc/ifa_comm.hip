@@ -23,6 +23,7 @@
 // the multi-rank paths -- engine threads, slicing, merges, hand-over, distributed argmax -- run in the GPU tests.
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -40,15 +41,25 @@ struct LocalGroup {
     std::condition_variable cv;
     int arrived = 0;
     uint64_t gen = 0;
+    bool aborted = false;       // set by ifa_comm_abort: every waiter wakes up and every later call fails
     const void *sendp[64];
     void *recvp[64];
-    struct Slot { const void *src = nullptr; size_t bytes = 0; bool full = false; } slots[64][64];
-    void barrier()
+    struct Slot { const void *src = nullptr; size_t bytes = 0; bool full = false, refused = false; } slots[64][64];
+    // false: the group was aborted (a peer failed): the caller must return an error instead of touching peer buffers
+    bool barrier()
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const uint64_t g = gen;
         if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        else cv.wait(lk, [&] { return gen != g || aborted; });
+        return !aborted;
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
     }
 };
 
@@ -75,9 +86,13 @@ __global__ void __launch_bounds__(256) k_local_allgather(const PtrTable t, int n
 
 } // namespace
 
+static std::atomic<unsigned long long> g_comm_serial{1};
+
 struct ifa_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
+    unsigned long long serial = g_comm_serial++;      // identity of this communicator object (ifa_comm_serial)
+    std::atomic<bool> aborted{false};
     std::shared_ptr<LocalGroup> local;      // loopback group (ranks sharing a device); comm == nullptr then
 };
 
@@ -144,12 +159,24 @@ int ifa_comm_init_all(const int *device_ids, int n, ifa_comm **comms_out)
 int ifa_comm_destroy(ifa_comm *c)
 {
     if (!c) return IFA_OK;
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->comm && !c->aborted.load()) (void)ncclCommDestroy(c->comm);
     delete c;
     return IFA_OK;
 }
 
 int ifa_comm_capturable(const ifa_comm *c) { return (c && c->local) ? 0 : 1; }
+unsigned long long ifa_comm_serial(const ifa_comm *c) { return c ? c->serial : 0ull; }
+
+// A rank that fails between two collectives leaves its peers blocked in the next one.  Abort wakes them: RCCL
+// communicators are aborted (ncclCommAbort: outstanding and later operations fail), loopback groups raise a flag that
+// every rendezvous checks.  The communicator is unusable afterwards; destroy it.
+int ifa_comm_abort(ifa_comm *c)
+{
+    if (!c) return IFA_OK;
+    if (c->local) c->local->abort();
+    else if (c->comm && !c->aborted.exchange(true)) (void)ncclCommAbort(c->comm);      // (frees the communicator: not destroyed again)
+    return IFA_OK;
+}
 int ifa_comm_rank(const ifa_comm *c) { return c ? c->rank : -1; }
 int ifa_comm_size(const ifa_comm *c) { return c ? c->nranks : 0; }
 
@@ -165,7 +192,7 @@ int ifa_allreduce_sum_f16(ifa_comm *c, const void *send_f16, void *recv_f16, siz
         LocalGroup &g = *c->local;
         IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
         { std::lock_guard<std::mutex> lk(g.mu); g.sendp[c->rank] = send_f16; g.recvp[c->rank] = recv_f16; }
-        g.barrier();
+        if (!g.barrier()) return ifa_fail(IFA_ERR_STATE, "ifa_allreduce_sum_f16: the group was aborted (a peer failed)");
         if (c->rank == 0) {
             PtrTable t; memset(&t, 0, sizeof(t));
             for (int r = 0; r < g.n; r++) { t.send[r] = g.sendp[r]; t.recv[r] = g.recvp[r]; }
@@ -173,7 +200,7 @@ int ifa_allreduce_sum_f16(ifa_comm *c, const void *send_f16, void *recv_f16, siz
             IFA_LAUNCH_CHECK();
             IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
         }
-        g.barrier();
+        if (!g.barrier()) return ifa_fail(IFA_ERR_STATE, "ifa_allreduce_sum_f16: the group was aborted (a peer failed)");
         return IFA_OK;
     }
     IFA_NCCL_CHECK(ncclAllReduce(send_f16, recv_f16, count, ncclFloat16, ncclSum, c->comm, ifa_s(stream)));
@@ -188,7 +215,7 @@ int ifa_allgather(ifa_comm *c, const void *send, void *recv, size_t bytes_per_ra
         LocalGroup &g = *c->local;
         IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
         { std::lock_guard<std::mutex> lk(g.mu); g.sendp[c->rank] = send; g.recvp[c->rank] = recv; }
-        g.barrier();
+        if (!g.barrier()) return ifa_fail(IFA_ERR_STATE, "ifa_allgather: the group was aborted (a peer failed)");
         if (c->rank == 0) {
             PtrTable t; memset(&t, 0, sizeof(t));
             for (int r = 0; r < g.n; r++) { t.send[r] = g.sendp[r]; t.recv[r] = g.recvp[r]; }
@@ -196,7 +223,7 @@ int ifa_allgather(ifa_comm *c, const void *send, void *recv, size_t bytes_per_ra
             IFA_LAUNCH_CHECK();
             IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
         }
-        g.barrier();
+        if (!g.barrier()) return ifa_fail(IFA_ERR_STATE, "ifa_allgather: the group was aborted (a peer failed)");
         return IFA_OK;
     }
     IFA_NCCL_CHECK(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, c->comm, ifa_s(stream)));
@@ -212,12 +239,12 @@ int ifa_broadcast(ifa_comm *c, void *buf, size_t bytes, int root, ifa_stream str
         LocalGroup &g = *c->local;
         IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
         { std::lock_guard<std::mutex> lk(g.mu); g.recvp[c->rank] = buf; }
-        g.barrier();
+        if (!g.barrier()) return ifa_fail(IFA_ERR_STATE, "ifa_broadcast: the group was aborted (a peer failed)");
         if (c->rank != root) {
             IFA_HIP_CHECK(hipMemcpyAsync(buf, g.recvp[root], bytes, hipMemcpyDeviceToDevice, ifa_s(stream)));
             IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
         }
-        g.barrier();
+        if (!g.barrier()) return ifa_fail(IFA_ERR_STATE, "ifa_broadcast: the group was aborted (a peer failed)");
         return IFA_OK;
     }
     IFA_NCCL_CHECK(ncclBroadcast(buf, buf, bytes, ncclInt8, root, c->comm, ifa_s(stream)));
@@ -233,10 +260,13 @@ int ifa_send(ifa_comm *c, const void *buf, size_t bytes, int peer, ifa_stream st
         IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));
         std::unique_lock<std::mutex> lk(g.mu);
         LocalGroup::Slot &sl = g.slots[c->rank][peer];
-        g.cv.wait(lk, [&] { return !sl.full; });
-        sl.src = buf; sl.bytes = bytes; sl.full = true;
+        g.cv.wait(lk, [&] { return !sl.full || g.aborted; });
+        if (g.aborted) return ifa_fail(IFA_ERR_STATE, "ifa_send: the group was aborted (a peer failed)");
+        sl.src = buf; sl.bytes = bytes; sl.full = true; sl.refused = false;
         g.cv.notify_all();
-        g.cv.wait(lk, [&] { return !sl.full; });
+        g.cv.wait(lk, [&] { return !sl.full || g.aborted; });
+        if (g.aborted) { sl.full = false; return ifa_fail(IFA_ERR_STATE, "ifa_send: the group was aborted (a peer failed)"); }
+        if (sl.refused) return ifa_fail(IFA_ERR_ARG, "ifa_send: the receiver expected another size than %zu bytes", bytes);
         return IFA_OK;
     }
     IFA_NCCL_CHECK(ncclSend(buf, bytes, ncclInt8, peer, c->comm, ifa_s(stream)));
@@ -253,8 +283,14 @@ int ifa_recv(ifa_comm *c, void *buf, size_t bytes, int peer, ifa_stream stream)
         {
             std::unique_lock<std::mutex> lk(g.mu);
             LocalGroup::Slot &sl = g.slots[peer][c->rank];
-            g.cv.wait(lk, [&] { return sl.full; });
-            IFA_REQUIRE(sl.bytes == bytes, "ifa_recv: %zu bytes expected, the peer sends %zu", bytes, sl.bytes);
+            g.cv.wait(lk, [&] { return sl.full || g.aborted; });
+            if (g.aborted) return ifa_fail(IFA_ERR_STATE, "ifa_recv: the group was aborted (a peer failed)");
+            if (sl.bytes != bytes) {      // release the sender too (it would wait for the slot forever) and tell it why
+                const size_t got = sl.bytes;
+                sl.full = false; sl.refused = true;
+                g.cv.notify_all();
+                return ifa_fail(IFA_ERR_ARG, "ifa_recv: %zu bytes expected, the peer sends %zu", bytes, got);
+            }
             src = sl.src;
         }
         IFA_HIP_CHECK(hipMemcpyAsync(buf, src, bytes, hipMemcpyDeviceToDevice, ifa_s(stream)));

@@ -112,6 +112,13 @@ struct ifa_model {
     int *tp_tok = nullptr;
     hipGraph_t tp_graph = nullptr;
     hipGraphExec_t tp_graph_exec = nullptr;
+    // what the captured multi-GPU step was recorded with: communicator identities and every topology field its launches
+    // depend on.  A call with anything else re-captures (a replay would use a stale communicator / offsets).
+    struct TpKey {
+        unsigned long long tp = 0, world = 0; int tp_size = 0, stage = 0, n_stages = 0, prev = 0, next = 0, src = 0, voff = 0, force = 0, fuse = 0, slot = 0;
+        bool operator==(const TpKey &o) const { return tp == o.tp && world == o.world && tp_size == o.tp_size && stage == o.stage && n_stages == o.n_stages
+                && prev == o.prev && next == o.next && src == o.src && voff == o.voff && force == o.force && fuse == o.fuse && slot == o.slot; }
+    } tp_key;
     const ifa_tp_topology *topo = nullptr;     // set by the partition entry points for the duration of a T > 1 / batched step
     size_t tp_rows_cap = 0;                    // rows the distributed-argmax scratch (tp_best / tp_gather / tp_tok) holds
     int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
@@ -2715,13 +2722,24 @@ int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_tok
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
     const bool use_graph = m->opt_graph && t.n_stages == 1 && (!t.tp || ifa_comm_capturable(t.tp));
+    {
+        ifa_model::TpKey key;
+        key.tp = ifa_comm_serial(t.tp); key.world = ifa_comm_serial(t.world); key.tp_size = t.tp ? ifa_comm_size(t.tp) : 1;
+        key.stage = t.stage; key.n_stages = t.n_stages; key.prev = t.prev_rank; key.next = t.next_rank; key.src = t.token_src;
+        key.voff = t.vocab_offset; key.force = t.force_collectives; key.fuse = m->opt_tp_fuse_add; key.slot = m->cur_slot;
+        if (m->tp_graph_exec && !(key == m->tp_key)) {
+            (void)hipGraphExecDestroy(m->tp_graph_exec); m->tp_graph_exec = nullptr;
+            if (m->tp_graph) { (void)hipGraphDestroy(m->tp_graph); m->tp_graph = nullptr; }
+        }
+        m->tp_key = key;
+    }
     int done = 0;
     if (!(use_graph && m->tp_graph_exec)) {
         // the first step runs eagerly: it creates whatever the collectives allocate lazily, so that the capture below
         // records pure launches
         if ((rc = tp_step(m, t, first_token, start_pos))) return rc;
         done = 1;
-        if (use_graph) {
+        if (use_graph && done < n_steps) {      // (a one-step call has nothing to replay: no capture, no instantiate)
             IFA_HIP_CHECK(hipStreamSynchronize(s));
             IFA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             rc = tp_step(m, t, -1, -1);

@@ -38,7 +38,18 @@ struct InferenceEngine::MultiGpu {
     uint64_t generation = 0;
     int pending = 0;
     bool stop = false;
+    int first_failed = -1;
+    bool broken = false;      // a rank failed inside a step: the communicators were aborted, the engine cannot continue
     std::vector<std::string> errors;
+
+    // A rank that fails before or between the collectives of a step leaves its peers blocked in theirs (RCCL, or the
+    // loopback group's rendezvous) and Run() would never return.  The failing rank's thread aborts every communicator of
+    // the job: the peers come back with an error, Run() reports the FIRST failure.
+    void AbortGroups()
+    {
+        for (ifa_comm *c : tp) if (c) ifa_comm_abort(c);
+        for (ifa_comm *c : world) if (c) ifa_comm_abort(c);
+    }
 
     void Start()
     {
@@ -56,10 +67,16 @@ struct InferenceEngine::MultiGpu {
                         seen = generation; fn = job;
                     }
                     const int rc = fn(r);
+                    bool first_failure = false;
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         errors[(size_t)r] = rc == 0 ? std::string() : std::string(ifa_last_error());   // (thread-local message)
                         if (rc != 0 && errors[(size_t)r].empty()) errors[(size_t)r] = "error " + std::to_string(rc);
+                        if (rc != 0 && !broken) { broken = true; first_failure = true; first_failed = r; }
+                    }
+                    if (first_failure && plans.size() > 1) AbortGroups();
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
                         if (--pending == 0) cv_done.notify_all();
                     }
                 }
@@ -70,11 +87,17 @@ struct InferenceEngine::MultiGpu {
     {
         {
             std::lock_guard<std::mutex> lk(mu);
+            if (broken) { EngineSetError("%s: the engine's device group was aborted after an earlier failure; create a new engine", what); return false; }
             job = fn; pending = (int)plans.size(); generation++;
         }
         cv_job.notify_all();
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
+        if (first_failed >= 0) {      // the rank whose failure started it (the others only report the abort)
+            const size_t r = (size_t)first_failed;
+            EngineSetError("%s failed on rank %zu (device %d): %s", what, r, plans[r].device, errors[r].c_str());
+            return false;
+        }
         for (size_t r = 0; r < errors.size(); r++)
             if (!errors[r].empty()) { EngineSetError("%s failed on rank %zu (device %d): %s", what, r, plans[r].device, errors[r].c_str()); return false; }
         return true;
@@ -230,8 +253,13 @@ bool InferenceEngine::Init(const InferenceConfig &cfg)
         std::vector<int> excl;
         if (spec_.unk_token_id >= 0 && spec_.unk_token_id < spec_.hyper_params.vocab_size) excl.push_back(spec_.unk_token_id);
         for (int id : spec_.invalid_token_ids)
-            if (id >= 0 && id < spec_.hyper_params.vocab_size && excl.size() < 3 && std::find(excl.begin(), excl.end(), id) == excl.end()) excl.push_back(id);
+            if (id >= 0 && id < spec_.hyper_params.vocab_size && std::find(excl.begin(), excl.end(), id) == excl.end()) excl.push_back(id);
+        // GetSortedTopK skips EVERY Invalid-type token: the host pool keeps the full list.  The device argmax holds three
+        // ids; a vocabulary with more makes greedy queries select on the host too (one logits row per step), so that no
+        // id is silently dropped
         default_sampling_.excluded_ids = excl;
+        host_greedy_ = excl.size() > 3;
+        if (excl.size() > 3) excl.resize(3);
         std::vector<ifa_model *> all;
         if (multi_) for (WorkerPlan &w : multi_->plans) all.push_back(w.model); else all.push_back(model_);
         for (ifa_model *mm : all)
@@ -419,7 +447,7 @@ bool InferenceEngine::Infer(InferenceResult &res)
         for (int r = 0; r < n; r++) { toks[(size_t)r] = batch[(size_t)r]->tokens.back(); pos[(size_t)r] = batch[(size_t)r]->processed; slots[(size_t)r] = batch[(size_t)r]->kv_slot; }
         void *lg = nullptr;
         bool any_sampled = false;
-        for (Query *bq : batch) any_sampled = any_sampled || bq->strategy != SamplingStrategyId::Greedy;
+        for (Query *bq : batch) any_sampled = any_sampled || bq->strategy != SamplingStrategyId::Greedy || host_greedy_;
         if (config_.return_output_tensors || any_sampled) {
             if ((size_t)n > logits_rows_) {
                 if (logits_dev_) ifa_free(logits_dev_);
@@ -446,7 +474,7 @@ bool InferenceEngine::Infer(InferenceResult &res)
             q.processed = (int)q.tokens.size();
             IdWeight w; w.id = next[(size_t)r]; w.weight = 1.0f;
             item.next_tokens.push_back(w);
-            if (q.strategy != SamplingStrategyId::Greedy && !SampleRow(q, all.data() + (size_t)r * V, item)) return false;
+            if ((q.strategy != SamplingStrategyId::Greedy || host_greedy_) && !SampleRow(q, all.data() + (size_t)r * V, item)) return false;
             res.items.push_back(std::move(item));
         }
     }
@@ -458,7 +486,7 @@ bool InferenceEngine::Infer(InferenceResult &res)
         if (n_new <= 0) continue;                                    // nothing committed since the last step
         QueryInferenceResult item; item.query_id = q.id; item.prefix_len = q.processed;
         int next = -1;
-        const bool sampled = q.strategy != SamplingStrategyId::Greedy;
+        const bool sampled = q.strategy != SamplingStrategyId::Greedy || host_greedy_;
         const bool want_tensor = config_.return_output_tensors || sampled;
         if (multi_) {                                                // partition over several GPUs: every rank steps at once
             if (!MultiStep(q, n_new, want_tensor, item, next)) return false;
@@ -534,6 +562,7 @@ bool InferenceEngine::Generate(int query_id, int n_steps, std::vector<int> &new_
     Query &q = it->second;
     if (n_steps <= 0) return true;
     if (q.ended) { EngineSetError("Query %d has ended", query_id); return false; }
+    if (host_greedy_) { EngineSetError("Generate() decodes on the device, whose argmax excludes at most 3 token ids; this vocabulary has %zu (use Infer / CommitInferenceResult)", default_sampling_.excluded_ids.size()); return false; }
     if (q.strategy != SamplingStrategyId::Greedy) { EngineSetError("Generate() decodes greedily on the device; query %d uses strategy %d (use Infer / CommitInferenceResult)", query_id, (int)q.strategy); return false; }
     {   // nothing is touched unless the whole request fits (the device token ring holds 1024 steps per call)
         const int max_ctx = spec_.max_context_len > 0 ? spec_.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN;

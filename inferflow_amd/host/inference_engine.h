@@ -174,6 +174,7 @@ private:
     int kv_slots_ = 1;
     SamplingStrategyId default_strategy_ = SamplingStrategyId::Greedy;
     StdSamplingConfig default_sampling_;
+    bool host_greedy_ = false;      // more excluded token ids than the device argmax holds: greedy selection on the host
     std::map<int, Query> queries_;
     void *logits_dev_ = nullptr;
     size_t logits_rows_ = 0;
