@@ -306,6 +306,14 @@ int ifa_comm_capturable(const ifa_comm *c);
 /* identity of the communicator OBJECT (a new one at the same address gets a new serial): what a cached, captured step
  * is keyed on */
 unsigned long long ifa_comm_serial(const ifa_comm *c);
+/* One-shot all-reduce (csrc/ifa_comm.hip): communicators made by ifa_comm_init_all whose devices can map each other's
+ * memory exchange vectors of <= 64 KB directly (push into peer inboxes + epoch flags, sum in rank order in half: the
+ * arithmetic of MergeTensors, inference_worker.cc:2197-2260) instead of a ring collective -- one launch per rank, no host
+ * rendezvous.  ifa_comm_oneshot: 1 if this communicator does; ifa_comm_set_oneshot(c, 0) keeps RCCL for every size;
+ * ifa_comm_status: non-zero if a wait inside a one-shot all-reduce of this rank gave up (2 s). */
+int ifa_comm_oneshot(const ifa_comm *c);
+int ifa_comm_set_oneshot(ifa_comm *c, int on);
+int ifa_comm_status(ifa_comm *c);
 /* Wake every rank blocked in (or later entering) a collective of this communicator with an error: called by the rank
  * that failed, or by whoever supervises the ranks (ncclCommAbort, inference_worker.cc has no counterpart: the reference
  * deadlocks its worker threads in this case).  The communicator can only be destroyed afterwards. */

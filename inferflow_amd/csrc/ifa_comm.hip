@@ -25,6 +25,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -84,6 +85,96 @@ __global__ void __launch_bounds__(256) k_local_allgather(const PtrTable t, int n
     for (int r = 0; r < n; r++) reinterpret_cast<uint8_t *>(t.recv[r])[i] = v;
 }
 
+// ---------------------------------------------------------------- one-shot all-reduce for a decode step's vectors
+// A T = 1 step merges two [dim] vectors per layer (DistributeAndMergeTensors, inference_worker.cc:2148-2335): 64
+// all-reduces of 8 KB per token on Llama-2-7B.  A ring collective is built for bandwidth; at this size the cost is
+// latency, so ranks that can map each other's memory (one process driving several GPUs with peer access, or ranks
+// sharing a device) exchange the vectors directly:
+//   every rank PUSHES its vector into slot [epoch parity][my rank] of every rank's inbox (posted writes over xGMI),
+//   then stores `epoch` into its flag word on every rank; a rank waits until its own flag words all show `epoch`,
+//   adds the n slots of its inbox in RANK ORDER in half precision -- ((v0 + v1) + v2) ..., the MergeTensors order, the
+//   same on every rank -- and writes the result.  One launch of one workgroup per rank, no host involvement: capturable.
+// Two inbox halves alternate by epoch parity: a rank can only be one all-reduce ahead of the slowest (it needs that
+// rank's flag of epoch e to finish e), so half (e & 1) is never rewritten while somebody still reads epoch e - 2 from it.
+// Payload and flags travel as system-scope atomics (8-byte payload words: write-through stores, loads that bypass the
+// caches), so no cache maintenance is assumed.  Every wait is bounded (ONESHOT_TIMEOUT_TICKS of the 100 MHz clock); a
+// rank that gives up raises its status word (ifa_comm_status) and produces no result.
+constexpr size_t ONESHOT_MAX_BYTES = 64 * 1024;            // per vector (dim <= 32768 halves)
+constexpr long long ONESHOT_TIMEOUT_TICKS = 200000000;     // 2 s
+
+struct OneShotPeers {
+    unsigned long long *inbox[64];      // rank r's inbox: [2][n][ONESHOT_MAX_BYTES / 8] words, on r's device
+    unsigned *flags[64];                // rank r's flags: [2][n] epochs
+};
+
+struct OneShot {
+    int n = 0;
+    OneShotPeers peers;                 // the same table on every rank
+    std::vector<unsigned *> epoch;      // per rank: device counter of completed all-reduces
+    std::vector<unsigned *> status;     // per rank: device word, non-zero = a wait gave up
+    std::vector<int> device;
+    bool ready = false;
+    ~OneShot()
+    {
+        for (int r = 0; r < n; r++) {
+            (void)hipSetDevice(device[(size_t)r]);
+            if (peers.inbox[r]) (void)hipFree(peers.inbox[r]);
+            if (peers.flags[r]) (void)hipFree(peers.flags[r]);
+            if (epoch[(size_t)r]) (void)hipFree(epoch[(size_t)r]);
+            if (status[(size_t)r]) (void)hipFree(status[(size_t)r]);
+        }
+    }
+};
+
+__global__ void __launch_bounds__(1024) k_oneshot_allreduce_f16(const OneShotPeers P, int me, int n, unsigned *epoch_ctr, unsigned *status,
+                                                                const ifa::half_t *__restrict__ send, ifa::half_t *__restrict__ recv, size_t count)
+{
+    const unsigned e = *epoch_ctr + 1u;
+    const unsigned par = e & 1u;
+    const size_t words = (count + 3) / 4;                      // 8-byte words (4 halves); the tail word is zero-padded
+    const size_t slot_words = ONESHOT_MAX_BYTES / 8;
+    // push
+    for (size_t i = threadIdx.x; i < words; i += blockDim.x) {
+        unsigned long long w = 0;
+        for (int k = 0; k < 4; k++) {
+            const size_t idx = i * 4 + (size_t)k;
+            const unsigned long long hb = idx < count ? (unsigned long long)__builtin_bit_cast(unsigned short, send[idx]) : 0ull;
+            w |= hb << (16 * k);
+        }
+        for (int p = 0; p < n; p++)
+            __hip_atomic_store(P.inbox[p] + ((size_t)par * n + (size_t)me) * slot_words + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if ((int)threadIdx.x < n) __hip_atomic_store(P.flags[threadIdx.x] + par * n + me, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // wait for every rank's vector of this epoch
+    __shared__ int failed;
+    if (threadIdx.x == 0) failed = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(P.flags[me] + par * n + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > ONESHOT_TIMEOUT_TICKS) { failed = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (failed) { if (threadIdx.x == 0) *status = e; return; }
+    // sum in rank order, in half (MergeTensors, inference_worker.cc:2197-2260)
+    for (size_t i = threadIdx.x; i < words; i += blockDim.x) {
+        unsigned long long w = __hip_atomic_load(P.inbox[me] + ((size_t)par * n) * slot_words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ifa::half_t acc[4];
+        for (int k = 0; k < 4; k++) acc[k] = __builtin_bit_cast(ifa::half_t, (unsigned short)(w >> (16 * k)));
+        for (int r = 1; r < n; r++) {
+            w = __hip_atomic_load(P.inbox[me] + ((size_t)par * n + (size_t)r) * slot_words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int k = 0; k < 4; k++)
+                acc[k] = ifa::f2h(ifa::h2f(acc[k]) + ifa::h2f(__builtin_bit_cast(ifa::half_t, (unsigned short)(w >> (16 * k)))));
+        }
+        for (int k = 0; k < 4; k++) { const size_t idx = i * 4 + (size_t)k; if (idx < count) recv[idx] = acc[k]; }
+    }
+    if (threadIdx.x == 0) *epoch_ctr = e;
+}
+
 } // namespace
 
 static std::atomic<unsigned long long> g_comm_serial{1};
@@ -93,7 +184,9 @@ struct ifa_comm {
     int rank = 0, nranks = 1, device = 0;
     unsigned long long serial = g_comm_serial++;      // identity of this communicator object (ifa_comm_serial)
     std::atomic<bool> aborted{false};
+    bool no_oneshot = false;                // ifa_comm_set_oneshot(c, 0): keep RCCL / the rendezvous for every size
     std::shared_ptr<LocalGroup> local;      // loopback group (ranks sharing a device); comm == nullptr then
+    std::shared_ptr<OneShot> oneshot;       // peer-mapped exchange for small all-reduces (null: RCCL / rendezvous only)
 };
 
 #define IFA_NCCL_CHECK(expr)                                                                  \
@@ -130,6 +223,55 @@ int ifa_comm_init_rank(const void *id_128, int nranks, int rank, int device, ifa
     return IFA_OK;
 }
 
+// Inboxes, flags and counters on every rank's device, peer access between the devices, and a visibility self-test: every
+// rank's words must be writable AND readable from every device within 100 ms, otherwise the group keeps RCCL (or the
+// rendezvous) for every size -- the one-shot path can be absent, never wrong.
+static std::shared_ptr<OneShot> oneshot_setup(const int *device_ids, int n)
+{
+    if (n < 2 || getenv("IFA_NO_ONESHOT")) return nullptr;
+    auto os = std::make_shared<OneShot>();
+    os->n = n; os->epoch.assign((size_t)n, nullptr); os->status.assign((size_t)n, nullptr); os->device.assign(device_ids, device_ids + n);
+    memset(&os->peers, 0, sizeof(os->peers));
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    bool ok = true;
+    for (int a = 0; a < n && ok; a++)
+        for (int b = 0; b < n && ok; b++) {
+            if (device_ids[a] == device_ids[b]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device_ids[a], device_ids[b]) != hipSuccess || !can) { ok = false; break; }
+            (void)hipSetDevice(device_ids[a]);
+            const hipError_t e = hipDeviceEnablePeerAccess(device_ids[b], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+            (void)hipGetLastError();
+        }
+    const size_t inbox_bytes = 2 * (size_t)n * ONESHOT_MAX_BYTES, flag_bytes = 2 * (size_t)n * sizeof(unsigned);
+    for (int r = 0; r < n && ok; r++) {
+        ok = hipSetDevice(device_ids[r]) == hipSuccess
+            && hipMalloc((void **)&os->peers.inbox[r], inbox_bytes) == hipSuccess && hipMalloc((void **)&os->peers.flags[r], flag_bytes + 64) == hipSuccess
+            && hipMalloc((void **)&os->epoch[(size_t)r], 4) == hipSuccess && hipMalloc((void **)&os->status[(size_t)r], 4) == hipSuccess
+            && hipMemset(os->peers.flags[r], 0, flag_bytes + 64) == hipSuccess && hipMemset(os->epoch[(size_t)r], 0, 4) == hipSuccess
+            && hipMemset(os->status[(size_t)r], 0, 4) == hipSuccess;
+    }
+    // self-test: rank a's device writes a tagged word into every rank's spare flag area, every rank's device reads it back
+    if (ok) {
+        for (int a = 0; a < n && ok; a++) {
+            (void)hipSetDevice(device_ids[a]);
+            for (int b = 0; b < n && ok; b++) {
+                const unsigned tag = 0xA5000000u | (unsigned)(a * 64 + b);
+                ok = hipMemcpy(reinterpret_cast<char *>(os->peers.flags[b]) + flag_bytes, &tag, 4, hipMemcpyHostToDevice) == hipSuccess;
+                unsigned back = 0;
+                ok = ok && hipMemcpy(&back, reinterpret_cast<char *>(os->peers.flags[b]) + flag_bytes, 4, hipMemcpyDeviceToHost) == hipSuccess && back == tag;
+            }
+        }
+        for (int r = 0; r < n && ok; r++) { (void)hipSetDevice(device_ids[r]); ok = hipMemset(reinterpret_cast<char *>(os->peers.flags[r]) + flag_bytes, 0, 64) == hipSuccess; }
+    }
+    (void)hipSetDevice(prev);
+    (void)hipGetLastError();
+    os->ready = ok;
+    return ok ? os : nullptr;
+}
+
 int ifa_comm_init_all(const int *device_ids, int n, ifa_comm **comms_out)
 {
     IFA_REQUIRE(device_ids && comms_out && n >= 1 && n <= 64, "ifa_comm_init_all: n %d", n);
@@ -139,18 +281,25 @@ int ifa_comm_init_all(const int *device_ids, int n, ifa_comm **comms_out)
         for (int i = 1; i < n; i++) IFA_REQUIRE(device_ids[i] == device_ids[0], "ifa_comm_init_all: a loopback group lives on ONE device");
         auto grp = std::make_shared<LocalGroup>();
         grp->n = n;
+        std::shared_ptr<OneShot> os = oneshot_setup(device_ids, n);
         for (int i = 0; i < n; i++) {
             ifa_comm *c = new ifa_comm();
-            c->rank = i; c->nranks = n; c->device = device_ids[i]; c->local = grp;
+            c->rank = i; c->nranks = n; c->device = device_ids[i]; c->local = grp; c->oneshot = os;
+            // Ranks that share a device are NOT guaranteed to run at the same time: their streams may sit on the same
+            // hardware queue (the runtime has a handful), and a kernel that spins for a peer queued behind it never sees
+            // that peer.  The exchange is therefore off by default for loopback groups (tests switch it on for <= 4 ranks
+            // with ifa_comm_set_oneshot to check its arithmetic); one rank per GPU -- what it is for -- has no such limit.
+            c->no_oneshot = true;
             comms_out[i] = c;
         }
         return IFA_OK;
     }
     std::vector<ncclComm_t> cs((size_t)n);
     IFA_NCCL_CHECK(ncclCommInitAll(cs.data(), n, device_ids));
+    std::shared_ptr<OneShot> os = oneshot_setup(device_ids, n);
     for (int i = 0; i < n; i++) {
         ifa_comm *c = new ifa_comm();
-        c->comm = cs[(size_t)i]; c->rank = i; c->nranks = n; c->device = device_ids[i];
+        c->comm = cs[(size_t)i]; c->rank = i; c->nranks = n; c->device = device_ids[i]; c->oneshot = os;
         comms_out[i] = c;
     }
     return IFA_OK;
@@ -166,6 +315,19 @@ int ifa_comm_destroy(ifa_comm *c)
 
 int ifa_comm_capturable(const ifa_comm *c) { return (c && c->local) ? 0 : 1; }
 unsigned long long ifa_comm_serial(const ifa_comm *c) { return c ? c->serial : 0ull; }
+
+// 1 if small all-reduces of this communicator take the one-shot peer exchange
+int ifa_comm_oneshot(const ifa_comm *c) { return (c && c->oneshot && c->oneshot->ready && !c->no_oneshot) ? 1 : 0; }
+int ifa_comm_set_oneshot(ifa_comm *c, int on) { if (c) c->no_oneshot = !on; return IFA_OK; }
+// non-zero: a wait inside a one-shot all-reduce of this rank gave up (synchronises the device; call it after the stream
+// was synchronised, e.g. at the end of a decode call)
+int ifa_comm_status(ifa_comm *c)
+{
+    if (!c || !c->oneshot) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, c->oneshot->status[(size_t)c->rank], 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)v;
+}
 
 // A rank that fails between two collectives leaves its peers blocked in the next one.  Abort wakes them: RCCL
 // communicators are aborted (ncclCommAbort: outstanding and later operations fail), loopback groups raise a flag that
@@ -188,6 +350,13 @@ int ifa_allreduce_sum_f16(ifa_comm *c, const void *send_f16, void *recv_f16, siz
 {
     IFA_REQUIRE(c && (c->comm || c->local) && send_f16 && recv_f16, "ifa_allreduce_sum_f16: null pointer");
     if (count == 0) return IFA_OK;
+    if (c->oneshot && c->oneshot->ready && count * 2 <= ONESHOT_MAX_BYTES && !c->no_oneshot) {
+        OneShot &os = *c->oneshot;
+        k_oneshot_allreduce_f16<<<dim3(1), dim3(1024), 0, ifa_s(stream)>>>(os.peers, c->rank, os.n, os.epoch[(size_t)c->rank], os.status[(size_t)c->rank],
+                                                                          (const ifa::half_t *)send_f16, (ifa::half_t *)recv_f16, count);
+        IFA_LAUNCH_CHECK();
+        return IFA_OK;
+    }
     if (c->local) {
         LocalGroup &g = *c->local;
         IFA_HIP_CHECK(hipStreamSynchronize(ifa_s(stream)));

@@ -227,6 +227,19 @@ class Comm:
     def recv(self, t, peer, stream=None):
         check(lib().ifa_recv(self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), int(peer), C.c_void_p(stream)))
 
+    def oneshot(self):
+        """True if small all-reduces of this communicator take the peer-mapped one-shot exchange (csrc/ifa_comm.hip)."""
+        return bool(lib().ifa_comm_oneshot(self._h))
+
+    def set_oneshot(self, on):
+        check(lib().ifa_comm_set_oneshot(self._h, int(bool(on))))
+
+    def status(self):
+        return int(lib().ifa_comm_status(self._h))
+
+    def abort(self):
+        check(lib().ifa_comm_abort(self._h))
+
     def close(self):
         if self._h:
             lib().ifa_comm_destroy(self._h)

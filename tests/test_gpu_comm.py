@@ -208,3 +208,93 @@ def test_allreduce_and_send_recv_over_two_gpus():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert res[0][1] == 3.0 and res[1][1] == 3.0 and res[1][2] == 0.0
+
+
+def _loopback_allreduce(n, count, oneshot, rounds=3):
+    """n rank threads on ONE device, each with its own stream-less tensor: returns (results per round per rank, expected)"""
+    import threading
+    comms = W.Comm.init_all([0] * n)
+    for c in comms:
+        c.set_oneshot(oneshot)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + n + count)
+    data = [[(torch.randn(count, generator=gen, device="cuda") * 3).half() for _ in range(n)] for _ in range(rounds)]
+    out = [[None] * n for _ in range(rounds)]
+    errs = []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for k in range(rounds):
+                    t = data[k][r].clone()
+                    comms[r].all_reduce_f16(t, stream=s.cuda_stream)
+                    s.synchronize()
+                    out[k][r] = t
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+    [t.start() for t in th]
+    [t.join(60) for t in th]
+    assert not errs, errs
+    st = [c.status() for c in comms]
+    used = comms[0].oneshot()
+    for c in comms:
+        c.close()
+    exp = []
+    for k in range(rounds):       # ((v0 + v1) + v2) ... in half: MergeTensors order (inference_worker.cc:2197-2260)
+        acc = data[k][0].clone()
+        for r in range(1, n):
+            acc = (acc.float() + data[k][r].float()).half()
+        exp.append(acc)
+    return out, exp, st, used
+
+
+@pytest.mark.parametrize("n,count", [(2, 4096), (4, 4096), (4, 8192), (3, 1001)])
+def test_oneshot_allreduce_sums_in_rank_order_like_the_rendezvous_path(n, count):
+    """The peer-mapped one-shot all-reduce (ranks sharing this box's one GPU map each other's memory trivially): every
+    rank gets the rank-order half sum, bit for bit, over several epochs (both inbox halves); the host-rendezvous path of
+    the same group gives the same bits.  (At most 4 ranks here: ranks sharing a device need a hardware queue each to run at
+    the same time, which is why the exchange is opt-in for loopback groups.)"""
+    out, exp, st, used = _loopback_allreduce(n, count, True)
+    assert used, "one-shot exchange was not set up"
+    assert st == [0] * n
+    for k in range(len(exp)):
+        for r in range(n):
+            assert torch.equal(out[k][r], exp[k]), (k, r)
+    out2, exp2, _, used2 = _loopback_allreduce(n, count, False)
+    assert not used2
+    for k in range(len(exp2)):
+        for r in range(n):
+            assert torch.equal(out2[k][r], exp2[k]), (k, r)
+
+
+def test_abort_wakes_a_rank_blocked_in_a_collective():
+    """A peer that fails never reaches the collective: ifa_comm_abort makes the waiting rank return an error instead of
+    blocking forever (the host engine calls it from the failing rank's thread, host/inference_engine.cc)."""
+    import threading
+    import time
+    comms = W.Comm.init_all([0, 0])
+    for c in comms:
+        c.set_oneshot(False)
+    res = {}
+
+    def waiter():
+        torch.cuda.set_device(0)
+        x = torch.ones(64, device="cuda").half()
+        try:
+            comms[0].all_reduce_f16(x)
+            res["ok"] = True
+        except Exception as e:  # noqa: BLE001
+            res["err"] = repr(e)
+
+    t = threading.Thread(target=waiter)
+    t.start()
+    time.sleep(0.3)
+    assert t.is_alive()                 # blocked in the rendezvous: rank 1 never comes
+    comms[1].abort()
+    t.join(10)
+    assert not t.is_alive() and "err" in res and "abort" in res["err"]
+    for c in comms:
+        c.close()
