@@ -88,6 +88,48 @@ def reference_cpu_baseline(n_tokens=128):
         shutil.rmtree(d, ignore_errors=True)
 
 
+class Watchdog:
+    """A hang in communicator setup or in a collective must not cost the whole scaling record: every rank watches its own
+    progress and, when a phase overruns its limit, rank 0 prints ONE JSON line with an "error" key (the driver's contract)
+    and the process exits -- which makes the launcher tear the other ranks down.  Limits: IFA_BENCH_TIMEOUT_INIT /
+    IFA_BENCH_TIMEOUT_STEP seconds."""
+
+    def __init__(self, rank, world, args):
+        import threading
+        self.rank, self.world, self.args = rank, world, args
+        self.phase, self.deadline, self.out_fd = "start", None, 1
+        self.lock = threading.Lock()
+        t = threading.Thread(target=self._watch, daemon=True)
+        t.start()
+
+    def arm(self, phase, seconds):
+        with self.lock:
+            self.phase, self.deadline = phase, time.monotonic() + seconds
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def _watch(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                phase = self.phase
+            if late:
+                msg = "rank %d of %d made no progress in phase '%s' within its limit: aborting the run" % (self.rank, self.world, phase)
+                sys.stderr.write("bench.py watchdog: %s\n" % msg)
+                sys.stderr.flush()
+                if self.rank == 0:
+                    line = json.dumps({"metric": "decode tokens/sec (aborted)", "value": None, "unit": "tokens/s", "n_gpus": self.world,
+                                       "steps": self.args.steps, "warmup": self.args.warmup, "error": msg, "higher_is_better": True})
+                    try:
+                        os.write(self.out_fd, (line + "\n").encode())
+                    except OSError:
+                        pass
+                os._exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +155,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    t_init = float(os.environ.get("IFA_BENCH_TIMEOUT_INIT", "420"))
+    t_step = float(os.environ.get("IFA_BENCH_TIMEOUT_STEP", "180"))
+    dog = Watchdog(rank, world, args)
+    dog.arm("process group + weights + communicators", t_init)
     if args.gpus > 1 or world > 1 or os.environ.get("IFA_FORCE_TP"):
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -133,6 +179,7 @@ def main():
     # everything up to the final print goes to stderr
     sys.stdout.flush()
     saved_stdout = os.dup(1)
+    dog.out_fd = saved_stdout
     os.dup2(2, 1)
     t_build = time.perf_counter()
     runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank, groups=args.groups)
@@ -147,24 +194,29 @@ def main():
         torch.cuda.synchronize()
 
     # prefill (timed separately; op-by-op path)
+    dog.arm("prefill", t_step)
     barrier()
     t0 = time.perf_counter()
     tok = runner.prefill(prompt)
     barrier()
     prefill_s = time.perf_counter() - t0
 
+    dog.arm("warm-up steps", t_step)
     toks_w, _ = runner.decode(tok, PROMPT_LEN, warmup) if warmup > 0 else ([tok], 0.0)
     tok = int(toks_w[-1])
+    dog.arm("timed steps", t_step)
     barrier()
     t0 = time.perf_counter()
     toks, gpu_ms = runner.decode(tok, PROMPT_LEN + warmup, steps)
     barrier()
     wall = time.perf_counter() - t0
+    dog.arm("reduce of the step times", t_step)
     if world > 1:
         tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
 
+    dog.disarm()
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
