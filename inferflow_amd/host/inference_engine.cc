@@ -377,6 +377,51 @@ bool InferenceEngine::MultiStep(Query &q, int n_new, bool want_tensor, QueryInfe
     return true;
 }
 
+// One batched decode step of n queries over the (single) tensor-parallel device group: every rank's thread calls
+// ifa_model_tp_decode_batch with the same rows; `all` (if wanted) receives the [n][vocab] logits assembled from the ranks'
+// vocabulary shards.
+bool InferenceEngine::MultiBatchStep(const std::vector<int> &toks, const std::vector<int> &pos, const std::vector<int> &slots,
+                                     std::vector<int> &next, bool want_tensor, std::vector<uint16_t> &all)
+{
+    MultiGpu &M = *multi_;
+    const int R = (int)M.plans.size(), P = M.P, V = spec_.hyper_params.vocab_size, n = (int)toks.size();
+    const size_t shard = (size_t)V / (size_t)P;
+    if (want_tensor && (size_t)n > M.shard_rows) {
+        for (int i = (M.G - 1) * P; i < R; i++) {
+            ifa_set_device(M.plans[(size_t)i].device);
+            if (M.shard_dev[(size_t)i]) { ifa_free(M.shard_dev[(size_t)i]); M.shard_dev[(size_t)i] = nullptr; }
+            if (ifa_malloc(&M.shard_dev[(size_t)i], (size_t)n * shard * 2) != IFA_OK) { EngineSetError("logits buffer: %s", ifa_last_error()); return false; }
+        }
+        M.shard_rows = (size_t)n;
+    }
+    std::vector<std::vector<int>> nexts((size_t)R, std::vector<int>((size_t)n, -1));
+    std::vector<std::vector<uint16_t>> host((size_t)R);
+    const bool ok = M.Run([&](int i) -> int {
+        ifa_model *mm = M.plans[(size_t)i].model;
+        void *lg = want_tensor ? M.shard_dev[(size_t)i] : nullptr;
+        int rc = ifa_model_tp_decode_batch(mm, &M.topo[(size_t)i], n, toks.data(), pos.data(), slots.data(), nexts[(size_t)i].data(), lg);
+        if (rc) return rc;
+        if (lg) {
+            host[(size_t)i].resize((size_t)n * shard);
+            rc = ifa_memcpy_d2h(host[(size_t)i].data(), lg, (size_t)n * shard * 2, ifa_model_stream(mm));
+            if (!rc) rc = ifa_stream_sync(ifa_model_stream(mm));
+        }
+        return rc;
+    }, "batched decode step");
+    if (!ok) return false;
+    next = nexts[(size_t)(R - 1)];
+    for (int i = 0; i < R; i++)
+        if (nexts[(size_t)i] != next) { EngineSetError("ranks disagree on the next tokens of a batched step"); return false; }
+    if (want_tensor) {
+        all.resize((size_t)n * V);
+        for (int r = 0; r < P; r++) {
+            const std::vector<uint16_t> &h = host[(size_t)((M.G - 1) * P + r)];
+            for (int row = 0; row < n; row++) memcpy(&all[(size_t)row * V + (size_t)r * shard], &h[(size_t)row * shard], shard * 2);
+        }
+    }
+    return true;
+}
+
 int InferenceEngine::AddQuery(const std::vector<int> &tokens, const QueryOptions &query_options)
 {
     if (!model_) { EngineSetError("The engine is not initialized"); return -1; }
@@ -439,7 +484,9 @@ bool InferenceEngine::Infer(InferenceResult &res)
     std::vector<Query *> batch;
     for (auto &kv : queries_) {
         Query &q = kv.second;
-        if (!multi_ && !q.ended && (int)q.tokens.size() < max_ctx && q.processed > 0 && (int)q.tokens.size() - q.processed == 1) batch.push_back(&q);
+        // (a partition with several layer groups steps its queries one by one: a batched step is one tensor-parallel group's)
+        const bool batchable = !multi_ || multi_->G == 1;
+        if (batchable && !q.ended && (int)q.tokens.size() < max_ctx && q.processed > 0 && (int)q.tokens.size() - q.processed == 1) batch.push_back(&q);
     }
     if ((int)batch.size() >= std::max(2, config_.dynamic_batching_min_queries)) {
         const int n = (int)batch.size();
@@ -448,6 +495,13 @@ bool InferenceEngine::Infer(InferenceResult &res)
         void *lg = nullptr;
         bool any_sampled = false;
         for (Query *bq : batch) any_sampled = any_sampled || bq->strategy != SamplingStrategyId::Greedy || host_greedy_;
+        std::vector<uint16_t> all;
+        if (multi_) {
+            // Query batching over a tensor-parallel device group (the reference: query batching, inference_engine.cc:1054-1124,
+            // inside Infer_TensorParallelism, :1222-1296): every rank runs ONE batched step over the same queries -- merges
+            // over [n][dim], one distributed argmax per row (ifa_model_tp_decode_batch) -- and hands back its vocabulary shard
+            if (!MultiBatchStep(toks, pos, slots, next, config_.return_output_tensors || any_sampled, all)) return false;
+        } else {
         if (config_.return_output_tensors || any_sampled) {
             if ((size_t)n > logits_rows_) {
                 if (logits_dev_) ifa_free(logits_dev_);
@@ -460,17 +514,17 @@ bool InferenceEngine::Infer(InferenceResult &res)
         if (ifa_model_decode_batch(model_, n, toks.data(), pos.data(), slots.data(), next.data(), lg) != IFA_OK) {
             EngineSetError("batched decode step failed: %s", ifa_last_error()); return false;
         }
-        std::vector<uint16_t> all;
         if (lg) {
             all.resize((size_t)n * V);
             if (ifa_memcpy_d2h(all.data(), lg, all.size() * 2, ifa_model_stream(model_)) != IFA_OK || ifa_stream_sync(ifa_model_stream(model_)) != IFA_OK) {
                 EngineSetError("logits copy: %s", ifa_last_error()); return false;
             }
         }
+        }
         for (int r = 0; r < n; r++) {
             Query &q = *batch[(size_t)r];
             QueryInferenceResult item; item.query_id = q.id; item.prefix_len = q.processed;
-            if (lg && config_.return_output_tensors) { item.output_rows = 1; item.output_cols = V; item.output_tensor.assign(all.begin() + (size_t)r * V, all.begin() + (size_t)(r + 1) * V); }
+            if (!all.empty() && config_.return_output_tensors) { item.output_rows = 1; item.output_cols = V; item.output_tensor.assign(all.begin() + (size_t)r * V, all.begin() + (size_t)(r + 1) * V); }
             q.processed = (int)q.tokens.size();
             IdWeight w; w.id = next[(size_t)r]; w.weight = 1.0f;
             item.next_tokens.push_back(w);

@@ -39,6 +39,7 @@ enum class PositionEmbeddingAlg { EMPTY = 0, ROPE = 1, ALIBI = 2 };
 
 struct ModelSpec {
     std::string sid;
+    bool moe_top_k_from_spec = false;      // "moe_top_k" was given in network_structure (config.json does not override it)
     ModelHyperParams hyper_params;
     std::string dir, spec_file, config_file;
     std::vector<std::string> model_files;
@@ -165,6 +166,8 @@ private:
     struct MultiGpu;
     MultiGpu *multi_ = nullptr;
     bool InitMulti(const std::vector<std::vector<int>> &groups);
+    bool MultiBatchStep(const std::vector<int> &toks, const std::vector<int> &pos, const std::vector<int> &slots, std::vector<int> &next,
+                        bool want_tensor, std::vector<uint16_t> &all);
     bool MultiStep(Query &q, int n_new, bool want_tensor, QueryInferenceResult &item, int &next);
     InferenceConfig config_;
     ModelSpec spec_;

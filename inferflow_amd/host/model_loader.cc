@@ -128,7 +128,7 @@ bool LoadModelSpecJson(ModelSpec &spec, const std::string &path)
     ns->GetBool("is_parallel_attn", spec.is_parallel_attn);
     ns->GetBool("mlp_attn_share_input", spec.mlp_attn_share_input);
     ns->GetNumber("expert_count", hp.experts);
-    ns->GetNumber("moe_top_k", hp.moe_top_k);
+    spec.moe_top_k_from_spec = ns->GetNumber("moe_top_k", hp.moe_top_k);
     ns->GetBool("moe_norm_top_k_prob", hp.moe_norm_top_k_prob);
     ns->GetString("tensor_name_prefix", spec.tensor_name_prefix);
     if (const JsonValue *tm = ns->Get("tensor_name_mapping"))
@@ -201,7 +201,7 @@ struct Uploader {
         if ((long long)(rows * cols) < (long long)spec->tensor_quant_threshold || cap <= 0 || cols % (size_t)cap != 0) return IFA_F16;
         return wdt;
     }
-    bool Put(int layer, int tid, int target, const uint16_t *f16, size_t rows, size_t cols)
+    bool Put(int layer, int tid, int target, const uint16_t *f16, size_t rows, size_t cols, int expert = -1)
     {
         if (dev.empty()) { dev.assign(plans->size(), nullptr); dev_bytes.assign(plans->size(), 0); }
         for (size_t wi = 0; wi < plans->size(); wi++) {
@@ -232,8 +232,8 @@ struct Uploader {
                 dev_bytes[wi] = bytes;
             }
             if (ifa_memcpy_h2d(dev[wi], src, bytes, nullptr) != IFA_OK || ifa_stream_sync(nullptr) != IFA_OK
-                || ifa_model_set_tensor_f16(w.model, sl.local_layer, tid, -1, tgt, dev[wi], srows, scols) != IFA_OK) {
-                EngineSetError("uploading tensor %d of layer %d failed: %s", tid, layer, ifa_last_error());
+                || ifa_model_set_tensor_f16(w.model, sl.local_layer, tid, expert, tgt, dev[wi], srows, scols) != IFA_OK) {
+                EngineSetError("uploading tensor %d of layer %d (expert %d) failed: %s", tid, layer, expert, ifa_last_error());
                 return false;
             }
         }
@@ -253,7 +253,10 @@ bool CreateWorkers(std::vector<WorkerPlan> &plans, const ModelSpec &spec)
     if (hp.embd_dims <= 0 || hp.decoder_layers <= 0 || hp.decoder_heads <= 0 || hp.vocab_size <= 0 || hp.hidden_dim <= 0) {
         EngineSetError("model %s: incomplete hyper-parameters", spec.sid.c_str()); return false;
     }
-    if (hp.experts > 0) { EngineSetError("model %s: MoE models are loaded through the Python worker for now", spec.sid.c_str()); return false; }
+    if (hp.experts > 0 && (hp.moe_top_k < 1 || hp.moe_top_k > hp.experts || hp.experts > 64)) {
+        EngineSetError("model %s: %d experts with moe_top_k %d is not supported (1 <= top_k <= experts <= 64)", spec.sid.c_str(), hp.experts, hp.moe_top_k);
+        return false;
+    }
     const int kv_heads = hp.decoder_kv_heads > 0 ? hp.decoder_kv_heads : hp.decoder_heads;
     for (WorkerPlan &w : plans) {
         if (w.layer1 < 0) {         // layer range of the worker's device group
@@ -287,6 +290,9 @@ bool CreateWorkers(std::vector<WorkerPlan> &plans, const ModelSpec &spec)
         c.full_quant_gemv = 1; c.tp_rank = w.tp_rank; c.tp_size = P; c.device = w.device;
         c.attn_norm_base = spec.attn_pre_norm_base; c.ffn_norm_base = spec.ffn_pre_norm_base; c.out_norm_base = spec.output_norm_base;
         c.attn_out_scale = spec.attn_out_scale; c.ffn_out_scale = spec.ffn_out_scale; c.out_scale = spec.out_scale;
+        // sparse mixture of experts (network_builder.cc:81-84, 205-209: one FFN per expert + the router "moe.gate"): every
+        // rank of a device group holds its row / column slice of EVERY expert, the router is replicated
+        c.experts = hp.experts; c.moe_top_k = hp.experts > 0 ? hp.moe_top_k : 0; c.moe_norm_topk = hp.moe_norm_top_k_prob ? 1 : 0;
         if (ifa_model_create(&c, &w.model) != IFA_OK) { EngineSetError("ifa_model_create (device %d): %s", w.device, ifa_last_error()); return false; }
     }
     return true;
@@ -427,6 +433,12 @@ bool LoadHfConfig(ModelSpec &spec)
     root.GetNumber("max_position_embeddings", hp.training_context_len);
     root.GetNumber("rope_theta", spec.rope_theta);
     if (hp.decoder_kv_heads <= 0) hp.decoder_kv_heads = hp.decoder_heads;
+    // mixture of experts: the spec's expert_count / moe_top_k win, config.json fills what the spec leaves open
+    if (spec.network_structure.find("moe") != std::string::npos) {
+        if (hp.experts <= 0) root.GetNumber("num_local_experts", hp.experts);
+        int k = 0;
+        if (root.GetNumber("num_experts_per_tok", k) && k > 0 && !spec.moe_top_k_from_spec) hp.moe_top_k = k;
+    }
     return true;
 }
 
@@ -456,13 +468,17 @@ bool LoadSafetensors(std::vector<WorkerPlan> &plans, ModelSpec &spec)
     const size_t D = (size_t)hp.embd_dims, F = (size_t)hp.hidden_dim, V = (size_t)hp.vocab_size;
     const size_t HS = D / (size_t)hp.decoder_heads, KV = (size_t)hp.decoder_kv_heads * HS;
     std::vector<uint16_t> f16;
-    auto put = [&](const std::string &name, int layer, int tid, size_t rows, size_t cols, bool matrix, bool required) -> int {
+    auto put = [&](const std::string &name, int layer, int tid, size_t rows, size_t cols, bool matrix, bool required, int expert = -1) -> int {
         auto it = by_std.find(name);
         if (it == by_std.end()) { if (required) EngineSetError("tensor %s is missing", name.c_str()); return required ? -1 : 0; }
         if (!ReadStTensor(it->second, rows, cols, f16, name)) return -1;
         const int target = tid == IFA_T_LM_HEAD ? LmHeadType(spec, rows, cols) : (matrix ? up.MatrixType(rows, cols) : IFA_F16);
-        return up.Put(layer, tid, target, f16.data(), rows, cols) ? 1 : -1;
+        return up.Put(layer, tid, target, f16.data(), rows, cols, expert) ? 1 : -1;
     };
+    // Mixtral-style checkpoints (data/models/mixtral_8x7b_instruct_v0.1/model_spec.safetensors.json): the router
+    // "block_sparse_moe.gate" [experts][dim] and per expert w1 / w3 [ffn][dim], w2 [dim][ffn]; the standard names the
+    // reference maps them to ("dec.{i}.moe.gate", "dec.{i}.moe.expert.{j}.w1") are accepted as well
+    const int n_experts = hp.experts;
     if (put("embed_tokens.weight", -1, IFA_T_EMBD, V, D, false, true) < 0) return false;
     const std::vector<uint16_t> embd = f16;
     for (int l = 0; l < hp.decoder_layers; l++) {
@@ -502,8 +518,31 @@ bool LoadSafetensors(std::vector<WorkerPlan> &plans, ModelSpec &spec)
             fused_qkv = true;
             break;
         }
+        bool moe_layer = false;
+        if (n_experts > 0) {
+            const std::string ls = std::to_string(l);
+            const std::string gate_names[] = {p + "block_sparse_moe.gate.weight", "dec." + ls + ".moe.gate.weight", p + "moe.gate.weight"};
+            for (const std::string &gn : gate_names) {
+                if (by_std.find(gn) == by_std.end()) continue;
+                if (put(gn, l, IFA_T_MOE_GATE, (size_t)n_experts, D, false, true) < 0) return false;
+                moe_layer = true;
+                break;
+            }
+            if (moe_layer) {
+                for (int j = 0; j < n_experts; j++) {
+                    const std::string js = std::to_string(j);
+                    const std::string bases[] = {p + "block_sparse_moe.experts." + js + ".", "dec." + ls + ".moe.expert." + js + ".", p + "moe.expert." + js + "."};
+                    const std::string *base = nullptr;
+                    for (const std::string &b : bases) if (by_std.find(b + "w1.weight") != by_std.end()) { base = &b; break; }
+                    if (!base) { EngineSetError("layer %d: the tensors of expert %d are missing", l, j); return false; }
+                    if (put(*base + "w1.weight", l, IFA_T_W1, F, D, true, true, j) < 0 || put(*base + "w2.weight", l, IFA_T_W2, D, F, true, true, j) < 0
+                        || put(*base + "w3.weight", l, IFA_T_W3, F, D, true, true, j) < 0) return false;
+                }
+            }
+        }
         for (const E &e : es) {
             if (fused_qkv && (e.tid == IFA_T_WQ || e.tid == IFA_T_WK || e.tid == IFA_T_WV)) continue;
+            if (moe_layer && (e.tid == IFA_T_W1 || e.tid == IFA_T_W2 || e.tid == IFA_T_W3)) continue;      // the experts are this layer's FFN
             if (put(p + e.name, l, e.tid, e.rows, e.cols, e.matrix, true) < 0) return false;
         }
         const E bs[] = {{"self_attn.q_proj.bias", IFA_T_WQ_B, 1, D, false}, {"self_attn.k_proj.bias", IFA_T_WK_B, 1, KV, false},
@@ -566,8 +605,20 @@ bool LoadSynthetic(std::vector<WorkerPlan> &plans, ModelSpec &spec)
         struct E { int tid; size_t rows, cols; };
         const E es[] = {{IFA_T_WQ, D, D}, {IFA_T_WK, KV, D}, {IFA_T_WV, KV, D}, {IFA_T_WO, D, D}, {IFA_T_W1, F, D}, {IFA_T_W3, F, D}, {IFA_T_W2, D, F}};
         for (const E &e : es) {
+            const bool ffn = e.tid == IFA_T_W1 || e.tid == IFA_T_W2 || e.tid == IFA_T_W3;
+            if (hp.experts > 0 && ffn) {      // one FFN per expert (the seeds of inferflow_amd/synth.py)
+                for (int j = 0; j < hp.experts; j++) {
+                    FillNormalF16(w, e.rows * e.cols, 100000 + ((uint64_t)l * 64 + (uint64_t)j) * 16 + (uint64_t)e.tid, spec.synthetic_std);
+                    if (!up.Put(l, e.tid, up.MatrixType(e.rows, e.cols), w.data(), e.rows, e.cols, j)) return false;
+                }
+                continue;
+            }
             FillNormalF16(w, e.rows * e.cols, 1000 + (uint64_t)l * 16 + (uint64_t)e.tid, spec.synthetic_std);
             if (!up.Put(l, e.tid, up.MatrixType(e.rows, e.cols), w.data(), e.rows, e.cols)) return false;
+        }
+        if (hp.experts > 0) {                  // the router: always F16
+            FillNormalF16(w, (size_t)hp.experts * D, 1000 + (uint64_t)l * 16 + (uint64_t)IFA_T_MOE_GATE, spec.synthetic_std);
+            if (!up.Put(l, IFA_T_MOE_GATE, IFA_F16, w.data(), (size_t)hp.experts, D)) return false;
         }
     }
     return true;

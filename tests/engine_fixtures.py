@@ -20,14 +20,25 @@ def _shape(kind, s):
     return {"norm": (1, d), "q": (d, d), "kv": (kv, d), "o": (d, d), "up": (f, d), "down": (d, f)}[kind]
 
 
+MOE_SHAPE = dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000, experts=4, moe_top_k=2)
+
+
 def make_weights(s=SHAPE, seed=5, std=0.06, shared_classifier=False):
-    """{(layer, tid): float32 array [rows, cols]} incl. (-1, EMBD/OUT_NORM/LM_HEAD)."""
+    """{(layer, tid): float32 array [rows, cols]} incl. (-1, EMBD/OUT_NORM/LM_HEAD); mixture-of-experts shapes
+    (s["experts"] > 0): the FFN matrices are (layer, tid, expert) and (layer, T_MOE_GATE) is the router."""
     rng = np.random.default_rng(seed)
     w = {(-1, W.T_EMBD): rng.normal(0, std, (s["vocab"], s["dim"])).astype(np.float32)}
+    ne = s.get("experts", 0)
     for tid, kind in KINDS:
         for l in range(s["layers"]):
             r, c = _shape(kind, s)
+            if ne and tid in (W.T_W1, W.T_W2, W.T_W3):
+                for e in range(ne):
+                    w[(l, tid, e)] = rng.normal(0, std, (r, c)).astype(np.float32)
+                continue
             w[(l, tid)] = (1.0 + rng.normal(0, 0.02, (r, c))).astype(np.float32) if kind == "norm" else rng.normal(0, std, (r, c)).astype(np.float32)
+    for l in range(s["layers"] if ne else 0):
+        w[(l, W.T_MOE_GATE)] = rng.normal(0, 0.3, (ne, s["dim"])).astype(np.float32)
     w[(-1, W.T_OUT_NORM)] = (1.0 + rng.normal(0, 0.02, (1, s["dim"]))).astype(np.float32)
     w[(-1, W.T_LM_HEAD)] = w[(-1, W.T_EMBD)] if shared_classifier else rng.normal(0, std, (s["vocab"], s["dim"])).astype(np.float32)
     return w
@@ -71,7 +82,14 @@ def write_safetensors(path, w, s=SHAPE, dtype="F16", fused_qkv=None):
     fused_qkv: None, or the qkv_format (0 / 1) of a single self_attn.qkv_proj tensor replacing q/k/v_proj."""
     tensors = {"model.embed_tokens.weight": w[(-1, W.T_EMBD)], "model.norm.weight": w[(-1, W.T_OUT_NORM)].reshape(-1),
                "lm_head.weight": w[(-1, W.T_LM_HEAD)]}
-    for (l, tid), arr in w.items():
+    for key, arr in w.items():
+        l, tid = key[0], key[1]
+        if len(key) == 3:        # Mixtral names (data/models/mixtral_8x7b_instruct_v0.1/model_spec.safetensors.json)
+            tensors["model.layers.%d.block_sparse_moe.experts.%d.%s.weight" % (l, key[2], {W.T_W1: "w1", W.T_W2: "w2", W.T_W3: "w3"}[tid])] = arr
+            continue
+        if l >= 0 and tid == W.T_MOE_GATE:
+            tensors["model.layers.%d.block_sparse_moe.gate.weight" % l] = arr
+            continue
         if l >= 0:
             if fused_qkv is not None and tid in (W.T_WQ, W.T_WK, W.T_WV):
                 if tid == W.T_WQ:
@@ -145,13 +163,20 @@ def write_model_dir(d, fmt="llama2.c", wd="Q4", kvd="Q8", thr=0, ctx=64, ret="tr
         write_safetensors(os.path.join(d, "model.safetensors"), w, s, st_dtype, fused_qkv)
         if fused_qkv is not None:
             spec["network_structure"]["qkv_format"] = fused_qkv
-        json.dump({"hidden_size": s["dim"], "intermediate_size": s["ffn"], "num_hidden_layers": s["layers"],
-                   "num_attention_heads": s["heads"], "num_key_value_heads": s["kv_heads"], "vocab_size": s["vocab"],
-                   "max_position_embeddings": 2048, "rope_theta": 10000.0}, open(os.path.join(d, "config.json"), "w"))
+        cfgj = {"hidden_size": s["dim"], "intermediate_size": s["ffn"], "num_hidden_layers": s["layers"],
+                "num_attention_heads": s["heads"], "num_key_value_heads": s["kv_heads"], "vocab_size": s["vocab"],
+                "max_position_embeddings": 2048, "rope_theta": 10000.0}
+        if s.get("experts", 0):
+            spec["network_structure"].update(type="transformer.decoder_only.sparse_moe", expert_count=s["experts"], using_expert_count=s["experts"],
+                                             moe_top_k=s["moe_top_k"])
+            cfgj.update(num_local_experts=s["experts"], num_experts_per_tok=s["moe_top_k"])
+        json.dump(cfgj, open(os.path.join(d, "config.json"), "w"))
     else:
         spec.update(model_file_format="synthetic", model_files=[])
         spec["hyper_params"] = hyper or {"vocab_size": s["vocab"], "embd_dims": s["dim"], "hidden_dim": s["ffn"], "decoder_layers": s["layers"],
                                          "decoder_heads": s["heads"], "decoder_kv_heads": s["kv_heads"]}
+        if s.get("experts", 0):
+            spec["network_structure"].update(type="transformer.decoder_only.sparse_moe", expert_count=s["experts"], moe_top_k=s["moe_top_k"])
         spec["synthetic_std"] = 0.06
     json.dump(spec, open(os.path.join(d, "model_spec.json"), "w"), indent=2)
     ini = os.path.join(d, "engine.ini")
@@ -163,7 +188,8 @@ def write_model_dir(d, fmt="llama2.c", wd="Q4", kvd="Q8", thr=0, ctx=64, ret="tr
 def host_tensors(w, s, wdtype, thr=0, lm_quant=True):
     """The oracle's view of what the engine loads: F16-rounded sources + target dtypes (NetworkBuilder policy)."""
     host = {}
-    for (l, tid), arr in w.items():
+    for key, arr in w.items():
+        l, tid = key[0], key[1]
         rows, cols = arr.shape
         is_matrix = tid in (W.T_WQ, W.T_WK, W.T_WV, W.T_WO, W.T_W1, W.T_W2, W.T_W3)
         target = dt.F16
@@ -171,5 +197,5 @@ def host_tensors(w, s, wdtype, thr=0, lm_quant=True):
             target = wdtype
         if tid == W.T_LM_HEAD and l < 0 and wdtype >= 7 and s["layers"] <= 20 and lm_quant:
             target = wdtype
-        host[(l, tid)] = (target, arr.astype(np.float16), rows, cols)
+        host[key] = (target, arr.astype(np.float16), rows, cols)
     return host

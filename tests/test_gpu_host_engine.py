@@ -213,3 +213,57 @@ def test_model_decoding_strategy_from_the_ini(tmp_path):
     open(ini, "w").write(text.replace('{"name":"sample.top_p", "top_p":0.5, "max_k":3}', "sample.nonsense"))
     with pytest.raises(EngineError, match="Invalid decoding_strategy"):
         InferenceEngine.from_ini(ini)
+
+
+# ---- mixture of experts through the .ini surface (configs[4])
+@pytest.mark.parametrize("devices,tp_merge", [("0", 1), ("0&0", 2)], ids=["one_worker", "tensor_parallel_2"])
+def test_moe_safetensors_checkpoint_through_the_engine_matches_oracle(tmp_path, devices, tp_merge):
+    """A Mixtral-named safetensors checkpoint (block_sparse_moe.gate / experts.{j}.w1|w2|w3, 4 experts, top-2) loaded by
+    host/model_loader.cc: prefill logits and greedy decode against the whole-model oracle -- on one worker and over a
+    tensor-parallel device group (every rank holds its slice of every expert; merge restated in the oracle)."""
+    s = fx.MOE_SHAPE
+    ini, w = fx.write_model_dir(str(tmp_path), fmt="safetensors", wd="Q4", kvd="F16", qk_order=2, s=s, devices=devices)
+    eng = InferenceEngine.from_ini(ini)
+    host = fx.host_tensors(w, s, dt.Q4_B32T1A)
+    om = oracle_model_from_host(host, s, 64, dt.F16, rope_order=2, unk_id=0, **({"tp_merge": tp_merge} if tp_merge > 1 else {}))
+    prompt = np.random.default_rng(8).integers(3, 1000, 11).astype(np.int32)
+    qid = eng.add_query(prompt)
+    (q, tok), = eng.infer()
+    tok_o, lg_o = om.forward(prompt, 0, nthreads=4)
+    cos, mad = _close(eng.last_logits(qid), lg_o)
+    assert cos >= 0.9995 and mad <= 0.03, (cos, mad)
+    cur, pos = tok, len(prompt)
+    for step in range(8):
+        t_or, l_or = om.forward(np.array([cur], np.int32), pos, nthreads=4)
+        assert eng.commit({qid: cur})
+        (q, tok), = eng.infer()
+        top2 = np.sort(l_or[0].astype(np.float32))[-2:]
+        if top2[1] - top2[0] > 0.03:
+            assert tok == t_or, "step %d" % step
+        cur, pos = tok, pos + 1
+    eng.close()
+
+
+def test_moe_synthetic_model_generates_and_batches(tmp_path):
+    """model_file_format = synthetic with expert_count: bin/ifa_llm_inference's path; three queries advance together
+    through one batched step and each follows its own single-query trajectory."""
+    s = fx.MOE_SHAPE
+    ini, _ = fx.write_model_dir(str(tmp_path), fmt="synthetic", wd="Q4", kvd="F16", ret="false", maxq=4, s=s)
+    eng = InferenceEngine.from_ini(ini)
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(3, 1000, n).astype(np.int32) for n in (6, 9, 4)]
+    solo = []
+    for pr in prompts:
+        qid = eng.add_query(pr)
+        gen, _ = eng.generate(qid, 6)
+        solo.append([int(t) for t in gen])
+        assert eng.remove_query(qid)
+    qids = [eng.add_query(pr) for pr in prompts]
+    outs = {q: [] for q in qids}
+    for _ in range(6):
+        for q, t in eng.infer():
+            outs[q].append(int(t))
+        eng.commit({q: outs[q][-1] for q in qids})
+    for q, ref in zip(qids, solo):
+        assert outs[q] == ref
+    eng.close()

@@ -130,3 +130,32 @@ def test_two_gpu_partitions_match_oracle(tmp_path, devices):
 @pytest.mark.skipif(NGPU < 4, reason="needs 4 GPUs")
 def test_hybrid_2x2_matches_oracle(tmp_path):
     assert _run_against_oracle(tmp_path, "0&1;2&3", "false", tp_merge=2) == 4
+
+
+def test_query_batching_on_a_tensor_parallel_engine_matches_single_query_steps(tmp_path):
+    """Dynamic batching INSIDE a partitioned engine (reference: query batching inside
+    Infer_TensorParallelism, inference_engine.cc:1054-1124 + :1222-1296): three queries on "devices = 0&0" advance through
+    ONE batched step per Infer() (ifa_model_tp_decode_batch on every rank) and reproduce what each gives alone."""
+    ini, _ = fx.write_model_dir(str(tmp_path), fmt="llama2.c", wd="Q4", kvd="F16", ret="false", maxq=4, devices="0&0")
+    eng = InferenceEngine.from_ini(ini)
+    assert eng.model_info("partition_ranks") == 2
+    rng = np.random.default_rng(9)
+    prompts = [rng.integers(3, 1000, n).astype(np.int32) for n in (7, 5, 10)]
+    solo = []
+    for pr in prompts:
+        qid = eng.add_query(pr)
+        toks = []
+        for _ in range(6):
+            (q, t), = eng.infer()
+            toks.append(int(t)); eng.commit({qid: t})
+        solo.append(toks)
+        assert eng.remove_query(qid)
+    qids = [eng.add_query(pr) for pr in prompts]
+    outs = {q: [] for q in qids}
+    for _ in range(6):
+        for q, t in eng.infer():
+            outs[q].append(int(t))
+        eng.commit({q: outs[q][-1] for q in qids})
+    for q, ref in zip(qids, solo):
+        assert outs[q] == ref
+    eng.close()
