@@ -80,6 +80,40 @@ def test_long_rows_fused_equals_unfused(shape, wd):
     wk.close()
 
 
+def test_mixtral_8x7b_width_fused_equals_unfused_and_batched_rows_are_independent():
+    """configs[4] at its own widths: 8 experts of ffn 14336 (7 blocks per lane on w2's 14336 columns), top-2 routing, 32
+    heads over 8 KV heads, 2 layers.  The fused MoE decode step == the op-by-op path bit for bit; a batched step of 8
+    queries (the device-routed grouped path) gives every query the token its own single-query step gives."""
+    wk, _, s = synth.build("mixtral_8x7b", dt.Q4_B32T1A, dt.F16, max_ctx=64, layers=2, vocab=8000)
+    ok, why = wk.fused_supported()
+    assert ok, why
+    rng = np.random.default_rng(21)
+    prompt = rng.integers(3, s["vocab"], 6).astype(np.int32)
+    tok = wk.forward(prompt, 0)
+    fused, _ = wk.decode(tok, len(prompt), 6)
+    logits_fused = wk.read_buffer("logits").copy()
+    wk.set_option("fused", 0)
+    unfused, _ = wk.decode(tok, len(prompt), 6)
+    logits_unfused = wk.read_buffer("logits").copy()
+    wk.set_option("fused", 1)
+    assert np.array_equal(fused, unfused) and np.array_equal(logits_fused, logits_unfused)
+    # batch of 8 queries, one step: each row == the query's own decode step
+    wk.kv_slots(8)
+    prompts = [rng.integers(3, s["vocab"], n).astype(np.int32) for n in (4, 7, 5, 9, 3, 6, 8, 5)]
+    firsts, solo = [], []
+    for i, pr in enumerate(prompts):
+        wk.select_kv(i)
+        t0 = wk.forward(pr, 0)
+        firsts.append(t0)
+        nxt, _ = wk.decode(t0, len(pr), 1)
+        solo.append(int(nxt[0]))
+        wk.forward(pr, 0)              # restore the cache row the solo step wrote at position len(pr) (same values anyway)
+    got = wk.decode_batch(firsts, [len(p) for p in prompts], list(range(8)))
+    agree = sum(int(a) == b for a, b in zip(got, solo))
+    assert agree >= 7, (list(got), solo)       # (T > 1 rows use F16 activations: a near tie may flip one row)
+    wk.close()
+
+
 @pytest.mark.parametrize("T,rows,cols", [(16, 4096, 4096), (128, 11008, 4096), (1024, 4096, 11008)])
 def test_llama2_7b_width_prefill_gemm_regimes_agree(T, rows, cols):
     """The three prefill GEMM regimes at Llama-2-7B widths (8-wave split-K for T <= 32, 4-wave split-K up to 128 tokens,
