@@ -222,6 +222,10 @@ typedef struct {
      * the attention output, the FFN output and the last layer's output (attn_out_scale / ffn_out_scale / out_scale:
      * MiniCPM; inference_worker.cc:568-570, 842-843, 928-929).  Scales <= 0 mean 1. */
     float attn_norm_base, ffn_norm_base, out_norm_base, attn_out_scale, ffn_out_scale, out_scale;
+    /* TensorOpr::LinearNorm on the decoder input (has_embedding_linear_norm / embedding_linear_scale: Gemma, MiniCPM;
+     * inference_worker.cc:447-451, tensor_opr.cu:482-497): every embedding row is multiplied by this scale;
+     * 0 = absent, < 0 = the reference's default sqrt(dim). */
+    float embd_scale;
 } ifa_model_config;
 
 /* tensor ids for ifa_model_set_tensor (StdDeviceNetwork, src/transformer/model.h:168-276) */

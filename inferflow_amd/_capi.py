@@ -177,7 +177,7 @@ class ModelConfig(C.Structure):
             "rope_theta", "partial_rotary", "kq_scale", "eps")] + [(n, C.c_int) for n in (
                 "kv_dtype", "full_quant_gemv", "experts", "moe_top_k", "moe_norm_topk",
                 "tp_rank", "tp_size", "device")] + [(n, C.c_float) for n in (
-                    "attn_norm_base", "ffn_norm_base", "out_norm_base", "attn_out_scale", "ffn_out_scale", "out_scale")]
+                    "attn_norm_base", "ffn_norm_base", "out_norm_base", "attn_out_scale", "ffn_out_scale", "out_scale", "embd_scale")]
 
 
 def _declare(L):

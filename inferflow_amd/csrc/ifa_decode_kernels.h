@@ -403,11 +403,12 @@ struct DecGemvParams {
     const half_t *norm_w, *norm_b;
     float multi_base, eps;
     int cols, nblk;            // nblk = WEIGHT blocks per row (cols / block capacity of the format)
-    int nsets, total_rows;
+    short nsets, act_kind;     // (16-bit fields: the struct is kept at 248 bytes, see below)
+    int total_rows;
     const uint8_t *W0[3];      // tiled rows of each set
     const uint8_t *W1;         // w3 (EPI_GLU), paired with W0[0]
     int rows[3];
-    int act_kind;
+    float post_scale;          // see pre_scale
     half_t *xn_out;            // optional copy of the normalised activation
     long long *trace;          // optional [gridDim.x][8] wall-clock stamps (100 MHz) for tuning
     half_t *y[3];
@@ -423,7 +424,11 @@ struct DecGemvParams {
     const int *moe_sel;
     const half_t *moe_w;
     const half_t *moe_acc;     // running sum over the experts visited so far (read when moe_slot > 0)
-    int moe_slot, moe_tab_off;
+    short moe_slot, moe_tab_off;
+    // TensorOpr::Scale of the reference's layer wiring, 0 = absent: pre_scale multiplies the product (+ bias) before the
+    // residual is added (attn_out_scale / ffn_out_scale, inference_worker.cc:841-843, 927-929), post_scale the sum after it
+    // (out_scale on the last layer's output); each is its own F16 rounding like the separate Scale launch it replaces
+    float pre_scale;
 };
 // (tools/probes/gap_probe.hip: the boundary between two trivial launches is 1.58-1.60 us for any workgroup size, grid,
 // LDS size and argument-block size from 64 to 512 bytes; what matters is which fields the first instructions wait for)
@@ -471,9 +476,13 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
 {
     const int row = d.row;
     half_t y = dec_bias(a0, d.b0, row);
+    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_PLAIN) {
+        if (P.pre_scale != 0.0f) y = f2h(h2f(y) * P.pre_scale);      // TensorOpr::Scale (k_scale)
+    }
     if constexpr (EPI == EPI_RESIDUAL) {
         y = f2h(h2f(res) + h2f(y));                         // TensorOpr::Add (half add)
         if (P.residual2) y = f2h(h2f(y) + h2f(res2));
+        if (P.post_scale != 0.0f) y = f2h(h2f(y) * P.post_scale);
     } else if constexpr (EPI == EPI_GLU || EPI == EPI_MOE_GLU) {
         half_t t2 = dec_bias(a1, d.b1, row);
         half_t act = f2h(act_fn(h2f(y), P.act_kind));       // TensorOpr::Activation -> F16
@@ -485,8 +494,10 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
         const half_t prev = P.moe_slot == 0 ? (half_t)0 : P.moe_acc[row];
         y = __builtin_fmaf16(y, wexp, prev);                // TensorOpr::AddByRowIndex
         if constexpr (EPI == EPI_MOE_LAST) {
+            if (P.pre_scale != 0.0f) y = f2h(h2f(y) * P.pre_scale);
             y = f2h(h2f(y) + h2f(P.residual[row]));         // + residual (Add(ff_out, residual))
             if (P.residual2) y = f2h(h2f(y) + h2f(P.residual2[row]));
+            if (P.post_scale != 0.0f) y = f2h(h2f(y) * P.post_scale);
         }
     }
     d.y[row] = y;
@@ -1473,15 +1484,27 @@ __host__ __device__ inline size_t dec_attn_smem(int head_dim, int max_ctx)
 // state[8 + i] = i-th generated token of the current launch batch.
 // Also fills the step's RoPE table: tab[c] = (cos, sin) of pos * theta_scale^c,
 // the same expression rope_rotate() evaluates per element (ifa_math.h).
+// embd_scale != 0: TensorOpr::LinearNorm on the decoder input (has_embedding_linear_norm, inference_worker.cc:447-451; tensor_opr.cu:482-497
+// = Tensor_Scale_Kernel: half((float)e * scale)), fused into the row copy
+__device__ __forceinline__ u32x4 embd_row_scale(u32x4 v, float embd_scale)
+{
+    if (embd_scale == 0.0f) return v;
+    half8_t h = __builtin_bit_cast(half8_t, v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = f2h(h2f(h[i]) * embd_scale);
+    return __builtin_bit_cast(u32x4, h);
+}
+
 // batched step: embedding row of every query's token (grid (x, queries)) and its RoPE table rope_tab[query][head_dim]
 static __global__ void __launch_bounds__(256) k_dec_batch_gather(const half_t *__restrict__ embd, const int *__restrict__ tokens,
                                                                  const int *__restrict__ positions, int dim, int vocab, half_t *__restrict__ x,
-                                                                 float *__restrict__ rope_tab, int head_dim, float theta, int rope_dims)
+                                                                 float *__restrict__ rope_tab, int head_dim, float theta, int rope_dims,
+                                                                 float embd_scale)
 {
     const int b = blockIdx.y;
     const int tok = min(max(tokens[b], 0), vocab - 1);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim / 8; c += gridDim.x * blockDim.x)
-        reinterpret_cast<u32x4 *>(x + (size_t)b * dim)[c] = reinterpret_cast<const u32x4 *>(embd + (size_t)tok * dim)[c];
+        reinterpret_cast<u32x4 *>(x + (size_t)b * dim)[c] = embd_row_scale(reinterpret_cast<const u32x4 *>(embd + (size_t)tok * dim)[c], embd_scale);
     if (blockIdx.x == 0 && rope_tab) {
         const int pos = positions[b];
         for (int c = threadIdx.x; c < head_dim / 2; c += blockDim.x) {
@@ -1495,13 +1518,13 @@ static __global__ void __launch_bounds__(256) k_dec_batch_gather(const half_t *_
 static __global__ void __launch_bounds__(256) k_dec_gather(const half_t *__restrict__ embd, const int *__restrict__ state,
                                                     int dim, int vocab, half_t *__restrict__ x,
                                                     float *__restrict__ rope_tab, int head_dim, float theta,
-                                                    int rope_dims)
+                                                    int rope_dims, float embd_scale)
 {
     if (embd) {      // null: the layer input arrives from the previous pipeline stage, only the RoPE table is needed
         int tok = state[0];
         tok = min(max(tok, 0), vocab - 1);
         for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim / 8; c += gridDim.x * blockDim.x)
-            reinterpret_cast<u32x4 *>(x)[c] = reinterpret_cast<const u32x4 *>(embd + (size_t)tok * dim)[c];
+            reinterpret_cast<u32x4 *>(x)[c] = embd_row_scale(reinterpret_cast<const u32x4 *>(embd + (size_t)tok * dim)[c], embd_scale);
     }
     if (blockIdx.x == 0 && rope_tab) {
         const int pos = state[1];

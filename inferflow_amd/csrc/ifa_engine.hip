@@ -240,8 +240,8 @@ static bool fused_supported(const ifa_model *m, std::string *why)
     const ifa_model_config &c = m->cfg;
     auto fail = [&](const char *s) { if (why) *why = s; return false; };
     if (c.experts > 64 || (c.experts > 0 && (c.moe_top_k < 1 || c.moe_top_k > 8))) return fail("MoE: experts / top_k out of range");
-    if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale))
-        return fail("models with output scales (attn_out_scale / ffn_out_scale / out_scale) use the op-by-op path");
+    if ((scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) && c.tp_size > 1)
+        return fail("output scales (attn_out_scale / ffn_out_scale / out_scale) on a partitioned model use the op-by-op path");
     if (c.experts > 0 && (c.norm_kind != 0 || c.parallel_attn || c.share_input)) return fail("MoE layers need the sequential RMS-norm wiring");
     if (!c.full_quant_gemv) return fail("full_quant_gemv disabled");
     if (c.head_dim != 32 && c.head_dim != 48 && c.head_dim != 64 && c.head_dim != 80 && c.head_dim != 96 && c.head_dim != 128)
@@ -434,6 +434,7 @@ static int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial = nul
     }
     P.b0[0] = (const half_t *)L.t[T_WO_B].data;
     P.y[0] = m->a; P.residual = x;
+    if (scale_on(m->cfg.attn_out_scale)) P.pre_scale = m->cfg.attn_out_scale;      // Scale(self_att_out) fused in front of the residual add
     if (m->cfg.parallel_attn || m->cfg.share_input)      // the residual is added once, after the FFN (inference_worker.cc:847-851)
         return preq ? launch_dec_gemv<EPI_PLAIN, 2>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream)
                     : launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
@@ -508,6 +509,8 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
             return launch_dec_gemv<EPI_MOE_ACC, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
         }
         P.y[0] = moe_last ? xnext : m->f; P.residual = m->a; P.residual2 = residual2;
+        if (moe_last && scale_on(m->cfg.ffn_out_scale)) P.pre_scale = m->cfg.ffn_out_scale;
+        if (moe_last && l + 1 == m->cfg.layers && scale_on(m->cfg.out_scale)) P.post_scale = m->cfg.out_scale;
         if (moe_last) return launch_dec_gemv<EPI_MOE_LAST, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
         return launch_dec_gemv<EPI_MOE_ACC, 0>(e2.dtype, P, m->opt_rpw_w2, m->stream);
     }
@@ -519,6 +522,8 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
     }
     P.b0[0] = (const half_t *)L.t[T_W2_B].data;
     P.y[0] = xnext; P.residual = m->a; P.residual2 = residual2;     // + layer input for parallel / shared-input models
+    if (scale_on(m->cfg.ffn_out_scale)) P.pre_scale = m->cfg.ffn_out_scale;                               // Scale(ff_out)
+    if (l + 1 == m->cfg.layers && scale_on(m->cfg.out_scale)) P.post_scale = m->cfg.out_scale;        // Scale(last layer's output)
     return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
 }
 
@@ -772,6 +777,7 @@ static bool persist_supported(ifa_model *m, std::string *why)
     if (c.experts > 0) return fail("persistent decode: mixture-of-experts layers use the five-launch path");
     if (c.norm_kind != 0 || c.parallel_attn || c.share_input) return fail("persistent decode: sequential RMS-norm wiring only");
     if (c.tp_size > 1) return fail("persistent decode: single-worker models only");
+    if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) return fail("persistent decode: no output scales");
     if (c.head_dim != 64 && c.head_dim != 128) return fail("persistent decode: head_dim 64 / 128");
     if (c.heads * c.head_dim != c.dim) return fail("persistent decode: heads * head_dim must equal dim");
     if (c.kv_dtype != F16 && c.kv_dtype != Q8_B32T2) return fail("persistent decode: F16 or Q8 KV cache");
@@ -950,7 +956,7 @@ static int enqueue_fused_step(ifa_model *m)
     hipStream_t s = m->stream;
     k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows, m->x,
                                                c.rope_order ? m->rope_tab : nullptr, c.head_dim, c.rope_theta,
-                                               (int)(c.head_dim * c.partial_rotary + 0.5f));
+                                               (int)(c.head_dim * c.partial_rotary + 0.5f), c.embd_scale);
     IFA_LAUNCH_CHECK();
     half_t *x = m->x, *xnext = m->x2;
     int rc;
@@ -1055,13 +1061,15 @@ static int ensure_scratch(ifa_model *m, int T)
 }
 
 __global__ void __launch_bounds__(256) k_gather_rows(const half_t *__restrict__ embd, const int *__restrict__ tokens,
-                                                     int T, int dim, int vocab, half_t *__restrict__ x)
+                                                     int T, int dim, int vocab, half_t *__restrict__ x, float embd_scale)
 {
     const int t = blockIdx.y;
     int tok = tokens[t];
     tok = min(max(tok, 0), vocab - 1);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim; c += gridDim.x * blockDim.x)
-        x[(size_t)t * dim + c] = embd[(size_t)tok * dim + c];
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim; c += gridDim.x * blockDim.x) {
+        const half_t e = embd[(size_t)tok * dim + c];
+        x[(size_t)t * dim + c] = embd_scale != 0.0f ? f2h(h2f(e) * embd_scale) : e;       // LinearNorm (inference_worker.cc:447-451)
+    }
 }
 
 // MatrixMultiplicationEx + MatrixMultiplication dispatch (inference_worker.cc:2337-2432)
@@ -1279,7 +1287,7 @@ static int moe_ffn(ifa_model *m, Layer &L, const half_t *ff_n, int T)
         const int n = (int)rows[(size_t)e].size();
         if (n == 0) continue;
         const int *idx_dev = m->moe_idx + start[(size_t)e];
-        k_gather_rows<<<dim3(4, (unsigned)n), dim3(256), 0, m->stream>>>(ff_n, idx_dev, n, (int)D, T, m->moe_in);
+        k_gather_rows<<<dim3(4, (unsigned)n), dim3(256), 0, m->stream>>>(ff_n, idx_dev, n, (int)D, T, m->moe_in, 0.0f);
         IFA_LAUNCH_CHECK();
         const Tensor *ew = &L.experts[(size_t)e * 3];
         if ((rc = ffn_dense(m, m->moe_in, n, ew[0], none, ew[2], none, ew[1], none, m->moe_out))) return rc;
@@ -1382,7 +1390,7 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     if (first_stage) {
         IFA_HIP_CHECK(hipMemcpyAsync(m->tokens_dev, tokens_host, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, m->stream));
         k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->tokens_dev, T, (int)D,
-                                                                          (int)m->g[T_EMBD].rows, m->x);
+                                                                          (int)m->g[T_EMBD].rows, m->x, c.embd_scale);
         IFA_LAUNCH_CHECK();
     } else if ((rc = ifa_recv(tp->world, m->x, (size_t)T * D * 2, tp->prev_rank, s))) return rc;     // the previous group's [T][dim] output
     half_t *x = m->x;
@@ -1827,10 +1835,10 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     if (fused)
         k_dec_batch_gather<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, tok_d, pos_d, (int)D, (int)m->g[T_EMBD].rows,
                                                                               m->x, c.rope_order ? m->brope : nullptr, c.head_dim, c.rope_theta,
-                                                                              (int)(c.head_dim * c.partial_rotary + 0.5f));
+                                                                              (int)(c.head_dim * c.partial_rotary + 0.5f), c.embd_scale);
     else
         k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, tok_d, T, (int)D,
-                                                                          (int)m->g[T_EMBD].rows, m->x);
+                                                                          (int)m->g[T_EMBD].rows, m->x, c.embd_scale);
     IFA_LAUNCH_CHECK();
     half_t *x = m->x;
     const Tensor none;
@@ -1958,6 +1966,7 @@ int ifa_model_create(const ifa_model_config *cfg, ifa_model **out)
     if (m->cfg.partial_rotary <= 0) m->cfg.partial_rotary = 1.0f;
     if (m->cfg.tp_size <= 0) m->cfg.tp_size = 1;
     for (float *sc : {&m->cfg.attn_out_scale, &m->cfg.ffn_out_scale, &m->cfg.out_scale}) if (*sc <= 0.0f) *sc = 1.0f;
+    if (m->cfg.embd_scale < 0.0f) m->cfg.embd_scale = sqrtf((float)m->cfg.dim);      // LinearNorm's default scale (tensor_opr.cu:492-494)
     m->layers.resize((size_t)cfg->layers);
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete m; return ifa_fail(IFA_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -2427,6 +2436,9 @@ static int tp_ready(ifa_model *m)
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
     if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
+    const ifa_model_config &c = m->cfg;      // the fused epilogues apply out_scale after the LOCAL last layer: single-worker models only
+    if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale))
+        return ifa_fail(IFA_ERR_STATE, "fused path unavailable: output scales on a partitioned model use the op-by-op path");
     return ensure_scratch(m, 1);
 }
 
@@ -2443,7 +2455,7 @@ int ifa_model_tp_begin(ifa_model *m, int token, int pos)
     k_tp_set_state<<<1, 1, 0, m->stream>>>(m->state, token, pos);     // token < 0: keep the id already on the device
     k_dec_gather<<<dim3(2), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows,
                                                        m->x, c.rope_order ? m->rope_tab : nullptr, c.head_dim, c.rope_theta,
-                                                       (int)(c.head_dim * c.partial_rotary + 0.5f));
+                                                       (int)(c.head_dim * c.partial_rotary + 0.5f), c.embd_scale);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
@@ -2459,7 +2471,7 @@ int ifa_model_tp_begin_hidden(ifa_model *m, const void *x_f16, int pos)
     IFA_HIP_CHECK(hipMemcpyAsync(m->x, x_f16, (size_t)c.dim * 2, hipMemcpyDeviceToDevice, m->stream));
     k_tp_set_state<<<1, 1, 0, m->stream>>>(m->state, -1, pos);
     k_dec_gather<<<dim3(1), dim3(256), 0, m->stream>>>(nullptr, m->state, c.dim, 1, m->x, c.rope_order ? m->rope_tab : nullptr,
-                                                       c.head_dim, c.rope_theta, (int)(c.head_dim * c.partial_rotary + 0.5f));
+                                                       c.head_dim, c.rope_theta, (int)(c.head_dim * c.partial_rotary + 0.5f), c.embd_scale);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
@@ -2833,7 +2845,7 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
     };
     k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, m->cfg.dim, (int)m->g[T_EMBD].rows, m->x,
                                                m->cfg.rope_order ? m->rope_tab : nullptr, m->cfg.head_dim, m->cfg.rope_theta,
-                                               (int)(m->cfg.head_dim * m->cfg.partial_rotary + 0.5f));
+                                               (int)(m->cfg.head_dim * m->cfg.partial_rotary + 0.5f), m->cfg.embd_scale);
     for (int i = 0; i < 3; i++) if ((rc = one(i))) return rc;
     if (m->opt_trace) {
         if (!m->trace) IFA_HIP_CHECK(hipMalloc((void **)&m->trace, sizeof(long long) * 2048 * 8));

@@ -51,6 +51,8 @@ struct ModelSpec {
     float rope_theta = 10000.0f, partial_rotary_factor = 1.0f, kq_scale = 1.0f;
     float attn_pre_norm_base = 0, ffn_pre_norm_base = 0, output_norm_base = 0;      // RMS weight = base + w (Gemma)
     float attn_out_scale = 1, ffn_out_scale = 1, out_scale = 1;                       // TensorOpr::Scale (MiniCPM)
+    bool has_embedding_linear_norm = false;                                           // TensorOpr::LinearNorm on the decoder input (Gemma, MiniCPM)
+    float embedding_linear_scale = 0;                                                 // <= 0.0001: sqrt(embd_dims)
     int qk_column_order = 0, qkv_format = 0;
     bool is_parallel_attn = false, mlp_attn_share_input = false;
     std::string tensor_name_prefix;

@@ -125,6 +125,8 @@ bool LoadModelSpecJson(ModelSpec &spec, const std::string &path)
     ns->GetNumber("attn_out_scale", spec.attn_out_scale);
     ns->GetNumber("ffn_out_scale", spec.ffn_out_scale);
     ns->GetNumber("out_scale", spec.out_scale);
+    ns->GetBool("has_embedding_linear_norm", spec.has_embedding_linear_norm);          // model_reader.cc:374-377
+    ns->GetNumber("embedding_linear_scale", spec.embedding_linear_scale);
     ns->GetBool("is_parallel_attn", spec.is_parallel_attn);
     ns->GetBool("mlp_attn_share_input", spec.mlp_attn_share_input);
     ns->GetNumber("expert_count", hp.experts);
@@ -290,6 +292,8 @@ bool CreateWorkers(std::vector<WorkerPlan> &plans, const ModelSpec &spec)
         c.full_quant_gemv = 1; c.tp_rank = w.tp_rank; c.tp_size = P; c.device = w.device;
         c.attn_norm_base = spec.attn_pre_norm_base; c.ffn_norm_base = spec.ffn_pre_norm_base; c.out_norm_base = spec.output_norm_base;
         c.attn_out_scale = spec.attn_out_scale; c.ffn_out_scale = spec.ffn_out_scale; c.out_scale = spec.out_scale;
+        // LinearNorm of the decoder input (inference_worker.cc:447-451): scale <= 0.0001 means sqrt(dim) (tensor_opr.cu:492-494)
+        c.embd_scale = !spec.has_embedding_linear_norm ? 0.0f : (spec.embedding_linear_scale <= 0.0001f ? -1.0f : spec.embedding_linear_scale);
         // sparse mixture of experts (network_builder.cc:81-84, 205-209: one FFN per expert + the router "moe.gate"): every
         // rank of a device group holds its row / column slice of EVERY expert, the router is replicated
         c.experts = hp.experts; c.moe_top_k = hp.experts > 0 ? hp.moe_top_k : 0; c.moe_norm_topk = hp.moe_norm_top_k_prob ? 1 : 0;

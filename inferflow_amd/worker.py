@@ -18,7 +18,8 @@ T_WQ_B, T_WK_B, T_WV_B, T_WO_B, T_W1_B, T_W2_B, T_W3_B = 22, 23, 24, 25, 26, 27,
 _DEFAULTS = dict(norm_kind=0, act_kind=0, is_glu=1, rope_order=2, use_alibi=0, parallel_attn=0, share_input=0,
                  rope_theta=10000.0, partial_rotary=1.0, kq_scale=1.0, eps=1e-5, kv_dtype=dt.F16,
                  full_quant_gemv=1, experts=0, moe_top_k=0, moe_norm_topk=1, tp_rank=0, tp_size=1, device=0,
-                 attn_norm_base=0.0, ffn_norm_base=0.0, out_norm_base=0.0, attn_out_scale=1.0, ffn_out_scale=1.0, out_scale=1.0)
+                 attn_norm_base=0.0, ffn_norm_base=0.0, out_norm_base=0.0, attn_out_scale=1.0, ffn_out_scale=1.0, out_scale=1.0,
+                 embd_scale=0.0)
 
 
 class DecodeWorker:

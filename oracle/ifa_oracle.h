@@ -115,6 +115,10 @@ typedef struct {
      * {attn_out_scale, ffn_out_scale, out_scale} (TensorOpr::Scale, inference_worker.cc:568-570,842-843,928-929; MiniCPM);
      * scales <= 0 mean 1 */
     float attn_norm_base, ffn_norm_base, out_norm_base, attn_out_scale, ffn_out_scale, out_scale;
+    /* TensorOpr::LinearNorm on the decoder input (has_embedding_linear_norm, inference_worker.cc:447-451;
+     * tensor_opr.cu:482-497 = Scale by embedding_linear_scale, or sqrt(dim) when that is <= 0.0001): 0 = absent,
+     * < 0 = sqrt(dim) */
+    float embd_scale;
     /* id the greedy selection never offers: the vocabulary's unk id (GetSortedTopK, sampling_strategy.cc:281-297;
      * StdVocabulary's default is 0); < 0: none */
     int unk_id;

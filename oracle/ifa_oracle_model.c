@@ -233,6 +233,8 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
             if (tokens[t] < 0 || (size_t)tokens[t] >= e->rows) { rc = -3; goto done; }
             memcpy(x + (size_t)t * D, (const orc_f16 *)e->data + (size_t)tokens[t] * D, D * 2);
         }
+        if (c->embd_scale != 0.0f)       /* ProcessPreLayer's LinearNorm (inference_worker.cc:447-451): Tensor_Scale_Kernel, F16 out */
+            orc_scale(x, c->embd_scale < 0.0f ? sqrtf((float)D) : c->embd_scale, (size_t)T * D, x);
     }
     const int rope_dims = (int)((float)c->head_dim * c->partial_rotary + 0.5f);
     const int rope_cols = rope_dims;

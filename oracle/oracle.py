@@ -323,7 +323,7 @@ class ModelCfg(C.Structure):
         "share_input")] + [(n, C.c_float) for n in (
             "rope_theta", "partial_rotary", "kq_scale", "eps")] + [(n, C.c_int) for n in (
                 "kv_dtype", "full_quant_gemv", "experts", "moe_top_k", "moe_norm_topk")] + [(n, C.c_float) for n in (
-                    "attn_norm_base", "ffn_norm_base", "out_norm_base", "attn_out_scale", "ffn_out_scale", "out_scale")] + [("unk_id", C.c_int), ("tp_merge", C.c_int)]
+                    "attn_norm_base", "ffn_norm_base", "out_norm_base", "attn_out_scale", "ffn_out_scale", "out_scale", "embd_scale")] + [("unk_id", C.c_int), ("tp_merge", C.c_int)]
 
 
 class Model:
@@ -335,7 +335,7 @@ class Model:
                         share_input=0, rope_theta=10000.0, partial_rotary=1.0, kq_scale=1.0, eps=1e-5,
                         kv_dtype=F16, full_quant_gemv=1, experts=0, moe_top_k=0, moe_norm_topk=1,
                         attn_norm_base=0.0, ffn_norm_base=0.0, out_norm_base=0.0, attn_out_scale=1.0, ffn_out_scale=1.0,
-                        out_scale=1.0, unk_id=-1, tp_merge=1)
+                        out_scale=1.0, embd_scale=0.0, unk_id=-1, tp_merge=1)
         defaults.update(kw)
         for k, v in defaults.items():
             setattr(cfg, k, v)

@@ -147,17 +147,18 @@ prompt_template = {{bos}}{{query}}
 
 
 def write_model_dir(d, fmt="llama2.c", wd="Q4", kvd="Q8", thr=0, ctx=64, ret="true", maxq=6, s=SHAPE, seed=5, qk_order=0,
-                    st_dtype="F16", hyper=None, fused_qkv=None, std=0.06, shared_classifier=False, devices="0", force_partition="false"):
-    """Returns (ini_path, weights dict or None)."""
+                    st_dtype="F16", hyper=None, fused_qkv=None, std=0.06, shared_classifier=False, devices="0", force_partition="false", net_extra=None):
+    """Returns (ini_path, weights dict or None).  net_extra: more network_structure keys (scales, linear norm ...)."""
     os.makedirs(d, exist_ok=True)
     spec = json.loads(json.dumps(SPEC))
     spec["network_structure"]["qk_column_order"] = qk_order
+    spec["network_structure"].update(net_extra or {})
     w = None
     if fmt == "llama2.c":
         w = make_weights(s, seed, std, shared_classifier=shared_classifier)
         write_llama2c(os.path.join(d, "model.bin"), w, s, seq_len=ctx, shared_classifier=shared_classifier)
     elif fmt == "safetensors":
-        w = make_weights(s, seed)
+        w = make_weights(s, seed, std)
         spec.update(model_file_format="safetensors", model_files=["model.safetensors.index.json", "model.safetensors"], config_file="config.json")
         spec["network_structure"]["tensor_name_prefix"] = "model."
         write_safetensors(os.path.join(d, "model.safetensors"), w, s, st_dtype, fused_qkv)

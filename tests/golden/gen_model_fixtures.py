@@ -15,6 +15,11 @@ src/transformer/model_reader.cc:3248-3430, a tokenizer file in the format of Rea
     top2_gap                  float32 [N]   top-1 minus top-2 of the reference's fp32 logits over the allowed ids
     excluded_ids              int32 []      ids GetSortedTopK never offers (the unk id; sampling_strategy.cc:281-297)
 
+The `st_*` cases are the same kind of run on a SAFETENSORS directory (HF tensor names under the "model." prefix, config.json
+hyper-parameters, qk_column_order 2 = HF's rotate-half column order, a vocab.txt read by LoadTokenizer_Txt
+model_reader.cc:1098-1137): they pin the safetensors loader's name map and the RoPE pairing of qk_column_order 2 to the
+reference engine itself (fields fmt / qk_order say how tests must write the model directory).
+
 Nothing here is imported by the product or at GPU-test time; the .npz files are data.
     python tests/golden/gen_model_fixtures.py
 """
@@ -39,6 +44,11 @@ CASES = {
     "gqa": (dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000), 5, 0.06, 9, 72, False),
     "gqa_deep": (dict(dim=384, layers=4, heads=6, kv_heads=2, head_dim=64, ffn=1024, vocab=1200), 33, 0.05, 17, 72, True),
     "stories15m_shape": (dict(dim=288, layers=6, heads=6, kv_heads=6, head_dim=48, ffn=768, vocab=2000), 77, 0.05, 12, 72, True),
+}
+# safetensors directories: name -> (shape, seed, std, prompt_len, steps, qk_column_order)
+ST_CASES = {
+    "st_gqa_hf": (dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000), 57, 0.06, 11, 72, 2),
+    "st_mha_interleaved": (dict(dim=256, layers=2, heads=4, kv_heads=4, head_dim=64, ffn=512, vocab=1000), 43, 0.06, 9, 64, 0),
 }
 
 REF_INI = """[transformer_engine]
@@ -103,6 +113,28 @@ def write_ref_model_dir(d, shape, seed, std, ctx, shared):
     return ini, w
 
 
+def write_ref_safetensors_dir(d, shape, seed, std, ctx, qk_order):
+    """HF-named F16 safetensors + config.json + vocab.txt, the spec keys of data/models/*/model_spec.safetensors.json."""
+    os.makedirs(d, exist_ok=True)
+    w = fx.make_weights(shape, seed, std)
+    fx.write_safetensors(os.path.join(d, "model.safetensors"), w, shape, "F16")
+    with open(os.path.join(d, "vocab.txt"), "w") as f:
+        for i in range(shape["vocab"]):
+            f.write(("<unk>", "<s>", "</s>")[i] + "\n" if i < 3 else "t%d\n" % i)
+    spec = json.loads(json.dumps(fx.SPEC))
+    spec.update(model_file_format="safetensors", model_files=["model.safetensors"], config_file="config.json", tokenizer_file="vocab.txt")
+    ns = spec["network_structure"]
+    ns["tensor_name_prefix"] = "model."
+    ns["qk_column_order"] = qk_order
+    json.dump(spec, open(os.path.join(d, "model_spec.json"), "w"), indent=2)
+    json.dump({"hidden_size": shape["dim"], "intermediate_size": shape["ffn"], "num_hidden_layers": shape["layers"],
+               "num_attention_heads": shape["heads"], "num_key_value_heads": shape["kv_heads"], "vocab_size": shape["vocab"],
+               "max_position_embeddings": 2048, "rope_theta": 10000.0}, open(os.path.join(d, "config.json"), "w"))
+    ini = os.path.join(d, "engine.ini")
+    open(ini, "w").write(REF_INI.format(ctx=ctx))
+    return ini, w
+
+
 def run_reference(ini, prompt, steps, quiet=False):
     d = os.path.dirname(ini)
     pf = os.path.join(d, "prompt.i32")
@@ -134,10 +166,14 @@ def run_reference(ini, prompt, steps, quiet=False):
 def main():
     if not os.path.exists(DRIVER):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_engine"])
-    for name, (shape, seed, std, plen, steps, shared) in CASES.items():
+    cases = [(n, c[:5] + (c[5], "llama2.c", 0)) for n, c in CASES.items()] + [(n, c[:5] + (False, "safetensors", c[5])) for n, c in ST_CASES.items()]
+    for name, (shape, seed, std, plen, steps, shared, fmt, qk_order) in cases:
         with tempfile.TemporaryDirectory() as d:
             ctx = 128
-            ini, _ = write_ref_model_dir(d + "/", shape, seed, std, ctx, shared)
+            if fmt == "safetensors":
+                ini, _ = write_ref_safetensors_dir(d + "/", shape, seed, std, ctx, qk_order)
+            else:
+                ini, _ = write_ref_model_dir(d + "/", shape, seed, std, ctx, shared)
             prompt = np.random.default_rng(1000 + seed).integers(3, shape["vocab"], plen).astype(np.int32)
             r = run_reference(ini, prompt, steps)
         allrows = np.concatenate([r["prefill"][-1:], r["steps"]], 0)
@@ -151,7 +187,8 @@ def main():
         path = os.path.join(ROOT, "tests", "golden", "ref_model_%s.npz" % name)
         np.savez_compressed(path, shape=json.dumps(shape), seed=seed, std=std, shared_classifier=shared, ctx=ctx, prompt=prompt,
                             tokens=r["tokens"], prefill_logits=r["prefill"].astype(np.float16),
-                            step_logits=r["steps"].astype(np.float16), top2_gap=gap, excluded_ids=np.array([0], np.int32))
+                            step_logits=r["steps"].astype(np.float16), top2_gap=gap, excluded_ids=np.array([0], np.int32),
+                            fmt=fmt, qk_order=qk_order)
         print("%s: %d distinct greedy ids in %d steps, min top-2 gap %.4f, %d KB" % (
             name, len(set(r["tokens"].tolist())), steps, gap.min(), os.path.getsize(path) // 1024))
 

@@ -34,7 +34,20 @@ def load(name):
         fxt[k] = int(fxt[k])
     fxt["std"] = float(fxt["std"])
     fxt["shared_classifier"] = bool(fxt["shared_classifier"])
+    fxt["fmt"] = str(fxt.get("fmt", "llama2.c"))          # "safetensors": HF names under "model.", config.json hyper-parameters
+    fxt["qk_order"] = int(fxt.get("qk_order", 0))        # ModelSpec qk_column_order the reference was run with
     return fxt
+
+
+def rope_order(fxt):
+    """The worker's RoPE pairing for the fixture's qk_column_order (unary_tensor_opr.h:661-735: 2 = (c, c + dims/2))."""
+    return 2 if fxt["qk_order"] == 2 else 1
+
+
+def write_model_dir(d, fxt, **kw):
+    """The model directory of the fixture in ITS checkpoint format, for the HIP engine (tests/engine_fixtures.write_model_dir)."""
+    return fx.write_model_dir(d, fmt=fxt["fmt"], ctx=fxt["ctx"], s=fxt["shape"], seed=fxt["seed"], std=fxt["std"],
+                              shared_classifier=fxt["shared_classifier"], qk_order=fxt["qk_order"], **kw)
 
 
 def weights(fxt):

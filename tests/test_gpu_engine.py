@@ -221,13 +221,16 @@ def _build_custom(shape, wd, kvd, max_ctx, cfg, with_bias=False, std=0.06):
 FALCON40_LIKE = dict(norm_kind=1, act_kind=1, is_glu=0, share_input=1, rope_order=2)      # two norms on the layer input
 BLOOM_LIKE = dict(norm_kind=1, act_kind=1, is_glu=0, rope_order=0, use_alibi=1)             # sequential, std norm, ALiBi
 RMS_PARALLEL = dict(parallel_attn=1)                                                       # llama-style weights, parallel wiring
-GEMMA_LIKE = dict(attn_norm_base=1.0, ffn_norm_base=1.0, out_norm_base=1.0, act_kind=1)     # RMS weight = 1 + w, GELU-gated
-MINICPM_LIKE = dict(attn_out_scale=0.25, ffn_out_scale=0.25, out_scale=0.111111)            # TensorOpr::Scale on the outputs
+# RMS weight = 1 + w, GELU-gated, embeddings * sqrt(dim) (has_embedding_linear_norm: LinearNorm, inference_worker.cc:447-451)
+GEMMA_LIKE = dict(attn_norm_base=1.0, ffn_norm_base=1.0, out_norm_base=1.0, act_kind=1, embd_scale=-1.0)
+# TensorOpr::Scale on the outputs + embedding_linear_scale 12 (data/models/minicpm_2b_dpo_bf16/model_spec.json)
+MINICPM_LIKE = dict(attn_out_scale=0.25, ffn_out_scale=0.25, out_scale=0.111111, embd_scale=12.0)
 
 
 @pytest.mark.parametrize("name,cfg,bias", [("falcon_like", FALCON_LIKE, True), ("falcon40_like", FALCON40_LIKE, False),
                                             ("bloom_like", BLOOM_LIKE, True), ("rms_parallel", RMS_PARALLEL, False),
                                             ("gemma_like", GEMMA_LIKE, False), ("minicpm_like", MINICPM_LIKE, False),
+                                            ("minicpm_parallel", dict(MINICPM_LIKE, parallel_attn=1), True),
                                             ("llama_bias_q8kv", dict(), True)])
 def test_other_wirings_fused_and_op_path(name, cfg, bias):
     """Std-norm / GELU / non-gated FFN / parallel attention / shared input / ALiBi / bias models: the op-by-op path
@@ -236,7 +239,7 @@ def test_other_wirings_fused_and_op_path(name, cfg, bias):
     kvd = dt.Q8_B32T2 if "q8kv" in name else dt.F16
     wk, om, s = _build_custom("test_gqa", dt.Q4_B32T1A, kvd, 32, cfg, with_bias=bias)
     ok, why = wk.fused_supported()
-    assert ok or name == "minicpm_like", why          # output scales run op-by-op (decode falls back by itself)
+    assert ok, why          # output scales (MiniCPM) are folded into the Wo / W2 epilogues like the residuals
     prompt = np.array([7, 99, 512, 3, 41], np.int32)
     lg = torch.empty((len(prompt), s["vocab"]), dtype=torch.float16, device="cuda")
     tok = wk.forward(prompt, 0, lg)

@@ -61,6 +61,43 @@ def test_serving_loop_matches_oracle(tmp_path, fmt, wd_name, wd, kv_name, kvd, q
     eng.close()
 
 
+@pytest.mark.parametrize("net,cfg", [
+    # data/models/minicpm_2b_dpo_bf16/model_spec.json: scaled embeddings and output scales
+    (dict(has_embedding_linear_norm=True, embedding_linear_scale=12, attn_out_scale=0.25, ffn_out_scale=0.25, out_scale=0.111111),
+     dict(embd_scale=12.0, attn_out_scale=0.25, ffn_out_scale=0.25, out_scale=0.111111)),
+    # data/models/gemma_2b_it/model_spec.json: LinearNorm with the default scale sqrt(dim), RMS weights 1 + w
+    (dict(has_embedding_linear_norm=True, attn_pre_norm_base=1.0, ffn_pre_norm_base=1.0, output_norm_base=1.0),
+     dict(embd_scale=-1.0, attn_norm_base=1.0, ffn_norm_base=1.0, out_norm_base=1.0)),
+], ids=["minicpm_spec", "gemma_spec"])
+def test_linear_norm_and_output_scales_from_the_model_spec(tmp_path, net, cfg):
+    """has_embedding_linear_norm / embedding_linear_scale (ProcessPreLayer's LinearNorm, inference_worker.cc:447-451) and the
+    three output scales (:568-570, 842-843, 928-929) are read from network_structure and run inside the fused decode launches
+    (scale folded into the embedding gather and the Wo / W2 epilogues)."""
+    ini, w = fx.write_model_dir(str(tmp_path), fmt="llama2.c", wd="Q4", kvd="F16", net_extra=net, std=0.02 if "out_scale" not in net else 0.06)
+    eng = InferenceEngine.from_ini(ini)
+    host = fx.host_tensors(w, fx.SHAPE, dt.Q4_B32T1A)
+    om = oracle_model_from_host(host, fx.SHAPE, 64, dt.F16, rope_order=1, unk_id=0, **cfg)
+    prompt = np.random.default_rng(5).integers(3, 1000, 7).astype(np.int32)
+    qid = eng.add_query(prompt)
+    (q, tok), = eng.infer()
+    tok_o, lg_o = om.forward(prompt, 0, nthreads=4)
+    cos, mad = _close(eng.last_logits(qid), lg_o)
+    assert cos >= 0.9995 and mad <= 0.02 * float(np.abs(lg_o.astype(np.float32)).max()) + 0.02, (cos, mad)
+    cur, pos = tok, len(prompt)
+    for step in range(8):
+        t_or, l_or = om.forward(np.array([cur], np.int32), pos, nthreads=4)
+        assert eng.commit({qid: cur})
+        (q, tok), = eng.infer()
+        row = eng.last_logits(qid)[0]
+        cos, mad = _close(row, l_or[0])
+        assert cos >= 0.9995 and mad <= 0.02 * float(np.abs(l_or.astype(np.float32)).max()) + 0.02, (step, cos, mad)
+        top2 = np.sort(l_or[0].astype(np.float32))[-2:]
+        if top2[1] - top2[0] > 0.03:
+            assert tok == t_or, "step %d" % step
+        cur, pos = tok, pos + 1
+    eng.close()
+
+
 def test_generate_equals_step_loop_and_queries_are_independent(tmp_path):
     ini, _ = fx.write_model_dir(str(tmp_path), fmt="synthetic", wd="Q4", kvd="F16", ret="false", maxq=2)
     eng = InferenceEngine.from_ini(ini)

@@ -1,7 +1,9 @@
 """-m gpu: the HIP engine (C++ InferenceEngine facade -> C ABI -> fused decode kernels / prefill kernels) on the SAME
 llama2.c checkpoints the REFERENCE's CPU inference path was run on, against the reference's own outputs
 (tests/golden/ref_model_*.npz, generator tests/golden/gen_model_fixtures.py).  F16 weights and F16 KV cache: the unquantised
-model, so every difference is rounding (tests/ref_fixtures.py states the tolerance)."""
+model, so every difference is rounding (tests/ref_fixtures.py states the tolerance).  The st_* fixtures are SAFETENSORS
+directories the reference engine itself loaded (HF names, config.json, qk_column_order 2 and 0): they pin
+host/model_loader.cc's name map and the RoPE pairing it selects to the reference, not to the oracle."""
 import numpy as np
 import pytest
 
@@ -16,8 +18,7 @@ pytestmark = pytest.mark.gpu
 def test_hip_engine_matches_reference_cpu_path(tmp_path, name):
     fxt = rf.load(name)
     s = fxt["shape"]
-    ini, _ = fx.write_model_dir(str(tmp_path), fmt="llama2.c", wd="F16", kvd="F16", ctx=fxt["ctx"], s=s, seed=fxt["seed"],
-                                std=fxt["std"], shared_classifier=fxt["shared_classifier"])
+    ini, _ = rf.write_model_dir(str(tmp_path), fxt, wd="F16", kvd="F16")     # llama2.c or safetensors, as the reference read it
     eng = InferenceEngine.from_ini(ini)
     prompt = fxt["prompt"]
     qid = eng.add_query(prompt)
@@ -41,13 +42,12 @@ def test_hip_engine_matches_reference_cpu_path(tmp_path, name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["gqa", "gqa_deep"])
+@pytest.mark.parametrize("name", ["gqa", "gqa_deep", "st_gqa_hf"])
 def test_hip_engine_free_running_greedy_follows_reference(tmp_path, name):
     """Generate() (tokens fed back on the device, no host in the loop) reproduces the reference's greedy ids until the
     first step whose top-2 gap is a tie at this precision."""
     fxt = rf.load(name)
-    ini, _ = fx.write_model_dir(str(tmp_path), fmt="llama2.c", wd="F16", kvd="F16", ctx=fxt["ctx"], s=fxt["shape"], seed=fxt["seed"],
-                                std=fxt["std"], shared_classifier=fxt["shared_classifier"], ret="false")
+    ini, _ = rf.write_model_dir(str(tmp_path), fxt, wd="F16", kvd="F16", ret="false")
     eng = InferenceEngine.from_ini(ini)
     qid = eng.add_query(fxt["prompt"])
     (q, tok), = eng.infer()

@@ -18,7 +18,7 @@ def test_oracle_model_matches_reference_cpu_path(name):
     s = fxt["shape"]
     w = rf.weights(fxt)
     host = fx.host_tensors(w, s, dt.F16)
-    om = oracle_model_from_host(host, s, fxt["ctx"], dt.F16, rope_order=1)
+    om = oracle_model_from_host(host, s, fxt["ctx"], dt.F16, rope_order=rf.rope_order(fxt))
     prompt = fxt["prompt"]
     _, lg = om.forward(prompt, 0, nthreads=4)
     rows = []
