@@ -37,6 +37,7 @@ struct Tensor {
     int dtype = -1;
     void *data = nullptr;    // reference layout (AoS blocks / F16), engine-owned
     void *tiled = nullptr;   // row-local plane layout for the fused kernels (or null)
+    void *mo = nullptr;      // MFMA-operand-order copy for the small-batch rows GEMM (ifa_gemm_rows_mfma.h), built on first use
     size_t rows = 0, cols = 0;
     bool present() const { return data != nullptr; }
 };
@@ -98,7 +99,7 @@ struct ifa_model {
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr, 8};
-    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1;
+    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -168,10 +169,14 @@ static void free_tensor(Tensor &t)
 {
     if (t.data) (void)hipFree(t.data);
     if (t.tiled) (void)hipFree(t.tiled);
+    if (t.mo) (void)hipFree(t.mo);
     t = Tensor();
 }
 
 static bool is_q4(int dt) { return dt == Q4_B32T1A || dt == Q4_B32T1B; }
+static int ensure_mo(ifa_model *m);
+static const uint8_t *rows_w(const ifa_model *m, const Tensor &t);
+static int rows_mo(const ifa_model *m, const Tensor &t);
 static bool scale_on(float s) { return s < 0.9999f || s > 1.0001f; }     // the reference's test for "scale != 1"
 // same tiled layout and arithmetic (the A/B variants differ only in how the quantizer picked base/scale)
 static bool same_fmt(int a, int b) { return a == b || (is_q4(a) && is_q4(b)); }
@@ -1407,17 +1412,19 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     // weights dequantised once per workgroup and step into LDS; reference-layout rows), norms as their own launches.
     const bool pf_big = !tp && T > 128 && prefill_big_ok(m);
     const bool pf_fused = pf_big || (!tp && T >= 2 && T <= 16 && batch_fused_ok(m, T) && c.experts == 0);
+    if (pf_fused && !pf_big && (rc = ensure_mo(m))) return rc;
     for (int l = 0; l < c.layers && pf_fused; l++) {
         Layer &L = m->layers[l];
         const size_t F = c.ffn;
-        const bool norm_fused = !pf_big && T <= 8;
-        auto wp = [&](int id) { return (const uint8_t *)(pf_big ? L.t[id].data : L.t[id].tiled); };
+        const bool norm_fused = !pf_big && (T <= 8 || rows_mo(m, L.t[T_WQ]));
+        auto wp = [&](int id) { return pf_big ? (const uint8_t *)L.t[id].data : rows_w(m, L.t[id]); };
+        const int mo_flag = pf_big ? 0 : rows_mo(m, L.t[T_WQ]);
         auto lin = [&](const GmArgs &A, int id, int epi, int norm) {
             return pf_big ? gemm_big(L.t[id].dtype, A, epi, m->stream) : gemm_rows_mfma_launch(A, epi, norm, m->stream);
         };
         Tensor nob;
         GmArgs P;
-        auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = T; P.eps = c.eps; P.act_kind = c.act_kind; };
+        auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = T; P.eps = c.eps; P.act_kind = c.act_kind; P.mo = mo_flag; };
         clear();
         if (!norm_fused && (rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], pf_big ? L.t[T_ATTN_NORM_B] : nob, m->xn, c.attn_norm_base))) return rc;
         P.W[0] = wp(T_WQ); P.W[1] = wp(T_WK); P.W[2] = wp(T_WV);
@@ -1640,6 +1647,33 @@ static void *kv_ptr(ifa_model *m, size_t layer, int slot, bool is_v)
 }
 
 
+// The rows GEMM's own copy of the seven matrices of every dense layer (MO layout): built when the first batched step or short
+// prompt needs it (never inside a stream capture), dropped with the tensor.  4.3 GB more for Llama-2-7B Q4.
+static int ensure_mo(ifa_model *m)
+{
+    if (!m->opt_rows_mo) return IFA_OK;
+    const ifa_model_config &c = m->cfg;
+    bool built = false;
+    for (Layer &L : m->layers) {
+        const bool moe = c.experts > 0 && L.t[T_MOE_GATE].present();
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids) {
+            Tensor &t = L.t[id];
+            if (moe && (id == T_W1 || id == T_W3 || id == T_W2)) continue;
+            if (t.mo || !t.present() || !t.tiled || !is_q4(t.dtype) || t.cols % 128 != 0) continue;
+            IFA_HIP_CHECK(hipMalloc(&t.mo, gemm_rows_mo_bytes(t.rows, t.cols)));
+            int rc = gemm_rows_mo_build(t.tiled, t.rows, t.cols, t.mo, m->stream);
+            if (rc) return rc;
+            built = true;
+        }
+    }
+    if (built) IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return IFA_OK;
+}
+// weight pointer of a rows-GEMM launch: the MO copy when it exists (all sets of a launch alike: ensure_mo builds all or none)
+static const uint8_t *rows_w(const ifa_model *m, const Tensor &t) { return (const uint8_t *)(m->opt_rows_mo && t.mo ? t.mo : t.tiled); }
+static int rows_mo(const ifa_model *m, const Tensor &t) { return m->opt_rows_mo && t.mo ? 1 : 0; }
+
 // ---- the batched step as five launches per layer (the structure of the batch-1 step: ifa_gemm_rows_mfma.hip with the norm
 // prologue / GLU / residual epilogues, k_dec_attn<.., BATCH>): dense models with the sequential RMS wiring, every linear in
 // tiled Q4_B32T1, 2..16 queries.  Everything else takes the op-by-op rows below.
@@ -1699,10 +1733,10 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = n; P.eps = c.eps; P.act_kind = c.act_kind; };
     // 1. RmsNorm -> wq | wk | wv  (one virtual row space, one [n][q | k | v] output)
     clear();
-    P.W[0] = (const uint8_t *)L.t[T_WQ].tiled; P.W[1] = (const uint8_t *)L.t[T_WK].tiled; P.W[2] = (const uint8_t *)L.t[T_WV].tiled;
+    P.W[0] = rows_w(m, L.t[T_WQ]); P.W[1] = rows_w(m, L.t[T_WK]); P.W[2] = rows_w(m, L.t[T_WV]); P.mo = rows_mo(m, L.t[T_WQ]);
     P.rows[0] = (int)QD; P.rows[1] = (int)KVD; P.rows[2] = (int)KVD; P.nsets = 3; P.nblk = (int)(D / 32);
     // (9..16 queries: the activation rows are staged in chunks of 2048 columns, so the norm runs as its own launch)
-    const bool norm_fused = n <= 8;
+    const bool norm_fused = n <= 8 || rows_mo(m, L.t[T_WQ]);      // (MO layout: 16 rows x 4096 columns are one chunk too)
     Tensor nob;
     if (!norm_fused && (rc = norm_rows(m, x, n, L.t[T_ATTN_NORM], nob, m->xn, c.attn_norm_base))) return rc;
     P.X = norm_fused ? x : m->xn; P.ldx = (int)D;
@@ -1739,7 +1773,7 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     }
     // 3. wo (+ bias) + residual
     clear();
-    P.W[0] = (const uint8_t *)L.t[T_WO].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(QD / 32);
+    P.W[0] = rows_w(m, L.t[T_WO]); P.mo = rows_mo(m, L.t[T_WO]); P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(QD / 32);
     P.X = m->att; P.ldx = (int)QD; P.bias[0] = (const half_t *)L.t[T_WO_B].data;
     P.Y = m->a; P.ldy = (int)D; P.res = x; P.ldres = (int)D;
     if ((rc = gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream))) return rc;
@@ -1752,7 +1786,7 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     }
     // 4. RmsNorm -> w1, w3 -> act(w1 x) * (w3 x)
     clear();
-    P.W[0] = (const uint8_t *)L.t[T_W1].tiled; P.W1 = (const uint8_t *)L.t[T_W3].tiled; P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
+    P.W[0] = rows_w(m, L.t[T_W1]); P.W1 = rows_w(m, L.t[T_W3]); P.mo = rows_mo(m, L.t[T_W1]); P.rows[0] = (int)F; P.nsets = 1; P.nblk = (int)(D / 32);
     if (!norm_fused && (rc = norm_rows(m, m->a, n, L.t[T_FFN_NORM], nob, m->hn, c.ffn_norm_base))) return rc;
     P.X = norm_fused ? m->a : m->hn; P.ldx = (int)D;
     if (norm_fused) { P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.multi_base = c.ffn_norm_base; }
@@ -1761,7 +1795,7 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     if ((rc = gemm_rows_mfma_launch(P, GM_GLU, norm_fused ? 1 : 0, m->stream))) return rc;
     // 5. w2 (+ bias) + residual -> the next layer's input
     clear();
-    P.W[0] = (const uint8_t *)L.t[T_W2].tiled; P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(F / 32);
+    P.W[0] = rows_w(m, L.t[T_W2]); P.mo = rows_mo(m, L.t[T_W2]); P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(F / 32);
     P.X = m->t1; P.ldx = (int)F; P.bias[0] = (const half_t *)L.t[T_W2_B].data;
     P.Y = xnext; P.ldy = (int)D; P.res = m->a; P.ldres = (int)D;
     return gemm_rows_mfma_launch(P, GM_RESIDUAL, 0, m->stream);
@@ -1816,6 +1850,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     // (measured on Llama-2-7B Q4: the batched step is bound by the small-T GEMM kernels, ~6.7 ms with or without the
     //  graph, so replay is opt-in: set_option("batch_graph", 1))
     const bool fused = batch_fused_ok(m, n);          // five launches per layer: launch-bound without a graph, so it is replayed
+    if (fused) { int rcm = ensure_mo(m); if (rcm) return rcm; }
     // (MoE layers of the fused step route on the device -- no host round trip -- so they are captured too)
     const bool use_graph = (m->opt_batch_graph || fused) && m->opt_graph && (!has_moe || fused) && !logits_out && !tp;
     const int attn_ctx = use_graph ? c.max_ctx : max_ctx;     // LDS sizing of the attention kernel must not depend on the step
@@ -2223,7 +2258,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)

@@ -28,7 +28,17 @@ struct GmArgs {
     int act_kind;
     half_t *Yset[3];               // optional: set i written to its own matrix Yset[i][t * ldyset[i] + row] (q, k, v of a prompt)
     int ldyset[3];
+    int mo;                        // W[] / W1 are MO-layout copies (below) instead of the tiled layout
+    long long *trace;              // optional [workgroups][16] wall-clock stamps (tuning: IFA_ROWS_TRACE=1 prints a timeline per launch)
 };
+
+// MO layout ("MFMA operand order") of a Q4_B32T1A matrix [rows][cols], cols % 128 == 0: per tile of 16 rows
+//   nsup = cols / 128 supersteps of 1024 bytes: lane l = 16 g + r of a wave owns bytes 16 l .. 16 l + 15 = the 16 code bytes of
+//   block 4 S + g of row 16 tile + r (exactly its A operands of the superstep's four MFMAs), then
+//   ceil(nsup / 4) quads of 1024 bytes: lane l owns the (base, scale) words of its blocks in supersteps 4 Q .. 4 Q + 3.
+// Rows past the end and the pad of the last quad are zero.  Same size as the tiled copy (+ the pad).
+size_t gemm_rows_mo_bytes(size_t rows, size_t cols);
+int gemm_rows_mo_build(const void *tiled, size_t rows, size_t cols, void *mo, hipStream_t s);
 
 // rows of 16 per set when nsets > 1, cols % 128 == 0, 2 <= T <= 8; norm == 1 needs cols <= 4096
 bool gemm_rows_mfma_fused_ok(const GmArgs &P, int epi, int norm);

@@ -452,6 +452,53 @@ def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, shape, n
     wk.close()
 
 
+@pytest.mark.parametrize("n", [2, 7, 8, 13, 16])
+@pytest.mark.parametrize("shape", ["test_mha", "test_gqa"])
+def test_rows_gemm_operand_order_copy_is_bit_identical_to_the_tiled_path(shape, n):
+    """The MO ("MFMA operand order") copy of the weights feeds the same operands to the same MFMAs as the tiled path's LDS
+    turn (ifa_gemm_rows_mfma.hip).  Up to 8 rows both layouts give a wave the same blocks of K: prompts of 3..8 tokens and the
+    fused batched step of up to 8 queries must be bit-identical with rows_mo 1 / 0, eager and as a graph replay.  For 9..16
+    rows the tiled path walks 2048-column chunks (its LDS also holds the waves' patches) while the MO path stages one
+    4096-column chunk: same products, another fp32 summation order -- compared within a tolerance."""
+    wk, _, s = synth.build(shape, dt.Q4_B32T1A, dt.F16, max_ctx=48, quant_threshold=0, std=0.06)
+    V = s["vocab"]
+    wk.kv_slots(2 * n)
+    rng = np.random.default_rng(90 + n)
+    prompts = [rng.integers(3, V, 3 + (i * 5) % 6).astype(np.int32) for i in range(n)]
+    long_prompt = rng.integers(3, V, 13).astype(np.int32)
+    out = {}
+    for mo in (1, 0):
+        wk.set_option("rows_mo", mo)
+        cur, pos = [], []
+        for i, pr in enumerate(prompts):
+            wk.select_kv(mo * n + i)
+            lgp = torch.empty((len(pr), V), dtype=torch.float16, device="cuda")
+            cur.append(wk.forward(pr, 0, lgp)); pos.append(len(pr))
+            out[(mo, "prompt", i)] = g.host(lgp).copy()
+        lg = torch.empty((n, V), dtype=torch.float16, device="cuda")
+        for step in range(3):
+            slots = list(range(mo * n, mo * n + n))
+            t_e = wk.decode_batch(cur, pos, slots, lg)
+            out[(mo, "step", step)] = g.host(lg).copy()
+            t_g = wk.decode_batch(cur, pos, slots)
+            assert [int(t) for t in t_e] == [int(t) for t in t_g]
+            out[(mo, "tok", step)] = [int(t) for t in t_e]
+            cur = [int(t) for t in t_e]; pos = [p + 1 for p in pos]
+        wk.select_kv(mo * n)
+        lgl = torch.empty((len(long_prompt), V), dtype=torch.float16, device="cuda")
+        wk.forward(long_prompt, 0, lgl)
+        out[(mo, "long", 0)] = g.host(lgl).copy()
+    for key in [k for k in out if k[0] == 1]:
+        a, b = np.asarray(out[key]), np.asarray(out[(0,) + key[1:]])
+        if key[1] == "long" or (key[1] == "step" and n > 8):
+            a32, b32 = a.astype(np.float32), b.astype(np.float32)
+            cos = float((a32 * b32).sum() / (np.linalg.norm(a32) * np.linalg.norm(b32)))
+            assert cos >= 0.99999 and np.abs(a32 - b32).max() <= 0.01, (key, cos, np.abs(a32 - b32).max())
+        elif not (key[1] == "tok" and n > 8):
+            assert np.array_equal(a, b), key
+    wk.close()
+
+
 @pytest.mark.parametrize("T", [2, 5, 8, 11, 16])
 @pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["kvf16", "kvq8"])
 def test_fused_short_prompt_layer_matches_op_by_op_layer(kvd, T):
