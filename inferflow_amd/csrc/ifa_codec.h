@@ -21,6 +21,15 @@ struct RawBlock {
 #pragma unroll
         for (int i = 0; i < BYTES / 2; i++) w[i] = q[i];
     }
+    // the same from a pointer known to be DEVICE memory (global loads even when the pointer's origin is opaque to the compiler:
+    // FLAT loads also count on lgkmcnt, so LDS waits would wait for them)
+    __device__ __forceinline__ void load_global(const uint8_t *p)
+    {
+        typedef const __attribute__((address_space(1))) uint16_t gu16;
+        gu16 *q = (gu16 *)p;
+#pragma unroll
+        for (int i = 0; i < BYTES / 2; i++) w[i] = q[i];
+    }
     __device__ __forceinline__ void store(uint8_t *p) const
     {
         uint16_t *q = reinterpret_cast<uint16_t *>(p);

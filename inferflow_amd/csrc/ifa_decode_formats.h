@@ -24,7 +24,14 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct XLds;   // ifa_decode_kernels.h
 
 template <typename T>
-__device__ __forceinline__ T nt_load(const void *p) { return __builtin_nontemporal_load(reinterpret_cast<const T *>(p)); }
+__device__ __forceinline__ T nt_load(const void *p)
+{
+    // weights live in device memory: say so.  A pointer that reached the kernel through memory (the MoE expert table) or an
+    // integer would otherwise be loaded from with FLAT instructions, which count on lgkmcnt too -- every LDS wait then also waits
+    // for the weight requests in flight (ifa_gemm_rows_mfma_body.h, rows-trace)
+    typedef const __attribute__((address_space(1))) T gT;
+    return __builtin_nontemporal_load((gT *)p);
+}
 
 // Where a weight row's bytes come from: HBM (non-temporal requests, the five-launch kernels) or the LDS ring the
 // persistent layer kernel's loader wave fills (ifa_decode_persist.h; offsets wrap at the ring size).  The WRow*::load_src

@@ -336,8 +336,8 @@ struct WRowQ4 {
         for (int j = 0; j < NJ; j++) {
             const int blk = min(blk0 + lane + 64 * j, nblk - 1);
 #if IFA_NT_WEIGHTS
-            c[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wrow + (size_t)blk * 16));
-            sb[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(wrow + (size_t)nblk * 16 + (size_t)blk * 4));
+            c[j] = nt_load<u32x4>(wrow + (size_t)blk * 16);              // (global address space stated: see nt_load)
+            sb[j] = nt_load<uint32_t>(wrow + (size_t)nblk * 16 + (size_t)blk * 4);
 #else
             c[j] = *reinterpret_cast<const u32x4 *>(wrow + (size_t)blk * 16);
             sb[j] = *reinterpret_cast<const uint32_t *>(wrow + (size_t)nblk * 16 + (size_t)blk * 4);
@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_f16(const DecLmHeadP
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
                 const int c = min(lane + 64 * j, chunks - 1);
-                dst[rr][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(P.W + (size_t)row * P.cols) + c);
+                dst[rr][j] = nt_load<u32x4>(reinterpret_cast<const u32x4 *>(P.W + (size_t)row * P.cols) + c);
             }
         }
     };
@@ -924,6 +924,10 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         pkc = br.kc; pvc = br.vc; pos_b = br.n_ctx - 1;
         pq += (size_t)blockIdx.y * P.q_stride;
     }
+    // The cache rows are read through pointers whose address space is STATED (IFA_GP): in the batched step they come from the
+    // table in memory, and the FLAT loads the compiler emits for a pointer of unknown origin also count on lgkmcnt -- every LDS
+    // wait of the score / softmax phases then waited for the K / V requests in flight
+#define IFA_GP(T, p) ((const __attribute__((address_space(1))) T *)(p))
     uint8_t *const kcw = BATCH ? const_cast<uint8_t *>(pkc) : P.kcache;      // the cache rows this workgroup may write
     uint8_t *const vcw = BATCH ? const_cast<uint8_t *>(pvc) : P.vcache;
     const float *const rope_tab = BATCH ? P.rope_tab + (size_t)blockIdx.y * HD : P.rope_tab;
@@ -960,20 +964,20 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
             if constexpr (KALIGN == 8) {
 #pragma unroll
                 for (int i = 0; i < KBYTES / 8; i++) {
-                    const u32x2 t = reinterpret_cast<const u32x2 *>(rowp)[i];
+                    const u32x2 t = IFA_GP(u32x2, rowp)[i];
                     kq32[2 * i] = t[0]; kq32[2 * i + 1] = t[1];
                 }
             } else if constexpr (KALIGN == 4) {
 #pragma unroll
-                for (int i = 0; i < KBYTES / 4; i++) kq32[i] = reinterpret_cast<const uint32_t *>(rowp)[i];
+                for (int i = 0; i < KBYTES / 4; i++) kq32[i] = IFA_GP(uint32_t, rowp)[i];
             } else {
 #pragma unroll
-                for (int i = 0; i < KBYTES / 2; i++) kq16[i] = reinterpret_cast<const uint16_t *>(rowp)[i];
+                for (int i = 0; i < KBYTES / 2; i++) kq16[i] = IFA_GP(uint16_t, rowp)[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < HD / 8; i++) {
-                const u32x4 t = reinterpret_cast<const u32x4 *>(rowp)[i];
+                const u32x4 t = IFA_GP(u32x4, rowp)[i];
                 kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
             }
         }
@@ -998,9 +1002,9 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     for (int i = 0; i < VPRE; i++) {
         const int j = min(sp + NSPLIT * i, DEC_ATTN_MIN_ROWS - 1);
         if constexpr (!Q8) {
-            vreg[i] = reinterpret_cast<const u32x4 *>(pvc + (size_t)j * row_bytes + head_off)[dg];
+            vreg[i] = IFA_GP(u32x4, pvc + (size_t)j * row_bytes + head_off)[dg];
         } else {
-            const uint16_t *blk = reinterpret_cast<const uint16_t *>(pvc + (size_t)j * row_bytes + vq_off);
+            const auto *blk = IFA_GP(uint16_t, pvc + (size_t)j * row_bytes + vq_off);
             vq[i][0] = blk[0];
 #pragma unroll
             for (int e = 0; e < 4; e++) vq[i][1 + e] = blk[1 + (dg % 4) * 4 + e];
@@ -1185,8 +1189,8 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         o[6] = __builtin_fmaf(pj, (float)v67[0], o[6]); o[7] = __builtin_fmaf(pj, (float)v67[1], o[7]);
     };
     auto acc_q8 = [&](float pj, int j) {
-        const uint16_t *blk = reinterpret_cast<const uint16_t *>(pvc + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34);
-        const uint16_t *cp = blk + 1 + (dg % 4) * 4;
+        const auto *blk = IFA_GP(uint16_t, pvc + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34);
+        const auto *cp = blk + 1 + (dg % 4) * 4;
         acc_q8w(pj, blk[0], cp[0], cp[1], cp[2], cp[3]);
     };
 #pragma unroll
@@ -1203,7 +1207,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         const float pj = h2f(S[j]);
         if (j == pos) acc_new(pj);
         else if constexpr (Q8) acc_q8(pj, j);
-        else acc_v(pj, reinterpret_cast<const u32x4 *>(pvc + (size_t)j * row_bytes + head_off)[dg]);
+        else acc_v(pj, IFA_GP(u32x4, pvc + (size_t)j * row_bytes + head_off)[dg]);
     }
     if (vact) {
 #pragma unroll

@@ -1021,12 +1021,12 @@ static int ensure_scratch(ifa_model *m, int T)
         || (rc = re(m->logits, (size_t)T * c.vocab)))
         return rc;
     if (!m->dqkv) IFA_HIP_CHECK(hipMalloc((void **)&m->dqkv, (QD + 2 * KVD) * sizeof(half_t)));
-    if (T <= 16 && (size_t)T > m->bqkv_rows) {
+    if (T <= 32 && (size_t)T > m->bqkv_rows) {
         if (m->bqkv) IFA_HIP_CHECK(hipFree(m->bqkv));
         if (m->brope) IFA_HIP_CHECK(hipFree(m->brope));
-        IFA_HIP_CHECK(hipMalloc((void **)&m->bqkv, 16 * (QD + 2 * KVD) * sizeof(half_t)));
-        IFA_HIP_CHECK(hipMalloc((void **)&m->brope, 16 * (size_t)c.head_dim * sizeof(float)));
-        m->bqkv_rows = 16;
+        IFA_HIP_CHECK(hipMalloc((void **)&m->bqkv, 32 * (QD + 2 * KVD) * sizeof(half_t)));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->brope, 32 * (size_t)c.head_dim * sizeof(float)));
+        m->bqkv_rows = 32;
     }
     if (c.experts > 0) {
         const size_t cap = (size_t)T * (size_t)std::max(1, c.moe_top_k);
@@ -1411,12 +1411,12 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     // Prompts above 128 tokens take the same four launches per layer from the large-tile GEMM (ifa_gemm.hip, k_gemm_big: the
     // weights dequantised once per workgroup and step into LDS; reference-layout rows), norms as their own launches.
     const bool pf_big = !tp && T > 128 && prefill_big_ok(m);
-    const bool pf_fused = pf_big || (!tp && T >= 2 && T <= 16 && batch_fused_ok(m, T) && c.experts == 0);
+    const bool pf_fused = pf_big || (!tp && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
     if (pf_fused && !pf_big && (rc = ensure_mo(m))) return rc;
     for (int l = 0; l < c.layers && pf_fused; l++) {
         Layer &L = m->layers[l];
         const size_t F = c.ffn;
-        const bool norm_fused = !pf_big && (T <= 8 || rows_mo(m, L.t[T_WQ]));
+        const bool norm_fused = !pf_big && (T <= 8 || rows_mo(m, L.t[T_WQ])) && T <= 16;
         auto wp = [&](int id) { return pf_big ? (const uint8_t *)L.t[id].data : rows_w(m, L.t[id]); };
         const int mo_flag = pf_big ? 0 : rows_mo(m, L.t[T_WQ]);
         auto lin = [&](const GmArgs &A, int id, int epi, int norm) {
@@ -1680,7 +1680,7 @@ static int rows_mo(const ifa_model *m, const Tensor &t) { return m->opt_rows_mo 
 static bool batch_fused_ok(const ifa_model *m, int n)
 {
     const ifa_model_config &c = m->cfg;
-    if (!m->opt_batch_fused || !m->opt_gemm_rows || !gemm_rows_use_mfma() || n < 2 || n > 16 || m->topo) return false;
+    if (!m->opt_batch_fused || !m->opt_gemm_rows || !gemm_rows_use_mfma() || n < 2 || n > (m->opt_rows_mo ? 32 : 16) || m->topo) return false;      // (17..32 rows: MO copies only)
     if (c.norm_kind != 0 || c.parallel_attn || c.share_input) return false;
     if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) return false;
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
@@ -1736,7 +1736,7 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     P.W[0] = rows_w(m, L.t[T_WQ]); P.W[1] = rows_w(m, L.t[T_WK]); P.W[2] = rows_w(m, L.t[T_WV]); P.mo = rows_mo(m, L.t[T_WQ]);
     P.rows[0] = (int)QD; P.rows[1] = (int)KVD; P.rows[2] = (int)KVD; P.nsets = 3; P.nblk = (int)(D / 32);
     // (9..16 queries: the activation rows are staged in chunks of 2048 columns, so the norm runs as its own launch)
-    const bool norm_fused = n <= 8 || rows_mo(m, L.t[T_WQ]);      // (MO layout: 16 rows x 4096 columns are one chunk too)
+    const bool norm_fused = (n <= 8 || rows_mo(m, L.t[T_WQ])) && n <= 16;      // (MO layout: 16 rows x 4096 columns are one chunk too; 17..32 rows: chunked)
     Tensor nob;
     if (!norm_fused && (rc = norm_rows(m, x, n, L.t[T_ATTN_NORM], nob, m->xn, c.attn_norm_base))) return rc;
     P.X = norm_fused ? x : m->xn; P.ldx = (int)D;
@@ -2384,12 +2384,13 @@ int ifa_model_decode_batch(ifa_model *m, int n, const int *tokens_host, const in
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     // more queries than the fused five-launch step takes (16): balanced chunks of <= 16, each its own step (the queries are
     // independent; 32 queries op-by-op took 6.7 ms against 2 x 3.1 ms for two fused steps)
-    if (n > 16 && batch_fused_ok(m, 16)) {
+    const int fused_max = batch_fused_ok(m, 32) ? 32 : 16;
+    if (n > fused_max && batch_fused_ok(m, 16)) {
         for (int c0 = 0; c0 < n; c0++) if (kv_slots_host[c0] < 0) return ifa_fail(IFA_ERR_ARG, "decode_batch: KV slot %d", kv_slots_host[c0]);
         for (int a = 0; a < n; a++)
             for (int b = 0; b < a; b++)
                 if (kv_slots_host[a] == kv_slots_host[b]) return ifa_fail(IFA_ERR_ARG, "decode_batch: KV slot %d used twice", kv_slots_host[a]);
-        const int k = (n + 15) / 16, per = (n + k - 1) / k;
+        const int k = (n + fused_max - 1) / fused_max, per = (n + k - 1) / k;
         for (int c0 = 0; c0 < n; c0 += per) {
             const int nc = std::min(per, n - c0);
             int rc = forward_batch(m, nc, tokens_host + c0, positions_host + c0, kv_slots_host + c0, next_tokens_host ? next_tokens_host + c0 : nullptr,

@@ -65,7 +65,7 @@ __device__ __forceinline__ void load_block_f16(const uint8_t *__restrict__ W, si
     } else {
         constexpr int BB = block_bytes(DT);
         RawBlock<BB> blk;
-        blk.load(W + (row * (size_t)nblk + (size_t)b) * BB);
+        blk.load_global(W + (row * (size_t)nblk + (size_t)b) * BB);
         int q[CAP]; float scale, base;
         decode_block<DT>(blk, q, scale, base);
 #pragma unroll
@@ -84,15 +84,19 @@ struct WRaw {
     RawBlock<(DT == F16 || Q4FAST) ? 2 : BB> blk;
     __device__ __forceinline__ void load(const uint8_t *__restrict__ W, size_t row, int nblk, int b)
     {
+        // (weights are device memory: global loads whatever the pointer's origin -- the MoE expert table hands it over through
+        //  memory, and FLAT loads would count on lgkmcnt next to the LDS traffic of the step loop)
         const uint8_t *p = W + (row * (size_t)nblk + (size_t)b) * BB;
+        typedef const __attribute__((address_space(1))) u32x4 gu4;
+        typedef const __attribute__((address_space(1))) uint32_t gu1;
         if constexpr (DT == F16) {
 #pragma unroll
-            for (int i = 0; i < CAP / 8; i++) f16v[i] = reinterpret_cast<const u32x4 *>(p)[i];
+            for (int i = 0; i < CAP / 8; i++) f16v[i] = ((gu4 *)p)[i];
         } else if constexpr (Q4FAST) {
 #pragma unroll
-            for (int i = 0; i < 5; i++) q4[i] = reinterpret_cast<const uint32_t *>(p)[i];
+            for (int i = 0; i < 5; i++) q4[i] = ((gu1 *)p)[i];
         } else {
-            blk.load(p);
+            blk.load_global(p);
         }
     }
     // materialise the raw registers here (an empty asm the compiler cannot move a use across)

@@ -138,7 +138,7 @@ static int gm_launch1(int wgs, size_t smem, const GmArgs &P, int epi, int norm, 
 
 bool gemm_rows_mfma_fused_ok(const GmArgs &P, int epi, int norm)
 {
-    if (P.T < 2 || P.T > 16 || P.nblk <= 0 || P.nblk % 4 != 0 || P.nsets < 1 || P.nsets > 3) return false;
+    if (P.T < 2 || P.T > (P.mo ? 32 : 16) || P.nblk <= 0 || P.nblk % 4 != 0 || P.nsets < 1 || P.nsets > 3) return false;      // (17..32 rows: MO layout only)
     if (norm == 1 && (P.nblk * 32 > GmGeo<32>::CHUNK_COLS || P.T > (P.mo ? 16 : 8))) return false;      // the norm prologue: whole rows in one chunk (tiled layout: <= 8 rows)
     if (epi == GM_GLU && (P.nsets != 1 || !P.W1)) return false;
     for (int i = 0; i < P.nsets; i++) if (P.rows[i] <= 0 || (P.nsets > 1 && P.rows[i] % 16 != 0)) return false;

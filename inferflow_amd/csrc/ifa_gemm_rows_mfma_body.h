@@ -84,10 +84,14 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     // product keeps the plain kernel's registers and prefetch depth (MAXT counts both; the epilogue pairs the accumulators)
     constexpr bool GLU = EPI == GM_GLU;
     static_assert(!GLU || MAXT % 2 == 0, "GM_GLU: tiles per workgroup come in pairs");
-    using G = GmGeo<MO ? 32 : gm_cs(TX)>;            // MO: no patches, so 16 rows x 4096 columns fit too (131 KB)
+    // MO: no patches, so 16 rows x 4096 columns fit too (131 KB); 17..32 rows (MO only): TWO 16-query column tiles share every
+    // dequantised A operand (NT = 2), staged in 2048-column chunks (32 rows x 4 KB)
+    constexpr int NT = TX > 16 ? 2 : 1;
+    static_assert(NT == 1 || (MO && NORM == 0 && CH == 0), "17..32 rows: MO layout, chunked rows, norm as its own launch");
+    using G = GmGeo<(MO && TX <= 16) ? 32 : gm_cs(TX)>;
     using GmGrp = GmGrpT<G::NI>;
     static_assert(NORM == 0 || G::CHUNK_SUP == 32, "the norm prologue needs the whole row in one chunk");
-    constexpr int PD = 3;                             // groups in flight per wave
+    constexpr int PD = (MO && G::NJ == 2) ? 5 : 3;    // groups in flight per wave (a group is 5 KB, or 2.5 KB with 2048-column chunks)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -119,6 +123,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     const int nq4 = (nsup + 3) >> 2;                              // MO: header quads per tile
     const size_t mo_tile = (size_t)(nsup + nq4) * 1024;           // MO: bytes per 16-row tile
     const int trow = min(r, T - 1);                               // B operand: token of this lane (columns past T: duplicates, never stored)
+    const int trow1 = min(r + 16, T - 1);                         // second column tile (NT == 2)
 
     // a group = this wave's 16 rows x BPW blocks of (tile, chunk): blocks blk0 .. blk0 + BPW - 1, blk0 = 4 CS chunk + BPW wave
     // valid == false (past the last group): all lanes re-read the first bytes of the matrix -- one cache line, no branch
@@ -166,7 +171,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
         }
     };
     char *patch = smem + (size_t)TX * G::ROW_STRIDE + (size_t)wave * G::PATCH_BYTES;        // this wave's transposition patch
-    auto compute = [&](const GmGrp &q, int chunk, f4m &acc) {
+    auto compute = [&](const GmGrp &q, int chunk, f4m &acc, f4m &acc1) {
         if constexpr (!MO) {
         // ---- through the patch: rows of BPW code blocks and rows of BPW (base, scale) words, both at a stride that makes the
         // 16-row reads below conflict-free
@@ -192,6 +197,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             }
             const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale = hbits2f((uint16_t)(sbw >> 16));
             const char *xrow = smem + (size_t)trow * G::ROW_STRIDE + (size_t)((wave * G::BPW + 4 * j + g) * 32) * 2;
+            const char *xrow1 = smem + (size_t)trow1 * G::ROW_STRIDE + (size_t)((wave * G::BPW + 4 * j + g) * 32) * 2;
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
                 const uint32_t cw = cw4[s4];
@@ -208,13 +214,19 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
                 const h8m a = {w0[0], w0[1], w1[0], w1[1], w2[0], w2[1], w3[0], w3[1]};
                 const h8m b = *reinterpret_cast<const h8m *>(xrow + s4 * 16);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+                if constexpr (NT == 2) {
+                    const h8m b1 = *reinterpret_cast<const h8m *>(xrow1 + s4 * 16);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc1, 0, 0, 0);
+                }
             }
         }
     };
 
-    f4m acc[MAXT];
+    f4m acc[MAXT], acc1[NT == 2 ? MAXT : 1];
 #pragma unroll
     for (int i = 0; i < MAXT; i++) acc[i] = f4m{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < (NT == 2 ? MAXT : 1); i++) acc1[i] = f4m{0.0f, 0.0f, 0.0f, 0.0f};
     // PD groups of requests in flight per wave (a group = 4 supersteps = 5 KB per wave): one group ahead left every wave
     // waiting ~half of the time for HBM
     GmGrp buf[PD];
@@ -344,7 +356,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             // waves 0..3 ran ahead (all their groups done while waves 4..7 had finished two of eight: rows-trace), i.e. only half of
             // the CU's requests were cycling.  Alternate the priority per group so the pair takes turns.
             if (((qi + (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
-            compute(buf[0], chunk, acc[it]);
+            compute(buf[0], chunk, acc[it], acc1[NT == 2 ? it : 0]);
             if (trc && tid == 0 && qi == 0) trc[3] = wall_clock64();
 #pragma unroll
             for (int d = 0; d + 1 < PD; d++) buf[d] = buf[d + 1];
@@ -376,16 +388,18 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     if (trc && lane == 0) trc[8 + wave] = wall_clock64();
     __syncthreads();                                               // the activation image is free: partials take its place
     if (trc && tid == 0) trc[4] = wall_clock64();
-    float *part = reinterpret_cast<float *>(smem);                 // [MAXT][8 waves][256]
+    float *part = reinterpret_cast<float *>(smem);                 // [NT][MAXT][8 waves][256]
 #pragma unroll
-    for (int it = 0; it < MAXT; it++)
+    for (int it = 0; it < MAXT; it++) {
         *reinterpret_cast<f4m *>(part + ((size_t)(it * GM_WAVES + wave) * 64 + lane) * 4) = acc[it];
+        if constexpr (NT == 2) *reinterpret_cast<f4m *>(part + ((size_t)((MAXT + it) * GM_WAVES + wave) * 64 + lane) * 4) = acc1[it];
+    }
     __syncthreads();
     {
         // both halves of the workgroup: thread e = tid & 255 owns element e of the tiles (pairs) whose index parity is tid >> 8
         const int e = tid & 255, hsel = tid >> 8;
         const int l = e >> 2, i = e & 3;
-        const int m = (l >> 4) * 4 + i, n = l & 15;
+        const int m = (l >> 4) * 4 + i;
         auto total = [&](int it) {
             float sum = 0.0f;
 #pragma unroll
@@ -394,27 +408,31 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
         };
         constexpr int STEP = GLU ? 2 : 1;
 #pragma unroll
-        for (int it = 0; it < MAXT; it += STEP) {
-            if (((it / STEP) & 1) != hsel) continue;
-            const int vt = tile_of(it);
-            const GmTile tl = gm_locate(S, min(vt, ntiles - 1));
-            const int row = tl.row0 + m;
-            const float s0 = total(it);
-            float s1 = 0.0f;
-            if constexpr (GLU) s1 = total(it + 1);
-            if (vt < ntiles && row < tl.nrows && n < T) {
-                half_t y = f2h(s0);
-                if (tl.b0) y = f2h(h2f(y) + h2f(tl.b0[row]));
-                const size_t vrow = (size_t)tl.vrow0 + m;
-                if constexpr (EPI == GM_RESIDUAL) {
-                    y = f2h(h2f(P.res[(size_t)n * P.ldres + vrow]) + h2f(y));          // TensorOpr::Add (half add)
-                } else if constexpr (GLU) {
-                    half_t y3 = f2h(s1);
-                    if (P.bias1) y3 = f2h(h2f(y3) + h2f(P.bias1[row]));
-                    const half_t act = f2h(act_fn(h2f(y), P.act_kind));                // TensorOpr::Activation -> F16
-                    y = f2h(h2f(act) * h2f(y3));                                       // TensorOpr::Mul
+        for (int nt = 0; nt < NT; nt++) {
+            const int n = (l & 15) + 16 * nt;
+#pragma unroll
+            for (int it = 0; it < MAXT; it += STEP) {
+                if (((it / STEP) & 1) != hsel) continue;
+                const int vt = tile_of(it);
+                const GmTile tl = gm_locate(S, min(vt, ntiles - 1));
+                const int row = tl.row0 + m;
+                const float s0 = total(nt * MAXT + it);
+                float s1 = 0.0f;
+                if constexpr (GLU) s1 = total(nt * MAXT + it + 1);
+                if (vt < ntiles && row < tl.nrows && n < T) {
+                    half_t y = f2h(s0);
+                    if (tl.b0) y = f2h(h2f(y) + h2f(tl.b0[row]));
+                    const size_t vrow = (size_t)tl.vrow0 + m;
+                    if constexpr (EPI == GM_RESIDUAL) {
+                        y = f2h(h2f(P.res[(size_t)n * P.ldres + vrow]) + h2f(y));          // TensorOpr::Add (half add)
+                    } else if constexpr (GLU) {
+                        half_t y3 = f2h(s1);
+                        if (P.bias1) y3 = f2h(h2f(y3) + h2f(P.bias1[row]));
+                        const half_t act = f2h(act_fn(h2f(y), P.act_kind));                // TensorOpr::Activation -> F16
+                        y = f2h(h2f(act) * h2f(y3));                                       // TensorOpr::Mul
+                    }
+                    tl.y[(size_t)n * tl.ldy + row] = y;
                 }
-                tl.y[(size_t)n * tl.ldy + row] = y;
             }
         }
     }
@@ -431,7 +449,8 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma(const GmArgs P)
 static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : 16)); }
 static size_t gm_smem(int T, int maxt, int mo)
 {
-    const int tx = mo ? (T <= 8 ? 8 : 16) : gm_tx(T);
+    const int tx = mo ? (T <= 8 ? 8 : (T <= 16 ? 16 : 32)) : gm_tx(T);
+    if (mo && tx == 32) return std::max((size_t)32 * GmGeo<16>::ROW_STRIDE, (size_t)2 * maxt * GM_WAVES * 256 * 4);
     if (mo) return std::max((size_t)tx * GmGeo<32>::ROW_STRIDE + (size_t)16 * GM_WAVES * 4, (size_t)maxt * GM_WAVES * 256 * 4);
     const size_t row = tx > 8 ? GmGeo<16>::ROW_STRIDE : GmGeo<32>::ROW_STRIDE, patch = tx > 8 ? GmGeo<16>::PATCH_BYTES : GmGeo<32>::PATCH_BYTES;
     const size_t ximg = (size_t)tx * row + (size_t)GM_WAVES * patch + 8 * GM_WAVES * 4;      // + the norm's group sums

@@ -36,16 +36,27 @@ static int mo_launch2(int wgs, size_t smem, const GmArgs &P, int epi, int norm, 
     return ifa_fail(IFA_ERR_ARG, "rows GEMM (MO): no kernel for epilogue %d / norm %d / %s", epi, norm, one ? "one chunk" : "chunked");
 }
 
+// 17..32 rows: two column tiles per A operand, rows staged in 2048-column chunks (always the chunk loop, no norm prologue)
+template <int MT>
+static int mo_launch32(int wgs, size_t smem, const GmArgs &P, int epi, int norm, hipStream_t s)
+{
+    if (epi == GM_PLAIN && norm == 0) return mo_launch4<MT, 32, GM_PLAIN, 0, 0>(wgs, smem, P, s);
+    if (epi == GM_RESIDUAL && norm == 0) return mo_launch4<MT, 32, GM_RESIDUAL, 0, 0>(wgs, smem, P, s);
+    if constexpr (MT % 2 == 0) { if (epi == GM_GLU && norm == 0) return mo_launch4<MT, 32, GM_GLU, 0, 0>(wgs, smem, P, s); }
+    return ifa_fail(IFA_ERR_ARG, "rows GEMM (MO, 17..32 rows): no kernel for epilogue %d / norm %d", epi, norm);
+}
+
 template <int MT>
 static int mo_launch1(int wgs, size_t smem, const GmArgs &P, int epi, int norm, bool one, hipStream_t s)
 {
     if (P.T <= 8) return mo_launch2<MT, 8>(wgs, smem, P, epi, norm, one, s);
-    return mo_launch2<MT, 16>(wgs, smem, P, epi, norm, one, s);
+    if (P.T <= 16) return mo_launch2<MT, 16>(wgs, smem, P, epi, norm, one, s);
+    return mo_launch32<MT>(wgs, smem, P, epi, norm, s);
 }
 
 int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, hipStream_t s)
 {
-    const bool one = P.nblk * 32 <= GmGeo<32>::CHUNK_COLS;
+    const bool one = P.nblk * 32 <= GmGeo<32>::CHUNK_COLS && P.T <= 16;
     if (norm == 1 && !one) return ifa_fail(IFA_ERR_ARG, "rows GEMM (MO): the norm prologue needs the whole row in one chunk");
     const size_t smem = gm_smem(P.T, maxt, 1);
     switch (maxt) {

@@ -413,7 +413,7 @@ def test_dynamic_batching_rows_are_independent_queries(kvd):
     wk.close()
 
 
-@pytest.mark.parametrize("n", [2, 5, 8, 11, 16, 20])
+@pytest.mark.parametrize("n", [2, 5, 8, 11, 16, 20, 27, 32])
 @pytest.mark.parametrize("kvd,shape", [(dt.F16, "test_mha"), (dt.Q8_B32T2, "test_mha"), (dt.F16, "test_moe")], ids=["kvf16", "kvq8", "moe"])
 def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, shape, n):
     """The batched decode step as five launches per layer (norm prologue + wq|wk|wv, batched k_dec_attn, wo + residual,
@@ -452,7 +452,7 @@ def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, shape, n
     wk.close()
 
 
-@pytest.mark.parametrize("n", [2, 7, 8, 13, 16])
+@pytest.mark.parametrize("n", [2, 7, 8, 13, 16, 24])
 @pytest.mark.parametrize("shape", ["test_mha", "test_gqa"])
 def test_rows_gemm_operand_order_copy_is_bit_identical_to_the_tiled_path(shape, n):
     """The MO ("MFMA operand order") copy of the weights feeds the same operands to the same MFMAs as the tiled path's LDS
