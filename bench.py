@@ -130,6 +130,61 @@ class Watchdog:
                 os._exit(3)
 
 
+def loopback_line(args):
+    """R tensor-parallel ranks on device 0 through the product surface (.ini -> InferenceEngine -> MultiGpu -> loopback group)."""
+    import tempfile
+    import numpy as np
+    import torch
+    from inferflow_amd import synth
+    from inferflow_amd.engine import InferenceEngine
+    s = synth.SHAPES[args.shape]
+    R = args.loopback
+    d = tempfile.mkdtemp(prefix="ifa_loopback_")
+    spec = {"config_file": "", "model_files": [], "model_file_format": "synthetic", "tokenizer_file": "", "tokenization_algorithm": "bpe",
+            "generation_config": "", "synthetic_std": 0.02,
+            "hyper_params": {"vocab_size": s["vocab"], "embd_dims": s["dim"], "hidden_dim": s["ffn"], "decoder_layers": s["layers"],
+                             "decoder_heads": s["heads"], "decoder_kv_heads": s["kv_heads"]},
+            "network_structure": {"type": "transformer.llama", "normalization_function": "rms", "activation_function": "silu",
+                                  "position_embedding": "rope", "qk_column_order": 2, "tensor_name_prefix": "", "tensor_name_mapping": {}}}
+    json.dump(spec, open(os.path.join(d, "model_spec.json"), "w"))
+    ini = os.path.join(d, "engine.ini")
+    open(ini, "w").write("[transformer_engine]\nmodels = bench\ndevices = %s\ndecoder_cpu_layer_count = 0\ncpu_threads = 8\n"
+                         "max_concurrent_queries = 2\nreturn_output_tensors = false\n\n[model.bench]\nmodel_dir = ${config_dir}\n"
+                         "model_specification_file = model_spec.json\ndevice_weight_data_type = %s\ndevice_kv_cache_data_type = %s\n"
+                         "tensor_quant_threshold = 0\nmax_context_len = %d\nprompt_template = {bos}{query}\n" % (
+                             "&".join(["0"] * R), {"q4": "Q4", "q3h": "Q3H", "q8": "Q8"}.get(args.wdtype.lower(), "Q4"),
+                             {"f16": "F16", "q8": "Q8"}[args.kv_dtype.lower()], PROMPT_LEN + args.warmup + args.steps + 16))
+    sys.stdout.flush()
+    saved = os.dup(1); os.dup2(2, 1)
+    dog = Watchdog(0, 1, args); dog.out_fd = saved
+    dog.arm("loopback engine init", float(os.environ.get("IFA_BENCH_TIMEOUT_INIT", "420")))
+    eng = InferenceEngine.from_ini(ini)
+    qid = eng.add_query(np.random.default_rng(42).integers(3, s["vocab"], PROMPT_LEN).astype(np.int32))
+    (q, tok), = eng.infer()
+    eng.commit({qid: tok})
+    dog.arm("loopback steps", float(os.environ.get("IFA_BENCH_TIMEOUT_STEP", "180")))
+    if args.warmup > 0:
+        eng.generate(qid, args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen, _ = eng.generate(qid, args.steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dog.disarm()
+    ranks = eng.model_info("partition_ranks")
+    eng.close()
+    out = {"metric": "decode tokens/sec, %s batch=1 greedy (whole job)" % args.shape, "value": args.steps / wall, "unit": "tokens/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+           "config": {"workload": "%s decode through the .ini surface, %d tensor-parallel ranks on ONE device" % (args.shape, R),
+                      "parallelism": "tp%d loopback (one process, %d worker threads, in-process group instead of RCCL; partition_ranks = %d)" % (R, R, ranks),
+                      "collectives": "loopback group (csrc/ifa_comm.hip LocalGroup): same slicing, merges and step logic as the RCCL path"},
+           "note": "functional check of the N > 1 path on a one-GPU box: R ranks share the device, so this is not a scaling number",
+           "last_tokens": [int(t) for t in gen[-4:]]}
+    os.dup2(saved, 1)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +198,9 @@ def main():
     ap.add_argument("--prefill-lens", default="128,1024", help="extra prompt lengths whose prefill rate is reported (N=1 only)")
     ap.add_argument("--batch", type=int, default=8, help="also time dynamic-batching decode: B queries, one new token each per "
                     "step (N=1 only; reported as batch_decode, never as value; 0 = skip)")
+    ap.add_argument("--loopback", type=int, default=0, help="R > 1: run the tensor-parallel partition with R ranks on ONE device "
+                    "(the C++ InferenceEngine with devices = 0&0..., in-process loopback group instead of RCCL) and print its line; "
+                    "a functional check of the N > 1 step logic on a one-GPU box, not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     args = ap.parse_args()
@@ -151,6 +209,8 @@ def main():
     import torch
     import torch.distributed as dist
     from inferflow_amd import dtypes as dt, synth
+    if args.loopback > 1:
+        return loopback_line(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -256,13 +316,14 @@ def main():
     if world == 1 and hasattr(runner, "export_host_tensors") and not os.environ.get("IFA_FORCE_TP") and not is_moe:
         s = runner.shape
         ffn_rows, d = s["ffn"], s["dim"]
-        ffn13_bytes = (2 if s.get("is_glu", 1) else 1) * ffn_rows * dt.row_bytes(wd, d)
+        rb = dt.streamed_row_bytes                 # bytes the decode kernels stream per row (Q3H_B64T1: 36 per 64 weights, not the 32 of the AoS block)
+        ffn13_bytes = (2 if s.get("is_glu", 1) else 1) * ffn_rows * rb(wd, d)
         us = runner.worker.time_kernel(3, 320)
         per_kernel = {}
         names = ["qkv", "attn", "wo", "ffn13", "w2", "lm_head"]
-        kb = [(s["heads"] + 2 * s["kv_heads"]) * s["head_dim"] * dt.row_bytes(wd, d), None,
-              d * dt.row_bytes(wd, s["heads"] * s["head_dim"]), ffn13_bytes,
-              d * dt.row_bytes(wd, ffn_rows), s["vocab"] * d * 2]
+        kb = [(s["heads"] + 2 * s["kv_heads"]) * s["head_dim"] * rb(wd, d), None,
+              d * rb(wd, s["heads"] * s["head_dim"]), ffn13_bytes,
+              d * rb(wd, ffn_rows), s["vocab"] * d * 2]
         for i, nm in enumerate(names):
             u = runner.worker.time_kernel(i, 160)
             per_kernel[nm] = {"us": u, "GBps": (kb[i] / u / 1e3) if kb[i] else None}
@@ -272,10 +333,12 @@ def main():
         traffic, traffic_note = None, None
         try:
             from inferflow_amd.build import source_hash
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            import glob
+            pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]        # the newest round's
+            pmc = json.load(open(pmc_path))
             if pmc.get("source_hash") != source_hash():
-                traffic_note = "profiles/r02_pmc_traffic.json was taken with kernel sources %s, this build is %s: stale, not reported" % (
-                    pmc.get("source_hash"), source_hash())
+                traffic_note = "profiles/%s was taken with kernel sources %s, this build is %s: stale, not reported" % (
+                    os.path.basename(pmc_path), pmc.get("source_hash"), source_hash())
             elif wd == dt.Q4_B32T1A and args.shape == "llama2_7b":
                 import re                                                                     # <DT 13, NJ 2, RW any, EPI_GLU 2, NORM 1, ...>
                 traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()     # demangled or mangled name
@@ -287,6 +350,26 @@ def main():
                            "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
                            "bytes_per_launch": ffn13_bytes, "us_per_launch": us}
         out["kernels"] = per_kernel
+        # ---- the persistent layer kernel (csrc/ifa_decode_persist.h: one launch for all layers of a token, opt-in option
+        # "persist"): measured beside the five-launch step on the same model, never the headline value.  Same tokens required.
+        try:
+            wk = runner.worker
+            ps_n = min(32, steps)
+            ref_t, _ = wk.decode(tok, PROMPT_LEN + warmup, ps_n)
+            wk.set_option("persist", 1)
+            wk.decode(tok, PROMPT_LEN + warmup, 4)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ps_t, _ = wk.decode(tok, PROMPT_LEN + warmup, ps_n)
+            torch.cuda.synchronize()
+            ps_s = time.perf_counter() - t0
+            out["persistent_layer_kernel"] = {"tok_s": ps_n / ps_s, "us_per_layer": wk.time_kernel(6, 20) / s["layers"],
+                                              "tokens_equal_five_launch": bool(np.array_equal(ref_t, ps_t)),
+                                              "note": "opt-in (set_option persist=1); the five-launch step above is the default"}
+        except Exception as e:
+            out["persistent_layer_kernel"] = {"error": repr(e)[:200]}
+        finally:
+            runner.worker.set_option("persist", 0)
     # ---- prefill rate at longer prompts (16 / 128 / 1024-token prompts), outside the timed decode region
     if world == 1 and hasattr(runner, "worker") and not os.environ.get("IFA_FORCE_TP"):
         pf = {}
@@ -300,6 +383,7 @@ def main():
             torch.cuda.synchronize()
             pf[str(n)] = n / (time.perf_counter() - t0)
         out["prefill_tok_s_by_prompt_len"] = pf
+        out["prefill_tok_s"] = pf[str(max([PROMPT_LEN] + prefill_lens))]      # warm, the longest measured prompt (1024 tokens by default)
         flops_per_token = 2.0 * (w_bytes - runner.shape["vocab"] * runner.shape["dim"] * 2) / dt.row_bytes(wd, 32) * 32
         out["prefill_linear_TFLOPs_at_longest"] = pf[str(max([PROMPT_LEN] + prefill_lens))] * flops_per_token / 1e12
         longest = max([PROMPT_LEN] + prefill_lens)
