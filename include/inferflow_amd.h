@@ -249,7 +249,10 @@ int ifa_model_set_tensor_f16(ifa_model *m, int layer, int tensor_id, int expert,
 /* allocate KV caches (KVCache::Init, kv_cache.cc:278-319) and scratch */
 int ifa_model_finalize(ifa_model *m);
 int ifa_model_reset(ifa_model *m);
-/* options: "fused" (1), "graph" (1), "rpw_qkv|rpw_wo|rpw_ffn|rpw_w2|rpw_lm" (0 = auto) */
+/* options: "fused" (1), "graph" (1), "rpw_qkv|rpw_wo|rpw_ffn|rpw_w2|rpw_lm" (0 = auto), "batch_fused" (1), "rows_mo" (1: the batched
+ * step and short prompts stream MFMA-operand-order copies of the weights, built on first use), "persist" (0; 1 = the decode
+ * step of a dense single-worker model as ONE launch for all layers, csrc/ifa_decode_persist.h: bit-identical, slower than the
+ * five-launch step on MI355X, kept as comparator), "persist_timeout_us" (bounded waits of that launch), "attn_split_ctx" (512) */
 /* Independent KV caches inside one worker, one per concurrent query -- the reference keeps a LayerKVCache set
  * per query processor (QueryStateTable, src/transformer/query_state_table.h:19-85; KVCache::Init, kv_cache.cc:278-319).
  * ifa_model_kv_slots grows the number of caches to n_slots (slot 0 exists after finalize); ifa_model_select_kv
