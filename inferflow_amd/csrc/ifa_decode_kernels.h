@@ -991,7 +991,10 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     // 128 KB of K / V rows below these few bytes arrived 1.5 us later than they had to (phase stamps)
     const int dq = min(tid, HD - 1);
     const half_t q_in = pq[(size_t)h * HD + dq], k_in = pq[(size_t)(pheads + kvh) * HD + dq], v_in = pq[(size_t)(pheads + pkvh + kvh) * HD + dq];
-    load_k(tid);                       // (tid < DEC_ATTN_MIN_ROWS <= rows of the cache)
+    // (tid < DEC_ATTN_MIN_ROWS <= rows of the cache.)  Batched step: the position arrived with the cache pointers, so rows past
+    // the context are clamped to the last one (duplicate addresses: one cache line) -- unclamped, every (head, query) workgroup
+    // pulled 2 x 64 KB of cache rows whatever its context: 134 MB per layer at 32 queries, the whole cost of that launch
+    load_k(BATCH ? min(tid, pos_b) : tid);
     const int dg = tid % DG, sp = tid / DG;
     const bool vact = (256 % DG == 0) || sp < NSPLIT;   // this thread takes part in P.V
     constexpr int VPRE = 256 / NSPLIT;                  // prefetched V keys per thread: j = sp + NSPLIT*i (256 keys)
@@ -1000,7 +1003,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     const size_t vq_off = head_off + (size_t)(dg / 4) * 34;
 #pragma unroll
     for (int i = 0; i < VPRE; i++) {
-        const int j = min(sp + NSPLIT * i, DEC_ATTN_MIN_ROWS - 1);
+        const int j = min(sp + NSPLIT * i, BATCH ? pos_b : DEC_ATTN_MIN_ROWS - 1);
         if constexpr (!Q8) {
             vreg[i] = IFA_GP(u32x4, pvc + (size_t)j * row_bytes + head_off)[dg];
         } else {

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp; mkdir -p gpurun_out/r03
-IFA_BATCH_SIZES=32 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r03/prof_b32 -o b32 --output-format csv -- python tools/bench_batch.py > gpurun_out/r03/prof_b32.log 2>&1
-find gpurun_out/r03/prof_b32 -name "*kernel_trace*" -delete
+timeout 600 python -m pytest tests/test_gpu_engine.py tests/test_gpu_host_engine.py tests/test_gpu_comm.py -q -m gpu -k "batch or dynamic or operand" 2>&1 | grep -E "^E  |^FAILED|passed|failed" | cut -c1-200 | head
+IFA_BATCH_SIZES=2,8,16,32 timeout 300 python tools/bench_batch.py 2>/dev/null
