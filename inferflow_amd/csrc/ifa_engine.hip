@@ -174,6 +174,8 @@ static void free_tensor(Tensor &t)
 }
 
 static bool is_q4(int dt) { return dt == Q4_B32T1A || dt == Q4_B32T1B; }
+// formats the MO copy of the rows GEMM takes: 4-bit codes with value q * scale + base (the 64-weight ones only through MO)
+static bool rows_mo_fmt(int dt) { return is_q4(dt) || dt == Q4_B64T1 || dt == Q3H_B64T1; }
 static int ensure_mo(ifa_model *m);
 static const uint8_t *rows_w(const ifa_model *m, const Tensor &t);
 static int rows_mo(const ifa_model *m, const Tensor &t);
@@ -1660,9 +1662,9 @@ static int ensure_mo(ifa_model *m)
         for (int id : ids) {
             Tensor &t = L.t[id];
             if (moe && (id == T_W1 || id == T_W3 || id == T_W2)) continue;
-            if (t.mo || !t.present() || !t.tiled || !is_q4(t.dtype) || t.cols % 128 != 0) continue;
+            if (t.mo || !t.present() || !t.tiled || !rows_mo_fmt(t.dtype) || t.cols % 128 != 0) continue;
             IFA_HIP_CHECK(hipMalloc(&t.mo, gemm_rows_mo_bytes(t.rows, t.cols)));
-            int rc = gemm_rows_mo_build(t.tiled, t.rows, t.cols, t.mo, m->stream);
+            int rc = gemm_rows_mo_build(t.dtype, t.tiled, t.rows, t.cols, t.mo, m->stream);
             if (rc) return rc;
             built = true;
         }
@@ -1693,7 +1695,8 @@ static bool batch_fused_ok(const ifa_model *m, int n)
         const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
         for (int id : ids) {
             if (moe && (id == T_W1 || id == T_W3 || id == T_W2)) continue;
-            if (!L.t[id].present() || !L.t[id].tiled || !is_q4(L.t[id].dtype)) return false;
+            if (!L.t[id].present() || !L.t[id].tiled) return false;
+            if (!is_q4(L.t[id].dtype) && !(m->opt_rows_mo && rows_mo_fmt(L.t[id].dtype) && L.t[id].cols % 128 == 0)) return false;
         }
         if (moe && !moe_device_ok(m, L)) return false;
         if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present() || L.t[T_ATTN_NORM_B].present() || L.t[T_FFN_NORM_B].present()) return false;

@@ -32,13 +32,15 @@ struct GmArgs {
     long long *trace;              // optional [workgroups][16] wall-clock stamps (tuning: IFA_ROWS_TRACE=1 prints a timeline per launch)
 };
 
-// MO layout ("MFMA operand order") of a Q4_B32T1A matrix [rows][cols], cols % 128 == 0: per tile of 16 rows
+// MO layout ("MFMA operand order") of a matrix [rows][cols] of 4-bit codes with value q * scale + base, cols % 128 == 0: per tile of 16 rows
 //   nsup = cols / 128 supersteps of 1024 bytes: lane l = 16 g + r of a wave owns bytes 16 l .. 16 l + 15 = the 16 code bytes of
 //   block 4 S + g of row 16 tile + r (exactly its A operands of the superstep's four MFMAs), then
 //   ceil(nsup / 4) quads of 1024 bytes: lane l owns the (base, scale) words of its blocks in supersteps 4 Q .. 4 Q + 3.
 // Rows past the end and the pad of the last quad are zero.  Same size as the tiled copy (+ the pad).
 size_t gemm_rows_mo_bytes(size_t rows, size_t cols);
-int gemm_rows_mo_build(const void *tiled, size_t rows, size_t cols, void *mo, hipStream_t s);
+// dtype: Q4_B32T1A / B, or the 64-weight nibble formats Q4_B64T1 / Q3H_B64T1 (one (base, scale) per 64 weights, written for both
+// 32-weight halves: the kernel then runs unchanged; cols % 128 == 0)
+int gemm_rows_mo_build(int dtype, const void *tiled, size_t rows, size_t cols, void *mo, hipStream_t s);
 
 // rows of 16 per set when nsets > 1, cols % 128 == 0, 2 <= T <= 8; norm == 1 needs cols <= 4096
 bool gemm_rows_mfma_fused_ok(const GmArgs &P, int epi, int norm);

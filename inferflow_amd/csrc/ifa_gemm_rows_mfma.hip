@@ -28,12 +28,16 @@
 
 namespace ifa {
 
-// MO layout of one Q4_B32T1A matrix from its tiled copy: thread = (tile, superstep S, lane (r, g)) copies the 16 code bytes
-// of block 4S + g of row 16 tile + r and its (base, scale) word; rows past the end: zero codes and words (weight 0)
-__global__ void __launch_bounds__(256) k_gemm_rows_mo_build(const uint8_t *__restrict__ tiled, int rows, int nblk, uint8_t *__restrict__ mo)
+// MO layout of one matrix from its tiled copy: thread = (tile, superstep S, lane (r, g)) copies the 16 code bytes of the 32 weights
+// 32 (4S + g) .. + 31 of row 16 tile + r and their (base, scale) word; rows past the end: zero codes and words (weight 0).
+// B64: the source is a nibble-pair format with ONE (base, scale) per 64 weights -- Q4_B64T1, and Q3H_B64T1 as it is streamed
+// (ifa_tiled.h: [32 B codes] x n, [base, scale] x n per row) -- whose value is q * scale + base like Q4_B32T1: the 64-block's
+// word is written for both of its halves, and the rows GEMM runs unchanged on 32-weight blocks.
+template <bool B64>
+__global__ void __launch_bounds__(256) k_gemm_rows_mo_build(const uint8_t *__restrict__ tiled, int rows, int nblk, size_t row_bytes, uint8_t *__restrict__ mo)
 {
-    const int nsup = nblk >> 2, nq4 = (nsup + 3) >> 2;
-    const size_t mo_tile = (size_t)(nsup + nq4) * 1024, row_bytes = tiled_row_bytes(Q4_B32T1A, (size_t)nblk);
+    const int nsup = nblk >> 2, nq4 = (nsup + 3) >> 2;            // nblk: 32-weight blocks per row
+    const size_t mo_tile = (size_t)(nsup + nq4) * 1024;
     const int ntiles = (rows + 15) >> 4;
     const size_t total = (size_t)ntiles * nq4 * 4 * 64;            // (supersteps padded to whole quads: the pad's words are zero)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -46,8 +50,15 @@ __global__ void __launch_bounds__(256) k_gemm_rows_mo_build(const uint8_t *__res
         u32x4 c = {0, 0, 0, 0};
         uint32_t w = 0;
         if (in) {
-            c = *reinterpret_cast<const u32x4 *>(tiled + (size_t)row * row_bytes + (size_t)blk * 16);
-            w = *reinterpret_cast<const uint32_t *>(tiled + (size_t)row * row_bytes + (size_t)nblk * 16 + (size_t)blk * 4);
+            const uint8_t *rp = tiled + (size_t)row * row_bytes;
+            if constexpr (B64) {
+                const int n64 = nblk >> 1;
+                c = *reinterpret_cast<const u32x4 *>(rp + (size_t)(blk >> 1) * 32 + (size_t)(blk & 1) * 16);
+                w = *reinterpret_cast<const uint32_t *>(rp + (size_t)n64 * 32 + (size_t)(blk >> 1) * 4);
+            } else {
+                c = *reinterpret_cast<const u32x4 *>(rp + (size_t)blk * 16);
+                w = *reinterpret_cast<const uint32_t *>(rp + (size_t)nblk * 16 + (size_t)blk * 4);
+            }
         }
         uint8_t *tb = mo + (size_t)tile * mo_tile;
         if (S < nsup) *reinterpret_cast<u32x4 *>(tb + (size_t)S * 1024 + (size_t)lane * 16) = c;
@@ -230,7 +241,7 @@ int gemm_rows_mfma(const void *Wt_tiled, size_t rows, size_t cols, const void *x
         void *&mo = cache[std::make_pair(Wt_tiled, rows * 65537 + cols)];
         if (!mo) {
             IFA_HIP_CHECK(hipMalloc(&mo, gemm_rows_mo_bytes(rows, cols)));
-            int rc = gemm_rows_mo_build(Wt_tiled, rows, cols, mo, s);
+            int rc = gemm_rows_mo_build(Q4_B32T1A, Wt_tiled, rows, cols, mo, s);
             if (rc) return rc;
         }
         P.W[0] = (const uint8_t *)mo; P.mo = 1;
@@ -263,12 +274,16 @@ size_t gemm_rows_mo_bytes(size_t rows, size_t cols)
     return (rows + 15) / 16 * (nsup + nq4) * 1024;
 }
 
-int gemm_rows_mo_build(const void *tiled, size_t rows, size_t cols, void *mo, hipStream_t s)
+int gemm_rows_mo_build(int dtype, const void *tiled, size_t rows, size_t cols, void *mo, hipStream_t s)
 {
     IFA_REQUIRE(tiled && mo && rows > 0 && cols % 128 == 0, "gemm_rows_mo_build: %zu x %zu", rows, cols);
     const size_t items = (rows + 15) / 16 * ((cols / 128 + 3) / 4 * 4) * 64;
-    k_gemm_rows_mo_build<<<dim3((unsigned)std::min<size_t>(65535, (items + 255) / 256)), dim3(256), 0, s>>>((const uint8_t *)tiled, (int)rows, (int)(cols / 32),
-                                                                                                            (uint8_t *)mo);
+    const dim3 grid((unsigned)std::min<size_t>(65535, (items + 255) / 256)), block(256);
+    if (dtype == Q4_B32T1A || dtype == Q4_B32T1B)
+        k_gemm_rows_mo_build<false><<<grid, block, 0, s>>>((const uint8_t *)tiled, (int)rows, (int)(cols / 32), tiled_row_bytes(dtype, cols / 32), (uint8_t *)mo);
+    else if (dtype == Q4_B64T1 || dtype == Q3H_B64T1)
+        k_gemm_rows_mo_build<true><<<grid, block, 0, s>>>((const uint8_t *)tiled, (int)rows, (int)(cols / 32), tiled_row_bytes(dtype, cols / 64), (uint8_t *)mo);
+    else return ifa_fail(IFA_ERR_ARG, "gemm_rows_mo_build: format %d has no MO layout (value = q * scale + base nibble formats only)", dtype);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }

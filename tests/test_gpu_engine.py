@@ -452,6 +452,45 @@ def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, shape, n
     wk.close()
 
 
+@pytest.mark.parametrize("n", [3, 8, 12, 20])
+@pytest.mark.parametrize("wd", [dt.Q3H_B64T1, dt.Q4_B64T1], ids=["q3h", "q4_b64"])
+def test_fused_batched_step_for_the_64_weight_nibble_formats(wd, n):
+    """Q3H_B64T1 (as streamed: nibble pairs) and Q4_B64T1 have the value q * scale + base of Q4_B32T1 with one (base, scale) per
+    64 weights: their MO copies write the word for both 32-weight halves and the fused batched step (rows GEMM on the matrix
+    cores) runs unchanged.  Against the op-by-op rows of the same worker (generic GEMM on the reference-layout blocks: same
+    dequantised halves, another summation order) and against its own graph replay; short prompts take the same kernels."""
+    wk, _, s = synth.build("test_mha", wd, dt.F16, max_ctx=48, quant_threshold=0, std=0.06)
+    V = s["vocab"]
+    wk.kv_slots(2 * n)
+    rng = np.random.default_rng(70 + n)
+    prompts = [rng.integers(3, V, 3 + (i * 5) % 11).astype(np.int32) for i in range(n)]
+    cur, pos = [], []
+    for i, pr in enumerate(prompts):
+        wk.set_option("batch_fused", 1)
+        wk.select_kv(i); lg1 = torch.empty((len(pr), V), dtype=torch.float16, device="cuda"); t = wk.forward(pr, 0, lg1)
+        wk.set_option("batch_fused", 0)
+        wk.select_kv(n + i); lg0 = torch.empty((len(pr), V), dtype=torch.float16, device="cuda"); wk.forward(pr, 0, lg0)
+        a, b = g.host(lg1).astype(np.float32), g.host(lg0).astype(np.float32)
+        cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+        assert cos >= 0.9999 and np.abs(a - b).max() <= 0.02, ("prompt", i, cos, np.abs(a - b).max())
+        cur.append(t); pos.append(len(pr))
+    lgf = torch.empty((n, V), dtype=torch.float16, device="cuda")
+    lgu = torch.empty((n, V), dtype=torch.float16, device="cuda")
+    for step in range(3):
+        wk.set_option("batch_fused", 1)
+        tf = wk.decode_batch(cur, pos, list(range(n)), lgf)
+        wk.set_option("batch_fused", 0)
+        wk.decode_batch(cur, pos, list(range(n, 2 * n)), lgu)
+        a, b = g.host(lgf).astype(np.float32), g.host(lgu).astype(np.float32)
+        cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+        assert cos >= 0.9999 and np.abs(a - b).max() <= 0.02, (step, cos, np.abs(a - b).max())
+        wk.set_option("batch_fused", 1)
+        tg = wk.decode_batch(cur, pos, list(range(n)))
+        assert [int(t) for t in tg] == [int(t) for t in tf], step
+        cur = [int(t) for t in tf]; pos = [p + 1 for p in pos]
+    wk.close()
+
+
 @pytest.mark.parametrize("n", [2, 7, 8, 13, 16, 24])
 @pytest.mark.parametrize("shape", ["test_mha", "test_gqa"])
 def test_rows_gemm_operand_order_copy_is_bit_identical_to_the_tiled_path(shape, n):

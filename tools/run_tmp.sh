@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_engine.py tests/test_gpu_host_engine.py tests/test_gpu_comm.py -q -m gpu -k "batch or dynamic or operand" 2>&1 | grep -E "^E  |^FAILED|passed|failed" | cut -c1-200 | head
-IFA_BATCH_SIZES=2,8,16,32 timeout 300 python tools/bench_batch.py 2>/dev/null
+timeout 600 python -m pytest tests/test_gpu_engine.py -q -m gpu -k "nibble_formats or operand or fused_batched" 2>&1 | grep -E "^E  |^FAILED|passed|failed" | cut -c1-240 | head
+timeout 600 python bench.py --no-cpu-baseline --wdtype q3h --kv-dtype q8 --prefill-lens "" 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('q3h q8', round(j['value'],1), j.get('batch_decode'))"
