@@ -38,6 +38,7 @@ struct Tensor {
     void *data = nullptr;    // reference layout (AoS blocks / F16), engine-owned
     void *tiled = nullptr;   // row-local plane layout for the fused kernels (or null)
     void *mo = nullptr;      // MFMA-operand-order copy for the small-batch rows GEMM (ifa_gemm_rows_mfma.h), built on first use
+    void *x32 = nullptr;     // 64-weight nibble formats: the same values as Q4_B32T1A reference-layout blocks, for the large-tile prefill GEMM
     size_t rows = 0, cols = 0;
     bool present() const { return data != nullptr; }
 };
@@ -170,6 +171,7 @@ static void free_tensor(Tensor &t)
     if (t.data) (void)hipFree(t.data);
     if (t.tiled) (void)hipFree(t.tiled);
     if (t.mo) (void)hipFree(t.mo);
+    if (t.x32) (void)hipFree(t.x32);
     t = Tensor();
 }
 
@@ -177,6 +179,7 @@ static bool is_q4(int dt) { return dt == Q4_B32T1A || dt == Q4_B32T1B; }
 // formats the MO copy of the rows GEMM takes: 4-bit codes with value q * scale + base (the 64-weight ones only through MO)
 static bool rows_mo_fmt(int dt) { return is_q4(dt) || dt == Q4_B64T1 || dt == Q3H_B64T1; }
 static int ensure_mo(ifa_model *m);
+static int ensure_x32(ifa_model *m);
 static const uint8_t *rows_w(const ifa_model *m, const Tensor &t);
 static int rows_mo(const ifa_model *m, const Tensor &t);
 static bool scale_on(float s) { return s < 0.9999f || s > 1.0001f; }     // the reference's test for "scale != 1"
@@ -1415,14 +1418,15 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     const bool pf_big = !tp && T > 128 && prefill_big_ok(m);
     const bool pf_fused = pf_big || (!tp && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
     if (pf_fused && !pf_big && (rc = ensure_mo(m))) return rc;
+    if (pf_big && (rc = ensure_x32(m))) return rc;
     for (int l = 0; l < c.layers && pf_fused; l++) {
         Layer &L = m->layers[l];
         const size_t F = c.ffn;
         const bool norm_fused = !pf_big && (T <= 8 || rows_mo(m, L.t[T_WQ])) && T <= 16;
-        auto wp = [&](int id) { return pf_big ? (const uint8_t *)L.t[id].data : rows_w(m, L.t[id]); };
+        auto wp = [&](int id) { return pf_big ? (const uint8_t *)(L.t[id].x32 ? L.t[id].x32 : L.t[id].data) : rows_w(m, L.t[id]); };
         const int mo_flag = pf_big ? 0 : rows_mo(m, L.t[T_WQ]);
         auto lin = [&](const GmArgs &A, int id, int epi, int norm) {
-            return pf_big ? gemm_big(L.t[id].dtype, A, epi, m->stream) : gemm_rows_mfma_launch(A, epi, norm, m->stream);
+            return pf_big ? gemm_big(L.t[id].x32 ? (int)Q4_B32T1A : L.t[id].dtype, A, epi, m->stream) : gemm_rows_mfma_launch(A, epi, norm, m->stream);
         };
         Tensor nob;
         GmArgs P;
@@ -1672,6 +1676,24 @@ static int ensure_mo(ifa_model *m)
     if (built) IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     return IFA_OK;
 }
+// Long prompts of a model in a 64-weight nibble format: Q4_B32T1A-layout copies of the dense layers' matrices for k_gemm_big
+static int ensure_x32(ifa_model *m)
+{
+    bool built = false;
+    for (Layer &L : m->layers) {
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids) {
+            Tensor &t = L.t[id];
+            if (t.x32 || !t.present() || !t.tiled || (t.dtype != Q4_B64T1 && t.dtype != Q3H_B64T1) || t.cols % 64 != 0) continue;
+            IFA_HIP_CHECK(hipMalloc(&t.x32, t.rows * (t.cols / 32) * 20));
+            int rc = expand_b64_to_q4b32(t.dtype, t.tiled, t.rows, t.cols, t.x32, m->stream);
+            if (rc) return rc;
+            built = true;
+        }
+    }
+    if (built) IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return IFA_OK;
+}
 // weight pointer of a rows-GEMM launch: the MO copy when it exists (all sets of a launch alike: ensure_mo builds all or none)
 static const uint8_t *rows_w(const ifa_model *m, const Tensor &t) { return (const uint8_t *)(m->opt_rows_mo && t.mo ? t.mo : t.tiled); }
 static int rows_mo(const ifa_model *m, const Tensor &t) { return m->opt_rows_mo && t.mo ? 1 : 0; }
@@ -1718,7 +1740,8 @@ static bool prefill_big_ok(const ifa_model *m)
         const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
         for (int id : ids) {
             if (moe && (id == T_W1 || id == T_W3 || id == T_W2)) continue;
-            if (!L.t[id].present() || !L.t[id].data || (L.t[id].dtype != Q4_B32T1A && L.t[id].dtype != Q4_B32T1B)) return false;
+            const bool b64 = (L.t[id].dtype == Q4_B64T1 || L.t[id].dtype == Q3H_B64T1) && L.t[id].tiled;      // via their Q4_B32T1A-layout copy (ensure_x32)
+            if (!L.t[id].present() || !L.t[id].data || (L.t[id].dtype != Q4_B32T1A && L.t[id].dtype != Q4_B32T1B && !b64)) return false;
         }
         if (L.t[T_WK].dtype != L.t[T_WQ].dtype || L.t[T_WV].dtype != L.t[T_WQ].dtype || (!moe && L.t[T_W3].dtype != L.t[T_W1].dtype)) return false;
         if (!L.t[T_ATTN_NORM].present() || !L.t[T_FFN_NORM].present()) return false;

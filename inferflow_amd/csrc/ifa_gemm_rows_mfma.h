@@ -46,4 +46,7 @@ int gemm_rows_mo_build(int dtype, const void *tiled, size_t rows, size_t cols, v
 bool gemm_rows_mfma_fused_ok(const GmArgs &P, int epi, int norm);
 int gemm_rows_mfma_launch(const GmArgs &P, int epi, int norm, hipStream_t s);
 
+// Q4_B64T1 / Q3H_B64T1 (tiled, as streamed) -> Q4_B32T1A reference-layout rows of cols / 32 twenty-byte blocks (same values)
+int expand_b64_to_q4b32(int dtype, const void *tiled, size_t rows, size_t cols, void *out_aos, hipStream_t s);
+
 } // namespace ifa

@@ -268,6 +268,34 @@ int gemm_rows_mfma_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, c
     }
 }
 
+// The 64-weight nibble formats (Q4_B64T1; Q3H_B64T1 as streamed) rewritten as Q4_B32T1A reference-layout blocks -- {base, scale,
+// 16 code bytes} per 32 weights, the 64-block's word in both halves: the same values q * scale + base -- so that long prompts
+// take the large-tile GEMM (ifa_gemm.hip, k_gemm_big: blocks of <= 32 values) instead of the split-K kernel.  Compute-bound
+// work: the extra 4 bytes per 64 weights do not matter there.
+__global__ void __launch_bounds__(256) k_expand_b64_to_q4b32(const uint8_t *__restrict__ tiled, size_t rows, int n64, size_t row_bytes, uint8_t *__restrict__ out)
+{
+    const size_t total = rows * (size_t)n64 * 2;                  // 32-weight blocks
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / ((size_t)n64 * 2);
+        const int b32 = (int)(i % ((size_t)n64 * 2));
+        const uint8_t *rp = tiled + row * row_bytes;
+        const u32x4 c = *reinterpret_cast<const u32x4 *>(rp + (size_t)(b32 >> 1) * 32 + (size_t)(b32 & 1) * 16);
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(rp + (size_t)n64 * 32 + (size_t)(b32 >> 1) * 4);
+        uint32_t *o = reinterpret_cast<uint32_t *>(out + i * 20);
+        o[0] = w; o[1] = c[0]; o[2] = c[1]; o[3] = c[2]; o[4] = c[3];
+    }
+}
+
+int expand_b64_to_q4b32(int dtype, const void *tiled, size_t rows, size_t cols, void *out_aos, hipStream_t s)
+{
+    IFA_REQUIRE(tiled && out_aos && rows > 0 && cols % 64 == 0 && (dtype == Q4_B64T1 || dtype == Q3H_B64T1), "expand_b64_to_q4b32: format %d, %zu x %zu", dtype, rows, cols);
+    const size_t total = rows * (cols / 32);
+    k_expand_b64_to_q4b32<<<dim3((unsigned)std::min<size_t>(65535, (total + 255) / 256)), dim3(256), 0, s>>>((const uint8_t *)tiled, rows, (int)(cols / 64),
+                                                                                                          tiled_row_bytes(dtype, cols / 64), (uint8_t *)out_aos);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
 size_t gemm_rows_mo_bytes(size_t rows, size_t cols)
 {
     const size_t nsup = cols / 128, nq4 = (nsup + 3) / 4;

@@ -608,15 +608,18 @@ def test_1100_token_prompt_two_pass_attention_matches_oracle():
     wk.close()
 
 
-@pytest.mark.parametrize("kvd,shape", [(dt.F16, "test_gqa"), (dt.Q8_B32T2, "test_gqa"), (dt.F16, "test_moe")], ids=["kvf16", "kvq8", "moe"])
-def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd, shape):
+@pytest.mark.parametrize("kvd,shape,wd", [(dt.F16, "test_gqa", dt.Q4_B32T1A), (dt.Q8_B32T2, "test_gqa", dt.Q4_B32T1A), (dt.F16, "test_moe", dt.Q4_B32T1A),
+                                          (dt.Q8_B32T2, "test_gqa", dt.Q3H_B64T1), (dt.F16, "test_gqa", dt.Q4_B64T1)],
+                         ids=["kvf16", "kvq8", "moe", "q3h_kvq8", "q4_b64"])
+def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd, shape, wd):
     """Prompts above 128 tokens run a layer's linears as four launches of the large-tile GEMM (csrc/ifa_gemm.hip, k_gemm_big:
     wq | wk | wv into q / k / v, wo + residual, w1 / w3 + GLU, w2 + residual; forward_ops, pf_big) -- a 170-token prompt and
     a 160-token continuation of it against the oracle (src/transformer/inference_worker.cc:640-1050) and against the
     op-by-op layer of the same library (prefill_big = 0), then decode steps on the cache it wrote.  Mixture-of-experts
-    layers: the attention half as two such launches, the expert FFNs device-routed over the rows (moe_ffn)."""
+    layers: the attention half as two such launches, the expert FFNs device-routed over the rows (moe_ffn).  The 64-weight
+    nibble formats (Q3H_B64T1, Q4_B64T1) take the same kernel through a Q4_B32T1A-layout copy of the same values (ensure_x32)."""
     max_ctx = 400
-    wk, host, s = synth.build(shape, dt.Q4_B32T1A, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
+    wk, host, s = synth.build(shape, wd, kvd, max_ctx=max_ctx, quant_threshold=0, std=0.06, keep_host=True)
     om = oracle_model_from_host(host, s, max_ctx, kvd)
     V = s["vocab"]
     prompt = np.random.default_rng(21).integers(3, V, 330).astype(np.int32)
