@@ -241,29 +241,67 @@ def main():
     saved_stdout = os.dup(1)
     dog.out_fd = saved_stdout
     os.dup2(2, 1)
-    t_build = time.perf_counter()
-    runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank, groups=args.groups)
-    t_build = time.perf_counter() - t_build
-
     rng = np.random.default_rng(42)
-    prompt = rng.integers(3, runner.shape["vocab"], PROMPT_LEN).astype(np.int32)
+    prompt = rng.integers(3, synth.SHAPES[args.shape]["vocab"], PROMPT_LEN).astype(np.int32)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # prefill (timed separately; op-by-op path)
-    dog.arm("prefill", t_step)
-    barrier()
-    t0 = time.perf_counter()
-    tok = runner.prefill(prompt)
-    barrier()
-    prefill_s = time.perf_counter() - t0
+    # ---- build + prefill + warm-up as a TRIAL.  With more than one rank the C path (RCCL collectives captured into the step's
+    # hipGraph) has never run on hardware here: if any rank fails, the failing rank aborts its communicators (peers blocked in a
+    # collective return an error), all ranks agree on the outcome over torch.distributed and the next mode is tried -- the same
+    # C path with eager (uncaptured) steps, then the round-1 runner (torch.distributed collectives around the worker segments).
+    multi = world > 1 or bool(os.environ.get("IFA_FORCE_TP"))
+    modes = ["c-graph", "c-eager", "torch"] if multi else ["single"]
+    if os.environ.get("IFA_TP_BACKEND", "c") == "torch":
+        modes = ["torch"]
+    inject = [x for x in os.environ.get("IFA_BENCH_FAIL_MODES", "").split(",") if x]      # tests: pretend these modes fail
+    fallbacks, runner, mode_used = [], None, None
+    for mode in modes:
+        ok, err = 1, ""
+        try:
+            dog.arm("build + prefill + warm-up [%s]" % mode, t_init)
+            if mode == "torch":
+                os.environ["IFA_TP_BACKEND"] = "torch"
+            t_build = time.perf_counter()
+            runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank, groups=args.groups)
+            t_build = time.perf_counter() - t_build
+            if mode == "c-eager":
+                runner.worker.set_option("graph", 0)
+            if mode in inject:
+                raise RuntimeError("injected failure of mode %s" % mode)
+            barrier()
+            t0 = time.perf_counter()
+            tok = runner.prefill(prompt)
+            barrier()
+            prefill_s = time.perf_counter() - t0
+            toks_w, _ = runner.decode(tok, PROMPT_LEN, warmup) if warmup > 0 else ([tok], 0.0)
+            tok = int(toks_w[-1])
+        except Exception as e:      # noqa: BLE001
+            ok, err = 0, repr(e)[:300]
+            for cm in (getattr(runner, "tp_comm", None), getattr(runner, "world_comm", None)):
+                try:
+                    if cm is not None:
+                        cm.abort()
+                except Exception:      # noqa: BLE001
+                    pass
+        if multi and dist.is_initialized():
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok_all = int(flag.item())
+        else:
+            ok_all = ok
+        if ok_all:
+            mode_used = mode
+            break
+        fallbacks.append({"mode": mode, "error_on_this_rank": err or "a peer failed"})
+        print("bench: mode %s failed on rank %d (%s); trying the next one" % (mode, rank, err or "a peer failed"), file=sys.stderr, flush=True)
+        runner = None
+    if mode_used is None:
+        raise RuntimeError("every multi-GPU mode failed: %r" % (fallbacks,))
 
-    dog.arm("warm-up steps", t_step)
-    toks_w, _ = runner.decode(tok, PROMPT_LEN, warmup) if warmup > 0 else ([tok], 0.0)
-    tok = int(toks_w[-1])
     dog.arm("timed steps", t_step)
     barrier()
     t0 = time.perf_counter()
@@ -301,7 +339,8 @@ def main():
                                                                   PROMPT_LEN + warmup, PROMPT_LEN + warmup + steps),
                    "parallelism": ("single" if world == 1 else "tp%d" % world if args.groups == 1
                                    else "hybrid: %d layer groups x tp%d" % (args.groups, world // args.groups)),
-                   "collectives": getattr(runner, "backend", "torch.distributed (nccl = RCCL)") if (world > 1 or os.environ.get("IFA_FORCE_TP")) else None,
+                   "collectives": (getattr(runner, "backend", "torch.distributed (nccl = RCCL)") + (" [eager steps]" if mode_used == "c-eager" else "")) if (world > 1 or os.environ.get("IFA_FORCE_TP")) else None,
+                   "fallbacks": fallbacks,
                    "weights_bytes": w_bytes,
                    "bytes_per_token": bytes_per_token},
         "gpu_event_ms_per_step": gpu_ms / steps if gpu_ms and gpu_ms > 0 else None,
@@ -448,8 +487,14 @@ def main():
         except Exception as e:
             out["cpu_baseline_reference"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
     sys.stdout.flush()
+    try:                                   # C stdio too: RCCL's banner sits in libc's buffer while fd 1 points at stderr; flushed
+        import ctypes                      # after the restore it would land on the real stdout next to the JSON line
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                          # anything printed during teardown (communicator destruction) goes to stderr again
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
