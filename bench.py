@@ -254,7 +254,7 @@ def main():
     # collective return an error), all ranks agree on the outcome over torch.distributed and the next mode is tried -- the same
     # C path with eager (uncaptured) steps, then the round-1 runner (torch.distributed collectives around the worker segments).
     multi = world > 1 or bool(os.environ.get("IFA_FORCE_TP"))
-    modes = ["c-graph", "c-eager", "torch"] if multi else ["single"]
+    modes = ["c-oneshot", "c-graph", "c-eager", "torch"] if multi else ["single"]
     if os.environ.get("IFA_TP_BACKEND", "c") == "torch":
         modes = ["torch"]
     inject = [x for x in os.environ.get("IFA_BENCH_FAIL_MODES", "").split(",") if x]      # tests: pretend these modes fail
@@ -265,6 +265,10 @@ def main():
             dog.arm("build + prefill + warm-up [%s]" % mode, t_init)
             if mode == "torch":
                 os.environ["IFA_TP_BACKEND"] = "torch"
+            # c-oneshot: the C path with the cross-process one-shot exchange for the decode-size all-reduces (IPC-mapped inboxes)
+            os.environ["IFA_ONESHOT_IPC"] = "1" if mode == "c-oneshot" else "0"
+            if mode == "c-oneshot" and (world // max(1, args.groups)) < 2:
+                continue                                   # no tensor-parallel group of 2+ ranks: nothing to exchange
             t_build = time.perf_counter()
             runner = parallel.build_runner(args.shape, wd, kvd, max_ctx, world, rank, local_rank, groups=args.groups)
             t_build = time.perf_counter() - t_build
@@ -278,6 +282,18 @@ def main():
             barrier()
             prefill_s = time.perf_counter() - t0
             toks_w, _ = runner.decode(tok, PROMPT_LEN, warmup) if warmup > 0 else ([tok], 0.0)
+            if mode == "c-oneshot":
+                # never validated on hardware before this run: the same steps again through RCCL (a step rewrites the same cache
+                # rows: idempotent) must give the same leading tokens, and no wait of the exchange may have given up
+                if not getattr(runner, "oneshot_ipc", False):
+                    raise RuntimeError("one-shot exchange not available")
+                k = max(1, min(len(toks_w), 6))
+                runner.tp_comm.set_oneshot(0); runner.worker.set_option("graph", 1)       # (any option change drops the captured step)
+                toks_r, _ = runner.decode(tok, PROMPT_LEN, k)
+                if runner.tp_comm.status() != 0 or [int(t) for t in toks_w[:min(k, 4)]] != [int(t) for t in toks_r[:min(k, 4)]]:
+                    raise RuntimeError("one-shot exchange disagrees with RCCL: %r vs %r (status %d)" % (
+                        [int(t) for t in toks_w[:k]], [int(t) for t in toks_r[:k]], runner.tp_comm.status()))
+                runner.tp_comm.set_oneshot(1); runner.worker.set_option("graph", 1)
             tok = int(toks_w[-1])
         except Exception as e:      # noqa: BLE001
             ok, err = 0, repr(e)[:300]
@@ -339,7 +355,7 @@ def main():
                                                                   PROMPT_LEN + warmup, PROMPT_LEN + warmup + steps),
                    "parallelism": ("single" if world == 1 else "tp%d" % world if args.groups == 1
                                    else "hybrid: %d layer groups x tp%d" % (args.groups, world // args.groups)),
-                   "collectives": (getattr(runner, "backend", "torch.distributed (nccl = RCCL)") + (" [eager steps]" if mode_used == "c-eager" else "")) if (world > 1 or os.environ.get("IFA_FORCE_TP")) else None,
+                   "collectives": (getattr(runner, "backend", "torch.distributed (nccl = RCCL)") + (" [eager steps]" if mode_used == "c-eager" else " [decode-size all-reduces: one-shot exchange over IPC-mapped inboxes, checked against RCCL]" if mode_used == "c-oneshot" else "")) if (world > 1 or os.environ.get("IFA_FORCE_TP")) else None,
                    "fallbacks": fallbacks,
                    "weights_bytes": w_bytes,
                    "bytes_per_token": bytes_per_token},

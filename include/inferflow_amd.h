@@ -319,6 +319,12 @@ unsigned long long ifa_comm_serial(const ifa_comm *c);
  * rendezvous.  ifa_comm_oneshot: 1 if this communicator does; ifa_comm_set_oneshot(c, 0) keeps RCCL for every size;
  * ifa_comm_status: non-zero if a wait inside a one-shot all-reduce of this rank gave up (2 s). */
 int ifa_comm_oneshot(const ifa_comm *c);
+/* One process per rank (ifa_comm_init_rank): export allocates this rank's inbox / flags and writes their two IPC handles
+ * (IFA_ONESHOT_HANDLE_BYTES); the caller gathers all ranks' handles in rank order over the channel that carried the
+ * communicator id; import maps the peers' buffers (hipIpcOpenMemHandle) -- ifa_comm_oneshot(c) is 1 afterwards. */
+#define IFA_ONESHOT_HANDLE_BYTES 128
+int ifa_comm_oneshot_export(ifa_comm *c, void *handle_out_128);
+int ifa_comm_oneshot_import(ifa_comm *c, const void *handles_all_ranks);
 int ifa_comm_set_oneshot(ifa_comm *c, int on);
 int ifa_comm_status(ifa_comm *c);
 /* Wake every rank blocked in (or later entering) a collective of this communicator with an error: called by the rank

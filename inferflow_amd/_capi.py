@@ -124,6 +124,8 @@ SIGNATURES = {
     "ifa_comm_serial": (C.c_ulonglong, [_vp]),
     "ifa_comm_abort": (_i, [_vp]),
     "ifa_comm_oneshot": (_i, [_vp]),
+    "ifa_comm_oneshot_export": (_i, [_vp, _vp]),
+    "ifa_comm_oneshot_import": (_i, [_vp, _vp]),
     "ifa_comm_set_oneshot": (_i, [_vp, _i]),
     "ifa_comm_status": (_i, [_vp]),
     "ifa_comm_rank": (_i, [_vp]),

@@ -114,9 +114,16 @@ struct OneShot {
     std::vector<unsigned *> status;     // per rank: device word, non-zero = a wait gave up
     std::vector<int> device;
     bool ready = false;
+    int ipc_self = -1;                  // >= 0: one process per rank -- only entry ipc_self is this process's allocation, the
+                                        // other entries of `peers` are hipIpcOpenMemHandle mappings of the peers' buffers
     ~OneShot()
     {
         for (int r = 0; r < n; r++) {
+            if (ipc_self >= 0 && r != ipc_self) {
+                if (peers.inbox[r]) (void)hipIpcCloseMemHandle(peers.inbox[r]);
+                if (peers.flags[r]) (void)hipIpcCloseMemHandle(peers.flags[r]);
+                continue;
+            }
             (void)hipSetDevice(device[(size_t)r]);
             if (peers.inbox[r]) (void)hipFree(peers.inbox[r]);
             if (peers.flags[r]) (void)hipFree(peers.flags[r]);
@@ -185,6 +192,7 @@ struct ifa_comm {
     unsigned long long serial = g_comm_serial++;      // identity of this communicator object (ifa_comm_serial)
     std::atomic<bool> aborted{false};
     bool no_oneshot = false;                // ifa_comm_set_oneshot(c, 0): keep RCCL / the rendezvous for every size
+    bool no_rccl = false;                   // IFA_COMM_TEST_NO_RCCL: one-shot all-reduces only (tests)
     std::shared_ptr<LocalGroup> local;      // loopback group (ranks sharing a device); comm == nullptr then
     std::shared_ptr<OneShot> oneshot;       // peer-mapped exchange for small all-reduces (null: RCCL / rendezvous only)
 };
@@ -217,9 +225,64 @@ int ifa_comm_init_rank(const void *id_128, int nranks, int rank, int device, ifa
     memcpy(&id, id_128, sizeof(id));
     ifa_comm *c = new ifa_comm();
     c->rank = rank; c->nranks = nranks; c->device = device;
+    if (getenv("IFA_COMM_TEST_NO_RCCL")) {      // tests of the cross-process one-shot exchange on ONE device (RCCL refuses two ranks on
+        c->no_rccl = true;                      // a device): the communicator then only serves all-reduces that take the one-shot path
+        *out = c;
+        return IFA_OK;
+    }
     ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
     if (r != ncclSuccess) { delete c; return ifa_fail(IFA_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, nranks, device, ncclGetErrorString(r)); }
     *out = c;
+    return IFA_OK;
+}
+
+// One process per rank (ifa_comm_init_rank): the one-shot exchange needs the peers' inboxes and flags mapped into this process.
+// export: allocate this rank's buffers and hand out their IPC handles (2 x 64 bytes); the caller gathers the handles of all ranks
+// over whatever channel carried the communicator id; import: map them (hipIpcOpenMemHandle) -- from then on all-reduces of
+// <= 64 KB take the one-shot kernel.  Nothing here proves cross-device visibility: the first exchanges have bounded waits
+// (ifa_comm_status), and callers that can should compare a few steps against the RCCL path before relying on it (bench.py does).
+int ifa_comm_oneshot_export(ifa_comm *c, void *handle_out_128)
+{
+    IFA_REQUIRE(c && handle_out_128 && !c->local, "ifa_comm_oneshot_export: a communicator made by ifa_comm_init_rank is needed");
+    IFA_REQUIRE(c->nranks >= 2 && c->nranks <= 64, "ifa_comm_oneshot_export: %d ranks", c->nranks);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+    IFA_HIP_CHECK(hipSetDevice(c->device));
+    auto os = std::make_shared<OneShot>();
+    const int n = c->nranks;
+    os->n = n; os->ipc_self = c->rank;
+    os->epoch.assign((size_t)n, nullptr); os->status.assign((size_t)n, nullptr); os->device.assign((size_t)n, c->device);
+    memset(&os->peers, 0, sizeof(os->peers));
+    const size_t inbox_bytes = 2 * (size_t)n * ONESHOT_MAX_BYTES, flag_bytes = 2 * (size_t)n * sizeof(unsigned);
+    IFA_HIP_CHECK(hipMalloc((void **)&os->peers.inbox[c->rank], inbox_bytes));
+    IFA_HIP_CHECK(hipMalloc((void **)&os->peers.flags[c->rank], flag_bytes + 64));
+    IFA_HIP_CHECK(hipMalloc((void **)&os->epoch[(size_t)c->rank], 4));
+    IFA_HIP_CHECK(hipMalloc((void **)&os->status[(size_t)c->rank], 4));
+    IFA_HIP_CHECK(hipMemset(os->peers.flags[c->rank], 0, flag_bytes + 64));
+    IFA_HIP_CHECK(hipMemset(os->epoch[(size_t)c->rank], 0, 4));
+    IFA_HIP_CHECK(hipMemset(os->status[(size_t)c->rank], 0, 4));
+    hipIpcMemHandle_t h[2];
+    IFA_HIP_CHECK(hipIpcGetMemHandle(&h[0], os->peers.inbox[c->rank]));
+    IFA_HIP_CHECK(hipIpcGetMemHandle(&h[1], os->peers.flags[c->rank]));
+    memcpy(handle_out_128, h, sizeof(h));
+    c->oneshot = os;                   // not ready until the peers are mapped
+    return IFA_OK;
+}
+
+int ifa_comm_oneshot_import(ifa_comm *c, const void *handles_all)
+{
+    IFA_REQUIRE(c && handles_all && c->oneshot && c->oneshot->ipc_self == c->rank && !c->oneshot->ready, "ifa_comm_oneshot_import: call ifa_comm_oneshot_export first");
+    IFA_HIP_CHECK(hipSetDevice(c->device));
+    OneShot &os = *c->oneshot;
+    const hipIpcMemHandle_t *h = reinterpret_cast<const hipIpcMemHandle_t *>(handles_all);
+    for (int r = 0; r < os.n; r++) {
+        if (r == c->rank) continue;
+        void *pi = nullptr, *pf = nullptr;
+        IFA_HIP_CHECK(hipIpcOpenMemHandle(&pi, h[2 * r], hipIpcMemLazyEnablePeerAccess));
+        os.peers.inbox[r] = (unsigned long long *)pi;
+        IFA_HIP_CHECK(hipIpcOpenMemHandle(&pf, h[2 * r + 1], hipIpcMemLazyEnablePeerAccess));
+        os.peers.flags[r] = (unsigned *)pf;
+    }
+    os.ready = true;
     return IFA_OK;
 }
 
@@ -348,7 +411,7 @@ int ifa_comm_group_end(void) { IFA_NCCL_CHECK(ncclGroupEnd()); return IFA_OK; }
 
 int ifa_allreduce_sum_f16(ifa_comm *c, const void *send_f16, void *recv_f16, size_t count, ifa_stream stream)
 {
-    IFA_REQUIRE(c && (c->comm || c->local) && send_f16 && recv_f16, "ifa_allreduce_sum_f16: null pointer");
+    IFA_REQUIRE(c && (c->comm || c->local || c->no_rccl) && send_f16 && recv_f16, "ifa_allreduce_sum_f16: null pointer");
     if (count == 0) return IFA_OK;
     if (c->oneshot && c->oneshot->ready && count * 2 <= ONESHOT_MAX_BYTES && !c->no_oneshot) {
         OneShot &os = *c->oneshot;
@@ -372,6 +435,7 @@ int ifa_allreduce_sum_f16(ifa_comm *c, const void *send_f16, void *recv_f16, siz
         if (!g.barrier()) return ifa_fail(IFA_ERR_STATE, "ifa_allreduce_sum_f16: the group was aborted (a peer failed)");
         return IFA_OK;
     }
+    IFA_REQUIRE(c->comm, "ifa_allreduce_sum_f16: this communicator has no RCCL side (IFA_COMM_TEST_NO_RCCL) and the one-shot path does not apply (%zu halves)", count);
     IFA_NCCL_CHECK(ncclAllReduce(send_f16, recv_f16, count, ncclFloat16, ncclSum, c->comm, ifa_s(stream)));
     return IFA_OK;
 }

@@ -343,6 +343,17 @@ class CTPRunner:
         if tp_size > 1 or self.force_collectives:
             ids = [share_id(g * tp_size, rank == g * tp_size) for g in range(groups)]     # collective: same order on every rank
             self.tp_comm = W.Comm(ids[self.stage], tp_size, self.tp_rank, local_rank)
+            # IFA_ONESHOT_IPC=1: map the group's one-shot inboxes across the processes (csrc/ifa_comm.hip; the handles travel
+            # like the communicator id) -- decode-size all-reduces then skip RCCL.  Opt-in: bench.py switches it on as its
+            # first mode and compares a few steps against the RCCL path before timing with it.
+            self.oneshot_ipc = False
+            if os.environ.get("IFA_ONESHOT_IPC") == "1" and tp_size > 1 and world > 1:
+                mine = torch.frombuffer(bytearray(self.tp_comm.oneshot_export()), dtype=torch.uint8).to(dev)
+                allh = [torch.zeros(128, dtype=torch.uint8, device=dev) for _ in range(world)]
+                dist.all_gather(allh, mine)                                    # collective over the job: every rank takes part
+                base = self.stage * tp_size
+                self.tp_comm.oneshot_import(b"".join(bytes(allh[base + r].cpu().numpy().tobytes()) for r in range(tp_size)))
+                self.oneshot_ipc = self.tp_comm.oneshot()
         self.worker, self.shape, self.local_shape = build_tp_worker(
             shape_name, wdtype, kv_dtype, max_ctx, tp_size, self.tp_rank, device=local_rank, layer_range=ranges[self.stage],
             first_stage=self.stage == 0, last_stage=self.stage == groups - 1, **overrides)

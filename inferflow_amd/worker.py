@@ -232,6 +232,17 @@ class Comm:
         """True if small all-reduces of this communicator take the peer-mapped one-shot exchange (csrc/ifa_comm.hip)."""
         return bool(lib().ifa_comm_oneshot(self._h))
 
+    def oneshot_export(self):
+        """One process per rank: allocate this rank's one-shot buffers; returns their IPC handles (128 bytes) for the peers."""
+        buf = (C.c_ubyte * 128)()
+        check(lib().ifa_comm_oneshot_export(self._h, buf))
+        return bytes(buf)
+
+    def oneshot_import(self, handles_all_ranks):
+        """Map the peers' buffers: handles_all_ranks = the concatenated oneshot_export() results of all ranks, in rank order."""
+        b = bytes(handles_all_ranks)
+        check(lib().ifa_comm_oneshot_import(self._h, (C.c_ubyte * len(b)).from_buffer_copy(b)))
+
     def set_oneshot(self, on):
         check(lib().ifa_comm_set_oneshot(self._h, int(bool(on))))
 
