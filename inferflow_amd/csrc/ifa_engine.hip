@@ -2845,6 +2845,12 @@ int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_tok
         *elapsed_ms = ms;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
+    // a bounded wait of the one-shot exchange that gave up (a peer that never arrived) left this rank without a sum: the
+    // tokens above are not results -- fail the call (the engine then aborts the group) instead of returning them
+    if (t.tp && ifa_comm_oneshot(t.tp)) {
+        const int st = ifa_comm_status(t.tp);
+        if (st != 0) return ifa_fail(IFA_ERR_STATE, "tensor-parallel decode: a wait inside the one-shot all-reduce gave up (epoch %d): a peer did not arrive", st);
+    }
     return IFA_OK;
 }
 
