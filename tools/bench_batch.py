@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Aggregate decode rate with dynamic batching (Llama-2-7B Q4): n queries advance one token per step."""
-import json, os, sys, time
+import gc, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from inferflow_amd import dtypes as dt, synth
@@ -19,6 +19,7 @@ for n in [int(v) for v in os.environ.get("IFA_BATCH_SIZES", "1,2,4,8,16,32").spl
     cur, pos = list(first[:n]), [16] * n
     steps = 24
     for w in range(2):
+        gc.collect(); gc.disable()          # host-driven steps: no 35-60 ms cyclic-collector pause inside the timed pass
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for st in range(steps):
             if n == 1:
@@ -28,4 +29,5 @@ for n in [int(v) for v in os.environ.get("IFA_BATCH_SIZES", "1,2,4,8,16,32").spl
                 cur = [int(t) for t in wk.decode_batch(cur, pos, list(range(n)))]
             pos = [p + 1 for p in pos]
         torch.cuda.synchronize(); dt_s = time.perf_counter() - t0
+        gc.enable()
     print(json.dumps({"shape": shape, "queries": n, "ms_per_step": dt_s * 1e3 / steps, "aggregate_tok_s": n * steps / dt_s}), flush=True)
