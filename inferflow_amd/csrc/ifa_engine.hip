@@ -48,6 +48,7 @@ struct Layer {
     std::vector<Tensor> experts;   // [expert][3]: w1, w2, w3 (MoE layers)
     void *moe_table = nullptr;     // device: [expert][4] tiled pointers {w1, w3, w2, -} for the fused decode kernels
     void *moe_table_aos = nullptr; // device: [expert][3] reference-layout pointers {w1, w2, w3} for the grouped T > 1 launches
+    void *moe_table_mo = nullptr;  // device: [expert][4] MO copies {w1, w3, w2, -} for the experts with 2..8 rows of a batched step (ensure_mo)
     void *kcache = nullptr, *vcache = nullptr;
 };
 
@@ -733,6 +734,7 @@ int gemm_rows_q4_grouped_cap(size_t cols);
 bool gemm_rows_use_mfma();
 bool gemm_rows_mfma_ok(size_t rows, size_t cols, size_t tokens);
 int gemm_rows_mfma_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, int max_rows, hipStream_t s);
+int gemm_rows_mo_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, int glu, int act_kind, hipStream_t s);
 int gemm_rows_q4_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, hipStream_t s);
 int moe_gather(const void *src, const int *idx, const int *counts, int max_entries, int dim, void *dst, hipStream_t s);
 int moe_combine(const void *y, const int *epos, const void *wsel, int T, int top_k, int dim, void *out, hipStream_t s);
@@ -1326,6 +1328,7 @@ static bool moe_device_ok(const ifa_model *m, const Layer &L)
     return true;
 }
 
+static int max_smalls_possible(bool rows_kernel, int E, int cap) { return rows_kernel ? std::min(E, cap / 2) : 0; }
 static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
 {
     const ifa_model_config &c = m->cfg;
@@ -1353,6 +1356,10 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
                               (MoeSingle *)m->moe_singles, (MoeTile *)m->moe_smalls, m->moe_counts, m->stream))) return rc;
     MoeSmallGroup sg;
     sg.smalls = (const MoeTile *)m->moe_smalls; sg.counts = m->moe_counts; sg.wtab_tiled = (const uint8_t *const *)L.moe_table; sg.which_tiled = 0;
+    // MO copies of the experts (ensure_mo, built by the batched step before its capture): the small groups then take ONE launch
+    // for w1 / w3 with the gated product as its output, and one for w2 -- instead of three launches and an element-wise pass
+    sg.wtab_mo = (rows_mfma && m->opt_rows_mo) ? (const uint8_t *const *)L.moe_table_mo : nullptr;
+    const bool smalls_mo = sg.wtab_mo != nullptr && max_smalls_possible(rows_kernel, E, cap) > 0;
     const int max_smalls = rows_kernel ? std::min(E, cap / 2) : 0;
     if ((rc = moe_gather(ff_n, m->moe_idx, m->moe_counts, cap, (int)D, m->moe_gin, m->stream))) return rc;
     MoeGroup g;
@@ -1365,18 +1372,23 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     g.which = 0;
     if ((rc = gemm_q_grouped(wdt, g, F, D, m->moe_gin, m->moe_g1, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, F, D, m->moe_xq_in, m->moe_g1, max_singles, m->stream))) return rc;
-    if (max_smalls && (rc = rows_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls))) return rc;
+    if (max_smalls && !smalls_mo && (rc = rows_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls))) return rc;
     g.which = 2; sg.which_tiled = 1;
     if ((rc = gemm_q_grouped(wdt, g, F, D, m->moe_gin, m->moe_g3, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, F, D, m->moe_xq_in, m->moe_g3, max_singles, m->stream))) return rc;
-    if (max_smalls && (rc = rows_grouped(sg, F, D, m->moe_gin, m->moe_g3, max_smalls))) return rc;
+    if (max_smalls && !smalls_mo && (rc = rows_grouped(sg, F, D, m->moe_gin, m->moe_g3, max_smalls))) return rc;
     if ((rc = ifa_activation_mul(c.act_kind, m->moe_g1, m->moe_g3, (size_t)cap * F, m->moe_g1, s))) return rc;
+    if (max_smalls && smalls_mo) {      // (after the element-wise pass over all rows: the small groups' rows of g1 are written here, gated)
+        sg.which_tiled = 0;
+        if ((rc = gemm_rows_mo_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls, 1, c.act_kind, m->stream))) return rc;
+    }
     if ((rc = ifa_quantize_act_q8(m->moe_g1, (size_t)cap, F, m->moe_xq_mid, s))) return rc;
     g.which = 1;
     if ((rc = gemm_q_grouped(wdt, g, D, F, m->moe_g1, m->moe_gout, max_tiles, tile_rows, m->stream))) return rc;
     if ((rc = gemv_ax8_grouped(wdt, g, D, F, m->moe_xq_mid, m->moe_gout, max_singles, m->stream))) return rc;
     sg.which_tiled = 2;
-    if (max_smalls && (rc = rows_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls))) return rc;
+    if (max_smalls && smalls_mo) { if ((rc = gemm_rows_mo_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls, 0, c.act_kind, m->stream))) return rc; }
+    else if (max_smalls && (rc = rows_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls))) return rc;
     return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, m->f, m->stream);
 }
 
@@ -1672,6 +1684,30 @@ static int ensure_mo(ifa_model *m)
             if (rc) return rc;
             built = true;
         }
+    }
+    // mixture-of-experts layers: the experts' matrices too, with their pointer table {w1, w3, w2, -} (the order of moe_table):
+    // the experts that collect 2..8 rows of a batched step take the grouped MO launches (moe_ffn_device)
+    for (Layer &L : m->layers) {
+        if (!(c.experts > 0 && L.t[T_MOE_GATE].present()) || L.moe_table_mo || (int)L.experts.size() != c.experts * 3) continue;
+        bool ok = true;
+        for (Tensor &t : L.experts) ok = ok && t.present() && t.tiled && is_q4(t.dtype) && t.cols % 128 == 0;
+        if (!ok) continue;
+        std::vector<void *> tab((size_t)c.experts * 4, nullptr);
+        for (int e = 0; e < c.experts; e++) {
+            const int order[3] = {0, 2, 1};                       // experts[e * 3 + {0, 1, 2}] = w1, w2, w3
+            for (int k = 0; k < 3; k++) {
+                Tensor &t = L.experts[(size_t)e * 3 + order[k]];
+                if (!t.mo) {
+                    IFA_HIP_CHECK(hipMalloc(&t.mo, gemm_rows_mo_bytes(t.rows, t.cols)));
+                    int rc = gemm_rows_mo_build(t.dtype, t.tiled, t.rows, t.cols, t.mo, m->stream);
+                    if (rc) return rc;
+                    built = true;
+                }
+                tab[(size_t)e * 4 + k] = t.mo;
+            }
+        }
+        IFA_HIP_CHECK(hipMalloc(&L.moe_table_mo, tab.size() * sizeof(void *)));
+        IFA_HIP_CHECK(hipMemcpy(L.moe_table_mo, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice));
     }
     if (built) IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     return IFA_OK;
@@ -2050,6 +2086,7 @@ int ifa_model_destroy(ifa_model *m)
         for (Tensor &t : L.experts) free_tensor(t);
         if (L.moe_table) (void)hipFree(L.moe_table);
         if (L.moe_table_aos) (void)hipFree(L.moe_table_aos);
+        if (L.moe_table_mo) (void)hipFree(L.moe_table_mo);
         if (L.kcache) (void)hipFree(L.kcache);
         if (L.vcache) (void)hipFree(L.vcache);
     }

@@ -460,5 +460,7 @@ static size_t gm_smem(int T, int maxt, int mo)
 
 // MO-layout kernels (ifa_gemm_rows_mo.hip); wgs / maxt from gemm_rows_mfma_launch's geometry
 int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, hipStream_t s);
+// the experts with 2..8 rows of a mixture-of-experts layer on their MO copies; glu: w1 / w3 pairs with act(.) * (.) as the output
+int gemm_rows_mo_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, int glu, int act_kind, hipStream_t s);
 
 } // namespace ifa

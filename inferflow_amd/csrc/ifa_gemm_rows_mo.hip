@@ -69,4 +69,68 @@ int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, h
     }
 }
 
+// Mixture of experts, experts with 2..8 rows ("smalls", ifa_moe.h): blockIdx.y is one expert's group of consecutive rows of the
+// gathered activations; its MO weights come from the pointer table {w1, w3, w2, -}.  EPI == GM_GLU: w1 and w3 of the expert in
+// ONE launch with act(w1 x) * (w3 x) as the output (the tiled path runs two launches and an element-wise kernel).
+template <int MAXT, int EPI, int CH>
+__global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mo_grouped(const MoeSmallGroup grp, int rows, int nblk, int act_kind, const half_t *__restrict__ X,
+                                                                     half_t *__restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.y >= grp.counts[3]) return;
+    const MoeTile gq = grp.smalls[blockIdx.y];
+    GmArgs P;
+    P.W[0] = grp.wtab_mo[4 * gq.expert + grp.which_tiled]; P.W[1] = nullptr; P.W[2] = nullptr;
+    P.W1 = EPI == GM_GLU ? grp.wtab_mo[4 * gq.expert + grp.which_tiled + 1] : nullptr;
+    P.rows[0] = rows; P.rows[1] = 0; P.rows[2] = 0; P.nsets = 1; P.total_rows = rows; P.nblk = nblk; P.T = gq.nrows;
+    P.X = X + (size_t)gq.row0 * nblk * 32; P.ldx = nblk * 32; P.multi_base = 0.0f; P.eps = 0.0f; P.norm_w = nullptr;
+    P.bias[0] = nullptr; P.bias[1] = nullptr; P.bias[2] = nullptr; P.bias1 = nullptr;
+    P.Y = Y + (size_t)gq.row0 * rows; P.res = nullptr; P.ldy = rows; P.ldres = 0; P.act_kind = act_kind;
+    P.Yset[0] = nullptr; P.Yset[1] = nullptr; P.Yset[2] = nullptr; P.ldyset[0] = 0; P.ldyset[1] = 0; P.ldyset[2] = 0;
+    P.mo = 1; P.trace = nullptr;
+    gemm_rows_mfma_body<MAXT, 8, EPI, 0, true, CH>(P, smem);
+}
+
+template <int MT, int EPI, int CH>
+static int mo_launch_grouped(int wgs, int groups, size_t smem, const MoeSmallGroup &grp, size_t rows, size_t cols, int act_kind, const void *X, void *Y, hipStream_t s)
+{
+    auto kern = k_gemm_rows_mo_grouped<MT, EPI, CH>;
+    if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    kern<<<dim3((unsigned)wgs, (unsigned)groups), dim3(GM_THREADS), smem, s>>>(grp, (int)rows, (int)(cols / 32), act_kind, (const half_t *)X, (half_t *)Y);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+// rows / cols of ONE expert matrix (glu: of w1 and of w3); X / Y: the gathered activations / outputs of all entries; groups of 2..8 rows
+int gemm_rows_mo_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, int glu, int act_kind, hipStream_t s)
+{
+    if (!grp.wtab_mo || cols % 128 != 0 || rows == 0) return ifa_fail(IFA_ERR_STATE, "grouped rows GEMM (MO): %zu x %zu", rows, cols);
+    if (max_groups <= 0) return IFA_OK;
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipDeviceProp_t prop; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+    // the experts share the chip: two workgroups fit a CU (66 KB of LDS each), so up to 2 * CUs / groups workgroups per expert
+    const int ntiles = (int)((rows + 15) / 16), cap = std::max(32, 2 * ncu / max_groups);
+    int w = std::min(cap, ntiles), mt = (ntiles + w - 1) / w;
+    if (glu) {                          // pairs (w1 tile, w3 tile): 1..4 pairs per workgroup
+        if (mt > 4) { mt = 4; w = (ntiles + 3) / 4; }
+        mt = mt == 3 ? 6 : mt * 2;
+    } else {
+        if (mt > 8) { mt = 8; w = (ntiles + 7) / 8; }
+        if (mt == 5) mt = 6;
+        if (mt == 7) mt = 8;
+    }
+    const bool one = cols <= (size_t)GmGeo<32>::CHUNK_COLS;
+    const size_t smem = gm_smem(8, mt, 1);
+#define IFA_MOG(MTV) \
+    if (mt == MTV) { \
+        if (glu) { if constexpr (MTV % 2 == 0) return one ? mo_launch_grouped<MTV, GM_GLU, 1>(w, max_groups, smem, grp, rows, cols, act_kind, X, Y, s) \
+                                                          : mo_launch_grouped<MTV, GM_GLU, 0>(w, max_groups, smem, grp, rows, cols, act_kind, X, Y, s); } \
+        else return one ? mo_launch_grouped<MTV, GM_PLAIN, 1>(w, max_groups, smem, grp, rows, cols, act_kind, X, Y, s) \
+                        : mo_launch_grouped<MTV, GM_PLAIN, 0>(w, max_groups, smem, grp, rows, cols, act_kind, X, Y, s); \
+    }
+    IFA_MOG(1) IFA_MOG(2) IFA_MOG(3) IFA_MOG(4) IFA_MOG(6) IFA_MOG(8)
+#undef IFA_MOG
+    return ifa_fail(IFA_ERR_ARG, "grouped rows GEMM (MO): %d tiles per workgroup", mt);
+}
+
 } // namespace ifa

@@ -32,6 +32,7 @@ struct MoeSmallGroup {
     const int *counts;
     const uint8_t *const *wtab_tiled;
     int which_tiled;                // 0 w1, 1 w3, 2 w2
+    const uint8_t *const *wtab_mo;  // the same table of MO copies (ifa_gemm_rows_mfma.h), or null
 };
 
 } // namespace ifa
