@@ -995,6 +995,16 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     // the context are clamped to the last one (duplicate addresses: one cache line) -- unclamped, every (head, query) workgroup
     // pulled 2 x 64 KB of cache rows whatever its context: 134 MB per layer at 32 queries, the whole cost of that launch
     load_k(BATCH ? min(tid, pos_b) : tid);
+    // this step's (cos, sin) pair of the thread that will rotate: requested BETWEEN the K and the V rows -- behind both it was the
+    // newest request, and the rotation waited (vmcnt(0)) for the whole prefetch; unconditional (a valid dummy address without RoPE)
+    float rope_cs = 1.0f, rope_sn = 0.0f;
+    {
+        const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
+        const float *rt = rope_tab ? rope_tab : reinterpret_cast<const float *>(pq);
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 cs = *IFA_GP(f32x2, rt + 2 * c);
+        if (P.rope_order != 0) { rope_cs = cs[0]; rope_sn = cs[1]; }
+    }
     const int dg = tid % DG, sp = tid / DG;
     const bool vact = (256 % DG == 0) || sp < NSPLIT;   // this thread takes part in P.V
     constexpr int VPRE = 256 / NSPLIT;                  // prefetched V keys per thread: j = sp + NSPLIT*i (256 keys)
@@ -1007,10 +1017,14 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         if constexpr (!Q8) {
             vreg[i] = IFA_GP(u32x4, pvc + (size_t)j * row_bytes + head_off)[dg];
         } else {
+            // the thread's 8 codes as ONE 8-byte request at a 2-byte-aligned address (global memory takes unaligned dwords): five
+            // 2-byte requests per key were 80 load instructions per thread ahead of everything else in the kernel
             const auto *blk = IFA_GP(uint16_t, pvc + (size_t)j * row_bytes + vq_off);
+            typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
             vq[i][0] = blk[0];
-#pragma unroll
-            for (int e = 0; e < 4; e++) vq[i][1 + e] = blk[1 + (dg % 4) * 4 + e];
+            const u32x2_a2 cw = *IFA_GP(u32x2_a2, blk + 1 + (dg % 4) * 4);
+            vq[i][1] = (uint16_t)(cw[0] & 0xFFFFu); vq[i][2] = (uint16_t)(cw[0] >> 16);
+            vq[i][3] = (uint16_t)(cw[1] & 0xFFFFu); vq[i][4] = (uint16_t)(cw[1] >> 16);
         }
     }
 
@@ -1018,13 +1032,10 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     // will rotate (requested now, used after the staging barrier)
     const bool tr = P.trace != nullptr && tid == 0;
     if (tr) P.trace[h * 8 + 0] = wall_clock64();
-    const int pos = BATCH ? pos_b : P.state[1];
+    // (a SCALAR load through the constant address space: as a vector load it was the newest request of the wave, and waiting for it
+    //  -- vmcnt(0) -- meant waiting for every K / V row requested above before the new token's values could even be staged)
+    const int pos = BATCH ? pos_b : *(const __attribute__((address_space(4))) int *)(P.state + 1);
     const int n_ctx = pos + 1;
-    float rope_cs = 1.0f, rope_sn = 0.0f;
-    if (P.rope_order != 0) {
-        const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
-        rope_cs = rope_tab[2 * c]; rope_sn = rope_tab[2 * c + 1];
-    }
     // ---- stage q, k_new, v_new; RoPE on q and k (TensorOpr::PositionEmbedding, F16 in/out)
     if (tid < HD) { qs[tid] = q_in; kn[tid] = k_in; vn[tid] = v_in; }
     __syncthreads();
@@ -1039,14 +1050,16 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     // ---- KV store of the new row (LayerKVCache::SetKRows/SetVRows, kv_cache.cc:159-249)
     if constexpr (Q8) {
         constexpr int NB = HD / 32;
-        for (int b = wave; b < 2 * NB; b += 4) {
+        // one 32-value block per HALF wave (HD = 128: the 4 + 4 blocks of the new k and v rows on the 8 half waves at once; the
+        // block maximum by DPP + one permute): two blocks per wave one after the other on 32 lanes with five LDS permutes each was
+        // 0.9 us of this kernel.  Same operations per element as before (the maximum does not depend on the order).
+        for (int b = wave * 2 + (lane >> 5); b < 2 * NB; b += 8) {
             half_t *src = b < NB ? kn : vn;
             const int bb = b < NB ? b : b - NB;
-            if (lane < 32) {
-                const float val = h2f(src[bb * 32 + lane]);
-                float mx = fabsf(val);
-#pragma unroll
-                for (int m = 16; m > 0; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 32));
+            const int l32 = lane & 31;
+            {
+                const float val = h2f(src[bb * 32 + l32]);
+                const float mx = half_wave_max(fabsf(val));
                 const float sc = mx / 127;
                 int qv = sc <= 0.000001f ? 0 : (int)roundf(val / sc);
                 qv = min(max(qv, -128), 127);
@@ -1054,10 +1067,10 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
                 if (writer) {
                     uint8_t *cache = b < NB ? kcw : vcw;
                     uint8_t *blk = cache + (size_t)pos * row_bytes + head_off + (size_t)bb * 34;
-                    blk[2 + lane] = (uint8_t)(int8_t)qv;
-                    if (lane == 0) *reinterpret_cast<uint16_t *>(blk) = __builtin_bit_cast(uint16_t, sch);
+                    blk[2 + l32] = (uint8_t)(int8_t)qv;
+                    if (l32 == 0) *reinterpret_cast<uint16_t *>(blk) = __builtin_bit_cast(uint16_t, sch);
                 }
-                src[bb * 32 + lane] = f2h((float)qv * h2f(sch));   // dequantised value, as GetKRows returns it
+                src[bb * 32 + l32] = f2h((float)qv * h2f(sch));   // dequantised value, as GetKRows returns it
             }
         }
         __syncthreads();
@@ -1193,8 +1206,9 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     };
     auto acc_q8 = [&](float pj, int j) {
         const auto *blk = IFA_GP(uint16_t, pvc + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34);
-        const auto *cp = blk + 1 + (dg % 4) * 4;
-        acc_q8w(pj, blk[0], cp[0], cp[1], cp[2], cp[3]);
+        typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
+        const u32x2_a2 cw = *IFA_GP(u32x2_a2, blk + 1 + (dg % 4) * 4);      // (one unaligned 8-byte request: see the prefetch above)
+        acc_q8w(pj, blk[0], (uint16_t)(cw[0] & 0xFFFFu), (uint16_t)(cw[0] >> 16), (uint16_t)(cw[1] & 0xFFFFu), (uint16_t)(cw[1] >> 16));
     };
 #pragma unroll
     for (int i = 0; i < VPRE; i++) {        // first 256 keys: V rows already in registers (static indexing)
@@ -1260,7 +1274,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     __shared__ __attribute__((aligned(16))) half_t vn[HD];
     __shared__ float red[4];
     const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = P.state[1], n_ctx = pos + 1;
+    const int pos = *(const __attribute__((address_space(4))) int *)(P.state + 1), n_ctx = pos + 1;      // (scalar load: see k_dec_attn)
     int j0, j1; dec_split_range(n_ctx, ws.nsplits, sidx, j0, j1);
     const int group = P.heads / P.kv_heads, kvh = h / group;
     const bool has_new = pos >= j0 && pos < j1;             // this split owns the new token's row
@@ -1390,7 +1404,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
     float *opart = red + 8;                                          // [NSPLIT][HD]
     half_t *Pl = reinterpret_cast<half_t *>(opart + NSPLIT * HD);    // this split's probabilities
     const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = P.state[1], n_ctx = pos + 1;
+    const int pos = *(const __attribute__((address_space(4))) int *)(P.state + 1), n_ctx = pos + 1;      // (scalar load: see k_dec_attn)
     int j0, j1; dec_split_range(n_ctx, ws.nsplits, sidx, j0, j1);
     const int group = P.heads / P.kv_heads, kvh = h / group;
     const int kv_dim = P.kv_heads * HD;
