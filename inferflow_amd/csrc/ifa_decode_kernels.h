@@ -236,7 +236,18 @@ struct XPre {
             }
             __syncthreads();
             if (trc) trc[5] = wall_clock64();
-            scale = rms_scale_of(rms_total(L.part, (chunks + 63) >> 6), cols, eps);
+            // the group sums in ascending order (rms_total's order), read as 16-byte words with the groups past the row end
+            // masked to +0 (exact): a loop over the runtime group count was one dependent LDS round trip per group
+            const int ng = (chunks + 63) >> 6;
+            float total = 0.0f;
+            typedef float f4p __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int v4 = 0; v4 < 4 * MAXC; v4++) {          // <= 16 waves x MAXC chunks per thread
+                const f4p p = reinterpret_cast<const f4p *>(L.part)[v4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) total = total + ((v4 * 4 + i) < ng ? p[i] : 0.0f);
+            }
+            scale = rms_scale_of(total, cols, eps);
             if (trc) trc[6] = wall_clock64();
         } else {
             if (trc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
@@ -1565,8 +1576,13 @@ static __global__ void __launch_bounds__(1024) k_dec_argmax_advance(const half_t
 {
     __shared__ float bv[16];
     __shared__ int bi[16];
-    const int ne = min(max(state[3], 0), 3);
-    const int e0 = ne > 0 ? state[4] : -1, e1 = ne > 1 ? state[5] : -1, e2 = ne > 2 ? state[6] : -1;
+    // the state words through the constant address space: ONE scalar request next to the scan's vector loads (as vector loads they
+    // were two dependent cold round trips in front of the scan and a third behind it)
+    const __attribute__((address_space(4))) int *cs = (const __attribute__((address_space(4))) int *)state;
+    const int st_pos = cs[1], st_step = cs[2];
+    const int ne = min(max(cs[3], 0), 3);
+    const int x4 = cs[4], x5 = cs[5], x6 = cs[6];
+    const int e0 = ne > 0 ? x4 : -1, e1 = ne > 1 ? x5 : -1, e2 = ne > 2 ? x6 : -1;
     float best = -INFINITY; int besti = 0x7FFFFFFF;
     argmax_scan(v, (size_t)n, e0, e1, e2, (int)threadIdx.x, (int)blockDim.x, best, besti);
 #pragma unroll
@@ -1581,10 +1597,10 @@ static __global__ void __launch_bounds__(1024) k_dec_argmax_advance(const half_t
         for (int w = 1; w < (int)(blockDim.x >> 6); w++)
             if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
         if (besti == 0x7FFFFFFF) besti = 0;
-        const int step = state[2];
+        const int step = st_step;
         state[8 + (step % ring)] = besti;
         state[0] = besti;
-        state[1] = state[1] + 1;
+        state[1] = st_pos + 1;
         state[2] = step + 1;
     }
 }
