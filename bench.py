@@ -88,6 +88,71 @@ def reference_cpu_baseline(n_tokens=128):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def reference_cpu_baseline_7b_width(n_tokens=12, layers=1):
+    """The reference's CPU path on the HEADLINE model's widths: a `layers`-layer Llama-2-7B-shaped llama2.c checkpoint
+    (F32 weights: what its CPU side runs; all 32 layers would be a 27 GB file per bench run), with this engine on the same file
+    (Q4 weights, F16 KV cache: the headline formats) next to it."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import oracle as o
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen_model_fixtures as gmf
+    from inferflow_amd.engine import InferenceEngine
+    from tests import engine_fixtures as fx
+    if not os.path.exists(gmf.DRIVER):
+        raise RuntimeError("oracle/_ref/ifa_ref_engine is not built (needs /root/reference at build time)")
+    shape = dict(dim=4096, layers=layers, heads=32, kv_heads=32, head_dim=128, ffn=11008, vocab=32000)
+    threads = min(o.usable_cpus(), 16)
+    d = tempfile.mkdtemp(prefix="ifa_ref_cpu7b_")
+    try:
+        # the checkpoint in the llama2.c layout (model_reader.cc:3248-3430), written tensor by tensor from the fast float32 generator
+        # (tests/engine_fixtures.make_weights draws float64: half a minute for 0.33 G values)
+        import struct
+        rng = np.random.default_rng(16)
+        ctx = 128
+        with open(os.path.join(d, "model.bin"), "wb") as f:
+            f.write(struct.pack("<7i", shape["dim"], shape["ffn"], layers, shape["heads"], shape["kv_heads"], shape["vocab"], ctx))      # vocab > 0: shared classifier
+            f.write((rng.standard_normal((shape["vocab"], shape["dim"]), dtype=np.float32) * 0.02).tobytes())
+            for tid, kind in fx.KINDS:
+                for l in range(layers):
+                    r_, c_ = fx._shape(kind, shape)
+                    t = rng.standard_normal((r_, c_), dtype=np.float32) * 0.02
+                    f.write(((1.0 + t) if kind == "norm" else t).tobytes())
+            f.write(np.ones((1, shape["dim"]), np.float32).tobytes())
+            f.write(b"\0" * (ctx * shape["head_dim"]))
+        gmf.write_tokenizer(os.path.join(d, "tokenizer.bin"), shape["vocab"])
+        spec = json.loads(json.dumps(fx.SPEC)); spec["tokenizer_file"] = "tokenizer.bin"; spec["qkv_format"] = 1
+        json.dump(spec, open(os.path.join(d, "model_spec.json"), "w"))
+        ini = os.path.join(d, "engine.ini")
+        open(ini, "w").write(gmf.REF_INI.format(ctx=ctx).replace("cpu_threads = 4", "cpu_threads = %d" % threads).replace("return_output_tensors = true", "return_output_tensors = false"))
+        prompt = np.random.default_rng(16).integers(3, shape["vocab"], 4).astype(np.int32)
+        r = gmf.run_reference(ini, prompt, n_tokens + 1, quiet=True)
+        ref_tok_s = n_tokens / (r["decode_ms"] / 1e3)
+        # this engine on the very same model.bin (same directory, its own .ini): Q4 weights quantised at load, F16 cache
+        gini = os.path.join(d, "engine_gpu.ini")
+        open(gini, "w").write(fx.INI.format(name="ref7b", wd="Q4", kvd="F16", thr=0, ctx=128, ret="false", maxq=2, devices="0", force_partition="false"))
+        eng = InferenceEngine.from_ini(gini)
+        qid = eng.add_query(prompt)
+        (q, tok), = eng.infer()
+        eng.commit({qid: tok})
+        eng.generate(qid, 8)
+        t0 = time.perf_counter()
+        eng.generate(qid, 64)
+        gpu_tok_s = 64 / (time.perf_counter() - t0)
+        eng.close()
+        bytes_tok = (layers * (4 * 4096 * 4096 + 3 * 4096 * 11008) + 32000 * 4096) * 4
+        return {"value": ref_tok_s, "unit": "tokens/s", "cores": threads, "kind": "reference",
+                "sample": "the reference's CPU path (oracle/_ref/ifa_ref_engine) on a %d-layer Llama-2-7B-WIDTH llama2.c checkpoint (d 4096, ffn 11008, "
+                          "32 heads, vocab 32000, shared classifier, F32 weights: %.2f GB read per token = %.1f GB/s), 4-token prompt + %d greedy "
+                          "tokens, cpu_threads %d" % (layers, bytes_tok / 1e9, bytes_tok * ref_tok_s / 1e9, n_tokens, threads),
+                "gpu_same_checkpoint_tok_s": gpu_tok_s,
+                "note": "a %d-layer slice of the headline shape (layers + shared classifier), not the headline workload: the 32-layer model streams %.1fx these bytes per token" % (
+                    layers, ((32 * (4 * 4096 * 4096 + 3 * 4096 * 11008) + 32000 * 4096) * 4) / float(bytes_tok))}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 class Watchdog:
     """A hang in communicator setup or in a collective must not cost the whole scaling record: every rank watches its own
     progress and, when a phase overruns its limit, rank 0 prints ONE JSON line with an "error" key (the driver's contract)
@@ -509,6 +574,11 @@ def main():
             out["cpu_baseline_reference"] = reference_cpu_baseline()
         except Exception as e:
             out["cpu_baseline_reference"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
+        if args.shape == "llama2_7b":
+            try:
+                out["cpu_baseline_reference_7b_width"] = reference_cpu_baseline_7b_width()
+            except Exception as e:
+                out["cpu_baseline_reference_7b_width"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
     sys.stdout.flush()
     try:                                   # C stdio too: RCCL's banner sits in libc's buffer while fd 1 points at stderr; flushed
         import ctypes                      # after the restore it would land on the real stdout next to the JSON line
