@@ -348,12 +348,29 @@ class CTPRunner:
             # first mode and compares a few steps against the RCCL path before timing with it.
             self.oneshot_ipc = False
             if os.environ.get("IFA_ONESHOT_IPC") == "1" and tp_size > 1 and world > 1:
-                mine = torch.frombuffer(bytearray(self.tp_comm.oneshot_export()), dtype=torch.uint8).to(dev)
+                # every step below is taken by EVERY rank whatever happened to it locally (a rank that skipped a collective would
+                # strand the others), and the outcome is agreed: one failure anywhere keeps RCCL everywhere
+                ok, handle = 1, bytes(128)
+                try:
+                    handle = self.tp_comm.oneshot_export()
+                except Exception:      # noqa: BLE001
+                    ok = 0
+                mine = torch.frombuffer(bytearray(handle), dtype=torch.uint8).to(dev)
                 allh = [torch.zeros(128, dtype=torch.uint8, device=dev) for _ in range(world)]
-                dist.all_gather(allh, mine)                                    # collective over the job: every rank takes part
-                base = self.stage * tp_size
-                self.tp_comm.oneshot_import(b"".join(bytes(allh[base + r].cpu().numpy().tobytes()) for r in range(tp_size)))
-                self.oneshot_ipc = self.tp_comm.oneshot()
+                dist.all_gather(allh, mine)
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()):
+                    base = self.stage * tp_size
+                    try:
+                        self.tp_comm.oneshot_import(b"".join(bytes(allh[base + r].cpu().numpy().tobytes()) for r in range(tp_size)))
+                    except Exception:      # noqa: BLE001
+                        ok = 0
+                    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                self.oneshot_ipc = bool(int(flag.item())) and self.tp_comm.oneshot()
+                if not self.oneshot_ipc:
+                    self.tp_comm.set_oneshot(0)
         self.worker, self.shape, self.local_shape = build_tp_worker(
             shape_name, wdtype, kv_dtype, max_ctx, tp_size, self.tp_rank, device=local_rank, layer_range=ranges[self.stage],
             first_stage=self.stage == 0, last_stage=self.stage == groups - 1, **overrides)
