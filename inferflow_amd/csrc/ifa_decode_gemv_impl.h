@@ -31,6 +31,16 @@ namespace ifa {
 #define IFA_T_RW_W2 0
 #endif
 
+#ifndef IFA_T_NP_QKV
+#define IFA_T_NP_QKV -1
+#endif
+#ifndef IFA_T_NP_GLU
+#define IFA_T_NP_GLU -1
+#endif
+#ifndef IFA_T_NP_W2
+#define IFA_T_NP_W2 -1
+#endif
+
 // which of the four per-layer kernels a template instance is (by epilogue / prologue), for the overrides above
 constexpr int dec_role(int epi, int norm) { return epi == EPI_GLU ? 2 : (epi == EPI_RESIDUAL ? (norm == 2 ? 1 : 3) : (epi == EPI_PLAIN && norm == 1 ? 0 : -1)); }
 
@@ -80,7 +90,24 @@ constexpr int dec_threads(int epi, int norm, int nj, bool xadd)
     }
     if ((DT == Q3H_B64T1 || DT == Q4_B64T1 || DT == Q5_B64T1) && nj == 1 && !xadd && epi == EPI_GLU) return 1024;          // (see dec_rw)
     if (DT == Q8_B32T2 && nj == 2 && !xadd && epi == EPI_GLU) return 1024;
+    if (DT == Q4_B32T1A && nj == 2 && !xadd && epi == EPI_PLAIN && norm == 1) return 1024;      // QKV with the wave-specialised prologue (r04 sweep: 8.8 -> 8.3 us)
     return (DT == Q4_B32T1A && nj == 2 && !xadd && (epi == EPI_GLU || (epi == EPI_RESIDUAL && norm == 0))) ? 1024 : DEC_THREADS;
+}
+
+// waves that run the norm / quantiser prologue while the others already stream their rows (k_dec_gemv's NP; 0 = every wave
+// takes part in the prologue, the round 1-3 form).  Only the dense per-layer kernels with a prologue.
+template <int DT>
+constexpr int dec_np(int epi, int norm, int nj, bool xadd, int th)
+{
+    if (xadd || norm == 2) return 0;
+    const int role = dec_role(epi, norm);
+    const int forced = role == 0 ? IFA_T_NP_QKV : role == 2 ? IFA_T_NP_GLU : role == 3 ? IFA_T_NP_W2 : -1;
+    if (forced >= 0) return forced < th / 64 ? forced : 0;
+    // round-4 sweep on Llama-2-7B Q4 (gpurun_out sweeps, DESIGN.md section 3 "wave-specialised prologue"): half of the waves
+    // run the prologue -- QKV 9.6 -> 8.2-8.5 us (1024 threads), W1/W3 13.1 -> 12.95, W2 9.05 -> 8.0-8.1 (512 threads);
+    // a quarter or three quarters of the waves lose (the prologue's VALU time, or too few early requests)
+    if (role == 0 || role == 2 || role == 3) return th / 128;
+    return 0;
 }
 
 template <int DT, int EPI, int NORM, bool XADD = false>
@@ -127,7 +154,8 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
 #define IFA_DG(NJV) \
     case NJV: if constexpr (NJV <= DecGemvLimits<DT>::MAXNJ && NJV <= NJCAP) { \
         constexpr int THV = dec_threads<DT>(EPI, NORM, NJV, XADD); \
-        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(EPI, NORM, NJV, NM, THV), EPI, NORM, XADD, THV>; \
+        constexpr int NPV = dec_np<DT>(EPI, NORM, NJV, XADD, THV); \
+        auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(EPI, NORM, NJV, NM, THV), EPI, NORM, XADD, THV, NPV>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         kern<<<grid, dim3(THV), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, P); } break;
     switch (nj) { IFA_DG(1) IFA_DG(2) IFA_DG(3) IFA_DG(4) IFA_DG(5) IFA_DG(6) IFA_DG(7) IFA_DG(8) }

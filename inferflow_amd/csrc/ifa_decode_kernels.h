@@ -160,8 +160,27 @@ __host__ __device__ inline XqImage xq_image_carve(void *base, int cols)
 // XADD: the activation is the sum x + (add [+ add_bias]) of two vectors (tensor parallelism: layer input + the
 // all-reduced product, bias once after the merge); the sum -- two half additions in TensorOpr::Add order -- replaces x
 // and workgroup 0 stores it for the residual that follows.
-template <int NORM, int MAXC, bool XADD = false>
+// NT > 0 (wave-specialised kernels, k_dec_gemv<.., NP>): only threads [0, NT) -- the workgroup's first NT / 64 waves -- run the
+// prologue; they synchronise with each other through two LDS counters (part[130]: partial sums written, part[131]: codes
+// written) instead of s_barrier, so that the OTHER waves can sit behind their weight requests without holding the prologue
+// up, and everybody waits for part[131] == NT / 64 before reading the image (xpre_wait_image).  Same chunk -> lane / group
+// assignment rule (chunk c = tid + k * threads: lane c % 64 of group c / 64), so the statistics and the codes are the
+// same bits for any NT.
+__device__ __forceinline__ void lds_counter_add(float *slot)
+{
+    asm volatile("" ::: "memory");      // the wave's earlier LDS writes stay ahead of the counter (the LDS performs a wave's accesses in order)
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(slot), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_counter_wait(float *slot, uint32_t target)
+{
+    volatile uint32_t *c = reinterpret_cast<volatile uint32_t *>(slot);
+    while (__builtin_amdgcn_readfirstlane(*c) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+template <int NORM, int MAXC, bool XADD = false, int NT = 0>
 struct XPre {
+    static __device__ __forceinline__ int nthr() { return NT ? NT : (int)blockDim.x; }
     half8_t xv[MAXC];
     half8_t wv[NORM ? MAXC : 1], bv[NORM ? MAXC : 1];
     half8_t av[XADD ? MAXC : 1], abv[XADD ? MAXC : 1];
@@ -201,7 +220,7 @@ struct XPre {
         const int chunks = cols >> 3;
 #pragma unroll
         for (int k = 0; k < MAXC; k++) {
-            const int c = threadIdx.x + k * (int)blockDim.x;
+            const int c = threadIdx.x + k * nthr();
             if (c < chunks) {
                 xv[k] = *reinterpret_cast<const half8_t *>(x + (size_t)c * 8);
                 if constexpr (NORM == 1) {
@@ -222,10 +241,10 @@ struct XPre {
         if constexpr (NORM == 1) {
             // sum of squares in the canonical order of ifa_math.h: chunk c = tid + k*blockDim is lane c % 64 of group
             // c / 64 = wave + k * (blockDim / 64); no staging of x, one barrier
-            const int lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+            const int lane = tid & 63, wave = tid >> 6, nwaves = nthr() >> 6;
 #pragma unroll
             for (int k = 0; k < MAXC; k++) {
-                const int c = tid + k * (int)blockDim.x;
+                const int c = tid + k * nthr();
                 half8_t v8 = xv[k];
                 if (c >= chunks) {
 #pragma unroll
@@ -234,7 +253,8 @@ struct XPre {
                 const float pg = wave_sum(rms_chunk_sq(v8));
                 if (lane == 0) L.part[wave + k * nwaves] = pg;
             }
-            __syncthreads();
+            if constexpr (NT > 0) { if (lane == 0) lds_counter_add(L.part + 130); lds_counter_wait(L.part + 130, NT / 64); }
+            else __syncthreads();
             if (trc) trc[5] = wall_clock64();
             // the group sums in ascending order (rms_total's order), read as 16-byte words with the groups past the row end
             // masked to +0 (exact): a loop over the runtime group count was one dependent LDS round trip per group
@@ -254,7 +274,7 @@ struct XPre {
         }
 #pragma unroll
         for (int k = 0; k < MAXC; k++) {
-            const int c = tid + k * (int)blockDim.x;
+            const int c = tid + k * nthr();
             if (c >= chunks) continue;       // whole quads (4 lanes = one block) are in or out together
             float v[8];
             if constexpr (NORM == 1) {
@@ -297,7 +317,8 @@ struct XPre {
                 L.xsum[c >> 2] = (float)s;
             }
         }
-        __syncthreads();
+        if constexpr (NT > 0) { if ((tid & 63) == 0) lds_counter_add(L.part + 131); }
+        else __syncthreads();
     }
 };
 
@@ -526,7 +547,12 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
 //      (bias / residual / activation) so the epilogue's loads overlap too.
 // TH = threads per workgroup: 512 (two waves per SIMD, 256 registers each) or 1024 (four waves per SIMD, 128 registers, half
 // the rows in flight per wave) -- chosen per kernel shape by the launcher (ifa_decode_gemv_impl.h)
-template <int DT, int NJ, int RW, int EPI, int NORM, bool XADD = false, int TH = DEC_THREADS>
+// NP > 0: WAVE-SPECIALISED prologue (round 4).  Waves [0, NP) request the activation, run the norm + quantiser among
+// themselves (LDS counters, XPre<.., NT>) and only then request their rows; waves [NP, TH/64) request ALL their rows right
+// after the first barrier and wait for the image behind them.  In the classic form every wave takes part in the prologue's
+// barriers, so at most D1 rows per wave (what the CU's memory queue accepts without blocking) can be in flight while the
+// activation arrives and is quantised -- the stream had a hole of 2-2.5 us per launch (profiles/r04_*trace*).
+template <int DT, int NJ, int RW, int EPI, int NORM, bool XADD = false, int TH = DEC_THREADS, int NP = 0>
 __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols,
                                                           const DecGemvParams P)
 {
@@ -534,11 +560,13 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     // -amdgpu-kernarg-preload-count they arrive in SGPRs at wave launch, so the activation requests -- the head of
     // the kernel's critical path -- do not wait for the first scalar load of the argument block
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(NP == 0 || (NORM != 2 && !XADD && NP * 64 < TH), "wave-specialised prologue: a norm / quantiser prologue, some loader waves");
     // the activation requests go out first, from preloaded arguments only (nothing here waits for a scalar load)
-    constexpr int MAXC = NORM == 2 ? 1 : (NJ * 8 * block_capacity(DT) + TH - 1) / TH;      // cols <= 64 * capacity * NJ: chunks of 8 per thread
-    XPre<NORM == 2 ? 0 : NORM, MAXC, XADD> pre;
+    constexpr int PT = NP ? NP * 64 : TH;                                                 // threads that run the prologue
+    constexpr int MAXC = NORM == 2 ? 1 : (NJ * 8 * block_capacity(DT) + PT - 1) / PT;      // cols <= 64 * capacity * NJ: chunks of 8 per thread
+    XPre<NORM == 2 ? 0 : NORM, MAXC, XADD, NP * 64> pre;
     if constexpr (NORM != 2) {
-        pre.issue(px, pnw, pnb, pcols);
+        if (NP == 0 || threadIdx.x < PT) pre.issue(px, pnw, pnb, pcols);
         if constexpr (XADD) pre.issue_add(P.x_add, P.x_add_bias, pcols);
     }
     const long long t_start = wall_clock64();
@@ -631,6 +659,23 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     } else {
         // the CU's memory queue is FIFO across waves: make sure every wave's activation
         // request is queued before ANY wave floods it with weight requests
+        if constexpr (NP > 0) {
+            if (threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }      // the two LDS counters (bit pattern of +0)
+            __syncthreads();
+            if (wave >= NP) {
+                load_rows(0, 0, RW);
+                load_epi(0);
+                if (P.trace != nullptr && threadIdx.x == NP * 64 && NORM == 1) P.trace[blockIdx.x * 8 + 4] = wall_clock64();
+            } else {
+                if (tr) P.trace[blockIdx.x * 8 + 1] = wall_clock64();
+                pre.finish(P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out,
+                           (P.trace != nullptr && threadIdx.x == 0) ? P.trace + blockIdx.x * 8 : nullptr);
+                load_rows(0, 0, RW);
+                load_epi(0);
+                if (tr) P.trace[blockIdx.x * 8 + 2] = wall_clock64();
+            }
+            lds_counter_wait(L.part + 131, NP);
+        } else {
         __syncthreads();
         load_rows(0, 0, D1);
         if (tr) P.trace[blockIdx.x * 8 + 1] = wall_clock64();
@@ -640,6 +685,7 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         load_rows(0, D1, RW);
         load_epi(0);
         if (tr) P.trace[blockIdx.x * 8 + 2] = wall_clock64();
+        }
         if (gw >= P.total_rows) return;
         X.load(L.codes, L.scale, L.xsum, lane, P.nblk);
     }
