@@ -56,6 +56,32 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+_INC_RE = None
+
+
+def local_deps(src, _seen=None):
+    """The csrc / include headers a translation unit pulls in (recursive scan of #include "..."), so that a header edit only
+    rebuilds the units that see it (the per-format GEMV units take ~2 min each)."""
+    global _INC_RE
+    import re
+    if _INC_RE is None:
+        _INC_RE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+    seen = _seen if _seen is not None else set()
+    try:
+        text = open(src, errors="replace").read()
+    except OSError:
+        return seen
+    for name in _INC_RE.findall(text):
+        for d in (os.path.dirname(src), CSRC, os.path.join(_HERE, "..", "include")):
+            cand = os.path.normpath(os.path.join(d, name))
+            if os.path.exists(cand):
+                if cand not in seen:
+                    seen.add(cand)
+                    local_deps(cand, seen)
+                break
+    return seen
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -84,8 +110,9 @@ def build_library(force=False, verbose=False, jobs=None):
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
+        dep_t = max([os.path.getmtime(h) for h in local_deps(src)] + [0])
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
-                and os.path.getmtime(obj) > hdr_t):
+                and os.path.getmtime(obj) > dep_t):
             continue
         cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_HERE, "..", "include"), "-c", src, "-o", obj]
         if verbose:

@@ -899,662 +899,7 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_f16(const DecLmHeadP
     }
 }
 
-// ------------------------------------------------------------------ attention
-struct DecAttnParams {
-    const half_t *q;           // [heads*head_dim]   pre-RoPE
-    const half_t *k_new;       // [kv_heads*head_dim] pre-RoPE
-    const half_t *v_new;       // [kv_heads*head_dim]
-    uint8_t *kcache, *vcache;  // [max_ctx][kv_row_bytes]
-    const int *state;          // state[1] = position of the new token
-    const float *rope_tab;     // [head_dim/2][2] cos,sin of this step (k_dec_gather)
-    int heads, kv_heads, kv_q8;
-    float kq_scale;
-    int rope_order, rope_cols;
-    int alibi, alibi_base, alibi_total;
-    half_t *out;               // [heads*head_dim]
-    int max_ctx;
-    int8_t *xq;                // optional XqImage of `out` (Q8_B32T2, the quantiser the Wo GEMV would run in its prologue)
-    long long *trace;          // optional [heads][8] wall-clock stamps (100 MHz) for tuning
-    // batched step (k_dec_attn<.., BATCH = true>, grid (heads, queries)): query b reads q|k|v at q + b * q_stride, its cache
-    // pointers and context from batch_rows[b], its RoPE pairs at rope_tab + b * head_dim, and writes out + b * heads * head_dim
-    const void *batch_rows;    // DecAttnBatchRow[queries]
-    int q_stride;
-};
-struct DecAttnBatchRow { const uint8_t *kc, *vc; int n_ctx, pad; };
-
-// Quantize(kqv_merged) (inference_worker.cc:1339-1346) done where the vector is produced: a head is HD/32 whole
-// Q8_B32T2 blocks, so the blocks are local to the head's workgroup and the codes are those of the Alg2 quantizer
-// (tensor_quant.h:44-82) bit for bit.  Called by threads [0, HD) of the workgroup of head h with their output value.
-template <int HD>
-__device__ __forceinline__ void dec_attn_emit_q8(int8_t *xq, int cols, int h, int d, half_t yh)
-{
-    const XqImage Q = xq_image_carve(xq, cols);
-    const float val = h2f(yh);
-    const float mx = half_wave_max(fabsf(val));
-    const float qs = mx / 127;
-    const int qv = q8_round_div1(val, qs);
-    const int sum = half_wave_sum_i32(qv);
-    Q.codes[(size_t)h * HD + d] = (int8_t)qv;
-    if ((d & 31) == 0) {
-        const int blk = (h * HD + d) >> 5;
-        Q.scale[blk] = h2f(f2h(qs));
-        Q.xsum[blk] = (float)sum;
-    }
-}
-
-// rotate one pair with a precomputed (cos, sin); same expressions as rope_rotate
-__device__ __forceinline__ void rope_apply(half_t *row, int col, float c, float s, int order, int rope_cols)
-{
-    int i0, i1;
-    if (order == 2) { if (2 * col >= rope_cols) return; i0 = col; i1 = col + rope_cols / 2; }
-    else { i0 = 2 * col; i1 = 2 * col + 1; }
-    const float x0 = h2f(row[i0]), x1 = h2f(row[i1]);
-    float a = x0 * c, bq = x1 * s, d = x0 * s, e = x1 * c;
-    row[i0] = f2h(a - bq);
-    row[i1] = f2h(d + e);
-}
-
-// One workgroup (256 threads) per query head.
-//  * K rows: one key per lane, whole row slice in registers (loads issued at
-//    kernel entry, before q/k/v staging), fp32 fma in d order == Gemm_Alg2 order,
-//    so S is bit-exact with the reference arithmetic.
-//  * V rows: thread (d-group of 8, key residue mod 256/(HD/8)); loads for the
-//    first key chunk are also issued at entry.  Partials are combined in a fixed
-//    order through LDS.
-//  * the new token's K/V never round-trip through HBM: they come from LDS and are
-//    written to the cache by the first head of each KV group.
-// pq / pkc / pvc / pheads / pkvh repeat the new token's q|k|v vector (ONE buffer: q, then k at + heads*HD, then v at
-// + (heads + kv_heads)*HD), the layer's K / V cache and the head counts as leading scalar arguments: a by-value struct is
-// fetched with scalar loads (cold after every kernel boundary), these 8 dwords are preloaded into SGPRs at wave launch, so
-// the q / k / v values and the first 256 K / V rows are requested with the kernel's first instructions.  The caches hold
-// at least DEC_ATTN_MIN_ROWS rows (the engine pads the allocation), so that first chunk needs no clamp.
-constexpr int DEC_ATTN_MIN_ROWS = 256;
-
-template <int HD, bool Q8, bool BATCH = false>
-__global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_t *pkc, const uint8_t *pvc, int pheads, int pkvh,
-                                                  const DecAttnParams P)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int pos_b = 0;
-    if constexpr (BATCH) {      // the query's cache pointers and position come from the step's table (one scalar fetch)
-        const DecAttnBatchRow br = reinterpret_cast<const DecAttnBatchRow *>(P.batch_rows)[blockIdx.y];
-        pkc = br.kc; pvc = br.vc; pos_b = br.n_ctx - 1;
-        pq += (size_t)blockIdx.y * P.q_stride;
-    }
-    // The cache rows are read through pointers whose address space is STATED (IFA_GP): in the batched step they come from the
-    // table in memory, and the FLAT loads the compiler emits for a pointer of unknown origin also count on lgkmcnt -- every LDS
-    // wait of the score / softmax phases then waited for the K / V requests in flight
-#define IFA_GP(T, p) ((const __attribute__((address_space(1))) T *)(p))
-    uint8_t *const kcw = BATCH ? const_cast<uint8_t *>(pkc) : P.kcache;      // the cache rows this workgroup may write
-    uint8_t *const vcw = BATCH ? const_cast<uint8_t *>(pvc) : P.vcache;
-    const float *const rope_tab = BATCH ? P.rope_tab + (size_t)blockIdx.y * HD : P.rope_tab;
-    half_t *const outp = BATCH ? P.out + (size_t)blockIdx.y * pheads * HD : P.out;
-    static_assert(HD % 8 == 0 && HD <= 128 && (!Q8 || HD % 32 == 0), "head size: multiples of 8 up to 128 (Q8 rows: whole 32-blocks)");
-    constexpr int DG = HD / 8;            // threads covering one V row (8 dims each)
-    constexpr int NSPLIT = 256 / DG;      // key residues handled in parallel (head sizes 48 / 80 / 96: the last 256 % DG threads idle)
-    half_t *qs = reinterpret_cast<half_t *>(smem);                 // [HD] rotated q
-    half_t *kn = qs + HD;                                          // [HD] rotated (and Q8 round-tripped) new k
-    half_t *vn = kn + HD;                                          // [HD] new v (Q8 round-tripped)
-    float *red = reinterpret_cast<float *>(vn + HD);               // [16]
-    float *opart = red + 16;                                       // [NSPLIT][HD]
-    half_t *S = reinterpret_cast<half_t *>(opart + NSPLIT * HD);   // [n_ctx]
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int group = pheads / pkvh;
-    const int kvh = h / group;
-    const bool writer = (h % group) == 0;
-    const int kv_dim = pkvh * HD;
-    const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
-    const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
-
-    // ---- issue the new token's values, then the first chunk of K (key = tid) and V loads before anything else.  Keys
-    // past the context are loaded too (never used) instead of being masked off: loads under an exec mask make every later
-    // wait a vmcnt(0), and the position comes from device memory -- nothing here waits for it, or for the argument block
-    // Q8 rows: a head's slice is (HD/32)*34 bytes, 8-byte aligned for HD=128, 4-byte for HD=64, 2-byte for HD=32
-    constexpr int KBYTES = (HD / 32) * 34;
-    constexpr int KALIGN = HD == 128 ? 8 : (HD == 64 ? 4 : 2);
-    uint32_t kreg[Q8 ? 1 : HD / 2];
-    uint32_t kq32[(Q8 && KALIGN >= 4) ? KBYTES / 4 : 1];
-    uint16_t kq16[(Q8 && KALIGN < 4) ? KBYTES / 2 : 1];
-    auto load_k = [&](int j) {
-        const uint8_t *rowp = pkc + (size_t)j * row_bytes + head_off;
-        if constexpr (Q8) {
-            if constexpr (KALIGN == 8) {
-#pragma unroll
-                for (int i = 0; i < KBYTES / 8; i++) {
-                    const u32x2 t = IFA_GP(u32x2, rowp)[i];
-                    kq32[2 * i] = t[0]; kq32[2 * i + 1] = t[1];
-                }
-            } else if constexpr (KALIGN == 4) {
-#pragma unroll
-                for (int i = 0; i < KBYTES / 4; i++) kq32[i] = IFA_GP(uint32_t, rowp)[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < KBYTES / 2; i++) kq16[i] = IFA_GP(uint16_t, rowp)[i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < HD / 8; i++) {
-                const u32x4 t = IFA_GP(u32x4, rowp)[i];
-                kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
-            }
-        }
-    };
-    // byte B (compile-time) of the Q8 slice held in registers
-    auto kbyte = [&](int B) -> uint32_t {
-        if constexpr (KALIGN >= 4) return (kq32[B >> 2] >> (8 * (B & 3))) & 0xFFu;
-        else return (kq16[B >> 1] >> (8 * (B & 1))) & 0xFFu;
-    };
-    // the new token's q / k / v values and this step's (cos, sin) pair FIRST: loads return in issue order, and behind the
-    // 128 KB of K / V rows below these few bytes arrived 1.5 us later than they had to (phase stamps)
-    const int dq = min(tid, HD - 1);
-    const half_t q_in = pq[(size_t)h * HD + dq], k_in = pq[(size_t)(pheads + kvh) * HD + dq], v_in = pq[(size_t)(pheads + pkvh + kvh) * HD + dq];
-    // (tid < DEC_ATTN_MIN_ROWS <= rows of the cache.)  Batched step: the position arrived with the cache pointers, so rows past
-    // the context are clamped to the last one (duplicate addresses: one cache line) -- unclamped, every (head, query) workgroup
-    // pulled 2 x 64 KB of cache rows whatever its context: 134 MB per layer at 32 queries, the whole cost of that launch
-    load_k(BATCH ? min(tid, pos_b) : tid);
-    // this step's (cos, sin) pair of the thread that will rotate: requested BETWEEN the K and the V rows -- behind both it was the
-    // newest request, and the rotation waited (vmcnt(0)) for the whole prefetch; unconditional (a valid dummy address without RoPE)
-    float rope_cs = 1.0f, rope_sn = 0.0f;
-    {
-        const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
-        const float *rt = rope_tab ? rope_tab : reinterpret_cast<const float *>(pq);
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 cs = *IFA_GP(f32x2, rt + 2 * c);
-        if (P.rope_order != 0) { rope_cs = cs[0]; rope_sn = cs[1]; }
-    }
-    const int dg = tid % DG, sp = tid / DG;
-    const bool vact = (256 % DG == 0) || sp < NSPLIT;   // this thread takes part in P.V
-    constexpr int VPRE = 256 / NSPLIT;                  // prefetched V keys per thread: j = sp + NSPLIT*i (256 keys)
-    u32x4 vreg[Q8 ? 1 : VPRE];
-    uint16_t vq[Q8 ? VPRE : 1][5];                      // Q8: {scale, 4 x 2 codes} of this thread's 8 dims, 2-byte aligned
-    const size_t vq_off = head_off + (size_t)(dg / 4) * 34;
-#pragma unroll
-    for (int i = 0; i < VPRE; i++) {
-        const int j = min(sp + NSPLIT * i, BATCH ? pos_b : DEC_ATTN_MIN_ROWS - 1);
-        if constexpr (!Q8) {
-            vreg[i] = IFA_GP(u32x4, pvc + (size_t)j * row_bytes + head_off)[dg];
-        } else {
-            // the thread's 8 codes as ONE 8-byte request at a 2-byte-aligned address (global memory takes unaligned dwords): five
-            // 2-byte requests per key were 80 load instructions per thread ahead of everything else in the kernel
-            const auto *blk = IFA_GP(uint16_t, pvc + (size_t)j * row_bytes + vq_off);
-            typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
-            vq[i][0] = blk[0];
-            const u32x2_a2 cw = *IFA_GP(u32x2_a2, blk + 1 + (dg % 4) * 4);
-            vq[i][1] = (uint16_t)(cw[0] & 0xFFFFu); vq[i][2] = (uint16_t)(cw[0] >> 16);
-            vq[i][3] = (uint16_t)(cw[1] & 0xFFFFu); vq[i][4] = (uint16_t)(cw[1] >> 16);
-        }
-    }
-
-    // ---- everything below may wait for the argument block: the position, this step's (cos, sin) pair of the thread that
-    // will rotate (requested now, used after the staging barrier)
-    const bool tr = P.trace != nullptr && tid == 0;
-    if (tr) P.trace[h * 8 + 0] = wall_clock64();
-    // (a SCALAR load through the constant address space: as a vector load it was the newest request of the wave, and waiting for it
-    //  -- vmcnt(0) -- meant waiting for every K / V row requested above before the new token's values could even be staged)
-    const int pos = BATCH ? pos_b : *(const __attribute__((address_space(4))) int *)(P.state + 1);
-    const int n_ctx = pos + 1;
-    // ---- stage q, k_new, v_new; RoPE on q and k (TensorOpr::PositionEmbedding, F16 in/out)
-    if (tid < HD) { qs[tid] = q_in; kn[tid] = k_in; vn[tid] = v_in; }
-    __syncthreads();
-    if (tr) P.trace[h * 8 + 1] = wall_clock64();
-    if (P.rope_order != 0) {
-        if (tid < HD) {     // threads [0,HD/2) rotate q pairs, [HD/2,HD) rotate k pairs
-            const int c = tid < HD / 2 ? tid : tid - HD / 2;
-            rope_apply(tid < HD / 2 ? qs : kn, c, rope_cs, rope_sn, P.rope_order, P.rope_cols);
-        }
-        __syncthreads();
-    }
-    // ---- KV store of the new row (LayerKVCache::SetKRows/SetVRows, kv_cache.cc:159-249)
-    if constexpr (Q8) {
-        constexpr int NB = HD / 32;
-        // one 32-value block per HALF wave (HD = 128: the 4 + 4 blocks of the new k and v rows on the 8 half waves at once; the
-        // block maximum by DPP + one permute): two blocks per wave one after the other on 32 lanes with five LDS permutes each was
-        // 0.9 us of this kernel.  Same operations per element as before (the maximum does not depend on the order).
-        for (int b = wave * 2 + (lane >> 5); b < 2 * NB; b += 8) {
-            half_t *src = b < NB ? kn : vn;
-            const int bb = b < NB ? b : b - NB;
-            const int l32 = lane & 31;
-            {
-                const float val = h2f(src[bb * 32 + l32]);
-                const float mx = half_wave_max(fabsf(val));
-                const float sc = mx / 127;
-                int qv = sc <= 0.000001f ? 0 : (int)roundf(val / sc);
-                qv = min(max(qv, -128), 127);
-                const half_t sch = f2h(sc);
-                if (writer) {
-                    uint8_t *cache = b < NB ? kcw : vcw;
-                    uint8_t *blk = cache + (size_t)pos * row_bytes + head_off + (size_t)bb * 34;
-                    blk[2 + l32] = (uint8_t)(int8_t)qv;
-                    if (l32 == 0) *reinterpret_cast<uint16_t *>(blk) = __builtin_bit_cast(uint16_t, sch);
-                }
-                src[bb * 32 + l32] = f2h((float)qv * h2f(sch));   // dequantised value, as GetKRows returns it
-            }
-        }
-        __syncthreads();
-    } else {
-        if (writer && tid < HD) {
-            reinterpret_cast<half_t *>(kcw + (size_t)pos * row_bytes + head_off)[tid] = kn[tid];
-            reinterpret_cast<half_t *>(vcw + (size_t)pos * row_bytes + head_off)[tid] = vn[tid];
-        }
-    }
-
-    // ---- scores: one key per lane, fp32 fma in d order (Gemm_Alg2_Kernel order, products exact)
-    if (tr) P.trace[h * 8 + 2] = wall_clock64();
-    const float alpha = 1.0f / sqrtf((float)HD) / P.kq_scale;
-    const float mk = P.alibi ? alibi_slope(h + P.alibi_base, P.alibi_total) : 0.0f;
-    float lmax = -INFINITY;
-    for (int j = tid; j < n_ctx; j += 256) {
-        float c = 0.0f;
-        if (Q8 && j == pos) {
-            // the new token's (round-tripped) key: wide LDS reads into registers, then the same chain -- a scalar loop
-            // over LDS kept the whole workgroup waiting at the next barrier for ~0.7 us
-            uint32_t knr[HD / 2];
-#pragma unroll
-            for (int i = 0; i < HD / 8; i++) {
-                const u32x4 t = reinterpret_cast<const u32x4 *>(kn)[i];
-                knr[4 * i] = t[0]; knr[4 * i + 1] = t[1]; knr[4 * i + 2] = t[2]; knr[4 * i + 3] = t[3];
-            }
-#pragma unroll
-            for (int i = 0; i < HD / 2; i++) {
-                const half2_t k2 = __builtin_bit_cast(half2_t, knr[i]);
-                c = __builtin_fmaf(h2f(qs[2 * i]), (float)k2[0], c);
-                c = __builtin_fmaf(h2f(qs[2 * i + 1]), (float)k2[1], c);
-            }
-        } else {
-            if constexpr (!Q8) {
-                // the new token's key comes from LDS into the same registers (wide reads) and takes the common path: a
-                // scalar loop over LDS here kept the whole workgroup waiting at the next barrier for ~0.7 us
-                if (j == pos) {
-#pragma unroll
-                    for (int i = 0; i < HD / 8; i++) {
-                        const u32x4 t = reinterpret_cast<const u32x4 *>(kn)[i];
-                        kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
-                    }
-                } else if (j >= 256) load_k(j);      // later chunks: load now (first chunk was prefetched)
-            } else if (j >= 256) load_k(j);
-            if constexpr (Q8) {
-#pragma unroll
-                for (int b = 0; b < HD / 32; b++) {
-                    const uint16_t scb = (uint16_t)(kbyte(b * 34) | (kbyte(b * 34 + 1) << 8));
-                    if constexpr (KALIGN >= 4) {
-                        // four codes per dword (q8x4_dequant_h); a block's codes start at byte 34 b + 2 of the slice
-                        const half_t sch = __builtin_bit_cast(half_t, scb);
-                        const half2_t sc2 = {sch, sch};
-#pragma unroll
-                        for (int w4 = 0; w4 < 8; w4++) {
-                            const int B0 = b * 34 + 2 + 4 * w4;
-                            const uint32_t cw = (B0 & 3) == 0 ? kq32[B0 >> 2]
-                                : __builtin_amdgcn_alignbyte(kq32[(B0 >> 2) + 1 < (int)(sizeof(kq32) / 4) ? (B0 >> 2) + 1 : (B0 >> 2)], kq32[B0 >> 2], (B0 & 3));
-                            half2_t lo, hi;
-                            q8x4_dequant_h(cw, sc2, lo, hi);
-                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4]), (float)lo[0], c);
-                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 1]), (float)lo[1], c);
-                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 2]), (float)hi[0], c);
-                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 3]), (float)hi[1], c);
-                        }
-                    } else {
-                        const float sc = hbits2f(scb);
-#pragma unroll
-                        for (int i = 0; i < 32; i++) {
-                            const int qv = (int)(int8_t)kbyte(b * 34 + 2 + i);
-                            const float kvv = h2f(f2h((float)qv * sc));
-                            c = __builtin_fmaf(h2f(qs[b * 32 + i]), kvv, c);
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < HD / 2; i++) {
-                    const half2_t k2 = __builtin_bit_cast(half2_t, kreg[i]);
-                    c = __builtin_fmaf(h2f(qs[2 * i]), (float)k2[0], c);
-                    c = __builtin_fmaf(h2f(qs[2 * i + 1]), (float)k2[1], c);
-                }
-            }
-        }
-        half_t s = f2h(alpha * c);
-        if (P.alibi) { float a = (float)j * mk; s = f2h(a + h2f(s)); }
-        S[j] = s;
-        lmax = fmaxf(lmax, P.kq_scale * h2f(s));
-    }
-    if (tr) P.trace[h * 8 + 3] = wall_clock64();
-    lmax = wave_max(lmax);
-    if (lane == 0) red[wave] = lmax;
-    __syncthreads();
-    if (tr) P.trace[h * 8 + 4] = wall_clock64();
-    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float lsum = 0.0f;
-    for (int j = tid; j < n_ctx; j += 256) {
-        const float e = expf(P.kq_scale * h2f(S[j]) - mx);
-        lsum += e;
-        S[j] = f2h(e);
-    }
-    lsum = wave_sum(lsum);
-    if (lane == 0) red[4 + wave] = lsum;
-    __syncthreads();
-    const float inv = 1.0f / (((red[4] + red[5]) + red[6]) + red[7]);
-    for (int j = tid; j < n_ctx; j += 256) S[j] = f2h(h2f(S[j]) * inv);
-    __syncthreads();
-    if (tr) P.trace[h * 8 + 5] = wall_clock64();
-
-    // ---- O = P.V : thread (sp, dg) accumulates keys j = sp + NSPLIT*i for its 8 dims
-    float o[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) o[i] = 0.0f;
-    auto acc_v = [&](float pj, const u32x4 vv) {
-        const half8_t v8 = __builtin_bit_cast(half8_t, vv);
-#pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, (float)v8[e], o[e]);
-    };
-    auto acc_new = [&](float pj) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pj, h2f(vn[dg * 8 + e]), o[e]);
-    };
-    // 8 codes (four 2-byte pieces) of one Q8 V block times its scale, accumulated in element order
-    auto acc_q8w = [&](float pj, uint16_t scb, uint16_t c0, uint16_t c1, uint16_t c2, uint16_t c3) {
-        const half_t sch = __builtin_bit_cast(half_t, scb);
-        const half2_t sc2 = {sch, sch};
-        half2_t v01, v23, v45, v67;
-        q8x4_dequant_h((uint32_t)c0 | ((uint32_t)c1 << 16), sc2, v01, v23);
-        q8x4_dequant_h((uint32_t)c2 | ((uint32_t)c3 << 16), sc2, v45, v67);
-        o[0] = __builtin_fmaf(pj, (float)v01[0], o[0]); o[1] = __builtin_fmaf(pj, (float)v01[1], o[1]);
-        o[2] = __builtin_fmaf(pj, (float)v23[0], o[2]); o[3] = __builtin_fmaf(pj, (float)v23[1], o[3]);
-        o[4] = __builtin_fmaf(pj, (float)v45[0], o[4]); o[5] = __builtin_fmaf(pj, (float)v45[1], o[5]);
-        o[6] = __builtin_fmaf(pj, (float)v67[0], o[6]); o[7] = __builtin_fmaf(pj, (float)v67[1], o[7]);
-    };
-    auto acc_q8 = [&](float pj, int j) {
-        const auto *blk = IFA_GP(uint16_t, pvc + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34);
-        typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
-        const u32x2_a2 cw = *IFA_GP(u32x2_a2, blk + 1 + (dg % 4) * 4);      // (one unaligned 8-byte request: see the prefetch above)
-        acc_q8w(pj, blk[0], (uint16_t)(cw[0] & 0xFFFFu), (uint16_t)(cw[0] >> 16), (uint16_t)(cw[1] & 0xFFFFu), (uint16_t)(cw[1] >> 16));
-    };
-#pragma unroll
-    for (int i = 0; i < VPRE; i++) {        // first 256 keys: V rows already in registers (static indexing)
-        const int j = sp + NSPLIT * i;
-        if (j < n_ctx && vact) {
-            const float pj = h2f(S[j]);
-            if (j == pos) acc_new(pj);
-            else if constexpr (Q8) acc_q8w(pj, vq[i][0], vq[i][1], vq[i][2], vq[i][3], vq[i][4]);
-            else acc_v(pj, vreg[i]);
-        }
-    }
-    for (int j = vact ? sp + NSPLIT * VPRE : n_ctx; j < n_ctx; j += NSPLIT) {
-        const float pj = h2f(S[j]);
-        if (j == pos) acc_new(pj);
-        else if constexpr (Q8) acc_q8(pj, j);
-        else acc_v(pj, IFA_GP(u32x4, pvc + (size_t)j * row_bytes + head_off)[dg]);
-    }
-    if (vact) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
-    }
-    if (tr) P.trace[h * 8 + 6] = wall_clock64();
-    __syncthreads();
-    if (tid < HD) {
-        float acc = opart[tid];
-        for (int s2 = 1; s2 < NSPLIT; s2++) acc = acc + opart[s2 * HD + tid];
-        const half_t yh = f2h(acc);
-        outp[(size_t)h * HD + tid] = yh;
-        if constexpr (HD % 32 == 0 && !BATCH) { if (P.xq) dec_attn_emit_q8<HD>(P.xq, P.heads * HD, h, tid, yh); }
-    }
-    if (tr) P.trace[h * 8 + 7] = wall_clock64();
-}
-
-// ------------------------------------------------------------ long contexts: keys split over workgroups
-// k_dec_attn keeps one workgroup per head, which is latency-optimal for a few hundred keys but reads the whole
-// K/V history of a head through ONE compute unit (4K keys: ~190 us per layer).  Past a threshold the decode step
-// uses three kernels instead, with the SAME rounding points (S and P are half, global max and sum):
-//   k_dec_attn_scores  (head, split): RoPE, KV store of the new row, S_j = half(alpha q.k_j) for its keys -> workspace,
-//                                      local maximum
-//   k_dec_attn_pv      (head, split): global max, the full-row sum of exp (recomputed per split: a few thousand
-//                                      expf), P_j = half(half(e_j) * 1/sum) for its keys, partial P.V in fp32
-//   k_dec_attn_combine (head)       : sum of the partial outputs in split order -> half
-constexpr int DEC_ATTN_MAX_SPLITS = 32;      // splits per head are chosen per decode call from the context it will reach (8 / 16 / 32)
-
-struct DecAttnSplitWs {
-    half_t *S;        // [heads][max_ctx]
-    float *lmax;      // [heads][nsplits]
-    float *opart;     // [heads][nsplits][head_dim]
-    int nsplits;      // <= DEC_ATTN_MAX_SPLITS
-};
-
-__device__ __forceinline__ void dec_split_range(int n_ctx, int nsplits, int s, int &j0, int &j1)
-{
-    const int chunk = ((n_ctx + nsplits - 1) / nsplits + 63) / 64 * 64;
-    j0 = min(s * chunk, n_ctx); j1 = min(j0 + chunk, n_ctx);
-}
-
-template <int HD, bool Q8>
-__global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, const DecAttnSplitWs ws)
-{
-    __shared__ __attribute__((aligned(16))) half_t qs[HD];
-    __shared__ __attribute__((aligned(16))) half_t kn[HD];
-    __shared__ __attribute__((aligned(16))) half_t vn[HD];
-    __shared__ float red[4];
-    const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = *(const __attribute__((address_space(4))) int *)(P.state + 1), n_ctx = pos + 1;      // (scalar load: see k_dec_attn)
-    int j0, j1; dec_split_range(n_ctx, ws.nsplits, sidx, j0, j1);
-    const int group = P.heads / P.kv_heads, kvh = h / group;
-    const bool has_new = pos >= j0 && pos < j1;             // this split owns the new token's row
-    const bool writer = has_new && (h % group) == 0;
-    const int kv_dim = P.kv_heads * HD;
-    const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
-    const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
-    for (int d = tid; d < HD; d += 256) {
-        qs[d] = P.q[(size_t)h * HD + d];
-        kn[d] = P.k_new[(size_t)kvh * HD + d];
-        vn[d] = P.v_new[(size_t)kvh * HD + d];
-    }
-    __syncthreads();
-    if (P.rope_order != 0) {
-        if (tid < HD) {
-            const int c = tid < HD / 2 ? tid : tid - HD / 2;
-            rope_apply(tid < HD / 2 ? qs : kn, c, P.rope_tab[2 * c], P.rope_tab[2 * c + 1], P.rope_order, P.rope_cols);
-        }
-        __syncthreads();
-    }
-    if (has_new) {      // KV store of the new row (and its Q8 round trip), as in k_dec_attn
-        if constexpr (Q8) {
-            constexpr int NB = HD / 32;
-            for (int b = wave; b < 2 * NB; b += 4) {
-                half_t *src = b < NB ? kn : vn;
-                const int bb = b < NB ? b : b - NB;
-                if (lane < 32) {
-                    const float val = h2f(src[bb * 32 + lane]);
-                    float mx = fabsf(val);
-#pragma unroll
-                    for (int m2 = 16; m2 > 0; m2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m2, 32));
-                    const float sc = mx / 127;
-                    int qv = sc <= 0.000001f ? 0 : (int)roundf(val / sc);
-                    qv = min(max(qv, -128), 127);
-                    const half_t sch = f2h(sc);
-                    if (writer) {
-                        uint8_t *cache = b < NB ? P.kcache : P.vcache;
-                        uint8_t *blk = cache + (size_t)pos * row_bytes + head_off + (size_t)bb * 34;
-                        blk[2 + lane] = (uint8_t)(int8_t)qv;
-                        if (lane == 0) *reinterpret_cast<uint16_t *>(blk) = __builtin_bit_cast(uint16_t, sch);
-                    }
-                    src[bb * 32 + lane] = f2h((float)qv * h2f(sch));
-                }
-            }
-            __syncthreads();
-        } else if (writer && tid < HD) {
-            reinterpret_cast<half_t *>(P.kcache + (size_t)pos * row_bytes + head_off)[tid] = kn[tid];
-            reinterpret_cast<half_t *>(P.vcache + (size_t)pos * row_bytes + head_off)[tid] = vn[tid];
-        }
-    }
-    const float alpha = 1.0f / sqrtf((float)HD) / P.kq_scale;
-    const float mk = P.alibi ? alibi_slope(h + P.alibi_base, P.alibi_total) : 0.0f;
-    float lmax = -INFINITY;
-    // F16 cache: a lane's key row (HD halfs) is requested COALESCED -- a wave request covers 64 / (HD/8) whole rows -- and
-    // turned through LDS so that every lane then holds its own key's row: one key per lane with its own 16-byte requests
-    // touched 64 rows per request (14 us per layer at 4096 keys).  The dot product below is unchanged (fp32 fma in d order).
-    constexpr int KCH = HD / 8;                                   // 16-byte chunks per row
-    constexpr int KROWB = HD * 2 + 16;                            // bytes per staged row (+16: conflict-free row reads)
-    extern __shared__ __attribute__((aligned(16))) char kst[];    // [256][KROWB] (F16 cache only: dec_attn_scores_smem)
-    for (int jb = j0; jb < j1; jb += 256) {
-        const int j = jb + tid;
-        u32x4 krow[Q8 ? 1 : KCH];
-        if constexpr (!Q8) {
-            u32x4 kin[KCH];
-#pragma unroll
-            for (int i2 = 0; i2 < KCH; i2++) {                    // piece idx = tid + 256 i2: row idx / KCH, chunk idx % KCH
-                const int idx = tid + 256 * i2;
-                const int jr = min(jb + idx / KCH, j1 - 1);
-                kin[i2] = reinterpret_cast<const u32x4 *>(P.kcache + (size_t)jr * row_bytes + head_off)[idx % KCH];
-            }
-            __syncthreads();                                      // the previous pass's rows have been read
-#pragma unroll
-            for (int i2 = 0; i2 < KCH; i2++) {
-                const int idx = tid + 256 * i2;
-                *reinterpret_cast<u32x4 *>(kst + (size_t)(idx / KCH) * KROWB + (size_t)(idx % KCH) * 16) = kin[i2];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i2 = 0; i2 < KCH; i2++) krow[i2] = *reinterpret_cast<const u32x4 *>(kst + (size_t)tid * KROWB + (size_t)i2 * 16);
-        }
-        if (j >= j1) continue;
-        float c = 0.0f;
-        if (j == pos) {
-#pragma unroll 8
-            for (int d = 0; d < HD; d++) c = __builtin_fmaf(h2f(qs[d]), h2f(kn[d]), c);
-        } else {
-            const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
-            if constexpr (Q8) {
-#pragma unroll
-                for (int b = 0; b < HD / 32; b++) {
-                    const uint16_t *p16 = reinterpret_cast<const uint16_t *>(rowp + b * 34);
-                    const float sc = hbits2f(p16[0]);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const uint32_t two = p16[1 + i];
-                        const float k0 = h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), k1 = h2f(f2h((float)(int)(int8_t)(two >> 8) * sc));
-                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i]), k0, c);
-                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i + 1]), k1, c);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < HD / 8; i++) {
-                    const half8_t k8 = __builtin_bit_cast(half8_t, krow[i]);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) c = __builtin_fmaf(h2f(qs[8 * i + e]), (float)k8[e], c);
-                }
-            }
-        }
-        half_t sv = f2h(alpha * c);
-        if (P.alibi) { float a = (float)j * mk; sv = f2h(a + h2f(sv)); }
-        ws.S[(size_t)h * P.max_ctx + j] = sv;
-        lmax = fmaxf(lmax, P.kq_scale * h2f(sv));
-    }
-    lmax = wave_max(lmax);
-    if (lane == 0) red[wave] = lmax;
-    __syncthreads();
-    if (tid == 0) ws.lmax[h * ws.nsplits + sidx] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-
-template <int HD, bool Q8>
-__global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, const DecAttnSplitWs ws)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int DG = HD / 8, NSPLIT = 256 / DG;
-    float *red = reinterpret_cast<float *>(smem);                    // [8]
-    float *opart = red + 8;                                          // [NSPLIT][HD]
-    half_t *Pl = reinterpret_cast<half_t *>(opart + NSPLIT * HD);    // this split's probabilities
-    const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = *(const __attribute__((address_space(4))) int *)(P.state + 1), n_ctx = pos + 1;      // (scalar load: see k_dec_attn)
-    int j0, j1; dec_split_range(n_ctx, ws.nsplits, sidx, j0, j1);
-    const int group = P.heads / P.kv_heads, kvh = h / group;
-    const int kv_dim = P.kv_heads * HD;
-    const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
-    const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
-    const half_t *Sg = ws.S + (size_t)h * P.max_ctx;
-    float mx = -INFINITY;
-    for (int s2 = 0; s2 < ws.nsplits; s2++) mx = fmaxf(mx, ws.lmax[h * ws.nsplits + s2]);
-    // the full-row sum, in the same order as the one-workgroup kernel (strided by 256, wave tree, 4 waves)
-    float lsum = 0.0f;
-    for (int j = tid; j < n_ctx; j += 256) lsum += expf(P.kq_scale * h2f(Sg[j]) - mx);
-    lsum = wave_sum(lsum);
-    if (lane == 0) red[wave] = lsum;
-    __syncthreads();
-    const float inv = 1.0f / (((red[0] + red[1]) + red[2]) + red[3]);
-    for (int j = j0 + tid; j < j1; j += 256) {
-        const half_t eh = f2h(expf(P.kq_scale * h2f(Sg[j]) - mx));
-        Pl[j - j0] = f2h(h2f(eh) * inv);
-    }
-    __syncthreads();
-    const int dg = tid % DG, sp = tid / DG;
-    const bool vact = (256 % DG == 0) || sp < NSPLIT;
-    float o[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) o[i] = 0.0f;
-    for (int j = vact ? j0 + sp : j1; j < j1; j += (Q8 ? 1 : 4) * NSPLIT) {
-        const float pj = h2f(Pl[j - j0]);
-        if constexpr (Q8) {
-            const uint8_t *blk = P.vcache + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
-            const uint16_t *p16 = reinterpret_cast<const uint16_t *>(blk);
-            const float sc = hbits2f(p16[0]);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t two = p16[1 + (dg % 4) * 4 + e];
-                o[2 * e] = __builtin_fmaf(pj, h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), o[2 * e]);
-                o[2 * e + 1] = __builtin_fmaf(pj, h2f(f2h((float)(int)(int8_t)(two >> 8) * sc)), o[2 * e + 1]);
-            }
-        } else {
-            // four rows of this thread's key sequence are requested before the first is multiplied (one request in flight
-            // per thread left the split kernels at 1.6 TB/s); rows past the split are clamped and skipped -- same order of
-            // accumulation as a plain loop
-            u32x4 vr[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                vr[u] = reinterpret_cast<const u32x4 *>(P.vcache + (size_t)min(j + u * NSPLIT, j1 - 1) * row_bytes + head_off)[dg];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (j + u * NSPLIT >= j1) break;
-                const float pu = h2f(Pl[j + u * NSPLIT - j0]);
-                const half8_t v8 = __builtin_bit_cast(half8_t, vr[u]);
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pu, (float)v8[e], o[e]);
-            }
-        }
-    }
-    if (vact) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) opart[sp * HD + dg * 8 + e] = o[e];
-    }
-    __syncthreads();
-    if (tid < HD) {
-        float acc = opart[tid];
-        for (int s2 = 1; s2 < NSPLIT; s2++) acc = acc + opart[s2 * HD + tid];
-        ws.opart[((size_t)h * ws.nsplits + sidx) * HD + tid] = acc;
-    }
-}
-
-template <int HD>
-__global__ void __launch_bounds__(HD) k_dec_attn_combine(const DecAttnSplitWs ws, half_t *__restrict__ out, int8_t *xq, int heads)
-{
-    const int h = blockIdx.x, d = threadIdx.x;
-    const float *p = ws.opart + (size_t)h * ws.nsplits * HD + d;
-    float acc = p[0];
-    for (int s2 = 1; s2 < ws.nsplits; s2++) acc = acc + p[(size_t)s2 * HD];
-    const half_t yh = f2h(acc);
-    out[(size_t)h * HD + d] = yh;
-    if constexpr (HD % 32 == 0) { if (xq) dec_attn_emit_q8<HD>(xq, heads * HD, h, d, yh); }
-}
-
-__host__ __device__ inline size_t dec_attn_scores_smem(int head_dim, bool q8) { return q8 ? 16 : (size_t)256 * (head_dim * 2 + 16); }
-
-__host__ __device__ inline size_t dec_attn_pv_smem(int head_dim, int max_ctx, int nsplits = 8)
-{
-    const size_t nsplit = 256 / (head_dim / 8);
-    const size_t chunk = (((size_t)max_ctx + nsplits - 1) / nsplits + 63) / 64 * 64;
-    return 8 * 4 + nsplit * head_dim * 4 + chunk * 2 + 16;
-}
-
-__host__ __device__ inline size_t dec_attn_smem(int head_dim, int max_ctx)
-{
-    const size_t nsplit = 256 / (head_dim / 8);
-    return (size_t)head_dim * 3 * 2 + 16 * 4 + nsplit * head_dim * 4 + (((size_t)max_ctx * 2 + 15) & ~(size_t)15) + 16;
-}
+// (the decode attention kernels: ifa_decode_attn.h)
 
 // ------------------------------------------------------------- small kernels
 // state[0] = current token id, state[1] = its position, state[2] = steps done; state[3..6] = excluded ids (see

@@ -26,6 +26,7 @@
 // hanging the GPU; the host turns a non-zero P.err into an error return (ifa_model_decode).
 #pragma once
 #include "ifa_decode_kernels.h"
+#include "ifa_decode_attn.h"
 
 namespace ifa {
 

@@ -17,6 +17,7 @@
 #include <vector>
 #include "ifa_host.h"
 #include "ifa_decode_kernels.h"
+#include "ifa_decode_attn.h"
 #include "ifa_decode_gemv.h"
 #include "ifa_moe.h"
 #include "ifa_gemm_rows_mfma.h"
@@ -101,6 +102,7 @@ struct ifa_model {
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr, 8};
+    int attn_pb = 256, opt_attn_kt = 1;      // cache rows the one-workgroup decode attention requests at entry (64 / 128 / 256: the bucket the call stays inside); K rows through the LDS tile
     int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
@@ -165,6 +167,10 @@ static void choose_attn_split(ifa_model *m, int reach)
 {
     const int want = (m->opt_attn_split_ctx > 0 && reach > m->opt_attn_split_ctx) ? (reach > 8192 ? 32 : (reach > 2048 ? 16 : 8)) : 0;
     if (want != m->attn_split) { m->attn_split = want; drop_graphs(m); }
+    // rows of the K / V cache the one-workgroup kernel requests before it knows the position: the bucket this call stays
+    // inside (a longer context only costs the direct loads of the rows past it)
+    const int pb = reach <= 64 ? 64 : (reach <= 128 ? 128 : 256);
+    if (pb != m->attn_pb) { m->attn_pb = pb; drop_graphs(m); }
 }
 
 static void free_tensor(Tensor &t)
@@ -405,21 +411,31 @@ static int launch_attn(ifa_model *m, int l)
         IFA_LAUNCH_CHECK();
         return IFA_OK;
     }
-    const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx);
+    const int pb = (m->attn_pb == 64 || m->attn_pb == 128) ? m->attn_pb : 256;
+    const bool kt = m->opt_attn_kt && !A.kv_q8 && (c.head_dim == 32 || c.head_dim == 64 || c.head_dim == 128)
+        && dec_attn_smem(c.head_dim, c.max_ctx, pb) <= IFA_LDS_LIMIT;
+    const size_t asmem = dec_attn_smem(c.head_dim, c.max_ctx, kt ? pb : 0);
     const dim3 grid((unsigned)c.heads), block(256);
     // (attention_lds_ok() routed contexts whose score row does not fit the 160 KiB LDS to the split kernels above)
+#define IFA_ATTN_GO(HDV, Q8V, PBV, KTV) do { \
+        auto kern = k_dec_attn<HDV, Q8V, false, PBV, KTV>; \
+        if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
+        kern<<<grid, block, asmem, m->stream>>>(A.q, A.kcache, A.vcache, A.heads, A.kv_heads, A); } while (0)
+#define IFA_ATTN_PB(HDV, Q8V, KTV) do { if (pb == 64) IFA_ATTN_GO(HDV, Q8V, 64, KTV); else if (pb == 128) IFA_ATTN_GO(HDV, Q8V, 128, KTV); else IFA_ATTN_GO(HDV, Q8V, 256, KTV); } while (0)
+    // head sizes with a power-of-two number of 16-byte pieces take the K rows through the LDS tile (F16 cache)
 #define IFA_ATTN(HDV) \
-    case HDV: if (A.kv_q8) { if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
-                             k_dec_attn<HDV, true><<<grid, block, asmem, m->stream>>>(A.q, A.kcache, A.vcache, A.heads, A.kv_heads, A); } \
-              else { if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
-                     k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A.q, A.kcache, A.vcache, A.heads, A.kv_heads, A); } break;
+    case HDV: if (A.kv_q8) IFA_ATTN_PB(HDV, true, false); else if (kt) IFA_ATTN_PB(HDV, false, true); else IFA_ATTN_PB(HDV, false, false); break;
+#define IFA_ATTN_Q(HDV) \
+    case HDV: if (A.kv_q8) IFA_ATTN_GO(HDV, true, 256, false); else IFA_ATTN_GO(HDV, false, 256, false); break;
 #define IFA_ATTN_F(HDV) \
-    case HDV: if (asmem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dec_attn<HDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem)); \
-              k_dec_attn<HDV, false><<<grid, block, asmem, m->stream>>>(A.q, A.kcache, A.vcache, A.heads, A.kv_heads, A); break;
+    case HDV: IFA_ATTN_GO(HDV, false, 256, false); break;
     switch (c.head_dim) {
-        IFA_ATTN(32) IFA_ATTN(64) IFA_ATTN(96) IFA_ATTN(128) IFA_ATTN_F(48) IFA_ATTN_F(80)
+        IFA_ATTN(32) IFA_ATTN(64) IFA_ATTN_Q(96) IFA_ATTN(128) IFA_ATTN_F(48) IFA_ATTN_F(80)
     default: return ifa_fail(IFA_ERR_ARG, "fused attention: head_dim %d", c.head_dim);
     }
+#undef IFA_ATTN_Q
+#undef IFA_ATTN_PB
+#undef IFA_ATTN_GO
 #undef IFA_ATTN_F
 #undef IFA_ATTN
     IFA_LAUNCH_CHECK();
@@ -2321,7 +2337,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
