@@ -511,10 +511,7 @@ def main():
                                    "frac": out["prefill_linear_TFLOPs_at_longest"] / 2500.0,
                                    "note": "flops of the layers' linear products (2 x tokens x weights) / WHOLE prefill time of a %d-token prompt "
                                            "(attention, norms, RoPE, cache writes, lm_head of the last row included in the time); dense F16 MFMA peak" % longest}
-        import inferflow_amd as ia
-        lib_on = bool(ia.lib().ifa_gemm_library_min_tokens(-1))
-        out["prefill_gemm_route"] = ("dequantise-once + hipBLASLt above 128 tokens (opt-in, IFA_GEMM_LT_MIN_TOKENS)" if lib_on else
-                                     "in-tree kernels only (csrc/ifa_gemm.hip: large-tile MFMA kernel above 128 tokens, four launches per layer); library route off")
+        out["prefill_gemm_route"] = "in-tree kernels only (csrc/ifa_gemm.hip: large-tile MFMA kernel above 128 tokens, four launches per layer); no vendor GEMM in the library"
     # ---- dynamic batching: B queries with their own KV caches, one decode step appends one token to each (the reference's
     # InferenceEngine::Infer over several queries, inference_engine.cc:1300-1406); outside the timed headline region
     if world == 1 and args.batch > 1 and hasattr(runner, "worker") and not os.environ.get("IFA_FORCE_TP"):

@@ -104,20 +104,14 @@ int ifa_gemv(int w_dtype, const void *W, size_t rows, size_t cols,
  * every lane dequantises the blocks it needs into its MFMA operand registers (split-K kernels, weight-stream bound);
  * above 128 tokens (formats with blocks of <= 32 values) a workgroup dequantises its weight tile once per K step into
  * LDS and 256 x 256 / 128 x 256 / 128 x 128 output tiles are multiplied from there (v_mfma_f32_32x32x16_f16).
- * OPT-IN: from ifa_gemm_library_min_tokens() tokens on the weights are instead dequantised once into a per-stream F16
- * scratch and multiplied by hipBLASLt (bound at run time; same arithmetic) -- off unless switched on. */
+ * Every T runs these in-tree kernels: the library neither links nor loads a vendor GEMM. */
 int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x_f16, size_t tokens,
              const void *bias_f16, void *y_f16, ifa_stream stream);
-/* sets the token count from which ifa_gemm hands the product to hipBLASLt (0 = never: the default, < 0 = only query);
- * returns the previous threshold (0 also when hipBLASLt cannot be loaded).  Environment: IFA_GEMM_LT_MIN_TOKENS. */
-int ifa_gemm_library_min_tokens(int min_tokens);
-/* 1 when hipBLASLt could be loaded (the opt-in route above is usable), else 0 */
-int ifa_gemm_library_available(void);
 /* the large-tile kernel for tokens > 128 (default 1; 0: the smaller-tile kernels serve every T).  Bit-identical results
  * either way.  < 0 only queries; returns the previous setting */
 int ifa_gemm_big_tiles(int on);
-/* frees the F16 scratch / workspace the library path keeps for this stream on the current device (call before destroying
- * a stream that ran ifa_gemm with >= that many tokens; ifa_model_destroy / ifa_model_set_stream do it for the worker's) */
+/* frees the scratch the prefill kernels keep for this stream on the current device (call before destroying a stream that ran
+ * long-prompt attention; ifa_model_destroy / ifa_model_set_stream do it for the worker's) */
 int ifa_gemm_release_stream(ifa_stream stream);
 
 /* Re-tile reference-layout rows into the row-local plane layout the fused

@@ -66,8 +66,6 @@ SIGNATURES = {
     "ifa_quantize_act_q8": (_i, [_vp, _sz, _sz, _vp, _vp]),
     "ifa_gemv": (_i, [_i, _vp, _sz, _sz, _i, _vp, _vp, _vp, _vp]),
     "ifa_gemm": (_i, [_i, _vp, _sz, _sz, _vp, _sz, _vp, _vp, _vp]),
-    "ifa_gemm_library_min_tokens": (_i, [_i]),
-    "ifa_gemm_library_available": (_i, []),
     "ifa_attention_two_pass_min": (_i, [_i]),
     "ifa_attention_two_pass_min_keys": (_i, [_i]),
     "ifa_gemm_big_tiles": (_i, [_i]),

@@ -852,7 +852,7 @@ std::mutex g_sg_mutex;
 std::map<std::pair<int, hipStream_t>, SgWs> g_sg_ws;
 }
 namespace ifa {
-void attn_release_stream(int dev, hipStream_t s)          // called by ifa_gemm_release_stream (ifa_gemm_lt.hip)
+void attn_release_stream(int dev, hipStream_t s)          // called by ifa_gemm_release_stream (ifa_gemm.hip)
 {
     std::lock_guard<std::mutex> lock(g_sg_mutex);
     auto it = g_sg_ws.find({dev, s});

@@ -82,12 +82,48 @@ constexpr int DEC_ATTN_MIN_ROWS = 256;
 // and transposed through an XOR-swizzled LDS tile into the one-key-per-lane registers of the score chain.  One key per lane
 // straight from memory is 64 different cache lines per wave instruction: the 256-row prefetch was 4096 line requests per
 // CU, ~1.7 us of the kernel before its first stamp (r04 trace: the score phase waited for K, the P.V phase for V).
-template <int HD, bool Q8, bool BATCH = false, int PB = DEC_ATTN_MIN_ROWS, bool KT = false>
-__global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_t *pkc, const uint8_t *pvc, int pheads, int pkvh,
-                                                  const DecAttnParams P)
+// FUSED (k_dec_qkv_attn, ifa_decode_qkv_attn.h): the body runs as the tail of the QKV launch on the first 256 threads of the
+// head's designated workgroup -- the new token's q | k | v values arrive as {epoch, half} granules written by the workgroups
+// that computed those rows (FusedIn), the position is already known (rows past it are not requested), head = `h_in`.
+struct DecAttnFusedIn {
+    const unsigned long long *gran;     // [rows of q | k | v] granules of this layer
+    unsigned epoch;                     // tag of this step
+    int pos;                            // position of the new token
+    unsigned *err;                      // error word: set when a wait gives up
+    long long timeout_ticks;            // wall_clock64 ticks (100 MHz) a wait may take
+    // the head's quantised output for the Wo rows computed in the SAME launch (k_dec_qkv_attn<.., WO>), or null: granules
+    // [cols / 4] code dwords | [cols / 32] scales | [cols / 32] code sums | [heads] done flags, cols = heads * HD
+    unsigned long long *att_gran;
+};
+
+// indices into the attention-output granules (see DecAttnFusedIn::att_gran)
+__host__ __device__ inline int att_gran_count(int heads, int hd) { return heads * hd / 4 + 2 * (heads * hd / 32) + heads; }
+
+// What a thread requests at entry and keeps until the phases that use it: its key's row (or its pieces of the K tile), its V
+// pieces, the step's (cos, sin) pair, the new token's values.  A struct so that the fused launch can REQUEST (PHASE 1) long
+// before it COMPUTES (PHASE 2): behind its own weight rows, so that the cache rows arrive with the end of the weight stream.
+template <int HD, bool Q8, int PB, bool KT>
+struct DecAttnRegs {
+    static constexpr int DG = HD / 8, NSPLIT = 256 / DG, VPRE = PB / NSPLIT;
+    static constexpr int KBYTES = (HD / 32) * 34;
+    static constexpr int KALIGN = HD == 128 ? 8 : (HD == 64 ? 4 : 2);
+    uint32_t kreg[Q8 ? 1 : HD / 2];
+    uint32_t kq32[(Q8 && KALIGN >= 4) ? KBYTES / 4 : 1];
+    uint16_t kq16[(Q8 && KALIGN < 4) ? KBYTES / 2 : 1];
+    u32x4 kt[KT ? PB / NSPLIT : 1];
+    u32x4 vreg[Q8 ? 1 : VPRE];
+    uint32_t vqs[Q8 ? VPRE : 1], vqc[Q8 ? VPRE : 1][2];  // Q8: block scale (half bits) and the 8 codes of this thread's 8 dims (dwords: 16-bit members went to scratch)
+    float rope_cs, rope_sn;
+    half_t q_in, k_in, v_in;
+};
+
+// PHASE 0: the whole kernel; 1: the entry requests only; 2: everything behind them (R filled by a PHASE 1 call)
+template <int HD, bool Q8, bool BATCH, int PB, bool KT, bool FUSED, int PHASE = 0>
+__device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, const uint8_t *pkc, const uint8_t *pvc, int pheads, int pkvh,
+                                              const DecAttnParams &P, const int h_in, const DecAttnFusedIn &F, DecAttnRegs<HD, Q8, PB, KT> &R)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     int pos_b = 0;
+    if constexpr (FUSED) pos_b = F.pos;
     if constexpr (BATCH) {      // the query's cache pointers and position come from the step's table (one scalar fetch)
         const DecAttnBatchRow br = reinterpret_cast<const DecAttnBatchRow *>(P.batch_rows)[blockIdx.y];
         pkc = br.kc; pvc = br.vc; pos_b = br.n_ctx - 1;
@@ -110,10 +146,11 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     float *red = reinterpret_cast<float *>(vn + HD);               // [16]
     float *opart = red + 16;                                       // [NSPLIT][HD]
     static_assert(!KT || (!Q8 && !BATCH && (DG & (DG - 1)) == 0 && PB % NSPLIT == 0), "K tile through LDS: F16 rows, one query, power-of-two pieces per row");
+    static_assert(!(FUSED && BATCH), "the fused tail is a single-query kernel");
     static_assert(PB >= NSPLIT && PB <= DEC_ATTN_MIN_ROWS, "prefetch bucket");
     uint8_t *ktile = reinterpret_cast<uint8_t *>(opart + NSPLIT * HD);                         // KT: [PB][HD] halves, 16-byte pieces XOR-swizzled by key
     half_t *S = reinterpret_cast<half_t *>(ktile + (KT ? (size_t)PB * HD * 2 : 0));            // [n_ctx]
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = h_in, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int group = pheads / pkvh;
     const int kvh = h / group;
     const bool writer = (h % group) == 0;
@@ -127,9 +164,9 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     // Q8 rows: a head's slice is (HD/32)*34 bytes, 8-byte aligned for HD=128, 4-byte for HD=64, 2-byte for HD=32
     constexpr int KBYTES = (HD / 32) * 34;
     constexpr int KALIGN = HD == 128 ? 8 : (HD == 64 ? 4 : 2);
-    uint32_t kreg[Q8 ? 1 : HD / 2];
-    uint32_t kq32[(Q8 && KALIGN >= 4) ? KBYTES / 4 : 1];
-    uint16_t kq16[(Q8 && KALIGN < 4) ? KBYTES / 2 : 1];
+    auto &kreg = R.kreg; auto &kq32 = R.kq32; auto &kq16 = R.kq16; auto &kt = R.kt; auto &vreg = R.vreg; auto &vqs = R.vqs; auto &vqc = R.vqc;
+    float &rope_cs = R.rope_cs, &rope_sn = R.rope_sn;
+    half_t &q_in = R.q_in, &k_in = R.k_in, &v_in = R.v_in;
     auto load_k = [&](int j) {
         const uint8_t *rowp = pkc + (size_t)j * row_bytes + head_off;
         if constexpr (Q8) {
@@ -162,21 +199,26 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     // the new token's q / k / v values and this step's (cos, sin) pair FIRST: loads return in issue order, and behind the
     // 128 KB of K / V rows below these few bytes arrived 1.5 us later than they had to (phase stamps)
     const int dq = min(tid, HD - 1);
-    const half_t q_in = pq[(size_t)h * HD + dq], k_in = pq[(size_t)(pheads + kvh) * HD + dq], v_in = pq[(size_t)(pheads + pkvh + kvh) * HD + dq];
+    if constexpr (PHASE != 2) {
+    q_in = (half_t)0; k_in = (half_t)0; v_in = (half_t)0;
+    if constexpr (!FUSED) { q_in = pq[(size_t)h * HD + dq]; k_in = pq[(size_t)(pheads + kvh) * HD + dq]; v_in = pq[(size_t)(pheads + pkvh + kvh) * HD + dq]; }
+    }
     // (tid < DEC_ATTN_MIN_ROWS <= rows of the cache.)  Batched step: the position arrived with the cache pointers, so rows past
     // the context are clamped to the last one (duplicate addresses: one cache line) -- unclamped, every (head, query) workgroup
     // pulled 2 x 64 KB of cache rows whatever its context: 134 MB per layer at 32 queries, the whole cost of that launch
     const int dg = tid % DG, sp = tid / DG;
-    u32x4 kt[KT ? PB / NSPLIT : 1];
+    const bool vact = (256 % DG == 0) || sp < NSPLIT;   // this thread takes part in P.V
+    constexpr int VPRE = PB / NSPLIT;                   // prefetched V keys per thread: j = sp + NSPLIT*i (PB keys)
+    if constexpr (PHASE != 2) {
     if constexpr (KT) {
 #pragma unroll
-        for (int i = 0; i < PB / NSPLIT; i++) kt[i] = IFA_GP(u32x4, pkc + (size_t)min(sp + NSPLIT * i, PB - 1) * row_bytes + head_off)[dg];
+        for (int i = 0; i < PB / NSPLIT; i++) kt[i] = IFA_GP(u32x4, pkc + (size_t)min(sp + NSPLIT * i, FUSED ? min(pos_b, PB - 1) : PB - 1) * row_bytes + head_off)[dg];
     } else {
-        load_k(BATCH ? min(tid, pos_b) : min(tid, PB - 1));
+        load_k((BATCH || FUSED) ? min(tid, min(pos_b, PB - 1)) : min(tid, PB - 1));
     }
     // this step's (cos, sin) pair of the thread that will rotate: requested BETWEEN the K and the V rows -- behind both it was the
     // newest request, and the rotation waited (vmcnt(0)) for the whole prefetch; unconditional (a valid dummy address without RoPE)
-    float rope_cs = 1.0f, rope_sn = 0.0f;
+    rope_cs = 1.0f; rope_sn = 0.0f;
     {
         const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
         const float *rt = rope_tab ? rope_tab : reinterpret_cast<const float *>(pq);
@@ -184,14 +226,10 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         const f32x2 cs = *IFA_GP(f32x2, rt + 2 * c);
         if (P.rope_order != 0) { rope_cs = cs[0]; rope_sn = cs[1]; }
     }
-    const bool vact = (256 % DG == 0) || sp < NSPLIT;   // this thread takes part in P.V
-    constexpr int VPRE = PB / NSPLIT;                   // prefetched V keys per thread: j = sp + NSPLIT*i (PB keys)
-    u32x4 vreg[Q8 ? 1 : VPRE];
-    uint16_t vq[Q8 ? VPRE : 1][5];                      // Q8: {scale, 4 x 2 codes} of this thread's 8 dims, 2-byte aligned
     const size_t vq_off = head_off + (size_t)(dg / 4) * 34;
 #pragma unroll
     for (int i = 0; i < VPRE; i++) {
-        const int j = min(sp + NSPLIT * i, BATCH ? pos_b : PB - 1);
+        const int j = min(sp + NSPLIT * i, BATCH ? pos_b : (FUSED ? min(pos_b, PB - 1) : PB - 1));
         if constexpr (!Q8) {
             vreg[i] = IFA_GP(u32x4, pvc + (size_t)j * row_bytes + head_off)[dg];
         } else {
@@ -199,12 +237,13 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
             // 2-byte requests per key were 80 load instructions per thread ahead of everything else in the kernel
             const auto *blk = IFA_GP(uint16_t, pvc + (size_t)j * row_bytes + vq_off);
             typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
-            vq[i][0] = blk[0];
+            vqs[i] = blk[0];
             const u32x2_a2 cw = *IFA_GP(u32x2_a2, blk + 1 + (dg % 4) * 4);
-            vq[i][1] = (uint16_t)(cw[0] & 0xFFFFu); vq[i][2] = (uint16_t)(cw[0] >> 16);
-            vq[i][3] = (uint16_t)(cw[1] & 0xFFFFu); vq[i][4] = (uint16_t)(cw[1] >> 16);
+            vqc[i][0] = cw[0]; vqc[i][1] = cw[1];
         }
     }
+    }       // (PHASE != 2)
+    if constexpr (PHASE == 1) return;
 
     // ---- everything below may wait for the argument block: the position, this step's (cos, sin) pair of the thread that
     // will rotate (requested now, used after the staging barrier)
@@ -212,8 +251,27 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
     if (tr) P.trace[h * 8 + 0] = wall_clock64();
     // (a SCALAR load through the constant address space: as a vector load it was the newest request of the wave, and waiting for it
     //  -- vmcnt(0) -- meant waiting for every K / V row requested above before the new token's values could even be staged)
-    const int pos = BATCH ? pos_b : *(const __attribute__((address_space(4))) int *)(P.state + 1);
+    const int pos = (BATCH || FUSED) ? pos_b : *(const __attribute__((address_space(4))) int *)(P.state + 1);
     const int n_ctx = pos + 1;
+    if constexpr (FUSED) {
+        // the new token's values: one granule per row, valid when its tag is this step's epoch.  The producers are the other
+        // workgroups of the head's group (and this one): bounded wait, the error word tells the host
+        if (tid < HD) {
+            const unsigned long long *gq = F.gran + (size_t)h * HD + tid, *gk = F.gran + (size_t)(pheads + kvh) * HD + tid,
+                                     *gv = F.gran + (size_t)(pheads + pkvh + kvh) * HD + tid;
+            const long long t_give_up = wall_clock64() + F.timeout_ticks;
+            for (;;) {
+                const unsigned long long a = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long b = __hip_atomic_load(gk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long c = __hip_atomic_load(gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (unsigned)(a >> 32) == F.epoch && (unsigned)(b >> 32) == F.epoch && (unsigned)(c >> 32) == F.epoch;
+                q_in = __builtin_bit_cast(half_t, (uint16_t)a); k_in = __builtin_bit_cast(half_t, (uint16_t)b); v_in = __builtin_bit_cast(half_t, (uint16_t)c);
+                if (__all(ok)) break;
+                if (wall_clock64() > t_give_up) { if (lane == 0) atomicExch(F.err, 0x51u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
     // ---- stage q, k_new, v_new; RoPE on q and k (TensorOpr::PositionEmbedding, F16 in/out)
     if (tid < HD) { qs[tid] = q_in; kn[tid] = k_in; vn[tid] = v_in; }
     __syncthreads();
@@ -411,7 +469,7 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         if (j < n_ctx && vact) {
             const float pj = h2f(S[j]);
             if (j == pos) acc_new(pj);
-            else if constexpr (Q8) acc_q8w(pj, vq[i][0], vq[i][1], vq[i][2], vq[i][3], vq[i][4]);
+            else if constexpr (Q8) acc_q8w(pj, (uint16_t)vqs[i], (uint16_t)(vqc[i][0] & 0xFFFFu), (uint16_t)(vqc[i][0] >> 16), (uint16_t)(vqc[i][1] & 0xFFFFu), (uint16_t)(vqc[i][1] >> 16));
             else acc_v(pj, vreg[i]);
         }
     }
@@ -433,8 +491,41 @@ __global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_
         const half_t yh = f2h(acc);
         outp[(size_t)h * HD + tid] = yh;
         if constexpr (HD % 32 == 0 && !BATCH) { if (P.xq) dec_attn_emit_q8<HD>(P.xq, P.heads * HD, h, tid, yh); }
+        if constexpr (FUSED && HD % 32 == 0) {
+            if (F.att_gran) {
+                // the Alg2 quantiser of dec_attn_emit_q8 (same expressions), published as granules: four codes per dword (the quad's
+                // codes gathered with two DPP quad permutes), the block's scale and code sum by its first lane, the head's flag last
+                const float val = h2f(yh);
+                const float mxv = half_wave_max(fabsf(val));
+                const float qsc = mxv / 127;
+                const int qv = q8_round_div1(val, qsc);
+                const int sum = half_wave_sum_i32(qv);
+                const int q1 = dpp_xor1(qv), q2 = dpp_xor2(qv), q3 = dpp_xor1(q2);
+                const unsigned long long tagw = (unsigned long long)F.epoch << 32;
+                const int cols = pheads * HD, nc = cols / 4, nbk = cols / 32;
+                if ((tid & 3) == 0) {
+                    const uint32_t w4 = (uint32_t)(qv & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+                    __hip_atomic_store(F.att_gran + (h * HD + tid) / 4, tagw | w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((tid & 31) == 0) {
+                    const int blk = (h * HD + tid) >> 5;
+                    __hip_atomic_store(F.att_gran + nc + blk, tagw | __builtin_bit_cast(uint32_t, h2f(f2h(qsc))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(F.att_gran + nc + nbk + blk, tagw | __builtin_bit_cast(uint32_t, (float)sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid == 0) __hip_atomic_store(F.att_gran + nc + 2 * nbk + h, tagw | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     if (tr) P.trace[h * 8 + 7] = wall_clock64();
+}
+
+template <int HD, bool Q8, bool BATCH = false, int PB = DEC_ATTN_MIN_ROWS, bool KT = false>
+__global__ void __launch_bounds__(256) k_dec_attn(const half_t *pq, const uint8_t *pkc, const uint8_t *pvc, int pheads, int pkvh,
+                                                  const DecAttnParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DecAttnRegs<HD, Q8, PB, KT> R;
+    dec_attn_body<HD, Q8, BATCH, PB, KT, false>(smem, pq, pkc, pvc, pheads, pkvh, P, (int)blockIdx.x, DecAttnFusedIn{}, R);
 }
 
 // ------------------------------------------------------------ long contexts: keys split over workgroups

@@ -1,0 +1,263 @@
+// ifa_decode_qkv_attn.h -- round 4: the decode attention as the TAIL of the Wq|Wk|Wv launch (one kernel boundary per
+// layer less: 5 -> 4 launches).
+//
+// Reference ops fused here (batch 1): RmsNorm -> Quantize -> Wq, Wk, Wv GEMV (+bias) (inference_worker.cc:1407-1621) and,
+// for each query head, RoPE -> SetK/VRows -> GetK/VRows -> Gemm_Alg2 -> SoftMax -> Gemm_Alg2 -> Quantize (:983-1312),
+// with the arithmetic and rounding points of k_dec_gemv / k_dec_attn (both bodies are shared: fused == five-launch step bit
+// for bit, tests/test_gpu_fused_attn.py).
+//
+// Why it is legal without a device-wide hand-off: the q / k / v rows of ONE kv group (its `group` query heads + its key head
+// + its value head: (group + 2) * HD rows) are a property of the row -> workgroup mapping.  Here the grid is cut into
+// kv_heads sets of `gk` workgroups; set g computes exactly the rows of kv group g (k_dec_gemv deals rows round-robin over
+// all waves instead), so the attention of a head waits for gk workgroups -- 8 for Llama-2-7B -- not for the grid:
+//   * every finished row is published as ONE 8-byte {epoch, half} granule (agent-scope relaxed store: write-through,
+//     MI355X_MICROARCH.md "Persistent kernels" price list, form R2 -- no flag, no fence, valid iff the tag matches);
+//   * the head's designated workgroup (its own rows are part of the set, so it arrives with the others) requests the
+//     head's K / V rows -- now that the position is known, only rows that exist -- polls the 3 * HD granules while those
+//     are in flight, and runs dec_attn_body<FUSED>;
+//   * tag = (decode-call counter, position of the step): every granule of a layer is rewritten every step, so the tag only has
+//     to differ from the previous step's; the arena (one region per layer) is zeroed once at allocation, tags are never 0.
+// Every wait is bounded (timeout -> error word -> ifa_model_decode fails loudly); the grid is one workgroup per CU, so all
+// producers of a head are resident whenever its consumer waits.
+#pragma once
+#include "ifa_decode_kernels.h"
+#include "ifa_decode_attn.h"
+
+namespace ifa {
+
+struct DecQkvAttnExtra {
+    unsigned long long *gran;       // this layer's granules, [(heads + 2 kv_heads) * HD]
+    const unsigned *epoch;          // device word: number of the decode call (ifa_model_decode writes it before the steps)
+    unsigned epoch_add;             // added to it (ifa_model_time_kernel: distinct tags for repeated launches of one step)
+    unsigned *err;                  // error word (ifa_model::ps_err)
+    int timeout_us;
+    int gk;                         // workgroups per kv group; grid = kv_heads * gk
+    unsigned long long *att_gran;   // WO: this layer's attention-output granules (att_gran_count entries)
+};
+
+constexpr int QA_THREADS = 512;     // 8 waves: two per SIMD, 256 registers each (the attention tail needs ~140)
+
+// WO: the launch also computes the Wo rows (+ bias, + residual: EPI_RESIDUAL of k_dec_gemv<.., NORM == 2>).  The workgroups that
+// do NOT run a head's attention -- 224 of 256 for Llama-2-7B -- deal Wo's rows among themselves, request them right behind
+// their q | k | v rows (the whole Wo share of a CU, ~50 KB, sits in registers while the attention runs), then wait for the
+// heads' done flags, gather the quantised attention output (granules -> the LDS image X.load reads) and finish their rows:
+// the Wo launch's boundary, its 1 us to the first request and its 1.2 us to the first byte are gone (r04 trace).
+// RWO = Wo rows per wave = ceil(rows / (8 * non-attention workgroups)).
+template <int DT, int NJ, int RW, int NORM, int HD, bool Q8, int PB, bool KT, int NP, bool WO = false, int RWO = 3>
+__global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols,
+                                                             const DecGemvParams P, const DecAttnParams A, const DecQkvAttnExtra E,
+                                                             const DecGemvParams PW)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long t_kernel = wall_clock64();
+    static_assert(NORM == 0 || NORM == 1, "QKV prologue: quantiser with or without the RMS norm");
+    static_assert(NP > 0 && NP * 64 < QA_THREADS, "wave-specialised prologue");
+    constexpr int TH = QA_THREADS, PT = NP * 64;
+    constexpr int MAXC = (NJ * 8 * block_capacity(DT) + PT - 1) / PT;
+    XPre<NORM, MAXC, false, PT> pre;
+    if (threadIdx.x < PT) pre.issue(px, pnw, pnb, pcols);
+    // the position and the step's tag: scalar loads, waited for long after the weight requests
+    const int pos = *(const __attribute__((address_space(4))) int *)(A.state + 1);
+    // tag of this step's granules: (decode call, position) -- every granule is rewritten every step, so a tag only has to differ
+    // from the previous step's (next position of the same call, or another call)
+    const unsigned epoch = ((*(const __attribute__((address_space(4))) unsigned *)(E.epoch) + E.epoch_add) << 20) | ((unsigned)pos & 0xFFFFFu);
+    const XLds L = xlds_carve(smem, pcols);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    using Fmt = DecFmt<DT, NJ>;
+    const size_t row_bytes = tiled_row_bytes(DT, (size_t)P.nblk);
+    // kv group of this workgroup and its rows: local row lr = i * (gk * 8) + (workgroup in group) * 8 + wave, i < RW
+    const int g = (int)blockIdx.x / E.gk, bg = (int)blockIdx.x - g * E.gk;
+    const int group = A.heads / A.kv_heads;
+    const int RG = (group + 2) * HD;
+    const int WGV = E.gk * (TH / 64);
+    const int lw = bg * (TH / 64) + wave;
+    struct Row { const uint8_t *w; const half_t *b; half_t *y; int row, vrow; };
+    // (selects over kernel-argument scalars, like dec_locate: an indexed read of P.W0[] would be a vector load with a vmcnt(0) behind it)
+    auto locate = [&](int lr) {
+        Row r;
+        const int nq = group * HD;
+        const bool isk = lr >= nq && lr < nq + HD, isv = lr >= nq + HD;
+        r.row = isv ? g * HD + (lr - nq - HD) : (isk ? g * HD + (lr - nq) : g * nq + lr);
+        r.w = isv ? P.W0[2] : (isk ? P.W0[1] : P.W0[0]);
+        r.b = isv ? P.b0[2] : (isk ? P.b0[1] : P.b0[0]);
+        r.y = isv ? P.y[2] : (isk ? P.y[1] : P.y[0]);
+        r.vrow = isv ? (A.heads + A.kv_heads) * HD + r.row : (isk ? A.heads * HD + r.row : r.row);
+        return r;
+    };
+    typename Fmt::W w[RW];
+    auto load_rows = [&]() {
+        const bool full = (RW - 1) * WGV + lw < RG;
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < RW; i++) { const Row r = locate(i * WGV + lw); w[i].load(r.w + (size_t)r.row * row_bytes, P.nblk, lane); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RW; i++) {
+                if (i > 0 && i * WGV + lw >= RG) continue;
+                const Row r = locate(min(i * WGV + lw, RG - 1));
+                w[i].load(r.w + (size_t)r.row * row_bytes, P.nblk, lane);
+            }
+        }
+    };
+    // the attention tail: workgroup bg == a * (gk / group) of the set runs query head g * group + a, on its waves 0-3 (the
+    // prologue waves).  They request the head's K / V rows right behind their weight rows: the cache rows then arrive with the
+    // end of the weight stream instead of one memory round trip after the last q | k | v row
+    static_assert(NP == 4, "the prologue waves are the attention waves");
+    const int per = E.gk / group;
+    const bool attn_wg = bg % per == 0;
+    const int head = g * group + bg / per;
+    DecAttnFusedIn F;
+    F.gran = E.gran; F.epoch = epoch; F.pos = pos; F.err = E.err; F.timeout_ticks = (long long)E.timeout_us * 100;
+    F.att_gran = WO ? E.att_gran : nullptr;
+    // Wo rows of this wave: the non-attention workgroups numbered in grid order, rows dealt round-robin over their waves
+    typename Fmt::W wo[WO ? RWO : 1];
+    half_t wres = (half_t)0;
+    const int n_attn_before = g * group + (bg + per - 1) / per;            // attention workgroups with a smaller index
+    const int wv_wo = (A.kv_heads * E.gk - A.heads) * (TH / 64);            // waves that take Wo rows
+    const int gw_wo = ((int)blockIdx.x - n_attn_before) * (TH / 64) + wave;
+    const size_t wo_row_bytes = tiled_row_bytes(DT, (size_t)PW.nblk);
+    auto load_wo = [&]() {
+        if constexpr (WO) {
+            if (attn_wg) return;
+#pragma unroll
+            for (int i = 0; i < RWO; i++) {
+                const int v = i * wv_wo + gw_wo;
+                if (i > 0 && v >= PW.total_rows) continue;
+                wo[i].load(PW.W0[0] + (size_t)min(v, PW.total_rows - 1) * wo_row_bytes, PW.nblk, lane);
+            }
+            wres = PW.residual[min(min(lane, RWO - 1) * wv_wo + gw_wo, PW.total_rows - 1)];
+        }
+    };
+    if (threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }
+    __syncthreads();
+    if (wave >= NP) {
+        load_rows();
+    } else {
+        pre.finish(P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out, nullptr);
+        load_rows();
+    }
+    lds_counter_wait(L.part + 131, NP);
+    typename Fmt::X X;
+    X.load(L.codes, L.scale, L.xsum, lane, P.nblk);
+    {
+        float a[RW];
+#pragma unroll
+        for (int i = 0; i < RW; i++) a[i] = w[i].dot(X);
+#pragma unroll
+        for (int i = 0; i < RW; i++) a[i] = wave_sum(a[i]);
+        float a0 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < RW; i++) { if (lane == i) a0 = a[i]; }
+        const int lr = lane * WGV + lw;
+        if (lane < RW && lr < RG) {
+            const Row r = locate(lr);
+            half_t y = dec_bias(a0, r.b, r.row);
+            if (P.pre_scale != 0.0f) y = f2h(h2f(y) * P.pre_scale);
+            r.y[r.row] = y;                                     // (the q | k | v buffer stays available to the debug / op paths)
+            __hip_atomic_store(E.gran + r.vrow, ((unsigned long long)epoch << 32) | (unsigned long long)__builtin_bit_cast(uint16_t, y),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (A.trace && threadIdx.x == 0) {      // tuning: every workgroup's start / rows-published stamps behind the heads' attention stamps
+        A.trace[(size_t)(A.heads + (int)blockIdx.x) * 8 + 0] = t_kernel;
+        A.trace[(size_t)(A.heads + (int)blockIdx.x) * 8 + 1] = wall_clock64();
+    }
+    // the Wo rows are requested now that this wave's q | k | v rows are out: they stream while the heads' attention runs and the
+    // memory system has nothing else to do (requested behind the q | k | v rows they delayed every head by the 10 MB they add)
+    load_wo();
+    if (attn_wg) {
+        __syncthreads();             // every wave of this workgroup is done with the activation image: the LDS is the attention's now
+        if (wave >= 4) return;
+        DecAttnRegs<HD, Q8, PB, KT> R;
+        dec_attn_body<HD, Q8, false, PB, KT, true>(smem, nullptr, A.kcache, A.vcache, A.heads, A.kv_heads, A, head, F, R);
+        return;
+    }
+    if constexpr (WO) {
+        // ---- the Wo rows.  Wave 0 waits for the heads' flags (one granule per head, polled with a pause: 256 bytes per round and
+        // workgroup), then every thread fetches its share of the image and checks each granule's tag itself (the flag of a head
+        // is not ordered behind its data), retrying the ones that are not there yet
+        const int cols = PW.cols, nc = cols / 4, nbk = cols / 32, ng = nc + 2 * nbk;
+        const long long t_give_up = wall_clock64() + F.timeout_ticks;
+        if (wave == 0) {
+            // (until most heads are done: the last ones are waited for on the data granules themselves -- one memory round trip
+            //  instead of two behind the last head; polling the 10 KB image from the start would be 2 MB per round over the grid)
+            const int enough = A.heads - (A.heads >> 3);
+            for (;;) {
+                int cnt = 0;
+                for (int hh = lane; hh < A.heads; hh += 64)
+                    cnt += (unsigned)(__hip_atomic_load(E.att_gran + ng + hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == epoch ? 1 : 0;
+                const int done = (int)wave_sum((float)cnt);       // (small integers: exact)
+                if (done >= enough) break;
+                if (wall_clock64() > t_give_up) { if (lane == 0) atomicExch(E.err, 0x52u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        long long *const trw = (A.trace && threadIdx.x == 0) ? A.trace + (size_t)(A.heads + (int)blockIdx.x) * 8 : nullptr;
+        if (trw) trw[2] = wall_clock64();
+        __syncthreads();             // (also: every wave has read the QKV activation image, the LDS takes the Wo input now)
+        const XLds LW = xlds_carve(smem, cols);
+        {
+            // this thread's granules (i = tid + k * TH): all requested at once, the missing ones again until they are there
+            constexpr int MAXG = 4;                              // cols <= 4 * 512 * 32 / 10: 4096 columns need 3
+            unsigned long long gv[MAXG];
+            unsigned have = 0;
+            for (;;) {
+#pragma unroll
+                for (int k = 0; k < MAXG; k++) {
+                    const int i = (int)threadIdx.x + k * TH;
+                    if (i < ng && !((have >> k) & 1u)) gv[k] = __hip_atomic_load(E.att_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool all = true;
+#pragma unroll
+                for (int k = 0; k < MAXG; k++) {
+                    const int i = (int)threadIdx.x + k * TH;
+                    if (i < ng && !((have >> k) & 1u)) {
+                        if ((unsigned)(gv[k] >> 32) == epoch) have |= 1u << k; else all = false;
+                    }
+                }
+                if (all) break;
+                if (wall_clock64() > t_give_up) { atomicExch(E.err, 0x53u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < MAXG; k++) {
+                const int i = (int)threadIdx.x + k * TH;
+                if (i < ng) {
+                    const uint32_t dv = (uint32_t)gv[k];
+                    if (i < nc) reinterpret_cast<uint32_t *>(LW.codes)[i] = dv;
+                    else if (i < nc + nbk) LW.scale[i - nc] = __builtin_bit_cast(float, dv);
+                    else LW.xsum[i - nc - nbk] = __builtin_bit_cast(float, dv);
+                }
+            }
+        }
+        if (trw) trw[3] = wall_clock64();
+        __syncthreads();
+        typename Fmt::X XW;
+        XW.load(LW.codes, LW.scale, LW.xsum, lane, PW.nblk);
+        float aw[RWO];
+#pragma unroll
+        for (int i = 0; i < RWO; i++) aw[i] = (i == 0 || i * wv_wo + gw_wo < PW.total_rows) ? wo[i].dot(XW) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < RWO; i++) aw[i] = wave_sum(aw[i]);
+        float a0 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < RWO; i++) { if (lane == i) a0 = aw[i]; }
+        const int v = lane * wv_wo + gw_wo;
+        if (lane < RWO && v < PW.total_rows) dec_finish_row<EPI_RESIDUAL>(PW, dec_locate(PW, v), a0, 0.0f, wres, (half_t)0);
+        if (trw) trw[4] = wall_clock64();
+    }
+}
+
+// host side (one translation unit per weight format: ifa_dqkvattn_<format>.hip)
+bool dec_qkv_attn_supported(int w_dtype, int cols, int heads, int kv_heads, int head_dim, int num_cus, int *gk_out, int *rw_out);
+// PW: the Wo launch's parameters (EPI_RESIDUAL, quantised attention output as its input) when the Wo rows ride along, else null
+int dec_qkv_attn_launch(int w_dtype, int norm, bool kv_q8, int pb, bool kt, const DecGemvParams &P, const DecAttnParams &A, const DecQkvAttnExtra &E,
+                        const DecGemvParams *PW, int max_ctx, hipStream_t s);
+// can the Wo rows ride along?  ([dim][heads * head_dim] of the QKV format, dealt <= 3 rows per wave)
+bool dec_qkv_attn_wo_supported(int w_dtype, int wo_dtype, int wo_rows, int wo_cols, int heads, int kv_heads, int head_dim, int gk);
+template <int DT>
+int dec_qkv_attn_launch_dt(int norm, bool kv_q8, int pb, bool kt, int rw, const DecGemvParams &P, const DecAttnParams &A, const DecQkvAttnExtra &E,
+                           const DecGemvParams *PW, int max_ctx, hipStream_t s);
+
+} // namespace ifa

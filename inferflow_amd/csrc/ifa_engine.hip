@@ -23,6 +23,7 @@
 #include "ifa_gemm_rows_mfma.h"
 #include "ifa_gemm_big.h"
 #include "ifa_decode_persist_launch.h"
+#include "ifa_decode_qkv_attn.h"
 
 using namespace ifa;
 
@@ -102,6 +103,14 @@ struct ifa_model {
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr, 8};
+    // attention as the tail of the QKV launch (ifa_decode_qkv_attn.h): granules [layers][(heads + 2 kv_heads) * head_dim], the
+    // decode-call counter the tags are built from, its own error word
+    int opt_fuse_attn = 1, opt_fuse_attn_timeout_us = 20000, qa_on = 0, qa_gk = 0;
+    int opt_fuse_wo = 0, qa_wo = 0;            // ... and the Wo rows behind it (same launch, 3 launches per layer): bit-identical, but the two memory round trips of its
+                                               // hand-off cost what the Wo launch costs (r04 trace: 3.3 us behind the last head against 4.6 us for the launch, and the attention runs
+                                               // 0.3 us longer next to the Wo stream) -- opt-in
+    unsigned long long *qa_gran = nullptr, *qa_att_gran = nullptr;
+    unsigned *qa_call = nullptr, *qa_err = nullptr, qa_calls = 0;
     int attn_pb = 256, opt_attn_kt = 1;      // cache rows the one-workgroup decode attention requests at entry (64 / 128 / 256: the bucket the call stays inside); K rows through the LDS tile
     int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
@@ -315,6 +324,94 @@ static int sep_norm(ifa_model *m, const half_t *x, const Tensor &w, const Tensor
     return ifa_layernorm(m->cfg.norm_kind, x, 1, (size_t)m->cfg.dim, w.data, b.data, 0.0f, m->cfg.eps, dst, (ifa_stream)m->stream);
 }
 
+static void attn_params(ifa_model *m, int l, DecAttnParams &A);
+// Can layer l take the attention as the tail of its QKV launch?  (the one-workgroup-per-head attention, RMS-norm wiring, q / k / v
+// of one int8-path format with a kernel instance, no tensor-parallel pending sum)
+static bool qkv_attn_layer_ok(const ifa_model *m, int l, int *gk_out)
+{
+    const ifa_model_config &c = m->cfg;
+    const Layer &L = m->layers[(size_t)l];
+    if (c.norm_kind != 0 || c.tp_size > 1) return false;
+    const Tensor &wq = L.t[T_WQ], &wk = L.t[T_WK], &wv = L.t[T_WV];
+    if (!wq.present() || !wk.present() || !wv.present() || !wq.tiled || !wk.tiled || !wv.tiled) return false;
+    if (!fused_int8(wq.dtype) || !same_fmt(wq.dtype, wk.dtype) || !same_fmt(wq.dtype, wv.dtype)) return false;
+    if ((int)wq.rows != c.heads * c.head_dim || (int)wk.rows != c.kv_heads * c.head_dim || (int)wv.rows != c.kv_heads * c.head_dim) return false;
+    int rw = 0;
+    return dec_qkv_attn_supported(wq.dtype, (int)wq.cols, c.heads, c.kv_heads, c.head_dim, num_cus(), gk_out, &rw);
+}
+
+// decides qa_on for the next captured step and allocates what the fused launch needs (never under capture)
+static int qkv_attn_ready(ifa_model *m)
+{
+    const ifa_model_config &c = m->cfg;
+    int want = m->opt_fuse_attn && !m->attn_split && !m->persist_mode && dec_attn_smem(c.head_dim, c.max_ctx, 256) <= IFA_LDS_LIMIT;
+    int gk = 0;
+    for (int l = 0; want && l < c.layers; l++) if (!qkv_attn_layer_ok(m, l, &gk)) want = 0;
+    // the Wo rows ride along when every layer's Wo is a plain residual GEMV over the quantised attention output
+    int want_wo = want && m->opt_fuse_wo && m->attq && m->opt_attn_q8 && !c.parallel_attn && !c.share_input && !scale_on(c.attn_out_scale);
+    for (int l = 0; want_wo && l < c.layers; l++) {
+        const Tensor &wo = m->layers[(size_t)l].t[T_WO];
+        if (!wo.present() || !wo.tiled || !dec_qkv_attn_wo_supported(m->layers[(size_t)l].t[T_WQ].dtype, wo.dtype, (int)wo.rows, (int)wo.cols, c.heads, c.kv_heads, c.head_dim, gk))
+            want_wo = 0;
+    }
+    if (want && !m->qa_gran) {
+        const size_t n = (size_t)c.layers * (size_t)(c.heads + 2 * c.kv_heads) * c.head_dim;
+        IFA_HIP_CHECK(hipMalloc((void **)&m->qa_gran, n * 8));
+        IFA_HIP_CHECK(hipMemsetAsync(m->qa_gran, 0, n * 8, m->stream));
+        const size_t na = (size_t)c.layers * (size_t)att_gran_count(c.heads, c.head_dim);
+        IFA_HIP_CHECK(hipMalloc((void **)&m->qa_att_gran, na * 8));
+        IFA_HIP_CHECK(hipMemsetAsync(m->qa_att_gran, 0, na * 8, m->stream));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->qa_call, 16));
+        IFA_HIP_CHECK(hipMemsetAsync(m->qa_call, 0, 16, m->stream));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->qa_err, 16));
+        IFA_HIP_CHECK(hipMemsetAsync(m->qa_err, 0, 16, m->stream));
+        IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    }
+    if (want != m->qa_on || (want && gk != m->qa_gk) || want_wo != m->qa_wo) { m->qa_on = want; m->qa_gk = gk; m->qa_wo = want_wo; drop_graphs(m); }
+    return IFA_OK;
+}
+
+static void qkv_params(ifa_model *m, int l, const half_t *x, DecGemvParams &P)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    memset(&P, 0, sizeof(P));
+    P.x = x; P.norm_w = (const half_t *)L.t[T_ATTN_NORM].data; P.norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
+    P.multi_base = c.attn_norm_base; P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32;
+    if (c.parallel_attn) P.xn_out = m->xn;
+    const int ids[3] = {T_WQ, T_WK, T_WV}; const int bids[3] = {T_WQ_B, T_WK_B, T_WV_B};
+    const size_t QDd = (size_t)c.heads * c.head_dim, KVDd = (size_t)c.kv_heads * c.head_dim;
+    half_t *outs[3] = {m->dqkv, m->dqkv + QDd, m->dqkv + QDd + KVDd};
+    for (int i = 0; i < 3; i++) {
+        P.W0[i] = wbytes(L.t[ids[i]]); P.b0[i] = (const half_t *)L.t[bids[i]].data;
+        P.y[i] = outs[i]; P.rows[i] = (int)L.t[ids[i]].rows;
+    }
+    P.nsets = 3;
+}
+
+// QKV GEMVs + the attention of every head in ONE launch (tag_add: distinct tags for the timing loop's repeated launches)
+static int launch_qkv_attn(ifa_model *m, int l, const half_t *x, unsigned tag_add = 0)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    DecGemvParams P; qkv_params(m, l, x, P);
+    DecAttnParams A; attn_params(m, l, A);
+    DecQkvAttnExtra E; memset(&E, 0, sizeof(E));
+    E.gran = m->qa_gran + (size_t)l * (size_t)(c.heads + 2 * c.kv_heads) * c.head_dim;
+    E.epoch = m->qa_call; E.epoch_add = tag_add; E.err = m->qa_err; E.timeout_us = m->opt_fuse_attn_timeout_us; E.gk = m->qa_gk;
+    E.att_gran = m->qa_att_gran + (size_t)l * (size_t)att_gran_count(c.heads, c.head_dim);
+    const int pb = (m->attn_pb == 64 || m->attn_pb == 128) ? m->attn_pb : 256;
+    const bool kt = m->opt_attn_kt && !A.kv_q8 && dec_attn_smem(c.head_dim, c.max_ctx, pb) <= IFA_LDS_LIMIT;
+    DecGemvParams PW; memset(&PW, 0, sizeof(PW));
+    if (m->qa_wo) {      // launch_wo's EPI_RESIDUAL parameters; the input arrives as granules, not through PW.x
+        PW.cols = (int)L.t[T_WO].cols; PW.nblk = PW.cols / 32; PW.eps = c.eps;
+        PW.W0[0] = wbytes(L.t[T_WO]); PW.rows[0] = (int)L.t[T_WO].rows; PW.nsets = 1;
+        PW.b0[0] = (const half_t *)L.t[T_WO_B].data; PW.y[0] = m->a; PW.residual = x;
+        A.xq = nullptr;                 // nobody reads the global image
+    }
+    return dec_qkv_attn_launch(L.t[T_WQ].dtype, 1, A.kv_q8 != 0, pb, kt, P, A, E, m->qa_wo ? &PW : nullptr, c.max_ctx, m->stream);
+}
+
 static int launch_qkv(ifa_model *m, int l, const half_t *x)
 {
     const ifa_model_config &c = m->cfg;
@@ -359,6 +456,20 @@ static int launch_qkv(ifa_model *m, int l, const half_t *x)
         if (rc) return rc;
     }
     return IFA_OK;
+}
+
+static void attn_params(ifa_model *m, int l, DecAttnParams &A)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    const int rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f);
+    memset(&A, 0, sizeof(A));
+    A.q = m->dqkv; A.k_new = m->dqkv + (size_t)c.heads * c.head_dim; A.v_new = A.k_new + (size_t)c.kv_heads * c.head_dim; A.kcache = (uint8_t *)L.kcache; A.vcache = (uint8_t *)L.vcache;
+    A.state = m->state; A.rope_tab = m->rope_tab; A.heads = c.heads; A.kv_heads = c.kv_heads;
+    A.kv_q8 = c.kv_dtype == Q8_B32T2; A.kq_scale = c.use_alibi ? 1.0f : c.kq_scale;
+    A.rope_order = c.rope_order; A.rope_cols = rope_dims;
+    A.alibi = c.use_alibi; A.alibi_base = c.tp_rank * c.heads; A.alibi_total = c.heads * std::max(1, c.tp_size);
+    A.out = m->att; A.max_ctx = c.max_ctx; A.xq = (c.head_dim % 32 == 0) ? m->attq : nullptr; A.trace = g_trace_ptr;
 }
 
 static int launch_attn(ifa_model *m, int l)
@@ -997,9 +1108,13 @@ static int enqueue_fused_step(ifa_model *m)
         return IFA_OK;
     }
     for (int l = 0; l < n_layers; l++) {
-        if ((rc = launch_qkv(m, l, x))) return rc;
-        if ((rc = launch_attn(m, l))) return rc;
-        if ((rc = launch_wo(m, l, x))) return rc;
+        if (m->qa_on) {
+            if ((rc = launch_qkv_attn(m, l, x))) return rc;
+        } else {
+            if ((rc = launch_qkv(m, l, x))) return rc;
+            if ((rc = launch_attn(m, l))) return rc;
+        }
+        if (!(m->qa_on && m->qa_wo) && (rc = launch_wo(m, l, x))) return rc;
         Layer &L = m->layers[(size_t)l];
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
             if ((rc = launch_moe_router(m, l))) return rc;
@@ -2131,6 +2246,10 @@ int ifa_model_destroy(ifa_model *m)
     if (m->rope_tab) (void)hipFree(m->rope_tab);
     if (m->tokens_dev) (void)hipFree(m->tokens_dev);
     if (m->host_pinned) (void)hipHostFree(m->host_pinned);
+    if (m->qa_gran) (void)hipFree(m->qa_gran);
+    if (m->qa_call) (void)hipFree(m->qa_call);
+    if (m->qa_att_gran) (void)hipFree(m->qa_att_gran);
+    if (m->qa_err) (void)hipFree(m->qa_err);
     if (m->stream) (void)ifa_gemm_release_stream((ifa_stream)m->stream);
     if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -2337,7 +2456,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
@@ -2417,8 +2536,14 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
         if (want != m->persist_mode) { m->persist_mode = want; drop_graphs(m); }
         if (want) { const PsLayer *tab = nullptr; if ((rc = persist_table(m, &tab))) return rc; }      // (allocates: not under capture)
     }
+    if ((rc = qkv_attn_ready(m))) return rc;
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
+    if (m->qa_on) {      // the granule tags of this call: (call counter, position) -- consecutive steps never share one
+        m->qa_calls = (m->qa_calls % 4000u) + 1u;
+        m->host_pinned[6] = (int)m->qa_calls;
+        IFA_HIP_CHECK(hipMemcpyAsync(m->qa_call, m->host_pinned + 6, sizeof(int), hipMemcpyHostToDevice, s));
+    }
     if (m->opt_graph && !m->graph_exec) {
         IFA_HIP_CHECK(hipStreamSynchronize(s));
         IFA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -2442,7 +2567,17 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     int *perr = m->host_pinned + 8 + ifa_model::RING;
     perr[0] = 0;
     if (m->persist_mode) IFA_HIP_CHECK(hipMemcpyAsync(perr, m->ps_err, 16, hipMemcpyDeviceToHost, s));
+    int *qerr = perr + 4;
+    qerr[0] = 0;
+    if (m->qa_on) IFA_HIP_CHECK(hipMemcpyAsync(qerr, m->qa_err, 4, hipMemcpyDeviceToHost, s));
     IFA_HIP_CHECK(hipStreamSynchronize(s));
+    if (qerr[0] != 0) {      // a head's workgroup gave up waiting for its q | k | v rows: the step's results are not valid
+        (void)hipMemsetAsync(m->qa_err, 0, 16, s);
+        (void)hipStreamSynchronize(s);
+        if (elapsed_ms) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+        return ifa_fail(IFA_ERR_STATE, "fused QKV + attention launch: a wait for the new token's q | k | v rows timed out (code 0x%x); "
+                        "set option fuse_attn=0 to use the five-launch step", (unsigned)qerr[0]);
+    }
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     if (perr[0] != 0) {      // a wait inside the persistent launch gave up: the step's results are not valid
         const unsigned code = (unsigned)perr[0];
@@ -2926,7 +3061,7 @@ int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, voi
 int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
 {
     IFA_REQUIRE(m && m->finalized && avg_us, "ifa_model_time_kernel: bad arguments");
-    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 6, "ifa_model_time_kernel: which %d iters %d", which, iters);
+    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 7, "ifa_model_time_kernel: which %d iters %d", which, iters);
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
     if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
@@ -2951,8 +3086,13 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
         const PsLayer *tab = nullptr;
         if ((rc = persist_table(m, &tab))) return rc;
     }
+    if (which == 7) {      // QKV + attention as one launch
+        if ((rc = qkv_attn_ready(m))) return rc;
+        if (!m->qa_on) return ifa_fail(IFA_ERR_STATE, "fused QKV + attention launch unavailable for this model / option set");
+    }
     auto one = [&](int i) -> int {
         if (which == 6) return launch_persist(m, 0, m->cfg.layers, m->x, m->x2);
+        if (which == 7) return launch_qkv_attn(m, i % m->cfg.layers, m->x, (unsigned)(i + 1));
         const int l = m->opt_bench_mode == 1 ? 0 : i % m->cfg.layers;     // rotate over layers: distinct weights every launch
         if (m->opt_bench_mode == 2) touch_layer(l);
         switch (which) {

@@ -1,0 +1,60 @@
+"""The attention as the tail of the QKV launch (csrc/ifa_decode_qkv_attn.h, option fuse_attn) and, opt-in, the Wo rows behind it
+(fuse_wo): tokens, last-step logits and the KV cache must be bit-identical to the five-launch step (same kernel bodies, the
+hand-off is the only difference), and the launch must be the one that runs for the headline shape."""
+import numpy as np
+import pytest
+
+from inferflow_amd import dtypes as dt, synth, worker as W
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("llama2_7b", dt.Q4_B32T1A, dt.F16, 4),        # headline widths (4 layers keep the test fast), 8 workgroups per head
+    ("llama2_7b", dt.Q3H_B64T1, dt.Q8_B32T2, 4),   # configs[2]: 3.5-bit weights, 8-bit KV cache
+    ("mixtral_dense_like", dt.Q4_B32T1A, dt.F16, 3),
+]
+
+
+def _build(shape, wd, kvd, layers, max_ctx=320):
+    if shape == "mixtral_dense_like":       # grouped-query geometry of Mixtral (32 heads, 8 kv heads, dim 4096) with a dense FFN
+        return synth.build("llama2_7b", wd, kvd, max_ctx=max_ctx, layers=layers, kv_heads=8, ffn=14336)
+    return synth.build(shape, wd, kvd, max_ctx=max_ctx, layers=layers)
+
+
+def _run(wk, s, prompt, steps, **opts):
+    for k, v in opts.items():
+        wk.set_option(k, v)
+    wk.reset()
+    tok = wk.forward(prompt, 0)
+    toks, _ = wk.decode(int(tok), len(prompt), steps)
+    logits = wk.read_buffer("logits").view(np.uint16).copy()
+    kc = wk.read_buffer("kcache", layer=s["layers"] - 1).copy()
+    vc = wk.read_buffer("vcache", layer=s["layers"] - 1).copy()
+    return list(toks), logits, kc, vc
+
+
+@pytest.mark.parametrize("shape,wd,kvd,layers", CASES, ids=["llama7b_q4_f16", "llama7b_q3h_kvq8", "gqa8_q4_f16"])
+def test_fused_qkv_attention_launch_is_bit_identical(shape, wd, kvd, layers):
+    wk, _, s = _build(shape, wd, kvd, layers)
+    prompt = (np.arange(20, dtype=np.int32) * 11 + 5) % s["vocab"]
+    # contexts that cross the 64 / 128 / 256 prefetch buckets: 20 .. 20 + 250
+    for steps in (40, 120, 250):
+        ref = _run(wk, s, prompt, steps, fuse_attn=0, fuse_wo=0)
+        for opts in ({"fuse_attn": 1, "fuse_wo": 0}, {"fuse_attn": 1, "fuse_wo": 1}):
+            got = _run(wk, s, prompt, steps, **opts)
+            assert got[0] == ref[0], "tokens differ (%r, %d steps)" % (opts, steps)
+            assert np.array_equal(got[1], ref[1]), "logits differ (%r, %d steps)" % (opts, steps)
+            assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), "KV cache differs (%r, %d steps)" % (opts, steps)
+    # the fused launch is really the one that ran: its timing entry point refuses models it does not take
+    assert wk.time_kernel(7, 4) > 0.0
+
+
+def test_fused_launch_declines_shapes_it_has_no_kernel_for():
+    # 6 x 48 heads (stories15M): no instance -> the five-launch step runs, same tokens as with the option off
+    wk, _, s = synth.build("tiny15m", dt.F16, dt.F16, max_ctx=128)
+    prompt = np.arange(3, 11, dtype=np.int32)
+    a = _run(wk, s, prompt, 24, fuse_attn=1)
+    b = _run(wk, s, prompt, 24, fuse_attn=0)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    with pytest.raises(Exception):
+        wk.time_kernel(7, 2)

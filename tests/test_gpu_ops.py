@@ -365,41 +365,6 @@ def test_gemm_prefill_matches_per_token_oracle(d, T, rows, cols):
     assert g.half_ulp_diff(y1[0], y_orc).max() <= 1
 
 
-@pytest.mark.parametrize("d", [dt.Q4_B32T1A, dt.Q4_B32T1B, dt.Q3H_B64T1, dt.Q8_B32T2, dt.F16], ids=IDS([dt.Q4_B32T1A, dt.Q4_B32T1B, dt.Q3H_B64T1, dt.Q8_B32T2, dt.F16]))
-def test_gemm_library_path_matches_the_fused_kernel_and_the_oracle(d):
-    """From ifa_gemm_library_min_tokens() tokens on, ifa_gemm dequantises once and calls hipBLASLt (csrc/ifa_gemm_lt.hip):
-    same half-rounded weights, fp32 accumulation in another order -> same tolerance as the fused kernel."""
-    L = g.capi()
-    if not L.ifa_gemm_library_available():
-        pytest.skip("hipBLASLt not loadable on this box")
-    prev = L.ifa_gemm_library_min_tokens(-1)
-    T, rows, cols = 192, 320, 1024
-    rng = np.random.default_rng(77 + d)
-    w = rng.normal(0, 0.05, (rows, cols)).astype(np.float16)
-    x = rng.normal(0, 1.0, (T, cols)).astype(np.float16)
-    bias = rng.normal(0, 0.5, rows).astype(np.float16)
-    Wq = w if d == dt.F16 else o.quantize(d, w)
-    Wd, xd, bd = g.dev(Wq), g.dev(x), g.dev(bias)
-    try:
-        L.ifa_gemm_library_min_tokens(0)
-        y_own = g.host(g.gemm(d, Wd, rows, cols, xd, bd))
-        L.ifa_gemm_library_min_tokens(64)
-        y_lib = g.host(g.gemm(d, Wd, rows, cols, xd, bd))
-        y_lib_nobias = g.host(g.gemm(d, Wd, rows, cols, xd))
-    finally:
-        L.ifa_gemm_library_min_tokens(prev)
-    for t in (0, T // 2, T - 1):
-        y_orc, y64 = o.gemv_f16x(d, Wq, rows, cols, x[t], bias=bias, want_f64=True)
-        for y in (y_own, y_lib):
-            ulp = g.half_ulp_diff(y[t], y_orc)
-            small = np.abs(y[t].astype(np.float32) - y_orc.astype(np.float32)) <= 1e-3 * float(np.abs(y64).mean() + 1e-6)
-            assert ((ulp <= 2) | small).all(), (t, ulp.max())
-        y_nb = o.gemv_f16x(d, Wq, rows, cols, x[t])
-        assert (g.half_ulp_diff(y_lib_nobias[t], y_nb) <= 2).mean() >= 0.98
-    # the two paths agree with each other far inside that tolerance
-    assert (g.half_ulp_diff(y_own, y_lib) <= 2).mean() >= 0.995
-
-
 BIG_DT = [dt.Q4_B32T1A, dt.Q4_B32T1B, dt.Q8_B32T2, dt.Q5_B32T1, dt.Q4_B16, dt.F16]
 
 
@@ -418,17 +383,16 @@ def test_gemm_large_tile_kernel_matches_per_token_oracle(d, T, rows, cols):
     bias = rng.normal(0, 0.5, rows).astype(np.float16)
     Wq = w if d == dt.F16 else o.quantize(d, w)
     Wd, xd, bd = g.dev(Wq), g.dev(x), g.dev(bias)
-    prev_big, prev_lib = L.ifa_gemm_big_tiles(-1), L.ifa_gemm_library_min_tokens(-1)
+    prev_big = L.ifa_gemm_big_tiles(-1)
     ys = {}
     try:
-        L.ifa_gemm_library_min_tokens(0)
         for name, mode in (("auto", 1), ("256x256", 1 | (1 << 8)), ("128x256", 1 | (2 << 8)), ("128x128", 1 | (3 << 8)), ("small", 0)):
             L.ifa_gemm_big_tiles(mode)
             ys[name] = g.host(g.gemm(d, Wd, rows, cols, xd, bd))
         L.ifa_gemm_big_tiles(1)
         y_nobias = g.host(g.gemm(d, Wd, rows, cols, xd))
     finally:
-        L.ifa_gemm_big_tiles(prev_big); L.ifa_gemm_library_min_tokens(prev_lib)
+        L.ifa_gemm_big_tiles(prev_big)
     for t in (0, 127, 128, T // 2, T - 1):
         y_orc, y64 = o.gemv_f16x(d, Wq, rows, cols, x[t], bias=bias, want_f64=True)
         ulp = g.half_ulp_diff(ys["auto"][t], y_orc)

@@ -8,8 +8,6 @@ from inferflow_amd import dtypes as dt
 from tests import gpu_util as g
 L = ia.lib()
 import ctypes
-lib_thr = int(os.environ.get("IFA_GEMM_LT_MIN_TOKENS", "129"))
-print(json.dumps({"library_min_tokens": lib_thr, "library_available": bool(L.ifa_gemm_library_min_tokens(-1))}), flush=True)
 for d in (dt.Q4_B32T1A, dt.Q3H_B64T1, dt.F16):
     for T, rows, cols in [(16, 4096, 4096), (128, 4096, 4096), (1024, 4096, 4096), (1024, 11008, 4096), (1024, 4096, 11008), (256, 4096, 4096), (256, 11008, 4096), (512, 4096, 4096), (512, 11008, 4096), (4096, 4096, 4096)]:
         w = (torch.randn(rows, cols, device="cuda") * 0.02).half()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Prefill rate of long prompts: four large-tile GEMM launches per layer (prefill_big = 1, in-tree kernel) against the
-op-by-op layer (prefill_big = 0: dequantise-once + library GEMM above 128 tokens when the library is present)."""
+op-by-op layer (prefill_big = 0: the smaller-tile kernels serve every T)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -7,7 +7,6 @@ import inferflow_amd as ia
 from inferflow_amd import dtypes as dt
 from tests import gpu_util as g
 L = ia.lib()
-L.ifa_gemm_library_min_tokens(0)
 d = dt.Q4_B32T1A
 for T, rows, cols in [(4096, 4096, 4096), (4096, 4096, 4160), (4096, 4096, 4224), (4096, 4096, 4352), (1024, 4096, 4096), (1024, 4096, 4224)]:
     w = (torch.randn(rows, cols, device="cuda") * 0.02).half()
