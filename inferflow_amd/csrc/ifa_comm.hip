@@ -237,6 +237,29 @@ int ifa_comm_init_rank(const void *id_128, int nranks, int rank, int device, ifa
 }
 
 // One process per rank (ifa_comm_init_rank): the one-shot exchange needs the peers' inboxes and flags mapped into this process.
+// Inboxes, flags and counters are FINE-GRAINED device memory: kernels on different GPUs signal each other through them while
+// they run, and the HSA memory model only promises cross-agent visibility of coarse-grained (plain hipMalloc) memory at
+// dispatch boundaries -- a fresh flag next to a stale payload would be a silently wrong sum.
+static hipError_t oneshot_alloc(void **p, size_t bytes)
+{
+    return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+}
+
+// In-kernel visibility probe between two devices: the reader spins (bounded) on a word of ITS OWN device's flag area while the
+// writer, a kernel running on the OTHER device at the same time, stores the tag with system scope.  A host-side hipMemcpy
+// round trip (round 3's self-test) says nothing about what a running kernel sees.
+static __global__ void k_oneshot_probe_wait(const unsigned *word, unsigned tag, unsigned *seen, long long timeout_ticks)
+{
+    const long long t_end = wall_clock64() + timeout_ticks;
+    unsigned v = 0;
+    while ((v = __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) != tag && wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
+    *seen = v == tag ? 1u : 0u;
+}
+static __global__ void k_oneshot_probe_post(unsigned *word, unsigned tag)
+{
+    __hip_atomic_store(word, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // export: allocate this rank's buffers and hand out their IPC handles (2 x 64 bytes); the caller gathers the handles of all ranks
 // over whatever channel carried the communicator id; import: map them (hipIpcOpenMemHandle) -- from then on all-reduces of
 // <= 64 KB take the one-shot kernel.  Nothing here proves cross-device visibility: the first exchanges have bounded waits
@@ -253,10 +276,10 @@ int ifa_comm_oneshot_export(ifa_comm *c, void *handle_out_128)
     os->epoch.assign((size_t)n, nullptr); os->status.assign((size_t)n, nullptr); os->device.assign((size_t)n, c->device);
     memset(&os->peers, 0, sizeof(os->peers));
     const size_t inbox_bytes = 2 * (size_t)n * ONESHOT_MAX_BYTES, flag_bytes = 2 * (size_t)n * sizeof(unsigned);
-    IFA_HIP_CHECK(hipMalloc((void **)&os->peers.inbox[c->rank], inbox_bytes));
-    IFA_HIP_CHECK(hipMalloc((void **)&os->peers.flags[c->rank], flag_bytes + 64));
-    IFA_HIP_CHECK(hipMalloc((void **)&os->epoch[(size_t)c->rank], 4));
-    IFA_HIP_CHECK(hipMalloc((void **)&os->status[(size_t)c->rank], 4));
+    IFA_HIP_CHECK(oneshot_alloc((void **)&os->peers.inbox[c->rank], inbox_bytes));
+    IFA_HIP_CHECK(oneshot_alloc((void **)&os->peers.flags[c->rank], flag_bytes + 64));
+    IFA_HIP_CHECK(oneshot_alloc((void **)&os->epoch[(size_t)c->rank], 4));
+    IFA_HIP_CHECK(oneshot_alloc((void **)&os->status[(size_t)c->rank], 4));
     IFA_HIP_CHECK(hipMemset(os->peers.flags[c->rank], 0, flag_bytes + 64));
     IFA_HIP_CHECK(hipMemset(os->epoch[(size_t)c->rank], 0, 4));
     IFA_HIP_CHECK(hipMemset(os->status[(size_t)c->rank], 0, 4));
@@ -311,20 +334,30 @@ static std::shared_ptr<OneShot> oneshot_setup(const int *device_ids, int n)
     const size_t inbox_bytes = 2 * (size_t)n * ONESHOT_MAX_BYTES, flag_bytes = 2 * (size_t)n * sizeof(unsigned);
     for (int r = 0; r < n && ok; r++) {
         ok = hipSetDevice(device_ids[r]) == hipSuccess
-            && hipMalloc((void **)&os->peers.inbox[r], inbox_bytes) == hipSuccess && hipMalloc((void **)&os->peers.flags[r], flag_bytes + 64) == hipSuccess
-            && hipMalloc((void **)&os->epoch[(size_t)r], 4) == hipSuccess && hipMalloc((void **)&os->status[(size_t)r], 4) == hipSuccess
+            && oneshot_alloc((void **)&os->peers.inbox[r], inbox_bytes) == hipSuccess && oneshot_alloc((void **)&os->peers.flags[r], flag_bytes + 64) == hipSuccess
+            && oneshot_alloc((void **)&os->epoch[(size_t)r], 4) == hipSuccess && oneshot_alloc((void **)&os->status[(size_t)r], 4) == hipSuccess
             && hipMemset(os->peers.flags[r], 0, flag_bytes + 64) == hipSuccess && hipMemset(os->epoch[(size_t)r], 0, 4) == hipSuccess
             && hipMemset(os->status[(size_t)r], 0, 4) == hipSuccess;
     }
-    // self-test: rank a's device writes a tagged word into every rank's spare flag area, every rank's device reads it back
+    // self-test between every pair of DIFFERENT devices: a kernel on b's device waits (<= 100 ms) for the word a kernel on a's
+    // device posts into b's spare flag area while it runs (ranks on one device share its L2: nothing to prove there)
     if (ok) {
+        unsigned *seen = nullptr;
         for (int a = 0; a < n && ok; a++) {
-            (void)hipSetDevice(device_ids[a]);
             for (int b = 0; b < n && ok; b++) {
+                if (device_ids[a] == device_ids[b]) continue;
                 const unsigned tag = 0xA5000000u | (unsigned)(a * 64 + b);
-                ok = hipMemcpy(reinterpret_cast<char *>(os->peers.flags[b]) + flag_bytes, &tag, 4, hipMemcpyHostToDevice) == hipSuccess;
-                unsigned back = 0;
-                ok = ok && hipMemcpy(&back, reinterpret_cast<char *>(os->peers.flags[b]) + flag_bytes, 4, hipMemcpyDeviceToHost) == hipSuccess && back == tag;
+                unsigned *word = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(os->peers.flags[b]) + flag_bytes);
+                ok = hipSetDevice(device_ids[b]) == hipSuccess && oneshot_alloc((void **)&seen, 4) == hipSuccess && hipMemset(seen, 0, 4) == hipSuccess;
+                if (!ok) break;
+                k_oneshot_probe_wait<<<1, 1>>>(word, tag, seen, 10000000LL);                 // the reader first: it is running when the post arrives
+                ok = hipGetLastError() == hipSuccess && hipSetDevice(device_ids[a]) == hipSuccess;
+                if (ok) { k_oneshot_probe_post<<<1, 1>>>(word, tag); ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess; }
+                unsigned got = 0;
+                ok = ok && hipSetDevice(device_ids[b]) == hipSuccess && hipDeviceSynchronize() == hipSuccess
+                    && hipMemcpy(&got, seen, 4, hipMemcpyDeviceToHost) == hipSuccess && got == 1u;
+                (void)hipSetDevice(device_ids[b]);
+                if (seen) { (void)hipFree(seen); seen = nullptr; }
             }
         }
         for (int r = 0; r < n && ok; r++) { (void)hipSetDevice(device_ids[r]); ok = hipMemset(reinterpret_cast<char *>(os->peers.flags[r]) + flag_bytes, 0, 64) == hipSuccess; }
@@ -363,6 +396,9 @@ int ifa_comm_init_all(const int *device_ids, int n, ifa_comm **comms_out)
     for (int i = 0; i < n; i++) {
         ifa_comm *c = new ifa_comm();
         c->comm = cs[(size_t)i]; c->rank = i; c->nranks = n; c->device = device_ids[i]; c->oneshot = os;
+        // The peer exchange has not run between two real devices yet (no multi-GPU box in four rounds): RCCL carries every
+        // size until a caller switches it on (ifa_comm_set_oneshot) after checking a few steps against RCCL, as bench.py does
+        c->no_oneshot = true;
         comms_out[i] = c;
     }
     return IFA_OK;
@@ -403,7 +439,15 @@ int ifa_comm_abort(ifa_comm *c)
     return IFA_OK;
 }
 int ifa_comm_rank(const ifa_comm *c) { return c ? c->rank : -1; }
-int ifa_comm_size(const ifa_comm *c) { return c ? c->nranks : 0; }
+// ranks of the communicator: what RCCL itself counts for RCCL communicators (ncclCommCount -- bench.py reports it as ranks_seen),
+// the constructor's figure for in-process loopback groups
+int ifa_comm_size(const ifa_comm *c)
+{
+    if (!c) return 0;
+    int n = 0;
+    if (c->comm && !c->aborted.load() && ncclCommCount(c->comm, &n) == ncclSuccess && n > 0) return n;
+    return c->nranks;
+}
 
 // one host thread issuing the calls of several ranks (ifa_comm_init_all communicators) brackets them with these
 int ifa_comm_group_start(void) { IFA_NCCL_CHECK(ncclGroupStart()); return IFA_OK; }

@@ -274,6 +274,15 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
     }
     // ---- stage q, k_new, v_new; RoPE on q and k (TensorOpr::PositionEmbedding, F16 in/out)
     if (tid < HD) { qs[tid] = q_in; kn[tid] = k_in; vn[tid] = v_in; }
+    if constexpr (KT) {
+        // the K rows into the tile (piece dg of key j at piece slot dg ^ (j % DG): a 16-lane group writes one whole row, and
+        // reads -- key j = lane, piece i -- hit 16 different slots) under the SAME barrier as the staged values
+#pragma unroll
+        for (int i = 0; i < PB / NSPLIT; i++) {
+            const int j = sp + NSPLIT * i;
+            *reinterpret_cast<u32x4 *>(ktile + ((size_t)j * DG + (size_t)(dg ^ (j & (DG - 1)))) * 16) = kt[i];
+        }
+    }
     __syncthreads();
     if (tr) P.trace[h * 8 + 1] = wall_clock64();
     if (P.rope_order != 0) {
@@ -318,14 +327,7 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
     }
 
     if constexpr (KT) {
-        // the K rows into the tile (piece dg of key j at piece slot dg ^ (j % DG): a 16-lane group writes one whole row, and
-        // reads -- key j = lane, piece i -- hit 16 different slots), then key tid's row into the score chain's registers
-#pragma unroll
-        for (int i = 0; i < PB / NSPLIT; i++) {
-            const int j = sp + NSPLIT * i;
-            *reinterpret_cast<u32x4 *>(ktile + ((size_t)j * DG + (size_t)(dg ^ (j & (DG - 1)))) * 16) = kt[i];
-        }
-        __syncthreads();
+        // key tid's row out of the tile (written before the staging barrier) into the score chain's registers
         if (tid < PB) {
 #pragma unroll
             for (int i = 0; i < DG; i++) {
@@ -414,6 +416,19 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
     }
     if (tr) P.trace[h * 8 + 3] = wall_clock64();
     lmax = wave_max(lmax);
+    if (n_ctx <= 64) {
+        // all keys live in wave 0: its maximum IS the row maximum (the other waves hold -inf) and its sum the row sum (the others
+        // add +0, exact), so the two cross-wave reductions and their barriers fall away -- the same values bit for bit
+        if (wave == 0) {
+            if (tr) P.trace[h * 8 + 4] = wall_clock64();
+            float e = 0.0f;
+            if (tid < n_ctx) e = expf(P.kq_scale * h2f(S[tid]) - lmax);
+            const float lsum0 = wave_sum(e);
+            const float inv0 = 1.0f / (((lsum0 + 0.0f) + 0.0f) + 0.0f);
+            if (tid < n_ctx) S[tid] = f2h(h2f(f2h(e)) * inv0);
+        }
+        __syncthreads();
+    } else {
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     if (tr) P.trace[h * 8 + 4] = wall_clock64();
@@ -430,6 +445,7 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
     const float inv = 1.0f / (((red[4] + red[5]) + red[6]) + red[7]);
     for (int j = tid; j < n_ctx; j += 256) S[j] = f2h(h2f(S[j]) * inv);
     __syncthreads();
+    }
     if (tr) P.trace[h * 8 + 5] = wall_clock64();
 
     // ---- O = P.V : thread (sp, dg) accumulates keys j = sp + NSPLIT*i for its 8 dims

@@ -661,9 +661,16 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         // request is queued before ANY wave floods it with weight requests
         if constexpr (NP > 0) {
             if (threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }      // the two LDS counters (bit pattern of +0)
+            // the loader waves' first row goes out BEFORE the barrier: its addresses wait for the argument block (~0.4 us, by which
+            // time the activation requests of the prologue waves -- issued from preloaded arguments -- are queued), the barrier
+            // then costs the prologue waves nothing (they wait ~1 us for the activation anyway) and the stream starts ~0.3 us earlier
+            // (NORM == 1 only: the [dim] activation is one or two requests per prologue thread; W2's 11008-value input is six, and weight
+            //  requests slipping in between them delayed its quantiser: 8.0 -> 8.7 us)
+            constexpr int EARLY = NORM == 1 ? 1 : 0;
+            if (EARLY && wave >= NP) load_rows(0, 0, 1);
             __syncthreads();
             if (wave >= NP) {
-                load_rows(0, 0, RW);
+                load_rows(0, EARLY, RW);
                 load_epi(0);
                 if (P.trace != nullptr && threadIdx.x == NP * 64 && NORM == 1) P.trace[blockIdx.x * 8 + 4] = wall_clock64();
             } else {

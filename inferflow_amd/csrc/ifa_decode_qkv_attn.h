@@ -86,14 +86,15 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
         return r;
     };
     typename Fmt::W w[RW];
-    auto load_rows = [&]() {
+    auto load_rows = [&](int i0, int i1) {
         const bool full = (RW - 1) * WGV + lw < RG;
         if (full) {
 #pragma unroll
-            for (int i = 0; i < RW; i++) { const Row r = locate(i * WGV + lw); w[i].load(r.w + (size_t)r.row * row_bytes, P.nblk, lane); }
+            for (int i = 0; i < RW; i++) { if (i < i0 || i >= i1) continue; const Row r = locate(i * WGV + lw); w[i].load(r.w + (size_t)r.row * row_bytes, P.nblk, lane); }
         } else {
 #pragma unroll
             for (int i = 0; i < RW; i++) {
+                if (i < i0 || i >= i1) continue;
                 if (i > 0 && i * WGV + lw >= RG) continue;
                 const Row r = locate(min(i * WGV + lw, RG - 1));
                 w[i].load(r.w + (size_t)r.row * row_bytes, P.nblk, lane);
@@ -130,12 +131,13 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
         }
     };
     if (threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }
+    if (wave >= NP) load_rows(0, 1);          // (before the barrier: see k_dec_gemv)
     __syncthreads();
     if (wave >= NP) {
-        load_rows();
+        load_rows(1, RW);
     } else {
         pre.finish(P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out, nullptr);
-        load_rows();
+        load_rows(0, RW);
     }
     lds_counter_wait(L.part + 131, NP);
     typename Fmt::X X;

@@ -129,9 +129,10 @@ struct ifa_model {
     // what the captured multi-GPU step was recorded with: communicator identities and every topology field its launches
     // depend on.  A call with anything else re-captures (a replay would use a stale communicator / offsets).
     struct TpKey {
-        unsigned long long tp = 0, world = 0; int tp_size = 0, stage = 0, n_stages = 0, prev = 0, next = 0, src = 0, voff = 0, force = 0, fuse = 0, slot = 0;
+        unsigned long long tp = 0, world = 0; int tp_size = 0, stage = 0, n_stages = 0, prev = 0, next = 0, src = 0, voff = 0, force = 0, fuse = 0, slot = 0, oneshot = 0;
         bool operator==(const TpKey &o) const { return tp == o.tp && world == o.world && tp_size == o.tp_size && stage == o.stage && n_stages == o.n_stages
-                && prev == o.prev && next == o.next && src == o.src && voff == o.voff && force == o.force && fuse == o.fuse && slot == o.slot; }
+                && prev == o.prev && next == o.next && src == o.src && voff == o.voff && force == o.force && fuse == o.fuse && slot == o.slot
+                && oneshot == o.oneshot; }      // (oneshot: the captured collectives are the exchange or RCCL -- a switch forces a re-capture)
     } tp_key;
     const ifa_tp_topology *topo = nullptr;     // set by the partition entry points for the duration of a T > 1 / batched step
     size_t tp_rows_cap = 0;                    // rows the distributed-argmax scratch (tp_best / tp_gather / tp_tok) holds
@@ -1798,9 +1799,27 @@ static void *kv_ptr(ifa_model *m, size_t layer, int slot, bool is_v)
 
 // The rows GEMM's own copy of the seven matrices of every dense layer (MO layout): built when the first batched step or short
 // prompt needs it (never inside a stream capture), dropped with the tensor.  4.3 GB more for Llama-2-7B Q4.
+static int ensure_mo_build(ifa_model *m);
+// (a failed allocation -- the copies are 4.3 GB for Llama-2-7B Q4 -- is not an error of the step that triggered it: every partial
+//  copy is dropped, opt_rows_mo goes off and the tiled kernels (<= 16 rows per launch) serve the batched steps)
 static int ensure_mo(ifa_model *m)
 {
     if (!m->opt_rows_mo) return IFA_OK;
+    const int rc = ensure_mo_build(m);
+    if (rc == IFA_OK) return IFA_OK;
+    (void)hipGetLastError();
+    for (Layer &L : m->layers) {
+        for (Tensor &t : L.t) if (t.mo) { (void)hipFree(t.mo); t.mo = nullptr; }
+        for (Tensor &t : L.experts) if (t.mo) { (void)hipFree(t.mo); t.mo = nullptr; }
+        if (L.moe_table_mo) { (void)hipFree(L.moe_table_mo); L.moe_table_mo = nullptr; }
+    }
+    m->opt_rows_mo = 0;
+    drop_graphs(m);
+    fprintf(stderr, "inferflow_amd: the rows GEMM's operand-order weight copies could not be built (%s); batched steps use the tiled kernels\n", ifa_last_error());
+    return IFA_OK;
+}
+static int ensure_mo_build(ifa_model *m)
+{
     const ifa_model_config &c = m->cfg;
     bool built = false;
     for (Layer &L : m->layers) {
@@ -2307,6 +2326,10 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
         } else t = &L.t[tensor_id];
     }
     free_tensor(*t);
+    if (expert >= 0) {      // the layer's table of MO copies points into the copy just freed: ensure_mo rebuilds it
+        Layer &Lx = m->layers[(size_t)layer];
+        if (Lx.moe_table_mo) { (void)hipFree(Lx.moe_table_mo); Lx.moe_table_mo = nullptr; }
+    }
     // load time: the source may have been produced on another stream (e.g. the caller's default stream)
     IFA_HIP_CHECK(hipDeviceSynchronize());
     const size_t bytes = rows * ifa_row_bytes(dtype, cols);
@@ -2924,6 +2947,19 @@ static int tp_check(ifa_model *m, const ifa_tp_topology *topo, const char *who)
 // fed through the decode path one after the other (the merges are [dim] vectors); the greedy next token of the last
 // one comes back on every rank.  logits_shard_out_dev (nullable, last device group): this rank's lm_head rows of every
 // token, [n_tokens][shard rows] F16 (return_output_tensors).
+// A bounded wait of the one-shot exchange that gave up (a peer that never arrived) left this rank without a sum -- and its epoch
+// one behind its peers'.  Every partition entry point checks after its stream sync: the call fails (the engine then aborts the
+// group), the captured steps are dropped and this communicator keeps RCCL for every size from now on.
+static int tp_oneshot_status(ifa_model *m, const ifa_tp_topology &t, const char *who)
+{
+    if (!t.tp || !ifa_comm_oneshot(t.tp)) return IFA_OK;
+    const int st = ifa_comm_status(t.tp);
+    if (st == 0) return IFA_OK;
+    (void)ifa_comm_set_oneshot(t.tp, 0);
+    drop_graphs(m);
+    return ifa_fail(IFA_ERR_STATE, "%s: a wait inside the one-shot all-reduce gave up (epoch %d): a peer did not arrive; the exchange is off for this communicator", who, st);
+}
+
 int ifa_model_tp_prefill(ifa_model *m, const ifa_tp_topology *topo, const int *tokens_host, int n_tokens, int start_pos,
                          void *logits_shard_out_dev, int *next_token_host)
 {
@@ -2939,6 +2975,7 @@ int ifa_model_tp_prefill(ifa_model *m, const ifa_tp_topology *topo, const int *t
         m->topo = topo;
         rc = forward_ops(m, tokens_host, n_tokens, start_pos, logits_shard_out_dev, next_token_host);
         m->topo = nullptr;
+        if (rc == IFA_OK) { (void)hipStreamSynchronize(m->stream); rc = tp_oneshot_status(m, *topo, "ifa_model_tp_prefill"); }
         return rc;
     }
     const size_t shard = m->g[T_LM_HEAD].present() ? m->g[T_LM_HEAD].rows * 2 : 0;
@@ -2950,6 +2987,7 @@ int ifa_model_tp_prefill(ifa_model *m, const ifa_tp_topology *topo, const int *t
     }
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 4, m->tp_tok, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = tp_oneshot_status(m, *topo, "ifa_model_tp_prefill"))) return rc;
     if (next_token_host) *next_token_host = m->host_pinned[4];
     return IFA_OK;
 }
@@ -2965,6 +3003,7 @@ int ifa_model_tp_decode_batch(ifa_model *m, const ifa_tp_topology *topo, int n, 
     m->topo = topo;
     rc = forward_batch(m, n, tokens_host, positions_host, kv_slots_host, next_tokens_host, logits_shard_out_dev);
     m->topo = nullptr;
+    if (rc == IFA_OK) { (void)hipStreamSynchronize(m->stream); rc = tp_oneshot_status(m, *topo, "ifa_model_tp_decode_batch"); }
     return rc;
 }
 
@@ -2989,6 +3028,7 @@ int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_tok
         key.tp = ifa_comm_serial(t.tp); key.world = ifa_comm_serial(t.world); key.tp_size = t.tp ? ifa_comm_size(t.tp) : 1;
         key.stage = t.stage; key.n_stages = t.n_stages; key.prev = t.prev_rank; key.next = t.next_rank; key.src = t.token_src;
         key.voff = t.vocab_offset; key.force = t.force_collectives; key.fuse = m->opt_tp_fuse_add; key.slot = m->cur_slot;
+        key.oneshot = t.tp ? ifa_comm_oneshot(t.tp) : 0;
         if (m->tp_graph_exec && !(key == m->tp_key)) {
             (void)hipGraphExecDestroy(m->tp_graph_exec); m->tp_graph_exec = nullptr;
             if (m->tp_graph) { (void)hipGraphDestroy(m->tp_graph); m->tp_graph = nullptr; }
@@ -3035,11 +3075,7 @@ int ifa_model_tp_decode(ifa_model *m, const ifa_tp_topology *topo, int first_tok
     }
     // a bounded wait of the one-shot exchange that gave up (a peer that never arrived) left this rank without a sum: the
     // tokens above are not results -- fail the call (the engine then aborts the group) instead of returning them
-    if (t.tp && ifa_comm_oneshot(t.tp)) {
-        const int st = ifa_comm_status(t.tp);
-        if (st != 0) return ifa_fail(IFA_ERR_STATE, "tensor-parallel decode: a wait inside the one-shot all-reduce gave up (epoch %d): a peer did not arrive", st);
-    }
-    return IFA_OK;
+    return tp_oneshot_status(m, t, "ifa_model_tp_decode");
 }
 
 int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols)

@@ -246,6 +246,10 @@ class Comm:
     def set_oneshot(self, on):
         check(lib().ifa_comm_set_oneshot(self._h, int(bool(on))))
 
+    def size(self):
+        """Ranks of the communicator as the library reports them (ncclCommCount for RCCL communicators)."""
+        return int(lib().ifa_comm_size(self._h))
+
     def status(self):
         return int(lib().ifa_comm_status(self._h))
 

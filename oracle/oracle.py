@@ -73,7 +73,9 @@ _ref = None
 def lib():
     global _lib
     if _lib is None:
-        so = build()
+        # IFA_ORACLE_LIB: another build of the SAME sources (bench.py times an -O3 -march=native build made on the box it runs on;
+        # the parity tests always use the committed recipe: -O2, no -march, no FMA contraction)
+        so = os.environ.get("IFA_ORACLE_LIB") or build()
         L = C.CDLL(so)
         L.orc_set_num_threads(C.c_int(usable_cpus()))      # the default for every OpenMP loop of the oracle
         L.orc_block_capacity.restype = C.c_int

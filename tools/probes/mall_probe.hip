@@ -55,6 +55,8 @@ struct MainArgs {
     unsigned long long *stamps;     // [4]: wg0 start, x arrived, end; or null
     // C: prefetch by surplus workgroups (attention kernel only)
     const u32x4 *P; size_t pn16;
+    // D: address-translation warm-up: workgroups 0-7 (one per XCD) touch one line per `tstride16` units of the NEXT kernel's weights
+    const u32x4 *T; size_t tn16, tstride16;
 };
 
 // a GEMV-shaped kernel: x first (dependent on the previous kernel), a prologue of ~PROLOG sleep units, then all of the
@@ -67,6 +69,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(112))) k_
     const unsigned long long t0 = wall_clock64();
     if (t == 0 && blockIdx.x == 0 && a.prog) __hip_atomic_fetch_add(a.prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned xa = a.x[t], xb = a.x[t + 1024];
+    unsigned tacc = 0;
+    if (a.T && blockIdx.x < 8) {
+        for (size_t i = (size_t)t * a.tstride16; i < a.tn16; i += (size_t)1024 * a.tstride16) tacc ^= a.T[i].x;
+    }
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * 1024;
     const size_t i0 = (size_t)blockIdx.x * 1024 + t;
@@ -92,6 +98,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(112))) k_
         acc = __builtin_amdgcn_sdot4((int)v[k].w, (int)xs[(k * 4 + 3 + t) & (XN / 2 - 1)], acc, false);
     }
     for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    if (tacc == 0x12345679u) acc ^= 1;
     if ((t & 63) == 0) a.y[(blockIdx.x * 16 + (t >> 6)) & (XN / 2 - 1)] = (unsigned)acc | 1u;
     if (a.stamps && t == 0 && blockIdx.x == 0) { a.stamps[0] = t0; a.stamps[1] = t1; a.stamps[2] = wall_clock64(); }
 }
@@ -175,7 +182,7 @@ int main(int argc, char **argv)
     std::vector<unsigned long long> hst(512);
 
     // ------------------------------------------------------------ A
-    {
+    if (!(argc > 2 && atoi(argv[2]) == 4)) {
         const size_t pool_bytes = (size_t)1536 << 20;
         u32x4 *pool; CK(hipMalloc(&pool, pool_bytes)); CK(hipMemset(pool, 0x11, pool_bytes));
         const size_t flush16 = ((size_t)768 << 20) / 16;          // the upper half is the "other traffic"
@@ -236,7 +243,7 @@ int main(int argc, char **argv)
     hipEvent_t t0, t1, ev; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1)); CK(hipEventCreate(&ev));
 
     // chain graph; attn_prefetch_mb > 0: the attention kernel's surplus workgroups read that much of what follows it
-    auto build = [&](bool nt, double attn_prefetch_mb) {
+    auto build = [&](bool nt, double attn_prefetch_mb, size_t touch_stride_bytes = 0) {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
         int ki = 0;
@@ -251,8 +258,10 @@ int main(int argc, char **argv)
                     const int wgs = attn_prefetch_mb > 0 ? 256 : 32;
                     hipLaunchKernelGGL(k_attn, dim3(wgs), dim3(256), 0, s0, a, 32);
                 } else {
-                    const Seg &sg = segs[l * 4 + (k == 0 ? 0 : k - 1)];
+                    const int si = l * 4 + (k == 0 ? 0 : k - 1);
+                    const Seg &sg = segs[si];
                     a.W = W + sg.off16; a.n16 = sg.n16;
+                    if (touch_stride_bytes && si + 1 < (int)segs.size()) { a.T = W + segs[si + 1].off16; a.tn16 = segs[si + 1].n16; a.tstride16 = touch_stride_bytes / 16; }
                     if (nt) hipLaunchKernelGGL((k_main<true, 14>), dim3(256), dim3(1024), 0, s0, a);
                     else hipLaunchKernelGGL((k_main<false, 14>), dim3(256), dim3(1024), 0, s0, a);
                 }
@@ -302,13 +311,26 @@ int main(int argc, char **argv)
     run("serial, nt weight loads", g_nt, 0, 0);
     run("serial, default-policy weight loads", g_def, 0, 0);
     char nm[128];
+    if (!(argc > 2 && atoi(argv[2]) == 4))
     for (int th : {64, 128, 256})
         for (int ahead : {2, 4, 8}) {
             snprintf(nm, sizeof nm, "prefetcher %3d thr/CU, %d kernels ahead, chain nt", th, ahead);
             run(nm, g_nt, th, ahead);
         }
+    if (!(argc > 2 && atoi(argv[2]) == 4)) {
     run("prefetcher 128 thr/CU, 4 kernels ahead, chain default", g_def, 128, 4);
     run("prefetcher 128 thr/CU, unthrottled (1000 ahead), chain nt", g_nt, 128, 1000);
+    }
+    if (argc > 2 && atoi(argv[2]) == 4) {
+        printf("D. address-translation warm-up: each kernel's workgroups 0-7 touch one line per stride of the next kernel's weights\n");
+        for (size_t st : {(size_t)4096, (size_t)65536, (size_t)(2 << 20)}) {
+            hipGraphExec_t g = build(true, 0, st);
+            snprintf(nm, sizeof nm, "touch stride %zu B, chain nt", st);
+            run(nm, g, 0, 0);
+        }
+        run("serial again, nt weight loads", g_nt, 0, 0);
+        return 0;
+    }
     printf("C. prefetch by the attention kernel's surplus workgroups\n");
     for (double pmb : {10.49, 30.0, 50.0, 66.85}) {
         hipGraphExec_t g = build(true, pmb);
