@@ -24,6 +24,7 @@
 #include "ifa_gemm_big.h"
 #include "ifa_decode_persist_launch.h"
 #include "ifa_decode_qkv_attn.h"
+#include "ifa_decode_wo_ffn.h"
 
 using namespace ifa;
 
@@ -110,6 +111,12 @@ struct ifa_model {
                                                // hand-off cost what the Wo launch costs (r04 trace: 3.3 us behind the last head against 4.6 us for the launch, and the attention runs
                                                // 0.3 us longer next to the Wo stream) -- opt-in
     unsigned long long *qa_gran = nullptr, *qa_att_gran = nullptr;
+    // the Wo rows in FRONT of the W1 / W3 launch (ifa_decode_wo_ffn.h): done flags [layers][workgroups]
+    // Built, bit-identical, SLOWER (r04: 19.8-21.6 us against 4.6 + 12.7 for the two launches): the front waves' chain -- Wo rows 4.4 us,
+    // the all-gather of 8 KB among 256 workgroups 5-6 us (a software grid barrier plus a broadcast read of one small buffer by every
+    // CU), norm + quantiser 1.6-2.5 us -- ends after the loader waves' stream does, so nothing is hidden.  Opt-in (fuse_wo_ffn).
+    int opt_fuse_wo_ffn = 0, wf_on = 0;
+    unsigned long long *wf_gran = nullptr;
     unsigned *qa_call = nullptr, *qa_err = nullptr, qa_calls = 0;
     int attn_pb = 256, opt_attn_kt = 1;      // cache rows the one-workgroup decode attention requests at entry (64 / 128 / 256: the bucket the call stays inside); K rows through the LDS tile
     int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1;
@@ -359,6 +366,8 @@ static int qkv_attn_ready(ifa_model *m)
         const size_t n = (size_t)c.layers * (size_t)(c.heads + 2 * c.kv_heads) * c.head_dim;
         IFA_HIP_CHECK(hipMalloc((void **)&m->qa_gran, n * 8));
         IFA_HIP_CHECK(hipMemsetAsync(m->qa_gran, 0, n * 8, m->stream));
+        if (m->qa_call) { (void)hipFree(m->qa_call); m->qa_call = nullptr; }
+        if (m->qa_err) { (void)hipFree(m->qa_err); m->qa_err = nullptr; }
         const size_t na = (size_t)c.layers * (size_t)att_gran_count(c.heads, c.head_dim);
         IFA_HIP_CHECK(hipMalloc((void **)&m->qa_att_gran, na * 8));
         IFA_HIP_CHECK(hipMemsetAsync(m->qa_att_gran, 0, na * 8, m->stream));
@@ -368,7 +377,29 @@ static int qkv_attn_ready(ifa_model *m)
         IFA_HIP_CHECK(hipMemsetAsync(m->qa_err, 0, 16, m->stream));
         IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     }
-    if (want != m->qa_on || (want && gk != m->qa_gk) || want_wo != m->qa_wo) { m->qa_on = want; m->qa_gk = gk; m->qa_wo = want_wo; drop_graphs(m); }
+    // the Wo rows in front of the W1 / W3 launch: dense gated / plain FFN behind an RMS pre-norm, sequential wiring, the attention
+    // output arriving quantised (XqImage), Wo / W1 / W3 of one format with a kernel instance
+    int want_wf = m->opt_fuse_wo_ffn && !m->persist_mode && !want_wo && c.norm_kind == 0 && c.tp_size <= 1 && c.experts == 0 && m->attq && m->opt_attn_q8
+        && c.head_dim % 32 == 0 && !c.parallel_attn && !c.share_input && !scale_on(c.attn_out_scale);
+    for (int l = 0; want_wf && l < c.layers; l++) {
+        const Layer &L = m->layers[(size_t)l];
+        const Tensor &wo = L.t[T_WO], &w1 = L.t[T_W1], &w3 = L.t[T_W3];
+        if (!wo.present() || !wo.tiled || !w1.present() || !w1.tiled || (w3.present() && !w3.tiled) || !L.t[T_FFN_NORM].present()
+            || (int)wo.cols != c.heads * c.head_dim || (int)wo.rows != c.dim || (int)w1.cols != c.dim
+            || !dec_wo_ffn_supported(w1.dtype, wo.dtype, w3.present() ? w3.dtype : w1.dtype, c.dim, (int)wo.cols, (int)w1.rows, w3.present(), num_cus()))
+            want_wf = 0;
+    }
+    if (want_wf && !m->wf_gran) {
+        const size_t n = (size_t)c.layers * (size_t)num_cus();          // one done flag per workgroup and layer
+        IFA_HIP_CHECK(hipMalloc((void **)&m->wf_gran, n * 8));
+        IFA_HIP_CHECK(hipMemsetAsync(m->wf_gran, 0, n * 8, m->stream));
+        if (!m->qa_call) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_call, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_call, 0, 16, m->stream)); }
+        if (!m->qa_err) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_err, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_err, 0, 16, m->stream)); }
+        IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    }
+    if (want != m->qa_on || (want && gk != m->qa_gk) || want_wo != m->qa_wo || want_wf != m->wf_on) {
+        m->qa_on = want; m->qa_gk = gk; m->qa_wo = want_wo; m->wf_on = want_wf; drop_graphs(m);
+    }
     return IFA_OK;
 }
 
@@ -411,6 +442,28 @@ static int launch_qkv_attn(ifa_model *m, int l, const half_t *x, unsigned tag_ad
         A.xq = nullptr;                 // nobody reads the global image
     }
     return dec_qkv_attn_launch(L.t[T_WQ].dtype, 1, A.kv_q8 != 0, pb, kt, P, A, E, m->qa_wo ? &PW : nullptr, c.max_ctx, m->stream);
+}
+
+// Wo rows + FFN up-projection (norm, quantiser, W1 | W3, activation, gate) in ONE launch
+static int launch_wo_ffn(ifa_model *m, int l, const half_t *x, unsigned tag_add = 0)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    DecGemvParams PW; memset(&PW, 0, sizeof(PW));       // launch_wo's EPI_RESIDUAL / NORM 2 parameters
+    PW.x = reinterpret_cast<const half_t *>(m->attq); PW.cols = (int)L.t[T_WO].cols; PW.nblk = PW.cols / 32; PW.eps = c.eps;
+    PW.W0[0] = wbytes(L.t[T_WO]); PW.rows[0] = (int)L.t[T_WO].rows; PW.nsets = 1;
+    PW.b0[0] = (const half_t *)L.t[T_WO_B].data; PW.y[0] = m->a; PW.residual = x;
+    DecGemvParams P; memset(&P, 0, sizeof(P));         // launch_ffn13's dense EPI_GLU / EPI_ACT, NORM 1 parameters
+    P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
+    P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32; P.act_kind = c.act_kind; P.multi_base = c.ffn_norm_base;
+    P.W0[0] = wbytes(L.t[T_W1]); P.b0[0] = (const half_t *)L.t[T_W1_B].data;
+    P.y[0] = m->t1; P.rows[0] = (int)L.t[T_W1].rows; P.nsets = 1;
+    const bool glu = L.t[T_W3].present();
+    if (glu) { P.W1 = wbytes(L.t[T_W3]); P.b1 = (const half_t *)L.t[T_W3_B].data; }
+    DecWoFfnExtra E; memset(&E, 0, sizeof(E));
+    E.a_flags = m->wf_gran + (size_t)l * (size_t)num_cus(); E.state = m->state; E.epoch = m->qa_call; E.epoch_add = tag_add;
+    E.err = m->qa_err; E.timeout_us = m->opt_fuse_attn_timeout_us; E.trace = g_trace_ptr;
+    return dec_wo_ffn_launch(L.t[T_W1].dtype, glu, PW, P, E, num_cus(), m->stream);
 }
 
 static int launch_qkv(ifa_model *m, int l, const half_t *x)
@@ -1115,7 +1168,9 @@ static int enqueue_fused_step(ifa_model *m)
             if ((rc = launch_qkv(m, l, x))) return rc;
             if ((rc = launch_attn(m, l))) return rc;
         }
-        if (!(m->qa_on && m->qa_wo) && (rc = launch_wo(m, l, x))) return rc;
+        if (m->wf_on) {
+            if ((rc = launch_wo_ffn(m, l, x))) return rc;
+        } else if (!(m->qa_on && m->qa_wo) && (rc = launch_wo(m, l, x))) return rc;
         Layer &L = m->layers[(size_t)l];
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
             if ((rc = launch_moe_router(m, l))) return rc;
@@ -1129,7 +1184,7 @@ static int enqueue_fused_step(ifa_model *m)
             }
         } else {
             const bool extra = c.parallel_attn || c.share_input;
-            if ((rc = launch_ffn13(m, l, -1, x))) return rc;
+            if (!m->wf_on && (rc = launch_ffn13(m, l, -1, x))) return rc;
             if ((rc = launch_w2(m, l, xnext, nullptr, -1, false, extra ? x : nullptr))) return rc;
         }
         std::swap(x, xnext);
@@ -2268,6 +2323,7 @@ int ifa_model_destroy(ifa_model *m)
     if (m->qa_gran) (void)hipFree(m->qa_gran);
     if (m->qa_call) (void)hipFree(m->qa_call);
     if (m->qa_att_gran) (void)hipFree(m->qa_att_gran);
+    if (m->wf_gran) (void)hipFree(m->wf_gran);
     if (m->qa_err) (void)hipFree(m->qa_err);
     if (m->stream) (void)ifa_gemm_release_stream((ifa_stream)m->stream);
     if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
@@ -2479,7 +2535,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
@@ -2562,7 +2618,7 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     if ((rc = qkv_attn_ready(m))) return rc;
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
-    if (m->qa_on) {      // the granule tags of this call: (call counter, position) -- consecutive steps never share one
+    if (m->qa_on || m->wf_on) {      // the granule tags of this call: (call counter, position) -- consecutive steps never share one
         m->qa_calls = (m->qa_calls % 4000u) + 1u;
         m->host_pinned[6] = (int)m->qa_calls;
         IFA_HIP_CHECK(hipMemcpyAsync(m->qa_call, m->host_pinned + 6, sizeof(int), hipMemcpyHostToDevice, s));
@@ -2592,14 +2648,14 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     if (m->persist_mode) IFA_HIP_CHECK(hipMemcpyAsync(perr, m->ps_err, 16, hipMemcpyDeviceToHost, s));
     int *qerr = perr + 4;
     qerr[0] = 0;
-    if (m->qa_on) IFA_HIP_CHECK(hipMemcpyAsync(qerr, m->qa_err, 4, hipMemcpyDeviceToHost, s));
+    if (m->qa_on || m->wf_on) IFA_HIP_CHECK(hipMemcpyAsync(qerr, m->qa_err, 4, hipMemcpyDeviceToHost, s));
     IFA_HIP_CHECK(hipStreamSynchronize(s));
     if (qerr[0] != 0) {      // a head's workgroup gave up waiting for its q | k | v rows: the step's results are not valid
         (void)hipMemsetAsync(m->qa_err, 0, 16, s);
         (void)hipStreamSynchronize(s);
         if (elapsed_ms) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-        return ifa_fail(IFA_ERR_STATE, "fused QKV + attention launch: a wait for the new token's q | k | v rows timed out (code 0x%x); "
-                        "set option fuse_attn=0 to use the five-launch step", (unsigned)qerr[0]);
+        return ifa_fail(IFA_ERR_STATE, "fused decode launch: a wait for another workgroup's rows timed out (code 0x%x: 0x5_ q | k | v / attention output, 0x6_ Wo output); "
+                        "set options fuse_attn=0 fuse_wo_ffn=0 to use the five-launch step", (unsigned)qerr[0]);
     }
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     if (perr[0] != 0) {      // a wait inside the persistent launch gave up: the step's results are not valid
@@ -3097,7 +3153,7 @@ int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, voi
 int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
 {
     IFA_REQUIRE(m && m->finalized && avg_us, "ifa_model_time_kernel: bad arguments");
-    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 7, "ifa_model_time_kernel: which %d iters %d", which, iters);
+    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 8, "ifa_model_time_kernel: which %d iters %d", which, iters);
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
     if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
@@ -3122,13 +3178,15 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
         const PsLayer *tab = nullptr;
         if ((rc = persist_table(m, &tab))) return rc;
     }
-    if (which == 7) {      // QKV + attention as one launch
+    if (which == 7 || which == 8) {      // QKV + attention as one launch; Wo + W1 / W3 as one launch
         if ((rc = qkv_attn_ready(m))) return rc;
-        if (!m->qa_on) return ifa_fail(IFA_ERR_STATE, "fused QKV + attention launch unavailable for this model / option set");
+        if (which == 7 && !m->qa_on) return ifa_fail(IFA_ERR_STATE, "fused QKV + attention launch unavailable for this model / option set");
+        if (which == 8 && !m->wf_on) return ifa_fail(IFA_ERR_STATE, "fused Wo + FFN launch unavailable for this model / option set");
     }
     auto one = [&](int i) -> int {
         if (which == 6) return launch_persist(m, 0, m->cfg.layers, m->x, m->x2);
         if (which == 7) return launch_qkv_attn(m, i % m->cfg.layers, m->x, (unsigned)(i + 1));
+        if (which == 8) return launch_wo_ffn(m, i % m->cfg.layers, m->x, (unsigned)(i + 1));
         const int l = m->opt_bench_mode == 1 ? 0 : i % m->cfg.layers;     // rotate over layers: distinct weights every launch
         if (m->opt_bench_mode == 2) touch_layer(l);
         switch (which) {

@@ -1,5 +1,5 @@
 """The attention as the tail of the QKV launch (csrc/ifa_decode_qkv_attn.h, option fuse_attn) and, opt-in, the Wo rows behind it
-(fuse_wo): tokens, last-step logits and the KV cache must be bit-identical to the five-launch step (same kernel bodies, the
+(fuse_wo) or in front of the W1 / W3 launch (csrc/ifa_decode_wo_ffn.h, fuse_wo_ffn): tokens, last-step logits and the KV cache must be bit-identical to the five-launch step (same kernel bodies, the
 hand-off is the only difference), and the launch must be the one that runs for the headline shape."""
 import numpy as np
 import pytest
@@ -39,8 +39,9 @@ def test_fused_qkv_attention_launch_is_bit_identical(shape, wd, kvd, layers):
     prompt = (np.arange(20, dtype=np.int32) * 11 + 5) % s["vocab"]
     # contexts that cross the 64 / 128 / 256 prefetch buckets: 20 .. 20 + 250
     for steps in (40, 120, 250):
-        ref = _run(wk, s, prompt, steps, fuse_attn=0, fuse_wo=0)
-        for opts in ({"fuse_attn": 1, "fuse_wo": 0}, {"fuse_attn": 1, "fuse_wo": 1}):
+        ref = _run(wk, s, prompt, steps, fuse_attn=0, fuse_wo=0, fuse_wo_ffn=0)
+        for opts in ({"fuse_attn": 1, "fuse_wo": 0}, {"fuse_attn": 1, "fuse_wo": 1}, {"fuse_attn": 1, "fuse_wo": 0, "fuse_wo_ffn": 1},
+                     {"fuse_attn": 0, "fuse_wo": 0, "fuse_wo_ffn": 1}):
             got = _run(wk, s, prompt, steps, **opts)
             assert got[0] == ref[0], "tokens differ (%r, %d steps)" % (opts, steps)
             assert np.array_equal(got[1], ref[1]), "logits differ (%r, %d steps)" % (opts, steps)

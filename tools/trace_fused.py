@@ -11,8 +11,15 @@ tok = wk.forward(np.arange(3, 19, dtype=np.int32), 0)
 toks, ms = wk.decode(int(tok), 16, 48)          # positions up to 64: the prefetch bucket of the timing launches
 wk.set_option("trace", 1)
 H = s["heads"]
-for which, nm in [(7, "qkv+attn fused"), (0, "qkv"), (1, "attn")]:
+for which, nm in [(7, "qkv+attn fused"), (0, "qkv"), (1, "attn"), (8, "wo+ffn13 fused"), (2, "wo"), (3, "ffn13")]:
     us = wk.time_kernel(which, 33)
+    if which == 8:
+        tr = wk.read_buffer("trace").view(np.int64).reshape(2048, 8)[:256]
+        t0 = tr[:, 0].min()
+        lab = ["start", "wo_rows_published", "a_gathered", "image_ready", "front_rows_requested", "loader_rows_requested", "front_end", "loader_end"]
+        print("%s event_us %.2f | us after the launch's first instruction, median (max) over workgroups: " % (nm, us) +
+              "  ".join("%s %.2f (%.2f)" % (lab[i], float(np.median(tr[:, i] - t0)) * 0.01, (tr[:, i].max() - t0) * 0.01) for i in range(1, 8)))
+        continue
     if which != 7:
         print("%s event_us %.2f" % (nm, us)); continue
     tr = wk.read_buffer("trace").view(np.int64).reshape(2048, 8)
