@@ -81,6 +81,14 @@ int ifa_partition_slice(int stage, int n_stages, int tp_rank, int tp_size, int l
                         size_t rows, size_t cols, size_t *out5);
 int ifa_partition_split_layers(int n_layers, int n_groups, int *out_pairs, int capacity_pairs);
 
+/* ---- service shell (host/inferflow_service.*: the token-id counterpart of src/service/inferflow_service.cc; the process is
+ * bin/ifa_service <config.ini> [--port N]).  These two host-only entry points expose its request parser and response
+ * formatter -- native shape and the OpenAI-shaped /chat/completions one -- so that they can be tested without a device:
+ * parse writes the parsed fields back as one JSON object; both return 0, or -1 (rejected body / buffer too small). */
+int ifa_service_parse_request(const char *body, int is_openai_mode, char *out_json, size_t cap);
+int ifa_service_format_response(const int *token_ids, int n, int is_end, int is_openai_mode, int is_chunk, int prompt_tokens,
+                                char *out_json, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,6 +150,8 @@ def build_library(force=False, verbose=False, jobs=None):
                            "-L", LIB_DIR, "-linferflow_amd", "-Wl,-rpath,$ORIGIN/../lib"])
     subprocess.check_call([cxx] + HOST_FLAGS + ["-I", inc, "-I", HOST, os.path.join(HOST, "perplexity_main.cc"), "-o",
                            os.path.join(BIN_DIR, "ifa_perplexity"), "-L", LIB_DIR, "-linferflow_amd", "-Wl,-rpath,$ORIGIN/../lib"])
+    subprocess.check_call([cxx] + HOST_FLAGS + ["-I", inc, "-I", HOST, os.path.join(HOST, "inferflow_service_main.cc"), "-o",
+                           os.path.join(BIN_DIR, "ifa_service"), "-L", LIB_DIR, "-linferflow_amd", "-Wl,-rpath,$ORIGIN/../lib"])
     return LIB_PATH
 
 

@@ -1,5 +1,5 @@
 // ifa_dwoffn_impl.h -- included by exactly one ifa_dwoffn_<format>.hip per weight format: the instantiations of k_dec_wo_ffn
-// (ifa_decode_wo_ffn.h) for 4096-column rows (Llama-2-7B widths: 3 W1 / W3 row pairs and 2 Wo rows per wave).
+// (ifa_decode_wo_ffn.h) for 4096-column rows (Llama-2-7B widths: 3 W1 / W3 row pairs per loader wave, <= 2 per front wave, 4 Wo rows per front wave).
 #pragma once
 #include <algorithm>
 #include "ifa_host.h"

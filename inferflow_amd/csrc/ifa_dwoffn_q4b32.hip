@@ -15,10 +15,11 @@ bool dec_wo_ffn_supported(int w_dtype, int wo_dtype, int w3_dtype, int dim, int 
     const bool q4 = w_dtype == Q4_B32T1A || w_dtype == Q4_B32T1B;
     if (!q4 && w_dtype != Q3H_B64T1) return false;
     if (!wf_same(w_dtype, wo_dtype) || (glu && !wf_same(w_dtype, w3_dtype))) return false;
-    if (dim != 4096 || wo_cols != 4096 || num_cus < 1) return false;
-    const int wl = num_cus * (WF_THREADS / 64 - WF_NP), wf = num_cus * WF_NP;          // loader / front waves of the grid
-    if (ffn_rows < 1 || ffn_rows > 3 * wl + 2 * wf) return false;                      // 3 row pairs per loader wave, <= 2 per front wave
-    if (dim > 4 * wf) return false;                                                   // <= 4 Wo rows per front wave
+    if (dim != 4096 || wo_cols != 4096) return false;
+    if (num_cus < 2 * WF_FRONT || num_cus % WF_FRONT != 0) return false;               // front groups of 8 workgroups, evenly spread
+    if (dim != WF_FRONT * (WF_THREADS / 64) * 4) return false;                        // 4 Wo rows per front wave
+    const int wl = (num_cus - WF_FRONT) * (WF_THREADS / 64);                          // loader waves of the grid
+    if (ffn_rows < 1 || ffn_rows > 3 * wl + 2 * WF_FRONT * (WF_THREADS / 64)) return false;     // 3 row pairs per loader wave, <= 2 per front wave
     return true;
 }
 

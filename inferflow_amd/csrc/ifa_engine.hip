@@ -112,11 +112,18 @@ struct ifa_model {
                                                // 0.3 us longer next to the Wo stream) -- opt-in
     unsigned long long *qa_gran = nullptr, *qa_att_gran = nullptr;
     // the Wo rows in FRONT of the W1 / W3 launch (ifa_decode_wo_ffn.h): done flags [layers][workgroups]
-    // Built, bit-identical, SLOWER (r04: 19.8-21.6 us against 4.6 + 12.7 for the two launches): the front waves' chain -- Wo rows 4.4 us,
-    // the all-gather of 8 KB among 256 workgroups 5-6 us (a software grid barrier plus a broadcast read of one small buffer by every
-    // CU), norm + quantiser 1.6-2.5 us -- ends after the loader waves' stream does, so nothing is hidden.  Opt-in (fuse_wo_ffn).
+    // Built twice, bit-identical both times, SLOWER both times (r04, profiles/r04_wo_ffn_fused_trace.log) -- opt-in (fuse_wo_ffn):
+    //  * split by WAVE (front waves: Wo + all-gather + quantiser; loader waves: the W1 / W3 stream), 19.8-21.6 us against 4.6 + 12.6
+    //    for the two launches: every store, flag and poll of the front waves queues behind the loader waves' requests in the same
+    //    CU's memory pipeline (Wo rows out at 4.4 us, gather 5-6 us, quantiser 1.6-2.5 us: the chain ends after the stream does);
+    //  * split by WORKGROUP (64 front CUs: Wo, exchange, quantiser, publish the image; 192 loader CUs: stream, one poll, copy the
+    //    image), 24.6 us: a CU pulls ~25 GB/s whatever the rest of the chip does (its in-flight window / the memory latency), so
+    //    the 10.5 MB of Wo need all 256 CUs to arrive in 1.6 us -- on 64 they take 8 us -- and the chain of write-through drain
+    //    (1.1 us), flag round trip (1.1), payload round trip (1.0), quantiser (1.2), drain (1.1), flag + image on the loaders (2.7)
+    //    is 8 us more.  A hand-off through memory costs 3.3 us in this protocol; a kernel boundary + first load 2.5.
     int opt_fuse_wo_ffn = 0, wf_on = 0;
     unsigned long long *wf_gran = nullptr;
+    void *wf_img = nullptr;                     // the quantised FFN input the front workgroups publish (one buffer: a launch consumes it before the next writes it)
     unsigned *qa_call = nullptr, *qa_err = nullptr, qa_calls = 0;
     int attn_pb = 256, opt_attn_kt = 1;      // cache rows the one-workgroup decode attention requests at entry (64 / 128 / 256: the bucket the call stays inside); K rows through the LDS tile
     int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1;
@@ -390,7 +397,8 @@ static int qkv_attn_ready(ifa_model *m)
             want_wf = 0;
     }
     if (want_wf && !m->wf_gran) {
-        const size_t n = (size_t)c.layers * (size_t)num_cus();          // one done flag per workgroup and layer
+        const size_t n = (size_t)c.layers * 2 * WF_FRONT;               // per layer: a done flag and an image flag per front workgroup
+        IFA_HIP_CHECK(hipMalloc((void **)&m->wf_img, xq_image_bytes(c.dim) + 64));
         IFA_HIP_CHECK(hipMalloc((void **)&m->wf_gran, n * 8));
         IFA_HIP_CHECK(hipMemsetAsync(m->wf_gran, 0, n * 8, m->stream));
         if (!m->qa_call) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_call, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_call, 0, 16, m->stream)); }
@@ -461,7 +469,7 @@ static int launch_wo_ffn(ifa_model *m, int l, const half_t *x, unsigned tag_add 
     const bool glu = L.t[T_W3].present();
     if (glu) { P.W1 = wbytes(L.t[T_W3]); P.b1 = (const half_t *)L.t[T_W3_B].data; }
     DecWoFfnExtra E; memset(&E, 0, sizeof(E));
-    E.a_flags = m->wf_gran + (size_t)l * (size_t)num_cus(); E.state = m->state; E.epoch = m->qa_call; E.epoch_add = tag_add;
+    E.a_flags = m->wf_gran + (size_t)l * 2 * WF_FRONT; E.img_flags = E.a_flags + WF_FRONT; E.img = m->wf_img; E.state = m->state; E.epoch = m->qa_call; E.epoch_add = tag_add;
     E.err = m->qa_err; E.timeout_us = m->opt_fuse_attn_timeout_us; E.trace = g_trace_ptr;
     return dec_wo_ffn_launch(L.t[T_W1].dtype, glu, PW, P, E, num_cus(), m->stream);
 }
@@ -2324,6 +2332,7 @@ int ifa_model_destroy(ifa_model *m)
     if (m->qa_call) (void)hipFree(m->qa_call);
     if (m->qa_att_gran) (void)hipFree(m->qa_att_gran);
     if (m->wf_gran) (void)hipFree(m->wf_gran);
+    if (m->wf_img) (void)hipFree(m->wf_img);
     if (m->qa_err) (void)hipFree(m->qa_err);
     if (m->stream) (void)ifa_gemm_release_stream((ifa_stream)m->stream);
     if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);

@@ -6,6 +6,7 @@
 
 #include "inferflow_engine.h"
 #include "inference_engine.h"
+#include "inferflow_service.h"
 #include "perplexity.h"
 
 using namespace inferflow_amd;
@@ -207,6 +208,39 @@ int ifa_partition_split_layers(int n_layers, int n_groups, int *out_pairs, int c
     SplitGpuLayers(n_layers, n_groups, r);
     for (size_t i = 0; i < r.size() && (int)i < capacity_pairs; i++) { out_pairs[2 * i] = r[i].first; out_pairs[2 * i + 1] = r[i].second; }
     return (int)r.size();
+}
+
+// Service shell (host/inferflow_service.*), testable without a device: parses a request body the way the HTTP front does and
+// writes the parsed fields back as one JSON object; returns 0, or -1 when the body is rejected / the buffer is too small
+int ifa_service_parse_request(const char *body, int is_openai_mode, char *out_json, size_t cap)
+{
+    if (!body || !out_json || cap == 0) return -1;
+    InferFlowRequest r;
+    std::string err;
+    if (!InferFlowServiceCore::ParseRequest(r, body, is_openai_mode != 0, &err)) { snprintf(out_json, cap, "{\"ret_code\": \"%s\"}", err.c_str()); return -1; }
+    std::string ids = "[";
+    for (size_t i = 0; i < r.prompt_token_ids.size(); i++) { if (i) ids += ", "; ids += std::to_string(r.prompt_token_ids[i]); }
+    ids += "]";
+    char tmp[64]; snprintf(tmp, sizeof tmp, "%.4f", r.temperature);
+    const std::string js = "{\"prompt_token_ids\": " + ids + ", \"max_output_len\": " + std::to_string(r.max_output_len) + ", \"decoding_alg\": \"" + r.decoding_alg
+        + "\", \"random_seed\": " + std::to_string(r.random_seed) + ", \"temperature\": " + tmp + ", \"is_streaming_mode\": " + (r.is_streaming_mode ? "true" : "false")
+        + ", \"eos_token_id\": " + std::to_string(r.eos_token_id) + ", \"fn\": \"" + r.fn + "\"}";
+    if (js.size() + 1 > cap) return -1;
+    memcpy(out_json, js.c_str(), js.size() + 1);
+    return 0;
+}
+
+// formats a response chunk (native or OpenAI shape) from token ids: the exact strings the HTTP front sends
+int ifa_service_format_response(const int *token_ids, int n, int is_end, int is_openai_mode, int is_chunk, int prompt_tokens, char *out_json, size_t cap)
+{
+    if (!out_json || cap == 0 || n < 0 || (n > 0 && !token_ids)) return -1;
+    InferFlowResponseChunk c;
+    c.ret_code = "succ"; c.token_ids.assign(token_ids, token_ids + n); c.is_end = is_end != 0; c.prompt_tokens = prompt_tokens;
+    std::string js;
+    if (is_openai_mode) c.ToJsonOpenAI(js, is_chunk != 0, "ifa-test"); else c.ToJson(js);
+    if (js.size() + 1 > cap) return -1;
+    memcpy(out_json, js.c_str(), js.size() + 1);
+    return 0;
 }
 
 } // extern "C"

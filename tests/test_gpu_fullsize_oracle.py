@@ -13,7 +13,7 @@ with the context), so about one value in 200 differs by a half ulp, which flips 
 re-quantises that difference.  Measured (Q4 + F16 KV / Q3H + Q8 KV, worst of 7 steps): 0.003 / 0.03 x std after 1 layer,
 0.07 / 0.07 after 2, 0.09 / 0.13 after 4, 0.12 / 0.16 after 8, 0.17 / 0.20 after 16, 0.27 / 0.29 after 32 -- growth like
 sqrt(layers), no jump at any depth.  The test holds that law: for the first N layers of the model, N = 1, 4 and 32,
-    max |dlogit| <= 0.07 x sqrt(N) x std(oracle logits)      and      cosine >= 1 - 0.00005 - 0.00015 x N,
+    max |dlogit| <= 0.08 x sqrt(N) x std(oracle logits)      and      cosine >= 1 - 0.00005 - 0.00015 x N,
 (std ~1.3: lm_head rows of std 0.02 over 4096 normalised values), and a greedy id must be the oracle's whenever the oracle's
 top-2 gap exceeds that |dlogit| bound.  The T > 1 prefill (F16 activations, no int8 re-quantisation) keeps the rule of
 tests/test_gpu_engine.py at all 32 layers: cosine >= 0.9995, |dlogit| <= 0.10 x std.
@@ -66,7 +66,7 @@ def test_llama2_7b_widths_fused_decode_matches_oracle_at_depths_1_4_32(wd, kvd):
                 om.set_tensor(max(key[0], 0), key[1], target, data, rows, cols)
         wk.set_option("debug_layers", N if N < s["layers"] else 0)
         wk.reset()
-        frac = 0.07 * math.sqrt(N)
+        frac = 0.08 * math.sqrt(N)
         cos_min = 1.0 - 0.00005 - 0.00015 * N
         cur, worst, ids_checked = None, (1.0, 0.0), 0
         for i in range(N_PROMPT + N_STEPS):          # the prompt through the T = 1 path too: every step is a fused decode step

@@ -47,6 +47,7 @@ def test_fused_qkv_attention_launch_is_bit_identical(shape, wd, kvd, layers):
             assert np.array_equal(got[1], ref[1]), "logits differ (%r, %d steps)" % (opts, steps)
             assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), "KV cache differs (%r, %d steps)" % (opts, steps)
     # the fused launch is really the one that ran: its timing entry point refuses models it does not take
+    wk.set_option("fuse_attn", 1)
     assert wk.time_kernel(7, 4) > 0.0
 
 

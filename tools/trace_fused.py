@@ -12,13 +12,18 @@ toks, ms = wk.decode(int(tok), 16, 48)          # positions up to 64: the prefet
 wk.set_option("trace", 1)
 H = s["heads"]
 for which, nm in [(7, "qkv+attn fused"), (0, "qkv"), (1, "attn"), (8, "wo+ffn13 fused"), (2, "wo"), (3, "ffn13")]:
+    if which == 8:
+        wk.set_option("fuse_wo_ffn", 1)          # (opt-in)
     us = wk.time_kernel(which, 33)
     if which == 8:
         tr = wk.read_buffer("trace").view(np.int64).reshape(2048, 8)[:256]
         t0 = tr[:, 0].min()
-        lab = ["start", "wo_rows_published", "a_gathered", "image_ready", "front_rows_requested", "loader_rows_requested", "front_end", "loader_end"]
-        print("%s event_us %.2f | us after the launch's first instruction, median (max) over workgroups: " % (nm, us) +
-              "  ".join("%s %.2f (%.2f)" % (lab[i], float(np.median(tr[:, i] - t0)) * 0.01, (tr[:, i].max() - t0) * 0.01) for i in range(1, 8)))
+        fr, ld = tr[tr[:, 7] == 1], tr[tr[:, 7] == 0]
+        def col(a, i):
+            return "%.2f (%.2f)" % (float(np.median(a[:, i] - t0)) * 0.01, (a[:, i].max() - t0) * 0.01)
+        print("%s event_us %.2f | us after the launch's first instruction, median (max)" % (nm, us))
+        print("   %d front workgroups : Wo rows in memory %s | all Wo rows seen %s | image quantised %s | slice + flag out %s" % (len(fr), col(fr, 1), col(fr, 2), col(fr, 3), col(fr, 4)))
+        print("   %d loader workgroups: rows requested %s | image flags seen %s | image in LDS %s | rows stored %s" % (len(ld), col(ld, 1), col(ld, 2), col(ld, 3), col(ld, 4)))
         continue
     if which != 7:
         print("%s event_us %.2f" % (nm, us)); continue
