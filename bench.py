@@ -67,7 +67,7 @@ def cpu_baseline(wk_host_tensors, shape, n_tokens, threads, kv_dtype):
         gaps.append(lg)
     dt_s = time.perf_counter() - t0
     # (outside the timed region) the top-2 gap of every step in units of the logits' standard deviation: a greedy id may only
-    # differ from the GPU's where this is inside the stated tolerance (tests/test_gpu_fullsize_oracle.py: 0.10 x std)
+    # differ from the GPU's where this is inside the stated tolerance (tests/test_gpu_fullsize_oracle.py: 0.08 sqrt(layers) x std)
     rel = [None]
     for lg in gaps[1:]:
         row = np.asarray(lg, dtype=np.float32).reshape(-1)
@@ -641,8 +641,11 @@ def main():
                 agree = sum(1 for a, b in zip(cpu_toks, forced) if a == b)
                 first = next((i for i, (a, b) in enumerate(zip(cpu_toks, free)) if a != b), None)
                 port["tokens_agree_with_gpu"] = "%d/%d" % (agree, len(cpu_toks))       # same history fed to both (teacher forcing)
-                outside = sum(1 for a, b, gp in zip(cpu_toks, forced, cpu_gaps) if a != b and gp is not None and gp > 0.10)
-                port["token_mismatches_outside_tolerance"] = outside                    # top-2 gap of the port's logits > 0.10 x their std: must be 0
+                # the depth law of tests/test_gpu_fullsize_oracle.py: |dlogit| <= 0.08 sqrt(layers) x std on the int8 T = 1 path
+                tol = 0.08 * (runner.shape["layers"] ** 0.5)
+                outside = sum(1 for a, b, gp in zip(cpu_toks, forced, cpu_gaps) if a != b and gp is not None and gp > tol)
+                port["token_mismatches_outside_tolerance"] = outside                    # top-2 gap of the port's logits > tol x their std: must be 0
+                port["token_tolerance_in_std"] = tol
                 port["free_running_common_prefix"] = first if first is not None else len(cpu_toks)
                 port["tokens_note"] = ("greedy ids of the fused GPU decode against the port's on the SAME token history, all %d layers, "
                                        "random-init weights (flat logits: a top-2 gap inside the stated logit tolerance flips an id; "

@@ -77,6 +77,9 @@ __device__ __forceinline__ GmTile gm_locate(const GmSets &S, int vt)
 // one contiguous KiB per wave and the LDS patch (store, wait, read back: a ~1.2 us dependent chain per group) disappears.
 // Same operands, same MFMA order: bit-identical to the tiled path.
 // CH: 1 = the K range is ONE chunk of activation rows (checked by the launcher): straight-line code with counted waits
+#ifndef IFA_ROWS_BARRIER_FIRST
+#define IFA_ROWS_BARRIER_FIRST 1
+#endif
 template <int MAXT, int TX, int EPI, int NORM, bool MO, int CH>
 __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 {
@@ -364,11 +367,22 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
         }
     };
     x_store(0);
+    // The staging barrier FIRST, the other PD - 1 groups behind it (round 4): requested in front of the barrier, every wave sat in
+    // its load issue (4 x 5 KB per wave against a full memory queue) before it could arrive -- the rows were staged at 3.0 us and
+    // the barrier passed at 4.8 (rows-trace: "other groups requested 3.22, x staged 4.77"); the first group is in flight since 0.8
+#if IFA_ROWS_BARRIER_FIRST
+    __syncthreads();
+    if (trc && tid == 0) trc[2] = wall_clock64();
+#pragma unroll
+    for (int d = 1; d < PD; d++) fetch_q(buf[d], d);
+    if (trc && tid == 0) trc[18] = wall_clock64();
+#else
 #pragma unroll
     for (int d = 1; d < PD; d++) fetch_q(buf[d], d);
     if (trc && tid == 0) trc[18] = wall_clock64();
     __syncthreads();
     if (trc && tid == 0) trc[2] = wall_clock64();
+#endif
     if constexpr (CH == 1) {
         run_chunk(0);
     } else {
