@@ -23,6 +23,7 @@
 #include "ifa_gemm_rows_mfma.h"
 #include "ifa_gemm_big.h"
 #include "ifa_decode_persist_launch.h"
+#include "ifa_decode_lmhead_tail.h"
 #include "ifa_decode_qkv_attn.h"
 #include "ifa_decode_wo_ffn.h"
 
@@ -125,6 +126,10 @@ struct ifa_model {
     unsigned long long *wf_gran = nullptr;
     void *wf_img = nullptr;                     // the quantised FFN input the front workgroups publish (one buffer: a launch consumes it before the next writes it)
     unsigned *qa_call = nullptr, *qa_err = nullptr, qa_calls = 0;
+    // the end of the step as one launch (ifa_decode_lmhead_tail.h): lm_head + argmax + state advance + the next step's gather.
+    // st_on = what the captured step uses (F16 lm_head with the RMS / no final norm)
+    int opt_step_tail = 1, st_on = 0;
+    unsigned long long *st_keys = nullptr; unsigned *st_counter = nullptr; int st_keys_n = 0;
     int attn_pb = 256, opt_attn_kt = 1;      // cache rows the one-workgroup decode attention requests at entry (64 / 128 / 256: the bucket the call stays inside); K rows through the LDS tile
     int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
@@ -253,24 +258,39 @@ static int launch_dec_gemv(int w_dtype, const DecGemvParams &P, int wgs_per_cu_o
     return dec_gemv_launch(w_dtype, EPI, NORM, P, wgs_per_cu_opt, s, g_trace_ptr);
 }
 
-static int launch_lmhead(const DecLmHeadParams &P, int norm, int wgs_per_cu_opt, hipStream_t s)
+static int lmhead_grid(const DecLmHeadParams &P, int wgs_per_cu_opt)
+{
+    const int nj = (P.cols / 8 + 63) / 64;
+    const int R = nj <= 4 ? 2 : 1;
+    const int nbatch = (P.rows + R - 1) / R;
+    const int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 2;
+    return std::max(1, std::min(num_cus() * per_cu, (nbatch + DEC_WAVES - 1) / DEC_WAVES));
+}
+
+static int launch_lmhead(const DecLmHeadParams &P, int norm, int wgs_per_cu_opt, hipStream_t s, const DecStepTail *Z = nullptr)
 {
     const int chunks = P.cols / 8;
     const int nj = (chunks + 63) / 64;
     if (P.cols % 8 != 0 || nj < 1 || nj > 16) return ifa_fail(IFA_ERR_ARG, "fused lm_head supports cols %% 8 == 0 and <= 8192 (got %d)", P.cols);
     const int R = nj <= 4 ? 2 : 1;
     const int nbatch = (P.rows + R - 1) / R;
-    const int per_cu = wgs_per_cu_opt > 0 ? wgs_per_cu_opt : 2;
-    int wgs = std::min(num_cus() * per_cu, (nbatch + DEC_WAVES - 1) / DEC_WAVES);
-    if (wgs < 1) wgs = 1;
-    dim3 grid((unsigned)wgs);
+    (void)nbatch;
+    dim3 grid((unsigned)lmhead_grid(P, wgs_per_cu_opt));
     const size_t smem = (((size_t)P.cols * 2 + 15) & ~(size_t)15) + 132 * 4 + 16;
 #define IFA_LM(NJV, RV) \
     case NJV: if (norm) k_dec_lmhead_f16<NJV, RV, 1><<<grid, dim3(DEC_THREADS), smem, s>>>(P); \
               else k_dec_lmhead_f16<NJV, RV, 0><<<grid, dim3(DEC_THREADS), smem, s>>>(P); break;
+#define IFA_LMT(NJV, RV) \
+    case NJV: if (norm) k_dec_lmhead_tail<NJV, RV, 1><<<grid, dim3(DEC_THREADS), smem, s>>>(P, *Z); \
+              else k_dec_lmhead_tail<NJV, RV, 0><<<grid, dim3(DEC_THREADS), smem, s>>>(P, *Z); break;
+    if (Z) {
+        switch (nj) { IFA_LMT(1, 2) IFA_LMT(2, 2) IFA_LMT(3, 2) IFA_LMT(4, 2) IFA_LMT(5, 1) IFA_LMT(6, 1) IFA_LMT(7, 1) IFA_LMT(8, 1)
+                      IFA_LMT(9, 1) IFA_LMT(10, 1) IFA_LMT(11, 1) IFA_LMT(12, 1) IFA_LMT(13, 1) IFA_LMT(14, 1) IFA_LMT(15, 1) IFA_LMT(16, 1) }
+    } else
     switch (nj) { IFA_LM(1, 2) IFA_LM(2, 2) IFA_LM(3, 2) IFA_LM(4, 2) IFA_LM(5, 1) IFA_LM(6, 1) IFA_LM(7, 1) IFA_LM(8, 1)
                   IFA_LM(9, 1) IFA_LM(10, 1) IFA_LM(11, 1) IFA_LM(12, 1) IFA_LM(13, 1) IFA_LM(14, 1) IFA_LM(15, 1) IFA_LM(16, 1) }
 #undef IFA_LM
+#undef IFA_LMT
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
@@ -727,6 +747,65 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
     return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
 }
 
+// can the step end in the one-launch tail?  (F16 lm_head behind the RMS / no final norm, the embedding table on this worker)
+static bool step_tail_ok(const ifa_model *m)
+{
+    const ifa_model_config &c = m->cfg;
+    return m->opt_step_tail && m->g[T_LM_HEAD].present() && m->g[T_LM_HEAD].dtype == F16 && m->g[T_EMBD].present()
+        && !(c.norm_kind != 0 && m->g[T_OUT_NORM].present()) && c.dim % 8 == 0 && c.dim <= 8192;
+}
+
+static DecLmHeadParams lm_params(ifa_model *m, const half_t *x, half_t *logits_out)
+{
+    const ifa_model_config &c = m->cfg;
+    DecLmHeadParams H; memset(&H, 0, sizeof(H));
+    H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
+    H.eps = c.eps; H.cols = c.dim; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = logits_out ? logits_out : m->logits;
+    H.rows = (int)m->g[T_LM_HEAD].rows; H.xn_out = m->xn; H.multi_base = c.out_norm_base;
+    return H;
+}
+
+// (allocates: not under capture)
+static int step_tail_ready(ifa_model *m)
+{
+    const int want = step_tail_ok(m) ? 1 : 0;
+    if (want != m->st_on) { m->st_on = want; drop_graphs(m); }
+    if (!want) return IFA_OK;
+    const int grid = lmhead_grid(lm_params(m, m->x, nullptr), m->opt_rpw_lm);
+    if (grid > m->st_keys_n) {
+        IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+        if (m->st_keys) (void)hipFree(m->st_keys);
+        m->st_keys = nullptr; m->st_keys_n = 0;
+        IFA_HIP_CHECK(hipMalloc((void **)&m->st_keys, sizeof(unsigned long long) * (size_t)grid));
+        m->st_keys_n = grid;
+    }
+    if (!m->st_counter) IFA_HIP_CHECK(hipMalloc((void **)&m->st_counter, 16));
+    return IFA_OK;
+}
+
+// the last launch of a captured step: lm_head, argmax, state advance and the next step's gather (k_dec_lmhead_tail)
+static int launch_lm_tail(ifa_model *m, const half_t *x)
+{
+    const ifa_model_config &c = m->cfg;
+    const DecLmHeadParams H = lm_params(m, x, nullptr);
+    DecStepTail Z; memset(&Z, 0, sizeof(Z));
+    Z.state = m->state; Z.ring = ifa_model::RING; Z.keys = m->st_keys; Z.counter = m->st_counter;
+    Z.embd = (const half_t *)m->g[T_EMBD].data; Z.vocab = (int)m->g[T_EMBD].rows; Z.x_out = m->x;
+    Z.rope_tab = c.rope_order ? m->rope_tab : nullptr; Z.head_dim = c.head_dim; Z.theta = c.rope_theta;
+    Z.rope_dims = (int)(c.head_dim * c.partial_rotary + 0.5f); Z.embd_scale = c.embd_scale;
+    return launch_lmhead(H, m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, m->stream, &Z);
+}
+
+static int launch_gather(ifa_model *m)
+{
+    const ifa_model_config &c = m->cfg;
+    k_dec_gather<<<dim3(2), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows, m->x,
+                                                       c.rope_order ? m->rope_tab : nullptr, c.head_dim, c.rope_theta,
+                                                       (int)(c.head_dim * c.partial_rotary + 0.5f), c.embd_scale);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
 static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr)
 {
     const ifa_model_config &c = m->cfg;
@@ -747,11 +826,7 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
         H2.rows = (int)lmt.rows;
         return launch_lmhead(H2, 0, m->opt_rpw_lm, m->stream);
     }
-    DecLmHeadParams H; memset(&H, 0, sizeof(H));
-    H.x = x; H.norm_w = (const half_t *)m->g[T_OUT_NORM].data; H.norm_b = (const half_t *)m->g[T_OUT_NORM_B].data;
-    H.eps = c.eps; H.cols = c.dim; H.W = (const half_t *)m->g[T_LM_HEAD].data; H.logits = logits_out ? logits_out : m->logits;
-    H.rows = (int)m->g[T_LM_HEAD].rows; H.xn_out = m->xn; H.multi_base = c.out_norm_base;
-    return launch_lmhead(H, m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, m->stream);
+    return launch_lmhead(lm_params(m, x, logits_out), m->g[T_OUT_NORM].present() ? 1 : 0, m->opt_rpw_lm, m->stream);
 }
 
 // Device-side counterpart of the host routing in moe_ffn (HostTensorOpr::BuildRowsForMoE, host_tensor_opr.cc:190-244):
@@ -1155,15 +1230,14 @@ static int enqueue_fused_step(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
     hipStream_t s = m->stream;
-    k_dec_gather<<<dim3(2), dim3(256), 0, s>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows, m->x,
-                                               c.rope_order ? m->rope_tab : nullptr, c.head_dim, c.rope_theta,
-                                               (int)(c.head_dim * c.partial_rotary + 0.5f), c.embd_scale);
-    IFA_LAUNCH_CHECK();
-    half_t *x = m->x, *xnext = m->x2;
     int rc;
+    // st_on: the previous step's last launch (or ifa_model_decode, for a call's first step) has gathered this step's input
+    if (!m->st_on && (rc = launch_gather(m))) return rc;
+    half_t *x = m->x, *xnext = m->x2;
     const int n_layers = (m->opt_debug_layers > 0 && m->opt_debug_layers < c.layers) ? m->opt_debug_layers : c.layers;
     if (m->persist_mode) {
         if ((rc = launch_persist(m, 0, n_layers, x, xnext))) return rc;
+        if (m->st_on) return launch_lm_tail(m, xnext);
         if ((rc = launch_lm(m, xnext))) return rc;
         k_dec_argmax_advance<<<dim3(1), dim3(1024), 0, s>>>(m->logits, (int)m->g[T_LM_HEAD].rows, m->state, ifa_model::RING);
         IFA_LAUNCH_CHECK();
@@ -1197,6 +1271,7 @@ static int enqueue_fused_step(ifa_model *m)
         }
         std::swap(x, xnext);
     }
+    if (m->st_on) return launch_lm_tail(m, x);
     if ((rc = launch_lm(m, x))) return rc;
     k_dec_argmax_advance<<<dim3(1), dim3(1024), 0, s>>>(m->logits, (int)m->g[T_LM_HEAD].rows, m->state, ifa_model::RING);
     IFA_LAUNCH_CHECK();
@@ -2334,6 +2409,8 @@ int ifa_model_destroy(ifa_model *m)
     if (m->wf_gran) (void)hipFree(m->wf_gran);
     if (m->wf_img) (void)hipFree(m->wf_img);
     if (m->qa_err) (void)hipFree(m->qa_err);
+    if (m->st_keys) (void)hipFree(m->st_keys);
+    if (m->st_counter) (void)hipFree(m->st_counter);
     if (m->stream) (void)ifa_gemm_release_stream((ifa_stream)m->stream);
     if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -2544,7 +2621,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
@@ -2625,6 +2702,7 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
         if (want) { const PsLayer *tab = nullptr; if ((rc = persist_table(m, &tab))) return rc; }      // (allocates: not under capture)
     }
     if ((rc = qkv_attn_ready(m))) return rc;
+    if ((rc = step_tail_ready(m))) return rc;
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
     if (m->qa_on || m->wf_on) {      // the granule tags of this call: (call counter, position) -- consecutive steps never share one
@@ -2646,6 +2724,10 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1)); IFA_HIP_CHECK(hipEventRecord(e0, s)); }
+    if (m->st_on) {      // the call's first step: arrivals counted from zero (the workgroup count is this call's), input gathered here
+        IFA_HIP_CHECK(hipMemsetAsync(m->st_counter, 0, 4, s));
+        if ((rc = launch_gather(m))) return rc;
+    }
     for (int i = 0; i < n_steps; i++) {
         if (m->opt_graph) IFA_HIP_CHECK(hipGraphLaunch(m->graph_exec, s));
         else if ((rc = enqueue_fused_step(m))) return rc;

@@ -39,7 +39,8 @@ def test_fused_qkv_attention_launch_is_bit_identical(shape, wd, kvd, layers):
     prompt = (np.arange(20, dtype=np.int32) * 11 + 5) % s["vocab"]
     # contexts that cross the 64 / 128 / 256 prefetch buckets: 20 .. 20 + 250
     for steps in (40, 120, 250):
-        ref = _run(wk, s, prompt, steps, fuse_attn=0, fuse_wo=0, fuse_wo_ffn=0)
+        ref = _run(wk, s, prompt, steps, fuse_attn=0, fuse_wo=0, fuse_wo_ffn=0, step_tail=0)
+        wk.set_option("step_tail", 1)
         for opts in ({"fuse_attn": 1, "fuse_wo": 0}, {"fuse_attn": 1, "fuse_wo": 1}, {"fuse_attn": 1, "fuse_wo": 0, "fuse_wo_ffn": 1},
                      {"fuse_attn": 0, "fuse_wo": 0, "fuse_wo_ffn": 1}):
             got = _run(wk, s, prompt, steps, **opts)
@@ -60,3 +61,40 @@ def test_fused_launch_declines_shapes_it_has_no_kernel_for():
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
     with pytest.raises(Exception):
         wk.time_kernel(7, 2)
+
+
+@pytest.mark.parametrize("shape,wd,kvd", [("llama2_7b", dt.Q4_B32T1A, dt.F16), ("tiny15m", dt.F16, dt.F16), ("tiny15m", dt.Q8_B32T2, dt.F16)],
+                         ids=["llama7b_q4", "tiny15m_f16", "tiny15m_q8"])
+def test_step_tail_launch_is_bit_identical(shape, wd, kvd):
+    """lm_head + argmax + state advance + the next step's gather as ONE launch (csrc/ifa_decode_lmhead_tail.h, option step_tail)
+    against the three launches it replaces: tokens and logits of every call, with excluded ids, across several calls and a
+    changed workgroup count (rpw_lm) between them."""
+    kw = {"layers": 2} if shape == "llama2_7b" else {}
+    wk, _, s = synth.build(shape, wd, kvd, max_ctx=256, **kw)
+    prompt = (np.arange(9, dtype=np.int32) * 13 + 2) % s["vocab"]
+
+    def run(tail, excl):
+        wk.set_option("step_tail", tail)
+        wk.set_excluded_tokens(excl)
+        out = []
+        wk.reset()
+        tok = int(wk.forward(prompt, 0))
+        pos = len(prompt)
+        for rpw, steps in ((0, 17), (1, 5), (3, 30), (0, 1), (0, 40)):
+            wk.set_option("rpw_lm", rpw)
+            toks, _ = wk.decode(tok, pos, steps)
+            out.append((list(toks), wk.read_buffer("logits").view(np.uint16).copy()))
+            tok, pos = int(toks[-1]), pos + steps
+        wk.set_option("rpw_lm", 0)
+        return out
+
+    free = run(0, [])
+    first = free[0][0][0]
+    for excl in ([], [first], [first, free[0][0][1], 0]):
+        a, b = run(0, excl), run(1, excl)
+        for (ta, la), (tb, lb) in zip(a, b):
+            assert ta == tb, "tokens differ (excluded %r)" % (excl,)
+            assert np.array_equal(la, lb), "logits differ (excluded %r)" % (excl,)
+        if excl:
+            assert all(t not in excl for ts, _ in b for t in ts)
+    wk.set_excluded_tokens([])
