@@ -165,7 +165,8 @@ int gemm_rows_mfma_launch(const GmArgs &P0, int epi, int norm, hipStream_t s)
     for (int i = 0; i < P.nsets; i++) P.total_rows += P.rows[i];
     if (!gemm_rows_mfma_fused_ok(P, epi, norm)) return ifa_fail(IFA_ERR_ARG, "rows GEMM: shape not covered (T %d, %d blocks, %d sets)", P.T, P.nblk, P.nsets);
     int wgs, maxt;
-    gm_geometry((size_t)P.total_rows, gm_num_cus(), &wgs, &maxt);
+    static const int per_cu = getenv("IFA_ROWS_WGS_PER_CU") ? std::max(1, atoi(getenv("IFA_ROWS_WGS_PER_CU"))) : 1;     // tuning aid
+    gm_geometry((size_t)P.total_rows, gm_num_cus() * (P.T <= 8 ? per_cu : 1), &wgs, &maxt);
     if (epi == GM_GLU) {                       // pairs of tiles: 1, 2, 3, 4 pairs per workgroup
         if (maxt > 4) { maxt = 4; wgs = ((P.total_rows + 15) / 16 + 3) / 4; }
         maxt = maxt == 3 ? 6 : maxt * 2;

@@ -12,6 +12,7 @@
 #include "ifa_decode_kernels.h"
 #include "ifa_moe.h"
 #include "ifa_gemm_rows_mfma.h"
+#include "ifa_dequant_q4.h"
 
 namespace ifa {
 
@@ -80,6 +81,9 @@ __device__ __forceinline__ GmTile gm_locate(const GmSets &S, int vt)
 #ifndef IFA_ROWS_BARRIER_FIRST
 #define IFA_ROWS_BARRIER_FIRST 1
 #endif
+#ifndef IFA_ROWS_FETCH_EARLY
+#define IFA_ROWS_FETCH_EARLY 1
+#endif
 template <int MAXT, int TX, int EPI, int NORM, bool MO, int CH>
 __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 {
@@ -125,6 +129,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     const size_t row_bytes = tiled_row_bytes(Q4_B32T1A, (size_t)nblk);
     const int nq4 = (nsup + 3) >> 2;                              // MO: header quads per tile
     const size_t mo_tile = (size_t)(nsup + nq4) * 1024;           // MO: bytes per 16-row tile
+    const float fp8_up = q4_fp8_up();                             // (ifa_dequant_q4.h)
     const int trow = min(r, T - 1);                               // B operand: token of this lane (columns past T: duplicates, never stored)
     const int trow1 = min(r + 16, T - 1);                         // second column tile (NT == 2)
 
@@ -198,23 +203,16 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
                 cw4 = *reinterpret_cast<const u32x4 *>(patch + (size_t)r * G::CSTRIDE + (size_t)(4 * j + g) * 16);
                 sbw = *reinterpret_cast<const uint32_t *>(patch + 16 * G::CSTRIDE + (size_t)r * G::SSTRIDE + (size_t)(4 * j + g) * 4);
             }
-            const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale = hbits2f((uint16_t)(sbw >> 16));
+            const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale_up = hbits2f((uint16_t)(sbw >> 16)) * fp8_up;
             const char *xrow = smem + (size_t)trow * G::ROW_STRIDE + (size_t)((wave * G::BPW + 4 * j + g) * 32) * 2;
             const char *xrow1 = smem + (size_t)trow1 * G::ROW_STRIDE + (size_t)((wave * G::BPW + 4 * j + g) * 32) * 2;
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
-                const uint32_t cw = cw4[s4];
-                // byte b of the word: low nibble = element 8 s4 + 2b, high nibble = the next one (ifa_gemm_rows.hip)
-                const uint32_t lo = cw & 0x0F0F0F0Fu, hi = (cw >> 4) & 0x0F0F0F0Fu;
-                // two weights per v_pk_fma_f32 + v_cvt_pk_f16_f32 (round to nearest even): the reference's dequantised halves
-                const f2m s2 = {scale, scale}, b2 = {base, base};
-                const f2m q0 = {ubyte_f32<0>(lo), ubyte_f32<0>(hi)}, q1 = {ubyte_f32<1>(lo), ubyte_f32<1>(hi)};
-                const f2m q2 = {ubyte_f32<2>(lo), ubyte_f32<2>(hi)}, q3 = {ubyte_f32<3>(lo), ubyte_f32<3>(hi)};
-                const h2m w0 = __builtin_convertvector(__builtin_elementwise_fma(q0, s2, b2), h2m);
-                const h2m w1 = __builtin_convertvector(__builtin_elementwise_fma(q1, s2, b2), h2m);
-                const h2m w2 = __builtin_convertvector(__builtin_elementwise_fma(q2, s2, b2), h2m);
-                const h2m w3 = __builtin_convertvector(__builtin_elementwise_fma(q3, s2, b2), h2m);
-                const h8m a = {w0[0], w0[1], w1[0], w1[1], w2[0], w2[1], w3[0], w3[1]};
+                // byte b of the word: low nibble = element 8 s4 + 2b, high nibble = the next one (ifa_gemm_rows.hip); the reference's
+                // dequantised halves, two codes per conversion (ifa_dequant_q4.h: 15 VALU instructions per 8 weights, was 19)
+                q4_h2 wq[4];
+                q4x8_dequant(cw4[s4], scale_up, base, wq);
+                const h8m a = {wq[0][0], wq[0][1], wq[1][0], wq[1][1], wq[2][0], wq[2][1], wq[3][0], wq[3][1]};
                 const h8m b = *reinterpret_cast<const h8m *>(xrow + s4 * 16);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
                 if constexpr (NT == 2) {
@@ -234,7 +232,13 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     // waiting ~half of the time for HBM
     GmGrp buf[PD];
     const int nq = nchunk * MAXT;                                  // (chunk, tile) pairs in execution order: chunk outer
-    auto fetch_q = [&](GmGrp &q, int qi) { const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, ch, qi < nq); };
+    // (one chunk: the groups past the last one are not requested at all -- qi is a literal after unrolling, the test folds away.
+    //  As clamped dummy loads they were 5 of the 8 group requests of a wave of the wq | wk | wv launch: ~0.6 us of the CU's
+    //  request path.  The chunk loop keeps them: a branch around a load makes every later wait a vmcnt(0).)
+    auto fetch_q = [&](GmGrp &q, int qi) __attribute__((always_inline)) {
+        if constexpr (CH == 1) { if (qi >= MAXT) return; }
+        const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, ch, qi < nq);
+    };
     // The CU's memory pipeline is FIFO across waves (ifa_decode_kernels.h): the activation rows of the first chunk are
     // requested by all threads, and a barrier passed, BEFORE any weight request -- else they arrive behind the weights.
     // A full chunk is 512 16-byte pieces per row: piece tid of row k is thread tid's k-th request.
@@ -253,7 +257,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             nwv = *reinterpret_cast<const u32x4 *>((nwp ? nwp : Xp) + (size_t)min(xpiece, per_row - 1) * 8);   // (no weight: a valid dummy address)
     };
     long long *const trc_x = P.trace ? P.trace + (size_t)blockIdx.x * 32 : nullptr;
-    auto x_store = [&](int chunk) {
+    auto x_store = [&](int chunk, bool first_chunk = false) {
         const int per_row = min(G::CHUNK_COLS, K - chunk * G::CHUNK_COLS) >> 3;
         if constexpr (NORM == 1) {
             // RMS norm of every row in the canonical order of ifa_math.h: piece c = tid is lane c % 64 of group c / 64 = wave
@@ -327,6 +331,18 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
                 xv[k] = __builtin_bit_cast(u32x4, o);
             }
         }
+#if IFA_ROWS_FETCH_EARLY
+        if constexpr (NORM == 0) {
+            // Round 4: plain staging (wo, w2, all 17..32-row launches): the other PD - 1 groups are requested BEFORE the rows are
+            // stored -- behind the rows' own requests in this CU's queue, so the rows still return first -- instead of behind the
+            // staging barrier: 32 queries 3.69 -> 3.36 ms per step, 16 queries 2.28 -> 2.18 (2 queries: unchanged)
+            if (first_chunk) {
+#pragma unroll
+                for (int d = 1; d < PD; d++) fetch_q(buf[d], d);
+                if (trc_x && tid == 0) trc_x[18] = wall_clock64();
+            }
+        }
+#endif
         if (trc_x && tid == 0) trc_x[16] = wall_clock64();
         // UNCONDITIONAL stores (rows past T hold duplicates of row T - 1, pieces past the row end duplicates of its last piece: both
         // inside the image, never read as data): a branch around the store made the wait in front of it vmcnt(0), i.e. the staging
@@ -366,11 +382,19 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             fetch_q(buf[PD - 1], qi + PD);
         }
     };
-    x_store(0);
+    x_store(0, true);
     // The staging barrier FIRST, the other PD - 1 groups behind it (round 4): requested in front of the barrier, every wave sat in
     // its load issue (4 x 5 KB per wave against a full memory queue) before it could arrive -- the rows were staged at 3.0 us and
     // the barrier passed at 4.8 (rows-trace: "other groups requested 3.22, x staged 4.77"); the first group is in flight since 0.8
-#if IFA_ROWS_BARRIER_FIRST
+#if IFA_ROWS_FETCH_EARLY
+    __syncthreads();
+    if (trc && tid == 0) trc[2] = wall_clock64();
+    if constexpr (NORM == 1) {      // (norm prologue: requested from inside the staging, every wave would sit in its load issue for ~1.2 us with the rows still to scale)
+#pragma unroll
+        for (int d = 1; d < PD; d++) fetch_q(buf[d], d);
+        if (trc && tid == 0) trc[18] = wall_clock64();
+    }
+#elif IFA_ROWS_BARRIER_FIRST
     __syncthreads();
     if (trc && tid == 0) trc[2] = wall_clock64();
 #pragma unroll
@@ -463,7 +487,7 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma(const GmArgs P)
 static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : 16)); }
 static size_t gm_smem(int T, int maxt, int mo)
 {
-    const int tx = mo ? (T <= 8 ? 8 : (T <= 16 ? 16 : 32)) : gm_tx(T);
+    const int tx = mo ? (T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : (T <= 16 ? 16 : 32)))) : gm_tx(T);
     if (mo && tx == 32) return std::max((size_t)32 * GmGeo<16>::ROW_STRIDE, (size_t)2 * maxt * GM_WAVES * 256 * 4);
     if (mo) return std::max((size_t)tx * GmGeo<32>::ROW_STRIDE + (size_t)16 * GM_WAVES * 4, (size_t)maxt * GM_WAVES * 256 * 4);
     const size_t row = tx > 8 ? GmGeo<16>::ROW_STRIDE : GmGeo<32>::ROW_STRIDE, patch = tx > 8 ? GmGeo<16>::PATCH_BYTES : GmGeo<32>::PATCH_BYTES;
