@@ -21,7 +21,6 @@
 #include "ifa_decode_gemv.h"
 #include "ifa_moe.h"
 #include "ifa_gemm_rows_mfma.h"
-#include "ifa_gemm_rows_gemv.h"
 #include "ifa_gemm_big.h"
 #include "ifa_decode_persist_launch.h"
 #include "ifa_decode_lmhead_tail.h"
@@ -132,7 +131,7 @@ struct ifa_model {
     int opt_step_tail = 1, st_on = 0;
     unsigned long long *st_keys = nullptr; unsigned *st_counter = nullptr; int st_keys_n = 0;
     int attn_pb = 256, opt_attn_kt = 1;      // cache rows the one-workgroup decode attention requests at entry (64 / 128 / 256: the bucket the call stays inside); K rows through the LDS tile
-    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1, opt_rows_gemv = 0;
+    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -2082,26 +2081,12 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     int rc;
     GmArgs P;
     auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = n; P.eps = c.eps; P.act_kind = c.act_kind; };
-    // 2..4 queries: the streaming kernels with the batch-1 GEMV's structure on the tiled rows (ifa_gemm_rows_gemv.h) instead of the
-    // matrix-core tiles; all linears of the layer alike
-    bool gv = m->opt_rows_gemv && n <= 4;
-    {
-        const bool moe_l = c.experts > 0 && L.t[T_MOE_GATE].present();
-        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
-        for (int id : ids) {
-            if (moe_l && (id == T_W1 || id == T_W3 || id == T_W2)) continue;
-            gv = gv && is_q4(L.t[id].dtype) && L.t[id].tiled && L.t[id].cols % 32 == 0 && L.t[id].cols <= 16384;
-        }
-    }
-    auto rows_w = [&](const ifa_model *mm, const Tensor &t) { return gv ? (const uint8_t *)t.tiled : ::rows_w(mm, t); };
-    auto rows_mo = [&](const ifa_model *mm, const Tensor &t) { return gv ? 0 : ::rows_mo(mm, t); };
-    auto gemm_rows_mfma_launch = [&](const GmArgs &A, int epi, int norm, hipStream_t st) { return gv ? gemm_rows_gemv_launch(A, epi, norm, st) : ifa::gemm_rows_mfma_launch(A, epi, norm, st); };
     // 1. RmsNorm -> wq | wk | wv  (one virtual row space, one [n][q | k | v] output)
     clear();
     P.W[0] = rows_w(m, L.t[T_WQ]); P.W[1] = rows_w(m, L.t[T_WK]); P.W[2] = rows_w(m, L.t[T_WV]); P.mo = rows_mo(m, L.t[T_WQ]);
     P.rows[0] = (int)QD; P.rows[1] = (int)KVD; P.rows[2] = (int)KVD; P.nsets = 3; P.nblk = (int)(D / 32);
     // (9..16 queries: the activation rows are staged in chunks of 2048 columns, so the norm runs as its own launch)
-    const bool norm_fused = gv || ((n <= 8 || rows_mo(m, L.t[T_WQ])) && n <= 16);      // (MO layout: 16 rows x 4096 columns are one chunk too; 17..32 rows: chunked)
+    const bool norm_fused = (n <= 8 || rows_mo(m, L.t[T_WQ])) && n <= 16;      // (MO layout: 16 rows x 4096 columns are one chunk too; 17..32 rows: chunked)
     Tensor nob;
     if (!norm_fused && (rc = norm_rows(m, x, n, L.t[T_ATTN_NORM], nob, m->xn, c.attn_norm_base))) return rc;
     P.X = norm_fused ? x : m->xn; P.ldx = (int)D;
@@ -2636,7 +2621,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"rows_gemv", &m->opt_rows_gemv}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
