@@ -6,7 +6,7 @@
 // argmax_scan (largest value, lowest id among equals, the excluded ids never offered: SamplingStrategy::GetSortedTopK,
 // sampling_strategy.cc:281-297), the workgroup reduces its 8 waves, stores ONE 64-bit key -- (ordered value bits << 32) |
 // (0xFFFFFFFF - id): an unsigned maximum is the argmax -- past the caches, drains the store and bumps a counter; the workgroup
-// whose bump is the launch's last (old % grid == grid - 1: the counter only ever grows by `grid` per launch) reads all keys,
+// whose bump is the launch's last (old == grid - 1; it puts the counter back to zero for the next launch) reads all keys,
 // writes the state words exactly as k_dec_argmax_advance does, copies the new token's embedding row and fills the RoPE table of
 // the new position.  Same logits buffer, same ids, same state: tokens bit-identical to the three-launch tail (tests).
 #pragma once
@@ -17,7 +17,7 @@ namespace ifa {
 struct DecStepTail {
     int *state; int ring;
     unsigned long long *keys;       // [grid] per-workgroup best
-    unsigned *counter;              // arrivals, never reset
+    unsigned *counter;              // arrivals of the running launch (zero between launches)
     const half_t *embd; int vocab; half_t *x_out;
     float *rope_tab; int head_dim; float theta; int rope_dims; float embd_scale;
 };
@@ -142,12 +142,13 @@ __global__ void __launch_bounds__(DEC_THREADS) k_dec_lmhead_tail(const DecLmHead
         __hip_atomic_store(Z.keys + blockIdx.x, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the key is in memory before the arrival is counted
         const unsigned old = __hip_atomic_fetch_add(Z.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = (old % gridDim.x == gridDim.x - 1) ? 1u : 0u;
+        flag[0] = (old == gridDim.x - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (flag[0] == 0u) return;
     // ---- the launch's last workgroup: the argmax over the workgroups' keys, then k_dec_argmax_advance's state update and
     // k_dec_gather's row copy + RoPE table for the NEW token at the NEW position
+    if (tid == 0) __hip_atomic_store(Z.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every arrival of this launch is in: the next launch counts from zero
     unsigned long long mk = 0ull;
     for (int i = tid; i < (int)gridDim.x; i += DEC_THREADS) {
         const unsigned long long k = __hip_atomic_load(Z.keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

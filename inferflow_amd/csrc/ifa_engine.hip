@@ -779,7 +779,10 @@ static int step_tail_ready(ifa_model *m)
         IFA_HIP_CHECK(hipMalloc((void **)&m->st_keys, sizeof(unsigned long long) * (size_t)grid));
         m->st_keys_n = grid;
     }
-    if (!m->st_counter) IFA_HIP_CHECK(hipMalloc((void **)&m->st_counter, 16));
+    if (!m->st_counter) {
+        IFA_HIP_CHECK(hipMalloc((void **)&m->st_counter, 16));
+        IFA_HIP_CHECK(hipMemsetAsync(m->st_counter, 0, 16, m->stream));
+    }
     return IFA_OK;
 }
 
@@ -835,7 +838,7 @@ static int launch_lm(ifa_model *m, const half_t *x, half_t *logits_out = nullptr
 // top-k of one row by ONE wave, lane e = expert e with probability p (lanes >= E: -inf): k_moe_topk's rules -- repeated first
 // maximum, probabilities below 1e-5 dropped, optional renormalisation in pick order, kept experts in ascending id, unused
 // slots expert 0 / weight 0.  (The one-thread form walked local arrays that live in scratch: ~20 us of dependent loads.)
-__device__ __forceinline__ void moe_topk_wave(float p, int lane, int E, int top_k, int norm_topk, int *__restrict__ sel, half_t *__restrict__ wout)
+__device__ __forceinline__ void moe_topk_wave(float p, int lane, int E, int top_k, int norm_topk, int *__restrict__ sel, half_t *__restrict__ wout, int unused_id = 0)
 {
     bool used = lane >= E;
     int idx[8]; float w[8];
@@ -872,7 +875,7 @@ __device__ __forceinline__ void moe_topk_wave(float p, int lane, int E, int top_
             for (int j2 = 0; j2 < 8; j2++) rank += (j2 < n && idx[j2] < idx[j]) ? 1 : 0;
             sel[rank] = idx[j]; wout[rank] = f2h(w[j]);
         }
-        for (int slot = n; slot < top_k; slot++) { sel[slot] = 0; wout[slot] = (half_t)0; }
+        for (int slot = n; slot < top_k; slot++) { sel[slot] = unused_id; wout[slot] = (half_t)0; }
     }
 }
 
@@ -890,8 +893,15 @@ __global__ void __launch_bounds__(64) k_moe_topk(const half_t *__restrict__ prob
 __global__ void __launch_bounds__(512) k_dec_moe_router(const half_t *__restrict__ x, const half_t *__restrict__ nw, const half_t *__restrict__ nb,
                                                         float multi_base, float eps, int cols, const half_t *__restrict__ gate_w, int E, int top_k,
                                                         int norm_topk, half_t *__restrict__ hn_out, half_t *__restrict__ probs_out,
-                                                        int *__restrict__ sel, half_t *__restrict__ wout)
+                                                        int *__restrict__ sel, half_t *__restrict__ wout, int unused_id)
 {
+    // one workgroup per row (the batched step: blockIdx.x = query; a decode step: one row); rows are `cols` apart, a row's
+    // routing top_k slots apart, unused slots carry `unused_id` (0 for the fused decode step: weight 0 makes them no-ops; -1 for
+    // the list builder of the batched step, k_moe_route_rows' convention)
+    x += (size_t)blockIdx.x * cols;
+    if (hn_out) hn_out += (size_t)blockIdx.x * cols;
+    if (probs_out) probs_out += (size_t)blockIdx.x * E;
+    sel += (size_t)blockIdx.x * top_k; wout += (size_t)blockIdx.x * top_k;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t *xs = reinterpret_cast<half_t *>(smem);                                                    // [cols]
     float *part = reinterpret_cast<float *>(smem + (((size_t)cols * 2 + 15) & ~(size_t)15));         // [64] group sums
@@ -979,7 +989,7 @@ __global__ void __launch_bounds__(512) k_dec_moe_router(const half_t *__restrict
     // ---- top-k by wave 0, lane e = expert e (k_moe_topk's rules: repeated first maximum, probabilities below 1e-5 dropped,
     // optional renormalisation in pick order, kept experts in ascending id, unused slots expert 0 / weight 0).  The
     // one-thread form walks local arrays that live in scratch: ~20 us of dependent scratch loads per layer.
-    if (wave == 0) moe_topk_wave(lane < E ? h2f(probs[lane]) : -INFINITY, lane, E, top_k, norm_topk, sel, wout);
+    if (wave == 0) moe_topk_wave(lane < E ? h2f(probs[lane]) : -INFINITY, lane, E, top_k, norm_topk, sel, wout, unused_id);
 }
 
 extern "C" int ifa_add_layernorm(int kind, const void *a, const void *addend, size_t rows, size_t cols, const void *w, const void *b,
@@ -1001,7 +1011,7 @@ int gemm_rows_mfma_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, c
 int gemm_rows_mo_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, int glu, int act_kind, hipStream_t s);
 int gemm_rows_q4_grouped(const MoeSmallGroup &grp, size_t rows, size_t cols, const void *X, void *Y, int max_groups, hipStream_t s);
 int moe_gather(const void *src, const int *idx, const int *counts, int max_entries, int dim, void *dst, hipStream_t s);
-int moe_combine(const void *y, const int *epos, const void *wsel, int T, int top_k, int dim, void *out, hipStream_t s);
+int moe_combine(const void *y, const int *epos, const void *wsel, int T, int top_k, int dim, void *out, hipStream_t s, const void *residual = nullptr);
 int gemm_q_grouped(int w_dtype, const MoeGroup &grp, size_t N, size_t K, const void *X, void *Y, int max_tiles, int tile_rows, hipStream_t s);
 int gemv_ax8_grouped(int w_dtype, const MoeGroup &grp, size_t rows, size_t cols, const void *xq8_rows, void *y_rows, int max_singles,
                      hipStream_t s);
@@ -1023,7 +1033,7 @@ static int launch_moe_router(ifa_model *m, int l)
         k_dec_moe_router<<<1, 512, smem, m->stream>>>(m->a, has_norm ? (const half_t *)L.t[T_FFN_NORM].data : nullptr,
                                                       has_norm ? (const half_t *)L.t[T_FFN_NORM_B].data : nullptr, c.ffn_norm_base, has_norm ? c.eps : -1.0f,
                                                       c.dim, (const half_t *)gw.data, c.experts, c.moe_top_k, c.moe_norm_topk, m->hn, m->moe_gate, m->moe_route,
-                                                      reinterpret_cast<half_t *>(reinterpret_cast<char *>(m->moe_route) + 32));
+                                                      reinterpret_cast<half_t *>(reinterpret_cast<char *>(m->moe_route) + 32), 0);
         IFA_LAUNCH_CHECK();
         return IFA_OK;
     }
@@ -1506,7 +1516,7 @@ static int ffn_dense(ifa_model *m, const half_t *x, int T, const Tensor &w1, con
 // optional renormalisation) -> the selected experts' FFNs in ascending expert order, each row on the T=1
 // path -> B[row] = hfma(out, weight, B[row]) (AddByRowIdx_Kernel).  Result in m->f.
 static bool moe_device_ok(const ifa_model *m, const Layer &L);
-static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T);
+static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T, const half_t *pre_norm = nullptr, const half_t *residual = nullptr, half_t *out = nullptr);
 
 static int moe_ffn(ifa_model *m, Layer &L, const half_t *ff_n, int T)
 {
@@ -1599,7 +1609,18 @@ static bool moe_device_ok(const ifa_model *m, const Layer &L)
 }
 
 static int max_smalls_possible(bool rows_kernel, int E, int cap) { return rows_kernel ? std::min(E, cap / 2) : 0; }
-static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
+// can the rows of a batched step be routed by ONE launch (k_dec_moe_router, a workgroup per row: norm, F16 gate GEMV, softmax, top-k)?
+static bool moe_router_rows_ok(const ifa_model *m, const Layer &L, int T)
+{
+    const ifa_model_config &c = m->cfg;
+    const Tensor &gw = L.t[T_MOE_GATE];
+    return m->opt_moe_router_fused && T <= 32 && c.norm_kind == 0 && gw.dtype == F16 && c.dim % 8 == 0 && c.dim <= 16384 && c.experts <= 64
+        && (int)gw.cols == c.dim && L.t[T_FFN_NORM].present();
+}
+
+// pre_norm: the rows BEFORE the FFN norm (ff_n is then where the normalised rows go): the batched step's router launch does the norm too
+// residual / out: the layer's residual Add in the combine launch, result in `out` (default: the FFN output alone in m->f)
+static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T, const half_t *pre_norm, const half_t *residual, half_t *out)
 {
     const ifa_model_config &c = m->cfg;
     const size_t D = (size_t)c.dim, F = L.experts[0].rows;
@@ -1607,9 +1628,19 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     ifa_stream s = (ifa_stream)m->stream;
     int rc;
     Tensor none;
-    if ((rc = matmul(m, ff_n, T, L.t[T_MOE_GATE], none, m->moe_gate))) return rc;
-    if ((rc = ifa_softmax(m->moe_gate, E, T, 1, -1, 1.0f, s))) return rc;
-    if ((rc = ifa_moe_route_topk(m->moe_gate, (size_t)T, E, K, c.moe_norm_topk, m->moe_sel, m->moe_selw, s))) return rc;
+    if (pre_norm) {
+        // norm + gate + softmax + top-k of every row as one launch instead of four (each with the arithmetic of the decode step's
+        // router: the gate product is the F16 GEMV's fp32 chain, not the GEMM tile's): 25 -> 7 us per layer at 8 queries
+        const size_t smem = (((size_t)c.dim * 2 + 15) & ~(size_t)15) + 64 * 4 + 64 * 2;
+        k_dec_moe_router<<<dim3((unsigned)T), 512, smem, m->stream>>>(pre_norm, (const half_t *)L.t[T_FFN_NORM].data, (const half_t *)L.t[T_FFN_NORM_B].data,
+                                                                      c.ffn_norm_base, c.eps, c.dim, (const half_t *)L.t[T_MOE_GATE].data, E, K, c.moe_norm_topk,
+                                                                      const_cast<half_t *>(ff_n), m->moe_gate, m->moe_sel, (half_t *)m->moe_selw, -1);
+        IFA_LAUNCH_CHECK();
+    } else {
+        if ((rc = matmul(m, ff_n, T, L.t[T_MOE_GATE], none, m->moe_gate))) return rc;
+        if ((rc = ifa_softmax(m->moe_gate, E, T, 1, -1, 1.0f, s))) return rc;
+        if ((rc = ifa_moe_route_topk(m->moe_gate, (size_t)T, E, K, c.moe_norm_topk, m->moe_sel, m->moe_selw, s))) return rc;
+    }
     // rows per expert on average >= 96: 128-row tiles (each decoded weight block feeds four MFMA tiles); else 64-row split-K tiles
     const int tile_rows = (cap / std::max(1, E) >= 96) ? 128 : 64;
     // a handful of rows per expert (dynamic batching): experts with 2..small_max rows stream their tiled Q4 weights once
@@ -1659,7 +1690,7 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T)
     sg.which_tiled = 2;
     if (max_smalls && smalls_mo) { if ((rc = gemm_rows_mo_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls, 0, c.act_kind, m->stream))) return rc; }
     else if (max_smalls && (rc = rows_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls))) return rc;
-    return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, m->f, m->stream);
+    return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, out ? out : m->f, m->stream, residual);
 }
 
 static bool batch_fused_ok(const ifa_model *m, int n);
@@ -2130,8 +2161,11 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
         // mixture of experts: norm, the device-routed expert FFNs over the n rows (moe_ffn_device), residual
         Tensor none;
-        if ((rc = norm_rows(m, m->a, n, L.t[T_FFN_NORM], none, m->hn, c.ffn_norm_base))) return rc;
-        if ((rc = moe_ffn(m, L, m->hn, n))) return rc;
+        if (moe_device_ok(m, L) && moe_router_rows_ok(m, L, n)) return moe_ffn_device(m, L, m->hn, n, m->a, m->a, xnext);
+        {
+            if ((rc = norm_rows(m, m->a, n, L.t[T_FFN_NORM], none, m->hn, c.ffn_norm_base))) return rc;
+            if ((rc = moe_ffn(m, L, m->hn, n))) return rc;
+        }
         return ifa_add(m->f, m->a, (size_t)n * D, 0, xnext, (ifa_stream)m->stream);
     }
     // 4. RmsNorm -> w1, w3 -> act(w1 x) * (w3 x)
@@ -2724,10 +2758,7 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1)); IFA_HIP_CHECK(hipEventRecord(e0, s)); }
-    if (m->st_on) {      // the call's first step: arrivals counted from zero (the workgroup count is this call's), input gathered here
-        IFA_HIP_CHECK(hipMemsetAsync(m->st_counter, 0, 4, s));
-        if ((rc = launch_gather(m))) return rc;
-    }
+    if (m->st_on && (rc = launch_gather(m))) return rc;      // the call's first step: its input is gathered here, every later one by the step before it
     for (int i = 0; i < n_steps; i++) {
         if (m->opt_graph) IFA_HIP_CHECK(hipGraphLaunch(m->graph_exec, s));
         else if ((rc = enqueue_fused_step(m))) return rc;

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_moe_gather(const half_t *__restrict__ s
 // out[t][d] = hfma(y[pos_j][d], w_j, ...) over row t's experts in ascending expert order, starting from 0
 // (the memset + AddByRowIdx_Kernel sequence of the reference's expert loop, src/kernels/binary_tensor_opr.h:80-125)
 __global__ void __launch_bounds__(256) k_moe_combine(const half_t *__restrict__ y, const int *__restrict__ epos, const half_t *__restrict__ wsel,
-                                                     int T, int top_k, int dim, half_t *__restrict__ out)
+                                                     int T, int top_k, int dim, half_t *__restrict__ out, const half_t *__restrict__ residual)
 {
     const int t = blockIdx.y;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,6 +80,8 @@ __global__ void __launch_bounds__(256) k_moe_combine(const half_t *__restrict__ 
         const int pos = epos[t * top_k + j];
         if (pos >= 0) acc = __builtin_fmaf16(y[(size_t)pos * dim + d], wsel[t * top_k + j], acc);
     }
+    // residual: the layer's TensorOpr::Add behind the expert loop (its own half rounding), in the same launch
+    if (residual) acc = f2h(h2f(residual[(size_t)t * dim + d]) + h2f(acc));
     out[(size_t)t * dim + d] = acc;
 }
 
@@ -99,9 +101,10 @@ int moe_gather(const void *src, const int *idx, const int *counts, int max_entri
     return IFA_OK;
 }
 
-int moe_combine(const void *y, const int *epos, const void *wsel, int T, int top_k, int dim, void *out, hipStream_t s)
+int moe_combine(const void *y, const int *epos, const void *wsel, int T, int top_k, int dim, void *out, hipStream_t s, const void *residual)
 {
-    k_moe_combine<<<dim3(ifa_cdiv((size_t)dim, 256), (unsigned)T), dim3(256), 0, s>>>((const half_t *)y, epos, (const half_t *)wsel, T, top_k, dim, (half_t *)out);
+    k_moe_combine<<<dim3(ifa_cdiv((size_t)dim, 256), (unsigned)T), dim3(256), 0, s>>>((const half_t *)y, epos, (const half_t *)wsel, T, top_k, dim, (half_t *)out,
+                                                                                     (const half_t *)residual);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
