@@ -78,6 +78,10 @@ __device__ __forceinline__ GmTile gm_locate(const GmSets &S, int vt)
 // one contiguous KiB per wave and the LDS patch (store, wait, read back: a ~1.2 us dependent chain per group) disappears.
 // Same operands, same MFMA order: bit-identical to the tiled path.
 // CH: 1 = the K range is ONE chunk of activation rows (checked by the launcher): straight-line code with counted waits
+//     2 = rows longer than a chunk staged WHOLE, once (MO, <= 4 rows, no norm: w2 of a batched step of 2..4 queries, the 2..4-row
+//         expert groups of a MoE step): the weight groups still walk 4096-column chunks, but no chunk is re-staged -- the chunk
+//         loop of CH = 0 stages, passes two barriers and drains its waves once per chunk (rows-trace at 2 queries, K = 11008:
+//         the data is in by 5 us, the loop ends at 10)
 #ifndef IFA_ROWS_BARRIER_FIRST
 #define IFA_ROWS_BARRIER_FIRST 1
 #endif
@@ -95,6 +99,8 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     // dequantised A operand (NT = 2), staged in 2048-column chunks (32 rows x 4 KB)
     constexpr int NT = TX > 16 ? 2 : 1;
     static_assert(NT == 1 || (MO && NORM == 0 && CH == 0), "17..32 rows: MO layout, chunked rows, norm as its own launch");
+    constexpr bool WHOLE = CH == 2;
+    static_assert(!WHOLE || (MO && NORM == 0 && TX <= 4), "whole-row staging: MO layout, <= 4 rows, no norm prologue");
     using G = GmGeo<(MO && TX <= 16) ? 32 : gm_cs(TX)>;
     using GmGrp = GmGrpT<G::NI>;
     static_assert(NORM == 0 || G::CHUNK_SUP == 32, "the norm prologue needs the whole row in one chunk");
@@ -130,6 +136,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     const int nq4 = (nsup + 3) >> 2;                              // MO: header quads per tile
     const size_t mo_tile = (size_t)(nsup + nq4) * 1024;           // MO: bytes per 16-row tile
     const float fp8_up = q4_fp8_up();                             // (ifa_dequant_q4.h)
+    const int row_stride = WHOLE ? K * 2 + 16 : G::ROW_STRIDE;    // bytes per activation row in LDS
     const int trow = min(r, T - 1);                               // B operand: token of this lane (columns past T: duplicates, never stored)
     const int trow1 = min(r + 16, T - 1);                         // second column tile (NT == 2)
 
@@ -204,8 +211,9 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
                 sbw = *reinterpret_cast<const uint32_t *>(patch + 16 * G::CSTRIDE + (size_t)r * G::SSTRIDE + (size_t)(4 * j + g) * 4);
             }
             const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale_up = hbits2f((uint16_t)(sbw >> 16)) * fp8_up;
-            const char *xrow = smem + (size_t)trow * G::ROW_STRIDE + (size_t)((wave * G::BPW + 4 * j + g) * 32) * 2;
-            const char *xrow1 = smem + (size_t)trow1 * G::ROW_STRIDE + (size_t)((wave * G::BPW + 4 * j + g) * 32) * 2;
+            const int xcol = (WHOLE ? chunk * G::CHUNK_COLS : 0) + (wave * G::BPW + 4 * j + g) * 32;
+            const char *xrow = smem + (size_t)trow * row_stride + (size_t)xcol * 2;
+            const char *xrow1 = smem + (size_t)trow1 * row_stride + (size_t)xcol * 2;
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
                 // byte b of the word: low nibble = element 8 s4 + 2b, high nibble = the next one (ifa_gemm_rows.hip); the reference's
@@ -255,6 +263,26 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             xv[k] = *reinterpret_cast<const u32x4 *>(Xp + (size_t)min(xsub + G::XR * k, T - 1) * ldx + c0 + (size_t)min(xpiece, per_row - 1) * 8);
         if constexpr (NORM == 1)
             nwv = *reinterpret_cast<const u32x4 *>((nwp ? nwp : Xp) + (size_t)min(xpiece, per_row - 1) * 8);   // (no weight: a valid dummy address)
+    };
+    // whole rows (CH == 2): piece tid + 512 p of every row, p < 4 (K <= 16384); pieces past the row end are duplicates of its last
+    // piece -- requested and stored unconditionally (same bytes to the same place), like the clamped rows above
+    constexpr int WP = WHOLE ? 4 : 1;
+    u32x4 xw[WHOLE ? TX : 1][WP];
+    auto xw_request = [&]() {
+        const int pieces = K >> 3;
+#pragma unroll
+        for (int k = 0; k < (WHOLE ? TX : 1); k++)
+#pragma unroll
+            for (int pp = 0; pp < WP; pp++)
+                xw[k][pp] = *reinterpret_cast<const u32x4 *>(Xp + (size_t)min(k, T - 1) * ldx + (size_t)min(tid + GM_THREADS * pp, pieces - 1) * 8);
+    };
+    auto xw_store = [&]() {
+        const int pieces = K >> 3;
+#pragma unroll
+        for (int k = 0; k < (WHOLE ? TX : 1); k++)
+#pragma unroll
+            for (int pp = 0; pp < WP; pp++)
+                *reinterpret_cast<u32x4 *>(smem + (size_t)k * row_stride + (size_t)min(tid + GM_THREADS * pp, pieces - 1) * 16) = xw[k][pp];
     };
     long long *const trc_x = P.trace ? P.trace + (size_t)blockIdx.x * 32 : nullptr;
     auto x_store = [&](int chunk, bool first_chunk = false) {
@@ -356,7 +384,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     };
     long long *const trc = P.trace ? P.trace + (size_t)blockIdx.x * 32 : nullptr;
     if (trc && tid == 0) trc[0] = wall_clock64();
-    x_request(0);
+    if constexpr (WHOLE) xw_request(); else x_request(0);
     __syncthreads();
     if (trc && tid == 0) trc[1] = wall_clock64();
     // ONE group per wave is requested in front of the staging, the rest behind it: with all PD groups (30 MB chip-wide for a
@@ -382,7 +410,11 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             fetch_q(buf[PD - 1], qi + PD);
         }
     };
-    x_store(0, true);
+    if constexpr (WHOLE) {
+#pragma unroll
+        for (int d = 1; d < PD; d++) fetch_q(buf[d], d);      // (behind the rows' own requests in this CU's queue, see x_store)
+        xw_store();
+    } else x_store(0, true);
     // The staging barrier FIRST, the other PD - 1 groups behind it (round 4): requested in front of the barrier, every wave sat in
     // its load issue (4 x 5 KB per wave against a full memory queue) before it could arrive -- the rows were staged at 3.0 us and
     // the barrier passed at 4.8 (rows-trace: "other groups requested 3.22, x staged 4.77"); the first group is in flight since 0.8
@@ -409,6 +441,8 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 #endif
     if constexpr (CH == 1) {
         run_chunk(0);
+    } else if constexpr (WHOLE) {
+        for (int chunk = 0; chunk < nchunk; chunk++) run_chunk(chunk);
     } else {
         for (int chunk = 0; chunk < nchunk; chunk++) {
             const int nx = min(chunk + 1, nchunk - 1);
@@ -485,6 +519,8 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma(const GmArgs P)
 }
 
 static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : 16)); }
+// whole-row staging (CH == 2): tx rows of K columns
+static size_t gm_smem_whole(int tx, int K, int maxt) { return std::max((size_t)tx * ((size_t)K * 2 + 16), (size_t)maxt * GM_WAVES * 256 * 4); }
 static size_t gm_smem(int T, int maxt, int mo)
 {
     const int tx = mo ? (T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : (T <= 16 ? 16 : 32)))) : gm_tx(T);

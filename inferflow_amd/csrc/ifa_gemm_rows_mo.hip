@@ -57,9 +57,35 @@ static int mo_launch1(int wgs, size_t smem, const GmArgs &P, int epi, int norm, 
     return mo_launch32<MT>(wgs, smem, P, epi, norm, s);
 }
 
+// 2..4 rows longer than one chunk, no norm: staged whole (CH = 2)
+template <int MT>
+static int mo_launch_whole(int wgs, size_t smem, const GmArgs &P, int epi, hipStream_t s)
+{
+    if (P.T <= 2) {
+        if (epi == GM_PLAIN) return mo_launch4<MT, 2, GM_PLAIN, 0, 2>(wgs, smem, P, s);
+        if (epi == GM_RESIDUAL) return mo_launch4<MT, 2, GM_RESIDUAL, 0, 2>(wgs, smem, P, s);
+    } else {
+        if (epi == GM_PLAIN) return mo_launch4<MT, 4, GM_PLAIN, 0, 2>(wgs, smem, P, s);
+        if (epi == GM_RESIDUAL) return mo_launch4<MT, 4, GM_RESIDUAL, 0, 2>(wgs, smem, P, s);
+    }
+    return ifa_fail(IFA_ERR_ARG, "rows GEMM (MO, whole rows): no kernel for epilogue %d", epi);
+}
+
 int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, hipStream_t s)
 {
     const bool one = P.nblk * 32 <= GmGeo<32>::CHUNK_COLS && P.T <= 16;
+    const int K = P.nblk * 32;
+    if (!one && norm == 0 && P.T <= 4 && K <= 16384 && (epi == GM_PLAIN || epi == GM_RESIDUAL) && gm_smem_whole(P.T <= 2 ? 2 : 4, K, maxt) <= (size_t)150 * 1024) {
+        const size_t smw = gm_smem_whole(P.T <= 2 ? 2 : 4, K, maxt);
+        switch (maxt) {
+        case 1: return mo_launch_whole<1>(wgs, smw, P, epi, s);
+        case 2: return mo_launch_whole<2>(wgs, smw, P, epi, s);
+        case 3: return mo_launch_whole<3>(wgs, smw, P, epi, s);
+        case 4: return mo_launch_whole<4>(wgs, smw, P, epi, s);
+        case 6: return mo_launch_whole<6>(wgs, smw, P, epi, s);
+        default: return mo_launch_whole<8>(wgs, smw, P, epi, s);
+        }
+    }
     if (norm == 1 && !one) return ifa_fail(IFA_ERR_ARG, "rows GEMM (MO): the norm prologue needs the whole row in one chunk");
     const size_t smem = gm_smem(P.T, maxt, 1);
     switch (maxt) {
@@ -77,7 +103,7 @@ int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, h
 // ONE launch with act(w1 x) * (w3 x) as the output (the tiled path runs two launches and an element-wise kernel).
 template <int MAXT, int EPI, int CH>
 __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mo_grouped(const MoeSmallGroup grp, int rows, int nblk, int act_kind, const half_t *__restrict__ X,
-                                                                     half_t *__restrict__ Y)
+                                                                     half_t *__restrict__ Y, int whole_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.y >= grp.counts[3]) return;
@@ -91,15 +117,23 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mo_grouped(const MoeSm
     P.Y = Y + (size_t)gq.row0 * rows; P.res = nullptr; P.ldy = rows; P.ldres = 0; P.act_kind = act_kind;
     P.Yset[0] = nullptr; P.Yset[1] = nullptr; P.Yset[2] = nullptr; P.ldyset[0] = 0; P.ldyset[1] = 0; P.ldyset[2] = 0;
     P.mo = 1; P.trace = nullptr;
-    gemm_rows_mfma_body<MAXT, 8, EPI, 0, true, CH>(P, smem);
+    // groups of 2..4 rows (most of them: 16 entries over 8 experts): four rows staged instead of eight, and rows longer than a chunk
+    // (w2) staged whole -- no re-staging, no barriers in the chunk loop
+    if (gq.nrows <= 4 && (CH == 1 || (size_t)4 * ((size_t)nblk * 64 + 16) <= (size_t)whole_lds)) {
+        if constexpr (CH == 1) gemm_rows_mfma_body<MAXT, 4, EPI, 0, true, 1>(P, smem);
+        else gemm_rows_mfma_body<MAXT, 4, EPI, 0, true, 2>(P, smem);
+    } else gemm_rows_mfma_body<MAXT, 8, EPI, 0, true, CH>(P, smem);
 }
 
 template <int MT, int EPI, int CH>
 static int mo_launch_grouped(int wgs, int groups, size_t smem, const MoeSmallGroup &grp, size_t rows, size_t cols, int act_kind, const void *X, void *Y, hipStream_t s)
 {
     auto kern = k_gemm_rows_mo_grouped<MT, EPI, CH>;
+    // rows longer than a chunk: room for four whole rows when that fits (groups of <= 4 rows then skip the chunk re-staging)
+    int whole_lds = 0;
+    if (CH == 0 && gm_smem_whole(4, (int)cols, MT) <= (size_t)150 * 1024) { whole_lds = (int)gm_smem_whole(4, (int)cols, MT); smem = std::max(smem, (size_t)whole_lds); }
     if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<dim3((unsigned)wgs, (unsigned)groups), dim3(GM_THREADS), smem, s>>>(grp, (int)rows, (int)(cols / 32), act_kind, (const half_t *)X, (half_t *)Y);
+    kern<<<dim3((unsigned)wgs, (unsigned)groups), dim3(GM_THREADS), smem, s>>>(grp, (int)rows, (int)(cols / 32), act_kind, (const half_t *)X, (half_t *)Y, whole_lds);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }

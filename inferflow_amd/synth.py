@@ -17,6 +17,8 @@ SHAPES = {
     # small GQA shapes for parity tests
     "test_gqa": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000),
     "test_mha": dict(dim=256, layers=3, heads=8, kv_heads=8, head_dim=32, ffn=640, vocab=777),
+    # w2 rows longer than one 4096-column chunk of the rows GEMM (chunk loop / whole-row staging)
+    "test_longffn": dict(dim=256, layers=2, heads=4, kv_heads=4, head_dim=64, ffn=4352, vocab=500),
     # data/models/yi_34b_chat (configs[3]) and a Llama-2-70B-shaped model: w2 rows of 20480 / 28672 columns
     "yi_34b": dict(dim=7168, layers=60, heads=56, kv_heads=8, head_dim=128, ffn=20480, vocab=64000),
     "llama2_70b": dict(dim=8192, layers=80, heads=64, kv_heads=8, head_dim=128, ffn=28672, vocab=32000),
@@ -27,6 +29,7 @@ SHAPES = {
     # Mixtral-8x7B (data/models/mixtral_8x7b_instruct_v0.1) and a small MoE shape for parity tests
     "mixtral_8x7b": dict(dim=4096, layers=32, heads=32, kv_heads=8, head_dim=128, ffn=14336, vocab=32000, experts=8, moe_top_k=2),
     "test_moe": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=512, vocab=1000, experts=4, moe_top_k=2),
+    "test_moe_longffn": dict(dim=256, layers=2, heads=4, kv_heads=2, head_dim=64, ffn=4352, vocab=600, experts=4, moe_top_k=2),
     # a small Falcon-40B-like wiring (LayerNorm, GELU, plain MLP, shared MLP / attention input, grouped KV heads)
     "test_falcon": dict(dim=256, layers=2, heads=8, kv_heads=2, head_dim=32, ffn=512, vocab=1000,
                         norm_kind=1, act_kind=1, is_glu=0, share_input=1, rope_order=2),

@@ -403,7 +403,8 @@ def test_dynamic_batching_rows_are_independent_queries(kvd):
 
 
 @pytest.mark.parametrize("n", [2, 5, 8, 11, 16, 20, 27, 32])
-@pytest.mark.parametrize("kvd,shape", [(dt.F16, "test_mha"), (dt.Q8_B32T2, "test_mha"), (dt.F16, "test_moe")], ids=["kvf16", "kvq8", "moe"])
+@pytest.mark.parametrize("kvd,shape", [(dt.F16, "test_mha"), (dt.Q8_B32T2, "test_mha"), (dt.F16, "test_moe"), (dt.F16, "test_moe_longffn")],
+                         ids=["kvf16", "kvq8", "moe", "moe_longffn"])
 def test_fused_batched_step_matches_op_by_op_rows_and_graph_replay(kvd, shape, n):
     """The batched decode step as five launches per layer (norm prologue + wq|wk|wv, batched k_dec_attn, wo + residual,
     norm + w1/w3 + GLU, w2 + residual: ifa_gemm_rows_mfma.hip, batch_fused_layer) against the op-by-op rows of the same
@@ -480,14 +481,16 @@ def test_fused_batched_step_for_the_64_weight_nibble_formats(wd, n):
     wk.close()
 
 
-@pytest.mark.parametrize("n", [2, 7, 8, 13, 16, 24])
-@pytest.mark.parametrize("shape", ["test_mha", "test_gqa"])
+@pytest.mark.parametrize("n", [2, 3, 4, 7, 8, 13, 16, 24])
+@pytest.mark.parametrize("shape", ["test_mha", "test_gqa", "test_longffn"])
 def test_rows_gemm_operand_order_copy_is_bit_identical_to_the_tiled_path(shape, n):
     """The MO ("MFMA operand order") copy of the weights feeds the same operands to the same MFMAs as the tiled path's LDS
     turn (ifa_gemm_rows_mfma.hip).  Up to 8 rows both layouts give a wave the same blocks of K: prompts of 3..8 tokens and the
     fused batched step of up to 8 queries must be bit-identical with rows_mo 1 / 0, eager and as a graph replay.  For 9..16
     rows the tiled path walks 2048-column chunks (its LDS also holds the waves' patches) while the MO path stages one
-    4096-column chunk: same products, another fp32 summation order -- compared within a tolerance."""
+    4096-column chunk: same products, another fp32 summation order -- compared within a tolerance.  test_longffn: w2 rows of
+    4352 columns walk two chunks; with the MO copy 2..4 rows are staged whole (CH = 2), 5..8 chunk by chunk -- the same blocks per
+    wave in the same order as the tiled path's chunk loop, so still bit-identical up to 8 rows."""
     wk, _, s = synth.build(shape, dt.Q4_B32T1A, dt.F16, max_ctx=48, quant_threshold=0, std=0.06)
     V = s["vocab"]
     wk.kv_slots(2 * n)
