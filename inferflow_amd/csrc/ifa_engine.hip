@@ -24,6 +24,7 @@
 #include "ifa_gemm_big.h"
 #include "ifa_decode_persist_launch.h"
 #include "ifa_decode_lmhead_tail.h"
+#include "ifa_decode_singles.h"
 #include "ifa_decode_qkv_attn.h"
 #include "ifa_decode_wo_ffn.h"
 
@@ -131,7 +132,7 @@ struct ifa_model {
     int opt_step_tail = 1, st_on = 0;
     unsigned long long *st_keys = nullptr; unsigned *st_counter = nullptr; int st_keys_n = 0;
     int attn_pb = 256, opt_attn_kt = 1;      // cache rows the one-workgroup decode attention requests at entry (64 / 128 / 256: the bucket the call stays inside); K rows through the LDS tile
-    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1;
+    int attn_split = 0, opt_attn_split_ctx = 512, opt_batch_graph = 0, opt_gemm_rows = 1, opt_batch_fused = 1, opt_moe_router_fused = 1, opt_prefill_big = 1, opt_rows_mo = 1, opt_moe_singles = 1;
     // independent KV caches ("query slots", one per concurrent query like the reference's per-query
     // LayerKVCache sets): the inactive ones park their cache pointers and captured graph here
     struct KvSlot { std::vector<void *> k, v; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -1668,6 +1669,22 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T, con
     g.wtab = (const uint8_t *const *)L.moe_table_aos; g.on = 1;
     // (T <= small_max: no expert can collect more rows than the small groups take -- the tile list is empty, its launches are skipped)
     const int max_tiles = (small_max > 0 && T <= small_max) ? 0 : cap / tile_rows + E, max_singles = std::min(E, cap);
+    // Single-row experts (round 4): when no expert can collect a tile of rows (max_tiles == 0: a batched decode step) and the small
+    // groups gate their own products (MO copies), the singles are the only rows the quantiser / element-wise launches below serve --
+    // they then take two launches of the decode GEMV's structure on the tiled expert tables (ifa_decode_singles.h) instead of six
+    if (m->opt_moe_singles && max_tiles == 0 && (smalls_mo || max_smalls == 0) && L.moe_table && dec_singles_supported(wdt, F, D, true)
+        && dec_singles_supported(wdt, D, F, false)) {
+        DecSinglesParams S; memset(&S, 0, sizeof(S));
+        S.singles = (const MoeSingle *)m->moe_singles; S.counts = m->moe_counts; S.wtab = (const uint8_t *const *)L.moe_table; S.act_kind = c.act_kind;
+        S.which = 0; S.X = m->moe_gin; S.ldx = (int)D; S.Y = m->moe_g1; S.ldy = (int)F; S.rows = (int)F; S.cols = (int)D; S.nblk = (int)(D / 32);
+        if ((rc = dec_singles_launch(wdt, S, true, max_singles, m->stream))) return rc;               // act(w1 x) * (w3 x)
+        if (max_smalls) { sg.which_tiled = 0; if ((rc = gemm_rows_mo_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls, 1, c.act_kind, m->stream))) return rc; }
+        S.which = 2; S.X = m->moe_g1; S.ldx = (int)F; S.Y = m->moe_gout; S.ldy = (int)D; S.rows = (int)D; S.cols = (int)F; S.nblk = (int)(F / 32);
+        if ((rc = dec_singles_launch(wdt, S, false, max_singles, m->stream))) return rc;              // w2
+        sg.which_tiled = 2;
+        if (max_smalls && (rc = gemm_rows_mo_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls, 0, c.act_kind, m->stream))) return rc;
+        return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, out ? out : m->f, m->stream, residual);
+    }
     // single-row experts take the quantised row (TensorOpr::Quantize in front of Gemv_AX, inference_worker.cc:1772-1774)
     if ((rc = ifa_quantize_act_q8(m->moe_gin, (size_t)cap, D, m->moe_xq_in, s))) return rc;
     g.which = 0;
@@ -2655,7 +2672,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"moe_singles", &m->opt_moe_singles}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)

@@ -661,3 +661,35 @@ def test_long_prompt_large_tile_layer_matches_oracle_and_op_by_op_layer(kvd, sha
             break
         t_o, pos = int(nxt), pos + 1
     wk.close()
+
+
+@pytest.mark.parametrize("shape", ["test_moe", "test_moe_longffn"])
+@pytest.mark.parametrize("n", [3, 5, 8])
+def test_single_row_experts_of_a_batched_moe_step_match_the_grouped_gemv_path(shape, n):
+    """The single-row experts of a batched MoE step (csrc/ifa_decode_singles.h: quantiser + tiled-row GEMV + gate in two launches,
+    option moe_singles) against the round-3 path (quantiser launches + k_gemv_ax8_grouped on the reference-layout blocks +
+    element-wise gate): both are the reference's T = 1 arithmetic for such a row (Q8 activations, int8 dot), so the logits of the
+    step must be bit-identical, eager and as a graph replay."""
+    wk, _, s = synth.build(shape, dt.Q4_B32T1A, dt.F16, max_ctx=48, quant_threshold=0, std=0.06)
+    V = s["vocab"]
+    wk.kv_slots(2 * n)
+    rng = np.random.default_rng(300 + n)
+    prompts = [rng.integers(3, V, 3 + (i * 5) % 7).astype(np.int32) for i in range(n)]
+    cur, pos = [], []
+    for i, pr in enumerate(prompts):
+        wk.select_kv(i); t = wk.forward(pr, 0)
+        wk.select_kv(n + i); assert wk.forward(pr, 0) == t
+        cur.append(t); pos.append(len(pr))
+    la = torch.empty((n, V), dtype=torch.float16, device="cuda")
+    lb = torch.empty((n, V), dtype=torch.float16, device="cuda")
+    for step in range(4):
+        wk.set_option("moe_singles", 1)
+        ta = wk.decode_batch(cur, pos, list(range(n)), la)
+        tg = wk.decode_batch(cur, pos, list(range(n)))                       # graph replay of the same step
+        wk.set_option("moe_singles", 0)
+        tb = wk.decode_batch(cur, pos, list(range(n, 2 * n)), lb)
+        assert np.array_equal(g.host(la), g.host(lb)), step
+        assert [int(t) for t in ta] == [int(t) for t in tb] == [int(t) for t in tg], step
+        cur = [int(t) for t in ta]; pos = [p + 1 for p in pos]
+    wk.set_option("moe_singles", 1)
+    wk.close()
