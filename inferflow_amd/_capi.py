@@ -97,6 +97,7 @@ SIGNATURES = {
     "ifa_model_fused_supported": (_i, [_vp, C.c_char_p, _sz]),
     "ifa_model_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ifa_model_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "ifa_model_decode_prepare": (_i, [_vp, _i, _i]),
     "ifa_add_by_row_index": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "ifa_model_kv_slots": (_i, [_vp, _i]),
     "ifa_model_select_kv": (_i, [_vp, _i]),

@@ -96,6 +96,10 @@ struct ifa_model {
     // decode graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // the same step captured opt_graph_steps times in a row (option graph_steps, default 1 = off): a replay boundary costs ~8.6 us
+    // against ~1.5 us between two launches inside a graph (rocprofv3 trace of the bench) -- but replays of 4 / 8 / 16 steps measured
+    // SLOWER per token than single steps (1.2514 / 1.2524 / 1.2502 ms against 1.2427: profiles/r04_ab_options.log), so it stays opt-in
+    hipGraph_t graph_n = nullptr; hipGraphExec_t graph_exec_n = nullptr; int graph_n_steps = 0, opt_graph_steps = 1;
     // tensor parallelism: a seam's "layer input + merged product (+ bias)" waiting to be formed in the prologue of the
     // GEMV that consumes it (instead of one or two tiny add kernels per seam)
     struct PendingAdd { const half_t *x = nullptr, *add = nullptr, *bias = nullptr; half_t *out = nullptr; bool on = false; } pend;
@@ -183,6 +187,8 @@ static void drop_graphs(ifa_model *m)
     if (m->tp_graph) { (void)hipGraphDestroy(m->tp_graph); m->tp_graph = nullptr; }
     if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
     if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+    if (m->graph_exec_n) { (void)hipGraphExecDestroy(m->graph_exec_n); m->graph_exec_n = nullptr; }
+    if (m->graph_n) { (void)hipGraphDestroy(m->graph_n); m->graph_n = nullptr; }
     for (auto &sl : m->slots) {
         if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
         if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
@@ -2659,6 +2665,8 @@ int ifa_model_select_kv(ifa_model *m, int slot)
     out.k.clear(); out.v.clear();
     for (Layer &L : m->layers) { out.k.push_back(L.kcache); out.v.push_back(L.vcache); }
     out.graph = m->graph; out.exec = m->graph_exec;
+    if (m->graph_exec_n) { (void)hipGraphExecDestroy(m->graph_exec_n); m->graph_exec_n = nullptr; }      // (the multi-step replay is not kept per slot)
+    if (m->graph_n) { (void)hipGraphDestroy(m->graph_n); m->graph_n = nullptr; }
     for (size_t l = 0; l < m->layers.size(); l++) { m->layers[l].kcache = in.k[l]; m->layers[l].vcache = in.v[l]; }
     m->graph = in.graph; m->graph_exec = in.exec;
     in.k.clear(); in.v.clear(); in.graph = nullptr; in.exec = nullptr;
@@ -2672,7 +2680,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"moe_singles", &m->opt_moe_singles}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"moe_singles", &m->opt_moe_singles}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
@@ -2716,7 +2724,22 @@ int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int pr
     return forward_ops(m, tokens_host, n_tokens, prefix_len, logits_out_dev, next_token_host);
 }
 
+static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps, int *out_tokens_host, float *elapsed_ms, bool prepare_only);
 int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, int *out_tokens_host, float *elapsed_ms)
+{
+    return decode_impl(m, first_token, start_pos, n_steps, out_tokens_host, elapsed_ms, false);
+}
+
+// Everything a decode call of n_steps from start_pos sets up before its first launch -- the attention variant of the contexts it
+// reaches, the hand-off arenas, the captured step(s) -- without running a step: a caller that times its first call (bench.py with
+// --warmup 0, a service's first request) keeps graph capture / instantiation out of it.  The KV cache and the activations are not
+// touched (the token / position words are rewritten by every call anyway).
+int ifa_model_decode_prepare(ifa_model *m, int start_pos, int n_steps)
+{
+    return decode_impl(m, 0, start_pos, n_steps, nullptr, nullptr, true);
+}
+
+static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps, int *out_tokens_host, float *elapsed_ms, bool prepare_only)
 {
     IFA_REQUIRE(m && m->finalized, "ifa_model_decode: model not finalized");
     IFA_REQUIRE(n_steps > 0 && n_steps <= ifa_model::RING, "ifa_model_decode: n_steps %d (max %d per call)", n_steps, ifa_model::RING);
@@ -2727,6 +2750,7 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     std::string why;
     if (!m->opt_fused || !fused_supported(m, &why)) {
         // op-by-op fallback: same semantics, host-driven
+        if (prepare_only) return IFA_OK;
         int tok = first_token;
         for (int i = 0; i < n_steps; i++) {
             int nt = 0;
@@ -2738,6 +2762,11 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
         if (elapsed_ms) *elapsed_ms = -1.0f;
         return IFA_OK;
     }
+    static const bool trace_host = getenv("IFA_TRACE_DECODE") != nullptr;       // tuning aid: host-side timeline of the call on stderr
+    const auto th0 = std::chrono::steady_clock::now();
+    auto th = [&](const char *what) {
+        if (trace_host) fprintf(stderr, "decode-host %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count());
+    };
     int rc = ensure_scratch(m, 1);
     if (rc) return rc;
     hipStream_t s = m->stream;
@@ -2773,13 +2802,33 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
         m->graph = gph;
         IFA_HIP_CHECK(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
     }
+    const int S = m->opt_graph_steps;
+    if (m->opt_graph && S > 1 && n_steps >= S && (!m->graph_exec_n || m->graph_n_steps != S)) {
+        if (m->graph_exec_n) { (void)hipGraphExecDestroy(m->graph_exec_n); m->graph_exec_n = nullptr; }
+        if (m->graph_n) { (void)hipGraphDestroy(m->graph_n); m->graph_n = nullptr; }
+        IFA_HIP_CHECK(hipStreamSynchronize(s));
+        IFA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < S && !rc; i++) rc = enqueue_fused_step(m);
+        hipGraph_t gph = nullptr;
+        hipError_t e = hipStreamEndCapture(s, &gph);
+        if (rc) { if (gph) (void)hipGraphDestroy(gph); return rc; }
+        if (e != hipSuccess) return ifa_fail(IFA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        m->graph_n = gph; m->graph_n_steps = S;
+        IFA_HIP_CHECK(hipGraphInstantiate(&m->graph_exec_n, m->graph_n, nullptr, nullptr, 0));
+    }
+    if (prepare_only) return IFA_OK;
+    th("state copies enqueued");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventCreate(&e0)); IFA_HIP_CHECK(hipEventCreate(&e1)); IFA_HIP_CHECK(hipEventRecord(e0, s)); }
+    th("events created, first recorded");
     if (m->st_on && (rc = launch_gather(m))) return rc;      // the call's first step: its input is gathered here, every later one by the step before it
-    for (int i = 0; i < n_steps; i++) {
+    for (int i = 0; i < n_steps;) {
+        if (m->opt_graph && m->graph_exec_n && m->graph_n_steps == S && S > 1 && n_steps - i >= S) { IFA_HIP_CHECK(hipGraphLaunch(m->graph_exec_n, s)); i += S; continue; }
         if (m->opt_graph) IFA_HIP_CHECK(hipGraphLaunch(m->graph_exec, s));
         else if ((rc = enqueue_fused_step(m))) return rc;
+        i++;
     }
+    th("steps enqueued");
     if (elapsed_ms) IFA_HIP_CHECK(hipEventRecord(e1, s));
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n_steps, hipMemcpyDeviceToHost, s));
     int *perr = m->host_pinned + 8 + ifa_model::RING;
@@ -2788,7 +2837,9 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
     int *qerr = perr + 4;
     qerr[0] = 0;
     if (m->qa_on || m->wf_on) IFA_HIP_CHECK(hipMemcpyAsync(qerr, m->qa_err, 4, hipMemcpyDeviceToHost, s));
+    th("copies back enqueued");
     IFA_HIP_CHECK(hipStreamSynchronize(s));
+    th("stream synchronised");
     if (qerr[0] != 0) {      // a head's workgroup gave up waiting for its q | k | v rows: the step's results are not valid
         (void)hipMemsetAsync(m->qa_err, 0, 16, s);
         (void)hipStreamSynchronize(s);
@@ -2805,6 +2856,7 @@ int ifa_model_decode(ifa_model *m, int first_token, int start_pos, int n_steps, 
                         "set option persist=0 to use the five-launch path", code >> 8, code & 0xFFu, perr[1], perr[2], perr[3]);
     }
     if (out_tokens_host) memcpy(out_tokens_host, m->host_pinned + 8, sizeof(int) * (size_t)n_steps);
+    th("done");
     return IFA_OK;
 }
 

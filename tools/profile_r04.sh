@@ -5,7 +5,9 @@
 #   3. the bench lines (after 2: they carry the traffic of THIS build)                            -> r04_bench_n1.json (+ _steps128, _q3h_q8, _q3h_f16)
 #   4. per-phase traces of the fused launches and the four GEMVs                                  -> r04_fused_launch_phase_trace.log, r04_kernel_phase_trace.log
 #   5. A / B of the round's options at the headline shape                                         -> r04_ab_options.log
-#   6. dynamic batching 1..32 queries, Mixtral batch 8 (unchanged kernels: regression record)    -> r04_bench_batch.jsonl, r04_bench_mixtral.json
+#   6. dynamic batching 1..32 queries, Mixtral batch 8                                           -> r04_bench_batch.jsonl, r04_bench_mixtral.json
+#   7. per-kernel rocprofv3 averages of the batched step (2 / 8 / 17 / 32 queries, Mixtral batch 8), rows-GEMM phase trace at 2 queries
+#                                                                                                 -> r04_batch*_kernel_stats.csv, r04_rows_gemm_phase_trace.log
 set -x
 OUT=$PWD/gpurun_out/prof_r04
 rm -rf $OUT; mkdir -p $OUT
@@ -22,9 +24,12 @@ timeout 600 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --wdtype q3h
 timeout 600 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --wdtype q3h --prefill-lens "" --batch 0 > $OUT/r04_bench_n1_q3h_f16.json 2>> $OUT/bench.err
 timeout 300 python tools/trace_fused.py > $OUT/r04_fused_launch_phase_trace.log 2>&1
 timeout 300 python tools/trace_kernels.py > $OUT/r04_kernel_phase_trace.log 2>&1
-(for o in fuse_attn attn_kt fuse_wo fuse_wo_ffn; do timeout 300 python tools/ab_option.py $o --steps 20 --prompt 21 --kernels; done) > $OUT/r04_ab_options.log 2>&1
+(for o in fuse_attn attn_kt step_tail fuse_wo fuse_wo_ffn; do timeout 300 python tools/ab_option.py $o --steps 20 --prompt 21 --kernels; done; timeout 300 python tools/ab_option.py graph_steps --values 1,4,8,16 --steps 20 --prompt 21) > $OUT/r04_ab_options.log 2>&1
 timeout 600 python bench.py --no-cpu-baseline --shape mixtral_8x7b --batch 8 --steps 64 > $OUT/r04_bench_mixtral.json 2>> $OUT/bench.err
 IFA_BATCH_SIZES=1,2,4,8,16,17,24,32 timeout 600 python tools/bench_batch.py > $OUT/r04_bench_batch.jsonl 2>> $OUT/bench.err
+bash tools/profile_batch.sh > $OUT/profile_batch.log 2>&1
+for f in gpurun_out/prof_batch/*_kernel_stats.csv; do cp $f $OUT/r04_$(basename $f); done
+(IFA_NO_GRAPH=1 IFA_ROWS_TRACE=1 timeout 200 python tools/batch_steps.py llama2_7b 2 2 2>&1 | grep "rows-trace" | tail -12; IFA_NO_GRAPH=1 IFA_ROWS_TRACE=1 timeout 200 python tools/batch_steps.py llama2_7b 32 2 2>&1 | grep "rows-trace" | tail -12) > $OUT/r04_rows_gemm_phase_trace.log 2>&1
 rm -rf $OUT/stats $OUT/pmc
 ls -la $OUT
 tail -3 $OUT/bench.err
