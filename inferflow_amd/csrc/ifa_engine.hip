@@ -64,6 +64,9 @@ struct ifa_model {
     std::vector<Layer> layers;
     Tensor g[10];
     hipStream_t stream = nullptr;
+    // side stream + fork / join events of the batched MoE step: the single-row experts run next to the small groups (both stream
+    // expert matrices nobody else reads and neither saturates the memory system alone); created on first use
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int opt_moe_overlap = 1;
     bool own_stream = true;
     bool finalized = false;
     // scratch
@@ -1616,6 +1619,16 @@ static bool moe_device_ok(const ifa_model *m, const Layer &L)
 }
 
 static int max_smalls_possible(bool rows_kernel, int E, int cap) { return rows_kernel ? std::min(E, cap / 2) : 0; }
+// (also called by the batched step before it starts a capture: nothing is created inside one)
+static int ensure_side_stream(ifa_model *m)
+{
+    if (m->side_stream) return IFA_OK;
+    IFA_HIP_CHECK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+    IFA_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    IFA_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    return IFA_OK;
+}
+
 // can the rows of a batched step be routed by ONE launch (k_dec_moe_router, a workgroup per row: norm, F16 gate GEMV, softmax, top-k)?
 static bool moe_router_rows_ok(const ifa_model *m, const Layer &L, int T)
 {
@@ -1682,13 +1695,29 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T, con
         && dec_singles_supported(wdt, D, F, false)) {
         DecSinglesParams S; memset(&S, 0, sizeof(S));
         S.singles = (const MoeSingle *)m->moe_singles; S.counts = m->moe_counts; S.wtab = (const uint8_t *const *)L.moe_table; S.act_kind = c.act_kind;
+        // the singles' two launches on the side stream, the small groups' two on the main one: disjoint rows of g1 / gout, joined in
+        // front of the combine (inside a capture the fork / join become graph edges)
+        hipStream_t ss = m->stream;
+        if (m->opt_moe_overlap && max_smalls) {
+            if ((rc = ensure_side_stream(m))) return rc;
+            ss = m->side_stream;
+            IFA_HIP_CHECK(hipEventRecord(m->ev_fork, m->stream));
+            IFA_HIP_CHECK(hipStreamWaitEvent(ss, m->ev_fork, 0));
+        }
         S.which = 0; S.X = m->moe_gin; S.ldx = (int)D; S.Y = m->moe_g1; S.ldy = (int)F; S.rows = (int)F; S.cols = (int)D; S.nblk = (int)(D / 32);
-        if ((rc = dec_singles_launch(wdt, S, true, max_singles, m->stream))) return rc;               // act(w1 x) * (w3 x)
-        if (max_smalls) { sg.which_tiled = 0; if ((rc = gemm_rows_mo_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls, 1, c.act_kind, m->stream))) return rc; }
+        if ((rc = dec_singles_launch(wdt, S, true, max_singles, ss))) return rc;                      // act(w1 x) * (w3 x)
         S.which = 2; S.X = m->moe_g1; S.ldx = (int)F; S.Y = m->moe_gout; S.ldy = (int)D; S.rows = (int)D; S.cols = (int)F; S.nblk = (int)(F / 32);
-        if ((rc = dec_singles_launch(wdt, S, false, max_singles, m->stream))) return rc;              // w2
-        sg.which_tiled = 2;
-        if (max_smalls && (rc = gemm_rows_mo_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls, 0, c.act_kind, m->stream))) return rc;
+        if ((rc = dec_singles_launch(wdt, S, false, max_singles, ss))) return rc;                     // w2
+        if (max_smalls) {
+            sg.which_tiled = 0;
+            if ((rc = gemm_rows_mo_grouped(sg, F, D, m->moe_gin, m->moe_g1, max_smalls, 1, c.act_kind, m->stream))) return rc;
+            sg.which_tiled = 2;
+            if ((rc = gemm_rows_mo_grouped(sg, D, F, m->moe_g1, m->moe_gout, max_smalls, 0, c.act_kind, m->stream))) return rc;
+        }
+        if (ss != m->stream) {
+            IFA_HIP_CHECK(hipEventRecord(m->ev_join, ss));
+            IFA_HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+        }
         return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, out ? out : m->f, m->stream, residual);
     }
     // single-row experts take the quantised row (TensorOpr::Quantize in front of Gemv_AX, inference_worker.cc:1772-1774)
@@ -2258,6 +2287,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     //  graph, so replay is opt-in: set_option("batch_graph", 1))
     const bool fused = batch_fused_ok(m, n);          // five launches per layer: launch-bound without a graph, so it is replayed
     if (fused) { int rcm = ensure_mo(m); if (rcm) return rcm; }
+    if (has_moe && m->opt_moe_overlap) { int rcs = ensure_side_stream(m); if (rcs) return rcs; }
     // (MoE layers of the fused step route on the device -- no host round trip -- so they are captured too)
     const bool use_graph = (m->opt_batch_graph || fused) && m->opt_graph && (!has_moe || fused) && !logits_out && !tp;
     const int attn_ctx = use_graph ? c.max_ctx : max_ctx;     // LDS sizing of the attention kernel must not depend on the step
@@ -2470,6 +2500,9 @@ int ifa_model_destroy(ifa_model *m)
     if (m->st_counter) (void)hipFree(m->st_counter);
     if (m->stream) (void)ifa_gemm_release_stream((ifa_stream)m->stream);
     if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
+    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     delete m;
     return IFA_OK;
 }
@@ -2680,7 +2713,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"moe_singles", &m->opt_moe_singles}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)

@@ -98,3 +98,22 @@ def test_step_tail_launch_is_bit_identical(shape, wd, kvd):
         if excl:
             assert all(t not in excl for ts, _ in b for t in ts)
     wk.set_excluded_tokens([])
+
+
+def test_decode_prepare_runs_no_step_and_changes_no_result():
+    """ifa_model_decode_prepare captures what a decode call replays without running a step: the KV cache rows and the tokens /
+    logits of the call that follows are those of a worker that was never prepared; graph_steps > 1 (several steps per replay,
+    opt-in) gives the same tokens and logits as single-step replays."""
+    wk, _, s = synth.build("llama2_7b", dt.Q4_B32T1A, dt.F16, max_ctx=256, layers=2)
+    prompt = (np.arange(12, dtype=np.int32) * 5 + 1) % s["vocab"]
+    ref = _run(wk, s, prompt, 21)
+    wk.reset()
+    tok = wk.forward(prompt, 0)
+    kc0 = wk.read_buffer("kcache", layer=1).copy()
+    wk.decode_prepare(len(prompt), 21)
+    assert np.array_equal(wk.read_buffer("kcache", layer=1), kc0)
+    toks, _ = wk.decode(int(tok), len(prompt), 21)
+    assert list(toks) == ref[0] and np.array_equal(wk.read_buffer("logits").view(np.uint16), ref[1])
+    got = _run(wk, s, prompt, 21, graph_steps=4)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    wk.set_option("graph_steps", 1)
