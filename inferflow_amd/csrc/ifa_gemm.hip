@@ -17,6 +17,8 @@
 #include <type_traits>
 #include <cstring>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include "ifa_host.h"
 #include "ifa_codec.h"
 #include "ifa_moe.h"
@@ -363,11 +365,17 @@ typedef const __attribute__((address_space(1))) void pf_glb_t;
 // outputs, bias, residual, GLU pair; W[] / W1 are REFERENCE-layout rows here) + the tile geometry.
 // EPI: GM_PLAIN | GM_RESIDUAL (Y = half(res + y), TensorOpr::Add) | GM_GLU (a weight tile = BN / 2 rows of w1 and the
 // same BN / 2 rows of w3, both halves meet in the epilogue's LDS tile: Y = half(half(act(y1)) * y3)).
-struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; };
+// KS = 2 (round 4, 128 x 128 tiles of a product that offers no more tiles than CUs: wo and w2 of a 1024-token prompt are 256 tiles of
+// four waves -- one workgroup per CU, the matrix pipe 25 % busy): two workgroups per tile, each walks half of K; the first half's
+// fp32 accumulators go through memory (write-through stores, one flag per tile) to the workgroup of the second half, which adds them
+// IN THAT ORDER (first half + second half: deterministic) and runs the epilogue.  The grid lists all first halves, then all second
+// halves: a second half is never resident before its first half.  part / flags: per-stream scratch of the launcher.
+struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; unsigned long long *part; unsigned *flags; };
 
-template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN, int BK = PF_BK>
+template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN, int BK = PF_BK, int KS = 1>
 __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const BigGeo G)
 {
+    static_assert(KS == 1 || KS == 2 || KS == 4, "split-K: one, two or four workgroups per tile");
     // BK: columns per K step -- 64, or 128 for 128 x 128 tiles that run one workgroup per CU (half the barriers per product)
     constexpr int ROWB = BK * 2, CPR = BK / 8, RPP = 1024 / ROWB;     // LDS row bytes, 16-byte chunks per row, rows per direct-to-LDS piece
     auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : (r & 15); };
@@ -392,13 +400,14 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     // XCD-aware tile order (bijective for any grid size)
     int wg;
     {
-        const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int nwg = (int)gridDim.x / KS, orig = (int)blockIdx.x % nwg, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
+    const int kz = KS == 1 ? 0 : (int)blockIdx.x / ((int)gridDim.x / KS);       // which half of K (wave-uniform)
     // tiles in bands of GM token tiles, weight tiles next, token tiles of the band fastest: the workgroups an XCD runs
     // at the same time form a compact block (GM token tiles x a few weight tiles) whose operand tiles its L2 shares
     constexpr int GM = 1024 / BM;
-    const int tiles_n = (int)gridDim.x / tiles_m;
+    const int tiles_n = (int)gridDim.x / KS / tiles_m;
     const int band = wg / (GM * tiles_n), within = wg % (GM * tiles_n), band_m = min(GM, tiles_m - band * GM);
     const int t0 = (band * GM + within % band_m) * BM, tn = G.tn0 + within / band_m;
     // weight tile -> (matrix, first row); everything selected by VALUE from the argument block (no indexed struct access)
@@ -407,7 +416,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     const int N = set == 0 ? P.rows[0] : (set == 1 ? P.rows[1] : P.rows[2]);
     const uint8_t *__restrict__ W = set == 0 ? P.W[0] : (set == 1 ? P.W[1] : P.W[2]);
     const half_t *__restrict__ bias = set == 0 ? P.bias[0] : (set == 1 ? P.bias[1] : P.bias[2]);
-    const int nsteps = K / BK;
+    const int nsteps = K / BK / KS, s0 = kz * nsteps;       // this workgroup's K steps: [s0, s0 + nsteps)
     // ---- activation tile: per-lane source pointers of this wave's 8-row pieces
     const half_t *xsrc[AI];
 #pragma unroll
@@ -419,7 +428,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     auto stage_x = [&](int step, int buf, int j0, int j1) {
 #pragma unroll
         for (int j = j0; j < j1; j++)
-            __builtin_amdgcn_global_load_lds((pf_glb_t *)(xsrc[j] + (size_t)step * BK),
+            __builtin_amdgcn_global_load_lds((pf_glb_t *)(xsrc[j] + (size_t)(s0 + step) * BK),
                                              (pf_lds_t *)(smem + (size_t)buf * A_BYTES + (size_t)(wave * AI + j) * 1024), 16, 0, 0);
     };
     // ---- weight tile: (row, block) slots over the threads.  BK = 64: two blocks of a row on adjacent lanes, rows in the
@@ -433,8 +442,8 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
         for (int j = 0; j < WB; j++) {
             const int idx = min(tid + j * NT, NB - 1);
             const int nl = slot_row(idx), bb = slot_blk(idx);
-            if constexpr (GLU) wr[j].load(nl < BNE ? W : P.W1, (size_t)min(n0 + (nl < BNE ? nl : nl - BNE), N - 1), nblk, step * BPS + bb);
-            else wr[j].load(W, (size_t)min(n0 + nl, N - 1), nblk, step * BPS + bb);
+            if constexpr (GLU) wr[j].load(nl < BNE ? W : P.W1, (size_t)min(n0 + (nl < BNE ? nl : nl - BNE), N - 1), nblk, (s0 + step) * BPS + bb);
+            else wr[j].load(W, (size_t)min(n0 + nl, N - 1), nblk, (s0 + step) * BPS + bb);
         }
     };
     // the raw bytes of the block(s) being dequantised this step (wr is refilled for the step after next meanwhile);
@@ -535,6 +544,57 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
         }
         mma(af[1], bf[1]);
     }
+    if constexpr (KS > 1) {
+        // thread tid's accumulators as 8-byte words q * NT + tid of the tile's scratch slot kz (coalesced either way); the workgroup of
+        // the LAST part of K waits for the KS - 1 others (one counter per tile) and adds their sums in K order: part 0 + part 1 + ... + own
+        constexpr int NQ = TA * TB * 8;
+        unsigned long long *pt = G.part + (size_t)wg * ((size_t)(KS - 1) * NQ * NT);
+        unsigned *flag = G.flags + wg;
+        if (kz < KS - 1) {
+            unsigned long long *mine = pt + (size_t)kz * NQ * NT;
+#pragma unroll
+            for (int a = 0; a < TA; a++)
+#pragma unroll
+                for (int b = 0; b < TB; b++)
+#pragma unroll
+                    for (int rp = 0; rp < 8; rp++) {
+                        const float f0 = acc[a][b][2 * rp], f1 = acc[a][b][2 * rp + 1];       // (scalars first: a bit_cast of a vector ELEMENT read element 0 every time)
+                        const unsigned long long v = (unsigned long long)__builtin_bit_cast(uint32_t, f0) | ((unsigned long long)__builtin_bit_cast(uint32_t, f1) << 32);
+                        __hip_atomic_store(mine + (size_t)((a * TB + b) * 8 + rp) * NT + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the partial sums are in memory ...
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the counter says so
+            return;
+        }
+        if (tid == 0) {
+            const long long t_wait = wall_clock64();
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(KS - 1)) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t_wait > 200000000ll) break;                   // (2 s: never in a healthy launch; the tests would see the sums)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < TA; a++)
+#pragma unroll
+            for (int b = 0; b < TB; b++)
+#pragma unroll
+                for (int rp = 0; rp < 8; rp++) {
+                    float s0f = 0.0f, s1f = 0.0f;
+#pragma unroll
+                    for (int z = 0; z < KS - 1; z++) {
+                        const unsigned long long v = __hip_atomic_load(pt + (size_t)z * NQ * NT + (size_t)((a * TB + b) * 8 + rp) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float p0 = __builtin_bit_cast(float, (uint32_t)v), p1 = __builtin_bit_cast(float, (uint32_t)(v >> 32));
+                        s0f = z == 0 ? p0 : s0f + p0; s1f = z == 0 ? p1 : s1f + p1;
+                    }
+                    acc[a][b][2 * rp] = s0f + acc[a][b][2 * rp];
+                    acc[a][b][2 * rp + 1] = s1f + acc[a][b][2 * rp + 1];
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch on this stream
+    }
     // ---- epilogue
     half_t *__restrict__ Yo; int ldo, vrow0 = 0;
     if (P.Yset[0]) { Yo = set == 0 ? P.Yset[0] : (set == 1 ? P.Yset[1] : P.Yset[2]); ldo = set == 0 ? P.ldyset[0] : (set == 1 ? P.ldyset[1] : P.ldyset[2]); }
@@ -612,6 +672,39 @@ static int gemm_num_cus()
 static int g_gemm_big = 1;       // ifa_gemm_big_tiles(0 / 1): the large-tile kernel for T > 128 (default on; blocks of <= 32 values -- the 64-value formats keep k_gemm_q); bits 8-9: force a tile shape (measurement)
 
 // tile shape by estimated time: rounds of workgroups over the chip x the measured cost of one round
+// per-(device, stream) scratch of the split-K launches: the first halves' accumulators + one flag per tile (flags zero between launches)
+constexpr size_t SPLITK_FLAG_BYTES = 16384;      // one counter per tile, in front of the partial sums
+struct SplitKScratch { void *p = nullptr; size_t bytes = 0; };
+static std::mutex g_splitk_mu;
+static std::map<std::pair<int, hipStream_t>, SplitKScratch> g_splitk;
+static int gemm_splitk_scratch(hipStream_t s, size_t part_bytes, size_t tiles, void **out)
+{
+    int dev = 0;
+    IFA_HIP_CHECK(hipGetDevice(&dev));
+    if (tiles * 4 > SPLITK_FLAG_BYTES) return ifa_fail(IFA_ERR_ARG, "split-K: %zu tiles", tiles);
+    const size_t need = SPLITK_FLAG_BYTES + part_bytes;
+    std::lock_guard<std::mutex> lk(g_splitk_mu);
+    SplitKScratch &sc = g_splitk[std::make_pair(dev, s)];
+    if (sc.bytes < need) {
+        IFA_HIP_CHECK(hipStreamSynchronize(s));
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.bytes = 0;
+        IFA_HIP_CHECK(hipMalloc(&sc.p, need));
+        IFA_HIP_CHECK(hipMemsetAsync(sc.p, 0, need, s));          // (flags: zero; the launches that follow on this stream see it)
+        sc.bytes = need;
+    }
+    *out = sc.p;
+    return IFA_OK;
+}
+static void gemm_splitk_release(int dev, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_splitk_mu);
+    auto it = g_splitk.find(std::make_pair(dev, s));
+    if (it == g_splitk.end()) return;
+    if (it->second.p) (void)hipFree(it->second.p);
+    g_splitk.erase(it);
+}
+
 // (256 x 256: 1 workgroup per CU; 128 x 256: 1 per CU, 0.68 of the time; 128 x 128: 2 per CU, 0.75 -- 0.41 alone)
 template <int DT, int EPI>
 static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
@@ -625,16 +718,23 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         for (int i = 0; i < P.nsets; i++) n += ifa_cdiv((size_t)P.rows[i], bne);
         return n;
     };
-    auto run = [&](auto bm, auto bn, auto wm, auto wn, int tn0, int tn_count, auto bk) {      // weight tiles [tn0, tn0 + tn_count)
-        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value, WM = decltype(wm)::value, WN = decltype(wn)::value, BK = decltype(bk)::value;
+    auto run = [&](auto bm, auto bn, auto wm, auto wn, int tn0, int tn_count, auto bk, auto ks) -> int {      // weight tiles [tn0, tn0 + tn_count)
+        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value, WM = decltype(wm)::value, WN = decltype(wn)::value, BK = decltype(bk)::value, KS = decltype(ks)::value;
         constexpr int BNE = EPI == GM_GLU ? BN / 2 : BN;
         BigGeo G;
         G.tile0[0] = 0;
         for (int i = 0; i < 3; i++) G.tile0[i + 1] = G.tile0[i] + (i < P.nsets ? (int)ifa_cdiv((size_t)P.rows[i], (size_t)BNE) : 0);
         for (int i = P.nsets; i < 3; i++) G.tile0[i] = 1 << 30;        // (absent sets are never selected)
-        G.tiles_m = (int)ifa_cdiv(T, (size_t)BM); G.K = P.nblk * CAP; G.tn0 = tn0;
+        G.tiles_m = (int)ifa_cdiv(T, (size_t)BM); G.K = P.nblk * CAP; G.tn0 = tn0; G.part = nullptr; G.flags = nullptr;
+        if constexpr (KS > 1) {
+            const size_t tiles = (size_t)G.tiles_m * tn_count, part_bytes = tiles * (size_t)(KS - 1) * BM * BN * 4;
+            void *scratch = nullptr;
+            int rcs = gemm_splitk_scratch(s, part_bytes, tiles, &scratch);
+            if (rcs) return rcs;
+            G.flags = (unsigned *)scratch; G.part = (unsigned long long *)((char *)scratch + SPLITK_FLAG_BYTES);      // (flags at a FIXED place: they are zero between launches)
+        }
         const size_t smem = std::max(2 * (size_t)(BM + BN) * (BK * 2), (size_t)BM * (BN * 2 + 64));      // operand tiles; the epilogue's output tile
-        auto kern = k_gemm_big<DT, BM, BN, WM, WN, EPI, BK>;
+        auto kern = k_gemm_big<DT, BM, BN, WM, WN, EPI, BK, KS>;
         // (function attributes are per device: one bit per device of this instantiation -- the C++ engine drives several GPUs
         // from one process)
         static std::atomic<uint64_t> attr_set{0};
@@ -645,10 +745,12 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             attr_set.fetch_or(bit, std::memory_order_relaxed);
         }
-        kern<<<dim3((unsigned)(G.tiles_m * tn_count)), dim3(WM * WN * 64), smem, s>>>(P, G);
+        kern<<<dim3((unsigned)(G.tiles_m * tn_count * KS)), dim3(WM * WN * 64), smem, s>>>(P, G);
+        return IFA_OK;
     };
     using std::integral_constant;
     typedef integral_constant<int, 256> I256; typedef integral_constant<int, 128> I128; typedef integral_constant<int, 2> I2; typedef integral_constant<int, 4> I4; typedef integral_constant<int, 64> K64;
+    typedef integral_constant<int, 1> S1;
     const int force = (g_gemm_big >> 8) & 3;        // (measurement: 1 / 2 / 3 force a tile shape)
     auto rounds = [&](size_t bm, size_t bn, size_t per_cu) { return (double)ifa_cdiv(ifa_cdiv(T, bm) * ntiles(bn), cus * per_cu); };
     // 256 x 256: whole rounds of the chip; what is left of the last round goes to a second launch of 128-token tiles when
@@ -662,15 +764,26 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
     const double c128 = n128 <= cus ? 0.41 : rounds(128, 128, 2) * 0.75;
     int pick = force;
     if (!pick) pick = (c256 <= c128x256 && c256 <= c128) ? 1 : (c128x256 <= c128 ? 2 : 3);
+    int rc = IFA_OK;
     if (pick == 1 && CAP <= 32) {
         if (split && !force) {
-            run(I256(), I256(), I2(), I4(), 0, (int)full_n, K64());
-            run(I128(), I256(), I2(), I4(), (int)full_n, (int)rem_n, K64());
-        } else run(I256(), I256(), I2(), I4(), 0, (int)tn256, K64());
+            rc = run(I256(), I256(), I2(), I4(), 0, (int)full_n, K64(), S1());
+            if (!rc) rc = run(I128(), I256(), I2(), I4(), (int)full_n, (int)rem_n, K64(), S1());
+        } else rc = run(I256(), I256(), I2(), I4(), 0, (int)tn256, K64(), S1());
     } else if (pick == 2 || pick == 1)
-        run(I128(), I256(), I2(), I4(), 0, (int)tn256, K64());
-    else
-        run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64());      // (K steps of 128 columns -- BK = 128 -- measured: 57 -> 72 us at 1024 x 4096 x 4096)
+        rc = run(I128(), I256(), I2(), I4(), 0, (int)tn256, K64(), S1());
+    else {
+        // 128 x 128 tiles that fill no more than one workgroup slot per CU (two fit): both halves of K at once -- only for products
+        // big enough to matter (>= half the chip), never when a tile shape is forced (measurement / the bit-identity tests).
+        // Llama-2-7B prefill: 1024 tokens 51.4K -> 54.2K tok/s, 768: 40.4K -> 44.2K, 512: 35.1K -> 42.4K.  (256 x 256 tiles split four
+        // ways -- the efficient tile shape, one part per CU -- measured no better: 53.2K at 1024 tokens, three partial tiles through memory.)
+        const bool splitk = !force && EPI != GM_GLU && (g_gemm_big & (1 << 12)) == 0 && n128 <= cus && n128 * 2 >= cus && (P.nblk * CAP / PF_BK) % 2 == 0 && P.nblk * CAP >= 2048;
+        if constexpr (EPI != GM_GLU) {
+            if (splitk) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), integral_constant<int, 2>());
+            else rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());
+        } else rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());      // (K steps of 128 columns -- BK = 128 -- measured: 57 -> 72 us at 1024 x 4096 x 4096)
+    }
+    if (rc) return rc;
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
@@ -812,5 +925,6 @@ extern "C" int ifa_gemm_release_stream(ifa_stream stream)
     if (hipGetDevice(&dev) != hipSuccess) return IFA_OK;
     (void)hipStreamSynchronize(ifa_s(stream));
     ifa::attn_release_stream(dev, ifa_s(stream));
+    gemm_splitk_release(dev, ifa_s(stream));
     return IFA_OK;
 }

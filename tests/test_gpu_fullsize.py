@@ -145,3 +145,34 @@ def test_llama2_7b_width_prefill_gemm_regimes_agree(T, rows, cols):
     tol = 4e-3 * max(1.0, float(np.abs(ref).max()))
     assert np.abs(y_own - ref).max() <= tol
     assert np.abs(y_small - ref).max() <= tol
+
+
+@pytest.mark.parametrize("T,rows,cols", [(1024, 4096, 11008), (512, 4096, 4096), (640, 4096, 4096)])
+def test_prefill_gemm_split_k_is_deterministic_and_matches_the_unsplit_kernel(T, rows, cols):
+    """128 x 128 tiles of a product that offers no more tiles than CUs run as TWO workgroups per tile, each over half of K; the
+    first half's fp32 sums reach the second workgroup through memory and are added first half + second half (csrc/ifa_gemm.hip,
+    k_gemm_big<.., KS = 2>).  Same bits on every run (fixed order), within the F16 rounding of the unsplit kernel (another fp32
+    summation order: the halves are rounded once each), flags left zero (a second product of another shape on the same stream)."""
+    import torch
+    from tests import gpu_util as g
+    L = g.capi()
+    torch.manual_seed(T + cols)
+    w = (torch.randn(rows, cols, device="cuda") * 0.02).half()
+    W = g.quantize(dt.Q4_B32T1A, w)
+    x = (torch.randn(T, cols, device="cuda") * 0.5).half()
+    bias = (torch.randn(rows, device="cuda") * 0.3).half()
+    prev = L.ifa_gemm_big_tiles(-1)
+    try:
+        L.ifa_gemm_big_tiles(1)
+        y1 = g.host(g.gemm(dt.Q4_B32T1A, W, rows, cols, x, bias))
+        y2 = g.host(g.gemm(dt.Q4_B32T1A, W, rows, cols, x[:T - 3], bias))         # (ragged token count next: same scratch, flags must be clean)
+        y3 = g.host(g.gemm(dt.Q4_B32T1A, W, rows, cols, x, bias))
+        L.ifa_gemm_big_tiles(1 | (1 << 12))                                       # split-K off
+        y0 = g.host(g.gemm(dt.Q4_B32T1A, W, rows, cols, x, bias))
+    finally:
+        L.ifa_gemm_big_tiles(prev)
+    assert np.array_equal(y1, y3) and np.array_equal(y1[:T - 3], y2)
+    a, b = y1.astype(np.float32), y0.astype(np.float32)
+    close = np.abs(a - b) <= np.maximum(2 * np.spacing(np.abs(b).astype(np.float16)).astype(np.float32), 1e-3 * float(np.abs(b).mean()))
+    assert close.mean() >= 0.999, close.mean()
+    assert np.abs(a - b).max() <= 4e-3 * max(1.0, float(np.abs(b).max()))
