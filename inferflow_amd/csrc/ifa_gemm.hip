@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
             const long long t_wait = wall_clock64();
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(KS - 1)) {
                 __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t_wait > 200000000ll) break;                   // (2 s: never in a healthy launch; the tests would see the sums)
+                if (wall_clock64() - t_wait > 500000000ll) __builtin_trap();        // (5 s without the other parts' sums: abort the launch -- the next HIP call fails loudly -- rather than add garbage)
             }
         }
         __syncthreads();
