@@ -7,6 +7,7 @@
 #   5. A / B of the round's options at the headline shape                                         -> r04_ab_options.log
 #   6. dynamic batching 1..32 queries, Mixtral batch 8                                           -> r04_bench_batch.jsonl, r04_bench_mixtral.json
 #   8. prefill by prompt length with and without the split-K form of the large-tile GEMM            -> r04_prefill_split_k.log
+#      rocprofv3 averages of four 1024-token prefills                                           -> r04_prefill_1024_kernel_stats.csv
 #   7. per-kernel rocprofv3 averages of the batched step (2 / 8 / 17 / 32 queries, Mixtral batch 8), rows-GEMM phase trace at 2 queries
 #                                                                                                 -> r04_batch*_kernel_stats.csv, r04_rows_gemm_phase_trace.log
 set -x
@@ -32,6 +33,8 @@ bash tools/profile_batch.sh > $OUT/profile_batch.log 2>&1
 for f in gpurun_out/prof_batch/*_kernel_stats.csv; do cp $f $OUT/r04_$(basename $f); done
 (IFA_NO_GRAPH=1 IFA_ROWS_TRACE=1 timeout 200 python tools/batch_steps.py llama2_7b 2 2 2>&1 | grep "rows-trace" | tail -12; IFA_NO_GRAPH=1 IFA_ROWS_TRACE=1 timeout 200 python tools/batch_steps.py llama2_7b 32 2 2>&1 | grep "rows-trace" | tail -12) > $OUT/r04_rows_gemm_phase_trace.log 2>&1
 (for t in 256 512 768 1024 2048; do timeout 200 python tools/prefill_steps.py llama2_7b $t 3 2>&1 | tail -1; IFA_NO_SPLITK=1 timeout 200 python tools/prefill_steps.py llama2_7b $t 3 2>&1 | tail -1 | sed 's/$/   (split-K off)/'; done) > $OUT/r04_prefill_split_k.log 2>&1
-rm -rf $OUT/stats $OUT/pmc
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pfst -o st -- python $R/tools/prefill_steps.py llama2_7b 1024 4 > $OUT/pfst.log 2>&1)
+head -24 $(find $OUT/pfst -name "*kernel_stats.csv" | head -1) > $OUT/r04_prefill_1024_kernel_stats.csv
+rm -rf $OUT/stats $OUT/pmc $OUT/pfst
 ls -la $OUT
 tail -3 $OUT/bench.err
