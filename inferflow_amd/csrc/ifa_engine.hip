@@ -2286,7 +2286,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     // (measured on Llama-2-7B Q4: the batched step is bound by the small-T GEMM kernels, ~6.7 ms with or without the
     //  graph, so replay is opt-in: set_option("batch_graph", 1))
     const bool fused = batch_fused_ok(m, n);          // five launches per layer: launch-bound without a graph, so it is replayed
-    if (fused) { int rcm = ensure_mo(m); if (rcm) return rcm; }
+    if (fused) { int rcm = ensure_mo(m); if (rcm) return rcm; if ((rcm = gemm_rows_kparts_reserve(m->stream))) return rcm; }
     if (has_moe && m->opt_moe_overlap) { int rcs = ensure_side_stream(m); if (rcs) return rcs; }
     // (MoE layers of the fused step route on the device -- no host round trip -- so they are captured too)
     const bool use_graph = (m->opt_batch_graph || fused) && m->opt_graph && (!has_moe || fused) && !logits_out && !tp;

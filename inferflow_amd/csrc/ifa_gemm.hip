@@ -662,6 +662,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
 using namespace ifa;
 
 namespace ifa { void attn_release_stream(int dev, hipStream_t s); }      // ifa_attn.hip: the score-tile workspace of the stream
+namespace ifa { void rows_kparts_release(int dev, hipStream_t s); }      // ifa_gemm_rows_mo.hip: the K-parts scratch of the stream
 
 static int gemm_num_cus()
 {
@@ -926,5 +927,6 @@ extern "C" int ifa_gemm_release_stream(ifa_stream stream)
     (void)hipStreamSynchronize(ifa_s(stream));
     ifa::attn_release_stream(dev, ifa_s(stream));
     gemm_splitk_release(dev, ifa_s(stream));
+    ifa::rows_kparts_release(dev, ifa_s(stream));
     return IFA_OK;
 }

@@ -30,6 +30,12 @@ struct GmArgs {
     int ldyset[3];
     int mo;                        // W[] / W1 are MO-layout copies (below) instead of the tiled layout
     long long *trace;              // optional [workgroups][16] wall-clock stamps (tuning: IFA_ROWS_TRACE=1 prints a timeline per launch)
+    // K parts (round 4: chunked rows of 9..32 queries, kernels instantiated with KPM > 0): kparts consecutive workgroups share a
+    // group of KPM * kparts tiles; each walks its own chunks of K for ALL of them, leaves the fp32 sums of the tiles it does not
+    // finish in kpart_sums as 8-byte {1, value} granules (zero between launches) and finishes tiles [kp * KPM, (kp + 1) * KPM):
+    // its own part from LDS, the others' granules polled, added in K order.  Filled by the launcher; 0 = off.
+    int kparts;
+    unsigned long long *kpart_sums;
 };
 
 // MO layout ("MFMA operand order") of a matrix [rows][cols] of 4-bit codes with value q * scale + base, cols % 128 == 0: per tile of 16 rows
@@ -43,6 +49,8 @@ size_t gemm_rows_mo_bytes(size_t rows, size_t cols);
 int gemm_rows_mo_build(int dtype, const void *tiled, size_t rows, size_t cols, void *mo, hipStream_t s);
 
 // rows of 16 per set when nsets > 1, cols % 128 == 0, 2 <= T <= 8; norm == 1 needs cols <= 4096
+// the per-stream scratch of the K-parts launches exists (call before capturing a step that may use them)
+int gemm_rows_kparts_reserve(hipStream_t s);
 bool gemm_rows_mfma_fused_ok(const GmArgs &P, int epi, int norm);
 int gemm_rows_mfma_launch(const GmArgs &P, int epi, int norm, hipStream_t s);
 

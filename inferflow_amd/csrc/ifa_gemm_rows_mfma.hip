@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma_grouped(const Moe
     P.bias[0] = nullptr; P.bias[1] = nullptr; P.bias[2] = nullptr; P.bias1 = nullptr;
     P.Y = Y + (size_t)gq.row0 * rows; P.res = nullptr; P.ldy = rows; P.ldres = 0; P.act_kind = 0;
     P.Yset[0] = nullptr; P.Yset[1] = nullptr; P.Yset[2] = nullptr; P.ldyset[0] = 0; P.ldyset[1] = 0; P.ldyset[2] = 0;
-    P.mo = 0; P.trace = nullptr;
+    P.mo = 0; P.trace = nullptr; P.kparts = 0; P.kpart_sums = nullptr;
     gemm_rows_mfma_body<MAXT, TX, GM_PLAIN, 0, false, 0>(P, smem);
 }
 

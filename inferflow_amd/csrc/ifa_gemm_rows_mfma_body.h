@@ -88,9 +88,10 @@ __device__ __forceinline__ GmTile gm_locate(const GmSets &S, int vt)
 #ifndef IFA_ROWS_FETCH_EARLY
 #define IFA_ROWS_FETCH_EARLY 1
 #endif
-template <int MAXT, int TX, int EPI, int NORM, bool MO, int CH>
+template <int MAXT, int TX, int EPI, int NORM, bool MO, int CH, int KPM = 0>
 __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 {
+    static_assert(KPM == 0 || (CH == 0 && EPI != GM_GLU && NORM == 0 && MO && MAXT % KPM == 0), "K parts: chunk loop, MO layout, no gated pair, no norm prologue");
     // GM_GLU: a workgroup's tiles come in PAIRS -- `it` even: tile (it / 2) of w1, odd: the same tile of w3 -- so the gated
     // product keeps the plain kernel's registers and prefetch depth (MAXT counts both; the epilogue pairs the accumulators)
     constexpr bool GLU = EPI == GM_GLU;
@@ -142,7 +143,11 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 
     // a group = this wave's 16 rows x BPW blocks of (tile, chunk): blocks blk0 .. blk0 + BPW - 1, blk0 = 4 CS chunk + BPW wave
     // valid == false (past the last group): all lanes re-read the first bytes of the matrix -- one cache line, no branch
-    auto tile_of = [&](int it) { return GLU ? (int)blockIdx.x + (it >> 1) * (int)gridDim.x : (int)blockIdx.x + it * (int)gridDim.x; };
+    // K parts (KPM > 0, GmArgs::kparts): workgroup ids kparts * g + kp share tile group g
+    const int kparts = KPM > 0 ? MAXT / KPM : 1;
+    const int kp = KPM > 0 ? (int)blockIdx.x % kparts : 0;
+    const int wgx = KPM > 0 ? (int)blockIdx.x / kparts : (int)blockIdx.x, nwgx = KPM > 0 ? (int)gridDim.x / kparts : (int)gridDim.x;
+    auto tile_of = [&](int it) { return GLU ? wgx + (it >> 1) * nwgx : wgx + it * nwgx; };
     constexpr int RPI = 64 / G::BPW;               // rows per code request
     constexpr int LPR = G::BPW / 4;                // lanes per row of (base, scale) words (4 blocks' words each)
     // Weight requests are GLOBAL loads through an explicit address-space cast: the set pointers pass through integers
@@ -239,13 +244,15 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     // PD groups of requests in flight per wave (a group = 4 supersteps = 5 KB per wave): one group ahead left every wave
     // waiting ~half of the time for HBM
     GmGrp buf[PD];
-    const int nq = nchunk * MAXT;                                  // (chunk, tile) pairs in execution order: chunk outer
+    // this workgroup's chunks [c_lo, c_hi) of K (all of them without K parts; the launcher makes nchunk == kparts * cpp)
+    const int cpp = nchunk / kparts, c_lo = kp * cpp, c_hi = c_lo + cpp;
+    const int nq = cpp * MAXT;                                     // (chunk, tile) pairs in execution order: chunk outer
     // (one chunk: the groups past the last one are not requested at all -- qi is a literal after unrolling, the test folds away.
     //  As clamped dummy loads they were 5 of the 8 group requests of a wave of the wq | wk | wv launch: ~0.6 us of the CU's
     //  request path.  The chunk loop keeps them: a branch around a load makes every later wait a vmcnt(0).)
     auto fetch_q = [&](GmGrp &q, int qi) __attribute__((always_inline)) {
         if constexpr (CH == 1) { if (qi >= MAXT) return; }
-        const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, ch, qi < nq);
+        const int ch = qi / MAXT; fetch(q, qi - ch * MAXT, c_lo + ch, qi < nq);
     };
     // The CU's memory pipeline is FIFO across waves (ifa_decode_kernels.h): the activation rows of the first chunk are
     // requested by all threads, and a barrier passed, BEFORE any weight request -- else they arrive behind the weights.
@@ -384,7 +391,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     };
     long long *const trc = P.trace ? P.trace + (size_t)blockIdx.x * 32 : nullptr;
     if (trc && tid == 0) trc[0] = wall_clock64();
-    if constexpr (WHOLE) xw_request(); else x_request(0);
+    if constexpr (WHOLE) xw_request(); else x_request(c_lo);
     __syncthreads();
     if (trc && tid == 0) trc[1] = wall_clock64();
     // ONE group per wave is requested in front of the staging, the rest behind it: with all PD groups (30 MB chip-wide for a
@@ -395,10 +402,10 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     // after them), so staging them does not wait for the weight groups in flight.  That needs straight-line code: the
     // single-chunk case (K <= 4096: wq | wk | wv, wo, w1 / w3) is its own path, and in the chunk loop the NEXT chunk's rows
     // are requested before the current chunk's weight groups and stored after them.
-    auto run_chunk = [&](int chunk) __attribute__((always_inline)) {
+    auto run_chunk = [&](int chunk) __attribute__((always_inline)) {           // chunk: absolute; the groups are counted from c_lo
 #pragma unroll
         for (int it = 0; it < MAXT; it++) {
-            const int qi = chunk * MAXT + it;
+            const int qi = (chunk - c_lo) * MAXT + it;
             // The two waves of a SIMD (w, w + 4) are both VALU-ready most of the time and the issue arbiter favours the older one:
             // waves 0..3 ran ahead (all their groups done while waves 4..7 had finished two of eight: rows-trace), i.e. only half of
             // the CU's requests were cycling.  Alternate the priority per group so the pair takes turns.
@@ -414,7 +421,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 #pragma unroll
         for (int d = 1; d < PD; d++) fetch_q(buf[d], d);      // (behind the rows' own requests in this CU's queue, see x_store)
         xw_store();
-    } else x_store(0, true);
+    } else x_store(c_lo, true);
     // The staging barrier FIRST, the other PD - 1 groups behind it (round 4): requested in front of the barrier, every wave sat in
     // its load issue (4 x 5 KB per wave against a full memory queue) before it could arrive -- the rows were staged at 3.0 us and
     // the barrier passed at 4.8 (rows-trace: "other groups requested 3.22, x staged 4.77"); the first group is in flight since 0.8
@@ -444,11 +451,11 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     } else if constexpr (WHOLE) {
         for (int chunk = 0; chunk < nchunk; chunk++) run_chunk(chunk);
     } else {
-        for (int chunk = 0; chunk < nchunk; chunk++) {
-            const int nx = min(chunk + 1, nchunk - 1);
-            if (nchunk > 1) x_request(nx);                         // (last chunk: re-read, never stored)
+        for (int chunk = c_lo; chunk < c_hi; chunk++) {
+            const int nx = min(chunk + 1, c_hi - 1);
+            if (cpp > 1) x_request(nx);                            // (last chunk: re-read, never stored)
             run_chunk(chunk);
-            if (chunk + 1 < nchunk) {
+            if (chunk + 1 < c_hi) {
                 __syncthreads();                                   // this chunk's fragments have been read
                 x_store(nx);
                 __syncthreads();
@@ -479,6 +486,110 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
             return sum;
         };
         constexpr int STEP = GLU ? 2 : 1;
+        // bias / residual / gate of one output element (tile vt, column tile nt) and its store
+        auto emit = [&](int vt, int nt, float s0, float s1) {
+            const int n = (l & 15) + 16 * nt;
+            const GmTile tl = gm_locate(S, min(vt, ntiles - 1));
+            const int row = tl.row0 + m;
+            if (vt < ntiles && row < tl.nrows && n < T) {
+                half_t y = f2h(s0);
+                if (tl.b0) y = f2h(h2f(y) + h2f(tl.b0[row]));
+                const size_t vrow = (size_t)tl.vrow0 + m;
+                if constexpr (EPI == GM_RESIDUAL) {
+                    y = f2h(h2f(P.res[(size_t)n * P.ldres + vrow]) + h2f(y));          // TensorOpr::Add (half add)
+                } else if constexpr (GLU) {
+                    half_t y3 = f2h(s1);
+                    if (P.bias1) y3 = f2h(h2f(y3) + h2f(P.bias1[row]));
+                    const half_t act = f2h(act_fn(h2f(y), P.act_kind));                // TensorOpr::Activation -> F16
+                    y = f2h(h2f(act) * h2f(y3));                                       // TensorOpr::Mul
+                }
+                tl.y[(size_t)n * tl.ldy + row] = y;
+            }
+        };
+        if constexpr (KPM > 0) {
+            // ---- K parts, reduce-scatter form.  (One finishing workgroup per group was prototyped first: its CU pulled 123 KB of
+            // partial sums at ~25 GB/s while the others idled -- 8-11 us behind a loop that had gone from 21 to 11 us.)
+            unsigned long long *const gsum = P.kpart_sums;
+            auto slot = [&](int vt, int part_id, int nt) { return gsum + (((size_t)vt * kparts + part_id) * NT + nt) * 256 + e; };
+            // A. the sums of the tiles other workgroups finish: write-through granules, nothing waits for them here
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int it = 0; it < MAXT; it++) {
+                    if ((it & 1) != hsel || it / KPM == kp) continue;
+                    const int vt = tile_of(it);
+                    if (vt >= ntiles) continue;
+                    const float v = total(nt * MAXT + it);
+                    __hip_atomic_store(slot(vt, kp, nt), (1ull << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            // B. the tiles this workgroup finishes: its own part from LDS, the other parts' granules polled (all requests first)
+            float own[NT][KPM];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int j = 0; j < KPM; j++) {
+                    const int it = kp * KPM + j;
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < GM_WAVES; w++) sum = sum + part[(size_t)((nt * MAXT + it) * GM_WAVES + w) * 256 + e];
+                    own[nt][j] = sum;
+                }
+            unsigned long long u[NT][KPM][7];
+            const long long t_wait = wall_clock64();
+            for (;;) {
+                bool all = true;
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int j = 0; j < KPM; j++) {
+                        const int it = kp * KPM + j;
+                        if ((it & 1) != hsel) continue;         // (wave-uniform: the other half of the workgroup finishes the tiles of the other parity)
+                        const int vt = min(tile_of(it), ntiles - 1);
+#pragma unroll
+                        for (int z = 0; z < 7; z++) {           // the other parts in K order: z < kp -> part z, else part z + 1 (clamped duplicates past the end: never looked at)
+                            const int q = min(z < kp ? z : z + 1, kparts - 1);
+                            u[nt][j][z] = __hip_atomic_load(slot(vt, q, nt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int j = 0; j < KPM; j++) {
+                        const int it = kp * KPM + j;
+                        if ((it & 1) != hsel || tile_of(it) >= ntiles) continue;
+#pragma unroll
+                        for (int z = 0; z < 7; z++) if (z < kparts - 1) all = all && (u[nt][j][z] >> 32) == 1ull;
+                    }
+                if (__builtin_amdgcn_ballot_w64(!all) == 0ull) break;           // (per wave: every lane's granules are in)
+                if (wall_clock64() - t_wait > 500000000ll) __builtin_trap();     // (5 s: abort the launch rather than add garbage)
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int j = 0; j < KPM; j++) {
+                    const int it = kp * KPM + j;
+                    if ((it & 1) != hsel) continue;
+                    const int vt = tile_of(it);
+                    if (vt >= ntiles) continue;
+                    // K order: parts 0 .. kp - 1, own, kp + 1 .. kparts - 1
+                    float sum = 0.0f;
+                    bool first = true;
+#pragma unroll
+                    for (int z = 0; z < 8; z++) {
+                        if (z >= kparts) continue;
+                        const float term = z == kp ? own[nt][j] : __builtin_bit_cast(float, (uint32_t)u[nt][j][z < kp ? z : z - 1]);
+                        sum = first ? term : sum + term;
+                        first = false;
+                    }
+#pragma unroll
+                    for (int z = 0; z < 8; z++)
+                        if (z < kparts && z != kp) __hip_atomic_store(slot(vt, z, nt), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                    emit(vt, nt, sum, 0.0f);
+                }
+            if (trc && tid == 0) trc[5] = wall_clock64();
+            return;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             const int n = (l & 15) + 16 * nt;
@@ -511,11 +622,11 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     if (trc && tid == 0) trc[5] = wall_clock64();
 }
 
-template <int MAXT, int TX, int EPI, int NORM, bool MO, int CH>
+template <int MAXT, int TX, int EPI, int NORM, bool MO, int CH, int KPM = 0>
 __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mfma(const GmArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_rows_mfma_body<MAXT, TX, EPI, NORM, MO, CH>(P, smem);
+    gemm_rows_mfma_body<MAXT, TX, EPI, NORM, MO, CH, KPM>(P, smem);
 }
 
 static int gm_tx(int T) { return T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 8 ? 8 : 16)); }

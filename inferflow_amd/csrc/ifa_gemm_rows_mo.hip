@@ -3,9 +3,70 @@
 // A operand, a superstep of a tile one contiguous KiB per wave; 16 activation rows x 4096 columns fit the LDS (no patches), so
 // wq | wk | wv, wo and w1 / w3 of a 4096-wide model are single-chunk kernels (CH = 1: straight-line, counted waits) for every
 // batch of 2..16 rows; longer rows (w2) walk 4096-column chunks.  Rows are staged as 8 or 16 (TX).
+#include <mutex>
 #include "ifa_gemm_rows_mfma_body.h"
 
 namespace ifa {
+
+static int dec_num_cus_rows()
+{
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipDeviceProp_t prop; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+    return ncu;
+}
+// per-(device, stream) scratch of the K-parts launches: the parts' tile sums as 8-byte {tag, value} granules, zero between launches
+struct KPartsScratch { void *p = nullptr; size_t bytes = 0; };
+static std::mutex g_kparts_mu;
+static std::map<std::pair<int, hipStream_t>, KPartsScratch> g_kparts;
+static const int g_rows_kparts_off = getenv("IFA_ROWS_KPARTS_OFF") ? 1 : 0;       // tuning aid (A / B)
+static int rows_kparts_scratch(hipStream_t s, size_t need, void **out)
+{
+    int dev = 0;
+    IFA_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_kparts_mu);
+    KPartsScratch &sc = g_kparts[std::make_pair(dev, s)];
+    if (sc.bytes < need) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &st);
+        if (st != hipStreamCaptureStatusNone) return ifa_fail(IFA_ERR_STATE, "rows GEMM K parts: the scratch must exist before a capture (gemm_rows_kparts_reserve)");
+        IFA_HIP_CHECK(hipStreamSynchronize(s));
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.bytes = 0;
+        const size_t alloc = std::max(need, (size_t)16 << 20);
+        IFA_HIP_CHECK(hipMalloc(&sc.p, alloc));
+        IFA_HIP_CHECK(hipMemsetAsync(sc.p, 0, alloc, s));
+        sc.bytes = alloc;
+    }
+    *out = sc.p;
+    return IFA_OK;
+}
+// the scratch of the stream exists (>= 16 MB: every 7B..70B-width product of up to 32 rows) -- called before a capture
+int gemm_rows_kparts_reserve(hipStream_t s)
+{
+    void *p = nullptr;
+    return rows_kparts_scratch(s, 1, &p);       // (any size: the allocation is >= 16 MB)
+}
+void rows_kparts_release(int dev, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_kparts_mu);
+    auto it = g_kparts.find(std::make_pair(dev, s));
+    if (it == g_kparts.end()) return;
+    if (it->second.p) (void)hipFree(it->second.p);
+    g_kparts.erase(it);
+}
+
+template <int MT, int KPM>
+static int mo_launch_kparts(int wgs, size_t smem, const GmArgs &P, int epi, hipStream_t s)
+{
+#define IFA_KP(TXV, EPIV) { auto kern = k_gemm_rows_mfma<MT, TXV, EPIV, 0, true, 0, KPM>; \
+        if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        kern<<<dim3((unsigned)wgs), dim3(GM_THREADS), smem, s>>>(P); }
+    if (P.T <= 16) { if (epi == GM_PLAIN) IFA_KP(16, GM_PLAIN) else IFA_KP(16, GM_RESIDUAL) }
+    else { if (epi == GM_PLAIN) IFA_KP(32, GM_PLAIN) else IFA_KP(32, GM_RESIDUAL) }
+#undef IFA_KP
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
 
 template <int MT, int TX, int EPI, int NORM, int CH>
 static int mo_launch4(int wgs, size_t smem, const GmArgs &P, hipStream_t s)
@@ -87,6 +148,46 @@ int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, h
         }
     }
     if (norm == 1 && !one) return ifa_fail(IFA_ERR_ARG, "rows GEMM (MO): the norm prologue needs the whole row in one chunk");
+    // K parts (GmArgs::kparts): 9..32 rows walking three chunks or more.  Every workgroup stages T rows of EVERY chunk for its
+    // tiles: at 32 queries w2 (256 tiles, K = 11008: six 2048-column chunks) moved 180 MB of activations L2 -> LDS for 25 MB of
+    // weights and ran at the L2's ~10 TB/s (21 us, rows-trace).  With kparts = the chunk count a workgroup takes ONE chunk of kparts
+    // times as many tiles (rows staged once: 33 MB in all) and finishes its share of them (reduce-scatter of the fp32 tile sums).
+    if (!one && norm == 0 && (epi == GM_PLAIN || epi == GM_RESIDUAL) && P.T >= 9 && !g_rows_kparts_off && (maxt == 1 || maxt == 2)) {
+        const int chunk_sup = P.T <= 16 ? 32 : 16, nsup = P.nblk / 4, nchunk = (nsup + chunk_sup - 1) / chunk_sup;
+        int kparts = 0;
+        // (every workgroup of a group must be resident at once -- the finishers poll their group's other parts: a workgroup that
+        //  waits for a free CU delays its whole group by a kernel's length (w2, 258 workgroups: median end 14.6 us, the last group 27))
+        const int ntiles_all = (P.total_rows + 15) / 16;
+        for (int d = std::min(nchunk, 8 / maxt); d >= 2 && nchunk >= 3; d--) {
+            if (nchunk % d != 0 || maxt * d == 5 || maxt * d == 7) continue;
+            if ((ntiles_all + maxt * d - 1) / (maxt * d) * d > dec_num_cus_rows()) continue;
+            kparts = d; break;
+        }
+        if (kparts >= 2) {
+            const int ntiles = (P.total_rows + 15) / 16, maxt_k = maxt * kparts, groups = (ntiles + maxt_k - 1) / maxt_k;
+            const int NTc = P.T > 16 ? 2 : 1;
+            GmArgs Q = P;
+            void *scratch = nullptr;
+            int rc = rows_kparts_scratch(s, (size_t)groups * maxt_k * kparts * NTc * 256 * 8, &scratch);
+            if (rc) return rc;
+            Q.kparts = kparts; Q.kpart_sums = (unsigned long long *)scratch;
+            const size_t smem_k = gm_smem(P.T, maxt_k, 1);
+            const int wgs_k = groups * kparts;
+            if (maxt == 1) switch (maxt_k) {
+                case 2: return mo_launch_kparts<2, 1>(wgs_k, smem_k, Q, epi, s);
+                case 3: return mo_launch_kparts<3, 1>(wgs_k, smem_k, Q, epi, s);
+                case 4: return mo_launch_kparts<4, 1>(wgs_k, smem_k, Q, epi, s);
+                case 6: return mo_launch_kparts<6, 1>(wgs_k, smem_k, Q, epi, s);
+                case 8: return mo_launch_kparts<8, 1>(wgs_k, smem_k, Q, epi, s);
+                default: break;
+            } else switch (maxt_k) {
+                case 4: return mo_launch_kparts<4, 2>(wgs_k, smem_k, Q, epi, s);
+                case 6: return mo_launch_kparts<6, 2>(wgs_k, smem_k, Q, epi, s);
+                case 8: return mo_launch_kparts<8, 2>(wgs_k, smem_k, Q, epi, s);
+                default: break;
+            }
+        }
+    }
     const size_t smem = gm_smem(P.T, maxt, 1);
     switch (maxt) {
     case 1: return mo_launch1<1>(wgs, smem, P, epi, norm, one, s);
@@ -116,7 +217,7 @@ __global__ void __launch_bounds__(GM_THREADS) k_gemm_rows_mo_grouped(const MoeSm
     P.bias[0] = nullptr; P.bias[1] = nullptr; P.bias[2] = nullptr; P.bias1 = nullptr;
     P.Y = Y + (size_t)gq.row0 * rows; P.res = nullptr; P.ldy = rows; P.ldres = 0; P.act_kind = act_kind;
     P.Yset[0] = nullptr; P.Yset[1] = nullptr; P.Yset[2] = nullptr; P.ldyset[0] = 0; P.ldyset[1] = 0; P.ldyset[2] = 0;
-    P.mo = 1; P.trace = nullptr;
+    P.mo = 1; P.trace = nullptr; P.kparts = 0; P.kpart_sums = nullptr;
     // groups of 2..4 rows (most of them: 16 entries over 8 experts): four rows staged instead of eight, and rows longer than a chunk
     // (w2) staged whole -- no re-staging, no barriers in the chunk loop
     if (gq.nrows <= 4 && (CH == 1 || (size_t)4 * ((size_t)nblk * 64 + 16) <= (size_t)whole_lds)) {
