@@ -19,6 +19,8 @@ struct KPartsScratch { void *p = nullptr; size_t bytes = 0; };
 static std::mutex g_kparts_mu;
 static std::map<std::pair<int, hipStream_t>, KPartsScratch> g_kparts;
 static const int g_rows_kparts_off = getenv("IFA_ROWS_KPARTS_OFF") ? 1 : 0;       // tuning aid (A / B)
+// (from two chunks on: wo of 17..32 queries as two parts 10.5 -> 9.5 us; 32 queries 3.22 -> 3.18 ms)
+static const int KPARTS_MIN_CHUNKS = getenv("IFA_ROWS_KPARTS_MIN") ? atoi(getenv("IFA_ROWS_KPARTS_MIN")) : 2;
 static int rows_kparts_scratch(hipStream_t s, size_t need, void **out)
 {
     int dev = 0;
@@ -148,7 +150,7 @@ int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, h
         }
     }
     if (norm == 1 && !one) return ifa_fail(IFA_ERR_ARG, "rows GEMM (MO): the norm prologue needs the whole row in one chunk");
-    // K parts (GmArgs::kparts): 9..32 rows walking three chunks or more.  Every workgroup stages T rows of EVERY chunk for its
+    // K parts (GmArgs::kparts): 9..32 rows walking two chunks or more (one tile per workgroup before: maxt 1 or 2).  Every workgroup stages T rows of EVERY chunk for its
     // tiles: at 32 queries w2 (256 tiles, K = 11008: six 2048-column chunks) moved 180 MB of activations L2 -> LDS for 25 MB of
     // weights and ran at the L2's ~10 TB/s (21 us, rows-trace).  With kparts = the chunk count a workgroup takes ONE chunk of kparts
     // times as many tiles (rows staged once: 33 MB in all) and finishes its share of them (reduce-scatter of the fp32 tile sums).
@@ -158,7 +160,7 @@ int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, h
         // (every workgroup of a group must be resident at once -- the finishers poll their group's other parts: a workgroup that
         //  waits for a free CU delays its whole group by a kernel's length (w2, 258 workgroups: median end 14.6 us, the last group 27))
         const int ntiles_all = (P.total_rows + 15) / 16;
-        for (int d = std::min(nchunk, 8 / maxt); d >= 2 && nchunk >= 3; d--) {
+        for (int d = std::min(nchunk, 8 / maxt); d >= 2 && nchunk >= KPARTS_MIN_CHUNKS; d--) {
             if (nchunk % d != 0 || maxt * d == 5 || maxt * d == 7) continue;
             if ((ntiles_all + maxt * d - 1) / (maxt * d) * d > dec_num_cus_rows()) continue;
             kparts = d; break;
