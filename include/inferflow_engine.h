@@ -88,6 +88,12 @@ int ifa_partition_split_layers(int n_layers, int n_groups, int *out_pairs, int c
 int ifa_service_parse_request(const char *body, int is_openai_mode, char *out_json, size_t cap);
 int ifa_service_format_response(const int *token_ids, int n, int is_end, int is_openai_mode, int is_chunk, int prompt_tokens,
                                 char *out_json, size_t cap);
+/* host-only: the service's Infer / Commit LOOP (InferFlowServiceCore, the counterpart of src/service/inferflow_service.cc:60-129)
+ * over a loopback engine with InferenceEngine's query-table semantics (a query whose context is full is ended WITHOUT an item; the
+ * fail_at_infer_call-th Infer returns false).  Runs n_requests queries one after the other; writes a JSON list of
+ * {ok, hung, ret_code, is_end, finish_reason, token_ids, active, openai}.  0, or -1 on bad arguments / a small buffer. */
+int ifa_service_selftest_loop(int max_ctx, int max_queries, int fail_at_infer_call, const int *prompt, int n_prompt, int max_output_len,
+                              int eos_token_id, int n_requests, int timeout_ms, char *out_json, size_t cap);
 
 #ifdef __cplusplus
 }

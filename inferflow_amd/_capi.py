@@ -166,6 +166,7 @@ ENGINE_SIGNATURES = {
     "ifa_engine_model_info": (_i, [_vp, C.c_char_p]),
     "ifa_service_parse_request": (_i, [C.c_char_p, _i, C.c_char_p, _sz]),
     "ifa_service_format_response": (_i, [_ip, _i, _i, _i, _i, _i, C.c_char_p, _sz]),
+    "ifa_service_selftest_loop": (_i, [_i, _i, _i, _ip, _i, _i, _i, _i, _i, C.c_char_p, _sz]),
     "ifa_partition_slice": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _sz, _sz, C.POINTER(_sz)]),
     "ifa_partition_split_layers": (_i, [_i, _i, _ip, _i]),
 }

@@ -1,6 +1,8 @@
 // engine_capi.cc -- C ABI of the InferenceEngine facade (include/inferflow_engine.h)
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <future>
 #include <map>
 #include <string>
 
@@ -238,6 +240,87 @@ int ifa_service_format_response(const int *token_ids, int n, int is_end, int is_
     c.ret_code = "succ"; c.token_ids.assign(token_ids, token_ids + n); c.is_end = is_end != 0; c.prompt_tokens = prompt_tokens;
     std::string js;
     if (is_openai_mode) c.ToJsonOpenAI(js, is_chunk != 0, "ifa-test"); else c.ToJson(js);
+    if (js.size() + 1 > cap) return -1;
+    memcpy(out_json, js.c_str(), js.size() + 1);
+    return 0;
+}
+
+// ---- the service LOOP without a device -------------------------------------------------------------------------------------------
+// A host-only QueryEngine with InferenceEngine's query-table semantics (AddQuery: > 0 id / 0 busy / -1 too long; Infer: one item
+// per query with uncommitted tokens, a query whose context is full is marked ended and gets NO item, a failed step returns false
+// without items; Commit appends, is_end ends) over a trivial "model": next token = (last + 1) % vocab.
+namespace {
+struct LoopbackEngine : QueryEngine {
+    struct Q { std::vector<int> tokens; int processed = 0; bool ended = false; };
+    std::map<int, Q> qs;
+    int max_ctx, max_queries, fail_at, vocab = 1000, next_id = 1, infer_calls = 0;
+    LoopbackEngine(int ctx, int mq, int fail) : max_ctx(ctx), max_queries(mq), fail_at(fail) {}
+    int AddQuery(const std::vector<int> &t, const QueryOptions &) override {
+        if (t.empty() || (int)t.size() >= max_ctx) return -1;
+        if ((int)qs.size() >= max_queries) return 0;
+        Q q; q.tokens = t; qs[next_id] = q; return next_id++;
+    }
+    int QueryCount() const override { return (int)qs.size(); }
+    bool Infer(InferenceResult &res) override {
+        res.items.clear();
+        if (++infer_calls == fail_at) return false;
+        for (auto &kv : qs) {
+            Q &q = kv.second;
+            if (q.ended) continue;
+            if ((int)q.tokens.size() >= max_ctx) { q.ended = true; continue; }
+            if ((int)q.tokens.size() - q.processed <= 0) continue;
+            QueryInferenceResult item; item.query_id = kv.first; item.prefix_len = q.processed;
+            IdWeight w; w.id = (q.tokens.back() + 1) % vocab; w.weight = 1.0f;
+            item.next_tokens.push_back(w);
+            q.processed = (int)q.tokens.size();
+            res.items.push_back(item);
+        }
+        return true;
+    }
+    bool CommitInferenceResult(const std::map<int, QueryNextToken> &m) override {
+        for (const auto &kv : m) { auto it = qs.find(kv.first); if (it == qs.end()) continue; it->second.tokens.push_back(kv.second.id); if (kv.second.is_end) it->second.ended = true; }
+        return true;
+    }
+    bool RemoveQuery(int id) override { return qs.erase(id) != 0; }
+    bool QueryEnded(int id) const override { auto it = qs.find(id); return it == qs.end() || it->second.ended; }
+    int MaxContextLen() const override { return max_ctx; }
+    SamplingStrategyId GetSamplingStrategyId(const std::string &) const override { return SamplingStrategyId::Greedy; }
+    std::string Version() const override { return "loopback"; }
+    std::string ModelId() const override { return "loopback"; }
+    int VocabSize() const override { return vocab; }
+};
+}
+
+// n_requests queries one after the other through InferFlowServiceCore::ProcessQuery over the engine above; every one must
+// RETURN (a handler stuck in its wait loop is reported as "hung": the core is stopped to release it) and hand its slot back
+// (an "error.busy" after max_queries earlier requests means a leak).  Writes a JSON list of the results.
+int ifa_service_selftest_loop(int max_ctx, int max_queries, int fail_at_infer_call, const int *prompt, int n_prompt, int max_output_len,
+                              int eos_token_id, int n_requests, int timeout_ms, char *out_json, size_t cap)
+{
+    if (!out_json || cap == 0 || n_prompt < 0 || (n_prompt > 0 && !prompt) || n_requests < 1) return -1;
+    LoopbackEngine eng(max_ctx, max_queries, fail_at_infer_call);
+    InferFlowServiceCore core(eng);
+    core.Start();
+    std::string js = "[";
+    for (int r = 0; r < n_requests; r++) {
+        InferFlowRequest req;
+        req.prompt_token_ids.assign(prompt, prompt + n_prompt);
+        req.max_output_len = max_output_len; req.eos_token_id = eos_token_id;
+        InferFlowResponseChunk res;
+        bool ok = false, hung = false;
+        auto fut = std::async(std::launch::async, [&] { return core.ProcessQuery(res, req, nullptr); });
+        if (fut.wait_for(std::chrono::milliseconds(timeout_ms)) != std::future_status::ready) { hung = true; core.Stop(); }
+        ok = fut.get();
+        if (hung) core.Start();
+        std::string ids = "[";
+        for (size_t i = 0; i < res.token_ids.size(); i++) { if (i) ids += ", "; ids += std::to_string(res.token_ids[i]); }
+        std::string openai; res.ToJsonOpenAI(openai, false, "ifa-test");
+        js += std::string(r ? ", " : "") + "{\"ok\": " + (ok ? "true" : "false") + ", \"hung\": " + (hung ? "true" : "false") + ", \"ret_code\": \"" + res.ret_code
+            + "\", \"is_end\": " + (res.is_end ? "true" : "false") + ", \"finish_reason\": \"" + res.finish_reason + "\", \"token_ids\": " + ids + "], \"active\": "
+            + std::to_string(eng.QueryCount()) + ", \"openai\": " + openai + "}";
+    }
+    core.Stop();
+    js += "]";
     if (js.size() + 1 > cap) return -1;
     memcpy(out_json, js.c_str(), js.size() + 1);
     return 0;

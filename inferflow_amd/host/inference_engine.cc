@@ -472,6 +472,12 @@ bool InferenceEngine::RemoveQuery(int query_id)
     return queries_.erase(query_id) != 0;
 }
 
+bool InferenceEngine::QueryEnded(int query_id) const
+{
+    auto it = queries_.find(query_id);
+    return it == queries_.end() || it->second.ended;
+}
+
 bool InferenceEngine::Infer(InferenceResult &res)
 {
     res.items.clear(); res.perf_stat.time_map.clear();

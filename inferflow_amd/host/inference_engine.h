@@ -117,10 +117,30 @@ struct InferenceResult {
     InferencePerfStat perf_stat;
 };
 
-class InferenceEngine {
+// What the service shell (inferflow_service.h) needs from an engine: the query-level calls of the reference's InferenceEngine
+// (src/transformer/inference_engine.h:41-75) plus two facts the reference's service reads off its query table -- whether a
+// query has ended inside the engine (context full) and the context limit.  InferenceEngine implements it; the CPU tests drive
+// the service loop over a host-only implementation.
+class QueryEngine {
+public:
+    virtual ~QueryEngine() {}
+    virtual int AddQuery(const std::vector<int> &tokens, const QueryOptions &query_options) = 0;
+    virtual int QueryCount() const = 0;
+    virtual bool Infer(InferenceResult &res) = 0;
+    virtual bool CommitInferenceResult(const std::map<int, QueryNextToken> &query_map) = 0;
+    virtual bool RemoveQuery(int query_id) = 0;
+    virtual bool QueryEnded(int query_id) const = 0;       // true also for an unknown id
+    virtual int MaxContextLen() const = 0;
+    virtual SamplingStrategyId GetSamplingStrategyId(const std::string &str = "") const = 0;
+    virtual std::string Version() const = 0;
+    virtual std::string ModelId() const = 0;
+    virtual int VocabSize() const = 0;
+};
+
+class InferenceEngine : public QueryEngine {
 public:
     InferenceEngine();
-    ~InferenceEngine();
+    ~InferenceEngine() override;
     InferenceEngine(const InferenceEngine &) = delete;
     InferenceEngine &operator=(const InferenceEngine &) = delete;
     void Clear();
@@ -130,21 +150,26 @@ public:
     bool Init(const InferenceConfig &cfg);
 
     // > 0: query id, 0: busy (max_concurrent_queries reached), < 0: error
-    int AddQuery(const std::vector<int> &tokens, const QueryOptions &query_options);
-    int QueryCount() const;
-    // one step for every active query: prefill of the pending tokens, or one decode step
-    bool Infer(InferenceResult &res);
-    bool CommitInferenceResult(const std::map<int, QueryNextToken> &query_map);
-    bool RemoveQuery(int query_id);
+    int AddQuery(const std::vector<int> &tokens, const QueryOptions &query_options) override;
+    int QueryCount() const override;
+    // one step for every active query: prefill of the pending tokens, or one decode step.  A query whose context is full
+    // (tokens == max_context_len) is marked ended and gets NO item (QueryEnded tells the caller).
+    bool Infer(InferenceResult &res) override;
+    bool CommitInferenceResult(const std::map<int, QueryNextToken> &query_map) override;
+    bool RemoveQuery(int query_id) override;
+    bool QueryEnded(int query_id) const override;
+    int MaxContextLen() const override { return spec_.max_context_len > 0 ? spec_.max_context_len : ModelSpec::DEFAULT_MAX_CONTEXT_LEN; }
+    std::string ModelId() const override { return spec_.sid; }
+    int VocabSize() const override { return spec_.hyper_params.vocab_size; }
 
     // Extension: n greedy steps with the token fed back on the device (hipGraph replay, no host
     // round trip per token).  Equivalent to n x {Infer, CommitInferenceResult(greedy)}.
     bool Generate(int query_id, int n_steps, std::vector<int> &new_tokens, float *gpu_ms = nullptr);
 
     // id of a strategy name ("sample.top_p" ...); empty: the model's own decoding_strategy
-    SamplingStrategyId GetSamplingStrategyId(const std::string &str = "") const;
+    SamplingStrategyId GetSamplingStrategyId(const std::string &str = "") const override;
     const ModelSpec &model_spec() const { return spec_; }
-    std::string Version() const { return "inferflow_amd 0.1 (MI355X)"; }
+    std::string Version() const override { return "inferflow_amd 0.1 (MI355X)"; }
     int default_device_id() const { return device_; }
     int PartitionRanks() const;     // workers of the multi-GPU partition (1: single device)
     ifa_model *worker() { return model_; }

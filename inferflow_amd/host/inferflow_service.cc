@@ -3,10 +3,12 @@
 #include "inferflow_service.h"
 
 #include <arpa/inet.h>
+#include <poll.h>
 #include <netinet/in.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -35,7 +37,7 @@ void InferFlowResponseChunk::ToJsonOpenAI(std::string &out, bool is_chunk, const
 {
     const bool failed = !ret_code.empty() && ret_code != "succ";
     if (failed) { out = "{\"error\": {\"message\": \"" + ret_code + "\", \"type\": \"invalid_request_error\"}}"; return; }
-    const std::string finish = !is_end ? "null" : "\"length\"";
+    const std::string finish = !is_end ? "null" : ("\"" + (finish_reason.empty() ? std::string("length") : finish_reason) + "\"");
     out = "{\"id\": \"" + id + "\", \"object\": \"" + (is_chunk ? "chat.completion.chunk" : "chat.completion") + "\", \"choices\": [{\"index\": 0, \""
         + (is_chunk ? "delta" : "message") + "\": {\"role\": \"assistant\", \"token_ids\": " + JoinIds(token_ids) + "}, \"finish_reason\": " + finish + "}]";
     if (!is_chunk) out += ", \"usage\": {\"prompt_tokens\": " + std::to_string(prompt_tokens) + ", \"completion_tokens\": " + std::to_string(token_ids.size())
@@ -91,32 +93,47 @@ void InferFlowServiceCore::Stop()
     if (loop_.joinable()) loop_.join();
 }
 
-// InferFlowServiceCore::Infer (inferflow_service.cc:73-131): one engine step for every active query
+// InferFlowServiceCore::Infer (inferflow_service.cc:73-131): one engine step for every active query.
+// Every registered query leaves a step in one of three states: it got a token (recorded, committed, ended by the service's own
+// EOS / max_len rule), the engine ended it without a token (its context is full: QueryEnded), or the step failed (Infer returned
+// false: every query that got nothing ends with an error code) -- a handler never waits for a query the engine will not advance.
 bool InferFlowServiceCore::InferOnce()
 {
     std::unique_lock<std::mutex> eg(engine_lock_);
     if (engine_.QueryCount() == 0) { eg.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); return true; }
     InferenceResult result;
     const bool ok = engine_.Infer(result);
-    if (result.items.empty()) { eg.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); return ok; }
-    steps_++;
+    if (!result.items.empty()) steps_++;
     std::map<int, QueryNextToken> commit;
     {
         std::lock_guard<std::mutex> g(lock_);
         for (const QueryInferenceResult &item : result.items) {
             if (item.next_tokens.empty()) continue;
+            auto it = query_to_result_.find(item.query_id);
+            if (it == query_to_result_.end()) continue;          // (a query the handler already dropped)
             const int id = item.next_tokens[0].id;
-            QueryResult &qr = query_to_result_[item.query_id];
+            QueryResult &qr = it->second;
             qr.tokens.push_back(id);
             qr.produced++;
             tokens_out_++;
             QueryNextToken nt; nt.id = id;
-            nt.is_end = (qr.eos >= 0 && id == qr.eos) || (qr.max_len > 0 && qr.produced >= qr.max_len);
-            qr.is_end = nt.is_end;
+            const bool eos = qr.eos >= 0 && id == qr.eos;
+            nt.is_end = eos || (qr.max_len > 0 && qr.produced >= qr.max_len);
+            if (nt.is_end) { qr.is_end = true; qr.reason = eos ? "stop" : "length"; }
             commit[item.query_id] = nt;
         }
     }
-    engine_.CommitInferenceResult(commit);
+    if (!commit.empty()) engine_.CommitInferenceResult(commit);
+    {
+        std::lock_guard<std::mutex> g(lock_);
+        for (auto &kv : query_to_result_) {
+            QueryResult &qr = kv.second;
+            if (qr.is_end || commit.count(kv.first)) continue;
+            if (!ok) { qr.is_end = true; qr.reason = "error"; qr.err = "error.inference_failed"; }
+            else if (engine_.QueryEnded(kv.first)) { qr.is_end = true; qr.reason = "length"; }      // context full (or the query is gone)
+        }
+    }
+    if (result.items.empty()) { eg.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
     return ok;
 }
 
@@ -127,22 +144,29 @@ bool InferFlowServiceCore::ProcessQuery(InferFlowResponseChunk &result, const In
     result = InferFlowResponseChunk();
     result.prompt_tokens = (int)request.prompt_token_ids.size();
     if (request.prompt_token_ids.empty()) { result.ret_code = "error.empty_request"; return false; }
+    // the output length is bounded by the context whatever the request says (0 or negative: "as much as fits"): a query the
+    // engine ends by itself produces no token, so an unbounded request would otherwise only end on EOS
+    const int max_ctx = engine_.MaxContextLen();
+    const int room = max_ctx - (int)request.prompt_token_ids.size() - 1;
+    if (room < 1) { result.ret_code = "error.too_long_request"; return false; }
+    const int max_len = request.max_output_len > 0 ? std::min(request.max_output_len, room) : room;
     QueryOptions qo;
     qo.strategy_id = (int)engine_.GetSamplingStrategyId(request.decoding_alg);
     qo.random_seed = request.random_seed;
     qo.temperature = request.temperature;
-    qo.max_output_len = request.max_output_len;
+    qo.max_output_len = max_len;
     int qid = 0;
     {
         // registered before the loop can step the query (the loop holds engine_lock_ for a whole Infer + Commit)
         std::lock_guard<std::mutex> eg(engine_lock_);
         std::lock_guard<std::mutex> g(lock_);
         qid = engine_.AddQuery(request.prompt_token_ids, qo);
-        if (qid > 0) { QueryResult &qr = query_to_result_[qid]; qr.max_len = request.max_output_len; qr.eos = request.eos_token_id; }
+        if (qid > 0) { QueryResult &qr = query_to_result_[qid]; qr.max_len = max_len; qr.eos = request.eos_token_id; }
     }
     if (qid <= 0) { result.ret_code = qid == 0 ? "error.busy" : "error.invalid_query"; return false; }
     queries_++;
     bool is_end = false;
+    std::string reason, err;
     while (!is_end && running_.load()) {
         std::this_thread::sleep_for(std::chrono::microseconds(500));
         std::vector<int> fresh;
@@ -152,12 +176,12 @@ bool InferFlowServiceCore::ProcessQuery(InferFlowResponseChunk &result, const In
             if (it == query_to_result_.end()) break;
             fresh.swap(it->second.tokens);
             is_end = it->second.is_end;
-            if (is_end) query_to_result_.erase(it);
+            if (is_end) { reason = it->second.reason; err = it->second.err; query_to_result_.erase(it); }
         }
         result.token_ids.insert(result.token_ids.end(), fresh.begin(), fresh.end());
         if (on_chunk && (!fresh.empty() || is_end)) {
             InferFlowResponseChunk chunk;
-            chunk.token_ids = fresh; chunk.is_end = is_end;
+            chunk.token_ids = fresh; chunk.is_end = is_end; chunk.finish_reason = reason;
             chunk.time_cost = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
             if (!(*on_chunk)(chunk)) {      // the client went away: drop the query (reference: engine_.RemoveQuery on a failed WriteChunk)
                 std::lock_guard<std::mutex> eg(engine_lock_);
@@ -174,19 +198,20 @@ bool InferFlowServiceCore::ProcessQuery(InferFlowResponseChunk &result, const In
         std::lock_guard<std::mutex> g(lock_);
         query_to_result_.erase(qid);
     }
-    result.ret_code = "succ";
     result.is_end = is_end;
+    result.finish_reason = reason;
     result.time_cost = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
-    return true;
+    if (!err.empty()) { result.ret_code = err; return false; }
+    result.ret_code = is_end ? "succ" : "error.service_stopped";
+    return is_end;
 }
 
 void InferFlowServiceCore::GetStat(std::string &json) const
 {
-    const ModelSpec &spec = engine_.model_spec();
     std::lock_guard<std::mutex> eg(engine_lock_);
-    json = "{\"version\": \"" + engine_.Version() + "\", \"model\": \"" + spec.sid + "\", \"active_queries\": " + std::to_string(engine_.QueryCount())
+    json = "{\"version\": \"" + engine_.Version() + "\", \"model\": \"" + engine_.ModelId() + "\", \"active_queries\": " + std::to_string(engine_.QueryCount())
         + ", \"served_queries\": " + std::to_string(queries_.load()) + ", \"engine_steps\": " + std::to_string(steps_.load())
-        + ", \"output_tokens\": " + std::to_string(tokens_out_.load()) + ", \"vocab_size\": " + std::to_string(spec.hyper_params.vocab_size) + "}";
+        + ", \"output_tokens\": " + std::to_string(tokens_out_.load()) + ", \"vocab_size\": " + std::to_string(engine_.VocabSize()) + "}";
 }
 
 // ------------------------------------------------------------------ HTTP front
@@ -203,7 +228,7 @@ static bool SendAll(int fd, const std::string &s)
 
 static std::string HttpHeader(int status, const std::string &content_type, long long body_len, bool chunked)
 {
-    std::string h = "HTTP/1.1 " + std::to_string(status) + (status == 200 ? " OK" : status == 400 ? " Bad Request" : status == 404 ? " Not Found" : " Error") + "\r\n";
+    std::string h = "HTTP/1.1 " + std::to_string(status) + (status == 200 ? " OK" : status == 400 ? " Bad Request" : status == 404 ? " Not Found" : status == 503 ? " Service Unavailable" : " Error") + "\r\n";
     h += "Content-Type: " + content_type + "\r\nConnection: close\r\n";
     if (chunked) h += "Transfer-Encoding: chunked\r\n";
     else h += "Content-Length: " + std::to_string(body_len) + "\r\n";
@@ -229,15 +254,28 @@ void InferFlowService::Stop()
 {
     stop_.store(true);
     if (listen_fd_ >= 0) { shutdown(listen_fd_, SHUT_RDWR); close(listen_fd_); listen_fd_ = -1; }
-    core_.Stop();
+    core_.Stop();        // running_ = false: every handler inside ProcessQuery leaves its wait loop and returns its query to the engine
+    // the connection threads are detached but counted: nobody may still be inside HandleConnection (touching core_ / the engine)
+    // when the owner destroys them
+    for (int i = 0; i < 20000 && connections_.load() > 0; i++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
 }
 
 void InferFlowService::Serve()
 {
     while (!stop_.load()) {
+        pollfd pf; pf.fd = listen_fd_; pf.events = POLLIN; pf.revents = 0;
+        const int pr = poll(&pf, 1, 100);            // the stop flag (set by a signal handler) is seen within 100 ms
+        if (pr <= 0) continue;
         const int fd = accept(listen_fd_, nullptr, nullptr);
         if (fd < 0) { if (stop_.load()) break; continue; }
-        std::thread([this, fd] { HandleConnection(fd); close(fd); }).detach();
+        if (connections_.load() >= MAX_CONNECTIONS) {
+            const std::string b = "{\"ret_code\": \"error.busy\"}";
+            SendAll(fd, HttpHeader(503, "application/json", (long long)b.size(), false) + b);
+            close(fd);
+            continue;
+        }
+        connections_++;
+        std::thread([this, fd] { HandleConnection(fd); close(fd); connections_--; }).detach();
     }
 }
 

@@ -44,13 +44,16 @@ struct InferFlowResponseChunk {           // InferFlowResponseChunk
     bool is_end = false;
     float time_cost = 0;
     int prompt_tokens = 0;
+    // why the query ended: "stop" (the request's eos_token_id was produced) | "length" (max_output_len, or the context is full)
+    // | "error" (the engine step failed; ret_code says which).  The OpenAI shape reports it as finish_reason.
+    std::string finish_reason;
     void ToJson(std::string &out) const;
     void ToJsonOpenAI(std::string &out, bool is_chunk, const std::string &id) const;
 };
 
 class InferFlowServiceCore {
 public:
-    explicit InferFlowServiceCore(InferenceEngine &engine) : engine_(engine) {}
+    explicit InferFlowServiceCore(QueryEngine &engine) : engine_(engine) {}
     ~InferFlowServiceCore() { Stop(); }
     void Start();                          // spawns the Infer loop
     void Stop();
@@ -62,9 +65,9 @@ public:
     void GetStat(std::string &json) const;
 
 private:
-    struct QueryResult { std::vector<int> tokens; bool is_end = false; int max_len = 0, eos = -1, produced = 0; };
+    struct QueryResult { std::vector<int> tokens; bool is_end = false; int max_len = 0, eos = -1, produced = 0; std::string reason, err; };
     bool InferOnce();
-    InferenceEngine &engine_;
+    QueryEngine &engine_;
     std::thread loop_;
     std::atomic<bool> running_{false};
     mutable std::mutex engine_lock_;     // the facade's query table is not thread-safe: AddQuery / Infer + Commit / RemoveQuery take turns
@@ -73,19 +76,26 @@ private:
     std::atomic<long long> steps_{0}, tokens_out_{0}, queries_{0};
 };
 
-// Minimal HTTP/1.1 front (one thread per connection, Connection: close; streaming responses use chunked transfer encoding)
+// Minimal HTTP/1.1 front (one thread per connection, at most MAX_CONNECTIONS of them, Connection: close; streaming responses use
+// chunked transfer encoding).  Shutdown: RequestStop() only sets a flag (callable from a signal handler); Serve() polls the
+// listening socket, sees the flag and returns; Stop() -- from the thread that owns the service, never from a handler -- stops the
+// core loop (which releases every handler waiting in ProcessQuery) and waits until the last connection thread has left
+// HandleConnection, so that the engine and the core outlive every user.
 class InferFlowService {
 public:
-    InferFlowService(InferenceEngine &engine) : core_(engine) {}
+    static constexpr int MAX_CONNECTIONS = 256;
+    InferFlowService(QueryEngine &engine) : core_(engine) {}
     ~InferFlowService() { Stop(); }
     bool Start(int port, int *bound_port = nullptr);       // port 0: any free port
+    void RequestStop() { stop_.store(true); }               // async-signal-safe
     void Stop();
-    void Serve();                                           // accept loop (blocks until Stop)
+    void Serve();                                           // accept loop (blocks until RequestStop / Stop)
 private:
     void HandleConnection(int fd);
     InferFlowServiceCore core_;
     int listen_fd_ = -1;
     std::atomic<bool> stop_{false};
+    std::atomic<int> connections_{0};
 };
 
 } // namespace inferflow_amd

@@ -12,7 +12,8 @@
 using namespace inferflow_amd;
 
 static InferFlowService *g_service = nullptr;
-static void on_signal(int) { if (g_service) g_service->Stop(); }
+// the handler only sets a flag (async-signal-safe); Serve() sees it and returns, main() then stops the service in order
+static void on_signal(int) { if (g_service) g_service->RequestStop(); }
 
 int main(int argc, char **argv)
 {
@@ -37,5 +38,7 @@ int main(int argc, char **argv)
     signal(SIGINT, on_signal); signal(SIGTERM, on_signal);
     printf("listening on 127.0.0.1:%d\n", bound); fflush(stdout);
     service.Serve();
+    service.Stop();          // core loop joined, every connection thread out of the service -- before `service` and `engine` are destroyed
+    g_service = nullptr;
     return 0;
 }

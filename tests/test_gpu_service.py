@@ -63,6 +63,19 @@ def test_service_shell_serves_token_id_queries(tmp_path):
         for r in out:
             assert r["ret_code"] == "succ" and len(r["token_ids"]) == 12
         assert sum(r["token_ids"] == want for r in out) >= 3       # (a batched step runs T > 1 kernels: F16 activations may flip a near-tie)
+        # more output than the context holds (prompt 9 + 500 > max_context_len 128): cut at what fits, the handler returns and
+        # the KV slot goes back -- asked maxq + 1 times, so a leaked slot would answer error.busy
+        for _ in range(5):
+            st, data = _post(port, "/", {"prompt_token_ids": prompt, "max_output_len": 500})
+            r = json.loads(data)
+            assert st == 200 and r["ret_code"] == "succ" and r["is_end"] is True and len(r["token_ids"]) == 128 - len(prompt) - 1, r
+            assert r["token_ids"][:12] == want
+        # EOS: the third token of the greedy continuation as eos_token_id ends the query there, finish_reason "stop"
+        eos = want[2]
+        k = want.index(eos) + 1
+        st, data = _post(port, "/v1/chat/completions", {"messages": [{"role": "user", "content_token_ids": prompt}], "max_tokens": 12, "eos_token_id": eos})
+        r = json.loads(data)
+        assert st == 200 and r["choices"][0]["message"]["token_ids"] == want[:k] and r["choices"][0]["finish_reason"] == "stop", r
         # an empty request is refused, the engine keeps serving
         st, data = _post(port, "/", {"prompt_token_ids": []})
         assert st == 400 and json.loads(data)["ret_code"] == "error.empty_request"
@@ -70,7 +83,7 @@ def test_service_shell_serves_token_id_queries(tmp_path):
         c.request("GET", "/stat")
         stat = json.loads(c.getresponse().read().decode())
         c.close()
-        assert stat["active_queries"] == 0 and stat["served_queries"] >= 7 and stat["output_tokens"] >= 7 * 12
+        assert stat["active_queries"] == 0 and stat["served_queries"] >= 13 and stat["output_tokens"] >= 7 * 12
     finally:
         p.terminate()
         p.wait(timeout=20)
