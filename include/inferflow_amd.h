@@ -107,9 +107,22 @@ int ifa_gemv(int w_dtype, const void *W, size_t rows, size_t cols,
  * Every T runs these in-tree kernels: the library neither links nor loads a vendor GEMM. */
 int ifa_gemm(int w_dtype, const void *W, size_t rows, size_t cols, const void *x_f16, size_t tokens,
              const void *bias_f16, void *y_f16, ifa_stream stream);
-/* the large-tile kernel for tokens > 128 (default 1; 0: the smaller-tile kernels serve every T).  Bit-identical results
- * either way.  < 0 only queries; returns the previous setting */
+/* the large-tile kernel for tokens > 128 (default 1; 0: the smaller-tile kernels serve every T).  The tile kernels add the same
+ * products in DIFFERENT orders (and the split-K form of the 128 x 128 tiles adds its two halves of K as first + second): results
+ * agree within the F16 rounding of one product row, they are not bit-identical.  < 0 only queries; returns the previous setting */
 int ifa_gemm_big_tiles(int on);
+
+/* ---- launches that wait for sibling workgroups inside the launch (the fused QKV + attention step, the split-K halves of the
+ * large-tile GEMM, the K parts of the 9..32-row GEMM).  They are chosen only when the whole waiting grid can be resident at once:
+ * occupancy of the kernel x the CUs this process may use (ROC_GLOBAL_CU_MASK / HSA_CU_MASK are read; IFA_VISIBLE_CUS overrides).
+ * Every wait is bounded (0.2 s); one that gives up leaves a code, the synchronising call (ifa_stream_sync, ifa_model_forward /
+ * _decode / _decode_batch) returns IFA_ERR_STATE, and the waiting launches stay off for the rest of the process -- the HIP context
+ * survives, the non-waiting kernels serve from there on.  IFA_NO_INLAUNCH_WAITS=1 (environment) starts the process that way;
+ * per model: ifa_model_set_option "rows_kparts" / "gemm_splitk" / "fuse_attn" = 0.
+ * host-only helpers (no device needed): the residency rule and the CU-mask reader behind that choice. */
+int ifa_wait_grid_decision(int blocks_per_cu, int visible_cus, long long grid);      /* 1: the grid fits */
+int ifa_visible_cus_from_mask(const char *mask_text, int device, int device_cus);    /* CUs the mask leaves for `device` */
+int ifa_inlaunch_waits_enabled(void);
 /* frees the scratch the prefill kernels keep for this stream on the current device (call before destroying a stream that ran
  * long-prompt attention; ifa_model_destroy / ifa_model_set_stream do it for the worker's) */
 int ifa_gemm_release_stream(ifa_stream stream);

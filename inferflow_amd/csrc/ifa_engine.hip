@@ -170,6 +170,8 @@ struct ifa_model {
     // Q8 quantiser are issue-bound on the few resident waves.  persist_mode = what the captured step uses.
     int opt_persist = 0, opt_persist_ctx = 512, opt_persist_timeout_us = 20000, opt_persist_trace = -1, opt_persist_debug = 0, opt_persist_depth = 0, opt_persist_prio = 0;
     int opt_debug_layers = 0;                  // > 0: the decode step runs only the first N layers (both paths; tools/debug_persist.py)
+    int opt_rows_kparts = 1, opt_gemm_splitk = 1;   // 0: never the launches whose workgroups wait for partner workgroups (K parts of the 9..32-row GEMM, split-K halves of the large-tile GEMM)
+    int opt_debug_mo_alloc_fail = 0;           // tests: ensure_mo_build fails like an exhausted allocator after its first copy
     int persist_mode = 0, ps_state = 0;        // ps_state: 0 unknown, 1 usable (copies built), -1 unsupported
     std::string ps_why;
     std::vector<void *> ps_wqkv, ps_w13;       // per layer: wq | wk | wv rows in one buffer; w1 / w3 interleaved row by row
@@ -389,9 +391,12 @@ static bool qkv_attn_layer_ok(const ifa_model *m, int l, int *gk_out)
 static int qkv_attn_ready(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
-    int want = m->opt_fuse_attn && !m->attn_split && !m->persist_mode && dec_attn_smem(c.head_dim, c.max_ctx, 256) <= IFA_LDS_LIMIT;
+    int want = m->opt_fuse_attn && waits_enabled() && !m->attn_split && !m->persist_mode && dec_attn_smem(c.head_dim, c.max_ctx, 256) <= IFA_LDS_LIMIT;
     int gk = 0;
     for (int l = 0; want && l < c.layers; l++) if (!qkv_attn_layer_ok(m, l, &gk)) want = 0;
+    // a head's attention waits for the gk workgroups of its kv group: the grid (kv_heads * gk workgroups of 512 threads at 256
+    // registers, one per CU) must be resident at once on the CUs this process may use (CU mask, partitioned device)
+    if (want && (long long)c.kv_heads * gk > (long long)visible_cus()) want = 0;
     // the Wo rows ride along when every layer's Wo is a plain residual GEMV over the quantised attention output
     int want_wo = want && m->opt_fuse_wo && m->attq && m->opt_attn_q8 && !c.parallel_attn && !c.share_input && !scale_on(c.attn_out_scale);
     for (int l = 0; want_wo && l < c.layers; l++) {
@@ -1781,8 +1786,11 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     // Prompts above 128 tokens take the same four launches per layer from the large-tile GEMM (ifa_gemm.hip, k_gemm_big: the
     // weights dequantised once per workgroup and step into LDS; reference-layout rows), norms as their own launches.
     const bool pf_big = !tp && T > 128 && prefill_big_ok(m);
-    const bool pf_fused = pf_big || (!tp && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
-    if (pf_fused && !pf_big && (rc = ensure_mo(m))) return rc;
+    bool pf_fused = pf_big || (!tp && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
+    if (pf_fused && !pf_big) {
+        if ((rc = ensure_mo(m))) return rc;
+        pf_fused = batch_fused_ok(m, T);          // (ensure_mo may have switched the copies off: ask again, see forward_batch)
+    }
     if (pf_big && (rc = ensure_x32(m))) return rc;
     for (int l = 0; l < c.layers && pf_fused; l++) {
         Layer &L = m->layers[l];
@@ -1795,7 +1803,7 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         };
         Tensor nob;
         GmArgs P;
-        auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = T; P.eps = c.eps; P.act_kind = c.act_kind; P.mo = mo_flag; };
+        auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = T; P.eps = c.eps; P.act_kind = c.act_kind; P.mo = mo_flag; P.no_waits = pf_big ? !m->opt_gemm_splitk : !m->opt_rows_kparts; };
         clear();
         if (!norm_fused && (rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], pf_big ? L.t[T_ATTN_NORM_B] : nob, m->xn, c.attn_norm_base))) return rc;
         P.W[0] = wp(T_WQ); P.W[1] = wp(T_WK); P.W[2] = wp(T_WV);
@@ -1965,6 +1973,7 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     }
     const auto host_t1 = std::chrono::steady_clock::now();
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = wait_err_check("forward step"))) { drop_graphs(m); return rc; }      // (a split-K / K-parts wait gave up: the step is not valid; those launches are off now)
     if (trace_host)      // how much of a step is the host enqueuing (launch-bound) vs the GPU draining what was enqueued
         fprintf(stderr, "forward T=%d: enqueue %.3f ms, total %.3f ms\n", T, std::chrono::duration<double, std::milli>(host_t1 - host_t0).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());
@@ -2026,6 +2035,7 @@ static int ensure_mo_build(ifa_model *m);
 static int ensure_mo(ifa_model *m)
 {
     if (!m->opt_rows_mo) return IFA_OK;
+    // (option "debug_mo_alloc_fail": the build reports an allocation failure after its first copy -- the tests' way to walk the downgrade)
     const int rc = ensure_mo_build(m);
     if (rc == IFA_OK) return IFA_OK;
     (void)hipGetLastError();
@@ -2050,6 +2060,7 @@ static int ensure_mo_build(ifa_model *m)
             Tensor &t = L.t[id];
             if (moe && (id == T_W1 || id == T_W3 || id == T_W2)) continue;
             if (t.mo || !t.present() || !t.tiled || !rows_mo_fmt(t.dtype) || t.cols % 128 != 0) continue;
+            if (m->opt_debug_mo_alloc_fail && built) return ifa_fail(IFA_ERR_HIP, "hipMalloc: out of memory (simulated: debug_mo_alloc_fail)");
             IFA_HIP_CHECK(hipMalloc(&t.mo, gemm_rows_mo_bytes(t.rows, t.cols)));
             int rc = gemm_rows_mo_build(t.dtype, t.tiled, t.rows, t.cols, t.mo, m->stream);
             if (rc) return rc;
@@ -2163,7 +2174,7 @@ static int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
     int rc;
     GmArgs P;
-    auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = n; P.eps = c.eps; P.act_kind = c.act_kind; };
+    auto clear = [&]() { memset(&P, 0, sizeof(P)); P.T = n; P.eps = c.eps; P.act_kind = c.act_kind; P.no_waits = !m->opt_rows_kparts; };
     // 1. RmsNorm -> wq | wk | wv  (one virtual row space, one [n][q | k | v] output)
     clear();
     P.W[0] = rows_w(m, L.t[T_WQ]); P.W[1] = rows_w(m, L.t[T_WK]); P.W[2] = rows_w(m, L.t[T_WV]); P.mo = rows_mo(m, L.t[T_WQ]);
@@ -2285,8 +2296,15 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
     for (const Layer &Lc : m->layers) has_moe = has_moe || (c.experts > 0 && Lc.t[T_MOE_GATE].present());
     // (measured on Llama-2-7B Q4: the batched step is bound by the small-T GEMM kernels, ~6.7 ms with or without the
     //  graph, so replay is opt-in: set_option("batch_graph", 1))
-    const bool fused = batch_fused_ok(m, n);          // five launches per layer: launch-bound without a graph, so it is replayed
-    if (fused) { int rcm = ensure_mo(m); if (rcm) return rcm; if ((rcm = gemm_rows_kparts_reserve(m->stream))) return rcm; }
+    bool fused = batch_fused_ok(m, n);          // five launches per layer: launch-bound without a graph, so it is replayed
+    if (fused) {
+        int rcm = ensure_mo(m); if (rcm) return rcm;
+        // ensure_mo may have DOWNGRADED the model (the copies did not fit: opt_rows_mo = 0): what batch_fused_ok answered with the
+        // copies in view -- up to 32 rows, the 64-weight formats -- no longer holds, so it is asked again before a path or a graph
+        // is chosen; a step the tiled kernels do not cover takes the op-by-op rows below
+        fused = batch_fused_ok(m, n);
+        if (fused && (rcm = gemm_rows_kparts_reserve(m->stream))) return rcm;
+    }
     if (has_moe && m->opt_moe_overlap) { int rcs = ensure_side_stream(m); if (rcs) return rcs; }
     // (MoE layers of the fused step route on the device -- no host round trip -- so they are captured too)
     const bool use_graph = (m->opt_batch_graph || fused) && m->opt_graph && (!has_moe || fused) && !logits_out && !tp;
@@ -2296,6 +2314,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         if (it != m->batch_graphs.end()) {
             IFA_HIP_CHECK(hipGraphLaunch(it->second, m->stream));
             IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+            if ((rc = wait_err_check("batched decode step"))) { drop_graphs(m); return rc; }      // (the captured steps hold K-parts launches: re-captured without them)
             if (next_tokens) for (int r = 0; r < n; r++) next_tokens[r] = m->host_pinned[8 + r];
             return IFA_OK;
         }
@@ -2416,6 +2435,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
         IFA_HIP_CHECK(hipGraphLaunch(ex, m->stream));
     } else if (rc) return rc;
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = wait_err_check("batched decode step"))) { drop_graphs(m); return rc; }
     if (next_tokens) for (int r = 0; r < n; r++) next_tokens[r] = m->host_pinned[8 + r];
     return IFA_OK;
 }
@@ -2713,7 +2733,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
@@ -2877,8 +2897,13 @@ static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps
         (void)hipMemsetAsync(m->qa_err, 0, 16, s);
         (void)hipStreamSynchronize(s);
         if (elapsed_ms) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+        // the waiting launches go off for this model (and, process-wide, for every model created later): the next call captures the
+        // five-launch step, whose kernels wait for nothing
+        m->opt_fuse_attn = 0; m->opt_fuse_wo = 0; m->opt_fuse_wo_ffn = 0;
+        drop_graphs(m);
+        waits_disable("the fused QKV + attention launch timed out waiting for sibling workgroups");
         return ifa_fail(IFA_ERR_STATE, "fused decode launch: a wait for another workgroup's rows timed out (code 0x%x: 0x5_ q | k | v / attention output, 0x6_ Wo output); "
-                        "set options fuse_attn=0 fuse_wo_ffn=0 to use the five-launch step", (unsigned)qerr[0]);
+                        "the results of this call are not valid -- repeat it: options fuse_attn / fuse_wo / fuse_wo_ffn are off now (five-launch step)", (unsigned)qerr[0]);
     }
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     if (perr[0] != 0) {      // a wait inside the persistent launch gave up: the step's results are not valid

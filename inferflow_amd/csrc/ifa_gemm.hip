@@ -370,7 +370,7 @@ typedef const __attribute__((address_space(1))) void pf_glb_t;
 // fp32 accumulators go through memory (write-through stores, one flag per tile) to the workgroup of the second half, which adds them
 // IN THAT ORDER (first half + second half: deterministic) and runs the epilogue.  The grid lists all first halves, then all second
 // halves: a second half is never resident before its first half.  part / flags: per-stream scratch of the launcher.
-struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; unsigned long long *part; unsigned *flags; };
+struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; unsigned long long *part; unsigned *flags; unsigned *err; };
 
 template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN, int BK = PF_BK, int KS = 1>
 __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const BigGeo G)
@@ -571,7 +571,10 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
             const long long t_wait = wall_clock64();
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(KS - 1)) {
                 __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t_wait > 500000000ll) __builtin_trap();        // (5 s without the other parts' sums: abort the launch -- the next HIP call fails loudly -- rather than add garbage)
+                if (wall_clock64() - t_wait > WAIT_TIMEOUT_TICKS) {      // the first halves are not resident: leave a code and go on (garbage sums; the host fails the
+                    if (G.err) __hip_atomic_store(G.err, 0x81u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // call and switches the waiting launches off)
+                    break;
+                }
             }
         }
         __syncthreads();
@@ -726,8 +729,9 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         G.tile0[0] = 0;
         for (int i = 0; i < 3; i++) G.tile0[i + 1] = G.tile0[i] + (i < P.nsets ? (int)ifa_cdiv((size_t)P.rows[i], (size_t)BNE) : 0);
         for (int i = P.nsets; i < 3; i++) G.tile0[i] = 1 << 30;        // (absent sets are never selected)
-        G.tiles_m = (int)ifa_cdiv(T, (size_t)BM); G.K = P.nblk * CAP; G.tn0 = tn0; G.part = nullptr; G.flags = nullptr;
+        G.tiles_m = (int)ifa_cdiv(T, (size_t)BM); G.K = P.nblk * CAP; G.tn0 = tn0; G.part = nullptr; G.flags = nullptr; G.err = nullptr;
         if constexpr (KS > 1) {
+            G.err = wait_err_word();
             const size_t tiles = (size_t)G.tiles_m * tn_count, part_bytes = tiles * (size_t)(KS - 1) * BM * BN * 4;
             void *scratch = nullptr;
             int rcs = gemm_splitk_scratch(s, part_bytes, tiles, &scratch);
@@ -745,6 +749,9 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             attr_set.fetch_or(bit, std::memory_order_relaxed);
+        }
+        if constexpr (KS > 1) {      // the second halves wait for the first halves: the whole grid must be resident at once (1: not launched)
+            if (!wait_grid_fits((const void *)kern, WM * WN * 64, smem, (long long)G.tiles_m * tn_count * KS)) return 1;
         }
         kern<<<dim3((unsigned)(G.tiles_m * tn_count * KS)), dim3(WM * WN * 64), smem, s>>>(P, G);
         return IFA_OK;
@@ -778,10 +785,11 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         // big enough to matter (>= half the chip), never when a tile shape is forced (measurement / the bit-identity tests).
         // Llama-2-7B prefill: 1024 tokens 51.4K -> 54.2K tok/s, 768: 40.4K -> 44.2K, 512: 35.1K -> 42.4K.  (256 x 256 tiles split four
         // ways -- the efficient tile shape, one part per CU -- measured no better: 53.2K at 1024 tokens, three partial tiles through memory.)
-        const bool splitk = !force && EPI != GM_GLU && (g_gemm_big & (1 << 12)) == 0 && n128 <= cus && n128 * 2 >= cus && (P.nblk * CAP / PF_BK) % 2 == 0 && P.nblk * CAP >= 2048;
+        const bool splitk = !force && EPI != GM_GLU && (g_gemm_big & (1 << 12)) == 0 && !P.no_waits && waits_enabled() && n128 <= cus && n128 * 2 >= cus && (P.nblk * CAP / PF_BK) % 2 == 0 && P.nblk * CAP >= 2048;
         if constexpr (EPI != GM_GLU) {
+            rc = 1;
             if (splitk) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), integral_constant<int, 2>());
-            else rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());
+            if (rc == 1) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());      // (no split, or its grid cannot be resident at once)
         } else rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());      // (K steps of 128 columns -- BK = 128 -- measured: 57 -> 72 us at 1024 x 4096 x 4096)
     }
     if (rc) return rc;

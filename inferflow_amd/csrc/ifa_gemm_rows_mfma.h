@@ -36,6 +36,11 @@ struct GmArgs {
     // its own part from LDS, the others' granules polled, added in K order.  Filled by the launcher; 0 = off.
     int kparts;
     unsigned long long *kpart_sums;
+    // in-launch waits (ifa_host.h): the device's wait-error word (filled by the launchers that wait: K parts here, the split-K
+    // halves of k_gemm_big), and the caller's veto -- no_waits != 0: never pick a launch that waits (model options rows_kparts /
+    // gemm_splitk = 0)
+    unsigned *wait_err;
+    int no_waits;
 };
 
 // MO layout ("MFMA operand order") of a matrix [rows][cols] of 4-bit codes with value q * scale + base, cols % 128 == 0: per tile of 16 rows

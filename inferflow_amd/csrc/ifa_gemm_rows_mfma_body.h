@@ -561,7 +561,10 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
                         for (int z = 0; z < 7; z++) if (z < kparts - 1) all = all && (u[nt][j][z] >> 32) == 1ull;
                     }
                 if (__builtin_amdgcn_ballot_w64(!all) == 0ull) break;           // (per wave: every lane's granules are in)
-                if (wall_clock64() - t_wait > 500000000ll) __builtin_trap();     // (5 s: abort the launch rather than add garbage)
+                if (wall_clock64() - t_wait > WAIT_TIMEOUT_TICKS) {              // the partners are not resident: leave a code and go on (the host fails the call
+                    if (P.wait_err && (tid & 63) == 0) __hip_atomic_store(P.wait_err, 0x71u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // and switches the waiting launches off)
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll

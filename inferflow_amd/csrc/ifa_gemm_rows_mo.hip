@@ -60,8 +60,10 @@ void rows_kparts_release(int dev, hipStream_t s)
 template <int MT, int KPM>
 static int mo_launch_kparts(int wgs, size_t smem, const GmArgs &P, int epi, hipStream_t s)
 {
+    // returns 1 (nothing launched) when the grid cannot be resident at once: the caller takes the launch without K parts
 #define IFA_KP(TXV, EPIV) { auto kern = k_gemm_rows_mfma<MT, TXV, EPIV, 0, true, 0, KPM>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        if (!wait_grid_fits((const void *)kern, GM_THREADS, smem, wgs)) return 1; \
         kern<<<dim3((unsigned)wgs), dim3(GM_THREADS), smem, s>>>(P); }
     if (P.T <= 16) { if (epi == GM_PLAIN) IFA_KP(16, GM_PLAIN) else IFA_KP(16, GM_RESIDUAL) }
     else { if (epi == GM_PLAIN) IFA_KP(32, GM_PLAIN) else IFA_KP(32, GM_RESIDUAL) }
@@ -154,7 +156,7 @@ int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, h
     // tiles: at 32 queries w2 (256 tiles, K = 11008: six 2048-column chunks) moved 180 MB of activations L2 -> LDS for 25 MB of
     // weights and ran at the L2's ~10 TB/s (21 us, rows-trace).  With kparts = the chunk count a workgroup takes ONE chunk of kparts
     // times as many tiles (rows staged once: 33 MB in all) and finishes its share of them (reduce-scatter of the fp32 tile sums).
-    if (!one && norm == 0 && (epi == GM_PLAIN || epi == GM_RESIDUAL) && P.T >= 9 && !g_rows_kparts_off && (maxt == 1 || maxt == 2)) {
+    if (!one && norm == 0 && (epi == GM_PLAIN || epi == GM_RESIDUAL) && P.T >= 9 && !g_rows_kparts_off && !P.no_waits && waits_enabled() && (maxt == 1 || maxt == 2)) {
         const int chunk_sup = P.T <= 16 ? 32 : 16, nsup = P.nblk / 4, nchunk = (nsup + chunk_sup - 1) / chunk_sup;
         int kparts = 0;
         // (every workgroup of a group must be resident at once -- the finishers poll their group's other parts: a workgroup that
@@ -162,7 +164,7 @@ int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, h
         const int ntiles_all = (P.total_rows + 15) / 16;
         for (int d = std::min(nchunk, 8 / maxt); d >= 2 && nchunk >= KPARTS_MIN_CHUNKS; d--) {
             if (nchunk % d != 0 || maxt * d == 5 || maxt * d == 7) continue;
-            if ((ntiles_all + maxt * d - 1) / (maxt * d) * d > dec_num_cus_rows()) continue;
+            if ((ntiles_all + maxt * d - 1) / (maxt * d) * d > std::min(dec_num_cus_rows(), visible_cus())) continue;
             kparts = d; break;
         }
         if (kparts >= 2) {
@@ -172,22 +174,24 @@ int gemm_rows_mo_launch(const GmArgs &P, int epi, int norm, int wgs, int maxt, h
             void *scratch = nullptr;
             int rc = rows_kparts_scratch(s, (size_t)groups * maxt_k * kparts * NTc * 256 * 8, &scratch);
             if (rc) return rc;
-            Q.kparts = kparts; Q.kpart_sums = (unsigned long long *)scratch;
+            Q.kparts = kparts; Q.kpart_sums = (unsigned long long *)scratch; Q.wait_err = wait_err_word();
             const size_t smem_k = gm_smem(P.T, maxt_k, 1);
             const int wgs_k = groups * kparts;
+            int rk = 1;        // 1: not launched (no instance for this shape, or the grid cannot be resident at once) -> the plain launch below
             if (maxt == 1) switch (maxt_k) {
-                case 2: return mo_launch_kparts<2, 1>(wgs_k, smem_k, Q, epi, s);
-                case 3: return mo_launch_kparts<3, 1>(wgs_k, smem_k, Q, epi, s);
-                case 4: return mo_launch_kparts<4, 1>(wgs_k, smem_k, Q, epi, s);
-                case 6: return mo_launch_kparts<6, 1>(wgs_k, smem_k, Q, epi, s);
-                case 8: return mo_launch_kparts<8, 1>(wgs_k, smem_k, Q, epi, s);
+                case 2: rk = mo_launch_kparts<2, 1>(wgs_k, smem_k, Q, epi, s); break;
+                case 3: rk = mo_launch_kparts<3, 1>(wgs_k, smem_k, Q, epi, s); break;
+                case 4: rk = mo_launch_kparts<4, 1>(wgs_k, smem_k, Q, epi, s); break;
+                case 6: rk = mo_launch_kparts<6, 1>(wgs_k, smem_k, Q, epi, s); break;
+                case 8: rk = mo_launch_kparts<8, 1>(wgs_k, smem_k, Q, epi, s); break;
                 default: break;
             } else switch (maxt_k) {
-                case 4: return mo_launch_kparts<4, 2>(wgs_k, smem_k, Q, epi, s);
-                case 6: return mo_launch_kparts<6, 2>(wgs_k, smem_k, Q, epi, s);
-                case 8: return mo_launch_kparts<8, 2>(wgs_k, smem_k, Q, epi, s);
+                case 4: rk = mo_launch_kparts<4, 2>(wgs_k, smem_k, Q, epi, s); break;
+                case 6: rk = mo_launch_kparts<6, 2>(wgs_k, smem_k, Q, epi, s); break;
+                case 8: rk = mo_launch_kparts<8, 2>(wgs_k, smem_k, Q, epi, s); break;
                 default: break;
             }
+            if (rk != 1) return rk;
         }
     }
     const size_t smem = gm_smem(P.T, maxt, 1);
