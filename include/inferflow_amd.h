@@ -411,6 +411,8 @@ int ifa_model_tp_decode_batch(ifa_model *m, const ifa_tp_topology *topo, int n, 
                               const int *kv_slots_host, int *next_tokens_host, void *logits_shard_out_dev);
 /* reference-layout copy of a loaded tensor (device pointer); returns 1 if the tensor is not set */
 int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols);
+/* the same for W1 / W2 / W3 of expert `expert` of a mixture-of-experts layer */
+int ifa_model_get_expert_tensor(ifa_model *m, int layer, int expert, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols);
 /* Average duration (HIP events on the worker's stream) of `iters` back-to-back
  * launches of one fused decode kernel, rotating over the layers' weights:
  * which = 0 qkv, 1 attention, 2 wo, 3 ffn w1/w3, 4 w2, 5 lm_head.  For bench.py's roofline. */

@@ -72,6 +72,12 @@ double ifa_perplexity_token_nll(const uint16_t *logits_f16, int vocab, int token
  * (workers of the multi-GPU partition; 1 = single device); -1 if unknown */
 int ifa_engine_model_info(ifa_engine *e, const char *key);
 
+/* the per-device worker of partition rank `rank` (an ifa_model * for the ifa_model_* calls of inferflow_amd.h; rank 0 of a
+ * single-device engine) and its place in the partition {stage, n_stages, tp_rank, tp_size, layer0, layer1}: the counterpart of
+ * reaching a GpuInferenceWorker through InferenceEngine (src/transformer/inference_engine.cc:1916-1984).  NULL / -1: no such rank. */
+void *ifa_engine_worker(ifa_engine *e, int rank);
+int ifa_engine_worker_plan(ifa_engine *e, int rank, int *out6);
+
 /* host-only: the partition rules the engine applies to "devices = 0&1;2&3" (BY_TENSOR slices of
  * network_builder.cc:1594-1686 / device_tensor_builder.cu:203-239, layer ranges of NetworkBuilder::SplitGpuLayers
  * :2094-2118).  slice: 1 + {row0, row1, col0, col1, local layer} of tensor (layer, tensor_id) [rows][cols] for the worker

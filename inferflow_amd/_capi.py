@@ -143,6 +143,7 @@ SIGNATURES = {
     "ifa_model_tp_prefill": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ifa_model_tp_decode_batch": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ifa_model_get_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
+    "ifa_model_get_expert_tensor": (_i, [_vp, _i, _i, _i, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
 }
 
 
@@ -167,6 +168,8 @@ ENGINE_SIGNATURES = {
     "ifa_engine_perplexity": (_i, [_vp, _ip, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ifa_perplexity_token_nll": (C.c_double, [_vp, _i, _i]),
     "ifa_engine_model_info": (_i, [_vp, C.c_char_p]),
+    "ifa_engine_worker": (_vp, [_vp, _i]),
+    "ifa_engine_worker_plan": (_i, [_vp, _i, _ip]),
     "ifa_service_parse_request": (_i, [C.c_char_p, _i, C.c_char_p, _sz]),
     "ifa_service_format_response": (_i, [_ip, _i, _i, _i, _i, _i, C.c_char_p, _sz]),
     "ifa_service_selftest_loop": (_i, [_i, _i, _i, _ip, _i, _i, _i, _i, _i, C.c_char_p, _sz]),

@@ -170,6 +170,10 @@ struct ifa_model {
     // Q8 quantiser are issue-bound on the few resident waves.  persist_mode = what the captured step uses.
     int opt_persist = 0, opt_persist_ctx = 512, opt_persist_timeout_us = 20000, opt_persist_trace = -1, opt_persist_debug = 0, opt_persist_depth = 0, opt_persist_prio = 0;
     int opt_debug_layers = 0;                  // > 0: the decode step runs only the first N layers (both paths; tools/debug_persist.py)
+    // layer-wise parity tests (tests/test_gpu_layerwise_oracle.py): the fused decode step starts at layer debug_layer0 (with
+    // debug_layers = N: layers [layer0, layer0 + N)) and, with debug_hidden_in, takes its input from the buffer "x" as the caller
+    // left it instead of gathering the token's embedding row -- the SAME captured launches the bench times, fed the oracle's state
+    int opt_debug_layer0 = 0, opt_debug_hidden_in = 0;
     int opt_rows_kparts = 1, opt_gemm_splitk = 1;   // 0: never the launches whose workgroups wait for partner workgroups (K parts of the 9..32-row GEMM, split-K halves of the large-tile GEMM)
     int opt_debug_mo_alloc_fail = 0;           // tests: ensure_mo_build fails like an exhausted allocator after its first copy
     int persist_mode = 0, ps_state = 0;        // ps_state: 0 unknown, 1 usable (copies built), -1 unsupported
@@ -817,7 +821,8 @@ static int launch_lm_tail(ifa_model *m, const half_t *x)
 static int launch_gather(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
-    k_dec_gather<<<dim3(2), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows, m->x,
+    // (debug_hidden_in: the layer input is what the caller stored in "x"; only the step's RoPE table is built)
+    k_dec_gather<<<dim3(2), dim3(256), 0, m->stream>>>(m->opt_debug_hidden_in ? nullptr : (const half_t *)m->g[T_EMBD].data, m->state, c.dim, (int)m->g[T_EMBD].rows, m->x,
                                                        c.rope_order ? m->rope_tab : nullptr, c.head_dim, c.rope_theta,
                                                        (int)(c.head_dim * c.partial_rotary + 0.5f), c.embd_scale);
     IFA_LAUNCH_CHECK();
@@ -1259,7 +1264,8 @@ static int enqueue_fused_step(ifa_model *m)
     // st_on: the previous step's last launch (or ifa_model_decode, for a call's first step) has gathered this step's input
     if (!m->st_on && (rc = launch_gather(m))) return rc;
     half_t *x = m->x, *xnext = m->x2;
-    const int n_layers = (m->opt_debug_layers > 0 && m->opt_debug_layers < c.layers) ? m->opt_debug_layers : c.layers;
+    const int l_first = std::min(std::max(m->opt_debug_layer0, 0), c.layers - 1);
+    const int n_layers = (m->opt_debug_layers > 0 && l_first + m->opt_debug_layers < c.layers) ? l_first + m->opt_debug_layers : c.layers;
     if (m->persist_mode) {
         if ((rc = launch_persist(m, 0, n_layers, x, xnext))) return rc;
         if (m->st_on) return launch_lm_tail(m, xnext);
@@ -1268,7 +1274,7 @@ static int enqueue_fused_step(ifa_model *m)
         IFA_LAUNCH_CHECK();
         return IFA_OK;
     }
-    for (int l = 0; l < n_layers; l++) {
+    for (int l = l_first; l < n_layers; l++) {
         if (m->qa_on) {
             if ((rc = launch_qkv_attn(m, l, x))) return rc;
         } else {
@@ -2735,7 +2741,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
         {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
-        {"debug_layers", &m->opt_debug_layers}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
+        {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
@@ -3397,6 +3403,21 @@ int ifa_model_get_tensor(ifa_model *m, int layer, int tensor_id, int *dtype, voi
     if (rows) *rows = t->rows;
     if (cols) *cols = t->cols;
     return t->present() ? IFA_OK : 1;   /* 1 = tensor not set (not an error) */
+}
+
+// W1 / W2 / W3 of one expert of a mixture-of-experts layer (the layer's own tensor ids name the dense FFN)
+int ifa_model_get_expert_tensor(ifa_model *m, int layer, int expert, int tensor_id, int *dtype, void **dptr, size_t *rows, size_t *cols)
+{
+    IFA_REQUIRE(m && layer >= 0 && layer < m->cfg.layers, "ifa_model_get_expert_tensor: layer %d", layer);
+    IFA_REQUIRE(tensor_id == T_W1 || tensor_id == T_W2 || tensor_id == T_W3, "ifa_model_get_expert_tensor: tensor id %d (w1 / w2 / w3 only)", tensor_id);
+    const Layer &L = m->layers[(size_t)layer];
+    IFA_REQUIRE(expert >= 0 && (size_t)expert * 3 + 2 < L.experts.size(), "ifa_model_get_expert_tensor: expert %d of layer %d", expert, layer);
+    const Tensor &t = L.experts[(size_t)expert * 3 + (tensor_id == T_W1 ? 0 : (tensor_id == T_W2 ? 1 : 2))];
+    if (dtype) *dtype = t.dtype;
+    if (dptr) *dptr = t.data;
+    if (rows) *rows = t.rows;
+    if (cols) *cols = t.cols;
+    return t.present() ? IFA_OK : 1;
 }
 
 int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)

@@ -108,6 +108,34 @@ class InferenceEngine:
     def model_info(self, key):
         return _capi.lib().ifa_engine_model_info(self._h, key.encode())
 
+    def worker_plan(self, rank):
+        """{stage, n_stages, tp_rank, tp_size, layer0, layer1} of partition rank `rank` (None: no such rank)"""
+        out = (C.c_int * 6)()
+        if _capi.lib().ifa_engine_worker_plan(self._h, int(rank), out) != 0:
+            return None
+        return dict(zip(("stage", "n_stages", "tp_rank", "tp_size", "layer0", "layer1"), [int(v) for v in out]))
+
+    def worker_tensor(self, rank, layer, tid, expert=-1):
+        """(dtype, uint8 host copy, rows, cols) of the slice of tensor (layer local to the rank, tid) rank `rank` holds -- reference
+        layout bytes -- or None.  Test surface: the ranks' slices put together are the model the oracle is given."""
+        from . import dtypes as dt
+        L = _capi.lib()
+        h = L.ifa_engine_worker(self._h, int(rank))
+        if not h:
+            return None
+        d, p, r, c = C.c_int(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+        if expert >= 0:
+            rc = L.ifa_model_get_expert_tensor(C.c_void_p(h), layer, expert, tid, C.byref(d), C.byref(p), C.byref(r), C.byref(c))
+        else:
+            rc = L.ifa_model_get_tensor(C.c_void_p(h), layer, tid, C.byref(d), C.byref(p), C.byref(r), C.byref(c))
+        if rc != 0:
+            return None
+        nbytes = r.value * dt.row_bytes(d.value, c.value)
+        out = np.empty(nbytes, np.uint8)
+        _capi.check(L.ifa_memcpy_d2h(out.ctypes.data_as(C.c_void_p), p, nbytes, None))
+        _capi.check(L.ifa_stream_sync(None))
+        return d.value, out, r.value, c.value
+
 
 def sampling_choose(logits_f16, strategy_id, max_k=8, top_p=0.9, pool_size=50, temperature=1.0, seed=1, n_draws=1):
     """Host-only StdSamplingStrategy::ChooseTokens on one F16 logits row: (drawn ids, their probabilities, pool ids, pool probs)."""

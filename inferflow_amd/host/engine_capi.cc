@@ -190,6 +190,11 @@ int ifa_engine_model_info(ifa_engine *e, const char *key)
     return -1;
 }
 
+// the worker (ifa_model *, for the ifa_model_* calls of include/inferflow_amd.h) of partition rank `rank` and its plan
+// {stage, n_stages, tp_rank, tp_size, layer0, layer1}; null / -1 for a rank that does not exist
+void *ifa_engine_worker(ifa_engine *e, int rank) { return e ? (void *)e->engine.worker(rank) : nullptr; }
+int ifa_engine_worker_plan(ifa_engine *e, int rank, int *out6) { return e && out6 && e->engine.WorkerPlanOf(rank, out6) ? 0 : -1; }
+
 // host-only: the partition rules of the multi-GPU engine (model_loader.cc) for tests and tools
 int ifa_partition_slice(int stage, int n_stages, int tp_rank, int tp_size, int layer0, int layer1, int layer, int tensor_id,
                         size_t rows, size_t cols, size_t *out5)

@@ -447,6 +447,23 @@ int InferenceEngine::AddQuery(const std::vector<int> &tokens, const QueryOptions
 
 int InferenceEngine::QueryCount() const { return (int)queries_.size(); }
 int InferenceEngine::PartitionRanks() const { return multi_ ? (int)multi_->plans.size() : 1; }
+ifa_model *InferenceEngine::worker(int rank)
+{
+    if (!multi_) return rank == 0 ? model_ : nullptr;
+    return rank >= 0 && rank < (int)multi_->plans.size() ? multi_->plans[(size_t)rank].model : nullptr;
+}
+bool InferenceEngine::WorkerPlanOf(int rank, int out6[6]) const
+{
+    if (!multi_) {
+        if (rank != 0) return false;
+        out6[0] = 0; out6[1] = 1; out6[2] = 0; out6[3] = 1; out6[4] = 0; out6[5] = spec_.hyper_params.decoder_layers;
+        return true;
+    }
+    if (rank < 0 || rank >= (int)multi_->plans.size()) return false;
+    const WorkerPlan &w = multi_->plans[(size_t)rank];
+    out6[0] = w.stage; out6[1] = w.n_stages; out6[2] = w.tp_rank; out6[3] = w.tp_size; out6[4] = w.layer0; out6[5] = w.layer1;
+    return true;
+}
 
 SamplingStrategyId InferenceEngine::GetSamplingStrategyId(const std::string &str) const
 {

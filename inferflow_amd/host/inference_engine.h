@@ -173,6 +173,10 @@ public:
     int default_device_id() const { return device_; }
     int PartitionRanks() const;     // workers of the multi-GPU partition (1: single device)
     ifa_model *worker() { return model_; }
+    // worker of partition rank r and its place in the partition (stage, n_stages, tp_rank, tp_size, layer0, layer1); rank 0 of a
+    // single-device engine is worker().  The tests read the ranks' weight slices back and rebuild the whole model for the oracle.
+    ifa_model *worker(int rank);
+    bool WorkerPlanOf(int rank, int out6[6]) const;
 
 private:
     struct Query {

@@ -52,8 +52,12 @@ def gen_f16(shape, seed, std=0.02, device="cuda"):
 
 
 def build(shape_name, wdtype=dt.Q4_B32T1A, kv_dtype=dt.F16, max_ctx=1024, quant_threshold=TENSOR_QUANT_THRESHOLD,
-          std=0.02, keep_host=False, device=0, **overrides):
-    """Returns (worker, host_tensors or None).  host_tensors: {(layer, tid): (dtype, np array, rows, cols)}."""
+          std=0.02, keep_host=False, device=0, embd_std=None, tied_lm_head=None, **overrides):
+    """Returns (worker, host_tensors or None).  host_tensors: {(layer, tid): (dtype, np array, rows, cols)}.
+    embd_std / tied_lm_head = (permutation seed, scale): the "peaky" model of the free-running parity test -- embedding rows of std
+    embd_std (the token's own row then carries through the residual stream) and lm_head[v] = scale * embedding[perm[v]]: the logit
+    of the one row aligned with the current token's embedding stands several logit-std above the rest, so greedy ids are well
+    separated although every layer is random (next token = perm^-1(current): a walk along a cycle of the permutation)."""
     s = dict(SHAPES[shape_name])
     s.update({k: v for k, v in overrides.items() if k in s})
     extra = {k: v for k, v in overrides.items() if k not in s}
@@ -68,9 +72,16 @@ def build(shape_name, wdtype=dt.Q4_B32T1A, kv_dtype=dt.F16, max_ctx=1024, quant_
             key = (layer, tid) if expert < 0 else (layer, tid, expert)
             host[key] = (target, t16.cpu().view(torch.int16).numpy().view("float16").copy(), rows, cols)
 
-    put(-1, W.T_EMBD, dt.F16, gen_f16((s["vocab"], s["dim"]), 999, std, dev))
+    embd = gen_f16((s["vocab"], s["dim"]), 999, std if embd_std is None else embd_std, dev)
+    put(-1, W.T_EMBD, dt.F16, embd)
     put(-1, W.T_OUT_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
-    put(-1, W.T_LM_HEAD, dt.F16, gen_f16((s["vocab"], s["dim"]), 998, std, dev))
+    if tied_lm_head is None:
+        put(-1, W.T_LM_HEAD, dt.F16, gen_f16((s["vocab"], s["dim"]), 998, std, dev))
+    else:
+        pg = torch.Generator(device="cpu"); pg.manual_seed(int(tied_lm_head[0]))
+        perm = torch.randperm(s["vocab"], generator=pg).to(dev)
+        put(-1, W.T_LM_HEAD, dt.F16, (embd[perm].float() * float(tied_lm_head[1])).half())
+    del embd
     for layer in range(s["layers"]):
         put(layer, W.T_ATTN_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))
         put(layer, W.T_FFN_NORM, dt.F16, torch.ones(s["dim"], dtype=torch.float16, device=dev))

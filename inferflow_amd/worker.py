@@ -169,6 +169,14 @@ class DecodeWorker:
         check(lib().ifa_stream_sync(None))
         return out
 
+    def write_buffer(self, name, data, layer=0, offset=0):
+        """host bytes -> a worker buffer (debug surface of the layer-wise parity tests: the layer input "x", K / V cache rows)"""
+        a = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        p, n = self.buffer(name, layer)
+        assert offset + a.size <= n, (name, offset, a.size, n)
+        check(lib().ifa_memcpy_h2d(C.c_void_p(p + offset), a.ctypes.data_as(C.c_void_p), a.size, None))
+        check(lib().ifa_stream_sync(None))
+
     def close(self):
         if self._h:
             lib().ifa_model_destroy(self._h)

@@ -150,6 +150,9 @@ int orc_model_forward(orc_model *m, const int *tokens, int n_tokens, int prefix_
                       orc_f16 *logits_out, int nthreads);
 /* debugging tap: copy of the last hidden state after final norm, F16[dim] */
 const orc_f16 *orc_model_last_hidden(const orc_model *m);
+/* test hooks: per-layer inputs of the last row ([layers + 1][dim], caller-owned buffer; NULL: off) and a layer's K / V cache */
+void orc_model_set_capture(orc_model *m, orc_f16 *buf);
+void *orc_model_kv_cache(orc_model *m, int layer, int is_v);
 
 #ifdef __cplusplus
 }

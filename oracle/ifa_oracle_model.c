@@ -40,6 +40,7 @@ struct orc_model {
     orc_tensor g[ORC_MAX_TENSOR_ID];
     orc_layer *layers;
     orc_f16 *last_hidden;
+    orc_f16 *capture;    /* optional (orc_model_set_capture): [layers + 1][dim] */
 };
 
 static int is_quant(int dtype) { return dtype != ORC_F16 && dtype != ORC_F32; }
@@ -111,6 +112,16 @@ void orc_model_reset(orc_model *m)
 }
 
 const orc_f16 *orc_model_last_hidden(const orc_model *m) { return m->last_hidden; }
+
+/* Test hooks for the layer-wise (teacher-forced) comparison: every forward copies the LAST row's input of each layer to
+ * buf[l * dim ..] and the last layer's output to buf[layers * dim ..] (buf: caller-owned, NULL switches it off); the K / V
+ * cache of a layer as the forward left it ([max_ctx] rows of the cache's row format). */
+void orc_model_set_capture(orc_model *m, orc_f16 *buf) { m->capture = buf; }
+void *orc_model_kv_cache(orc_model *m, int layer, int is_v)
+{
+    if (layer < 0 || layer >= m->cfg.layers) return NULL;
+    return is_v ? m->layers[layer].vcache : m->layers[layer].kcache;
+}
 
 /* C[T][rows(W)] = A[T][cols(W)] x W^T (+bias), reference dispatch rules. */
 static int matmul(const orc_model *m, const orc_f16 *A, int T, const orc_tensor *W,
@@ -240,6 +251,7 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
     const int rope_cols = rope_dims;
     for (int l = 0; l < c->layers && rc == 0; l++) {
         orc_layer *L = &m->layers[l];
+        if (m->capture) memcpy(m->capture + (size_t)l * D, x + (size_t)(T - 1) * D, D * 2);
         /* attention pre-norm (inference_worker.cc:1038) */
         const orc_f16 *attn_in = x;
         if (L->t[ORC_T_ATTN_NORM].data) {
@@ -330,6 +342,7 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
         if (c->parallel_attn || c->share_input) orc_add(f, x, (size_t)T * D, 0, f);
         memcpy(x, f, sizeof(orc_f16) * (size_t)T * D);
     }
+    if (rc == 0 && m->capture) memcpy(m->capture + (size_t)c->layers * D, x + (size_t)(T - 1) * D, D * 2);
     if (rc == 0) {
         /* ProcessPostLayer, inference_worker.cc:552-624 */
         if (scale_on(m->cfg.out_scale)) orc_scale(x, m->cfg.out_scale, (size_t)T * D, x);      /* :568-570, in place */

@@ -84,6 +84,7 @@ def lib():
         L.orc_row_bytes.argtypes = [C.c_int, C.c_size_t]
         L.orc_model_create.restype = C.c_void_p
         L.orc_model_last_hidden.restype = C.c_void_p
+        L.orc_model_kv_cache.restype = C.c_void_p
         _lib = L
     return _lib
 
@@ -364,6 +365,21 @@ class Model:
         if tok < 0:
             raise RuntimeError("orc_model_forward failed: %d" % tok)
         return tok, (logits.view(np.float16) if want_logits else None)
+
+    def capture_layers(self, on=True):
+        """every forward() records the last row's input of each layer + the last layer's output: layer_io() -> [layers + 1][dim]"""
+        self._cap = np.zeros((self.cfg.layers + 1, self.cfg.dim), np.uint16) if on else None
+        lib().orc_model_set_capture(self._h, _p(self._cap) if on else None)
+
+    def layer_io(self):
+        return self._cap.view(np.float16).copy()
+
+    def kv_rows(self, layer, is_v, n_rows):
+        """rows [0, n_rows) of a layer's K (or V) cache as the forwards left them: uint8 [n_rows][row bytes of the cache format]"""
+        kvd = self.cfg.kv_heads * self.cfg.head_dim
+        rb = row_bytes(Q8_B32T2 if self.cfg.kv_dtype == Q8_B32T2 else F16, kvd)
+        p = lib().orc_model_kv_cache(self._h, C.c_int(layer), C.c_int(1 if is_v else 0))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n_rows * rb,)).reshape(n_rows, rb).copy()
 
     def last_hidden(self):
         p = lib().orc_model_last_hidden(self._h)

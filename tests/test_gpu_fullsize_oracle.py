@@ -12,8 +12,12 @@ different orders (the oracle restates the reference's CUDA lane order, the kerne
 with the context), so about one value in 200 differs by a half ulp, which flips an int8 code now and then, and every later layer
 re-quantises that difference.  Measured (Q4 + F16 KV / Q3H + Q8 KV, worst of 7 steps): 0.003 / 0.03 x std after 1 layer,
 0.07 / 0.07 after 2, 0.09 / 0.13 after 4, 0.12 / 0.16 after 8, 0.17 / 0.20 after 16, 0.27 / 0.29 after 32 -- growth like
-sqrt(layers), no jump at any depth.  The test holds that law: for the first N layers of the model, N = 1, 4 and 32,
+sqrt(layers), no jump at any depth.  The test holds that law for the first N = 4 and N = 32 layers of the model,
     max |dlogit| <= 0.08 x sqrt(N) x std(oracle logits)      and      cosine >= 1 - 0.00005 - 0.00015 x N,
+and holds ONE layer (N = 1) to what one layer measures, not to the law's slack (0.08 was 25x the measured figure):
+    max |dlogit| <= 0.01 x std (F16 KV: measured 0.0015-0.003) / 0.05 x std (Q8 KV: 0.028-0.03, the cache row is a second
+    int8 re-quantisation inside the layer)      and      cosine >= 0.99999 / 0.9999;
+that every SINGLE layer of the 32 -- not only the first -- stays inside its one-layer figure is tests/test_gpu_layerwise_oracle.py,
 (std ~1.3: lm_head rows of std 0.02 over 4096 normalised values), and a greedy id must be the oracle's whenever the oracle's
 top-2 gap exceeds that |dlogit| bound.  The T > 1 prefill (F16 activations, no int8 re-quantisation) keeps the rule of
 tests/test_gpu_engine.py at all 32 layers: cosine >= 0.9995, |dlogit| <= 0.10 x std.
@@ -68,6 +72,8 @@ def test_llama2_7b_widths_fused_decode_matches_oracle_at_depths_1_4_32(wd, kvd):
         wk.reset()
         frac = 0.08 * math.sqrt(N)
         cos_min = 1.0 - 0.00005 - 0.00015 * N
+        if N == 1:
+            frac, cos_min = (0.01, 0.99999) if kvd == dt.F16 else (0.05, 0.9999)
         cur, worst, ids_checked = None, (1.0, 0.0), 0
         for i in range(N_PROMPT + N_STEPS):          # the prompt through the T = 1 path too: every step is a fused decode step
             tok_in = int(prompt[i]) if i < N_PROMPT else cur
