@@ -138,36 +138,78 @@ def reference_cpu_baseline(n_tokens=128):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def reference_cpu_baseline_7b_width(n_tokens=16, layers=8):
-    """The reference's CPU path on the HEADLINE model's widths: a `layers`-layer Llama-2-7B-shaped llama2.c checkpoint
-    (F32 weights: what its CPU side runs; all 32 layers would be a 27 GB file per bench run), with this engine on the same file
-    (Q4 weights, F16 KV cache: the headline formats) next to it."""
+def _host_avail_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+def _ref_checkpoint_dir(file_gb):
+    """Where the F32 checkpoint goes: memory (/dev/shm) when the host has room for the file AND the reference's own copy of it,
+    else the temporary directory on disk."""
+    import shutil
+    import tempfile
+    try:
+        shm_free = shutil.disk_usage("/dev/shm").free / 2 ** 30
+    except OSError:
+        shm_free = 0.0
+    if shm_free >= file_gb + 2 and _host_avail_gb() >= 2.4 * file_gb + 8:
+        return tempfile.mkdtemp(prefix="ifa_ref_cpu7b_", dir="/dev/shm"), "/dev/shm"
+    return tempfile.mkdtemp(prefix="ifa_ref_cpu7b_"), "disk"
+
+
+def pick_reference_layers(avail_gb=None, disk_gb=None):
+    """How many of the 32 layers the reference's CPU path is timed on, by what the host can hold: the F32 llama2.c checkpoint
+    (0.81 GB per layer + 0.52 GB) is written to a temporary directory AND read into the reference process's heap.  32 layers need
+    ~27 GB of file (page cache can drop it) + ~27 GB of heap; 16 and 8 layers are the fallbacks (the line says which)."""
+    import shutil
+    import tempfile
+    if avail_gb is None:
+        avail_gb = _host_avail_gb()
+    if disk_gb is None:
+        disk_gb = shutil.disk_usage(tempfile.gettempdir()).free / 2 ** 30
+    for layers in (32, 16, 8):
+        file_gb = layers * 0.81 + 0.55
+        if avail_gb >= 1.35 * file_gb + 6 and disk_gb >= file_gb + 4:
+            return layers
+    return 0
+
+
+def reference_cpu_baseline_7b_width(n_tokens=16, layers=32, with_gpu=True):
+    """The reference's CPU path on the HEADLINE model (SURVEY 8d "C2-shaped weights, >= 16 tokens"): a Llama-2-7B
+    llama2.c checkpoint of `layers` layers (F32 weights: what its CPU side runs; all 32 layers = the headline model, a 27 GB file)
+    with this engine on the same file (Q4 weights, F16 KV cache: the headline formats) next to it.  Machine-readable: "layers",
+    "model_layers", "full_model", "bytes_per_token"."""
     import shutil
     import tempfile
     import numpy as np
     import oracle as o
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import gen_model_fixtures as gmf
-    from inferflow_amd.engine import InferenceEngine
     from tests import engine_fixtures as fx
     if not os.path.exists(gmf.DRIVER):
         raise RuntimeError("oracle/_ref/ifa_ref_engine is not built (needs /root/reference at build time)")
     shape = dict(dim=4096, layers=layers, heads=32, kv_heads=32, head_dim=128, ffn=11008, vocab=32000)
     threads = min(o.usable_cpus(), 16)
-    d = tempfile.mkdtemp(prefix="ifa_ref_cpu7b_")
+    d, where = _ref_checkpoint_dir(layers * 0.81 + 0.55)
+    t_start = time.perf_counter()
     try:
         # the checkpoint in the llama2.c layout (model_reader.cc:3248-3430), written tensor by tensor from the fast float32 generator
         # (tests/engine_fixtures.make_weights draws float64: half a minute for 0.33 G values)
         import struct
         rng = np.random.default_rng(16)
         ctx = 128
-        # one pool of normal draws, every tensor a window of it at its own offset (drawing 1.9 G values would take longer than
+        # one pool of normal draws, every tensor a window of it at its own offset (drawing 6.7 G values would take longer than
         # the measurement; the values only have to be well-conditioned and different from tensor to tensor)
         biggest = shape["vocab"] * shape["dim"]
         pool = rng.standard_normal(biggest + (1 << 22), dtype=np.float32) * np.float32(0.02)
         with open(os.path.join(d, "model.bin"), "wb") as f:
             f.write(struct.pack("<7i", shape["dim"], shape["ffn"], layers, shape["heads"], shape["kv_heads"], shape["vocab"], ctx))      # vocab > 0: shared classifier
-            f.write(pool[:biggest].tobytes())
+            f.write(memoryview(pool[:biggest]))
             k = 0
             for tid, kind in fx.KINDS:
                 for l in range(layers):
@@ -175,37 +217,51 @@ def reference_cpu_baseline_7b_width(n_tokens=16, layers=8):
                     k += 1
                     off = (k * 1000003) % (1 << 22)
                     t = pool[off:off + r_ * c_]
-                    f.write(((1.0 + t) if kind == "norm" else t).tobytes())
+                    f.write(memoryview(np.ascontiguousarray((1.0 + t) if kind == "norm" else t)))      # (no tobytes() copy: 26 GB go through here)
             f.write(np.ones((1, shape["dim"]), np.float32).tobytes())
             f.write(b"\0" * (ctx * shape["head_dim"]))
+        del pool
         gmf.write_tokenizer(os.path.join(d, "tokenizer.bin"), shape["vocab"])
         spec = json.loads(json.dumps(fx.SPEC)); spec["tokenizer_file"] = "tokenizer.bin"; spec["qkv_format"] = 1
         json.dump(spec, open(os.path.join(d, "model_spec.json"), "w"))
         ini = os.path.join(d, "engine.ini")
         open(ini, "w").write(gmf.REF_INI.format(ctx=ctx).replace("cpu_threads = 4", "cpu_threads = %d" % threads).replace("return_output_tensors = true", "return_output_tensors = false"))
         prompt = np.random.default_rng(16).integers(3, shape["vocab"], 4).astype(np.int32)
+        t_written = time.perf_counter()
         r = gmf.run_reference(ini, prompt, n_tokens + 1, quiet=True)
+        t_ref = time.perf_counter()
         ref_tok_s = n_tokens / (r["decode_ms"] / 1e3)
-        # this engine on the very same model.bin (same directory, its own .ini): Q4 weights quantised at load, F16 cache
-        gini = os.path.join(d, "engine_gpu.ini")
-        open(gini, "w").write(fx.INI.format(name="ref7b", wd="Q4", kvd="F16", thr=0, ctx=128, ret="false", maxq=2, devices="0", force_partition="false"))
-        eng = InferenceEngine.from_ini(gini)
-        qid = eng.add_query(prompt)
-        (q, tok), = eng.infer()
-        eng.commit({qid: tok})
-        eng.generate(qid, 8)
-        t0 = time.perf_counter()
-        eng.generate(qid, 64)
-        gpu_tok_s = 64 / (time.perf_counter() - t0)
-        eng.close()
-        bytes_tok = (layers * (4 * 4096 * 4096 + 3 * 4096 * 11008) + 32000 * 4096) * 4
-        return {"value": ref_tok_s, "unit": "tokens/s", "cores": threads, "kind": "reference",
-                "sample": "the reference's CPU path (oracle/_ref/ifa_ref_engine) on a %d-layer Llama-2-7B-WIDTH llama2.c checkpoint (d 4096, ffn 11008, "
-                          "32 heads, vocab 32000, shared classifier, F32 weights: %.2f GB read per token = %.1f GB/s), 4-token prompt + %d greedy "
-                          "tokens, cpu_threads %d" % (layers, bytes_tok / 1e9, bytes_tok * ref_tok_s / 1e9, n_tokens, threads),
-                "gpu_same_checkpoint_tok_s": gpu_tok_s,
-                "note": "a %d-layer slice of the headline shape (layers + shared classifier), not the headline workload: the 32-layer model streams %.1fx these bytes per token" % (
-                    layers, ((32 * (4 * 4096 * 4096 + 3 * 4096 * 11008) + 32000 * 4096) * 4) / float(bytes_tok))}
+        gpu_tok_s = None
+        if with_gpu:
+            # this engine on the very same model.bin (same directory, its own .ini): Q4 weights quantised at load, F16 cache
+            from inferflow_amd.engine import InferenceEngine
+            gini = os.path.join(d, "engine_gpu.ini")
+            open(gini, "w").write(fx.INI.format(name="ref7b", wd="Q4", kvd="F16", thr=0, ctx=128, ret="false", maxq=2, devices="0", force_partition="false"))
+            eng = InferenceEngine.from_ini(gini)
+            qid = eng.add_query(prompt)
+            (q, tok), = eng.infer()
+            eng.commit({qid: tok})
+            eng.generate(qid, 8)
+            t0 = time.perf_counter()
+            eng.generate(qid, 64)
+            gpu_tok_s = 64 / (time.perf_counter() - t0)
+            eng.close()
+        per_layer = (4 * 4096 * 4096 + 3 * 4096 * 11008) * 4
+        bytes_tok = layers * per_layer + 32000 * 4096 * 4
+        full = layers == 32
+        out = {"value": ref_tok_s, "unit": "tokens/s", "cores": threads, "kind": "reference",
+               "layers": layers, "model_layers": 32, "full_model": full, "weights": "F32 (the reference's CPU path reads F32 / F16 weights)",
+               "bytes_per_token": bytes_tok,
+               "sample": "the reference's CPU path (oracle/_ref/ifa_ref_engine) on a %d-layer Llama-2-7B llama2.c checkpoint (d 4096, ffn 11008, "
+                         "32 heads, vocab 32000, shared classifier, F32 weights: %.2f GB read per token = %.1f GB/s), 4-token prompt + %d greedy "
+                         "tokens, cpu_threads %d; checkpoint written to %s in %.0f s, reference load + prompt + decode %.0f s" % (
+                             layers, bytes_tok / 1e9, bytes_tok * ref_tok_s / 1e9, n_tokens, threads, where, t_written - t_start, t_ref - t_written),
+               "seconds": time.perf_counter() - t_start,
+               "gpu_same_checkpoint_tok_s": gpu_tok_s}
+        if not full:
+            out["note"] = ("a %d-layer slice of the headline shape (layers + shared classifier), not the headline workload: the 32-layer model "
+                           "streams %.1fx these bytes per token" % (layers, (32 * per_layer + 32000 * 4096 * 4) / float(bytes_tok)))
+        return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -669,14 +725,47 @@ def main():
         except Exception as e:
             out["cpu_baseline_reference"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
         if args.shape == "llama2_7b":
-            try:
-                out["cpu_baseline_reference_7b_width"] = reference_cpu_baseline_7b_width()
-            except Exception as e:
-                out["cpu_baseline_reference_7b_width"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
-    # cpu_baseline (the contract's key): the REFERENCE's own CPU path on the headline widths when it could be timed (kind
-    # "reference": an 8-of-32-layer slice, stated in its sample), else the port on the whole model
-    r7 = out.get("cpu_baseline_reference_7b_width") or {}
-    if r7.get("value"):
+            # the reference on the HEADLINE model: all 32 layers when the host can hold the 27 GB F32 checkpoint (pick_reference_layers),
+            # else the largest slice that fits -- and the 8-layer slice of round 4 as its own line either way
+            n_ref = int(os.environ.get("IFA_BENCH_REF_LAYERS", "-1"))
+            forced = n_ref >= 0
+            if n_ref < 0:
+                n_ref = pick_reference_layers()
+            budget_s = float(os.environ.get("IFA_BENCH_REF_BUDGET_S", "240"))
+            # the 8-layer slice first (round 4's line, kept as its own key): what it took also says what all 32 layers will take on
+            # this host (file write + load + decode scale with the layer count) -- the default run must stay inside a few minutes
+            t8 = None
+            if n_ref >= 8 and not os.environ.get("IFA_BENCH_SKIP_8_LAYERS"):
+                try:
+                    r8 = reference_cpu_baseline_7b_width(layers=8)
+                    out["cpu_baseline_reference_7b_8_layers"] = r8
+                    t8 = r8.get("seconds")
+                except Exception as e:
+                    out["cpu_baseline_reference_7b_8_layers"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "layers": 8, "sample": "failed: %r" % (e,)}
+            why = ""
+            if not forced and t8:
+                while n_ref > 8 and t8 * (n_ref * 0.81 + 0.55) / (8 * 0.81 + 0.55) > budget_s:
+                    why = " (all 32 layers predicted at %.0f s from the 8-layer run, over the %.0f s budget IFA_BENCH_REF_BUDGET_S)" % (t8 * (32 * 0.81 + 0.55) / (8 * 0.81 + 0.55), budget_s)
+                    n_ref //= 2
+            if n_ref > 8:
+                try:
+                    out["cpu_baseline_reference_7b"] = reference_cpu_baseline_7b_width(layers=n_ref)
+                    if why:
+                        out["cpu_baseline_reference_7b"]["note"] = out["cpu_baseline_reference_7b"].get("note", "") + why
+                except Exception as e:
+                    out["cpu_baseline_reference_7b"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "layers": n_ref, "sample": "failed: %r" % (e,)}
+            elif n_ref == 8:
+                out["cpu_baseline_reference_7b"] = dict(out.get("cpu_baseline_reference_7b_8_layers") or {}, note_layers="only the 8-layer slice ran" + (why or
+                                                        ": %.0f GB of host memory available, all 32 layers need ~42" % _host_avail_gb()))
+            else:
+                out["cpu_baseline_reference_7b"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference", "layers": 0,
+                                                    "sample": "not run: %.0f GB of host memory available, the 8-layer checkpoint needs ~15" % _host_avail_gb()}
+    # cpu_baseline (the contract's key) is ALWAYS on the headline workload -- all 32 layers of the model the GPU number is quoted on
+    # (ADVICE r4): the REFERENCE's own CPU path when the host could hold the full checkpoint (kind "reference", "full_model": true,
+    # F32 weights: what that path runs), else the oracle port of the quantised path on the whole model (kind "port").  A slice of
+    # the model is never put under this key; slices keep their own keys with a machine-readable "layers" field.
+    r7 = out.get("cpu_baseline_reference_7b") or {}
+    if r7.get("value") and r7.get("full_model"):
         out["cpu_baseline"] = r7
     elif "cpu_baseline_port" in out:
         out["cpu_baseline"] = out["cpu_baseline_port"]

@@ -76,6 +76,42 @@ __device__ __forceinline__ void rope_apply(half_t *row, int col, float c, float 
 // at least DEC_ATTN_MIN_ROWS rows (the engine pads the allocation), so that first chunk needs no clamp.
 constexpr int DEC_ATTN_MIN_ROWS = 256;
 
+// Score chains per key.  The reference's Gemm_Alg2 adds a key's HD products as ONE fp32 chain in d order (gemm.h:83-178), and
+// rounds 1-4 kept that order: 128 dependent fma per key, each waiting for the one before it (the compiler pads the chain with a
+// wait state per step; on the single wave that holds a short context's keys this was 0.76 us of the 4 us attention tail,
+// profiles/r04_fused_launch_phase_trace.log).  SURVEY 8(c) asks for fp results within tolerance, not for this order: by default
+// the products go through v_dot2_f32_f16 -- two F16 x F16 products and the fp32 accumulator in ONE instruction, the pairs
+// (2 i, 2 i + 1) exactly as q and the key row hold them in memory -- into IFA_ATTN_NACC independent chains (pair i to chain
+// i % NACC), added as ((c0 + c1) + (c2 + c3)) at the end: 64 instructions per key instead of 128 + 128 wait states, the same
+// value to within a few fp32 ulp of a 128-term sum, rounded to half right after.  -DIFA_ATTN_NACC=1 restores the order-exact
+// fma chain (the bit-identity of the fused launches against the five-launch step holds either way: they share this body).
+#ifndef IFA_ATTN_NACC
+#define IFA_ATTN_NACC 4
+#endif
+struct ScoreAcc {
+    float c[IFA_ATTN_NACC];
+    __device__ __forceinline__ ScoreAcc() {
+#pragma unroll
+        for (int i = 0; i < IFA_ATTN_NACC; i++) c[i] = 0.0f;
+    }
+    // elements (2 p, 2 p + 1) of the row: p is a constant after unrolling, so c[] stays in registers
+    __device__ __forceinline__ void add2(int p, half2_t q, half2_t k) {
+        if constexpr (IFA_ATTN_NACC == 1) {
+            c[0] = __builtin_fmaf((float)q[0], (float)k[0], c[0]);
+            c[0] = __builtin_fmaf((float)q[1], (float)k[1], c[0]);
+        } else {
+            c[p % IFA_ATTN_NACC] = __builtin_amdgcn_fdot2(q, k, c[p % IFA_ATTN_NACC], false);
+        }
+    }
+    __device__ __forceinline__ void add(int d, float q, float k) { c[d % IFA_ATTN_NACC] = __builtin_fmaf(q, k, c[d % IFA_ATTN_NACC]); }
+    __device__ __forceinline__ float total() const {
+        if constexpr (IFA_ATTN_NACC == 1) return c[0];
+        else if constexpr (IFA_ATTN_NACC == 2) return c[0] + c[1];
+        else if constexpr (IFA_ATTN_NACC == 4) return (c[0] + c[1]) + (c[2] + c[3]);
+        else { float t = c[0]; for (int i = 1; i < IFA_ATTN_NACC; i++) t = t + c[i]; return t; }
+    }
+};
+
 // PB: cache rows requested at kernel entry (before the position is known): the engine passes the bucket (64 / 128 / 256) the
 // decode call stays inside, rows past it take the loops' direct loads.  KT (F16 cache, head sizes with a power-of-two number
 // of 16-byte pieces): the K rows are requested like the V rows -- 16 bytes per lane, a wave instruction covers whole rows --
@@ -342,7 +378,7 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
     const float mk = P.alibi ? alibi_slope(h + P.alibi_base, P.alibi_total) : 0.0f;
     float lmax = -INFINITY;
     for (int j = tid; j < n_ctx; j += 256) {
-        float c = 0.0f;
+        ScoreAcc acc;
         if (Q8 && j == pos) {
             // the new token's (round-tripped) key: wide LDS reads into registers, then the same chain -- a scalar loop
             // over LDS kept the whole workgroup waiting at the next barrier for ~0.7 us
@@ -353,11 +389,7 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
                 knr[4 * i] = t[0]; knr[4 * i + 1] = t[1]; knr[4 * i + 2] = t[2]; knr[4 * i + 3] = t[3];
             }
 #pragma unroll
-            for (int i = 0; i < HD / 2; i++) {
-                const half2_t k2 = __builtin_bit_cast(half2_t, knr[i]);
-                c = __builtin_fmaf(h2f(qs[2 * i]), (float)k2[0], c);
-                c = __builtin_fmaf(h2f(qs[2 * i + 1]), (float)k2[1], c);
-            }
+            for (int i = 0; i < HD / 2; i++) acc.add2(i, reinterpret_cast<const half2_t *>(qs)[i], __builtin_bit_cast(half2_t, knr[i]));
         } else {
             if constexpr (!Q8) {
                 // the new token's key comes from LDS into the same registers (wide reads) and takes the common path: a
@@ -385,10 +417,8 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
                                 : __builtin_amdgcn_alignbyte(kq32[(B0 >> 2) + 1 < (int)(sizeof(kq32) / 4) ? (B0 >> 2) + 1 : (B0 >> 2)], kq32[B0 >> 2], (B0 & 3));
                             half2_t lo, hi;
                             q8x4_dequant_h(cw, sc2, lo, hi);
-                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4]), (float)lo[0], c);
-                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 1]), (float)lo[1], c);
-                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 2]), (float)hi[0], c);
-                            c = __builtin_fmaf(h2f(qs[b * 32 + 4 * w4 + 3]), (float)hi[1], c);
+                            acc.add2(2 * w4, reinterpret_cast<const half2_t *>(qs)[b * 16 + 2 * w4], lo);
+                            acc.add2(2 * w4 + 1, reinterpret_cast<const half2_t *>(qs)[b * 16 + 2 * w4 + 1], hi);
                         }
                     } else {
                         const float sc = hbits2f(scb);
@@ -396,19 +426,16 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
                         for (int i = 0; i < 32; i++) {
                             const int qv = (int)(int8_t)kbyte(b * 34 + 2 + i);
                             const float kvv = h2f(f2h((float)qv * sc));
-                            c = __builtin_fmaf(h2f(qs[b * 32 + i]), kvv, c);
+                            acc.add(i, h2f(qs[b * 32 + i]), kvv);
                         }
                     }
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < HD / 2; i++) {
-                    const half2_t k2 = __builtin_bit_cast(half2_t, kreg[i]);
-                    c = __builtin_fmaf(h2f(qs[2 * i]), (float)k2[0], c);
-                    c = __builtin_fmaf(h2f(qs[2 * i + 1]), (float)k2[1], c);
-                }
+                for (int i = 0; i < HD / 2; i++) acc.add2(i, reinterpret_cast<const half2_t *>(qs)[i], __builtin_bit_cast(half2_t, kreg[i]));
             }
         }
+        const float c = acc.total();
         half_t s = f2h(alpha * c);
         if (P.alibi) { float a = (float)j * mk; s = f2h(a + h2f(s)); }
         S[j] = s;

@@ -125,6 +125,19 @@ class DecodeWorker:
             out = out.view(np.uint16)
         return d.value, out, r.value, c.value
 
+    def get_expert_tensor_host(self, layer, expert, tid):
+        """(dtype, uint8 copy, rows, cols) of W1 / W2 / W3 of one expert of an MoE layer in reference layout, or None"""
+        d, p, r, c = C.c_int(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+        rc = lib().ifa_model_get_expert_tensor(self._h, layer, expert, tid, C.byref(d), C.byref(p), C.byref(r), C.byref(c))
+        if rc == 1:
+            return None
+        check(rc)
+        nbytes = r.value * dt.row_bytes(d.value, c.value)
+        out = np.empty(nbytes, np.uint8)
+        check(lib().ifa_memcpy_d2h(out.ctypes.data_as(C.c_void_p), p, nbytes, None))
+        check(lib().ifa_stream_sync(None))
+        return d.value, out, r.value, c.value
+
     # ---- tensor-parallel segments (enqueue only; the caller all-reduces in between) ----
     def set_stream(self, stream_ptr):
         check(lib().ifa_model_set_stream(self._h, C.c_void_p(stream_ptr)))

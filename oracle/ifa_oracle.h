@@ -153,6 +153,9 @@ const orc_f16 *orc_model_last_hidden(const orc_model *m);
 /* test hooks: per-layer inputs of the last row ([layers + 1][dim], caller-owned buffer; NULL: off) and a layer's K / V cache */
 void orc_model_set_capture(orc_model *m, orc_f16 *buf);
 void *orc_model_kv_cache(orc_model *m, int layer, int is_v);
+/* smallest router gap p[k-th] - p[(k+1)-th] over the rows and layers of the last forward (2.0: no MoE layer ran) */
+float orc_model_last_moe_margin(const orc_model *m);
+void orc_model_set_layer_margins(orc_model *m, float *buf);      /* [layers]: the gap of every layer of the last forward; NULL: off */
 
 #ifdef __cplusplus
 }

