@@ -602,6 +602,9 @@ def main():
         # ---- the persistent layer kernel (csrc/ifa_decode_persist.h: one launch for all layers of a token, opt-in option
         # "persist"): measured beside the five-launch step on the same model, never the headline value.  Same tokens required.
         try:
+            from inferflow_amd import lib as _lib
+            if not _lib().ifa_experimental_built():      # parked under csrc/experimental/ (57 vs 38 us per layer): not in the default library
+                raise RuntimeError("not built (IFA_EXPERIMENTAL=1 builds the parked launches in)")
             wk = runner.worker
             ps_n = min(32, steps)
             ref_t, _ = wk.decode(tok, PROMPT_LEN + warmup, ps_n)
@@ -616,7 +619,8 @@ def main():
                                               "tokens_equal_five_launch": bool(np.array_equal(ref_t, ps_t)),
                                               "note": "opt-in (set_option persist=1); the five-launch step above is the default"}
         except Exception as e:
-            out["persistent_layer_kernel"] = {"error": repr(e)[:200]}
+            if "not built" not in repr(e):
+                out["persistent_layer_kernel"] = {"error": repr(e)[:200]}
         finally:
             runner.worker.set_option("persist", 0)
     # ---- prefill rate at longer prompts (16 / 128 / 1024-token prompts), outside the timed decode region

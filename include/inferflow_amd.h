@@ -123,6 +123,9 @@ int ifa_gemm_big_tiles(int on);
 int ifa_wait_grid_decision(int blocks_per_cu, int visible_cus, long long grid);      /* 1: the grid fits */
 int ifa_visible_cus_from_mask(const char *mask_text, int device, int device_cus);    /* CUs the mask leaves for `device` */
 int ifa_inlaunch_waits_enabled(void);
+/* 1 if this library was built with the experimental launches of csrc/experimental/ (options "persist", "fuse_wo", "fuse_wo_ffn":
+ * built, bit-identical, measured slower than the default step -- IFA_EXPERIMENTAL=1 at build time); 0: those options are inert */
+int ifa_experimental_built(void);
 /* frees the scratch the prefill kernels keep for this stream on the current device (call before destroying a stream that ran
  * long-prompt attention; ifa_model_destroy / ifa_model_set_stream do it for the worker's) */
 int ifa_gemm_release_stream(ifa_stream stream);

@@ -23,3 +23,5 @@ int dec_persist_launch(int w_dtype, int nja, int njb, int hd, int kvq8, const Ps
 }
 
 } // namespace ifa
+
+extern "C" int ifa_experimental_built(void) { return 1; }

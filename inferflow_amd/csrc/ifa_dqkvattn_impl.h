@@ -22,7 +22,13 @@ static int qa_go2(const DecGemvParams &P, const DecAttnParams &A, const DecQkvAt
 template <int DT, int NJ, int RW, int NORM, bool Q8, int PB, bool KT>
 static int qa_go(const DecGemvParams &P, const DecAttnParams &A, const DecQkvAttnExtra &E, const DecGemvParams *PW, int max_ctx, hipStream_t s)
 {
+#ifdef IFA_EXPERIMENTAL
     if (PW) return qa_go2<DT, NJ, RW, NORM, Q8, PB, KT, true>(P, A, E, *PW, max_ctx, s);
+#else
+    // (the Wo rows behind the attention in the same launch -- option fuse_wo: bit-identical, measured SLOWER, r04 -- are built
+    //  with IFA_EXPERIMENTAL=1 only; dec_qkv_attn_wo_supported() answers false otherwise, so the engine never asks)
+    if (PW) return ifa_fail(IFA_ERR_STATE, "fused QKV + attention + Wo: an experimental launch this library was built without (IFA_EXPERIMENTAL=1)");
+#endif
     DecGemvParams none = DecGemvParams();
     return qa_go2<DT, NJ, RW, NORM, Q8, PB, KT, false>(P, A, E, none, max_ctx, s);
 }

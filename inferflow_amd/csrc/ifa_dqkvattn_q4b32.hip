@@ -29,6 +29,9 @@ bool dec_qkv_attn_supported(int w_dtype, int cols, int heads, int kv_heads, int 
 
 bool dec_qkv_attn_wo_supported(int w_dtype, int wo_dtype, int wo_rows, int wo_cols, int heads, int kv_heads, int head_dim, int gk)
 {
+#ifndef IFA_EXPERIMENTAL
+    return false;        // (the instances exist in experimental builds only: ifa_dqkvattn_impl.h)
+#endif
     const bool q4 = w_dtype == Q4_B32T1A || w_dtype == Q4_B32T1B, q4o = wo_dtype == Q4_B32T1A || wo_dtype == Q4_B32T1B;
     if (!((q4 && q4o) || (w_dtype == wo_dtype))) return false;
     if (wo_cols != heads * head_dim || wo_cols != 4096 || wo_rows < 1) return false;        // (the kernel instances: 4096-column rows)

@@ -22,11 +22,11 @@
 #include "ifa_moe.h"
 #include "ifa_gemm_rows_mfma.h"
 #include "ifa_gemm_big.h"
-#include "ifa_decode_persist_launch.h"
+#include "experimental/ifa_decode_persist_launch.h"      // (declarations; the kernels are built with IFA_EXPERIMENTAL=1 only: ifa_experimental_off.hip)
 #include "ifa_decode_lmhead_tail.h"
 #include "ifa_decode_singles.h"
 #include "ifa_decode_qkv_attn.h"
-#include "ifa_decode_wo_ffn.h"
+#include "experimental/ifa_decode_wo_ffn.h"
 
 using namespace ifa;
 

@@ -125,7 +125,8 @@ def test_mixtral_8x7b_width_eight_queries_tensor_parallel_loopback_engine_matche
     """Mixtral-8x7B's widths through the product surface with `devices = 0&0` and EIGHT concurrent queries, FOUR layers deep: whole-model
     logits of a random-init mixture-of-experts model are comparable only while router near ties are rare -- at all 32 layers 55 of
     56 rows met one (r05: profiles/r05_mixtral_routing_ties.log) and ran different experts on the two sides; at 4 layers most rows
-    are clean.  Rows whose oracle margin is a near tie (and the later rows of that query) are excused and counted.  The full DEPTH
+    are clean.  A row outside the law is excused only if the oracle's router margin of that row is a near tie (or an earlier row of the query
+    already parted at one); at least half of the 56 rows must be inside the law.  The full DEPTH
     -- every one of the 32 layers against the oracle -- is tests/test_gpu_layerwise_oracle.py::...mixtral..."""
     _need_host_gb(16)
     ini, s = _write_engine(tmp_path, "mixtral_8x7b", "0&0", maxq=8, layers=4)
@@ -176,22 +177,27 @@ def test_mixtral_8x7b_width_eight_queries_tensor_parallel_loopback_engine_matche
         rows, toks, margins = orc[q]
         parted = False
         for i in range(N_STEPS + 1):
-            parted = parted or margins[i] < ROUTE_TIE
-            if parted:
-                c_, m_ = _cos_mad(eng_rows[q][i], rows[i].astype(np.float32))
-                excused.append((q, i, round(margins[i], 5), round(c_, 4)))
+            row_fails = []
+            # (row 0: the prompt -- T > 1 kernels for prompts of 2+ tokens, the depth law covers both)
+            cos, mad, sep = _check_row("query %d (prompt of %d) row %d, router margin %.4f" % (q, len(prompts[qi]), i, margins[i]), eng_rows[q][i], rows[i], frac, cos_min, row_fails)
+            if row_fails:
+                # outside the law: legitimate only where a router cut of THIS row is a near tie, or an earlier row of the query
+                # already parted at one (its cache rows differ from the oracle's from there on)
+                parted = parted or margins[i] < ROUTE_TIE
+                if parted:
+                    excused.append((q, i, round(margins[i], 5), round(cos, 4)))
+                else:
+                    fails.extend(row_fails)
                 continue
             checked += 1
-            # (row 0: the prompt -- T > 1 kernels for prompts of 2+ tokens, the depth law covers both)
-            cos, mad, sep = _check_row("query %d (prompt of %d) row %d, router margin %.4f" % (q, len(prompts[qi]), i, margins[i]), eng_rows[q][i], rows[i], frac, cos_min, fails)
             worst = (min(worst[0], cos), max(worst[1], mad))
-            if sep:
+            if sep and not parted:
                 ids += 1
                 if eng_toks[q][i] != toks[i]:
                     id_fails.append((q, i))
     print("Mixtral rows excused for a router near tie (query, row, margin, cos): %s" % (excused,))
     assert not fails and not id_fails, ("rows outside the depth law (tag, cos, |dlogit| / std): %s; ids: %s" % (fails, id_fails))
-    assert checked >= (N_STEPS + 1) * NQ // 3, "too many rows excused: %d checked of %d" % (checked, (N_STEPS + 1) * NQ)
+    assert checked >= (N_STEPS + 1) * NQ // 2, "too many rows excused: %d inside the law of %d" % (checked, (N_STEPS + 1) * NQ)
     print("Mixtral-8x7B widths Q4, 4 layers, devices = 0&0, 8 queries per step: %d rows checked, %d excused; cos >= %.6f |dlogit| <= %.4f std (law %.3f), %d ids compared" % (
         checked, len(excused), worst[0], worst[1], frac, ids))
     eng.close()

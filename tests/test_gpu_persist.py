@@ -5,7 +5,9 @@ Reference sequence: src/transformer/inference_worker.cc:762-981, :1116-1312."""
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not __import__("inferflow_amd").lib().ifa_experimental_built(),
+                                 reason="the persistent launch is a parked dead end (csrc/experimental/): built with IFA_EXPERIMENTAL=1 only")]
 
 torch = pytest.importorskip("torch")
 if not torch.cuda.is_available():

@@ -39,7 +39,8 @@ def build(variants):
     b.build_library()
     hipcc = b._hipcc()
     obj_dir = os.path.join(b.LIB_DIR, "obj")
-    others = [os.path.join(obj_dir, f) for f in sorted(os.listdir(obj_dir)) if f.endswith(".o") and not any(f.startswith(u + ".") for u in UNITS)]
+    want = [os.path.basename(x) + ".o" for x in b.sources()] + ["host_" + os.path.basename(x) + ".o" for x in b.host_sources()]     # (not whatever old objects lie in the directory)
+    others = [os.path.join(obj_dir, f) for f in want if not any(f.startswith(u + ".") for u in UNITS)]
     procs = []
     for name, flags in variants.items():
         d = os.path.join(VDIR, name)
@@ -53,7 +54,7 @@ def build(variants):
                     and os.path.exists(ff) and open(ff).read().strip() == flags.strip():
                 procs.append((name, obj, None))          # object is current: relink only
                 continue
-            cmd = [hipcc] + b.HIPCC_FLAGS + flags.split() + ["-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj]
+            cmd = [hipcc] + b.HIPCC_FLAGS + flags.split() + ["-I", os.path.join(ROOT, "include"), "-I", b.CSRC, "-c", src, "-o", obj]
             procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
             live = [q for _, _, q in procs if q is not None and q.poll() is None]
             while len(live) >= 6:
