@@ -531,9 +531,14 @@ def main():
 
     tok_s = steps / wall
     n_avg = PROMPT_LEN + warmup + steps / 2.0
-    w_bytes = synth.weight_bytes(args.shape, wd, streamed=True)      # what the decode kernels read (Q3H: 36 B per 64 weights)
+    # ALGORITHMIC bytes (the reference's own block sizes -- Q3H_B64T1 is 32 B per 64 weights) are what every roofline
+    # figure of this line is computed on; the bytes the decode kernels actually stream are reported beside them (they differ for
+    # Q3H_B64T1 only: its pair codes are expanded to nibbles at load time, 36 B per 64 weights -- 1.125x wasted traffic by construction)
+    w_bytes = synth.weight_bytes(args.shape, wd, streamed=False)
+    w_bytes_streamed = synth.weight_bytes(args.shape, wd, streamed=True)
     kv_bytes = synth.kv_bytes_per_ctx_row(args.shape, kvd)
     bytes_per_token = w_bytes + kv_bytes * n_avg
+    bytes_per_token_streamed = w_bytes_streamed + kv_bytes * n_avg
     out = {
         "metric": "decode tokens/sec, %s %s batch=1 greedy (whole job)" % (
             {"llama2_7b": "Llama-2-7B", "mixtral_8x7b": "Mixtral-8x7B", "yi_34b": "Yi-34B", "falcon_40b": "Falcon-40B",
@@ -551,11 +556,13 @@ def main():
                    "collectives": (getattr(runner, "backend", "torch.distributed (nccl = RCCL)") + (" [eager steps]" if mode_used == "c-eager" else " [decode-size all-reduces: one-shot exchange over IPC-mapped inboxes, checked against RCCL]" if mode_used == "c-oneshot" else "")) if (world > 1 or os.environ.get("IFA_FORCE_TP")) else None,
                    "fallbacks": fallbacks,
                    "weights_bytes": w_bytes,
-                   "bytes_per_token": bytes_per_token},
+                   "bytes_per_token": bytes_per_token,
+                   "streamed_bytes_per_token": bytes_per_token_streamed},
         "gpu_event_ms_per_step": gpu_ms / steps if gpu_ms and gpu_ms > 0 else None,
         "collective_modes": collective_modes,
         "token_hbm_GBps": bytes_per_token * tok_s / 1e9,
         "token_roofline_frac": bytes_per_token * tok_s / 1e9 / HBM_PEAK_GBPS,
+        "token_roofline_frac_streamed": bytes_per_token_streamed * tok_s / 1e9 / HBM_PEAK_GBPS,
         "prefill_tok_s": PROMPT_LEN / prefill_s,
         "build_s": t_build,
         "last_tokens": [int(t) for t in toks[-4:]],
@@ -565,8 +572,9 @@ def main():
     if world == 1 and hasattr(runner, "export_host_tensors") and not os.environ.get("IFA_FORCE_TP") and not is_moe:
         s = runner.shape
         ffn_rows, d = s["ffn"], s["dim"]
-        rb = dt.streamed_row_bytes                 # bytes the decode kernels stream per row (Q3H_B64T1: 36 per 64 weights, not the 32 of the AoS block)
+        rb = dt.row_bytes                          # ALGORITHMIC bytes per row (the reference's block sizes; Q3H_B64T1: 32 per 64 weights)
         ffn13_bytes = (2 if s.get("is_glu", 1) else 1) * ffn_rows * rb(wd, d)
+        ffn13_streamed = (2 if s.get("is_glu", 1) else 1) * ffn_rows * dt.streamed_row_bytes(wd, d)
         us = runner.worker.time_kernel(3, 320)
         per_kernel = {}
         names = ["qkv", "attn", "wo", "ffn13", "w2", "lm_head"]
@@ -584,6 +592,9 @@ def main():
             from inferflow_amd.build import source_hash
             import glob
             pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]        # the newest round's
+            if wd == dt.Q3H_B64T1:          # configs[2]: its own PMC pass (tools/profile_r05.sh)
+                q = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_q3h_q8_traffic.json")))
+                pmc_path = q[-1] if q else pmc_path
             pmc = json.load(open(pmc_path))
             if pmc.get("source_hash") != source_hash():
                 traffic_note = "profiles/%s was taken with kernel sources %s, this build is %s: stale, not reported" % (
@@ -592,12 +603,16 @@ def main():
                 import re                                                                     # <DT 13, NJ 2, RW any, EPI_GLU 2, NORM 1, ...>
                 traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()     # demangled or mangled name
                            if re.match(r"ifa::k_dec_gemv<13, 2, \d+, 2, 1", k) or re.match(r"_ZN3ifa10k_dec_gemvILi13ELi2ELi\d+ELi2ELi1E", k)][0]
+            elif wd == dt.Q3H_B64T1 and args.shape == "llama2_7b" and "q3h" in os.path.basename(pmc_path):
+                import re                                                                     # <DT 18, NJ 1, RW any, EPI_GLU 2, NORM 1, ...>
+                traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()
+                           if re.match(r"ifa::k_dec_gemv<18, 1, \d+, 2, 1", k) or re.match(r"_ZN3ifa10k_dec_gemvILi18ELi1ELi\d+ELi2ELi1E", k)][0]
         except Exception as e:
             traffic, traffic_note = None, "no PMC summary: %r" % (e,)
         out["roofline"] = {"bound": "hbm", "kernel": "k_dec_gemv<%s, EPI_GLU> (fused RMSNorm+Q8 quant+W1/W3 GEMV+SiLU*mul)" % dt.name(wd),
                            "achieved": ffn13_bytes / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                           "bytes_per_launch": ffn13_bytes, "us_per_launch": us}
+                           "bytes_per_launch": ffn13_bytes, "streamed_bytes_per_launch": ffn13_streamed, "us_per_launch": us}
         out["kernels"] = per_kernel
         # ---- the persistent layer kernel (csrc/ifa_decode_persist.h: one launch for all layers of a token, opt-in option
         # "persist"): measured beside the five-launch step on the same model, never the headline value.  Same tokens required.

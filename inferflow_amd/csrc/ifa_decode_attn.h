@@ -76,17 +76,18 @@ __device__ __forceinline__ void rope_apply(half_t *row, int col, float c, float 
 // at least DEC_ATTN_MIN_ROWS rows (the engine pads the allocation), so that first chunk needs no clamp.
 constexpr int DEC_ATTN_MIN_ROWS = 256;
 
-// Score chains per key.  The reference's Gemm_Alg2 adds a key's HD products as ONE fp32 chain in d order (gemm.h:83-178), and
-// rounds 1-4 kept that order: 128 dependent fma per key, each waiting for the one before it (the compiler pads the chain with a
-// wait state per step; on the single wave that holds a short context's keys this was 0.76 us of the 4 us attention tail,
-// profiles/r04_fused_launch_phase_trace.log).  SURVEY 8(c) asks for fp results within tolerance, not for this order: by default
-// the products go through v_dot2_f32_f16 -- two F16 x F16 products and the fp32 accumulator in ONE instruction, the pairs
-// (2 i, 2 i + 1) exactly as q and the key row hold them in memory -- into IFA_ATTN_NACC independent chains (pair i to chain
-// i % NACC), added as ((c0 + c1) + (c2 + c3)) at the end: 64 instructions per key instead of 128 + 128 wait states, the same
-// value to within a few fp32 ulp of a 128-term sum, rounded to half right after.  -DIFA_ATTN_NACC=1 restores the order-exact
-// fma chain (the bit-identity of the fused launches against the five-launch step holds either way: they share this body).
+// Score chains per key.  The reference's Gemm_Alg2 adds a key's HD products as ONE fp32 chain in d order (gemm.h:83-178); this body
+// keeps that order by default (IFA_ATTN_NACC = 1): 128 dependent fma per key, the compiler pads the chain with a wait state per
+// step.  Round 5 measured the alternative SURVEY 8(c) allows (fp within tolerance): -DIFA_ATTN_NACC=4 sends the pairs
+// (2 i, 2 i + 1) -- exactly as q and the key row hold them in memory -- through v_dot2_f32_f16 into four independent chains,
+// added as ((c0 + c1) + (c2 + c3)): 64 instructions per key instead of 128 + 128 wait states.  On MI355X the score phase of the
+// fused launch's attention tail went 0.76 -> 0.52 us (profiles/r05_attention_dot2_trace.log) -- 0.24 us of a 38 us layer,
+// +0.2 % tokens/s, inside the box-to-box noise -- because a single wave's tail is bound by its ~1000 serial instructions and
+// five barriers, not by this chain.  It also parts the fused step from the op-level attention kernels (ifa_attn.hip keeps the
+// reference order), i.e. it costs the bit-identity "fused decode == op-by-op decode" that tests/test_gpu_engine.py holds for every
+// format.  Not worth that: the order-exact chain stays the default, the dot2 form a build option with its numbers on file.
 #ifndef IFA_ATTN_NACC
-#define IFA_ATTN_NACC 4
+#define IFA_ATTN_NACC 1
 #endif
 struct ScoreAcc {
     float c[IFA_ATTN_NACC];
