@@ -580,11 +580,13 @@ void FillNormalF16(std::vector<uint16_t> &out, size_t n, uint64_t seed, float st
     for (unsigned t = 0; t < nt; t++)
         ts.emplace_back([&, t]() {
             for (size_t p = pairs * t / nt; p < pairs * (t + 1) / nt; p++) {
+                // Box-Muller in single precision (24-bit uniforms): the values end up as F16 with std 0.02, and a 34B-parameter
+                // model draws 17 G pairs -- the double-precision form was two minutes of a 16-core host per model
                 const uint64_t a = Mix64(seed * 0x100000001B3ull + 2 * p), b = Mix64(seed * 0x100000001B3ull + 2 * p + 1);
-                const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
-                const double r = sqrt(-2.0 * log(u1)), th = 6.283185307179586 * u2;
-                out[2 * p] = F32ToF16((float)(r * cos(th)) * std_dev);
-                if (2 * p + 1 < n) out[2 * p + 1] = F32ToF16((float)(r * sin(th)) * std_dev);
+                const float u1 = ((float)(a >> 40) + 1.0f) * (1.0f / 16777217.0f), u2 = (float)(b >> 40) * (1.0f / 16777216.0f);
+                const float r = sqrtf(-2.0f * logf(u1)), th = 6.2831853f * u2;
+                out[2 * p] = F32ToF16(r * cosf(th) * std_dev);
+                if (2 * p + 1 < n) out[2 * p + 1] = F32ToF16(r * sinf(th) * std_dev);
             }
         });
     for (auto &t : ts) t.join();

@@ -825,6 +825,55 @@ int orc_gemv_f16x(int dtype_w, const uint8_t *W, size_t rows, size_t cols,
     return err ? -1 : 0;
 }
 
+/* The same product for T activation rows: Y[t] = orc_gemv_f16x(W, X[t]) for every t, bit for bit -- each weight row is
+ * dequantised ONCE (the software F16 conversions of a row cost far more than the dot itself) and then multiplied with every
+ * activation row by the loop of orc_gemv_f16x (same products, same serial fp32 order).  Test infrastructure only: what it buys
+ * is the run time of the T > 1 steps of the whole-model oracle at 34B-40B widths. */
+int orc_gemm_f16x(int dtype_w, const uint8_t *W, size_t rows, size_t cols, const orc_f16 *X, size_t T,
+                  const orc_f16 *bias, orc_f16 *Y)
+{
+    int cap = orc_block_capacity(dtype_w);
+    if (cap <= 0 || cols % (size_t)cap != 0 || T == 0) return -1;
+    size_t rb = orc_row_bytes(dtype_w, cols);
+    float *xf = (float *)malloc(sizeof(float) * cols * T);
+    if (!xf) return -1;
+    orc_h2f_n(X, xf, cols * T);
+    int err = 0;
+    #pragma omp parallel
+    {
+        orc_f16 *wrow_h = (orc_f16 *)malloc(sizeof(orc_f16) * cols);
+        float *wf = (float *)malloc(sizeof(float) * cols);
+        #pragma omp for schedule(static)
+        for (long r = 0; r < (long)rows; r++) {
+            const orc_f16 *wh;
+            if (dtype_w == ORC_F16) {
+                wh = (const orc_f16 *)(W + (size_t)r * rb);
+            } else if (dtype_w == ORC_F32) {
+                orc_f2h_n((const float *)(W + (size_t)r * rb), wrow_h, cols);
+                wh = wrow_h;
+            } else {
+                if (orc_dequantize_rows(dtype_w, W + (size_t)r * rb, 1, cols, wrow_h) != 0) { err = 1; continue; }
+                wh = wrow_h;
+            }
+            for (size_t c = 0; c < cols; c++) wf[c] = orc_h2f(wh[c]);
+            for (size_t t = 0; t < T; t++) {
+                const float *xt = xf + t * cols;
+                float acc = 0.0f;
+                for (size_t c = 0; c < cols; c++) {
+                    float p = wf[c] * xt[c];
+                    acc = acc + p;
+                }
+                orc_f16 yh = orc_f2h(acc);
+                if (bias) yh = orc_f2h(orc_h2f(yh) + orc_h2f(bias[r]));
+                Y[t * rows + (size_t)r] = yh;
+            }
+        }
+        free(wrow_h); free(wf);
+    }
+    free(xf);
+    return err ? -1 : 0;
+}
+
 /* ----------------------------------------------------------- normalisation */
 /* Tensor_RmsNorm_Kernel, src/kernels/unary_tensor_opr.h:216-289; launcher
  * block (128,1), eps 1e-5 (src/tensor/tensor_opr.cu:568-577).             */

@@ -67,6 +67,9 @@ int orc_gemv_ax8(int dtype_w, const uint8_t *W, size_t rows, size_t cols,
                  const uint8_t *xq8, orc_f16 *y, double *y_f64 /* nullable */);
 int orc_gemv_f16x(int dtype_w, const uint8_t *W, size_t rows, size_t cols,
                   const orc_f16 *x, const orc_f16 *bias, orc_f16 *y, double *y_f64);
+/* the same for T activation rows at once (X [T][cols], Y [T][rows]): each weight row dequantised once; results bit-identical to T calls */
+int orc_gemm_f16x(int dtype_w, const uint8_t *W, size_t rows, size_t cols, const orc_f16 *X, size_t T,
+                  const orc_f16 *bias, orc_f16 *Y);
 
 /* Normalisation (eps = 1e-5 in the reference launchers). */
 void orc_rmsnorm(const orc_f16 *x, size_t rows, size_t cols, const orc_f16 *w,

@@ -147,6 +147,8 @@ static int matmul(const orc_model *m, const orc_f16 *A, int T, const orc_tensor 
         if (bptr) orc_add(C, bptr, N, 0, C);
         return 0;
     }
+    if (T > 1)      /* (every row of W dequantised once for the T rows of A: the per-token loop below, bit for bit, at a fraction of the time) */
+        return orc_gemm_f16x(W->dtype, (const uint8_t *)W->data, N, K, A, (size_t)T, bptr, C);
     for (int t = 0; t < T; t++) {
         int rc = orc_gemv_f16x(W->dtype, (const uint8_t *)W->data, N, K, A + (size_t)t * K, bptr,
                                C + (size_t)t * N, NULL);

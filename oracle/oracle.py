@@ -231,6 +231,19 @@ def gemv_f16x(dt, W, rows, cols, x, bias=None, want_f64=False):
     return (y.view(np.float16), y64) if want_f64 else y.view(np.float16)
 
 
+def gemm_f16x(dt, W, rows, cols, X, bias=None):
+    """Y[t] = gemv_f16x(W, X[t]) for all rows of X at once (each weight row dequantised once; bit-identical to the per-row calls)"""
+    W = np.ascontiguousarray(W)
+    x16 = _f16(X)
+    T = x16.shape[0]
+    y = np.empty((T, rows), np.uint16)
+    b16 = _f16(bias) if bias is not None else None
+    rc = lib().orc_gemm_f16x(dt, _p(W), C.c_size_t(rows), C.c_size_t(cols), _p(x16), C.c_size_t(T), _p(b16) if b16 is not None else None, _p(y))
+    if rc != 0:
+        raise ValueError("orc_gemm_f16x failed")
+    return y.view(np.float16)
+
+
 def rmsnorm(x, w=None, b=None, multi_base=0.0, eps=1e-5, nthreads_x=128):
     x16 = _f16(x)
     rows, cols = x16.shape

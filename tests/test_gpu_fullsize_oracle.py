@@ -48,17 +48,19 @@ def _cos_mad(a, b):
 @pytest.mark.parametrize("wd,kvd", [(dt.Q4_B32T1A, dt.F16), (dt.Q3H_B64T1, dt.Q8_B32T2)], ids=["q4_kvf16", "q3h_kvq8"])
 def test_llama2_7b_widths_fused_decode_matches_oracle_at_depths_1_4_32(wd, kvd):
     max_ctx = 64
-    wk, host, s = synth.build("llama2_7b", wd, kvd, max_ctx=max_ctx, keep_host=True)
+    wk, _, s = synth.build("llama2_7b", wd, kvd, max_ctx=max_ctx)
     assert s["layers"] == 32 and s["dim"] == 4096 and s["vocab"] == 32000
     ok, why = wk.fused_supported()
     assert ok, why
+    # the oracle multiplies the blocks the device quantiser wrote, READ BACK from the worker (the quantiser itself is pinned bit for bit
+    # against the reference header in tests/test_gpu_ops.py; quantising 6.5 G weights again on the host cost half a minute per case)
+    host = [(-1, t) for t in (0, 1, 3)] + [(l, t) for l in range(s["layers"]) for t in (10, 12, 13, 14, 15, 16, 18, 19, 20)]
     quantised = {}
 
     def tensor(key):
         if key not in quantised:
-            target, arr, rows, cols = host[key]
-            data = arr.reshape(rows, cols).view(np.uint16) if target == dt.F16 else o.quantize(target, arr.reshape(rows, cols))
-            quantised[key] = (target, data, rows, cols)
+            d, data, rows, cols = wk.get_tensor_host(max(key[0], 0), key[1])
+            quantised[key] = (d, data.reshape(rows, cols) if d == dt.F16 else data.reshape(rows, -1), rows, cols)
         return quantised[key]
 
     prompt = np.random.default_rng(2024).integers(3, s["vocab"], N_PROMPT).astype(np.int32)

@@ -120,3 +120,18 @@ def test_specialised_q4_gemv_loop_is_bit_identical_to_the_general_one():
                 om.lib().orc_set_slow_paths(0)
             assert np.array_equal(fast, slow), (d, rows, cols)
     assert 1 <= o.usable_cpus() <= (os.cpu_count() or 1)
+
+
+def test_multi_row_product_is_the_per_row_product_bit_for_bit():
+    """orc_gemm_f16x (the whole-model oracle's T > 1 steps: every weight row dequantised once) against orc_gemv_f16x row by row"""
+    rng = np.random.default_rng(31)
+    for d in (o.Q4_B32T1A, o.Q3H_B64T1, o.Q8_B32T2, o.Q6_B64T1, o.Q2_B32T1B, o.F16):
+        rows, cols, T = 96, 256, 5
+        w = (rng.standard_normal((rows, cols)) * 0.05).astype(np.float16)
+        W = w.view(np.uint16) if d == o.F16 else o.quantize(d, w)
+        X = rng.standard_normal((T, cols)).astype(np.float16)
+        b = rng.standard_normal(rows).astype(np.float16)
+        for bias in (None, b):
+            got = o.gemm_f16x(d, W, rows, cols, X, bias)
+            ref = np.stack([o.gemv_f16x(d, W, rows, cols, X[t], bias=bias) for t in range(T)])
+            assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), (d, bias is None)
