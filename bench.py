@@ -170,11 +170,18 @@ def pick_reference_layers(avail_gb=None, disk_gb=None):
     import tempfile
     if avail_gb is None:
         avail_gb = _host_avail_gb()
+    shm_gb = 0.0
     if disk_gb is None:
         disk_gb = shutil.disk_usage(tempfile.gettempdir()).free / 2 ** 30
+        try:
+            shm_gb = shutil.disk_usage("/dev/shm").free / 2 ** 30         # (_ref_checkpoint_dir writes there when memory allows)
+        except OSError:
+            shm_gb = 0.0
     for layers in (32, 16, 8):
         file_gb = layers * 0.81 + 0.55
-        if avail_gb >= 1.35 * file_gb + 6 and disk_gb >= file_gb + 4:
+        on_disk = avail_gb >= 1.35 * file_gb + 6 and disk_gb >= file_gb + 4
+        in_memory = shm_gb >= file_gb + 2 and avail_gb >= 2.4 * file_gb + 8
+        if on_disk or in_memory:
             return layers
     return 0
 

@@ -147,7 +147,13 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
     int wgs = std::min(dec_num_cus() * per_cu, (P.total_rows + waves - 1) / waves);
     if (wgs < 1) wgs = 1;
     const dim3 grid((unsigned)wgs);
+    if (wgs > 0xFFFF || P.nblk > 0xFFFF) return ifa_fail(IFA_ERR_ARG, "fused GEMV: grid %d / %d blocks per row exceed the packed launch scalars", wgs, P.nblk);
     const size_t smem = xlds_bytes(P.cols);
+    // the matrix pointer as a preloaded kernel argument when the launch has ONE matrix (pair) and no expert table (k_dec_gemv)
+    const uint8_t *pw0 = (P.nsets == 1 && !epi_is_moe(EPI) && !P.w_table) ? P.W0[0] : nullptr;
+#ifdef IFA_NO_PRELOAD_W            // (A / B: the row addresses from the argument block, as before round 5)
+    pw0 = nullptr;
+#endif
     // inputs that are normalised or feed an activation are [dim] vectors (dim <= 8192): <= 4 blocks per lane of a B32 format
     constexpr int NJCAP = (NORM == 1 || EPI == EPI_GLU || EPI == EPI_ACT || EPI == EPI_MOE_GLU || EPI == EPI_MOE_ACT) ? 4 : 8;
     if (nj > NJCAP) return ifa_fail(IFA_ERR_ARG, "fused GEMV: %d columns exceed the limit for a normalised / gated input", P.cols);
@@ -157,7 +163,7 @@ static int dec_gemv_launch_en(const DecGemvParams &P, int wgs_per_cu_opt, hipStr
         constexpr int NPV = dec_np<DT>(EPI, NORM, NJV, XADD, THV); \
         auto kern = k_dec_gemv<DT, NJV, dec_rw<DT>(EPI, NORM, NJV, NM, THV), EPI, NORM, XADD, THV, NPV>; \
         if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        kern<<<grid, dim3(THV), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, P); } break;
+        kern<<<grid, dim3(THV), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, pw0, P.W1, (int)((unsigned)P.nblk | ((unsigned)wgs << 16)), P.total_rows, P); } break;
     switch (nj) { IFA_DG(1) IFA_DG(2) IFA_DG(3) IFA_DG(4) IFA_DG(5) IFA_DG(6) IFA_DG(7) IFA_DG(8) }
 #undef IFA_DG
     IFA_LAUNCH_CHECK();

@@ -554,11 +554,17 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
 // activation arrives and is quantised -- the stream had a hole of 2-2.5 us per launch (profiles/r04_*trace*).
 template <int DT, int NJ, int RW, int EPI, int NORM, bool XADD = false, int TH = DEC_THREADS, int NP = 0>
 __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols,
+                                                          const uint8_t *pw0, const uint8_t *pw1, int pnblk_grid, int ptotal,
                                                           const DecGemvParams P)
 {
     // px / pnw / pnb / pcols repeat P.x / P.norm_w / P.norm_b / P.cols as leading scalar arguments: with
     // -amdgpu-kernarg-preload-count they arrive in SGPRs at wave launch, so the activation requests -- the head of
-    // the kernel's critical path -- do not wait for the first scalar load of the argument block
+    // the kernel's critical path -- do not wait for the first scalar load of the argument block.
+    // pw0 / pw1 / pnblk / ptotal (round 5) do the same for the WEIGHT requests: pnblk = P.nblk and ptotal = P.total_rows for every
+    // launch; pw0 = P.W0[0], pw1 = P.W1 for the single-matrix launches (Wo, W1 / W3, W2), pw0 = null when there are several sets
+    // or an expert table (the row addresses then come from the argument block as before).  Every row address of such a launch is then a function of preloaded scalars and
+    // the wave's own id: the stream's first request no longer waits ~0.4 us for the argument block's scalar load (r04 trace:
+    // "loads issued" at 0.9-1.0 us of the launch; the argument block is cold after every kernel boundary)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(NP == 0 || (NORM != 2 && !XADD && NP * 64 < TH), "wave-specialised prologue: a norm / quantiser prologue, some loader waves");
     // the activation requests go out first, from preloaded arguments only (nothing here waits for a scalar load)
@@ -574,14 +580,20 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform (SGPR)
     const int gw = blockIdx.x * (TH / 64) + wave;
-    const int W = gridDim.x * (TH / 64);
+    // (the grid size from the preloaded scalar too: gridDim.x is a HIDDEN kernel argument, i.e. one more scalar load of the cold
+    //  argument block in front of the first row address)
+    const int W = (int)((unsigned)pnblk_grid >> 16) * (TH / 64);
     using Fmt = DecFmt<DT, NJ>;
-    const size_t row_bytes = tiled_row_bytes(DT, (size_t)P.nblk);
     constexpr int NM = epi_is_glu(EPI) ? 2 : 1;
-    const int npass = (P.total_rows + RW * W - 1) / (RW * W);
+    // single-matrix launch: rows, blocks and matrix pointers from the preloaded scalars (see above); the selects below are on a
+    // wave-uniform condition the compiler resolves with scalar instructions -- nothing on this path reads the argument block
+    const bool single = !epi_is_moe(EPI) && pw0 != nullptr;
+    const int nblk_k = pnblk_grid & 0xFFFF, total_rows = ptotal;          // (= P.nblk, P.total_rows for EVERY launch: no select on the argument block)
+    const size_t row_bytes = tiled_row_bytes(DT, (size_t)nblk_k);
+    const int npass = (total_rows + RW * W - 1) / (RW * W);
 
-    const bool tr = P.trace != nullptr && threadIdx.x == 64;
-    if (tr) P.trace[blockIdx.x * 8 + 0] = t_start;
+    // (P.trace is the first field of the argument block anything here reads: its test sits BEHIND the first weight requests,
+    //  trace_on() below)
 
     // MoE: the expert's matrices, looked up once (uniform scalar loads) from the router's choice
     // (several sets = several router slots in one launch: set i is the expert of slot moe_slot + i)
@@ -609,13 +621,18 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         // window with duplicates (2 of 3 requests of the Wo kernel, 10 % of W1/W3).  `full` is wave-uniform (gw is an
         // SGPR): a wave whose pass is complete -- every wave of most launches -- takes the straight-line path without
         // per-row branches; only the first row of a pass is clamped, so that every wave owns defined registers
-        const bool full = (pass * RW + RW - 1) * W + gw < P.total_rows;
+        const bool full = (pass * RW + RW - 1) * W + gw < total_rows;
         auto one = [&](int i) {
-            const int v = min((pass * RW + i) * W + gw, P.total_rows - 1);
+            const int v = min((pass * RW + i) * W + gw, total_rows - 1);
+            if (single) {      // (a uniform branch, not a select: the other arm waits for the argument block)
+                w[0][i].load(pw0 + (size_t)v * row_bytes, nblk_k, lane);
+                if constexpr (NM == 2) w[1][i].load(pw1 + (size_t)v * row_bytes, nblk_k, lane);
+                return;
+            }
             const DecRow d = dec_locate(P, v);
             const uint8_t *W0 = epi_is_moe(EPI) ? moe_pick(d.si, moeW0, moeW0b, moeW0c) : d.W0;
-            w[0][i].load(W0 + (size_t)d.row * row_bytes, P.nblk, lane);
-            if constexpr (NM == 2) { const uint8_t *W1 = epi_is_moe(EPI) ? moe_pick(d.si, moeW1, moeW1b, moeW1c) : d.W1; w[1][i].load(W1 + (size_t)d.row * row_bytes, P.nblk, lane); }
+            w[0][i].load(W0 + (size_t)d.row * row_bytes, nblk_k, lane);
+            if constexpr (NM == 2) { const uint8_t *W1 = epi_is_moe(EPI) ? moe_pick(d.si, moeW1, moeW1b, moeW1c) : d.W1; w[1][i].load(W1 + (size_t)d.row * row_bytes, nblk_k, lane); }
         };
         if (full) {
 #pragma unroll
@@ -624,7 +641,7 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
 #pragma unroll
             for (int i = 0; i < RW; i++) {
                 if (i < i0 || i >= i1) continue;
-                if (i > 0 && (pass * RW + i) * W + gw >= P.total_rows) continue;
+                if (i > 0 && (pass * RW + i) * W + gw >= total_rows) continue;
                 one(i);
             }
         }
@@ -635,8 +652,8 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     half_t res = (half_t)0, res2 = (half_t)0;
     auto load_epi = [&](int pass) {
         if constexpr (EPI == EPI_RESIDUAL) {
-            const int v = min((pass * RW + min(lane, RW - 1)) * W + gw, P.total_rows - 1);
-            const int row = dec_locate(P, v).row;
+            const int v = min((pass * RW + min(lane, RW - 1)) * W + gw, total_rows - 1);
+            const int row = single ? v : dec_locate(P, v).row;
             res = P.residual[row];
             if (P.residual2) res2 = P.residual2[row];
         }
@@ -647,15 +664,18 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
     constexpr int D1 = (NM * NJ * Fmt::DW >= 15) ? 1 : 2;
 
     typename Fmt::X X;
+    bool tr = false;
+    auto trace_on = [&]() { tr = P.trace != nullptr && threadIdx.x == 64; if (tr) P.trace[blockIdx.x * 8 + 0] = t_start; };
     if constexpr (NORM == 2) {
         // the producing kernel left the quantised activation: a wave's requests are its slice of it, then its rows --
         // no cooperative step, no barrier, no LDS
         const XqImage Q = xq_image_carve(const_cast<half_t *>(px), pcols);      // (px = P.x: the image, not F16 values)
-        X.load(Q.codes, Q.scale, Q.xsum, lane, P.nblk);
+        X.load(Q.codes, Q.scale, Q.xsum, lane, nblk_k);
         load_rows(0, 0, RW);
         load_epi(0);
+        trace_on();
         if (tr) { P.trace[blockIdx.x * 8 + 1] = wall_clock64(); P.trace[blockIdx.x * 8 + 2] = wall_clock64(); }
-        if (gw >= P.total_rows) return;
+        if (gw >= total_rows) return;
     } else {
         // the CU's memory queue is FIFO across waves: make sure every wave's activation
         // request is queued before ANY wave floods it with weight requests
@@ -668,6 +688,7 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
             //  requests slipping in between them delayed its quantiser: 8.0 -> 8.7 us)
             constexpr int EARLY = NORM == 1 ? 1 : 0;
             if (EARLY && wave >= NP) load_rows(0, 0, 1);
+            trace_on();
             __syncthreads();
             if (wave >= NP) {
                 load_rows(0, EARLY, RW);
@@ -685,6 +706,7 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         } else {
         __syncthreads();
         load_rows(0, 0, D1);
+        trace_on();
         if (tr) P.trace[blockIdx.x * 8 + 1] = wall_clock64();
         if constexpr (XADD) pre.apply_add(P.x_add_bias, P.cols, P.xsum_out);
         pre.finish(P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out,
@@ -693,8 +715,8 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
         load_epi(0);
         if (tr) P.trace[blockIdx.x * 8 + 2] = wall_clock64();
         }
-        if (gw >= P.total_rows) return;
-        X.load(L.codes, L.scale, L.xsum, lane, P.nblk);
+        if (gw >= total_rows) return;
+        X.load(L.codes, L.scale, L.xsum, lane, nblk_k);
     }
     if (tr) P.trace[blockIdx.x * 8 + 3] = wall_clock64();
 
@@ -716,7 +738,7 @@ __global__ void __launch_bounds__(TH) k_dec_gemv(const half_t *px, const half_t 
             if (lane == i) { a0 = a[0][i]; if constexpr (NM == 2) a1 = a[1][i]; }
         }
         const int v = (pass * RW + lane) * W + gw;
-        if (lane < RW && v < P.total_rows) {
+        if (lane < RW && v < total_rows) {
             dec_finish_row<EPI>(P, dec_locate(P, v), a0, a1, res, res2);
         }
     }

@@ -44,10 +44,17 @@ constexpr int QA_THREADS = 512;     // 8 waves: two per SIMD, 256 registers each
 // the Wo launch's boundary, its 1 us to the first request and its 1.2 us to the first byte are gone (r04 trace).
 // RWO = Wo rows per wave = ceil(rows / (8 * non-attention workgroups)).
 template <int DT, int NJ, int RW, int NORM, int HD, bool Q8, int PB, bool KT, int NP, bool WO = false, int RWO = 3>
-__global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols,
+__global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols, int pgeo,
+                                                             const uint8_t *pwq, const uint8_t *pwk, const uint8_t *pwv,
                                                              const DecGemvParams P, const DecAttnParams A, const DecQkvAttnExtra E,
                                                              const DecGemvParams PW)
 {
+    // pgeo / pwq / pwk / pwv (round 5): heads | kv_heads << 8 | gk << 16 and the three matrices as leading scalar arguments -- with
+    // px / pnw / pnb / pcols they fill the 14 dwords the hardware preloads into SGPRs at wave launch, so that every q | k | v row
+    // address is a function of preloaded scalars and the workgroup's id: the weight stream's first request does not wait for
+    // the (cold) argument block (k_dec_gemv does the same: A / B on one box 808 vs 798-802 tok/s, profiles/r05_preload_ab.log)
+    const int g_heads = pgeo & 0xFF, g_kvh = (pgeo >> 8) & 0xFF, g_gk = (pgeo >> 16) & 0xFFFF;
+    const int g_nblk = pcols / block_capacity(DT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long t_kernel = wall_clock64();
     static_assert(NORM == 0 || NORM == 1, "QKV prologue: quantiser with or without the RMS norm");
@@ -56,21 +63,16 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     constexpr int MAXC = (NJ * 8 * block_capacity(DT) + PT - 1) / PT;
     XPre<NORM, MAXC, false, PT> pre;
     if (threadIdx.x < PT) pre.issue(px, pnw, pnb, pcols);
-    // the position and the step's tag: scalar loads, waited for long after the weight requests
-    const int pos = *(const __attribute__((address_space(4))) int *)(A.state + 1);
-    // tag of this step's granules: (decode call, position) -- every granule is rewritten every step, so a tag only has to differ
-    // from the previous step's (next position of the same call, or another call)
-    const unsigned epoch = ((*(const __attribute__((address_space(4))) unsigned *)(E.epoch) + E.epoch_add) << 20) | ((unsigned)pos & 0xFFFFFu);
     const XLds L = xlds_carve(smem, pcols);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     using Fmt = DecFmt<DT, NJ>;
-    const size_t row_bytes = tiled_row_bytes(DT, (size_t)P.nblk);
+    const size_t row_bytes = tiled_row_bytes(DT, (size_t)g_nblk);
     // kv group of this workgroup and its rows: local row lr = i * (gk * 8) + (workgroup in group) * 8 + wave, i < RW
-    const int g = (int)blockIdx.x / E.gk, bg = (int)blockIdx.x - g * E.gk;
-    const int group = A.heads / A.kv_heads;
+    const int g = (int)blockIdx.x / g_gk, bg = (int)blockIdx.x - g * g_gk;
+    const int group = g_heads / g_kvh;
     const int RG = (group + 2) * HD;
-    const int WGV = E.gk * (TH / 64);
+    const int WGV = g_gk * (TH / 64);
     const int lw = bg * (TH / 64) + wave;
     struct Row { const uint8_t *w; const half_t *b; half_t *y; int row, vrow; };
     // (selects over kernel-argument scalars, like dec_locate: an indexed read of P.W0[] would be a vector load with a vmcnt(0) behind it)
@@ -82,22 +84,30 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
         r.w = isv ? P.W0[2] : (isk ? P.W0[1] : P.W0[0]);
         r.b = isv ? P.b0[2] : (isk ? P.b0[1] : P.b0[0]);
         r.y = isv ? P.y[2] : (isk ? P.y[1] : P.y[0]);
-        r.vrow = isv ? (A.heads + A.kv_heads) * HD + r.row : (isk ? A.heads * HD + r.row : r.row);
+        r.vrow = isv ? (g_heads + g_kvh) * HD + r.row : (isk ? g_heads * HD + r.row : r.row);
         return r;
     };
     typename Fmt::W w[RW];
+    // the address of local row lr's weights from the PRELOADED pointers alone (no wait for the argument block)
+    auto wrow = [&](int lr) -> const uint8_t * {
+        const int nq = group * HD;
+        const bool isk = lr >= nq && lr < nq + HD, isv = lr >= nq + HD;
+        const int row = isv ? g * HD + (lr - nq - HD) : (isk ? g * HD + (lr - nq) : g * nq + lr);
+        // (sums, not a three-way choice of pointers: the compiler turns that choice into a table in scratch memory)
+        const uint64_t q = (uint64_t)pwq, dk = (uint64_t)pwk - q, dv = (uint64_t)pwv - q;
+        return (const uint8_t *)(q + (isk ? dk : 0) + (isv ? dv : 0)) + (size_t)row * row_bytes;
+    };
     auto load_rows = [&](int i0, int i1) {
         const bool full = (RW - 1) * WGV + lw < RG;
         if (full) {
 #pragma unroll
-            for (int i = 0; i < RW; i++) { if (i < i0 || i >= i1) continue; const Row r = locate(i * WGV + lw); w[i].load(r.w + (size_t)r.row * row_bytes, P.nblk, lane); }
+            for (int i = 0; i < RW; i++) { if (i < i0 || i >= i1) continue; w[i].load(wrow(i * WGV + lw), g_nblk, lane); }
         } else {
 #pragma unroll
             for (int i = 0; i < RW; i++) {
                 if (i < i0 || i >= i1) continue;
                 if (i > 0 && i * WGV + lw >= RG) continue;
-                const Row r = locate(min(i * WGV + lw, RG - 1));
-                w[i].load(r.w + (size_t)r.row * row_bytes, P.nblk, lane);
+                w[i].load(wrow(min(i * WGV + lw, RG - 1)), g_nblk, lane);
             }
         }
     };
@@ -105,12 +115,9 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     // prologue waves).  They request the head's K / V rows right behind their weight rows: the cache rows then arrive with the
     // end of the weight stream instead of one memory round trip after the last q | k | v row
     static_assert(NP == 4, "the prologue waves are the attention waves");
-    const int per = E.gk / group;
+    const int per = g_gk / group;
     const bool attn_wg = bg % per == 0;
     const int head = g * group + bg / per;
-    DecAttnFusedIn F;
-    F.gran = E.gran; F.epoch = epoch; F.pos = pos; F.err = E.err; F.timeout_ticks = (long long)E.timeout_us * 100;
-    F.att_gran = WO ? E.att_gran : nullptr;
     // Wo rows of this wave: the non-attention workgroups numbered in grid order, rows dealt round-robin over their waves
     typename Fmt::W wo[WO ? RWO : 1];
     half_t wres = (half_t)0;
@@ -132,6 +139,15 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     };
     if (threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }
     if (wave >= NP) load_rows(0, 1);          // (before the barrier: see k_dec_gemv)
+    // the position and the step's tag: scalar loads through pointers of the argument block -- read BEHIND the first weight
+    // requests, which need nothing but preloaded scalars
+    const int pos = *(const __attribute__((address_space(4))) int *)(A.state + 1);
+    // tag of this step's granules: (decode call, position) -- every granule is rewritten every step, so a tag only has to differ
+    // from the previous step's (next position of the same call, or another call)
+    const unsigned epoch = ((*(const __attribute__((address_space(4))) unsigned *)(E.epoch) + E.epoch_add) << 20) | ((unsigned)pos & 0xFFFFFu);
+    DecAttnFusedIn F;
+    F.gran = E.gran; F.epoch = epoch; F.pos = pos; F.err = E.err; F.timeout_ticks = (long long)E.timeout_us * 100;
+    F.att_gran = WO ? E.att_gran : nullptr;
     __syncthreads();
     if (wave >= NP) {
         load_rows(1, RW);
@@ -141,7 +157,7 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     }
     lds_counter_wait(L.part + 131, NP);
     typename Fmt::X X;
-    X.load(L.codes, L.scale, L.xsum, lane, P.nblk);
+    X.load(L.codes, L.scale, L.xsum, lane, g_nblk);
     {
         float a[RW];
 #pragma unroll

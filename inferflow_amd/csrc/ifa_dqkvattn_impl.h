@@ -14,7 +14,9 @@ static int qa_go2(const DecGemvParams &P, const DecAttnParams &A, const DecQkvAt
     const size_t smem = std::max(std::max(xlds_bytes(P.cols), WO ? xlds_bytes(PW.cols) : (size_t)0), dec_attn_smem(HD, max_ctx, KT ? PB : 0));
     if (smem > (size_t)160 * 1024) return ifa_fail(IFA_ERR_ARG, "fused QKV + attention: %zu bytes of LDS", smem);
     if (smem > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<dim3((unsigned)(A.kv_heads * E.gk)), dim3(QA_THREADS), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, P, A, E, PW);
+    if (A.heads > 255 || A.kv_heads > 255 || E.gk > 0xFFFF) return ifa_fail(IFA_ERR_ARG, "fused QKV + attention: geometry exceeds the packed launch scalar");
+    const int pgeo = A.heads | (A.kv_heads << 8) | (E.gk << 16);
+    kern<<<dim3((unsigned)(A.kv_heads * E.gk)), dim3(QA_THREADS), smem, s>>>(P.x, P.norm_w, P.norm_b, P.cols, pgeo, P.W0[0], P.W0[1], P.W0[2], P, A, E, PW);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }

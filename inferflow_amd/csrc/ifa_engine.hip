@@ -2629,6 +2629,7 @@ int ifa_model_finalize(ifa_model *m)
 {
     IFA_REQUIRE(m, "ifa_model_finalize: null model");
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    (void)wait_err_word();       // (the device's wait-error word exists before any step can be captured: ifa_host.h)
     const ifa_model_config &c = m->cfg;
     const size_t KVD = (size_t)c.kv_heads * c.head_dim;
     IFA_REQUIRE(c.kv_dtype != Q8_B32T2 || KVD % 32 == 0, "Q8 KV cache needs kv_dim %% 32 == 0");

@@ -46,6 +46,9 @@ static int rows_kparts_scratch(hipStream_t s, size_t need, void **out)
 int gemm_rows_kparts_reserve(hipStream_t s)
 {
     void *p = nullptr;
+    (void)wait_err_word();      // the device's wait-error word is pinned host memory: allocated HERE, never under a stream capture
+                                // (hipHostMalloc inside a thread-local capture fails and poisons it: "operation failed due to a
+                                //  previous error during capture" at the first captured K-parts launch, r05 bench_batch at 17 queries)
     return rows_kparts_scratch(s, 1, &p);       // (any size: the allocation is >= 16 MB)
 }
 void rows_kparts_release(int dev, hipStream_t s)

@@ -44,3 +44,19 @@ def test_disarmed_watchdog_lets_the_run_finish():
     script = SCRIPT.replace('dog.arm("pretend collective", 1.0)\ntime.sleep(30)', 'dog.arm("x", 1.0); dog.disarm(); time.sleep(2)')
     p = subprocess.run([sys.executable, "-c", script % ROOT, "0"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 0 and "not reached" in p.stdout
+
+
+def test_reference_cpu_baseline_picks_the_depth_the_host_can_hold():
+    """bench.py's cpu_baseline is the reference's CPU path on ALL 32 layers when the host can hold the 26.4 GB F32 checkpoint twice
+    (file + the reference's heap), else the largest slice that fits -- and says which"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.pick_reference_layers(avail_gb=3000, disk_gb=500) == 32
+    assert b.pick_reference_layers(avail_gb=62, disk_gb=118) == 32
+    assert b.pick_reference_layers(avail_gb=30, disk_gb=118) == 16
+    assert b.pick_reference_layers(avail_gb=18, disk_gb=118) == 8
+    assert b.pick_reference_layers(avail_gb=8, disk_gb=118) == 0
+    assert b.pick_reference_layers(avail_gb=3000, disk_gb=20) == 16      # the file itself must fit the temporary directory

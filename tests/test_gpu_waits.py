@@ -77,6 +77,23 @@ def test_rows_kparts_option_switches_the_waiting_launch_off(n):
     wk.close()
 
 
+@pytest.mark.parametrize("n", [17, 24])
+def test_kparts_launches_inside_a_captured_batched_step(n):
+    """The K-parts launches of a 17..32-query step under stream capture (no logits requested: the step is captured and replayed) --
+    found by tools/bench_batch.py in round 5: the launcher allocated its wait-error word (pinned host memory) at first use, which
+    inside a thread-local capture fails and poisons the capture.  Captured and replayed steps must equal the eager step's ids."""
+    wk, _, s = synth.build("test_longffn", dt.Q4_B32T1A, dt.F16, max_ctx=48, quant_threshold=0, std=0.06)
+    V = s["vocab"]
+    wk.kv_slots(n)
+    cur, pos = _prefill_slots(wk, V, n, 29)
+    lg = torch.empty((n, V), dtype=torch.float16, device="cuda")
+    eager = wk.decode_batch(cur, pos, list(range(n)), lg)                 # eager (logits requested)
+    first = wk.decode_batch(cur, pos, list(range(n)))                     # captures the step, runs it once
+    again = wk.decode_batch(cur, pos, list(range(n)))                     # replay
+    assert [int(t) for t in first] == [int(t) for t in eager] == [int(t) for t in again]
+    wk.close()
+
+
 def test_gemm_splitk_option_switches_the_waiting_launch_off():
     """a 256-token prompt at dim 4096-class widths takes 128 x 128 tiles in two halves of K by default; gemm_splitk = 0: whole K"""
     wk, _, s = synth.build("llama2_7b", dt.Q4_B32T1A, dt.F16, max_ctx=320, layers=1, vocab=2000)

@@ -20,6 +20,7 @@ python tools/pmc_summary.py $(find $OUT/pmc -name "*counter_collection.csv" | he
 cp $OUT/r05_pmc_traffic.json profiles/r05_pmc_traffic.json
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmcq -o pmc -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --prefill-lens "" --batch 0 --wdtype q3h --kv-dtype q8 > $OUT/pmcq.log 2>&1)
 python tools/pmc_summary.py $(find $OUT/pmcq -name "*counter_collection.csv" | head -1) $OUT/r05_pmc_q3h_q8_traffic.json > $OUT/pmcq_summary.log 2>&1
+cp $OUT/r05_pmc_q3h_q8_traffic.json profiles/r05_pmc_q3h_q8_traffic.json
 timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/r05_bench_n1.json 2> $OUT/bench.err
 timeout 600 python bench.py --no-cpu-baseline > $OUT/r05_bench_n1_steps128.json 2>> $OUT/bench.err
 timeout 600 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --wdtype q3h --kv-dtype q8 --prefill-lens "" --batch 0 > $OUT/r05_bench_n1_q3h_q8.json 2>> $OUT/bench.err
