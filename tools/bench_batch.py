@@ -10,6 +10,8 @@ NMAX = 32
 wk.kv_slots(NMAX)
 if "graph" in sys.argv: wk.set_option("batch_graph", 1)
 if os.environ.get("IFA_BATCH_FUSED") == "0": wk.set_option("batch_fused", 0)      # the op-by-op rows for comparison
+for kv in filter(None, os.environ.get("IFA_BATCH_OPTS", "").split(",")):      # e.g. IFA_BATCH_OPTS=rows_norm32=0,rows_kparts=0 (A / B)
+    wk.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 rng = np.random.default_rng(3)
 first = []
 for i in range(NMAX):
