@@ -785,10 +785,17 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         // big enough to matter (>= half the chip), never when a tile shape is forced (measurement / the bit-identity tests).
         // Llama-2-7B prefill: 1024 tokens 51.4K -> 54.2K tok/s, 768: 40.4K -> 44.2K, 512: 35.1K -> 42.4K.  (256 x 256 tiles split four
         // ways -- the efficient tile shape, one part per CU -- measured no better: 53.2K at 1024 tokens, three partial tiles through memory.)
-        const bool splitk = !force && EPI != GM_GLU && (g_gemm_big & (1 << 12)) == 0 && !P.no_waits && waits_enabled() && n128 <= cus && n128 * 2 >= cus && (P.nblk * CAP / PF_BK) % 2 == 0 && P.nblk * CAP >= 2048;
+        const bool may_split = !force && EPI != GM_GLU && (g_gemm_big & (1 << 12)) == 0 && !P.no_waits && waits_enabled();
+        const size_t ksteps = (size_t)P.nblk * CAP / PF_BK;
+        const bool splitk = may_split && n128 <= cus && n128 * 2 >= cus && ksteps % 2 == 0 && P.nblk * CAP >= 2048;
+        // Round 5, prompts of 48..128 tokens (ONE token tile; the engine sends them here from `prefill_big_min` + 1 tokens on): wq | wk | wv
+        // are 96 tiles, wo and w2 32 -- a quarter or an eighth of the chip.  Four parts of K per tile when that still fits two
+        // workgroups per CU and a part keeps >= 1024 columns: 64 tokens 7.46 -> 7.10 ms, 128 tokens 8.22 -> 7.46 (profiles/r05_prompt_lengths.log)
+        const bool splitk4 = may_split && n128 * 2 < cus && n128 * 4 <= 2 * cus && ksteps % 4 == 0 && P.nblk * CAP >= 4096;
         if constexpr (EPI != GM_GLU) {
             rc = 1;
-            if (splitk) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), integral_constant<int, 2>());
+            if (splitk4) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), integral_constant<int, 4>());
+            else if (splitk) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), integral_constant<int, 2>());
             if (rc == 1) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());      // (no split, or its grid cannot be resident at once)
         } else rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());      // (K steps of 128 columns -- BK = 128 -- measured: 57 -> 72 us at 1024 x 4096 x 4096)
     }

@@ -282,25 +282,37 @@ def test_moe_safetensors_checkpoint_through_the_engine_matches_oracle(tmp_path, 
 
 
 def test_moe_synthetic_model_generates_and_batches(tmp_path):
-    """model_file_format = synthetic with expert_count: bin/ifa_llm_inference's path; three queries advance together
-    through one batched step and each follows its own single-query trajectory."""
+    """model_file_format = synthetic with expert_count: bin/ifa_llm_inference's path; three queries advance together through one
+    batched step, each on its own single-query trajectory.  Teacher-forced: every batched step is fed the SOLO run's token, so
+    both sides see the same context at every step (a free-running comparison of a small random MoE model ends at the first near-tie:
+    the batched rows take the F16 GEMM, the single query the int8 GEMV, and a flipped id changes everything behind it); ids must
+    agree wherever the solo logits' top-2 gap exceeds 0.05, and most steps must be such steps."""
     s = fx.MOE_SHAPE
-    ini, _ = fx.write_model_dir(str(tmp_path), fmt="synthetic", wd="Q4", kvd="F16", ret="false", maxq=4, s=s)
+    ini, _ = fx.write_model_dir(str(tmp_path), fmt="synthetic", wd="Q4", kvd="F16", ret="true", maxq=4, s=s)
     eng = InferenceEngine.from_ini(ini)
     rng = np.random.default_rng(5)
     prompts = [rng.integers(3, 1000, n).astype(np.int32) for n in (6, 9, 4)]
-    solo = []
+    STEPS, TIE = 6, 0.05
+    solo, gaps = [], []
     for pr in prompts:
         qid = eng.add_query(pr)
-        gen, _ = eng.generate(qid, 6)
-        solo.append([int(t) for t in gen])
+        toks, gap = [], []
+        for _ in range(STEPS):
+            (q, t), = eng.infer()
+            top2 = np.sort(eng.last_logits(qid)[-1].astype(np.float32))[-2:]
+            toks.append(int(t)); gap.append(float(top2[1] - top2[0]))
+            assert eng.commit({qid: int(t)})
+        solo.append(toks); gaps.append(gap)
         assert eng.remove_query(qid)
     qids = [eng.add_query(pr) for pr in prompts]
-    outs = {q: [] for q in qids}
-    for _ in range(6):
-        for q, t in eng.infer():
-            outs[q].append(int(t))
-        eng.commit({q: outs[q][-1] for q in qids})
-    for q, ref in zip(qids, solo):
-        assert outs[q] == ref
+    checked = 0
+    for step in range(STEPS):
+        res = {q: int(t) for q, t in eng.infer()}
+        assert sorted(res) == sorted(qids)
+        for i, q in enumerate(qids):
+            if gaps[i][step] > TIE:
+                assert res[q] == solo[i][step], (i, step, gaps[i][step])
+                checked += 1
+        eng.commit({q: solo[i][step] for i, q in enumerate(qids)})
+    assert checked >= (len(qids) * STEPS) // 2, (checked, gaps)
     eng.close()

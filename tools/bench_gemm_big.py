@@ -11,6 +11,8 @@ from inferflow_amd import dtypes as dt
 from tests import gpu_util as g
 L = ia.lib()
 shapes = [(1024, 4096, 4096), (1024, 11008, 4096), (1024, 4096, 11008), (256, 4096, 4096), (512, 11008, 4096), (4096, 4096, 4096), (1000, 4096, 4096)]
+if os.environ.get("IFA_GEMM_SHAPES"):      # "T,rows,cols;T,rows,cols"
+    shapes = [tuple(int(v) for v in sh.split(",")) for sh in os.environ["IFA_GEMM_SHAPES"].split(";")]
 dts = [dt.Q4_B32T1A, dt.Q3H_B64T1, dt.F16] if "--all" in sys.argv else [dt.Q4_B32T1A]
 for d in dts:
     for T, rows, cols in shapes:
