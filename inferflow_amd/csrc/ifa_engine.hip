@@ -178,6 +178,7 @@ struct ifa_model {
     // four parts of K for the products that offer 32..96 tiles, 64 / 96 / 128 tokens run 5 / 8 / 9 % faster than the op-by-op layer
     // (7 products + 4 element-wise launches), 40 tokens the same (profiles/r05_prompt_lengths.log)
     int opt_prefill_big_min = 47;
+    int opt_prefill_chunk = 1;      // prompts of 34..48 tokens as two passes of <= 32 tokens (ifa_model_forward)
     int opt_rows_kparts = 1, opt_gemm_splitk = 1;   // 0: never the launches whose workgroups wait for partner workgroups (K parts of the 9..32-row GEMM, split-K halves of the large-tile GEMM)
     int opt_debug_mo_alloc_fail = 0;           // tests: ensure_mo_build fails like an exhausted allocator after its first copy
     int persist_mode = 0, ps_state = 0;        // ps_state: 0 unknown, 1 usable (copies built), -1 unsupported
@@ -1762,7 +1763,8 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T, con
 
 static bool batch_fused_ok(const ifa_model *m, int n);
 static bool prefill_big_ok(const ifa_model *m);
-static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token)
+// no_head: a chunk of a longer prompt that is not its last one -- the layers only (KV cache rows written), no lm_head / argmax / sync
+static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token, bool no_head = false)
 {
     const ifa_model_config &c = m->cfg;
     if (T <= 0 || prefix_len < 0 || prefix_len + T > c.max_ctx)
@@ -1959,6 +1961,7 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         if (next_token) *next_token = m->host_pinned[0];
         return IFA_OK;
     }
+    if (no_head && !logits_out) return IFA_OK;
     if (scale_on(c.out_scale) && (rc = ifa_scale(x, c.out_scale, (size_t)T * D, x, s))) return rc;
     const half_t *hfin = x;
     if (m->g[T_OUT_NORM].present()) {
@@ -2744,7 +2747,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_big_min", &m->opt_prefill_big_min}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
@@ -2785,6 +2788,19 @@ int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int pr
     IFA_REQUIRE(m && m->finalized, "ifa_model_forward: model not finalized");
     IFA_REQUIRE(tokens_host, "ifa_model_forward: null tokens");
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    // Round 5: prompts of 34..48 tokens as TWO passes of the rows GEMM (32 tokens, then 2..16: the weights stream into registers five
+    // groups deep) instead of one pass of the op-by-op layer: 40 tokens 7.08 -> 6.35 ms, 48 tokens 7.26 -> 6.67 (profiles/r05_prompt_lengths.log;
+    // two passes of 17..32 rows each -- 49..64 tokens -- measured no faster than the tile kernels).  The second pass reads the first
+    // one's K / V rows from the cache like any continued prompt; every row goes through the kernels of a prompt of <= 32 tokens.  Never
+    // a one-token pass: a single row takes the int8 GEMV (the reference's rule for ONE row), which is not how a prompt's rows are computed.
+    if (m->opt_prefill_chunk && !m->topo && n_tokens >= 34 && n_tokens <= 48 && m->cfg.experts == 0 && batch_fused_ok(m, 32)
+        && prefix_len >= 0 && prefix_len + n_tokens <= m->cfg.max_ctx) {
+        const int t1 = 32;
+        const size_t V = m->g[T_LM_HEAD].rows;
+        int rc = forward_ops(m, tokens_host, t1, prefix_len, logits_out_dev, nullptr, true);
+        if (rc) return rc;
+        return forward_ops(m, tokens_host + t1, n_tokens - t1, prefix_len + t1, logits_out_dev ? (char *)logits_out_dev + (size_t)t1 * V * 2 : nullptr, next_token_host);
+    }
     return forward_ops(m, tokens_host, n_tokens, prefix_len, logits_out_dev, next_token_host);
 }
 

@@ -1,0 +1,52 @@
+"""-m gpu: the two prompt routes added in round 5 agree with the routes they replace (same rows, other kernels: agreement within the F16
+rounding of the summation order), on two layers of Llama-2-7B width:
+  * 34..48 tokens: two passes of the rows GEMM (32 + the rest; option prefill_chunk) against the op-by-op layer;
+  * 48..128 tokens: the four large-tile launches per layer (option prefill_big_min 47, with four parts of K for products of 32..96
+    tiles) against the op-by-op layer (prefill_big_min 128)."""
+import numpy as np
+import pytest
+import torch
+
+from inferflow_amd import dtypes as dt, synth
+from tests import gpu_util as g
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(wk, toks, V):
+    lg = torch.empty((len(toks), V), dtype=torch.float16, device="cuda")
+    wk.reset()
+    tok = wk.forward(toks, 0, lg)
+    return int(tok), g.host(lg).astype(np.float32)
+
+
+def _agree(a, b):
+    cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+    return cos >= 0.9999 and float(np.abs(a - b).max()) <= 0.02 * float(b.std()) + 0.01, (cos, float(np.abs(a - b).max()), float(b.std()))
+
+
+@pytest.mark.parametrize("T", [34, 40, 48])
+def test_two_pass_prompt_agrees_with_the_single_pass(T):
+    wk, _, s = synth.build("llama2_7b", dt.Q4_B32T1A, dt.F16, max_ctx=64, layers=2, vocab=2000)
+    toks = np.random.default_rng(T).integers(3, s["vocab"], T).astype(np.int32)
+    out = {}
+    for v in (1, 0):
+        wk.set_option("prefill_chunk", v)
+        out[v] = _rows(wk, toks, s["vocab"])
+    ok, why = _agree(out[1][1], out[0][1])          # ALL rows: the first pass's logits land in rows 0..31, the second's behind them
+    assert ok, why
+    wk.close()
+
+
+@pytest.mark.parametrize("T", [48, 64, 128])
+def test_short_prompt_large_tile_route_agrees_with_the_op_by_op_layer(T):
+    wk, _, s = synth.build("llama2_7b", dt.Q4_B32T1A, dt.F16, max_ctx=160, layers=2, vocab=2000)
+    toks = np.random.default_rng(T).integers(3, s["vocab"], T).astype(np.int32)
+    out = {}
+    wk.set_option("prefill_chunk", 0)
+    for v in (47, 128):
+        wk.set_option("prefill_big_min", v)
+        out[v] = _rows(wk, toks, s["vocab"])
+    ok, why = _agree(out[47][1], out[128][1])
+    assert ok, why
+    wk.close()
