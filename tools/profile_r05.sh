@@ -8,6 +8,7 @@
 #   5. A / B of the options that are still on the default path                                        -> r05_ab_options.log
 #   6. dynamic batching 1..32 queries, Mixtral batch 8                                                -> r05_bench_batch.jsonl, r05_bench_mixtral.json
 #   7. rocprofv3 averages of four 1024-token prefills                                                 -> r05_prefill_1024_kernel_stats.csv
+#   8. prefill by prompt length, default routes                                                        -> r05_prefill_by_prompt_length.log
 set -x
 OUT=$PWD/gpurun_out/prof_r05
 rm -rf $OUT; mkdir -p $OUT
@@ -32,6 +33,7 @@ timeout 600 python bench.py --no-cpu-baseline --shape mixtral_8x7b --batch 8 --s
 IFA_BATCH_SIZES=1,2,4,8,16,17,24,32 timeout 600 python tools/bench_batch.py > $OUT/r05_bench_batch.jsonl 2>> $OUT/bench.err
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pfst -o st -- python $R/tools/prefill_steps.py llama2_7b 1024 4 > $OUT/pfst.log 2>&1)
 head -24 $(find $OUT/pfst -name "*kernel_stats.csv" | head -1) > $OUT/r05_prefill_1024_kernel_stats.csv
+IFA_AB_OPTION=prefill_chunk IFA_BIG_MINS=1 IFA_PROMPT_LENS=16,32,40,48,64,96,128,256,512,1024 timeout 400 python tools/bench_prompt_lens.py 2>&1 | grep "^T=" > $OUT/r05_prefill_by_prompt_length.log
 rm -rf $OUT/stats $OUT/pmc $OUT/pmcq $OUT/pfst
 ls -la $OUT
 tail -3 $OUT/bench.err
