@@ -1795,7 +1795,7 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     // prompts of 2..16 tokens on a dense Q4 model with the sequential RMS wiring: the linears of a layer as FOUR launches of
     // the rows GEMM (ifa_gemm_rows_mfma.hip) -- norm prologue + wq | wk | wv into q / k / v, wo + residual, norm + w1 / w3 +
     // GLU, w2 + residual -- instead of seven products and four element-wise launches (9..16 tokens: the norms stay launches)
-    // Prompts above 128 tokens take the same four launches per layer from the large-tile GEMM (ifa_gemm.hip, k_gemm_big: the
+    // Prompts above `prefill_big_min` tokens (47; round 4: 128) take the same four launches per layer from the large-tile GEMM (ifa_gemm.hip, k_gemm_big: the
     // weights dequantised once per workgroup and step into LDS; reference-layout rows), norms as their own launches.
     const bool pf_big = !tp && T > std::max(32, m->opt_prefill_big_min) && prefill_big_ok(m);
     bool pf_fused = pf_big || (!tp && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
@@ -2157,7 +2157,7 @@ static bool batch_fused_ok(const ifa_model *m, int n)
     return true;
 }
 
-// prompts above 128 tokens as four launches of the large-tile GEMM per layer (forward_ops, pf_big): dense layers with the
+// prompts above `prefill_big_min` tokens as four launches of the large-tile GEMM per layer (forward_ops, pf_big): dense layers with the
 // sequential wiring, every linear a 20-byte-block Q4 tensor (wq / wk / wv of one format), dims in multiples of 64
 static bool prefill_big_ok(const ifa_model *m)
 {
