@@ -50,3 +50,30 @@ def test_short_prompt_large_tile_route_agrees_with_the_op_by_op_layer(T):
     ok, why = _agree(out[47][1], out[128][1])
     assert ok, why
     wk.close()
+
+
+@pytest.mark.parametrize("T", [40, 64, 128])
+def test_short_prompt_routes_match_the_oracle(T):
+    """... and against the ORACLE (the reference's T > 1 rule: F16 activations x dequantised weights, fp32 sums), not only against each
+    other: two layers of Llama-2-7B width, the model read back from the worker, every row of the prompt.  40 tokens = two passes of
+    the rows GEMM, 64 / 128 = the large-tile launches with four parts of K.  Measured (r05): worst row 0.006-0.007 x std(logits) at 2 layers; bound 0.03 x std
+    on every row (the whole-model law of test_gpu_fullsize_oracle would allow 0.08 sqrt(2) = 0.11), cosine >= 0.9999."""
+    from tests import model_util as mu
+    wk, _, s = synth.build("llama2_7b", dt.Q4_B32T1A, dt.F16, max_ctx=160, layers=2, vocab=2000)
+    om = mu.oracle_model_from_worker(wk, s, 160)
+    toks = np.random.default_rng(100 + T).integers(3, s["vocab"], T).astype(np.int32)
+    tok, rows = _rows(wk, toks, s["vocab"])
+    t_or, l_or = om.forward(toks, 0, nthreads=8)
+    ref = l_or.astype(np.float32)
+    std = float(ref.std())
+    worst = 0.0
+    for i in range(T):
+        cos = float((rows[i] * ref[i]).sum() / (np.linalg.norm(rows[i]) * np.linalg.norm(ref[i])))
+        mad = float(np.abs(rows[i] - ref[i]).max())
+        worst = max(worst, mad / std)
+        assert cos >= 0.9999 and mad <= 0.03 * std, (i, cos, mad / std)
+    top2 = np.sort(ref[-1])[-2:]
+    if top2[1] - top2[0] > 0.03 * std:
+        assert tok == int(t_or)
+    print("T=%d worst row %.4f x std" % (T, worst))
+    wk.close()
