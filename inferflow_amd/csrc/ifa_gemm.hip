@@ -792,12 +792,20 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         // are 96 tiles, wo and w2 32 -- a quarter or an eighth of the chip.  Four parts of K per tile when that still fits two
         // workgroups per CU and a part keeps >= 1024 columns: 64 tokens 7.46 -> 7.10 ms, 128 tokens 8.22 -> 7.46 (profiles/r05_prompt_lengths.log)
         const bool splitk4 = may_split && n128 * 2 < cus && n128 * 4 <= 2 * cus && ksteps % 4 == 0 && P.nblk * CAP >= 4096;
+        // Eight waves per tile (2 x 4: two per SIMD take turns in the step's serial chain) up to 512 tokens: 64 / 128 / 256 / 512 tokens
+        // 7.17 / 7.44 / 8.60 / 12.28 -> 6.86 / 7.09 / 8.47 / 12.15 ms, three alternating runs on one box; four waves above (1024 tokens:
+        // 19.0 vs 19.25 ms -- there the tiles are wo / w2 in two halves of K, two workgroups per CU already).  Same products either way.
+        const bool w8 = !force && T <= 512 && CAP <= 32;
+        auto run128 = [&](auto ks) -> int {
+            if (w8) return run(I128(), I128(), I2(), I4(), 0, (int)ntiles(128), K64(), ks);
+            return run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), ks);
+        };
         if constexpr (EPI != GM_GLU) {
             rc = 1;
-            if (splitk4) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), integral_constant<int, 4>());
-            else if (splitk) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), integral_constant<int, 2>());
-            if (rc == 1) rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());      // (no split, or its grid cannot be resident at once)
-        } else rc = run(I128(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());      // (K steps of 128 columns -- BK = 128 -- measured: 57 -> 72 us at 1024 x 4096 x 4096)
+            if (splitk4) rc = run128(integral_constant<int, 4>());
+            else if (splitk) rc = run128(integral_constant<int, 2>());
+            if (rc == 1) rc = run128(S1());      // (no split, or its grid cannot be resident at once)
+        } else rc = run128(S1());      // (K steps of 128 columns -- BK = 128 -- measured: 57 -> 72 us at 1024 x 4096 x 4096)
     }
     if (rc) return rc;
     IFA_LAUNCH_CHECK();
