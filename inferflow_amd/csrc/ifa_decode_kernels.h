@@ -231,6 +231,22 @@ struct XPre {
         }
     }
 
+    // the norm weights alone (ifa_decode_chain.h: the values arrive as granules, gathered into xv by the caller)
+    __device__ __forceinline__ void issue_norm(const half_t *__restrict__ nw, const half_t *__restrict__ nb, int cols)
+    {
+        if constexpr (NORM == 1) {
+            const int chunks = cols >> 3;
+#pragma unroll
+            for (int k = 0; k < MAXC; k++) {
+                const int c = threadIdx.x + k * nthr();
+                if (c < chunks) {
+                    if (nw) wv[k] = *reinterpret_cast<const half8_t *>(nw + (size_t)c * 8);
+                    if (nb) bv[k] = *reinterpret_cast<const half8_t *>(nb + (size_t)c * 8);
+                }
+            }
+        }
+    }
+
     __device__ __forceinline__ void finish(const half_t *__restrict__ nw, const half_t *__restrict__ nb,
                                            float multi_base, float eps, int cols, const XLds &L,
                                            half_t *__restrict__ xn_out, long long *trc = nullptr)
@@ -503,8 +519,8 @@ __device__ __forceinline__ DecRow dec_locate(const DecGemvParams &P, int v)
 // lane-local end of a row: bias, then the epilogue of the fused op sequence
 // res / res2: P.residual[row] / P.residual2[row], requested right behind the row's weights (EPI_RESIDUAL)
 template <int EPI>
-__device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const DecRow d, float a0, float a1, half_t res = (half_t)0,
-                                               half_t res2 = (half_t)0)
+__device__ __forceinline__ half_t dec_row_value(const DecGemvParams &P, const DecRow d, float a0, float a1, half_t res = (half_t)0,
+                                                half_t res2 = (half_t)0)
 {
     const int row = d.row;
     half_t y = dec_bias(a0, d.b0, row);
@@ -532,7 +548,14 @@ __device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const Dec
             if (P.post_scale != 0.0f) y = f2h(h2f(y) * P.post_scale);
         }
     }
-    d.y[row] = y;
+    return y;
+}
+
+template <int EPI>
+__device__ __forceinline__ void dec_finish_row(const DecGemvParams &P, const DecRow d, float a0, float a1, half_t res = (half_t)0,
+                                               half_t res2 = (half_t)0)
+{
+    d.y[d.row] = dec_row_value<EPI>(P, d, a0, a1, res, res2);
 }
 
 // RW = rows (EPI_GLU: row pairs) per wave and pass; rows are strided over the waves

@@ -26,6 +26,7 @@
 #include "ifa_decode_lmhead_tail.h"
 #include "ifa_decode_singles.h"
 #include "ifa_decode_qkv_attn.h"
+#include "ifa_decode_chain.h"
 #include "experimental/ifa_decode_wo_ffn.h"
 
 using namespace ifa;
@@ -134,6 +135,10 @@ struct ifa_model {
     unsigned long long *wf_gran = nullptr;
     void *wf_img = nullptr;                     // the quantised FFN input the front workgroups publish (one buffer: a launch consumes it before the next writes it)
     unsigned *qa_call = nullptr, *qa_err = nullptr, qa_calls = 0;
+    // consecutive GEMV ops of a layer as ONE launch with the next op's rows requested before the hand-off (ifa_decode_chain.h):
+    // option fuse_ffn = 1: W1 | W3 -> W2; 2: Wo -> W1 | W3 -> W2.  ch_on = what the captured step uses.  Granules [layers][dim + ffn].
+    int opt_fuse_ffn = 0, ch_on = 0, opt_chain_late_w2 = 0;
+    uint32_t *ch_gran = nullptr, *ch_flags = nullptr;      // flags [layers][2][CH_FLAGS]
     // the end of the step as one launch (ifa_decode_lmhead_tail.h): lm_head + argmax + state advance + the next step's gather.
     // st_on = what the captured step uses (F16 lm_head with the RMS / no final norm)
     int opt_step_tail = 1, st_on = 0;
@@ -449,8 +454,34 @@ static int qkv_attn_ready(ifa_model *m)
         if (!m->qa_err) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_err, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_err, 0, 16, m->stream)); }
         IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     }
-    if (want != m->qa_on || (want && gk != m->qa_gk) || want_wo != m->qa_wo || want_wf != m->wf_on) {
-        m->qa_on = want; m->qa_gk = gk; m->qa_wo = want_wo; m->wf_on = want_wf; drop_graphs(m);
+    // the chained FFN launch: dense gated FFN behind an RMS pre-norm, sequential wiring, W1 / W3 / W2 (and Wo) of one format with an
+    // instance, one workgroup per CU resident at once
+    int want_ch = (m->opt_fuse_ffn && waits_enabled() && !m->persist_mode && !want_wf && c.norm_kind == 0 && c.tp_size <= 1 && c.experts == 0
+                   && !c.parallel_attn && !c.share_input && num_cus() <= visible_cus()) ? std::min(m->opt_fuse_ffn, 2) : 0;
+    if (want_ch == 2 && (want_wo || !m->attq || !m->opt_attn_q8 || c.head_dim % 32 != 0)) want_ch = 1;
+    for (int l = 0; want_ch && l < c.layers; l++) {
+        const Layer &L = m->layers[(size_t)l];
+        const Tensor &wo = L.t[T_WO], &w1 = L.t[T_W1], &w3 = L.t[T_W3], &w2 = L.t[T_W2];
+        if (!w1.present() || !w1.tiled || !w3.present() || !w3.tiled || !w2.present() || !w2.tiled || !L.t[T_FFN_NORM].present()
+            || (int)w1.cols != c.dim || (int)w2.rows != c.dim || w2.cols != w1.rows || w3.rows != w1.rows || !same_fmt(w1.dtype, w3.dtype)
+            || !dec_chain_supported(w1.dtype, w2.dtype, w1.dtype, c.dim, (int)w1.rows, false, c.dim, num_cus()))
+            want_ch = 0;
+        else if (want_ch == 2 && (!wo.present() || !wo.tiled || (int)wo.rows != c.dim
+                                  || !dec_chain_supported(w1.dtype, w2.dtype, wo.dtype, c.dim, (int)w1.rows, true, (int)wo.cols, num_cus())))
+            want_ch = 1;
+    }
+    if (want_ch && !m->ch_gran) {
+        const size_t n = (size_t)c.layers * (size_t)(c.dim + (int)m->layers[0].t[T_W1].rows);
+        IFA_HIP_CHECK(hipMalloc((void **)&m->ch_gran, n * 4));
+        IFA_HIP_CHECK(hipMemsetAsync(m->ch_gran, 0, n * 4, m->stream));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->ch_flags, (size_t)c.layers * 2 * 1024 * 4));
+        IFA_HIP_CHECK(hipMemsetAsync(m->ch_flags, 0, (size_t)c.layers * 2 * 1024 * 4, m->stream));
+        if (!m->qa_call) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_call, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_call, 0, 16, m->stream)); }
+        if (!m->qa_err) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_err, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_err, 0, 16, m->stream)); }
+        IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    }
+    if (want != m->qa_on || (want && gk != m->qa_gk) || want_wo != m->qa_wo || want_wf != m->wf_on || want_ch != m->ch_on) {
+        m->qa_on = want; m->qa_gk = gk; m->qa_wo = want_wo; m->wf_on = want_wf; m->ch_on = want_ch; drop_graphs(m);
     }
     return IFA_OK;
 }
@@ -769,6 +800,39 @@ static int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial = nullp
     if (scale_on(m->cfg.ffn_out_scale)) P.pre_scale = m->cfg.ffn_out_scale;                               // Scale(ff_out)
     if (l + 1 == m->cfg.layers && scale_on(m->cfg.out_scale)) P.post_scale = m->cfg.out_scale;        // Scale(last layer's output)
     return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
+}
+
+// [Wo ->] W1 | W3 -> W2 of layer l as ONE launch (ifa_decode_chain.h); x = the layer input (Wo's residual), xnext = the layer output
+static int launch_chain(ifa_model *m, int l, const half_t *x, half_t *xnext, unsigned tag_add = 0)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    const bool wo = m->ch_on == 2;
+    DecGemvParams PW; memset(&PW, 0, sizeof(PW));       // launch_wo's EPI_RESIDUAL / NORM 2 parameters
+    if (wo) {
+        PW.x = reinterpret_cast<const half_t *>(m->attq); PW.cols = (int)L.t[T_WO].cols; PW.eps = c.eps;
+        PW.W0[0] = wbytes(L.t[T_WO]); PW.rows[0] = (int)L.t[T_WO].rows;
+        PW.b0[0] = (const half_t *)L.t[T_WO_B].data; PW.y[0] = m->a; PW.residual = x;
+        if (scale_on(c.attn_out_scale)) PW.pre_scale = c.attn_out_scale;
+    }
+    DecGemvParams P; memset(&P, 0, sizeof(P));          // launch_ffn13's dense EPI_GLU, NORM 1 parameters
+    P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
+    P.eps = c.eps; P.cols = c.dim; P.act_kind = c.act_kind; P.multi_base = c.ffn_norm_base;
+    P.W0[0] = wbytes(L.t[T_W1]); P.b0[0] = (const half_t *)L.t[T_W1_B].data; P.y[0] = m->t1; P.rows[0] = (int)L.t[T_W1].rows;
+    P.W1 = wbytes(L.t[T_W3]); P.b1 = (const half_t *)L.t[T_W3_B].data;
+    DecGemvParams Q; memset(&Q, 0, sizeof(Q));          // launch_w2's EPI_RESIDUAL parameters
+    Q.x = m->t1; Q.cols = (int)L.t[T_W2].cols; Q.eps = c.eps;
+    Q.W0[0] = wbytes(L.t[T_W2]); Q.rows[0] = (int)L.t[T_W2].rows; Q.b0[0] = (const half_t *)L.t[T_W2_B].data;
+    Q.y[0] = xnext; Q.residual = m->a;
+    if (scale_on(c.ffn_out_scale)) Q.pre_scale = c.ffn_out_scale;
+    if (l + 1 == c.layers && scale_on(c.out_scale)) Q.post_scale = c.out_scale;
+    DecChainExtra E; memset(&E, 0, sizeof(E));
+    const size_t per = (size_t)c.dim + L.t[T_W1].rows;
+    E.gran_a = m->ch_gran + (size_t)l * per; E.gran_h = E.gran_a + c.dim;
+    E.flags_a = m->ch_flags + (size_t)l * 2048; E.flags_h = E.flags_a + 1024;
+    E.state = m->state; E.epoch = m->qa_call; E.epoch_add = tag_add; E.err = m->qa_err; E.timeout_us = m->opt_fuse_attn_timeout_us;
+    E.trace = g_trace_ptr; E.late_w2 = m->opt_chain_late_w2;
+    return dec_chain_launch(L.t[T_W1].dtype, true, 1, wo, P, Q, wo ? &PW : nullptr, E, num_cus(), m->stream);
 }
 
 // can the step end in the one-launch tail?  (F16 lm_head behind the RMS / no final norm, the embedding table on this worker)
@@ -1285,6 +1349,12 @@ static int enqueue_fused_step(ifa_model *m)
         } else {
             if ((rc = launch_qkv(m, l, x))) return rc;
             if ((rc = launch_attn(m, l))) return rc;
+        }
+        if (m->ch_on) {      // [Wo ->] W1 | W3 -> W2 as one launch
+            if (m->ch_on == 1 && !(m->qa_on && m->qa_wo) && (rc = launch_wo(m, l, x))) return rc;
+            if ((rc = launch_chain(m, l, x, xnext))) return rc;
+            std::swap(x, xnext);
+            continue;
         }
         if (m->wf_on) {
             if ((rc = launch_wo_ffn(m, l, x))) return rc;
@@ -2524,6 +2594,8 @@ int ifa_model_destroy(ifa_model *m)
     if (m->tokens_dev) (void)hipFree(m->tokens_dev);
     if (m->host_pinned) (void)hipHostFree(m->host_pinned);
     if (m->qa_gran) (void)hipFree(m->qa_gran);
+    if (m->ch_gran) (void)hipFree(m->ch_gran);
+    if (m->ch_flags) (void)hipFree(m->ch_flags);
     if (m->qa_call) (void)hipFree(m->qa_call);
     if (m->qa_att_gran) (void)hipFree(m->qa_att_gran);
     if (m->wf_gran) (void)hipFree(m->wf_gran);
@@ -2747,7 +2819,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"chain_late_w2", &m->opt_chain_late_w2}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)
@@ -2865,7 +2937,7 @@ static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps
     if ((rc = step_tail_ready(m))) return rc;
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
-    if (m->qa_on || m->wf_on) {      // the granule tags of this call: (call counter, position) -- consecutive steps never share one
+    if (m->qa_on || m->wf_on || m->ch_on) {      // the granule tags of this call: (call counter, position) -- consecutive steps never share one
         m->qa_calls = (m->qa_calls % 4000u) + 1u;
         m->host_pinned[6] = (int)m->qa_calls;
         IFA_HIP_CHECK(hipMemcpyAsync(m->qa_call, m->host_pinned + 6, sizeof(int), hipMemcpyHostToDevice, s));
@@ -2916,7 +2988,7 @@ static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps
     if (m->persist_mode) IFA_HIP_CHECK(hipMemcpyAsync(perr, m->ps_err, 16, hipMemcpyDeviceToHost, s));
     int *qerr = perr + 4;
     qerr[0] = 0;
-    if (m->qa_on || m->wf_on) IFA_HIP_CHECK(hipMemcpyAsync(qerr, m->qa_err, 4, hipMemcpyDeviceToHost, s));
+    if (m->qa_on || m->wf_on || m->ch_on) IFA_HIP_CHECK(hipMemcpyAsync(qerr, m->qa_err, 4, hipMemcpyDeviceToHost, s));
     th("copies back enqueued");
     IFA_HIP_CHECK(hipStreamSynchronize(s));
     th("stream synchronised");
@@ -2926,11 +2998,11 @@ static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps
         if (elapsed_ms) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
         // the waiting launches go off for this model (and, process-wide, for every model created later): the next call captures the
         // five-launch step, whose kernels wait for nothing
-        m->opt_fuse_attn = 0; m->opt_fuse_wo = 0; m->opt_fuse_wo_ffn = 0;
+        m->opt_fuse_attn = 0; m->opt_fuse_wo = 0; m->opt_fuse_wo_ffn = 0; m->opt_fuse_ffn = 0;
         drop_graphs(m);
         waits_disable("the fused QKV + attention launch timed out waiting for sibling workgroups");
-        return ifa_fail(IFA_ERR_STATE, "fused decode launch: a wait for another workgroup's rows timed out (code 0x%x: 0x5_ q | k | v / attention output, 0x6_ Wo output); "
-                        "the results of this call are not valid -- repeat it: options fuse_attn / fuse_wo / fuse_wo_ffn are off now (five-launch step)", (unsigned)qerr[0]);
+        return ifa_fail(IFA_ERR_STATE, "fused decode launch: a wait for another workgroup's rows timed out (code 0x%x: 0x5_ q | k | v / attention output, 0x6_ Wo output, 0x9_ chained FFN launch); "
+                        "the results of this call are not valid -- repeat it: options fuse_attn / fuse_wo / fuse_wo_ffn / fuse_ffn are off now (five-launch step)", (unsigned)qerr[0]);
     }
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     if (perr[0] != 0) {      // a wait inside the persistent launch gave up: the step's results are not valid
@@ -3444,7 +3516,7 @@ int ifa_model_get_expert_tensor(ifa_model *m, int layer, int expert, int tensor_
 int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
 {
     IFA_REQUIRE(m && m->finalized && avg_us, "ifa_model_time_kernel: bad arguments");
-    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 8, "ifa_model_time_kernel: which %d iters %d", which, iters);
+    IFA_REQUIRE(iters > 0 && which >= 0 && which <= 9, "ifa_model_time_kernel: which %d iters %d", which, iters);
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
     if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
@@ -3469,8 +3541,9 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
         const PsLayer *tab = nullptr;
         if ((rc = persist_table(m, &tab))) return rc;
     }
-    if (which == 7 || which == 8) {      // QKV + attention as one launch; Wo + W1 / W3 as one launch
+    if (which == 7 || which == 8 || which == 9) {      // QKV + attention as one launch; Wo + W1 / W3 as one launch; the chained FFN launch
         if ((rc = qkv_attn_ready(m))) return rc;
+        if (which == 9 && !m->ch_on) return ifa_fail(IFA_ERR_STATE, "chained FFN launch unavailable for this model / option set");
         if (which == 7 && !m->qa_on) return ifa_fail(IFA_ERR_STATE, "fused QKV + attention launch unavailable for this model / option set");
         if (which == 8 && !m->wf_on) return ifa_fail(IFA_ERR_STATE, "fused Wo + FFN launch unavailable for this model / option set");
     }
@@ -3478,6 +3551,7 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
         if (which == 6) return launch_persist(m, 0, m->cfg.layers, m->x, m->x2);
         if (which == 7) return launch_qkv_attn(m, i % m->cfg.layers, m->x, (unsigned)(i + 1));
         if (which == 8) return launch_wo_ffn(m, i % m->cfg.layers, m->x, (unsigned)(i + 1));
+        if (which == 9) return launch_chain(m, i % m->cfg.layers, m->x, m->x2, (unsigned)(i + 1));
         const int l = m->opt_bench_mode == 1 ? 0 : i % m->cfg.layers;     // rotate over layers: distinct weights every launch
         if (m->opt_bench_mode == 2) touch_layer(l);
         switch (which) {
