@@ -184,6 +184,9 @@ struct ifa_model {
     // (7 products + 4 element-wise launches), 40 tokens the same (profiles/r05_prompt_lengths.log)
     int opt_prefill_big_min = 47;
     int opt_prefill_chunk = 1;      // prompts of 34..48 tokens as two passes of <= 32 tokens (ifa_model_forward)
+    // round 6: prompts of prefill_big_min + 1 .. prefill_mid_max tokens take the four launches per layer from k_gemm_mid (ifa_gemm_mid.hip:
+    // ring of direct-to-LDS stages, weights dequantised into the MFMA operand registers) when every linear is Q4_B32T1A / B
+    int opt_prefill_mid = 1, opt_prefill_mid_max = 256;      // (320 tokens and up: the large tiles win again, profiles/r06_prefill_mid_ab.log)
     int opt_rows_kparts = 1, opt_gemm_splitk = 1;   // 0: never the launches whose workgroups wait for partner workgroups (K parts of the 9..32-row GEMM, split-K halves of the large-tile GEMM)
     int opt_debug_mo_alloc_fail = 0;           // tests: ensure_mo_build fails like an exhausted allocator after its first copy
     int persist_mode = 0, ps_state = 0;        // ps_state: 0 unknown, 1 usable (copies built), -1 unsupported
@@ -1874,13 +1877,22 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
         pf_fused = batch_fused_ok(m, T);          // (ensure_mo may have switched the copies off: ask again, see forward_batch)
     }
     if (pf_big && (rc = ensure_x32(m))) return rc;
+    // the mid-length kernel: every linear of every layer a 20-byte-block Q4 tensor with its tiled copy, dense FFN
+    bool pf_mid = pf_big && m->opt_prefill_mid && m->opt_rows_mo && T <= m->opt_prefill_mid_max && c.experts == 0;
+    if (pf_mid && (rc = ensure_mo(m))) return rc;
+    for (int l = 0; l < c.layers && pf_mid; l++) {
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids) { const Tensor &t = m->layers[(size_t)l].t[id]; if (!t.present() || !t.mo || t.cols % 128 != 0 || t.rows % 16 != 0) pf_mid = false; }
+    }
     for (int l = 0; l < c.layers && pf_fused; l++) {
         Layer &L = m->layers[l];
         const size_t F = c.ffn;
         const bool norm_fused = !pf_big && (T <= 8 || rows_mo(m, L.t[T_WQ])) && T <= 16;
-        auto wp = [&](int id) { return pf_big ? (const uint8_t *)(L.t[id].x32 ? L.t[id].x32 : L.t[id].data) : rows_w(m, L.t[id]); };
-        const int mo_flag = pf_big ? 0 : rows_mo(m, L.t[T_WQ]);
+        auto wp = [&](int id) { return pf_mid ? (const uint8_t *)L.t[id].mo : (pf_big ? (const uint8_t *)(L.t[id].x32 ? L.t[id].x32 : L.t[id].data) : rows_w(m, L.t[id])); };
+        const int mo_flag = pf_mid ? 1 : (pf_big ? 0 : rows_mo(m, L.t[T_WQ]));
         auto lin = [&](const GmArgs &A, int id, int epi, int norm) {
+            if (pf_mid && gemm_mid_ok(L.t[id].dtype, A, epi)) return gemm_mid(A, epi, m->stream);
+            if (pf_mid) return ifa_fail(IFA_ERR_STATE, "mid-length GEMM declined a product of layer tensor %d", id);
             return pf_big ? gemm_big(L.t[id].x32 ? (int)Q4_B32T1A : L.t[id].dtype, A, epi, m->stream) : gemm_rows_mfma_launch(A, epi, norm, m->stream);
         };
         Tensor nob;
@@ -2044,6 +2056,13 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
     const size_t V = lm.rows;                        // (this rank's vocabulary shard under tensor parallelism)
     int t0 = logits_out ? 0 : T - 1;
     if (logits_out) { if ((rc = matmul(m, hfin, T, lm, none, m->logits))) return rc; }
+    else if (lm.dtype == F16 && D % 8 == 0 && D <= 8192) {
+        // the last row only: the decode step's lm_head kernel on the normalised row (same per-row chain as the op-level GEMV --
+        // bit-identical logits -- at 6 TB/s instead of 1.1: 232 -> 45 us per prompt, rocprofv3 r06)
+        DecLmHeadParams H2; memset(&H2, 0, sizeof(H2));
+        H2.x = hfin + (size_t)t0 * D; H2.eps = c.eps; H2.cols = (int)D; H2.W = (const half_t *)lm.data; H2.logits = m->logits + (size_t)t0 * V; H2.rows = (int)V;
+        if ((rc = launch_lmhead(H2, 0, m->opt_rpw_lm, m->stream))) return rc;
+    }
     else { if ((rc = matmul(m, hfin + (size_t)t0 * D, 1, lm, none, m->logits + (size_t)t0 * V))) return rc; }
     if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
     if (tp) {                // distributed argmax of the last row over the group's shards (+ announcement to the other groups)
@@ -2819,7 +2838,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"chain_late_w2", &m->opt_chain_late_w2}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"chain_late_w2", &m->opt_chain_late_w2}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)

@@ -370,7 +370,7 @@ typedef const __attribute__((address_space(1))) void pf_glb_t;
 // fp32 accumulators go through memory (write-through stores, one flag per tile) to the workgroup of the second half, which adds them
 // IN THAT ORDER (first half + second half: deterministic) and runs the epilogue.  The grid lists all first halves, then all second
 // halves: a second half is never resident before its first half.  part / flags: per-stream scratch of the launcher.
-struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; unsigned long long *part; unsigned *flags; unsigned *err; };
+// (BigGeo: ifa_gemm_big.h)
 
 template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN, int BK = PF_BK, int KS = 1>
 __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const BigGeo G)
@@ -681,7 +681,8 @@ constexpr size_t SPLITK_FLAG_BYTES = 16384;      // one counter per tile, in fro
 struct SplitKScratch { void *p = nullptr; size_t bytes = 0; };
 static std::mutex g_splitk_mu;
 static std::map<std::pair<int, hipStream_t>, SplitKScratch> g_splitk;
-static int gemm_splitk_scratch(hipStream_t s, size_t part_bytes, size_t tiles, void **out)
+namespace ifa { int gemm_splitk_scratch(hipStream_t s, size_t part_bytes, size_t tiles, void **out); }
+int ifa::gemm_splitk_scratch(hipStream_t s, size_t part_bytes, size_t tiles, void **out)
 {
     int dev = 0;
     IFA_HIP_CHECK(hipGetDevice(&dev));
@@ -759,7 +760,7 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
     using std::integral_constant;
     typedef integral_constant<int, 256> I256; typedef integral_constant<int, 128> I128; typedef integral_constant<int, 2> I2; typedef integral_constant<int, 4> I4; typedef integral_constant<int, 64> K64;
     typedef integral_constant<int, 1> S1;
-    const int force = (g_gemm_big >> 8) & 3;        // (measurement: 1 / 2 / 3 force a tile shape)
+    const int force = (g_gemm_big >> 8) & 7;        // (measurement: 1 / 2 / 3 force a tile shape; 4 / 5 / 6: the small tiles below)
     auto rounds = [&](size_t bm, size_t bn, size_t per_cu) { return (double)ifa_cdiv(ifa_cdiv(T, bm) * ntiles(bn), cus * per_cu); };
     // 256 x 256: whole rounds of the chip; what is left of the last round goes to a second launch of 128-token tiles when
     // those fit the chip in one go (1024 tokens x 11008 GLU pairs: 86 weight tiles = 64 x 4 workgroups + 22 x 8)
@@ -773,7 +774,11 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
     int pick = force;
     if (!pick) pick = (c256 <= c128x256 && c256 <= c128) ? 1 : (c128x256 <= c128 ? 2 : 3);
     int rc = IFA_OK;
-    if (pick == 1 && CAP <= 32) {
+    typedef integral_constant<int, 64> I64;
+    if (pick == 4 && CAP <= 32) rc = run(I64(), I64(), I2(), I2(), 0, (int)ntiles(64), K64(), S1());
+    else if (pick == 5 && CAP <= 32) rc = run(I128(), I64(), I2(), I2(), 0, (int)ntiles(64), K64(), S1());
+    else if (pick == 6 && CAP <= 32) rc = run(I64(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());
+    else if (pick == 1 && CAP <= 32) {
         if (split && !force) {
             rc = run(I256(), I256(), I2(), I4(), 0, (int)full_n, K64(), S1());
             if (!rc) rc = run(I128(), I256(), I2(), I4(), (int)full_n, (int)rem_n, K64(), S1());
