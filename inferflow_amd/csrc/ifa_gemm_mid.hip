@@ -49,6 +49,9 @@ constexpr int MD_STAGE = MD_A_BYTES + MD_WC_BYTES + MD_WS_BYTES;    // 21 KB
 #ifndef IFA_MID_ABL
 #define IFA_MID_ABL 0
 #endif
+#ifndef IFA_MID_WAUX
+#define IFA_MID_WAUX 0       // cache policy of the weight requests (2 = non-temporal)
+#endif
 constexpr int MD_VM = IFA_MID_ABL == 1 ? 2 : (IFA_MID_ABL == 5 ? 4 : 6);                     // direct-to-LDS requests per wave and stage: 4 (activations) + 2 (weights)
 
 __device__ __forceinline__ md_u4 md_lds_b128(uint32_t addr) { md_u4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; }
@@ -114,19 +117,28 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
         wsrc = Wm + (size_t)tile16 * mo_tile + (size_t)(lane & 31) * 16;
         wsbs = wsrc + (size_t)nsup * 1024;
     }
-    auto issue = [&](int step, int slot) {
+    // the six requests of a stage, one at a time (piece 0..3: activation rows, 4: codes, 5: (base, scale) words): the main loop places
+    // them between its MFMAs
+    auto issue_piece = [&](int step, int slot, int piece) {
         char *st = smem + (size_t)slot * MD_STAGE;
+        if (piece < 4) {
 #if IFA_MID_ABL != 1
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            __builtin_amdgcn_global_load_lds((md_glb_t *)(xsrc[j] + (size_t)(s0 + step) * BK), (md_lds_t *)(st + (size_t)(wave * 4 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((md_glb_t *)(xsrc[piece] + (size_t)(s0 + step) * BK), (md_lds_t *)(st + (size_t)(wave * 4 + piece) * 1024), 16, 0, 0);
 #endif
+            return;
+        }
 #if IFA_MID_ABL != 5
         const int S = (s0 + step) >> 1, half = (s0 + step) & 1;
-        __builtin_amdgcn_global_load_lds((md_glb_t *)(wsrc + (size_t)S * 1024 + (size_t)half * 512), (md_lds_t *)(st + MD_A_BYTES + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((md_glb_t *)(wsbs + (size_t)(S >> 2) * 1024 + (size_t)half * 512 + (size_t)(S & 3) * 4),
-                                         (md_lds_t *)(st + MD_A_BYTES + MD_WC_BYTES + wave * 256), 4, 0, 0);
+        if (piece == 4)
+            __builtin_amdgcn_global_load_lds((md_glb_t *)(wsrc + (size_t)S * 1024 + (size_t)half * 512), (md_lds_t *)(st + MD_A_BYTES + wave * 1024), 16, 0, IFA_MID_WAUX);
+        else
+            __builtin_amdgcn_global_load_lds((md_glb_t *)(wsbs + (size_t)(S >> 2) * 1024 + (size_t)half * 512 + (size_t)(S & 3) * 4),
+                                             (md_lds_t *)(st + MD_A_BYTES + MD_WC_BYTES + wave * 256), 4, 0, IFA_MID_WAUX);
 #endif
+    };
+    auto issue = [&](int step, int slot) {
+#pragma unroll
+        for (int pc = 0; pc < 6; pc++) issue_piece(step, slot, pc);
     };
 
     // ---- per-lane LDS offsets: lane (i, g) reads token row i of a 32-row tile, chunk 2 ks + g; weight row i of its wave
@@ -158,65 +170,76 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
         __builtin_amdgcn_s_barrier();
 #endif
         asm volatile("" ::: "memory");
-        {
-            const int nslot = slot == 0 ? NS - 1 : slot - 1;
-            issue(min(step + NS - 1, nsteps - 1), nslot);
-        }
+        const int nslot = slot == 0 ? NS - 1 : slot - 1, nstep = min(step + NS - 1, nsteps - 1);      // the stage requested during this step
         const uint32_t sb = (uint32_t)(slot * MD_STAGE);
-        // every LDS read of the step goes out at once (one wait instead of four: a wave alone on its SIMD paid the LDS round trip per
-        // 16-column group), then the step is VALU + MFMA only: the codes of group ks + 1 are dequantised between the MFMAs of group ks
+        // A wave alone on its SIMD issues in order: request issue (6 x ~80 cycles), the 19 LDS reads and their latency, the conversion and
+        // the MFMAs ran one after the other (0.65 us per step, IFA_MID_TRACE; the MFMAs alone are 0.21).  Now only the raw weights and the
+        // first group's activation fragments are read in front of the MFMAs; the other groups' fragments, the next stage's requests and
+        // the next group's conversion go BETWEEN the MFMAs (sched_barrier pins the order).
         md_u4 cw[2]; md_u2 sw; md_u4 fa[4][TA];
         cw[0] = md_lds_b128(wc_off + sb);
         cw[1] = md_lds_b128(wc_off + sb + 256);
         sw[0] = md_lds_b32(ws_off + sb);
         sw[1] = md_lds_b32(ws_off + sb + 64);
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-            for (int a = 0; a < TA; a++) fa[ks][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((2 * ks) ^ lc) << 4));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw[0]), "+v"(cw[1]), "+v"(sw),
-                     "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
-                     "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[2][2]), "+v"(fa[2][3]), "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fa[3][2]), "+v"(fa[3][3]));
-        // this lane's 8 weights of group ks: chunk 2 (ks % 2) + g of block ks / 2
-        auto dq = [&](int ks) {
+        for (int a = 0; a < TA; a++) fa[0][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((0) ^ lc) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw[0]), "+v"(cw[1]), "+v"(sw), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]));
+        // this lane's 8 weights of group ks: chunk 2 (ks % 2) + g of block ks / 2 -- value half(fma(q, scale, base)), q4x8_dequant's
+        // arithmetic (ifa_dequant_q4.h) in four pieces
+        uint32_t d_lo = 0, d_hi = 0; q4_f2 d_s2 = {0, 0}, d_b2 = {0, 0}, d_e02 = {0, 0}, d_e46 = {0, 0}, d_o13 = {0, 0}, d_o57 = {0, 0};
+        auto dq_a = [&](int ks) {
             const int h = ks >> 1;
             const uint32_t sbw = sw[h];
-            const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale = hbits2f((uint16_t)(sbw >> 16));
+            const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale = hbits2f((uint16_t)(sbw >> 16)) * fp8_up;
             const uint32_t c_lo = cw[h][2 * (ks & 1)], c_hi = cw[h][2 * (ks & 1) + 1];      // (scalars first: one select, not an indexed element read)
             const uint32_t code = g ? c_hi : c_lo;
-            q4_h2 w4[4];
-#if IFA_MID_ABL == 3
-            w4[0] = w4[1] = w4[2] = w4[3] = __builtin_bit_cast(q4_h2, code ^ sbw);
-#else
-            q4x8_dequant(code, scale * fp8_up, base, w4);
-#endif
-            md_h8 fb;
-#pragma unroll
-            for (int e = 0; e < 4; e++) { fb[2 * e] = w4[e][0]; fb[2 * e + 1] = w4[e][1]; }
-            return fb;
+            d_lo = code & 0x0F0F0F0Fu; d_hi = (code >> 4) & 0x0F0F0F0Fu;
+            d_s2 = q4_f2{scale, scale}; d_b2 = q4_f2{base, base};
         };
-        md_h8 fb[4];
-        fb[0] = dq(0);
+        auto dq_b = [&]() {
+            d_e02 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)d_lo, false), d_s2, d_b2);
+            d_e46 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)d_lo, true), d_s2, d_b2);
+        };
+        auto dq_c = [&]() {
+            d_o13 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)d_hi, false), d_s2, d_b2);
+            d_o57 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)d_hi, true), d_s2, d_b2);
+        };
+        auto dq_d = [&]() {
+            const q4_h2 w0 = __builtin_convertvector(q4_f2{d_e02[0], d_o13[0]}, q4_h2), w1 = __builtin_convertvector(q4_f2{d_e02[1], d_o13[1]}, q4_h2);
+            const q4_h2 w2 = __builtin_convertvector(q4_f2{d_e46[0], d_o57[0]}, q4_h2), w3 = __builtin_convertvector(q4_f2{d_e46[1], d_o57[1]}, q4_h2);
+            return md_h8{w0[0], w0[1], w1[0], w1[1], w2[0], w2[1], w3[0], w3[1]};
+        };
+        auto frag = [&](int ks, int a) { fa[ks][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((2 * ks) ^ lc) << 4)); };
+        md_h8 fbc, fbn;
+        dq_a(0); dq_b(); dq_c(); fbc = dq_d();
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            if (ks < 3) fb[ks + 1] = dq(ks + 1);
 #if IFA_MID_ABL == 2
 #pragma unroll
-            for (int a = 0; a < TA; a++) acc[a][ks] += (float)fb[ks][a] * (float)__builtin_bit_cast(md_h8, fa[ks][a])[0];
+            for (int a = 0; a < TA; a++) acc[a][ks] += (float)fbc[a] * (float)__builtin_bit_cast(md_h8, fa[ks][a])[0];
+            if (ks < 3) { dq_a(ks + 1); dq_b(); dq_c(); fbn = dq_d(); for (int a = 0; a < TA; a++) frag(ks + 1, a); }
+            if (ks < 3) { issue_piece(nstep, nslot, 2 * ks); issue_piece(nstep, nslot, 2 * ks + 1); }
 #else
-#pragma unroll
-            for (int a = 0; a < TA; a++)
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][a]), fb[ks], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][0]), fbc, acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 3) { frag(ks + 1, 0); frag(ks + 1, 1); dq_a(ks + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][1]), fbc, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 3) { frag(ks + 1, 2); frag(ks + 1, 3); dq_b(); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][2]), fbc, acc[2], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 3) { dq_c(); issue_piece(nstep, nslot, 2 * ks); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][3]), fbc, acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 3) { fbn = dq_d(); issue_piece(nstep, nslot, 2 * ks + 1); }
 #endif
-#ifndef IFA_MID_NO_SCHED
-            if (ks < 3) {      // one MFMA, then a quarter of the next group's conversion, four times (cdna_hip_programming.md T19)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // VALU
-                }
-            }
-#endif
+            if (ks < 3)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks + 1][0]), "+v"(fa[ks + 1][1]), "+v"(fa[ks + 1][2]), "+v"(fa[ks + 1][3]));
+            fbc = fbn;
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
