@@ -243,7 +243,12 @@ enum {
     IFA_T_EMBD = 0, IFA_T_OUT_NORM = 1, IFA_T_OUT_NORM_B = 2, IFA_T_LM_HEAD = 3,
     IFA_T_ATTN_NORM = 10, IFA_T_ATTN_NORM_B = 11, IFA_T_WQ = 12, IFA_T_WK = 13, IFA_T_WV = 14, IFA_T_WO = 15,
     IFA_T_FFN_NORM = 16, IFA_T_FFN_NORM_B = 17, IFA_T_W1 = 18, IFA_T_W2 = 19, IFA_T_W3 = 20, IFA_T_MOE_GATE = 21,
-    IFA_T_WQ_B = 22, IFA_T_WK_B = 23, IFA_T_WV_B = 24, IFA_T_WO_B = 25, IFA_T_W1_B = 26, IFA_T_W2_B = 27, IFA_T_W3_B = 28
+    IFA_T_WQ_B = 22, IFA_T_WK_B = 23, IFA_T_WV_B = 24, IFA_T_WO_B = 25, IFA_T_W1_B = 26, IFA_T_W2_B = 27, IFA_T_W3_B = 28,
+    /* self_attn.post_norm / feed_forward.post_norm (+ biases): StdDeviceNetwork::AttentionLayer::post_norm, FeedForwardLayer::post_norm
+     * (src/transformer/model.h:168-276); applied by ProcessGpuLayer (inference_worker.cc:857-866, 954-965).  Models that carry them take
+     * the op-by-op layer (the fused decode / prompt launches decline).  ModelSpec::is_attn_post_as_residual (model.h:113, default
+     * true) is the model option "attn_post_as_residual". */
+    IFA_T_ATTN_POST_NORM = 29, IFA_T_ATTN_POST_NORM_B = 30, IFA_T_FFN_POST_NORM = 31, IFA_T_FFN_POST_NORM_B = 32
 };
 
 int ifa_model_create(const ifa_model_config *cfg, ifa_model **out);

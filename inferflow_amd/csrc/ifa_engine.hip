@@ -37,7 +37,8 @@ enum { T_EMBD = 0, T_OUT_NORM = 1, T_OUT_NORM_B = 2, T_LM_HEAD = 3,
        T_ATTN_NORM = 10, T_ATTN_NORM_B = 11, T_WQ = 12, T_WK = 13, T_WV = 14, T_WO = 15,
        T_FFN_NORM = 16, T_FFN_NORM_B = 17, T_W1 = 18, T_W2 = 19, T_W3 = 20, T_MOE_GATE = 21,
        T_WQ_B = 22, T_WK_B = 23, T_WV_B = 24, T_WO_B = 25, T_W1_B = 26, T_W2_B = 27, T_W3_B = 28,
-       T_MAX = 32 };
+       T_ATTN_POST_NORM = 29, T_ATTN_POST_NORM_B = 30, T_FFN_POST_NORM = 31, T_FFN_POST_NORM_B = 32,      // self_attn.post_norm / feed_forward.post_norm (model.h:168-276)
+       T_MAX = 36 };
 
 struct Tensor {
     int dtype = -1;
@@ -168,6 +169,9 @@ struct ifa_model {
     } tp_key;
     const ifa_tp_topology *topo = nullptr;     // set by the partition entry points for the duration of a T > 1 / batched step
     size_t tp_rows_cap = 0;                    // rows the distributed-argmax scratch (tp_best / tp_gather / tp_tok) holds
+    // is_attn_post_as_residual (model.h:113, default true): with an attention post-norm, the FFN's residual is the NORMALISED tensor
+    int opt_attn_post_as_residual = 1;
+    half_t *pn = nullptr;           // [tokens][dim] scratch of the post norms (allocated with the other activations)
     int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
     // persistent decode layers (ifa_decode_persist.h): all layers of a token as ONE launch, bit-identical to the five-launch
     // layer.  Opt-in (option "persist"): measured on MI355X it is SLOWER than five launches for this workload (55 vs 43.5 us
@@ -324,11 +328,19 @@ static int launch_lmhead(const DecLmHeadParams &P, int norm, int wgs_per_cu_opt,
     return IFA_OK;
 }
 
+// self_attn.post_norm / feed_forward.post_norm (OPT / BERT-style specs): the op-by-op layer only (layer_tail_ops)
+static bool has_post_norms(const ifa_model *m)
+{
+    for (const Layer &L : m->layers) if (L.t[T_ATTN_POST_NORM].present() || L.t[T_FFN_POST_NORM].present()) return true;
+    return false;
+}
+
 // Can the fused decode path run this model?  (otherwise decode falls back to forward())
 static bool fused_supported(const ifa_model *m, std::string *why)
 {
     const ifa_model_config &c = m->cfg;
     auto fail = [&](const char *s) { if (why) *why = s; return false; };
+    if (has_post_norms(m)) return fail("post norms (self_attn.post_norm / feed_forward.post_norm) use the op-by-op path");
     if (c.experts > 64 || (c.experts > 0 && (c.moe_top_k < 1 || c.moe_top_k > 8))) return fail("MoE: experts / top_k out of range");
     if ((scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) && c.tp_size > 1)
         return fail("output scales (attn_out_scale / ffn_out_scale / out_scale) on a partitioned model use the op-by-op path");
@@ -1401,7 +1413,7 @@ static int ensure_scratch(ifa_model *m, int T)
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
     size_t maxcols = std::max(std::max(D, QD), F);
     int rc;
-    if ((rc = re(m->x, T * D)) || (rc = re(m->x2, T * D)) || (rc = re(m->xn, T * D)) || (rc = re(m->hn, T * D))
+    if ((rc = re(m->x, T * D)) || (rc = re(m->x2, T * D)) || (rc = re(m->xn, T * D)) || (rc = re(m->hn, T * D)) || (rc = re(m->pn, T * D))
         || (rc = re(m->q, T * QD)) || (rc = re(m->k, T * KVD)) || (rc = re(m->v, T * KVD)) || (rc = re(m->att, T * QD))
         || (rc = re(m->a, T * D)) || (rc = re(m->f, T * D)) || (rc = re(m->t1, std::max<size_t>(T, 3) * F)) || (rc = re(m->t2, T * F))
         || (rc = re(m->logits, (size_t)T * c.vocab)))
@@ -1834,6 +1846,79 @@ static int moe_ffn_device(ifa_model *m, Layer &L, const half_t *ff_n, int T, con
     return moe_combine(m->moe_gout, m->moe_epos, m->moe_selw, T, K, (int)D, out ? out : m->f, m->stream, residual);
 }
 
+// Everything of a layer behind the attention product in m->a (bias added / shards merged): TensorOpr::Scale of the attention
+// output, the residual wiring, the optional post norms, the FFN (dense or mixture of experts) and the adds in front of what
+// follows -- ProcessGpuLayer, inference_worker.cc:841-965.  Shared by the prompt path and the batched step.  x: the layer
+// input (on return: the layer output, m->x / m->f exchanged); attn_in: the attention's normalised input (parallel attention feeds
+// it to the FFN); xn_ready: m->xn holds the next norm's output already (fused into the last Add).
+//   self_attn.post_norm (:857-866): residual = a (+ x); a' = Norm(residual); the FFN reads a'; is_attn_post_as_residual picks a' as
+//   the residual too.  feed_forward.post_norm (:954-965): the layer output is Norm(ffn out + residual [+ x]).
+static int layer_tail_ops(ifa_model *m, int l, int T, half_t *&x, const half_t *attn_in, bool &xn_ready)
+{
+    const ifa_model_config &c = m->cfg;
+    Layer &L = m->layers[(size_t)l];
+    ifa_stream s = m->stream;
+    const size_t D = c.dim;
+    const Tensor none;
+    const bool merging = tp_merging(m), seq_wiring = !c.parallel_attn && !c.share_input;
+    const bool a_post = L.t[T_ATTN_POST_NORM].present(), f_post = L.t[T_FFN_POST_NORM].present();
+    int rc;
+    if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
+    const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
+    const half_t *ff_n = ff_in;
+    const half_t *residual = m->a;
+    if (a_post) {
+        if (seq_wiring && (rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
+        if ((rc = norm_rows(m, m->a, T, L.t[T_ATTN_POST_NORM], L.t[T_ATTN_POST_NORM_B], m->pn, 0.0f))) return rc;
+        if (m->opt_attn_post_as_residual) residual = m->pn;
+        if (!c.parallel_attn && !c.share_input) ff_in = m->pn;
+        ff_n = ff_in;
+        if (L.t[T_FFN_NORM].present()) {
+            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
+            ff_n = m->hn;
+        }
+    } else if (seq_wiring && L.t[T_FFN_NORM].present()) {          // Add(x, attn out) + ffn norm
+        if ((rc = ifa_add_layernorm(c.norm_kind, x, m->a, (size_t)T, D, L.t[T_FFN_NORM].data, L.t[T_FFN_NORM_B].present() ? L.t[T_FFN_NORM_B].data : nullptr,
+                                    c.ffn_norm_base, c.eps, m->a, m->hn, s))) return rc;
+        ff_n = m->hn;
+    } else {
+        if (seq_wiring && (rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
+        if (L.t[T_FFN_NORM].present()) {
+            if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
+            ff_n = m->hn;
+        }
+    }
+    if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
+        if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
+        if ((rc = tp_merge_rows(m, m->f, T, none))) return rc;          // every expert sliced like the dense FFN: one merge of the weighted sums
+    } else {
+        if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], merging ? none : L.t[T_W2_B], m->f))) return rc;
+        if ((rc = tp_merge_rows(m, m->f, T, L.t[T_W2_B]))) return rc;
+    }
+    if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
+    // Add(ffn out, residual) + the norm in front of what comes next: the next layer's attention norm, or the output norm
+    const bool last_layer = l + 1 == c.layers;
+    const Tensor &nw = last_layer ? m->g[T_OUT_NORM] : m->layers[(size_t)l + 1].t[T_ATTN_NORM];
+    const Tensor &nb = last_layer ? m->g[T_OUT_NORM_B] : m->layers[(size_t)l + 1].t[T_ATTN_NORM_B];
+    xn_ready = false;
+    if (!a_post && !f_post && seq_wiring && nw.present() && !(last_layer && scale_on(c.out_scale))) {
+        if ((rc = ifa_add_layernorm(c.norm_kind, m->f, m->a, (size_t)T, D, nw.data, nb.present() ? nb.data : nullptr,
+                                    last_layer ? c.out_norm_base : c.attn_norm_base, c.eps, m->f, m->xn, s))) return rc;
+        xn_ready = true;
+    } else {
+        if ((rc = ifa_add(m->f, residual, (size_t)T * D, 0, m->f, s))) return rc;
+        if (c.parallel_attn || c.share_input)
+            if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
+        if (f_post) {
+            if ((rc = norm_rows(m, m->f, T, L.t[T_FFN_POST_NORM], L.t[T_FFN_POST_NORM_B], m->hn, 0.0f))) return rc;
+            std::swap(m->f, m->hn);
+        }
+    }
+    std::swap(m->x, m->f);
+    x = m->x;
+    return IFA_OK;
+}
+
 static bool batch_fused_ok(const ifa_model *m, int n);
 static bool prefill_big_ok(const ifa_model *m);
 // no_head: a chunk of a longer prompt that is not its last one -- the layers only (KV cache rows written), no lm_head / argmax / sync
@@ -1996,43 +2081,7 @@ static int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_l
                                 c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
         if ((rc = matmul(m, m->att, T, L.t[T_WO], merging ? none : L.t[T_WO_B], m->a))) return rc;
         if ((rc = tp_merge_rows(m, m->a, T, L.t[T_WO_B]))) return rc;       // BY_TENSOR: sum of the ranks' partial products, bias after
-        if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
-        const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
-        const half_t *ff_n = ff_in;
-        if (seq_wiring && L.t[T_FFN_NORM].present()) {          // Add(x, attn out) + ffn norm
-            if ((rc = ifa_add_layernorm(c.norm_kind, x, m->a, (size_t)T, D, L.t[T_FFN_NORM].data, L.t[T_FFN_NORM_B].present() ? L.t[T_FFN_NORM_B].data : nullptr,
-                                        c.ffn_norm_base, c.eps, m->a, m->hn, s))) return rc;
-            ff_n = m->hn;
-        } else {
-            if (seq_wiring && (rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
-            if (L.t[T_FFN_NORM].present()) {
-                if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
-                ff_n = m->hn;
-            }
-        }
-        if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
-            if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
-            if ((rc = tp_merge_rows(m, m->f, T, none))) return rc;          // every expert sliced like the dense FFN: one merge of the weighted sums
-        } else {
-            if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], merging ? none : L.t[T_W2_B], m->f))) return rc;
-            if ((rc = tp_merge_rows(m, m->f, T, L.t[T_W2_B]))) return rc;
-        }
-        if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
-        // Add(ffn out, a) + the norm in front of what comes next: the next layer's attention norm, or the output norm
-        const bool last_layer = l + 1 == c.layers;
-        const Tensor &nw = last_layer ? m->g[T_OUT_NORM] : m->layers[l + 1].t[T_ATTN_NORM];
-        const Tensor &nb = last_layer ? m->g[T_OUT_NORM_B] : m->layers[l + 1].t[T_ATTN_NORM_B];
-        if (seq_wiring && nw.present() && !(last_layer && scale_on(c.out_scale))) {
-            if ((rc = ifa_add_layernorm(c.norm_kind, m->f, m->a, (size_t)T, D, nw.data, nb.present() ? nb.data : nullptr,
-                                        last_layer ? c.out_norm_base : c.attn_norm_base, c.eps, m->f, m->xn, s))) return rc;
-            xn_ready = true;
-        } else {
-            if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
-            if (c.parallel_attn || c.share_input)
-                if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
-        }
-        std::swap(m->x, m->f);
-        x = m->x;
+        if ((rc = layer_tail_ops(m, l, T, x, attn_in, xn_ready))) return rc;
     }
     if (!last_stage) {       // BY_LAYER / HYBRID: hand the [T][dim] output to the next device group, then learn the token
         if ((rc = ifa_send(tp->world, x, (size_t)T * D * 2, tp->next_rank, s))) return rc;
@@ -2225,6 +2274,7 @@ static bool batch_fused_ok(const ifa_model *m, int n)
 {
     const ifa_model_config &c = m->cfg;
     if (!m->opt_batch_fused || !m->opt_gemm_rows || !gemm_rows_use_mfma() || n < 2 || n > (m->opt_rows_mo ? 32 : 16) || m->topo) return false;      // (17..32 rows: MO copies only)
+    if (has_post_norms(m)) return false;
     if (c.norm_kind != 0 || c.parallel_attn || c.share_input) return false;
     if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) return false;
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim, F = c.ffn;
@@ -2251,7 +2301,7 @@ static bool batch_fused_ok(const ifa_model *m, int n)
 static bool prefill_big_ok(const ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
-    if (!m->opt_prefill_big || m->topo || c.parallel_attn || c.share_input) return false;
+    if (!m->opt_prefill_big || m->topo || c.parallel_attn || c.share_input || has_post_norms(m)) return false;
     if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale)) return false;
     const size_t D = c.dim, QD = (size_t)c.heads * c.head_dim, F = c.ffn;
     if (D % 64 || QD % 64 || F % 64) return false;
@@ -2467,42 +2517,7 @@ static int forward_batch(ifa_model *m, int n, const int *tokens_host, const int 
                                      c.use_alibi, c.tp_rank * c.heads, c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
         if ((rc = matmul(m, m->att, T, L.t[T_WO], merging ? none : L.t[T_WO_B], m->a))) return rc;
         if ((rc = tp_merge_rows(m, m->a, T, L.t[T_WO_B]))) return rc;
-        if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
-        const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
-        const half_t *ff_n = ff_in;
-        if (seq_wiring && L.t[T_FFN_NORM].present()) {
-            if ((rc = ifa_add_layernorm(c.norm_kind, x, m->a, (size_t)T, D, L.t[T_FFN_NORM].data, L.t[T_FFN_NORM_B].present() ? L.t[T_FFN_NORM_B].data : nullptr,
-                                        c.ffn_norm_base, c.eps, m->a, m->hn, s))) return rc;
-            ff_n = m->hn;
-        } else {
-            if (seq_wiring && (rc = ifa_add(x, m->a, (size_t)T * D, 0, m->a, s))) return rc;
-            if (L.t[T_FFN_NORM].present()) {
-                if ((rc = norm_rows(m, ff_in, T, L.t[T_FFN_NORM], L.t[T_FFN_NORM_B], m->hn, c.ffn_norm_base))) return rc;
-                ff_n = m->hn;
-            }
-        }
-        if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
-            if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
-            if ((rc = tp_merge_rows(m, m->f, T, none))) return rc;
-        } else {
-            if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], merging ? none : L.t[T_W2_B], m->f))) return rc;
-            if ((rc = tp_merge_rows(m, m->f, T, L.t[T_W2_B]))) return rc;
-        }
-        if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
-        const bool last_layer = l + 1 == c.layers;
-        const Tensor &nw = last_layer ? m->g[T_OUT_NORM] : m->layers[(size_t)l + 1].t[T_ATTN_NORM];
-        const Tensor &nb = last_layer ? m->g[T_OUT_NORM_B] : m->layers[(size_t)l + 1].t[T_ATTN_NORM_B];
-        if (seq_wiring && nw.present() && !(last_layer && scale_on(c.out_scale))) {
-            if ((rc = ifa_add_layernorm(c.norm_kind, m->f, m->a, (size_t)T, D, nw.data, nb.present() ? nb.data : nullptr,
-                                        last_layer ? c.out_norm_base : c.attn_norm_base, c.eps, m->f, m->xn, s))) return rc;
-            xn_ready = true;
-        } else {
-            if ((rc = ifa_add(m->f, m->a, (size_t)T * D, 0, m->f, s))) return rc;
-            if (c.parallel_attn || c.share_input)
-                if ((rc = ifa_add(m->f, x, (size_t)T * D, 0, m->f, s))) return rc;
-        }
-        std::swap(m->x, m->f);
-        x = m->x;
+        if ((rc = layer_tail_ops(m, l, T, x, attn_in, xn_ready))) return rc;
     }
     if (scale_on(c.out_scale) && (rc = ifa_scale(x, c.out_scale, (size_t)T * D, x, s))) return rc;
     const half_t *hfin = x;
@@ -2593,7 +2608,7 @@ int ifa_model_destroy(ifa_model *m)
     if (m->attn_ws.lmax) (void)hipFree(m->attn_ws.lmax);
     if (m->attn_ws.opart) (void)hipFree(m->attn_ws.opart);
     for (Tensor &t : m->g) free_tensor(t);
-    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->q, &m->k, &m->v, &m->dqkv, &m->bqkv, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits,
+    half_t **bufs[] = {&m->x, &m->x2, &m->xn, &m->hn, &m->pn, &m->q, &m->k, &m->v, &m->dqkv, &m->bqkv, &m->att, &m->a, &m->f, &m->t1, &m->t2, &m->logits,
                        &m->moe_gate, &m->moe_out, &m->moe_in, &m->moe_wdev};
     for (half_t **b : bufs) if (*b) (void)hipFree(*b);
     if (m->moe_idx) (void)hipFree(m->moe_idx);
@@ -2838,7 +2853,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"chain_late_w2", &m->opt_chain_late_w2}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"attn_post_as_residual", &m->opt_attn_post_as_residual}, {"chain_late_w2", &m->opt_chain_late_w2}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
         {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
         {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
     for (auto &o : opts)

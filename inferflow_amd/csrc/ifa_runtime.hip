@@ -39,10 +39,12 @@ unsigned *wait_err_word()
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     std::lock_guard<std::mutex> lk(g_wait_mu);
     auto it = g_wait_words.find(dev);
-    if (it != g_wait_words.end()) return it->second;
+    if (it != g_wait_words.end() && it->second) return it->second;
+    // (a failed allocation -- e.g. the first use fell inside a stream capture -- is NOT remembered: the next call tries again, and
+    //  the launchers below take their non-waiting kernels while the word is missing)
     unsigned *p = nullptr;
-    if (hipHostMalloc((void **)&p, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
-    if (p) memset(p, 0, 64);
+    if (hipHostMalloc((void **)&p, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    memset(p, 0, 64);
     g_wait_words[dev] = p;
     return p;
 }
@@ -82,6 +84,7 @@ int wait_err_check(const char *who)
 // ROC_GLOBAL_CU_MASK / HSA_CU_MASK name the CUs a process may use; the runtime keeps reporting the device's full count.
 // Forms: a hex mask ("0xffff", ROC_GLOBAL_CU_MASK) or "<gpu>:<ranges>" lists separated by ';' ("0:0-31;1:0-15", HSA_CU_MASK).
 // Returns the CU count the mask leaves for `device`, or device_cus when the text names no mask for it / cannot be read.
+int visible_cus_uncached();
 static int cus_from_mask(const char *mask, int device, int device_cus)
 {
     if (!mask || !*mask) return device_cus;
@@ -106,7 +109,23 @@ static int cus_from_mask(const char *mask, int device, int device_cus)
         pos = end + 1;
         const size_t colon = ent.find(':');
         if (colon == std::string::npos) continue;
-        if (atoi(ent.substr(0, colon).c_str()) != device) continue;
+        {   // GPU list in front of ':' -- ids and ranges separated by ',' ("0,2-3:0-31"); an entry that cannot be read counts as "masked, size unknown"
+            const std::string gl = ent.substr(0, colon);
+            bool match = false, bad = gl.empty();
+            size_t gp = 0;
+            while (gp < gl.size() && !bad) {
+                size_t ge = gl.find(',', gp);
+                if (ge == std::string::npos) ge = gl.size();
+                const std::string gr = gl.substr(gp, ge - gp);
+                gp = ge + 1;
+                if (gr.empty() || gr.find_first_not_of("0123456789-") != std::string::npos) { bad = true; break; }
+                const size_t gd = gr.find('-');
+                const int ga = atoi(gr.c_str()), gb = gd == std::string::npos ? ga : atoi(gr.c_str() + gd + 1);
+                if (device >= ga && device <= gb) match = true;
+            }
+            if (bad) return 0;          // conservative: no launch waits when a mask is set but unreadable
+            if (!match) continue;
+        }
         int n = 0;
         size_t q = colon + 1;
         while (q < ent.size()) {
@@ -123,7 +142,22 @@ static int cus_from_mask(const char *mask, int device, int device_cus)
     return device_cus;
 }
 
+static std::map<int, int> g_visible_cus;      // per device: the environment is read once
 int visible_cus()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    {
+        std::lock_guard<std::mutex> lk(g_wait_mu);
+        auto it = g_visible_cus.find(dev);
+        if (it != g_visible_cus.end()) return it->second;
+    }
+    const int v = visible_cus_uncached();
+    std::lock_guard<std::mutex> lk(g_wait_mu);
+    g_visible_cus[dev] = v;
+    return v;
+}
+int visible_cus_uncached()
 {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -140,6 +174,7 @@ static std::map<std::pair<const void *, size_t>, int> g_occ;
 bool wait_grid_fits(const void *kernel, int threads, size_t smem_bytes, long long grid)
 {
     if (!waits_enabled()) return false;
+    if (!wait_err_word()) return false;      // a timed-out wait could not be reported: the launches that wait are not chosen
     int occ = 0;
     {
         std::lock_guard<std::mutex> lk(g_wait_mu);

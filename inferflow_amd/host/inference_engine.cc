@@ -165,6 +165,17 @@ static bool LoadModelSpec(ModelSpec &spec, const IniConfig &cfg, const std::stri
         if (dt < 0) { EngineSetError("Invalid device_weight_data_type for model %s", spec.sid.c_str()); return false; }
         spec.device_weight_data_type = dt;
     }
+    {   // device_weight_data_type.<tensor>: element size >= 2 -> F16 (inference_engine.cc:1685-1687)
+        static const struct { const char *name; int tid; } kTensors[] = {{"attn_wq", IFA_T_WQ}, {"attn_wk", IFA_T_WK}, {"attn_wv", IFA_T_WV},
+            {"attn_wo", IFA_T_WO}, {"ffn_w1", IFA_T_W1}, {"ffn_w2", IFA_T_W2}, {"ffn_w3", IFA_T_W3}};
+        for (const auto &kt : kTensors) {
+            std::string v;
+            if (!cfg.GetItem(section, std::string("device_weight_data_type.") + kt.name, v) || v.empty()) continue;
+            const int dt = ifa_dtype_from_name(IniConfig::Lower(v).c_str());
+            if (dt < 0) { EngineSetError("Invalid device_weight_data_type.%s for model %s", kt.name, spec.sid.c_str()); return false; }
+            spec.device_weight_data_types[kt.tid] = (dt == IFA_F32 || dt == IFA_F16) ? IFA_F16 : dt;
+        }
+    }
     str.clear();
     if (cfg.GetItem(section, "device_kv_cache_data_type", str) && !str.empty()) {
         const int dt = ifa_dtype_from_name(IniConfig::Lower(str).c_str());

@@ -55,6 +55,7 @@ struct ModelSpec {
     float embedding_linear_scale = 0;                                                 // <= 0.0001: sqrt(embd_dims)
     int qk_column_order = 0, qkv_format = 0;
     bool is_parallel_attn = false, mlp_attn_share_input = false;
+    bool is_attn_post_as_residual = true;   // model.h:113: with a self_attn.post_norm, the FFN's residual is the normalised tensor
     std::string tensor_name_prefix;
     std::map<std::string, std::string> tensor_name_map;
     std::string decoding_strategy;
@@ -64,6 +65,10 @@ struct ModelSpec {
     std::vector<int> invalid_token_ids;
     std::string decoder_input_template;     // kept for round-tripping the .ini; unused (token-id queries)
     int device_weight_data_type = 1;        // ElementType ids = ifa_dtype; F16
+    // device_weight_data_type.<tensor> (inference_engine.cc:1664-1690; tensors attn_wq / attn_wk / attn_wv / attn_wo / ffn_w1 / ffn_w2 /
+    // ffn_w3, NetworkStructure::BuildLayerTensorIdMap): per-tensor override of the type above, indexed by IFA_T_* id; -1 = Auto
+    int device_weight_data_types[40] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                        -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     int device_kv_cache_data_type = 8;      // Q8_B32T2 (the reference's default, model.h:137)
     int tensor_quant_threshold = 2000 * 2000;
     static const int DEFAULT_MAX_CONTEXT_LEN = 1024;

@@ -129,6 +129,7 @@ bool LoadModelSpecJson(ModelSpec &spec, const std::string &path)
     ns->GetNumber("embedding_linear_scale", spec.embedding_linear_scale);
     ns->GetBool("is_parallel_attn", spec.is_parallel_attn);
     ns->GetBool("mlp_attn_share_input", spec.mlp_attn_share_input);
+    ns->GetBool("is_attn_post_as_residual", spec.is_attn_post_as_residual);            // model_reader.cc (network_structure), model.h:113
     ns->GetNumber("expert_count", hp.experts);
     spec.moe_top_k_from_spec = ns->GetNumber("moe_top_k", hp.moe_top_k);
     ns->GetBool("moe_norm_top_k_prob", hp.moe_norm_top_k_prob);
@@ -195,9 +196,11 @@ struct Uploader {
     ~Uploader() { for (size_t i = 0; i < dev.size(); i++) if (dev[i]) { ifa_set_device((*plans)[i].device); ifa_free(dev[i]); } }
 
     static bool IsQuant(int dt) { return dt >= 7; }
-    int MatrixType(size_t rows, size_t cols) const
+    // tid: the tensor's IFA_T_* id, for its device_weight_data_type.<tensor> override (NetworkBuilder::BuildTask_Std, network_builder.cc:1551-1555)
+    int MatrixType(size_t rows, size_t cols, int tid = -1) const
     {
-        const int wdt = spec->device_weight_data_type;
+        int wdt = spec->device_weight_data_type;
+        if (tid >= 0 && tid < 40 && spec->device_weight_data_types[tid] >= 0) wdt = spec->device_weight_data_types[tid];
         if (!IsQuant(wdt)) return wdt == IFA_F32 ? IFA_F16 : wdt;       // F16 compute either way
         const int cap = ifa_block_capacity(wdt);
         if ((long long)(rows * cols) < (long long)spec->tensor_quant_threshold || cap <= 0 || cols % (size_t)cap != 0) return IFA_F16;
@@ -298,6 +301,7 @@ bool CreateWorkers(std::vector<WorkerPlan> &plans, const ModelSpec &spec)
         // rank of a device group holds its row / column slice of EVERY expert, the router is replicated
         c.experts = hp.experts; c.moe_top_k = hp.experts > 0 ? hp.moe_top_k : 0; c.moe_norm_topk = hp.moe_norm_top_k_prob ? 1 : 0;
         if (ifa_model_create(&c, &w.model) != IFA_OK) { EngineSetError("ifa_model_create (device %d): %s", w.device, ifa_last_error()); return false; }
+        (void)ifa_model_set_option(w.model, "attn_post_as_residual", spec.is_attn_post_as_residual ? 1 : 0);
     }
     return true;
 }
@@ -358,7 +362,7 @@ bool LoadLlama2DotC(std::vector<WorkerPlan> &plans, ModelSpec &spec)
     for (const Kind &k : kinds)                 // grouped by kind: [L][rows][cols] each
         for (size_t l = 0; l < L; l++) {
             if (!read(k.rows, k.cols)) return false;
-            const int target = k.matrix ? up.MatrixType(k.rows, k.cols) : IFA_F16;
+            const int target = k.matrix ? up.MatrixType(k.rows, k.cols, k.tid) : IFA_F16;
             if (!up.Put((int)l, k.tid, target, f16.data(), k.rows, k.cols)) return false;
         }
     if (!read(1, D) || !up.Put(-1, IFA_T_OUT_NORM, IFA_F16, f16.data(), 1, D)) return false;
@@ -476,7 +480,7 @@ bool LoadSafetensors(std::vector<WorkerPlan> &plans, ModelSpec &spec)
         auto it = by_std.find(name);
         if (it == by_std.end()) { if (required) EngineSetError("tensor %s is missing", name.c_str()); return required ? -1 : 0; }
         if (!ReadStTensor(it->second, rows, cols, f16, name)) return -1;
-        const int target = tid == IFA_T_LM_HEAD ? LmHeadType(spec, rows, cols) : (matrix ? up.MatrixType(rows, cols) : IFA_F16);
+        const int target = tid == IFA_T_LM_HEAD ? LmHeadType(spec, rows, cols) : (matrix ? up.MatrixType(rows, cols, tid) : IFA_F16);
         return up.Put(layer, tid, target, f16.data(), rows, cols, expert) ? 1 : -1;
     };
     // Mixtral-style checkpoints (data/models/mixtral_8x7b_instruct_v0.1/model_spec.safetensors.json): the router
@@ -517,8 +521,8 @@ bool LoadSafetensors(std::vector<WorkerPlan> &plans, ModelSpec &spec)
                 memcpy(k.data(), f16.data() + QDr * D, KV * D * 2);
                 memcpy(v.data(), f16.data() + (QDr + KV) * D, KV * D * 2);
             }
-            if (!up.Put(l, IFA_T_WQ, up.MatrixType(QDr, D), q.data(), QDr, D) || !up.Put(l, IFA_T_WK, up.MatrixType(KV, D), k.data(), KV, D)
-                || !up.Put(l, IFA_T_WV, up.MatrixType(KV, D), v.data(), KV, D)) return false;
+            if (!up.Put(l, IFA_T_WQ, up.MatrixType(QDr, D, IFA_T_WQ), q.data(), QDr, D) || !up.Put(l, IFA_T_WK, up.MatrixType(KV, D, IFA_T_WK), k.data(), KV, D)
+                || !up.Put(l, IFA_T_WV, up.MatrixType(KV, D, IFA_T_WV), v.data(), KV, D)) return false;
             fused_qkv = true;
             break;
         }
@@ -549,8 +553,12 @@ bool LoadSafetensors(std::vector<WorkerPlan> &plans, ModelSpec &spec)
             if (moe_layer && (e.tid == IFA_T_W1 || e.tid == IFA_T_W2 || e.tid == IFA_T_W3)) continue;      // the experts are this layer's FFN
             if (put(p + e.name, l, e.tid, e.rows, e.cols, e.matrix, true) < 0) return false;
         }
+        // optional: biases, and the post norms in the reference's standard names (self_attn.post_norm / feed_forward.post_norm,
+        // NetworkStructure::BuildTensorNameToIdMap, network_structure.cc:131-134; reached through the spec's tensor_name_mapping)
         const E bs[] = {{"self_attn.q_proj.bias", IFA_T_WQ_B, 1, D, false}, {"self_attn.k_proj.bias", IFA_T_WK_B, 1, KV, false},
-                        {"self_attn.v_proj.bias", IFA_T_WV_B, 1, KV, false}};
+                        {"self_attn.v_proj.bias", IFA_T_WV_B, 1, KV, false},
+                        {"self_attn.post_norm.weight", IFA_T_ATTN_POST_NORM, 1, D, false}, {"self_attn.post_norm.bias", IFA_T_ATTN_POST_NORM_B, 1, D, false},
+                        {"feed_forward.post_norm.weight", IFA_T_FFN_POST_NORM, 1, D, false}, {"feed_forward.post_norm.bias", IFA_T_FFN_POST_NORM_B, 1, D, false}};
         for (const E &e : bs) if (put(p + e.name, l, e.tid, e.rows, e.cols, false, false) < 0) return false;
     }
     if (put("norm.weight", -1, IFA_T_OUT_NORM, 1, D, false, true) < 0) return false;
@@ -615,12 +623,12 @@ bool LoadSynthetic(std::vector<WorkerPlan> &plans, ModelSpec &spec)
             if (hp.experts > 0 && ffn) {      // one FFN per expert (the seeds of inferflow_amd/synth.py)
                 for (int j = 0; j < hp.experts; j++) {
                     FillNormalF16(w, e.rows * e.cols, 100000 + ((uint64_t)l * 64 + (uint64_t)j) * 16 + (uint64_t)e.tid, spec.synthetic_std);
-                    if (!up.Put(l, e.tid, up.MatrixType(e.rows, e.cols), w.data(), e.rows, e.cols, j)) return false;
+                    if (!up.Put(l, e.tid, up.MatrixType(e.rows, e.cols, e.tid), w.data(), e.rows, e.cols, j)) return false;
                 }
                 continue;
             }
             FillNormalF16(w, e.rows * e.cols, 1000 + (uint64_t)l * 16 + (uint64_t)e.tid, spec.synthetic_std);
-            if (!up.Put(l, e.tid, up.MatrixType(e.rows, e.cols), w.data(), e.rows, e.cols)) return false;
+            if (!up.Put(l, e.tid, up.MatrixType(e.rows, e.cols, e.tid), w.data(), e.rows, e.cols)) return false;
         }
         if (hp.experts > 0) {                  // the router: always F16
             FillNormalF16(w, (size_t)hp.experts * D, 1000 + (uint64_t)l * 16 + (uint64_t)IFA_T_MOE_GATE, spec.synthetic_std);

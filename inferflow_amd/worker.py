@@ -14,6 +14,7 @@ T_EMBD, T_OUT_NORM, T_OUT_NORM_B, T_LM_HEAD = 0, 1, 2, 3
 T_ATTN_NORM, T_ATTN_NORM_B, T_WQ, T_WK, T_WV, T_WO = 10, 11, 12, 13, 14, 15
 T_FFN_NORM, T_FFN_NORM_B, T_W1, T_W2, T_W3, T_MOE_GATE = 16, 17, 18, 19, 20, 21
 T_WQ_B, T_WK_B, T_WV_B, T_WO_B, T_W1_B, T_W2_B, T_W3_B = 22, 23, 24, 25, 26, 27, 28
+T_ATTN_POST_NORM, T_ATTN_POST_NORM_B, T_FFN_POST_NORM, T_FFN_POST_NORM_B = 29, 30, 31, 32      # self_attn.post_norm / feed_forward.post_norm
 
 _DEFAULTS = dict(norm_kind=0, act_kind=0, is_glu=1, rope_order=2, use_alibi=0, parallel_attn=0, share_input=0,
                  rope_theta=10000.0, partial_rotary=1.0, kq_scale=1.0, eps=1e-5, kv_dtype=dt.F16,

@@ -142,11 +142,15 @@ enum { ORC_T_EMBD = 0, ORC_T_OUT_NORM = 1, ORC_T_OUT_NORM_B = 2, ORC_T_LM_HEAD =
        ORC_T_WV = 14, ORC_T_WO = 15, ORC_T_FFN_NORM = 16, ORC_T_FFN_NORM_B = 17,
        ORC_T_W1 = 18, ORC_T_W2 = 19, ORC_T_W3 = 20, ORC_T_MOE_GATE = 21,
        ORC_T_WQ_B = 22, ORC_T_WK_B = 23, ORC_T_WV_B = 24, ORC_T_WO_B = 25,
-       ORC_T_W1_B = 26, ORC_T_W2_B = 27, ORC_T_W3_B = 28 };
+       ORC_T_W1_B = 26, ORC_T_W2_B = 27, ORC_T_W3_B = 28,
+       /* self_attn.post_norm / feed_forward.post_norm (model.h:168-276; inference_worker.cc:857-866, 954-965) */
+       ORC_T_ATTN_POST_NORM = 29, ORC_T_ATTN_POST_NORM_B = 30, ORC_T_FFN_POST_NORM = 31, ORC_T_FFN_POST_NORM_B = 32 };
 /* Attach (no copy) a tensor already in its final dtype.  expert = -1 for dense. */
 int orc_model_set_tensor(orc_model *m, int layer, int tensor_id, int expert, int dtype,
                          const void *data, size_t rows, size_t cols);
 void orc_model_reset(orc_model *m);
+/* ModelSpec::is_attn_post_as_residual (model.h:113, default true): with a self_attn.post_norm, the FFN's residual is the normalised tensor */
+void orc_model_set_attn_post_as_residual(orc_model *m, int on);
 /* Process n_tokens new tokens at positions [prefix_len, prefix_len+n_tokens).
  * logits_out: F16 [n_tokens][vocab] (may be NULL).  Returns greedy argmax of last row. */
 int orc_model_forward(orc_model *m, const int *tokens, int n_tokens, int prefix_len,

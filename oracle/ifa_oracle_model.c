@@ -21,7 +21,7 @@
 #include <omp.h>
 #endif
 
-#define ORC_MAX_TENSOR_ID 32
+#define ORC_MAX_TENSOR_ID 36
 
 typedef struct {
     int dtype;
@@ -42,6 +42,7 @@ struct orc_model {
     orc_f16 *last_hidden;
     orc_f16 *capture;    /* optional (orc_model_set_capture): [layers + 1][dim] */
     float *layer_margin; /* optional (orc_model_set_layer_margins): [layers], the same gap per layer (2.0 where no MoE layer ran) */
+    int attn_post_as_residual; /* ModelSpec::is_attn_post_as_residual (default 1) */
     float moe_margin;    /* smallest gap between the LAST selected and the FIRST rejected router probability over the rows and layers of the last forward */
 };
 
@@ -60,6 +61,7 @@ orc_model *orc_model_create(const orc_model_cfg *cfg)
 {
     orc_model *m = (orc_model *)calloc(1, sizeof(orc_model));
     m->cfg = *cfg;
+    m->attn_post_as_residual = 1;
     if (m->cfg.eps <= 0) m->cfg.eps = 1e-5f;
     if (m->cfg.kq_scale <= 0) m->cfg.kq_scale = 1.0f;
     if (m->cfg.partial_rotary <= 0) m->cfg.partial_rotary = 1.0f;
@@ -102,6 +104,8 @@ int orc_model_set_tensor(orc_model *m, int layer, int tensor_id, int expert, int
     m->layers[layer].t[tensor_id] = t;
     return 0;
 }
+
+void orc_model_set_attn_post_as_residual(orc_model *m, int on) { m->attn_post_as_residual = on ? 1 : 0; }
 
 void orc_model_reset(orc_model *m)
 {
@@ -238,6 +242,7 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
     orc_f16 *x = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
     orc_f16 *xn = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
     orc_f16 *hn = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
+    orc_f16 *pn = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * D);
     orc_f16 *q = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * QD);
     orc_f16 *k = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * KVD);
     orc_f16 *v = (orc_f16 *)malloc(sizeof(orc_f16) * (size_t)T * KVD);
@@ -291,7 +296,14 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
         if (scale_on(c->attn_out_scale)) orc_scale(a, c->attn_out_scale, (size_t)T * D, a);   /* :842-843 */
         /* residual (inference_worker.cc:847-851) */
         if (!c->parallel_attn && !c->share_input) orc_add(x, a, (size_t)T * D, 0, a);
-        const orc_f16 *ff_in = c->parallel_attn ? attn_in : (c->share_input ? x : a);
+        /* self_attn.post_norm (:854-866): att_out = Norm(a); the residual follows it when is_attn_post_as_residual */
+        const orc_f16 *residual = a, *att_out = a;
+        if (L->t[ORC_T_ATTN_POST_NORM].data) {
+            norm_rows(m, a, T, &L->t[ORC_T_ATTN_POST_NORM], &L->t[ORC_T_ATTN_POST_NORM_B], pn, 0.0f);
+            att_out = pn;
+            if (m->attn_post_as_residual) residual = pn;
+        }
+        const orc_f16 *ff_in = c->parallel_attn ? attn_in : (c->share_input ? x : att_out);
         const orc_f16 *ff_n = ff_in;
         if (L->t[ORC_T_FFN_NORM].data) {
             norm_rows(m, ff_in, T, &L->t[ORC_T_FFN_NORM], &L->t[ORC_T_FFN_NORM_B], hn, c->ffn_norm_base);
@@ -358,8 +370,12 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
         if (rc) break;
         if (scale_on(c->ffn_out_scale)) orc_scale(f, c->ffn_out_scale, (size_t)T * D, f);      /* :928-929 */
         /* layer_out = ff_out + residual (+ layer_input) (inference_worker.cc:936-947) */
-        orc_add(f, a, (size_t)T * D, 0, f);
+        orc_add(f, residual, (size_t)T * D, 0, f);
         if (c->parallel_attn || c->share_input) orc_add(f, x, (size_t)T * D, 0, f);
+        if (L->t[ORC_T_FFN_POST_NORM].data) {      /* feed_forward.post_norm (:954-965) */
+            norm_rows(m, f, T, &L->t[ORC_T_FFN_POST_NORM], &L->t[ORC_T_FFN_POST_NORM_B], pn, 0.0f);
+            memcpy(f, pn, sizeof(orc_f16) * (size_t)T * D);
+        }
         memcpy(x, f, sizeof(orc_f16) * (size_t)T * D);
     }
     if (rc == 0 && m->capture) memcpy(m->capture + (size_t)c->layers * D, x + (size_t)(T - 1) * D, D * 2);
@@ -396,6 +412,6 @@ int orc_model_forward(orc_model *m, const int *tokens, int T, int prefix_len,
         rc = -11;
     }
 done:
-    free(x); free(xn); free(hn); free(q); free(k); free(v); free(att); free(a); free(f);
+    free(x); free(xn); free(hn); free(pn); free(q); free(k); free(v); free(att); free(a); free(f);
     return rc;
 }

@@ -28,6 +28,7 @@ T_EMBD, T_OUT_NORM, T_OUT_NORM_B, T_LM_HEAD = 0, 1, 2, 3
 T_ATTN_NORM, T_ATTN_NORM_B, T_WQ, T_WK, T_WV, T_WO = 10, 11, 12, 13, 14, 15
 T_FFN_NORM, T_FFN_NORM_B, T_W1, T_W2, T_W3, T_MOE_GATE = 16, 17, 18, 19, 20, 21
 T_WQ_B, T_WK_B, T_WV_B, T_WO_B, T_W1_B, T_W2_B, T_W3_B = 22, 23, 24, 25, 26, 27, 28
+T_ATTN_POST_NORM, T_ATTN_POST_NORM_B, T_FFN_POST_NORM, T_FFN_POST_NORM_B = 29, 30, 31, 32
 
 
 def build(force=False):
@@ -369,6 +370,10 @@ class Model:
 
     def reset(self):
         lib().orc_model_reset(self._h)
+
+    def set_attn_post_as_residual(self, on):
+        """ModelSpec::is_attn_post_as_residual (model.h:113): the FFN's residual is the attention post-norm's output (default) or its input."""
+        lib().orc_model_set_attn_post_as_residual(self._h, int(bool(on)))
 
     def forward(self, tokens, prefix_len, want_logits=True, nthreads=0):
         toks = np.ascontiguousarray(tokens, np.int32)

@@ -171,7 +171,7 @@ def test_decode_rejects_out_of_range_positions():
 FALCON_LIKE = dict(norm_kind=1, act_kind=1, is_glu=0, parallel_attn=1, rope_order=1)
 
 
-def _build_custom(shape, wd, kvd, max_ctx, cfg, with_bias=False, std=0.06):
+def _build_custom(shape, wd, kvd, max_ctx, cfg, with_bias=False, std=0.06, post=None):
     """A worker + oracle pair for non-llama wiring (std norm, GELU, no w3, parallel attention, biases)."""
     import oracle as o
     from inferflow_amd import worker as W
@@ -192,14 +192,18 @@ def _build_custom(shape, wd, kvd, max_ctx, cfg, with_bias=False, std=0.06):
     put(-1, W.T_OUT_NORM, dt.F16, rng.normal(1, 0.1, d)); put(-1, W.T_OUT_NORM_B, dt.F16, rng.normal(0, 0.05, d))
     put(-1, W.T_LM_HEAD, dt.F16, rng.normal(0, std, (v, d)))
     for l in range(s["layers"]):
-        put(l, W.T_ATTN_NORM, dt.F16, rng.normal(1, 0.1, d)); put(l, W.T_ATTN_NORM_B, dt.F16, rng.normal(0, 0.05, d))
+        if post != "only":
+            put(l, W.T_ATTN_NORM, dt.F16, rng.normal(1, 0.1, d)); put(l, W.T_ATTN_NORM_B, dt.F16, rng.normal(0, 0.05, d))
         for tid, shp in [(W.T_WQ, (qd, d)), (W.T_WK, (kvdim, d)), (W.T_WV, (kvdim, d)), (W.T_WO, (d, qd)),
                          (W.T_W1, (f, d)), (W.T_W2, (d, f))]:
             put(l, tid, wd, rng.normal(0, std, shp))
         if cfg.get("is_glu", 1):
             put(l, W.T_W3, wd, rng.normal(0, std, (f, d)))
-        if not cfg.get("parallel_attn"):
+        if not cfg.get("parallel_attn") and post != "only":
             put(l, W.T_FFN_NORM, dt.F16, rng.normal(1, 0.1, d))
+        if post:      # self_attn.post_norm / feed_forward.post_norm (+ biases)
+            put(l, W.T_ATTN_POST_NORM, dt.F16, rng.normal(1, 0.1, d)); put(l, W.T_ATTN_POST_NORM_B, dt.F16, rng.normal(0, 0.05, d))
+            put(l, W.T_FFN_POST_NORM, dt.F16, rng.normal(1, 0.1, d)); put(l, W.T_FFN_POST_NORM_B, dt.F16, rng.normal(0, 0.05, d))
         if with_bias:
             for tid, n in [(W.T_WQ_B, qd), (W.T_WK_B, kvdim), (W.T_WV_B, kvdim), (W.T_WO_B, d), (W.T_W1_B, f), (W.T_W2_B, d)]:
                 put(l, tid, dt.F16, rng.normal(0, 0.05, n))
@@ -247,6 +251,40 @@ def test_other_wirings_fused_and_op_path(name, cfg, bias):
     toks_ops, _ = wk.decode(tok, len(prompt), 6)
     assert np.array_equal(toks, toks_ops)
     assert np.array_equal(lg_fused, wk.read_buffer("logits"))
+    wk.close()
+
+
+@pytest.mark.parametrize("name,cfg,post,as_res", [
+    ("post_ln_only", dict(norm_kind=1, act_kind=2, is_glu=0), "only", 1),          # BERT / OPT-350m style: no pre norms, both post norms
+    ("pre_and_post", dict(), "both", 1),                                           # pre norms + post norms, the residual follows the post norm
+    ("pre_and_post_residual_before", dict(), "both", 0),                           # is_attn_post_as_residual = false (Mixtral's spec form)
+    ("post_parallel", dict(norm_kind=1, act_kind=1, is_glu=0, parallel_attn=1), "both", 1)])
+def test_post_norm_wirings_match_oracle(name, cfg, post, as_res):
+    """self_attn.post_norm / feed_forward.post_norm and is_attn_post_as_residual (ProcessGpuLayer, inference_worker.cc:857-866,
+    954-965; model.h:113): the op-by-op layer against the oracle on a prompt and on single-token steps (such models decline the
+    fused launches: decode runs the same ops token by token), and the batched step against the single-query steps."""
+    wk, om, s = _build_custom("test_gqa", dt.Q4_B32T1A, dt.F16, 32, cfg, with_bias=True, post=post)
+    wk.set_option("attn_post_as_residual", as_res)
+    om.set_attn_post_as_residual(as_res)
+    ok, why = wk.fused_supported()
+    assert not ok and "post norm" in why
+    prompt = np.array([7, 99, 512, 3, 41], np.int32)
+    lg = torch.empty((len(prompt), s["vocab"]), dtype=torch.float16, device="cuda")
+    tok = wk.forward(prompt, 0, lg)
+    tok_o, lg_o = om.forward(prompt, 0, nthreads=4)
+    cos, mad = _logits_close(g.host(lg), lg_o)
+    assert cos >= 0.9995 and mad <= 0.02 * float(np.abs(lg_o.astype(np.float32)).max()) + 0.02, (name, cos, mad)
+    toks, _ = wk.decode(tok, len(prompt), 5)
+    cur = tok
+    for i in range(5):
+        t_o, l_o = om.forward(np.array([cur], np.int32), len(prompt) + i, nthreads=4)
+        top2 = np.sort(l_o[0].astype(np.float32))[-2:]
+        assert int(toks[i]) == t_o or top2[1] - top2[0] <= LOGIT_TOL, "step %d" % i
+        cur = int(toks[i])
+    # the flag matters: the other setting gives different logits on the same weights
+    om.reset(); om.set_attn_post_as_residual(1 - as_res)
+    _, lg_other = om.forward(prompt, 0, nthreads=4)
+    assert np.abs(lg_other.astype(np.float32) - lg_o.astype(np.float32)).max() > 0.05
     wk.close()
 
 

@@ -27,6 +27,8 @@ def test_missing_file_and_section(tmp_path):
     ("models = tiny_test", "models = other", "directory of model"),
     ("model_specification_file = model_spec.json", "model_specification_file = missing.json", "specification file"),
     ("devices = 0", "devices = 0&1;2", "same size"),
+    # per-tensor override of the weight type (inference_engine.cc:1664-1690): an unknown type name is refused with the key's name
+    ("device_weight_data_type = Q4", "device_weight_data_type = Q4\ndevice_weight_data_type.ffn_w2 = Q7x", "device_weight_data_type.ffn_w2"),
 ])
 def test_ini_errors(tmp_path, old, new, msg):
     ini, _ = fx.write_model_dir(str(tmp_path), fmt="synthetic")

@@ -29,6 +29,10 @@ def test_cu_masks_are_read():
     assert f(b"1:0-7", 0, 256) == 256                           # no entry for this device: everything
     assert f(b"garbage", 0, 256) == 256                         # unreadable: assume the device's own count
     assert f(b"0:0-511", 0, 256) == 256                         # never more than the device has
+    # a GPU LIST in front of the colon (ids and ranges): every listed device gets the mask
+    assert f(b"0,1:0-31", 1, 256) == 32 and f(b"0,2-3:0-15", 3, 256) == 16 and f(b"0,2-3:0-15", 1, 256) == 256
+    # a mask that names GPUs in a form that cannot be read: conservative -- 0 CUs, so no launch that waits is chosen
+    assert f(b"gpu0:0-31", 0, 256) == 0
 
 
 def test_waits_start_enabled():
