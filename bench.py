@@ -594,7 +594,7 @@ def main():
         # HBM bytes per launch of that kernel from the PMC pass (rocprofv3 --pmc FETCH_SIZE, own run: tools/profile_r02.sh;
         # summary and correction in profiles/r02_pmc_traffic.json, produced by tools/pmc_summary.py).  The file names the
         # build it was taken with (hash of the kernel sources): numbers of another build are NOT reported
-        traffic, traffic_note = None, None
+        traffic, traffic_note, traffic_source = None, None, None
         try:
             from inferflow_amd.build import source_hash
             import glob
@@ -603,6 +603,7 @@ def main():
                 q = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_q3h_q8_traffic.json")))
                 pmc_path = q[-1] if q else pmc_path
             pmc = json.load(open(pmc_path))
+            traffic_source = "profiles/" + os.path.basename(pmc_path) + " (rocprofv3 --pmc FETCH_SIZE pass of this build, tools/refresh_pmc.sh; replayed, not measured in this run)"
             if pmc.get("source_hash") != source_hash():
                 traffic_note = "profiles/%s was taken with kernel sources %s, this build is %s: stale, not reported" % (
                     os.path.basename(pmc_path), pmc.get("source_hash"), source_hash())
@@ -618,33 +619,9 @@ def main():
             traffic, traffic_note = None, "no PMC summary: %r" % (e,)
         out["roofline"] = {"bound": "hbm", "kernel": "k_dec_gemv<%s, EPI_GLU> (fused RMSNorm+Q8 quant+W1/W3 GEMV+SiLU*mul)" % dt.name(wd),
                            "achieved": ffn13_bytes / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
+                           "frac": ffn13_bytes / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note, "traffic_source": traffic_source,
                            "bytes_per_launch": ffn13_bytes, "streamed_bytes_per_launch": ffn13_streamed, "us_per_launch": us}
         out["kernels"] = per_kernel
-        # ---- the persistent layer kernel (csrc/ifa_decode_persist.h: one launch for all layers of a token, opt-in option
-        # "persist"): measured beside the five-launch step on the same model, never the headline value.  Same tokens required.
-        try:
-            from inferflow_amd import lib as _lib
-            if not _lib().ifa_experimental_built():      # parked under csrc/experimental/ (57 vs 38 us per layer): not in the default library
-                raise RuntimeError("not built (IFA_EXPERIMENTAL=1 builds the parked launches in)")
-            wk = runner.worker
-            ps_n = min(32, steps)
-            ref_t, _ = wk.decode(tok, PROMPT_LEN + warmup, ps_n)
-            wk.set_option("persist", 1)
-            wk.decode(tok, PROMPT_LEN + warmup, 4)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ps_t, _ = wk.decode(tok, PROMPT_LEN + warmup, ps_n)
-            torch.cuda.synchronize()
-            ps_s = time.perf_counter() - t0
-            out["persistent_layer_kernel"] = {"tok_s": ps_n / ps_s, "us_per_layer": wk.time_kernel(6, 20) / s["layers"],
-                                              "tokens_equal_five_launch": bool(np.array_equal(ref_t, ps_t)),
-                                              "note": "opt-in (set_option persist=1); the five-launch step above is the default"}
-        except Exception as e:
-            if "not built" not in repr(e):
-                out["persistent_layer_kernel"] = {"error": repr(e)[:200]}
-        finally:
-            runner.worker.set_option("persist", 0)
     # ---- prefill rate at longer prompts (16 / 128 / 1024-token prompts), outside the timed decode region
     if world == 1 and hasattr(runner, "worker") and not os.environ.get("IFA_FORCE_TP"):
         pf = {}

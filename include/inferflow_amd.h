@@ -123,9 +123,6 @@ int ifa_gemm_big_tiles(int on);
 int ifa_wait_grid_decision(int blocks_per_cu, int visible_cus, long long grid);      /* 1: the grid fits */
 int ifa_visible_cus_from_mask(const char *mask_text, int device, int device_cus);    /* CUs the mask leaves for `device` */
 int ifa_inlaunch_waits_enabled(void);
-/* 1 if this library was built with the experimental launches of csrc/experimental/ (options "persist", "fuse_wo", "fuse_wo_ffn":
- * built, bit-identical, measured slower than the default step -- IFA_EXPERIMENTAL=1 at build time); 0: those options are inert */
-int ifa_experimental_built(void);
 /* frees the scratch the prefill kernels keep for this stream on the current device (call before destroying a stream that ran
  * long-prompt attention; ifa_model_destroy / ifa_model_set_stream do it for the worker's) */
 int ifa_gemm_release_stream(ifa_stream stream);
@@ -265,9 +262,10 @@ int ifa_model_set_tensor_f16(ifa_model *m, int layer, int tensor_id, int expert,
 int ifa_model_finalize(ifa_model *m);
 int ifa_model_reset(ifa_model *m);
 /* options: "fused" (1), "graph" (1), "rpw_qkv|rpw_wo|rpw_ffn|rpw_w2|rpw_lm" (0 = auto), "batch_fused" (1), "rows_mo" (1: the batched
- * step and short prompts stream MFMA-operand-order copies of the weights, built on first use), "persist" (0; 1 = the decode
- * step of a dense single-worker model as ONE launch for all layers, csrc/ifa_decode_persist.h: bit-identical, slower than the
- * five-launch step on MI355X, kept as comparator), "persist_timeout_us" (bounded waits of that launch), "attn_split_ctx" (512) */
+ * step and short prompts stream MFMA-operand-order copies of the weights, built on first use), "attn_split_ctx" (512), "fuse_attn" (1: the attention as the
+ * tail of the wq | wk | wv launch), "fuse_ffn" (0; 1 / 2: [Wo ->] W1 | W3 -> W2 as one chained launch, csrc/ifa_decode_chain.h: bit-identical,
+ * measured slower than the separate launches on MI355X, kept as the measurement harness of that statement), "prefill_mid" (1),
+ * "prefill_mid_max" (256), "prefill_big_min" (47), "attn_post_as_residual" (1) */
 /* Independent KV caches inside one worker, one per concurrent query -- the reference keeps a LayerKVCache set
  * per query processor (QueryStateTable, src/transformer/query_state_table.h:19-85; KVCache::Init, kv_cache.cc:278-319).
  * ifa_model_kv_slots grows the number of caches to n_slots (slot 0 exists after finalize); ifa_model_select_kv

@@ -72,7 +72,6 @@ SIGNATURES = {
     "ifa_wait_grid_decision": (_i, [_i, _i, C.c_longlong]),
     "ifa_visible_cus_from_mask": (_i, [C.c_char_p, _i, _i]),
     "ifa_inlaunch_waits_enabled": (_i, []),
-    "ifa_experimental_built": (_i, []),
     "ifa_gemm_release_stream": (_i, [_vp]),
     "ifa_tiled_row_bytes": (_sz, [_i, _sz]),
     "ifa_repack_weights": (_i, [_i, _vp, _sz, _sz, _vp, _vp]),

@@ -38,14 +38,8 @@ CLI_PATH = os.path.join(BIN_DIR, "ifa_llm_inference")
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function"]
 
 
-EXPERIMENTAL = bool(os.environ.get("IFA_EXPERIMENTAL"))      # build csrc/experimental/ in (measured dead ends: see ifa_experimental_off.hip)
-
-
 def sources():
-    srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp"))
-    if EXPERIMENTAL:
-        srcs = [s for s in srcs if os.path.basename(s) != "ifa_experimental_off.hip"] + glob.glob(os.path.join(CSRC, "experimental", "*.hip"))
-    return sorted(srcs)
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
 def host_sources():
@@ -57,7 +51,7 @@ def source_hash():
     """Identity of the kernel sources a profile was taken with (bench.py refuses PMC numbers of another build)."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip"))):      # (the default library's sources: csrc/experimental/ is not in it)
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip"))):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
@@ -94,7 +88,7 @@ def is_stale():
     t = os.path.getmtime(LIB_PATH)
     if not os.path.exists(CLI_PATH):
         return True
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "experimental", "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
     deps += glob.glob(os.path.join(HOST, "*.cc")) + glob.glob(os.path.join(HOST, "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -120,7 +114,7 @@ def build_library(force=False, verbose=False, jobs=None):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and os.path.getmtime(obj) > dep_t):
             continue
-        cmd = [hipcc] + HIPCC_FLAGS + (["-DIFA_EXPERIMENTAL=1"] if EXPERIMENTAL else []) + ["-I", os.path.join(_HERE, "..", "include"), "-I", CSRC, "-c", src, "-o", obj]
+        cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_HERE, "..", "include"), "-I", CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

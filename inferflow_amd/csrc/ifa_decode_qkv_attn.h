@@ -32,22 +32,14 @@ struct DecQkvAttnExtra {
     unsigned *err;                  // error word (ifa_model::ps_err)
     int timeout_us;
     int gk;                         // workgroups per kv group; grid = kv_heads * gk
-    unsigned long long *att_gran;   // WO: this layer's attention-output granules (att_gran_count entries)
 };
 
 constexpr int QA_THREADS = 512;     // 8 waves: two per SIMD, 256 registers each (the attention tail needs ~140)
 
-// WO: the launch also computes the Wo rows (+ bias, + residual: EPI_RESIDUAL of k_dec_gemv<.., NORM == 2>).  The workgroups that
-// do NOT run a head's attention -- 224 of 256 for Llama-2-7B -- deal Wo's rows among themselves, request them right behind
-// their q | k | v rows (the whole Wo share of a CU, ~50 KB, sits in registers while the attention runs), then wait for the
-// heads' done flags, gather the quantised attention output (granules -> the LDS image X.load reads) and finish their rows:
-// the Wo launch's boundary, its 1 us to the first request and its 1.2 us to the first byte are gone (r04 trace).
-// RWO = Wo rows per wave = ceil(rows / (8 * non-attention workgroups)).
-template <int DT, int NJ, int RW, int NORM, int HD, bool Q8, int PB, bool KT, int NP, bool WO = false, int RWO = 3>
+template <int DT, int NJ, int RW, int NORM, int HD, bool Q8, int PB, bool KT, int NP>
 __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols, int pgeo,
                                                              const uint8_t *pwq, const uint8_t *pwk, const uint8_t *pwv,
-                                                             const DecGemvParams P, const DecAttnParams A, const DecQkvAttnExtra E,
-                                                             const DecGemvParams PW)
+                                                             const DecGemvParams P, const DecAttnParams A, const DecQkvAttnExtra E)
 {
     // pgeo / pwq / pwk / pwv (round 5): heads | kv_heads << 8 | gk << 16 and the three matrices as leading scalar arguments -- with
     // px / pnw / pnb / pcols they fill the 14 dwords the hardware preloads into SGPRs at wave launch, so that every q | k | v row
@@ -118,25 +110,6 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     const int per = g_gk / group;
     const bool attn_wg = bg % per == 0;
     const int head = g * group + bg / per;
-    // Wo rows of this wave: the non-attention workgroups numbered in grid order, rows dealt round-robin over their waves
-    typename Fmt::W wo[WO ? RWO : 1];
-    half_t wres = (half_t)0;
-    const int n_attn_before = g * group + (bg + per - 1) / per;            // attention workgroups with a smaller index
-    const int wv_wo = (A.kv_heads * E.gk - A.heads) * (TH / 64);            // waves that take Wo rows
-    const int gw_wo = ((int)blockIdx.x - n_attn_before) * (TH / 64) + wave;
-    const size_t wo_row_bytes = tiled_row_bytes(DT, (size_t)PW.nblk);
-    auto load_wo = [&]() {
-        if constexpr (WO) {
-            if (attn_wg) return;
-#pragma unroll
-            for (int i = 0; i < RWO; i++) {
-                const int v = i * wv_wo + gw_wo;
-                if (i > 0 && v >= PW.total_rows) continue;
-                wo[i].load(PW.W0[0] + (size_t)min(v, PW.total_rows - 1) * wo_row_bytes, PW.nblk, lane);
-            }
-            wres = PW.residual[min(min(lane, RWO - 1) * wv_wo + gw_wo, PW.total_rows - 1)];
-        }
-    };
     if (threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }
     if (wave >= NP) load_rows(0, 1);          // (before the barrier: see k_dec_gemv)
     // the position and the step's tag: scalar loads through pointers of the argument block -- read BEHIND the first weight
@@ -147,7 +120,7 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     const unsigned epoch = ((*(const __attribute__((address_space(4))) unsigned *)(E.epoch) + E.epoch_add) << 20) | ((unsigned)pos & 0xFFFFFu);
     DecAttnFusedIn F;
     F.gran = E.gran; F.epoch = epoch; F.pos = pos; F.err = E.err; F.timeout_ticks = (long long)E.timeout_us * 100;
-    F.att_gran = WO ? E.att_gran : nullptr;
+    F.att_gran = nullptr;
     __syncthreads();
     if (wave >= NP) {
         load_rows(1, RW);
@@ -181,9 +154,6 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
         A.trace[(size_t)(A.heads + (int)blockIdx.x) * 8 + 0] = t_kernel;
         A.trace[(size_t)(A.heads + (int)blockIdx.x) * 8 + 1] = wall_clock64();
     }
-    // the Wo rows are requested now that this wave's q | k | v rows are out: they stream while the heads' attention runs and the
-    // memory system has nothing else to do (requested behind the q | k | v rows they delayed every head by the 10 MB they add)
-    load_wo();
     if (attn_wg) {
         __syncthreads();             // every wave of this workgroup is done with the activation image: the LDS is the attention's now
         if (wave >= 4) return;
@@ -191,91 +161,14 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
         dec_attn_body<HD, Q8, false, PB, KT, true>(smem, nullptr, A.kcache, A.vcache, A.heads, A.kv_heads, A, head, F, R);
         return;
     }
-    if constexpr (WO) {
-        // ---- the Wo rows.  Wave 0 waits for the heads' flags (one granule per head, polled with a pause: 256 bytes per round and
-        // workgroup), then every thread fetches its share of the image and checks each granule's tag itself (the flag of a head
-        // is not ordered behind its data), retrying the ones that are not there yet
-        const int cols = PW.cols, nc = cols / 4, nbk = cols / 32, ng = nc + 2 * nbk;
-        const long long t_give_up = wall_clock64() + F.timeout_ticks;
-        if (wave == 0) {
-            // (until most heads are done: the last ones are waited for on the data granules themselves -- one memory round trip
-            //  instead of two behind the last head; polling the 10 KB image from the start would be 2 MB per round over the grid)
-            const int enough = A.heads - (A.heads >> 3);
-            for (;;) {
-                int cnt = 0;
-                for (int hh = lane; hh < A.heads; hh += 64)
-                    cnt += (unsigned)(__hip_atomic_load(E.att_gran + ng + hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == epoch ? 1 : 0;
-                const int done = (int)wave_sum((float)cnt);       // (small integers: exact)
-                if (done >= enough) break;
-                if (wall_clock64() > t_give_up) { if (lane == 0) atomicExch(E.err, 0x52u); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        long long *const trw = (A.trace && threadIdx.x == 0) ? A.trace + (size_t)(A.heads + (int)blockIdx.x) * 8 : nullptr;
-        if (trw) trw[2] = wall_clock64();
-        __syncthreads();             // (also: every wave has read the QKV activation image, the LDS takes the Wo input now)
-        const XLds LW = xlds_carve(smem, cols);
-        {
-            // this thread's granules (i = tid + k * TH): all requested at once, the missing ones again until they are there
-            constexpr int MAXG = 4;                              // cols <= 4 * 512 * 32 / 10: 4096 columns need 3
-            unsigned long long gv[MAXG];
-            unsigned have = 0;
-            for (;;) {
-#pragma unroll
-                for (int k = 0; k < MAXG; k++) {
-                    const int i = (int)threadIdx.x + k * TH;
-                    if (i < ng && !((have >> k) & 1u)) gv[k] = __hip_atomic_load(E.att_gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                bool all = true;
-#pragma unroll
-                for (int k = 0; k < MAXG; k++) {
-                    const int i = (int)threadIdx.x + k * TH;
-                    if (i < ng && !((have >> k) & 1u)) {
-                        if ((unsigned)(gv[k] >> 32) == epoch) have |= 1u << k; else all = false;
-                    }
-                }
-                if (all) break;
-                if (wall_clock64() > t_give_up) { atomicExch(E.err, 0x53u); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int k = 0; k < MAXG; k++) {
-                const int i = (int)threadIdx.x + k * TH;
-                if (i < ng) {
-                    const uint32_t dv = (uint32_t)gv[k];
-                    if (i < nc) reinterpret_cast<uint32_t *>(LW.codes)[i] = dv;
-                    else if (i < nc + nbk) LW.scale[i - nc] = __builtin_bit_cast(float, dv);
-                    else LW.xsum[i - nc - nbk] = __builtin_bit_cast(float, dv);
-                }
-            }
-        }
-        if (trw) trw[3] = wall_clock64();
-        __syncthreads();
-        typename Fmt::X XW;
-        XW.load(LW.codes, LW.scale, LW.xsum, lane, PW.nblk);
-        float aw[RWO];
-#pragma unroll
-        for (int i = 0; i < RWO; i++) aw[i] = (i == 0 || i * wv_wo + gw_wo < PW.total_rows) ? wo[i].dot(XW) : 0.0f;
-#pragma unroll
-        for (int i = 0; i < RWO; i++) aw[i] = wave_sum(aw[i]);
-        float a0 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < RWO; i++) { if (lane == i) a0 = aw[i]; }
-        const int v = lane * wv_wo + gw_wo;
-        if (lane < RWO && v < PW.total_rows) dec_finish_row<EPI_RESIDUAL>(PW, dec_locate(PW, v), a0, 0.0f, wres, (half_t)0);
-        if (trw) trw[4] = wall_clock64();
-    }
 }
 
 // host side (one translation unit per weight format: ifa_dqkvattn_<format>.hip)
 bool dec_qkv_attn_supported(int w_dtype, int cols, int heads, int kv_heads, int head_dim, int num_cus, int *gk_out, int *rw_out);
-// PW: the Wo launch's parameters (EPI_RESIDUAL, quantised attention output as its input) when the Wo rows ride along, else null
 int dec_qkv_attn_launch(int w_dtype, int norm, bool kv_q8, int pb, bool kt, const DecGemvParams &P, const DecAttnParams &A, const DecQkvAttnExtra &E,
-                        const DecGemvParams *PW, int max_ctx, hipStream_t s);
-// can the Wo rows ride along?  ([dim][heads * head_dim] of the QKV format, dealt <= 3 rows per wave)
-bool dec_qkv_attn_wo_supported(int w_dtype, int wo_dtype, int wo_rows, int wo_cols, int heads, int kv_heads, int head_dim, int gk);
+                        int max_ctx, hipStream_t s);
 template <int DT>
 int dec_qkv_attn_launch_dt(int norm, bool kv_q8, int pb, bool kt, int rw, const DecGemvParams &P, const DecAttnParams &A, const DecQkvAttnExtra &E,
-                           const DecGemvParams *PW, int max_ctx, hipStream_t s);
+                           int max_ctx, hipStream_t s);
 
 } // namespace ifa

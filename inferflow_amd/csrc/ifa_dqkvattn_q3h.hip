@@ -3,5 +3,5 @@
 #include "ifa_dqkvattn_impl.h"
 
 namespace ifa {
-template int dec_qkv_attn_launch_dt<Q3H_B64T1>(int, bool, int, bool, int, const DecGemvParams &, const DecAttnParams &, const DecQkvAttnExtra &, const DecGemvParams *, int, hipStream_t);
+template int dec_qkv_attn_launch_dt<Q3H_B64T1>(int, bool, int, bool, int, const DecGemvParams &, const DecAttnParams &, const DecQkvAttnExtra &, int, hipStream_t);
 } // namespace ifa

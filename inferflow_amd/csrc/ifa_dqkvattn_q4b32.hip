@@ -4,8 +4,8 @@
 
 namespace ifa {
 
-extern template int dec_qkv_attn_launch_dt<Q3H_B64T1>(int, bool, int, bool, int, const DecGemvParams &, const DecAttnParams &, const DecQkvAttnExtra &, const DecGemvParams *, int, hipStream_t);
-template int dec_qkv_attn_launch_dt<Q4_B32T1A>(int, bool, int, bool, int, const DecGemvParams &, const DecAttnParams &, const DecQkvAttnExtra &, const DecGemvParams *, int, hipStream_t);
+extern template int dec_qkv_attn_launch_dt<Q3H_B64T1>(int, bool, int, bool, int, const DecGemvParams &, const DecAttnParams &, const DecQkvAttnExtra &, int, hipStream_t);
+template int dec_qkv_attn_launch_dt<Q4_B32T1A>(int, bool, int, bool, int, const DecGemvParams &, const DecAttnParams &, const DecQkvAttnExtra &, int, hipStream_t);
 
 // Which models take the fused launch: q / k / v of one int8-path format with a kernel instance; 128-wide heads; a grid of one
 // workgroup per CU that splits evenly into kv groups (gk workgroups each, a multiple of the query heads per group) whose
@@ -27,26 +27,9 @@ bool dec_qkv_attn_supported(int w_dtype, int cols, int heads, int kv_heads, int 
     return true;
 }
 
-bool dec_qkv_attn_wo_supported(int w_dtype, int wo_dtype, int wo_rows, int wo_cols, int heads, int kv_heads, int head_dim, int gk)
-{
-#ifndef IFA_EXPERIMENTAL
-    return false;        // (the instances exist in experimental builds only: ifa_dqkvattn_impl.h)
-#endif
-    const bool q4 = w_dtype == Q4_B32T1A || w_dtype == Q4_B32T1B, q4o = wo_dtype == Q4_B32T1A || wo_dtype == Q4_B32T1B;
-    if (!((q4 && q4o) || (w_dtype == wo_dtype))) return false;
-    if (wo_cols != heads * head_dim || wo_cols != 4096 || wo_rows < 1) return false;        // (the kernel instances: 4096-column rows)
-    const int waves = (kv_heads * gk - heads) * (QA_THREADS / 64);
-    return waves > 0 && (wo_rows + waves - 1) / waves <= 3;
-}
-
 int dec_qkv_attn_launch(int w_dtype, int norm, bool kv_q8, int pb, bool kt, const DecGemvParams &P0, const DecAttnParams &A, const DecQkvAttnExtra &E,
-                        const DecGemvParams *PW0, int max_ctx, hipStream_t s)
+                        int max_ctx, hipStream_t s)
 {
-    DecGemvParams PWv; const DecGemvParams *PW = nullptr;
-    if (PW0) {
-        PWv = *PW0; PWv.trace = nullptr; PWv.total_rows = PWv.rows[0]; PWv.nblk = PWv.cols / block_capacity(w_dtype); PWv.nsets = 1;
-        PW = &PWv;
-    }
     DecGemvParams P = P0;
     P.trace = nullptr;
     P.total_rows = P.rows[0] + P.rows[1] + P.rows[2];
@@ -55,8 +38,8 @@ int dec_qkv_attn_launch(int w_dtype, int norm, bool kv_q8, int pb, bool kt, cons
     if (!dec_qkv_attn_supported(w_dtype, P.cols, A.heads, A.kv_heads, 128, A.kv_heads * E.gk, &gk, &rw) || gk != E.gk)
         return ifa_fail(IFA_ERR_ARG, "fused QKV + attention: unsupported shape");
     switch (w_dtype) {
-    case Q4_B32T1A: case Q4_B32T1B: return dec_qkv_attn_launch_dt<Q4_B32T1A>(norm, kv_q8, pb, kt, rw, P, A, E, PW, max_ctx, s);
-    case Q3H_B64T1: return dec_qkv_attn_launch_dt<Q3H_B64T1>(norm, kv_q8, pb, kt, rw, P, A, E, PW, max_ctx, s);
+    case Q4_B32T1A: case Q4_B32T1B: return dec_qkv_attn_launch_dt<Q4_B32T1A>(norm, kv_q8, pb, kt, rw, P, A, E, max_ctx, s);
+    case Q3H_B64T1: return dec_qkv_attn_launch_dt<Q3H_B64T1>(norm, kv_q8, pb, kt, rw, P, A, E, max_ctx, s);
     default: return ifa_fail(IFA_ERR_DTYPE, "fused QKV + attention: dtype %d", w_dtype);
     }
 }

@@ -22,12 +22,10 @@
 #include "ifa_moe.h"
 #include "ifa_gemm_rows_mfma.h"
 #include "ifa_gemm_big.h"
-#include "experimental/ifa_decode_persist_launch.h"      // (declarations; the kernels are built with IFA_EXPERIMENTAL=1 only: ifa_experimental_off.hip)
 #include "ifa_decode_lmhead_tail.h"
 #include "ifa_decode_singles.h"
 #include "ifa_decode_qkv_attn.h"
 #include "ifa_decode_chain.h"
-#include "experimental/ifa_decode_wo_ffn.h"
 
 using namespace ifa;
 
@@ -118,23 +116,7 @@ struct ifa_model {
     // attention as the tail of the QKV launch (ifa_decode_qkv_attn.h): granules [layers][(heads + 2 kv_heads) * head_dim], the
     // decode-call counter the tags are built from, its own error word
     int opt_fuse_attn = 1, opt_fuse_attn_timeout_us = 20000, qa_on = 0, qa_gk = 0;
-    int opt_fuse_wo = 0, qa_wo = 0;            // ... and the Wo rows behind it (same launch, 3 launches per layer): bit-identical, but the two memory round trips of its
-                                               // hand-off cost what the Wo launch costs (r04 trace: 3.3 us behind the last head against 4.6 us for the launch, and the attention runs
-                                               // 0.3 us longer next to the Wo stream) -- opt-in
-    unsigned long long *qa_gran = nullptr, *qa_att_gran = nullptr;
-    // the Wo rows in FRONT of the W1 / W3 launch (ifa_decode_wo_ffn.h): done flags [layers][workgroups]
-    // Built twice, bit-identical both times, SLOWER both times (r04, profiles/r04_wo_ffn_fused_trace.log) -- opt-in (fuse_wo_ffn):
-    //  * split by WAVE (front waves: Wo + all-gather + quantiser; loader waves: the W1 / W3 stream), 19.8-21.6 us against 4.6 + 12.6
-    //    for the two launches: every store, flag and poll of the front waves queues behind the loader waves' requests in the same
-    //    CU's memory pipeline (Wo rows out at 4.4 us, gather 5-6 us, quantiser 1.6-2.5 us: the chain ends after the stream does);
-    //  * split by WORKGROUP (64 front CUs: Wo, exchange, quantiser, publish the image; 192 loader CUs: stream, one poll, copy the
-    //    image), 24.6 us: a CU pulls ~25 GB/s whatever the rest of the chip does (its in-flight window / the memory latency), so
-    //    the 10.5 MB of Wo need all 256 CUs to arrive in 1.6 us -- on 64 they take 8 us -- and the chain of write-through drain
-    //    (1.1 us), flag round trip (1.1), payload round trip (1.0), quantiser (1.2), drain (1.1), flag + image on the loaders (2.7)
-    //    is 8 us more.  A hand-off through memory costs 3.3 us in this protocol; a kernel boundary + first load 2.5.
-    int opt_fuse_wo_ffn = 0, wf_on = 0;
-    unsigned long long *wf_gran = nullptr;
-    void *wf_img = nullptr;                     // the quantised FFN input the front workgroups publish (one buffer: a launch consumes it before the next writes it)
+    unsigned long long *qa_gran = nullptr;
     unsigned *qa_call = nullptr, *qa_err = nullptr, qa_calls = 0;
     // consecutive GEMV ops of a layer as ONE launch with the next op's rows requested before the hand-off (ifa_decode_chain.h):
     // option fuse_ffn = 1: W1 | W3 -> W2; 2: Wo -> W1 | W3 -> W2.  ch_on = what the captured step uses.  Granules [layers][dim + ffn].
@@ -173,12 +155,7 @@ struct ifa_model {
     int opt_attn_post_as_residual = 1;
     half_t *pn = nullptr;           // [tokens][dim] scratch of the post norms (allocated with the other activations)
     int opt_fused = 1, opt_graph = 1, opt_rpw_qkv = 0, opt_rpw_wo = 0, opt_rpw_ffn = 0, opt_rpw_w2 = 0, opt_rpw_lm = 0;
-    // persistent decode layers (ifa_decode_persist.h): all layers of a token as ONE launch, bit-identical to the five-launch
-    // layer.  Opt-in (option "persist"): measured on MI355X it is SLOWER than five launches for this workload (55 vs 43.5 us
-    // per Llama-2-7B layer) -- the hand-offs cost what the kernel boundaries cost and the 4-bit decode +
-    // Q8 quantiser are issue-bound on the few resident waves.  persist_mode = what the captured step uses.
-    int opt_persist = 0, opt_persist_ctx = 512, opt_persist_timeout_us = 20000, opt_persist_trace = -1, opt_persist_debug = 0, opt_persist_depth = 0, opt_persist_prio = 0;
-    int opt_debug_layers = 0;                  // > 0: the decode step runs only the first N layers (both paths; tools/debug_persist.py)
+    int opt_debug_layers = 0;                  // > 0: the decode step runs only the first N layers (tools/debug_engine.py)
     // layer-wise parity tests (tests/test_gpu_layerwise_oracle.py): the fused decode step starts at layer debug_layer0 (with
     // debug_layers = N: layers [layer0, layer0 + N)) and, with debug_hidden_in, takes its input from the buffer "x" as the caller
     // left it instead of gathering the token's embedding row -- the SAME captured launches the bench times, fed the oracle's state
@@ -193,17 +170,6 @@ struct ifa_model {
     int opt_prefill_mid = 1, opt_prefill_mid_max = 256;      // (320 tokens and up: the large tiles win again, profiles/r06_prefill_mid_ab.log)
     int opt_rows_kparts = 1, opt_gemm_splitk = 1;   // 0: never the launches whose workgroups wait for partner workgroups (K parts of the 9..32-row GEMM, split-K halves of the large-tile GEMM)
     int opt_debug_mo_alloc_fail = 0;           // tests: ensure_mo_build fails like an exhausted allocator after its first copy
-    int persist_mode = 0, ps_state = 0;        // ps_state: 0 unknown, 1 usable (copies built), -1 unsupported
-    std::string ps_why;
-    std::vector<void *> ps_wqkv, ps_w13;       // per layer: wq | wk | wv rows in one buffer; w1 / w3 interleaved row by row
-    std::vector<void *> ps_bqkv, ps_b13;       // per layer: the biases in the same order (null when the model has none)
-    std::map<int, void *> ps_tabs;             // per KV slot: device PsLayer[layers]
-    unsigned long long *ps_arena = nullptr;    // granule arenas of the five edges
-    size_t ps_arena_bytes = 0, ps_goff[5] = {0, 0, 0, 0, 0};
-    unsigned *ps_err = nullptr;                // device [4]: code, workgroup, layer, wave
-    long long *ps_trace = nullptr;             // device [workgroups][32]
-    int ps_nja = 0, ps_njb = 0, ps_ncu = 0;
-    size_t ps_smem = 0;
     static constexpr int RING = 1024;
 };
 
@@ -420,60 +386,29 @@ static bool qkv_attn_layer_ok(const ifa_model *m, int l, int *gk_out)
 static int qkv_attn_ready(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
-    int want = m->opt_fuse_attn && waits_enabled() && !m->attn_split && !m->persist_mode && dec_attn_smem(c.head_dim, c.max_ctx, 256) <= IFA_LDS_LIMIT;
+    int want = m->opt_fuse_attn && waits_enabled() && !m->attn_split && dec_attn_smem(c.head_dim, c.max_ctx, 256) <= IFA_LDS_LIMIT;
     int gk = 0;
     for (int l = 0; want && l < c.layers; l++) if (!qkv_attn_layer_ok(m, l, &gk)) want = 0;
     // a head's attention waits for the gk workgroups of its kv group: the grid (kv_heads * gk workgroups of 512 threads at 256
     // registers, one per CU) must be resident at once on the CUs this process may use (CU mask, partitioned device)
     if (want && (long long)c.kv_heads * gk > (long long)visible_cus()) want = 0;
-    // the Wo rows ride along when every layer's Wo is a plain residual GEMV over the quantised attention output
-    int want_wo = want && m->opt_fuse_wo && m->attq && m->opt_attn_q8 && !c.parallel_attn && !c.share_input && !scale_on(c.attn_out_scale);
-    for (int l = 0; want_wo && l < c.layers; l++) {
-        const Tensor &wo = m->layers[(size_t)l].t[T_WO];
-        if (!wo.present() || !wo.tiled || !dec_qkv_attn_wo_supported(m->layers[(size_t)l].t[T_WQ].dtype, wo.dtype, (int)wo.rows, (int)wo.cols, c.heads, c.kv_heads, c.head_dim, gk))
-            want_wo = 0;
-    }
     if (want && !m->qa_gran) {
         const size_t n = (size_t)c.layers * (size_t)(c.heads + 2 * c.kv_heads) * c.head_dim;
         IFA_HIP_CHECK(hipMalloc((void **)&m->qa_gran, n * 8));
         IFA_HIP_CHECK(hipMemsetAsync(m->qa_gran, 0, n * 8, m->stream));
         if (m->qa_call) { (void)hipFree(m->qa_call); m->qa_call = nullptr; }
         if (m->qa_err) { (void)hipFree(m->qa_err); m->qa_err = nullptr; }
-        const size_t na = (size_t)c.layers * (size_t)att_gran_count(c.heads, c.head_dim);
-        IFA_HIP_CHECK(hipMalloc((void **)&m->qa_att_gran, na * 8));
-        IFA_HIP_CHECK(hipMemsetAsync(m->qa_att_gran, 0, na * 8, m->stream));
         IFA_HIP_CHECK(hipMalloc((void **)&m->qa_call, 16));
         IFA_HIP_CHECK(hipMemsetAsync(m->qa_call, 0, 16, m->stream));
         IFA_HIP_CHECK(hipMalloc((void **)&m->qa_err, 16));
         IFA_HIP_CHECK(hipMemsetAsync(m->qa_err, 0, 16, m->stream));
         IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     }
-    // the Wo rows in front of the W1 / W3 launch: dense gated / plain FFN behind an RMS pre-norm, sequential wiring, the attention
-    // output arriving quantised (XqImage), Wo / W1 / W3 of one format with a kernel instance
-    int want_wf = m->opt_fuse_wo_ffn && !m->persist_mode && !want_wo && c.norm_kind == 0 && c.tp_size <= 1 && c.experts == 0 && m->attq && m->opt_attn_q8
-        && c.head_dim % 32 == 0 && !c.parallel_attn && !c.share_input && !scale_on(c.attn_out_scale);
-    for (int l = 0; want_wf && l < c.layers; l++) {
-        const Layer &L = m->layers[(size_t)l];
-        const Tensor &wo = L.t[T_WO], &w1 = L.t[T_W1], &w3 = L.t[T_W3];
-        if (!wo.present() || !wo.tiled || !w1.present() || !w1.tiled || (w3.present() && !w3.tiled) || !L.t[T_FFN_NORM].present()
-            || (int)wo.cols != c.heads * c.head_dim || (int)wo.rows != c.dim || (int)w1.cols != c.dim
-            || !dec_wo_ffn_supported(w1.dtype, wo.dtype, w3.present() ? w3.dtype : w1.dtype, c.dim, (int)wo.cols, (int)w1.rows, w3.present(), num_cus()))
-            want_wf = 0;
-    }
-    if (want_wf && !m->wf_gran) {
-        const size_t n = (size_t)c.layers * 2 * WF_FRONT;               // per layer: a done flag and an image flag per front workgroup
-        IFA_HIP_CHECK(hipMalloc((void **)&m->wf_img, xq_image_bytes(c.dim) + 64));
-        IFA_HIP_CHECK(hipMalloc((void **)&m->wf_gran, n * 8));
-        IFA_HIP_CHECK(hipMemsetAsync(m->wf_gran, 0, n * 8, m->stream));
-        if (!m->qa_call) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_call, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_call, 0, 16, m->stream)); }
-        if (!m->qa_err) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_err, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_err, 0, 16, m->stream)); }
-        IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
-    }
     // the chained FFN launch: dense gated FFN behind an RMS pre-norm, sequential wiring, W1 / W3 / W2 (and Wo) of one format with an
     // instance, one workgroup per CU resident at once
-    int want_ch = (m->opt_fuse_ffn && waits_enabled() && !m->persist_mode && !want_wf && c.norm_kind == 0 && c.tp_size <= 1 && c.experts == 0
+    int want_ch = (m->opt_fuse_ffn && waits_enabled() && c.norm_kind == 0 && c.tp_size <= 1 && c.experts == 0
                    && !c.parallel_attn && !c.share_input && num_cus() <= visible_cus()) ? std::min(m->opt_fuse_ffn, 2) : 0;
-    if (want_ch == 2 && (want_wo || !m->attq || !m->opt_attn_q8 || c.head_dim % 32 != 0)) want_ch = 1;
+    if (want_ch == 2 && (!m->attq || !m->opt_attn_q8 || c.head_dim % 32 != 0)) want_ch = 1;
     for (int l = 0; want_ch && l < c.layers; l++) {
         const Layer &L = m->layers[(size_t)l];
         const Tensor &wo = L.t[T_WO], &w1 = L.t[T_W1], &w3 = L.t[T_W3], &w2 = L.t[T_W2];
@@ -495,8 +430,8 @@ static int qkv_attn_ready(ifa_model *m)
         if (!m->qa_err) { IFA_HIP_CHECK(hipMalloc((void **)&m->qa_err, 16)); IFA_HIP_CHECK(hipMemsetAsync(m->qa_err, 0, 16, m->stream)); }
         IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     }
-    if (want != m->qa_on || (want && gk != m->qa_gk) || want_wo != m->qa_wo || want_wf != m->wf_on || want_ch != m->ch_on) {
-        m->qa_on = want; m->qa_gk = gk; m->qa_wo = want_wo; m->wf_on = want_wf; m->ch_on = want_ch; drop_graphs(m);
+    if (want != m->qa_on || (want && gk != m->qa_gk) || want_ch != m->ch_on) {
+        m->qa_on = want; m->qa_gk = gk; m->ch_on = want_ch; drop_graphs(m);
     }
     return IFA_OK;
 }
@@ -529,39 +464,9 @@ static int launch_qkv_attn(ifa_model *m, int l, const half_t *x, unsigned tag_ad
     DecQkvAttnExtra E; memset(&E, 0, sizeof(E));
     E.gran = m->qa_gran + (size_t)l * (size_t)(c.heads + 2 * c.kv_heads) * c.head_dim;
     E.epoch = m->qa_call; E.epoch_add = tag_add; E.err = m->qa_err; E.timeout_us = m->opt_fuse_attn_timeout_us; E.gk = m->qa_gk;
-    E.att_gran = m->qa_att_gran + (size_t)l * (size_t)att_gran_count(c.heads, c.head_dim);
     const int pb = (m->attn_pb == 64 || m->attn_pb == 128) ? m->attn_pb : 256;
     const bool kt = m->opt_attn_kt && !A.kv_q8 && dec_attn_smem(c.head_dim, c.max_ctx, pb) <= IFA_LDS_LIMIT;
-    DecGemvParams PW; memset(&PW, 0, sizeof(PW));
-    if (m->qa_wo) {      // launch_wo's EPI_RESIDUAL parameters; the input arrives as granules, not through PW.x
-        PW.cols = (int)L.t[T_WO].cols; PW.nblk = PW.cols / 32; PW.eps = c.eps;
-        PW.W0[0] = wbytes(L.t[T_WO]); PW.rows[0] = (int)L.t[T_WO].rows; PW.nsets = 1;
-        PW.b0[0] = (const half_t *)L.t[T_WO_B].data; PW.y[0] = m->a; PW.residual = x;
-        A.xq = nullptr;                 // nobody reads the global image
-    }
-    return dec_qkv_attn_launch(L.t[T_WQ].dtype, 1, A.kv_q8 != 0, pb, kt, P, A, E, m->qa_wo ? &PW : nullptr, c.max_ctx, m->stream);
-}
-
-// Wo rows + FFN up-projection (norm, quantiser, W1 | W3, activation, gate) in ONE launch
-static int launch_wo_ffn(ifa_model *m, int l, const half_t *x, unsigned tag_add = 0)
-{
-    const ifa_model_config &c = m->cfg;
-    Layer &L = m->layers[(size_t)l];
-    DecGemvParams PW; memset(&PW, 0, sizeof(PW));       // launch_wo's EPI_RESIDUAL / NORM 2 parameters
-    PW.x = reinterpret_cast<const half_t *>(m->attq); PW.cols = (int)L.t[T_WO].cols; PW.nblk = PW.cols / 32; PW.eps = c.eps;
-    PW.W0[0] = wbytes(L.t[T_WO]); PW.rows[0] = (int)L.t[T_WO].rows; PW.nsets = 1;
-    PW.b0[0] = (const half_t *)L.t[T_WO_B].data; PW.y[0] = m->a; PW.residual = x;
-    DecGemvParams P; memset(&P, 0, sizeof(P));         // launch_ffn13's dense EPI_GLU / EPI_ACT, NORM 1 parameters
-    P.x = m->a; P.norm_w = (const half_t *)L.t[T_FFN_NORM].data; P.norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
-    P.eps = c.eps; P.cols = c.dim; P.nblk = c.dim / 32; P.act_kind = c.act_kind; P.multi_base = c.ffn_norm_base;
-    P.W0[0] = wbytes(L.t[T_W1]); P.b0[0] = (const half_t *)L.t[T_W1_B].data;
-    P.y[0] = m->t1; P.rows[0] = (int)L.t[T_W1].rows; P.nsets = 1;
-    const bool glu = L.t[T_W3].present();
-    if (glu) { P.W1 = wbytes(L.t[T_W3]); P.b1 = (const half_t *)L.t[T_W3_B].data; }
-    DecWoFfnExtra E; memset(&E, 0, sizeof(E));
-    E.a_flags = m->wf_gran + (size_t)l * 2 * WF_FRONT; E.img_flags = E.a_flags + WF_FRONT; E.img = m->wf_img; E.state = m->state; E.epoch = m->qa_call; E.epoch_add = tag_add;
-    E.err = m->qa_err; E.timeout_us = m->opt_fuse_attn_timeout_us; E.trace = g_trace_ptr;
-    return dec_wo_ffn_launch(L.t[T_W1].dtype, glu, PW, P, E, num_cus(), m->stream);
+    return dec_qkv_attn_launch(L.t[T_WQ].dtype, 1, A.kv_q8 != 0, pb, kt, P, A, E, c.max_ctx, m->stream);
 }
 
 static int launch_qkv(ifa_model *m, int l, const half_t *x)
@@ -1154,192 +1059,6 @@ static int launch_moe_router(ifa_model *m, int l)
     return IFA_OK;
 }
 
-// ------------------------------------------------ persistent decode layers (ifa_decode_persist.h)
-// Which models: the sequential RMS-norm wiring with a gated FFN (Llama / Mistral / Yi family), all seven matrices of
-// a layer in ONE int8-GEMV format that has kernels (Q4_B32T1A/B, Q3H_B64T1), heads * head_dim == dim, head_dim 64 / 128,
-// F16 or Q8 KV cache.  Everything else keeps the five-launch layer.
-static bool persist_supported(ifa_model *m, std::string *why)
-{
-    const ifa_model_config &c = m->cfg;
-    auto fail = [&](const char *s) { if (why) *why = s; return false; };
-    std::string w2;
-    if (!fused_supported(m, &w2)) { if (why) *why = w2; return false; }
-    if (c.experts > 0) return fail("persistent decode: mixture-of-experts layers use the five-launch path");
-    if (c.norm_kind != 0 || c.parallel_attn || c.share_input) return fail("persistent decode: sequential RMS-norm wiring only");
-    if (c.tp_size > 1) return fail("persistent decode: single-worker models only");
-    if (scale_on(c.attn_out_scale) || scale_on(c.ffn_out_scale) || scale_on(c.out_scale)) return fail("persistent decode: no output scales");
-    if (c.head_dim != 64 && c.head_dim != 128) return fail("persistent decode: head_dim 64 / 128");
-    if (c.heads * c.head_dim != c.dim) return fail("persistent decode: heads * head_dim must equal dim");
-    if (c.kv_dtype != F16 && c.kv_dtype != Q8_B32T2) return fail("persistent decode: F16 or Q8 KV cache");
-    if (c.dim % 64 != 0 || c.ffn % 64 != 0) return fail("persistent decode: dim / ffn must be multiples of 64");
-    const int ncu = num_cus();
-    if (c.heads > ncu) return fail("persistent decode: more heads than compute units");
-    const int dt0 = m->layers.empty() ? -1 : m->layers[0].t[T_WQ].dtype;
-    if (!(is_q4(dt0) || dt0 == Q3H_B64T1)) return fail("persistent decode: weight format without a persistent kernel");
-    const size_t QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim;
-    for (const Layer &L : m->layers) {
-        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
-        for (int id : ids) {
-            const Tensor &t = L.t[id];
-            if (!t.present() || !t.tiled || !same_fmt(t.dtype, dt0)) return fail("persistent decode: all seven matrices of a layer must share one int8-GEMV format");
-        }
-        if (L.t[T_WQ].rows != QD || L.t[T_WK].rows != KVD || L.t[T_WV].rows != KVD || L.t[T_WO].rows != (size_t)c.dim || L.t[T_WO].cols != QD
-            || L.t[T_W1].rows != (size_t)c.ffn || L.t[T_W3].rows != (size_t)c.ffn || L.t[T_W2].rows != (size_t)c.dim || L.t[T_W2].cols != (size_t)c.ffn
-            || L.t[T_WQ].cols != (size_t)c.dim || L.t[T_W1].cols != (size_t)c.dim)
-            return fail("persistent decode: unexpected matrix shapes");
-        if (!L.t[T_FFN_NORM].present()) return fail("persistent decode: ffn pre-norm required");
-    }
-    const int cap = block_capacity(dt0);
-    const int nja = (c.dim / cap + 63) / 64, njb = (c.ffn / cap + 63) / 64;
-    if (!dec_persist_has(dt0, nja, njb, c.head_dim)) return fail("persistent decode: no kernel instantiated for this shape");
-    const size_t rb_a = tiled_row_bytes(dt0, (size_t)c.dim / cap), rb_b = tiled_row_bytes(dt0, (size_t)c.ffn / cap);
-    if (4 * rb_a + 4096 > PS_RING || 2 * rb_b + 4096 > PS_RING) return fail("persistent decode: a row batch does not fit the LDS ring");
-    if (((size_t)c.dim / 2 + ncu - 1) / ncu * 2 > (size_t)PS_RES) return fail("persistent decode: too few compute units for this width");
-    if (ps_lds_bytes(std::max(c.dim, c.ffn), c.head_dim) > IFA_LDS_LIMIT) return fail("persistent decode: activation images do not fit the LDS next to the ring");
-    return true;
-}
-
-// load-time copies in the loader's streaming order + the granule arena
-static int persist_build(ifa_model *m)
-{
-    const ifa_model_config &c = m->cfg;
-    const int dt0 = m->layers[0].t[T_WQ].dtype, cap = block_capacity(dt0);
-    const size_t rb_a = tiled_row_bytes(dt0, (size_t)c.dim / cap);
-    const size_t QD = (size_t)c.heads * c.head_dim, KVD = (size_t)c.kv_heads * c.head_dim;
-    m->ps_wqkv.assign(m->layers.size(), nullptr); m->ps_w13.assign(m->layers.size(), nullptr);
-    m->ps_bqkv.assign(m->layers.size(), nullptr); m->ps_b13.assign(m->layers.size(), nullptr);
-    for (size_t l = 0; l < m->layers.size(); l++) {
-        Layer &L = m->layers[l];
-        uint8_t *qkv = nullptr, *w13 = nullptr;
-        IFA_HIP_CHECK(hipMalloc((void **)&qkv, (QD + 2 * KVD) * rb_a));
-        IFA_HIP_CHECK(hipMalloc((void **)&w13, 2 * (size_t)c.ffn * rb_a));
-        m->ps_wqkv[l] = qkv; m->ps_w13[l] = w13;
-        IFA_HIP_CHECK(hipMemcpyAsync(qkv, L.t[T_WQ].tiled, QD * rb_a, hipMemcpyDeviceToDevice, m->stream));
-        IFA_HIP_CHECK(hipMemcpyAsync(qkv + QD * rb_a, L.t[T_WK].tiled, KVD * rb_a, hipMemcpyDeviceToDevice, m->stream));
-        IFA_HIP_CHECK(hipMemcpyAsync(qkv + (QD + KVD) * rb_a, L.t[T_WV].tiled, KVD * rb_a, hipMemcpyDeviceToDevice, m->stream));
-        IFA_HIP_CHECK(hipMemcpy2DAsync(w13, 2 * rb_a, L.t[T_W1].tiled, rb_a, rb_a, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
-        IFA_HIP_CHECK(hipMemcpy2DAsync(w13 + rb_a, 2 * rb_a, L.t[T_W3].tiled, rb_a, rb_a, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
-        // biases (F16 vectors) in the same order; a missing one of a group counts as zeros
-        if (L.t[T_WQ_B].present() || L.t[T_WK_B].present() || L.t[T_WV_B].present()) {
-            half_t *b = nullptr;
-            IFA_HIP_CHECK(hipMalloc((void **)&b, (QD + 2 * KVD) * 2));
-            IFA_HIP_CHECK(hipMemsetAsync(b, 0, (QD + 2 * KVD) * 2, m->stream));
-            if (L.t[T_WQ_B].present()) IFA_HIP_CHECK(hipMemcpyAsync(b, L.t[T_WQ_B].data, QD * 2, hipMemcpyDeviceToDevice, m->stream));
-            if (L.t[T_WK_B].present()) IFA_HIP_CHECK(hipMemcpyAsync(b + QD, L.t[T_WK_B].data, KVD * 2, hipMemcpyDeviceToDevice, m->stream));
-            if (L.t[T_WV_B].present()) IFA_HIP_CHECK(hipMemcpyAsync(b + QD + KVD, L.t[T_WV_B].data, KVD * 2, hipMemcpyDeviceToDevice, m->stream));
-            m->ps_bqkv[l] = b;
-        }
-        if (L.t[T_W1_B].present() || L.t[T_W3_B].present()) {
-            half_t *b = nullptr;
-            IFA_HIP_CHECK(hipMalloc((void **)&b, 2 * (size_t)c.ffn * 2));
-            IFA_HIP_CHECK(hipMemsetAsync(b, 0, 2 * (size_t)c.ffn * 2, m->stream));
-            if (L.t[T_W1_B].present()) IFA_HIP_CHECK(hipMemcpy2DAsync(b, 4, L.t[T_W1_B].data, 2, 2, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
-            if (L.t[T_W3_B].present()) IFA_HIP_CHECK(hipMemcpy2DAsync(b + 1, 4, L.t[T_W3_B].data, 2, 2, (size_t)c.ffn, hipMemcpyDeviceToDevice, m->stream));
-            m->ps_b13[l] = b;
-        }
-    }
-    const size_t counts[5] = {(size_t)c.dim / 2, (QD + 2 * KVD) / 2, QD / 4 + QD / 16, (size_t)c.dim / 2, (size_t)c.ffn / 2};
-    size_t off = 0;
-    for (int i = 0; i < 5; i++) { m->ps_goff[i] = off; off += (counts[i] + 63) / 64 * 64; }
-    m->ps_arena_bytes = off * 8;
-    IFA_HIP_CHECK(hipMalloc((void **)&m->ps_arena, m->ps_arena_bytes));
-    IFA_HIP_CHECK(hipMalloc((void **)&m->ps_err, 16));
-    IFA_HIP_CHECK(hipMemsetAsync(m->ps_err, 0, 16, m->stream));
-    m->ps_ncu = num_cus();
-    IFA_HIP_CHECK(hipMalloc((void **)&m->ps_trace, sizeof(long long) * 32 * (size_t)m->ps_ncu));
-    IFA_HIP_CHECK(hipMemsetAsync(m->ps_trace, 0, sizeof(long long) * 32 * (size_t)m->ps_ncu, m->stream));
-    m->ps_nja = (c.dim / cap + 63) / 64; m->ps_njb = (c.ffn / cap + 63) / 64;
-    m->ps_smem = ps_lds_bytes(std::max(c.dim, c.ffn), c.head_dim);
-    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
-    return IFA_OK;
-}
-
-static void persist_drop(ifa_model *m)
-{
-    for (void *p : m->ps_wqkv) if (p) (void)hipFree(p);
-    for (void *p : m->ps_w13) if (p) (void)hipFree(p);
-    for (void *p : m->ps_bqkv) if (p) (void)hipFree(p);
-    for (void *p : m->ps_b13) if (p) (void)hipFree(p);
-    m->ps_wqkv.clear(); m->ps_w13.clear(); m->ps_bqkv.clear(); m->ps_b13.clear();
-    for (auto &kv : m->ps_tabs) if (kv.second) (void)hipFree(kv.second);
-    m->ps_tabs.clear();
-    if (m->ps_arena) { (void)hipFree(m->ps_arena); m->ps_arena = nullptr; }
-    if (m->ps_err) { (void)hipFree(m->ps_err); m->ps_err = nullptr; }
-    if (m->ps_trace) { (void)hipFree(m->ps_trace); m->ps_trace = nullptr; }
-    m->ps_state = 0; m->persist_mode = 0;
-}
-
-// *usable = 1 if this model can use the persistent launch (copies built on first use)
-static int persist_ready(ifa_model *m, int *usable)
-{
-    *usable = 0;
-    if (m->ps_state == 0) {
-        if (!persist_supported(m, &m->ps_why)) m->ps_state = -1;
-        else {
-            int rc = persist_build(m);
-            if (rc) { persist_drop(m); m->ps_state = -1; return rc; }
-            m->ps_state = 1;
-        }
-    }
-    *usable = m->ps_state > 0 ? 1 : 0;
-    return IFA_OK;
-}
-
-// the layer table of the active KV slot (a slot's cache allocations never move)
-static int persist_table(ifa_model *m, const PsLayer **out)
-{
-    auto it = m->ps_tabs.find(m->cur_slot);
-    if (it == m->ps_tabs.end()) {
-        std::vector<PsLayer> tab(m->layers.size());
-        for (size_t l = 0; l < m->layers.size(); l++) {
-            Layer &L = m->layers[l];
-            PsLayer &d = tab[l];
-            memset(&d, 0, sizeof(d));
-            d.wqkv = (const uint8_t *)m->ps_wqkv[l]; d.wo = (const uint8_t *)L.t[T_WO].tiled;
-            d.w13 = (const uint8_t *)m->ps_w13[l]; d.w2 = (const uint8_t *)L.t[T_W2].tiled;
-            d.attn_norm = (const half_t *)L.t[T_ATTN_NORM].data; d.attn_norm_b = (const half_t *)L.t[T_ATTN_NORM_B].data;
-            d.ffn_norm = (const half_t *)L.t[T_FFN_NORM].data; d.ffn_norm_b = (const half_t *)L.t[T_FFN_NORM_B].data;
-            d.bqkv = (const half_t *)m->ps_bqkv[l]; d.bo = (const half_t *)L.t[T_WO_B].data; d.b13 = (const half_t *)m->ps_b13[l];
-            d.b2 = (const half_t *)L.t[T_W2_B].data;
-            d.kcache = (uint8_t *)L.kcache; d.vcache = (uint8_t *)L.vcache;
-        }
-        void *dev = nullptr;
-        IFA_HIP_CHECK(hipMalloc(&dev, tab.size() * sizeof(PsLayer)));
-        IFA_HIP_CHECK(hipMemcpy(dev, tab.data(), tab.size() * sizeof(PsLayer), hipMemcpyHostToDevice));
-        it = m->ps_tabs.emplace(m->cur_slot, dev).first;
-    }
-    *out = (const PsLayer *)it->second;
-    return IFA_OK;
-}
-
-// layers [l0, l1) of the step as one launch: x_in -> x_out (plain F16 vectors)
-static int launch_persist(ifa_model *m, int l0, int l1, const half_t *x_in, half_t *x_out)
-{
-    const ifa_model_config &c = m->cfg;
-    const PsLayer *tab = nullptr;
-    int rc = persist_table(m, &tab);
-    if (rc) return rc;
-    const int dt0 = m->layers[0].t[T_WQ].dtype, cap = block_capacity(dt0);
-    IFA_HIP_CHECK(hipMemsetAsync(m->ps_arena, 0, m->ps_arena_bytes, m->stream));      // tags of the previous token
-    PsParams P; memset(&P, 0, sizeof(P));
-    P.layers = tab; P.x_in = x_in; P.x_out = x_out; P.state = m->state; P.rope_tab = m->rope_tab;
-    P.g_x = m->ps_arena + m->ps_goff[0]; P.g_qkv = m->ps_arena + m->ps_goff[1]; P.g_att = m->ps_arena + m->ps_goff[2];
-    P.g_a = m->ps_arena + m->ps_goff[3]; P.g_act = m->ps_arena + m->ps_goff[4];
-    P.err = m->ps_err; P.trace = m->opt_persist_trace >= 0 ? m->ps_trace : nullptr; P.trace_layer = m->opt_persist_trace;
-    P.dbg_att = m->opt_persist_debug ? m->att : nullptr;
-    P.layer_begin = l0; P.layer_end = l1;
-    P.dim = c.dim; P.ffn = c.ffn; P.heads = c.heads; P.kv_heads = c.kv_heads;
-    P.nblk_a = c.dim / cap; P.nblk_b = c.ffn / cap;
-    P.row_bytes_a = (unsigned)tiled_row_bytes(dt0, (size_t)P.nblk_a); P.row_bytes_b = (unsigned)tiled_row_bytes(dt0, (size_t)P.nblk_b);
-    P.eps = c.eps; P.attn_norm_base = c.attn_norm_base; P.ffn_norm_base = c.ffn_norm_base;
-    P.kq_scale = c.use_alibi ? 1.0f : c.kq_scale; P.act_kind = c.act_kind;
-    P.rope_order = c.rope_order; P.rope_cols = (int)(c.head_dim * c.partial_rotary + 0.5f);
-    P.alibi = c.use_alibi; P.alibi_base = c.tp_rank * c.heads; P.alibi_total = c.heads * std::max(1, c.tp_size);
-    P.timeout_ticks = (unsigned)std::max(100, m->opt_persist_timeout_us) * 100u;
-    P.tune_depth = m->opt_persist_depth; P.tune_prio = m->opt_persist_prio;
-    return dec_persist_launch(dt0, m->ps_nja, m->ps_njb, c.head_dim, c.kv_dtype == Q8_B32T2 ? 1 : 0, P, m->ps_ncu, m->ps_smem, m->stream);
-}
-
 static int enqueue_fused_step(ifa_model *m)
 {
     const ifa_model_config &c = m->cfg;
@@ -1350,14 +1069,6 @@ static int enqueue_fused_step(ifa_model *m)
     half_t *x = m->x, *xnext = m->x2;
     const int l_first = std::min(std::max(m->opt_debug_layer0, 0), c.layers - 1);
     const int n_layers = (m->opt_debug_layers > 0 && l_first + m->opt_debug_layers < c.layers) ? l_first + m->opt_debug_layers : c.layers;
-    if (m->persist_mode) {
-        if ((rc = launch_persist(m, 0, n_layers, x, xnext))) return rc;
-        if (m->st_on) return launch_lm_tail(m, xnext);
-        if ((rc = launch_lm(m, xnext))) return rc;
-        k_dec_argmax_advance<<<dim3(1), dim3(1024), 0, s>>>(m->logits, (int)m->g[T_LM_HEAD].rows, m->state, ifa_model::RING);
-        IFA_LAUNCH_CHECK();
-        return IFA_OK;
-    }
     for (int l = l_first; l < n_layers; l++) {
         if (m->qa_on) {
             if ((rc = launch_qkv_attn(m, l, x))) return rc;
@@ -1366,14 +1077,12 @@ static int enqueue_fused_step(ifa_model *m)
             if ((rc = launch_attn(m, l))) return rc;
         }
         if (m->ch_on) {      // [Wo ->] W1 | W3 -> W2 as one launch
-            if (m->ch_on == 1 && !(m->qa_on && m->qa_wo) && (rc = launch_wo(m, l, x))) return rc;
+            if (m->ch_on == 1 && (rc = launch_wo(m, l, x))) return rc;
             if ((rc = launch_chain(m, l, x, xnext))) return rc;
             std::swap(x, xnext);
             continue;
         }
-        if (m->wf_on) {
-            if ((rc = launch_wo_ffn(m, l, x))) return rc;
-        } else if (!(m->qa_on && m->qa_wo) && (rc = launch_wo(m, l, x))) return rc;
+        if ((rc = launch_wo(m, l, x))) return rc;
         Layer &L = m->layers[(size_t)l];
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
             if ((rc = launch_moe_router(m, l))) return rc;
@@ -1387,7 +1096,7 @@ static int enqueue_fused_step(ifa_model *m)
             }
         } else {
             const bool extra = c.parallel_attn || c.share_input;
-            if (!m->wf_on && (rc = launch_ffn13(m, l, -1, x))) return rc;
+            if ((rc = launch_ffn13(m, l, -1, x))) return rc;
             if ((rc = launch_w2(m, l, xnext, nullptr, -1, false, extra ? x : nullptr))) return rc;
         }
         std::swap(x, xnext);
@@ -2622,7 +2331,6 @@ int ifa_model_destroy(ifa_model *m)
       for (void *b : mb) if (b) (void)hipFree(b); }
     { void *tpb[] = {m->tp_a, m->tp_f, m->tp_hid, m->tp_logits, m->tp_best, m->tp_gather, m->tp_tok};
       for (void *b : tpb) if (b) (void)hipFree(b); }
-    persist_drop(m);
     if (m->state) (void)hipFree(m->state);
     if (m->rope_tab) (void)hipFree(m->rope_tab);
     if (m->tokens_dev) (void)hipFree(m->tokens_dev);
@@ -2631,9 +2339,6 @@ int ifa_model_destroy(ifa_model *m)
     if (m->ch_gran) (void)hipFree(m->ch_gran);
     if (m->ch_flags) (void)hipFree(m->ch_flags);
     if (m->qa_call) (void)hipFree(m->qa_call);
-    if (m->qa_att_gran) (void)hipFree(m->qa_att_gran);
-    if (m->wf_gran) (void)hipFree(m->wf_gran);
-    if (m->wf_img) (void)hipFree(m->wf_img);
     if (m->qa_err) (void)hipFree(m->qa_err);
     if (m->st_keys) (void)hipFree(m->st_keys);
     if (m->st_counter) (void)hipFree(m->st_counter);
@@ -2716,7 +2421,6 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
     }
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
     drop_graphs(m);
-    persist_drop(m);         // the persistent launch's streaming copies and layer tables follow the tensors
     return IFA_OK;
 }
 
@@ -2853,9 +2557,9 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_wo", &m->opt_fuse_wo}, {"fuse_wo_ffn", &m->opt_fuse_wo_ffn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"attn_post_as_residual", &m->opt_attn_post_as_residual}, {"chain_late_w2", &m->opt_chain_late_w2}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, {"persist", &m->opt_persist}, {"persist_ctx", &m->opt_persist_ctx},
-        {"persist_timeout_us", &m->opt_persist_timeout_us}, {"persist_trace", &m->opt_persist_trace}, {"persist_debug", &m->opt_persist_debug},
-        {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}, {"persist_depth", &m->opt_persist_depth}, {"persist_prio", &m->opt_persist_prio}};
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"attn_post_as_residual", &m->opt_attn_post_as_residual}, {"chain_late_w2", &m->opt_chain_late_w2}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, 
+        
+        {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}};
     for (auto &o : opts)
         if (strcmp(o.n, name) == 0) {
             *o.p = value;
@@ -2959,19 +2663,11 @@ static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps
     // attention variant of this call: one workgroup per head, or keys split over workgroups once the context the
     // call reaches passes the threshold (the captured step is re-captured when the variant changes)
     choose_attn_split(m, start_pos + n_steps);
-    {   // one persistent launch for the layers while the context stays short enough for one CU per head
-        int want = 0;
-        if (m->opt_persist && start_pos + n_steps <= std::min(m->opt_persist_ctx, (int)PS_MAX_CTX)) {
-            if ((rc = persist_ready(m, &want))) return rc;
-        }
-        if (want != m->persist_mode) { m->persist_mode = want; drop_graphs(m); }
-        if (want) { const PsLayer *tab = nullptr; if ((rc = persist_table(m, &tab))) return rc; }      // (allocates: not under capture)
-    }
     if ((rc = qkv_attn_ready(m))) return rc;
     if ((rc = step_tail_ready(m))) return rc;
     m->host_pinned[0] = first_token; m->host_pinned[1] = start_pos; m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));
-    if (m->qa_on || m->wf_on || m->ch_on) {      // the granule tags of this call: (call counter, position) -- consecutive steps never share one
+    if (m->qa_on || m->ch_on) {      // the granule tags of this call: (call counter, position) -- consecutive steps never share one
         m->qa_calls = (m->qa_calls % 4000u) + 1u;
         m->host_pinned[6] = (int)m->qa_calls;
         IFA_HIP_CHECK(hipMemcpyAsync(m->qa_call, m->host_pinned + 6, sizeof(int), hipMemcpyHostToDevice, s));
@@ -3017,12 +2713,9 @@ static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps
     th("steps enqueued");
     if (elapsed_ms) IFA_HIP_CHECK(hipEventRecord(e1, s));
     IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 8, m->state + 8, sizeof(int) * (size_t)n_steps, hipMemcpyDeviceToHost, s));
-    int *perr = m->host_pinned + 8 + ifa_model::RING;
-    perr[0] = 0;
-    if (m->persist_mode) IFA_HIP_CHECK(hipMemcpyAsync(perr, m->ps_err, 16, hipMemcpyDeviceToHost, s));
-    int *qerr = perr + 4;
+    int *qerr = m->host_pinned + 8 + ifa_model::RING;
     qerr[0] = 0;
-    if (m->qa_on || m->wf_on || m->ch_on) IFA_HIP_CHECK(hipMemcpyAsync(qerr, m->qa_err, 4, hipMemcpyDeviceToHost, s));
+    if (m->qa_on || m->ch_on) IFA_HIP_CHECK(hipMemcpyAsync(qerr, m->qa_err, 4, hipMemcpyDeviceToHost, s));
     th("copies back enqueued");
     IFA_HIP_CHECK(hipStreamSynchronize(s));
     th("stream synchronised");
@@ -3032,20 +2725,13 @@ static int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps
         if (elapsed_ms) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
         // the waiting launches go off for this model (and, process-wide, for every model created later): the next call captures the
         // five-launch step, whose kernels wait for nothing
-        m->opt_fuse_attn = 0; m->opt_fuse_wo = 0; m->opt_fuse_wo_ffn = 0; m->opt_fuse_ffn = 0;
+        m->opt_fuse_attn = 0; m->opt_fuse_ffn = 0;
         drop_graphs(m);
         waits_disable("the fused QKV + attention launch timed out waiting for sibling workgroups");
         return ifa_fail(IFA_ERR_STATE, "fused decode launch: a wait for another workgroup's rows timed out (code 0x%x: 0x5_ q | k | v / attention output, 0x6_ Wo output, 0x9_ chained FFN launch); "
-                        "the results of this call are not valid -- repeat it: options fuse_attn / fuse_wo / fuse_wo_ffn / fuse_ffn are off now (five-launch step)", (unsigned)qerr[0]);
+                        "the results of this call are not valid -- repeat it: options fuse_attn / fuse_ffn are off now (five-launch step)", (unsigned)qerr[0]);
     }
     if (elapsed_ms) { IFA_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-    if (perr[0] != 0) {      // a wait inside the persistent launch gave up: the step's results are not valid
-        const unsigned code = (unsigned)perr[0];
-        (void)hipMemsetAsync(m->ps_err, 0, 16, s);
-        (void)hipStreamSynchronize(s);
-        return ifa_fail(IFA_ERR_STATE, "persistent decode launch gave up waiting: phase 0x%x kind %u (workgroup %d, layer %d, wave %d); "
-                        "set option persist=0 to use the five-launch path", code >> 8, code & 0xFFu, perr[1], perr[2], perr[3]);
-    }
     if (out_tokens_host) memcpy(out_tokens_host, m->host_pinned + 8, sizeof(int) * (size_t)n_steps);
     th("done");
     return IFA_OK;
@@ -3086,8 +2772,6 @@ int ifa_model_get_buffer(ifa_model *m, const char *name, int layer, void **dptr,
     else if (!strcmp(name, "tp_logits")) { p = m->tp_logits; b = m->tp_logits ? m->g[T_LM_HEAD].rows * 2 : 0; }
     else if (!strcmp(name, "trace")) { p = m->trace; b = m->trace ? sizeof(long long) * 2048 * 8 : 0; }
     else if (!strcmp(name, "hidden")) { p = m->xn; b = (size_t)c.dim * 2; }
-    else if (!strcmp(name, "ps_trace")) { p = m->ps_trace; b = m->ps_trace ? sizeof(long long) * 32 * (size_t)m->ps_ncu : 0; }
-    else if (!strcmp(name, "ps_arena")) { p = m->ps_arena; b = m->ps_arena_bytes; }
     else if (!strcmp(name, "x")) { p = m->x; b = (size_t)c.dim * 2; }
     else if (!strcmp(name, "x2")) { p = m->x2; b = (size_t)c.dim * 2; }
     else if (!strcmp(name, "dqkv")) { p = m->dqkv; b = ((size_t)c.heads + 2 * (size_t)c.kv_heads) * c.head_dim * 2; }
@@ -3568,23 +3252,13 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
             k_touch<<<dim3(8), dim3(256), 0, s>>>((const uint8_t *)t.tiled, bytes, (size_t)m->opt_touch_stride, m->state + 7);
         }
     };
-    if (which == 6) {      // all layers as the one persistent launch
-        int usable = 0;
-        if ((rc = persist_ready(m, &usable))) return rc;
-        if (!usable) return ifa_fail(IFA_ERR_STATE, "persistent decode unavailable: %s", m->ps_why.c_str());
-        const PsLayer *tab = nullptr;
-        if ((rc = persist_table(m, &tab))) return rc;
-    }
-    if (which == 7 || which == 8 || which == 9) {      // QKV + attention as one launch; Wo + W1 / W3 as one launch; the chained FFN launch
+    if (which == 7 || which == 9) {      // QKV + attention as one launch; the chained FFN launch
         if ((rc = qkv_attn_ready(m))) return rc;
         if (which == 9 && !m->ch_on) return ifa_fail(IFA_ERR_STATE, "chained FFN launch unavailable for this model / option set");
         if (which == 7 && !m->qa_on) return ifa_fail(IFA_ERR_STATE, "fused QKV + attention launch unavailable for this model / option set");
-        if (which == 8 && !m->wf_on) return ifa_fail(IFA_ERR_STATE, "fused Wo + FFN launch unavailable for this model / option set");
     }
     auto one = [&](int i) -> int {
-        if (which == 6) return launch_persist(m, 0, m->cfg.layers, m->x, m->x2);
         if (which == 7) return launch_qkv_attn(m, i % m->cfg.layers, m->x, (unsigned)(i + 1));
-        if (which == 8) return launch_wo_ffn(m, i % m->cfg.layers, m->x, (unsigned)(i + 1));
         if (which == 9) return launch_chain(m, i % m->cfg.layers, m->x, m->x2, (unsigned)(i + 1));
         const int l = m->opt_bench_mode == 1 ? 0 : i % m->cfg.layers;     // rotate over layers: distinct weights every launch
         if (m->opt_bench_mode == 2) touch_layer(l);

@@ -1,6 +1,6 @@
-"""The attention as the tail of the QKV launch (csrc/ifa_decode_qkv_attn.h, option fuse_attn) and, opt-in, the Wo rows behind it
-(fuse_wo) or in front of the W1 / W3 launch (csrc/ifa_decode_wo_ffn.h, fuse_wo_ffn): tokens, last-step logits and the KV cache must be bit-identical to the five-launch step (same kernel bodies, the
-hand-off is the only difference), and the launch must be the one that runs for the headline shape."""
+"""The attention as the tail of the QKV launch (csrc/ifa_decode_qkv_attn.h, option fuse_attn): tokens, last-step logits and the KV
+cache must be bit-identical to the five-launch step (same kernel bodies, the hand-off is the only difference), and the launch must be
+the one that runs for the headline shape.  (The chained FFN launch has its own file: tests/test_gpu_chain.py.)"""
 import numpy as np
 import pytest
 
@@ -39,13 +39,9 @@ def test_fused_qkv_attention_launch_is_bit_identical(shape, wd, kvd, layers):
     prompt = (np.arange(20, dtype=np.int32) * 11 + 5) % s["vocab"]
     # contexts that cross the 64 / 128 / 256 prefetch buckets: 20 .. 20 + 250
     for steps in (40, 120, 250):
-        ref = _run(wk, s, prompt, steps, fuse_attn=0, fuse_wo=0, fuse_wo_ffn=0, step_tail=0)
+        ref = _run(wk, s, prompt, steps, fuse_attn=0, step_tail=0)
         wk.set_option("step_tail", 1)
-        import inferflow_amd as _ia
-        sets = [{"fuse_attn": 1, "fuse_wo": 0}]
-        if _ia.lib().ifa_experimental_built():      # the parked launches (csrc/experimental/): only in a library built with IFA_EXPERIMENTAL=1
-            sets += [{"fuse_attn": 1, "fuse_wo": 1}, {"fuse_attn": 1, "fuse_wo": 0, "fuse_wo_ffn": 1}, {"fuse_attn": 0, "fuse_wo": 0, "fuse_wo_ffn": 1}]
-        for opts in sets:
+        for opts in [{"fuse_attn": 1}]:
             got = _run(wk, s, prompt, steps, **opts)
             assert got[0] == ref[0], "tokens differ (%r, %d steps)" % (opts, steps)
             assert np.array_equal(got[1], ref[1]), "logits differ (%r, %d steps)" % (opts, steps)

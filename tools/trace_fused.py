@@ -11,13 +11,9 @@ tok = wk.forward(np.arange(3, 19, dtype=np.int32), 0)
 toks, ms = wk.decode(int(tok), 16, 48)          # positions up to 64: the prefetch bucket of the timing launches
 wk.set_option("trace", 1)
 H = s["heads"]
-import inferflow_amd as _ia
-_parked = [(8, "wo+ffn13 fused")] if _ia.lib().ifa_experimental_built() else []      # (csrc/experimental/: only in an IFA_EXPERIMENTAL=1 library)
-for which, nm in [(7, "qkv+attn fused"), (0, "qkv"), (1, "attn")] + _parked + [(2, "wo"), (3, "ffn13")]:
-    if which == 8:
-        wk.set_option("fuse_wo_ffn", 1)          # (opt-in)
+for which, nm in [(7, "qkv+attn fused"), (0, "qkv"), (1, "attn"), (2, "wo"), (3, "ffn13")]:
     us = wk.time_kernel(which, 33)
-    if which == 8:
+    if False:
         tr = wk.read_buffer("trace").view(np.int64).reshape(2048, 8)[:256]
         t0 = tr[:, 0].min()
         fr, ld = tr[tr[:, 7] == 1], tr[tr[:, 7] == 0]
