@@ -708,6 +708,19 @@ int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps, int *
     IFA_REQUIRE(m->g[T_EMBD].present() && m->g[T_LM_HEAD].present(), "ifa_model_decode: embeddings / lm_head missing (pipeline stage worker)");
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
     std::string why;
+    if (m->opt_exact_order) {      // order-exact steps, host-driven (a failure is an error, never a silent change of arithmetic)
+        if (prepare_only) return IFA_OK;
+        int tok = first_token;
+        for (int i = 0; i < n_steps; i++) {
+            int nt = 0;
+            int rc = forward_exact(m, tok, start_pos + i, nullptr, &nt);
+            if (rc) return rc;
+            if (out_tokens_host) out_tokens_host[i] = nt;
+            tok = nt;
+        }
+        if (elapsed_ms) *elapsed_ms = -1.0f;
+        return IFA_OK;
+    }
     if (!m->opt_fused || !fused_supported(m, &why)) {
         // op-by-op fallback: same semantics, host-driven
         if (prepare_only) return IFA_OK;

@@ -683,6 +683,15 @@ int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int pr
     IFA_REQUIRE(m && m->finalized, "ifa_model_forward: model not finalized");
     IFA_REQUIRE(tokens_host, "ifa_model_forward: null tokens");
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    if (m->opt_exact_order) {      // order-exact: the tokens one by one through the single-row step (the reference's T = 1 branch for every row)
+        const size_t V = m->g[T_LM_HEAD].present() ? m->g[T_LM_HEAD].rows : 0;
+        for (int t = 0; t < n_tokens; t++) {
+            int rc = forward_exact(m, tokens_host[t], prefix_len + t, logits_out_dev ? (char *)logits_out_dev + (size_t)t * V * 2 : nullptr,
+                                   t == n_tokens - 1 ? next_token_host : nullptr);
+            if (rc) return rc;
+        }
+        return IFA_OK;
+    }
     // Round 5: prompts of 34..48 tokens as TWO passes of the rows GEMM (32 tokens, then 2..16: the weights stream into registers five
     // groups deep) instead of one pass of the op-by-op layer: 40 tokens 7.08 -> 6.35 ms, 48 tokens 7.26 -> 6.67 (profiles/r05_prompt_lengths.log;
     // two passes of 17..32 rows each -- 49..64 tokens -- measured no faster than the tile kernels).  The second pass reads the first

@@ -5,6 +5,7 @@
 //   ifa_engine_decode.hip   the fused batch-1 decode step: launch parameters of every fused kernel, graph capture, ifa_model_decode
 //   ifa_engine_forward.hip  prompts and batched steps: op-by-op layer, the four-launch prompt routes, batched steps, ifa_model_forward
 //   ifa_engine_moe.hip      mixture of experts: the router on the device, grouped expert launches of a batch, the host-routed fallback
+//   ifa_engine_exact.hip    option exact_order: single-token steps in the reference kernels' summation order (parity instrument)
 //   ifa_engine_tp.hip       tensor / layer partitions: per-seam entry points and the multi-GPU step driven from C
 #pragma once
 #include <chrono>
@@ -122,6 +123,8 @@ struct ifa_model {
     // consecutive GEMV ops of a layer as ONE launch with the next op's rows requested before the hand-off (ifa_decode_chain.h):
     // option fuse_ffn = 1: W1 | W3 -> W2; 2: Wo -> W1 | W3 -> W2.  ch_on = what the captured step uses.  Granules [layers][dim + ffn].
     int opt_fuse_ffn = 0, ch_on = 0, opt_chain_late_w2 = 0;
+    int opt_exact_order = 0;         // single-token steps in the reference kernels' summation order (ifa_engine_exact.hip): bit-identical to the oracle
+    float *exact_rope_tab = nullptr; // device: [max_ctx][head_dim / 2] (cos, sin) from the host libm, built on the first exact step
     uint32_t *ch_gran = nullptr, *ch_flags = nullptr;      // flags [layers][2][CH_FLAGS]
     // the end of the step as one launch (ifa_decode_lmhead_tail.h): lm_head + argmax + state advance + the next step's gather.
     // st_on = what the captured step uses (F16 lm_head with the RMS / no final norm)
@@ -312,6 +315,9 @@ int moe_ffn(ifa_model *m, Layer &L, const half_t *ff_n, int T);
 int max_smalls_possible(bool rows_kernel, int E, int cap);
 int ensure_side_stream(ifa_model *m);
 bool moe_router_rows_ok(const ifa_model *m, const Layer &L, int T);
+// ---- ifa_engine_exact.hip
+bool exact_supported(const ifa_model *m, std::string *why);
+int forward_exact(ifa_model *m, int token, int pos, void *logits_out, int *next_token);
 // ---- ifa_engine_tp.hip
 int tp_argmax_scratch(ifa_model *m, size_t n_rows);
 int tp_pick_rows(ifa_model *m, const ifa_tp_topology &t, const half_t *shard, size_t row_stride, int shard_rows, int n_rows);

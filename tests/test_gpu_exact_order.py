@@ -1,0 +1,80 @@
+"""-m gpu: option `exact_order` (csrc/ifa_exact.hip, csrc/ifa_engine_exact.hip) -- single-token steps in the summation order of the
+reference's CUDA kernels as the oracle restates them.  Everything a step leaves behind must be BIT-IDENTICAL to oracle.Model's:
+logits, greedy id, the last layer's output, the K / V rows of every layer (F16 rows, or int8 codes + scales of a Q8_B32T2 cache).
+Small shapes here, over the weight formats, wirings and cache formats the step accepts; the headline configurations at their own
+size are in tests/test_gpu_fullsize_oracle.py."""
+import numpy as np
+import pytest
+
+from inferflow_amd import dtypes as dt
+from tests.test_gpu_engine import _build_custom, MINICPM_LIKE
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("q4_f16kv", "test_gqa", dt.Q4_B32T1A, dt.F16, dict(), False),
+    ("q4b_q8kv_bias", "test_gqa", dt.Q4_B32T1B, dt.Q8_B32T2, dict(), True),
+    ("q3h_q8kv", "test_gqa", dt.Q3H_B64T1, dt.Q8_B32T2, dict(), False),
+    ("q4b64", "test_mha", dt.Q4_B64T1, dt.F16, dict(), False),
+    ("q5b64_rope1", "test_gqa", dt.Q5_B64T1, dt.F16, dict(rope_order=1), False),
+    ("q6b64", "test_mha", dt.Q6_B64T1, dt.Q8_B32T2, dict(), True),
+    ("q8t2_relu", "test_gqa", dt.Q8_B32T2, dt.F16, dict(act_kind=2), False),
+    ("f16_weights", "test_mha", dt.F16, dt.F16, dict(), True),
+    ("q5b32_f16_activations", "test_gqa", dt.Q5_B32T1, dt.F16, dict(), False),       # not on the int8 path: dequantised weights x F16 row
+    ("q2_no_glu", "test_gqa", dt.Q2_B32T1A, dt.Q8_B32T2, dict(is_glu=0), False),
+    ("minicpm_scales_norm_bases", "test_gqa", dt.Q4_B32T1A, dt.F16, dict(MINICPM_LIKE, attn_norm_base=1.0, ffn_norm_base=1.0, out_norm_base=1.0), False),
+]
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint8).reshape(-1), np.ascontiguousarray(b).view(np.uint8).reshape(-1))
+
+
+@pytest.mark.parametrize("name,shape,wd,kvd,cfg,bias", CASES, ids=[c[0] for c in CASES])
+def test_exact_order_steps_are_bit_identical_to_the_oracle(name, shape, wd, kvd, cfg, bias):
+    max_ctx = 48
+    wk, om, s = _build_custom(shape, wd, kvd, max_ctx, cfg, with_bias=bias)
+    wk.set_option("exact_order", 1)
+    om.capture_layers(True)
+    rng = np.random.default_rng(5)
+    prompt = rng.integers(0, s["vocab"], 5).astype(np.int32)
+    # the prompt through ifa_model_forward: in this mode its rows go one by one through the single-row step, like the oracle's here
+    tok = wk.forward(prompt, 0)
+    for i, t in enumerate(prompt):
+        tok_o, lg_o = om.forward(np.array([t], np.int32), i)
+    assert _same_bits(wk.read_buffer("logits").view(np.uint16), lg_o[0].view(np.uint16)), "prompt logits"
+    assert int(tok) == int(tok_o)
+    pos = len(prompt)
+    cur = int(tok_o)
+    for step in range(30):            # free-running on both sides: identical logits -> identical ids, contexts up to 35 keys
+        toks, _ = wk.decode(cur, pos, 1)
+        tok_o, lg_o = om.forward(np.array([cur], np.int32), pos)
+        assert _same_bits(wk.read_buffer("logits").view(np.uint16), lg_o[0].view(np.uint16)), "logits of step %d" % step
+        assert int(toks[0]) == int(tok_o), "greedy id of step %d" % step
+        if "out_scale" not in cfg:        # (TensorOpr::Scale of the output runs in place on both sides, after the oracle's tap)
+            assert _same_bits(wk.read_buffer("x").view(np.uint16), om.layer_io()[s["layers"]].view(np.uint16)), "last layer's output, step %d" % step
+        cur, pos = int(tok_o), pos + 1
+    for l in range(s["layers"]):      # every layer's cache rows: F16 rows or int8 codes + scales
+        rb = om.kv_rows(l, 0, pos).shape[1]
+        assert _same_bits(wk.read_buffer("kcache", layer=l, nbytes=pos * rb), om.kv_rows(l, 0, pos)), "K rows of layer %d" % l
+        assert _same_bits(wk.read_buffer("vcache", layer=l, nbytes=pos * rb), om.kv_rows(l, 1, pos)), "V rows of layer %d" % l
+    # several steps per call take the same route
+    wk.set_option("exact_order", 1)
+    toks, _ = wk.decode(cur, pos, 3)
+    for t in toks:
+        tok_o, _ = om.forward(np.array([cur], np.int32), pos)
+        assert int(t) == int(tok_o)
+        cur, pos = int(tok_o), pos + 1
+    wk.close()
+
+
+def test_exact_order_refuses_models_outside_the_step():
+    """GELU (tanhf) and Std-norm models have no order-exact step: the call fails, it never runs other arithmetic silently."""
+    from tests.test_gpu_engine import BLOOM_LIKE
+    wk, om, s = _build_custom("test_gqa", dt.Q4_B32T1A, dt.F16, 32, BLOOM_LIKE, with_bias=True)
+    wk.set_option("exact_order", 1)
+    with pytest.raises(Exception, match="exact_order"):
+        wk.decode(3, 0, 1)
+    wk.set_option("exact_order", 0)
+    wk.decode(3, 0, 1)
+    wk.close()
