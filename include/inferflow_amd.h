@@ -267,7 +267,8 @@ int ifa_model_reset(ifa_model *m);
  * measured slower than the separate launches on MI355X, kept as the measurement harness of that statement), "prefill_mid" (1),
  * "prefill_mid_max" (256), "prefill_big_min" (47), "attn_post_as_residual" (1), "exact_order" (0; 1: every single-token step -- and every row
  * of a prompt, one by one -- runs in the summation order of the reference's CUDA kernels, csrc/ifa_exact.hip: a parity instrument whose
- * logits, ids and int8 codes equal the CPU oracle's bit for bit; fails for models outside that step instead of changing arithmetic) */
+ * logits, ids and int8 codes equal the CPU oracle's bit for bit; fails for models outside that step instead of changing arithmetic),
+ * "q3h_native" (0; 1: Q3H_B64T1 Wo / W1 / W3 / W2 streamed at 32 bytes per block, pair codes decoded in the kernel: bit-identical, measured slower) */
 /* Independent KV caches inside one worker, one per concurrent query -- the reference keeps a LayerKVCache set
  * per query processor (QueryStateTable, src/transformer/query_state_table.h:19-85; KVCache::Init, kv_cache.cc:278-319).
  * ifa_model_kv_slots grows the number of caches to n_slots (slot 0 exists after finalize); ifa_model_select_kv

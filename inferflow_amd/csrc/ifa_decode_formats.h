@@ -337,4 +337,82 @@ struct WRowQ6B64 {
 
 // Q3H_B64T1 rows are streamed as nibble pairs (ifa_tiled.h: q3h_aos_to_nibbles), i.e. as WRowQ4B64 with codes 0..10.
 
+// Q3H_NATIVE: the same values at the format's own 32 bytes per block (engine option q3h_native; VERDICT r5 item 5: built to be
+// measured against the 36-byte nibble form).  Streamed block = the 28 bytes D0..D6 of q3h_aos_to_tiled (ifa_tiled.h: byte b of
+// D[w] = pair code p[4w + b] in its low 7 bits, bit 7 = bit w of p[28 + b]) + (base, scale); row layout
+// [D0..D3: 16 B x n][D4, D5: 8 B x n][D6, (base, scale): 8 B x n].  A pair code is p = q0 + 11 q1 (q0 = element 2k, q1 = 2k + 1),
+// and   sum q0 xe + q1 xo = sum p xe + sum q1 xo - 11 sum q1 xe   so q0 is never formed; q1 = (93 p + 64) >> 10 exactly for
+// p <= 120, two pairs per packed 16-bit multiply-add.  Per dword of four pairs: 8 VALU + 3 dot4 (nibble form: 3 + 2),
+// plus 14 VALU per block to gather the four pair codes that live in the top bits.
+template <int NJ>
+struct WRowQ3HN {
+    u32x4 c0[NJ];
+    u32x2 c1[NJ], c2[NJ];
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ wrow, int nblk, int lane, int blk0 = 0)
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int blk = min(blk0 + lane + 64 * j, nblk - 1);
+            c0[j] = nt_load<u32x4>(wrow + (size_t)blk * 16);
+            c1[j] = nt_load<u32x2>(wrow + (size_t)nblk * 16 + (size_t)blk * 8);
+            c2[j] = nt_load<u32x2>(wrow + (size_t)nblk * 24 + (size_t)blk * 8);
+        }
+    }
+    template <class S>
+    __device__ __forceinline__ void load_src(const S &src, int nblk, int lane, int blk0 = 0)
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t blk = (uint32_t)min(blk0 + lane + 64 * j, nblk - 1);
+            c0[j] = src.template ld<u32x4>(blk * 16);
+            c1[j] = src.template ld<u32x2>((uint32_t)nblk * 16 + blk * 8);
+            c2[j] = src.template ld<u32x2>((uint32_t)nblk * 24 + blk * 8);
+        }
+    }
+    // four pair codes (one per byte, < 121) -> their q1 = p / 11, one per byte: (93 p + 64) >> 10 in packed 16-bit lanes
+    // (v_pk_lshrrev_b16 / v_pk_mad_u16: 7 instructions per four pairs)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t q1_of(uint32_t P)
+    {
+        const u16x2 A = __builtin_bit_cast(u16x2, P & 0x00FF00FFu);
+        const u16x2 B = __builtin_bit_cast(u16x2, P) >> (unsigned short)8;
+        const u16x2 qa = (A * (unsigned short)93 + (unsigned short)64) >> (unsigned short)10;
+        const u16x2 qb = (B * (unsigned short)93 + (unsigned short)64) >> (unsigned short)10;
+        return __builtin_bit_cast(uint32_t, qa) | (__builtin_bit_cast(uint32_t, qb) << 8);
+    }
+    static __device__ __forceinline__ void pair4(uint32_t P, int xe, int xo, int &dp, int &dq)
+    {
+        const uint32_t Q = q1_of(P);
+        dp = sdot4((int)P, xe, dp);
+        dp = sdot4((int)Q, xo, dp);
+        dq = sdot4((int)Q, xe, dq);
+    }
+    __device__ __forceinline__ float dot(const XRegsB64<NJ> &X, float acc0 = 0.0f) const
+    {
+        float acc = acc0;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            // (scalar temporaries: a local array initialised from vector registers goes to scratch memory on this compiler)
+            const uint32_t D0 = c0[j][0], D1 = c0[j][1], D2 = c0[j][2], D3 = c0[j][3], D4 = c1[j][0], D5 = c1[j][1], D6 = c2[j][0];
+            const uint32_t sbw = c2[j][1];
+            const float base = hbits2f((uint16_t)(sbw & 0xFFFFu)), scale = hbits2f((uint16_t)(sbw >> 16));
+            const uint32_t E = ((D0 >> 7) & 0x01010101u) | ((D1 >> 6) & 0x02020202u) | ((D2 >> 5) & 0x04040404u) | ((D3 >> 4) & 0x08080808u)
+                             | ((D4 >> 3) & 0x10101010u) | ((D5 >> 2) & 0x20202020u) | ((D6 >> 1) & 0x40404040u);
+            const uint32_t m7 = 0x7F7F7F7Fu;
+            int dp0 = 0, dq0 = 0, dp1 = 0, dq1 = 0;
+            pair4(D0 & m7, X.xe[j][0][0], X.xo[j][0][0], dp0, dq0);
+            pair4(D1 & m7, X.xe[j][0][1], X.xo[j][0][1], dp0, dq0);
+            pair4(D2 & m7, X.xe[j][0][2], X.xo[j][0][2], dp0, dq0);
+            pair4(D3 & m7, X.xe[j][0][3], X.xo[j][0][3], dp0, dq0);
+            pair4(D4 & m7, X.xe[j][1][0], X.xo[j][1][0], dp1, dq1);
+            pair4(D5 & m7, X.xe[j][1][1], X.xo[j][1][1], dp1, dq1);
+            pair4(D6 & m7, X.xe[j][1][2], X.xo[j][1][2], dp1, dq1);
+            pair4(E, X.xe[j][1][3], X.xo[j][1][3], dp1, dq1);
+            acc = acc + dec_term(dp0 - 11 * dq0, scale, base, X.xsf[j][0], X.xs[j][0]);
+            acc = acc + dec_term(dp1 - 11 * dq1, scale, base, X.xsf[j][1], X.xs[j][1]);
+        }
+        return acc;
+    }
+};
+
 } // namespace ifa

@@ -30,4 +30,7 @@ int dec_gemv_launch_dt(int epi, int norm, const DecGemvParams &P, int wgs_per_cu
 
 int dec_num_cus();
 
+// Q3H_B64T1 reference-layout rows -> the native 32-byte streaming copy of ifa_decode_formats.h WRowQ3HN (ifa_dgemv_q3hn.hip)
+int q3h_native_rows(const void *aos, size_t rows, size_t cols, void *dst, hipStream_t s);
+
 } // namespace ifa

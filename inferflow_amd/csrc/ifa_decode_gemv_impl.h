@@ -64,7 +64,7 @@ constexpr int dec_rw(int epi, int norm, int nj, int nm, int th = DEC_THREADS)
     }
     // B64 formats (one block per lane at 4096 columns): sweep on Llama-2-7B Q3H + Q8 KV (configs[2];
     // profiles/r02_sweep_q3h.log): 544 -> 601 tok/s; the same entries measured on Q4_B64T1 / Q5_B64T1 (Q6_B64T1: 1024 threads spill)
-    if (DT == Q3H_B64T1 || DT == Q4_B64T1 || DT == Q5_B64T1 || DT == Q6_B64T1) {
+    if (DT == Q3H_B64T1 || DT == Q3H_NATIVE || DT == Q4_B64T1 || DT == Q5_B64T1 || DT == Q6_B64T1) {
         if (DT != Q6_B64T1 && epi == EPI_GLU && nj == 1 && th > DEC_THREADS) return 3;   // W1/W3 at 1024 threads: 16.7 -> 14.1 us (Q3H)
         if ((epi == EPI_RESIDUAL || epi == EPI_PLAIN) && norm == 2 && nj == 1) return 2; // Wo without a prologue: 6.3 -> 4.6 us
         if (epi == EPI_RESIDUAL && norm == 0 && nj == 3) return 2;                    // W2 (11008 columns): 10.4 -> 9.1 us
@@ -88,7 +88,7 @@ constexpr int dec_threads(int epi, int norm, int nj, bool xadd)
         const int forced = role == 0 ? IFA_T_TH_QKV : role == 1 ? IFA_T_TH_WO : role == 2 ? IFA_T_TH_GLU : role == 3 ? IFA_T_TH_W2 : 0;
         if (forced > 0) return forced;
     }
-    if ((DT == Q3H_B64T1 || DT == Q4_B64T1 || DT == Q5_B64T1) && nj == 1 && !xadd && epi == EPI_GLU) return 1024;          // (see dec_rw)
+    if ((DT == Q3H_B64T1 || DT == Q3H_NATIVE || DT == Q4_B64T1 || DT == Q5_B64T1) && nj == 1 && !xadd && epi == EPI_GLU) return 1024;          // (see dec_rw)
     if (DT == Q8_B32T2 && nj == 2 && !xadd && epi == EPI_GLU) return 1024;
     if (DT == Q4_B32T1A && nj == 2 && !xadd && epi == EPI_PLAIN && norm == 1) return 1024;      // QKV with the wave-specialised prologue (r04 sweep: 8.8 -> 8.3 us)
     return (DT == Q4_B32T1A && nj == 2 && !xadd && (epi == EPI_GLU || (epi == EPI_RESIDUAL && norm == 0))) ? 1024 : DEC_THREADS;

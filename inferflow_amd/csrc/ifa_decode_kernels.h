@@ -432,6 +432,7 @@ template <int NJ> struct DecFmt<Q4_B32T1A, NJ> { using X = XRegsQ4<NJ>; using W 
 template <int NJ> struct DecFmt<Q8_B32T2, NJ> { using X = XRegsNat<NJ>; using W = WRowQ8T2<NJ>; static constexpr int DW = 9; };
 template <int NJ> struct DecFmt<Q4_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ4B64<NJ>; static constexpr int DW = 9; };
 template <int NJ> struct DecFmt<Q3H_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ4B64<NJ>; static constexpr int DW = 9; };      // nibble-pair tiled form (ifa_tiled.h)
+template <int NJ> struct DecFmt<Q3H_NATIVE, NJ> { using X = XRegsB64<NJ>; using W = WRowQ3HN<NJ>; static constexpr int DW = 8; };       // native 32-byte form (option q3h_native)
 template <int NJ> struct DecFmt<Q5_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ5B64<NJ>; static constexpr int DW = 11; };
 template <int NJ> struct DecFmt<Q6_B64T1, NJ> { using X = XRegsB64<NJ>; using W = WRowQ6B64<NJ>; static constexpr int DW = 13; };
 

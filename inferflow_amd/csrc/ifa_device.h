@@ -16,11 +16,15 @@ enum DType : int {
     Q3_B32T1A = 19, Q3_B32T1B = 20, Q2_B32T1A = 21, Q2_B32T1B = 22
 };
 
+// internal id (never crosses the C ABI): Q3H_B64T1 values streamed at their native 32 bytes per block by the fused decode GEMV
+// (ifa_decode_formats.h WRowQ3HN; engine option q3h_native) instead of the 36-byte nibble-pair form
+constexpr int Q3H_NATIVE = 99;
+
 __host__ __device__ constexpr int block_capacity(int dt)
 {
     return (dt == F32 || dt == F16) ? 1
         : (dt == Q4_B16) ? 16
-        : (dt == Q6_B64T1 || dt == Q5_B64T1 || dt == Q4_B64T1 || dt == Q3H_B64T1) ? 64
+        : (dt == Q6_B64T1 || dt == Q5_B64T1 || dt == Q4_B64T1 || dt == Q3H_B64T1 || dt == Q3H_NATIVE) ? 64
         : (dt == Q8_B32T1 || dt == Q8_B32T2 || dt == Q5_B32T1 || dt == Q4_B32T1A || dt == Q4_B32T1B
            || dt == Q3_B32T1A || dt == Q3_B32T1B || dt == Q2_B32T1A || dt == Q2_B32T1B) ? 32 : 0;
 }
@@ -30,7 +34,7 @@ __host__ __device__ constexpr int block_bytes(int dt)
     return dt == F32 ? 4 : dt == F16 ? 2
         : dt == Q8_B32T1 ? 36 : dt == Q8_B32T2 ? 34 : dt == Q6_B64T1 ? 52 : dt == Q5_B64T1 ? 44
         : dt == Q5_B32T1 ? 24 : dt == Q4_B16 ? 10 : (dt == Q4_B32T1A || dt == Q4_B32T1B) ? 20
-        : dt == Q4_B64T1 ? 36 : dt == Q3H_B64T1 ? 32 : (dt == Q3_B32T1A || dt == Q3_B32T1B) ? 16
+        : dt == Q4_B64T1 ? 36 : (dt == Q3H_B64T1 || dt == Q3H_NATIVE) ? 32 : (dt == Q3_B32T1A || dt == Q3_B32T1B) ? 16
         : (dt == Q2_B32T1A || dt == Q2_B32T1B) ? 12 : 0;
 }
 

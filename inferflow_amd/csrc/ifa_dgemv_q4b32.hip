@@ -21,7 +21,7 @@ static int dec_maxnj(int dt)
     switch (dt) {
     case Q4_B32T1A: case Q4_B32T1B: return DecGemvLimits<Q4_B32T1A>::MAXNJ;
     case Q8_B32T2: return DecGemvLimits<Q8_B32T2>::MAXNJ;
-    case Q4_B64T1: case Q3H_B64T1: case Q5_B64T1: case Q6_B64T1: return DecGemvLimits<Q4_B64T1>::MAXNJ;
+    case Q4_B64T1: case Q3H_B64T1: case Q3H_NATIVE: case Q5_B64T1: case Q6_B64T1: return DecGemvLimits<Q4_B64T1>::MAXNJ;
     default: return 0;
     }
 }
@@ -56,6 +56,7 @@ int dec_gemv_launch(int w_dtype, int epi, int norm, const DecGemvParams &P0, int
     case Q8_B32T2: return dec_gemv_launch_dt<Q8_B32T2>(epi, norm, P, wgs_per_cu, s);
     case Q4_B64T1: return dec_gemv_launch_dt<Q4_B64T1>(epi, norm, P, wgs_per_cu, s);
     case Q3H_B64T1: return dec_gemv_launch_dt<Q3H_B64T1>(epi, norm, P, wgs_per_cu, s);
+    case Q3H_NATIVE: return dec_gemv_launch_dt<Q3H_NATIVE>(epi, norm, P, wgs_per_cu, s);
     case Q5_B64T1: return dec_gemv_launch_dt<Q5_B64T1>(epi, norm, P, wgs_per_cu, s);
     case Q6_B64T1: return dec_gemv_launch_dt<Q6_B64T1>(epi, norm, P, wgs_per_cu, s);
     default: return ifa_fail(IFA_ERR_DTYPE, "fused GEMV: dtype %d", w_dtype);

@@ -26,6 +26,7 @@ void free_tensor(Tensor &t)
     if (t.tiled) (void)hipFree(t.tiled);
     if (t.mo) (void)hipFree(t.mo);
     if (t.x32) (void)hipFree(t.x32);
+    if (t.q3hn) (void)hipFree(t.q3hn);
     t = Tensor();
 }
 
@@ -185,6 +186,26 @@ int ensure_x32(ifa_model *m)
     return IFA_OK;
 }
 
+// option q3h_native: the 32-byte-per-block streaming copies of the Q3H_B64T1 matrices the k_dec_gemv launches of a dense layer read
+// (Wo, W1, W3, W2), built on the first decode call with the option on
+int ensure_q3hn(ifa_model *m)
+{
+    bool built = false;
+    for (Layer &L : m->layers) {
+        const int ids[] = {T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids) {
+            Tensor &t = L.t[id];
+            if (t.q3hn || !t.present() || t.dtype != Q3H_B64T1 || t.cols % 64 != 0) continue;
+            IFA_HIP_CHECK(hipMalloc(&t.q3hn, t.rows * (t.cols / 64) * 32));
+            int rc = q3h_native_rows(t.data, t.rows, t.cols, t.q3hn, m->stream);
+            if (rc) return rc;
+            built = true;
+        }
+    }
+    if (built) IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return IFA_OK;
+}
+
 } // namespace ifae
 
 extern "C" {
@@ -280,7 +301,7 @@ int ifa_model_set_tensor(ifa_model *m, int layer, int tensor_id, int expert, int
     IFA_REQUIRE(tensor_id >= 0 && tensor_id < T_MAX, "ifa_model_set_tensor: tensor id %d", tensor_id);
     IFA_REQUIRE(expert < 0 || (expert < m->cfg.experts && layer >= 0 && (tensor_id == T_W1 || tensor_id == T_W2 || tensor_id == T_W3)),
                 "ifa_model_set_tensor: expert %d (of %d) / tensor %d", expert, m->cfg.experts, tensor_id);
-    IFA_REQUIRE(block_capacity(dtype) > 0 && dtype != F32, "ifa_model_set_tensor: dtype %d", dtype);
+    IFA_REQUIRE(block_capacity(dtype) > 0 && dtype != F32 && dtype != Q3H_NATIVE, "ifa_model_set_tensor: dtype %d", dtype);
     IFA_REQUIRE(cols % (size_t)block_capacity(dtype) == 0, "ifa_model_set_tensor: cols %zu vs block capacity", cols);
     {   // the scratch buffers are sized from the config and the kernels are launched with the tensor's dimensions: a
         // mismatch would write out of bounds on the device, so it is refused here (per-shard dimensions under TP)
@@ -479,7 +500,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"attn_post_as_residual", &m->opt_attn_post_as_residual}, {"chain_late_w2", &m->opt_chain_late_w2}, {"exact_order", &m->opt_exact_order}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, 
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"attn_post_as_residual", &m->opt_attn_post_as_residual}, {"chain_late_w2", &m->opt_chain_late_w2}, {"exact_order", &m->opt_exact_order}, {"q3h_native", &m->opt_q3h_native}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, 
         
         {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}};
     for (auto &o : opts)

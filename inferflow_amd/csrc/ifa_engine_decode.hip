@@ -38,7 +38,7 @@ bool fused_ok(const Tensor &t, bool long_rows)
 template <int EPI, int NORM>
 static int launch_dec_gemv(int w_dtype, const DecGemvParams &P, int wgs_per_cu_opt, hipStream_t s)
 {
-    if (!fused_int8(w_dtype)) {
+    if (!fused_int8(w_dtype) && w_dtype != Q3H_NATIVE) {
         if constexpr (NORM == 2 || epi_is_moe(EPI)) return ifa_fail(IFA_ERR_STATE, "fused GEMV: dtype %d has no kernel for this launch", w_dtype);
         else return dec_gemv_h_launch(w_dtype, EPI, NORM, P, s);
     }
@@ -398,6 +398,13 @@ int launch_attn(ifa_model *m, int l)
 }
 
 // partial != nullptr (tensor parallel): write the un-merged product there, no bias, no residual
+// option q3h_native: the launch's matrix and kernel format when the tensor has its 32-byte-per-block copy (ensure_q3hn)
+static int native_fmt(const ifa_model *m, const Tensor &t, const uint8_t *&w)
+{
+    if (m->opt_q3h_native && t.q3hn && t.dtype == Q3H_B64T1) { w = (const uint8_t *)t.q3hn; return Q3H_NATIVE; }
+    return t.dtype;
+}
+
 int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial)
 {
     Layer &L = m->layers[(size_t)l];
@@ -409,19 +416,20 @@ int launch_wo(ifa_model *m, int l, const half_t *x, half_t *partial)
     const bool preq = m->attq && m->opt_attn_q8 && m->cfg.head_dim % 32 == 0 && P.cols == m->cfg.heads * m->cfg.head_dim && fused_int8(L.t[T_WO].dtype)
         && dec_gemv_supported(L.t[T_WO].dtype, (size_t)P.cols);
     if (preq) P.x = reinterpret_cast<const half_t *>(m->attq);      // NORM == 2 kernels read the quantised image through P.x
+    const int dto = native_fmt(m, L.t[T_WO], P.W0[0]);
     if (partial) {
         P.y[0] = partial;
-        return preq ? launch_dec_gemv<EPI_PLAIN, 2>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream)
-                    : launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
+        return preq ? launch_dec_gemv<EPI_PLAIN, 2>(dto, P, m->opt_rpw_wo, m->stream)
+                    : launch_dec_gemv<EPI_PLAIN, 0>(dto, P, m->opt_rpw_wo, m->stream);
     }
     P.b0[0] = (const half_t *)L.t[T_WO_B].data;
     P.y[0] = m->a; P.residual = x;
     if (scale_on(m->cfg.attn_out_scale)) P.pre_scale = m->cfg.attn_out_scale;      // Scale(self_att_out) fused in front of the residual add
     if (m->cfg.parallel_attn || m->cfg.share_input)      // the residual is added once, after the FFN (inference_worker.cc:847-851)
-        return preq ? launch_dec_gemv<EPI_PLAIN, 2>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream)
-                    : launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
-    return preq ? launch_dec_gemv<EPI_RESIDUAL, 2>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream)
-                : launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_WO].dtype, P, m->opt_rpw_wo, m->stream);
+        return preq ? launch_dec_gemv<EPI_PLAIN, 2>(dto, P, m->opt_rpw_wo, m->stream)
+                    : launch_dec_gemv<EPI_PLAIN, 0>(dto, P, m->opt_rpw_wo, m->stream);
+    return preq ? launch_dec_gemv<EPI_RESIDUAL, 2>(dto, P, m->opt_rpw_wo, m->stream)
+                : launch_dec_gemv<EPI_RESIDUAL, 0>(dto, P, m->opt_rpw_wo, m->stream);
 }
 
 void moe_params(ifa_model *m, Layer &L, DecGemvParams &P, int slot, int tab_off)
@@ -467,7 +475,11 @@ int launch_ffn13(ifa_model *m, int l, int moe_slot, const half_t *x_layer, int m
     if (!need_norm) { P.norm_w = nullptr; P.norm_b = nullptr; }
     const bool glu = L.t[T_W3].present();
     if (glu) { P.W1 = wbytes(L.t[T_W3]); P.b1 = (const half_t *)L.t[T_W3_B].data; }
-    const int dtw = L.t[T_W1].dtype;
+    int dtw = L.t[T_W1].dtype;
+    if (m->opt_q3h_native && L.t[T_W1].q3hn && (!glu || L.t[T_W3].q3hn)) {      // both matrices of the pair in the native form, or neither
+        dtw = native_fmt(m, L.t[T_W1], P.W0[0]);
+        if (glu) (void)native_fmt(m, L.t[T_W3], P.W1);
+    }
     if (need_norm && m->pend.on && P.x == m->pend.out) {     // the FFN input is the pending sum
         P.x = m->pend.x; P.x_add = m->pend.add; P.x_add_bias = m->pend.bias; P.xsum_out = m->pend.out;
         m->pend.on = false;
@@ -498,15 +510,16 @@ int launch_w2(ifa_model *m, int l, half_t *xnext, half_t *partial, int moe_slot,
     }
     P.x = m->t1; P.cols = (int)L.t[T_W2].cols; P.nblk = P.cols / 32; P.eps = m->cfg.eps;
     P.W0[0] = wbytes(L.t[T_W2]); P.rows[0] = (int)L.t[T_W2].rows; P.nsets = 1;
+    const int dt2 = native_fmt(m, L.t[T_W2], P.W0[0]);
     if (partial) {
         P.y[0] = partial;
-        return launch_dec_gemv<EPI_PLAIN, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
+        return launch_dec_gemv<EPI_PLAIN, 0>(dt2, P, m->opt_rpw_w2, m->stream);
     }
     P.b0[0] = (const half_t *)L.t[T_W2_B].data;
     P.y[0] = xnext; P.residual = m->a; P.residual2 = residual2;     // + layer input for parallel / shared-input models
     if (scale_on(m->cfg.ffn_out_scale)) P.pre_scale = m->cfg.ffn_out_scale;                               // Scale(ff_out)
     if (l + 1 == m->cfg.layers && scale_on(m->cfg.out_scale)) P.post_scale = m->cfg.out_scale;        // Scale(last layer's output)
-    return launch_dec_gemv<EPI_RESIDUAL, 0>(L.t[T_W2].dtype, P, m->opt_rpw_w2, m->stream);
+    return launch_dec_gemv<EPI_RESIDUAL, 0>(dt2, P, m->opt_rpw_w2, m->stream);
 }
 
 // [Wo ->] W1 | W3 -> W2 of layer l as ONE launch (ifa_decode_chain.h); x = the layer input (Wo's residual), xnext = the layer output
@@ -742,6 +755,7 @@ int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps, int *
     };
     int rc = ensure_scratch(m, 1);
     if (rc) return rc;
+    if (m->opt_q3h_native && (rc = ensure_q3hn(m))) return rc;
     hipStream_t s = m->stream;
     // attention variant of this call: one workgroup per head, or keys split over workgroups once the context the
     // call reaches passes the threshold (the captured step is re-captured when the variant changes)
@@ -833,6 +847,7 @@ int ifa_model_time_kernel(ifa_model *m, int which, int iters, float *avg_us)
     if (!fused_supported(m, &why)) return ifa_fail(IFA_ERR_STATE, "fused path unavailable: %s", why.c_str());
     int rc = ensure_scratch(m, 1);
     if (rc) return rc;
+    if (m->opt_q3h_native && (rc = ensure_q3hn(m))) return rc;
     hipStream_t s = m->stream;
     m->host_pinned[0] = 1; m->host_pinned[1] = std::min(m->cfg.max_ctx - 1, 64); m->host_pinned[2] = 0;
     IFA_HIP_CHECK(hipMemcpyAsync(m->state, m->host_pinned, 3 * sizeof(int), hipMemcpyHostToDevice, s));

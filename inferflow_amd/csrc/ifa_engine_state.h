@@ -43,6 +43,7 @@ struct Tensor {
     void *data = nullptr;    // reference layout (AoS blocks / F16), engine-owned
     void *tiled = nullptr;   // row-local plane layout for the fused kernels (or null)
     void *mo = nullptr;      // MFMA-operand-order copy for the small-batch rows GEMM (ifa_gemm_rows_mfma.h), built on first use
+    void *q3hn = nullptr;    // Q3H_B64T1: the values at the format's native 32 bytes per block for the decode GEMVs (option q3h_native, built on first use)
     void *x32 = nullptr;     // 64-weight nibble formats: the same values as Q4_B32T1A reference-layout blocks, for the large-tile prefill GEMM
     size_t rows = 0, cols = 0;
     bool present() const { return data != nullptr; }
@@ -123,6 +124,7 @@ struct ifa_model {
     // consecutive GEMV ops of a layer as ONE launch with the next op's rows requested before the hand-off (ifa_decode_chain.h):
     // option fuse_ffn = 1: W1 | W3 -> W2; 2: Wo -> W1 | W3 -> W2.  ch_on = what the captured step uses.  Granules [layers][dim + ffn].
     int opt_fuse_ffn = 0, ch_on = 0, opt_chain_late_w2 = 0;
+    int opt_q3h_native = 0;          // Q3H_B64T1 linears of the dense FFN and Wo streamed at 32 instead of 36 bytes per block (A / B: profiles/r06_q3h_native_ab.log)
     int opt_exact_order = 0;         // single-token steps in the reference kernels' summation order (ifa_engine_exact.hip): bit-identical to the oracle
     float *exact_rope_tab = nullptr; // device: [max_ctx][head_dim / 2] (cos, sin) from the host libm, built on the first exact step
     uint32_t *ch_gran = nullptr, *ch_flags = nullptr;      // flags [layers][2][CH_FLAGS]
@@ -260,6 +262,7 @@ void *kv_ptr(ifa_model *m, size_t layer, int slot, bool is_v);
 int ensure_mo(ifa_model *m);
 int ensure_mo_build(ifa_model *m);
 int ensure_x32(ifa_model *m);
+int ensure_q3hn(ifa_model *m);
 int ensure_scratch(ifa_model *m, int T);
 // ---- ifa_engine_decode.hip
 void choose_attn_split(ifa_model *m, int reach);

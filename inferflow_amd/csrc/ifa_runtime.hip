@@ -258,11 +258,12 @@ int ifa_stream_sync(ifa_stream s)
     return ifa::wait_err_check("ifa_stream_sync");      // (a launch that waited for sibling workgroups in vain left its code: the synchronising call reports it)
 }
 
-int ifa_block_capacity(int dtype) { return ifa::block_capacity(dtype); }
-int ifa_block_bytes(int dtype) { return ifa::block_bytes(dtype); }
+// (ifa::Q3H_NATIVE is a kernel-format id inside the library, not an element type: the registry does not know it)
+int ifa_block_capacity(int dtype) { return dtype == ifa::Q3H_NATIVE ? 0 : ifa::block_capacity(dtype); }
+int ifa_block_bytes(int dtype) { return dtype == ifa::Q3H_NATIVE ? 0 : ifa::block_bytes(dtype); }
 size_t ifa_row_bytes(int dtype, size_t cols)
 {
-    int c = ifa::block_capacity(dtype);
+    int c = ifa_block_capacity(dtype);
     if (c <= 0) return 0;
     return (cols + (size_t)c - 1) / (size_t)c * (size_t)ifa::block_bytes(dtype);
 }

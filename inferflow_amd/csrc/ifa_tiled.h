@@ -21,7 +21,7 @@ template <int DT> struct TiledLayout;
 // multiple of 16 so that every row's big plane starts 16-byte aligned for any width
 // (e.g. 43 blocks per row when Llama-2-7B's W2 is column-sliced 8 ways).
 // bytes one block occupies in the tiled layout: the reference block's, except Q3H_B64T1 (see below)
-__host__ __device__ constexpr int tiled_block_bytes(int dtype) { return dtype == Q3H_B64T1 ? 36 : block_bytes(dtype); }
+__host__ __device__ constexpr int tiled_block_bytes(int dtype) { return dtype == Q3H_B64T1 ? 36 : block_bytes(dtype); }      // (Q3H_NATIVE: 32)
 
 __host__ __device__ inline size_t tiled_row_bytes(int dtype, size_t nblk)
 {

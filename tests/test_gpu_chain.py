@@ -56,3 +56,26 @@ def test_chained_launch_declines_shapes_it_has_no_kernel_for():
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
     with pytest.raises(Exception):
         wk.time_kernel(9, 2)
+
+
+def test_q3h_native_32_byte_stream_is_bit_identical_to_the_nibble_pair_stream():
+    """Option q3h_native: Wo / W1 / W3 / W2 of a Q3H_B64T1 model streamed at the format's own 32 bytes per 64
+    weights (pair codes decoded in the kernel: csrc/ifa_decode_formats.h WRowQ3HN) instead of the 36-byte nibble pairs: the same
+    integer dots, so tokens, logits and KV rows must not change by a bit -- at Llama-2-7B widths (4096 / 11008 columns: one and
+    three blocks per lane) and at a small GQA shape."""
+    for shape, kw in (("llama2_7b", dict(layers=3)), ("test_gqa", dict())):
+        wk, _, s = synth.build(shape, dt.Q3H_B64T1, dt.Q8_B32T2, max_ctx=160, **kw)
+        prompt = (np.arange(9, dtype=np.int32) * 7 + 3) % s["vocab"]
+
+        def run(native):
+            wk.set_option("q3h_native", native)
+            wk.reset()
+            tok = wk.forward(prompt, 0)
+            toks, _ = wk.decode(int(tok), len(prompt), 60)
+            return (list(toks), wk.read_buffer("logits").view(np.uint16).copy(), wk.read_buffer("kcache", layer=s["layers"] - 1).copy())
+
+        a, b = run(0), run(1)
+        assert a[0] == b[0], shape
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), shape
+        wk.set_option("q3h_native", 0)
+        wk.close()
