@@ -146,6 +146,21 @@ int layer_tail_ops(ifa_model *m, int l, int T, half_t *&x, const half_t *attn_in
 }
 
 // no_head: a chunk of a longer prompt that is not its last one -- the layers only (KV cache rows written), no lm_head / argmax / sync
+// 33 .. prefill_mid_max tokens through k_gemm_mid (csrc/ifa_gemm_mid.hip): the large-tile route's conditions + an operand-order copy of
+// every linear (built here on first use).  From 33 tokens on: 5.3 ms for 33..48 tokens against 5.9-6.6 for two passes of the rows
+// GEMM (tools/short_prompt_routes.py, profiles/r06_prefill_mid_parts.log)
+bool prefill_mid_ok(ifa_model *m, int T)
+{
+    const ifa_model_config &c = m->cfg;
+    if (!m->opt_prefill_mid || !m->opt_rows_mo || T <= 32 || T > m->opt_prefill_mid_max || c.experts != 0 || !prefill_big_ok(m)) return false;
+    if (ensure_mo(m) != IFA_OK) return false;
+    for (int l = 0; l < c.layers; l++) {
+        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
+        for (int id : ids) { const Tensor &t = m->layers[(size_t)l].t[id]; if (!t.present() || !t.mo || t.cols % 128 != 0 || t.rows % 16 != 0) return false; }
+    }
+    return true;
+}
+
 int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token, bool no_head)
 {
     const ifa_model_config &c = m->cfg;
@@ -179,20 +194,15 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
     // GLU, w2 + residual -- instead of seven products and four element-wise launches (9..16 tokens: the norms stay launches)
     // Prompts above `prefill_big_min` tokens (47; round 4: 128) take the same four launches per layer from the large-tile GEMM (ifa_gemm.hip, k_gemm_big: the
     // weights dequantised once per workgroup and step into LDS; reference-layout rows), norms as their own launches.
-    const bool pf_big = !tp && T > std::max(32, m->opt_prefill_big_min) && prefill_big_ok(m);
+    // the mid-length kernel (33 .. prefill_mid_max tokens): every linear of every layer a 4-bit tensor with its operand-order copy, dense FFN
+    const bool pf_mid = !tp && prefill_mid_ok(m, T);
+    const bool pf_big = pf_mid || (!tp && T > std::max(32, m->opt_prefill_big_min) && prefill_big_ok(m));
     bool pf_fused = pf_big || (!tp && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
     if (pf_fused && !pf_big) {
         if ((rc = ensure_mo(m))) return rc;
         pf_fused = batch_fused_ok(m, T);          // (ensure_mo may have switched the copies off: ask again, see forward_batch)
     }
-    if (pf_big && (rc = ensure_x32(m))) return rc;
-    // the mid-length kernel: every linear of every layer a 20-byte-block Q4 tensor with its tiled copy, dense FFN
-    bool pf_mid = pf_big && m->opt_prefill_mid && m->opt_rows_mo && T <= m->opt_prefill_mid_max && c.experts == 0;
-    if (pf_mid && (rc = ensure_mo(m))) return rc;
-    for (int l = 0; l < c.layers && pf_mid; l++) {
-        const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
-        for (int id : ids) { const Tensor &t = m->layers[(size_t)l].t[id]; if (!t.present() || !t.mo || t.cols % 128 != 0 || t.rows % 16 != 0) pf_mid = false; }
-    }
+    if (pf_big && !pf_mid && (rc = ensure_x32(m))) return rc;
     for (int l = 0; l < c.layers && pf_fused; l++) {
         Layer &L = m->layers[l];
         const size_t F = c.ffn;
@@ -697,7 +707,7 @@ int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int pr
     // two passes of 17..32 rows each -- 49..64 tokens -- measured no faster than the tile kernels).  The second pass reads the first
     // one's K / V rows from the cache like any continued prompt; every row goes through the kernels of a prompt of <= 32 tokens.  Never
     // a one-token pass: a single row takes the int8 GEMV (the reference's rule for ONE row), which is not how a prompt's rows are computed.
-    if (m->opt_prefill_chunk && !m->topo && n_tokens >= 34 && n_tokens <= 48 && m->cfg.experts == 0 && batch_fused_ok(m, 32)
+    if (m->opt_prefill_chunk && !m->topo && n_tokens >= 34 && n_tokens <= 48 && m->cfg.experts == 0 && !prefill_mid_ok(m, n_tokens) && batch_fused_ok(m, 32)
         && prefix_len >= 0 && prefix_len + n_tokens <= m->cfg.max_ctx) {
         const int t1 = 32;
         const size_t V = m->g[T_LM_HEAD].rows;

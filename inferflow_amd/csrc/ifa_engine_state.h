@@ -303,6 +303,7 @@ int layer_tail_ops(ifa_model *m, int l, int T, half_t *&x, const half_t *attn_in
 int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token, bool no_head = false);
 bool batch_fused_ok(const ifa_model *m, int n);
 bool prefill_big_ok(const ifa_model *m);
+bool prefill_mid_ok(ifa_model *m, int T);
 int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t *xnext, const void *rows_l);
 int forward_batch(ifa_model *m, int n, const int *tokens_host, const int *pos_host, const int *slot_host, int *next_tokens,
                          void *logits_out);

@@ -49,6 +49,9 @@ constexpr int MD_STAGE = MD_A_BYTES + MD_WC_BYTES + MD_WS_BYTES;    // 21 KB
 #ifndef IFA_MID_ABL
 #define IFA_MID_ABL 0
 #endif
+#ifndef IFA_MID_PF
+#define IFA_MID_PF 2        // 16-column groups of lead of the activation fragment reads (1: the first form, one group)
+#endif
 #ifndef IFA_MID_WAUX
 #define IFA_MID_WAUX 0       // cache policy of the weight requests (2 = non-temporal)
 #endif
@@ -183,7 +186,16 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
         sw[1] = md_lds_b32(ws_off + sb + 64);
 #pragma unroll
         for (int a = 0; a < TA; a++) fa[0][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((0) ^ lc) << 4));
+#if IFA_MID_PF >= 2
+        // fragments are requested TWO 16-column groups ahead (round 6, second pass): with one group of lead the wave sat in lgkmcnt(0)
+        // at the end of every group -- four waves read 64 KB of LDS per step, 512 cycles of the LDS pipe, as long as the step's MFMAs --
+        // so the waits are counted (LDS returns in order; nothing else of this loop counts on lgkmcnt) and the pipe never drains
+#pragma unroll
+        for (int a = 0; a < TA; a++) fa[1][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((2) ^ lc) << 4));
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cw[0]), "+v"(cw[1]), "+v"(sw));
+#else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw[0]), "+v"(cw[1]), "+v"(sw), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]));
+#endif
         // this lane's 8 weights of group ks: chunk 2 (ks % 2) + g of block ks / 2 -- value half(fma(q, scale, base)), q4x8_dequant's
         // arithmetic (ifa_dequant_q4.h) in four pieces
         uint32_t d_lo = 0, d_hi = 0; q4_f2 d_s2 = {0, 0}, d_b2 = {0, 0}, d_e02 = {0, 0}, d_e46 = {0, 0}, d_o13 = {0, 0}, d_o57 = {0, 0};
@@ -212,22 +224,29 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
         auto frag = [&](int ks, int a) { fa[ks][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((2 * ks) ^ lc) << 4)); };
         md_h8 fbc, fbn;
         dq_a(0); dq_b(); dq_c(); fbc = dq_d();
+#if IFA_MID_PF >= 2
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]));
+#endif
+        constexpr int LEAD = IFA_MID_PF >= 2 ? 2 : 1;      // groups of lead of the fragment requests
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
 #if IFA_MID_ABL == 2
 #pragma unroll
             for (int a = 0; a < TA; a++) acc[a][ks] += (float)fbc[a] * (float)__builtin_bit_cast(md_h8, fa[ks][a])[0];
-            if (ks < 3) { dq_a(ks + 1); dq_b(); dq_c(); fbn = dq_d(); for (int a = 0; a < TA; a++) frag(ks + 1, a); }
+            if (ks < 3) { dq_a(ks + 1); dq_b(); dq_c(); fbn = dq_d(); }
+            if (ks + LEAD < 4) for (int a = 0; a < TA; a++) frag(ks + LEAD, a);
             if (ks < 3) { issue_piece(nstep, nslot, 2 * ks); issue_piece(nstep, nslot, 2 * ks + 1); }
 #else
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][0]), fbc, acc[0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks < 3) { frag(ks + 1, 0); frag(ks + 1, 1); dq_a(ks + 1); }
+            if (ks + LEAD < 4) { frag(ks + LEAD, 0); frag(ks + LEAD, 1); }
+            if (ks < 3) dq_a(ks + 1);
             __builtin_amdgcn_sched_barrier(0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][1]), fbc, acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks < 3) { frag(ks + 1, 2); frag(ks + 1, 3); dq_b(); }
+            if (ks + LEAD < 4) { frag(ks + LEAD, 2); frag(ks + LEAD, 3); }
+            if (ks < 3) dq_b();
             __builtin_amdgcn_sched_barrier(0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][2]), fbc, acc[2], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -237,8 +256,13 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
             __builtin_amdgcn_sched_barrier(0);
             if (ks < 3) { fbn = dq_d(); issue_piece(nstep, nslot, 2 * ks + 1); }
 #endif
-            if (ks < 3)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks + 1][0]), "+v"(fa[ks + 1][1]), "+v"(fa[ks + 1][2]), "+v"(fa[ks + 1][3]));
+            if (ks < 3) {
+                // group ks + 1 has landed; with two groups of lead the requests of group ks + 2 (4 reads) may still be in flight
+                if (LEAD == 2 && ks + 2 < 4)
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[ks + 1][0]), "+v"(fa[ks + 1][1]), "+v"(fa[ks + 1][2]), "+v"(fa[ks + 1][3]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks + 1][0]), "+v"(fa[ks + 1][1]), "+v"(fa[ks + 1][2]), "+v"(fa[ks + 1][3]));
+            }
             fbc = fbn;
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
@@ -469,18 +493,25 @@ static int md_launch(const GmArgs &P, hipStream_t s)
     for (int i = P.nsets; i < 3; i++) G.tile0[i] = 1 << 30;
     G.tiles_m = (P.T + MD_BM - 1) / MD_BM; G.K = P.nblk * 32; G.tn0 = 0;
     const int ksteps = G.K / MD_BK;
-    const long long tiles = (long long)G.tiles_m * tn_count, cap = 2ll * md_num_cus();      // two workgroups fit a CU (LDS, registers)
+    // parts of K: the most that still put ONE workgroup on a CU (two fit -- LDS, registers -- but a grid between one and two per CU
+    // ends when the doubly loaded CUs do: wq | wk | wv of 128 tokens, 96 tiles: 384 workgroups 32.3 us, 192 workgroups 27; of 256
+    // tokens, 192 tiles: one part beats two; wo / w2 of one token tile, 32 tiles: eight parts, 256 workgroups, beat four -- 128 tokens
+    // 5.34 -> 4.86 ms in all, profiles/r06_prefill_mid_parts.log), every part >= MINS steps
+    static const bool two_per_cu = getenv("IFA_MID_TWO_PER_CU") != nullptr;      // (measurement: the first form's limit)
+    // (the gated pair keeps two per CU: 172 tiles of one token tile as 344 workgroups 45.7 us, as 172 workgroups 50.5)
+    const long long tiles = (long long)G.tiles_m * tn_count, cap = ((two_per_cu || EPI == GM_GLU) ? 2ll : 1ll) * md_num_cus();
     static const bool no_glu_split = getenv("IFA_MID_NO_GLU_SPLIT") != nullptr;      // (measurement: the gated pair as ONE part of K, like k_gemm_big's -- bit-identical products)
     const bool may = !P.no_waits && waits_enabled() && !(EPI == GM_GLU && no_glu_split);
     int rc = 1;
-    // parts of K: as many as the chip holds at once (two workgroups per CU), every part >= MINS steps
-    static const int force_ks = getenv("IFA_MID_KS") ? atoi(getenv("IFA_MID_KS")) : 0;      // (measurement)
+    static const int force_all = getenv("IFA_MID_KS") ? atoi(getenv("IFA_MID_KS")) : 0;      // (measurement: at most this many parts)
+    static const int force_epi = getenv(EPI == GM_PLAIN ? "IFA_MID_KS_PLAIN" : (EPI == GM_GLU ? "IFA_MID_KS_GLU" : "IFA_MID_KS_RES"))
+                                     ? atoi(getenv(EPI == GM_PLAIN ? "IFA_MID_KS_PLAIN" : (EPI == GM_GLU ? "IFA_MID_KS_GLU" : "IFA_MID_KS_RES"))) : 0;
+    const int force_ks = force_epi ? force_epi : force_all;
     static const int mins = getenv("IFA_MID_MINSTEPS") ? atoi(getenv("IFA_MID_MINSTEPS")) : 4;
     auto fits = [&](int ks) { return may && tiles * ks <= cap && ksteps / ks >= mins && (!force_ks || ks <= force_ks); };
-    // (8 / 16 parts fill the chip twice with short loops, but the exchanged sums grow with the part count -- 30 MB written and read
-    //  for wo at 16 parts: measured 30 us against 20 at 4 -- so they stay a measurement setting)
+    // (16 parts: the exchanged sums grow with the part count -- 30 MB written and read for wo: 30 us against 17 at 8 -- a measurement setting)
     if (force_ks >= 16 && fits(16)) rc = md_run<EPI, 16, IFA_MID_NS>(P, G, tn_count, s);
-    if (rc == 1 && force_ks >= 8 && fits(8)) rc = md_run<EPI, 8, IFA_MID_NS>(P, G, tn_count, s);
+    if (rc == 1 && fits(8)) rc = md_run<EPI, 8, IFA_MID_NS>(P, G, tn_count, s);
     if (rc == 1 && fits(4)) rc = md_run<EPI, 4, IFA_MID_NS>(P, G, tn_count, s);
     if (rc == 1 && fits(2)) rc = md_run<EPI, 2, IFA_MID_NS>(P, G, tn_count, s);
     if (rc == 1) rc = md_run<EPI, 1, IFA_MID_NS>(P, G, tn_count, s);
