@@ -41,10 +41,14 @@ typedef uint32_t md_u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void md_lds_t;
 typedef const __attribute__((address_space(1))) void md_glb_t;
 
+#ifndef IFA_MID_LOADERS
+#define IFA_MID_LOADERS 1   // 1: four more waves (one per SIMD) issue the direct-to-LDS requests; 0: the computing waves do, between their MFMAs
+#endif
 constexpr int MD_BM = 128, MD_BN = 128, MD_BK = 64, MD_NW = 4, MD_NT = 256;
 constexpr int MD_A_BYTES = MD_BM * MD_BK * 2;                       // 16 KB: activation tile of a step, rows of 128 bytes, 16-byte chunks swizzled
 constexpr int MD_WC_BYTES = MD_NW * 1024, MD_WS_BYTES = MD_NW * 256; // raw codes (32 rows x 2 blocks x 16 B per wave), (base, scale) words
 constexpr int MD_STAGE = MD_A_BYTES + MD_WC_BYTES + MD_WS_BYTES;    // 21 KB
+constexpr int MD_THREADS = IFA_MID_LOADERS ? 2 * MD_NT : MD_NT;     // launched threads (MD_NT of them compute and run the tails)
 // measurement builds (-DIFA_MID_ABL=n): 1 = no activation requests, 2 = no MFMA, 3 = no dequantisation, 4 = no barrier, 5 = no weight requests
 #ifndef IFA_MID_ABL
 #define IFA_MID_ABL 0
@@ -63,7 +67,7 @@ __device__ __forceinline__ uint32_t md_lds_b32(uint32_t addr) { uint32_t v; asm 
 // EPI: GM_PLAIN | GM_RESIDUAL | GM_GLU (a weight tile = 64 rows of w1 and the same 64 rows of w3).  KS: parts of K (workgroups per
 // tile).  NS: stages of the ring.
 template <int EPI, int KS, int NS>
-__global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo G)
+__global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const BigGeo G)
 {
     constexpr int BM = MD_BM, BN = MD_BN, BK = MD_BK, NW = MD_NW, NT = MD_NT, ROWB = BK * 2;
     constexpr bool GLU = EPI == GM_GLU;
@@ -76,7 +80,9 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
     const int T = P.T, nblk = P.nblk, tiles_m = G.tiles_m;
     const half_t *__restrict__ X = P.X;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & (NW - 1);              // a loader wave (IFA_MID_LOADERS) requests the pieces of the computing wave on its SIMD
+    const bool loader = wave_all >= NW;
     // XCD-aware tile order, bands of token tiles (k_gemm_big's mapping)
     int wg;
     {
@@ -160,15 +166,37 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
 
+    constexpr bool LD = IFA_MID_LOADERS != 0;
+    if (!LD || loader) {
 #pragma unroll
-    for (int p = 0; p < NS - 1; p++) issue(min(p, nsteps - 1), p);
+        for (int p = 0; p < NS - 1; p++) issue(min(p, nsteps - 1), p);
+    }
     int slot = 0;
+    if constexpr (LD) {
+        // The loader wave of a SIMD (IFA_MID_LOADERS): the six requests of a stage took their issue slots (~70 cycles each, ablation
+        // builds: profiles/r06_prefill_mid_parts.log) out of the ONE instruction stream that also issues the MFMAs; a second wave on
+        // the SIMD issues them on the memory port while the computing wave multiplies.  Same ring protocol, same barrier: the loader
+        // waits for ITS requests of stage `step` (vmcnt is per wave), every wave meets at the barrier, the loader requests stage
+        // step + NS - 1 into the slot the computing waves have just left.
+        if (loader) {
+            for (int step = 0; step < nsteps; step++) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * MD_VM) : "memory");
+                __builtin_amdgcn_s_barrier();
+                const int nslot = slot == 0 ? NS - 1 : slot - 1;
+                issue(min(step + NS - 1, nsteps - 1), nslot);
+                slot = slot + 1 == NS ? 0 : slot + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the repeats behind the last stage have landed before the ring is reused
+            __builtin_amdgcn_s_barrier();                          // (pairs with the computing waves' first barrier behind the loop)
+            return;
+        }
+    }
     if (trc) trc[1] = wall_clock64();
     for (int step = 0; step < nsteps; step++) {
         // stage `step` has landed (the NS - 2 younger stages may still be in flight); the barrier makes every wave's pieces visible
         // and says that every wave is done with the stage read last step, whose slot takes the request of stage step + NS - 1
         // (the bare barrier: __syncthreads() is fence + barrier, and the fence waits vmcnt(0) -- for the stages just requested)
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * MD_VM) : "memory");
+        if constexpr (!LD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * MD_VM) : "memory");
 #if IFA_MID_ABL != 4
         __builtin_amdgcn_s_barrier();
 #endif
@@ -235,7 +263,7 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
             for (int a = 0; a < TA; a++) acc[a][ks] += (float)fbc[a] * (float)__builtin_bit_cast(md_h8, fa[ks][a])[0];
             if (ks < 3) { dq_a(ks + 1); dq_b(); dq_c(); fbn = dq_d(); }
             if (ks + LEAD < 4) for (int a = 0; a < TA; a++) frag(ks + LEAD, a);
-            if (ks < 3) { issue_piece(nstep, nslot, 2 * ks); issue_piece(nstep, nslot, 2 * ks + 1); }
+            if (ks < 3 && !LD) { issue_piece(nstep, nslot, 2 * ks); issue_piece(nstep, nslot, 2 * ks + 1); }
 #else
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][0]), fbc, acc[0], 0, 0, 0);
@@ -250,11 +278,11 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
             __builtin_amdgcn_sched_barrier(0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][2]), fbc, acc[2], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks < 3) { dq_c(); issue_piece(nstep, nslot, 2 * ks); }
+            if (ks < 3) { dq_c(); if constexpr (!LD) issue_piece(nstep, nslot, 2 * ks); }
             __builtin_amdgcn_sched_barrier(0);
             acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][3]), fbc, acc[3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks < 3) { fbn = dq_d(); issue_piece(nstep, nslot, 2 * ks + 1); }
+            if (ks < 3) { fbn = dq_d(); if constexpr (!LD) issue_piece(nstep, nslot, 2 * ks + 1); }
 #endif
             if (ks < 3) {
                 // group ks + 1 has landed; with two groups of lead the requests of group ks + 2 (4 reads) may still be in flight
@@ -269,6 +297,7 @@ __global__ void __launch_bounds__(MD_NT) k_gemm_mid(const GmArgs P, const BigGeo
     }
     // the repeats requested behind the last stage must have landed before the ring's memory is used for anything else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (LD) __builtin_amdgcn_s_barrier();      // (the loader waves' last barrier: their requests have landed; they end there)
     if (trc) trc[2] = wall_clock64();
     // ---- parts of K as a REDUCE-SCATTER (KS > 1).  A thread's 64 sums are 16 units of 16 bytes; unit u = 4 a + q holds the 8 token
     // rows [8 u, 8 u + 8) of this lane's weight row.  Part kz OWNS units [kz UB, (kz + 1) UB), i.e. token rows [8 kz UB, 8 (kz + 1) UB) of the
@@ -452,7 +481,7 @@ static int md_run(const GmArgs &P, BigGeo G, int tn_count, hipStream_t s)
     }
     const long long grid = (long long)G.tiles_m * tn_count * KS;
     if constexpr (KS > 1) {
-        if (!wait_grid_fits((const void *)kern, MD_NT, smem, grid)) return 1;      // (1: not launched -- the caller takes fewer parts)
+        if (!wait_grid_fits((const void *)kern, MD_THREADS, smem, grid)) return 1;      // (1: not launched -- the caller takes fewer parts)
     }
     static const bool tracing = getenv("IFA_MID_TRACE") != nullptr;
     if (tracing) {      // measurement: per-workgroup phase stamps of this launch on stderr (synchronous)
@@ -461,7 +490,7 @@ static int md_run(const GmArgs &P, BigGeo G, int tn_count, hipStream_t s)
         if (buf && grid <= 4096) {
             (void)hipMemsetAsync(buf, 0, sizeof(long long) * 8 * (size_t)grid, s);
             GmArgs Q = P; Q.trace = buf;
-            kern<<<dim3((unsigned)grid), dim3(MD_NT), smem, s>>>(Q, G);
+            kern<<<dim3((unsigned)grid), dim3(MD_THREADS), smem, s>>>(Q, G);
             std::vector<long long> h((size_t)grid * 8);
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
@@ -474,7 +503,7 @@ static int md_run(const GmArgs &P, BigGeo G, int tn_count, hipStream_t s)
             return IFA_OK;
         }
     }
-    kern<<<dim3((unsigned)grid), dim3(MD_NT), smem, s>>>(P, G);
+    kern<<<dim3((unsigned)grid), dim3(MD_THREADS), smem, s>>>(P, G);
     return IFA_OK;
 }
 
