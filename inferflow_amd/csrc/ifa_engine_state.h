@@ -171,9 +171,10 @@ struct ifa_model {
     // (7 products + 4 element-wise launches), 40 tokens the same (profiles/r05_prompt_lengths.log)
     int opt_prefill_big_min = 47;
     int opt_prefill_chunk = 1;      // prompts of 34..48 tokens as two passes of <= 32 tokens (ifa_model_forward)
-    // round 6: prompts of prefill_big_min + 1 .. prefill_mid_max tokens take the four launches per layer from k_gemm_mid (ifa_gemm_mid.hip:
-    // ring of direct-to-LDS stages, weights dequantised into the MFMA operand registers) when every linear is Q4_B32T1A / B
-    int opt_prefill_mid = 1, opt_prefill_mid_max = 256;      // (320 tokens and up: the large tiles win again, profiles/r06_prefill_mid_ab.log)
+    // round 6: prompts of 33 .. prefill_mid_max tokens take the four launches per layer from k_gemm_mid (ifa_gemm_mid.hip: ring of
+    // direct-to-LDS stages requested by loader waves, weights dequantised into the MFMA operand registers) when every linear has its
+    // operand-order copy; 320..768 tokens 8-9 % faster than the large tiles, 1024 tokens a tie (profiles/r06_prefill_mid_parts.log)
+    int opt_prefill_mid = 1, opt_prefill_mid_max = 768;
     int opt_rows_kparts = 1, opt_gemm_splitk = 1;   // 0: never the launches whose workgroups wait for partner workgroups (K parts of the 9..32-row GEMM, split-K halves of the large-tile GEMM)
     int opt_debug_mo_alloc_fail = 0;           // tests: ensure_mo_build fails like an exhausted allocator after its first copy
     static constexpr int RING = 1024;

@@ -44,10 +44,10 @@ typedef const __attribute__((address_space(1))) void md_glb_t;
 #ifndef IFA_MID_LOADERS
 #define IFA_MID_LOADERS 1   // 1: four more waves (one per SIMD) issue the direct-to-LDS requests; 0: the computing waves do, between their MFMAs
 #endif
-constexpr int MD_BM = 128, MD_BN = 128, MD_BK = 64, MD_NW = 4, MD_NT = 256;
-constexpr int MD_A_BYTES = MD_BM * MD_BK * 2;                       // 16 KB: activation tile of a step, rows of 128 bytes, 16-byte chunks swizzled
+constexpr int MD_BN = 128, MD_BK = 64, MD_NW = 4, MD_NT = 256;      // (token rows of a tile: 32 TA, template parameter)
+constexpr int md_a_bytes(int ta) { return 32 * ta * MD_BK * 2; }       // activation tile of a step (TA = 4: 16 KB), rows of 128 bytes, 16-byte chunks swizzled
 constexpr int MD_WC_BYTES = MD_NW * 1024, MD_WS_BYTES = MD_NW * 256; // raw codes (32 rows x 2 blocks x 16 B per wave), (base, scale) words
-constexpr int MD_STAGE = MD_A_BYTES + MD_WC_BYTES + MD_WS_BYTES;    // 21 KB
+constexpr int md_stage(int ta) { return md_a_bytes(ta) + MD_WC_BYTES + MD_WS_BYTES; }    // 21 KB (TA = 4) / 37 KB (TA = 8)
 constexpr int MD_THREADS = IFA_MID_LOADERS ? 2 * MD_NT : MD_NT;     // launched threads (MD_NT of them compute and run the tails)
 // measurement builds (-DIFA_MID_ABL=n): 1 = no activation requests, 2 = no MFMA, 3 = no dequantisation, 4 = no barrier, 5 = no weight requests
 #ifndef IFA_MID_ABL
@@ -59,20 +59,21 @@ constexpr int MD_THREADS = IFA_MID_LOADERS ? 2 * MD_NT : MD_NT;     // launched 
 #ifndef IFA_MID_WAUX
 #define IFA_MID_WAUX 0       // cache policy of the weight requests (2 = non-temporal)
 #endif
-constexpr int MD_VM = IFA_MID_ABL == 1 ? 2 : (IFA_MID_ABL == 5 ? 4 : 6);                     // direct-to-LDS requests per wave and stage: 4 (activations) + 2 (weights)
+constexpr int md_vm(int ta) { return IFA_MID_ABL == 1 ? 2 : (IFA_MID_ABL == 5 ? ta : ta + 2); }      // direct-to-LDS requests per wave and stage: TA (activations) + 2 (weights)
 
 __device__ __forceinline__ md_u4 md_lds_b128(uint32_t addr) { md_u4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; }
 __device__ __forceinline__ uint32_t md_lds_b32(uint32_t addr) { uint32_t v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); return v; }
 
 // EPI: GM_PLAIN | GM_RESIDUAL | GM_GLU (a weight tile = 64 rows of w1 and the same 64 rows of w3).  KS: parts of K (workgroups per
-// tile).  NS: stages of the ring.
-template <int EPI, int KS, int NS>
+// tile).  NS: stages of the ring.  TA: 32-token accumulator tiles of a wave -- the tile is 32 TA tokens x 128 weight rows (TA = 8 from 512
+// tokens on: every dequantised weight and every request of the weight stream serves twice the products).
+template <int EPI, int KS, int NS, int TA>
 __global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const BigGeo G)
 {
-    constexpr int BM = MD_BM, BN = MD_BN, BK = MD_BK, NW = MD_NW, NT = MD_NT, ROWB = BK * 2;
+    constexpr int BM = 32 * TA, BN = MD_BN, BK = MD_BK, NW = MD_NW, NT = MD_NT, ROWB = BK * 2;
+    constexpr int MD_A_BYTES = md_a_bytes(TA), MD_STAGE = md_stage(TA), MD_VM = md_vm(TA), XP = TA;      // XP: activation pieces (8 token rows) a wave requests per stage
     constexpr bool GLU = EPI == GM_GLU;
     constexpr int BNE = GLU ? BN / 2 : BN;
-    constexpr int TA = 4;                                 // 32-token accumulator tiles of a wave (its 32 weight rows x all 128 tokens)
     auto swz = [](int r) { return (r >> 1) & 7; };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long *const trc = (P.trace && threadIdx.x == 0) ? P.trace + (size_t)blockIdx.x * 8 : nullptr;      // (measurement: IFA_MID_TRACE=1)
@@ -104,10 +105,10 @@ __global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const B
 
     // ---- sources of this wave's direct-to-LDS pieces
     // activations: 4 pieces of 8 token rows x 128 bytes; lane -> (row, chunk), the swizzle applied to the SOURCE (the load writes LDS linearly)
-    const half_t *xsrc[4];
+    const half_t *xsrc[XP];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int row = (wave * 4 + j) * 8 + lane / 8;
+    for (int j = 0; j < XP; j++) {
+        const int row = (wave * XP + j) * 8 + lane / 8;
         const int c = (lane % 8) ^ swz(row);
         xsrc[j] = X + (size_t)min(t0 + row, T - 1) * P.ldx + c * 8;
     }
@@ -130,15 +131,15 @@ __global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const B
     // them between its MFMAs
     auto issue_piece = [&](int step, int slot, int piece) {
         char *st = smem + (size_t)slot * MD_STAGE;
-        if (piece < 4) {
+        if (piece < XP) {
 #if IFA_MID_ABL != 1
-            __builtin_amdgcn_global_load_lds((md_glb_t *)(xsrc[piece] + (size_t)(s0 + step) * BK), (md_lds_t *)(st + (size_t)(wave * 4 + piece) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((md_glb_t *)(xsrc[piece] + (size_t)(s0 + step) * BK), (md_lds_t *)(st + (size_t)(wave * XP + piece) * 1024), 16, 0, 0);
 #endif
             return;
         }
 #if IFA_MID_ABL != 5
         const int S = (s0 + step) >> 1, half = (s0 + step) & 1;
-        if (piece == 4)
+        if (piece == XP)
             __builtin_amdgcn_global_load_lds((md_glb_t *)(wsrc + (size_t)S * 1024 + (size_t)half * 512), (md_lds_t *)(st + MD_A_BYTES + wave * 1024), 16, 0, IFA_MID_WAUX);
         else
             __builtin_amdgcn_global_load_lds((md_glb_t *)(wsbs + (size_t)(S >> 2) * 1024 + (size_t)half * 512 + (size_t)(S & 3) * 4),
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const B
     };
     auto issue = [&](int step, int slot) {
 #pragma unroll
-        for (int pc = 0; pc < 6; pc++) issue_piece(step, slot, pc);
+        for (int pc = 0; pc < XP + 2; pc++) issue_piece(step, slot, pc);
     };
 
     // ---- per-lane LDS offsets: lane (i, g) reads token row i of a 32-row tile, chunk 2 ks + g; weight row i of its wave
@@ -214,16 +215,21 @@ __global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const B
         sw[1] = md_lds_b32(ws_off + sb + 64);
 #pragma unroll
         for (int a = 0; a < TA; a++) fa[0][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((0) ^ lc) << 4));
-#if IFA_MID_PF >= 2
-        // fragments are requested TWO 16-column groups ahead (round 6, second pass): with one group of lead the wave sat in lgkmcnt(0)
-        // at the end of every group -- four waves read 64 KB of LDS per step, 512 cycles of the LDS pipe, as long as the step's MFMAs --
-        // so the waits are counted (LDS returns in order; nothing else of this loop counts on lgkmcnt) and the pipe never drains
+        // fragments are requested LEAD 16-column groups ahead (round 6, second pass): with one group of lead and TA = 4 the wave sat in
+        // lgkmcnt(0) at the end of every group -- four waves read 64 KB of LDS per step, 512 cycles of the LDS pipe, as long as the step's
+        // MFMAs -- so the waits are counted (LDS returns in order; nothing else of this loop counts on lgkmcnt; the counter holds 15) and
+        // the pipe never drains.  TA = 8: a group's eight MFMAs cover the next group's reads, one group of lead.
+        constexpr int LEAD = (IFA_MID_PF >= 2 && TA <= 4) ? 2 : 1;
+        if constexpr (LEAD == 2) {
 #pragma unroll
-        for (int a = 0; a < TA; a++) fa[1][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((2) ^ lc) << 4));
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cw[0]), "+v"(cw[1]), "+v"(sw));
-#else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cw[0]), "+v"(cw[1]), "+v"(sw), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]));
-#endif
+            for (int a = 0; a < TA; a++) fa[1][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((2) ^ lc) << 4));
+        }
+        // (a counted wait names the registers it makes valid: later uses depend on the statement)
+        auto landed = [&](int k) {
+#pragma unroll
+            for (int a = 0; a < TA; a++) asm volatile("" : "+v"(fa[k][a]));
+        };
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(cw[0]), "+v"(cw[1]), "+v"(sw) : "n"(TA * LEAD));
         // this lane's 8 weights of group ks: chunk 2 (ks % 2) + g of block ks / 2 -- value half(fma(q, scale, base)), q4x8_dequant's
         // arithmetic (ifa_dequant_q4.h) in four pieces
         uint32_t d_lo = 0, d_hi = 0; q4_f2 d_s2 = {0, 0}, d_b2 = {0, 0}, d_e02 = {0, 0}, d_e46 = {0, 0}, d_o13 = {0, 0}, d_o57 = {0, 0};
@@ -252,44 +258,39 @@ __global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const B
         auto frag = [&](int ks, int a) { fa[ks][a] = md_lds_b128(a_off + sb + (uint32_t)(a * 32 * ROWB) + (uint32_t)(((2 * ks) ^ lc) << 4)); };
         md_h8 fbc, fbn;
         dq_a(0); dq_b(); dq_c(); fbc = dq_d();
-#if IFA_MID_PF >= 2
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]));
-#endif
-        constexpr int LEAD = IFA_MID_PF >= 2 ? 2 : 1;      // groups of lead of the fragment requests
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(TA * (LEAD - 1)));
+        landed(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
 #if IFA_MID_ABL == 2
 #pragma unroll
-            for (int a = 0; a < TA; a++) acc[a][ks] += (float)fbc[a] * (float)__builtin_bit_cast(md_h8, fa[ks][a])[0];
+            for (int a = 0; a < TA; a++) acc[a][ks] += (float)fbc[a % 8] * (float)__builtin_bit_cast(md_h8, fa[ks][a])[0];
             if (ks < 3) { dq_a(ks + 1); dq_b(); dq_c(); fbn = dq_d(); }
             if (ks + LEAD < 4) for (int a = 0; a < TA; a++) frag(ks + LEAD, a);
-            if (ks < 3 && !LD) { issue_piece(nstep, nslot, 2 * ks); issue_piece(nstep, nslot, 2 * ks + 1); }
+            if (ks < 3 && !LD) for (int pc = ks * TA; pc < (ks + 1) * TA && pc < XP + 2; pc++) issue_piece(nstep, nslot, pc);
 #else
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][0]), fbc, acc[0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + LEAD < 4) { frag(ks + LEAD, 0); frag(ks + LEAD, 1); }
-            if (ks < 3) dq_a(ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][1]), fbc, acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + LEAD < 4) { frag(ks + LEAD, 2); frag(ks + LEAD, 3); }
-            if (ks < 3) dq_b();
-            __builtin_amdgcn_sched_barrier(0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][2]), fbc, acc[2], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks < 3) { dq_c(); if constexpr (!LD) issue_piece(nstep, nslot, 2 * ks); }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][3]), fbc, acc[3], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks < 3) { fbn = dq_d(); if constexpr (!LD) issue_piece(nstep, nslot, 2 * ks + 1); }
+            // TA MFMAs; between them (sched_barrier pins the order): the fragment reads of group ks + LEAD two at a time, the four pieces of
+            // the next group's conversion, and -- without loader waves -- the next stage's requests
+#pragma unroll
+            for (int a = 0; a < TA; a++) {
+                __builtin_amdgcn_sched_barrier(0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(md_h8, fa[ks][a]), fbc, acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + LEAD < 4 && 2 * a + 1 < TA) { frag(ks + LEAD, 2 * a); frag(ks + LEAD, 2 * a + 1); }
+                if (ks < 3) {
+                    if (a == 0) dq_a(ks + 1);
+                    else if (a == TA / 4) dq_b();
+                    else if (a == TA / 2) dq_c();
+                    else if (a == 3 * TA / 4) fbn = dq_d();
+                    if constexpr (!LD) { if (ks * TA + a < XP + 2) issue_piece(nstep, nslot, ks * TA + a); }
+                }
+            }
 #endif
             if (ks < 3) {
-                // group ks + 1 has landed; with two groups of lead the requests of group ks + 2 (4 reads) may still be in flight
-                if (LEAD == 2 && ks + 2 < 4)
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[ks + 1][0]), "+v"(fa[ks + 1][1]), "+v"(fa[ks + 1][2]), "+v"(fa[ks + 1][3]));
-                else
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks + 1][0]), "+v"(fa[ks + 1][1]), "+v"(fa[ks + 1][2]), "+v"(fa[ks + 1][3]));
+                // group ks + 1 has landed; with two groups of lead the TA requests of group ks + 2 may still be in flight
+                if (LEAD == 2 && ks + 2 < 4) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(TA));
+                else asm volatile("s_waitcnt lgkmcnt(0)");
+                landed(ks + 1);
             }
             fbc = fbn;
         }
@@ -306,7 +307,9 @@ __global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const B
     // sequence of additions whichever part performs it) and runs the epilogue for its rows.  k_gemm_big's form -- the last part
     // reads every other part's whole tile -- measured 8 us per launch here (192 KB through one CU) and limits KS; this one reads
     // (KS - 1) / KS x 64 KB per workgroup whatever KS is, so short products can be cut into enough parts to fill the chip twice.
-    constexpr int UB = 16 / KS;                          // units (8-row bands) a part owns
+    constexpr int NU = 4 * TA;                           // 8-token-row bands of the tile = 16-byte units of a thread's sums
+    static_assert(NU % KS == 0, "parts of K must divide the tile's row bands");
+    constexpr int UB = NU / KS;                          // units (8-row bands) a part owns
     const int row_lo = KS == 1 ? 0 : kz * UB * 8, nrows_own = KS == 1 ? BM : UB * 8;
     constexpr int VEC = BNE / 8;
     constexpr int PIECES = (BM / KS * VEC + NT - 1) / NT;  // 16-byte output pieces per thread (its part's rows)
@@ -323,7 +326,6 @@ __global__ void __launch_bounds__(MD_THREADS) k_gemm_mid(const GmArgs P, const B
         }
     }
     if constexpr (KS > 1) {
-        constexpr int NU = 16;
         char *pt = reinterpret_cast<char *>(G.part) + (size_t)wg * ((size_t)KS * NU * NT * 16);
         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pt, 0, KS * NU * NT * 16, 0x00020000);
         unsigned *arrive = G.flags + 2 * wg, *done = arrive + 1;
@@ -458,19 +460,19 @@ bool gemm_mid_ok(int w_dtype, const GmArgs &P, int epi)
     return true;
 }
 
-template <int EPI, int KS, int NS>
+template <int EPI, int KS, int NS, int TA>
 static int md_run(const GmArgs &P, BigGeo G, int tn_count, hipStream_t s)
 {
     if constexpr (KS > 1) {
         G.err = wait_err_word();
-        const size_t tiles = (size_t)G.tiles_m * tn_count, part_bytes = tiles * (size_t)KS * MD_BM * MD_BN * 4;
+        const size_t tiles = (size_t)G.tiles_m * tn_count, part_bytes = tiles * (size_t)KS * (32 * TA) * MD_BN * 4;
         void *scratch = nullptr;
         int rcs = gemm_splitk_scratch(s, part_bytes, 2 * tiles, &scratch);      // (two counters per tile)
         if (rcs) return rcs;
         G.flags = (unsigned *)scratch; G.part = (unsigned long long *)((char *)scratch + SPLITK_FLAG_BYTES_H);
     }
-    const size_t smem = std::max((size_t)NS * MD_STAGE, (size_t)MD_BM * (MD_BN * 2 + 64));
-    auto kern = k_gemm_mid<EPI, KS, NS>;
+    const size_t smem = std::max((size_t)NS * md_stage(TA), (size_t)(32 * TA) * (MD_BN * 2 + 64));
+    auto kern = k_gemm_mid<EPI, KS, NS, TA>;
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -498,8 +500,8 @@ static int md_run(const GmArgs &P, BigGeo G, int tn_count, hipStream_t s)
             for (long long b = 0; b < grid; b++) t0 = std::min(t0, h[(size_t)b * 8]);
             double mx[5] = {0, 0, 0, 0, 0}, sm[5] = {0, 0, 0, 0, 0};
             for (long long b = 0; b < grid; b++) for (int k = 0; k < 5; k++) { const double v = (h[(size_t)b * 8 + k] - t0) * 0.01; mx[k] = std::max(mx[k], v); sm[k] += v; }
-            fprintf(stderr, "k_gemm_mid<%d,%d,%d> grid %lld steps %d | us after the first workgroup's start, mean (max): start %.2f (%.2f) loop begins %.2f (%.2f) loop ends %.2f (%.2f) parts summed %.2f (%.2f) end %.2f (%.2f)\n",
-                    EPI, KS, NS, grid, G.K / MD_BK / KS, sm[0] / grid, mx[0], sm[1] / grid, mx[1], sm[2] / grid, mx[2], sm[3] / grid, mx[3], sm[4] / grid, mx[4]);
+            fprintf(stderr, "k_gemm_mid<%d,%d,%d,%d> grid %lld steps %d | us after the first workgroup's start, mean (max): start %.2f (%.2f) loop begins %.2f (%.2f) loop ends %.2f (%.2f) parts summed %.2f (%.2f) end %.2f (%.2f)\n",
+                    EPI, KS, NS, TA, grid, G.K / MD_BK / KS, sm[0] / grid, mx[0], sm[1] / grid, mx[1], sm[2] / grid, mx[2], sm[3] / grid, mx[3], sm[4] / grid, mx[4]);
             return IFA_OK;
         }
     }
@@ -511,9 +513,10 @@ static int md_run(const GmArgs &P, BigGeo G, int tn_count, hipStream_t s)
 #define IFA_MID_NS 3
 #endif
 
-template <int EPI>
+template <int EPI, int TA>
 static int md_launch(const GmArgs &P, hipStream_t s)
 {
+    constexpr int MD_BM = 32 * TA;
     constexpr int BNE = EPI == GM_GLU ? MD_BN / 2 : MD_BN;
     BigGeo G; memset(&G, 0, sizeof(G));
     G.tile0[0] = 0;
@@ -539,11 +542,11 @@ static int md_launch(const GmArgs &P, hipStream_t s)
     static const int mins = getenv("IFA_MID_MINSTEPS") ? atoi(getenv("IFA_MID_MINSTEPS")) : 4;
     auto fits = [&](int ks) { return may && tiles * ks <= cap && ksteps / ks >= mins && (!force_ks || ks <= force_ks); };
     // (16 parts: the exchanged sums grow with the part count -- 30 MB written and read for wo: 30 us against 17 at 8 -- a measurement setting)
-    if (force_ks >= 16 && fits(16)) rc = md_run<EPI, 16, IFA_MID_NS>(P, G, tn_count, s);
-    if (rc == 1 && fits(8)) rc = md_run<EPI, 8, IFA_MID_NS>(P, G, tn_count, s);
-    if (rc == 1 && fits(4)) rc = md_run<EPI, 4, IFA_MID_NS>(P, G, tn_count, s);
-    if (rc == 1 && fits(2)) rc = md_run<EPI, 2, IFA_MID_NS>(P, G, tn_count, s);
-    if (rc == 1) rc = md_run<EPI, 1, IFA_MID_NS>(P, G, tn_count, s);
+    if constexpr (TA == 4) { if (force_ks >= 16 && fits(16)) rc = md_run<EPI, 16, IFA_MID_NS, TA>(P, G, tn_count, s); }
+    if (rc == 1 && fits(8)) rc = md_run<EPI, 8, IFA_MID_NS, TA>(P, G, tn_count, s);
+    if (rc == 1 && fits(4)) rc = md_run<EPI, 4, IFA_MID_NS, TA>(P, G, tn_count, s);
+    if (rc == 1 && fits(2)) rc = md_run<EPI, 2, IFA_MID_NS, TA>(P, G, tn_count, s);
+    if (rc == 1) rc = md_run<EPI, 1, IFA_MID_NS, TA>(P, G, tn_count, s);
     if (rc) return rc;
     IFA_LAUNCH_CHECK();
     return IFA_OK;
@@ -552,9 +555,19 @@ static int md_launch(const GmArgs &P, hipStream_t s)
 int gemm_mid(const GmArgs &P, int epi, hipStream_t s)
 {
     if (!gemm_mid_ok(Q4_B32T1A, P, epi)) return ifa_fail(IFA_ERR_ARG, "mid-length GEMM: %d blocks per row / epilogue %d", P.nblk, epi);
-    if (epi == GM_PLAIN) return md_launch<GM_PLAIN>(P, s);
-    if (epi == GM_RESIDUAL) return md_launch<GM_RESIDUAL>(P, s);
-    return md_launch<GM_GLU>(P, s);
+    // 256-token tiles (TA = 8): the weight stream and its conversion serve twice the products per step
+    static const int force_ta = getenv("IFA_MID_TA") ? atoi(getenv("IFA_MID_TA")) : 0;      // (measurement)
+    // (measured round 6: 512 / 768 tokens 10.96 / 16.48 ms with 128-token tiles, 11.37 / 17.50 with 256; 1024 tokens 19.57 / 19.25 -- the
+    //  wide tile pays only where the large-tile kernel already ties, so it stays a measurement setting)
+    const bool wide = force_ta == 8;
+    if (wide) {
+        if (epi == GM_PLAIN) return md_launch<GM_PLAIN, 8>(P, s);
+        if (epi == GM_RESIDUAL) return md_launch<GM_RESIDUAL, 8>(P, s);
+        return md_launch<GM_GLU, 8>(P, s);
+    }
+    if (epi == GM_PLAIN) return md_launch<GM_PLAIN, 4>(P, s);
+    if (epi == GM_RESIDUAL) return md_launch<GM_RESIDUAL, 4>(P, s);
+    return md_launch<GM_GLU, 4>(P, s);
 }
 
 } // namespace ifa
