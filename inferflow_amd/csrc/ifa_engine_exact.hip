@@ -16,7 +16,7 @@ bool exact_supported(const ifa_model *m, std::string *why)
     if (m->topo || c.tp_size > 1) return no("partitioned model");
     if (c.norm_kind != 0) return no("Std norm (only the RMS kernel has an order-exact form)");
     if (c.use_alibi) return no("ALiBi");
-    if (c.experts > 0) return no("mixture of experts");
+    if (c.experts > 64 || (c.experts > 0 && (c.moe_top_k < 1 || c.moe_top_k > 8))) return no("more than 64 experts / top-k outside 1..8");
     if (c.parallel_attn || c.share_input) return no("parallel-attention / shared-input wiring");
     if (c.act_kind == 1) return no("GELU (tanhf of the host libm has no device restatement)");
     if (c.rope_order != 0 && (c.partial_rotary < 0.9999f || c.partial_rotary > 1.0001f)) return no("partial rotary embedding");
@@ -111,6 +111,34 @@ int forward_exact(ifa_model *m, int token, int pos, void *logits_out, int *next_
             if ((rc = exact_rmsnorm(m->a, 1, (int)D, (const half_t *)L.t[T_FFN_NORM].data, (const half_t *)L.t[T_FFN_NORM_B].data, c.ffn_norm_base, c.eps, m->hn, m->stream))) return rc;
             ff_n = m->hn;
         }
+        if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
+            // ProcessGpuLayer_Moe (inference_worker.cc:1924-2146) at one row: router GEMV (F16 gate) -> softmax -> top-k with
+            // BuildRowsForMoE's rules (ascending expert order, F16 weights: ifa_moe_route_topk, pinned to the reference's own rows) ->
+            // the selected experts' FFNs in that order, each added as  f = half(float(out x w + f))
+            const int E = c.experts, K = c.moe_top_k;
+            if ((rc = exact_matmul(m, ff_n, L.t[T_MOE_GATE], none, m->moe_gate))) return rc;
+            if ((rc = exact_softmax_row(m->moe_gate, E, 1.0f, m->stream))) return rc;
+            if ((rc = ifa_moe_route_topk(m->moe_gate, 1, E, K, c.moe_norm_topk, m->moe_sel, m->moe_selw, s))) return rc;
+            IFA_HIP_CHECK(hipMemcpyAsync(m->host_pinned + 16, m->moe_sel, sizeof(int) * (size_t)K, hipMemcpyDeviceToHost, m->stream));
+            IFA_HIP_CHECK(hipMemsetAsync(m->f, 0, D * 2, m->stream));
+            IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+            int sel[8];
+            for (int j = 0; j < K; j++) sel[j] = m->host_pinned[16 + j];
+            for (int j = 0; j < K; j++) {
+                const int ex = sel[j];
+                if (ex < 0) continue;          // (dropped: probability below 1e-5, or fewer experts than top-k)
+                if (ex >= E) return ifa_fail(IFA_ERR_STATE, "exact_order: router selected expert %d of %d", ex, E);
+                const Tensor *ew = &L.experts[(size_t)ex * 3];      // w1, w2, w3
+                const size_t Fe = ew[0].rows;
+                if ((rc = exact_matmul(m, ff_n, ew[0], none, m->t1))) return rc;
+                if (ew[2].present()) {
+                    if ((rc = exact_matmul(m, ff_n, ew[2], none, m->t2))) return rc;
+                    if ((rc = exact_act_mul(c.act_kind, m->t1, m->t2, Fe, m->t1, m->stream))) return rc;
+                } else if ((rc = exact_act_mul(c.act_kind, m->t1, nullptr, Fe, m->t1, m->stream))) return rc;
+                if ((rc = exact_matmul(m, m->t1, ew[1], none, m->moe_out))) return rc;
+                if ((rc = exact_moe_combine(m->f, m->moe_out, m->moe_selw + j, D, m->stream))) return rc;
+            }
+        } else {
         const size_t F = L.t[T_W1].rows;
         if ((rc = exact_matmul(m, ff_n, L.t[T_W1], L.t[T_W1_B], m->t1))) return rc;
         if (L.t[T_W3].present()) {
@@ -118,6 +146,7 @@ int forward_exact(ifa_model *m, int token, int pos, void *logits_out, int *next_
             if ((rc = exact_act_mul(c.act_kind, m->t1, m->t2, F, m->t1, m->stream))) return rc;
         } else if ((rc = exact_act_mul(c.act_kind, m->t1, nullptr, F, m->t1, m->stream))) return rc;
         if ((rc = exact_matmul(m, m->t1, L.t[T_W2], L.t[T_W2_B], m->f))) return rc;
+        }
         if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, D, m->f, s))) return rc;
         if ((rc = ifa_add(m->f, m->a, D, 0, m->f, s))) return rc;                  // layer_out = ff_out + residual (:936-947)
         std::swap(m->x, m->f);

@@ -263,6 +263,37 @@ __global__ void __launch_bounds__(256) k_exact_act_mul(const half_t *__restrict_
     y[i] = r;
 }
 
+// ---------------------------------------------------------------- router softmax over E experts (orc_softmax, one row) and the
+// weighted accumulation of an expert's output (AddByRowIdx_Kernel as the oracle restates it: double product + sum, float, half)
+__global__ void __launch_bounds__(64) k_exact_softmax_row(half_t *__restrict__ s, int cx, float scale)
+{
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int xi = 0; xi < cx; xi++) { const float v = scale * h2f(s[xi]); mx = mx > v ? mx : v; }
+    float lane = 0.0f;
+    if (tid < 32)
+        for (int xi = tid; xi < cx; xi += 32) {
+            const float v = scale * h2f(s[xi]);
+            const float e = expf_libm(v - mx);
+            lane = lane + e;
+            s[xi] = f2h(e);
+        }
+#pragma unroll
+    for (int mask = 16; mask > 0; mask >>= 1) lane = lane + __shfl_xor(lane, mask, 32);
+    const float inv = 1.0f / __shfl(lane, 0, 64);
+    __syncthreads();
+    if (tid < 32)
+        for (int xi = tid; xi < cx; xi += 32) s[xi] = f2h(h2f(s[xi]) * inv);
+}
+
+__global__ void __launch_bounds__(256) k_exact_moe_combine(half_t *__restrict__ f, const half_t *__restrict__ eo, const half_t *__restrict__ w, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double p = (double)h2f(eo[i]) * (double)h2f(w[0]) + (double)h2f(f[i]);
+    f[i] = f2h((float)p);
+}
+
 // ---------------------------------------------------------------- host entry points
 int exact_init(hipStream_t s)
 {
@@ -335,6 +366,21 @@ int exact_attention(const half_t *q, const void *kc, const void *vc, int kv_dtyp
         if (lds > 48 * 1024) IFA_HIP_CHECK(hipFuncSetAttribute((const void *)k_exact_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_exact_attention<false><<<(unsigned)heads, 256, lds, s>>>(q, (const uint8_t *)kc, (const uint8_t *)vc, row_bytes, n_ctx, heads, kv_heads, head_dim, alpha, sm_scale, out);
     }
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int exact_softmax_row(half_t *s_row, int cx, float scale, hipStream_t s)
+{
+    IFA_REQUIRE(exact_init(s) == IFA_OK, "exact softmax: table upload failed");
+    k_exact_softmax_row<<<1, 64, 0, s>>>(s_row, cx, scale);
+    IFA_LAUNCH_CHECK();
+    return IFA_OK;
+}
+
+int exact_moe_combine(half_t *f, const half_t *expert_out, const half_t *weight_dev, size_t n, hipStream_t s)
+{
+    k_exact_moe_combine<<<ifa_cdiv(n, 256), 256, 0, s>>>(f, expert_out, weight_dev, (int)n);
     IFA_LAUNCH_CHECK();
     return IFA_OK;
 }
