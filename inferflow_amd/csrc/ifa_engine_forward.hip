@@ -724,6 +724,20 @@ int ifa_model_decode_batch(ifa_model *m, int n, const int *tokens_host, const in
     IFA_REQUIRE(m && m->finalized, "ifa_model_decode_batch: model not finalized");
     IFA_REQUIRE(n >= 1 && n <= ifa_model::RING && tokens_host && positions_host && kv_slots_host, "ifa_model_decode_batch: bad arguments");
     IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    if (m->opt_exact_order) {      // order-exact: every query's row through the single-row step on ITS cache set (a batched step of the
+        // reference is n independent rows; its T > 1 linear branch has no order-exact form here, so the rows go one by one)
+        const int back = m->cur_slot;
+        const size_t V = m->g[T_LM_HEAD].present() ? m->g[T_LM_HEAD].rows : 0;
+        int rc = IFA_OK;
+        for (int i = 0; i < n && rc == IFA_OK; i++) {
+            if ((rc = ifa_model_select_kv(m, kv_slots_host[i]))) break;
+            int nt = 0;
+            rc = forward_exact(m, tokens_host[i], positions_host[i], logits_out_dev ? (char *)logits_out_dev + (size_t)i * V * 2 : nullptr, &nt);
+            if (next_tokens_host) next_tokens_host[i] = nt;
+        }
+        const int rb = ifa_model_select_kv(m, back);
+        return rc ? rc : rb;
+    }
     // more queries than the fused five-launch step takes (16): balanced chunks of <= 16, each its own step (the queries are
     // independent; 32 queries op-by-op took 6.7 ms against 2 x 3.1 ms for two fused steps)
     const int fused_max = batch_fused_ok(m, 32) ? 32 : 16;

@@ -125,3 +125,27 @@ def test_exact_order_mixture_of_experts_is_bit_identical_to_the_oracle(shape, wd
         assert _same_bits(wk.read_buffer("vcache", layer=l, nbytes=n * rb), om.kv_rows(l, 1, n))
     print("order-exact MoE %s: %d steps bit-identical; smallest router margin met %.5f" % (shape, n, min(margins)))
     wk.close()
+
+
+def test_exact_order_batched_step_runs_every_query_through_the_exact_row():
+    """ifa_model_decode_batch with exact_order on: three queries on their own KV cache sets, each row through the single-row step --
+    every query's logits and ids are those of an oracle of its own, bit for bit (a batched step of the reference is n independent rows)."""
+    import torch
+    wk, om0, s = _build_custom("test_gqa", dt.Q4_B32T1A, dt.Q8_B32T2, 40, dict(), with_bias=False)
+    oms = [om0] + [_build_custom("test_gqa", dt.Q4_B32T1A, dt.Q8_B32T2, 40, dict(), with_bias=False)[1] for _ in range(2)]      # (same seed: same weights)
+    wk.kv_slots(3)
+    wk.set_option("exact_order", 1)
+    rng = np.random.default_rng(3)
+    cur = [int(t) for t in rng.integers(0, s["vocab"], 3)]
+    pos = [0, 0, 0]
+    lg = torch.empty((3, s["vocab"]), dtype=torch.float16, device="cuda")
+    for step in range(12):
+        act = [0, 1, 2] if step % 3 else [2, 0]          # (ragged: not every query advances in every step)
+        nxt = wk.decode_batch([cur[q] for q in act], [pos[q] for q in act], act, lg)
+        rows = lg.cpu().numpy().view(np.uint16)
+        for j, q in enumerate(act):
+            tok_o, lg_o = oms[q].forward(np.array([cur[q]], np.int32), pos[q])
+            assert _same_bits(rows[j], lg_o[0].view(np.uint16)), "query %d step %d" % (q, step)
+            assert int(nxt[j]) == int(tok_o)
+            cur[q], pos[q] = int(tok_o), pos[q] + 1
+    wk.close()
