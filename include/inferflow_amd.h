@@ -179,6 +179,18 @@ int ifa_attention(const void *q_f16, const void *kcache, const void *vcache, int
                   int n_ctx, int q_tokens, int prefix_len, int heads, int kv_heads, int head_dim,
                   float kq_scale, int alibi, int alibi_base_head, int alibi_total_heads,
                   void *out_f16, ifa_stream stream);
+/* ---- parity instruments: single-row ops in the SUMMATION ORDER of the reference's CUDA kernels (csrc/ifa_exact.hip) -- the 32-lane walk +
+ * xor butterfly of Gemv_AX8_* (src/kernels/gemv.h:1499-1709; F16 activations: the serial fp32 order of the oracle's restatement of :469-1497),
+ * Tensor_RmsNorm_Kernel's 128 chunks (unary_tensor_opr.h:216-289), serial fp32 attention dots + the 32-lane softmax (gemm.h:83-178,
+ * unary_tensor_opr.h:480-535), SiLU / ReLU (+ gate) with libm's expf.  Results equal the CPU oracle's bit for bit; not timed kernels.
+ * Same argument meaning as ifa_layernorm / ifa_gemv / ifa_attention (one query row, no ALiBi) / ifa_activation_mul (gate may be NULL). */
+int ifa_exact_rmsnorm(const void *x_f16, size_t rows, size_t cols, const void *w_f16, const void *b_f16, float multi_base, float eps,
+                      void *y_f16, ifa_stream stream);
+int ifa_exact_gemv(int w_dtype, const void *W, size_t rows, size_t cols, int x_dtype, const void *x, const void *bias_f16, void *y_f16,
+                   ifa_stream stream);
+int ifa_exact_attention(const void *q_f16, const void *kcache, const void *vcache, int kv_dtype, int n_ctx, int heads, int kv_heads,
+                        int head_dim, float kq_scale, void *out_f16, ifa_stream stream);
+int ifa_exact_activation_mul(int kind, const void *a_f16, const void *gate_f16, size_t n, void *y_f16, ifa_stream stream);
 /* chunks of at least min_tokens queries (default 64; 0 = never, < 0 only queries) take the two-pass kernels: K / V blocks staged
  * once per query tile, scores recomputed in the second pass instead of a [queries x keys] tile; head_dim 64 / 128; same rounding
  * points as the staged 32-query kernel.  Default variant: 64 queries per workgroup, the key blocks split over wave pairs;

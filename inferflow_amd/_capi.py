@@ -77,6 +77,10 @@ SIGNATURES = {
     "ifa_repack_weights": (_i, [_i, _vp, _sz, _sz, _vp, _vp]),
     "ifa_gemv_tiled": (_i, [_i, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "ifa_layernorm": (_i, [_i, _vp, _sz, _sz, _vp, _vp, _f, _f, _vp, _vp]),
+    "ifa_exact_rmsnorm": (_i, [_vp, _sz, _sz, _vp, _vp, _f, _f, _vp, _vp]),
+    "ifa_exact_gemv": (_i, [_i, _vp, _sz, _sz, _i, _vp, _vp, _vp, _vp]),
+    "ifa_exact_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "ifa_exact_activation_mul": (_i, [_i, _vp, _vp, _sz, _vp, _vp]),
     "ifa_rope": (_i, [_vp, _i, _i, _i, _i, _f, _i, _f, _vp]),
     "ifa_alibi": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "ifa_softmax": (_i, [_vp, _i, _i, _i, _i, _f, _vp]),

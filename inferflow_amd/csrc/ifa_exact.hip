@@ -395,3 +395,47 @@ int exact_act_mul(int kind, const half_t *a, const half_t *gate, size_t n, half_
 }
 
 } // namespace ifa
+
+// ---------------------------------------------------------------- the same kernels behind the C ABI, one op at a time: the second link of
+// the parity chain (tests/test_gpu_fullsize_oracle.py: the worker's order-exact step == the oracle bit for bit; here every timed op
+// against its order-exact form on the SAME inputs, at full size, on the device)
+extern "C" {
+
+int ifa_exact_rmsnorm(const void *x_f16, size_t rows, size_t cols, const void *w_f16, const void *b_f16, float multi_base, float eps,
+                      void *y_f16, ifa_stream stream)
+{
+    IFA_REQUIRE(x_f16 && y_f16 && rows > 0 && cols > 0 && rows < (1u << 30) && cols < (1u << 30), "ifa_exact_rmsnorm: bad arguments");
+    return ifa::exact_rmsnorm((const ifa::half_t *)x_f16, (int)rows, (int)cols, (const ifa::half_t *)w_f16, (const ifa::half_t *)b_f16, multi_base, eps,
+                              (ifa::half_t *)y_f16, ifa_s(stream));
+}
+
+int ifa_exact_gemv(int w_dtype, const void *W, size_t rows, size_t cols, int x_dtype, const void *x, const void *bias_f16, void *y_f16, ifa_stream stream)
+{
+    IFA_REQUIRE(W && x && y_f16 && rows > 0 && cols > 0 && rows < (1u << 30) && cols < (1u << 30), "ifa_exact_gemv: bad arguments");
+    if (x_dtype == ifa::Q8_B32T2)
+        return ifa::exact_gemv_ax8(w_dtype, W, rows, cols, x, (const ifa::half_t *)bias_f16, (ifa::half_t *)y_f16, ifa_s(stream));
+    IFA_REQUIRE(x_dtype == ifa::F16, "ifa_exact_gemv: x dtype %d (F16 or Q8_B32T2)", x_dtype);
+    return ifa::exact_gemv_f16x(w_dtype, W, rows, cols, (const ifa::half_t *)x, (const ifa::half_t *)bias_f16, (ifa::half_t *)y_f16, ifa_s(stream));
+}
+
+int ifa_exact_attention(const void *q_f16, const void *kcache, const void *vcache, int kv_dtype, int n_ctx, int heads, int kv_heads, int head_dim,
+                        float kq_scale, void *out_f16, ifa_stream stream)
+{
+    IFA_REQUIRE(q_f16 && kcache && vcache && out_f16 && n_ctx > 0 && heads > 0 && kv_heads > 0 && heads % kv_heads == 0 && head_dim > 0,
+                "ifa_exact_attention: bad arguments");
+    IFA_REQUIRE(kv_dtype == ifa::F16 || (kv_dtype == ifa::Q8_B32T2 && (kv_heads * head_dim) % 32 == 0), "ifa_exact_attention: cache dtype %d", kv_dtype);
+    const size_t kvd = (size_t)kv_heads * head_dim;
+    const size_t row_bytes = kv_dtype == ifa::Q8_B32T2 ? kvd / 32 * 34 : kvd * 2;
+    const float alpha = 1.0f / sqrtf((float)head_dim) / kq_scale;
+    return ifa::exact_attention((const ifa::half_t *)q_f16, kcache, vcache, kv_dtype, row_bytes, n_ctx, heads, kv_heads, head_dim, alpha, kq_scale,
+                                (ifa::half_t *)out_f16, ifa_s(stream));
+}
+
+int ifa_exact_activation_mul(int kind, const void *a_f16, const void *gate_f16, size_t n, void *y_f16, ifa_stream stream)
+{
+    IFA_REQUIRE(a_f16 && y_f16 && n > 0 && n < (1u << 31), "ifa_exact_activation_mul: bad arguments");
+    return ifa::exact_act_mul(kind, (const ifa::half_t *)a_f16, (const ifa::half_t *)gate_f16, n, (ifa::half_t *)y_f16, ifa_s(stream));
+}
+
+} // extern "C"
+

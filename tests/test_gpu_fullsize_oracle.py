@@ -31,6 +31,7 @@ import numpy as np
 import pytest
 import torch
 
+import inferflow_amd as ia
 import oracle as o
 from inferflow_amd import dtypes as dt, synth
 from tests import gpu_util as g
@@ -155,3 +156,85 @@ def test_llama2_7b_widths_order_exact_steps_are_bit_identical_to_the_oracle_thro
     print("order-exact parity %s / %s: %d steps x 32 layers, logits, ids, last hidden state and %d K / V rows per layer bit-identical"
           % (dt.name(wd), dt.name(kvd), n, n))
     wk.close()
+
+
+def test_timed_ops_against_their_order_exact_forms_at_llama2_7b_size():
+    """The second link of the parity chain.  Link one: the worker's order-exact step equals the oracle bit for bit
+    through 32 layers (the test above).  Link two, here: every op of the timed path against its order-exact form (csrc/ifa_exact.hip,
+    ifa_exact_*) on the SAME device inputs at Llama-2-7B size -- what one op's wave64 summation order costs, with nothing compounding:
+      * RMS norm over 4096 values: <= 1 half ulp, <= 3 % of the values differ at all;
+      * int8 GEMV, Q4_B32T1A and Q3H_B64T1, the four shapes of a layer (4096 x 4096, 11008 x 4096, 4096 x 11008) + the tiled layout the
+        fused kernels stream: <= 1 half ulp on every row whose sum does not cancel (|y| >= 0.1 std), <= 3 % of the rows differ at all;
+      * the F16 lm_head GEMV (32000 x 4096): <= 1 half ulp, <= 3 % of the rows;
+      * SiLU x gate over 11008 values: <= 1 half ulp (device expf against libm's);
+      * decode attention over 300 keys, F16 and Q8 cache rows, 32 heads: |d| <= 2 half ulps of the output's scale."""
+    L = g.capi()
+    rng = np.random.default_rng(606)
+    D, F, V = 4096, 11008, 32000
+
+    def dot_rows_close(y_fast, y_ex, tag):
+        # both sides round the SAME fp32 terms summed in two orders: one half ulp apart at most, rarely -- except where a row's sum
+        # cancels to a small fraction of the rows' scale (the half ulp of the result is then finer than the fp32 noise of its terms)
+        ulp = g.half_ulp_diff(y_fast, y_ex)
+        yf = y_ex.astype(np.float32)
+        small = np.abs(yf) < 0.1 * float(yf.std())
+        assert ulp[~small].max() <= 1, (tag, int(ulp[~small].max()))       # (the cancelled rows: the absolute bound below)
+        assert (ulp != 0).mean() <= 0.03, (tag, float((ulp != 0).mean()))
+        assert (np.abs(y_fast.astype(np.float32) - yf) <= 2.0 ** -10 * np.maximum(np.abs(yf), 0.1 * float(yf.std()))).all(), tag
+        return "%.2f%% of rows" % (100.0 * float((ulp != 0).mean()))
+
+    # RMS norm
+    x = rng.normal(0, 1.3, (1, D)).astype(np.float16)
+    w = rng.normal(1, 0.1, D).astype(np.float16)
+    xd, wdv = g.dev(x), g.dev(w)
+    y_fast, y_ex = g.empty_f16(1, D), g.empty_f16(1, D)
+    ia.check(L.ifa_layernorm(0, g.p(xd), 1, D, g.p(wdv), None, 0.0, 1e-5, g.p(y_fast), g.stream()))
+    ia.check(L.ifa_exact_rmsnorm(g.p(xd), 1, D, g.p(wdv), None, 0.0, 1e-5, g.p(y_ex), g.stream()))
+    ulp = g.half_ulp_diff(g.host(y_fast), g.host(y_ex))
+    assert ulp.max() <= 1 and (ulp != 0).mean() <= 0.03, ("rms norm", int(ulp.max()), float((ulp != 0).mean()))
+    report = ["rms norm %d of %d differ" % (int((ulp != 0).sum()), ulp.size)]
+    # int8 GEMV
+    for wd in (dt.Q4_B32T1A, dt.Q3H_B64T1):
+        for rows, cols in ((D, D), (F, D), (D, F)):
+            wsrc = torch.randn((rows, cols), dtype=torch.float16, device="cuda") * 0.02
+            Wq = g.quantize(wd, wsrc)
+            xr = torch.randn((1, cols), dtype=torch.float16, device="cuda")
+            xq = g.quantize_act(xr)
+            y_fast = g.host(g.gemv(wd, Wq, rows, cols, xq, dt.Q8_B32T2))
+            y_tiled = g.host(g.gemv_tiled(wd, g.repack(wd, Wq, rows, cols), rows, cols, xq))
+            y_ex = g.empty_f16(rows)
+            ia.check(L.ifa_exact_gemv(wd, g.p(Wq), rows, cols, dt.Q8_B32T2, g.p(xq), None, g.p(y_ex), g.stream()))
+            y_ex = g.host(y_ex)
+            assert np.array_equal(y_fast.view(np.uint16), y_tiled.view(np.uint16))
+            report.append("%s %dx%d %s" % (dt.name(wd), rows, cols, dot_rows_close(y_fast, y_ex, (dt.name(wd), rows, cols))))
+    # F16 lm_head
+    Wl = torch.randn((V, D), dtype=torch.float16, device="cuda") * 0.02
+    xr = torch.randn((1, D), dtype=torch.float16, device="cuda")
+    y_fast = g.host(g.gemv(dt.F16, Wl, V, D, xr, dt.F16))
+    y_ex = g.empty_f16(V)
+    ia.check(L.ifa_exact_gemv(dt.F16, g.p(Wl), V, D, dt.F16, g.p(xr), None, g.p(y_ex), g.stream()))
+    report.append("lm_head " + dot_rows_close(y_fast, g.host(y_ex), "lm_head"))
+    # SiLU x gate
+    a = torch.randn((1, F), dtype=torch.float16, device="cuda") * 2.0
+    b = torch.randn((1, F), dtype=torch.float16, device="cuda")
+    y_fast, y_ex = g.empty_f16(1, F), g.empty_f16(1, F)
+    ia.check(L.ifa_activation_mul(0, g.p(a), g.p(b), F, g.p(y_fast), g.stream()))
+    ia.check(L.ifa_exact_activation_mul(0, g.p(a), g.p(b), F, g.p(y_ex), g.stream()))
+    ulp = g.half_ulp_diff(g.host(y_fast), g.host(y_ex))
+    assert ulp.max() <= 1, ("silu x gate", int(ulp.max()))
+    report.append("silu x gate %d of %d differ" % (int((ulp != 0).sum()), ulp.size))
+    # decode attention, one query row over 300 keys
+    heads, hd, n_ctx = 32, 128, 300
+    q = rng.normal(0, 1.0, (1, heads, hd)).astype(np.float16)
+    k = rng.normal(0, 1.0, (n_ctx, heads * hd)).astype(np.float16)
+    v = rng.normal(0, 1.0, (n_ctx, heads * hd)).astype(np.float16)
+    for kvd in (dt.F16, dt.Q8_B32T2):
+        kc, vc = (g.dev(k), g.dev(v)) if kvd == dt.F16 else (g.quantize_act(g.dev(k)), g.quantize_act(g.dev(v)))
+        o_fast, o_ex = g.empty_f16(1, heads * hd), g.empty_f16(1, heads * hd)
+        ia.check(L.ifa_attention(g.p(g.dev(q)), g.p(kc), g.p(vc), kvd, n_ctx, 1, n_ctx - 1, heads, heads, hd, 1.0, 0, 0, heads, g.p(o_fast), g.stream()))
+        ia.check(L.ifa_exact_attention(g.p(g.dev(q)), g.p(kc), g.p(vc), kvd, n_ctx, heads, heads, hd, 1.0, g.p(o_ex), g.stream()))
+        d = np.abs(g.host(o_fast).astype(np.float32) - g.host(o_ex).astype(np.float32))
+        scale = float(np.abs(g.host(o_ex).astype(np.float32)).max())
+        assert d.max() <= 2.0 * 2.0 ** -10 * scale, (dt.name(kvd), float(d.max()), scale)
+        report.append("attention %s max |d| %.5f (scale %.3f)" % (dt.name(kvd), float(d.max()), scale))
+    print("timed ops against their order-exact forms: " + "; ".join(report))
