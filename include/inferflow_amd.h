@@ -277,7 +277,7 @@ int ifa_model_reset(ifa_model *m);
  * step and short prompts stream MFMA-operand-order copies of the weights, built on first use), "attn_split_ctx" (512), "fuse_attn" (1: the attention as the
  * tail of the wq | wk | wv launch), "fuse_ffn" (0; 1 / 2: [Wo ->] W1 | W3 -> W2 as one chained launch, csrc/ifa_decode_chain.h: bit-identical,
  * measured slower than the separate launches on MI355X, kept as the measurement harness of that statement), "prefill_mid" (1),
- * "prefill_mid_max" (768), "prefill_big_min" (47), "attn_post_as_residual" (1), "exact_order" (0; 1: every single-token step -- and every row
+ * "prefill_mid_max" (768), "prefill_res_mid" (2048: up to this many tokens wo / w2 keep the mid-size kernel above prefill_mid_max), "prefill_big_min" (47), "attn_post_as_residual" (1), "exact_order" (0; 1: every single-token step -- and every row
  * of a prompt, one by one -- runs in the summation order of the reference's CUDA kernels, csrc/ifa_exact.hip: a parity instrument whose
  * logits, ids and int8 codes equal the CPU oracle's bit for bit; fails for models outside that step instead of changing arithmetic),
  * "q3h_native" (0; 1: Q3H_B64T1 Wo / W1 / W3 / W2 streamed at 32 bytes per block, pair codes decoded in the kernel: bit-identical, measured slower) */

@@ -149,10 +149,10 @@ int layer_tail_ops(ifa_model *m, int l, int T, half_t *&x, const half_t *attn_in
 // 33 .. prefill_mid_max tokens through k_gemm_mid (csrc/ifa_gemm_mid.hip): the large-tile route's conditions + an operand-order copy of
 // every linear (built here on first use).  From 33 tokens on: 5.3 ms for 33..48 tokens against 5.9-6.6 for two passes of the rows
 // GEMM (tools/short_prompt_routes.py, profiles/r06_prefill_mid_parts.log)
-bool prefill_mid_ok(ifa_model *m, int T)
+bool prefill_mid_ok(ifa_model *m, int T, bool any_length)
 {
     const ifa_model_config &c = m->cfg;
-    if (!m->opt_prefill_mid || !m->opt_rows_mo || T <= 32 || T > m->opt_prefill_mid_max || c.experts != 0 || !prefill_big_ok(m)) return false;
+    if (!m->opt_prefill_mid || !m->opt_rows_mo || T <= 32 || (!any_length && T > m->opt_prefill_mid_max) || c.experts != 0 || !prefill_big_ok(m)) return false;
     if (ensure_mo(m) != IFA_OK) return false;
     for (int l = 0; l < c.layers; l++) {
         const int ids[] = {T_WQ, T_WK, T_WV, T_WO, T_W1, T_W3, T_W2};
@@ -195,7 +195,7 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
     // Prompts above `prefill_big_min` tokens (47; round 4: 128) take the same four launches per layer from the large-tile GEMM (ifa_gemm.hip, k_gemm_big: the
     // weights dequantised once per workgroup and step into LDS; reference-layout rows), norms as their own launches.
     // the mid-length kernel (33 .. prefill_mid_max tokens): every linear of every layer a 4-bit tensor with its operand-order copy, dense FFN
-    const bool pf_mid = !tp && prefill_mid_ok(m, T);
+    const bool pf_mid = !tp && prefill_mid_ok(m, T, false);
     const bool pf_big = pf_mid || (!tp && T > std::max(32, m->opt_prefill_big_min) && prefill_big_ok(m));
     bool pf_fused = pf_big || (!tp && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
     if (pf_fused && !pf_big) {
@@ -203,6 +203,10 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
         pf_fused = batch_fused_ok(m, T);          // (ensure_mo may have switched the copies off: ask again, see forward_batch)
     }
     if (pf_big && !pf_mid && (rc = ensure_x32(m))) return rc;
+    // above prefill_mid_max: wo and w2 (4096 output columns: 128 x 128 tiles whatever the kernel) still through k_gemm_mid -- at 1024 tokens
+    // 41 / 102 us per launch against 51 / 143 for the split-K halves of the large-tile kernel, which keeps wq | wk | wv and the gated pair
+    // (profiles/r06_prefill_mid_parts.log section 13: 1024 / 1536 / 2048 tokens 4.5 / 3 / 0.8 % faster, 4096 tokens 4.7 % slower: up to 2048)
+    const bool pf_res_mid = pf_big && !pf_mid && !tp && T <= m->opt_prefill_res_mid && prefill_mid_ok(m, T, true);
     for (int l = 0; l < c.layers && pf_fused; l++) {
         Layer &L = m->layers[l];
         const size_t F = c.ffn;
@@ -254,7 +258,9 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
         P.W[0] = wp(T_WO); P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(QD / 32);
         P.X = m->att; P.ldx = (int)QD; P.bias[0] = (const half_t *)L.t[T_WO_B].data;
         P.Y = m->a; P.ldy = (int)D; P.res = x; P.ldres = (int)D;
-        if ((rc = lin(P, T_WO, GM_RESIDUAL, 0))) return rc;
+        if (pf_res_mid) { P.W[0] = (const uint8_t *)L.t[T_WO].mo; P.mo = 1; P.no_waits = !m->opt_rows_kparts; }
+        if (pf_res_mid && gemm_mid_ok(L.t[T_WO].dtype, P, GM_RESIDUAL)) { if ((rc = gemm_mid(P, GM_RESIDUAL, m->stream))) return rc; }
+        else { if (pf_res_mid) { P.W[0] = wp(T_WO); P.mo = mo_flag; } if ((rc = lin(P, T_WO, GM_RESIDUAL, 0))) return rc; }
         clear();
         if (!norm_fused && (rc = norm_rows(m, m->a, T, L.t[T_FFN_NORM], pf_big ? L.t[T_FFN_NORM_B] : nob, m->hn, c.ffn_norm_base))) return rc;
         if (c.experts > 0 && L.t[T_MOE_GATE].present()) {      // (pf_big only) mixture of experts: the attention half fused, the expert FFNs device-routed
@@ -274,7 +280,9 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
         P.W[0] = wp(T_W2); P.rows[0] = (int)D; P.nsets = 1; P.nblk = (int)(F / 32);
         P.X = m->t1; P.ldx = (int)F; P.bias[0] = (const half_t *)L.t[T_W2_B].data;
         P.Y = m->f; P.ldy = (int)D; P.res = m->a; P.ldres = (int)D;
-        if ((rc = lin(P, T_W2, GM_RESIDUAL, 0))) return rc;
+        if (pf_res_mid) { P.W[0] = (const uint8_t *)L.t[T_W2].mo; P.mo = 1; P.no_waits = !m->opt_rows_kparts; }
+        if (pf_res_mid && gemm_mid_ok(L.t[T_W2].dtype, P, GM_RESIDUAL)) { if ((rc = gemm_mid(P, GM_RESIDUAL, m->stream))) return rc; }
+        else { if (pf_res_mid) { P.W[0] = wp(T_W2); P.mo = mo_flag; } if ((rc = lin(P, T_W2, GM_RESIDUAL, 0))) return rc; }
         std::swap(m->x, m->f);
         x = m->x;
     }
@@ -707,7 +715,7 @@ int ifa_model_forward(ifa_model *m, const int *tokens_host, int n_tokens, int pr
     // two passes of 17..32 rows each -- 49..64 tokens -- measured no faster than the tile kernels).  The second pass reads the first
     // one's K / V rows from the cache like any continued prompt; every row goes through the kernels of a prompt of <= 32 tokens.  Never
     // a one-token pass: a single row takes the int8 GEMV (the reference's rule for ONE row), which is not how a prompt's rows are computed.
-    if (m->opt_prefill_chunk && !m->topo && n_tokens >= 34 && n_tokens <= 48 && m->cfg.experts == 0 && !prefill_mid_ok(m, n_tokens) && batch_fused_ok(m, 32)
+    if (m->opt_prefill_chunk && !m->topo && n_tokens >= 34 && n_tokens <= 48 && m->cfg.experts == 0 && !prefill_mid_ok(m, n_tokens, false) && batch_fused_ok(m, 32)
         && prefix_len >= 0 && prefix_len + n_tokens <= m->cfg.max_ctx) {
         const int t1 = 32;
         const size_t V = m->g[T_LM_HEAD].rows;

@@ -175,6 +175,7 @@ struct ifa_model {
     // direct-to-LDS stages requested by loader waves, weights dequantised into the MFMA operand registers) when every linear has its
     // operand-order copy; 320..768 tokens 8-9 % faster than the large tiles, 1024 tokens a tie (profiles/r06_prefill_mid_parts.log)
     int opt_prefill_mid = 1, opt_prefill_mid_max = 768;
+    int opt_prefill_res_mid = 2048;   // prefill_mid_max + 1 .. this many tokens: wo / w2 still through k_gemm_mid, the other products through the large tiles (0: never)
     int opt_rows_kparts = 1, opt_gemm_splitk = 1;   // 0: never the launches whose workgroups wait for partner workgroups (K parts of the 9..32-row GEMM, split-K halves of the large-tile GEMM)
     int opt_debug_mo_alloc_fail = 0;           // tests: ensure_mo_build fails like an exhausted allocator after its first copy
     static constexpr int RING = 1024;
@@ -304,7 +305,7 @@ int layer_tail_ops(ifa_model *m, int l, int T, half_t *&x, const half_t *attn_in
 int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token, bool no_head = false);
 bool batch_fused_ok(const ifa_model *m, int n);
 bool prefill_big_ok(const ifa_model *m);
-bool prefill_mid_ok(ifa_model *m, int T);
+bool prefill_mid_ok(ifa_model *m, int T, bool any_length);
 int batch_fused_layer(ifa_model *m, int l, int n, const half_t *x, half_t *xnext, const void *rows_l);
 int forward_batch(ifa_model *m, int n, const int *tokens_host, const int *pos_host, const int *slot_host, int *next_tokens,
                          void *logits_out);

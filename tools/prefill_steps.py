@@ -9,6 +9,9 @@ wk, _, s = synth.build(shape, dt.Q4_B32T1A, dt.F16, max_ctx=max(2048, T + 16))
 if os.environ.get("IFA_NO_SPLITK"):      # A / B: the large-tile kernel without its split-K form
     from inferflow_amd import _capi
     _capi.lib().ifa_gemm_big_tiles(1 | (1 << 12))
+for opt in ("prefill_mid_max", "prefill_res_mid", "prefill_mid"):      # A / B of a route option: IFA_PREFILL_MID_MAX=4096 ...
+    if os.environ.get("IFA_" + opt.upper()):
+        wk.set_option(opt, int(os.environ["IFA_" + opt.upper()]))
 rng = np.random.default_rng(3)
 prompt = rng.integers(3, s["vocab"], T).astype(np.int32)
 for rep in range(reps):
