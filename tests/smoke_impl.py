@@ -1,5 +1,6 @@
 """__graft_entry__.smoke(): one small decode of the hot path on cuda:0 (prefill
-+ fused graph decode of a tiny Q4 model), checked against the CPU oracle."""
++ fused graph decode of a tiny Q4 model), checked against the CPU oracle -- the timed path within its tolerance, then the same
+steps in the reference kernels' summation order (option exact_order) bit for bit."""
 import numpy as np
 import torch
 
@@ -29,4 +30,14 @@ def run():
         top2 = np.sort(l_o[0].astype(np.float32))[-2:]
         assert int(toks[i]) == t_o or top2[1] - top2[0] <= 0.05, "decode step %d mismatch" % i
         cur = int(toks[i])
+    # the order-exact step: logits and ids of four single-token steps equal the oracle's, every bit
+    wk.set_option("exact_order", 1)
+    om.reset()
+    cur = int(prompt[0])
+    for i in range(4):
+        t_gpu, _ = wk.decode(cur, i, 1)
+        t_o, l_o = om.forward(np.array([cur], np.int32), i)
+        assert np.array_equal(wk.read_buffer("logits").view(np.uint16), l_o[0].view(np.uint16)), "order-exact step %d: logits differ from the oracle's" % i
+        assert int(t_gpu[0]) == int(t_o)
+        cur = int(t_o)
     wk.close()
