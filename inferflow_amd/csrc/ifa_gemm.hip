@@ -375,7 +375,9 @@ typedef const __attribute__((address_space(1))) void pf_glb_t;
 template <int DT, int BM, int BN, int WM, int WN, int EPI = GM_PLAIN, int BK = PF_BK, int KS = 1>
 __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const BigGeo G)
 {
-    static_assert(KS == 1 || KS == 2 || KS == 4, "split-K: one, two or four workgroups per tile");
+    static_assert(KS == 0 || KS == 1 || KS == 2 || KS == 4, "split-K: one, two or four workgroups per tile; 0: the stream-K schedule");
+    constexpr bool SK = KS == 0;                        // stream-K (see below the tile order)
+    constexpr int KSD = SK ? 1 : KS;
     // BK: columns per K step -- 64, or 128 for 128 x 128 tiles that run one workgroup per CU (half the barriers per product)
     constexpr int ROWB = BK * 2, CPR = BK / 8, RPP = 1024 / ROWB;     // LDS row bytes, 16-byte chunks per row, rows per direct-to-LDS piece
     auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : (r & 15); };
@@ -395,19 +397,58 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     constexpr int AI = BM / RPP / NW;                   // direct-to-LDS instructions per wave and step (1 KB = RPP rows each)
     static_assert(BPS >= 1 && BM % (2 * RPP * NW) == 0 && (BK == 64 || BK == 128), "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    // Stream-K schedule (KS = 0; round 6, 256 x 256 tiles of a product whose tile count is no multiple of the CU count: w1 | w3 of a
+    // 1024-token prompt are 344 tiles on 256 CUs, wq | wk | wv 192): ONE workgroup per CU; each first takes G.sk_full whole tiles,
+    // then an equal share of the K steps of the G.sk_rem tiles that are left -- steps [b(w), b(w + 1)) of the remainder's linear
+    // (tile, step) space, b(w) = w * sk_rem * S / grid -- which touches at most two tiles.  A share that does not END its tile leaves
+    // its fp32 sums in the tile's scratch slot j (j = how many shares precede it in the tile) and bumps the tile's counter; the share
+    // that ends the tile waits for the j others, adds them in ONE order (own + slot 0 + slot 1 + ...: deterministic) and runs the
+    // epilogue.  A workgroup with two shares takes the one that STARTS a tile first: no workgroup waits before its partial sums are
+    // out, so there is no chain of waits through the grid.
+    const int bid = (int)blockIdx.x;
+    int nseg = 1, sk_b0 = 0, sk_b1 = 0, sk_tA = 0, sk_S = 0, sk_RS = 0;
+    bool sk_two = false;
+    if constexpr (SK) {
+        sk_S = K / BK; sk_RS = G.sk_rem * sk_S;
+        sk_b0 = (int)((long long)bid * sk_RS / (int)gridDim.x); sk_b1 = (int)((long long)(bid + 1) * sk_RS / (int)gridDim.x);
+        sk_tA = sk_b0 / sk_S;
+        sk_two = sk_b1 > (sk_tA + 1) * sk_S;
+        nseg = G.sk_full + (sk_b1 > sk_b0 ? 1 : 0) + (sk_two ? 1 : 0);
+    }
+#pragma unroll 1
+    for (int seg = 0; seg < nseg; seg++) {
+    // (stream-K: every lane constant below is derived from a laundered thread id, so that the compiler does not hoist the constants of
+    //  the fix-up and the epilogue out of this loop and keep them alive through the K loop, where they would spill)
+    int tid_l = tid0;
+    if constexpr (SK) asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l, lane = tid & 63;
     // XCD-aware tile order (bijective for any grid size)
-    int wg;
-    {
-        const int nwg = (int)gridDim.x / KS, orig = (int)blockIdx.x % nwg, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    int wg, kbeg = 0, nsteps = K / BK / KSD, sk_kind = 0, sk_j = 0, sk_rt = 0;       // sk_kind: 0 whole tile, 1 share that leaves partial sums, 2 share that ends the tile
+    if constexpr (SK) {
+        if (seg < G.sk_full) {
+            const int nwg = G.sk_full * (int)gridDim.x, orig = seg * (int)gridDim.x + bid, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+            wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        } else {
+            if (sk_two && seg == G.sk_full) { sk_rt = sk_tA + 1; kbeg = 0; nsteps = sk_b1 - sk_rt * sk_S; sk_kind = 1; sk_j = 0; }
+            else {
+                sk_rt = sk_tA; kbeg = sk_b0 - sk_tA * sk_S;
+                const int kend = min(sk_b1, (sk_tA + 1) * sk_S) - sk_tA * sk_S;
+                nsteps = kend - kbeg; sk_kind = kend == sk_S ? 2 : 1;
+                while (bid - sk_j >= 1 && (int)((long long)(bid - sk_j) * sk_RS / (int)gridDim.x) > sk_tA * sk_S) sk_j++;
+            }
+            wg = G.sk_full * (int)gridDim.x + sk_rt;
+        }
+    } else {
+        const int nwg = (int)gridDim.x / KSD, orig = bid % nwg, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int kz = KS == 1 ? 0 : (int)blockIdx.x / ((int)gridDim.x / KS);       // which half of K (wave-uniform)
+    const int kz = KSD == 1 ? 0 : bid / ((int)gridDim.x / KSD);       // which half of K (wave-uniform)
     // tiles in bands of GM token tiles, weight tiles next, token tiles of the band fastest: the workgroups an XCD runs
     // at the same time form a compact block (GM token tiles x a few weight tiles) whose operand tiles its L2 shares
     constexpr int GM = 1024 / BM;
-    const int tiles_n = (int)gridDim.x / KS / tiles_m;
+    const int tiles_n = SK ? G.sk_tiles_n : (int)gridDim.x / KSD / tiles_m;
     const int band = wg / (GM * tiles_n), within = wg % (GM * tiles_n), band_m = min(GM, tiles_m - band * GM);
     const int t0 = (band * GM + within % band_m) * BM, tn = G.tn0 + within / band_m;
     // weight tile -> (matrix, first row); everything selected by VALUE from the argument block (no indexed struct access)
@@ -416,7 +457,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     const int N = set == 0 ? P.rows[0] : (set == 1 ? P.rows[1] : P.rows[2]);
     const uint8_t *__restrict__ W = set == 0 ? P.W[0] : (set == 1 ? P.W[1] : P.W[2]);
     const half_t *__restrict__ bias = set == 0 ? P.bias[0] : (set == 1 ? P.bias[1] : P.bias[2]);
-    const int nsteps = K / BK / KS, s0 = kz * nsteps;       // this workgroup's K steps: [s0, s0 + nsteps)
+    const int s0 = SK ? kbeg : kz * nsteps;                 // this workgroup's K steps: [s0, s0 + nsteps)
     // ---- activation tile: per-lane source pointers of this wave's 8-row pieces
     const half_t *xsrc[AI];
 #pragma unroll
@@ -598,6 +639,68 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
         __syncthreads();
         if (tid == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch on this stream
     }
+    int etid = tid;
+    if constexpr (SK) asm volatile("" : "+v"(etid));      // (and once more behind the K loop)
+    const int ei = etid & 31, eg = (etid & 63) >> 5;
+    bool do_epi = true;
+    if constexpr (SK) {
+        constexpr int NQ = TA * TB * 8;
+        unsigned long long *pt = G.part + (size_t)sk_rt * ((size_t)G.sk_slots * NQ * NT);
+        unsigned *flag = G.flags + sk_rt;
+        if (sk_kind == 1) {
+            unsigned long long *mine = pt + (size_t)sk_j * NQ * NT;
+#pragma unroll
+            for (int a = 0; a < TA; a++)
+#pragma unroll
+                for (int b = 0; b < TB; b++)
+#pragma unroll
+                    for (int rp = 0; rp < 8; rp++) {
+                        const float f0 = acc[a][b][2 * rp], f1 = acc[a][b][2 * rp + 1];
+                        const unsigned long long v = (unsigned long long)__builtin_bit_cast(uint32_t, f0) | ((unsigned long long)__builtin_bit_cast(uint32_t, f1) << 32);
+                        __hip_atomic_store(mine + (size_t)((a * TB + b) * 8 + rp) * NT + etid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the partial sums are in memory ...
+            __syncthreads();
+            if (etid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the counter says so
+            do_epi = false;
+        }
+        // (the sums of the other shares are added in a loop whose trip count is zero for every other kind of share: a conditional block
+        //  around the additions made the compiler keep two copies of the 128 accumulators alive -- 50 to 100 spilled registers)
+        const int nz = sk_kind == 2 ? sk_j : 0;
+        if (nz > 0) {
+            if (etid == 0) {
+                const long long t_wait = wall_clock64();
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)sk_j) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t_wait > WAIT_TIMEOUT_TICKS) {      // (a partner is not resident: leave a code and go on -- the host fails the call)
+                        if (G.err) __hip_atomic_store(G.err, 0x82u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int z = 0; z < nz; z++) {                                     // own + slot 0 + slot 1 + ...: one fixed order
+            const unsigned long long *pz = pt + (size_t)z * NQ * NT + etid;
+#pragma unroll
+            for (int a = 0; a < TA; a++)
+#pragma unroll
+                for (int b = 0; b < TB; b++)
+#pragma unroll
+                    for (int rp = 0; rp < 8; rp++) {
+                        const unsigned long long v = __hip_atomic_load(pz + (size_t)((a * TB + b) * 8 + rp) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc[a][b][2 * rp] += __builtin_bit_cast(float, (uint32_t)v);
+                        acc[a][b][2 * rp + 1] += __builtin_bit_cast(float, (uint32_t)(v >> 32));
+                    }
+        }
+        if (nz > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (etid == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch on this stream
+        }
+    }
+    if (do_epi) {
     // ---- epilogue
     half_t *__restrict__ Yo; int ldo, vrow0 = 0;
     if (P.Yset[0]) { Yo = set == 0 ? P.Yset[0] : (set == 1 ? P.Yset[1] : P.Yset[2]); ldo = set == 0 ? P.ldyset[0] : (set == 1 ? P.ldyset[1] : P.ldyset[2]); }
@@ -610,10 +713,10 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     constexpr int CROW = BN * 2 + 64;
     __syncthreads();                                    // every wave is done with the operand tiles
     {
-        const bool odd = i & 1;
+        const bool odd = ei & 1;
 #pragma unroll
         for (int b = 0; b < TB; b++) {
-            const int cl = wn * WCOLS + b * 32 + i;
+            const int cl = wn * WCOLS + b * 32 + ei;
             float bv = 0.0f; bool hb = false;
             if constexpr (GLU) {
                 const half_t *bp = cl < BNE ? bias : P.bias1;
@@ -631,7 +734,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
                     const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
                     const uint32_t packed = odd ? (recv | (u1 << 16)) : (u0 | (recv << 16));
                     const int rr = 2 * rp + (odd ? 1 : 0);
-                    const int tl = wm * (BM / WM) + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+                    const int tl = wm * (BM / WM) + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * eg;
                     *reinterpret_cast<uint32_t *>(smem + (size_t)tl * CROW + (size_t)(cl & ~1) * 2) = packed;
                 }
         }
@@ -639,7 +742,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
     __syncthreads();
     {
         constexpr int VEC = BNE / 8;                    // 16-byte pieces per output row of the tile
-        for (int idx = tid; idx < BM * VEC; idx += NT) {
+        for (int idx = etid; idx < BM * VEC; idx += NT) {
             const int tl = idx / VEC, v = idx % VEC, tok = t0 + tl, n = n0 + v * 8;
             if (tok >= T || n >= N) continue;
             half8_t y = *reinterpret_cast<const half8_t *>(smem + (size_t)tl * CROW + (size_t)v * 16);
@@ -658,6 +761,9 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_big(const GmArgs P, const
             *reinterpret_cast<half8_t *>(Yo + (size_t)tok * ldo + vrow0 + n) = y;
         }
     }
+    }      // do_epi
+    if (seg + 1 < nseg) __syncthreads();      // (the next share stages into the LDS the epilogue has just read)
+    }      // shares of this workgroup
 }
 
 } // namespace ifa
@@ -731,6 +837,23 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
         for (int i = 0; i < 3; i++) G.tile0[i + 1] = G.tile0[i] + (i < P.nsets ? (int)ifa_cdiv((size_t)P.rows[i], (size_t)BNE) : 0);
         for (int i = P.nsets; i < 3; i++) G.tile0[i] = 1 << 30;        // (absent sets are never selected)
         G.tiles_m = (int)ifa_cdiv(T, (size_t)BM); G.K = P.nblk * CAP; G.tn0 = tn0; G.part = nullptr; G.flags = nullptr; G.err = nullptr;
+        G.sk_full = G.sk_rem = G.sk_tiles_n = G.sk_slots = 0;
+        size_t grid = (size_t)G.tiles_m * tn_count * (KS ? KS : 1);
+        if constexpr (KS == 0) {
+            // stream-K: one workgroup per CU; whole tiles first, then equal shares of the K steps of the tiles that are left
+            const size_t tiles = (size_t)G.tiles_m * tn_count, S = (size_t)G.K / BK;
+            grid = std::min(cus, tiles * S);
+            G.sk_full = (int)(tiles / grid); G.sk_rem = (int)(tiles % grid); G.sk_tiles_n = tn_count;
+            const size_t lmin = (size_t)G.sk_rem * S / grid;
+            G.sk_slots = G.sk_rem && lmin ? (int)ifa_cdiv(S - 1, lmin) : 0;
+            if (G.sk_rem) {
+                G.err = wait_err_word();
+                void *scratch = nullptr;
+                int rcs = gemm_splitk_scratch(s, (size_t)G.sk_rem * G.sk_slots * BM * BN * 4, (size_t)G.sk_rem, &scratch);
+                if (rcs) return rcs;
+                G.flags = (unsigned *)scratch; G.part = (unsigned long long *)((char *)scratch + SPLITK_FLAG_BYTES);
+            }
+        }
         if constexpr (KS > 1) {
             G.err = wait_err_word();
             const size_t tiles = (size_t)G.tiles_m * tn_count, part_bytes = tiles * (size_t)(KS - 1) * BM * BN * 4;
@@ -751,10 +874,10 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             attr_set.fetch_or(bit, std::memory_order_relaxed);
         }
-        if constexpr (KS > 1) {      // the second halves wait for the first halves: the whole grid must be resident at once (1: not launched)
-            if (!wait_grid_fits((const void *)kern, WM * WN * 64, smem, (long long)G.tiles_m * tn_count * KS)) return 1;
+        if constexpr (KS != 1) {      // the second halves wait for the first halves: the whole grid must be resident at once (1: not launched)
+            if (!wait_grid_fits((const void *)kern, WM * WN * 64, smem, (long long)grid)) return 1;
         }
-        kern<<<dim3((unsigned)(G.tiles_m * tn_count * KS)), dim3(WM * WN * 64), smem, s>>>(P, G);
+        kern<<<dim3((unsigned)grid), dim3(WM * WN * 64), smem, s>>>(P, G);
         return IFA_OK;
     };
     using std::integral_constant;
@@ -768,7 +891,25 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
     const size_t full_n = per_round ? (tn256 / per_round) * per_round : 0, rem_n = tn256 - full_n;
     const bool split = full_n > 0 && rem_n > 0 && ifa_cdiv(T, (size_t)128) * rem_n <= cus && tm256 * rem_n < cus * 3 / 4;
     const size_t n128 = ifa_cdiv(T, (size_t)128) * ntiles(128);
-    const double c256 = CAP > 32 ? 1e30 : (split ? (double)(full_n / per_round) + 0.68 : rounds(256, 256, 1));   // (64-value blocks: the 256 x 256 variant would spill)
+    double c256 = CAP > 32 ? 1e30 : (split ? (double)(full_n / per_round) + 0.68 : rounds(256, 256, 1));   // (64-value blocks: the 256 x 256 variant would spill)
+    // Round 6, stream-K on the 256 x 256 tiles (k_gemm_big<.., KS = 0>; OPT-IN, bit 13 of ifa_gemm_big_tiles): every CU takes
+    // floor(tiles / CUs) whole tiles and then an equal share of the K steps of the rest.  Built, deterministic, within the F16 rounding of
+    // the whole-tile kernel -- and measured SLOWER on the two products it was built for (1024-token prompt, Llama-2-7B Q4, one box,
+    // rocprofv3 averages over 128 launches): w1 | w3 (344 tiles) 259.5 us against 144.3 + 84.2 for the round of whole tiles + the
+    // 128-token-tile launch of the rest, wq | wk | wv (192 tiles) 135.6 against 117.5; prefill 20.4 against 18.6 ms (2048 tokens: 37.7
+    // against 34.9).  The tail it removes is 35 / 29 us per layer; a share that does not end its tile sends 256 KB of fp32 sums through
+    // memory (write-through stores, 64 MB per launch) and the share that ends the tile reads up to three of them -- MI355X_MICROARCH.md
+    // prices that at ~12 us out + 4 us per slot in on an idle chip, here it costs 50-65.  Eligible when a share is >= 20 steps (<= 3
+    // scratch slots per shared tile at K = 4096).  profiles/r06_stream_k_ab.log.
+    bool sk = false;
+    {
+        const size_t tiles = tm256 * tn256, S = (size_t)P.nblk * CAP / PF_BK, rem = tiles % cus, share = rem * S / cus;
+        const bool may_sk = !force && CAP <= 32 && (g_gemm_big & (1 << 13)) != 0 && !P.no_waits && waits_enabled() && tiles * 4 >= cus * 3;
+        if (may_sk && rem && share >= 20 && ifa_cdiv(S - 1, share) <= 3) {
+            const double csk = (double)(tiles / cus) + (double)rem / (double)cus + 0.10;
+            if (csk < c256) { c256 = csk; sk = true; }
+        }
+    }
     const double c128x256 = rounds(128, 256, 1) * 0.68;
     const double c128 = n128 <= cus ? 0.41 : rounds(128, 128, 2) * 0.75;
     int pick = force;
@@ -779,7 +920,10 @@ static int launch_gemm_big(const GmArgs &P0, hipStream_t s)
     else if (pick == 5 && CAP <= 32) rc = run(I128(), I64(), I2(), I2(), 0, (int)ntiles(64), K64(), S1());
     else if (pick == 6 && CAP <= 32) rc = run(I64(), I128(), I2(), I2(), 0, (int)ntiles(128), K64(), S1());
     else if (pick == 1 && CAP <= 32) {
-        if (split && !force) {
+        rc = 1;
+        if (sk) rc = run(I256(), I256(), I2(), I4(), 0, (int)tn256, K64(), integral_constant<int, 0>());
+        if (rc != 1) { /* stream-K launched (or failed for another reason than residency) */ }
+        else if (split && !force) {
             rc = run(I256(), I256(), I2(), I4(), 0, (int)full_n, K64(), S1());
             if (!rc) rc = run(I128(), I256(), I2(), I4(), (int)full_n, (int)rem_n, K64(), S1());
         } else rc = run(I256(), I256(), I2(), I4(), 0, (int)tn256, K64(), S1());

@@ -147,6 +147,47 @@ def test_llama2_7b_width_prefill_gemm_regimes_agree(T, rows, cols):
     assert np.abs(y_small - ref).max() <= tol
 
 
+@pytest.mark.parametrize("T,rows,cols", [(1024, 12288, 4096), (1024, 22016, 4096), (1000, 12288, 4096), (2048, 11008, 4096)])
+def test_prefill_gemm_stream_k_is_deterministic_and_matches_the_whole_tile_kernel(T, rows, cols):
+    """256 x 256 tiles of a product whose tile count is no multiple of the CU count run the stream-K schedule (csrc/ifa_gemm.hip,
+    k_gemm_big<.., KS = 0>; opt-in, bit 13 of ifa_gemm_big_tiles -- measured slower than the default launches,
+    profiles/r06_stream_k_ab.log): one workgroup per CU takes floor(tiles / CUs) whole tiles, then an equal share of the K steps of the
+    tiles that are left; shares that do not end their tile leave fp32 sums in scratch, the share that ends it adds them in one fixed
+    order.  192 tiles (the wq | wk | wv shape of a 1024-token prompt: shares of 48 steps, two tiles touched), 344 tiles (the w1 | w3
+    shape: one whole tile + shares of 22 steps, up to four shares per tile), a ragged token count, two whole rounds + a rest.  Same
+    bits on every run, within the F16 rounding of the whole-tile kernel (another fp32 summation order), counters left zero (a product
+    of another shape next on the same stream), and against the fp32 product with the dequantised weights."""
+    import torch
+    from tests import gpu_util as g
+    L = g.capi()
+    torch.manual_seed(T + rows)
+    w = (torch.randn(rows, cols, device="cuda") * 0.02).half()
+    W = g.quantize(dt.Q4_B32T1A, w)
+    x = (torch.randn(T, cols, device="cuda") * 0.5).half()
+    bias = (torch.randn(rows, device="cuda") * 0.3).half()
+    prev = L.ifa_gemm_big_tiles(-1)
+    try:
+        L.ifa_gemm_big_tiles(1 | (1 << 13))                                       # stream-K on (opt-in: measured slower, see the launcher)
+        y1 = g.host(g.gemm(dt.Q4_B32T1A, W, rows, cols, x, bias))
+        y2 = g.host(g.gemm(dt.Q4_B32T1A, W, rows - 256, cols, x[:T - 5], bias))   # (another shape next: same scratch, counters must be clean)
+        y3 = g.host(g.gemm(dt.Q4_B32T1A, W, rows, cols, x, bias))
+        L.ifa_gemm_big_tiles(1)                                                   # the default: whole tiles
+        y0 = g.host(g.gemm(dt.Q4_B32T1A, W, rows, cols, x, bias))
+        y2_0 = g.host(g.gemm(dt.Q4_B32T1A, W, rows - 256, cols, x[:T - 5], bias))
+    finally:
+        L.ifa_gemm_big_tiles(prev)
+    assert np.array_equal(y1, y3)
+    for a16, b16 in ((y1, y0), (y2, y2_0)):
+        a, b = a16.astype(np.float32), b16.astype(np.float32)
+        close = np.abs(a - b) <= np.maximum(2 * np.spacing(np.abs(b).astype(np.float16)).astype(np.float32), 1e-3 * float(np.abs(b).mean()))
+        assert close.mean() >= 0.999, close.mean()
+        assert np.abs(a - b).max() <= 4e-3 * max(1.0, float(np.abs(b).max()))
+    assert not np.array_equal(y1, y0)                                             # (the schedule really ran: another summation order somewhere)
+    wdq = g.dequantize(dt.Q4_B32T1A, W, cols).float()
+    ref = g.host((x.float() @ wdq.t() + bias.float()).contiguous())
+    assert np.abs(y1.astype(np.float32) - ref).max() <= 4e-3 * max(1.0, float(np.abs(ref).max()))
+
+
 @pytest.mark.parametrize("T,rows,cols", [(1024, 4096, 11008), (512, 4096, 4096), (640, 4096, 4096)])
 def test_prefill_gemm_split_k_is_deterministic_and_matches_the_unsplit_kernel(T, rows, cols):
     """128 x 128 tiles of a product that offers no more tiles than CUs run as TWO workgroups per tile, each over half of K; the
