@@ -280,7 +280,8 @@ int ifa_model_reset(ifa_model *m);
  * "prefill_mid_max" (768), "prefill_res_mid" (2048: up to this many tokens wo / w2 keep the mid-size kernel above prefill_mid_max), "prefill_big_min" (47), "attn_post_as_residual" (1), "exact_order" (0; 1: every single-token step -- and every row
  * of a prompt, one by one -- runs in the summation order of the reference's CUDA kernels, csrc/ifa_exact.hip: a parity instrument whose
  * logits, ids and int8 codes equal the CPU oracle's bit for bit; fails for models outside that step instead of changing arithmetic),
- * "q3h_native" (0; 1: Q3H_B64T1 Wo / W1 / W3 / W2 streamed at 32 bytes per block, pair codes decoded in the kernel: bit-identical, measured slower) */
+ * "q3h_native" (0; 1: Q3H_B64T1 Wo / W1 / W3 / W2 streamed at 32 bytes per block, pair codes decoded in the kernel: bit-identical, measured slower),
+ * "perf_stat" (0; 1: steps and prompts take the op-by-op layer with a HIP event pair around every phase, see ifa_model_perf_stat) */
 /* Independent KV caches inside one worker, one per concurrent query -- the reference keeps a LayerKVCache set
  * per query processor (QueryStateTable, src/transformer/query_state_table.h:19-85; KVCache::Init, kv_cache.cc:278-319).
  * ifa_model_kv_slots grows the number of caches to n_slots (slot 0 exists after finalize); ifa_model_select_kv
@@ -292,6 +293,15 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value);
  * Invalid-type tokens GetSortedTopK skips (sampling_strategy.cc:281-297).  None by default at this level; the engine
  * facade sets the model's unk id. */
 int ifa_model_set_excluded_tokens(ifa_model *m, const int *ids_host, int n);
+/* Per-phase times in the key space of the reference's InferencePerfStat (GpuInferenceWorker::UpdatePerfStat, inference_worker.cc:2670-2697;
+ * keys: (layer + 1) * 10000 + phase -- + 0 the whole layer for layers 0..5 (:318-322); for layer 0, the reference's layer_idx_for_study_:
+ * + 10 attention pre-norm, + 30 q / k / v products, + 50 RoPE + cache rows, + 60 scores / softmax / V product, + 90 wo, + 300 the attention
+ * part as a whole, + 710 FFN pre-norm, + 730 w1, + 750 w3, + 760 activation * gate, + 780 w2, + 700 the FFN as a whole, + 800 what follows it;
+ * 1000009 the output stage (:673-675), 1 the embedding rows (inference_engine.cc:1168-1176)).  With option "perf_stat" = 1 every
+ * ifa_model_forward / ifa_model_decode step ADDS the device milliseconds of its spans to the keys (the reference adds host-side launch times);
+ * this call drains the stream, copies up to cap (key, ms) pairs in ascending key order, stores the number of keys there are in *n_out and
+ * clears the map if clear != 0. */
+int ifa_model_perf_stat(ifa_model *m, int *keys_out, float *ms_out, int cap, int *n_out, int clear);
 /* 1 if the fused batch-1 decode kernels cover this model, else 0 (+ reason) */
 int ifa_model_fused_supported(ifa_model *m, char *why, size_t why_len);
 /* One Infer() step for one query: n_tokens new tokens at positions

@@ -55,6 +55,12 @@ int ifa_engine_commit(ifa_engine *e, const int *query_ids, const int *tokens, co
 /* rows/cols of the logits kept from the last Infer() for this query; copies min(capacity, rows*cols) halfs */
 int ifa_engine_last_logits(ifa_engine *e, int query_id, uint16_t *dst_f16, size_t capacity, int *rows, int *cols);
 
+/* InferenceResult::perf_stat of the last Infer() (InferencePerfStat::time_map, src/transformer/inference_types.h): up to `capacity`
+ * (key, milliseconds) pairs in ascending key order; returns how many keys there are.  Key 0 = the step end to end
+ * (inference_engine.cc:986-988); with is_study_mode = true in the .ini also the per-phase keys (layer + 1) * 10000 + phase of
+ * GpuInferenceWorker::UpdatePerfStat (inference_worker.cc:2670-2697; measured on the op-by-op step, see ifa_model_perf_stat). */
+int ifa_engine_perf_stat(ifa_engine *e, unsigned *keys, float *ms, int capacity);
+
 /* extension: n greedy steps with device-side token feedback (graph replay); returns tokens written or -1 */
 int ifa_engine_generate(ifa_engine *e, int query_id, int n_steps, int *out_tokens, float *gpu_ms);
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "ifa_model_reset": (_i, [_vp]),
     "ifa_model_set_option": (_i, [_vp, C.c_char_p, _i]),
     "ifa_model_set_excluded_tokens": (_i, [_vp, _vp, _i]),
+    "ifa_model_perf_stat": (_i, [_vp, _vp, _vp, _i, _vp, _i]),
     "ifa_model_fused_supported": (_i, [_vp, C.c_char_p, _sz]),
     "ifa_model_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ifa_model_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -168,6 +169,7 @@ ENGINE_SIGNATURES = {
     "ifa_engine_infer": (_i, [_vp, _ip, _ip, _i]),
     "ifa_engine_commit": (_i, [_vp, _ip, _ip, _ip, _i]),
     "ifa_engine_last_logits": (_i, [_vp, _i, _vp, _sz, _ip, _ip]),
+    "ifa_engine_perf_stat": (_i, [_vp, _vp, _vp, _i]),
     "ifa_engine_generate": (_i, [_vp, _i, _i, _ip, C.POINTER(_f)]),
     "ifa_engine_perplexity": (_i, [_vp, _ip, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ifa_perplexity_token_nll": (C.c_double, [_vp, _i, _i]),

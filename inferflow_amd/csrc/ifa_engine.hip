@@ -4,6 +4,45 @@
 
 namespace ifae {
 
+int perf_begin(ifa_model *m, int key)
+{
+    if (!m->opt_perf_stat) return -1;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(m->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return -1; }
+    auto take = [&]() -> hipEvent_t {
+        if (!m->perf_pool.empty()) { hipEvent_t e = m->perf_pool.back(); m->perf_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return e;
+    };
+    ifa_model::PerfSpanRec r; r.key = key; r.e0 = take(); r.e1 = take();
+    if (!r.e0 || !r.e1) { if (r.e0) m->perf_pool.push_back(r.e0); if (r.e1) m->perf_pool.push_back(r.e1); return -1; }
+    if (hipEventRecord(r.e0, m->stream) != hipSuccess) { (void)hipGetLastError(); m->perf_pool.push_back(r.e0); m->perf_pool.push_back(r.e1); return -1; }
+    m->perf_spans.push_back(r);
+    return (int)m->perf_spans.size() - 1;
+}
+
+void perf_end(ifa_model *m, int idx)
+{
+    if (idx < 0 || idx >= (int)m->perf_spans.size()) return;
+    if (hipEventRecord(m->perf_spans[(size_t)idx].e1, m->stream) != hipSuccess) (void)hipGetLastError();
+}
+
+// the stream is drained, every span's milliseconds are ADDED to its key (UpdatePerfStat's rule: iter->second += value)
+int perf_collect(ifa_model *m)
+{
+    if (m->perf_spans.empty()) return IFA_OK;
+    IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    for (auto &r : m->perf_spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) m->perf_map[r.key] += ms;
+        else (void)hipGetLastError();
+        m->perf_pool.push_back(r.e0); m->perf_pool.push_back(r.e1);
+    }
+    m->perf_spans.clear();
+    return IFA_OK;
+}
+
 void drop_graphs(ifa_model *m)
 {
     if (m->tp_graph_exec) { (void)hipGraphExecDestroy(m->tp_graph_exec); m->tp_graph_exec = nullptr; }
@@ -290,6 +329,8 @@ int ifa_model_destroy(ifa_model *m)
     if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    for (auto &r : m->perf_spans) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (hipEvent_t e : m->perf_pool) (void)hipEventDestroy(e);
     delete m;
     return IFA_OK;
 }
@@ -500,7 +541,7 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
     struct { const char *n; int *p; } opts[] = {
         {"fused", &m->opt_fused}, {"graph", &m->opt_graph}, {"rpw_qkv", &m->opt_rpw_qkv}, {"rpw_wo", &m->opt_rpw_wo},
         {"rpw_ffn", &m->opt_rpw_ffn}, {"rpw_w2", &m->opt_rpw_w2}, {"rpw_lm", &m->opt_rpw_lm}, {"trace", &m->opt_trace},
-        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"prefill_res_mid", &m->opt_prefill_res_mid}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"attn_post_as_residual", &m->opt_attn_post_as_residual}, {"chain_late_w2", &m->opt_chain_late_w2}, {"exact_order", &m->opt_exact_order}, {"q3h_native", &m->opt_q3h_native}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, 
+        {"bench_mode", &m->opt_bench_mode}, {"touch_stride", &m->opt_touch_stride}, {"attn_split_ctx", &m->opt_attn_split_ctx}, {"batch_graph", &m->opt_batch_graph}, {"gemm_rows", &m->opt_gemm_rows}, {"batch_fused", &m->opt_batch_fused}, {"rows_mo", &m->opt_rows_mo}, {"debug_mo_alloc_fail", &m->opt_debug_mo_alloc_fail}, {"rows_kparts", &m->opt_rows_kparts}, {"prefill_chunk", &m->opt_prefill_chunk}, {"prefill_big_min", &m->opt_prefill_big_min}, {"prefill_mid", &m->opt_prefill_mid}, {"prefill_mid_max", &m->opt_prefill_mid_max}, {"prefill_res_mid", &m->opt_prefill_res_mid}, {"gemm_splitk", &m->opt_gemm_splitk}, {"moe_singles", &m->opt_moe_singles}, {"moe_overlap", &m->opt_moe_overlap}, {"prefill_big", &m->opt_prefill_big}, {"moe_router_fused", &m->opt_moe_router_fused}, {"tp_fuse_add", &m->opt_tp_fuse_add}, {"attn_q8", &m->opt_attn_q8}, {"attn_kt", &m->opt_attn_kt}, {"fuse_attn", &m->opt_fuse_attn}, {"fuse_ffn", &m->opt_fuse_ffn}, {"attn_post_as_residual", &m->opt_attn_post_as_residual}, {"chain_late_w2", &m->opt_chain_late_w2}, {"exact_order", &m->opt_exact_order}, {"perf_stat", &m->opt_perf_stat}, {"q3h_native", &m->opt_q3h_native}, {"fuse_attn_timeout_us", &m->opt_fuse_attn_timeout_us}, {"step_tail", &m->opt_step_tail}, {"graph_steps", &m->opt_graph_steps}, {"moe_device", &m->opt_moe_device}, 
         
         {"debug_layers", &m->opt_debug_layers}, {"debug_layer0", &m->opt_debug_layer0}, {"debug_hidden_in", &m->opt_debug_hidden_in}};
     for (auto &o : opts)
@@ -515,6 +556,23 @@ int ifa_model_set_option(ifa_model *m, const char *name, int value)
 // ids the greedy selection never offers (GetSortedTopK skips the vocabulary's unk id and Invalid-type tokens,
 // src/transformer/sampling_strategy.cc:281-297): kept in the device state next to token / position so that the
 // captured step needs no re-capture when they change
+// (layer + 1) * 10000 + phase -> milliseconds accumulated since the last clear (ascending keys); see opt_perf_stat
+int ifa_model_perf_stat(ifa_model *m, int *keys_out, float *ms_out, int cap, int *n_out, int clear)
+{
+    IFA_REQUIRE(m && n_out && cap >= 0 && (cap == 0 || (keys_out && ms_out)), "ifa_model_perf_stat: null pointer");
+    IFA_HIP_CHECK(hipSetDevice(m->cfg.device));
+    int rc = perf_collect(m);
+    if (rc) return rc;
+    int n = 0;
+    for (auto &kv : m->perf_map) {
+        if (n < cap) { keys_out[n] = kv.first; ms_out[n] = kv.second; }
+        n++;
+    }
+    *n_out = n;                      // (the number of keys there are: a caller with a small buffer asks again)
+    if (clear) m->perf_map.clear();
+    return IFA_OK;
+}
+
 int ifa_model_set_excluded_tokens(ifa_model *m, const int *ids_host, int n)
 {
     IFA_REQUIRE(m && m->finalized, "ifa_model_set_excluded_tokens: model not finalized");

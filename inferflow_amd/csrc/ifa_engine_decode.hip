@@ -734,8 +734,8 @@ int decode_impl(ifa_model *m, int first_token, int start_pos, int n_steps, int *
         if (elapsed_ms) *elapsed_ms = -1.0f;
         return IFA_OK;
     }
-    if (!m->opt_fused || !fused_supported(m, &why)) {
-        // op-by-op fallback: same semantics, host-driven
+    if (!m->opt_fused || m->opt_perf_stat || !fused_supported(m, &why)) {
+        // op-by-op fallback: same semantics, host-driven (also the path of option perf_stat: one launch per reference op to time)
         if (prepare_only) return IFA_OK;
         int tok = first_token;
         for (int i = 0; i < n_steps; i++) {

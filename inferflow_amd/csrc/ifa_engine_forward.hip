@@ -60,15 +60,23 @@ int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tenso
 }
 
 int ffn_dense(ifa_model *m, const half_t *x, int T, const Tensor &w1, const Tensor &b1, const Tensor &w3, const Tensor &b3,
-                     const Tensor &w2, const Tensor &b2, half_t *out)
+                     const Tensor &w2, const Tensor &b2, half_t *out, int perf_base)
 {
     int rc;
     ifa_stream s = (ifa_stream)m->stream;
-    if ((rc = matmul(m, x, T, w1, b1, m->t1))) return rc;
+    // perf_stat keys of ProcessGpuLayer_FeedForward (inference_worker.cc:1790-1880): + 730 w1, + 750 w3, + 740 activation, + 760 Mul (here ONE
+    // launch, under + 760), + 780 w2 (with its input quantiser, the reference's + 770)
+    const bool st = perf_base > 0;
+    { PerfSpan sp(m, perf_base + 730, st); if ((rc = matmul(m, x, T, w1, b1, m->t1))) return rc; }
     if (w3.present()) {
-        if ((rc = matmul(m, x, T, w3, b3, m->t2))) return rc;
+        { PerfSpan sp(m, perf_base + 750, st); if ((rc = matmul(m, x, T, w3, b3, m->t2))) return rc; }
+        PerfSpan sp(m, perf_base + 760, st);
         if ((rc = ifa_activation_mul(m->cfg.act_kind, m->t1, m->t2, (size_t)T * w1.rows, m->t1, s))) return rc;
-    } else if ((rc = ifa_activation(m->cfg.act_kind, 0, m->t1, (size_t)T, w1.rows, m->t1, s))) return rc;
+    } else {
+        PerfSpan sp(m, perf_base + 740, st);
+        if ((rc = ifa_activation(m->cfg.act_kind, 0, m->t1, (size_t)T, w1.rows, m->t1, s))) return rc;
+    }
+    PerfSpan sp(m, perf_base + 780, st);
     return matmul(m, m->t1, T, w2, b2, out);
 }
 
@@ -89,6 +97,12 @@ int layer_tail_ops(ifa_model *m, int l, int T, half_t *&x, const half_t *attn_in
     const bool merging = tp_merging(m), seq_wiring = !c.parallel_attn && !c.share_input;
     const bool a_post = L.t[T_ATTN_POST_NORM].present(), f_post = L.t[T_FFN_POST_NORM].present();
     int rc;
+    // perf_stat (layer 0 = the reference's layer_idx_for_study_): + 710 the FFN's pre-norm (with the residual Add where both are one launch),
+    // + 700 ProcessGpuLayer_FeedForward as a whole (norm .. w2), + 800 what follows it (Adds, post norm; inference_worker.cc:919-950)
+    const int perf_base = m->opt_perf_stat && l == 0 ? (l + 1) * 10000 : 0;
+    const bool st = perf_base > 0;
+    PerfSpan sp_ffn(m, perf_base + 700, st);
+    PerfSpan sp_norm(m, perf_base + 710, st);
     if (scale_on(c.attn_out_scale) && (rc = ifa_scale(m->a, c.attn_out_scale, (size_t)T * D, m->a, s))) return rc;
     const half_t *ff_in = c.parallel_attn ? attn_in : (c.share_input ? x : m->a);
     const half_t *ff_n = ff_in;
@@ -114,13 +128,16 @@ int layer_tail_ops(ifa_model *m, int l, int T, half_t *&x, const half_t *attn_in
             ff_n = m->hn;
         }
     }
+    sp_norm.done();
     if (c.experts > 0 && L.t[T_MOE_GATE].present()) {
         if ((rc = moe_ffn(m, L, ff_n, T))) return rc;
         if ((rc = tp_merge_rows(m, m->f, T, none))) return rc;          // every expert sliced like the dense FFN: one merge of the weighted sums
     } else {
-        if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], merging ? none : L.t[T_W2_B], m->f))) return rc;
+        if ((rc = ffn_dense(m, ff_n, T, L.t[T_W1], L.t[T_W1_B], L.t[T_W3], L.t[T_W3_B], L.t[T_W2], merging ? none : L.t[T_W2_B], m->f, perf_base))) return rc;
         if ((rc = tp_merge_rows(m, m->f, T, L.t[T_W2_B]))) return rc;
     }
+    sp_ffn.done();
+    PerfSpan sp_post(m, perf_base + 800, st);
     if (scale_on(c.ffn_out_scale) && (rc = ifa_scale(m->f, c.ffn_out_scale, (size_t)T * D, m->f, s))) return rc;
     // Add(ffn out, residual) + the norm in front of what comes next: the next layer's attention norm, or the output norm
     const bool last_layer = l + 1 == c.layers;
@@ -177,6 +194,7 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
     static const bool trace_host = getenv("IFA_TRACE_FORWARD") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
     if (first_stage) {
+        PerfSpan sp_embd(m, 1);          // (key 1: the embedding rows, InferenceEngine::Infer_Std, inference_engine.cc:1168-1176)
         IFA_HIP_CHECK(hipMemcpyAsync(m->tokens_dev, tokens_host, sizeof(int) * (size_t)T, hipMemcpyHostToDevice, m->stream));
         k_gather_rows<<<dim3(4, (unsigned)T), dim3(256), 0, m->stream>>>((const half_t *)m->g[T_EMBD].data, m->tokens_dev, T, (int)D,
                                                                           (int)m->g[T_EMBD].rows, m->x, c.embd_scale);
@@ -195,9 +213,10 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
     // Prompts above `prefill_big_min` tokens (47; round 4: 128) take the same four launches per layer from the large-tile GEMM (ifa_gemm.hip, k_gemm_big: the
     // weights dequantised once per workgroup and step into LDS; reference-layout rows), norms as their own launches.
     // the mid-length kernel (33 .. prefill_mid_max tokens): every linear of every layer a 4-bit tensor with its operand-order copy, dense FFN
-    const bool pf_mid = !tp && prefill_mid_ok(m, T, false);
-    const bool pf_big = pf_mid || (!tp && T > std::max(32, m->opt_prefill_big_min) && prefill_big_ok(m));
-    bool pf_fused = pf_big || (!tp && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
+    const bool pstat = m->opt_perf_stat != 0;       // per-phase times: the op-by-op layer below (one launch per reference op), never the fused routes
+    const bool pf_mid = !tp && !pstat && prefill_mid_ok(m, T, false);
+    const bool pf_big = pf_mid || (!tp && !pstat && T > std::max(32, m->opt_prefill_big_min) && prefill_big_ok(m));
+    bool pf_fused = pf_big || (!tp && !pstat && T >= 2 && T <= 32 && batch_fused_ok(m, T) && c.experts == 0);
     if (pf_fused && !pf_big) {
         if ((rc = ensure_mo(m))) return rc;
         pf_fused = batch_fused_ok(m, T);          // (ensure_mo may have switched the copies off: ask again, see forward_batch)
@@ -288,15 +307,27 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
     }
     for (int l = pf_fused ? c.layers : 0; l < c.layers; l++) {
         Layer &L = m->layers[l];
+        // perf_stat spans in the reference's key space (inference_worker.cc:296-322, 806-950, 1030-1400): the whole layer under + 0 for layers
+        // 0..5; for layer 0 (layer_idx_for_study_) + 300 = ProcessGpuLayer_Attention as a whole, + 10 its pre-norm, + 30 the q / k / v products
+        // (with their input quantisers: the reference's + 20), + 50 RoPE + cache rows, + 60 scores / softmax / V product, + 90 wo (+ bias, merge)
+        const int pbase = (l + 1) * 10000;
+        const bool st = pstat && l == 0;
+        PerfSpan sp_layer(m, pbase + 0, pstat && l <= 5);
+        PerfSpan sp_attn(m, pbase + 300, st);
         const half_t *attn_in = x;
         if (L.t[T_ATTN_NORM].present()) {
+            PerfSpan sp(m, pbase + 10, st);
             if (!xn_ready && (rc = norm_rows(m, x, T, L.t[T_ATTN_NORM], L.t[T_ATTN_NORM_B], m->xn, c.attn_norm_base))) return rc;
             attn_in = m->xn;
         }
         xn_ready = false;
-        if ((rc = matmul(m, attn_in, T, L.t[T_WQ], L.t[T_WQ_B], m->q))) return rc;
-        if ((rc = matmul(m, attn_in, T, L.t[T_WK], L.t[T_WK_B], m->k))) return rc;
-        if ((rc = matmul(m, attn_in, T, L.t[T_WV], L.t[T_WV_B], m->v))) return rc;
+        {
+            PerfSpan sp(m, pbase + 30, st);
+            if ((rc = matmul(m, attn_in, T, L.t[T_WQ], L.t[T_WQ_B], m->q))) return rc;
+            if ((rc = matmul(m, attn_in, T, L.t[T_WK], L.t[T_WK_B], m->k))) return rc;
+            if ((rc = matmul(m, attn_in, T, L.t[T_WV], L.t[T_WV_B], m->v))) return rc;
+        }
+        PerfSpan sp_rope(m, pbase + 50, st);
         uint8_t *kdst = (uint8_t *)L.kcache + (size_t)prefix_len * m->kv_row_bytes;
         uint8_t *vdst = (uint8_t *)L.vcache + (size_t)prefix_len * m->kv_row_bytes;
         const bool kv_f16 = c.kv_dtype != Q8_B32T2;
@@ -318,11 +349,19 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
             IFA_HIP_CHECK(hipMemcpyAsync(kdst, m->k, (size_t)T * m->kv_row_bytes, hipMemcpyDeviceToDevice, m->stream));
             IFA_HIP_CHECK(hipMemcpyAsync(vdst, m->v, (size_t)T * m->kv_row_bytes, hipMemcpyDeviceToDevice, m->stream));
         }
-        if ((rc = ifa_attention(m->q, L.kcache, L.vcache, c.kv_dtype, prefix_len + T, T, prefix_len, c.heads, c.kv_heads,
-                                c.head_dim, c.use_alibi ? 1.0f : c.kq_scale, c.use_alibi, c.tp_rank * c.heads,
-                                c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
-        if ((rc = matmul(m, m->att, T, L.t[T_WO], merging ? none : L.t[T_WO_B], m->a))) return rc;
-        if ((rc = tp_merge_rows(m, m->a, T, L.t[T_WO_B]))) return rc;       // BY_TENSOR: sum of the ranks' partial products, bias after
+        sp_rope.done();
+        {
+            PerfSpan sp(m, pbase + 60, st);
+            if ((rc = ifa_attention(m->q, L.kcache, L.vcache, c.kv_dtype, prefix_len + T, T, prefix_len, c.heads, c.kv_heads,
+                                    c.head_dim, c.use_alibi ? 1.0f : c.kq_scale, c.use_alibi, c.tp_rank * c.heads,
+                                    c.heads * std::max(1, c.tp_size), m->att, s))) return rc;
+        }
+        {
+            PerfSpan sp(m, pbase + 90, st);
+            if ((rc = matmul(m, m->att, T, L.t[T_WO], merging ? none : L.t[T_WO_B], m->a))) return rc;
+            if ((rc = tp_merge_rows(m, m->a, T, L.t[T_WO_B]))) return rc;       // BY_TENSOR: sum of the ranks' partial products, bias after
+        }
+        sp_attn.done();
         if ((rc = layer_tail_ops(m, l, T, x, attn_in, xn_ready))) return rc;
     }
     if (!last_stage) {       // BY_LAYER / HYBRID: hand the [T][dim] output to the next device group, then learn the token
@@ -335,6 +374,7 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
         return IFA_OK;
     }
     if (no_head && !logits_out) return IFA_OK;
+    PerfSpan sp_out(m, 1000009);         // (ProcessPostLayer: output norm + lm_head, inference_worker.cc:326-336, 673-675)
     if (scale_on(c.out_scale) && (rc = ifa_scale(x, c.out_scale, (size_t)T * D, x, s))) return rc;
     const half_t *hfin = x;
     if (m->g[T_OUT_NORM].present()) {
@@ -355,6 +395,7 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
         if ((rc = launch_lmhead(H2, 0, m->opt_rpw_lm, m->stream))) return rc;
     }
     else { if ((rc = matmul(m, hfin + (size_t)t0 * D, 1, lm, none, m->logits + (size_t)t0 * V))) return rc; }
+    sp_out.done();
     if (logits_out) IFA_HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)T * V * 2, hipMemcpyDeviceToDevice, m->stream));
     if (tp) {                // distributed argmax of the last row over the group's shards (+ announcement to the other groups)
         if ((rc = tp_pick_rows(m, *tp, m->logits + (size_t)(T - 1) * V, V, (int)V, 1))) return rc;
@@ -366,6 +407,7 @@ int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, voi
     }
     const auto host_t1 = std::chrono::steady_clock::now();
     IFA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (pstat && (rc = perf_collect(m))) return rc;
     if ((rc = wait_err_check("forward step"))) { drop_graphs(m); return rc; }      // (a split-K / K-parts wait gave up: the step is not valid; those launches are off now)
     if (trace_host)      // how much of a step is the host enqueuing (launch-bound) vs the GPU draining what was enqueued
         fprintf(stderr, "forward T=%d: enqueue %.3f ms, total %.3f ms\n", T, std::chrono::duration<double, std::milli>(host_t1 - host_t0).count(),

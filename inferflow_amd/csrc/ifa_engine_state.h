@@ -125,6 +125,17 @@ struct ifa_model {
     // option fuse_ffn = 1: W1 | W3 -> W2; 2: Wo -> W1 | W3 -> W2.  ch_on = what the captured step uses.  Granules [layers][dim + ffn].
     int opt_fuse_ffn = 0, ch_on = 0, opt_chain_late_w2 = 0;
     int opt_q3h_native = 0;          // Q3H_B64T1 linears of the dense FFN and Wo streamed at 32 instead of 36 bytes per block (A / B: profiles/r06_q3h_native_ab.log)
+    // Per-phase times in the reference's key space (InferencePerfStat, GpuInferenceWorker::UpdatePerfStat, inference_worker.cc:2670-2697:
+    // (layer + 1) * 10000 + phase, the whole layer under + 0 for layers 0..5, the phases of layer 0 -- layer_idx_for_study_ -- under
+    // + 10 / 30 / 50 / 60 / 90 / 300 / 700 / 710 / 730 / 750 / 760 / 780 / 800, the output stage under 1000009, the embedding rows under 1).
+    // Option perf_stat = 1: steps and prompts take the op-by-op layer (one launch per reference op) with a HIP event pair around every
+    // phase; ifa_model_perf_stat reads the accumulated milliseconds.  The reference times the host side of the launches (TaskMonitor);
+    // these are device times of the same spans.
+    int opt_perf_stat = 0;
+    struct PerfSpanRec { int key; hipEvent_t e0, e1; };
+    std::vector<PerfSpanRec> perf_spans;
+    std::vector<hipEvent_t> perf_pool;
+    std::map<int, float> perf_map;
     int opt_exact_order = 0;         // single-token steps in the reference kernels' summation order (ifa_engine_exact.hip): bit-identical to the oracle
     float *exact_rope_tab = nullptr; // device: [max_ctx][head_dim / 2] (cos, sin) from the host libm, built on the first exact step
     uint32_t *ch_gran = nullptr, *ch_flags = nullptr;      // flags [layers][2][CH_FLAGS]
@@ -259,6 +270,16 @@ namespace ifae {
 
 // ---- ifa_engine.hip
 void drop_graphs(ifa_model *m);
+// perf_stat spans (ifa_engine.hip): no-ops unless the option is on.  PerfSpan brackets a phase on the model's stream.
+int perf_begin(ifa_model *m, int key);
+void perf_end(ifa_model *m, int idx);
+int perf_collect(ifa_model *m);
+struct PerfSpan {
+    ifa_model *m; int idx;
+    PerfSpan(ifa_model *mm, int key, bool on = true) : m(mm), idx(on ? perf_begin(mm, key) : -1) {}
+    ~PerfSpan() { done(); }
+    void done() { if (idx >= 0) { perf_end(m, idx); idx = -1; } }
+};
 void free_tensor(Tensor &t);
 void *kv_ptr(ifa_model *m, size_t layer, int slot, bool is_v);
 int ensure_mo(ifa_model *m);
@@ -300,7 +321,7 @@ int gather_rows(ifa_model *m, const half_t *src, const int *idx_dev, int T, int 
 int matmul(ifa_model *m, const half_t *A, int T, const Tensor &W, const Tensor &bias, half_t *C);
 int norm_rows(ifa_model *m, const half_t *x, int T, const Tensor &w, const Tensor &b, half_t *y, float base = 0.0f);
 int ffn_dense(ifa_model *m, const half_t *x, int T, const Tensor &w1, const Tensor &b1, const Tensor &w3, const Tensor &b3,
-                     const Tensor &w2, const Tensor &b2, half_t *out);
+                     const Tensor &w2, const Tensor &b2, half_t *out, int perf_base = 0);
 int layer_tail_ops(ifa_model *m, int l, int T, half_t *&x, const half_t *attn_in, bool &xn_ready);
 int forward_ops(ifa_model *m, const int *tokens_host, int T, int prefix_len, void *logits_out, int *next_token, bool no_head = false);
 bool batch_fused_ok(const ifa_model *m, int n);

@@ -80,6 +80,14 @@ class InferenceEngine:
             ids[i], toks[i], ends[i] = q, int(tok), int(bool(end))
         return bool(_capi.lib().ifa_engine_commit(self._h, ids, toks, ends, n))
 
+    def perf_stat(self):
+        """{key: ms} of the last infer(): key 0 end to end; in study mode the reference's per-phase keys (include/inferflow_engine.h)"""
+        keys = (C.c_uint * 256)(); ms = (C.c_float * 256)()
+        n = _capi.lib().ifa_engine_perf_stat(self._h, keys, ms, 256)
+        if n < 0:
+            raise EngineError(self._err())
+        return {int(keys[i]): float(ms[i]) for i in range(min(n, 256))}
+
     def last_logits(self, query_id):
         rows, cols = C.c_int(0), C.c_int(0)
         if not _capi.lib().ifa_engine_last_logits(self._h, query_id, None, 0, C.byref(rows), C.byref(cols)):

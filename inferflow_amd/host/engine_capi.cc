@@ -16,6 +16,7 @@ using namespace inferflow_amd;
 struct ifa_engine {
     InferenceEngine engine;
     std::map<int, QueryInferenceResult> last;     // per query: result of the most recent step
+    InferencePerfStat last_perf;                  // perf_stat of the most recent Infer()
 };
 
 extern "C" {
@@ -123,11 +124,23 @@ int ifa_engine_infer(ifa_engine *e, int *query_ids, int *next_tokens, int capaci
     if (!e) { EngineSetError("ifa_engine_infer: null engine"); return -1; }
     InferenceResult res;
     if (!e->engine.Infer(res)) return -1;
+    e->last_perf = res.perf_stat;
     int n = 0;
     for (QueryInferenceResult &item : res.items) {
         if (n < capacity && query_ids && next_tokens) { query_ids[n] = item.query_id; next_tokens[n] = item.next_tokens.empty() ? -1 : item.next_tokens[0].id; }
         n++;
         e->last[item.query_id] = std::move(item);
+    }
+    return n;
+}
+
+int ifa_engine_perf_stat(ifa_engine *e, unsigned *keys, float *ms, int capacity)
+{
+    if (!e) { EngineSetError("ifa_engine_perf_stat: null engine"); return -1; }
+    int n = 0;
+    for (const auto &kv : e->last_perf.time_map) {
+        if (n < capacity && keys && ms) { keys[n] = kv.first; ms[n] = kv.second; }
+        n++;
     }
     return n;
 }

@@ -276,6 +276,11 @@ bool InferenceEngine::Init(const InferenceConfig &cfg)
         for (ifa_model *mm : all)
             if (ifa_model_set_excluded_tokens(mm, excl.data(), (int)excl.size()) != IFA_OK) { EngineSetError("excluded tokens: %s", ifa_last_error()); Clear(); return false; }
     }
+    // Per-phase keys of InferencePerfStat ((layer + 1) * 10000 + phase, inference_worker.cc:2670-2697) are filled in study mode only: the
+    // reference times the host side of its launches for free, here the phases exist as separate launches only on the op-by-op step
+    // (worker option perf_stat).  Key 0 (end to end) is filled whenever enable_perf_stat is on, like inference_engine.cc:986-988.
+    perf_phases_ = !multi_ && config_.debug.is_study_mode && config_.debug.enable_perf_stat;
+    if (perf_phases_ && ifa_model_set_option(model_, "perf_stat", 1) != IFA_OK) { EngineSetError("perf_stat: %s", ifa_last_error()); Clear(); return false; }
     // one KV cache per concurrent query, like the reference's per-query LayerKVCache sets
     kv_slots_ = std::max(1, std::min(config_.max_concurrent_queries, 64));
     {
@@ -624,7 +629,13 @@ bool InferenceEngine::Infer(InferenceResult &res)
         if (item.next_tokens.empty()) { IdWeight w; w.id = next; w.weight = 1.0f; item.next_tokens.push_back(w); }
         res.items.push_back(std::move(item));
     }
-    res.perf_stat.time_map[0] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (perf_phases_) {
+        int keys[256]; float ms[256]; int n = 0;
+        if (ifa_model_perf_stat(model_, keys, ms, 256, &n, 1) != IFA_OK) { EngineSetError("perf_stat: %s", ifa_last_error()); return false; }
+        for (int i = 0; i < std::min(n, 256); i++) res.perf_stat.time_map[keys[i]] = ms[i];
+    }
+    if (config_.debug.enable_perf_stat)
+        res.perf_stat.time_map[0] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
 }
 

@@ -13,6 +13,7 @@
 // the hot path.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <map>
 #include <string>
 #include <vector>
@@ -115,7 +116,7 @@ struct QueryInferenceResult {
 
 struct QueryNextToken { int id = 0; bool is_end = false; };
 
-struct InferencePerfStat { std::map<uint32_t, float> time_map; };   // key 0: GPU step wall ms
+struct InferencePerfStat { std::map<uint32_t, float> time_map; };   // key 0: the step end to end (ms); study mode: the reference's per-phase keys, (layer + 1) * 10000 + phase
 
 struct InferenceResult {
     std::vector<QueryInferenceResult> items;
@@ -175,6 +176,15 @@ public:
     SamplingStrategyId GetSamplingStrategyId(const std::string &str = "") const override;
     const ModelSpec &model_spec() const { return spec_; }
     std::string Version() const override { return "inferflow_amd 0.1 (MI355X)"; }
+    const InferenceConfig &config() const { return config_; }
+    // "0 (E2E)\t<ms>" then "<key>\t<ms>" per line, ascending keys (InferenceEngine::PrintPerfStat, inference_engine.cc:2108-2120)
+    static void PrintPerfStat(FILE *strm, const InferencePerfStat &perf_stat)
+    {
+        for (const auto &kv : perf_stat.time_map) {
+            if (kv.first == 0) fprintf(strm, "0 (E2E)\t%g\n", kv.second);
+            else fprintf(strm, "%u\t%g\n", kv.first, kv.second);
+        }
+    }
     int default_device_id() const { return device_; }
     int PartitionRanks() const;     // workers of the multi-GPU partition (1: single device)
     ifa_model *worker() { return model_; }
@@ -213,6 +223,7 @@ private:
     int kv_slots_ = 1;
     SamplingStrategyId default_strategy_ = SamplingStrategyId::Greedy;
     StdSamplingConfig default_sampling_;
+    bool perf_phases_ = false;      // study mode: the per-phase keys of InferencePerfStat from the worker (ifa_model_perf_stat)
     bool host_greedy_ = false;      // more excluded token ids than the device argmax holds: greedy selection on the host
     std::map<int, Query> queries_;
     void *logits_dev_ = nullptr;

@@ -76,6 +76,10 @@ int main(int argc, char **argv)
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             (step == 0 ? prefill_ms : decode_ms) += ms;
             out.push_back(nt.id);
+            if (engine.config().debug.is_study_mode && engine.config().debug.enable_perf_stat && (step == 0 || step + 1 == max_new)) {
+                printf("perf_stat (step %d):\n", step);          // (the reference's tool writes the same lines to perf_stat.txt, llm_inference.cc:58-73)
+                InferenceEngine::PrintPerfStat(stdout, res.perf_stat);
+            }
         }
     }
     printf("prompt:");

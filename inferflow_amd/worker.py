@@ -55,6 +55,12 @@ class DecodeWorker:
     def set_option(self, name, value):
         check(lib().ifa_model_set_option(self._h, name.encode(), int(value)))
 
+    def perf_stat(self, clear=True):
+        """{key: ms} of option perf_stat in the reference's InferencePerfStat key space (include/inferflow_amd.h: ifa_model_perf_stat)"""
+        keys, ms, n = np.zeros(256, np.int32), np.zeros(256, np.float32), C.c_int(0)
+        check(lib().ifa_model_perf_stat(self._h, keys.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p), 256, C.byref(n), 1 if clear else 0))
+        return {int(k): float(v) for k, v in zip(keys[:min(n.value, 256)], ms[:min(n.value, 256)])}
+
     def set_excluded_tokens(self, ids):
         """ids (<= 3) the greedy argmax never selects (unk / Invalid-type tokens, sampling_strategy.cc:281-297)"""
         a = np.ascontiguousarray(ids, np.int32)
