@@ -8,7 +8,8 @@ namespace ifa {
 // P: the argument block of the rows GEMM (GmArgs) with W[] / W1 pointing at REFERENCE-layout rows (Tensor::data);
 // norm prologue fields are ignored.  epi: GM_PLAIN | GM_RESIDUAL | GM_GLU (the fused epilogues: Q4_B32T1A / B only).
 struct BigGeo { int tile0[4]; int tiles_m; int K; int tn0; unsigned long long *part; unsigned *flags; unsigned *err;
-                int sk_full, sk_rem, sk_tiles_n, sk_slots; };      // stream-K schedule (k_gemm_big<.., KS = 0>): whole tiles per workgroup, tiles shared by K steps, weight tiles of the launch, scratch slots per shared tile
+                int sk_full, sk_rem, sk_tiles_n, sk_slots;
+                int dbg_skip; };      // stream-K schedule (k_gemm_big<.., KS = 0>): whole tiles per workgroup, tiles shared by K steps, weight tiles of the launch, scratch slots per shared tile; dbg_skip (tests, bit 14 of ifa_gemm_big_tiles): the first parts of a split-K launch leave without publishing -- the last part's bounded wait must time out, leave its code and the host must fail the call and switch the waiting launches off
 // per-(device, stream) scratch of the split-K launches: one counter per tile (zero between launches, 16 KB) in front of the partial sums
 constexpr size_t SPLITK_FLAG_BYTES_H = 16384;
 int gemm_splitk_scratch(hipStream_t s, size_t part_bytes, size_t tiles, void **out);

@@ -238,3 +238,24 @@ def test_timed_ops_against_their_order_exact_forms_at_llama2_7b_size():
         assert d.max() <= 2.0 * 2.0 ** -10 * scale, (dt.name(kvd), float(d.max()), scale)
         report.append("attention %s max |d| %.5f (scale %.3f)" % (dt.name(kvd), float(d.max()), scale))
     print("timed ops against their order-exact forms: " + "; ".join(report))
+
+
+@pytest.mark.parametrize("wd", [dt.Q4_B32T1A, dt.Q3H_B64T1], ids=["q4", "q3h"])
+def test_llama2_7b_layer_blocks_on_the_device_equal_the_host_quantiser(wd):
+    """The depth tests above multiply the blocks READ BACK from the worker (quantising 6.5 G weights on the host per case is half a
+    minute): a device quantiser or repack fault would then sit on both sides.  This closes that link at full width: the
+    seven matrices of two layers of the same synthetic model are generated again on the host side of the test (same seeds,
+    inferflow_amd/synth.py), quantised by the ORACLE's quantiser (oracle.quantize: pinned to the reference header's bytes,
+    tests/test_oracle_golden.py) and compared bit for bit with what ifa_model_get_tensor returns in the reference layout."""
+    from inferflow_amd import worker as W
+    wk, _, s = synth.build("llama2_7b", wd, dt.F16, max_ctx=32, layers=2)
+    for layer in range(2):
+        for tid, kind in synth.MATRICES:
+            rows, cols = synth._shape(kind, s)
+            t16 = synth.gen_f16((rows, cols), 1000 + layer * 16 + tid, 0.02, "cuda:0")
+            host16 = t16.cpu().view(torch.int16).numpy().view(np.float16)
+            d, data, r, c = wk.get_tensor_host(layer, tid)
+            assert (d, r, c) == (wd, rows, cols)
+            want = o.quantize(wd, host16)
+            assert np.array_equal(data.reshape(rows, -1), want), "layer %d tensor %d: device blocks differ from the host quantiser" % (layer, tid)
+    wk.close()
