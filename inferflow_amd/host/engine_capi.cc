@@ -281,7 +281,9 @@ struct LoopbackEngine : QueryEngine {
     int QueryCount() const override { return (int)qs.size(); }
     bool Infer(InferenceResult &res) override {
         res.items.clear();
-        if (++infer_calls == fail_at) return false;
+        ++infer_calls;
+        if (infer_calls == fail_at) return false;                                        // fail_at = N > 0: call N fails once (a retry succeeds)
+        if (fail_at < 0 && (infer_calls == -fail_at || infer_calls == -fail_at + 1)) return false;      // fail_at = -N: calls N and N + 1 fail (the retry too)
         for (auto &kv : qs) {
             Q &q = kv.second;
             if (q.ended) continue;

@@ -102,7 +102,12 @@ bool InferFlowServiceCore::InferOnce()
     std::unique_lock<std::mutex> eg(engine_lock_);
     if (engine_.QueryCount() == 0) { eg.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); return true; }
     InferenceResult result;
-    const bool ok = engine_.Infer(result);
+    bool ok = engine_.Infer(result);
+    // One retry of a step that failed as a whole: the worker's bounded in-launch waits report a timeout as a FAILED call
+    // "repeat it: the waiting launches are off now" (IFA_ERR_STATE, include/inferflow_amd.h) -- recoverable by design, and a failed
+    // Infer() commits nothing (Query::processed moves only behind a successful step), so the same step is simply run again; a second
+    // failure ends the queries as before.
+    if (!ok && result.items.empty()) { retries_++; ok = engine_.Infer(result); }
     if (!result.items.empty()) steps_++;
     std::map<int, QueryNextToken> commit;
     {
@@ -147,7 +152,9 @@ bool InferFlowServiceCore::ProcessQuery(InferFlowResponseChunk &result, const In
     // the output length is bounded by the context whatever the request says (0 or negative: "as much as fits"): a query the
     // engine ends by itself produces no token, so an unbounded request would otherwise only end on EOS
     const int max_ctx = engine_.MaxContextLen();
-    const int room = max_ctx - (int)request.prompt_token_ids.size() - 1;
+    // (a prompt of P tokens yields at most max_ctx - P tokens: the step that produces token k + 1 needs P + k < max_ctx, the same
+    //  bound as InferenceEngine::AddQuery / Infer -- a prompt of max_ctx - 1 tokens is accepted and yields one token)
+    const int room = max_ctx - (int)request.prompt_token_ids.size();
     if (room < 1) { result.ret_code = "error.too_long_request"; return false; }
     const int max_len = request.max_output_len > 0 ? std::min(request.max_output_len, room) : room;
     QueryOptions qo;

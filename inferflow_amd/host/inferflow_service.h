@@ -73,7 +73,7 @@ private:
     mutable std::mutex engine_lock_;     // the facade's query table is not thread-safe: AddQuery / Infer + Commit / RemoveQuery take turns
     mutable std::mutex lock_;            // query_to_result_ (taken inside engine_lock_, never the other way round)
     std::map<int, QueryResult> query_to_result_;
-    std::atomic<long long> steps_{0}, tokens_out_{0}, queries_{0};
+    std::atomic<long long> steps_{0}, tokens_out_{0}, queries_{0}, retries_{0};      // retries_: steps run a second time after a failed Infer()
 };
 
 // Minimal HTTP/1.1 front (one thread per connection, at most MAX_CONNECTIONS of them, Connection: close; streaming responses use

@@ -76,7 +76,7 @@ def test_request_longer_than_the_context_is_clamped_and_returns():
     rs = _loop(16, [1, 2, 3, 4, 5], 100, n_requests=5)
     for r in rs:
         assert r["ok"] and not r["hung"] and r["ret_code"] == "succ" and r["is_end"] and r["finish_reason"] == "length", r
-        assert r["token_ids"] == list(range(6, 6 + 10)) and r["active"] == 0, r       # room = 16 - 5 - 1
+        assert r["token_ids"] == list(range(6, 6 + 11)) and r["active"] == 0, r       # room = 16 - 5: the engine's own bound (AddQuery / Infer)
     assert rs[0]["openai"]["choices"][0]["finish_reason"] == "length"
 
 
@@ -84,7 +84,7 @@ def test_unbounded_request_without_eos_ends_at_the_context_limit():
     # max_output_len <= 0 and no EOS: used to spin forever; after max_concurrent_queries of them every client got error.busy
     rs = _loop(12, [7, 8, 9], 0, n_requests=4, max_queries=2)
     for r in rs:
-        assert r["ok"] and not r["hung"] and r["ret_code"] == "succ" and len(r["token_ids"]) == 8 and r["active"] == 0, r
+        assert r["ok"] and not r["hung"] and r["ret_code"] == "succ" and len(r["token_ids"]) == 9 and r["active"] == 0, r
 
 
 def test_eos_ends_with_finish_reason_stop():
@@ -94,15 +94,25 @@ def test_eos_ends_with_finish_reason_stop():
 
 
 def test_prompt_that_leaves_no_room_is_refused():
-    r = _loop(8, [1, 2, 3, 4, 5, 6, 7], 4)[0]
+    r = _loop(8, [1, 2, 3, 4, 5, 6, 7, 8], 4)[0]
     assert not r["ok"] and not r["hung"] and r["ret_code"] == "error.too_long_request" and r["active"] == 0
+    # a prompt of max_ctx - 1 tokens is what AddQuery still accepts: one token comes back (the shell used to refuse it)
+    r = _loop(8, [1, 2, 3, 4, 5, 6, 7], 4)[0]
+    assert r["ok"] and not r["hung"] and r["ret_code"] == "succ" and r["token_ids"] == [8] and r["finish_reason"] == "length" and r["active"] == 0, r
 
 
 def test_failed_engine_step_ends_the_query_with_an_error_and_frees_its_slot():
-    # the 3rd Infer call fails (e.g. a fused launch's bounded wait gave up): the handler returns an error instead of spinning,
-    # the next requests are served
-    rs = _loop(64, [1, 2], 20, n_requests=3, max_queries=1, fail_at=3)
+    # the 3rd Infer call AND its retry fail: the handler returns an error instead of spinning, the next requests are served
+    rs = _loop(64, [1, 2], 20, n_requests=3, max_queries=1, fail_at=-3)
     assert not rs[0]["ok"] and not rs[0]["hung"] and rs[0]["ret_code"] == "error.inference_failed" and rs[0]["active"] == 0, rs[0]
     assert "error" in rs[0]["openai"]
     for r in rs[1:]:
         assert r["ok"] and r["ret_code"] == "succ" and len(r["token_ids"]) == 20, r
+
+
+def test_a_step_that_fails_once_is_run_again():
+    # a recoverable failure (the worker's bounded in-launch wait gave up: "repeat it: the waiting launches are off now"): the loop runs
+    # the same step once more and no in-flight request is lost
+    rs = _loop(64, [1, 2], 20, n_requests=3, max_queries=1, fail_at=3)
+    for r in rs:
+        assert r["ok"] and not r["hung"] and r["ret_code"] == "succ" and r["token_ids"] == list(range(3, 23)) and r["active"] == 0, r
