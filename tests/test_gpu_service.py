@@ -68,7 +68,7 @@ def test_service_shell_serves_token_id_queries(tmp_path):
         for _ in range(5):
             st, data = _post(port, "/", {"prompt_token_ids": prompt, "max_output_len": 500})
             r = json.loads(data)
-            assert st == 200 and r["ret_code"] == "succ" and r["is_end"] is True and len(r["token_ids"]) == 128 - len(prompt) - 1, r
+            assert st == 200 and r["ret_code"] == "succ" and r["is_end"] is True and len(r["token_ids"]) == 128 - len(prompt), r      # the engine's own bound: a step needs prompt + produced < max_ctx
             assert r["token_ids"][:12] == want
         # EOS: the third token of the greedy continuation as eos_token_id ends the query there, finish_reason "stop"
         eos = want[2]
