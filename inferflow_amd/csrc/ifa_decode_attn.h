@@ -612,6 +612,36 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     const int kv_dim = P.kv_heads * HD;
     const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
     const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
+    // Round 6 (second session): the key rows of the first pass are requested BEFORE the new token's values are staged, rotated and
+    // stored (they depend on the split only; the new token's own row is never read from the cache), and the rows of the next pass before
+    // the current one is multiplied: the kernel was a chain of ~6 dependent round trips for one or two passes of 256 keys.  Q8 rows come
+    // as 4- / 8-byte requests of the head's slice (68 two-byte loads per key before).  Same products in the same order.
+    constexpr int KCH = HD / 8;                                   // 16-byte chunks per F16 row
+    constexpr int KBYTES = (HD / 32) * 34;                        // Q8: bytes of a head's slice of a row
+    constexpr int KALIGN = HD == 128 ? 8 : (HD == 64 ? 4 : 2);    // ... and its alignment (see dec_attn_body)
+    constexpr bool QW = Q8 && KALIGN >= 4;                        // wide requests for the Q8 slice
+    u32x4 kin[Q8 ? 1 : KCH], knx[Q8 ? 1 : KCH];
+    uint32_t kq[QW ? KBYTES / 4 : 1], kqn[QW ? KBYTES / 4 : 1];
+    auto load_pass = [&](u32x4 (&dst)[Q8 ? 1 : KCH], uint32_t (&dq)[QW ? KBYTES / 4 : 1], int jb) {
+        if constexpr (!Q8) {
+#pragma unroll
+            for (int i2 = 0; i2 < KCH; i2++) {                    // piece idx = tid + 256 i2: row idx / KCH, chunk idx % KCH
+                const int idx = tid + 256 * i2;
+                const int jr = min(jb + idx / KCH, j1 - 1);
+                dst[i2] = reinterpret_cast<const u32x4 *>(P.kcache + (size_t)jr * row_bytes + head_off)[idx % KCH];
+            }
+        } else if constexpr (QW) {
+            const uint8_t *rowp = P.kcache + (size_t)min(jb + tid, j1 - 1) * row_bytes + head_off;
+            if constexpr (KALIGN == 8) {
+#pragma unroll
+                for (int i = 0; i < KBYTES / 8; i++) { const u32x2 t = reinterpret_cast<const u32x2 *>(rowp)[i]; dq[2 * i] = t[0]; dq[2 * i + 1] = t[1]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < KBYTES / 4; i++) dq[i] = reinterpret_cast<const uint32_t *>(rowp)[i];
+            }
+        }
+    };
+    if (j0 < j1) load_pass(kin, kq, j0);
     for (int d = tid; d < HD; d += 256) {
         qs[d] = P.q[(size_t)h * HD + d];
         kn[d] = P.k_new[(size_t)kvh * HD + d];
@@ -661,20 +691,14 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     // F16 cache: a lane's key row (HD halfs) is requested COALESCED -- a wave request covers 64 / (HD/8) whole rows -- and
     // turned through LDS so that every lane then holds its own key's row: one key per lane with its own 16-byte requests
     // touched 64 rows per request (14 us per layer at 4096 keys).  The dot product below is unchanged (fp32 fma in d order).
-    constexpr int KCH = HD / 8;                                   // 16-byte chunks per row
     constexpr int KROWB = HD * 2 + 16;                            // bytes per staged row (+16: conflict-free row reads)
     extern __shared__ __attribute__((aligned(16))) char kst[];    // [256][KROWB] (F16 cache only: dec_attn_scores_smem)
     for (int jb = j0; jb < j1; jb += 256) {
         const int j = jb + tid;
+        const bool more = jb + 256 < j1;
+        if (more) load_pass(knx, kqn, jb + 256);
         u32x4 krow[Q8 ? 1 : KCH];
         if constexpr (!Q8) {
-            u32x4 kin[KCH];
-#pragma unroll
-            for (int i2 = 0; i2 < KCH; i2++) {                    // piece idx = tid + 256 i2: row idx / KCH, chunk idx % KCH
-                const int idx = tid + 256 * i2;
-                const int jr = min(jb + idx / KCH, j1 - 1);
-                kin[i2] = reinterpret_cast<const u32x4 *>(P.kcache + (size_t)jr * row_bytes + head_off)[idx % KCH];
-            }
             __syncthreads();                                      // the previous pass's rows have been read
 #pragma unroll
             for (int i2 = 0; i2 < KCH; i2++) {
@@ -685,6 +709,20 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
 #pragma unroll
             for (int i2 = 0; i2 < KCH; i2++) krow[i2] = *reinterpret_cast<const u32x4 *>(kst + (size_t)tid * KROWB + (size_t)i2 * 16);
         }
+        uint32_t kqc[QW ? KBYTES / 4 : 1];
+        if constexpr (QW) {
+#pragma unroll
+            for (int i = 0; i < KBYTES / 4; i++) kqc[i] = kq[i];
+        }
+        if (more) {
+            if constexpr (!Q8) {
+#pragma unroll
+                for (int i2 = 0; i2 < KCH; i2++) kin[i2] = knx[i2];
+            } else if constexpr (QW) {
+#pragma unroll
+                for (int i = 0; i < KBYTES / 4; i++) kq[i] = kqn[i];
+            }
+        }
         if (j >= j1) continue;
         float c = 0.0f;
         if (j == pos) {
@@ -692,7 +730,21 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
             for (int d = 0; d < HD; d++) c = __builtin_fmaf(h2f(qs[d]), h2f(kn[d]), c);
         } else {
             const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
-            if constexpr (Q8) {
+            if constexpr (QW) {
+                // byte B (compile-time) of the slice held in registers; block b = bytes [34 b, 34 b + 34): scale (half), 32 codes
+                auto kb = [&](int B) -> uint32_t { return (kqc[B >> 2] >> (8 * (B & 3))) & 0xFFu; };
+#pragma unroll
+                for (int b = 0; b < HD / 32; b++) {
+                    const float sc = hbits2f((uint16_t)(kb(34 * b) | (kb(34 * b + 1) << 8)));
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t two = kb(34 * b + 2 + 2 * i) | (kb(34 * b + 3 + 2 * i) << 8);
+                        const float k0 = h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), k1 = h2f(f2h((float)(int)(int8_t)(two >> 8) * sc));
+                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i]), k0, c);
+                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i + 1]), k1, c);
+                    }
+                }
+            } else if constexpr (Q8) {
 #pragma unroll
                 for (int b = 0; b < HD / 32; b++) {
                     const uint16_t *p16 = reinterpret_cast<const uint16_t *>(rowp + b * 34);
@@ -725,6 +777,13 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     if (tid == 0) ws.lmax[h * ws.nsplits + sidx] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// Round 6 (second session): the same sums in the same order, fewer memory round trips.  The kernel was a chain of dependent requests --
+// the full-row sum walked S with one 2-byte load per thread and iteration (17 trips at 4096 keys), the P.V loop kept four V rows per
+// thread in flight (five trips per 320-key split), the Q8 loop one key -- 21 us per layer at 4096 keys for 33 MB of V (1.6 TB/s).  Now the
+// score row is staged through LDS in 16-byte pieces, 4096 keys at a time (thread t still adds keys t, t + 256, ... in ascending order),
+// and the V rows of the next eight keys of a thread are requested before the current eight are multiplied.
+constexpr int DEC_PV_STAGE = 4096;      // keys of the score row staged per pass (multiple of 256)
+
 template <int HD, bool Q8>
 __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, const DecAttnSplitWs ws)
 {
@@ -732,7 +791,8 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
     constexpr int DG = HD / 8, NSPLIT = 256 / DG;
     float *red = reinterpret_cast<float *>(smem);                    // [8]
     float *opart = red + 8;                                          // [NSPLIT][HD]
-    half_t *Pl = reinterpret_cast<half_t *>(opart + NSPLIT * HD);    // this split's probabilities
+    half_t *Sst = reinterpret_cast<half_t *>(opart + NSPLIT * HD);   // [DEC_PV_STAGE + 8] staged piece of the score row
+    half_t *Pl = Sst + DEC_PV_STAGE + 8;                             // this split's probabilities
     const int h = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pos = *(const __attribute__((address_space(4))) int *)(P.state + 1), n_ctx = pos + 1;      // (scalar load: see k_dec_attn)
     int j0, j1; dec_split_range(n_ctx, ws.nsplits, sidx, j0, j1);
@@ -741,11 +801,55 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
     const size_t row_bytes = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
     const size_t head_off = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
     const half_t *Sg = ws.S + (size_t)h * P.max_ctx;
+    const int dg = tid % DG, sp = tid / DG;
+    const bool vact = (256 % DG == 0) || sp < NSPLIT;
+    // ---- the first V rows of this thread's key sequence go out before anything else (they depend on the split only)
+    constexpr int VB = 8;                                             // keys per batch and thread
+    const int step = NSPLIT;
+    u32x4 vcur[Q8 ? 1 : VB], vnxt[Q8 ? 1 : VB];
+    uint32_t qs_c[Q8 ? VB : 1], qc_c[Q8 ? VB : 1][2], qs_n[Q8 ? VB : 1], qc_n[Q8 ? VB : 1][2];      // Q8: block scale (half bits) + this thread's 8 codes
+    const size_t vq_off = head_off + (size_t)(dg / 4) * 34;
+    auto load_v = [&](u32x4 (&dst)[Q8 ? 1 : VB], uint32_t (&ds)[Q8 ? VB : 1], uint32_t (&dc)[Q8 ? VB : 1][2], int j) {
+#pragma unroll
+        for (int u = 0; u < VB; u++) {
+            const int jr = min(j + u * step, max(j1 - 1, 0));
+            if constexpr (!Q8) dst[u] = reinterpret_cast<const u32x4 *>(P.vcache + (size_t)jr * row_bytes + head_off)[dg];
+            else {
+                // the thread's 8 codes as ONE 8-byte request at a 2-byte-aligned address (see dec_attn_body)
+                const uint16_t *blk = reinterpret_cast<const uint16_t *>(P.vcache + (size_t)jr * row_bytes + vq_off);
+                typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
+                ds[u] = blk[0];
+                const u32x2_a2 cw = *reinterpret_cast<const u32x2_a2 *>(blk + 1 + (dg % 4) * 4);
+                dc[u][0] = cw[0]; dc[u][1] = cw[1];
+            }
+        }
+    };
+    const int jv0 = vact ? j0 + sp : j1;
+    if (jv0 < j1) load_v(vcur, qs_c, qc_c, jv0);
     float mx = -INFINITY;
     for (int s2 = 0; s2 < ws.nsplits; s2++) mx = fmaxf(mx, ws.lmax[h * ws.nsplits + s2]);
-    // the full-row sum, in the same order as the one-workgroup kernel (strided by 256, wave tree, 4 waves)
+    // the full-row sum, in the same order as the one-workgroup kernel (strided by 256, wave tree, 4 waves); the row comes through LDS
     float lsum = 0.0f;
-    for (int j = tid; j < n_ctx; j += 256) lsum += expf(P.kq_scale * h2f(Sg[j]) - mx);
+    for (int c0 = 0; c0 < n_ctx; c0 += DEC_PV_STAGE) {
+        const int cn = min(DEC_PV_STAGE, n_ctx - c0);
+        const size_t g0 = (size_t)h * P.max_ctx + c0;                // first half of this piece in the workspace
+        const int off = (int)(g0 & 7);                                // ... and its distance from a 16-byte boundary
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(ws.S + (g0 - off));
+        u32x4 piece[DEC_PV_STAGE / 8 / 256 + 1];
+#pragma unroll
+        for (int i2 = 0; i2 < DEC_PV_STAGE / 8 / 256 + 1; i2++) {
+            const int pc = tid + 256 * i2;
+            if (pc * 8 < cn + off) piece[i2] = src[pc];
+        }
+        __syncthreads();                                              // (the previous piece has been read)
+#pragma unroll
+        for (int i2 = 0; i2 < DEC_PV_STAGE / 8 / 256 + 1; i2++) {
+            const int pc = tid + 256 * i2;
+            if (pc * 8 < cn + off) *reinterpret_cast<u32x4 *>(Sst + (size_t)pc * 8) = piece[i2];
+        }
+        __syncthreads();
+        for (int j = c0 + tid; j < c0 + cn; j += 256) lsum += expf(P.kq_scale * h2f(Sst[j - c0 + off]) - mx);
+    }
     lsum = wave_sum(lsum);
     if (lane == 0) red[wave] = lsum;
     __syncthreads();
@@ -755,38 +859,37 @@ __global__ void __launch_bounds__(256) k_dec_attn_pv(const DecAttnParams P, cons
         Pl[j - j0] = f2h(h2f(eh) * inv);
     }
     __syncthreads();
-    const int dg = tid % DG, sp = tid / DG;
-    const bool vact = (256 % DG == 0) || sp < NSPLIT;
     float o[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) o[i] = 0.0f;
-    for (int j = vact ? j0 + sp : j1; j < j1; j += (Q8 ? 1 : 4) * NSPLIT) {
-        const float pj = h2f(Pl[j - j0]);
-        if constexpr (Q8) {
-            const uint8_t *blk = P.vcache + (size_t)j * row_bytes + head_off + (size_t)(dg / 4) * 34;
-            const uint16_t *p16 = reinterpret_cast<const uint16_t *>(blk);
-            const float sc = hbits2f(p16[0]);
+    // batches of VB keys of this thread's sequence (j, j + NSPLIT, ...): the next batch is requested before the current one is
+    // multiplied; rows past the split are clamped and skipped -- the order of accumulation is that of a plain loop
+    for (int j = jv0; j < j1; j += VB * step) {
+        const bool more = j + VB * step < j1;
+        if (more) load_v(vnxt, qs_n, qc_n, j + VB * step);
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t two = p16[1 + (dg % 4) * 4 + e];
-                o[2 * e] = __builtin_fmaf(pj, h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), o[2 * e]);
-                o[2 * e + 1] = __builtin_fmaf(pj, h2f(f2h((float)(int)(int8_t)(two >> 8) * sc)), o[2 * e + 1]);
-            }
-        } else {
-            // four rows of this thread's key sequence are requested before the first is multiplied (one request in flight
-            // per thread left the split kernels at 1.6 TB/s); rows past the split are clamped and skipped -- same order of
-            // accumulation as a plain loop
-            u32x4 vr[4];
+        for (int u = 0; u < VB; u++) {
+            if (j + u * step >= j1) break;
+            const float pu = h2f(Pl[j + u * step - j0]);
+            if constexpr (Q8) {
+                const float sc = hbits2f((uint16_t)qs_c[u]);
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                vr[u] = reinterpret_cast<const u32x4 *>(P.vcache + (size_t)min(j + u * NSPLIT, j1 - 1) * row_bytes + head_off)[dg];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (j + u * NSPLIT >= j1) break;
-                const float pu = h2f(Pl[j + u * NSPLIT - j0]);
-                const half8_t v8 = __builtin_bit_cast(half8_t, vr[u]);
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t two = (qc_c[u][e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+                    o[2 * e] = __builtin_fmaf(pu, h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), o[2 * e]);
+                    o[2 * e + 1] = __builtin_fmaf(pu, h2f(f2h((float)(int)(int8_t)(two >> 8) * sc)), o[2 * e + 1]);
+                }
+            } else {
+                const half8_t v8 = __builtin_bit_cast(half8_t, vcur[u]);
 #pragma unroll
                 for (int e = 0; e < 8; e++) o[e] = __builtin_fmaf(pu, (float)v8[e], o[e]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < VB; u++) {
+                if constexpr (Q8) { qs_c[u] = qs_n[u]; qc_c[u][0] = qc_n[u][0]; qc_c[u][1] = qc_n[u][1]; }
+                else vcur[u] = vnxt[u];
             }
         }
     }
@@ -820,7 +923,7 @@ __host__ __device__ inline size_t dec_attn_pv_smem(int head_dim, int max_ctx, in
 {
     const size_t nsplit = 256 / (head_dim / 8);
     const size_t chunk = (((size_t)max_ctx + nsplits - 1) / nsplits + 63) / 64 * 64;
-    return 8 * 4 + nsplit * head_dim * 4 + chunk * 2 + 16;
+    return 8 * 4 + nsplit * head_dim * 4 + (size_t)(DEC_PV_STAGE + 8) * 2 + chunk * 2 + 16;      // + the staged piece of the score row
 }
 
 __host__ __device__ inline size_t dec_attn_smem(int head_dim, int max_ctx, int ktile_rows = 0)

@@ -460,7 +460,7 @@ int ifa_model_finalize(ifa_model *m)
         }
     }
     if (!m->attn_ws.S) {
-        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.S, (size_t)c.heads * c.max_ctx * 2));
+        IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.S, (size_t)c.heads * c.max_ctx * 2 + 64));      // (+ 64: the last row is read in whole 16-byte pieces)
         IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.lmax, (size_t)c.heads * DEC_ATTN_MAX_SPLITS * 4));
         IFA_HIP_CHECK(hipMalloc((void **)&m->attn_ws.opart, (size_t)c.heads * DEC_ATTN_MAX_SPLITS * c.head_dim * 4));
     }
