@@ -620,18 +620,18 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     constexpr int KBYTES = (HD / 32) * 34;                        // Q8: bytes of a head's slice of a row
     constexpr int KALIGN = HD == 128 ? 8 : (HD == 64 ? 4 : 2);    // ... and its alignment (see dec_attn_body)
     constexpr bool QW = Q8 && KALIGN >= 4;                        // wide requests for the Q8 slice
-    u32x4 kin[Q8 ? 1 : KCH], knx[Q8 ? 1 : KCH];
-    uint32_t kq[QW ? KBYTES / 4 : 1], kqn[QW ? KBYTES / 4 : 1];
+    u32x4 kin[Q8 ? 1 : KCH];
+    uint32_t kq[QW ? KBYTES / 4 : 1];
     auto load_pass = [&](u32x4 (&dst)[Q8 ? 1 : KCH], uint32_t (&dq)[QW ? KBYTES / 4 : 1], int jb) {
         if constexpr (!Q8) {
 #pragma unroll
             for (int i2 = 0; i2 < KCH; i2++) {                    // piece idx = tid + 256 i2: row idx / KCH, chunk idx % KCH
                 const int idx = tid + 256 * i2;
-                const int jr = min(jb + idx / KCH, j1 - 1);
+                const int jr = min(jb + idx / KCH, max(j1 - 1, 0));
                 dst[i2] = reinterpret_cast<const u32x4 *>(P.kcache + (size_t)jr * row_bytes + head_off)[idx % KCH];
             }
         } else if constexpr (QW) {
-            const uint8_t *rowp = P.kcache + (size_t)min(jb + tid, j1 - 1) * row_bytes + head_off;
+            const uint8_t *rowp = P.kcache + (size_t)min(jb + tid, max(j1 - 1, 0)) * row_bytes + head_off;
             if constexpr (KALIGN == 8) {
 #pragma unroll
                 for (int i = 0; i < KBYTES / 8; i++) { const u32x2 t = reinterpret_cast<const u32x2 *>(rowp)[i]; dq[2 * i] = t[0]; dq[2 * i + 1] = t[1]; }
@@ -641,17 +641,25 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
             }
         }
     };
-    if (j0 < j1) load_pass(kin, kq, j0);
-    for (int d = tid; d < HD; d += 256) {
-        qs[d] = P.q[(size_t)h * HD + d];
-        kn[d] = P.k_new[(size_t)kvh * HD + d];
-        vn[d] = P.v_new[(size_t)kvh * HD + d];
+    // the new token's values and this step's (cos, sin) pair FIRST, the key rows behind them: requests return in issue order, so the
+    // staging below waits for a few bytes while the rows are still in flight (all unconditional, clamped: exact vmcnt counting)
+    static_assert(HD <= 256, "one value per thread");
+    const int dq = min(tid, HD - 1);
+    const half_t q_in = P.q[(size_t)h * HD + dq], k_in = P.k_new[(size_t)kvh * HD + dq], v_in = P.v_new[(size_t)kvh * HD + dq];
+    float rope_c = 1.0f, rope_s = 0.0f;
+    {
+        const int c = min(tid < HD / 2 ? tid : tid - HD / 2, HD / 2 - 1);
+        const float *rt = P.rope_tab ? P.rope_tab : reinterpret_cast<const float *>(P.q);      // (a valid dummy address without RoPE)
+        const float c0v = rt[2 * c], s0v = rt[2 * c + 1];
+        if (P.rope_order != 0) { rope_c = c0v; rope_s = s0v; }
     }
+    load_pass(kin, kq, j0);
+    if (tid < HD) { qs[tid] = q_in; kn[tid] = k_in; vn[tid] = v_in; }
     __syncthreads();
     if (P.rope_order != 0) {
         if (tid < HD) {
             const int c = tid < HD / 2 ? tid : tid - HD / 2;
-            rope_apply(tid < HD / 2 ? qs : kn, c, P.rope_tab[2 * c], P.rope_tab[2 * c + 1], P.rope_order, P.rope_cols);
+            rope_apply(tid < HD / 2 ? qs : kn, c, rope_c, rope_s, P.rope_order, P.rope_cols);
         }
         __syncthreads();
     }
@@ -685,6 +693,11 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
             reinterpret_cast<half_t *>(P.vcache + (size_t)pos * row_bytes + head_off)[tid] = vn[tid];
         }
     }
+    // the rotated q in registers (HD halves per thread, read once in 16-byte pieces): the dot products below read q[d] from LDS once per
+    // product before -- HD broadcast reads per key and thread, as many LDS instructions as fmas.  Same values, same order.
+    half8_t qreg[HD / 8];
+#pragma unroll
+    for (int i = 0; i < HD / 8; i++) qreg[i] = *reinterpret_cast<const half8_t *>(qs + 8 * i);
     const float alpha = 1.0f / sqrtf((float)HD) / P.kq_scale;
     const float mk = P.alibi ? alibi_slope(h + P.alibi_base, P.alibi_total) : 0.0f;
     float lmax = -INFINITY;
@@ -695,8 +708,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     extern __shared__ __attribute__((aligned(16))) char kst[];    // [256][KROWB] (F16 cache only: dec_attn_scores_smem)
     for (int jb = j0; jb < j1; jb += 256) {
         const int j = jb + tid;
-        const bool more = jb + 256 < j1;
-        if (more) load_pass(knx, kqn, jb + 256);
+        if (jb > j0) load_pass(kin, kq, jb);                       // (the first pass's rows were requested at the head of the kernel)
         u32x4 krow[Q8 ? 1 : KCH];
         if constexpr (!Q8) {
             __syncthreads();                                      // the previous pass's rows have been read
@@ -709,20 +721,6 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
 #pragma unroll
             for (int i2 = 0; i2 < KCH; i2++) krow[i2] = *reinterpret_cast<const u32x4 *>(kst + (size_t)tid * KROWB + (size_t)i2 * 16);
         }
-        uint32_t kqc[QW ? KBYTES / 4 : 1];
-        if constexpr (QW) {
-#pragma unroll
-            for (int i = 0; i < KBYTES / 4; i++) kqc[i] = kq[i];
-        }
-        if (more) {
-            if constexpr (!Q8) {
-#pragma unroll
-                for (int i2 = 0; i2 < KCH; i2++) kin[i2] = knx[i2];
-            } else if constexpr (QW) {
-#pragma unroll
-                for (int i = 0; i < KBYTES / 4; i++) kq[i] = kqn[i];
-            }
-        }
         if (j >= j1) continue;
         float c = 0.0f;
         if (j == pos) {
@@ -732,7 +730,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
             const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
             if constexpr (QW) {
                 // byte B (compile-time) of the slice held in registers; block b = bytes [34 b, 34 b + 34): scale (half), 32 codes
-                auto kb = [&](int B) -> uint32_t { return (kqc[B >> 2] >> (8 * (B & 3))) & 0xFFu; };
+                auto kb = [&](int B) -> uint32_t { return (kq[B >> 2] >> (8 * (B & 3))) & 0xFFu; };
 #pragma unroll
                 for (int b = 0; b < HD / 32; b++) {
                     const float sc = hbits2f((uint16_t)(kb(34 * b) | (kb(34 * b + 1) << 8)));
@@ -740,8 +738,8 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
                     for (int i = 0; i < 16; i++) {
                         const uint32_t two = kb(34 * b + 2 + 2 * i) | (kb(34 * b + 3 + 2 * i) << 8);
                         const float k0 = h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), k1 = h2f(f2h((float)(int)(int8_t)(two >> 8) * sc));
-                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i]), k0, c);
-                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i + 1]), k1, c);
+                        c = __builtin_fmaf((float)qreg[(b * 32 + 2 * i) >> 3][(2 * i) & 7], k0, c);
+                        c = __builtin_fmaf((float)qreg[(b * 32 + 2 * i + 1) >> 3][(2 * i + 1) & 7], k1, c);
                     }
                 }
             } else if constexpr (Q8) {
@@ -753,8 +751,8 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
                     for (int i = 0; i < 16; i++) {
                         const uint32_t two = p16[1 + i];
                         const float k0 = h2f(f2h((float)(int)(int8_t)(two & 0xFF) * sc)), k1 = h2f(f2h((float)(int)(int8_t)(two >> 8) * sc));
-                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i]), k0, c);
-                        c = __builtin_fmaf(h2f(qs[b * 32 + 2 * i + 1]), k1, c);
+                        c = __builtin_fmaf((float)qreg[(b * 32 + 2 * i) >> 3][(2 * i) & 7], k0, c);
+                        c = __builtin_fmaf((float)qreg[(b * 32 + 2 * i + 1) >> 3][(2 * i + 1) & 7], k1, c);
                     }
                 }
             } else {
@@ -762,7 +760,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
                 for (int i = 0; i < HD / 8; i++) {
                     const half8_t k8 = __builtin_bit_cast(half8_t, krow[i]);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) c = __builtin_fmaf(h2f(qs[8 * i + e]), (float)k8[e], c);
+                    for (int e = 0; e < 8; e++) c = __builtin_fmaf((float)qreg[i][e], (float)k8[e], c);
                 }
             }
         }

@@ -336,6 +336,7 @@ int launch_attn(ifa_model *m, int l)
         // the LDS forces the split (very large max_context_len) as many as keep a split's probabilities inside the LDS
         int nsp = m->attn_split > 1 ? m->attn_split : 8;
         while (nsp < DEC_ATTN_MAX_SPLITS && dec_attn_pv_smem(c.head_dim, c.max_ctx, nsp) > IFA_LDS_LIMIT) nsp *= 2;
+        if (m->opt_attn_nsplits > 0) nsp = std::min(m->opt_attn_nsplits, DEC_ATTN_MAX_SPLITS);
         m->attn_ws.nsplits = nsp;
         const dim3 g2((unsigned)c.heads, (unsigned)nsp);
         const size_t psmem = dec_attn_pv_smem(c.head_dim, c.max_ctx, nsp);

@@ -9,6 +9,8 @@ kv = dt.Q8_B32T2 if "q8" in sys.argv else dt.F16
 n = int(sys.argv[1])
 shape = os.environ.get("IFA_SHAPE", "llama2_7b")
 wk, _, s = synth.build(shape, dt.Q4_B32T1A, kv, max_ctx=n + 100)
+for o in (os.environ.get("IFA_OPTS") or "").split(","):      # IFA_OPTS="attn_nsplits=16,attn_fold_combine=0"
+    if "=" in o: wk.set_option(o.split("=")[0], int(o.split("=")[1]))
 pr = np.random.default_rng(1).integers(3, s["vocab"], n).astype(np.int32)
 tok = wk.forward(pr, 0)
 t8, _ = wk.decode(tok, n, 8)
