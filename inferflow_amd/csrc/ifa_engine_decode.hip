@@ -8,7 +8,10 @@ namespace ifae {
 // history streams through that many CUs: 8 splits left 16K-key contexts at 2 TB/s).  The captured steps hold the choice.
 void choose_attn_split(ifa_model *m, int reach)
 {
-    const int want = (m->opt_attn_split_ctx > 0 && reach > m->opt_attn_split_ctx) ? (reach > 8192 ? 32 : (reach > 2048 ? 16 : 8)) : 0;
+    // splits per head by the context the call reaches: 8 up to 8192 keys, 16 above (round 6, second session, after the kernels lost their
+    // request chains: 2048 / 4096 / 8192 keys 563 / 484 / 404 tok/s with 8 splits against 535 / 483 / 400 with 16; 16384 keys 301 / 303 / 281
+    // with 8 / 16 / 32; Q8 cache 4096 keys 487 against 465 -- profiles/r06_long_context_decode.log.  Was 8 / 16 / 32 from 512 / 2048 / 8192.)
+    const int want = (m->opt_attn_split_ctx > 0 && reach > m->opt_attn_split_ctx) ? (reach > 8192 ? 16 : 8) : 0;
     if (want != m->attn_split) { m->attn_split = want; drop_graphs(m); }
     // rows of the K / V cache the one-workgroup kernel requests before it knows the position: the bucket this call stays
     // inside (a longer context only costs the direct loads of the rows past it)
