@@ -708,8 +708,11 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
     extern __shared__ __attribute__((aligned(16))) char kst[];    // [256][KROWB] (F16 cache only: dec_attn_scores_smem)
     for (int jb = j0; jb < j1; jb += 256) {
         const int j = jb + tid;
-        if (jb > j0) load_pass(kin, kq, jb);                       // (the first pass's rows were requested at the head of the kernel)
+        // the rows of the NEXT pass are requested as soon as this pass's registers are free (behind the LDS stores / the register copy):
+        // with one workgroup per CU (8 splits per head) nothing else overlaps a pass's memory round trip with the products of the one before
+        const int jn = min(jb + 256, max(j1 - 1, 0));              // (past the split: clamped, harmless)
         u32x4 krow[Q8 ? 1 : KCH];
+        uint32_t kqc[QW ? KBYTES / 4 : 1];
         if constexpr (!Q8) {
             __syncthreads();                                      // the previous pass's rows have been read
 #pragma unroll
@@ -717,9 +720,14 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
                 const int idx = tid + 256 * i2;
                 *reinterpret_cast<u32x4 *>(kst + (size_t)(idx / KCH) * KROWB + (size_t)(idx % KCH) * 16) = kin[i2];
             }
+            load_pass(kin, kq, jn);
             __syncthreads();
 #pragma unroll
             for (int i2 = 0; i2 < KCH; i2++) krow[i2] = *reinterpret_cast<const u32x4 *>(kst + (size_t)tid * KROWB + (size_t)i2 * 16);
+        } else if constexpr (QW) {
+#pragma unroll
+            for (int i = 0; i < KBYTES / 4; i++) kqc[i] = kq[i];
+            load_pass(kin, kq, jn);
         }
         if (j >= j1) continue;
         float c = 0.0f;
@@ -730,7 +738,7 @@ __global__ void __launch_bounds__(256) k_dec_attn_scores(const DecAttnParams P, 
             const uint8_t *rowp = P.kcache + (size_t)j * row_bytes + head_off;
             if constexpr (QW) {
                 // byte B (compile-time) of the slice held in registers; block b = bytes [34 b, 34 b + 34): scale (half), 32 codes
-                auto kb = [&](int B) -> uint32_t { return (kq[B >> 2] >> (8 * (B & 3))) & 0xFFu; };
+                auto kb = [&](int B) -> uint32_t { return (kqc[B >> 2] >> (8 * (B & 3))) & 0xFFu; };
 #pragma unroll
                 for (int b = 0; b < HD / 32; b++) {
                     const float sc = hbits2f((uint16_t)(kb(34 * b) | (kb(34 * b + 1) << 8)));
