@@ -378,8 +378,31 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
     const float alpha = 1.0f / sqrtf((float)HD) / P.kq_scale;
     const float mk = P.alibi ? alibi_slope(h + P.alibi_base, P.alibi_total) : 0.0f;
     float lmax = -INFINITY;
+    // BATCH (round 6, second session): the key row of the NEXT iteration is requested (into a second register set, clamped, unconditional)
+    // before this iteration's products -- the loop asked for a row and waited for it, one round trip per 256 keys with one workgroup per
+    // (head, query) and CU.  Single-query kernels stay as they were (they hand contexts past 320 keys to the split kernels).
+    uint32_t kreg2[(BATCH && !Q8) ? HD / 2 : 1];
+    uint32_t kq32b[(BATCH && Q8 && KALIGN >= 4) ? KBYTES / 4 : 1];
+    constexpr bool KPRE = BATCH && (!Q8 || KALIGN >= 4);
+    bool have = false;                                   // (KPRE) kreg / kq32 already hold row j
     for (int j = tid; j < n_ctx; j += 256) {
         ScoreAcc acc;
+        if constexpr (KPRE) {
+            const uint8_t *rowp2 = pkc + (size_t)min(j + 256, n_ctx - 1) * row_bytes + head_off;
+            if constexpr (!Q8) {
+#pragma unroll
+                for (int i = 0; i < HD / 8; i++) {
+                    const u32x4 t = IFA_GP(u32x4, rowp2)[i];
+                    kreg2[4 * i] = t[0]; kreg2[4 * i + 1] = t[1]; kreg2[4 * i + 2] = t[2]; kreg2[4 * i + 3] = t[3];
+                }
+            } else if constexpr (KALIGN == 8) {
+#pragma unroll
+                for (int i = 0; i < KBYTES / 8; i++) { const u32x2 t = IFA_GP(u32x2, rowp2)[i]; kq32b[2 * i] = t[0]; kq32b[2 * i + 1] = t[1]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < KBYTES / 4; i++) kq32b[i] = IFA_GP(uint32_t, rowp2)[i];
+            }
+        }
         if (Q8 && j == pos) {
             // the new token's (round-tripped) key: wide LDS reads into registers, then the same chain -- a scalar loop
             // over LDS kept the whole workgroup waiting at the next barrier for ~0.7 us
@@ -401,8 +424,8 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
                         const u32x4 t = reinterpret_cast<const u32x4 *>(kn)[i];
                         kreg[4 * i] = t[0]; kreg[4 * i + 1] = t[1]; kreg[4 * i + 2] = t[2]; kreg[4 * i + 3] = t[3];
                     }
-                } else if (j >= PB) load_k(j);       // rows past the prefetched bucket: load now
-            } else if (j >= PB) load_k(j);
+                } else if (j >= PB && !have) load_k(j);       // rows past the prefetched bucket: load now
+            } else if (j >= PB && !have) load_k(j);
             if constexpr (Q8) {
 #pragma unroll
                 for (int b = 0; b < HD / 32; b++) {
@@ -441,6 +464,16 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
         if (P.alibi) { float a = (float)j * mk; s = f2h(a + h2f(s)); }
         S[j] = s;
         lmax = fmaxf(lmax, P.kq_scale * h2f(s));
+        if constexpr (KPRE) {                            // the next iteration's row moves into the working registers
+            if constexpr (!Q8) {
+#pragma unroll
+                for (int i = 0; i < HD / 2; i++) kreg[i] = kreg2[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < KBYTES / 4; i++) kq32[i] = kq32b[i];
+            }
+            have = true;
+        }
     }
     if (tr) P.trace[h * 8 + 3] = wall_clock64();
     lmax = wave_max(lmax);
@@ -517,11 +550,47 @@ __device__ __forceinline__ void dec_attn_body(char *smem, const half_t *pq, cons
             else acc_v(pj, vreg[i]);
         }
     }
-    for (int j = vact ? sp + NSPLIT * VPRE : n_ctx; j < n_ctx; j += NSPLIT) {
-        const float pj = h2f(S[j]);
-        if (j == pos) acc_new(pj);
-        else if constexpr (Q8) acc_q8(pj, j);
-        else acc_v(pj, IFA_GP(u32x4, pvc + (size_t)j * row_bytes + head_off)[dg]);
+    // keys past the prefetched bucket (round 6, second session): batches of eight keys of this thread's sequence, the next batch
+    // requested before the current one is multiplied (unconditional, clamped rows).  The loop asked for one V piece per iteration and
+    // waited for it: a batched step at 2048 keys spent 96 us per layer in this kernel.  Same order of accumulation as the plain loop.
+    {
+        constexpr int TB = 8;
+        u32x4 tcur[Q8 ? 1 : TB], tnxt[Q8 ? 1 : TB];
+        uint32_t ts_c[Q8 ? TB : 1], tc_c[Q8 ? TB : 1][2], ts_n[Q8 ? TB : 1], tc_n[Q8 ? TB : 1][2];
+        const size_t tq_off = head_off + (size_t)(dg / 4) * 34;
+        auto tload = [&](u32x4 (&dst)[Q8 ? 1 : TB], uint32_t (&ds)[Q8 ? TB : 1], uint32_t (&dc)[Q8 ? TB : 1][2], int j) {
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int jr = min(j + u * NSPLIT, n_ctx - 1);
+                if constexpr (!Q8) dst[u] = IFA_GP(u32x4, pvc + (size_t)jr * row_bytes + head_off)[dg];
+                else {
+                    const auto *blk = IFA_GP(uint16_t, pvc + (size_t)jr * row_bytes + tq_off);
+                    typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
+                    ds[u] = blk[0];
+                    const u32x2_a2 cw = *IFA_GP(u32x2_a2, blk + 1 + (dg % 4) * 4);
+                    dc[u][0] = cw[0]; dc[u][1] = cw[1];
+                }
+            }
+        };
+        int j = vact ? sp + NSPLIT * VPRE : n_ctx;
+        if (j < n_ctx) tload(tcur, ts_c, tc_c, j);
+        for (; j < n_ctx; j += TB * NSPLIT) {
+            tload(tnxt, ts_n, tc_n, j + TB * NSPLIT);
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int jj = j + u * NSPLIT;
+                if (jj >= n_ctx) break;
+                const float pj = h2f(S[jj]);
+                if (jj == pos) acc_new(pj);
+                else if constexpr (Q8) acc_q8w(pj, (uint16_t)ts_c[u], (uint16_t)(tc_c[u][0] & 0xFFFFu), (uint16_t)(tc_c[u][0] >> 16), (uint16_t)(tc_c[u][1] & 0xFFFFu), (uint16_t)(tc_c[u][1] >> 16));
+                else acc_v(pj, tcur[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                if constexpr (Q8) { ts_c[u] = ts_n[u]; tc_c[u][0] = tc_n[u][0]; tc_c[u][1] = tc_n[u][1]; }
+                else tcur[u] = tnxt[u];
+            }
+        }
     }
     if (vact) {
 #pragma unroll
