@@ -440,6 +440,57 @@ def test_dynamic_batching_rows_are_independent_queries(kvd):
     wk.close()
 
 
+@pytest.mark.parametrize("kvd", [dt.F16, dt.Q8_B32T2], ids=["kvf16", "kvq8"])
+def test_batched_step_at_contexts_past_the_prefetched_bucket(kvd):
+    """Queries with several hundred cached keys in one batched step: k_dec_attn<.., BATCH> walks the keys past its 256-row entry prefetch
+    in 256-key iterations (K rows one iteration ahead) and the V rows in double-buffered batches of eight keys (round 6).  Every row
+    against the same query decoded alone on a copy of its cache through the single-query step (at these contexts: the keys-split-over-
+    workgroups kernels; Q8 activations alone vs F16 activations batched: the tolerance of test_dynamic_batching_rows_are_independent_queries),
+    the fused step against the op-by-op rows, and row order must not matter (identical bits under permutation)."""
+    wk, host, s = synth.build("test_gqa", dt.Q4_B32T1A, kvd, max_ctx=720, quant_threshold=0, std=0.06, keep_host=True)
+    V = s["vocab"]
+    wk.kv_slots(6)
+    rng = np.random.default_rng(29)
+    prompts = [rng.integers(3, V, n).astype(np.int32) for n in (300, 517, 690)]
+    first = []
+    for i, pr in enumerate(prompts):
+        wk.select_kv(i); first.append(wk.forward(pr, 0))
+        wk.select_kv(3 + i); assert wk.forward(pr, 0) == first[i]
+    cur, pos = list(first), [len(p) for p in prompts]
+    lg = torch.empty((3, V), dtype=torch.float16, device="cuda")
+    lgu = torch.empty((3, V), dtype=torch.float16, device="cuda")
+    lg1 = torch.empty((1, V), dtype=torch.float16, device="cuda")
+    agree = total = 0
+    for step in range(5):
+        wk.set_option("batch_fused", 1)
+        nxt = wk.decode_batch(cur, pos, [0, 1, 2], lg)
+        rows = g.host(lg).copy()
+        for i in range(3):
+            wk.select_kv(3 + i)
+            t1 = wk.forward(np.array([cur[i]], np.int32), pos[i], lg1)
+            cos, mad = _logits_close(rows[i], g.host(lg1)[0])
+            assert cos >= 0.999 and mad <= 0.03 * float(np.abs(rows[i].astype(np.float32)).max()) + 0.03, (step, i, cos, mad)
+            total += 1; agree += int(t1 == nxt[i])
+        cur = [int(t) for t in nxt]
+        pos = [p + 1 for p in pos]
+    assert agree >= total - 3
+    a = wk.decode_batch(cur, pos, [0, 1, 2], lg)
+    wk.set_option("batch_fused", 0)
+    wk.decode_batch(cur, pos, [0, 1, 2], lgu)                                  # op-by-op rows: same GEMM arithmetic, another attention kernel
+    A, U = g.host(lg).astype(np.float32), g.host(lgu).astype(np.float32)
+    cos = float((A * U).sum() / (np.linalg.norm(A) * np.linalg.norm(U)))
+    assert cos >= 0.9999 and np.abs(A - U).max() <= 0.02, (cos, np.abs(A - U).max())
+    wk.set_option("batch_fused", 1)
+    lgp = torch.empty((3, V), dtype=torch.float16, device="cuda")
+    b = wk.decode_batch([cur[2], cur[0], cur[1]], [pos[2], pos[0], pos[1]], [2, 0, 1], lgp)
+    assert [int(b[1]), int(b[2]), int(b[0])] == [int(t) for t in a]
+    A16, B16 = g.host(lg), g.host(lgp)
+    wk.decode_batch(cur, pos, [0, 1, 2], lg)
+    A16 = g.host(lg)
+    assert np.array_equal(A16[0], B16[1]) and np.array_equal(A16[1], B16[2]) and np.array_equal(A16[2], B16[0])
+    wk.close()
+
+
 @pytest.mark.parametrize("n", [2, 5, 8, 11, 16, 20, 27, 32])
 @pytest.mark.parametrize("kvd,shape", [(dt.F16, "test_mha"), (dt.Q8_B32T2, "test_mha"), (dt.F16, "test_moe"), (dt.F16, "test_moe_longffn")],
                          ids=["kvf16", "kvq8", "moe", "moe_longffn"])
