@@ -88,6 +88,12 @@ __device__ __forceinline__ GmTile gm_locate(const GmSets &S, int vt)
 #ifndef IFA_ROWS_FETCH_EARLY
 #define IFA_ROWS_FETCH_EARLY 1
 #endif
+// whole-row staging (CH == 2), order of the prologue: 0 = every weight group requested, then the rows stored (counted wait);
+// 1 = ONE group in flight, rows stored, barrier, then the other groups; 2 = rows stored and the barrier passed before ANY
+// weight request
+#ifndef IFA_ROWS_WHOLE_ORDER
+#define IFA_ROWS_WHOLE_ORDER 0
+#endif
 template <int MAXT, int TX, int EPI, int NORM, bool MO, int CH, int KPM = 0>
 __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 {
@@ -397,7 +403,7 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
     // ONE group per wave is requested in front of the staging, the rest behind it: with all PD groups (30 MB chip-wide for a
     // 12288-row matrix) queued first, the rows of late-starting workgroups sat behind them in the memory system -- staged at
     // 4.4 us instead of 1.4 (rows-trace)
-    fetch_q(buf[0], 0);
+    if constexpr (!(WHOLE && IFA_ROWS_WHOLE_ORDER == 2)) fetch_q(buf[0], 0);
     // The waits below must be COUNTED waits: the first chunk's rows are the oldest requests (vmcnt = the weight loads issued
     // after them), so staging them does not wait for the weight groups in flight.  That needs straight-line code: the
     // single-chunk case (K <= 4096: wq | wk | wv, wo, w1 / w3) is its own path, and in the chunk loop the NEXT chunk's rows
@@ -418,8 +424,10 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
         }
     };
     if constexpr (WHOLE) {
+        if constexpr (IFA_ROWS_WHOLE_ORDER == 0) {
 #pragma unroll
-        for (int d = 1; d < PD; d++) fetch_q(buf[d], d);      // (behind the rows' own requests in this CU's queue, see x_store)
+            for (int d = 1; d < PD; d++) fetch_q(buf[d], d);      // (behind the rows' own requests in this CU's queue, see x_store)
+        }
         xw_store();
     } else x_store(c_lo, true);
     // The staging barrier FIRST, the other PD - 1 groups behind it (round 4): requested in front of the barrier, every wave sat in
@@ -428,6 +436,11 @@ __device__ __forceinline__ void gemm_rows_mfma_body(const GmArgs &P, char *smem)
 #if IFA_ROWS_FETCH_EARLY
     __syncthreads();
     if (trc && tid == 0) trc[2] = wall_clock64();
+    if constexpr (WHOLE && IFA_ROWS_WHOLE_ORDER != 0) {
+#pragma unroll
+        for (int d = (IFA_ROWS_WHOLE_ORDER == 2 ? 0 : 1); d < PD; d++) fetch_q(buf[d], d);
+        if (trc && tid == 0) trc[18] = wall_clock64();
+    }
     if constexpr (NORM == 1) {      // (norm prologue: requested from inside the staging, every wave would sit in its load issue for ~1.2 us with the rows still to scale)
 #pragma unroll
         for (int d = 1; d < PD; d++) fetch_q(buf[d], d);
