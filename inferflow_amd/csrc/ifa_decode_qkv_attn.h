@@ -32,11 +32,23 @@ struct DecQkvAttnExtra {
     unsigned *err;                  // error word (ifa_model::ps_err)
     int timeout_us;
     int gk;                         // workgroups per kv group; grid = kv_heads * gk
+    int unload;                     // 1: the UL kernels -- the heads' workgroups take no q | k | v rows (256-row bucket, see k_dec_qkv_attn)
 };
 
+// the head's K / V rows of the entry bucket requested by the attention waves right behind their own weight rows (PHASE 1 of
+// dec_attn_body), not after the workgroup's last q | k | v row: at 21..41 keys the rows arrive during the granule wait either way,
+// from ~100 keys on the 2 x 256 bytes per key of ONE compute unit were the tail (150 / 256 keys: +3.8 / +7.2 us per layer)
+#ifndef IFA_QA_EARLY_KV
+#define IFA_QA_EARLY_KV 0
+#endif
 constexpr int QA_THREADS = 512;     // 8 waves: two per SIMD, 256 registers each (the attention tail needs ~140)
 
-template <int DT, int NJ, int RW, int NORM, int HD, bool Q8, int PB, bool KT, int NP>
+// UL ("unloaded heads", the 256-row bucket): a compute unit pulls ~26 GB/s from HBM however idle the chip is, and a head's cache rows
+// (2 x 256 bytes per key) come through ONE unit -- at 250 keys 128 KB, as much as the unit's share of the weights, and the real step
+// (cold rows; the timing loop's repeated launches find them in the cache) paid ~4 us per layer for them behind the last q | k | v row.
+// With UL the heads' workgroups take NO weight rows: they request their cache rows at the first instruction and poll the granules
+// while the other gk - group workgroups of the set stream all (group + 2) * HD rows (RW = 7 instead of 6 for Llama-2-7B).
+template <int DT, int NJ, int RW, int NORM, int HD, bool Q8, int PB, bool KT, int NP, bool UL = false>
 __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, const half_t *pnw, const half_t *pnb, int pcols, int pgeo,
                                                              const uint8_t *pwq, const uint8_t *pwk, const uint8_t *pwv,
                                                              const DecGemvParams P, const DecAttnParams A, const DecQkvAttnExtra E)
@@ -64,8 +76,13 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     const int g = (int)blockIdx.x / g_gk, bg = (int)blockIdx.x - g * g_gk;
     const int group = g_heads / g_kvh;
     const int RG = (group + 2) * HD;
-    const int WGV = g_gk * (TH / 64);
-    const int lw = bg * (TH / 64) + wave;
+    // the attention tail: workgroup bg == a * (gk / group) of the set runs query head g * group + a
+    const int per = g_gk / group;
+    const bool attn_wg = bg % per == 0;
+    const int head = g * group + bg / per;
+    // waves that take rows, and this wave's place among them (UL: the heads' workgroups are left out)
+    const int WGV = UL ? (g_gk - group) * (TH / 64) : g_gk * (TH / 64);
+    const int lw = UL ? (bg - bg / per - 1) * (TH / 64) + wave : bg * (TH / 64) + wave;
     struct Row { const uint8_t *w; const half_t *b; half_t *y; int row, vrow; };
     // (selects over kernel-argument scalars, like dec_locate: an indexed read of P.W0[] would be a vector load with a vmcnt(0) behind it)
     auto locate = [&](int lr) {
@@ -107,11 +124,9 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     // prologue waves).  They request the head's K / V rows right behind their weight rows: the cache rows then arrive with the
     // end of the weight stream instead of one memory round trip after the last q | k | v row
     static_assert(NP == 4, "the prologue waves are the attention waves");
-    const int per = g_gk / group;
-    const bool attn_wg = bg % per == 0;
-    const int head = g * group + bg / per;
-    if (threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }
-    if (wave >= NP) load_rows(0, 1);          // (before the barrier: see k_dec_gemv)
+    const bool ul_head = UL && attn_wg;
+    if (!ul_head && threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }
+    if (!ul_head && wave >= NP) load_rows(0, 1);          // (before the barrier: see k_dec_gemv)
     // the position and the step's tag: scalar loads through pointers of the argument block -- read BEHIND the first weight
     // requests, which need nothing but preloaded scalars
     const int pos = *(const __attribute__((address_space(4))) int *)(A.state + 1);
@@ -121,12 +136,24 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     DecAttnFusedIn F;
     F.gran = E.gran; F.epoch = epoch; F.pos = pos; F.err = E.err; F.timeout_ticks = (long long)E.timeout_us * 100;
     F.att_gran = nullptr;
+    if constexpr (UL) {
+        if (attn_wg) {      // no rows, no prologue, no barrier with the other waves: the cache rows are requested NOW
+            if (wave >= 4) return;
+            DecAttnRegs<HD, Q8, PB, KT> RU;
+            dec_attn_body<HD, Q8, false, PB, KT, true>(smem, nullptr, A.kcache, A.vcache, A.heads, A.kv_heads, A, head, F, RU);
+            return;
+        }
+    }
     __syncthreads();
+    DecAttnRegs<HD, Q8, PB, KT> R;
     if (wave >= NP) {
         load_rows(1, RW);
     } else {
         pre.finish(P.norm_w, P.norm_b, P.multi_base, P.eps, P.cols, L, P.xn_out, nullptr);
         load_rows(0, RW);
+#if IFA_QA_EARLY_KV
+        if (attn_wg) dec_attn_body<HD, Q8, false, PB, KT, true, 1>(smem, nullptr, A.kcache, A.vcache, A.heads, A.kv_heads, A, head, F, R);
+#endif
     }
     lds_counter_wait(L.part + 131, NP);
     typename Fmt::X X;
@@ -157,8 +184,7 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     if (attn_wg) {
         __syncthreads();             // every wave of this workgroup is done with the activation image: the LDS is the attention's now
         if (wave >= 4) return;
-        DecAttnRegs<HD, Q8, PB, KT> R;
-        dec_attn_body<HD, Q8, false, PB, KT, true>(smem, nullptr, A.kcache, A.vcache, A.heads, A.kv_heads, A, head, F, R);
+        dec_attn_body<HD, Q8, false, PB, KT, true, IFA_QA_EARLY_KV ? 2 : 0>(smem, nullptr, A.kcache, A.vcache, A.heads, A.kv_heads, A, head, F, R);
         return;
     }
 }

@@ -256,6 +256,7 @@ int launch_qkv_attn(ifa_model *m, int l, const half_t *x, unsigned tag_add)
     E.epoch = m->qa_call; E.epoch_add = tag_add; E.err = m->qa_err; E.timeout_us = m->opt_fuse_attn_timeout_us; E.gk = m->qa_gk;
     const int pb = (m->attn_pb == 64 || m->attn_pb == 128) ? m->attn_pb : 256;
     const bool kt = m->opt_attn_kt && !A.kv_q8 && dec_attn_smem(c.head_dim, c.max_ctx, pb) <= IFA_LDS_LIMIT;
+    E.unload = ((m->opt_attn_unload >= 1 && pb == 256) || (m->opt_attn_unload >= 2 && pb == 128 && (kt || A.kv_q8))) ? 1 : 0;      // (2: the 128-row bucket too -- measurement)
     return dec_qkv_attn_launch(L.t[T_WQ].dtype, 1, A.kv_q8 != 0, pb, kt, P, A, E, c.max_ctx, m->stream);
 }
 

@@ -116,6 +116,7 @@ struct ifa_model {
     std::map<int, hipGraphExec_t> batch_graphs;      // captured batched step per batch size (dense models)
     // long-context decode attention (keys split over workgroups): workspace, switch and the context it starts at
     DecAttnSplitWs attn_ws = {nullptr, nullptr, nullptr, 8};
+    int opt_attn_unload = 1;       // 1 (default): in the 256-row bucket the heads' workgroups of the fused QKV + attention launch take no weight rows (UL kernels)
     int opt_attn_nsplits = 0;      // > 0: splits per head whatever the context (measurement)
     // attention as the tail of the QKV launch (ifa_decode_qkv_attn.h): granules [layers][(heads + 2 kv_heads) * head_dim], the
     // decode-call counter the tags are built from, its own error word

@@ -41,7 +41,8 @@ def test_fused_qkv_attention_launch_is_bit_identical(shape, wd, kvd, layers):
     for steps in (40, 120, 250):
         ref = _run(wk, s, prompt, steps, fuse_attn=0, step_tail=0)
         wk.set_option("step_tail", 1)
-        for opts in [{"fuse_attn": 1}]:
+        # attn_unload (default 1): in the 256-row bucket the heads' workgroups take no weight rows (the UL kernels) -- both mappings
+        for opts in [{"fuse_attn": 1, "attn_unload": 0}, {"fuse_attn": 1, "attn_unload": 1}]:
             got = _run(wk, s, prompt, steps, **opts)
             assert got[0] == ref[0], "tokens differ (%r, %d steps)" % (opts, steps)
             assert np.array_equal(got[1], ref[1]), "logits differ (%r, %d steps)" % (opts, steps)

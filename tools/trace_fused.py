@@ -7,8 +7,9 @@ import numpy as np
 from inferflow_amd import dtypes as dt, synth
 kv = dt.Q8_B32T2 if len(sys.argv) > 1 and sys.argv[1] == "q8" else dt.F16
 wk, _, s = synth.build("llama2_7b", dt.Q4_B32T1A, kv, max_ctx=256)
-tok = wk.forward(np.arange(3, 19, dtype=np.int32), 0)
-toks, ms = wk.decode(int(tok), 16, 48)          # positions up to 64: the prefetch bucket of the timing launches
+NP = int(os.environ.get("IFA_TRACE_CTX", "16"))       # prompt length: the timing launches then sit at NP + 48 keys
+tok = wk.forward((np.arange(NP, dtype=np.int32) % 1000) + 3, 0)
+toks, ms = wk.decode(int(tok), NP, 48 if NP == 16 else 8)          # (16: positions up to 64, the prefetch bucket of the timing launches)
 wk.set_option("trace", 1)
 H = s["heads"]
 for which, nm in [(7, "qkv+attn fused"), (0, "qkv"), (1, "attn"), (2, "wo"), (3, "ffn13")]:
