@@ -274,8 +274,8 @@ int ifa_model_set_tensor_f16(ifa_model *m, int layer, int tensor_id, int expert,
 int ifa_model_finalize(ifa_model *m);
 int ifa_model_reset(ifa_model *m);
 /* options: "fused" (1), "graph" (1), "rpw_qkv|rpw_wo|rpw_ffn|rpw_w2|rpw_lm" (0 = auto), "batch_fused" (1), "rows_mo" (1: the batched
- * step and short prompts stream MFMA-operand-order copies of the weights, built on first use), "attn_split_ctx" (320: a decode call that reaches more keys than this runs the attention as scores / P.V / combine launches with a head's keys split over 8 or 16 workgroups), "fuse_attn" (1: the attention as the
- * tail of the wq | wk | wv launch), "fuse_ffn" (0; 1 / 2: [Wo ->] W1 | W3 -> W2 as one chained launch, csrc/ifa_decode_chain.h: bit-identical,
+ * step and short prompts stream MFMA-operand-order copies of the weights, built on first use), "attn_split_ctx" (-1 = by model: 512 keys, 640 with grouped queries, 320 without the fused launch; a decode call that reaches more keys than this runs the attention as scores / P.V / combine launches with a head's keys split over 8 or 16 workgroups; 0: never), "fuse_attn" (1: the attention as the
+ * tail of the wq | wk | wv launch), "attn_unload" (1: in the 256-row bucket of that launch the heads' workgroups take no weight rows and request their cache rows at once; 2: in the 128-row bucket too, measured slower), "fuse_ffn" (0; 1 / 2: [Wo ->] W1 | W3 -> W2 as one chained launch, csrc/ifa_decode_chain.h: bit-identical,
  * measured slower than the separate launches on MI355X, kept as the measurement harness of that statement), "prefill_mid" (1),
  * "prefill_mid_max" (768), "prefill_res_mid" (2048: up to this many tokens wo / w2 keep the mid-size kernel above prefill_mid_max), "prefill_big_min" (47), "attn_post_as_residual" (1), "exact_order" (0; 1: every single-token step -- and every row
  * of a prompt, one by one -- runs in the summation order of the reference's CUDA kernels, csrc/ifa_exact.hip: a parity instrument whose

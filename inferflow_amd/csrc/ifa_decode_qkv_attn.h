@@ -41,6 +41,9 @@ struct DecQkvAttnExtra {
 #ifndef IFA_QA_EARLY_KV
 #define IFA_QA_EARLY_KV 0
 #endif
+#ifndef IFA_QA_WARM_ROWS
+#define IFA_QA_WARM_ROWS 1
+#endif
 constexpr int QA_THREADS = 512;     // 8 waves: two per SIMD, 256 registers each (the attention tail needs ~140)
 
 // UL ("unloaded heads", the 256-row bucket): a compute unit pulls ~26 GB/s from HBM however idle the chip is, and a head's cache rows
@@ -138,7 +141,29 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
     F.att_gran = nullptr;
     if constexpr (UL) {
         if (attn_wg) {      // no rows, no prologue, no barrier with the other waves: the cache rows are requested NOW
-            if (wave >= 4) return;
+            if (wave >= 4) {
+                // The four waves the attention does not use pull the head's cache rows PAST the entry bucket towards this unit's L2
+                // (one dword per 64 bytes of every K / V slice, values unused): the tail's loop asks for those rows batch by batch
+                // behind the last q | k | v row, and each batch was a round trip to HBM through one compute unit
+#if IFA_QA_WARM_ROWS
+                if (pos >= PB) {
+                    constexpr int SB = Q8 ? (HD / 32) * 34 : HD * 2;
+                    const int kvh = head / group, kv_dim = g_kvh * HD;
+                    const size_t rb = Q8 ? (size_t)(kv_dim / 32) * 34 : (size_t)kv_dim * 2;
+                    const size_t ho = Q8 ? (size_t)((kvh * HD) / 32) * 34 : (size_t)kvh * HD * 2;
+                    const int t = (int)threadIdx.x - 256;
+                    const int off = min((t & 3) * 64, SB - 4) & ~1;
+                    typedef uint32_t u32_a2 __attribute__((aligned(2)));
+                    uint32_t acc = 0;
+                    for (int j = PB + (t >> 2); j <= pos; j += 64) {
+                        acc ^= *(const __attribute__((address_space(1))) u32_a2 *)(A.kcache + (size_t)j * rb + ho + off);
+                        acc ^= *(const __attribute__((address_space(1))) u32_a2 *)(A.vcache + (size_t)j * rb + ho + off);
+                    }
+                    if (acc == 0x9E3779B9u && A.trace) A.trace[(size_t)A.heads * 8 + 7] = (long long)acc;     // (keeps the loads; never read)
+                }
+#endif
+                return;
+            }
             DecAttnRegs<HD, Q8, PB, KT> RU;
             dec_attn_body<HD, Q8, false, PB, KT, true>(smem, nullptr, A.kcache, A.vcache, A.heads, A.kv_heads, A, head, F, RU);
             return;

@@ -6,12 +6,32 @@ namespace ifae {
 
 // keys split over workgroups past attn_split_ctx; 8 splits per head up to 2K keys, 16 up to 8K, 32 beyond (a head's K / V
 // history streams through that many CUs: 8 splits left 16K-key contexts at 2 TB/s).  The captured steps hold the choice.
+bool qkv_attn_layer_ok(const ifa_model *m, int l, int *gk_out);
+
+// From how many keys on a head's keys are split over workgroups.  attn_split_ctx >= 0: that many (0: never).  -1 (default): by what
+// the one-workgroup attention is -- as the tail of the QKV launch with the heads' workgroups unloaded in the 256-row bucket (attn_unload)
+// and the rows past the bucket pulled towards the L2 by the idle waves, it holds up to ~520 keys with one kv head per query head
+// (400 / 450 / 500 / 560 keys 689 / 674 / 661 / 635 tok/s against 658 / 655 / 653 / 651 split; Q8 cache 662 / 653 / 643 / 620 against
+// 642 / 639 / 638 / 635) and ~650 with grouped queries (Mixtral 560 keys 388 against 381): profiles/r06_attn_unload.log; 320 otherwise
+static int attn_split_threshold(const ifa_model *m)
+{
+    if (m->opt_attn_split_ctx >= 0) return m->opt_attn_split_ctx;
+    const ifa_model_config &c = m->cfg;
+    bool tail = m->opt_attn_unload && m->opt_fuse_attn && waits_enabled() && dec_attn_smem(c.head_dim, c.max_ctx, 256) <= IFA_LDS_LIMIT;
+    int gk = 0;
+    for (int l = 0; tail && l < c.layers; l++) if (!qkv_attn_layer_ok(m, l, &gk)) tail = false;
+    if (tail && (long long)c.kv_heads * gk > (long long)visible_cus()) tail = false;
+    if (!tail) return 320;
+    return c.heads > c.kv_heads ? 640 : 512;
+}
+
 void choose_attn_split(ifa_model *m, int reach)
 {
     // splits per head by the context the call reaches: 8 up to 8192 keys, 16 above (round 6, second session, after the kernels lost their
     // request chains: 2048 / 4096 / 8192 keys 563 / 484 / 404 tok/s with 8 splits against 535 / 483 / 400 with 16; 16384 keys 301 / 303 / 281
     // with 8 / 16 / 32; Q8 cache 4096 keys 487 against 465 -- profiles/r06_long_context_decode.log.  Was 8 / 16 / 32 from 512 / 2048 / 8192.)
-    const int want = (m->opt_attn_split_ctx > 0 && reach > m->opt_attn_split_ctx) ? (reach > 8192 ? 16 : 8) : 0;
+    const int thr = attn_split_threshold(m);
+    const int want = (thr > 0 && reach > thr) ? (reach > 8192 ? 16 : 8) : 0;
     if (want != m->attn_split) { m->attn_split = want; drop_graphs(m); }
     // rows of the K / V cache the one-workgroup kernel requests before it knows the position: the bucket this call stays
     // inside (a longer context only costs the direct loads of the rows past it)

@@ -8,6 +8,7 @@ from inferflow_amd import dtypes as dt, synth
 kv = dt.Q8_B32T2 if "q8" in sys.argv else dt.F16
 mc = [int(a) for a in sys.argv[1:] if a.isdigit()]
 wk, _, s = synth.build("llama2_7b", dt.Q4_B32T1A, kv, max_ctx=mc[0] if mc else 512)
+if os.environ.get("IFA_CTXK_UNLOAD"): wk.set_option("attn_unload", int(os.environ["IFA_CTXK_UNLOAD"]))
 rng = np.random.default_rng(1)
 for n in (16, 100, 200, 250, 300):
     pr = rng.integers(3, s["vocab"], n).astype(np.int32)
