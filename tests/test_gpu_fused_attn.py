@@ -15,7 +15,7 @@ CASES = [
 ]
 
 
-def _build(shape, wd, kvd, layers, max_ctx=320):
+def _build(shape, wd, kvd, layers, max_ctx=480):
     if shape == "mixtral_dense_like":       # grouped-query geometry of Mixtral (32 heads, 8 kv heads, dim 4096) with a dense FFN
         return synth.build("llama2_7b", wd, kvd, max_ctx=max_ctx, layers=layers, kv_heads=8, ffn=14336)
     return synth.build(shape, wd, kvd, max_ctx=max_ctx, layers=layers)
@@ -37,9 +37,11 @@ def _run(wk, s, prompt, steps, **opts):
 def test_fused_qkv_attention_launch_is_bit_identical(shape, wd, kvd, layers):
     wk, _, s = _build(shape, wd, kvd, layers)
     prompt = (np.arange(20, dtype=np.int32) * 11 + 5) % s["vocab"]
-    # contexts that cross the 64 / 128 / 256 prefetch buckets: 20 .. 20 + 250
-    for steps in (40, 120, 250):
-        ref = _run(wk, s, prompt, steps, fuse_attn=0, step_tail=0)
+    # contexts that cross the 64 / 128 / 256 prefetch buckets: 20 .. 20 + 250; 20 + 440: far past the 256-row bucket, still one
+    # workgroup per head (the default split threshold of these shapes is 512 / 640 keys)
+    for steps in (40, 120, 250, 440):
+        # (attn_split_ctx 0: one workgroup per head in every run -- the default threshold depends on the options compared here)
+        ref = _run(wk, s, prompt, steps, fuse_attn=0, step_tail=0, attn_split_ctx=0)
         wk.set_option("step_tail", 1)
         # attn_unload (default 1): in the 256-row bucket the heads' workgroups take no weight rows (the UL kernels) -- both mappings
         for opts in [{"fuse_attn": 1, "attn_unload": 0}, {"fuse_attn": 1, "attn_unload": 1}]:
