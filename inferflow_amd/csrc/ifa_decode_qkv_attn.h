@@ -35,9 +35,11 @@ struct DecQkvAttnExtra {
     int unload;                     // 1: the UL kernels -- the heads' workgroups take no q | k | v rows (256-row bucket, see k_dec_qkv_attn)
 };
 
-// the head's K / V rows of the entry bucket requested by the attention waves right behind their own weight rows (PHASE 1 of
-// dec_attn_body), not after the workgroup's last q | k | v row: at 21..41 keys the rows arrive during the granule wait either way,
-// from ~100 keys on the 2 x 256 bytes per key of ONE compute unit were the tail (150 / 256 keys: +3.8 / +7.2 us per layer)
+// IFA_QA_EARLY_KV (measurement, default 0): the head's K / V rows of the entry bucket requested by the attention waves right behind
+// their own weight rows (PHASE 1 of dec_attn_body; PHASE 2 at the tail) instead of after the workgroup's last q | k | v row.
+// Bit-identical and without effect (150 / 250 keys 734 / 694 against 729 / 689 tok/s, Q8 cache slightly slower): the bytes come through
+// the same compute unit either way -- what helps is taking the unit's weight rows away (UL below).  profiles/r06_attn_unload.log
+// IFA_QA_WARM_ROWS (default 1): see the UL branch of the kernel
 #ifndef IFA_QA_EARLY_KV
 #define IFA_QA_EARLY_KV 0
 #endif
@@ -124,8 +126,8 @@ __global__ void __launch_bounds__(QA_THREADS) k_dec_qkv_attn(const half_t *px, c
         }
     };
     // the attention tail: workgroup bg == a * (gk / group) of the set runs query head g * group + a, on its waves 0-3 (the
-    // prologue waves).  They request the head's K / V rows right behind their weight rows: the cache rows then arrive with the
-    // end of the weight stream instead of one memory round trip after the last q | k | v row
+    // prologue waves), which request the head's K / V rows at the entry of dec_attn_body: behind the workgroup's last row in the
+    // default mapping (the rows arrive while the granules are polled), at the kernel's first instructions with UL
     static_assert(NP == 4, "the prologue waves are the attention waves");
     const bool ul_head = UL && attn_wg;
     if (!ul_head && threadIdx.x == TH - 1) { L.part[130] = 0.0f; L.part[131] = 0.0f; }
