@@ -644,6 +644,26 @@ def main():
                                    "note": "flops of the layers' linear products (2 x tokens x weights) / WHOLE prefill time of a %d-token prompt "
                                            "(attention, norms, RoPE, cache writes, lm_head of the last row included in the time); dense F16 MFMA peak" % longest}
         out["prefill_gemm_route"] = "in-tree kernels only (csrc/ifa_gemm.hip: large-tile MFMA kernel above 128 tokens, four launches per layer); no vendor GEMM in the library"
+    # ---- decode rate at a few hundred keys (secondary key, outside the timed region): the headline line sits at 21..41 keys, a served
+    # query at hundreds; a real 16-step call after an n-token prompt (every layer's cache rows read cold, unlike a per-launch timing loop)
+    if world == 1 and hasattr(runner, "worker") and not os.environ.get("IFA_FORCE_TP") and not is_moe:
+        try:
+            by_ctx = {}
+            for n in (256, 450):
+                if n + 24 > max_ctx:
+                    continue
+                pr = rng.integers(3, runner.shape["vocab"], n).astype(np.int32)
+                tok = runner.worker.forward(pr, 0)
+                runner.worker.decode(int(tok), n, 4)
+                best = 0.0
+                for _ in range(2):
+                    _, ms = runner.worker.decode(int(tok), n, 16)
+                    best = max(best, 16e3 / ms)
+                by_ctx[str(n)] = best
+            if by_ctx:
+                out["decode_tok_s_by_context"] = by_ctx
+        except Exception as e:  # noqa: BLE001 -- a secondary leg must not cost the headline line
+            out["decode_tok_s_by_context"] = {"error": str(e)[:200]}
     # ---- dynamic batching: B queries with their own KV caches, one decode step appends one token to each (the reference's
     # InferenceEngine::Infer over several queries, inference_engine.cc:1300-1406); outside the timed headline region
     if world == 1 and args.batch > 1 and hasattr(runner, "worker") and not os.environ.get("IFA_FORCE_TP"):
